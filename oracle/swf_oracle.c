@@ -1,0 +1,1279 @@
+/*
+ * swf_oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of the reference's sliding-window Gauss-Newton hot path:
+ * factor residuals/Jacobians, Cauchy corrector, local parameterization, block J^T J,
+ * Schur elimination in the predefined order, dense Cholesky, dogleg trust-region loop.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * PARITY STATUS: "parity unpinned" against the reference binary.  The reference ships
+ * no tests/golden vectors for this path and its solver (ceres-solver-modified.tar) is
+ * absent from the tree (/root/reference/.MISSING_LARGE_BLOBS), and the factor sources
+ * need Eigen + Ceres headers that this image lacks, so nothing of the reference can be
+ * compiled here.  The factor math below follows the in-tree factor sources line by line
+ * (citations on each function); the solver loop restates the PUBLIC Ceres 2.x
+ * trust-region / DoglegStrategy(TRADITIONAL_DOGLEG) / DENSE_SCHUR algorithm with the
+ * defaults listed in SURVEY.md App. C.  The oracle is pinned instead by (1) an
+ * independent numpy implementation with manifold finite differences (tests/), and
+ * (2) committed golden vectors minted from this file (tests/golden/).
+ *
+ * R/ = /root/reference/rtk_visual_inertial_src/rtk_visual_inertial/src/
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/swf_types.h"
+
+#define CLIGHT 299792458.0        /* R/gnss/include/common_function.h:21 */
+#define OMGE 7.2921151467E-5      /* R/gnss/include/common_function.h:41 */
+
+/* ------------------------------------------------------------------ small LA */
+/* quaternions are stored (x, y, z, w) as in the pose block; Hamilton product */
+static void qmul(const double* a, const double* b, double* o) {
+    double ax = a[0], ay = a[1], az = a[2], aw = a[3];
+    double bx = b[0], by = b[1], bz = b[2], bw = b[3];
+    o[3] = aw * bw - ax * bx - ay * by - az * bz;
+    o[0] = aw * bx + ax * bw + ay * bz - az * by;
+    o[1] = aw * by + ay * bw + az * bx - ax * bz;
+    o[2] = aw * bz + az * bw + ax * by - ay * bx;
+}
+/* Eigen::Quaternion::inverse(): conjugate / squaredNorm */
+static void qinv(const double* q, double* o) {
+    double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    o[0] = -q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = q[3] / n2;
+}
+static void cross3(const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+/* Eigen q * v : v + w*(2 u x v) + u x (2 u x v) */
+static void qrot(const double* q, const double* v, double* o) {
+    double uv[3], t[3];
+    cross3(q, v, uv);
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    cross3(q, uv, t);
+    o[0] = v[0] + q[3] * uv[0] + t[0];
+    o[1] = v[1] + q[3] * uv[1] + t[1];
+    o[2] = v[2] + q[3] * uv[2] + t[2];
+}
+/* Eigen toRotationMatrix, row-major 3x3 */
+static void q2R(const double* q, double* R) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    double twx = tx * w, twy = ty * w, twz = tz * w;
+    double txx = tx * x, txy = ty * x, txz = tz * x;
+    double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+static void skew(const double* v, double* S) {   /* R/utility/utility.h:22-29 */
+    S[0] = 0;     S[1] = -v[2]; S[2] = v[1];
+    S[3] = v[2];  S[4] = 0;     S[5] = -v[0];
+    S[6] = -v[1]; S[7] = v[0];  S[8] = 0;
+}
+static void mat3mul(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+static void mat3T(const double* A, double* T) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[i * 3 + j] = A[j * 3 + i];
+}
+static void mat3vec(const double* A, const double* v, double* o) {
+    for (int i = 0; i < 3; i++) o[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
+}
+/* bottom-right 3x3 of Qleft(q) (R/utility/utility.h:31-38): w I + [v]x */
+static void qleft_br(const double* q, double* M) {
+    skew(q, M);
+    M[0] += q[3]; M[4] += q[3]; M[8] += q[3];
+}
+/* bottom-right 3x3 of Qleft(a) * Qright(b) (R/utility/utility.h:31-47) */
+static void qleft_qright_br(const double* a, const double* b, double* M) {
+    double L[9], Rr[9], S[9];
+    qleft_br(a, L);
+    skew(b, S);
+    for (int i = 0; i < 9; i++) Rr[i] = -S[i];
+    Rr[0] += b[3]; Rr[4] += b[3]; Rr[8] += b[3];
+    mat3mul(L, Rr, M);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i * 3 + j] += -a[i] * b[j];
+}
+
+/* dense Cholesky (lower, row-major n x n with leading dim ld), in place. returns 0 ok */
+static int chol_lower(double* A, int n, int ld) {
+    for (int j = 0; j < n; j++) {
+        double d = A[j * ld + j];
+        for (int k = 0; k < j; k++) d -= A[j * ld + k] * A[j * ld + k];
+        if (!(d > 0.0)) return -1;
+        d = sqrt(d);
+        A[j * ld + j] = d;
+        double inv = 1.0 / d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[i * ld + j];
+            const double* ai = A + i * ld; const double* aj = A + j * ld;
+            for (int k = 0; k < j; k++) s -= ai[k] * aj[k];
+            A[i * ld + j] = s * inv;
+        }
+    }
+    return 0;
+}
+/* solve L y = b then L^T x = y, in place on b */
+static void chol_solve(const double* L, int n, int ld, double* b) {
+    for (int i = 0; i < n; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= L[i * ld + k] * b[k];
+        b[i] = s / L[i * ld + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < n; k++) s -= L[k * ld + i] * b[k];
+        b[i] = s / L[i * ld + i];
+    }
+}
+/* inverse of small SPD matrix via Cholesky (ceres InvertPSDMatrix, full-rank path) */
+static int inv_spd(const double* A, int n, double* Ainv) {
+    double L[81];
+    for (int i = 0; i < n * n; i++) L[i] = A[i];
+    if (chol_lower(L, n, n)) return -1;
+    for (int c = 0; c < n; c++) {
+        double e[9];
+        for (int i = 0; i < n; i++) e[i] = (i == c) ? 1.0 : 0.0;
+        chol_solve(L, n, n, e);
+        for (int i = 0; i < n; i++) Ainv[i * n + c] = e[i];
+    }
+    return 0;
+}
+/* general inverse by LU with partial pivoting (Eigen::PartialPivLU::inverse analogue) */
+static int inv_lu(const double* A, int n, double* Ainv) {
+    double* M = (double*)malloc(sizeof(double) * n * 2 * n);
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) { M[i * 2 * n + j] = A[i * n + j]; M[i * 2 * n + n + j] = (i == j); }
+    }
+    for (int c = 0; c < n; c++) {
+        int p = c; double best = fabs(M[c * 2 * n + c]);
+        for (int r = c + 1; r < n; r++) if (fabs(M[r * 2 * n + c]) > best) { best = fabs(M[r * 2 * n + c]); p = r; }
+        if (best == 0.0) { free(M); return -1; }
+        if (p != c) for (int j = 0; j < 2 * n; j++) { double t = M[c * 2 * n + j]; M[c * 2 * n + j] = M[p * 2 * n + j]; M[p * 2 * n + j] = t; }
+        double inv = 1.0 / M[c * 2 * n + c];
+        for (int j = 0; j < 2 * n; j++) M[c * 2 * n + j] *= inv;
+        for (int r = 0; r < n; r++) if (r != c) {
+            double f = M[r * 2 * n + c];
+            if (f != 0.0) for (int j = 0; j < 2 * n; j++) M[r * 2 * n + j] -= f * M[c * 2 * n + j];
+        }
+    }
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Ainv[i * n + j] = M[i * 2 * n + n + j];
+    free(M);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ factors */
+
+/* projection_factor::Evaluate, R/factor/projection_factor.cpp:13-65.
+ * Jacobians are LOCAL size (7th pose column is zero in the reference; the local
+ * parameterization Jacobian is [I6;0], R/factor/pose_local_parameterization.cpp:21-27). */
+void oracle_eval_proj(const double* pose, const double* ex, const double* lm, const double* uv,
+                      double sqrt_info, const double* pbg,
+                      double* r, double* Jp /*2x6*/, double* Jex /*2x6*/, double* Jlm /*2x3*/) {
+    double Qj_inv[4], qic_inv[4], d[3], pts_imu[3], t[3], pc[3];
+    qinv(pose + 3, Qj_inv);
+    qinv(ex + 3, qic_inv);
+    d[0] = lm[0] - pose[0]; d[1] = lm[1] - pose[1]; d[2] = lm[2] - pose[2];
+    qrot(Qj_inv, d, pts_imu);
+    t[0] = pts_imu[0] + pbg[0] - ex[0]; t[1] = pts_imu[1] + pbg[1] - ex[1]; t[2] = pts_imu[2] + pbg[2] - ex[2];
+    qrot(qic_inv, t, pc);
+    double dep = pc[2];
+    r[0] = sqrt_info * (pc[0] / dep - uv[0]);
+    r[1] = sqrt_info * (pc[1] / dep - uv[1]);
+    if (!Jp && !Jex && !Jlm) return;
+    double Rj[9], ric[9], ricT[9], RjT[9];
+    q2R(pose + 3, Rj); q2R(ex + 3, ric);
+    mat3T(ric, ricT); mat3T(Rj, RjT);
+    double red[6] = { sqrt_info * (1. / dep), 0, sqrt_info * (-pc[0] / (dep * dep)),
+                      0, sqrt_info * (1. / dep), sqrt_info * (-pc[1] / (dep * dep)) };
+    double A[9], B[9], S[9];
+    mat3mul(ricT, RjT, A);            /* ric^T Rj^T */
+    if (Jp) {
+        skew(pts_imu, S);
+        mat3mul(ricT, S, B);          /* ric^T [pts_imu]x */
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) {
+            double a = 0, b = 0;
+            for (int k = 0; k < 3; k++) { a += red[i * 3 + k] * -A[k * 3 + j]; b += red[i * 3 + k] * B[k * 3 + j]; }
+            Jp[i * 6 + j] = a; Jp[i * 6 + 3 + j] = b;
+        }
+    }
+    if (Jex) {
+        skew(pc, S);
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) {
+            double a = 0, b = 0;
+            for (int k = 0; k < 3; k++) { a += red[i * 3 + k] * -ricT[k * 3 + j]; b += red[i * 3 + k] * S[k * 3 + j]; }
+            Jex[i * 6 + j] = a; Jex[i * 6 + 3 + j] = b;
+        }
+    }
+    if (Jlm) {
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += red[i * 3 + k] * A[k * 3 + j];
+            Jlm[i * 3 + j] = a;
+        }
+    }
+}
+
+/* deltaQ(theta) = (theta/2, 1), un-normalised: R/utility/utility.h:8-20 */
+static void deltaQ(const double* th, double* q) { q[0] = th[0] / 2; q[1] = th[1] / 2; q[2] = th[2] / 2; q[3] = 1.0; }
+
+/* IntegrationBase::evaluate (R/factor/integration_base.cpp:144-174) followed by
+ * IMUFactor::Evaluate (R/factor/imu_factor.cpp:5-101).  Jacobians local size, whitened. */
+void oracle_eval_imu(const double* pi, const double* sbi, const double* pj, const double* sbj,
+                     const double* pre, const double* pbg, const double* gw,
+                     double* r /*15*/, double* J0 /*15x6*/, double* J1 /*15x9*/, double* J2 /*15x6*/, double* J3 /*15x9*/) {
+    const double* Pi = pi; const double* Qi = pi + 3;
+    const double* Vi = sbi; const double* Bai = sbi + 3; const double* Bgi = sbi + 6;
+    const double* Pj = pj; const double* Qj = pj + 3;
+    const double* Vj = sbj; const double* Baj = sbj + 3; const double* Bgj = sbj + 6;
+    const double* dp = pre + SWF_PRE_DP; const double* dq = pre + SWF_PRE_DQ; const double* dv = pre + SWF_PRE_DV;
+    const double* lba = pre + SWF_PRE_LBA; const double* lbg = pre + SWF_PRE_LBG;
+    const double* dp_dba = pre + SWF_PRE_DP_DBA; const double* dp_dbg = pre + SWF_PRE_DP_DBG;
+    const double* dq_dbg = pre + SWF_PRE_DQ_DBG; const double* dv_dba = pre + SWF_PRE_DV_DBA;
+    const double* dv_dbg = pre + SWF_PRE_DV_DBG;
+    double T = pre[SWF_PRE_SUMDT];
+    const double* gyri = pre + SWF_PRE_GYRI; const double* gyrj = pre + SWF_PRE_GYRJ;
+    const double* SI = pre + SWF_PRE_SQRTINFO;
+
+    double dba[3], dbg[3], th[3], dqc[4], cq[4], cv[3], cp[3], t1[3], t2[3];
+    for (int k = 0; k < 3; k++) { dba[k] = Bai[k] - lba[k]; dbg[k] = Bgi[k] - lbg[k]; }
+    mat3vec(dq_dbg, dbg, th);
+    deltaQ(th, dqc);
+    qmul(dq, dqc, cq);                                  /* corrected_delta_q */
+    mat3vec(dv_dba, dba, t1); mat3vec(dv_dbg, dbg, t2);
+    for (int k = 0; k < 3; k++) cv[k] = dv[k] + t1[k] + t2[k];
+    mat3vec(dp_dba, dba, t1); mat3vec(dp_dbg, dbg, t2);
+    for (int k = 0; k < 3; k++) cp[k] = dp[k] + t1[k] + t2[k];
+
+    double Qi_inv[4], QjPbg[3], wi[3], wj[3], wiPbg[3], wjPbg[3], QjwjPbg[3];
+    qinv(Qi, Qi_inv);
+    qrot(Qj, pbg, QjPbg);
+    for (int k = 0; k < 3; k++) { wi[k] = gyri[k] - Bgi[k]; wj[k] = gyrj[k] - Bgj[k]; }
+    cross3(wi, pbg, wiPbg);       /* skew(gyri-Bgi) * Pbg */
+    cross3(wj, pbg, wjPbg);
+    qrot(Qj, wjPbg, QjwjPbg);
+
+    double ap[3], av[3], rp[3], rv[3];
+    for (int k = 0; k < 3; k++) {
+        ap[k] = 0.5 * gw[k] * T * T + ((Pj[k] - Pi[k]) - QjPbg[k]) - Vi[k] * T;
+        av[k] = gw[k] * T + (Vj[k] - QjwjPbg[k]) - Vi[k];
+    }
+    qrot(Qi_inv, ap, rp);
+    qrot(Qi_inv, av, rv);
+    double raw[15];
+    for (int k = 0; k < 3; k++) {
+        raw[0 + k] = rp[k] - cp[k] + pbg[k] + wiPbg[k] * T;
+        raw[6 + k] = rv[k] - cv[k] + wiPbg[k];
+        raw[9 + k] = Baj[k] - Bai[k];
+        raw[12 + k] = Bgj[k] - Bgi[k];
+    }
+    double cq_inv[4], qij[4], e[4];
+    qinv(cq, cq_inv);
+    qmul(Qi_inv, Qj, qij);
+    qmul(cq_inv, qij, e);
+    raw[3] = 2 * e[0]; raw[4] = 2 * e[1]; raw[5] = 2 * e[2];
+    for (int i = 0; i < 15; i++) {
+        double s = 0;
+        for (int k = 0; k < 15; k++) s += SI[i * 15 + k] * raw[k];
+        r[i] = s;
+    }
+    if (!J0 && !J1 && !J2 && !J3) return;
+
+    double Ri_inv[9], Rj[9], M[9], S[9], N[9], tmpq[4], tmpq2[4], Qj_inv[4];
+    q2R(Qi_inv, Ri_inv);
+    q2R(Qj, Rj);
+    qinv(Qj, Qj_inv);
+    double U[15 * 9];
+#define WHITEN(OUT, NC) \
+    for (int i_ = 0; i_ < 15; i_++) for (int j_ = 0; j_ < NC; j_++) { \
+        double s_ = 0; for (int k_ = 0; k_ < 15; k_++) s_ += SI[i_ * 15 + k_] * U[k_ * NC + j_]; \
+        OUT[i_ * NC + j_] = s_; }
+#define SETB(NC, R0, C0, MAT, SGN) \
+    for (int i_ = 0; i_ < 3; i_++) for (int j_ = 0; j_ < 3; j_++) U[(R0 + i_) * NC + C0 + j_] = SGN * MAT[i_ * 3 + j_];
+    if (J0) {
+        memset(U, 0, sizeof(double) * 15 * 6);
+        SETB(6, 0, 0, Ri_inv, -1.0)
+        skew(rp, S);                       /* skew(Qi^-1 * (...)) */
+        SETB(6, 0, 3, S, 1.0)
+        qmul(Qj_inv, Qi, tmpq);
+        qleft_qright_br(tmpq, cq, M);
+        SETB(6, 3, 3, M, -1.0)
+        skew(rv, S);
+        SETB(6, 6, 3, S, 1.0)
+        WHITEN(J0, 6)
+    }
+    if (J1) {
+        memset(U, 0, sizeof(double) * 15 * 9);
+        double Spbg[9];
+        skew(pbg, Spbg);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            U[(0 + i) * 9 + 0 + j] = -Ri_inv[i * 3 + j] * T;
+            U[(0 + i) * 9 + 3 + j] = -dp_dba[i * 3 + j];
+            U[(0 + i) * 9 + 6 + j] = -dp_dbg[i * 3 + j] + Spbg[i * 3 + j] * T;
+            U[(6 + i) * 9 + 0 + j] = -Ri_inv[i * 3 + j];
+            U[(6 + i) * 9 + 3 + j] = -dv_dba[i * 3 + j];
+            U[(6 + i) * 9 + 6 + j] = -dv_dbg[i * 3 + j] + Spbg[i * 3 + j];
+        }
+        qmul(Qj_inv, Qi, tmpq);
+        qmul(tmpq, dq, tmpq2);             /* Qj^-1 * Qi * delta_q (uncorrected, as in the reference) */
+        qleft_br(tmpq2, M);
+        mat3mul(M, dq_dbg, N);
+        SETB(9, 3, 6, N, -1.0)
+        for (int k = 0; k < 3; k++) { U[(9 + k) * 9 + 3 + k] = -1.0; U[(12 + k) * 9 + 6 + k] = -1.0; }
+        WHITEN(J1, 9)
+    }
+    if (J2) {
+        memset(U, 0, sizeof(double) * 15 * 6);
+        double RiRj[9], Spbg[9], S2[9];
+        mat3mul(Ri_inv, Rj, RiRj);
+        SETB(6, 0, 0, Ri_inv, 1.0)
+        skew(pbg, Spbg);
+        mat3mul(RiRj, Spbg, N);
+        SETB(6, 0, 3, N, 1.0)
+        qmul(cq_inv, Qi_inv, tmpq);
+        qmul(tmpq, Qj, tmpq2);
+        qleft_br(tmpq2, M);
+        SETB(6, 3, 3, M, 1.0)
+        skew(wjPbg, S2);
+        mat3mul(RiRj, S2, N);
+        SETB(6, 6, 3, N, 1.0)
+        WHITEN(J2, 6)
+    }
+    if (J3) {
+        memset(U, 0, sizeof(double) * 15 * 9);
+        double RiRj[9], Spbg[9];
+        mat3mul(Ri_inv, Rj, RiRj);
+        SETB(9, 6, 0, Ri_inv, 1.0)
+        skew(pbg, Spbg);
+        mat3mul(RiRj, Spbg, N);
+        SETB(9, 6, 6, N, -1.0)
+        for (int k = 0; k < 3; k++) { U[(9 + k) * 9 + 3 + k] = 1.0; U[(12 + k) * 9 + 6 + k] = 1.0; }
+        WHITEN(J3, 9)
+    }
+#undef WHITEN
+#undef SETB
+}
+
+/* distance(), R/gnss/src/common_function.cpp:126-134 (Sagnac in the range, not in e) */
+static double gnss_distance(const double* rr, const double* rs, double* e) {
+    for (int i = 0; i < 3; i++) e[i] = rr[i] - rs[i];
+    double r = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    for (int i = 0; i < 3; i++) e[i] /= r;
+    return r + OMGE * (rs[0] * rr[1] - rs[1] * rr[0]) / CLIGHT;
+}
+/* varerr2(), R/factor/gnss_factor.cpp:98-103 — NB single-precision sinf */
+static double varerr2(double el, double dt, double mea_var) {
+    double b = CLIGHT * 5e-12 * dt;
+    double sinel = sinf(el);
+    return (mea_var / sinel / sinel) + b * b;
+}
+/* RTKCarrierPhaseFactor::Evaluate, R/factor/gnss_factor.cpp:105-138.
+ * J = [w e(3) | 0 0 0] wrt pose (local 6), -w*lam wrt ambiguity, w wrt clock */
+void oracle_eval_cp(const double* pose, double amb, double clk, const double* dat, const double* base,
+                    double* r, double* Jpose /*6*/, double* Jamb, double* Jclk) {
+    double xg[3] = { pose[0] + base[0], pose[1] + base[1], pose[2] + base[2] }, e[3];
+    double r1 = gnss_distance(xg, dat, e);
+    double L1_lam = dat[3], lam = dat[4], el = dat[5], dtbr = dat[6], mv = dat[7], use_istd = dat[8];
+    double w = 1.0;
+    if (use_istd != 0.0) w = 1 / sqrt(varerr2(el, dtbr, mv));
+    *r = w * (r1 - amb * lam - L1_lam + clk);
+    if (Jpose) { Jpose[0] = w * e[0]; Jpose[1] = w * e[1]; Jpose[2] = w * e[2]; Jpose[3] = Jpose[4] = Jpose[5] = 0; }
+    if (Jamb) *Jamb = -w * lam;
+    if (Jclk) *Jclk = w;
+}
+/* RTKPseudorangeFactor::Evaluate, R/factor/gnss_factor.cpp:140-168 */
+void oracle_eval_pr(const double* pose, double clk, const double* dat, const double* base,
+                    double* r, double* Jpose /*6*/, double* Jclk) {
+    double xg[3] = { pose[0] + base[0], pose[1] + base[1], pose[2] + base[2] }, e[3];
+    double r1 = gnss_distance(xg, dat, e);
+    double P1 = dat[3], el = dat[4], dtbr = dat[5], mv = dat[6];
+    double w = 1 / sqrt(varerr2(el, dtbr, mv));
+    *r = w * (r1 - P1 + clk);
+    if (Jpose) { Jpose[0] = w * e[0]; Jpose[1] = w * e[1]; Jpose[2] = w * e[2]; Jpose[3] = Jpose[4] = Jpose[5] = 0; }
+    if (Jclk) *Jclk = w;
+}
+/* SppDopplerFactor::Evaluate, R/factor/gnss_factor.cpp:174-212 with velecitydistance(),
+ * R/gnss/src/common_function.cpp:411-421 */
+void oracle_eval_dop(const double* sb, double drift, const double* pose, const double* dat, const double* base,
+                     double* r, double* Jsb /*9*/, double* Jdrift, double* Jpose /*6*/) {
+    double xg[3] = { pose[0] + base[0], pose[1] + base[1], pose[2] + base[2] }, e[3], ev[3];
+    const double* rs = dat; const double* vs = dat + 3;
+    double D1_lam = dat[6], istd = dat[7];
+    for (int i = 0; i < 3; i++) e[i] = xg[i] - rs[i];
+    double rr = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    for (int i = 0; i < 3; i++) { e[i] /= rr; ev[i] = sb[i] - vs[i]; }
+    double rate = (ev[0] * e[0] + ev[1] * e[1] + ev[2] * e[2])
+                + OMGE / CLIGHT * (vs[1] * xg[0] + rs[1] * sb[0] - vs[0] * xg[1] - rs[0] * sb[1]);
+    *r = istd * (rate + drift + D1_lam);
+    if (Jsb) { memset(Jsb, 0, sizeof(double) * 9); Jsb[0] = istd * e[0]; Jsb[1] = istd * e[1]; Jsb[2] = istd * e[2]; }
+    if (Jdrift) *Jdrift = istd;
+    if (Jpose) {
+        /* istd * ev^T (I - e e^T) / r */
+        double ee = ev[0] * e[0] + ev[1] * e[1] + ev[2] * e[2];
+        for (int j = 0; j < 3; j++) Jpose[j] = istd * (ev[j] - ee * e[j]) / rr;
+        Jpose[3] = Jpose[4] = Jpose[5] = 0;
+    }
+}
+
+/* dx of one kept block of a prior, MarginalizationFactor::Evaluate,
+ * R/factor/marginalization_factor.cpp:416-431 */
+static void prior_block_dx(const double* x, const double* x0, int gsize, double* dx) {
+    if (gsize != 7) { for (int k = 0; k < gsize; k++) dx[k] = x[k] - x0[k]; return; }
+    dx[0] = x[0] - x0[0]; dx[1] = x[1] - x0[1]; dx[2] = x[2] - x0[2];
+    double q0i[4], dq[4];
+    qinv(x0 + 3, q0i);
+    qmul(q0i, x + 3, dq);
+    double s = (dq[3] >= 0) ? 2.0 : -2.0;
+    dx[3] = s * dq[0]; dx[4] = s * dq[1]; dx[5] = s * dq[2];
+}
+
+/* Cauchy loss + Ceres corrector as restated at R/factor/marginalization_factor.cpp:23-45.
+ * rho'' < 0 always for Cauchy => residual and Jacobian are scaled by sqrt(rho').
+ * Returns the block's cost 0.5*rho(s) (ceres::ResidualBlock::Evaluate). */
+static double cauchy_correct(double a, double* r, int nres, double** J, const int* ncols, int nj) {
+    double s = 0;
+    for (int i = 0; i < nres; i++) s += r[i] * r[i];
+    double b = a * a, c = 1.0 / b;
+    double sum = 1.0 + s * c, inv = 1.0 / sum;
+    double rho0 = b * log(sum), rho1 = inv > 2.2250738585072014e-308 ? inv : 2.2250738585072014e-308;
+    double rho2 = -c * (inv * inv);
+    double sr = sqrt(rho1), rs_scale, alpha_sq = 0.0;
+    if (s == 0.0 || rho2 <= 0.0) { rs_scale = sr; }
+    else {
+        double D = 1.0 + 2.0 * s * rho2 / rho1, alpha = 1.0 - sqrt(D);
+        rs_scale = sr / (1 - alpha); alpha_sq = alpha / s;
+    }
+    for (int q = 0; q < nj; q++) {
+        if (!J[q]) continue;
+        int nc = ncols[q];
+        if (alpha_sq != 0.0) {
+            for (int j = 0; j < nc; j++) {
+                double rtJ = 0;
+                for (int i = 0; i < nres; i++) rtJ += r[i] * J[q][i * nc + j];
+                for (int i = 0; i < nres; i++) J[q][i * nc + j] -= alpha_sq * r[i] * rtJ;
+            }
+        }
+        for (int i = 0; i < nres * nc; i++) J[q][i] *= sr;
+    }
+    for (int i = 0; i < nres; i++) r[i] *= rs_scale;
+    return 0.5 * rho0;
+}
+double oracle_cauchy_correct(double a, double* r, int nres, double* J, int ncols) {
+    double* Jp[1] = { J }; int nc[1] = { ncols };
+    return cauchy_correct(a, r, nres, Jp, nc, J ? 1 : 0);
+}
+
+/* PoseLocalParameterization::Plus, R/factor/pose_local_parameterization.cpp:5-19 */
+static void pose_plus(const double* x, const double* d, double* o) {
+    o[0] = x[0] + d[0]; o[1] = x[1] + d[1]; o[2] = x[2] + d[2];
+    double dq[4], q[4];
+    deltaQ(d + 3, dq);
+    qmul(x + 3, dq, q);
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    o[3] = q[0] / n; o[4] = q[1] / n; o[5] = q[2] / n; o[6] = q[3] / n;
+}
+void oracle_pose_plus(const double* x, const double* d, double* o) { pose_plus(x, d, o); }
+
+/* ------------------------------------------------------------------ pre-integration
+ * IntegrationBase ctor / push_back / propagate / midPointIntegration / get_sqrtinfo,
+ * R/factor/integration_base.cpp:5-142.  samples: [n][7] = dt, acc(3), gyr(3); the first
+ * sample's acc/gyr seed acc_0/gyr_0 (its dt is ignored), the rest are push_back()ed. */
+void oracle_preintegrate(const double* samples, int n, const double* ba, const double* bg,
+                         double acc_n, double gyr_n, double acc_w, double gyr_w, double* pre) {
+    double dp[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 1}, dv[3] = {0, 0, 0};
+    double jac[225], cov[225], F[225], V[15 * 18], tmp[225], tmp2[15 * 18];
+    memset(jac, 0, sizeof(jac)); memset(cov, 0, sizeof(cov));
+    for (int i = 0; i < 15; i++) jac[i * 15 + i] = 1.0;
+    double noise[18];
+    for (int k = 0; k < 3; k++) {
+        noise[k] = acc_n * acc_n; noise[3 + k] = gyr_n * gyr_n; noise[6 + k] = acc_n * acc_n;
+        noise[9 + k] = gyr_n * gyr_n; noise[12 + k] = acc_w * acc_w; noise[15 + k] = gyr_w * gyr_w;
+    }
+    double acc0[3] = { samples[1], samples[2], samples[3] }, gyr0[3] = { samples[4], samples[5], samples[6] };
+    double gyri[3] = { gyr0[0], gyr0[1], gyr0[2] }, gyrj[3] = { gyr0[0], gyr0[1], gyr0[2] };
+    double sum_dt = 0;
+    for (int s = 1; s < n; s++) {
+        double dt = samples[s * 7];
+        const double* acc1 = samples + s * 7 + 1; const double* gyr1 = samples + s * 7 + 4;
+        gyrj[0] = gyr1[0]; gyrj[1] = gyr1[1]; gyrj[2] = gyr1[2];
+        double a0[3], a1[3], w[3], un_acc0[3], un_acc1[3], un_acc[3], rq[4], hq[4];
+        for (int k = 0; k < 3; k++) { a0[k] = acc0[k] - ba[k]; a1[k] = acc1[k] - ba[k]; w[k] = 0.5 * (gyr0[k] + gyr1[k]) - bg[k]; }
+        qrot(dq, a0, un_acc0);
+        hq[0] = w[0] * dt / 2; hq[1] = w[1] * dt / 2; hq[2] = w[2] * dt / 2; hq[3] = 1;
+        qmul(dq, hq, rq);
+        qrot(rq, a1, un_acc1);
+        double rp[3], rv[3];
+        for (int k = 0; k < 3; k++) {
+            un_acc[k] = 0.5 * (un_acc0[k] + un_acc1[k]);
+            rp[k] = dp[k] + dv[k] * dt + 0.5 * un_acc[k] * dt * dt;
+            rv[k] = dv[k] + un_acc[k] * dt;
+        }
+        /* F, V : R/factor/integration_base.cpp:48-94 */
+        double R0[9], R1[9], Rw[9], Ra0[9], Ra1[9], ImRw[9], A[9], B[9], C[9];
+        q2R(dq, R0); q2R(rq, R1);
+        skew(w, Rw); skew(a0, Ra0); skew(a1, Ra1);
+        for (int i = 0; i < 9; i++) ImRw[i] = -Rw[i] * dt;
+        ImRw[0] += 1; ImRw[4] += 1; ImRw[8] += 1;
+        mat3mul(R0, Ra0, A);              /* R0 [a0]x */
+        mat3mul(R1, Ra1, B);              /* R1 [a1]x */
+        mat3mul(B, ImRw, C);              /* R1 [a1]x (I - [w]x dt) */
+        memset(F, 0, sizeof(F)); memset(V, 0, sizeof(V));
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            double I = (i == j);
+            F[(0 + i) * 15 + 0 + j] = I;
+            F[(0 + i) * 15 + 3 + j] = -0.25 * A[i * 3 + j] * dt * dt + -0.25 * C[i * 3 + j] * dt * dt;
+            F[(0 + i) * 15 + 6 + j] = I * dt;
+            F[(0 + i) * 15 + 9 + j] = -0.25 * (R0[i * 3 + j] + R1[i * 3 + j]) * dt * dt;
+            F[(0 + i) * 15 + 12 + j] = -0.25 * B[i * 3 + j] * dt * dt * -dt;
+            F[(3 + i) * 15 + 3 + j] = ImRw[i * 3 + j];
+            F[(3 + i) * 15 + 12 + j] = -1.0 * I * dt;
+            F[(6 + i) * 15 + 3 + j] = -0.5 * A[i * 3 + j] * dt + -0.5 * C[i * 3 + j] * dt;
+            F[(6 + i) * 15 + 6 + j] = I;
+            F[(6 + i) * 15 + 9 + j] = -0.5 * (R0[i * 3 + j] + R1[i * 3 + j]) * dt;
+            F[(6 + i) * 15 + 12 + j] = -0.5 * B[i * 3 + j] * dt * -dt;
+            F[(9 + i) * 15 + 9 + j] = I;
+            F[(12 + i) * 15 + 12 + j] = I;
+            V[(0 + i) * 18 + 0 + j] = 0.25 * R0[i * 3 + j] * dt * dt;
+            V[(0 + i) * 18 + 3 + j] = 0.25 * -B[i * 3 + j] * dt * dt * 0.5 * dt;
+            V[(0 + i) * 18 + 6 + j] = 0.25 * R1[i * 3 + j] * dt * dt;
+            V[(0 + i) * 18 + 9 + j] = V[(0 + i) * 18 + 3 + j];
+            V[(3 + i) * 18 + 3 + j] = 0.5 * I * dt;
+            V[(3 + i) * 18 + 9 + j] = 0.5 * I * dt;
+            V[(6 + i) * 18 + 0 + j] = 0.5 * R0[i * 3 + j] * dt;
+            V[(6 + i) * 18 + 3 + j] = 0.5 * -B[i * 3 + j] * dt * 0.5 * dt;
+            V[(6 + i) * 18 + 6 + j] = 0.5 * R1[i * 3 + j] * dt;
+            V[(6 + i) * 18 + 9 + j] = V[(6 + i) * 18 + 3 + j];
+            V[(9 + i) * 18 + 12 + j] = I * dt;
+            V[(12 + i) * 18 + 15 + j] = I * dt;
+        }
+        /* jacobian = F*jacobian ; covariance = F cov F^T + V Q V^T */
+        for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) {
+            double s2 = 0; for (int k = 0; k < 15; k++) s2 += F[i * 15 + k] * jac[k * 15 + j];
+            tmp[i * 15 + j] = s2;
+        }
+        memcpy(jac, tmp, sizeof(jac));
+        for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) {
+            double s2 = 0; for (int k = 0; k < 15; k++) s2 += F[i * 15 + k] * cov[k * 15 + j];
+            tmp[i * 15 + j] = s2;
+        }
+        for (int i = 0; i < 15; i++) for (int j = 0; j < 18; j++) tmp2[i * 18 + j] = V[i * 18 + j] * noise[j];
+        for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) {
+            double s2 = 0;
+            for (int k = 0; k < 15; k++) s2 += tmp[i * 15 + k] * F[j * 15 + k];
+            for (int k = 0; k < 18; k++) s2 += tmp2[i * 18 + k] * V[j * 18 + k];
+            cov[i * 15 + j] = s2;
+        }
+        /* propagate(): copy results, normalize delta_q, R/factor/integration_base.cpp:131-141 */
+        double nq = sqrt(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]);
+        for (int k = 0; k < 3; k++) { dp[k] = rp[k]; dv[k] = rv[k]; acc0[k] = acc1[k]; gyr0[k] = gyr1[k]; }
+        for (int k = 0; k < 4; k++) dq[k] = rq[k] / nq;
+        sum_dt += dt;
+    }
+    memset(pre, 0, sizeof(double) * SWF_PRE_DOUBLES);
+    for (int k = 0; k < 3; k++) {
+        pre[SWF_PRE_DP + k] = dp[k]; pre[SWF_PRE_DV + k] = dv[k];
+        pre[SWF_PRE_LBA + k] = ba[k]; pre[SWF_PRE_LBG + k] = bg[k];
+        pre[SWF_PRE_GYRI + k] = gyri[k]; pre[SWF_PRE_GYRJ + k] = gyrj[k];
+    }
+    for (int k = 0; k < 4; k++) pre[SWF_PRE_DQ + k] = dq[k];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        pre[SWF_PRE_DP_DBA + i * 3 + j] = jac[(0 + i) * 15 + 9 + j];
+        pre[SWF_PRE_DP_DBG + i * 3 + j] = jac[(0 + i) * 15 + 12 + j];
+        pre[SWF_PRE_DQ_DBG + i * 3 + j] = jac[(3 + i) * 15 + 12 + j];
+        pre[SWF_PRE_DV_DBA + i * 3 + j] = jac[(6 + i) * 15 + 9 + j];
+        pre[SWF_PRE_DV_DBG + i * 3 + j] = jac[(6 + i) * 15 + 12 + j];
+    }
+    pre[SWF_PRE_SUMDT] = sum_dt;
+    /* get_sqrtinfo: LLT(cov.inverse()).matrixL().transpose(), R/factor/integration_base.cpp:105-113 */
+    double ci[225];
+    if (inv_lu(cov, 15, ci) == 0) {
+        /* LLT reads the lower triangle */
+        for (int i = 0; i < 15; i++) for (int j = i + 1; j < 15; j++) ci[i * 15 + j] = ci[j * 15 + i];
+        if (chol_lower(ci, 15, 15) == 0)
+            for (int i = 0; i < 15; i++) for (int j = i; j < 15; j++) pre[SWF_PRE_SQRTINFO + i * 15 + j] = ci[j * 15 + i];
+    }
+}
+
+/* ------------------------------------------------------------------ solver */
+enum { F_PROJ = 0, F_IMU, F_CP, F_PR, F_DOP, F_SP, F_PRIOR };
+
+typedef struct {
+    int type, idx, nres, nblk;
+    int blk_off;      /* into fblk[] / fjoff[] */
+    int r_off;        /* into residual vector */
+} fac_t;
+
+typedef struct {
+    const swf_flat_window* w;
+    int n_blocks;
+    int* gsize; int* lsize; int* xoff;       /* per global block */
+    int* loc_off;                            /* offset in local vector (ordering order), -1 if const */
+    int* group;                              /* ordering group, -1 if const */
+    int n_loc, n_e, n_red;                   /* local dims: total, eliminated, reduced */
+    int n_x;                                 /* ambient dims of all blocks */
+    int n_eblk; int* eblk;                   /* group-0 blocks in order */
+    /* factors */
+    int n_fac; fac_t* fac;
+    int* fblk; int* fjoff; int n_slots;
+    int n_res; int n_jac;
+    /* adjacency e-block -> factors */
+    int* e_fac_off; int* e_fac;
+    int* blk2e;                              /* global block -> e index or -1 */
+    /* prior bookkeeping */
+    int* prior_blk_off; int* prior_J_off; int* prior_r_off; int* prior_x0_off;
+    /* work buffers */
+    double* x; double* xc;                   /* current / candidate ambient state */
+    double* res; double* jac;
+    double* g; double* diag;                 /* n_loc */
+    double* S; double* L; double* rhs;       /* reduced */
+    double* Sexp;                            /* copy of S before factorisation (export) */
+    double* gn; double* grad_s; double* step; double* delta;
+    double* einv; double* estrip; int* estrip_off; int* e_nbr_off; int* e_nbr; int* einv_off;
+    int estrip_total, e_nbr_total;
+    int nthreads;
+} ctx_t;
+
+static int blk_pool(const swf_flat_window* w, int b, int* idx) {
+    if (b < w->n_pose) { *idx = b; return 0; }
+    b -= w->n_pose;
+    if (b < w->n_sb) { *idx = b; return 1; }
+    b -= w->n_sb;
+    if (b < w->n_lm) { *idx = b; return 2; }
+    b -= w->n_lm;
+    *idx = b; return 3;
+}
+#define BID_POSE(w, i) (i)
+#define BID_SB(w, i) ((w)->n_pose + (i))
+#define BID_LM(w, i) ((w)->n_pose + (w)->n_sb + (i))
+#define BID_SC(w, i) ((w)->n_pose + (w)->n_sb + (w)->n_lm + (i))
+
+static void ctx_free(ctx_t* c);
+
+static ctx_t* ctx_build(const swf_flat_window* w) {
+    ctx_t* c = (ctx_t*)calloc(1, sizeof(ctx_t));
+    c->w = w;
+    int nb = w->n_pose + w->n_sb + w->n_lm + w->n_sc;
+    c->n_blocks = nb;
+    c->gsize = (int*)malloc(sizeof(int) * nb); c->lsize = (int*)malloc(sizeof(int) * nb);
+    c->xoff = (int*)malloc(sizeof(int) * nb); c->loc_off = (int*)malloc(sizeof(int) * nb);
+    c->group = (int*)malloc(sizeof(int) * nb); c->blk2e = (int*)malloc(sizeof(int) * nb);
+    int xo = 0;
+    for (int b = 0; b < nb; b++) {
+        int idx, p = blk_pool(w, b, &idx);
+        int gs = p == 0 ? 7 : p == 1 ? 9 : p == 2 ? 3 : 1;
+        c->gsize[b] = gs; c->lsize[b] = gs == 7 ? 6 : gs;
+        c->xoff[b] = xo; xo += gs;
+        c->loc_off[b] = -1; c->group[b] = -1; c->blk2e[b] = -1;
+    }
+    c->n_x = xo;
+    int lo = 0, ne = 0, neb = 0;
+    c->eblk = (int*)malloc(sizeof(int) * (w->n_order + 1));
+    for (int i = 0; i < w->n_order; i++) {
+        int b = w->order_block[i];
+        c->loc_off[b] = lo; c->group[b] = w->order_group[i];
+        lo += c->lsize[b];
+        if (w->order_group[i] == 0) { ne += c->lsize[b]; c->blk2e[b] = neb; c->eblk[neb++] = b; }
+    }
+    c->n_loc = lo; c->n_e = ne; c->n_red = lo - ne; c->n_eblk = neb;
+
+    /* factors */
+    int nf = w->n_proj + w->n_imu + w->n_cp + w->n_pr + w->n_dop + w->n_sp + w->n_prior;
+    c->n_fac = nf;
+    c->fac = (fac_t*)calloc(nf > 0 ? nf : 1, sizeof(fac_t));
+    int nslots = w->n_proj * 3 + w->n_imu * 4 + w->n_cp * 3 + w->n_pr * 2 + w->n_dop * 3 + w->n_sp;
+    c->prior_blk_off = (int*)malloc(sizeof(int) * (w->n_prior + 1));
+    c->prior_J_off = (int*)malloc(sizeof(int) * (w->n_prior + 1));
+    c->prior_r_off = (int*)malloc(sizeof(int) * (w->n_prior + 1));
+    c->prior_x0_off = (int*)malloc(sizeof(int) * (w->n_prior + 1));
+    {
+        int bo = 0, jo = 0, ro = 0, x0o = 0;
+        for (int k = 0; k < w->n_prior; k++) {
+            c->prior_blk_off[k] = bo; c->prior_J_off[k] = jo; c->prior_r_off[k] = ro; c->prior_x0_off[k] = x0o;
+            for (int q = 0; q < w->prior_nblk[k]; q++) x0o += c->gsize[w->prior_blk[bo + q]];
+            bo += w->prior_nblk[k]; jo += w->prior_dim[k] * w->prior_dim[k]; ro += w->prior_dim[k];
+            nslots += w->prior_nblk[k];
+        }
+        c->prior_blk_off[w->n_prior] = bo;
+    }
+    c->n_slots = nslots;
+    c->fblk = (int*)malloc(sizeof(int) * (nslots + 1)); c->fjoff = (int*)malloc(sizeof(int) * (nslots + 1));
+    int f = 0, so = 0, ro = 0, jo = 0;
+#define ADDF(T, I, NRES, NB) { fac_t* ff = &c->fac[f++]; ff->type = T; ff->idx = I; ff->nres = NRES; ff->nblk = NB; ff->blk_off = so; ff->r_off = ro; ro += NRES; }
+#define ADDS(B) { int b_ = (B); c->fblk[so] = b_; if (c->loc_off[b_] >= 0) { c->fjoff[so] = jo; jo += c->fac[f - 1].nres * c->lsize[b_]; } else c->fjoff[so] = -1; so++; }
+    for (int i = 0; i < w->n_proj; i++) { ADDF(F_PROJ, i, 2, 3) ADDS(BID_POSE(w, w->proj_idx[i * 3])) ADDS(BID_POSE(w, w->proj_idx[i * 3 + 1])) ADDS(BID_LM(w, w->proj_idx[i * 3 + 2])) }
+    for (int i = 0; i < w->n_imu; i++) { ADDF(F_IMU, i, 15, 4) ADDS(BID_POSE(w, w->imu_idx[i * 4])) ADDS(BID_SB(w, w->imu_idx[i * 4 + 1])) ADDS(BID_POSE(w, w->imu_idx[i * 4 + 2])) ADDS(BID_SB(w, w->imu_idx[i * 4 + 3])) }
+    for (int i = 0; i < w->n_cp; i++) { ADDF(F_CP, i, 1, 3) ADDS(BID_POSE(w, w->cp_idx[i * 3])) ADDS(BID_SC(w, w->cp_idx[i * 3 + 1])) ADDS(BID_SC(w, w->cp_idx[i * 3 + 2])) }
+    for (int i = 0; i < w->n_pr; i++) { ADDF(F_PR, i, 1, 2) ADDS(BID_POSE(w, w->pr_idx[i * 2])) ADDS(BID_SC(w, w->pr_idx[i * 2 + 1])) }
+    for (int i = 0; i < w->n_dop; i++) { ADDF(F_DOP, i, 1, 3) ADDS(BID_SB(w, w->dop_idx[i * 3])) ADDS(BID_SC(w, w->dop_idx[i * 3 + 1])) ADDS(BID_POSE(w, w->dop_idx[i * 3 + 2])) }
+    for (int i = 0; i < w->n_sp; i++) { ADDF(F_SP, i, 1, 1) ADDS(BID_SC(w, w->sp_idx[i])) }
+    for (int k = 0; k < w->n_prior; k++) {
+        ADDF(F_PRIOR, k, w->prior_dim[k], w->prior_nblk[k])
+        for (int q = 0; q < w->prior_nblk[k]; q++) ADDS(w->prior_blk[c->prior_blk_off[k] + q])
+    }
+#undef ADDF
+#undef ADDS
+    c->n_res = ro; c->n_jac = jo;
+
+    /* e-block adjacency; a factor may touch at most one group-0 block (independent set) */
+    c->e_fac_off = (int*)calloc(neb + 2, sizeof(int));
+    for (int i = 0; i < nf; i++) {
+        int cnt = 0;
+        for (int s = 0; s < c->fac[i].nblk; s++) { int e = c->blk2e[c->fblk[c->fac[i].blk_off + s]]; if (e >= 0) { c->e_fac_off[e + 1]++; cnt++; } }
+        if (cnt > 1) { fprintf(stderr, "oracle: group 0 is not an independent set (factor %d)\n", i); ctx_free(c); return NULL; }
+    }
+    for (int e = 0; e < neb; e++) c->e_fac_off[e + 1] += c->e_fac_off[e];
+    c->e_fac = (int*)malloc(sizeof(int) * (c->e_fac_off[neb] + 1));
+    {
+        int* fill = (int*)calloc(neb + 1, sizeof(int));
+        for (int i = 0; i < nf; i++)
+            for (int s = 0; s < c->fac[i].nblk; s++) { int e = c->blk2e[c->fblk[c->fac[i].blk_off + s]]; if (e >= 0) c->e_fac[c->e_fac_off[e] + fill[e]++] = i; }
+        free(fill);
+    }
+    /* e-block neighbour lists (distinct variable f-blocks, first-seen order) and strip layout */
+    c->e_nbr_off = (int*)calloc(neb + 2, sizeof(int));
+    c->estrip_off = (int*)calloc(neb + 2, sizeof(int));
+    c->einv_off = (int*)calloc(neb + 2, sizeof(int));
+    {
+        int cap = 16, tot = 0; int* nbr = (int*)malloc(sizeof(int) * cap);
+        int so2 = 0, eo = 0;
+        for (int e = 0; e < neb; e++) {
+            c->e_nbr_off[e] = tot; c->estrip_off[e] = so2; c->einv_off[e] = eo;
+            int le = c->lsize[c->eblk[e]], wsum = 0;
+            for (int q = c->e_fac_off[e]; q < c->e_fac_off[e + 1]; q++) {
+                fac_t* ff = &c->fac[c->e_fac[q]];
+                for (int s = 0; s < ff->nblk; s++) {
+                    int b = c->fblk[ff->blk_off + s];
+                    if (c->loc_off[b] < 0 || c->blk2e[b] >= 0) continue;
+                    int seen = 0;
+                    for (int t = c->e_nbr_off[e]; t < tot; t++) if (nbr[t] == b) { seen = 1; break; }
+                    if (!seen) { if (tot == cap) { cap *= 2; nbr = (int*)realloc(nbr, sizeof(int) * cap); } nbr[tot++] = b; wsum += c->lsize[b]; }
+                }
+            }
+            so2 += le * wsum; eo += le * le;
+        }
+        c->e_nbr_off[neb] = tot; c->estrip_off[neb] = so2; c->einv_off[neb] = eo;
+        c->e_nbr = nbr; c->e_nbr_total = tot; c->estrip_total = so2;
+    }
+    c->x = (double*)calloc(c->n_x + 1, sizeof(double)); c->xc = (double*)calloc(c->n_x + 1, sizeof(double));
+    c->res = (double*)calloc(c->n_res + 1, sizeof(double)); c->jac = (double*)calloc(c->n_jac + 1, sizeof(double));
+    c->g = (double*)calloc(c->n_loc + 1, sizeof(double)); c->diag = (double*)calloc(c->n_loc + 1, sizeof(double));
+    size_t nr2 = (size_t)c->n_red * c->n_red + 1;
+    c->S = (double*)calloc(nr2, sizeof(double)); c->L = (double*)calloc(nr2, sizeof(double)); c->Sexp = (double*)calloc(nr2, sizeof(double));
+    c->rhs = (double*)calloc(c->n_red + 1, sizeof(double));
+    c->gn = (double*)calloc(c->n_loc + 1, sizeof(double)); c->grad_s = (double*)calloc(c->n_loc + 1, sizeof(double));
+    c->step = (double*)calloc(c->n_loc + 1, sizeof(double)); c->delta = (double*)calloc(c->n_loc + 1, sizeof(double));
+    c->einv = (double*)calloc(c->einv_off[neb] + 1, sizeof(double));
+    c->estrip = (double*)calloc(c->estrip_total + 1, sizeof(double));
+    c->nthreads = 1;
+    return c;
+}
+static void ctx_free(ctx_t* c) {
+    if (!c) return;
+    free(c->gsize); free(c->lsize); free(c->xoff); free(c->loc_off); free(c->group); free(c->blk2e); free(c->eblk);
+    free(c->fac); free(c->fblk); free(c->fjoff); free(c->e_fac_off); free(c->e_fac);
+    free(c->prior_blk_off); free(c->prior_J_off); free(c->prior_r_off); free(c->prior_x0_off);
+    free(c->x); free(c->xc); free(c->res); free(c->jac); free(c->g); free(c->diag);
+    free(c->S); free(c->L); free(c->Sexp); free(c->rhs); free(c->gn); free(c->grad_s); free(c->step); free(c->delta);
+    free(c->einv); free(c->estrip); free(c->estrip_off); free(c->e_nbr_off); free(c->e_nbr); free(c->einv_off);
+    free(c);
+}
+static void ctx_load_state(ctx_t* c) {
+    const swf_flat_window* w = c->w;
+    double* x = c->x;
+    memcpy(x, w->pose, sizeof(double) * 7 * w->n_pose); x += 7 * w->n_pose;
+    memcpy(x, w->sb, sizeof(double) * 9 * w->n_sb); x += 9 * w->n_sb;
+    memcpy(x, w->lm, sizeof(double) * 3 * w->n_lm); x += 3 * w->n_lm;
+    memcpy(x, w->sc, sizeof(double) * w->n_sc);
+}
+static void ctx_store_state(ctx_t* c) {
+    const swf_flat_window* w = c->w;
+    const double* x = c->x;
+    memcpy(w->pose, x, sizeof(double) * 7 * w->n_pose); x += 7 * w->n_pose;
+    memcpy(w->sb, x, sizeof(double) * 9 * w->n_sb); x += 9 * w->n_sb;
+    memcpy(w->lm, x, sizeof(double) * 3 * w->n_lm); x += 3 * w->n_lm;
+    memcpy(w->sc, x, sizeof(double) * w->n_sc);
+}
+
+/* evaluate one factor at ambient state x; Jacobians (local, corrected) into c->jac if want_jac.
+ * returns the block cost (0.5*rho(s) or 0.5*|r|^2). */
+static double eval_factor(ctx_t* c, const fac_t* f, const double* x, int want_jac, double* res, double* jac) {
+    const swf_flat_window* w = c->w;
+    const int* blk = c->fblk + f->blk_off; const int* jo = c->fjoff + f->blk_off;
+    double* r = res + f->r_off;
+#define XP(s) (x + c->xoff[blk[s]])
+#define JP(s) ((want_jac && jo[s] >= 0) ? jac + jo[s] : NULL)
+    switch (f->type) {
+    case F_PROJ: {
+        double* J[3] = { JP(0), JP(1), JP(2) };
+        oracle_eval_proj(XP(0), XP(1), XP(2), w->proj_uv + f->idx * 2, w->proj_sqrt_info, w->pbg, r, J[0], J[1], J[2]);
+        if (w->proj_loss_a > 0) { int nc[3] = { 6, 6, 3 }; return cauchy_correct(w->proj_loss_a, r, 2, J, nc, 3); }
+        return 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    }
+    case F_IMU: {
+        oracle_eval_imu(XP(0), XP(1), XP(2), XP(3), w->imu_pre + (size_t)f->idx * SWF_PRE_DOUBLES, w->pbg, w->gw, r, JP(0), JP(1), JP(2), JP(3));
+        double s = 0; for (int i = 0; i < 15; i++) s += r[i] * r[i];
+        return 0.5 * s;
+    }
+    case F_CP: oracle_eval_cp(XP(0), *XP(1), *XP(2), w->cp_dat + f->idx * SWF_CP_DOUBLES, w->base, r, JP(0), JP(1), JP(2)); return 0.5 * r[0] * r[0];
+    case F_PR: oracle_eval_pr(XP(0), *XP(1), w->pr_dat + f->idx * SWF_PR_DOUBLES, w->base, r, JP(0), JP(1)); return 0.5 * r[0] * r[0];
+    case F_DOP: oracle_eval_dop(XP(0), *XP(1), XP(2), w->dop_dat + f->idx * SWF_DOP_DOUBLES, w->base, r, JP(0), JP(1), JP(2)); return 0.5 * r[0] * r[0];
+    case F_SP: { r[0] = w->sp_w[f->idx] * (*XP(0)); double* J = JP(0); if (J) J[0] = w->sp_w[f->idx]; return 0.5 * r[0] * r[0]; }
+    case F_PRIOR: {
+        int k = f->idx, n = f->nres;
+        const double* Jp = w->prior_J + c->prior_J_off[k];
+        const double* r0 = w->prior_r0 + c->prior_r_off[k];
+        const double* x0 = w->prior_x0 + c->prior_x0_off[k];
+        double* dx = (double*)malloc(sizeof(double) * n);
+        int col = 0;
+        for (int q = 0; q < f->nblk; q++) {
+            int b = blk[q];
+            prior_block_dx(x + c->xoff[b], x0, c->gsize[b], dx + col);
+            x0 += c->gsize[b]; col += c->lsize[b];
+        }
+        double s = 0;
+        for (int i = 0; i < n; i++) {
+            double a = r0[i];
+            for (int j = 0; j < n; j++) a += Jp[i * n + j] * dx[j];
+            r[i] = a; s += a * a;
+        }
+        free(dx);
+        if (want_jac) {
+            col = 0;
+            for (int q = 0; q < f->nblk; q++) {
+                int ls = c->lsize[blk[q]];
+                double* J = JP(q);
+                if (J) for (int i = 0; i < n; i++) for (int j = 0; j < ls; j++) J[i * ls + j] = Jp[i * n + col + j];
+                col += ls;
+            }
+        }
+        return 0.5 * s;
+    }
+    }
+#undef XP
+#undef JP
+    return 0;
+}
+
+static double evaluate(ctx_t* c, const double* x, int want_jac) {
+    double cost = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+:cost) num_threads(c->nthreads) if (c->nthreads > 1)
+#endif
+    for (int i = 0; i < c->n_fac; i++) cost += eval_factor(c, &c->fac[i], x, want_jac, c->res, c->jac);
+    return cost;
+}
+
+/* g = J^T r, diag = squared column norms, over the local vector */
+static void gradient_and_diag(ctx_t* c) {
+    memset(c->g, 0, sizeof(double) * c->n_loc); memset(c->diag, 0, sizeof(double) * c->n_loc);
+    for (int i = 0; i < c->n_fac; i++) {
+        const fac_t* f = &c->fac[i];
+        const double* r = c->res + f->r_off;
+        for (int s = 0; s < f->nblk; s++) {
+            int jo = c->fjoff[f->blk_off + s];
+            if (jo < 0) continue;
+            int b = c->fblk[f->blk_off + s], ls = c->lsize[b], lo = c->loc_off[b];
+            const double* J = c->jac + jo;
+            for (int k = 0; k < f->nres; k++) for (int j = 0; j < ls; j++) {
+                double v = J[k * ls + j];
+                c->g[lo + j] += v * r[k]; c->diag[lo + j] += v * v;
+            }
+        }
+    }
+}
+
+/* Schur elimination of group 0 with LM damping D^2 = mu * clamp(diag) (mu may be 0):
+ * S = F^T F + D_f^2 - sum_e H_fe (H_ee + D_e^2)^-1 H_ef ; rhs likewise (ceres SchurEliminator).
+ * dclamp = clamped squared column norms. */
+static int eliminate(ctx_t* c, const double* dclamp, double mu) {
+    int n = c->n_red, ne = c->n_e;
+    memset(c->S, 0, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; i++) { c->S[(size_t)i * n + i] = mu * dclamp[ne + i]; c->rhs[i] = c->g[ne + i]; }
+    /* F^T F from every factor over pairs of reduced blocks */
+    for (int i = 0; i < c->n_fac; i++) {
+        const fac_t* f = &c->fac[i];
+        for (int s = 0; s < f->nblk; s++) {
+            int jo1 = c->fjoff[f->blk_off + s]; int b1 = c->fblk[f->blk_off + s];
+            if (jo1 < 0 || c->blk2e[b1] >= 0) continue;
+            int l1 = c->lsize[b1], o1 = c->loc_off[b1] - ne;
+            const double* J1 = c->jac + jo1;
+            for (int t = 0; t < f->nblk; t++) {
+                int jo2 = c->fjoff[f->blk_off + t]; int b2 = c->fblk[f->blk_off + t];
+                if (jo2 < 0 || c->blk2e[b2] >= 0) continue;
+                int l2 = c->lsize[b2], o2 = c->loc_off[b2] - ne;
+                if (o2 > o1) continue;            /* lower triangle (block level) */
+                const double* J2 = c->jac + jo2;
+                for (int a = 0; a < l1; a++) for (int b = 0; b < l2; b++) {
+                    double sum = 0;
+                    for (int k = 0; k < f->nres; k++) sum += J1[k * l1 + a] * J2[k * l2 + b];
+                    c->S[(size_t)(o1 + a) * n + o2 + b] += sum;
+                }
+            }
+        }
+    }
+    /* e-blocks */
+    int fail = 0;
+    for (int e = 0; e < c->n_eblk; e++) {
+        int be = c->eblk[e], le = c->lsize[be], loe = c->loc_off[be];
+        double Hee[81], ge[9];
+        memset(Hee, 0, sizeof(Hee));
+        for (int a = 0; a < le; a++) { Hee[a * le + a] = mu * dclamp[loe + a]; ge[a] = c->g[loe + a]; }
+        int nn = c->e_nbr_off[e + 1] - c->e_nbr_off[e];
+        const int* nbr = c->e_nbr + c->e_nbr_off[e];
+        int wsum = 0; int coloff[512];
+        for (int t = 0; t < nn; t++) { coloff[t] = wsum; wsum += c->lsize[nbr[t]]; }
+        double* strip = c->estrip + c->estrip_off[e];      /* le x wsum : H_ef */
+        memset(strip, 0, sizeof(double) * le * wsum);
+        for (int q = c->e_fac_off[e]; q < c->e_fac_off[e + 1]; q++) {
+            const fac_t* f = &c->fac[c->e_fac[q]];
+            const double* Je = NULL;
+            for (int s = 0; s < f->nblk; s++) if (c->fblk[f->blk_off + s] == be) Je = c->jac + c->fjoff[f->blk_off + s];
+            for (int a = 0; a < le; a++) for (int b = 0; b < le; b++) {
+                double sum = 0; for (int k = 0; k < f->nres; k++) sum += Je[k * le + a] * Je[k * le + b];
+                Hee[a * le + b] += sum;
+            }
+            for (int s = 0; s < f->nblk; s++) {
+                int b2 = c->fblk[f->blk_off + s]; int jo2 = c->fjoff[f->blk_off + s];
+                if (jo2 < 0 || b2 == be) continue;
+                int t = 0; while (nbr[t] != b2) t++;
+                int l2 = c->lsize[b2];
+                const double* J2 = c->jac + jo2;
+                for (int a = 0; a < le; a++) for (int b = 0; b < l2; b++) {
+                    double sum = 0; for (int k = 0; k < f->nres; k++) sum += Je[k * le + a] * J2[k * l2 + b];
+                    strip[a * wsum + coloff[t] + b] += sum;
+                }
+            }
+        }
+        double* Einv = c->einv + c->einv_off[e];
+        if (inv_spd(Hee, le, Einv)) { fail = 1; continue; }
+        /* Y = Einv * strip (le x wsum); S -= strip^T Y ; rhs -= strip^T Einv ge */
+        double Y[9 * 512], Eg[9];
+        for (int a = 0; a < le; a++) {
+            double s = 0; for (int b = 0; b < le; b++) s += Einv[a * le + b] * ge[b];
+            Eg[a] = s;
+            for (int j = 0; j < wsum; j++) { double s2 = 0; for (int b = 0; b < le; b++) s2 += Einv[a * le + b] * strip[b * wsum + j]; Y[a * wsum + j] = s2; }
+        }
+        for (int t1 = 0; t1 < nn; t1++) {
+            int o1 = c->loc_off[nbr[t1]] - ne, l1 = c->lsize[nbr[t1]];
+            for (int a = 0; a < l1; a++) {
+                double s = 0; for (int k = 0; k < le; k++) s += strip[k * wsum + coloff[t1] + a] * Eg[k];
+                c->rhs[o1 + a] -= s;
+            }
+            for (int t2 = 0; t2 < nn; t2++) {
+                int o2 = c->loc_off[nbr[t2]] - ne, l2 = c->lsize[nbr[t2]];
+                if (o2 > o1) continue;
+                for (int a = 0; a < l1; a++) for (int b = 0; b < l2; b++) {
+                    double s = 0; for (int k = 0; k < le; k++) s += strip[k * wsum + coloff[t1] + a] * Y[k * wsum + coloff[t2] + b];
+                    c->S[(size_t)(o1 + a) * n + o2 + b] -= s;
+                }
+            }
+        }
+    }
+    return fail ? -1 : 0;
+}
+
+/* full linear solve: (J^T J + mu*dclamp) y = J^T r via Schur; y written to out (n_loc). */
+static int linear_solve(ctx_t* c, const double* dclamp, double mu, double* out) {
+    int n = c->n_red, ne = c->n_e;
+    if (eliminate(c, dclamp, mu)) return -1;
+    /* symmetrise lower->upper for export, keep a copy */
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) c->S[(size_t)j * n + i] = c->S[(size_t)i * n + j];
+    memcpy(c->Sexp, c->S, sizeof(double) * (size_t)n * n);
+    memcpy(c->L, c->S, sizeof(double) * (size_t)n * n);
+    if (chol_lower(c->L, n, n)) return -1;
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) c->L[(size_t)i * n + j] = 0.0;
+    double* y = out + ne;
+    memcpy(y, c->rhs, sizeof(double) * n);
+    chol_solve(c->L, n, n, y);
+    /* back-substitute e-blocks: y_e = Einv (g_e - H_ef y_f) */
+    for (int e = 0; e < c->n_eblk; e++) {
+        int be = c->eblk[e], le = c->lsize[be], loe = c->loc_off[be];
+        int nn = c->e_nbr_off[e + 1] - c->e_nbr_off[e];
+        const int* nbr = c->e_nbr + c->e_nbr_off[e];
+        int wsum = 0; for (int t = 0; t < nn; t++) wsum += c->lsize[nbr[t]];
+        const double* strip = c->estrip + c->estrip_off[e];
+        const double* Einv = c->einv + c->einv_off[e];
+        double t0[9];
+        for (int a = 0; a < le; a++) {
+            double s = c->g[loe + a]; int col = 0;
+            for (int t = 0; t < nn; t++) {
+                int o = c->loc_off[nbr[t]], l = c->lsize[nbr[t]];
+                for (int j = 0; j < l; j++) s -= strip[a * wsum + col + j] * out[o + j];
+                col += l;
+            }
+            t0[a] = s;
+        }
+        for (int a = 0; a < le; a++) { double s = 0; for (int b = 0; b < le; b++) s += Einv[a * le + b] * t0[b]; out[loe + a] = s; }
+    }
+    for (int i = 0; i < c->n_loc; i++) if (!isfinite(out[i])) return -1;
+    return 0;
+}
+
+/* || J v ||^2 and (J v).(r + J v / 2) helpers */
+static void jac_times(ctx_t* c, const double* v, double* sq, double* model) {
+    double s_sq = 0, s_model = 0;
+    for (int i = 0; i < c->n_fac; i++) {
+        const fac_t* f = &c->fac[i];
+        const double* r = c->res + f->r_off;
+        for (int k = 0; k < f->nres; k++) {
+            double a = 0;
+            for (int s = 0; s < f->nblk; s++) {
+                int jo = c->fjoff[f->blk_off + s];
+                if (jo < 0) continue;
+                int b = c->fblk[f->blk_off + s], ls = c->lsize[b], lo = c->loc_off[b];
+                const double* J = c->jac + jo + k * ls;
+                for (int j = 0; j < ls; j++) a += J[j] * v[lo + j];
+            }
+            s_sq += a * a; s_model += a * (r[k] + a / 2.0);
+        }
+    }
+    if (sq) *sq = s_sq;
+    if (model) *model = s_model;
+}
+
+/* x_plus = Plus(x, delta) over every variable block */
+static void plus_all(ctx_t* c, const double* x, const double* delta, double* xo) {
+    memcpy(xo, x, sizeof(double) * c->n_x);
+    for (int b = 0; b < c->n_blocks; b++) {
+        int lo = c->loc_off[b];
+        if (lo < 0) continue;
+        if (c->gsize[b] == 7) pose_plus(x + c->xoff[b], delta + lo, xo + c->xoff[b]);
+        else for (int k = 0; k < c->gsize[b]; k++) xo[c->xoff[b] + k] = x[c->xoff[b] + k] + delta[lo + k];
+    }
+}
+static double var_norm(ctx_t* c, const double* x, const double* y) {   /* over variable blocks, ambient */
+    double s = 0;
+    for (int b = 0; b < c->n_blocks; b++) {
+        if (c->loc_off[b] < 0) continue;
+        for (int k = 0; k < c->gsize[b]; k++) { double d = x[c->xoff[b] + k] - (y ? y[c->xoff[b] + k] : 0.0); s += d * d; }
+    }
+    return sqrt(s);
+}
+static double var_maxnorm_diff(ctx_t* c, const double* x, const double* y) {
+    double m = 0;
+    for (int b = 0; b < c->n_blocks; b++) {
+        if (c->loc_off[b] < 0) continue;
+        for (int k = 0; k < c->gsize[b]; k++) { double d = fabs(x[c->xoff[b] + k] - y[c->xoff[b] + k]); if (d > m) m = d; }
+    }
+    return m;
+}
+
+static double now_sec(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+/* Export buffers (analogue of ceres::internal::{lhs_out, rhs_out, lhs_out2, hs_row},
+ * R/swf/swf_gnss.cpp:25-94): any of S/rhs/L may be NULL; each n_red*n_red / n_red doubles.
+ * Also optional full-vector exports for tests: grad (n_loc), gn (n_loc, unscaled GN step). */
+typedef struct oracle_export {
+    double* S; double* rhs; double* L;
+    double* grad; double* gn_step; double* diag;
+    int32_t* loc_off;            /* [n_blocks] */
+} oracle_export;
+
+int oracle_dims(const swf_flat_window* w, int32_t* n_loc, int32_t* n_e, int32_t* n_red, int32_t* n_res) {
+    ctx_t* c = ctx_build(w);
+    if (!c) return -1;
+    if (n_loc) *n_loc = c->n_loc; if (n_e) *n_e = c->n_e; if (n_red) *n_red = c->n_red; if (n_res) *n_res = c->n_res;
+    ctx_free(c);
+    return 0;
+}
+
+/* evaluate all residual blocks at the window's current state; res: n_res, cost out */
+int oracle_evaluate(const swf_flat_window* w, double* cost, double* res) {
+    ctx_t* c = ctx_build(w);
+    if (!c) return -1;
+    ctx_load_state(c);
+    *cost = evaluate(c, c->x, 1);
+    if (res) memcpy(res, c->res, sizeof(double) * c->n_res);
+    ctx_free(c);
+    return 0;
+}
+
+/* The trust-region loop: public Ceres 2.x TrustRegionMinimizer::Minimize with
+ * DoglegStrategy(TRADITIONAL_DOGLEG) and DENSE_SCHUR, jacobi_scaling=false
+ * (call site R/swf/swf_image.cpp:198-251; options R/swf/swf.cpp:25-30). */
+int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* sum, oracle_export* ex) {
+    double t0 = now_sec();
+    ctx_t* c = ctx_build(w);
+    if (!c) return -1;
+    c->nthreads = opt->num_threads > 0 ? opt->num_threads : 1;
+    memset(sum, 0, sizeof(*sum));
+    ctx_load_state(c);
+    int n = c->n_loc;
+    sum->reduced_dim = c->n_red;
+    {
+        int td = 0;
+        for (int i = w->n_order - w->n_tail; i < w->n_order; i++) td += c->lsize[w->order_block[i]];
+        sum->tail_dim = td;
+    }
+    double* dclamp = (double*)malloc(sizeof(double) * (n + 1));
+    double* dsqrt = (double*)malloc(sizeof(double) * (n + 1));
+    double* tmp = (double*)malloc(sizeof(double) * (n + 1));
+    double* xt = (double*)malloc(sizeof(double) * (c->n_x + 1));
+    int rc = 0;
+
+    /* IterationZero */
+    double x_cost = evaluate(c, c->x, 1);
+    gradient_and_diag(c);
+    double x_norm = var_norm(c, c->x, NULL);
+    for (int i = 0; i < n; i++) tmp[i] = -c->g[i];
+    plus_all(c, c->x, tmp, xt);
+    double gmax = var_maxnorm_diff(c, c->x, xt);
+    sum->initial_cost = x_cost;
+    int it = 0;
+    sum->trace[0].cost = x_cost; sum->trace[0].gradient_max_norm = gmax;
+    sum->trace[0].trust_region_radius = opt->initial_trust_region_radius;
+    sum->trace[0].step_is_valid = 1; sum->trace[0].step_is_successful = 1;
+
+    if (opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) {
+        /* assemble + eliminate + factor at the current point, no damping, no step */
+        for (int i = 0; i < n; i++) dclamp[i] = 0.0;
+        int lrc = linear_solve(c, dclamp, 0.0, c->gn);
+        sum->termination = lrc ? SWF_LINEAR_SOLVER_FAILURE : SWF_ASSEMBLED_ONLY;
+        sum->final_cost = x_cost;
+        goto done;
+    }
+
+    double radius = opt->initial_trust_region_radius, mu = opt->min_mu;
+    int reuse = 0, invalid_run = 0;
+    double alpha = 0, dogleg_step_norm = 0;
+    sum->termination = SWF_RUNNING;
+    for (;;) {
+        /* FinalizeIterationAndCheckIfMinimizerCanContinue */
+        if (it >= opt->max_num_iterations) { sum->termination = SWF_NO_CONVERGENCE; break; }
+        if (gmax <= opt->gradient_tolerance) { sum->termination = SWF_CONVERGED_GRADIENT; break; }
+        if (radius < opt->min_trust_region_radius) { sum->termination = SWF_RADIUS_TOO_SMALL; break; }
+        it++;
+        swf_iteration* rec = &sum->trace[it < SWF_MAX_TRACE ? it : SWF_MAX_TRACE - 1];
+        memset(rec, 0, sizeof(*rec));
+        rec->gradient_max_norm = gmax;
+
+        /* DoglegStrategy::ComputeStep */
+        int lin_ok = 1;
+        if (!reuse) {
+            for (int i = 0; i < n; i++) {
+                double d = c->diag[i];
+                d = d < opt->min_diagonal ? opt->min_diagonal : d; d = d > opt->max_diagonal ? opt->max_diagonal : d;
+                dclamp[i] = d; dsqrt[i] = sqrt(d);
+            }
+            /* ComputeGradient (scaled) + ComputeCauchyPoint */
+            double gsq = 0;
+            for (int i = 0; i < n; i++) { c->grad_s[i] = c->g[i] / dsqrt[i]; gsq += c->grad_s[i] * c->grad_s[i]; tmp[i] = c->grad_s[i] / dsqrt[i]; }
+            double jg_sq; jac_times(c, tmp, &jg_sq, NULL);
+            alpha = gsq / jg_sq;
+            /* ComputeGaussNewtonStep with the mu retry loop */
+            lin_ok = 0;
+            while (mu < opt->max_mu) {
+                if (linear_solve(c, dclamp, mu, c->gn) == 0) { lin_ok = 1; break; }
+                mu *= opt->mu_increase_factor;
+            }
+            if (lin_ok) for (int i = 0; i < n; i++) c->gn[i] *= -dsqrt[i];     /* scaled GN step */
+        }
+        reuse = 1;
+        if (!lin_ok) {
+            /* HandleInvalidStep */
+            rec->step_is_valid = 0; rec->cost = x_cost; rec->trust_region_radius = radius;
+            if (++invalid_run >= 5) { sum->termination = SWF_LINEAR_SOLVER_FAILURE; break; }
+            mu *= opt->mu_increase_factor; reuse = 0;
+            continue;
+        }
+        /* ComputeTraditionalDoglegStep */
+        {
+            double gnorm = 0, gnn = 0, gdot = 0;
+            for (int i = 0; i < n; i++) { gnorm += c->grad_s[i] * c->grad_s[i]; gnn += c->gn[i] * c->gn[i]; gdot += c->grad_s[i] * c->gn[i]; }
+            gnorm = sqrt(gnorm); gnn = sqrt(gnn);
+            if (gnn <= radius) { for (int i = 0; i < n; i++) c->step[i] = c->gn[i]; dogleg_step_norm = gnn; }
+            else if (gnorm * alpha >= radius) { for (int i = 0; i < n; i++) c->step[i] = -(radius / gnorm) * c->grad_s[i]; dogleg_step_norm = radius; }
+            else {
+                double b_dot_a = -alpha * gdot;
+                double a_sq = pow(alpha * gnorm, 2.0);
+                double bma_sq = a_sq - 2 * b_dot_a + pow(gnn, 2);
+                double cc = b_dot_a - a_sq;
+                double d = sqrt(cc * cc + bma_sq * (pow(radius, 2.0) - a_sq));
+                double beta = (cc <= 0) ? (d - cc) / bma_sq : (radius * radius - a_sq) / (d + cc);
+                double sn = 0;
+                for (int i = 0; i < n; i++) { c->step[i] = (-alpha * (1.0 - beta)) * c->grad_s[i] + beta * c->gn[i]; sn += c->step[i] * c->step[i]; }
+                dogleg_step_norm = sqrt(sn);
+            }
+            for (int i = 0; i < n; i++) c->step[i] /= dsqrt[i];
+        }
+        /* model cost change */
+        double mdl; jac_times(c, c->step, NULL, &mdl);
+        double model_cost_change = -mdl;
+        rec->model_cost_change = model_cost_change;
+        if (!(model_cost_change > 0.0)) {
+            rec->step_is_valid = 0; rec->cost = x_cost; rec->trust_region_radius = radius;
+            if (++invalid_run >= 5) { sum->termination = SWF_LINEAR_SOLVER_FAILURE; break; }
+            mu *= opt->mu_increase_factor; reuse = 0;
+            continue;
+        }
+        rec->step_is_valid = 1; invalid_run = 0;
+        /* candidate point + cost-only evaluation */
+        plus_all(c, c->x, c->step, c->xc);
+        double cand_cost = evaluate(c, c->xc, 0);
+        if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+        /* ParameterToleranceReached */
+        rec->step_norm = var_norm(c, c->x, c->xc);
+        if (rec->step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
+            rec->cost = x_cost; rec->trust_region_radius = radius;
+            sum->termination = SWF_CONVERGED_PARAMETER; break;
+        }
+        /* FunctionToleranceReached */
+        rec->cost_change = x_cost - cand_cost;
+        if (fabs(rec->cost_change) <= opt->function_tolerance * x_cost) {
+            rec->cost = x_cost; rec->trust_region_radius = radius;
+            sum->termination = SWF_CONVERGED_FUNCTION; break;
+        }
+        rec->relative_decrease = rec->cost_change / model_cost_change;
+        if (rec->relative_decrease > opt->min_relative_decrease) {
+            /* HandleSuccessfulStep */
+            memcpy(c->x, c->xc, sizeof(double) * c->n_x);
+            x_norm = var_norm(c, c->x, NULL);
+            x_cost = evaluate(c, c->x, 1);
+            gradient_and_diag(c);
+            for (int i = 0; i < n; i++) tmp[i] = -c->g[i];
+            plus_all(c, c->x, tmp, xt);
+            gmax = var_maxnorm_diff(c, c->x, xt);
+            rec->step_is_successful = 1; rec->cost = x_cost; rec->gradient_max_norm = gmax;
+            sum->num_successful_steps++;
+            /* DoglegStrategy::StepAccepted */
+            if (rec->relative_decrease < 0.25) radius *= 0.5;
+            if (rec->relative_decrease > 0.75) radius = radius > 3.0 * dogleg_step_norm ? radius : 3.0 * dogleg_step_norm;
+            mu = opt->min_mu > 2.0 * mu / opt->mu_increase_factor ? opt->min_mu : 2.0 * mu / opt->mu_increase_factor;
+            reuse = 0;
+        } else {
+            rec->step_is_successful = 0; rec->cost = x_cost;
+            sum->num_unsuccessful_steps++;
+            radius *= 0.5; reuse = 1;         /* StepRejected */
+        }
+        rec->trust_region_radius = radius;
+    }
+    sum->final_cost = x_cost;
+done:
+    sum->num_iterations = it;
+    if (ex) {
+        size_t nr = (size_t)c->n_red;
+        if (ex->S) memcpy(ex->S, c->Sexp, sizeof(double) * nr * nr);
+        if (ex->rhs) memcpy(ex->rhs, c->rhs, sizeof(double) * nr);
+        if (ex->L) memcpy(ex->L, c->L, sizeof(double) * nr * nr);
+        if (ex->grad) memcpy(ex->grad, c->g, sizeof(double) * n);
+        if (ex->gn_step) memcpy(ex->gn_step, c->gn, sizeof(double) * n);
+        if (ex->diag) memcpy(ex->diag, c->diag, sizeof(double) * n);
+        if (ex->loc_off) for (int b = 0; b < c->n_blocks; b++) ex->loc_off[b] = c->loc_off[b];
+    }
+    ctx_store_state(c);
+    free(dclamp); free(dsqrt); free(tmp); free(xt);
+    ctx_free(c);
+    sum->minimizer_time_in_seconds = now_sec() - t0;
+    return rc;
+}

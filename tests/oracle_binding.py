@@ -1,0 +1,150 @@
+"""ctypes binding of oracle/libswf_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from rtk_visual_inertial_navigation_amd.flat import (FlatWindowC, OptionsC, SummaryC,
+                                                     default_options, PRE_DOUBLES)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+
+
+class ExportC(C.Structure):
+    _fields_ = [("S", _pd), ("rhs", _pd), ("L", _pd), ("grad", _pd), ("gn_step", _pd),
+                ("diag", _pd), ("loc_off", _pi)]
+
+
+_lib = None
+
+
+def build_oracle(force=False):
+    so = os.path.join(ORACLE_DIR, "libswf_oracle.so")
+    src = os.path.join(ORACLE_DIR, "swf_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = build_oracle()
+        try:
+            _lib = C.CDLL(so)
+        except OSError:
+            _lib = C.CDLL(build_oracle(force=True))
+        _lib.oracle_solve.restype = C.c_int
+        _lib.oracle_dims.restype = C.c_int
+        _lib.oracle_evaluate.restype = C.c_int
+        _lib.oracle_cauchy_correct.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_pd)
+
+
+def dims(win):
+    s = win.c_struct()
+    v = [C.c_int32() for _ in range(4)]
+    rc = lib().oracle_dims(C.byref(s), *[C.byref(x) for x in v])
+    assert rc == 0
+    return dict(n_loc=v[0].value, n_e=v[1].value, n_red=v[2].value, n_res=v[3].value)
+
+
+def evaluate(win):
+    d = dims(win)
+    res = np.zeros(d["n_res"])
+    cost = C.c_double()
+    s = win.c_struct()
+    assert lib().oracle_evaluate(C.byref(s), C.byref(cost), _p(res)) == 0
+    return cost.value, res
+
+
+def solve(win, opt=None, export=True):
+    """Runs the oracle solve IN PLACE on win's state. Returns (summary, export dict)."""
+    if opt is None:
+        opt = default_options()
+    d = dims(win)
+    n, nl = d["n_red"], d["n_loc"]
+    out = {}
+    ex = ExportC()
+    if export:
+        out = dict(S=np.zeros((n, n)), rhs=np.zeros(n), L=np.zeros((n, n)), grad=np.zeros(nl),
+                   gn_step=np.zeros(nl), diag=np.zeros(nl), loc_off=np.zeros(win.n_blocks, np.int32))
+        ex.S, ex.rhs, ex.L = _p(out["S"]), _p(out["rhs"]), _p(out["L"])
+        ex.grad, ex.gn_step, ex.diag = _p(out["grad"]), _p(out["gn_step"]), _p(out["diag"])
+        ex.loc_off = out["loc_off"].ctypes.data_as(_pi)
+    sm = SummaryC()
+    s = win.c_struct()
+    rc = lib().oracle_solve(C.byref(s), C.byref(opt), C.byref(sm), C.byref(ex) if export else None)
+    assert rc == 0
+    out.update(d)
+    return sm, out
+
+
+def eval_proj(pose, ex, lm, uv, sqrt_info, pbg):
+    r, Jp, Jex, Jlm = np.zeros(2), np.zeros((2, 6)), np.zeros((2, 6)), np.zeros((2, 3))
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pose, ex, lm, uv, pbg)]
+    lib().oracle_eval_proj(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), C.c_double(sqrt_info), _p(a[4]),
+                           _p(r), _p(Jp), _p(Jex), _p(Jlm))
+    return r, Jp, Jex, Jlm
+
+
+def eval_imu(pi, sbi, pj, sbj, pre, pbg, gw):
+    r = np.zeros(15)
+    J = [np.zeros((15, 6)), np.zeros((15, 9)), np.zeros((15, 6)), np.zeros((15, 9))]
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pi, sbi, pj, sbj, pre, pbg, gw)]
+    lib().oracle_eval_imu(*[_p(x) for x in a], _p(r), *[_p(x) for x in J])
+    return r, J
+
+
+def eval_cp(pose, amb, clk, dat, base):
+    r, Jp, Ja, Jc = C.c_double(), np.zeros(6), C.c_double(), C.c_double()
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pose, dat, base)]
+    lib().oracle_eval_cp(_p(a[0]), C.c_double(amb), C.c_double(clk), _p(a[1]), _p(a[2]),
+                         C.byref(r), _p(Jp), C.byref(Ja), C.byref(Jc))
+    return r.value, Jp, Ja.value, Jc.value
+
+
+def eval_pr(pose, clk, dat, base):
+    r, Jp, Jc = C.c_double(), np.zeros(6), C.c_double()
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pose, dat, base)]
+    lib().oracle_eval_pr(_p(a[0]), C.c_double(clk), _p(a[1]), _p(a[2]), C.byref(r), _p(Jp), C.byref(Jc))
+    return r.value, Jp, Jc.value
+
+
+def eval_dop(sb, drift, pose, dat, base):
+    r, Jsb, Jd, Jp = C.c_double(), np.zeros(9), C.c_double(), np.zeros(6)
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (sb, pose, dat, base)]
+    lib().oracle_eval_dop(_p(a[0]), C.c_double(drift), _p(a[1]), _p(a[2]), _p(a[3]),
+                          C.byref(r), _p(Jsb), C.byref(Jd), _p(Jp))
+    return r.value, Jsb, Jd.value, Jp
+
+
+def preintegrate(samples, ba, bg, acc_n, gyr_n, acc_w, gyr_w):
+    pre = np.zeros(PRE_DOUBLES)
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (samples, ba, bg)]
+    lib().oracle_preintegrate(_p(a[0]), C.c_int(a[0].shape[0]), _p(a[1]), _p(a[2]),
+                              C.c_double(acc_n), C.c_double(gyr_n), C.c_double(acc_w), C.c_double(gyr_w), _p(pre))
+    return pre
+
+
+def pose_plus(x, d):
+    o = np.zeros(7)
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, d)]
+    lib().oracle_pose_plus(_p(a[0]), _p(a[1]), _p(o))
+    return o
+
+
+def cauchy_correct(a, r, J):
+    r = np.array(r, dtype=np.float64); J = np.array(J, dtype=np.float64)
+    cost = lib().oracle_cauchy_correct(C.c_double(a), _p(r), C.c_int(r.size), _p(J), C.c_int(J.shape[1]))
+    return cost, r, J
