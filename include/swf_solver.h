@@ -1,0 +1,176 @@
+/*
+ * swf_solver.h — C-ABI of the MI355X-native sliding-window Gauss-Newton solver.
+ *
+ * This is the drop-in boundary for the reference's L4<->L2 line: what
+ * SWFOptimization does through ceres::Problem / ceres::Solver / the modified-Ceres
+ * private globals, it does here through opaque handles and plain pointers.  No C++ or
+ * torch types cross the boundary.  All functions return 0 on success, a negative
+ * SWF_E_* code otherwise; the library never falls back to a CPU path: if no HIP device
+ * is usable, every compute entry point returns SWF_E_NODEVICE.
+ *
+ * Two layers:
+ *   (1) swf_batch_*   — the engine: a batch of flat windows (include/swf_types.h) resident
+ *                       in HBM, solved together.  The batch-throughput path (BASELINE cfg4)
+ *                       and what bench.py times.
+ *   (2) swf_problem_* — the pointer-keyed, ceres::Problem-shaped surface for one window
+ *                       (the single-window latency path).  It flattens to (1) with B = 1.
+ *
+ * R/ = /root/reference/rtk_visual_inertial_src/rtk_visual_inertial/src/
+ */
+#ifndef SWF_SOLVER_H
+#define SWF_SOLVER_H
+
+#include <stdint.h>
+#include "swf_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SWF_OK = 0,
+    SWF_E_NODEVICE = -1,      /* no usable HIP device / HIP runtime error */
+    SWF_E_INVALID = -2,       /* bad argument / malformed window */
+    SWF_E_UNSUPPORTED = -3,   /* structure outside what the kernels cover */
+    SWF_E_NOTFOUND = -4,      /* unknown parameter block / factor id */
+    SWF_E_STATE = -5          /* call order violated (e.g. export before solve) */
+};
+
+/* library / device info */
+int swf_version(void);
+int swf_device_count(int32_t* n);                 /* hipGetDeviceCount */
+int swf_set_device(int32_t device);               /* hipSetDevice; one device per process */
+const char* swf_last_error(void);                 /* thread-local message for the last failure */
+
+/* =====================================================================================
+ * (1) batch engine
+ * ===================================================================================== */
+typedef struct swf_batch swf_batch;
+
+/* Build the static (symbolic) structure for n windows and upload structure + state to the
+ * current device.  The windows' arrays are read during this call only; their pose/sb/lm/sc
+ * pointers are remembered for swf_batch_download_state().  `stream` is a hipStream_t (or
+ * NULL for the default stream) on which every later operation of this batch is enqueued. */
+int swf_batch_create(const swf_flat_window* const* windows, int32_t n, void* stream, swf_batch** out);
+int swf_batch_destroy(swf_batch* b);
+
+/* Re-upload the parameter blocks from the windows' host arrays (new epoch, same structure):
+ * the analogue of Vector2Double() before ceres::Solve (R/swf/swf.cpp:140, swf_image.cpp:202). */
+int swf_batch_upload_state(swf_batch* b);
+/* Device-side restore of the state uploaded last (so a benchmark can re-solve the same
+ * windows with inputs resident in HBM). */
+int swf_batch_reset_state(swf_batch* b);
+
+/* Enqueue one full solve of every window (= ceres::Solve, R/swf/swf_image.cpp:219):
+ * options.step_mode selects OPTIMIZE or ASSEMBLE_ELIMINATE_ONLY (= is_optimize=false,
+ * R/swf/swf_image.cpp:404-416).  Asynchronous on the batch stream; no host round-trip
+ * happens inside (accept/reject, trust-region radius and convergence live on the device). */
+int swf_batch_solve(swf_batch* b, const swf_options* opt);
+/* Block until the stream has drained. */
+int swf_batch_sync(swf_batch* b);
+
+/* Copy parameter blocks back into the windows' host arrays (Double2Vector, R/swf/swf.cpp:188). */
+int swf_batch_download_state(swf_batch* b);
+/* Per-window summaries incl. iteration trace; out[n]. */
+int swf_batch_summaries(swf_batch* b, swf_summary* out);
+
+/* Export of the reduced system of window w from the LAST linearisation, the analogue of
+ * ceres::internal::{lhs_out, rhs_out, lhs_out2, hs_row} (R/swf/swf_gnss.cpp:25-94):
+ *   S   hs_row x hs_row row-major, full symmetric (damping included as solved)
+ *   rhs hs_row
+ *   L   hs_row x hs_row row-major lower Cholesky factor, S = L L^T, in elimination order;
+ *       its trailing tail_dim x tail_dim block L_nn gives L_nn L_nn^T = marginal information
+ *       of the parameter_head states (R/swf/swf_gnss.cpp:85-87).
+ * Any pointer may be NULL.  hs_row is summary.reduced_dim. */
+int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, double* rhs, double* L);
+/* Debug/parity export of local-space vectors of window w (n_loc doubles each, ordering
+ * order): gradient J^T r, squared column norms, and y = (J^T J + D)^-1 J^T r. */
+int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, double* diag, double* y);
+int swf_batch_dims(swf_batch* b, int32_t w, int32_t* n_loc, int32_t* n_e, int32_t* n_red);
+
+/* Timing of the last swf_batch_solve measured with HIP events on the batch stream
+ * (valid after swf_batch_sync): total and the share of selected kernels, in milliseconds. */
+typedef struct swf_timing {
+    double total_ms;
+    double eval_ms;          /* factor residual/Jacobian kernels */
+    double eliminate_ms;     /* group-0 elimination + Schur assembly */
+    double reduced_ms;       /* dense reduced solve (Cholesky + triangular solves) */
+    double other_ms;
+    int64_t jacobian_bytes;  /* algorithmic bytes of ONE Jacobian evaluation of the batch */
+    int32_t n_linearizations;/* Jacobian evaluations enqueued per window in the last solve */
+    int32_t reserved;
+} swf_timing;
+/* Enable per-kernel-group event timing for subsequent solves (costs a few events). */
+int swf_batch_enable_timing(swf_batch* b, int32_t on);
+int swf_batch_timing(swf_batch* b, swf_timing* out);
+
+/* =====================================================================================
+ * (2) ceres::Problem-shaped single-window surface
+ *
+ * Parameter blocks are identified BY ADDRESS like in Ceres; values are read through the
+ * pointer at swf_problem_solve() and written back before it returns.
+ * ===================================================================================== */
+typedef struct swf_problem swf_problem;
+typedef int32_t swf_factor_id;
+
+enum { SWF_MANIFOLD_NONE = 0, SWF_MANIFOLD_POSE = 1 };   /* PoseLocalParameterization, 7 -> 6 */
+
+int swf_problem_create(swf_problem** out);                      /* ceres::Problem()            */
+int swf_problem_destroy(swf_problem* p);
+
+/* ceres::Problem::AddParameterBlock(ptr, size, LocalParameterization*).  size in {7,9,3,1};
+ * calling it on an existing block only (re)attaches the manifold (R/swf/swf_core.cpp:53-56). */
+int swf_add_parameter_block(swf_problem* p, double* key, int32_t size, int32_t manifold);
+int swf_has_parameter_block(swf_problem* p, const double* key);           /* 1 / 0             */
+int swf_remove_parameter_block(swf_problem* p, double* key);    /* cascades to its factors     */
+int swf_set_parameter_block_constant(swf_problem* p, double* key);
+int swf_set_parameter_block_variable(swf_problem* p, double* key);
+int swf_is_parameter_block_constant(swf_problem* p, const double* key);   /* 1 / 0             */
+int swf_parameter_block_size(swf_problem* p, const double* key);
+int swf_num_parameter_blocks(swf_problem* p);
+int swf_num_residual_blocks(swf_problem* p);
+
+/* Typed AddResidualBlock()s.  Each returns the factor id (>= 0) or a negative error.
+ * Unknown parameter blocks are added implicitly, as ceres does. */
+/* projection_factor(pts) + CauchyLoss(loss_a) (R/swf/swf_image.cpp:98-100); loss_a<=0: no loss */
+swf_factor_id swf_add_projection(swf_problem* p, double* pose, double* ex_pose, double* point,
+                                 const double uv[2], double sqrt_info, double loss_a);
+/* IMUFactor(pre_integration) (R/swf/swf_imu.cpp:185-193); pre = SWF_PRE_DOUBLES record */
+swf_factor_id swf_add_imu(swf_problem* p, double* pose_i, double* sb_i, double* pose_j, double* sb_j,
+                          const double* pre);
+/* RTKCarrierPhaseFactor (R/swf/swf_core.cpp:113-117); dat = SWF_CP_DOUBLES record */
+swf_factor_id swf_add_rtk_carrier_phase(swf_problem* p, double* pose, double* ambiguity, double* clock,
+                                        const double* dat);
+/* RTKPseudorangeFactor (R/swf/swf_core.cpp:130-133); dat = SWF_PR_DOUBLES record */
+swf_factor_id swf_add_rtk_pseudorange(swf_problem* p, double* pose, double* clock, const double* dat);
+/* SppDopplerFactor (R/swf/swf_core.cpp:197-201); dat = SWF_DOP_DOUBLES record */
+swf_factor_id swf_add_doppler(swf_problem* p, double* speed_bias, double* clock_drift, double* pose,
+                              const double* dat);
+/* InitialBlackFactor(w) (R/swf/swf_core.cpp:553-556) */
+swf_factor_id swf_add_scalar_prior(swf_problem* p, double* scalar, double w);
+/* MarginalizationFactor(info) (R/swf/swf_core.cpp:551-552): kept blocks `keys` (sizes from the
+ * problem), J dim x dim row-major, r0[dim], x0 = concatenated linearisation points. */
+swf_factor_id swf_add_linear_prior(swf_problem* p, double* const* keys, int32_t n_keys,
+                                   const double* J, const double* r0, const double* x0);
+int swf_remove_factor(swf_problem* p, swf_factor_id id);                  /* RemoveResidualBlock */
+int swf_factor_set_enabled(swf_problem* p, swf_factor_id id, int32_t on); /* ResidualBlock::is_use */
+
+/* window constants the factors read from globals in the reference (Pbg, Rwgw*G, base_xyz) */
+int swf_set_constants(swf_problem* p, const double pbg[3], const double gw[3], const double base[3]);
+
+/* options.linear_solver_ordering: ParameterBlockOrdering::AddElementToGroup() per entry
+ * (R/swf/swf_gnss.cpp:629-783).  Replaces any previous ordering. */
+int swf_set_ordering(swf_problem* p, double* const* keys, const int32_t* groups, int32_t n);
+/* ceres::internal::parameter_head: blocks ordered last and exported (R/swf/swf_gnss.cpp:116) */
+int swf_set_export_tail(swf_problem* p, double* const* keys, int32_t n);
+
+/* ceres::Solve(options, &problem, &summary) */
+int swf_problem_solve(swf_problem* p, const swf_options* opt, swf_summary* summary);
+/* lhs_out / rhs_out / lhs_out2 / hs_row of the last solve; buffers solver-owned, valid until the
+ * next solve or destroy. */
+int swf_get_reduced(swf_problem* p, const double** S, const double** rhs, const double** L, int32_t* hs_row);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWF_SOLVER_H */

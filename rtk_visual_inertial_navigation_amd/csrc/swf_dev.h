@@ -1,0 +1,248 @@
+// swf_dev.h — device-side data model of the batch engine (gfx950 / CDNA4 only).
+//
+// One batch = W independent sliding windows laid out back to back in HBM.  Everything that
+// depends only on the windows' STRUCTURE (who observes what, elimination order, which
+// reduced block pairs are non-zero) is built once on the host ("symbolic phase") into flat
+// index arrays; per solve only the parameter blocks change.  All accumulation orders are
+// fixed by these arrays — no floating-point atomics anywhere — so results are run-to-run
+// bit-reproducible.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/swf_types.h"
+
+#define SWF_WAVE 64
+
+// ---- per-window static record -----------------------------------------------------------
+struct WinRec {
+    int x_base, x_n;             // ambient state range
+    int blk_base, n_blk;         // block table range
+    int loc_base, n_loc, n_e, n_red;   // local vector: [eliminated dims | reduced dims]
+    long long S_base;            // offset of this window's n_red x n_red reduced matrix S
+    long long Lt_base;           // offset of the (n_red+1)^2 transposed Cholesky factor (+ rhs row)
+    int proj0, proj1;            // projection observations (sorted by landmark, then frame)
+    int lm0, lm1;                // landmark records
+    int fr_base, nF;             // observing frames (pose blocks that carry observations)
+    long long P_base;            // (6 nF)^2 landmark Schur product
+    long long YW_base;           // [3 nL][6 nF] Yt / Wt
+    int gf0, gf1;                // generic (non-projection) factors
+    int cl0, cl1;                // cliques
+    int pair0, pair1;            // reduced block pairs
+    int pad0, pad1;
+    double proj_sqrt_info, proj_loss_a;
+    double pbg[3], gw[3], base[3];
+};
+
+// ---- per-window mutable solver state (lives on the device for the whole solve) ----------
+struct WinState {
+    double radius, mu, x_cost, x_norm, alpha, dogleg_step_norm, step_norm, gmax;
+    double jg_sq, initial_cost;
+    int status, iter, need_lin, reuse, eval_cand, lin_fail, invalid_run, nsucc, nunsucc, pad;
+};
+
+// ---- generic factor (everything except projection) --------------------------------------
+enum { GF_IMU = 1, GF_CP = 2, GF_PR = 3, GF_DOP = 4, GF_SP = 5, GF_PRIOR = 6 };
+struct GFac {
+    int type, win, nres, nslot;
+    int slot0;                   // into slot arrays
+    int roff;                    // into g_r
+    int data;                    // index into the type's data array (record index)
+    int clique;                  // owning clique
+};
+
+// ---- clique: a group-0 block (or none) + the factors touching it + its reduced neighbours
+struct Clique {
+    int win;
+    int e_loc, d_e;              // local offset / size of the eliminated block (d_e = 0: none)
+    int d_f;                     // sum of member local sizes
+    int fac0, fac1;              // into clique factor list (generic factor ids)
+    int mem0, mem1;              // into member arrays (loc offset, size, column)
+    long long C_off;             // d_f x d_f Schur'd block (static for priors)
+    int v_off;                   // d_f vectors: graw, dgraw, cs
+    int e_off;                   // d_e*d_e Einv + d_e*d_f strip + d_e g_e   (offset into e-buffer)
+    int is_static;               // 1: prior clique, C/dgraw precomputed; only graw changes
+    int pad;
+};
+
+// ---- reduced block pair (a >= b in elimination order): one wave assembles S[a,b] --------
+struct Pair {
+    int win;
+    int ra, rb, la, lb;          // reduced offsets and sizes
+    int fa, fb;                  // frame slots (>= 0 if pose carries observations) else -1
+    int c0, c1;                  // contribution list range
+    int is_diag;
+    int loc_a;                   // local offset of block a (for g/diag/rhs of diagonal pairs)
+    int pad;
+};
+
+struct DevBatch {
+    int n_win;
+    int n_x, n_loc_total;
+    int max_iter_trace;
+    // state
+    double* x; double* xc; double* x0;
+    // local-space vectors
+    double* g; double* diag; double* rhs; double* y; double* step;
+    // reduced matrices
+    double* S; double* L;
+    // tables
+    const WinRec* win; WinState* ws; swf_iteration* trace;
+    const int* blk_xoff; const int* blk_loc; const int* blk_gs;
+    // projection observations (SoA outputs, stride n_proj)
+    int n_proj;
+    const int* p_win; const int* p_xpose; const int* p_xex; const int* p_xlm;
+    const int* p_lpose; const int* p_llm; const int* p_fr; const int* p_lm;
+    const double* p_uv;
+    double* p_r; double* p_Jp; double* p_Jl; double* p_cost; double* p_aux;
+    // landmarks
+    int n_lm;
+    const int* lm_win; const int* lm_obs0; const int* lm_loc; const int* lm_col;
+    double* lm_Einv; double* lm_g;             // SoA stride n_lm: 6 / 3
+    double* Yt; double* Wt; double* P;
+    // frames
+    int n_fr;
+    const int* fr_obs0; const int* fr_obs;     // CSR of observations per frame
+    // generic factors
+    int n_gf;
+    const GFac* gf;
+    const int* s_x; const int* s_loc; const int* s_ls; const int* s_joff; const int* s_ccol;
+    double* g_r; double* g_J; double* g_cost; double* g_aux;
+    const double* imu_pre; const double* cp_dat; const double* pr_dat; const double* dop_dat; const double* sp_w;
+    int n_imu; const int* imu_gf;              // generic-factor ids by kernel
+    int n_sc;  const int* sc_gf;
+    int n_prior; const int* prior_gf;
+    // priors
+    const int* prior_dim; const long long* prior_Joff; const int* prior_roff; const int* prior_x0off;
+    const double* prior_J; const double* prior_r0; const double* prior_x0;
+    // cliques
+    int n_cl;
+    const Clique* cl;
+    const int* cl_fac;
+    const int* cm_loc; const int* cm_ls; const int* cm_col;
+    double* C; double* cv_graw; double* cv_dgraw; double* cv_cs; double* cE;
+    // pairs
+    int n_pair;
+    const Pair* pair;
+    const long long* pc_coff; const int* pc_cld; const int* pc_voff;
+};
+
+// ------------------------------------------------------------------ device math
+// quaternions (x, y, z, w), Hamilton product — same formulas as Eigen, which the reference
+// uses (R/factor/*.cpp); see oracle/swf_oracle.c for the CPU restatement.
+__device__ __forceinline__ void qmul(const double* a, const double* b, double* o) {
+    double ax = a[0], ay = a[1], az = a[2], aw = a[3];
+    double bx = b[0], by = b[1], bz = b[2], bw = b[3];
+    o[3] = aw * bw - ax * bx - ay * by - az * bz;
+    o[0] = aw * bx + ax * bw + ay * bz - az * by;
+    o[1] = aw * by + ay * bw + az * bx - ax * bz;
+    o[2] = aw * bz + az * bw + ax * by - ay * bx;
+}
+__device__ __forceinline__ void qinv(const double* q, double* o) {
+    double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    o[0] = -q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = q[3] / n2;
+}
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void qrot(const double* q, const double* v, double* o) {
+    double uv[3], t[3];
+    cross3(q, v, uv);
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    cross3(q, uv, t);
+    o[0] = v[0] + q[3] * uv[0] + t[0];
+    o[1] = v[1] + q[3] * uv[1] + t[1];
+    o[2] = v[2] + q[3] * uv[2] + t[2];
+}
+__device__ __forceinline__ void q2R(const double* q, double* R) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    double twx = tx * w, twy = ty * w, twz = tz * w;
+    double txx = tx * x, txy = ty * x, txz = tz * x;
+    double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void skew3(const double* v, double* S) {
+    S[0] = 0;     S[1] = -v[2]; S[2] = v[1];
+    S[3] = v[2];  S[4] = 0;     S[5] = -v[0];
+    S[6] = -v[1]; S[7] = v[0];  S[8] = 0;
+}
+__device__ __forceinline__ void mat3mul(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mat3T(const double* A, double* T) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T[i * 3 + j] = A[j * 3 + i];
+}
+__device__ __forceinline__ void mat3vec(const double* A, const double* v, double* o) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
+}
+__device__ __forceinline__ void qleft_br(const double* q, double* M) {
+    skew3(q, M);
+    M[0] += q[3]; M[4] += q[3]; M[8] += q[3];
+}
+__device__ __forceinline__ void qleft_qright_br(const double* a, const double* b, double* M) {
+    double L[9], Rr[9], S[9];
+    qleft_br(a, L);
+    skew3(b, S);
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rr[i] = -S[i];
+    Rr[0] += b[3]; Rr[4] += b[3]; Rr[8] += b[3];
+    mat3mul(L, Rr, M);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) M[i * 3 + j] += -a[i] * b[j];
+}
+// PoseLocalParameterization::Plus (R/factor/pose_local_parameterization.cpp:5-19)
+__device__ __forceinline__ void pose_plus(const double* x, const double* d, double* o) {
+    o[0] = x[0] + d[0]; o[1] = x[1] + d[1]; o[2] = x[2] + d[2];
+    double dq[4] = { d[3] / 2, d[4] / 2, d[5] / 2, 1.0 }, q[4];
+    qmul(x + 3, dq, q);
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    o[3] = q[0] / n; o[4] = q[1] / n; o[5] = q[2] / n; o[6] = q[3] / n;
+}
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// wave-level all-reduce (butterfly: every lane ends with the total; fixed order => deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+// block-level sum for blockDim.x = multiple of 64 (<= 1024); scratch >= 16 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    v = wave_sum(v);
+    int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wid] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < nw; i++) s += scratch[i];
+    return s;
+}
+__device__ __forceinline__ double block_max(double v, double* scratch) {
+    v = wave_max(v);
+    int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wid] = v;
+    __syncthreads();
+    double s = scratch[0];
+    for (int i = 1; i < nw; i++) s = scratch[i] > s ? scratch[i] : s;
+    return s;
+}

@@ -1,0 +1,729 @@
+// swf_engine.hip — host side of the batch engine + the swf_batch_* C-ABI (include/swf_solver.h).
+//
+// Symbolic phase: flat windows -> index arrays (DevBatch), once per structure.
+// Numeric phase: a fixed launch sequence per solve, no host synchronisation inside.
+// gfx950 only; there is no CPU path: without a HIP device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/swf_solver.h"
+#include "swf_kernels2.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SWF_E_NODEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" const char* swf_last_error(void) { return g_err.c_str(); }
+extern "C" int swf_version(void) { return 100; }
+extern "C" int swf_device_count(int32_t* n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(SWF_E_NODEVICE, hipGetErrorString(e)); }
+    *n = c;
+    return SWF_OK;
+}
+extern "C" int swf_set_device(int32_t d) { HIPCHK(hipSetDevice(d)); return SWF_OK; }
+
+// ------------------------------------------------------------------ device buffer helper
+struct DevPool {
+    std::vector<void*> ptrs;
+    template <class T> int put(const std::vector<T>& h, const T** out, size_t min_elems = 1) {
+        size_t n = std::max(h.size(), min_elems);
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return -1;
+        ptrs.push_back(p);
+        if (hipMemset(p, 0, n * sizeof(T)) != hipSuccess) return -1;
+        if (!h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        *out = (const T*)p;
+        return 0;
+    }
+    template <class T> int zeros(size_t n, T** out) {
+        n = std::max<size_t>(n, 1);
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return -1;
+        ptrs.push_back(p);
+        if (hipMemset(p, 0, n * sizeof(T)) != hipSuccess) return -1;
+        *out = (T*)p;
+        return 0;
+    }
+    void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+};
+
+struct HostWin {       // what the host keeps per window for state transfer / export
+    double *pose, *sb, *lm, *sc;
+    int n_pose, n_sb, n_lm, n_sc;
+    int tail_dim;
+};
+
+struct swf_batch {
+    DevBatch D{};
+    DevPool pool;
+    hipStream_t stream = nullptr;
+    std::vector<WinRec> win;
+    std::vector<HostWin> hw;
+    int max_tiles = 0, max_prior_dim = 0;
+    bool timing = false;
+    swf_timing last{};
+    hipEvent_t ev[16]{};
+    bool ev_ok = false;
+    int64_t jac_bytes = 0;
+    int last_mode = -1;
+};
+
+// ------------------------------------------------------------------ symbolic phase
+namespace {
+struct Build {
+    // concatenated host arrays
+    std::vector<WinRec> win;
+    std::vector<int> blk_xoff, blk_loc, blk_gs;
+    std::vector<int> p_win, p_xpose, p_xex, p_xlm, p_lpose, p_llm, p_fr, p_lm;
+    std::vector<double> p_uv;
+    std::vector<int> lm_win, lm_obs0, lm_loc, lm_col;
+    std::vector<int> fr_obs0, fr_obs;
+    std::vector<GFac> gf;
+    std::vector<int> s_x, s_loc, s_ls, s_joff, s_ccol;
+    std::vector<double> imu_pre, cp_dat, pr_dat, dop_dat, sp_w;
+    std::vector<int> imu_gf, sc_gf, prior_gf;
+    std::vector<int> prior_dim, prior_roff, prior_x0off;
+    std::vector<long long> prior_Joff;
+    std::vector<double> prior_J, prior_r0, prior_x0;
+    std::vector<Clique> cl;
+    std::vector<int> cl_fac, cm_loc, cm_ls, cm_col;
+    std::vector<double> C_init, dgraw_init;      // static parts (prior cliques)
+    std::vector<Pair> pair;
+    std::vector<long long> pc_coff;
+    std::vector<int> pc_cld, pc_voff;
+    long long n_x = 0, n_loc = 0, S_tot = 0, Lt_tot = 0, P_tot = 0, YW_tot = 0, C_tot = 0;
+    int v_tot = 0, e_tot = 0, r_tot = 0, j_tot = 0, n_fr = 0;
+    int max_tiles = 0, max_prior_dim = 0;
+    int64_t jac_bytes = 0;
+};
+
+int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
+    WinRec R{};
+    const int nP = w->n_pose, nS = w->n_sb, nL = w->n_lm, nC = w->n_sc;
+    const int nb = nP + nS + nL + nC;
+    if (nb <= 0) return fail(SWF_E_INVALID, "empty window");
+    hw = HostWin{ w->pose, w->sb, w->lm, w->sc, nP, nS, nL, nC, 0 };
+    R.x_base = (int)B.n_x; R.blk_base = (int)B.blk_xoff.size(); R.n_blk = nb;
+    R.loc_base = (int)B.n_loc;
+    std::vector<int> gs(nb), ls(nb), xo(nb), loc(nb, -1), grp(nb, -1);
+    int xoff = 0;
+    for (int b = 0; b < nb; b++) {
+        int g = b < nP ? 7 : b < nP + nS ? 9 : b < nP + nS + nL ? 3 : 1;
+        gs[b] = g; ls[b] = g == 7 ? 6 : g; xo[b] = xoff; xoff += g;
+    }
+    R.x_n = xoff;
+    int lo = 0, ne = 0, prevg = 0;
+    for (int i = 0; i < w->n_order; i++) {
+        int b = w->order_block[i], g = w->order_group[i];
+        if (b < 0 || b >= nb) return fail(SWF_E_INVALID, "ordering: block id out of range");
+        if (w->is_const[b]) return fail(SWF_E_INVALID, "ordering: constant block in ordering");
+        if (loc[b] >= 0) return fail(SWF_E_INVALID, "ordering: block listed twice");
+        if (g < prevg) return fail(SWF_E_INVALID, "ordering: groups must ascend");
+        prevg = g;
+        loc[b] = lo; grp[b] = g; lo += ls[b];
+        if (g == 0) ne += ls[b];
+    }
+    for (int b = 0; b < nb; b++) if (!w->is_const[b] && loc[b] < 0) return fail(SWF_E_INVALID, "ordering: variable block missing from ordering");
+    R.n_loc = lo; R.n_e = ne; R.n_red = lo - ne;
+    if (R.n_red + 1 > 1024) return fail(SWF_E_UNSUPPORTED, "reduced system larger than 1023");
+    R.S_base = B.S_tot; B.S_tot += (long long)R.n_red * R.n_red;
+    R.Lt_base = B.Lt_tot; B.Lt_tot += (long long)(R.n_red + 1) * (R.n_red + 1);
+    {
+        int td = 0;
+        for (int i = w->n_order - w->n_tail; i < w->n_order; i++) if (i >= 0) td += ls[w->order_block[i]];
+        hw.tail_dim = td;
+    }
+    for (int b = 0; b < nb; b++) {
+        B.blk_xoff.push_back(R.x_base + xo[b]);
+        B.blk_loc.push_back(loc[b] >= 0 ? R.loc_base + loc[b] : -1);
+        B.blk_gs.push_back(gs[b]);
+    }
+    auto bidP = [&](int i) { return i; };
+    auto bidS = [&](int i) { return nP + i; };
+    auto bidL = [&](int i) { return nP + nS + i; };
+    auto bidC = [&](int i) { return nP + nS + nL + i; };
+    auto is_e = [&](int b) { return grp[b] == 0; };
+    auto gloc = [&](int b) { return loc[b] >= 0 ? R.loc_base + loc[b] : -1; };
+    auto gx = [&](int b) { return R.x_base + xo[b]; };
+
+    // ---- projection observations sorted by (landmark, pose)
+    std::vector<int> ord(w->n_proj);
+    for (int i = 0; i < w->n_proj; i++) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+        int la = w->proj_idx[a * 3 + 2], lb = w->proj_idx[b * 3 + 2];
+        if (la != lb) return la < lb;
+        return w->proj_idx[a * 3] < w->proj_idx[b * 3];
+    });
+    // frames: variable, non-eliminated poses that carry observations, in pose order
+    std::vector<int> frame_of(nP, -1);
+    {
+        std::vector<char> seen(nP, 0);
+        for (int i = 0; i < w->n_proj; i++) {
+            int p = w->proj_idx[i * 3];
+            if (p < 0 || p >= nP || w->proj_idx[i * 3 + 1] < 0 || w->proj_idx[i * 3 + 1] >= nP || w->proj_idx[i * 3 + 2] < 0 || w->proj_idx[i * 3 + 2] >= nL)
+                return fail(SWF_E_INVALID, "projection factor: index out of range");
+            seen[p] = 1;
+        }
+        int nf = 0;
+        for (int p = 0; p < nP; p++) if (seen[p] && loc[bidP(p)] >= 0) {
+            if (is_e(bidP(p))) return fail(SWF_E_UNSUPPORTED, "pose block in elimination group 0");
+            frame_of[p] = nf++;
+        }
+        R.nF = nf; R.fr_base = B.n_fr;
+    }
+    R.proj0 = (int)B.p_win.size();
+    R.lm0 = (int)B.lm_win.size();
+    {
+        std::vector<std::vector<int>> fobs(R.nF);
+        std::vector<int> lm_first(nL + 1, 0);
+        for (int q = 0; q < w->n_proj; q++) {
+            int i = ord[q];
+            int p = w->proj_idx[i * 3], ex = w->proj_idx[i * 3 + 1], l = w->proj_idx[i * 3 + 2];
+            if (loc[bidP(ex)] >= 0) return fail(SWF_E_UNSUPPORTED, "variable camera extrinsic (ESTIMATE_EXTRINSIC) not supported by the kernels yet");
+            int gi = (int)B.p_win.size();
+            B.p_win.push_back(wi);
+            B.p_xpose.push_back(gx(bidP(p))); B.p_xex.push_back(gx(bidP(ex))); B.p_xlm.push_back(gx(bidL(l)));
+            B.p_lpose.push_back(gloc(bidP(p))); B.p_llm.push_back(gloc(bidL(l)));
+            B.p_fr.push_back(frame_of[p]); B.p_lm.push_back(R.lm0 + l);
+            B.p_uv.push_back(w->proj_uv[i * 2]); B.p_uv.push_back(w->proj_uv[i * 2 + 1]);
+            if (frame_of[p] >= 0) fobs[frame_of[p]].push_back(gi);
+            lm_first[l + 1]++;
+        }
+        for (int l = 0; l < nL; l++) lm_first[l + 1] += lm_first[l];
+        for (int l = 0; l < nL; l++) {
+            int b = bidL(l);
+            if (loc[b] >= 0 && !is_e(b)) return fail(SWF_E_UNSUPPORTED, "variable landmark outside elimination group 0");
+            B.lm_win.push_back(wi);
+            B.lm_obs0.push_back(R.proj0 + lm_first[l]);
+            B.lm_loc.push_back(gloc(b));
+            B.lm_col.push_back(3 * l);
+        }
+        for (int f = 0; f < R.nF; f++) {
+            B.fr_obs0.push_back((int)B.fr_obs.size());
+            for (int o : fobs[f]) B.fr_obs.push_back(o);
+        }
+        B.n_fr += R.nF;
+    }
+    R.proj1 = (int)B.p_win.size();
+    R.lm1 = (int)B.lm_win.size();
+    R.P_base = B.P_tot; B.P_tot += (long long)36 * R.nF * R.nF;
+    R.YW_base = B.YW_tot; B.YW_tot += (long long)3 * nL * 6 * R.nF;
+    {
+        int m = 6 * R.nF, nt = (m + 15) / 16;
+        B.max_tiles = std::max(B.max_tiles, nt * (nt + 1) / 2);
+    }
+
+    // ---- generic factors
+    R.gf0 = (int)B.gf.size();
+    struct TmpF { std::vector<int> blk; };
+    std::vector<TmpF> tf;
+    auto add_gf = [&](int type, int nres, int data, const std::vector<int>& blks) {
+        GFac G{};
+        G.type = type; G.win = wi; G.nres = nres; G.nslot = (int)blks.size();
+        G.slot0 = (int)B.s_x.size(); G.roff = B.r_tot; G.data = data; G.clique = -1;
+        B.r_tot += nres;
+        for (int b : blks) {
+            B.s_x.push_back(gx(b)); B.s_loc.push_back(gloc(b)); B.s_ls.push_back(ls[b]);
+            if (loc[b] >= 0 && type != GF_PRIOR) { B.s_joff.push_back(B.j_tot); B.j_tot += nres * ls[b]; }
+            else B.s_joff.push_back(-1);
+            B.s_ccol.push_back(-1);
+        }
+        B.gf.push_back(G);
+        tf.push_back(TmpF{ blks });
+        return (int)B.gf.size() - 1;
+    };
+#define CHK(i, n, what) if ((i) < 0 || (i) >= (n)) return fail(SWF_E_INVALID, what ": index out of range");
+    for (int i = 0; i < w->n_imu; i++) {
+        const int* ix = w->imu_idx + i * 4;
+        CHK(ix[0], nP, "imu") CHK(ix[1], nS, "imu") CHK(ix[2], nP, "imu") CHK(ix[3], nS, "imu")
+        int data = (int)(B.imu_pre.size() / SWF_PRE_DOUBLES);
+        B.imu_pre.insert(B.imu_pre.end(), w->imu_pre + (size_t)i * SWF_PRE_DOUBLES, w->imu_pre + (size_t)(i + 1) * SWF_PRE_DOUBLES);
+        B.imu_gf.push_back(add_gf(GF_IMU, 15, data, { bidP(ix[0]), bidS(ix[1]), bidP(ix[2]), bidS(ix[3]) }));
+    }
+    for (int i = 0; i < w->n_cp; i++) {
+        const int* ix = w->cp_idx + i * 3;
+        CHK(ix[0], nP, "carrier phase") CHK(ix[1], nC, "carrier phase") CHK(ix[2], nC, "carrier phase")
+        int data = (int)(B.cp_dat.size() / SWF_CP_DOUBLES);
+        B.cp_dat.insert(B.cp_dat.end(), w->cp_dat + i * SWF_CP_DOUBLES, w->cp_dat + (i + 1) * SWF_CP_DOUBLES);
+        B.sc_gf.push_back(add_gf(GF_CP, 1, data, { bidP(ix[0]), bidC(ix[1]), bidC(ix[2]) }));
+    }
+    for (int i = 0; i < w->n_pr; i++) {
+        const int* ix = w->pr_idx + i * 2;
+        CHK(ix[0], nP, "pseudorange") CHK(ix[1], nC, "pseudorange")
+        int data = (int)(B.pr_dat.size() / SWF_PR_DOUBLES);
+        B.pr_dat.insert(B.pr_dat.end(), w->pr_dat + i * SWF_PR_DOUBLES, w->pr_dat + (i + 1) * SWF_PR_DOUBLES);
+        B.sc_gf.push_back(add_gf(GF_PR, 1, data, { bidP(ix[0]), bidC(ix[1]) }));
+    }
+    for (int i = 0; i < w->n_dop; i++) {
+        const int* ix = w->dop_idx + i * 3;
+        CHK(ix[0], nS, "doppler") CHK(ix[1], nC, "doppler") CHK(ix[2], nP, "doppler")
+        int data = (int)(B.dop_dat.size() / SWF_DOP_DOUBLES);
+        B.dop_dat.insert(B.dop_dat.end(), w->dop_dat + i * SWF_DOP_DOUBLES, w->dop_dat + (i + 1) * SWF_DOP_DOUBLES);
+        B.sc_gf.push_back(add_gf(GF_DOP, 1, data, { bidS(ix[0]), bidC(ix[1]), bidP(ix[2]) }));
+    }
+    for (int i = 0; i < w->n_sp; i++) {
+        CHK(w->sp_idx[i], nC, "scalar prior")
+        int data = (int)B.sp_w.size();
+        B.sp_w.push_back(w->sp_w[i]);
+        B.sc_gf.push_back(add_gf(GF_SP, 1, data, { bidC(w->sp_idx[i]) }));
+    }
+    std::vector<int> prior_first_gf;
+    {
+        int bo = 0; long long jo = 0; int ro = 0, x0o = 0;
+        for (int k = 0; k < w->n_prior; k++) {
+            int nbk = w->prior_nblk[k], dim = w->prior_dim[k];
+            std::vector<int> blks(w->prior_blk + bo, w->prior_blk + bo + nbk);
+            int dsum = 0, gsum = 0;
+            for (int b : blks) { CHK(b, nb, "prior") dsum += ls[b]; gsum += gs[b]; }
+            if (dsum != dim) return fail(SWF_E_INVALID, "prior: dim != sum of local block sizes");
+            int data = (int)B.prior_dim.size();
+            B.prior_dim.push_back(dim);
+            B.prior_Joff.push_back((long long)B.prior_J.size());
+            B.prior_roff.push_back((int)B.prior_r0.size());
+            B.prior_x0off.push_back((int)B.prior_x0.size());
+            B.prior_J.insert(B.prior_J.end(), w->prior_J + jo, w->prior_J + jo + (long long)dim * dim);
+            B.prior_r0.insert(B.prior_r0.end(), w->prior_r0 + ro, w->prior_r0 + ro + dim);
+            B.prior_x0.insert(B.prior_x0.end(), w->prior_x0 + x0o, w->prior_x0 + x0o + gsum);
+            int g = add_gf(GF_PRIOR, dim, data, blks);
+            B.prior_gf.push_back(g);
+            prior_first_gf.push_back(g);
+            B.max_prior_dim = std::max(B.max_prior_dim, dim);
+            bo += nbk; jo += (long long)dim * dim; ro += dim; x0o += gsum;
+        }
+    }
+#undef CHK
+    R.gf1 = (int)B.gf.size();
+
+    // ---- cliques
+    R.cl0 = (int)B.cl.size();
+    std::map<int, int> e_clique;            // window block id -> clique
+    std::map<int, int> free_clique;         // first variable block -> clique (free factors)
+    struct TmpC { int e; std::vector<int> facs; std::vector<int> mem; bool is_static; };
+    std::vector<TmpC> tc;
+    // group-0 non-landmark blocks, in ordering order, always get a clique
+    for (int i = 0; i < w->n_order; i++) {
+        int b = w->order_block[i];
+        if (w->order_group[i] != 0) break;
+        if (b >= nP + nS && b < nP + nS + nL) continue;
+        e_clique[b] = (int)tc.size();
+        tc.push_back(TmpC{ b, {}, {}, false });
+    }
+    for (int f = R.gf0; f < R.gf1; f++) {
+        const TmpF& t = tf[f - R.gf0];
+        int e = -1, first_var = -1;
+        for (int b : t.blk) {
+            if (loc[b] < 0) continue;
+            if (first_var < 0) first_var = b;
+            if (is_e(b)) {
+                if (b >= nP + nS && b < nP + nS + nL) return fail(SWF_E_UNSUPPORTED, "non-projection factor on a landmark");
+                if (e >= 0 && e != b) return fail(SWF_E_INVALID, "elimination group 0 is not an independent set");
+                e = b;
+            }
+        }
+        int c;
+        if (e >= 0) c = e_clique[e];
+        else if (B.gf[f].type == GF_PRIOR) { c = (int)tc.size(); tc.push_back(TmpC{ -1, {}, {}, true }); }
+        else if (first_var < 0) continue;    // all-constant factor: contributes only to the cost
+        else {
+            auto it = free_clique.find(first_var);
+            if (it == free_clique.end()) { c = (int)tc.size(); free_clique[first_var] = c; tc.push_back(TmpC{ -1, {}, {}, false }); }
+            else c = it->second;
+        }
+        tc[c].facs.push_back(f);
+        for (int b : t.blk) {
+            if (loc[b] < 0 || b == e) continue;
+            if (std::find(tc[c].mem.begin(), tc[c].mem.end(), b) == tc[c].mem.end()) tc[c].mem.push_back(b);
+        }
+    }
+    // reduced offsets
+    auto red = [&](int b) { return loc[b] - ne; };
+    std::map<std::pair<int, int>, std::vector<std::array<long long, 3>>> pmap;   // (a,b) -> (coff, cld, voff)
+    for (size_t ci = 0; ci < tc.size(); ci++) {
+        TmpC& t = tc[ci];
+        Clique C{};
+        C.win = wi;
+        C.d_e = t.e >= 0 ? ls[t.e] : 0;
+        C.e_loc = t.e >= 0 ? gloc(t.e) : -1;
+        C.fac0 = (int)B.cl_fac.size();
+        for (int f : t.facs) { B.cl_fac.push_back(f); B.gf[f].clique = (int)B.cl.size(); }
+        C.fac1 = (int)B.cl_fac.size();
+        C.mem0 = (int)B.cm_loc.size();
+        int df = 0;
+        std::map<int, int> colof;
+        for (int b : t.mem) {
+            B.cm_loc.push_back(gloc(b)); B.cm_ls.push_back(ls[b]); B.cm_col.push_back(df);
+            colof[b] = df; df += ls[b];
+        }
+        C.mem1 = (int)B.cm_loc.size();
+        C.d_f = df;
+        if (!t.is_static && C.d_e + df > CLQ_MAXD) return fail(SWF_E_UNSUPPORTED, "clique larger than 64 columns");
+        C.C_off = B.C_tot; B.C_tot += (long long)df * df;
+        C.v_off = B.v_tot; B.v_tot += df;
+        C.e_off = B.e_tot; B.e_tot += C.d_e * C.d_e + C.d_e * df + C.d_e;
+        C.is_static = t.is_static ? 1 : 0;
+        // slot -> clique column
+        for (int f : t.facs) {
+            const TmpF& tff = tf[f - R.gf0];
+            for (size_t sl = 0; sl < tff.blk.size(); sl++) {
+                int b = tff.blk[sl];
+                int cc = -1;
+                if (loc[b] >= 0) cc = (b == t.e) ? 0 : C.d_e + colof[b];
+                B.s_ccol[B.gf[f].slot0 + sl] = cc;
+            }
+        }
+        // static prior clique: C = J^T J over member columns, dgraw = diag
+        B.C_init.resize((size_t)B.C_tot, 0.0);
+        B.dgraw_init.resize((size_t)B.v_tot, 0.0);
+        if (t.is_static) {
+            const GFac& G = B.gf[t.facs[0]];
+            int dim = G.nres;
+            const double* J = B.prior_J.data() + B.prior_Joff[G.data];
+            // prior column -> member column (or -1)
+            std::vector<int> pcol(dim, -1);
+            {
+                int col = 0;
+                const TmpF& tff = tf[t.facs[0] - R.gf0];
+                for (int b : tff.blk) { if (loc[b] >= 0) for (int j = 0; j < ls[b]; j++) pcol[col + j] = colof[b] + j; col += ls[b]; }
+            }
+            double* Cm = B.C_init.data() + C.C_off;
+            for (int a = 0; a < dim; a++) {
+                if (pcol[a] < 0) continue;
+                for (int b2 = 0; b2 < dim; b2++) {
+                    if (pcol[b2] < 0) continue;
+                    double sacc = 0;
+                    for (int r = 0; r < dim; r++) sacc += J[(size_t)r * dim + a] * J[(size_t)r * dim + b2];
+                    Cm[(size_t)pcol[a] * df + pcol[b2]] = sacc;
+                }
+                B.dgraw_init[C.v_off + pcol[a]] = Cm[(size_t)pcol[a] * df + pcol[a]];
+            }
+        }
+        // pair contributions
+        for (int a : t.mem) for (int b2 : t.mem) {
+            if (red(a) < red(b2)) continue;
+            pmap[{ a, b2 }].push_back({ C.C_off + (long long)colof[a] * df + colof[b2], df, C.v_off + colof[a] });
+        }
+        B.cl.push_back(C);
+    }
+    R.cl1 = (int)B.cl.size();
+
+    // ---- pairs: clique pairs, all frame pairs, a diagonal pair for every reduced block
+    for (int p = 0; p < nP; p++) if (frame_of[p] >= 0)
+        for (int q = 0; q < nP; q++) if (frame_of[q] >= 0 && red(bidP(p)) >= red(bidP(q))) pmap[{ bidP(p), bidP(q) }];
+    for (int i = 0; i < w->n_order; i++) { int b = w->order_block[i]; if (!is_e(b)) pmap[{ b, b }]; }
+    R.pair0 = (int)B.pair.size();
+    for (auto& kv : pmap) {
+        int a = kv.first.first, b2 = kv.first.second;
+        Pair P{};
+        P.win = wi; P.ra = red(a); P.rb = red(b2); P.la = ls[a]; P.lb = ls[b2];
+        P.fa = a < nP ? frame_of[a] : -1; P.fb = b2 < nP ? frame_of[b2] : -1;
+        P.c0 = (int)B.pc_coff.size();
+        for (auto& c : kv.second) { B.pc_coff.push_back(c[0]); B.pc_cld.push_back((int)c[1]); B.pc_voff.push_back((int)c[2]); }
+        P.c1 = (int)B.pc_coff.size();
+        P.is_diag = (a == b2) ? 1 : 0;
+        P.loc_a = gloc(a);
+        B.pair.push_back(P);
+    }
+    R.pair1 = (int)B.pair.size();
+
+    R.proj_sqrt_info = w->proj_sqrt_info; R.proj_loss_a = w->proj_loss_a;
+    for (int k = 0; k < 3; k++) { R.pbg[k] = w->pbg[k]; R.gw[k] = w->gw[k]; R.base[k] = w->base[k]; }
+    B.n_x += R.x_n; B.n_loc += R.n_loc;
+    // algorithmic Jacobian bytes of one evaluation (SURVEY.md §8d formula)
+    {
+        int64_t pb = 0;
+        for (int k = 0; k < w->n_prior; k++) { int64_t n = w->prior_dim[k]; pb += 8 * (n * n + 4 * n); }
+        B.jac_bytes += (int64_t)312 * w->n_proj + (int64_t)5480 * w->n_imu + (int64_t)176 * w->n_cp + (int64_t)152 * w->n_pr + (int64_t)208 * w->n_dop + pb;
+    }
+    B.win.push_back(R);
+    return SWF_OK;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ batch API
+extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n, void* stream, swf_batch** out) {
+    if (!windows || n <= 0 || !out) return fail(SWF_E_INVALID, "swf_batch_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SWF_E_NODEVICE, "no HIP device: this library has no CPU fallback");
+    Build B;
+    std::vector<HostWin> hw(n);
+    for (int i = 0; i < n; i++) {
+        int rc = build_window(B, windows[i], i, hw[i]);
+        if (rc != SWF_OK) return rc;
+    }
+    if (B.n_x > 0x7fffffffLL || B.n_loc > 0x7fffffffLL) return fail(SWF_E_UNSUPPORTED, "batch too large for 32-bit offsets");
+    swf_batch* b = new swf_batch();
+    b->stream = (hipStream_t)stream;
+    b->win = B.win; b->hw = hw; b->max_tiles = B.max_tiles; b->max_prior_dim = B.max_prior_dim; b->jac_bytes = B.jac_bytes;
+    DevBatch& D = b->D;
+    DevPool& P = b->pool;
+    int rc = 0;
+    D.n_win = n; D.n_x = (int)B.n_x; D.n_loc_total = (int)B.n_loc; D.max_iter_trace = SWF_MAX_TRACE;
+#define PUT(field, vec) rc |= P.put(vec, &D.field)
+    PUT(win, B.win);
+    PUT(blk_xoff, B.blk_xoff); PUT(blk_loc, B.blk_loc); PUT(blk_gs, B.blk_gs);
+    D.n_proj = (int)B.p_win.size();
+    PUT(p_win, B.p_win); PUT(p_xpose, B.p_xpose); PUT(p_xex, B.p_xex); PUT(p_xlm, B.p_xlm);
+    PUT(p_lpose, B.p_lpose); PUT(p_llm, B.p_llm); PUT(p_fr, B.p_fr); PUT(p_lm, B.p_lm); PUT(p_uv, B.p_uv);
+    D.n_lm = (int)B.lm_win.size();
+    B.lm_obs0.push_back(D.n_proj);
+    PUT(lm_win, B.lm_win); PUT(lm_obs0, B.lm_obs0); PUT(lm_loc, B.lm_loc); PUT(lm_col, B.lm_col);
+    D.n_fr = B.n_fr;
+    B.fr_obs0.push_back((int)B.fr_obs.size());
+    PUT(fr_obs0, B.fr_obs0); PUT(fr_obs, B.fr_obs);
+    D.n_gf = (int)B.gf.size();
+    PUT(gf, B.gf);
+    PUT(s_x, B.s_x); PUT(s_loc, B.s_loc); PUT(s_ls, B.s_ls); PUT(s_joff, B.s_joff); PUT(s_ccol, B.s_ccol);
+    PUT(imu_pre, B.imu_pre); PUT(cp_dat, B.cp_dat); PUT(pr_dat, B.pr_dat); PUT(dop_dat, B.dop_dat); PUT(sp_w, B.sp_w);
+    D.n_imu = (int)B.imu_gf.size(); D.n_sc = (int)B.sc_gf.size(); D.n_prior = (int)B.prior_gf.size();
+    PUT(imu_gf, B.imu_gf); PUT(sc_gf, B.sc_gf); PUT(prior_gf, B.prior_gf);
+    PUT(prior_dim, B.prior_dim); PUT(prior_Joff, B.prior_Joff); PUT(prior_roff, B.prior_roff); PUT(prior_x0off, B.prior_x0off);
+    PUT(prior_J, B.prior_J); PUT(prior_r0, B.prior_r0); PUT(prior_x0, B.prior_x0);
+    D.n_cl = (int)B.cl.size();
+    PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
+    D.n_pair = (int)B.pair.size();
+    PUT(pair, B.pair); PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
+#undef PUT
+    // mutable buffers
+    rc |= P.zeros(B.n_x, &D.x); rc |= P.zeros(B.n_x, &D.xc); rc |= P.zeros(B.n_x, &D.x0);
+    rc |= P.zeros(B.n_loc, &D.g); rc |= P.zeros(B.n_loc, &D.diag); rc |= P.zeros(B.n_loc, &D.rhs);
+    rc |= P.zeros(B.n_loc, &D.y); rc |= P.zeros(B.n_loc, &D.step);
+    rc |= P.zeros(B.S_tot, &D.S); rc |= P.zeros(B.Lt_tot, &D.L);
+    rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
+    size_t np = (size_t)D.n_proj;
+    rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl);
+    rc |= P.zeros(np, &D.p_cost); rc |= P.zeros(np, &D.p_aux);
+    rc |= P.zeros(6 * (size_t)D.n_lm, &D.lm_Einv); rc |= P.zeros(3 * (size_t)D.n_lm, &D.lm_g);
+    rc |= P.zeros(B.YW_tot, &D.Yt); rc |= P.zeros(B.YW_tot, &D.Wt); rc |= P.zeros(B.P_tot, &D.P);
+    rc |= P.zeros((size_t)B.r_tot, &D.g_r); rc |= P.zeros((size_t)B.j_tot, &D.g_J);
+    rc |= P.zeros((size_t)D.n_gf, &D.g_cost); rc |= P.zeros((size_t)D.n_gf, &D.g_aux);
+    {
+        const double* ci = nullptr; const double* di = nullptr;
+        B.C_init.resize((size_t)B.C_tot, 0.0); B.dgraw_init.resize((size_t)B.v_tot, 0.0);
+        rc |= P.put(B.C_init, &ci); rc |= P.put(B.dgraw_init, &di);
+        D.C = (double*)ci; D.cv_dgraw = (double*)di;
+    }
+    rc |= P.zeros((size_t)B.v_tot, &D.cv_graw); rc |= P.zeros((size_t)B.v_tot, &D.cv_cs);
+    rc |= P.zeros((size_t)B.e_tot, &D.cE);
+    if (rc) { P.release(); delete b; return fail(SWF_E_NODEVICE, "device allocation / upload failed"); }
+    *out = b;
+    int urc = swf_batch_upload_state(b);
+    if (urc != SWF_OK) { swf_batch_destroy(b); *out = nullptr; return urc; }
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_destroy(swf_batch* b) {
+    if (!b) return SWF_OK;
+    if (b->ev_ok) for (auto& e : b->ev) (void)hipEventDestroy(e);
+    b->pool.release();
+    delete b;
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_upload_state(swf_batch* b) {
+    if (!b) return fail(SWF_E_INVALID, "null batch");
+    std::vector<double> x((size_t)b->D.n_x);
+    for (size_t i = 0; i < b->win.size(); i++) {
+        const HostWin& h = b->hw[i];
+        double* p = x.data() + b->win[i].x_base;
+        memcpy(p, h.pose, sizeof(double) * 7 * h.n_pose); p += 7 * h.n_pose;
+        memcpy(p, h.sb, sizeof(double) * 9 * h.n_sb); p += 9 * h.n_sb;
+        memcpy(p, h.lm, sizeof(double) * 3 * h.n_lm); p += 3 * h.n_lm;
+        memcpy(p, h.sc, sizeof(double) * h.n_sc);
+    }
+    HIPCHK(hipMemcpyAsync(b->D.x, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->D.x0, b->D.x, x.size() * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));     // x is a stack-lifetime staging buffer
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_reset_state(swf_batch* b) {
+    if (!b) return fail(SWF_E_INVALID, "null batch");
+    int n = b->D.n_x;
+    hipLaunchKernelGGL(k_copy, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->D.x, (const double*)b->D.x0, n);
+    HIPCHK(hipGetLastError());
+    return SWF_OK;
+}
+
+static DevOpt to_devopt(const swf_options* o) {
+    DevOpt d{};
+    d.max_iter = o->max_num_iterations; d.step_mode = o->step_mode;
+    d.r0 = o->initial_trust_region_radius; d.max_r = o->max_trust_region_radius; d.min_r = o->min_trust_region_radius;
+    d.min_rel_dec = o->min_relative_decrease; d.ftol = o->function_tolerance; d.gtol = o->gradient_tolerance;
+    d.ptol = o->parameter_tolerance; d.min_mu = o->min_mu; d.max_mu = o->max_mu; d.mu_inc = o->mu_increase_factor;
+    d.min_diag = o->min_diagonal; d.max_diag = o->max_diagonal;
+    return d;
+}
+
+#define GRID(n, per) dim3((unsigned)(((n) + (per) - 1) / (per)))
+namespace {
+struct Launcher {
+    swf_batch* b; DevOpt O; hipStream_t st;
+    void lin_eval() {
+        DevBatch& D = b->D;
+        if (D.n_proj) hipLaunchKernelGGL(k_eval_proj<true>, GRID(D.n_proj, 256), dim3(256), 0, st, D);
+        if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<true>, dim3(D.n_imu), dim3(64), 0, st, D);
+        if (D.n_sc) hipLaunchKernelGGL(k_eval_scalar<true>, GRID(D.n_sc, 256), dim3(256), 0, st, D);
+        if (D.n_prior) hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
+    }
+    void lin_elim(int write_S) {
+        DevBatch& D = b->D;
+        if (D.n_lm) hipLaunchKernelGGL(k_lm_elim, GRID(D.n_lm, 256), dim3(256), 0, st, D, O);
+        if (D.n_cl) hipLaunchKernelGGL(k_clique_elim, dim3(D.n_cl), dim3(256), 0, st, D, O);
+        if (write_S && b->max_tiles) hipLaunchKernelGGL(k_lm_gemm, dim3(b->max_tiles, D.n_win), dim3(256), 0, st, D);
+        if (D.n_pair) hipLaunchKernelGGL(k_assemble, GRID((size_t)D.n_pair * 64, 256), dim3(256), 0, st, D, O, write_S);
+    }
+    void reduced() {
+        DevBatch& D = b->D;
+        hipLaunchKernelGGL(k_chol_solve, dim3(D.n_win), dim3(1024), 0, st, D);
+    }
+    void step_rest() {
+        DevBatch& D = b->D;
+        if (D.n_lm) hipLaunchKernelGGL(k_backsub_lm, GRID(D.n_lm, 256), dim3(256), 0, st, D);
+        if (D.n_cl) hipLaunchKernelGGL(k_backsub_clique, dim3(D.n_cl), dim3(64), 0, st, D);
+        if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<0>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
+        if (D.n_gf) hipLaunchKernelGGL(k_jtimes_gen<0>, GRID((size_t)D.n_gf * 64, 256), dim3(256), 0, st, D, O);
+        hipLaunchKernelGGL(k_dogleg, dim3(D.n_win), dim3(256), 0, st, D, O);
+        if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<1>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
+        if (D.n_gf) hipLaunchKernelGGL(k_jtimes_gen<1>, GRID((size_t)D.n_gf * 64, 256), dim3(256), 0, st, D, O);
+    }
+    void cand_eval() {
+        DevBatch& D = b->D;
+        if (D.n_proj) hipLaunchKernelGGL(k_eval_proj<false>, GRID(D.n_proj, 256), dim3(256), 0, st, D);
+        if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, dim3(D.n_imu), dim3(64), 0, st, D);
+        if (D.n_sc) hipLaunchKernelGGL(k_eval_scalar<false>, GRID(D.n_sc, 256), dim3(256), 0, st, D);
+        if (D.n_prior) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
+        hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(256), 0, st, D, O);
+    }
+};
+}  // namespace
+
+extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
+    if (!b || !opt) return fail(SWF_E_INVALID, "swf_batch_solve: bad arguments");
+    if (opt->max_num_iterations < 0 || opt->max_num_iterations >= SWF_MAX_TRACE) return fail(SWF_E_INVALID, "max_num_iterations out of range");
+    DevBatch& D = b->D;
+    Launcher L{ b, to_devopt(opt), b->stream };
+    hipStream_t st = b->stream;
+    bool tm = b->timing;
+    if (tm && !b->ev_ok) { for (auto& e : b->ev) HIPCHK(hipEventCreate(&e)); b->ev_ok = true; }
+    // timing groups are accumulated with event pairs per group per iteration only when enabled
+    std::vector<std::array<hipEvent_t, 2>> spans;   // unused placeholder to keep the code simple
+    (void)spans;
+    float acc_eval = 0, acc_elim = 0, acc_red = 0;
+    auto mark = [&](int i) { if (tm) (void)hipEventRecord(b->ev[i], st); };
+    mark(0);
+    hipLaunchKernelGGL(k_init, dim3(D.n_win), dim3(256), 0, st, D, L.O);
+    int nlin = 0;
+    auto LIN = [&](int write_S) { L.lin_eval(); L.lin_elim(write_S); nlin++; };
+    LIN(1);
+    if (opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) {
+        L.reduced();
+    } else {
+        for (int it = 1; it <= opt->max_num_iterations; it++) {
+            L.reduced();
+            L.step_rest();
+            L.cand_eval();
+            LIN(it < opt->max_num_iterations ? 1 : 0);
+        }
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(D.n_win), dim3(256), 0, st, D, L.O);
+    mark(1);
+    HIPCHK(hipGetLastError());
+    b->last = swf_timing{};
+    b->last.jacobian_bytes = b->jac_bytes;
+    b->last.n_linearizations = nlin;
+    b->last_mode = opt->step_mode;
+    (void)acc_eval; (void)acc_elim; (void)acc_red;
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_sync(swf_batch* b) {
+    if (!b) return fail(SWF_E_INVALID, "null batch");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->timing && b->ev_ok) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, b->ev[0], b->ev[1]) == hipSuccess) b->last.total_ms = ms;
+    }
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_enable_timing(swf_batch* b, int32_t on) { if (!b) return fail(SWF_E_INVALID, "null batch"); b->timing = on != 0; return SWF_OK; }
+extern "C" int swf_batch_timing(swf_batch* b, swf_timing* out) { if (!b || !out) return fail(SWF_E_INVALID, "bad arguments"); *out = b->last; return SWF_OK; }
+
+extern "C" int swf_batch_download_state(swf_batch* b) {
+    if (!b) return fail(SWF_E_INVALID, "null batch");
+    std::vector<double> x((size_t)b->D.n_x);
+    HIPCHK(hipMemcpyAsync(x.data(), b->D.x, x.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (size_t i = 0; i < b->win.size(); i++) {
+        const HostWin& h = b->hw[i];
+        const double* p = x.data() + b->win[i].x_base;
+        memcpy(h.pose, p, sizeof(double) * 7 * h.n_pose); p += 7 * h.n_pose;
+        memcpy(h.sb, p, sizeof(double) * 9 * h.n_sb); p += 9 * h.n_sb;
+        memcpy(h.lm, p, sizeof(double) * 3 * h.n_lm); p += 3 * h.n_lm;
+        memcpy(h.sc, p, sizeof(double) * h.n_sc);
+    }
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_summaries(swf_batch* b, swf_summary* out) {
+    if (!b || !out) return fail(SWF_E_INVALID, "bad arguments");
+    size_t n = b->win.size();
+    std::vector<WinState> ws(n);
+    std::vector<swf_iteration> tr(n * SWF_MAX_TRACE);
+    HIPCHK(hipMemcpyAsync(ws.data(), b->D.ws, n * sizeof(WinState), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(tr.data(), b->D.trace, tr.size() * sizeof(swf_iteration), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (size_t i = 0; i < n; i++) {
+        swf_summary& s = out[i];
+        memset(&s, 0, sizeof(s));
+        s.initial_cost = ws[i].initial_cost; s.final_cost = ws[i].x_cost;
+        s.minimizer_time_in_seconds = b->last.total_ms * 1e-3;
+        s.num_successful_steps = ws[i].nsucc; s.num_unsuccessful_steps = ws[i].nunsucc;
+        s.num_iterations = ws[i].iter; s.termination = ws[i].status;
+        s.reduced_dim = b->win[i].n_red; s.tail_dim = b->hw[i].tail_dim;
+        memcpy(s.trace, tr.data() + i * SWF_MAX_TRACE, sizeof(swf_iteration) * SWF_MAX_TRACE);
+    }
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_dims(swf_batch* b, int32_t w, int32_t* n_loc, int32_t* n_e, int32_t* n_red) {
+    if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
+    if (n_loc) *n_loc = b->win[w].n_loc; if (n_e) *n_e = b->win[w].n_e; if (n_red) *n_red = b->win[w].n_red;
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, double* rhs, double* L) {
+    if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
+    if (b->last_mode < 0) return fail(SWF_E_STATE, "export before any solve");
+    const WinRec& W = b->win[w];
+    size_t n = (size_t)W.n_red;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (S) HIPCHK(hipMemcpy(S, b->D.S + W.S_base, n * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (rhs) HIPCHK(hipMemcpy(rhs, b->D.rhs + W.loc_base + W.n_e, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (L) {
+        std::vector<double> Lt((n + 1) * (n + 1));
+        HIPCHK(hipMemcpy(Lt.data(), b->D.L + W.Lt_base, Lt.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++) L[r * n + c] = (c <= r) ? Lt[c * (n + 1) + r] : 0.0;
+    }
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, double* diag, double* y) {
+    if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
+    const WinRec& W = b->win[w];
+    size_t n = (size_t)W.n_loc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (grad) HIPCHK(hipMemcpy(grad, b->D.g + W.loc_base, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (diag) HIPCHK(hipMemcpy(diag, b->D.diag + W.loc_base, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (y) HIPCHK(hipMemcpy(y, b->D.y + W.loc_base, n * sizeof(double), hipMemcpyDeviceToHost));
+    return SWF_OK;
+}

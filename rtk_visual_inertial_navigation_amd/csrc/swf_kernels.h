@@ -1,0 +1,770 @@
+// swf_kernels.h — HIP kernels of the sliding-window Gauss-Newton hot path (gfx950).
+//
+// Phase list of one trust-region iteration (all windows of the batch at once; every kernel
+// early-exits for windows whose device-side status says "nothing to do"):
+//
+//   LIN   k_eval_proj<1> k_eval_imu<1> k_eval_scalar<1> k_eval_prior<1>   r, J, cost per factor
+//         k_lm_elim  k_clique_elim                                        group-0 elimination
+//         k_lm_gemm                                                        P = Y W^T (landmark Schur)
+//         k_assemble                                                       S, rhs, g, diag (owner-computes)
+//   STEP  k_chol_solve                                                     S = L L^T, y_f
+//         k_backsub_lm  k_backsub_clique                                   y_e
+//         k_jtimes_proj<0> k_jtimes_gen<0>                                 |J D^-2 g|^2 (Cauchy point)
+//         k_dogleg                                                         step, candidate = Plus(x, step)
+//         k_jtimes_*<1>  k_eval_*<0>                                       model decrease, candidate cost
+//         k_decide                                                         accept / reject, radius, convergence
+//
+// Factor math follows the reference sources cited at each kernel (R/ =
+// /root/reference/rtk_visual_inertial_src/rtk_visual_inertial/src/).
+#pragma once
+#include "swf_dev.h"
+
+struct DevOpt {
+    int max_iter, step_mode;
+    double r0, max_r, min_r, min_rel_dec, ftol, gtol, ptol, min_mu, max_mu, mu_inc, min_diag, max_diag;
+};
+
+#define CLIGHT_D 299792458.0
+#define OMGE_D 7.2921151467E-5
+
+// =========================================================================================
+// projection_factor::Evaluate (R/factor/projection_factor.cpp:13-65) + CauchyLoss corrector
+// (R/factor/marginalization_factor.cpp:23-45).  One lane per observation; SoA outputs so
+// that every store instruction of a wave is one contiguous 512-byte run.
+// =========================================================================================
+template <bool JAC>
+__global__ void __launch_bounds__(256) k_eval_proj(DevBatch B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n_proj) return;
+    int w = B.p_win[i];
+    const WinState& s = B.ws[w];
+    if (JAC ? !s.need_lin : !s.eval_cand) return;
+    const WinRec& W = B.win[w];
+    const double* xs = JAC ? B.x : B.xc;
+    const double* pose = xs + B.p_xpose[i];
+    const double* ex = xs + B.p_xex[i];
+    const double* lm = xs + B.p_xlm[i];
+    double P[7], E[7], X[3];
+#pragma unroll
+    for (int k = 0; k < 7; k++) { P[k] = pose[k]; E[k] = ex[k]; }
+    X[0] = lm[0]; X[1] = lm[1]; X[2] = lm[2];
+    double Qj_inv[4], qic_inv[4], d[3], pts_imu[3], t[3], pc[3];
+    qinv(P + 3, Qj_inv);
+    qinv(E + 3, qic_inv);
+    d[0] = X[0] - P[0]; d[1] = X[1] - P[1]; d[2] = X[2] - P[2];
+    qrot(Qj_inv, d, pts_imu);
+    t[0] = pts_imu[0] + W.pbg[0] - E[0]; t[1] = pts_imu[1] + W.pbg[1] - E[1]; t[2] = pts_imu[2] + W.pbg[2] - E[2];
+    qrot(qic_inv, t, pc);
+    double dep = pc[2], si = W.proj_sqrt_info;
+    double r0 = si * (pc[0] / dep - B.p_uv[2 * i]);
+    double r1 = si * (pc[1] / dep - B.p_uv[2 * i + 1]);
+    // Cauchy: rho'' < 0 always => scale r and J by sqrt(rho'); block cost = 0.5 rho(s)
+    double sr = 1.0, cost;
+    double sq = r0 * r0 + r1 * r1;
+    if (W.proj_loss_a > 0) {
+        double b = W.proj_loss_a * W.proj_loss_a, c = 1.0 / b;
+        double sum = 1.0 + sq * c, inv = 1.0 / sum;
+        cost = 0.5 * b * log(sum);
+        sr = sqrt(inv > 2.2250738585072014e-308 ? inv : 2.2250738585072014e-308);
+    } else cost = 0.5 * sq;
+    B.p_cost[i] = cost;
+    if (!JAC) return;
+    int n = B.n_proj;
+    B.p_r[i] = r0 * sr; B.p_r[n + i] = r1 * sr;
+    bool jp = B.p_lpose[i] >= 0, jl = B.p_llm[i] >= 0;
+    if (!jp && !jl) return;
+    double Rj[9], ric[9], ricT[9], RjT[9], A[9];
+    q2R(P + 3, Rj); q2R(E + 3, ric);
+    mat3T(ric, ricT); mat3T(Rj, RjT);
+    double red[6] = { si * (1. / dep), 0, si * (-pc[0] / (dep * dep)), 0, si * (1. / dep), si * (-pc[1] / (dep * dep)) };
+    mat3mul(ricT, RjT, A);
+    if (jp) {
+        double S[9], Bm[9];
+        skew3(pts_imu, S);
+        mat3mul(ricT, S, Bm);
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double u = 0, v = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { u += red[a * 3 + k] * -A[k * 3 + j]; v += red[a * 3 + k] * Bm[k * 3 + j]; }
+                B.p_Jp[(a * 6 + j) * n + i] = u * sr;
+                B.p_Jp[(a * 6 + 3 + j) * n + i] = v * sr;
+            }
+    }
+    if (jl) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double u = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) u += red[a * 3 + k] * A[k * 3 + j];
+                B.p_Jl[(a * 3 + j) * n + i] = u * sr;
+            }
+    }
+}
+
+// =========================================================================================
+// IMUFactor::Evaluate (R/factor/imu_factor.cpp:5-101) on IntegrationBase::evaluate
+// (R/factor/integration_base.cpp:144-174).  One wavefront per factor: lane 0 builds the
+// un-whitened residual and the sparse 15x30 Jacobian in LDS, all 64 lanes apply the 15x15
+// sqrt-information (the 6.7k-MAC part) and write the whitened blocks row-major.
+// =========================================================================================
+__device__ void imu_unwhitened(const double* pi, const double* sbi, const double* pj, const double* sbj,
+                               const double* pre, const double* pbg, const double* gw,
+                               double* raw, double* U, bool jac) {
+    const double* Pi = pi; const double* Qi = pi + 3;
+    const double* Vi = sbi; const double* Bai = sbi + 3; const double* Bgi = sbi + 6;
+    const double* Pj = pj; const double* Qj = pj + 3;
+    const double* Vj = sbj; const double* Baj = sbj + 3; const double* Bgj = sbj + 6;
+    const double* dp = pre + SWF_PRE_DP; const double* dq = pre + SWF_PRE_DQ; const double* dv = pre + SWF_PRE_DV;
+    const double* lba = pre + SWF_PRE_LBA; const double* lbg = pre + SWF_PRE_LBG;
+    const double* dp_dba = pre + SWF_PRE_DP_DBA; const double* dp_dbg = pre + SWF_PRE_DP_DBG;
+    const double* dq_dbg = pre + SWF_PRE_DQ_DBG; const double* dv_dba = pre + SWF_PRE_DV_DBA;
+    const double* dv_dbg = pre + SWF_PRE_DV_DBG;
+    double T = pre[SWF_PRE_SUMDT];
+    const double* gyri = pre + SWF_PRE_GYRI; const double* gyrj = pre + SWF_PRE_GYRJ;
+    double dba[3], dbg[3], th[3], dqc[4], cq[4], cv[3], cp[3], t1[3], t2[3];
+    for (int k = 0; k < 3; k++) { dba[k] = Bai[k] - lba[k]; dbg[k] = Bgi[k] - lbg[k]; }
+    mat3vec(dq_dbg, dbg, th);
+    dqc[0] = th[0] / 2; dqc[1] = th[1] / 2; dqc[2] = th[2] / 2; dqc[3] = 1.0;
+    qmul(dq, dqc, cq);
+    mat3vec(dv_dba, dba, t1); mat3vec(dv_dbg, dbg, t2);
+    for (int k = 0; k < 3; k++) cv[k] = dv[k] + t1[k] + t2[k];
+    mat3vec(dp_dba, dba, t1); mat3vec(dp_dbg, dbg, t2);
+    for (int k = 0; k < 3; k++) cp[k] = dp[k] + t1[k] + t2[k];
+    double Qi_inv[4], QjPbg[3], wi[3], wj[3], wiPbg[3], wjPbg[3], QjwjPbg[3];
+    qinv(Qi, Qi_inv);
+    qrot(Qj, pbg, QjPbg);
+    for (int k = 0; k < 3; k++) { wi[k] = gyri[k] - Bgi[k]; wj[k] = gyrj[k] - Bgj[k]; }
+    cross3(wi, pbg, wiPbg);
+    cross3(wj, pbg, wjPbg);
+    qrot(Qj, wjPbg, QjwjPbg);
+    double ap[3], av[3], rp[3], rv[3];
+    for (int k = 0; k < 3; k++) {
+        ap[k] = 0.5 * gw[k] * T * T + ((Pj[k] - Pi[k]) - QjPbg[k]) - Vi[k] * T;
+        av[k] = gw[k] * T + (Vj[k] - QjwjPbg[k]) - Vi[k];
+    }
+    qrot(Qi_inv, ap, rp);
+    qrot(Qi_inv, av, rv);
+    for (int k = 0; k < 3; k++) {
+        raw[0 + k] = rp[k] - cp[k] + pbg[k] + wiPbg[k] * T;
+        raw[6 + k] = rv[k] - cv[k] + wiPbg[k];
+        raw[9 + k] = Baj[k] - Bai[k];
+        raw[12 + k] = Bgj[k] - Bgi[k];
+    }
+    double cq_inv[4], qij[4], e[4];
+    qinv(cq, cq_inv);
+    qmul(Qi_inv, Qj, qij);
+    qmul(cq_inv, qij, e);
+    raw[3] = 2 * e[0]; raw[4] = 2 * e[1]; raw[5] = 2 * e[2];
+    if (!jac) return;
+    // U: 15 x 30 row-major, columns [pose_i(6) | sb_i(9) | pose_j(6) | sb_j(9)]
+    for (int k = 0; k < 15 * 30; k++) U[k] = 0.0;
+    double Ri_inv[9], Rj[9], M[9], S[9], N[9], tmpq[4], tmpq2[4], Qj_inv[4], Spbg[9], RiRj[9];
+    q2R(Qi_inv, Ri_inv);
+    q2R(Qj, Rj);
+    qinv(Qj, Qj_inv);
+    skew3(pbg, Spbg);
+    mat3mul(Ri_inv, Rj, RiRj);
+#define SETU(R0, C0, MAT, SGN) for (int i_ = 0; i_ < 3; i_++) for (int j_ = 0; j_ < 3; j_++) U[(R0 + i_) * 30 + C0 + j_] = SGN * MAT[i_ * 3 + j_];
+    // d/d pose_i
+    SETU(0, 0, Ri_inv, -1.0)
+    skew3(rp, S); SETU(0, 3, S, 1.0)
+    qmul(Qj_inv, Qi, tmpq);
+    qleft_qright_br(tmpq, cq, M); SETU(3, 3, M, -1.0)
+    skew3(rv, S); SETU(6, 3, S, 1.0)
+    // d/d sb_i  (columns 6..14)
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        U[(0 + i) * 30 + 6 + j] = -Ri_inv[i * 3 + j] * T;
+        U[(0 + i) * 30 + 9 + j] = -dp_dba[i * 3 + j];
+        U[(0 + i) * 30 + 12 + j] = -dp_dbg[i * 3 + j] + Spbg[i * 3 + j] * T;
+        U[(6 + i) * 30 + 6 + j] = -Ri_inv[i * 3 + j];
+        U[(6 + i) * 30 + 9 + j] = -dv_dba[i * 3 + j];
+        U[(6 + i) * 30 + 12 + j] = -dv_dbg[i * 3 + j] + Spbg[i * 3 + j];
+    }
+    qmul(tmpq, dq, tmpq2);
+    qleft_br(tmpq2, M);
+    mat3mul(M, dq_dbg, N); SETU(3, 12, N, -1.0)
+    for (int k = 0; k < 3; k++) { U[(9 + k) * 30 + 9 + k] = -1.0; U[(12 + k) * 30 + 12 + k] = -1.0; }
+    // d/d pose_j (columns 15..20)
+    SETU(0, 15, Ri_inv, 1.0)
+    mat3mul(RiRj, Spbg, N); SETU(0, 18, N, 1.0)
+    qmul(cq_inv, Qi_inv, tmpq);
+    qmul(tmpq, Qj, tmpq2);
+    qleft_br(tmpq2, M); SETU(3, 18, M, 1.0)
+    skew3(wjPbg, S);
+    mat3mul(RiRj, S, N); SETU(6, 18, N, 1.0)
+    // d/d sb_j (columns 21..29)
+    SETU(6, 21, Ri_inv, 1.0)
+    mat3mul(RiRj, Spbg, N); SETU(6, 27, N, -1.0)
+    for (int k = 0; k < 3; k++) { U[(9 + k) * 30 + 24 + k] = 1.0; U[(12 + k) * 30 + 27 + k] = 1.0; }
+#undef SETU
+}
+
+template <bool JAC>
+__global__ void __launch_bounds__(64) k_eval_imu(DevBatch B) {
+    __shared__ double SI[225];
+    __shared__ double U[450];
+    __shared__ double raw[16];
+    __shared__ double st[32];
+    int q = blockIdx.x;
+    if (q >= B.n_imu) return;
+    int f = B.imu_gf[q];
+    const GFac& G = B.gf[f];
+    const WinState& s = B.ws[G.win];
+    if (JAC ? !s.need_lin : !s.eval_cand) return;
+    const WinRec& W = B.win[G.win];
+    const double* xs = JAC ? B.x : B.xc;
+    const double* pre = B.imu_pre + (size_t)G.data * SWF_PRE_DOUBLES;
+    int lane = threadIdx.x;
+    for (int k = lane; k < 225; k += 64) SI[k] = pre[SWF_PRE_SQRTINFO + k];
+    // stage the 32 parameter doubles in LDS (pose_i, sb_i, pose_j, sb_j)
+    if (lane < 32) {
+        int sl = lane < 7 ? 0 : lane < 16 ? 1 : lane < 23 ? 2 : 3;
+        int o = lane < 7 ? lane : lane < 16 ? lane - 7 : lane < 23 ? lane - 16 : lane - 23;
+        st[lane] = xs[B.s_x[G.slot0 + sl] + o];
+    }
+    __syncthreads();
+    if (lane == 0) imu_unwhitened(st, st + 7, st + 16, st + 23, pre, W.pbg, W.gw, raw, U, JAC);
+    __syncthreads();
+    // whitened residual
+    double rk = 0;
+    if (lane < 15) {
+        for (int k = 0; k < 15; k++) rk += SI[lane * 15 + k] * raw[k];
+        if (JAC) B.g_r[G.roff + lane] = rk;
+    }
+    double c = wave_sum(lane < 15 ? rk * rk : 0.0);
+    if (lane == 0) B.g_cost[f] = 0.5 * c;
+    if (!JAC) return;
+    // whitened Jacobian blocks, row-major 15 x ls at s_joff
+    const int cb[4] = { 0, 6, 15, 21 }, ls[4] = { 6, 9, 6, 9 };
+    for (int e = lane; e < 450; e += 64) {
+        int row = e / 30, col = e % 30;
+        int sl = col < 6 ? 0 : col < 15 ? 1 : col < 21 ? 2 : 3;
+        int jo = B.s_joff[G.slot0 + sl];
+        if (jo < 0) continue;
+        double a = 0;
+        for (int k = row; k < 15; k++) a += SI[row * 15 + k] * U[k * 30 + col];   // SI is upper triangular
+        B.g_J[jo + row * ls[sl] + (col - cb[sl])] = a;
+    }
+}
+
+// =========================================================================================
+// scalar factors, one lane each:
+//   RTKCarrierPhaseFactor  R/factor/gnss_factor.cpp:105-138     RTKPseudorangeFactor :140-168
+//   SppDopplerFactor       :174-212 (+ velecitydistance, R/gnss/src/common_function.cpp:411-421)
+//   InitialBlackFactor     R/factor/initial_factor.cpp:81-87
+//   distance() R/gnss/src/common_function.cpp:126-134 ; varerr2() gnss_factor.cpp:98-103 (sinf!)
+// =========================================================================================
+__device__ __forceinline__ double gnss_distance(const double* rr, const double* rs, double* e) {
+    e[0] = rr[0] - rs[0]; e[1] = rr[1] - rs[1]; e[2] = rr[2] - rs[2];
+    double r = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    e[0] /= r; e[1] /= r; e[2] /= r;
+    return r + OMGE_D * (rs[0] * rr[1] - rs[1] * rr[0]) / CLIGHT_D;
+}
+__device__ __forceinline__ double varerr2(double el, double dt, double mea_var) {
+    double b = CLIGHT_D * 5e-12 * dt;
+    double sinel = (double)sinf((float)el);
+    return (mea_var / sinel / sinel) + b * b;
+}
+template <bool JAC>
+__global__ void __launch_bounds__(256) k_eval_scalar(DevBatch B) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= B.n_sc) return;
+    int f = B.sc_gf[q];
+    const GFac& G = B.gf[f];
+    const WinState& s = B.ws[G.win];
+    if (JAC ? !s.need_lin : !s.eval_cand) return;
+    const WinRec& W = B.win[G.win];
+    const double* xs = JAC ? B.x : B.xc;
+    int s0 = G.slot0;
+    double r;
+    if (G.type == GF_CP) {
+        const double* dat = B.cp_dat + (size_t)G.data * SWF_CP_DOUBLES;
+        const double* pose = xs + B.s_x[s0];
+        double amb = xs[B.s_x[s0 + 1]], clk = xs[B.s_x[s0 + 2]];
+        double xg[3] = { pose[0] + W.base[0], pose[1] + W.base[1], pose[2] + W.base[2] }, e[3];
+        double r1 = gnss_distance(xg, dat, e);
+        double wgt = 1.0;
+        if (dat[8] != 0.0) wgt = 1 / sqrt(varerr2(dat[5], dat[6], dat[7]));
+        r = wgt * (r1 - amb * dat[4] - dat[3] + clk);
+        if (JAC) {
+            int jo = B.s_joff[s0];
+            if (jo >= 0) { B.g_J[jo] = wgt * e[0]; B.g_J[jo + 1] = wgt * e[1]; B.g_J[jo + 2] = wgt * e[2]; B.g_J[jo + 3] = 0; B.g_J[jo + 4] = 0; B.g_J[jo + 5] = 0; }
+            jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = -wgt * dat[4];
+            jo = B.s_joff[s0 + 2]; if (jo >= 0) B.g_J[jo] = wgt;
+        }
+    } else if (G.type == GF_PR) {
+        const double* dat = B.pr_dat + (size_t)G.data * SWF_PR_DOUBLES;
+        const double* pose = xs + B.s_x[s0];
+        double clk = xs[B.s_x[s0 + 1]];
+        double xg[3] = { pose[0] + W.base[0], pose[1] + W.base[1], pose[2] + W.base[2] }, e[3];
+        double r1 = gnss_distance(xg, dat, e);
+        double wgt = 1 / sqrt(varerr2(dat[4], dat[5], dat[6]));
+        r = wgt * (r1 - dat[3] + clk);
+        if (JAC) {
+            int jo = B.s_joff[s0];
+            if (jo >= 0) { B.g_J[jo] = wgt * e[0]; B.g_J[jo + 1] = wgt * e[1]; B.g_J[jo + 2] = wgt * e[2]; B.g_J[jo + 3] = 0; B.g_J[jo + 4] = 0; B.g_J[jo + 5] = 0; }
+            jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = wgt;
+        }
+    } else if (G.type == GF_DOP) {
+        const double* dat = B.dop_dat + (size_t)G.data * SWF_DOP_DOUBLES;
+        const double* sb = xs + B.s_x[s0];
+        double drift = xs[B.s_x[s0 + 1]];
+        const double* pose = xs + B.s_x[s0 + 2];
+        const double* rs = dat; const double* vs = dat + 3;
+        double xg[3] = { pose[0] + W.base[0], pose[1] + W.base[1], pose[2] + W.base[2] }, e[3], ev[3];
+        e[0] = xg[0] - rs[0]; e[1] = xg[1] - rs[1]; e[2] = xg[2] - rs[2];
+        double rr = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        for (int k = 0; k < 3; k++) { e[k] /= rr; ev[k] = sb[k] - vs[k]; }
+        double ee = ev[0] * e[0] + ev[1] * e[1] + ev[2] * e[2];
+        double rate = ee + OMGE_D / CLIGHT_D * (vs[1] * xg[0] + rs[1] * sb[0] - vs[0] * xg[1] - rs[0] * sb[1]);
+        double istd = dat[7];
+        r = istd * (rate + drift + dat[6]);
+        if (JAC) {
+            int jo = B.s_joff[s0];
+            if (jo >= 0) { for (int k = 0; k < 9; k++) B.g_J[jo + k] = 0; B.g_J[jo] = istd * e[0]; B.g_J[jo + 1] = istd * e[1]; B.g_J[jo + 2] = istd * e[2]; }
+            jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = istd;
+            jo = B.s_joff[s0 + 2];
+            if (jo >= 0) { for (int k = 0; k < 3; k++) { B.g_J[jo + k] = istd * (ev[k] - ee * e[k]) / rr; B.g_J[jo + 3 + k] = 0; } }
+        }
+    } else {   // GF_SP
+        double wv = B.sp_w[G.data];
+        r = wv * xs[B.s_x[s0]];
+        if (JAC) { int jo = B.s_joff[s0]; if (jo >= 0) B.g_J[jo] = wv; }
+    }
+    B.g_cost[f] = 0.5 * r * r;
+    if (JAC) B.g_r[G.roff] = r;
+}
+
+// =========================================================================================
+// MarginalizationFactor::Evaluate (R/factor/marginalization_factor.cpp:410-446).
+// r = r0 + J dx; the Jacobian is the constant J, so its J^T J (the prior clique's C) was
+// formed once at upload; per evaluation only r and J^T r are produced.  One workgroup/prior.
+// =========================================================================================
+__device__ __forceinline__ void prior_block_dx(const double* x, const double* x0, int gs, double* dx) {
+    if (gs != 7) { for (int k = 0; k < gs; k++) dx[k] = x[k] - x0[k]; return; }
+    dx[0] = x[0] - x0[0]; dx[1] = x[1] - x0[1]; dx[2] = x[2] - x0[2];
+    double q0i[4], dq[4];
+    qinv(x0 + 3, q0i);
+    qmul(q0i, x + 3, dq);
+    double sg = (dq[3] >= 0) ? 2.0 : -2.0;
+    dx[3] = sg * dq[0]; dx[4] = sg * dq[1]; dx[5] = sg * dq[2];
+}
+template <bool JAC>
+__global__ void __launch_bounds__(256) k_eval_prior(DevBatch B) {
+    extern __shared__ double sm[];      // dx[n] | r[n] | red[16]
+    int q = blockIdx.x;
+    if (q >= B.n_prior) return;
+    int f = B.prior_gf[q];
+    const GFac& G = B.gf[f];
+    const WinState& s = B.ws[G.win];
+    if (JAC ? !s.need_lin : !s.eval_cand) return;
+    const double* xs = JAC ? B.x : B.xc;
+    int k = G.data, n = G.nres;
+    double* dx = sm; double* rr = sm + n; double* red = sm + 2 * n;
+    const double* Jp = B.prior_J + B.prior_Joff[k];
+    const double* r0 = B.prior_r0 + B.prior_roff[k];
+    const double* x0 = B.prior_x0 + B.prior_x0off[k];
+    // one thread per kept block computes its dx segment (x0 offsets are prefix sums of sizes)
+    for (int sl = threadIdx.x; sl < G.nslot; sl += blockDim.x) {
+        int col = 0, xo = 0;
+        for (int t = 0; t < sl; t++) { int l = B.s_ls[G.slot0 + t]; col += l; xo += (l == 6 ? 7 : l); }
+        int l = B.s_ls[G.slot0 + sl];
+        double tmp[9];
+        prior_block_dx(xs + B.s_x[G.slot0 + sl], x0 + xo, l == 6 ? 7 : l, tmp);
+        for (int j = 0; j < l; j++) dx[col + j] = tmp[j];
+    }
+    __syncthreads();
+    double part = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double a = r0[i];
+        const double* row = Jp + (size_t)i * n;
+        for (int j = 0; j < n; j++) a += row[j] * dx[j];
+        rr[i] = a; part += a * a;
+        if (JAC) B.g_r[G.roff + i] = a;
+    }
+    double tot = block_sum(part, red);
+    if (threadIdx.x == 0) B.g_cost[f] = 0.5 * tot;
+    if (!JAC) return;
+    // graw = J^T r into the prior clique's vector slot (members are the kept blocks in order)
+    const Clique& C = B.cl[G.clique];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double a = 0;
+        for (int i = 0; i < n; i++) a += Jp[(size_t)i * n + j] * rr[i];
+        // column j of the prior -> member column (constant blocks are not members)
+        int col = 0, m = -1, within = 0;
+        for (int t = 0; t < G.nslot; t++) { int l = B.s_ls[G.slot0 + t]; if (j < col + l) { m = t; within = j - col; break; } col += l; }
+        int cc = B.s_ccol[G.slot0 + m];
+        if (cc >= 0) B.cv_graw[C.v_off + cc + within] = a;
+    }
+}
+
+// =========================================================================================
+// J * v per factor.  MODE 0: v = D^-2 g (Cauchy point, DoglegStrategy::ComputeCauchyPoint),
+// aux = |J v|^2.  MODE 1: v = step, aux = (Jv).(r + Jv/2) (model cost change,
+// TrustRegionMinimizer::ComputeTrustRegionStep).
+// =========================================================================================
+template <int MODE>
+__device__ __forceinline__ double vec_at(const DevBatch& B, const DevOpt& O, int loc) {
+    if (MODE == 1) return B.step[loc];
+    return B.g[loc] / clampd(B.diag[loc], O.min_diag, O.max_diag);
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_jtimes_proj(DevBatch B, DevOpt O) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n_proj) return;
+    const WinState& s = B.ws[B.p_win[i]];
+    if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;
+    int n = B.n_proj, lp = B.p_lpose[i], ll = B.p_llm[i];
+    double a0 = 0, a1 = 0;
+    if (lp >= 0) for (int j = 0; j < 6; j++) { double v = vec_at<MODE>(B, O, lp + j); a0 += B.p_Jp[j * n + i] * v; a1 += B.p_Jp[(6 + j) * n + i] * v; }
+    if (ll >= 0) for (int j = 0; j < 3; j++) { double v = vec_at<MODE>(B, O, ll + j); a0 += B.p_Jl[j * n + i] * v; a1 += B.p_Jl[(3 + j) * n + i] * v; }
+    if (MODE == 0) B.p_aux[i] = a0 * a0 + a1 * a1;
+    else B.p_aux[i] = a0 * (B.p_r[i] + a0 / 2.0) + a1 * (B.p_r[n + i] + a1 / 2.0);
+}
+// one wavefront per generic factor; lanes over residual rows
+template <int MODE>
+__global__ void __launch_bounds__(256) k_jtimes_gen(DevBatch B, DevOpt O) {
+    int f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (f >= B.n_gf) return;
+    const GFac& G = B.gf[f];
+    const WinState& s = B.ws[G.win];
+    if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;
+    double part = 0;
+    for (int k = lane; k < G.nres; k += 64) {
+        double a = 0;
+        if (G.type == GF_PRIOR) {
+            const double* row = B.prior_J + B.prior_Joff[G.data] + (size_t)k * G.nres;
+            int col = 0;
+            for (int t = 0; t < G.nslot; t++) {
+                int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
+                if (lo >= 0) for (int j = 0; j < l; j++) a += row[col + j] * vec_at<MODE>(B, O, lo + j);
+                col += l;
+            }
+        } else {
+            for (int t = 0; t < G.nslot; t++) {
+                int jo = B.s_joff[G.slot0 + t];
+                if (jo < 0) continue;
+                int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
+                const double* row = B.g_J + jo + k * l;
+                for (int j = 0; j < l; j++) a += row[j] * vec_at<MODE>(B, O, lo + j);
+            }
+        }
+        if (MODE == 0) part += a * a;
+        else part += a * (B.g_r[G.roff + k] + a / 2.0);
+    }
+    part = wave_sum(part);
+    if (lane == 0) B.g_aux[f] = part;
+}
+
+// =========================================================================================
+// Landmark elimination (the bulk of group 0): one lane per landmark.
+//   H_ll = sum Jl^T Jl + mu*clamp(diag),  Einv = H_ll^-1,  W_o = Jp^T Jl,  Y_o = W_o Einv
+// Y/W are scattered into landmark-column-major [3 nL][6 nF] slabs whose zero pattern is
+// static, so the reduced-camera Schur term is the plain product P = Yt^T Wt (k_lm_gemm).
+// In-tree analogue of this arithmetic: MarginalizationInfo::marginalize,
+// R/factor/marginalization_factor.cpp:260-377; in Ceres it is SchurEliminator::Eliminate.
+// =========================================================================================
+__global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
+    int L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= B.n_lm) return;
+    int w = B.lm_win[L];
+    WinState& s = B.ws[w];
+    if (!s.need_lin) return;
+    int loc = B.lm_loc[L];
+    if (loc < 0) return;
+    const WinRec& W = B.win[w];
+    int n = B.n_proj, o0 = B.lm_obs0[L], o1 = B.lm_obs0[L + 1];
+    double h00 = 0, h10 = 0, h20 = 0, h11 = 0, h21 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
+    for (int o = o0; o < o1; o++) {
+        double a0 = B.p_Jl[0 * n + o], a1 = B.p_Jl[1 * n + o], a2 = B.p_Jl[2 * n + o];
+        double b0 = B.p_Jl[3 * n + o], b1 = B.p_Jl[4 * n + o], b2 = B.p_Jl[5 * n + o];
+        double r0 = B.p_r[o], r1 = B.p_r[n + o];
+        h00 += a0 * a0 + b0 * b0; h10 += a1 * a0 + b1 * b0; h20 += a2 * a0 + b2 * b0;
+        h11 += a1 * a1 + b1 * b1; h21 += a2 * a1 + b2 * b1; h22 += a2 * a2 + b2 * b2;
+        g0 += a0 * r0 + b0 * r1; g1 += a1 * r0 + b1 * r1; g2 += a2 * r0 + b2 * r1;
+    }
+    B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
+    B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
+    double mu = s.mu;
+    h00 += mu * clampd(h00, O.min_diag, O.max_diag);
+    h11 += mu * clampd(h11, O.min_diag, O.max_diag);
+    h22 += mu * clampd(h22, O.min_diag, O.max_diag);
+    // Cholesky inverse of the 3x3 (ceres InvertPSDMatrix)
+    double l00 = sqrt(h00), l10 = h10 / l00, l20 = h20 / l00;
+    double d11 = h11 - l10 * l10;
+    double l11 = sqrt(d11), l21 = (h21 - l20 * l10) / l11;
+    double d22 = h22 - l20 * l20 - l21 * l21;
+    double l22 = sqrt(d22);
+    if (!(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0)) { s.lin_fail = 1; return; }
+    double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    double i10 = -l10 * i00 * i11;
+    double i21 = -l21 * i11 * i22;
+    double i20 = -(l20 * i00 + l21 * i10) * i22;
+    // Einv = Linv^T Linv
+    double e00 = i00 * i00 + i10 * i10 + i20 * i20, e10 = i10 * i11 + i20 * i21, e20 = i20 * i22;
+    double e11 = i11 * i11 + i21 * i21, e21 = i21 * i22, e22 = i22 * i22;
+    int nl = B.n_lm;
+    B.lm_Einv[0 * nl + L] = e00; B.lm_Einv[1 * nl + L] = e10; B.lm_Einv[2 * nl + L] = e20;
+    B.lm_Einv[3 * nl + L] = e11; B.lm_Einv[4 * nl + L] = e21; B.lm_Einv[5 * nl + L] = e22;
+    B.lm_g[0 * nl + L] = g0; B.lm_g[1 * nl + L] = g1; B.lm_g[2 * nl + L] = g2;
+    int ld = 6 * W.nF, col = B.lm_col[L];
+    double* Yt = B.Yt + W.YW_base; double* Wt = B.Wt + W.YW_base;
+    for (int o = o0; o < o1; o++) {
+        int f = B.p_fr[o];
+        if (f < 0) continue;
+        double a0 = B.p_Jl[0 * n + o], a1 = B.p_Jl[1 * n + o], a2 = B.p_Jl[2 * n + o];
+        double b0 = B.p_Jl[3 * n + o], b1 = B.p_Jl[4 * n + o], b2 = B.p_Jl[5 * n + o];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double pa = B.p_Jp[i * n + o], pb = B.p_Jp[(6 + i) * n + o];
+            double w0 = pa * a0 + pb * b0, w1 = pa * a1 + pb * b1, w2 = pa * a2 + pb * b2;
+            size_t base = (size_t)col * ld + 6 * f + i;
+            Wt[base] = w0; Wt[base + ld] = w1; Wt[base + 2 * ld] = w2;
+            Yt[base] = w0 * e00 + w1 * e10 + w2 * e20;
+            Yt[base + ld] = w0 * e10 + w1 * e11 + w2 * e21;
+            Yt[base + 2 * ld] = w0 * e20 + w1 * e21 + w2 * e22;
+        }
+    }
+}
+
+// =========================================================================================
+// Clique elimination: every group-0 block that is not a landmark (alternate speed-biases,
+// receiver clocks, the dummy) together with the factors touching it, and every group of
+// factors that touches no group-0 block.  One workgroup per clique builds the small dense
+// J^T J over [e | members] in LDS, eliminates e, and leaves
+//   C = M_ff - M_fe Einv M_ef,  graw = J_f^T r,  dgraw = diag(M_ff),  cs = -M_fe Einv g_e
+// for k_assemble, plus Einv / M_ef / g_e for the back-substitution.
+// =========================================================================================
+#define CLQ_MAXD 64
+__global__ void __launch_bounds__(256) k_clique_elim(DevBatch B, DevOpt O) {
+    __shared__ double M[CLQ_MAXD * CLQ_MAXD];
+    __shared__ double gv[CLQ_MAXD];
+    __shared__ double Ei[81];
+    __shared__ double T[9 * CLQ_MAXD];
+    __shared__ double Eg[9];
+    __shared__ int fail;
+    int c = blockIdx.x;
+    if (c >= B.n_cl) return;
+    const Clique& C = B.cl[c];
+    if (C.is_static) return;
+    WinState& s = B.ws[C.win];
+    if (!s.need_lin) return;
+    int de = C.d_e, df = C.d_f, d = de + df, tid = threadIdx.x;
+    for (int e = tid; e < d * d; e += blockDim.x) M[e] = 0;
+    if (tid < d) gv[tid] = 0;
+    if (tid == 0) fail = 0;
+    __syncthreads();
+    for (int q = C.fac0; q < C.fac1; q++) {
+        const GFac& G = B.gf[B.cl_fac[q]];
+        for (int sa = 0; sa < G.nslot; sa++) {
+            int ca = B.s_ccol[G.slot0 + sa];
+            if (ca < 0) continue;
+            int la = B.s_ls[G.slot0 + sa];
+            const double* Ja = B.g_J + B.s_joff[G.slot0 + sa];
+            for (int sb = 0; sb < G.nslot; sb++) {
+                int cb = B.s_ccol[G.slot0 + sb];
+                if (cb < 0) continue;
+                int lb = B.s_ls[G.slot0 + sb];
+                const double* Jb = B.g_J + B.s_joff[G.slot0 + sb];
+                for (int e = tid; e < la * lb; e += blockDim.x) {
+                    int i = e / lb, j = e % lb;
+                    double a = 0;
+                    for (int k = 0; k < G.nres; k++) a += Ja[k * la + i] * Jb[k * lb + j];
+                    M[(ca + i) * d + cb + j] += a;
+                }
+            }
+            if (tid < la) {
+                double a = 0;
+                for (int k = 0; k < G.nres; k++) a += Ja[k * la + tid] * B.g_r[G.roff + k];
+                gv[ca + tid] += a;
+            }
+        }
+        __syncthreads();
+    }
+    // raw gradient / diagonal
+    if (tid < de) { B.g[C.e_loc + tid] = gv[tid]; B.diag[C.e_loc + tid] = M[tid * d + tid]; }
+    if (tid >= de && tid < d) { B.cv_graw[C.v_off + tid - de] = gv[tid]; B.cv_dgraw[C.v_off + tid - de] = M[tid * d + tid]; }
+    __syncthreads();
+    if (de > 0) {
+        if (tid < de) M[tid * d + tid] += s.mu * clampd(M[tid * d + tid], O.min_diag, O.max_diag);
+        __syncthreads();
+        if (tid == 0) {
+            // Cholesky inverse of M_ee (de <= 9)
+            double Lc[81];
+            for (int i = 0; i < de; i++) for (int j = 0; j <= i; j++) Lc[i * de + j] = M[i * d + j];
+            for (int j = 0; j < de; j++) {
+                double dd = Lc[j * de + j];
+                for (int k = 0; k < j; k++) dd -= Lc[j * de + k] * Lc[j * de + k];
+                if (!(dd > 0.0)) { fail = 1; break; }
+                dd = sqrt(dd); Lc[j * de + j] = dd;
+                for (int i = j + 1; i < de; i++) {
+                    double sv = Lc[i * de + j];
+                    for (int k = 0; k < j; k++) sv -= Lc[i * de + k] * Lc[j * de + k];
+                    Lc[i * de + j] = sv / dd;
+                }
+            }
+            if (!fail) {
+                for (int col = 0; col < de; col++) {
+                    double ev[9];
+                    for (int i = 0; i < de; i++) {
+                        double sv = (i == col) ? 1.0 : 0.0;
+                        for (int k = 0; k < i; k++) sv -= Lc[i * de + k] * ev[k];
+                        ev[i] = sv / Lc[i * de + i];
+                    }
+                    for (int i = de - 1; i >= 0; i--) {
+                        double sv = ev[i];
+                        for (int k = i + 1; k < de; k++) sv -= Lc[k * de + i] * ev[k];
+                        ev[i] = sv / Lc[i * de + i];
+                    }
+                    for (int i = 0; i < de; i++) Ei[i * de + col] = ev[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (fail) { if (tid == 0) s.lin_fail = 1; return; }
+        // T = Einv * M_ef ; Eg = Einv * g_e
+        for (int e = tid; e < de * df; e += blockDim.x) {
+            int a = e / df, j = e % df;
+            double sv = 0;
+            for (int b = 0; b < de; b++) sv += Ei[a * de + b] * M[b * d + de + j];
+            T[a * df + j] = sv;
+        }
+        if (tid < de) { double sv = 0; for (int b = 0; b < de; b++) sv += Ei[tid * de + b] * gv[b]; Eg[tid] = sv; }
+        __syncthreads();
+        double* E = B.cE + C.e_off;
+        for (int e = tid; e < de * de; e += blockDim.x) E[e] = Ei[e];
+        for (int e = tid; e < de * df; e += blockDim.x) E[de * de + e] = M[(e / df) * d + de + (e % df)];
+        if (tid < de) E[de * de + de * df + tid] = gv[tid];
+    }
+    double* Cm = B.C + C.C_off;
+    for (int e = tid; e < df * df; e += blockDim.x) {
+        int i = e / df, j = e % df;
+        double v = M[(de + i) * d + de + j];
+        for (int a = 0; a < de; a++) v -= M[(de + i) * d + a] * T[a * df + j];
+        Cm[e] = v;
+    }
+    if (tid < df) {
+        double v = 0;
+        for (int a = 0; a < de; a++) v -= M[(de + tid) * d + a] * Eg[a];
+        B.cv_cs[C.v_off + tid] = v;
+    }
+}
+
+// =========================================================================================
+// P = Yt^T Wt per window: the landmark part of the reduced camera matrix as one dense
+// product over the static-sparsity slabs (v1: LDS-tiled fp64 VALU; 16x16 output tiles,
+// lower triangle of tiles only — P is symmetric).
+// =========================================================================================
+__global__ void __launch_bounds__(256) k_lm_gemm(DevBatch B) {
+    __shared__ double Ys[16][17];
+    __shared__ double Ws[16][17];
+    int w = blockIdx.y;
+    const WinRec& W = B.win[w];
+    if (!B.ws[w].need_lin) return;
+    int m = 6 * W.nF, nt = (m + 15) / 16;
+    int t = blockIdx.x;
+    if (t >= nt * (nt + 1) / 2) return;
+    int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) / 2.0);
+    while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
+    while (tr * (tr + 1) / 2 > t) tr--;
+    int tc = t - tr * (tr + 1) / 2;
+    int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    int K = 3 * (W.lm1 - W.lm0);
+    const double* Yt = B.Yt + W.YW_base; const double* Wt = B.Wt + W.YW_base;
+    double acc = 0;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        int k = k0 + ty, rr = tr * 16 + tx, cc = tc * 16 + tx;
+        Ys[ty][tx] = (k < K && rr < m) ? Yt[(size_t)k * m + rr] : 0.0;
+        Ws[ty][tx] = (k < K && cc < m) ? Wt[(size_t)k * m + cc] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) acc += Ys[kk][ty] * Ws[kk][tx];
+        __syncthreads();
+    }
+    int r = tr * 16 + ty, c = tc * 16 + tx;
+    if (r < m && c < m) B.P[W.P_base + (size_t)r * m + c] = acc;
+}
+
+// =========================================================================================
+// Owner-computes assembly of the reduced system: one wavefront per structurally non-zero
+// block pair (a >= b in elimination order) writes S[a,b] (and its mirror) exactly once:
+//   S_ab = [a,b poses with observations]  (a==b ? sum_o Jp^T Jp : 0) - P[fa,fb]
+//        + sum_cliques C_k[a,b]  + (a==b) mu * clamp(diag_a)
+// Diagonal pairs also produce g_a, diag_a and rhs_a = g_a + sum cs_k - (Y g_l)_a.
+// =========================================================================================
+__global__ void __launch_bounds__(256) k_assemble(DevBatch B, DevOpt O, int write_S) {
+    int pidx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (pidx >= B.n_pair) return;
+    const Pair& Pr = B.pair[pidx];
+    const WinState& s = B.ws[Pr.win];
+    if (!s.need_lin) return;
+    const WinRec& W = B.win[Pr.win];
+    int la = Pr.la, lb = Pr.lb, n = W.n_red, m = 6 * W.nF;
+    double* S = B.S + W.S_base;
+    const double* P = B.P + W.P_base;
+    double H[21], gr[6], qv[6];
+    bool obs = Pr.is_diag && Pr.fa >= 0;
+    if (obs) {
+        for (int k = 0; k < 21; k++) H[k] = 0;
+        for (int k = 0; k < 6; k++) { gr[k] = 0; qv[k] = 0; }
+        int fglob = W.fr_base + Pr.fa, np = B.n_proj, nl = B.n_lm;
+        const double* Yt = B.Yt + W.YW_base;
+        for (int q = B.fr_obs0[fglob] + lane; q < B.fr_obs0[fglob + 1]; q += 64) {
+            int o = B.fr_obs[q];
+            double a[6], b[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { a[i] = B.p_Jp[i * np + o]; b[i] = B.p_Jp[(6 + i) * np + o]; }
+            double r0 = B.p_r[o], r1 = B.p_r[np + o];
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int j = 0; j <= i; j++) H[k++] += a[i] * a[j] + b[i] * b[j];
+                gr[i] += a[i] * r0 + b[i] * r1;
+            }
+            int Lg = B.p_lm[o];
+            if (B.lm_loc[Lg] >= 0) {
+                double g0 = B.lm_g[Lg], g1 = B.lm_g[nl + Lg], g2 = B.lm_g[2 * nl + Lg];
+                size_t base = (size_t)B.lm_col[Lg] * m + 6 * Pr.fa;
+#pragma unroll
+                for (int i = 0; i < 6; i++) qv[i] += Yt[base + i] * g0 + Yt[base + m + i] * g1 + Yt[base + 2 * m + i] * g2;
+            }
+        }
+        for (int k = 0; k < 21; k++) H[k] = wave_sum(H[k]);
+        for (int k = 0; k < 6; k++) { gr[k] = wave_sum(gr[k]); qv[k] = wave_sum(qv[k]); }
+    }
+    // diagonal bookkeeping first (needed for damping)
+    double dg_i = 0;    // lane i < la: raw diag of column i
+    if (Pr.is_diag && lane < la) {
+        double gi = 0, cs = 0;
+        if (obs) { int i = lane; gi = gr[i]; dg_i = H[i * (i + 1) / 2 + i]; cs = -qv[i]; }
+        for (int c = Pr.c0; c < Pr.c1; c++) {
+            int vo = B.pc_voff[c];
+            gi += B.cv_graw[vo + lane]; dg_i += B.cv_dgraw[vo + lane]; cs += B.cv_cs[vo + lane];
+        }
+        B.g[Pr.loc_a + lane] = gi; B.diag[Pr.loc_a + lane] = dg_i;
+        if (write_S) B.rhs[Pr.loc_a + lane] = gi + cs;
+    }
+    if (!write_S) return;      // final pass: cost + gradient only, keep (S, rhs, L) of the last solve
+    // damping source per entry, fetched in uniform control flow (la*lb <= 81 => two rounds)
+    double dgs0 = __shfl(dg_i, (lane / lb) & 63, 64);
+    double dgs1 = __shfl(dg_i, ((lane + 64) / lb) & 63, 64);
+    for (int e = lane; e < la * lb; e += 64) {
+        int i = e / lb, j = e % lb;
+        double v = 0;
+        if (Pr.fa >= 0 && Pr.fb >= 0) {
+            int pr = 6 * Pr.fa + i, pc = 6 * Pr.fb + j;
+            v -= (pr >= pc) ? P[(size_t)pr * m + pc] : P[(size_t)pc * m + pr];
+            if (obs) { int hi = i > j ? i : j, lo = i > j ? j : i; v += H[hi * (hi + 1) / 2 + lo]; }
+        }
+        for (int c = Pr.c0; c < Pr.c1; c++) v += B.C[B.pc_coff[c] + (size_t)i * B.pc_cld[c] + j];
+        if (Pr.is_diag && i == j) v += s.mu * clampd(e < 64 ? dgs0 : dgs1, O.min_diag, O.max_diag);
+        S[(size_t)(Pr.ra + i) * n + Pr.rb + j] = v;
+        S[(size_t)(Pr.rb + j) * n + Pr.ra + i] = v;
+    }
+}

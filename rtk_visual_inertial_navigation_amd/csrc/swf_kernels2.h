@@ -1,0 +1,473 @@
+// swf_kernels2.h — reduced solve, back-substitution and the on-device trust-region control.
+//
+// The dogleg loop restates the public Ceres 2.x TrustRegionMinimizer + DoglegStrategy
+// (TRADITIONAL_DOGLEG) that the reference drives through ceres::Solve
+// (R/swf/swf_image.cpp:198-251, options R/swf/swf.cpp:25-30; constants SURVEY.md App. C).
+// Accept/reject, radius, mu and convergence are decided per window on the device; the host
+// only enqueues a fixed sequence of launches and never reads anything back mid-solve.
+#pragma once
+#include "swf_kernels.h"
+
+// =========================================================================================
+// Dense reduced solve, one 1024-thread workgroup per window.
+// Blocked left-looking Cholesky S = L L^T in the predefined elimination order, one matrix
+// row per thread (accumulators in registers), 32-wide block columns:
+//   * the working factor is kept TRANSPOSED (Lt[k][r] = L[r][k], leading dim n+1) so that
+//     lanes = consecutive rows read consecutive addresses;
+//   * rhs rides along as row n of the matrix, so the forward solve y = L^-1 rhs falls out
+//     of the factorisation; only the backward solve L^T z = y is done separately;
+//   * the 32x32 diagonal block is factored inside wave 0 with cross-lane shuffles.
+// (v1 of this kernel: fp64 VALU; the MFMA trailing-update variant replaces the k-loop.)
+// =========================================================================================
+#define CH_NB 32
+#define CH_KC 64
+__global__ void __launch_bounds__(1024) k_chol_solve(DevBatch B) {
+    __shared__ double Lrow[CH_NB][CH_KC + 1];   // L[J0+c][k0+kk]
+    __shared__ double D[CH_NB][CH_NB + 1];      // diagonal block (lower)
+    __shared__ double zs[1024];
+    __shared__ double part[CH_NB][33];
+    __shared__ int fail;
+    int w = blockIdx.x;
+    WinState& s = B.ws[w];
+    if (!s.need_lin || s.lin_fail) return;
+    const WinRec& W = B.win[w];
+    int n = W.n_red, ld = n + 1, tid = threadIdx.x;
+    if (n <= 0) return;
+    const double* S = B.S + W.S_base;
+    double* Lt = B.L + W.Lt_base;
+    const double* rhs = B.rhs + W.loc_base + W.n_e;
+    if (tid == 0) fail = 0;
+    __syncthreads();
+    for (int J0 = 0; J0 < n; J0 += CH_NB) {
+        int nb = (n - J0) < CH_NB ? (n - J0) : CH_NB;
+        int r = J0 + tid;                       // my row (r == n : augmented rhs row)
+        bool active = r <= n;
+        double acc[CH_NB];
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) {
+            double v = 0;
+            if (active && c < nb) v = (r < n) ? S[(size_t)r * n + J0 + c] : rhs[J0 + c];
+            acc[c] = v;
+        }
+        // subtract contributions of the already factored columns
+        for (int k0 = 0; k0 < J0; k0 += CH_KC) {
+            int kc = (J0 - k0) < CH_KC ? (J0 - k0) : CH_KC;
+            for (int e = tid; e < CH_NB * CH_KC; e += 1024) {
+                int kk = e / CH_NB, c = e % CH_NB;
+                Lrow[c][kk] = (kk < kc && c < nb) ? Lt[(size_t)(k0 + kk) * ld + J0 + c] : 0.0;
+            }
+            __syncthreads();
+            if (active) {
+                for (int kk = 0; kk < kc; kk++) {
+                    double l = Lt[(size_t)(k0 + kk) * ld + r];
+#pragma unroll
+                    for (int c = 0; c < CH_NB; c++) acc[c] -= l * Lrow[c][kk];
+                }
+            }
+            __syncthreads();
+        }
+        // factor the diagonal block inside wave 0 (lanes 0..nb-1 hold rows J0..J0+nb-1)
+        if (tid < 64) {
+            int lane = tid;
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < CH_NB; c++) {
+                double dpiv = __shfl(acc[c], c, 64);
+                if (c < nb) {
+                    if (!(dpiv > 0.0)) bad = true;
+                    if (lane < nb) {
+                        double piv = sqrt(dpiv);
+                        if (lane == c) acc[c] = piv;
+                        else if (lane > c) acc[c] = acc[c] / piv;
+                    }
+                }
+#pragma unroll
+                for (int c2 = c + 1; c2 < CH_NB; c2++) {
+                    double l2 = __shfl(acc[c], c2, 64);       // L[c2][c]
+                    if (c2 < nb && lane < nb && lane >= c2) acc[c2] -= acc[c] * l2;
+                }
+            }
+            if (lane < nb) {
+#pragma unroll
+                for (int c = 0; c < CH_NB; c++) {
+                    D[lane][c] = (c <= lane) ? acc[c] : 0.0;
+                    if (c <= lane && c < nb) Lt[(size_t)(J0 + c) * ld + J0 + lane] = acc[c];
+                }
+            }
+            if (bad && lane == 0) fail = 1;
+        }
+        __syncthreads();
+        if (fail) { if (tid == 0) s.lin_fail = 1; return; }
+        // triangular solve for the rows below the block: x L_d^T = acc
+        if (active && r >= J0 + nb) {
+#pragma unroll
+            for (int c = 0; c < CH_NB; c++) {
+                if (c < nb) {
+                    double v = acc[c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) v -= acc[k] * D[c][k];
+                    v = v / D[c][c];
+                    acc[c] = v;
+                    Lt[(size_t)(J0 + c) * ld + r] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // backward solve L^T z = y, y = row n of L (Lt[k][n]); blocks from the bottom up
+    for (int e = tid; e < n; e += 1024) zs[e] = 0.0;
+    __syncthreads();
+    int nblk = (n + CH_NB - 1) / CH_NB;
+    for (int jb = nblk - 1; jb >= 0; jb--) {
+        int J0 = jb * CH_NB;
+        int nb = (n - J0) < CH_NB ? (n - J0) : CH_NB;
+        // partial dots over already solved z_r, r >= J0+nb : 32 rows x 32 parts
+        {
+            int kk = tid >> 5, pt = tid & 31;
+            double a = 0;
+            if (kk < nb) for (int r = J0 + nb + pt; r < n; r += 32) a += Lt[(size_t)(J0 + kk) * ld + r] * zs[r];
+            part[kk][pt] = a;
+        }
+        for (int e = tid; e < CH_NB * CH_NB; e += 1024) {
+            int c = e / CH_NB, k = e % CH_NB;      // D[c][k] = L[J0+c][J0+k], c >= k
+            D[c][k] = (c < nb && k <= c) ? Lt[(size_t)(J0 + k) * ld + J0 + c] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int lane = tid;
+            double b = 0;
+            if (lane < nb) {
+                double a = 0;
+                for (int pt = 0; pt < 32; pt++) a += part[lane][pt];
+                b = Lt[(size_t)(J0 + lane) * ld + n] - a;
+            }
+#pragma unroll
+            for (int c = CH_NB - 1; c >= 0; c--) {
+                double bc = __shfl(b, c, 64);
+                if (c < nb) {
+                    double zc = bc / D[c][c];
+                    if (lane == c) b = zc;
+                    else if (lane < c) b -= D[c][lane] * zc;
+                }
+            }
+            if (lane < nb) zs[J0 + lane] = b;
+        }
+        __syncthreads();
+    }
+    double* y = B.y + W.loc_base + W.n_e;
+    for (int e = tid; e < n; e += 1024) y[e] = zs[e];
+}
+
+// =========================================================================================
+// Back-substitution of the eliminated blocks: y_e = Einv (g_e - H_ef y_f)
+// =========================================================================================
+__global__ void __launch_bounds__(256) k_backsub_lm(DevBatch B) {
+    int L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= B.n_lm) return;
+    int w = B.lm_win[L];
+    const WinState& s = B.ws[w];
+    if (!s.need_lin || s.lin_fail) return;
+    int loc = B.lm_loc[L];
+    if (loc < 0) return;
+    const WinRec& W = B.win[w];
+    int nl = B.n_lm, ld = 6 * W.nF, col = B.lm_col[L];
+    const double* Wt = B.Wt + W.YW_base;
+    double t0 = B.lm_g[L], t1 = B.lm_g[nl + L], t2 = B.lm_g[2 * nl + L];
+    for (int o = B.lm_obs0[L]; o < B.lm_obs0[L + 1]; o++) {
+        int f = B.p_fr[o];
+        if (f < 0) continue;
+        int lp = B.p_lpose[o];
+        size_t base = (size_t)col * ld + 6 * f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double yv = B.y[lp + i];
+            t0 -= Wt[base + i] * yv; t1 -= Wt[base + ld + i] * yv; t2 -= Wt[base + 2 * ld + i] * yv;
+        }
+    }
+    double e00 = B.lm_Einv[L], e10 = B.lm_Einv[nl + L], e20 = B.lm_Einv[2 * nl + L];
+    double e11 = B.lm_Einv[3 * nl + L], e21 = B.lm_Einv[4 * nl + L], e22 = B.lm_Einv[5 * nl + L];
+    B.y[loc] = e00 * t0 + e10 * t1 + e20 * t2;
+    B.y[loc + 1] = e10 * t0 + e11 * t1 + e21 * t2;
+    B.y[loc + 2] = e20 * t0 + e21 * t1 + e22 * t2;
+}
+__global__ void __launch_bounds__(64) k_backsub_clique(DevBatch B) {
+    __shared__ double t[9];
+    int c = blockIdx.x;
+    if (c >= B.n_cl) return;
+    const Clique& C = B.cl[c];
+    if (C.d_e == 0) return;
+    const WinState& s = B.ws[C.win];
+    if (!s.need_lin || s.lin_fail) return;
+    int de = C.d_e, df = C.d_f, lane = threadIdx.x;
+    const double* E = B.cE + C.e_off;
+    if (lane < de) {
+        double a = E[de * de + de * df + lane];
+        for (int m = C.mem0; m < C.mem1; m++) {
+            int lo = B.cm_loc[m], l = B.cm_ls[m], cc = B.cm_col[m];
+            for (int j = 0; j < l; j++) a -= E[de * de + lane * df + cc + j] * B.y[lo + j];
+        }
+        t[lane] = a;
+    }
+    __syncthreads();
+    if (lane < de) {
+        double a = 0;
+        for (int b = 0; b < de; b++) a += E[lane * de + b] * t[b];
+        B.y[C.e_loc + lane] = a;
+    }
+}
+
+// =========================================================================================
+// per-window control kernels (one 256-thread workgroup per window)
+// =========================================================================================
+__device__ __forceinline__ double win_cost_sum(const DevBatch& B, const WinRec& W, double* red) {
+    double a = 0;
+    for (int i = W.proj0 + threadIdx.x; i < W.proj1; i += blockDim.x) a += B.p_cost[i];
+    for (int i = W.gf0 + threadIdx.x; i < W.gf1; i += blockDim.x) a += B.g_cost[i];
+    return block_sum(a, red);
+}
+__device__ __forceinline__ double win_aux_sum(const DevBatch& B, const WinRec& W, double* red) {
+    double a = 0;
+    for (int i = W.proj0 + threadIdx.x; i < W.proj1; i += blockDim.x) a += B.p_aux[i];
+    for (int i = W.gf0 + threadIdx.x; i < W.gf1; i += blockDim.x) a += B.g_aux[i];
+    return block_sum(a, red);
+}
+// || x ||_2 over variable blocks (ambient coordinates)
+__device__ __forceinline__ double win_x_norm(const DevBatch& B, const WinRec& W, const double* x, double* red) {
+    double a = 0;
+    for (int b = W.blk_base + threadIdx.x; b < W.blk_base + W.n_blk; b += blockDim.x) {
+        if (B.blk_loc[b] < 0) continue;
+        for (int k = 0; k < B.blk_gs[b]; k++) { double v = x[B.blk_xoff[b] + k]; a += v * v; }
+    }
+    return sqrt(block_sum(a, red));
+}
+// gradient_max_norm = || x - Plus(x, -g) ||_inf (TrustRegionMinimizer::EvaluateGradientAndJacobian)
+__device__ __forceinline__ double win_gmax(const DevBatch& B, const WinRec& W, double* red) {
+    double m = 0;
+    for (int b = W.blk_base + threadIdx.x; b < W.blk_base + W.n_blk; b += blockDim.x) {
+        int lo = B.blk_loc[b];
+        if (lo < 0) continue;
+        const double* x = B.x + B.blk_xoff[b];
+        if (B.blk_gs[b] == 7) {
+            double d[6], o[7];
+            for (int k = 0; k < 6; k++) d[k] = -B.g[lo + k];
+            pose_plus(x, d, o);
+            for (int k = 0; k < 7; k++) { double v = fabs(x[k] - o[k]); m = v > m ? v : m; }
+        } else {
+            for (int k = 0; k < B.blk_gs[b]; k++) { double v = fabs(B.g[lo + k]); m = v > m ? v : m; }
+        }
+    }
+    return block_max(m, red);
+}
+
+__global__ void __launch_bounds__(256) k_init(DevBatch B, DevOpt O) {
+    __shared__ double red[16];
+    int w = blockIdx.x;
+    const WinRec& W = B.win[w];
+    double xn = win_x_norm(B, W, B.x, red);
+    for (int k = threadIdx.x; k < B.max_iter_trace * (int)(sizeof(swf_iteration) / 8); k += blockDim.x)
+        ((double*)(B.trace + (size_t)w * B.max_iter_trace))[k] = 0.0;
+    if (threadIdx.x == 0) {
+        WinState& s = B.ws[w];
+        s.radius = O.r0; s.mu = (O.step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) ? 0.0 : O.min_mu;
+        s.x_cost = 0; s.x_norm = xn; s.alpha = 0; s.dogleg_step_norm = 0; s.step_norm = 0; s.gmax = 0;
+        s.jg_sq = 0; s.initial_cost = 0;
+        s.status = SWF_RUNNING; s.iter = 0; s.need_lin = 1; s.reuse = 0; s.eval_cand = 0; s.lin_fail = 0;
+        s.invalid_run = 0; s.nsucc = 0; s.nunsucc = 0;
+    }
+}
+
+// DoglegStrategy::ComputeStep (+ the bookkeeping of FinalizeIterationAndCheckIfMinimizerCanContinue)
+__global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
+    __shared__ double red[16];
+    __shared__ int go;
+    int w = blockIdx.x, tid = threadIdx.x;
+    WinState& s = B.ws[w];
+    if (s.status != SWF_RUNNING) return;
+    const WinRec& W = B.win[w];
+    swf_iteration* tr = B.trace + (size_t)w * B.max_iter_trace;
+    int fresh = s.need_lin;
+    double x_cost = s.x_cost, gmax = s.gmax, jg_sq = s.jg_sq;
+    if (fresh) {
+        x_cost = win_cost_sum(B, W, red);
+        if (!s.lin_fail) {
+            gmax = win_gmax(B, W, red);
+            jg_sq = win_aux_sum(B, W, red);
+        }
+    }
+    const double* g = B.g + W.loc_base; const double* dg = B.diag + W.loc_base; const double* y = B.y + W.loc_base;
+    double* step = B.step + W.loc_base;
+    int n = W.n_loc;
+    // scalars of the scaled problem: |g/d|, |d y|, (g/d).(−d y)
+    double a_g = 0, a_y = 0, a_d = 0;
+    for (int i = tid; i < n; i += blockDim.x) {
+        double dc = clampd(dg[i], O.min_diag, O.max_diag);
+        a_g += g[i] * g[i] / dc; a_y += dc * y[i] * y[i]; a_d += -g[i] * y[i];
+    }
+    double gsq = block_sum(a_g, red), ynn = block_sum(a_y, red), gdot = block_sum(a_d, red);
+    __syncthreads();
+    if (tid == 0) {
+        go = 0;
+        int it = s.iter;
+        if (fresh) {
+            s.x_cost = x_cost; s.gmax = gmax; s.jg_sq = jg_sq;
+            if (it == 0) { s.initial_cost = x_cost; tr[0].cost = x_cost; tr[0].trust_region_radius = s.radius; tr[0].step_is_valid = 1; tr[0].step_is_successful = 1; }
+            else tr[it].cost = x_cost;
+            tr[it].gradient_max_norm = gmax;
+            s.need_lin = 0;
+        }
+        if (it >= O.max_iter) s.status = SWF_NO_CONVERGENCE;
+        else if (gmax <= O.gtol && !s.lin_fail) s.status = SWF_CONVERGED_GRADIENT;
+        else if (s.radius < O.min_r) s.status = SWF_RADIUS_TOO_SMALL;
+        else {
+            it = ++s.iter;
+            swf_iteration& rec = tr[it < B.max_iter_trace ? it : B.max_iter_trace - 1];
+            rec.gradient_max_norm = gmax;
+            if (s.lin_fail) {
+                // Gauss-Newton solve failed: DoglegStrategy raises mu; HandleInvalidStep
+                rec.step_is_valid = 0; rec.cost = s.x_cost; rec.trust_region_radius = s.radius;
+                s.lin_fail = 0; s.eval_cand = 0;
+                s.mu *= O.mu_inc; s.reuse = 0; s.need_lin = 1;
+                if (++s.invalid_run >= 5 || s.mu >= O.max_mu) s.status = SWF_LINEAR_SOLVER_FAILURE;
+            } else {
+                if (!s.reuse) s.alpha = gsq / jg_sq;
+                s.reuse = 1;
+                go = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (!go) return;
+    // ComputeTraditionalDoglegStep in the scaled space, un-scaled on the fly
+    double gnorm = sqrt(gsq), gnn = sqrt(ynn), alpha = s.alpha, radius = s.radius;
+    int mode; double c1 = 0, c2 = 0;          // step = c1 * g / dclamp + c2 * y
+    double dnorm;
+    if (gnn <= radius) { mode = 0; c1 = 0; c2 = -1.0; dnorm = gnn; }
+    else if (gnorm * alpha >= radius) { mode = 1; c1 = -(radius / gnorm); c2 = 0; dnorm = radius; }
+    else {
+        double b_dot_a = -alpha * gdot;
+        double a_sq = pow(alpha * gnorm, 2.0);
+        double bma_sq = a_sq - 2 * b_dot_a + pow(gnn, 2);
+        double cc = b_dot_a - a_sq;
+        double dd = sqrt(cc * cc + bma_sq * (pow(radius, 2.0) - a_sq));
+        double beta = (cc <= 0) ? (dd - cc) / bma_sq : (radius * radius - a_sq) / (dd + cc);
+        mode = 2; c1 = -alpha * (1.0 - beta); c2 = -beta; dnorm = -1.0;
+    }
+    double a_s = 0;
+    for (int i = tid; i < n; i += blockDim.x) {
+        double dc = clampd(dg[i], O.min_diag, O.max_diag);
+        double ds = sqrt(dc);
+        // scaled step, then / dsqrt
+        double sc = c1 * (g[i] / ds) + c2 * (ds * y[i]);
+        a_s += sc * sc;
+        step[i] = sc / ds;
+    }
+    double sn = block_sum(a_s, red);
+    if (mode == 2) dnorm = sqrt(sn);
+    // candidate = Plus(x, step)
+    for (int i = W.x_base + tid; i < W.x_base + W.x_n; i += blockDim.x) B.xc[i] = B.x[i];
+    __syncthreads();
+    double a_n = 0;
+    for (int b = W.blk_base + tid; b < W.blk_base + W.n_blk; b += blockDim.x) {
+        int lo = B.blk_loc[b];
+        if (lo < 0) continue;
+        int xo = B.blk_xoff[b];
+        if (B.blk_gs[b] == 7) {
+            double o[7];
+            pose_plus(B.x + xo, B.step + lo, o);
+            for (int k = 0; k < 7; k++) { B.xc[xo + k] = o[k]; double v = B.x[xo + k] - o[k]; a_n += v * v; }
+        } else {
+            for (int k = 0; k < B.blk_gs[b]; k++) { double v = B.x[xo + k] + B.step[lo + k]; B.xc[xo + k] = v; double dv = B.x[xo + k] - v; a_n += dv * dv; }
+        }
+    }
+    double stepn = sqrt(block_sum(a_n, red));
+    if (tid == 0) { s.dogleg_step_norm = dnorm; s.step_norm = stepn; s.eval_cand = 1; }
+}
+
+// acceptance test + trust-region update (TrustRegionMinimizer::Minimize loop body,
+// DoglegStrategy::StepAccepted / StepRejected / StepIsInvalid)
+__global__ void __launch_bounds__(256) k_decide(DevBatch B, DevOpt O) {
+    __shared__ double red[16];
+    __shared__ int accept;
+    int w = blockIdx.x, tid = threadIdx.x;
+    WinState& s = B.ws[w];
+    if (s.status != SWF_RUNNING || !s.eval_cand) return;
+    const WinRec& W = B.win[w];
+    double cand = win_cost_sum(B, W, red);
+    double model_cost_change = -win_aux_sum(B, W, red);
+    if (!(cand == cand) || cand > 1.7976931348623157e308) cand = 1.7976931348623157e308;
+    __syncthreads();
+    if (tid == 0) {
+        accept = 0;
+        swf_iteration* tr = B.trace + (size_t)w * B.max_iter_trace;
+        swf_iteration& rec = tr[s.iter < B.max_iter_trace ? s.iter : B.max_iter_trace - 1];
+        s.eval_cand = 0;
+        rec.model_cost_change = model_cost_change;
+        if (!(model_cost_change > 0.0)) {
+            rec.step_is_valid = 0; rec.cost = s.x_cost; rec.trust_region_radius = s.radius;
+            s.mu *= O.mu_inc; s.reuse = 0; s.need_lin = 1;
+            if (++s.invalid_run >= 5) s.status = SWF_LINEAR_SOLVER_FAILURE;
+        } else {
+            rec.step_is_valid = 1; s.invalid_run = 0;
+            rec.step_norm = s.step_norm;
+            rec.cost_change = s.x_cost - cand;
+            if (s.step_norm <= O.ptol * (s.x_norm + O.ptol)) {
+                rec.cost = s.x_cost; rec.trust_region_radius = s.radius; s.status = SWF_CONVERGED_PARAMETER;
+            } else if (fabs(rec.cost_change) <= O.ftol * s.x_cost) {
+                rec.cost = s.x_cost; rec.trust_region_radius = s.radius; s.status = SWF_CONVERGED_FUNCTION;
+            } else {
+                rec.relative_decrease = rec.cost_change / model_cost_change;
+                if (rec.relative_decrease > O.min_rel_dec) {
+                    accept = 1;
+                    rec.step_is_successful = 1; rec.cost = cand; s.x_cost = cand; s.nsucc++;
+                    if (rec.relative_decrease < 0.25) s.radius *= 0.5;
+                    if (rec.relative_decrease > 0.75) s.radius = s.radius > 3.0 * s.dogleg_step_norm ? s.radius : 3.0 * s.dogleg_step_norm;
+                    double m2 = 2.0 * s.mu / O.mu_inc;
+                    s.mu = O.min_mu > m2 ? O.min_mu : m2;
+                    s.reuse = 0; s.need_lin = 1;
+                } else {
+                    rec.step_is_successful = 0; rec.cost = s.x_cost; s.nunsucc++;
+                    s.radius *= 0.5; s.reuse = 1;
+                }
+                rec.trust_region_radius = s.radius;
+            }
+        }
+    }
+    __syncthreads();
+    if (accept) {
+        for (int i = W.x_base + tid; i < W.x_base + W.x_n; i += blockDim.x) B.x[i] = B.xc[i];
+        __syncthreads();
+        double xn = win_x_norm(B, W, B.x, red);
+        if (tid == 0) s.x_norm = xn;
+    }
+}
+
+// after the last slot: fold the final linearisation (cost, gradient norm) into the trace
+__global__ void __launch_bounds__(256) k_finalize(DevBatch B, DevOpt O) {
+    __shared__ double red[16];
+    int w = blockIdx.x, tid = threadIdx.x;
+    WinState& s = B.ws[w];
+    const WinRec& W = B.win[w];
+    swf_iteration* tr = B.trace + (size_t)w * B.max_iter_trace;
+    if (s.need_lin && (s.status == SWF_RUNNING)) {
+        double x_cost = win_cost_sum(B, W, red);
+        double gmax = win_gmax(B, W, red);
+        if (tid == 0) {
+            s.x_cost = x_cost; s.gmax = gmax; s.need_lin = 0;
+            int it = s.iter < B.max_iter_trace ? s.iter : B.max_iter_trace - 1;
+            tr[it].cost = x_cost; tr[it].gradient_max_norm = gmax;
+            if (s.iter == 0) { s.initial_cost = x_cost; tr[0].trust_region_radius = s.radius; tr[0].step_is_valid = 1; tr[0].step_is_successful = 1; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s.status == SWF_RUNNING) {
+        if (O.step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) s.status = s.lin_fail ? SWF_LINEAR_SOLVER_FAILURE : SWF_ASSEMBLED_ONLY;
+        else if (s.gmax <= O.gtol) s.status = SWF_CONVERGED_GRADIENT;
+        else s.status = SWF_NO_CONVERGENCE;
+    }
+}
+
+// device-side state restore (bench: same inputs every step, already resident in HBM)
+__global__ void k_copy(double* dst, const double* src, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
