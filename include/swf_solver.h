@@ -88,20 +88,24 @@ int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, double* rhs, do
 int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, double* diag, double* y);
 int swf_batch_dims(swf_batch* b, int32_t w, int32_t* n_loc, int32_t* n_e, int32_t* n_red);
 
-/* Timing of the last swf_batch_solve measured with HIP events on the batch stream
- * (valid after swf_batch_sync): total and the share of selected kernels, in milliseconds. */
+/* Timing of the last swf_batch_solve, measured with HIP events recorded on the batch stream
+ * around individual kernel launches (valid after swf_batch_sync).  `mask` selects which
+ * kernels get an event pair per launch (bit k = SWF_K_*); bit 0 brackets the whole solve.
+ * ms[k] = summed duration, calls[k] = number of launches bracketed. */
+enum { SWF_K_TOTAL = 0, SWF_K_EVAL_PROJ = 1, SWF_K_EVAL_IMU = 2, SWF_K_EVAL_SCALAR = 3, SWF_K_EVAL_PRIOR = 4,
+       SWF_K_LM_ELIM = 5, SWF_K_CLIQUE_ELIM = 6, SWF_K_LM_GEMM = 7, SWF_K_ASSEMBLE = 8, SWF_K_CHOL = 9,
+       SWF_K_BACKSUB = 10, SWF_K_JTIMES = 11, SWF_K_DOGLEG = 12, SWF_K_CAND_EVAL = 13, SWF_K_DECIDE = 14,
+       SWF_K_COUNT = 16 };
 typedef struct swf_timing {
-    double total_ms;
-    double eval_ms;          /* factor residual/Jacobian kernels */
-    double eliminate_ms;     /* group-0 elimination + Schur assembly */
-    double reduced_ms;       /* dense reduced solve (Cholesky + triangular solves) */
-    double other_ms;
+    double ms[SWF_K_COUNT];
+    int32_t calls[SWF_K_COUNT];
     int64_t jacobian_bytes;  /* algorithmic bytes of ONE Jacobian evaluation of the batch */
+    int64_t proj_bytes;      /* the projection-factor share of it (312 B per observation) */
+    int64_t chol_flops;      /* sum over windows of n_red^3 / 3 (one factorisation of the batch) */
     int32_t n_linearizations;/* Jacobian evaluations enqueued per window in the last solve */
     int32_t reserved;
 } swf_timing;
-/* Enable per-kernel-group event timing for subsequent solves (costs a few events). */
-int swf_batch_enable_timing(swf_batch* b, int32_t on);
+int swf_batch_enable_timing(swf_batch* b, int32_t mask);
 int swf_batch_timing(swf_batch* b, swf_timing* out);
 
 /* =====================================================================================

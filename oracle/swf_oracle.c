@@ -372,10 +372,14 @@ static double gnss_distance(const double* rr, const double* rs, double* e) {
     for (int i = 0; i < 3; i++) e[i] /= r;
     return r + OMGE * (rs[0] * rr[1] - rs[1] * rr[0]) / CLIGHT;
 }
-/* varerr2(), R/factor/gnss_factor.cpp:98-103 — NB single-precision sinf */
+/* varerr2(), R/factor/gnss_factor.cpp:98-103 — NB the reference calls single-precision
+ * sinf().  sinf is libm-dependent in the last float ulp (glibc 2.35 differs from the correctly
+ * rounded value for ~1% of elevations, the device libm for more), so the restatement pins it
+ * to the CORRECTLY ROUNDED float sine: round-to-float of the fp64 sine of the float argument.
+ * Max deviation from any libm's sinf: 1 float ulp (6e-8 relative) on the weight. */
 static double varerr2(double el, double dt, double mea_var) {
     double b = CLIGHT * 5e-12 * dt;
-    double sinel = sinf(el);
+    double sinel = (double)(float)sin((double)(float)el);
     return (mea_var / sinel / sinel) + b * b;
 }
 /* RTKCarrierPhaseFactor::Evaluate, R/factor/gnss_factor.cpp:105-138.

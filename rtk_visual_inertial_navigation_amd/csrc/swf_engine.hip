@@ -20,6 +20,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SWF_E_NODEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 extern "C" const char* swf_last_error(void) { return g_err.c_str(); }
+void swf_internal_set_error(const std::string& m) { g_err = m; }
 extern "C" int swf_version(void) { return 100; }
 extern "C" int swf_device_count(int32_t* n) {
     int c = 0;
@@ -68,11 +69,12 @@ struct swf_batch {
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
     int max_tiles = 0, max_prior_dim = 0;
-    bool timing = false;
+    int timing = 0;                       // bitmask of SWF_K_* brackets
     swf_timing last{};
-    hipEvent_t ev[16]{};
-    bool ev_ok = false;
-    int64_t jac_bytes = 0;
+    std::vector<hipEvent_t> ev;           // event pool (pairs)
+    std::vector<int> ev_kind;             // kernel id per recorded pair
+    int ev_used = 0;
+    int64_t jac_bytes = 0, proj_bytes = 0, chol_flops = 0;
     int last_mode = -1;
 };
 
@@ -463,6 +465,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     swf_batch* b = new swf_batch();
     b->stream = (hipStream_t)stream;
     b->win = B.win; b->hw = hw; b->max_tiles = B.max_tiles; b->max_prior_dim = B.max_prior_dim; b->jac_bytes = B.jac_bytes;
+    b->proj_bytes = (int64_t)312 * (int64_t)B.p_win.size();
+    for (auto& W : B.win) b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3;
     DevBatch& D = b->D;
     DevPool& P = b->pool;
     int rc = 0;
@@ -522,7 +526,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
 
 extern "C" int swf_batch_destroy(swf_batch* b) {
     if (!b) return SWF_OK;
-    if (b->ev_ok) for (auto& e : b->ev) (void)hipEventDestroy(e);
+    for (auto& e : b->ev) (void)hipEventDestroy(e);
     b->pool.release();
     delete b;
     return SWF_OK;
@@ -567,41 +571,71 @@ static DevOpt to_devopt(const swf_options* o) {
 namespace {
 struct Launcher {
     swf_batch* b; DevOpt O; hipStream_t st;
+    // optional event pair around one launch
+    struct Bracket {
+        Launcher& L; int slot;
+        Bracket(Launcher& l, int kind) : L(l), slot(-1) {
+            swf_batch* b = L.b;
+            if (!(b->timing & (1 << kind))) return;
+            if ((size_t)(b->ev_used + 1) * 2 > b->ev.size()) {
+                size_t old = b->ev.size();
+                b->ev.resize(old + 64);
+                for (size_t i = old; i < b->ev.size(); i++) (void)hipEventCreate(&b->ev[i]);
+            }
+            slot = b->ev_used++;
+            b->ev_kind.push_back(kind);
+            (void)hipEventRecord(b->ev[2 * slot], L.st);
+        }
+        ~Bracket() { if (slot >= 0) (void)hipEventRecord(L.b->ev[2 * slot + 1], L.st); }
+    };
     void lin_eval() {
         DevBatch& D = b->D;
-        if (D.n_proj) hipLaunchKernelGGL(k_eval_proj<true>, GRID(D.n_proj, 256), dim3(256), 0, st, D);
-        if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<true>, dim3(D.n_imu), dim3(64), 0, st, D);
-        if (D.n_sc) hipLaunchKernelGGL(k_eval_scalar<true>, GRID(D.n_sc, 256), dim3(256), 0, st, D);
-        if (D.n_prior) hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
+        if (D.n_proj) { Bracket t(*this, SWF_K_EVAL_PROJ); hipLaunchKernelGGL(k_eval_proj<true>, GRID(D.n_proj, 256), dim3(256), 0, st, D); }
+        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, dim3(D.n_imu), dim3(64), 0, st, D); }
+        if (D.n_sc) { Bracket t(*this, SWF_K_EVAL_SCALAR); hipLaunchKernelGGL(k_eval_scalar<true>, GRID(D.n_sc, 256), dim3(256), 0, st, D); }
+        if (D.n_prior) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
     }
     void lin_elim(int write_S) {
         DevBatch& D = b->D;
-        if (D.n_lm) hipLaunchKernelGGL(k_lm_elim, GRID(D.n_lm, 256), dim3(256), 0, st, D, O);
-        if (D.n_cl) hipLaunchKernelGGL(k_clique_elim, dim3(D.n_cl), dim3(256), 0, st, D, O);
-        if (write_S && b->max_tiles) hipLaunchKernelGGL(k_lm_gemm, dim3(b->max_tiles, D.n_win), dim3(256), 0, st, D);
-        if (D.n_pair) hipLaunchKernelGGL(k_assemble, GRID((size_t)D.n_pair * 64, 256), dim3(256), 0, st, D, O, write_S);
+        if (D.n_lm) { Bracket t(*this, SWF_K_LM_ELIM); hipLaunchKernelGGL(k_lm_elim, GRID(D.n_lm, 256), dim3(256), 0, st, D, O); }
+        if (D.n_cl) { Bracket t(*this, SWF_K_CLIQUE_ELIM); hipLaunchKernelGGL(k_clique_elim, dim3(D.n_cl), dim3(256), 0, st, D, O); }
+        if (write_S && b->max_tiles) { Bracket t(*this, SWF_K_LM_GEMM); hipLaunchKernelGGL(k_lm_gemm, dim3(b->max_tiles, D.n_win), dim3(256), 0, st, D); }
+        if (D.n_pair) { Bracket t(*this, SWF_K_ASSEMBLE); hipLaunchKernelGGL(k_assemble, GRID((size_t)D.n_pair * 64, 256), dim3(256), 0, st, D, O, write_S); }
     }
     void reduced() {
         DevBatch& D = b->D;
+        Bracket t(*this, SWF_K_CHOL);
         hipLaunchKernelGGL(k_chol_solve, dim3(D.n_win), dim3(1024), 0, st, D);
     }
     void step_rest() {
         DevBatch& D = b->D;
-        if (D.n_lm) hipLaunchKernelGGL(k_backsub_lm, GRID(D.n_lm, 256), dim3(256), 0, st, D);
-        if (D.n_cl) hipLaunchKernelGGL(k_backsub_clique, dim3(D.n_cl), dim3(64), 0, st, D);
-        if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<0>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
-        if (D.n_gf) hipLaunchKernelGGL(k_jtimes_gen<0>, GRID((size_t)D.n_gf * 64, 256), dim3(256), 0, st, D, O);
-        hipLaunchKernelGGL(k_dogleg, dim3(D.n_win), dim3(256), 0, st, D, O);
-        if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<1>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
-        if (D.n_gf) hipLaunchKernelGGL(k_jtimes_gen<1>, GRID((size_t)D.n_gf * 64, 256), dim3(256), 0, st, D, O);
+        {
+            Bracket t(*this, SWF_K_BACKSUB);
+            if (D.n_lm) hipLaunchKernelGGL(k_backsub_lm, GRID(D.n_lm, 256), dim3(256), 0, st, D);
+            if (D.n_cl) hipLaunchKernelGGL(k_backsub_clique, dim3(D.n_cl), dim3(64), 0, st, D);
+        }
+        {
+            Bracket t(*this, SWF_K_JTIMES);
+            if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<0>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
+            if (D.n_gf) hipLaunchKernelGGL(k_jtimes_gen<0>, GRID((size_t)D.n_gf * 64, 256), dim3(256), 0, st, D, O);
+        }
+        { Bracket t(*this, SWF_K_DOGLEG); hipLaunchKernelGGL(k_dogleg, dim3(D.n_win), dim3(256), 0, st, D, O); }
+        {
+            Bracket t(*this, SWF_K_JTIMES);
+            if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<1>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
+            if (D.n_gf) hipLaunchKernelGGL(k_jtimes_gen<1>, GRID((size_t)D.n_gf * 64, 256), dim3(256), 0, st, D, O);
+        }
     }
     void cand_eval() {
         DevBatch& D = b->D;
-        if (D.n_proj) hipLaunchKernelGGL(k_eval_proj<false>, GRID(D.n_proj, 256), dim3(256), 0, st, D);
-        if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, dim3(D.n_imu), dim3(64), 0, st, D);
-        if (D.n_sc) hipLaunchKernelGGL(k_eval_scalar<false>, GRID(D.n_sc, 256), dim3(256), 0, st, D);
-        if (D.n_prior) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
-        hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(256), 0, st, D, O);
+        {
+            Bracket t(*this, SWF_K_CAND_EVAL);
+            if (D.n_proj) hipLaunchKernelGGL(k_eval_proj<false>, GRID(D.n_proj, 256), dim3(256), 0, st, D);
+            if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, dim3(D.n_imu), dim3(64), 0, st, D);
+            if (D.n_sc) hipLaunchKernelGGL(k_eval_scalar<false>, GRID(D.n_sc, 256), dim3(256), 0, st, D);
+            if (D.n_prior) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
+        }
+        { Bracket t(*this, SWF_K_DECIDE); hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(256), 0, st, D, O); }
     }
 };
 }  // namespace
@@ -612,50 +646,48 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
     DevBatch& D = b->D;
     Launcher L{ b, to_devopt(opt), b->stream };
     hipStream_t st = b->stream;
-    bool tm = b->timing;
-    if (tm && !b->ev_ok) { for (auto& e : b->ev) HIPCHK(hipEventCreate(&e)); b->ev_ok = true; }
-    // timing groups are accumulated with event pairs per group per iteration only when enabled
-    std::vector<std::array<hipEvent_t, 2>> spans;   // unused placeholder to keep the code simple
-    (void)spans;
-    float acc_eval = 0, acc_elim = 0, acc_red = 0;
-    auto mark = [&](int i) { if (tm) (void)hipEventRecord(b->ev[i], st); };
-    mark(0);
-    hipLaunchKernelGGL(k_init, dim3(D.n_win), dim3(256), 0, st, D, L.O);
+    b->ev_used = 0; b->ev_kind.clear();
     int nlin = 0;
-    auto LIN = [&](int write_S) { L.lin_eval(); L.lin_elim(write_S); nlin++; };
-    LIN(1);
-    if (opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) {
-        L.reduced();
-    } else {
-        for (int it = 1; it <= opt->max_num_iterations; it++) {
+    {
+        Launcher::Bracket total(L, SWF_K_TOTAL);
+        hipLaunchKernelGGL(k_init, dim3(D.n_win), dim3(256), 0, st, D, L.O);
+        auto LIN = [&](int write_S) { L.lin_eval(); L.lin_elim(write_S); nlin++; };
+        LIN(1);
+        if (opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) {
             L.reduced();
-            L.step_rest();
-            L.cand_eval();
-            LIN(it < opt->max_num_iterations ? 1 : 0);
+        } else {
+            for (int it = 1; it <= opt->max_num_iterations; it++) {
+                L.reduced();
+                L.step_rest();
+                L.cand_eval();
+                LIN(it < opt->max_num_iterations ? 1 : 0);
+            }
         }
+        hipLaunchKernelGGL(k_finalize, dim3(D.n_win), dim3(256), 0, st, D, L.O);
     }
-    hipLaunchKernelGGL(k_finalize, dim3(D.n_win), dim3(256), 0, st, D, L.O);
-    mark(1);
     HIPCHK(hipGetLastError());
     b->last = swf_timing{};
-    b->last.jacobian_bytes = b->jac_bytes;
+    b->last.jacobian_bytes = b->jac_bytes; b->last.proj_bytes = b->proj_bytes; b->last.chol_flops = b->chol_flops;
     b->last.n_linearizations = nlin;
     b->last_mode = opt->step_mode;
-    (void)acc_eval; (void)acc_elim; (void)acc_red;
     return SWF_OK;
 }
 
 extern "C" int swf_batch_sync(swf_batch* b) {
     if (!b) return fail(SWF_E_INVALID, "null batch");
     HIPCHK(hipStreamSynchronize(b->stream));
-    if (b->timing && b->ev_ok) {
+    for (int i = 0; i < b->ev_used; i++) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, b->ev[0], b->ev[1]) == hipSuccess) b->last.total_ms = ms;
+        if (hipEventElapsedTime(&ms, b->ev[2 * i], b->ev[2 * i + 1]) == hipSuccess) {
+            int k = b->ev_kind[i];
+            b->last.ms[k] += ms; b->last.calls[k]++;
+        }
     }
+    b->ev_used = 0; b->ev_kind.clear();
     return SWF_OK;
 }
 
-extern "C" int swf_batch_enable_timing(swf_batch* b, int32_t on) { if (!b) return fail(SWF_E_INVALID, "null batch"); b->timing = on != 0; return SWF_OK; }
+extern "C" int swf_batch_enable_timing(swf_batch* b, int32_t mask) { if (!b) return fail(SWF_E_INVALID, "null batch"); b->timing = mask; return SWF_OK; }
 extern "C" int swf_batch_timing(swf_batch* b, swf_timing* out) { if (!b || !out) return fail(SWF_E_INVALID, "bad arguments"); *out = b->last; return SWF_OK; }
 
 extern "C" int swf_batch_download_state(swf_batch* b) {
@@ -686,7 +718,7 @@ extern "C" int swf_batch_summaries(swf_batch* b, swf_summary* out) {
         swf_summary& s = out[i];
         memset(&s, 0, sizeof(s));
         s.initial_cost = ws[i].initial_cost; s.final_cost = ws[i].x_cost;
-        s.minimizer_time_in_seconds = b->last.total_ms * 1e-3;
+        s.minimizer_time_in_seconds = b->last.ms[SWF_K_TOTAL] * 1e-3;
         s.num_successful_steps = ws[i].nsucc; s.num_unsuccessful_steps = ws[i].nunsucc;
         s.num_iterations = ws[i].iter; s.termination = ws[i].status;
         s.reduced_dim = b->win[i].n_red; s.tail_dim = b->hw[i].tail_dim;

@@ -267,7 +267,9 @@ __device__ __forceinline__ double gnss_distance(const double* rr, const double* 
 }
 __device__ __forceinline__ double varerr2(double el, double dt, double mea_var) {
     double b = CLIGHT_D * 5e-12 * dt;
-    double sinel = (double)sinf((float)el);
+    // the reference calls single-precision sinf() (gnss_factor.cpp:100).  glibc's sinf is
+    // correctly rounded; the device libm's is not (1-2 ulp), so round the fp64 sine instead.
+    double sinel = (double)(float)sin((double)(float)el);
     return (mea_var / sinel / sinel) + b * b;
 }
 template <bool JAC>

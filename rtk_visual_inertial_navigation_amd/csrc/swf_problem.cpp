@@ -1,1 +1,336 @@
-// swf_problem.cpp — placeholder; the ceres::Problem-shaped layer is added in the next step.
+// swf_problem.cpp — the ceres::Problem / Solver::Solve shaped surface of include/swf_solver.h.
+//
+// Host bookkeeping only: pointer-keyed parameter blocks and typed factors are flattened into a
+// swf_flat_window (include/swf_types.h) whenever the STRUCTURE changed, and handed to the batch
+// engine (B = 1); per solve only parameter values travel.  Semantics follow what the reference
+// relies on: blocks identified by address, AddParameterBlock on an existing
+// block only re-attaches the manifold (R/swf/swf_core.cpp:53-56), RemoveParameterBlock cascades
+// to its residual blocks (R/factor/gnss_imu_factor.cpp:110-113), blocks that no enabled residual
+// block touches are left out of the solve (ceres removes unused blocks from the reduced program),
+// failures surface through the return code AND summary.termination.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/swf_solver.h"
+
+namespace {
+struct PBlock { int size; int manifold; bool constant; long seq; };
+enum FType { FT_PROJ, FT_IMU, FT_CP, FT_PR, FT_DOP, FT_SP, FT_PRIOR };
+struct PFactor {
+    FType type; bool alive, enabled;
+    std::vector<double*> keys;
+    std::vector<double> data;      // type-specific record
+    double sqrt_info = 0, loss_a = 0;
+    int dim = 0;                   // prior
+};
+}  // namespace
+
+struct swf_problem {
+    std::unordered_map<double*, PBlock> blocks;
+    long seq = 0;
+    std::vector<PFactor> factors;
+    std::vector<double*> order_keys; std::vector<int> order_groups;
+    std::vector<double*> tail_keys;
+    double pbg[3] = {0, 0, 0}, gw[3] = {0, 0, 9.8}, base[3] = {0, 0, 0};
+    bool dirty = true;             // structure changed since the batch was built
+    // flattened form (valid while !dirty)
+    swf_batch* batch = nullptr;
+    swf_flat_window fw{};
+    std::vector<double> pose, sb, lm, sc;
+    std::vector<double*> kpose, ksb, klm, ksc;       // key per pool slot
+    std::vector<uint8_t> is_const;
+    std::vector<int32_t> order_block, order_group;
+    std::vector<int32_t> proj_idx, imu_idx, cp_idx, pr_idx, dop_idx, sp_idx, prior_nblk, prior_dim, prior_blk;
+    std::vector<double> proj_uv, imu_pre, cp_dat, pr_dat, dop_dat, sp_w, prior_J, prior_r0, prior_x0;
+    // exports
+    std::vector<double> S, rhs, L;
+    int hs_row = 0;
+    bool solved = false;
+};
+
+void swf_internal_set_error(const std::string& m);
+static int pfail(int code, const std::string& m) { swf_internal_set_error(m); return code; }
+
+extern "C" {
+
+int swf_problem_create(swf_problem** out) { if (!out) return SWF_E_INVALID; *out = new swf_problem(); return SWF_OK; }
+int swf_problem_destroy(swf_problem* p) {
+    if (!p) return SWF_OK;
+    if (p->batch) swf_batch_destroy(p->batch);
+    delete p;
+    return SWF_OK;
+}
+
+int swf_add_parameter_block(swf_problem* p, double* key, int32_t size, int32_t manifold) {
+    if (!p || !key) return SWF_E_INVALID;
+    if (!(size == 7 || size == 9 || size == 3 || size == 1)) return pfail(SWF_E_UNSUPPORTED, "parameter block size must be 7, 9, 3 or 1");
+    auto it = p->blocks.find(key);
+    if (it != p->blocks.end()) {
+        if (it->second.size != size) return pfail(SWF_E_INVALID, "parameter block re-added with a different size");
+        it->second.manifold = manifold;
+        return SWF_OK;
+    }
+    p->blocks[key] = PBlock{ size, manifold, false, p->seq++ };
+    p->dirty = true;
+    return SWF_OK;
+}
+int swf_has_parameter_block(swf_problem* p, const double* key) { return p && p->blocks.count((double*)key) ? 1 : 0; }
+int swf_remove_parameter_block(swf_problem* p, double* key) {
+    if (!p) return SWF_E_INVALID;
+    auto it = p->blocks.find(key);
+    if (it == p->blocks.end()) return SWF_E_NOTFOUND;
+    for (auto& f : p->factors) if (f.alive && std::find(f.keys.begin(), f.keys.end(), key) != f.keys.end()) f.alive = false;
+    p->blocks.erase(it);
+    p->dirty = true;
+    return SWF_OK;
+}
+static int set_const(swf_problem* p, double* key, bool c) {
+    if (!p) return SWF_E_INVALID;
+    auto it = p->blocks.find(key);
+    if (it == p->blocks.end()) return SWF_E_NOTFOUND;
+    if (it->second.constant != c) { it->second.constant = c; p->dirty = true; }
+    return SWF_OK;
+}
+int swf_set_parameter_block_constant(swf_problem* p, double* key) { return set_const(p, key, true); }
+int swf_set_parameter_block_variable(swf_problem* p, double* key) { return set_const(p, key, false); }
+int swf_is_parameter_block_constant(swf_problem* p, const double* key) {
+    if (!p) return 0;
+    auto it = p->blocks.find((double*)key);
+    return it != p->blocks.end() && it->second.constant ? 1 : 0;
+}
+int swf_parameter_block_size(swf_problem* p, const double* key) {
+    if (!p) return SWF_E_INVALID;
+    auto it = p->blocks.find((double*)key);
+    return it == p->blocks.end() ? SWF_E_NOTFOUND : it->second.size;
+}
+int swf_num_parameter_blocks(swf_problem* p) { return p ? (int)p->blocks.size() : SWF_E_INVALID; }
+int swf_num_residual_blocks(swf_problem* p) {
+    if (!p) return SWF_E_INVALID;
+    int n = 0;
+    for (auto& f : p->factors) if (f.alive) n++;
+    return n;
+}
+
+static swf_factor_id add_factor(swf_problem* p, FType t, std::vector<double*> keys, const std::vector<int>& sizes,
+                                const double* data, size_t ndata) {
+    if (!p) return SWF_E_INVALID;
+    for (size_t i = 0; i < keys.size(); i++) {
+        if (!keys[i]) return SWF_E_INVALID;
+        auto it = p->blocks.find(keys[i]);
+        if (it == p->blocks.end()) {
+            int rc = swf_add_parameter_block(p, keys[i], sizes[i], sizes[i] == 7 ? SWF_MANIFOLD_POSE : SWF_MANIFOLD_NONE);
+            if (rc != SWF_OK) return rc;
+        } else if (it->second.size != sizes[i]) return pfail(SWF_E_INVALID, "factor: parameter block has the wrong size");
+    }
+    PFactor f; f.type = t; f.alive = true; f.enabled = true; f.keys = std::move(keys);
+    if (data && ndata) f.data.assign(data, data + ndata);
+    p->factors.push_back(std::move(f));
+    p->dirty = true;
+    return (swf_factor_id)p->factors.size() - 1;
+}
+
+swf_factor_id swf_add_projection(swf_problem* p, double* pose, double* ex, double* pt, const double uv[2], double sqrt_info, double loss_a) {
+    swf_factor_id id = add_factor(p, FT_PROJ, { pose, ex, pt }, { 7, 7, 3 }, uv, 2);
+    if (id >= 0) { p->factors[id].sqrt_info = sqrt_info; p->factors[id].loss_a = loss_a; }
+    return id;
+}
+swf_factor_id swf_add_imu(swf_problem* p, double* pi, double* si, double* pj, double* sj, const double* pre) {
+    return add_factor(p, FT_IMU, { pi, si, pj, sj }, { 7, 9, 7, 9 }, pre, SWF_PRE_DOUBLES);
+}
+swf_factor_id swf_add_rtk_carrier_phase(swf_problem* p, double* pose, double* amb, double* clk, const double* dat) {
+    return add_factor(p, FT_CP, { pose, amb, clk }, { 7, 1, 1 }, dat, SWF_CP_DOUBLES);
+}
+swf_factor_id swf_add_rtk_pseudorange(swf_problem* p, double* pose, double* clk, const double* dat) {
+    return add_factor(p, FT_PR, { pose, clk }, { 7, 1 }, dat, SWF_PR_DOUBLES);
+}
+swf_factor_id swf_add_doppler(swf_problem* p, double* sbp, double* drift, double* pose, const double* dat) {
+    return add_factor(p, FT_DOP, { sbp, drift, pose }, { 9, 1, 7 }, dat, SWF_DOP_DOUBLES);
+}
+swf_factor_id swf_add_scalar_prior(swf_problem* p, double* scalar, double w) {
+    return add_factor(p, FT_SP, { scalar }, { 1 }, &w, 1);
+}
+swf_factor_id swf_add_linear_prior(swf_problem* p, double* const* keys, int32_t n_keys, const double* J, const double* r0, const double* x0) {
+    if (!p || !keys || n_keys <= 0 || !J || !r0 || !x0) return SWF_E_INVALID;
+    std::vector<double*> k(keys, keys + n_keys);
+    std::vector<int> sizes;
+    int dim = 0, gsum = 0;
+    for (double* q : k) {
+        auto it = p->blocks.find(q);
+        if (it == p->blocks.end()) return pfail(SWF_E_NOTFOUND, "linear prior: unknown parameter block (sizes come from the problem)");
+        sizes.push_back(it->second.size);
+        dim += it->second.size == 7 ? 6 : it->second.size; gsum += it->second.size;
+    }
+    std::vector<double> data;
+    data.insert(data.end(), J, J + (size_t)dim * dim);
+    data.insert(data.end(), r0, r0 + dim);
+    data.insert(data.end(), x0, x0 + gsum);
+    swf_factor_id id = add_factor(p, FT_PRIOR, k, sizes, data.data(), data.size());
+    if (id >= 0) p->factors[id].dim = dim;
+    return id;
+}
+int swf_remove_factor(swf_problem* p, swf_factor_id id) {
+    if (!p || id < 0 || id >= (int)p->factors.size() || !p->factors[id].alive) return SWF_E_NOTFOUND;
+    p->factors[id].alive = false; p->dirty = true;
+    return SWF_OK;
+}
+int swf_factor_set_enabled(swf_problem* p, swf_factor_id id, int32_t on) {
+    if (!p || id < 0 || id >= (int)p->factors.size() || !p->factors[id].alive) return SWF_E_NOTFOUND;
+    bool b = on != 0;
+    if (p->factors[id].enabled != b) { p->factors[id].enabled = b; p->dirty = true; }
+    return SWF_OK;
+}
+int swf_set_constants(swf_problem* p, const double pbg[3], const double gw[3], const double base[3]) {
+    if (!p) return SWF_E_INVALID;
+    for (int k = 0; k < 3; k++) { if (pbg) p->pbg[k] = pbg[k]; if (gw) p->gw[k] = gw[k]; if (base) p->base[k] = base[k]; }
+    p->dirty = true;
+    return SWF_OK;
+}
+int swf_set_ordering(swf_problem* p, double* const* keys, const int32_t* groups, int32_t n) {
+    if (!p || (n > 0 && (!keys || !groups))) return SWF_E_INVALID;
+    p->order_keys.assign(keys, keys + n); p->order_groups.assign(groups, groups + n);
+    p->dirty = true;
+    return SWF_OK;
+}
+int swf_set_export_tail(swf_problem* p, double* const* keys, int32_t n) {
+    if (!p || (n > 0 && !keys)) return SWF_E_INVALID;
+    p->tail_keys.assign(keys, keys + n);
+    p->dirty = true;
+    return SWF_OK;
+}
+
+static int flatten(swf_problem* p) {
+    // blocks touched by at least one live, enabled factor, in insertion order per pool
+    std::map<long, double*> used;
+    for (auto& f : p->factors) if (f.alive && f.enabled) for (double* k : f.keys) used[p->blocks[k].seq] = k;
+    p->kpose.clear(); p->ksb.clear(); p->klm.clear(); p->ksc.clear();
+    for (auto& kv : used) {
+        int s = p->blocks[kv.second].size;
+        (s == 7 ? p->kpose : s == 9 ? p->ksb : s == 3 ? p->klm : p->ksc).push_back(kv.second);
+    }
+    int nP = (int)p->kpose.size(), nS = (int)p->ksb.size(), nL = (int)p->klm.size(), nC = (int)p->ksc.size();
+    std::unordered_map<double*, int> pool_idx, bid;
+    for (int i = 0; i < nP; i++) { pool_idx[p->kpose[i]] = i; bid[p->kpose[i]] = i; }
+    for (int i = 0; i < nS; i++) { pool_idx[p->ksb[i]] = i; bid[p->ksb[i]] = nP + i; }
+    for (int i = 0; i < nL; i++) { pool_idx[p->klm[i]] = i; bid[p->klm[i]] = nP + nS + i; }
+    for (int i = 0; i < nC; i++) { pool_idx[p->ksc[i]] = i; bid[p->ksc[i]] = nP + nS + nL + i; }
+    p->pose.assign(7 * (size_t)nP, 0); p->sb.assign(9 * (size_t)nS, 0); p->lm.assign(3 * (size_t)nL, 0); p->sc.assign((size_t)nC, 0);
+    p->is_const.assign((size_t)nP + nS + nL + nC, 0);
+    for (auto& kv : bid) p->is_const[kv.second] = p->blocks[kv.first].constant ? 1 : 0;
+    // ordering: keep the caller's (group, position) for used variable blocks; the tail is whatever
+    // the caller listed in parameter_head, expected at the end of the ordering
+    p->order_block.clear(); p->order_group.clear();
+    for (size_t i = 0; i < p->order_keys.size(); i++) {
+        auto it = bid.find(p->order_keys[i]);
+        if (it == bid.end() || p->is_const[it->second]) continue;
+        p->order_block.push_back(it->second); p->order_group.push_back(p->order_groups[i]);
+    }
+    int n_tail = 0;
+    for (int i = (int)p->order_block.size() - 1; i >= 0; i--) {
+        bool in_tail = false;
+        for (double* t : p->tail_keys) { auto it = bid.find(t); if (it != bid.end() && it->second == p->order_block[i]) in_tail = true; }
+        if (!in_tail) break;
+        n_tail++;
+    }
+    // factors
+    p->proj_idx.clear(); p->proj_uv.clear(); p->imu_idx.clear(); p->imu_pre.clear(); p->cp_idx.clear(); p->cp_dat.clear();
+    p->pr_idx.clear(); p->pr_dat.clear(); p->dop_idx.clear(); p->dop_dat.clear(); p->sp_idx.clear(); p->sp_w.clear();
+    p->prior_nblk.clear(); p->prior_dim.clear(); p->prior_blk.clear(); p->prior_J.clear(); p->prior_r0.clear(); p->prior_x0.clear();
+    double sqrt_info = 0, loss_a = 0; bool have_proj = false;
+    for (auto& f : p->factors) {
+        if (!f.alive || !f.enabled) continue;
+        switch (f.type) {
+        case FT_PROJ:
+            if (have_proj && (f.sqrt_info != sqrt_info || f.loss_a != loss_a))
+                return pfail(SWF_E_UNSUPPORTED, "projection factors must share sqrt_info and loss (static member in the reference)");
+            have_proj = true; sqrt_info = f.sqrt_info; loss_a = f.loss_a;
+            for (double* k : f.keys) p->proj_idx.push_back(pool_idx[k]);
+            p->proj_uv.insert(p->proj_uv.end(), f.data.begin(), f.data.end());
+            break;
+        case FT_IMU: for (double* k : f.keys) p->imu_idx.push_back(pool_idx[k]); p->imu_pre.insert(p->imu_pre.end(), f.data.begin(), f.data.end()); break;
+        case FT_CP: for (double* k : f.keys) p->cp_idx.push_back(pool_idx[k]); p->cp_dat.insert(p->cp_dat.end(), f.data.begin(), f.data.end()); break;
+        case FT_PR: for (double* k : f.keys) p->pr_idx.push_back(pool_idx[k]); p->pr_dat.insert(p->pr_dat.end(), f.data.begin(), f.data.end()); break;
+        case FT_DOP: for (double* k : f.keys) p->dop_idx.push_back(pool_idx[k]); p->dop_dat.insert(p->dop_dat.end(), f.data.begin(), f.data.end()); break;
+        case FT_SP: p->sp_idx.push_back(pool_idx[f.keys[0]]); p->sp_w.push_back(f.data[0]); break;
+        case FT_PRIOR: {
+            int dim = f.dim, gsum = 0;
+            p->prior_nblk.push_back((int)f.keys.size()); p->prior_dim.push_back(dim);
+            for (double* k : f.keys) { p->prior_blk.push_back(bid[k]); gsum += p->blocks[k].size; }
+            p->prior_J.insert(p->prior_J.end(), f.data.begin(), f.data.begin() + (size_t)dim * dim);
+            p->prior_r0.insert(p->prior_r0.end(), f.data.begin() + (size_t)dim * dim, f.data.begin() + (size_t)dim * dim + dim);
+            p->prior_x0.insert(p->prior_x0.end(), f.data.begin() + (size_t)dim * dim + dim, f.data.begin() + (size_t)dim * dim + dim + gsum);
+            break;
+        }
+        }
+    }
+    swf_flat_window& w = p->fw;
+    memset(&w, 0, sizeof(w));
+    w.n_pose = nP; w.pose = p->pose.data(); w.n_sb = nS; w.sb = p->sb.data(); w.n_lm = nL; w.lm = p->lm.data(); w.n_sc = nC; w.sc = p->sc.data();
+    w.is_const = p->is_const.data();
+    w.n_order = (int)p->order_block.size(); w.order_block = p->order_block.data(); w.order_group = p->order_group.data(); w.n_tail = n_tail;
+    w.n_proj = (int)p->proj_idx.size() / 3; w.proj_idx = p->proj_idx.data(); w.proj_uv = p->proj_uv.data();
+    w.proj_sqrt_info = sqrt_info; w.proj_loss_a = loss_a;
+    w.n_imu = (int)p->imu_idx.size() / 4; w.imu_idx = p->imu_idx.data(); w.imu_pre = p->imu_pre.data();
+    w.n_cp = (int)p->cp_idx.size() / 3; w.cp_idx = p->cp_idx.data(); w.cp_dat = p->cp_dat.data();
+    w.n_pr = (int)p->pr_idx.size() / 2; w.pr_idx = p->pr_idx.data(); w.pr_dat = p->pr_dat.data();
+    w.n_dop = (int)p->dop_idx.size() / 3; w.dop_idx = p->dop_idx.data(); w.dop_dat = p->dop_dat.data();
+    w.n_sp = (int)p->sp_idx.size(); w.sp_idx = p->sp_idx.data(); w.sp_w = p->sp_w.data();
+    w.n_prior = (int)p->prior_nblk.size(); w.prior_nblk = p->prior_nblk.data(); w.prior_dim = p->prior_dim.data();
+    w.prior_blk = p->prior_blk.data(); w.prior_J = p->prior_J.data(); w.prior_r0 = p->prior_r0.data(); w.prior_x0 = p->prior_x0.data();
+    for (int k = 0; k < 3; k++) { w.pbg[k] = p->pbg[k]; w.gw[k] = p->gw[k]; w.base[k] = p->base[k]; }
+    return SWF_OK;
+}
+
+static void gather_values(swf_problem* p) {      // Vector2Double direction: caller memory -> staging pools
+    for (size_t i = 0; i < p->kpose.size(); i++) memcpy(&p->pose[7 * i], p->kpose[i], 7 * sizeof(double));
+    for (size_t i = 0; i < p->ksb.size(); i++) memcpy(&p->sb[9 * i], p->ksb[i], 9 * sizeof(double));
+    for (size_t i = 0; i < p->klm.size(); i++) memcpy(&p->lm[3 * i], p->klm[i], 3 * sizeof(double));
+    for (size_t i = 0; i < p->ksc.size(); i++) p->sc[i] = *p->ksc[i];
+}
+static void scatter_values(swf_problem* p) {     // Double2Vector direction; constant blocks are never written
+    auto cst = [&](double* k) { return p->blocks[k].constant; };
+    for (size_t i = 0; i < p->kpose.size(); i++) if (!cst(p->kpose[i])) memcpy(p->kpose[i], &p->pose[7 * i], 7 * sizeof(double));
+    for (size_t i = 0; i < p->ksb.size(); i++) if (!cst(p->ksb[i])) memcpy(p->ksb[i], &p->sb[9 * i], 9 * sizeof(double));
+    for (size_t i = 0; i < p->klm.size(); i++) if (!cst(p->klm[i])) memcpy(p->klm[i], &p->lm[3 * i], 3 * sizeof(double));
+    for (size_t i = 0; i < p->ksc.size(); i++) if (!cst(p->ksc[i])) *p->ksc[i] = p->sc[i];
+}
+
+int swf_problem_solve(swf_problem* p, const swf_options* opt, swf_summary* summary) {
+    if (!p || !opt || !summary) return SWF_E_INVALID;
+    int rc;
+    if (p->dirty || !p->batch) {
+        if (p->batch) { swf_batch_destroy(p->batch); p->batch = nullptr; }
+        if ((rc = flatten(p)) != SWF_OK) return rc;
+        gather_values(p);
+        const swf_flat_window* wp = &p->fw;
+        if ((rc = swf_batch_create(&wp, 1, nullptr, &p->batch)) != SWF_OK) return rc;
+        p->dirty = false;
+    } else {
+        gather_values(p);
+        if ((rc = swf_batch_upload_state(p->batch)) != SWF_OK) return rc;
+    }
+    swf_batch_enable_timing(p->batch, 1);      // bracket the whole solve: summary.minimizer_time_in_seconds
+    if ((rc = swf_batch_solve(p->batch, opt)) != SWF_OK) return rc;
+    if ((rc = swf_batch_sync(p->batch)) != SWF_OK) return rc;
+    if ((rc = swf_batch_download_state(p->batch)) != SWF_OK) return rc;
+    scatter_values(p);
+    if ((rc = swf_batch_summaries(p->batch, summary)) != SWF_OK) return rc;
+    p->hs_row = summary->reduced_dim;
+    size_t n = (size_t)p->hs_row;
+    p->S.assign(n * n, 0); p->rhs.assign(n, 0); p->L.assign(n * n, 0);
+    if ((rc = swf_batch_export_reduced(p->batch, 0, p->S.data(), p->rhs.data(), p->L.data())) != SWF_OK) return rc;
+    p->solved = true;
+    return SWF_OK;
+}
+
+int swf_get_reduced(swf_problem* p, const double** S, const double** rhs, const double** L, int32_t* hs_row) {
+    if (!p) return SWF_E_INVALID;
+    if (!p->solved) return SWF_E_STATE;
+    if (S) *S = p->S.data(); if (rhs) *rhs = p->rhs.data(); if (L) *L = p->L.data(); if (hs_row) *hs_row = p->hs_row;
+    return SWF_OK;
+}
+
+}  // extern "C"

@@ -19,9 +19,13 @@ class SwfError(RuntimeError):
     pass
 
 
+K_NAMES = ["total", "eval_proj", "eval_imu", "eval_scalar", "eval_prior", "lm_elim", "clique_elim", "lm_gemm",
+           "assemble", "chol_solve", "backsub", "jtimes", "dogleg", "cand_eval", "decide", "_15"]
+
+
 class TimingC(C.Structure):
-    _fields_ = [("total_ms", C.c_double), ("eval_ms", C.c_double), ("eliminate_ms", C.c_double),
-                ("reduced_ms", C.c_double), ("other_ms", C.c_double), ("jacobian_bytes", C.c_int64),
+    _fields_ = [("ms", C.c_double * 16), ("calls", C.c_int32 * 16), ("jacobian_bytes", C.c_int64),
+                ("proj_bytes", C.c_int64), ("chol_flops", C.c_int64),
                 ("n_linearizations", C.c_int32), ("reserved", C.c_int32)]
 
 
@@ -138,10 +142,189 @@ class BatchSolver:
                                             y.ctypes.data_as(_pd)), "swf_batch_export_vectors")
         return g, d, y
 
-    def enable_timing(self, on=True):
-        _chk(lib().swf_batch_enable_timing(self._h, C.c_int32(1 if on else 0)), "swf_batch_enable_timing")
+    def enable_timing(self, mask=1):
+        """mask: bit k brackets kernel K_NAMES[k] with a HIP event pair per launch (bit 0 = whole solve);
+        True = everything."""
+        if mask is True:
+            mask = 0x7fff
+        _chk(lib().swf_batch_enable_timing(self._h, C.c_int32(int(mask))), "swf_batch_enable_timing")
 
     def timing(self):
         t = TimingC()
         _chk(lib().swf_batch_timing(self._h, C.byref(t)), "swf_batch_timing")
-        return {k: getattr(t, k) for k, _ in TimingC._fields_}
+        d = dict(jacobian_bytes=t.jacobian_bytes, proj_bytes=t.proj_bytes, chol_flops=t.chol_flops,
+                 n_linearizations=t.n_linearizations, total_ms=t.ms[0])
+        d["kernels"] = {K_NAMES[k]: dict(ms=t.ms[k], calls=t.calls[k]) for k in range(15) if t.calls[k]}
+        return d
+
+
+class Problem:
+    """ceres::Problem-shaped host mirror (swf_problem_*).  Parameter blocks are numpy float64
+    arrays owned by the caller and identified by address, as in Ceres; Solve() reads them and
+    writes the result back in place.  Method names follow the ceres::Problem members the
+    reference uses."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _chk(lib().swf_problem_create(C.byref(self._h)), "swf_problem_create")
+        self._keep = {}          # address -> array (keeps caller arrays alive)
+
+    def close(self):
+        if self._h:
+            lib().swf_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _p(self, arr):
+        assert isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]
+        self._keep[arr.ctypes.data] = arr
+        return arr.ctypes.data_as(_pd)
+
+    @staticmethod
+    def _d(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return a, a.ctypes.data_as(_pd)
+
+    # --- ceres::Problem members
+    def AddParameterBlock(self, arr, size, pose_manifold=False):
+        _chk(lib().swf_add_parameter_block(self._h, self._p(arr), C.c_int32(size), C.c_int32(1 if pose_manifold else 0)), "AddParameterBlock")
+
+    def HasParameterBlock(self, arr):
+        return bool(lib().swf_has_parameter_block(self._h, arr.ctypes.data_as(_pd)))
+
+    def RemoveParameterBlock(self, arr):
+        _chk(lib().swf_remove_parameter_block(self._h, arr.ctypes.data_as(_pd)), "RemoveParameterBlock")
+
+    def SetParameterBlockConstant(self, arr):
+        _chk(lib().swf_set_parameter_block_constant(self._h, arr.ctypes.data_as(_pd)), "SetParameterBlockConstant")
+
+    def SetParameterBlockVariable(self, arr):
+        _chk(lib().swf_set_parameter_block_variable(self._h, arr.ctypes.data_as(_pd)), "SetParameterBlockVariable")
+
+    def IsParameterBlockConstant(self, arr):
+        return bool(lib().swf_is_parameter_block_constant(self._h, arr.ctypes.data_as(_pd)))
+
+    def ParameterBlockSize(self, arr):
+        return lib().swf_parameter_block_size(self._h, arr.ctypes.data_as(_pd))
+
+    def NumParameterBlocks(self):
+        return lib().swf_num_parameter_blocks(self._h)
+
+    def NumResidualBlocks(self):
+        return lib().swf_num_residual_blocks(self._h)
+
+    def RemoveResidualBlock(self, fid):
+        _chk(lib().swf_remove_factor(self._h, C.c_int32(fid)), "RemoveResidualBlock")
+
+    def SetResidualBlockUsed(self, fid, on):          # ResidualBlock::is_use of the modified Ceres
+        _chk(lib().swf_factor_set_enabled(self._h, C.c_int32(fid), C.c_int32(1 if on else 0)), "is_use")
+
+    # --- typed AddResidualBlock()s
+    def _fid(self, rc, what):
+        if rc < 0:
+            raise SwfError("%s failed (%d): %s" % (what, rc, lib().swf_last_error().decode()))
+        return rc
+
+    def AddProjection(self, pose, ex, point, uv, sqrt_info=1000.0 / 1.5, cauchy_a=1.0):
+        a, pa = self._d(uv)
+        return self._fid(lib().swf_add_projection(self._h, self._p(pose), self._p(ex), self._p(point), pa,
+                                                  C.c_double(sqrt_info), C.c_double(cauchy_a)), "AddProjection")
+
+    def AddImu(self, pose_i, sb_i, pose_j, sb_j, pre):
+        a, pa = self._d(pre)
+        return self._fid(lib().swf_add_imu(self._h, self._p(pose_i), self._p(sb_i), self._p(pose_j), self._p(sb_j), pa), "AddImu")
+
+    def AddRtkCarrierPhase(self, pose, amb, clk, dat):
+        a, pa = self._d(dat)
+        return self._fid(lib().swf_add_rtk_carrier_phase(self._h, self._p(pose), self._p(amb), self._p(clk), pa), "AddRtkCarrierPhase")
+
+    def AddRtkPseudorange(self, pose, clk, dat):
+        a, pa = self._d(dat)
+        return self._fid(lib().swf_add_rtk_pseudorange(self._h, self._p(pose), self._p(clk), pa), "AddRtkPseudorange")
+
+    def AddDoppler(self, sb, drift, pose, dat):
+        a, pa = self._d(dat)
+        return self._fid(lib().swf_add_doppler(self._h, self._p(sb), self._p(drift), self._p(pose), pa), "AddDoppler")
+
+    def AddScalarPrior(self, scalar, w):
+        return self._fid(lib().swf_add_scalar_prior(self._h, self._p(scalar), C.c_double(w)), "AddScalarPrior")
+
+    def AddLinearPrior(self, blocks, J, r0, x0):
+        keys = (_pd * len(blocks))(*[self._p(b) for b in blocks])
+        aJ, pJ = self._d(J); ar, pr = self._d(r0); ax, px = self._d(x0)
+        return self._fid(lib().swf_add_linear_prior(self._h, keys, C.c_int32(len(blocks)), pJ, pr, px), "AddLinearPrior")
+
+    # --- window constants, ordering, parameter_head
+    def SetConstants(self, pbg, gw, base):
+        a, pa = self._d(pbg); b, pb = self._d(gw); c, pc = self._d(base)
+        _chk(lib().swf_set_constants(self._h, pa, pb, pc), "SetConstants")
+
+    def SetOrdering(self, blocks, groups):
+        keys = (_pd * len(blocks))(*[b.ctypes.data_as(_pd) for b in blocks])
+        g = np.ascontiguousarray(groups, dtype=np.int32)
+        _chk(lib().swf_set_ordering(self._h, keys, g.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(len(blocks))), "SetOrdering")
+
+    def SetParameterHead(self, blocks):
+        keys = (_pd * max(len(blocks), 1))(*[b.ctypes.data_as(_pd) for b in blocks])
+        _chk(lib().swf_set_export_tail(self._h, keys, C.c_int32(len(blocks))), "SetParameterHead")
+
+    # --- ceres::Solve
+    def Solve(self, opt=None):
+        opt = opt if opt is not None else default_options()
+        sm = SummaryC()
+        _chk(lib().swf_problem_solve(self._h, C.byref(opt), C.byref(sm)), "Solve")
+        return sm
+
+    def GetReduced(self):
+        S, r, L, n = _pd(), _pd(), _pd(), C.c_int32()
+        _chk(lib().swf_get_reduced(self._h, C.byref(S), C.byref(r), C.byref(L), C.byref(n)), "GetReduced")
+        n = n.value
+        return (np.ctypeslib.as_array(S, (n, n)).copy(), np.ctypeslib.as_array(r, (n,)).copy(),
+                np.ctypeslib.as_array(L, (n, n)).copy())
+
+
+def problem_from_window(w):
+    """Build a Problem from a FlatWindow the way the estimator would (AddParameterBlock /
+    AddResidualBlock / SetParameterBlockConstant / ordering), returning (problem, blocks) where
+    blocks[global_id] is the numpy parameter block."""
+    P = Problem()
+    a = w.a
+    pose = [a["pose"].reshape(-1, 7)[i].copy() for i in range(w.n_pose)]
+    sb = [a["sb"].reshape(-1, 9)[i].copy() for i in range(w.n_sb)]
+    lm = [a["lm"].reshape(-1, 3)[i].copy() for i in range(w.n_lm)]
+    sc = [a["sc"][i:i + 1].copy() for i in range(w.n_sc)]
+    blocks = pose + sb + lm + sc
+    P.SetConstants(w.pbg, w.gw, w.base)
+    for b in pose:
+        P.AddParameterBlock(b, 7, True)
+    for p_, e_, l_, uv in zip(*a["proj_idx"].reshape(-1, 3).T, a["proj_uv"].reshape(-1, 2)):
+        P.AddProjection(pose[p_], pose[e_], lm[l_], uv, w.proj_sqrt_info, w.proj_loss_a)
+    for ix, pre in zip(a["imu_idx"].reshape(-1, 4), a["imu_pre"].reshape(-1, 293)):
+        P.AddImu(pose[ix[0]], sb[ix[1]], pose[ix[2]], sb[ix[3]], pre)
+    for ix, d in zip(a["cp_idx"].reshape(-1, 3), a["cp_dat"].reshape(-1, 9)):
+        P.AddRtkCarrierPhase(pose[ix[0]], sc[ix[1]], sc[ix[2]], d)
+    for ix, d in zip(a["pr_idx"].reshape(-1, 2), a["pr_dat"].reshape(-1, 7)):
+        P.AddRtkPseudorange(pose[ix[0]], sc[ix[1]], d)
+    for ix, d in zip(a["dop_idx"].reshape(-1, 3), a["dop_dat"].reshape(-1, 8)):
+        P.AddDoppler(sb[ix[0]], sc[ix[1]], pose[ix[2]], d)
+    for i, wv in zip(a["sp_idx"], a["sp_w"]):
+        P.AddScalarPrior(sc[i], wv)
+    bo = jo = ro = xo = 0
+    for nb, dim in zip(a["prior_nblk"], a["prior_dim"]):
+        ids = a["prior_blk"][bo:bo + nb]
+        gs = sum(blocks[i].size for i in ids)
+        P.AddLinearPrior([blocks[i] for i in ids], a["prior_J"].ravel()[jo:jo + dim * dim],
+                         a["prior_r0"][ro:ro + dim], a["prior_x0"][xo:xo + gs])
+        bo += nb; jo += dim * dim; ro += dim; xo += gs
+    for i, c in enumerate(a["is_const"]):
+        if c:
+            P.SetParameterBlockConstant(blocks[i])
+    P.SetOrdering([blocks[i] for i in a["order_block"]], a["order_group"])
+    n_tail = w.n_tail
+    P.SetParameterHead([blocks[i] for i in a["order_block"][len(a["order_block"]) - n_tail:]] if n_tail else [])
+    return P, blocks

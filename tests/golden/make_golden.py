@@ -1,0 +1,60 @@
+"""Mints the golden fixtures from the CPU oracle.  Run here (container), commit the .npz:
+    python tests/golden/make_golden.py
+A fixture = the complete flat window (inputs) + the oracle's cost/step sequence, final state and
+first reduced system (expected outputs).  Pure data; nothing of the reference is involved (it has
+no tests or vectors for this path and cannot be built here)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+from rtk_visual_inertial_navigation_amd import synth                      # noqa: E402
+from rtk_visual_inertial_navigation_amd.flat import FlatWindow, default_options  # noqa: E402
+
+CASES = {
+    "vi_k4_f12": dict(config_id=2, K=4, F=12, S=0, seed=101),
+    "rtk_k5_f16_s4": dict(config_id=3, K=5, F=16, S=4, seed=202),
+    "dense_prior_k14_f30_s4": dict(config_id=5, K=14, F=30, S=4, seed=303),
+}
+ITERS = 6
+
+
+def save_case(path, w, gold):
+    d = {"a_" + k: v for k, v in w.a.items()}
+    d.update(n_tail=w.n_tail, proj_sqrt_info=w.proj_sqrt_info, proj_loss_a=w.proj_loss_a,
+             pbg=w.pbg, gw=w.gw, base=w.base)
+    d.update({"g_" + k: v for k, v in gold.items()})
+    np.savez_compressed(path, **d)
+
+
+def load_case(path):
+    z = np.load(path)
+    kw = {k[2:]: z[k] for k in z.files if k.startswith("a_")}
+    w = FlatWindow(n_tail=int(z["n_tail"]), proj_sqrt_info=float(z["proj_sqrt_info"]),
+                   proj_loss_a=float(z["proj_loss_a"]), pbg=z["pbg"], gw=z["gw"], base=z["base"], **kw)
+    gold = {k[2:]: z[k] for k in z.files if k.startswith("g_")}
+    return w, gold
+
+
+if __name__ == "__main__":
+    import oracle_binding as ob
+    for name, kw in CASES.items():
+        w0 = synth.make_window(**kw)
+        w = w0.copy()
+        sm, ex = ob.solve(w, default_options(max_num_iterations=ITERS))
+        wa = w0.copy()
+        sa, ea = ob.solve(wa, default_options(step_mode=1))
+        rows = sm.rows()
+        gold = dict(iters=ITERS, costs=np.array([r["cost"] for r in rows]),
+                    ok=np.array([r["step_is_successful"] for r in rows]),
+                    radius=np.array([r["trust_region_radius"] for r in rows]),
+                    step_norm=np.array([r["step_norm"] for r in rows]),
+                    pose=w.a["pose"], sb=w.a["sb"], lm=w.a["lm"], sc=w.a["sc"],
+                    S0=ea["S"], rhs0=ea["rhs"], L0=ea["L"], termination=sm.termination)
+        save_case(os.path.join(HERE, name + ".npz"), w0, gold)
+        print(name, os.path.getsize(os.path.join(HERE, name + ".npz")), "bytes; final cost", sm.final_cost)

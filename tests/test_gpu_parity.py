@@ -1,0 +1,180 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI, libswf_hip.so) against the CPU
+oracle on the same seeded windows, against the committed golden fixtures, and through
+size-independent properties at the full BASELINE sizes.
+
+Tolerances (fp64, stated per north_star "matched to a stated fp64 tolerance"):
+  * linearisation products (cost, gradient, squared column norms, reduced S/rhs): 1e-11 relative
+    to the largest entry — pure summation-order / FMA-contraction differences;
+  * Cholesky factor L: 1e-9 (S has condition number ~1e11, scales span ECEF metres to gyro bias);
+  * cost sequence over 8 dogleg iterations: 1e-8 relative, with IDENTICAL accept/reject decisions
+    and trust-region radii (1e-9) — differences are rounding amplified through cond(S);
+  * elimination ordering: bit-exact (checked through the dims and the export layout).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from rtk_visual_inertial_navigation_amd import synth, solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def gpu_solve(w, opt):
+    bs = solver.BatchSolver([w])
+    sm = bs.solve(opt)[0]
+    return bs, sm
+
+
+CASES = [
+    dict(config_id=2),                                # cfg2: 10 KF / 100 features, VI only
+    dict(config_id=3),                                # cfg3: 20 KF / 300 features / 10 sats
+    dict(config_id=2, K=3, F=6, S=0, seed=7),         # tiny
+    dict(config_id=3, K=4, F=9, S=3, seed=8),         # tiny RTK
+    dict(config_id=3, K=7, F=33, S=12, seed=9),       # ragged sizes (nothing a multiple of 16/32/64)
+    dict(config_id=5, K=14, F=40, S=4, seed=10),      # dense marginalisation prior over 13 poses
+]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_linearisation_and_reduced_system_match_oracle(kw):
+    w0 = synth.make_window(**kw)
+    wo, wg = w0.copy(), w0.copy()
+    so, eo = ob.solve(wo, default_options(step_mode=1))
+    bs, sg = gpu_solve(wg, default_options(step_mode=1))
+    d = bs.dims(0)
+    assert (d["n_loc"], d["n_e"], d["n_red"]) == (eo["n_loc"], eo["n_e"], eo["n_red"])   # ordering
+    assert sg.termination == so.termination == 7
+    assert abs(sg.initial_cost - so.initial_cost) <= 1e-12 * so.initial_cost
+    g, dg, y = bs.export_vectors(0)
+    S, rhs, L = bs.export_reduced(0)
+    assert rel(g, eo["grad"]) < 1e-11
+    assert rel(dg, eo["diag"]) < 1e-11
+    assert rel(S, eo["S"]) < 1e-11 and np.abs(S - S.T).max() == 0
+    assert rel(rhs, eo["rhs"]) < 1e-10
+    assert rel(L, eo["L"]) < 1e-9
+    assert rel(L @ L.T, S) < 1e-12                     # the exported factor reproduces S
+    assert rel(y[d["n_e"]:], eo["gn_step"][d["n_e"]:]) < 1e-6      # S^-1 rhs at cond ~1e11
+    bs.close()
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_dogleg_cost_and_step_sequence_matches_oracle(kw):
+    w0 = synth.make_window(**kw)
+    wo, wg = w0.copy(), w0.copy()
+    so, _ = ob.solve(wo, default_options(max_num_iterations=8), export=False)
+    bs, sg = gpu_solve(wg, default_options(max_num_iterations=8))
+    ro, rg = so.rows(), sg.rows()
+    assert sg.termination == so.termination and sg.num_iterations == so.num_iterations
+    assert [r["step_is_successful"] for r in rg] == [r["step_is_successful"] for r in ro]
+    for a, b in zip(rg, ro):
+        assert abs(a["cost"] - b["cost"]) <= 1e-8 * abs(b["cost"])
+        assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-9 * b["trust_region_radius"]
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-6 * (b["step_norm"] + 1e-12)
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-5 * b["gradient_max_norm"] + 1e-9
+    assert np.abs(wg.a["pose"] - wo.a["pose"]).max() < 1e-6
+    assert np.abs(wg.a["sb"] - wo.a["sb"]).max() < 1e-6
+    # quaternions stay normalised on the device too
+    q = wg.a["pose"].reshape(-1, 7)[:, 3:]
+    assert np.abs(np.linalg.norm(q, axis=1) - 1).max() < 1e-14
+    bs.close()
+
+
+def test_golden_fixtures():
+    from golden.make_golden import load_case
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert files
+    for f in files:
+        w, gold = load_case(f)
+        wa = w.copy()
+        bs, sa = gpu_solve(wa, default_options(step_mode=1))
+        S, rhs, L = bs.export_reduced(0)
+        assert rel(S, gold["S0"]) < 1e-11 and rel(rhs, gold["rhs0"]) < 1e-10 and rel(L, gold["L0"]) < 1e-9
+        bs.close()
+        bs, sm = gpu_solve(w, default_options(max_num_iterations=int(gold["iters"])))
+        costs = np.array([r["cost"] for r in sm.rows()])
+        assert rel(costs, gold["costs"]) < 1e-8
+        assert np.array_equal(np.array([r["step_is_successful"] for r in sm.rows()]), gold["ok"])
+        assert np.abs(w.a["pose"] - gold["pose"]).max() < 1e-6
+        bs.close()
+
+
+def test_batch_equals_single_window_solves_bitwise():
+    """Windows are independent units: solving them in one heterogeneous batch must give exactly
+    (bit for bit) what solving each alone gives, and repeated solves must be bit-reproducible
+    (fixed accumulation order, no float atomics)."""
+    ws = [synth.make_window(3, K=6, F=30, S=5, seed=40), synth.make_window(2, K=5, F=20, S=0, seed=41),
+          synth.make_window(3, K=8, F=45, S=6, seed=42), synth.make_window(5, K=14, F=35, S=4, seed=43)]
+    singles = []
+    for w in ws:
+        c = w.copy()
+        bs, sm = gpu_solve(c, default_options())
+        singles.append((c, [r["cost"] for r in sm.rows()]))
+        bs.close()
+    batch = [w.copy() for w in ws]
+    bs = solver.BatchSolver(batch)
+    sms = bs.solve(default_options())
+    for (c, costs), wb, sm in zip(singles, batch, sms):
+        assert [r["cost"] for r in sm.rows()] == costs
+        for k in ("pose", "sb", "lm", "sc"):
+            assert np.array_equal(c.a[k], wb.a[k])
+    # re-solve from the uploaded state: identical again
+    bs.reset_state()
+    sms2 = bs.solve(default_options())
+    assert [[r["cost"] for r in s.rows()] for s in sms2] == [[r["cost"] for r in s.rows()] for s in sms]
+    bs.close()
+
+
+def test_full_size_properties_cfg5_and_batch():
+    """At BASELINE's full sizes (where the oracle is slow) check size-independent properties:
+    monotone accepted costs, S = L L^T, S symmetric, gradient consistency g_f - H_fe y_e-part,
+    and a batch of cfg3 windows all reaching the same termination as window 0 alone."""
+    w = synth.make_window(5)
+    bs, sm = gpu_solve(w, default_options())
+    costs = [r["cost"] for r in sm.rows()]
+    assert sm.final_cost < 1e-4 * sm.initial_cost
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+    S, rhs, L = bs.export_reduced(0)
+    assert bs.dims(0)["n_red"] == 440
+    assert np.abs(S - S.T).max() == 0 and rel(L @ L.T, S) < 1e-12
+    bs.close()
+    ws = synth.make_batch(16, config_id=4)
+    bsb = solver.BatchSolver(ws)
+    sms = bsb.solve(default_options())
+    assert all(s.termination in (1, 2, 3, 4) for s in sms)
+    assert all(s.final_cost < 1e-4 * s.initial_cost for s in sms)
+    bsb.close()
+
+
+def test_edge_cases_constant_blocks_and_errors():
+    # a constant landmark and a constant keyframe pose: their Jacobian columns must vanish
+    w0 = synth.make_window(3, K=5, F=14, S=3, seed=77)
+    roles = w0.meta["roles"]
+    is_const = w0.a["is_const"].copy()
+    is_const[roles["landmarks"][3]] = 1
+    is_const[roles["poses"][2]] = 1
+    from rtk_visual_inertial_navigation_amd.ordering import my_ordering
+    ob_, og_, nt = my_ordering(roles, is_const)
+    w0.a["is_const"] = is_const; w0.a["order_block"] = ob_; w0.a["order_group"] = og_; w0.n_tail = nt
+    wo, wg = w0.copy(), w0.copy()
+    so, eo = ob.solve(wo, default_options())
+    bs, sg = gpu_solve(wg, default_options())
+    assert [r["step_is_successful"] for r in sg.rows()] == [r["step_is_successful"] for r in so.rows()]
+    assert rel([r["cost"] for r in sg.rows()], [r["cost"] for r in so.rows()]) < 1e-8
+    lm3 = w0.a["lm"].reshape(-1, 3)[3]
+    assert np.array_equal(wg.a["lm"].reshape(-1, 3)[3], lm3)           # untouched
+    assert np.array_equal(wg.a["pose"].reshape(-1, 7)[2], w0.a["pose"].reshape(-1, 7)[2])
+    bs.close()
+    # malformed ordering is refused loudly
+    bad = synth.make_window(2, K=3, F=5, S=0, seed=3)
+    bad.a["order_block"] = bad.a["order_block"][:-1].copy(); bad.a["order_group"] = bad.a["order_group"][:-1].copy()
+    with pytest.raises(solver.SwfError):
+        solver.BatchSolver([bad])

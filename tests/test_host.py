@@ -1,0 +1,82 @@
+"""CPU-side tests of the host logic: MyOrdering policy, generator determinism, flat-window
+packing, and that the C-ABI library loads and exports every symbol include/swf_solver.h declares
+(no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rtk_visual_inertial_navigation_amd import synth, solver, build
+from rtk_visual_inertial_navigation_amd.ordering import my_ordering
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generator_is_deterministic_and_matches_baseline_sizes():
+    a, b = synth.make_window(3), synth.make_window(3)
+    for k in a.a:
+        assert np.array_equal(a.a[k], b.a[k])
+    c = a.counts()
+    assert (c["n_proj"], c["n_imu"], c["n_cp"] + c["n_pr"], c["prior_dim"]) == (3000, 19, 400, [15])
+    c2 = synth.make_window(2).counts()
+    assert (c2["n_proj"], c2["n_imu"], c2["n_cp"]) == (500, 9, 0)
+
+
+def test_my_ordering_policy():
+    """App. B of SURVEY.md: group 0 = dummy, landmarks, every other ELIGIBLE speed-bias (prior
+    blocks are not eligible), clocks; then speed-biases, poses, ambiguities, prior blocks last."""
+    w = synth.make_window(3, K=6, F=10, S=3, seed=1)
+    r = w.meta["roles"]
+    ob, og = list(w.a["order_block"]), list(w.a["order_group"])
+    g = dict(zip(ob, og))
+    assert g[r["dummy"]] == 0 and all(g[b] == 0 for b in r["landmarks"]) and all(g[b] == 0 for b in r["clocks"])
+    sb = r["speed_bias"]
+    # sb0 is held by the prior -> not eligible; eligible = sb1..sb5, alternate ones (1,3,5) in group 0
+    assert [g[b] == 0 for b in sb] == [False, True, False, True, False, True]
+    # groups strictly ascend one block at a time after group 0
+    tail = [x for x in og if x > 0]
+    assert tail == list(range(1, len(tail) + 1))
+    # order: remaining speed-biases (frame order), poses, ambiguities, then prior's kept blocks
+    rest = [b for b, gg in zip(ob, og) if gg > 0]
+    exp = [sb[2], sb[4]] + r["poses"][1:] + r["rtk_ambiguities"] + [r["poses"][0], sb[0]]
+    assert rest == exp
+    # every variable block exactly once
+    nvar = int((w.a["is_const"] == 0).sum())
+    assert len(ob) == len(set(ob)) == nvar
+    # parameter_head goes last and is counted as the export tail
+    r2 = dict(r); r2["parameter_head"] = list(r["rtk_ambiguities"])
+    ob2, og2, nt = my_ordering(r2, w.a["is_const"])
+    assert nt == 3 and list(ob2[-3:]) == r["rtk_ambiguities"]
+
+
+def test_flat_window_struct_roundtrip():
+    w = synth.make_window(3, K=4, F=6, S=2, seed=2)
+    s = w.c_struct()
+    assert s.n_pose == 5 and s.n_sb == 4 and s.n_lm == 6 and s.n_proj == w.a["proj_idx"].size // 3
+    assert s.pose[7] == w.a["pose"].ravel()[7]
+    assert s.n_order == w.a["order_block"].size
+    assert abs(s.proj_sqrt_info - 1000.0 / 1.5) < 1e-12
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    build.build()
+    lib = ctypes.CDLL(solver.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "swf_solver.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(swf_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(solver.EXPORTED) <= declared
+    assert lib.swf_version() >= 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    """The product path must fail loudly when no HIP device is present."""
+    if solver.device_count() > 0:
+        pytest.skip("a GPU is present")
+    w = synth.make_window(2, K=3, F=5, S=0, seed=3)
+    with pytest.raises(solver.SwfError):
+        solver.BatchSolver([w])
