@@ -33,8 +33,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-x", "hip", "-o", LIB] + srcs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + \
+        os.environ.get("SWF_EXTRA_FLAGS", "").split() + ["-x", "hip", "-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

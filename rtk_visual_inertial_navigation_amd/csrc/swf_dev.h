@@ -61,7 +61,7 @@ struct Clique {
     int v_off;                   // d_f vectors: graw, dgraw, cs
     int e_off;                   // d_e*d_e Einv + d_e*d_f strip + d_e g_e   (offset into e-buffer)
     int is_static;               // 1: prior clique, C/dgraw precomputed; only graw changes
-    int pad;
+    int n_rows;                  // total residual rows of the clique's factors
 };
 
 // ---- reduced block pair (a >= b in elimination order): one wave assembles S[a,b] --------
@@ -117,7 +117,7 @@ struct DevBatch {
     // cliques
     int n_cl;
     const Clique* cl;
-    const int* cl_fac;
+    const int* cl_fac; const int* cl_frow;     // factor ids and their first row in the clique Jacobian
     const int* cm_loc; const int* cm_ls; const int* cm_col;
     double* C; double* cv_graw; double* cv_dgraw; double* cv_cs; double* cE;
     // pairs

@@ -68,7 +68,7 @@ struct swf_batch {
     hipStream_t stream = nullptr;
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
-    int max_tiles = 0, max_prior_dim = 0;
+    int max_tiles = 0, max_prior_dim = 0, max_red = 0;
     int timing = 0;                       // bitmask of SWF_K_* brackets
     swf_timing last{};
     std::vector<hipEvent_t> ev;           // event pool (pairs)
@@ -96,7 +96,7 @@ struct Build {
     std::vector<long long> prior_Joff;
     std::vector<double> prior_J, prior_r0, prior_x0;
     std::vector<Clique> cl;
-    std::vector<int> cl_fac, cm_loc, cm_ls, cm_col;
+    std::vector<int> cl_fac, cl_frow, cm_loc, cm_ls, cm_col;
     std::vector<double> C_init, dgraw_init;      // static parts (prior cliques)
     std::vector<Pair> pair;
     std::vector<long long> pc_coff;
@@ -355,8 +355,11 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         C.d_e = t.e >= 0 ? ls[t.e] : 0;
         C.e_loc = t.e >= 0 ? gloc(t.e) : -1;
         C.fac0 = (int)B.cl_fac.size();
-        for (int f : t.facs) { B.cl_fac.push_back(f); B.gf[f].clique = (int)B.cl.size(); }
+        int nrows = 0;
+        for (int f : t.facs) { B.cl_fac.push_back(f); B.cl_frow.push_back(nrows); nrows += B.gf[f].nres; B.gf[f].clique = (int)B.cl.size(); }
         C.fac1 = (int)B.cl_fac.size();
+        C.n_rows = nrows;
+        if (!t.is_static && nrows > CLQ_MAXR) return fail(SWF_E_UNSUPPORTED, "clique with more than 64 residual rows");
         C.mem0 = (int)B.cm_loc.size();
         int df = 0;
         std::map<int, int> colof;
@@ -466,7 +469,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->stream = (hipStream_t)stream;
     b->win = B.win; b->hw = hw; b->max_tiles = B.max_tiles; b->max_prior_dim = B.max_prior_dim; b->jac_bytes = B.jac_bytes;
     b->proj_bytes = (int64_t)312 * (int64_t)B.p_win.size();
-    for (auto& W : B.win) b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3;
+    for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); }
     DevBatch& D = b->D;
     DevPool& P = b->pool;
     int rc = 0;
@@ -492,7 +495,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     PUT(prior_dim, B.prior_dim); PUT(prior_Joff, B.prior_Joff); PUT(prior_roff, B.prior_roff); PUT(prior_x0off, B.prior_x0off);
     PUT(prior_J, B.prior_J); PUT(prior_r0, B.prior_r0); PUT(prior_x0, B.prior_x0);
     D.n_cl = (int)B.cl.size();
-    PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
+    PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cl_frow, B.cl_frow); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
     D.n_pair = (int)B.pair.size();
     PUT(pair, B.pair); PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
 #undef PUT
@@ -597,15 +600,16 @@ struct Launcher {
     }
     void lin_elim(int write_S) {
         DevBatch& D = b->D;
-        if (D.n_lm) { Bracket t(*this, SWF_K_LM_ELIM); hipLaunchKernelGGL(k_lm_elim, GRID(D.n_lm, 256), dim3(256), 0, st, D, O); }
+        if (D.n_lm) { Bracket t(*this, SWF_K_LM_ELIM); hipLaunchKernelGGL(k_lm_elim, GRID((size_t)D.n_lm * 16, 256), dim3(256), 0, st, D, O); }
         if (D.n_cl) { Bracket t(*this, SWF_K_CLIQUE_ELIM); hipLaunchKernelGGL(k_clique_elim, dim3(D.n_cl), dim3(256), 0, st, D, O); }
-        if (write_S && b->max_tiles) { Bracket t(*this, SWF_K_LM_GEMM); hipLaunchKernelGGL(k_lm_gemm, dim3(b->max_tiles, D.n_win), dim3(256), 0, st, D); }
+        if (write_S && b->max_tiles) { Bracket t(*this, SWF_K_LM_GEMM); hipLaunchKernelGGL(k_lm_gemm, dim3((b->max_tiles + 3) / 4, D.n_win), dim3(256), 0, st, D); }
         if (D.n_pair) { Bracket t(*this, SWF_K_ASSEMBLE); hipLaunchKernelGGL(k_assemble, GRID((size_t)D.n_pair * 64, 256), dim3(256), 0, st, D, O, write_S); }
     }
     void reduced() {
         DevBatch& D = b->D;
         Bracket t(*this, SWF_K_CHOL);
-        hipLaunchKernelGGL(k_chol_solve, dim3(D.n_win), dim3(1024), 0, st, D);
+        if (b->max_red + 1 <= 256) hipLaunchKernelGGL(k_chol_solve<256>, dim3(D.n_win), dim3(256), 0, st, D);
+        else hipLaunchKernelGGL(k_chol_solve<1024>, dim3(D.n_win), dim3(1024), 0, st, D);
     }
     void step_rest() {
         DevBatch& D = b->D;
@@ -759,3 +763,11 @@ extern "C" int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, d
     if (y) HIPCHK(hipMemcpy(y, b->D.y + W.loc_base, n * sizeof(double), hipMemcpyDeviceToHost));
     return SWF_OK;
 }
+
+#ifdef SWF_PROFILE_CHOL
+extern "C" int swf_debug_chol_stamps(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_stamps), 64 * sizeof(unsigned long long)) != hipSuccess) return SWF_E_NODEVICE;
+    return SWF_OK;
+}
+#endif

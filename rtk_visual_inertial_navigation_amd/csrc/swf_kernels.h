@@ -471,18 +471,27 @@ __global__ void __launch_bounds__(256) k_jtimes_gen(DevBatch B, DevOpt O) {
 // In-tree analogue of this arithmetic: MarginalizationInfo::marginalize,
 // R/factor/marginalization_factor.cpp:260-377; in Ceres it is SchurEliminator::Eliminate.
 // =========================================================================================
+__device__ __forceinline__ double grp16_sum(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
-    int L = blockIdx.x * blockDim.x + threadIdx.x;
-    if (L >= B.n_lm) return;
-    int w = B.lm_win[L];
+    // 16 lanes per landmark: lanes stride over its observations (all loads of a round are in
+    // flight together), 16-lane butterflies reduce H_ll / g_l, every lane then owns whole
+    // observations for the W / Y products and stores.
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int L = gid >> 4, sub = threadIdx.x & 15;
+    bool valid = L < B.n_lm;
+    int Lc = valid ? L : B.n_lm - 1;
+    int w = B.lm_win[Lc];
     WinState& s = B.ws[w];
-    if (!s.need_lin) return;
-    int loc = B.lm_loc[L];
-    if (loc < 0) return;
+    int loc = B.lm_loc[Lc];
+    bool act = valid && s.need_lin && loc >= 0;
     const WinRec& W = B.win[w];
-    int n = B.n_proj, o0 = B.lm_obs0[L], o1 = B.lm_obs0[L + 1];
+    int n = B.n_proj, o0 = B.lm_obs0[Lc], o1 = B.lm_obs0[Lc + 1];
     double h00 = 0, h10 = 0, h20 = 0, h11 = 0, h21 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
-    for (int o = o0; o < o1; o++) {
+    if (act) for (int o = o0 + sub; o < o1; o += 16) {
         double a0 = B.p_Jl[0 * n + o], a1 = B.p_Jl[1 * n + o], a2 = B.p_Jl[2 * n + o];
         double b0 = B.p_Jl[3 * n + o], b1 = B.p_Jl[4 * n + o], b2 = B.p_Jl[5 * n + o];
         double r0 = B.p_r[o], r1 = B.p_r[n + o];
@@ -490,8 +499,13 @@ __global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
         h11 += a1 * a1 + b1 * b1; h21 += a2 * a1 + b2 * b1; h22 += a2 * a2 + b2 * b2;
         g0 += a0 * r0 + b0 * r1; g1 += a1 * r0 + b1 * r1; g2 += a2 * r0 + b2 * r1;
     }
-    B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
-    B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
+    h00 = grp16_sum(h00); h10 = grp16_sum(h10); h20 = grp16_sum(h20); h11 = grp16_sum(h11); h21 = grp16_sum(h21); h22 = grp16_sum(h22);
+    g0 = grp16_sum(g0); g1 = grp16_sum(g1); g2 = grp16_sum(g2);
+    if (!act) return;
+    if (sub == 0) {
+        B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
+        B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
+    }
     double mu = s.mu;
     h00 += mu * clampd(h00, O.min_diag, O.max_diag);
     h11 += mu * clampd(h11, O.min_diag, O.max_diag);
@@ -502,21 +516,22 @@ __global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
     double l11 = sqrt(d11), l21 = (h21 - l20 * l10) / l11;
     double d22 = h22 - l20 * l20 - l21 * l21;
     double l22 = sqrt(d22);
-    if (!(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0)) { s.lin_fail = 1; return; }
+    if (!(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0)) { if (sub == 0) s.lin_fail = 1; return; }
     double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
     double i10 = -l10 * i00 * i11;
     double i21 = -l21 * i11 * i22;
     double i20 = -(l20 * i00 + l21 * i10) * i22;
-    // Einv = Linv^T Linv
     double e00 = i00 * i00 + i10 * i10 + i20 * i20, e10 = i10 * i11 + i20 * i21, e20 = i20 * i22;
     double e11 = i11 * i11 + i21 * i21, e21 = i21 * i22, e22 = i22 * i22;
     int nl = B.n_lm;
-    B.lm_Einv[0 * nl + L] = e00; B.lm_Einv[1 * nl + L] = e10; B.lm_Einv[2 * nl + L] = e20;
-    B.lm_Einv[3 * nl + L] = e11; B.lm_Einv[4 * nl + L] = e21; B.lm_Einv[5 * nl + L] = e22;
-    B.lm_g[0 * nl + L] = g0; B.lm_g[1 * nl + L] = g1; B.lm_g[2 * nl + L] = g2;
+    if (sub == 0) {
+        B.lm_Einv[0 * nl + L] = e00; B.lm_Einv[1 * nl + L] = e10; B.lm_Einv[2 * nl + L] = e20;
+        B.lm_Einv[3 * nl + L] = e11; B.lm_Einv[4 * nl + L] = e21; B.lm_Einv[5 * nl + L] = e22;
+        B.lm_g[0 * nl + L] = g0; B.lm_g[1 * nl + L] = g1; B.lm_g[2 * nl + L] = g2;
+    }
     int ld = 6 * W.nF, col = B.lm_col[L];
     double* Yt = B.Yt + W.YW_base; double* Wt = B.Wt + W.YW_base;
-    for (int o = o0; o < o1; o++) {
+    for (int o = o0 + sub; o < o1; o += 16) {
         int f = B.p_fr[o];
         if (f < 0) continue;
         double a0 = B.p_Jl[0 * n + o], a1 = B.p_Jl[1 * n + o], a2 = B.p_Jl[2 * n + o];
@@ -543,11 +558,14 @@ __global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
 // for k_assemble, plus Einv / M_ef / g_e for the back-substitution.
 // =========================================================================================
 #define CLQ_MAXD 64
+#define CLQ_MAXR 64
 __global__ void __launch_bounds__(256) k_clique_elim(DevBatch B, DevOpt O) {
-    __shared__ double M[CLQ_MAXD * CLQ_MAXD];
+    __shared__ double Jc[CLQ_MAXR][CLQ_MAXD + 1];   // dense clique Jacobian: rows = residual rows, cols = [e | members]
+    __shared__ double M[CLQ_MAXD][CLQ_MAXD + 1];
+    __shared__ double rv[CLQ_MAXR];
     __shared__ double gv[CLQ_MAXD];
-    __shared__ double Ei[81];
-    __shared__ double T[9 * CLQ_MAXD];
+    __shared__ double A[9][19];                     // Gauss-Jordan work [M_ee | I]
+    __shared__ double T[9][CLQ_MAXD + 1];
     __shared__ double Eg[9];
     __shared__ int fail;
     int c = blockIdx.x;
@@ -556,140 +574,132 @@ __global__ void __launch_bounds__(256) k_clique_elim(DevBatch B, DevOpt O) {
     if (C.is_static) return;
     WinState& s = B.ws[C.win];
     if (!s.need_lin) return;
-    int de = C.d_e, df = C.d_f, d = de + df, tid = threadIdx.x;
-    for (int e = tid; e < d * d; e += blockDim.x) M[e] = 0;
-    if (tid < d) gv[tid] = 0;
+    int de = C.d_e, df = C.d_f, d = de + df, tid = threadIdx.x, nrow = C.n_rows;
+    for (int e = tid; e < nrow * (CLQ_MAXD + 1); e += blockDim.x) (&Jc[0][0])[e] = 0.0;
     if (tid == 0) fail = 0;
     __syncthreads();
-    for (int q = C.fac0; q < C.fac1; q++) {
-        const GFac& G = B.gf[B.cl_fac[q]];
-        for (int sa = 0; sa < G.nslot; sa++) {
-            int ca = B.s_ccol[G.slot0 + sa];
-            if (ca < 0) continue;
-            int la = B.s_ls[G.slot0 + sa];
-            const double* Ja = B.g_J + B.s_joff[G.slot0 + sa];
-            for (int sb = 0; sb < G.nslot; sb++) {
-                int cb = B.s_ccol[G.slot0 + sb];
-                if (cb < 0) continue;
-                int lb = B.s_ls[G.slot0 + sb];
-                const double* Jb = B.g_J + B.s_joff[G.slot0 + sb];
-                for (int e = tid; e < la * lb; e += blockDim.x) {
-                    int i = e / lb, j = e % lb;
-                    double a = 0;
-                    for (int k = 0; k < G.nres; k++) a += Ja[k * la + i] * Jb[k * lb + j];
-                    M[(ca + i) * d + cb + j] += a;
-                }
-            }
-            if (tid < la) {
-                double a = 0;
-                for (int k = 0; k < G.nres; k++) a += Ja[k * la + tid] * B.g_r[G.roff + k];
-                gv[ca + tid] += a;
+    // scatter the factors' Jacobian blocks into Jc: 8 groups of 32 lanes, one factor per group
+    {
+        int grp = tid >> 5, gl = tid & 31;
+        for (int q = C.fac0 + grp; q < C.fac1; q += 8) {
+            const GFac& G = B.gf[B.cl_fac[q]];
+            int r0 = B.cl_frow[q];
+            for (int k = gl; k < G.nres; k += 32) rv[r0 + k] = B.g_r[G.roff + k];
+            for (int sl = 0; sl < G.nslot; sl++) {
+                int cc = B.s_ccol[G.slot0 + sl];
+                if (cc < 0) continue;
+                int l = B.s_ls[G.slot0 + sl];
+                const double* J = B.g_J + B.s_joff[G.slot0 + sl];
+                for (int e = gl; e < G.nres * l; e += 32) Jc[r0 + e / l][cc + e % l] = J[e];
             }
         }
-        __syncthreads();
     }
-    // raw gradient / diagonal
-    if (tid < de) { B.g[C.e_loc + tid] = gv[tid]; B.diag[C.e_loc + tid] = M[tid * d + tid]; }
-    if (tid >= de && tid < d) { B.cv_graw[C.v_off + tid - de] = gv[tid]; B.cv_dgraw[C.v_off + tid - de] = M[tid * d + tid]; }
     __syncthreads();
+    // M = Jc^T Jc (lower half + mirror), gv = Jc^T r
+    for (int e = tid; e < d * d; e += blockDim.x) {
+        int a = e / d, b = e % d;
+        if (b > a) continue;
+        double acc = 0;
+        for (int k = 0; k < nrow; k++) acc += Jc[k][a] * Jc[k][b];
+        M[a][b] = acc; M[b][a] = acc;
+    }
+    if (tid < d) { double acc = 0; for (int k = 0; k < nrow; k++) acc += Jc[k][tid] * rv[k]; gv[tid] = acc; }
+    __syncthreads();
+    // raw gradient / diagonal
+    if (tid < de) { B.g[C.e_loc + tid] = gv[tid]; B.diag[C.e_loc + tid] = M[tid][tid]; }
+    if (tid >= de && tid < d) { B.cv_graw[C.v_off + tid - de] = gv[tid]; B.cv_dgraw[C.v_off + tid - de] = M[tid][tid]; }
     if (de > 0) {
-        if (tid < de) M[tid * d + tid] += s.mu * clampd(M[tid * d + tid], O.min_diag, O.max_diag);
-        __syncthreads();
-        if (tid == 0) {
-            // Cholesky inverse of M_ee (de <= 9)
-            double Lc[81];
-            for (int i = 0; i < de; i++) for (int j = 0; j <= i; j++) Lc[i * de + j] = M[i * d + j];
-            for (int j = 0; j < de; j++) {
-                double dd = Lc[j * de + j];
-                for (int k = 0; k < j; k++) dd -= Lc[j * de + k] * Lc[j * de + k];
-                if (!(dd > 0.0)) { fail = 1; break; }
-                dd = sqrt(dd); Lc[j * de + j] = dd;
-                for (int i = j + 1; i < de; i++) {
-                    double sv = Lc[i * de + j];
-                    for (int k = 0; k < j; k++) sv -= Lc[i * de + k] * Lc[j * de + k];
-                    Lc[i * de + j] = sv / dd;
-                }
-            }
-            if (!fail) {
-                for (int col = 0; col < de; col++) {
-                    double ev[9];
-                    for (int i = 0; i < de; i++) {
-                        double sv = (i == col) ? 1.0 : 0.0;
-                        for (int k = 0; k < i; k++) sv -= Lc[i * de + k] * ev[k];
-                        ev[i] = sv / Lc[i * de + i];
-                    }
-                    for (int i = de - 1; i >= 0; i--) {
-                        double sv = ev[i];
-                        for (int k = i + 1; k < de; k++) sv -= Lc[k * de + i] * ev[k];
-                        ev[i] = sv / Lc[i * de + i];
-                    }
-                    for (int i = 0; i < de; i++) Ei[i * de + col] = ev[i];
-                }
-            }
+        // [M_ee + mu D | I] -> [I | Einv] by Gauss-Jordan (SPD: no pivoting), de*2de threads
+        int gi = tid / (2 * de), gj = tid % (2 * de);
+        bool on = tid < de * 2 * de;
+        if (on) {
+            double v = gj < de ? M[gi][gj] : ((gj - de) == gi ? 1.0 : 0.0);
+            if (gj == gi) v += s.mu * clampd(M[gi][gi], O.min_diag, O.max_diag);
+            A[gi][gj] = v;
         }
         __syncthreads();
+        for (int k = 0; k < de; k++) {
+            double piv = A[k][k], aik = 0, akj = 0;
+            if (on) { aik = A[gi][k]; akj = A[k][gj]; }
+            __syncthreads();
+            if (tid == 0 && !(piv > 0.0)) fail = 1;
+            if (on) A[gi][gj] = (gi == k) ? akj / piv : A[gi][gj] - aik * (akj / piv);
+            __syncthreads();
+        }
         if (fail) { if (tid == 0) s.lin_fail = 1; return; }
         // T = Einv * M_ef ; Eg = Einv * g_e
         for (int e = tid; e < de * df; e += blockDim.x) {
             int a = e / df, j = e % df;
             double sv = 0;
-            for (int b = 0; b < de; b++) sv += Ei[a * de + b] * M[b * d + de + j];
-            T[a * df + j] = sv;
+            for (int b = 0; b < de; b++) sv += A[a][de + b] * M[b][de + j];
+            T[a][j] = sv;
         }
-        if (tid < de) { double sv = 0; for (int b = 0; b < de; b++) sv += Ei[tid * de + b] * gv[b]; Eg[tid] = sv; }
+        if (tid < de) { double sv = 0; for (int b = 0; b < de; b++) sv += A[tid][de + b] * gv[b]; Eg[tid] = sv; }
         __syncthreads();
         double* E = B.cE + C.e_off;
-        for (int e = tid; e < de * de; e += blockDim.x) E[e] = Ei[e];
-        for (int e = tid; e < de * df; e += blockDim.x) E[de * de + e] = M[(e / df) * d + de + (e % df)];
+        for (int e = tid; e < de * de; e += blockDim.x) E[e] = A[e / de][de + e % de];
+        for (int e = tid; e < de * df; e += blockDim.x) E[de * de + e] = M[e / df][de + (e % df)];
         if (tid < de) E[de * de + de * df + tid] = gv[tid];
     }
     double* Cm = B.C + C.C_off;
     for (int e = tid; e < df * df; e += blockDim.x) {
         int i = e / df, j = e % df;
-        double v = M[(de + i) * d + de + j];
-        for (int a = 0; a < de; a++) v -= M[(de + i) * d + a] * T[a * df + j];
-        Cm[e] = v;
+        if (j > i) continue;
+        double v = M[de + i][de + j];
+        for (int a = 0; a < de; a++) v -= M[de + i][a] * T[a][j];
+        Cm[i * df + j] = v; Cm[j * df + i] = v;
     }
     if (tid < df) {
         double v = 0;
-        for (int a = 0; a < de; a++) v -= M[(de + tid) * d + a] * Eg[a];
+        for (int a = 0; a < de; a++) v -= M[de + tid][a] * Eg[a];
         B.cv_cs[C.v_off + tid] = v;
     }
 }
 
 // =========================================================================================
 // P = Yt^T Wt per window: the landmark part of the reduced camera matrix as one dense
-// product over the static-sparsity slabs (v1: LDS-tiled fp64 VALU; 16x16 output tiles,
-// lower triangle of tiles only — P is symmetric).
+// product over the static-sparsity slabs, on the fp64 matrix cores.  One wavefront per 16x16
+// output tile (lower triangle of tiles only; P is symmetric), v_mfma_f64_16x16x4_f64:
+//   A[i][k] = Yt[k0+k][r0+i], B[k][j] = Wt[k0+k][c0+j]  -> both operands are 16 contiguous
+//   doubles per k straight from memory (no LDS staging: every operand element feeds one lane).
+// f64 C/D layout: lane l, reg q holds D[row = (l>>4) + 4q][col = l&15].
 // =========================================================================================
+typedef double double4_t __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_lm_gemm(DevBatch B) {
-    __shared__ double Ys[16][17];
-    __shared__ double Ws[16][17];
     int w = blockIdx.y;
     const WinRec& W = B.win[w];
     if (!B.ws[w].need_lin) return;
     int m = 6 * W.nF, nt = (m + 15) / 16;
-    int t = blockIdx.x;
+    int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= nt * (nt + 1) / 2) return;
     int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) / 2.0);
     while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
     while (tr * (tr + 1) / 2 > t) tr--;
     int tc = t - tr * (tr + 1) / 2;
-    int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     int K = 3 * (W.lm1 - W.lm0);
     const double* Yt = B.Yt + W.YW_base; const double* Wt = B.Wt + W.YW_base;
-    double acc = 0;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        int k = k0 + ty, rr = tr * 16 + tx, cc = tc * 16 + tx;
-        Ys[ty][tx] = (k < K && rr < m) ? Yt[(size_t)k * m + rr] : 0.0;
-        Ws[ty][tx] = (k < K && cc < m) ? Wt[(size_t)k * m + cc] : 0.0;
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) acc += Ys[kk][ty] * Ws[kk][tx];
-        __syncthreads();
+    int li = lane & 15, lk = lane >> 4;
+    int ra = tr * 16 + li, cb = tc * 16 + li;
+    bool va = ra < m, vb = cb < m;
+    double4_t acc0 = { 0, 0, 0, 0 }, acc1 = { 0, 0, 0, 0 };
+    int k0 = 0;
+    for (; k0 + 8 <= K; k0 += 8) {
+        double a0 = va ? Yt[(size_t)(k0 + lk) * m + ra] : 0.0, b0 = vb ? Wt[(size_t)(k0 + lk) * m + cb] : 0.0;
+        double a1 = va ? Yt[(size_t)(k0 + 4 + lk) * m + ra] : 0.0, b1 = vb ? Wt[(size_t)(k0 + 4 + lk) * m + cb] : 0.0;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
     }
-    int r = tr * 16 + ty, c = tc * 16 + tx;
-    if (r < m && c < m) B.P[W.P_base + (size_t)r * m + c] = acc;
+    for (; k0 < K; k0 += 4) {
+        bool vk = (k0 + lk) < K;
+        double a0 = (va && vk) ? Yt[(size_t)(k0 + lk) * m + ra] : 0.0, b0 = (vb && vk) ? Wt[(size_t)(k0 + lk) * m + cb] : 0.0;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+    }
+    double* P = B.P + W.P_base;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int r = tr * 16 + lk + 4 * q, c = tc * 16 + li;
+        if (r < m && c < m) P[(size_t)r * m + c] = acc0[q] + acc1[q];
+    }
 }
 
 // =========================================================================================
@@ -758,6 +768,7 @@ __global__ void __launch_bounds__(256) k_assemble(DevBatch B, DevOpt O, int writ
     double dgs1 = __shfl(dg_i, ((lane + 64) / lb) & 63, 64);
     for (int e = lane; e < la * lb; e += 64) {
         int i = e / lb, j = e % lb;
+        if (Pr.is_diag && j > i) continue;          // lower half only; the mirror store fills the rest
         double v = 0;
         if (Pr.fa >= 0 && Pr.fb >= 0) {
             int pr = 6 * Pr.fa + i, pc = 6 * Pr.fb + j;

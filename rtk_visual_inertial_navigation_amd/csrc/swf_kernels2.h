@@ -9,23 +9,48 @@
 #include "swf_kernels.h"
 
 // =========================================================================================
-// Dense reduced solve, one 1024-thread workgroup per window.
-// Blocked left-looking Cholesky S = L L^T in the predefined elimination order, one matrix
-// row per thread (accumulators in registers), 32-wide block columns:
-//   * the working factor is kept TRANSPOSED (Lt[k][r] = L[r][k], leading dim n+1) so that
-//     lanes = consecutive rows read consecutive addresses;
-//   * rhs rides along as row n of the matrix, so the forward solve y = L^-1 rhs falls out
-//     of the factorisation; only the backward solve L^T z = y is done separately;
-//   * the 32x32 diagonal block is factored inside wave 0 with cross-lane shuffles.
-// (v1 of this kernel: fp64 VALU; the MFMA trailing-update variant replaces the k-loop.)
+// Dense reduced solve, one workgroup per window (256 threads when n_red < 256, else 1024).
+// Blocked left-looking Cholesky S = L L^T in the predefined elimination order, 32-wide block
+// columns, one matrix row per thread:
+//   * the O(n^3) part — block column minus (already factored columns)^2 — runs on the fp64
+//     matrix cores (v_mfma_f64_16x16x4_f64): each wave owns 64 rows x 32 columns = 4x2 tiles;
+//     both operands come straight from the TRANSPOSED working factor (Lt[k][r] = L[r][k],
+//     leading dim n+1), 16 contiguous doubles per k, so no LDS staging is needed;
+//   * the tiles are transposed through LDS into row-per-lane registers for the 32x32 diagonal
+//     factorisation (inside wave 0, column broadcast through LDS) and the triangular solve;
+//   * rhs rides along as row n of the matrix, so the forward solve y = L^-1 rhs falls out of
+//     the factorisation; only the backward solve L^T z = y is done separately.
+// f64 MFMA layouts: A[i][k]: lane = i + 16k;  B[k][j]: lane = j + 16k;
+//                   D: lane l, reg q -> D[row = (l>>4) + 4q][col = l&15].
 // =========================================================================================
 #define CH_NB 32
-#define CH_KC 64
-__global__ void __launch_bounds__(1024) k_chol_solve(DevBatch B) {
-    __shared__ double Lrow[CH_NB][CH_KC + 1];   // L[J0+c][k0+kk]
+#ifndef CH_OCC
+#define CH_OCC 2
+#endif
+#ifndef CH_KU
+#define CH_KU 4
+#endif
+// broadcast a double from a compile-time-constant lane through SGPRs (v_readlane_b32 x2)
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+#ifdef SWF_PROFILE_CHOL
+__device__ unsigned long long g_chol_stamps[64];
+#define CHSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CHACC(i, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#else
+#define CHSTAMP(i)
+#define CHACC(i, t0)
+#endif
+template <int NT>
+__global__ void __launch_bounds__(NT, NT == 256 ? CH_OCC : 4) k_chol_solve(DevBatch B) {
+    __shared__ double Xs[2][64][CH_NB + 1];     // tile -> row layout, two waves at a time
+    __shared__ double Dinv[CH_NB];              // 1 / L[c][c] of the current diagonal block
     __shared__ double D[CH_NB][CH_NB + 1];      // diagonal block (lower)
     __shared__ double zs[1024];
-    __shared__ double part[CH_NB][33];
+    __shared__ double part[CH_NB][NT / 32 + 1];
     __shared__ int fail;
     int w = blockIdx.x;
     WinState& s = B.ws[w];
@@ -36,58 +61,115 @@ __global__ void __launch_bounds__(1024) k_chol_solve(DevBatch B) {
     const double* S = B.S + W.S_base;
     double* Lt = B.L + W.Lt_base;
     const double* rhs = B.rhs + W.loc_base + W.n_e;
+    int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     if (tid == 0) fail = 0;
+#ifdef SWF_PROFILE_CHOL
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 64; i++) g_chol_stamps[i] = 0;
+    unsigned long long tph = 0;
+#endif
     __syncthreads();
+    CHSTAMP(0);
     for (int J0 = 0; J0 < n; J0 += CH_NB) {
+#ifdef SWF_PROFILE_CHOL
+        tph = __builtin_amdgcn_s_memtime();
+#endif
         int nb = (n - J0) < CH_NB ? (n - J0) : CH_NB;
         int r = J0 + tid;                       // my row (r == n : augmented rhs row)
         bool active = r <= n;
+        int rbase = J0 + 64 * wv;
+        bool wave_active = rbase <= n;
         double acc[CH_NB];
+        if (wave_active) {
+            double4_t T[4][2];
 #pragma unroll
-        for (int c = 0; c < CH_NB; c++) {
-            double v = 0;
-            if (active && c < nb) v = (r < n) ? S[(size_t)r * n + J0 + c] : rhs[J0 + c];
-            acc[c] = v;
-        }
-        // subtract contributions of the already factored columns
-        for (int k0 = 0; k0 < J0; k0 += CH_KC) {
-            int kc = (J0 - k0) < CH_KC ? (J0 - k0) : CH_KC;
-            for (int e = tid; e < CH_NB * CH_KC; e += 1024) {
-                int kk = e / CH_NB, c = e % CH_NB;
-                Lrow[c][kk] = (kk < kc && c < nb) ? Lt[(size_t)(k0 + kk) * ld + J0 + c] : 0.0;
-            }
-            __syncthreads();
-            if (active) {
-                for (int kk = 0; kk < kc; kk++) {
-                    double l = Lt[(size_t)(k0 + kk) * ld + r];
+            for (int ti = 0; ti < 4; ti++)
 #pragma unroll
-                    for (int c = 0; c < CH_NB; c++) acc[c] -= l * Lrow[c][kk];
+                for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        int rr = rbase + 16 * ti + lk + 4 * q, c = 16 * tj + li;
+                        double v = 0;
+                        if (rr <= n && c < nb) v = (rr < n) ? S[(size_t)rr * n + J0 + c] : rhs[J0 + c];
+                        T[ti][tj][q] = v;
+                    }
+            bool vb0 = li < nb, vb1 = (16 + li) < nb;
+            bool va[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++) va[ti] = (rbase + 16 * ti + li) <= n;
+            // J0 is a multiple of 32: 4*KU columns of k per trip, all operand loads issued up front
+            constexpr int KU = (NT == 256) ? CH_KU : 1;
+            for (int k0 = 0; k0 < J0; k0 += 4 * KU) {
+                double a[KU][4], b0[KU], b1[KU];
+#pragma unroll
+                for (int u = 0; u < KU; u++) {
+                    const double* Lk = Lt + (size_t)(k0 + 4 * u + lk) * ld;
+                    b0[u] = vb0 ? Lk[J0 + li] : 0.0; b1[u] = vb1 ? Lk[J0 + 16 + li] : 0.0;
+#pragma unroll
+                    for (int ti = 0; ti < 4; ti++) a[u][ti] = va[ti] ? -Lk[rbase + 16 * ti + li] : 0.0;
                 }
+#pragma unroll
+                for (int u = 0; u < KU; u++)
+#pragma unroll
+                    for (int ti = 0; ti < 4; ti++) {
+                        T[ti][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], b0[u], T[ti][0], 0, 0, 0);
+                        T[ti][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], b1[u], T[ti][1], 0, 0, 0);
+                    }
             }
-            __syncthreads();
+#ifdef SWF_PROFILE_CHOL
+            CHACC(8, tph); tph = __builtin_amdgcn_s_memtime();
+#endif
+            // tile layout -> one row per lane, four waves per round through LDS
+#pragma unroll 1
+            for (int rd = 0; rd < NT / 128; rd++) {
+                if ((wv >> 1) == rd) {
+#pragma unroll
+                    for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+                        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+                            for (int q = 0; q < 4; q++) Xs[wv & 1][16 * ti + lk + 4 * q][16 * tj + li] = T[ti][tj][q];
+                }
+                __syncthreads();
+                if ((wv >> 1) == rd) {
+#pragma unroll
+                    for (int c = 0; c < CH_NB; c++) acc[c] = Xs[wv & 1][lane][c];
+                }
+                __syncthreads();
+            }
+        } else {
+#pragma unroll 1
+            for (int rd = 0; rd < NT / 128; rd++) { __syncthreads(); __syncthreads(); }
+#pragma unroll
+            for (int c = 0; c < CH_NB; c++) acc[c] = 0.0;
         }
-        // factor the diagonal block inside wave 0 (lanes 0..nb-1 hold rows J0..J0+nb-1)
+        // factor the diagonal block inside wave 0 (lanes 0..nb-1 hold rows J0..J0+nb-1);
+        // each finished column is broadcast to the other lanes through LDS
+#ifdef SWF_PROFILE_CHOL
+        CHACC(9, tph); tph = __builtin_amdgcn_s_memtime();
+#endif
         if (tid < 64) {
-            int lane = tid;
+            // 32x32 diagonal block: right-looking Cholesky in registers inside wave 0 (lane = row).
+            // Column entries are broadcast with v_readlane (VALU -> SGPR), so the 32-step
+            // dependency chain never waits on an LDS round trip.
             bool bad = false;
+            bool inblk = lane < nb;
 #pragma unroll
             for (int c = 0; c < CH_NB; c++) {
-                double dpiv = __shfl(acc[c], c, 64);
+                double dpiv = readlane_d(acc[c], c);
                 if (c < nb) {
                     if (!(dpiv > 0.0)) bad = true;
-                    if (lane < nb) {
-                        double piv = sqrt(dpiv);
-                        if (lane == c) acc[c] = piv;
-                        else if (lane > c) acc[c] = acc[c] / piv;
-                    }
+                    // one reciprocal square root per column instead of sqrt + a division per row
+                    double ipiv = 1.0 / sqrt(dpiv);
+                    if (inblk) acc[c] = (lane == c) ? dpiv * ipiv : (lane > c ? acc[c] * ipiv : acc[c]);
+                    if (lane == c) Dinv[c] = ipiv;
                 }
 #pragma unroll
                 for (int c2 = c + 1; c2 < CH_NB; c2++) {
-                    double l2 = __shfl(acc[c], c2, 64);       // L[c2][c]
-                    if (c2 < nb && lane < nb && lane >= c2) acc[c2] -= acc[c] * l2;
+                    double l2 = readlane_d(acc[c], c2);       // L[c2][c]
+                    if (c2 < nb && inblk && lane >= c2) acc[c2] -= acc[c] * l2;
                 }
             }
-            if (lane < nb) {
+            if (inblk) {
 #pragma unroll
                 for (int c = 0; c < CH_NB; c++) {
                     D[lane][c] = (c <= lane) ? acc[c] : 0.0;
@@ -97,6 +179,9 @@ __global__ void __launch_bounds__(1024) k_chol_solve(DevBatch B) {
             if (bad && lane == 0) fail = 1;
         }
         __syncthreads();
+#ifdef SWF_PROFILE_CHOL
+        CHACC(10, tph); tph = __builtin_amdgcn_s_memtime();
+#endif
         if (fail) { if (tid == 0) s.lin_fail = 1; return; }
         // triangular solve for the rows below the block: x L_d^T = acc
         if (active && r >= J0 + nb) {
@@ -106,46 +191,51 @@ __global__ void __launch_bounds__(1024) k_chol_solve(DevBatch B) {
                     double v = acc[c];
 #pragma unroll
                     for (int k = 0; k < c; k++) v -= acc[k] * D[c][k];
-                    v = v / D[c][c];
+                    v = v * Dinv[c];
                     acc[c] = v;
                     Lt[(size_t)(J0 + c) * ld + r] = v;
                 }
             }
         }
         __syncthreads();
+#ifdef SWF_PROFILE_CHOL
+        CHACC(11, tph);
+#endif
     }
+    CHSTAMP(1);
     // backward solve L^T z = y, y = row n of L (Lt[k][n]); blocks from the bottom up
-    for (int e = tid; e < n; e += 1024) zs[e] = 0.0;
+    for (int e = tid; e < n; e += NT) zs[e] = 0.0;
     __syncthreads();
     int nblk = (n + CH_NB - 1) / CH_NB;
     for (int jb = nblk - 1; jb >= 0; jb--) {
         int J0 = jb * CH_NB;
         int nb = (n - J0) < CH_NB ? (n - J0) : CH_NB;
-        // partial dots over already solved z_r, r >= J0+nb : 32 rows x 32 parts
+        // partial dots over already solved z_r, r >= J0+nb
         {
-            int kk = tid >> 5, pt = tid & 31;
+            constexpr int PT = NT / 32;
+            int kk = tid / PT, pt = tid % PT;
             double a = 0;
-            if (kk < nb) for (int r = J0 + nb + pt; r < n; r += 32) a += Lt[(size_t)(J0 + kk) * ld + r] * zs[r];
+            if (kk < nb) for (int r = J0 + nb + pt; r < n; r += PT) a += Lt[(size_t)(J0 + kk) * ld + r] * zs[r];
             part[kk][pt] = a;
         }
-        for (int e = tid; e < CH_NB * CH_NB; e += 1024) {
+        for (int e = tid; e < CH_NB * CH_NB; e += NT) {
             int c = e / CH_NB, k = e % CH_NB;      // D[c][k] = L[J0+c][J0+k], c >= k
             D[c][k] = (c < nb && k <= c) ? Lt[(size_t)(J0 + k) * ld + J0 + c] : 0.0;
         }
+        if (tid < nb) Dinv[tid] = 1.0 / Lt[(size_t)(J0 + tid) * ld + J0 + tid];
         __syncthreads();
         if (tid < 64) {
-            int lane = tid;
             double b = 0;
             if (lane < nb) {
                 double a = 0;
-                for (int pt = 0; pt < 32; pt++) a += part[lane][pt];
+                for (int pt = 0; pt < NT / 32; pt++) a += part[lane][pt];
                 b = Lt[(size_t)(J0 + lane) * ld + n] - a;
             }
 #pragma unroll
             for (int c = CH_NB - 1; c >= 0; c--) {
-                double bc = __shfl(b, c, 64);
+                double bc = readlane_d(b, c);
                 if (c < nb) {
-                    double zc = bc / D[c][c];
+                    double zc = bc * Dinv[c];
                     if (lane == c) b = zc;
                     else if (lane < c) b -= D[c][lane] * zc;
                 }
@@ -155,7 +245,8 @@ __global__ void __launch_bounds__(1024) k_chol_solve(DevBatch B) {
         __syncthreads();
     }
     double* y = B.y + W.loc_base + W.n_e;
-    for (int e = tid; e < n; e += 1024) y[e] = zs[e];
+    for (int e = tid; e < n; e += NT) y[e] = zs[e];
+    CHSTAMP(2);
 }
 
 // =========================================================================================

@@ -10,7 +10,7 @@ import numpy as np
 from .flat import FlatWindowC, OptionsC, SummaryC, default_options
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswf_hip.so")
+LIB_PATH = os.environ.get("SWF_LIB", os.path.join(_HERE, "libswf_hip.so"))   # SWF_LIB: A/B builds for tuning
 _pd = C.POINTER(C.c_double)
 _lib = None
 

@@ -1,0 +1,15 @@
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from rtk_visual_inertial_navigation_amd import synth, solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+w = synth.make_window(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+bs = solver.BatchSolver([w])
+for _ in range(3):
+    bs.reset_state(); bs.solve(default_options(step_mode=1), download=False)
+out = (C.c_ulonglong * 64)()
+solver.lib().swf_debug_chol_stamps(out)
+s = list(out)
+print("n_red", bs.dims(0)["n_red"])
+print("factor total ticks", s[1] - s[0], "backward", s[2] - s[1], "(s_memtime ticks; 100 MHz const clock => x10 ns)")
+print("mfma+init", s[8], "transpose", s[9], "diag", s[10], "trsm", s[11])
