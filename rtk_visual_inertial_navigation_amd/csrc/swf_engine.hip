@@ -498,6 +498,21 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cl_frow, B.cl_frow); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
     D.n_pair = (int)B.pair.size();
     PUT(pair, B.pair); PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
+    {
+        std::vector<int> pd, po, clc[3], cle;
+        for (size_t i = 0; i < B.pair.size(); i++) (B.pair[i].is_diag ? pd : po).push_back((int)i);
+        for (size_t i = 0; i < B.cl.size(); i++) {
+            const Clique& c = B.cl[i];
+            if (c.d_e > 0) cle.push_back((int)i);
+            if (c.is_static) continue;
+            int d = c.d_e + c.d_f;
+            int cls = (c.d_e <= 1 && d <= 32 && c.n_rows <= 48) ? 0 : (c.n_rows <= 32 && d <= 48) ? 1 : 2;
+            clc[cls].push_back((int)i);
+        }
+        D.n_pd = (int)pd.size(); D.n_po = (int)po.size(); D.n_cle = (int)cle.size();
+        PUT(pd_idx, pd); PUT(po_idx, po); PUT(cle_idx, cle);
+        for (int k = 0; k < 3; k++) { D.n_clc[k] = (int)clc[k].size(); rc |= P.put(clc[k], &D.clc_idx[k]); }
+    }
 #undef PUT
     // mutable buffers
     rc |= P.zeros(B.n_x, &D.x); rc |= P.zeros(B.n_x, &D.xc); rc |= P.zeros(B.n_x, &D.x0);
@@ -601,9 +616,18 @@ struct Launcher {
     void lin_elim(int write_S) {
         DevBatch& D = b->D;
         if (D.n_lm) { Bracket t(*this, SWF_K_LM_ELIM); hipLaunchKernelGGL(k_lm_elim, GRID((size_t)D.n_lm * 16, 256), dim3(256), 0, st, D, O); }
-        if (D.n_cl) { Bracket t(*this, SWF_K_CLIQUE_ELIM); hipLaunchKernelGGL(k_clique_elim, dim3(D.n_cl), dim3(256), 0, st, D, O); }
+        {
+            Bracket t(*this, SWF_K_CLIQUE_ELIM);
+            if (D.n_clc[0]) hipLaunchKernelGGL((k_clique_elim<48, 32, 64, 0>), dim3(D.n_clc[0]), dim3(64), 0, st, D, O);
+            if (D.n_clc[1]) hipLaunchKernelGGL((k_clique_elim<32, 48, 256, 1>), dim3(D.n_clc[1]), dim3(256), 0, st, D, O);
+            if (D.n_clc[2]) hipLaunchKernelGGL((k_clique_elim<64, 64, 256, 2>), dim3(D.n_clc[2]), dim3(256), 0, st, D, O);
+        }
         if (write_S && b->max_tiles) { Bracket t(*this, SWF_K_LM_GEMM); hipLaunchKernelGGL(k_lm_gemm, dim3((b->max_tiles + 3) / 4, D.n_win), dim3(256), 0, st, D); }
-        if (D.n_pair) { Bracket t(*this, SWF_K_ASSEMBLE); hipLaunchKernelGGL(k_assemble, GRID((size_t)D.n_pair * 64, 256), dim3(256), 0, st, D, O, write_S); }
+        {
+            Bracket t(*this, SWF_K_ASSEMBLE);
+            if (D.n_pd) hipLaunchKernelGGL(k_assemble<true>, GRID((size_t)D.n_pd * 64, 256), dim3(256), 0, st, D, O, write_S);
+        }
+        if (D.n_po && write_S) { Bracket t(*this, 15); hipLaunchKernelGGL(k_assemble<false>, GRID((size_t)D.n_po * 16, 256), dim3(256), 0, st, D, O, write_S); }
     }
     void reduced() {
         DevBatch& D = b->D;
@@ -616,18 +640,22 @@ struct Launcher {
         {
             Bracket t(*this, SWF_K_BACKSUB);
             if (D.n_lm) hipLaunchKernelGGL(k_backsub_lm, GRID(D.n_lm, 256), dim3(256), 0, st, D);
-            if (D.n_cl) hipLaunchKernelGGL(k_backsub_clique, dim3(D.n_cl), dim3(64), 0, st, D);
+            if (D.n_cle) hipLaunchKernelGGL(k_backsub_clique, GRID((size_t)D.n_cle * 16, 256), dim3(256), 0, st, D);
         }
         {
             Bracket t(*this, SWF_K_JTIMES);
             if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<0>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
-            if (D.n_gf) hipLaunchKernelGGL(k_jtimes_gen<0>, GRID((size_t)D.n_gf * 64, 256), dim3(256), 0, st, D, O);
+            if (D.n_sc) hipLaunchKernelGGL(k_jtimes_scalar<0>, GRID(D.n_sc, 256), dim3(256), 0, st, D, O);
+            if (D.n_imu) hipLaunchKernelGGL(k_jtimes_imu<0>, GRID((size_t)D.n_imu * 16, 256), dim3(256), 0, st, D, O);
+            if (D.n_prior) hipLaunchKernelGGL(k_jtimes_prior<0>, GRID((size_t)D.n_prior * 64, 256), dim3(256), 0, st, D, O);
         }
         { Bracket t(*this, SWF_K_DOGLEG); hipLaunchKernelGGL(k_dogleg, dim3(D.n_win), dim3(256), 0, st, D, O); }
         {
             Bracket t(*this, SWF_K_JTIMES);
             if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<1>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
-            if (D.n_gf) hipLaunchKernelGGL(k_jtimes_gen<1>, GRID((size_t)D.n_gf * 64, 256), dim3(256), 0, st, D, O);
+            if (D.n_sc) hipLaunchKernelGGL(k_jtimes_scalar<1>, GRID(D.n_sc, 256), dim3(256), 0, st, D, O);
+            if (D.n_imu) hipLaunchKernelGGL(k_jtimes_imu<1>, GRID((size_t)D.n_imu * 16, 256), dim3(256), 0, st, D, O);
+            if (D.n_prior) hipLaunchKernelGGL(k_jtimes_prior<1>, GRID((size_t)D.n_prior * 64, 256), dim3(256), 0, st, D, O);
         }
     }
     void cand_eval() {
@@ -743,7 +771,10 @@ extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, doub
     const WinRec& W = b->win[w];
     size_t n = (size_t)W.n_red;
     HIPCHK(hipStreamSynchronize(b->stream));
-    if (S) HIPCHK(hipMemcpy(S, b->D.S + W.S_base, n * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (S) {
+        HIPCHK(hipMemcpy(S, b->D.S + W.S_base, n * n * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < n; r++) for (size_t c = r + 1; c < n; c++) S[r * n + c] = S[c * n + r];   // device keeps the lower triangle
+    }
     if (rhs) HIPCHK(hipMemcpy(rhs, b->D.rhs + W.loc_base + W.n_e, n * sizeof(double), hipMemcpyDeviceToHost));
     if (L) {
         std::vector<double> Lt((n + 1) * (n + 1));

@@ -410,6 +410,11 @@ __global__ void __launch_bounds__(256) k_eval_prior(DevBatch B) {
 // aux = |J v|^2.  MODE 1: v = step, aux = (Jv).(r + Jv/2) (model cost change,
 // TrustRegionMinimizer::ComputeTrustRegionStep).
 // =========================================================================================
+__device__ __forceinline__ double grp16_sum(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 template <int MODE>
 __device__ __forceinline__ double vec_at(const DevBatch& B, const DevOpt& O, int loc) {
     if (MODE == 1) return B.step[loc];
@@ -428,37 +433,69 @@ __global__ void __launch_bounds__(256) k_jtimes_proj(DevBatch B, DevOpt O) {
     if (MODE == 0) B.p_aux[i] = a0 * a0 + a1 * a1;
     else B.p_aux[i] = a0 * (B.p_r[i] + a0 / 2.0) + a1 * (B.p_r[n + i] + a1 / 2.0);
 }
-// one wavefront per generic factor; lanes over residual rows
+// row k of (J v) for a generic factor
 template <int MODE>
-__global__ void __launch_bounds__(256) k_jtimes_gen(DevBatch B, DevOpt O) {
-    int f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (f >= B.n_gf) return;
+__device__ __forceinline__ double gf_row_dot(const DevBatch& B, const DevOpt& O, const GFac& G, int k) {
+    double a = 0;
+    if (G.type == GF_PRIOR) {
+        const double* row = B.prior_J + B.prior_Joff[G.data] + (size_t)k * G.nres;
+        int col = 0;
+        for (int t = 0; t < G.nslot; t++) {
+            int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
+            if (lo >= 0) for (int j = 0; j < l; j++) a += row[col + j] * vec_at<MODE>(B, O, lo + j);
+            col += l;
+        }
+    } else {
+        for (int t = 0; t < G.nslot; t++) {
+            int jo = B.s_joff[G.slot0 + t];
+            if (jo < 0) continue;
+            int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
+            const double* row = B.g_J + jo + k * l;
+            for (int j = 0; j < l; j++) a += row[j] * vec_at<MODE>(B, O, lo + j);
+        }
+    }
+    return a;
+}
+template <int MODE>
+__device__ __forceinline__ double gf_row_term(const DevBatch& B, const GFac& G, int k, double a) {
+    return MODE == 0 ? a * a : a * (B.g_r[G.roff + k] + a / 2.0);
+}
+// scalar (one-row) factors: one lane each
+template <int MODE>
+__global__ void __launch_bounds__(256) k_jtimes_scalar(DevBatch B, DevOpt O) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= B.n_sc) return;
+    int f = B.sc_gf[q];
+    const GFac& G = B.gf[f];
+    const WinState& s = B.ws[G.win];
+    if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;
+    B.g_aux[f] = gf_row_term<MODE>(B, G, 0, gf_row_dot<MODE>(B, O, G, 0));
+}
+// IMU factors: 16 lanes per factor, one residual row per lane
+template <int MODE>
+__global__ void __launch_bounds__(256) k_jtimes_imu(DevBatch B, DevOpt O) {
+    int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    bool valid = q < B.n_imu;
+    int f = B.imu_gf[valid ? q : B.n_imu - 1];
+    const GFac& G = B.gf[f];
+    const WinState& s = B.ws[G.win];
+    bool act = valid && (MODE == 0 ? s.need_lin : s.eval_cand);
+    double part = 0;
+    if (act && sub < 15) part = gf_row_term<MODE>(B, G, sub, gf_row_dot<MODE>(B, O, G, sub));
+    part = grp16_sum(part);
+    if (act && sub == 0) B.g_aux[f] = part;
+}
+// priors: one wavefront per prior, lanes over residual rows
+template <int MODE>
+__global__ void __launch_bounds__(256) k_jtimes_prior(DevBatch B, DevOpt O) {
+    int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (q >= B.n_prior) return;
+    int f = B.prior_gf[q];
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
     if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;
     double part = 0;
-    for (int k = lane; k < G.nres; k += 64) {
-        double a = 0;
-        if (G.type == GF_PRIOR) {
-            const double* row = B.prior_J + B.prior_Joff[G.data] + (size_t)k * G.nres;
-            int col = 0;
-            for (int t = 0; t < G.nslot; t++) {
-                int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
-                if (lo >= 0) for (int j = 0; j < l; j++) a += row[col + j] * vec_at<MODE>(B, O, lo + j);
-                col += l;
-            }
-        } else {
-            for (int t = 0; t < G.nslot; t++) {
-                int jo = B.s_joff[G.slot0 + t];
-                if (jo < 0) continue;
-                int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
-                const double* row = B.g_J + jo + k * l;
-                for (int j = 0; j < l; j++) a += row[j] * vec_at<MODE>(B, O, lo + j);
-            }
-        }
-        if (MODE == 0) part += a * a;
-        else part += a * (B.g_r[G.roff + k] + a / 2.0);
-    }
+    for (int k = lane; k < G.nres; k += 64) part += gf_row_term<MODE>(B, G, k, gf_row_dot<MODE>(B, O, G, k));
     part = wave_sum(part);
     if (lane == 0) B.g_aux[f] = part;
 }
@@ -471,11 +508,6 @@ __global__ void __launch_bounds__(256) k_jtimes_gen(DevBatch B, DevOpt O) {
 // In-tree analogue of this arithmetic: MarginalizationInfo::marginalize,
 // R/factor/marginalization_factor.cpp:260-377; in Ceres it is SchurEliminator::Eliminate.
 // =========================================================================================
-__device__ __forceinline__ double grp16_sum(double v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 __global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
     // 16 lanes per landmark: lanes stride over its observations (all loads of a round are in
     // flight together), 16-lane butterflies reduce H_ll / g_l, every lane then owns whole
@@ -559,29 +591,31 @@ __global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
 // =========================================================================================
 #define CLQ_MAXD 64
 #define CLQ_MAXR 64
-__global__ void __launch_bounds__(256) k_clique_elim(DevBatch B, DevOpt O) {
-    __shared__ double Jc[CLQ_MAXR][CLQ_MAXD + 1];   // dense clique Jacobian: rows = residual rows, cols = [e | members]
-    __shared__ double M[CLQ_MAXD][CLQ_MAXD + 1];
-    __shared__ double rv[CLQ_MAXR];
-    __shared__ double gv[CLQ_MAXD];
+// size classes (host-assigned): 0 = d_e<=1, <=48 rows, <=32 cols, one wavefront (receiver clocks,
+// dummy, small free groups); 1 = <=32 rows, <=48 cols (speed-bias cliques); 2 = up to 64 x 64
+template <int MAXR, int MAXD, int NT, int CLS>
+__global__ void __launch_bounds__(NT) k_clique_elim(DevBatch B, DevOpt O) {
+    __shared__ double Jc[MAXR][MAXD + 1];           // dense clique Jacobian: rows = residual rows, cols = [e | members]
+    __shared__ double M[MAXD][MAXD + 1];
+    __shared__ double rv[MAXR];
+    __shared__ double gv[MAXD];
     __shared__ double A[9][19];                     // Gauss-Jordan work [M_ee | I]
-    __shared__ double T[9][CLQ_MAXD + 1];
+    __shared__ double T[9][MAXD + 1];
     __shared__ double Eg[9];
     __shared__ int fail;
-    int c = blockIdx.x;
-    if (c >= B.n_cl) return;
-    const Clique& C = B.cl[c];
-    if (C.is_static) return;
+    if ((int)blockIdx.x >= B.n_clc[CLS]) return;
+    const Clique& C = B.cl[B.clc_idx[CLS][blockIdx.x]];
     WinState& s = B.ws[C.win];
     if (!s.need_lin) return;
     int de = C.d_e, df = C.d_f, d = de + df, tid = threadIdx.x, nrow = C.n_rows;
-    for (int e = tid; e < nrow * (CLQ_MAXD + 1); e += blockDim.x) (&Jc[0][0])[e] = 0.0;
+    for (int e = tid; e < nrow * d; e += blockDim.x) Jc[e / d][e % d] = 0.0;
     if (tid == 0) fail = 0;
     __syncthreads();
     // scatter the factors' Jacobian blocks into Jc: 8 groups of 32 lanes, one factor per group
     {
+        constexpr int NG = NT / 32;
         int grp = tid >> 5, gl = tid & 31;
-        for (int q = C.fac0 + grp; q < C.fac1; q += 8) {
+        for (int q = C.fac0 + grp; q < C.fac1; q += NG) {
             const GFac& G = B.gf[B.cl_fac[q]];
             int r0 = B.cl_frow[q];
             for (int k = gl; k < G.nres; k += 32) rv[r0 + k] = B.g_r[G.roff + k];
@@ -704,15 +738,19 @@ __global__ void __launch_bounds__(256) k_lm_gemm(DevBatch B) {
 
 // =========================================================================================
 // Owner-computes assembly of the reduced system: one wavefront per structurally non-zero
-// block pair (a >= b in elimination order) writes S[a,b] (and its mirror) exactly once:
+// block pair (a >= b in elimination order) writes S[a,b] (lower triangle) exactly once:
 //   S_ab = [a,b poses with observations]  (a==b ? sum_o Jp^T Jp : 0) - P[fa,fb]
 //        + sum_cliques C_k[a,b]  + (a==b) mu * clamp(diag_a)
 // Diagonal pairs also produce g_a, diag_a and rhs_a = g_a + sum cs_k - (Y g_l)_a.
 // =========================================================================================
+// DIAG = true : one wavefront per diagonal pair (needs wave reductions over the frame's observations)
+// DIAG = false: 16 lanes per off-diagonal pair (four pairs per wavefront; no cross-lane traffic)
+template <bool DIAG>
 __global__ void __launch_bounds__(256) k_assemble(DevBatch B, DevOpt O, int write_S) {
-    int pidx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (pidx >= B.n_pair) return;
-    const Pair& Pr = B.pair[pidx];
+    constexpr int G = DIAG ? 64 : 16;
+    int gidx = (blockIdx.x * blockDim.x + threadIdx.x) / G, lane = threadIdx.x % G;
+    if (gidx >= (DIAG ? B.n_pd : B.n_po)) return;
+    const Pair& Pr = B.pair[(DIAG ? B.pd_idx : B.po_idx)[gidx]];
     const WinState& s = B.ws[Pr.win];
     if (!s.need_lin) return;
     const WinRec& W = B.win[Pr.win];
@@ -720,7 +758,7 @@ __global__ void __launch_bounds__(256) k_assemble(DevBatch B, DevOpt O, int writ
     double* S = B.S + W.S_base;
     const double* P = B.P + W.P_base;
     double H[21], gr[6], qv[6];
-    bool obs = Pr.is_diag && Pr.fa >= 0;
+    bool obs = DIAG && Pr.fa >= 0;
     if (obs) {
         for (int k = 0; k < 21; k++) H[k] = 0;
         for (int k = 0; k < 6; k++) { gr[k] = 0; qv[k] = 0; }
@@ -752,7 +790,7 @@ __global__ void __launch_bounds__(256) k_assemble(DevBatch B, DevOpt O, int writ
     }
     // diagonal bookkeeping first (needed for damping)
     double dg_i = 0;    // lane i < la: raw diag of column i
-    if (Pr.is_diag && lane < la) {
+    if (DIAG && lane < la) {
         double gi = 0, cs = 0;
         if (obs) { int i = lane; gi = gr[i]; dg_i = H[i * (i + 1) / 2 + i]; cs = -qv[i]; }
         for (int c = Pr.c0; c < Pr.c1; c++) {
@@ -764,11 +802,11 @@ __global__ void __launch_bounds__(256) k_assemble(DevBatch B, DevOpt O, int writ
     }
     if (!write_S) return;      // final pass: cost + gradient only, keep (S, rhs, L) of the last solve
     // damping source per entry, fetched in uniform control flow (la*lb <= 81 => two rounds)
-    double dgs0 = __shfl(dg_i, (lane / lb) & 63, 64);
-    double dgs1 = __shfl(dg_i, ((lane + 64) / lb) & 63, 64);
-    for (int e = lane; e < la * lb; e += 64) {
+    double dgs0 = 0, dgs1 = 0;
+    if (DIAG) { dgs0 = __shfl(dg_i, (lane / lb) & 63, 64); dgs1 = __shfl(dg_i, ((lane + 64) / lb) & 63, 64); }
+    for (int e = lane; e < la * lb; e += G) {
         int i = e / lb, j = e % lb;
-        if (Pr.is_diag && j > i) continue;          // lower half only; the mirror store fills the rest
+        if (DIAG && j > i) continue;                // lower half only; the mirror store fills the rest
         double v = 0;
         if (Pr.fa >= 0 && Pr.fb >= 0) {
             int pr = 6 * Pr.fa + i, pc = 6 * Pr.fb + j;
@@ -776,8 +814,7 @@ __global__ void __launch_bounds__(256) k_assemble(DevBatch B, DevOpt O, int writ
             if (obs) { int hi = i > j ? i : j, lo = i > j ? j : i; v += H[hi * (hi + 1) / 2 + lo]; }
         }
         for (int c = Pr.c0; c < Pr.c1; c++) v += B.C[B.pc_coff[c] + (size_t)i * B.pc_cld[c] + j];
-        if (Pr.is_diag && i == j) v += s.mu * clampd(e < 64 ? dgs0 : dgs1, O.min_diag, O.max_diag);
-        S[(size_t)(Pr.ra + i) * n + Pr.rb + j] = v;
-        S[(size_t)(Pr.rb + j) * n + Pr.ra + i] = v;
+        if (DIAG && i == j) v += s.mu * clampd(e < 64 ? dgs0 : dgs1, O.min_diag, O.max_diag);
+        S[(size_t)(Pr.ra + i) * n + Pr.rb + j] = v;      // lower triangle only; exports mirror on the host
     }
 }

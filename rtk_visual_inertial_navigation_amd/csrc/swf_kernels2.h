@@ -281,30 +281,31 @@ __global__ void __launch_bounds__(256) k_backsub_lm(DevBatch B) {
     B.y[loc + 1] = e10 * t0 + e11 * t1 + e21 * t2;
     B.y[loc + 2] = e20 * t0 + e21 * t1 + e22 * t2;
 }
-__global__ void __launch_bounds__(64) k_backsub_clique(DevBatch B) {
-    __shared__ double t[9];
-    int c = blockIdx.x;
-    if (c >= B.n_cl) return;
-    const Clique& C = B.cl[c];
-    if (C.d_e == 0) return;
+__global__ void __launch_bounds__(256) k_backsub_clique(DevBatch B) {
+    // 16 lanes per clique with an eliminated block (d_e <= 9): lane a forms t_a = g_e[a] - (M_ef y_f)_a,
+    // the Einv product gathers the t's with 16-wide shuffles
+    int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15, lane = threadIdx.x & 63;
+    bool valid = q < B.n_cle;
+    const Clique& C = B.cl[B.cle_idx[valid ? q : B.n_cle - 1]];
     const WinState& s = B.ws[C.win];
-    if (!s.need_lin || s.lin_fail) return;
-    int de = C.d_e, df = C.d_f, lane = threadIdx.x;
+    bool act = valid && s.need_lin && !s.lin_fail;
+    int de = C.d_e, df = C.d_f;
     const double* E = B.cE + C.e_off;
-    if (lane < de) {
-        double a = E[de * de + de * df + lane];
+    double t = 0;
+    if (act && sub < de) {
+        t = E[de * de + de * df + sub];
         for (int m = C.mem0; m < C.mem1; m++) {
             int lo = B.cm_loc[m], l = B.cm_ls[m], cc = B.cm_col[m];
-            for (int j = 0; j < l; j++) a -= E[de * de + lane * df + cc + j] * B.y[lo + j];
+            for (int j = 0; j < l; j++) t -= E[de * de + sub * df + cc + j] * B.y[lo + j];
         }
-        t[lane] = a;
     }
-    __syncthreads();
-    if (lane < de) {
-        double a = 0;
-        for (int b = 0; b < de; b++) a += E[lane * de + b] * t[b];
-        B.y[C.e_loc + lane] = a;
+    double a = 0;
+#pragma unroll
+    for (int b = 0; b < 9; b++) {
+        double tb = __shfl(t, (lane & ~15) + b, 64);
+        if (act && sub < de && b < de) a += E[sub * de + b] * tb;
     }
+    if (act && sub < de) B.y[C.e_loc + sub] = a;
 }
 
 // =========================================================================================

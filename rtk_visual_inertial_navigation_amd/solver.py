@@ -20,7 +20,7 @@ class SwfError(RuntimeError):
 
 
 K_NAMES = ["total", "eval_proj", "eval_imu", "eval_scalar", "eval_prior", "lm_elim", "clique_elim", "lm_gemm",
-           "assemble", "chol_solve", "backsub", "jtimes", "dogleg", "cand_eval", "decide", "_15"]
+           "assemble", "chol_solve", "backsub", "jtimes", "dogleg", "cand_eval", "decide", "assemble_off"]
 
 
 class TimingC(C.Structure):
@@ -146,7 +146,7 @@ class BatchSolver:
         """mask: bit k brackets kernel K_NAMES[k] with a HIP event pair per launch (bit 0 = whole solve);
         True = everything."""
         if mask is True:
-            mask = 0x7fff
+            mask = 0xffff
         _chk(lib().swf_batch_enable_timing(self._h, C.c_int32(int(mask))), "swf_batch_enable_timing")
 
     def timing(self):
@@ -154,7 +154,7 @@ class BatchSolver:
         _chk(lib().swf_batch_timing(self._h, C.byref(t)), "swf_batch_timing")
         d = dict(jacobian_bytes=t.jacobian_bytes, proj_bytes=t.proj_bytes, chol_flops=t.chol_flops,
                  n_linearizations=t.n_linearizations, total_ms=t.ms[0])
-        d["kernels"] = {K_NAMES[k]: dict(ms=t.ms[k], calls=t.calls[k]) for k in range(15) if t.calls[k]}
+        d["kernels"] = {K_NAMES[k]: dict(ms=t.ms[k], calls=t.calls[k]) for k in range(16) if t.calls[k]}
         return d
 
 
