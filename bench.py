@@ -96,10 +96,10 @@ def main():
     from rtk_visual_inertial_navigation_amd.flat import default_options
     solver.set_device(local_rank)
 
+    from rtk_visual_inertial_navigation_amd import shard
     B = a.windows
-    seed0 = synth.BASE_SEED + a.config + rank * B
     t0 = time.perf_counter()
-    windows = make_windows(a.config, [seed0 + i for i in range(B)])
+    windows = make_windows(a.config, shard.window_seeds(synth.BASE_SEED, a.config, B, rank))
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     bs = solver.BatchSolver(windows)
@@ -132,18 +132,10 @@ def main():
             d = acc.setdefault(k, dict(ms=0.0, calls=0)); d["ms"] += v["ms"]; d["calls"] += v["calls"]
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = shard.allreduce([dt], "max", device="cuda")[0]          # RCCL all-reduce (harness only)
     sms = bs.summaries()
-    its_local = sum(s.num_iterations for s in sms)
-    if world > 1:
-        ti = torch.tensor([its_local], device="cuda", dtype=torch.float64)
-        dist.all_reduce(ti, op=dist.ReduceOp.SUM)
-        its_total = float(ti.item())
-    else:
-        its_total = float(its_local)
+    its_total = shard.allreduce([float(sum(s.num_iterations for s in sms))], "sum", device="cuda")[0]
+    job = shard.gather_summaries(np.array([[s.final_cost, s.num_iterations, s.termination] for s in sms]), device="cuda")
     value = its_total * a.steps / dt
 
     if rank == 0:
@@ -190,6 +182,7 @@ def main():
                        "windows_per_gpu": B, "max_num_iterations": a.iters, "sharding": "independent windows, no data-path collective"},
             "windows_per_sec": world * B * a.steps / dt,
             "iterations_per_window": its_total / (world * B),
+            "job_final_cost_mean": float(job[:, 0].mean()), "job_windows": int(job.shape[0]),
             "roofline": roof,
             "roofline_jacobian": jac,
             "kernel_ms_per_solve_calibration": {k: v["ms"] for k, v in calib["kernels"].items()},

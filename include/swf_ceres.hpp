@@ -1,0 +1,201 @@
+// swf_ceres.hpp — header-only C++ adapter: the ceres::Problem / ceres::Solver names the
+// reference's estimator uses, implemented over the C-ABI of swf_solver.h.
+//
+// Purpose: estimator code written in the reference's style —
+//     ceres::LossFunction* loss = new ceres::CauchyLoss(1.0);
+//     projection_factor* f = new projection_factor(pts);
+//     my_problem.AddResidualBlock(f, loss, para_pose[j], para_ex_Pose[0], point.data());
+//     ceres::Solve(my_options, &my_problem, &summary);
+// — compiles against this header instead of <ceres/ceres.h> + the reference's factor headers.
+// The factor classes below carry only the CONSTRUCTOR ARGUMENTS (data); their arithmetic runs in
+// the HIP kernels.  Nothing here evaluates a residual on the CPU.
+//
+// Mapping (reference file:line -> here):
+//   projection_factor(pts)                      R/factor/projection_factor.h:9-18     -> swf_add_projection
+//   IMUFactor(pre_integration)                  R/factor/imu_factor.h:7-19            -> swf_add_imu (SWF_PRE_DOUBLES record)
+//   RTKCarrierPhaseFactor(...)                  R/factor/gnss_factor.h:8-40           -> swf_add_rtk_carrier_phase
+//   RTKPseudorangeFactor(...)                   R/factor/gnss_factor.h:43-66          -> swf_add_rtk_pseudorange
+//   SppDopplerFactor(...)                       R/factor/gnss_factor.h:108-131        -> swf_add_doppler
+//   InitialBlackFactor(istd)                    R/factor/initial_factor.h:42-48       -> swf_add_scalar_prior
+//   MarginalizationFactor(info)                 R/factor/marginalization_factor.h:104-110 -> swf_add_linear_prior
+//   ceres::internal::{parameter_head,is_optimize,lhs_out,rhs_out,lhs_out2,hs_row}
+//                                               R/swf/swf_gnss.cpp:25-94              -> swf_ceres::internal::* below
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "swf_solver.h"
+
+namespace swf_ceres {
+
+enum LinearSolverType { DENSE_SCHUR };
+enum TrustRegionStrategyType { DOGLEG };
+
+class LossFunction { public: virtual ~LossFunction() {} virtual double a() const = 0; };
+class CauchyLoss : public LossFunction { public: explicit CauchyLoss(double a) : a_(a) {} double a() const override { return a_; } private: double a_; };
+class LocalParameterization { public: virtual ~LocalParameterization() {} };
+
+// ---- typed cost functions (data carriers) ------------------------------------------------
+struct CostFunction { virtual ~CostFunction() {} };
+struct projection_factor : CostFunction {
+    double uv[2];
+    static double& sqrt_info() { static double v = 1000.0 / 1.5; return v; }   // R/swf/swf.cpp:47
+    template <class V3> explicit projection_factor(const V3& pts) { uv[0] = pts[0]; uv[1] = pts[1]; }
+};
+struct IMUFactor : CostFunction {
+    std::vector<double> pre;   // SWF_PRE_DOUBLES record, see include/swf_types.h
+    explicit IMUFactor(const double* record) : pre(record, record + SWF_PRE_DOUBLES) {}
+};
+struct RTKCarrierPhaseFactor : CostFunction {
+    double dat[SWF_CP_DOUBLES];
+    RTKCarrierPhaseFactor(const double* sat, double L1_lam, double lam, double el, double br_time_diff, double mea_var,
+                          const double* /*base_pos: window constant*/, bool use_istd, int /*sys*/, int /*f*/) {
+        dat[0] = sat[0]; dat[1] = sat[1]; dat[2] = sat[2]; dat[3] = L1_lam; dat[4] = lam; dat[5] = el;
+        dat[6] = br_time_diff; dat[7] = mea_var; dat[8] = use_istd ? 1.0 : 0.0;
+    }
+};
+struct RTKPseudorangeFactor : CostFunction {
+    double dat[SWF_PR_DOUBLES];
+    RTKPseudorangeFactor(const double* sat, double P1, double el, double br_time_diff, double mea_var, const double* /*base_pos*/) {
+        dat[0] = sat[0]; dat[1] = sat[1]; dat[2] = sat[2]; dat[3] = P1; dat[4] = el; dat[5] = br_time_diff; dat[6] = mea_var;
+    }
+};
+struct SppDopplerFactor : CostFunction {
+    double dat[SWF_DOP_DOUBLES];
+    SppDopplerFactor(const double* satv, const double* sat, const double* /*xyzt*/, double D1_lam, double istd, const double* /*base_pos*/) {
+        for (int k = 0; k < 3; k++) { dat[k] = sat[k]; dat[3 + k] = satv[k]; }
+        dat[6] = D1_lam; dat[7] = istd;
+    }
+};
+struct InitialBlackFactor : CostFunction { double istd; explicit InitialBlackFactor(double w) : istd(w) {} };
+// MarginalizationInfo's product: the linearised prior (J, r0, x0) over its kept blocks
+struct MarginalizationFactor : CostFunction {
+    std::vector<double> J, r0, x0;
+    MarginalizationFactor(const double* J_, const double* r0_, const double* x0_, int dim, int global_sum)
+        : J(J_, J_ + (size_t)dim * dim), r0(r0_, r0_ + dim), x0(x0_, x0_ + global_sum) {}
+};
+
+class PoseLocalParameterization : public LocalParameterization {};   // R/factor/pose_local_parameterization.h
+
+class ParameterBlockOrdering {
+  public:
+    void Clear() { keys_.clear(); groups_.clear(); }
+    void AddElementToGroup(double* p, int group) { keys_.push_back(p); groups_.push_back(group); }
+    int NumElements() const { return (int)keys_.size(); }
+    std::vector<double*> keys_; std::vector<int32_t> groups_;
+};
+
+namespace internal {
+// the modified Ceres' private globals, as the reference uses them (R/swf/swf_gnss.cpp:25-94)
+inline std::vector<double*>& parameter_head_ref() { static std::vector<double*> v; return v; }
+inline bool& is_optimize_ref() { static bool v = true; return v; }
+#define parameter_head parameter_head_ref()
+#define is_optimize is_optimize_ref()
+struct Exports { const double* lhs_out = nullptr; const double* rhs_out = nullptr; const double* lhs_out2 = nullptr; int hs_row = 0; };
+inline Exports& exports() { static Exports e; return e; }
+}  // namespace internal
+
+typedef int32_t ResidualBlockId;
+
+class Problem {
+  public:
+    Problem() { if (swf_problem_create(&h_) != SWF_OK) throw std::runtime_error("swf_problem_create"); }
+    ~Problem() { swf_problem_destroy(h_); }
+    Problem(const Problem&) = delete;
+    swf_problem* handle() { return h_; }
+
+    void AddParameterBlock(double* p, int size, LocalParameterization* lp = nullptr) {
+        chk(swf_add_parameter_block(h_, p, size, lp ? SWF_MANIFOLD_POSE : SWF_MANIFOLD_NONE), "AddParameterBlock");
+        delete lp;                       // Problem takes ownership, as in ceres
+    }
+    bool HasParameterBlock(const double* p) const { return swf_has_parameter_block(h_, p) != 0; }
+    void RemoveParameterBlock(double* p) { chk(swf_remove_parameter_block(h_, p), "RemoveParameterBlock"); }
+    void SetParameterBlockConstant(double* p) { chk(swf_set_parameter_block_constant(h_, p), "SetParameterBlockConstant"); }
+    void SetParameterBlockVariable(double* p) { chk(swf_set_parameter_block_variable(h_, p), "SetParameterBlockVariable"); }
+    bool IsParameterBlockConstant(const double* p) const { return swf_is_parameter_block_constant(h_, p) != 0; }
+    int ParameterBlockSize(const double* p) const { return swf_parameter_block_size(h_, p); }
+    int NumParameterBlocks() const { return swf_num_parameter_blocks(h_); }
+    int NumResidualBlocks() const { return swf_num_residual_blocks(h_); }
+    void RemoveResidualBlock(ResidualBlockId id) { chk(swf_remove_factor(h_, id), "RemoveResidualBlock"); }
+    void SetResidualBlockUse(ResidualBlockId id, bool is_use) { chk(swf_factor_set_enabled(h_, id, is_use), "is_use"); }
+    void SetConstants(const double* pbg, const double* gw, const double* base) { chk(swf_set_constants(h_, pbg, gw, base), "SetConstants"); }
+
+    // AddResidualBlock overloads by cost-function type; Problem takes ownership of cost and loss
+    ResidualBlockId AddResidualBlock(projection_factor* f, LossFunction* loss, double* pose, double* ex, double* pt) {
+        ResidualBlockId id = swf_add_projection(h_, pose, ex, pt, f->uv, projection_factor::sqrt_info(), loss ? loss->a() : 0.0);
+        delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(IMUFactor* f, LossFunction* loss, double* pi, double* si, double* pj, double* sj) {
+        ResidualBlockId id = swf_add_imu(h_, pi, si, pj, sj, f->pre.data()); delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(RTKCarrierPhaseFactor* f, LossFunction* loss, double* pose, double* amb, double* clk) {
+        ResidualBlockId id = swf_add_rtk_carrier_phase(h_, pose, amb, clk, f->dat); delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(RTKPseudorangeFactor* f, LossFunction* loss, double* pose, double* clk) {
+        ResidualBlockId id = swf_add_rtk_pseudorange(h_, pose, clk, f->dat); delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(SppDopplerFactor* f, LossFunction* loss, double* sb, double* drift, double* pose) {
+        ResidualBlockId id = swf_add_doppler(h_, sb, drift, pose, f->dat); delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(InitialBlackFactor* f, LossFunction* loss, double* scalar) {
+        ResidualBlockId id = swf_add_scalar_prior(h_, scalar, f->istd); delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(MarginalizationFactor* f, LossFunction* loss, const std::vector<double*>& blocks) {
+        ResidualBlockId id = swf_add_linear_prior(h_, blocks.data(), (int32_t)blocks.size(), f->J.data(), f->r0.data(), f->x0.data());
+        delete f; delete loss; return ck(id);
+    }
+
+  private:
+    static void chk(int rc, const char* what) { if (rc != SWF_OK) throw std::runtime_error(std::string(what) + ": " + swf_last_error()); }
+    static ResidualBlockId ck(ResidualBlockId id) { if (id < 0) throw std::runtime_error(std::string("AddResidualBlock: ") + swf_last_error()); return id; }
+    swf_problem* h_ = nullptr;
+};
+
+struct Solver {
+    struct Options {
+        LinearSolverType linear_solver_type = DENSE_SCHUR;
+        TrustRegionStrategyType trust_region_strategy_type = DOGLEG;
+        int max_num_iterations = 8;
+        int num_threads = 4;                 // accepted, unused: the device decides its own parallelism
+        bool jacobi_scaling = false;         // the reference sets 0 (R/swf/swf.cpp:27); scaling is not implemented
+        double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16;
+        std::shared_ptr<ParameterBlockOrdering> linear_solver_ordering;
+    };
+    struct Summary {
+        double initial_cost = 0, final_cost = 0, minimizer_time_in_seconds = 0;
+        int num_successful_steps = 0, num_unsuccessful_steps = 0, termination = 0;
+        swf_summary raw;
+        std::string BriefReport() const {
+            char b[256];
+            snprintf(b, sizeof b, "swf (MI355X) Report: Iterations: %d, Initial cost: %e, Final cost: %e, Termination: %d",
+                     raw.num_iterations, initial_cost, final_cost, termination);
+            return b;
+        }
+    };
+};
+
+// ceres::Solve(options, &problem, &summary) — R/swf/swf_image.cpp:219
+inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* s) {
+    swf_options opt; swf_options_default(&opt);
+    opt.max_num_iterations = o.max_num_iterations;
+    opt.initial_trust_region_radius = o.initial_trust_region_radius;
+    opt.max_trust_region_radius = o.max_trust_region_radius;
+    opt.step_mode = internal::is_optimize ? SWF_OPTIMIZE : SWF_ASSEMBLE_ELIMINATE_ONLY;
+    if (o.linear_solver_ordering)
+        swf_set_ordering(p->handle(), o.linear_solver_ordering->keys_.data(), o.linear_solver_ordering->groups_.data(), o.linear_solver_ordering->NumElements());
+    swf_set_export_tail(p->handle(), internal::parameter_head.data(), (int32_t)internal::parameter_head.size());
+    std::memset(&s->raw, 0, sizeof(s->raw));
+    int rc = swf_problem_solve(p->handle(), &opt, &s->raw);
+    s->initial_cost = s->raw.initial_cost; s->final_cost = rc == SWF_OK ? s->raw.final_cost : 1e300;   // callers test final_cost > 1e10
+    s->minimizer_time_in_seconds = s->raw.minimizer_time_in_seconds;
+    s->num_successful_steps = s->raw.num_successful_steps; s->num_unsuccessful_steps = s->raw.num_unsuccessful_steps;
+    s->termination = s->raw.termination;
+    internal::Exports& e = internal::exports();
+    if (rc == SWF_OK) swf_get_reduced(p->handle(), &e.lhs_out, &e.rhs_out, &e.lhs_out2, &e.hs_row);
+}
+
+}  // namespace swf_ceres

@@ -80,3 +80,35 @@ def test_no_cpu_fallback_without_gpu():
     w = synth.make_window(2, K=3, F=5, S=0, seed=3)
     with pytest.raises(solver.SwfError):
         solver.BatchSolver([w])
+
+
+def _compile_shim_example(tmp_path):
+    import subprocess
+    build.build()
+    exe = os.path.join(str(tmp_path), "shim_example")
+    libdir = os.path.dirname(solver.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "shim_example.cpp"),
+                           "-o", exe, "-L" + libdir, "-lswf_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_ceres_shaped_cpp_header_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """Estimator code in the reference's style (ceres::Problem / AddResidualBlock / ceres::Solve)
+    compiles against include/swf_ceres.hpp; without a GPU the solve reports final_cost > 1e10
+    (the failure convention the reference checks, R/swf/swf_image.cpp:220-223)."""
+    import subprocess
+    exe = _compile_shim_example(tmp_path)
+    if solver.device_count() > 0:
+        pytest.skip("a GPU is present (the run is covered by the gpu test)")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Final cost: 1.000000e+300" in r.stdout
+
+
+@pytest.mark.gpu
+def test_ceres_shaped_cpp_example_runs_on_gpu(tmp_path):
+    import subprocess
+    exe = _compile_shim_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Iterations:" in r.stdout
