@@ -24,11 +24,11 @@ struct WinRec {
     int lm0, lm1;                // landmark records
     int fr_base, nF;             // observing frames (pose blocks that carry observations)
     long long P_base;            // (6 nF)^2 landmark Schur product
-    long long YW_base;           // [3 nL][6 nF] Yt / Wt
+    long long YW_base;           // [nL][nF][36] cells: Y(3x6) | W(3x6) per (landmark, frame)
     int gf0, gf1;                // generic (non-projection) factors
     int cl0, cl1;                // cliques
     int pair0, pair1;            // reduced block pairs
-    int pad0, pad1;
+    int fsb0, fsb1;              // frame-sum blocks of this window
     double proj_sqrt_info, proj_loss_a;
     double pbg[3], gw[3], base[3];
 };
@@ -62,6 +62,7 @@ struct Clique {
     int e_off;                   // d_e*d_e Einv + d_e*d_f strip + d_e g_e   (offset into e-buffer)
     int is_static;               // 1: prior clique, C/dgraw precomputed; only graw changes
     int n_rows;                  // total residual rows of the clique's factors
+    int gl0, gl1, rl0, rl1;      // gather lists: Jacobian entries / residual rows
 };
 
 // ---- reduced block pair (a >= b in elimination order): one wave assembles S[a,b] --------
@@ -93,12 +94,16 @@ struct DevBatch {
     const int* p_win; const int* p_xpose; const int* p_xex; const int* p_xlm;
     const int* p_lpose; const int* p_llm; const int* p_fr; const int* p_lm;
     const double* p_uv;
-    double* p_r; double* p_Jp; double* p_Jl; double* p_cost; double* p_aux;
+    double* p_r; double* p_Jp; double* p_Jl; double* p_yg; double* p_cost; double* p_aux;
+    // two-level per-frame sums: blocks of <= 256 observations of one window
+    int n_fsb; const int* fsb_win; const int* fsb_obs0; const int* fsb_perm; const int* fsb_foff; const int* fsb_foff0; const int* fsb_out0;
+    double* fs_part;
     // landmarks
     int n_lm;
     const int* lm_win; const int* lm_obs0; const int* lm_loc; const int* lm_col;
     double* lm_Einv; double* lm_g;             // SoA stride n_lm: 6 / 3
-    double* Yt; double* Wt; double* P;
+    double* YW; double* P;                     // landmark Schur cells, product
+    const unsigned long long* lm_fmask;        // frames (slots < 64) each landmark is observed in
     // frames
     int n_fr;
     const int* fr_obs0; const int* fr_obs;     // CSR of observations per frame
@@ -121,6 +126,7 @@ struct DevBatch {
     const int* cm_loc; const int* cm_ls; const int* cm_col;
     double* C; double* cv_graw; double* cv_dgraw; double* cv_cs; double* cE;
     int n_clc[3]; const int* clc_idx[3];       // non-static cliques by size class
+    const int* cg_dst; const int* cg_src; const int* cr_dst; const int* cr_src;   // clique gather lists
     int n_cle; const int* cle_idx;             // cliques with an eliminated block (back-substitution)
     // pairs
     int n_pair;

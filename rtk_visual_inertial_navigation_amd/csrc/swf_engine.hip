@@ -87,6 +87,9 @@ struct Build {
     std::vector<int> p_win, p_xpose, p_xex, p_xlm, p_lpose, p_llm, p_fr, p_lm;
     std::vector<double> p_uv;
     std::vector<int> lm_win, lm_obs0, lm_loc, lm_col;
+    std::vector<unsigned long long> lm_fmask;
+    std::vector<int> fsb_win, fsb_obs0, fsb_perm, fsb_foff, fsb_foff0, fsb_out0;
+    long long fs_tot = 0;
     std::vector<int> fr_obs0, fr_obs;
     std::vector<GFac> gf;
     std::vector<int> s_x, s_loc, s_ls, s_joff, s_ccol;
@@ -96,7 +99,7 @@ struct Build {
     std::vector<long long> prior_Joff;
     std::vector<double> prior_J, prior_r0, prior_x0;
     std::vector<Clique> cl;
-    std::vector<int> cl_fac, cl_frow, cm_loc, cm_ls, cm_col;
+    std::vector<int> cl_fac, cl_frow, cm_loc, cm_ls, cm_col, cg_dst, cg_src, cr_dst, cr_src;
     std::vector<double> C_init, dgraw_init;      // static parts (prior cliques)
     std::vector<Pair> pair;
     std::vector<long long> pc_coff;
@@ -207,7 +210,13 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
             B.lm_obs0.push_back(R.proj0 + lm_first[l]);
             B.lm_loc.push_back(gloc(b));
             B.lm_col.push_back(3 * l);
+            B.lm_fmask.push_back(0ULL);
         }
+        for (int q = R.proj0; q < (int)B.p_win.size(); q++) {
+            int f = B.p_fr[q];
+            if (f >= 0) B.lm_fmask[B.p_lm[q]] |= (f < 64) ? (1ULL << f) : ~0ULL;
+        }
+        if (R.nF > 64) for (int l = 0; l < nL; l++) B.lm_fmask[R.lm0 + l] = ~0ULL;   // no skipping beyond 64 frames
         for (int f = 0; f < R.nF; f++) {
             B.fr_obs0.push_back((int)B.fr_obs.size());
             for (int o : fobs[f]) B.fr_obs.push_back(o);
@@ -216,11 +225,31 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     }
     R.proj1 = (int)B.p_win.size();
     R.lm1 = (int)B.lm_win.size();
-    R.P_base = B.P_tot; B.P_tot += (long long)36 * R.nF * R.nF;
-    R.YW_base = B.YW_tot; B.YW_tot += (long long)3 * nL * 6 * R.nF;
+    // frame-sum blocks: <= FS_BLK consecutive observations, frame-sorted permutation per block
+    R.fsb0 = (int)B.fsb_win.size();
+    for (int o0 = R.proj0; o0 < R.proj1; o0 += FS_BLK) {
+        int cnt = std::min(FS_BLK, R.proj1 - o0);
+        B.fsb_win.push_back(wi); B.fsb_obs0.push_back(o0);
+        B.fsb_foff0.push_back((int)B.fsb_foff.size());
+        B.fsb_out0.push_back((int)B.fs_tot); B.fs_tot += R.nF;
+        std::vector<std::vector<int>> byf(R.nF);
+        for (int t = 0; t < cnt; t++) { int f = B.p_fr[o0 + t]; if (f >= 0) byf[f].push_back(t); }
+        int pos = 0;
+        B.fsb_perm.resize((size_t)o0 + cnt, 0);
+        for (int f = 0; f < R.nF; f++) {
+            B.fsb_foff.push_back(pos);
+            for (int t : byf[f]) B.fsb_perm[(size_t)o0 + pos++] = t;
+        }
+        B.fsb_foff.push_back(pos);
+    }
+    R.fsb1 = (int)B.fsb_win.size();
+    R.P_base = B.P_tot; B.P_tot += (long long)36 * R.nF * R.nF;       // x GEMM_SPLIT partial products at allocation
+    R.YW_base = B.YW_tot; B.YW_tot += (long long)nL * R.nF * 36;
+    if (R.nF * 36 > GEMM_LDS_DOUBLES) return fail(SWF_E_UNSUPPORTED, "more than 160 observing frames");
     {
         int m = 6 * R.nF, nt = (m + 15) / 16;
         B.max_tiles = std::max(B.max_tiles, nt * (nt + 1) / 2);
+        if (nt * (nt + 1) / 2 > 128) return fail(SWF_E_UNSUPPORTED, "more than 40 observing frames in one window");
     }
 
     // ---- generic factors
@@ -384,6 +413,24 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
                 B.s_ccol[B.gf[f].slot0 + sl] = cc;
             }
         }
+        // gather lists for the dense clique Jacobian (row, column) <- g_J, and residual rows <- g_r
+        C.gl0 = (int)B.cg_dst.size(); C.rl0 = (int)B.cr_dst.size();
+        if (!t.is_static) {
+            int frow = 0;
+            for (int f : t.facs) {
+                const GFac& G = B.gf[f];
+                for (int k = 0; k < G.nres; k++) { B.cr_dst.push_back(frow + k); B.cr_src.push_back(G.roff + k); }
+                for (int sl = 0; sl < G.nslot; sl++) {
+                    int cc = B.s_ccol[G.slot0 + sl], jo = B.s_joff[G.slot0 + sl], l = B.s_ls[G.slot0 + sl];
+                    if (cc < 0 || jo < 0) continue;
+                    for (int k = 0; k < G.nres; k++) for (int j = 0; j < l; j++) {
+                        B.cg_dst.push_back(((frow + k) << 8) | (cc + j)); B.cg_src.push_back(jo + k * l + j);
+                    }
+                }
+                frow += G.nres;
+            }
+        }
+        C.gl1 = (int)B.cg_dst.size(); C.rl1 = (int)B.cr_dst.size();
         // static prior clique: C = J^T J over member columns, dgraw = diag
         B.C_init.resize((size_t)B.C_tot, 0.0);
         B.dgraw_init.resize((size_t)B.v_tot, 0.0);
@@ -482,10 +529,14 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     PUT(p_lpose, B.p_lpose); PUT(p_llm, B.p_llm); PUT(p_fr, B.p_fr); PUT(p_lm, B.p_lm); PUT(p_uv, B.p_uv);
     D.n_lm = (int)B.lm_win.size();
     B.lm_obs0.push_back(D.n_proj);
-    PUT(lm_win, B.lm_win); PUT(lm_obs0, B.lm_obs0); PUT(lm_loc, B.lm_loc); PUT(lm_col, B.lm_col);
+    PUT(lm_win, B.lm_win); PUT(lm_obs0, B.lm_obs0); PUT(lm_loc, B.lm_loc); PUT(lm_col, B.lm_col); PUT(lm_fmask, B.lm_fmask);
     D.n_fr = B.n_fr;
     B.fr_obs0.push_back((int)B.fr_obs.size());
     PUT(fr_obs0, B.fr_obs0); PUT(fr_obs, B.fr_obs);
+    D.n_fsb = (int)B.fsb_win.size();
+    B.fsb_obs0.push_back(D.n_proj); B.fsb_perm.resize((size_t)D.n_proj + 1, 0);
+    PUT(fsb_win, B.fsb_win); PUT(fsb_obs0, B.fsb_obs0); PUT(fsb_perm, B.fsb_perm); PUT(fsb_foff, B.fsb_foff); PUT(fsb_foff0, B.fsb_foff0); PUT(fsb_out0, B.fsb_out0);
+    rc |= P.zeros((size_t)B.fs_tot * FS_VAL, &D.fs_part);
     D.n_gf = (int)B.gf.size();
     PUT(gf, B.gf);
     PUT(s_x, B.s_x); PUT(s_loc, B.s_loc); PUT(s_ls, B.s_ls); PUT(s_joff, B.s_joff); PUT(s_ccol, B.s_ccol);
@@ -495,7 +546,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     PUT(prior_dim, B.prior_dim); PUT(prior_Joff, B.prior_Joff); PUT(prior_roff, B.prior_roff); PUT(prior_x0off, B.prior_x0off);
     PUT(prior_J, B.prior_J); PUT(prior_r0, B.prior_r0); PUT(prior_x0, B.prior_x0);
     D.n_cl = (int)B.cl.size();
-    PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cl_frow, B.cl_frow); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
+    PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cl_frow, B.cl_frow); PUT(cg_dst, B.cg_dst); PUT(cg_src, B.cg_src); PUT(cr_dst, B.cr_dst); PUT(cr_src, B.cr_src); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
     D.n_pair = (int)B.pair.size();
     PUT(pair, B.pair); PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
     {
@@ -521,10 +572,10 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     rc |= P.zeros(B.S_tot, &D.S); rc |= P.zeros(B.Lt_tot, &D.L);
     rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
     size_t np = (size_t)D.n_proj;
-    rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl);
+    rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl); rc |= P.zeros(6 * np, &D.p_yg);
     rc |= P.zeros(np, &D.p_cost); rc |= P.zeros(np, &D.p_aux);
     rc |= P.zeros(6 * (size_t)D.n_lm, &D.lm_Einv); rc |= P.zeros(3 * (size_t)D.n_lm, &D.lm_g);
-    rc |= P.zeros(B.YW_tot, &D.Yt); rc |= P.zeros(B.YW_tot, &D.Wt); rc |= P.zeros(B.P_tot, &D.P);
+    rc |= P.zeros(B.YW_tot, &D.YW); rc |= P.zeros(B.P_tot * GEMM_SPLIT, &D.P);
     rc |= P.zeros((size_t)B.r_tot, &D.g_r); rc |= P.zeros((size_t)B.j_tot, &D.g_J);
     rc |= P.zeros((size_t)D.n_gf, &D.g_cost); rc |= P.zeros((size_t)D.n_gf, &D.g_aux);
     {
@@ -609,7 +660,7 @@ struct Launcher {
     void lin_eval() {
         DevBatch& D = b->D;
         if (D.n_proj) { Bracket t(*this, SWF_K_EVAL_PROJ); hipLaunchKernelGGL(k_eval_proj<true>, GRID(D.n_proj, 256), dim3(256), 0, st, D); }
-        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, dim3(D.n_imu), dim3(64), 0, st, D); }
+        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * 16), 0, st, D); }
         if (D.n_sc) { Bracket t(*this, SWF_K_EVAL_SCALAR); hipLaunchKernelGGL(k_eval_scalar<true>, GRID(D.n_sc, 256), dim3(256), 0, st, D); }
         if (D.n_prior) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
     }
@@ -622,7 +673,12 @@ struct Launcher {
             if (D.n_clc[1]) hipLaunchKernelGGL((k_clique_elim<32, 48, 256, 1>), dim3(D.n_clc[1]), dim3(256), 0, st, D, O);
             if (D.n_clc[2]) hipLaunchKernelGGL((k_clique_elim<64, 64, 256, 2>), dim3(D.n_clc[2]), dim3(256), 0, st, D, O);
         }
-        if (write_S && b->max_tiles) { Bracket t(*this, SWF_K_LM_GEMM); hipLaunchKernelGGL(k_lm_gemm, dim3((b->max_tiles + 3) / 4, D.n_win), dim3(256), 0, st, D); }
+        if (write_S && b->max_tiles) {
+            Bracket t(*this, SWF_K_LM_GEMM);
+            if (b->max_tiles <= 36) hipLaunchKernelGGL((k_lm_gemm<256, 9>), dim3(D.n_win, GEMM_SPLIT), dim3(256), 0, st, D);
+            else hipLaunchKernelGGL((k_lm_gemm<1024, 8>), dim3(D.n_win, GEMM_SPLIT), dim3(1024), 0, st, D);
+        }
+        if (D.n_fsb) { Bracket t(*this, SWF_K_ASSEMBLE); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
         {
             Bracket t(*this, SWF_K_ASSEMBLE);
             if (D.n_pd) hipLaunchKernelGGL(k_assemble<true>, GRID((size_t)D.n_pd * 64, 256), dim3(256), 0, st, D, O, write_S);
@@ -663,7 +719,7 @@ struct Launcher {
         {
             Bracket t(*this, SWF_K_CAND_EVAL);
             if (D.n_proj) hipLaunchKernelGGL(k_eval_proj<false>, GRID(D.n_proj, 256), dim3(256), 0, st, D);
-            if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, dim3(D.n_imu), dim3(64), 0, st, D);
+            if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * 16), 0, st, D);
             if (D.n_sc) hipLaunchKernelGGL(k_eval_scalar<false>, GRID(D.n_sc, 256), dim3(256), 0, st, D);
             if (D.n_prior) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
         }

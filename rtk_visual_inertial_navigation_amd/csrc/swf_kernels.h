@@ -24,6 +24,20 @@ struct DevOpt {
     double r0, max_r, min_r, min_rel_dec, ftol, gtol, ptol, min_mu, max_mu, mu_inc, min_diag, max_diag;
 };
 
+__device__ __forceinline__ double grp16_sum(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// per-observation record (AoS, 256 B = 4 cache lines), written by k_eval_proj / k_lm_elim:
+//   [0..11] Jp (2x6 row-major)  [12..17] Jl (2x3)  [18..19] r  [20..25] Y g_l  [26..31] pad
+#define PREC 32
+#define PREC_JP 0
+#define PREC_JL 12
+#define PREC_R 18
+#define PREC_YG 20
+
 #define CLIGHT_D 299792458.0
 #define OMGE_D 7.2921151467E-5
 
@@ -204,50 +218,64 @@ __device__ void imu_unwhitened(const double* pi, const double* sbi, const double
 #undef SETU
 }
 
+#define IMU_FPB 8          // factors per block: 8 lanes run the un-whitened part side by side, 16 lanes per factor whiten
 template <bool JAC>
-__global__ void __launch_bounds__(64) k_eval_imu(DevBatch B) {
-    __shared__ double SI[225];
-    __shared__ double U[450];
-    __shared__ double raw[16];
-    __shared__ double st[32];
-    int q = blockIdx.x;
-    if (q >= B.n_imu) return;
-    int f = B.imu_gf[q];
+__global__ void __launch_bounds__(IMU_FPB * 16) k_eval_imu(DevBatch B) {
+    __shared__ double SI[IMU_FPB][225];
+    __shared__ double U[IMU_FPB][450];
+    __shared__ double raw[IMU_FPB][16];
+    __shared__ double st[IMU_FPB][32];
+    int tid = threadIdx.x, fl = tid >> 4, sub = tid & 15;
+    int q = blockIdx.x * IMU_FPB + fl;
+    bool valid = q < B.n_imu;
+    int f = B.imu_gf[valid ? q : B.n_imu - 1];
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
-    if (JAC ? !s.need_lin : !s.eval_cand) return;
+    bool act = valid && (JAC ? s.need_lin : s.eval_cand);
     const WinRec& W = B.win[G.win];
     const double* xs = JAC ? B.x : B.xc;
     const double* pre = B.imu_pre + (size_t)G.data * SWF_PRE_DOUBLES;
-    int lane = threadIdx.x;
-    for (int k = lane; k < 225; k += 64) SI[k] = pre[SWF_PRE_SQRTINFO + k];
-    // stage the 32 parameter doubles in LDS (pose_i, sb_i, pose_j, sb_j)
-    if (lane < 32) {
-        int sl = lane < 7 ? 0 : lane < 16 ? 1 : lane < 23 ? 2 : 3;
-        int o = lane < 7 ? lane : lane < 16 ? lane - 7 : lane < 23 ? lane - 16 : lane - 23;
-        st[lane] = xs[B.s_x[G.slot0 + sl] + o];
+    if (act) {
+        for (int k = sub; k < 225; k += 16) SI[fl][k] = pre[SWF_PRE_SQRTINFO + k];
+        for (int k = sub; k < 32; k += 16) {
+            int sl = k < 7 ? 0 : k < 16 ? 1 : k < 23 ? 2 : 3;
+            int o = k < 7 ? k : k < 16 ? k - 7 : k < 23 ? k - 16 : k - 23;
+            st[fl][k] = xs[B.s_x[G.slot0 + sl] + o];
+        }
     }
     __syncthreads();
-    if (lane == 0) imu_unwhitened(st, st + 7, st + 16, st + 23, pre, W.pbg, W.gw, raw, U, JAC);
+    // lanes 0..7 of the block: one factor each
+    if (tid < IMU_FPB) {
+        int q2 = blockIdx.x * IMU_FPB + tid;
+        if (q2 < B.n_imu) {
+            const GFac& G2 = B.gf[B.imu_gf[q2]];
+            const WinState& s2 = B.ws[G2.win];
+            if (JAC ? s2.need_lin : s2.eval_cand) {
+                const WinRec& W2 = B.win[G2.win];
+                imu_unwhitened(st[tid], st[tid] + 7, st[tid] + 16, st[tid] + 23, B.imu_pre + (size_t)G2.data * SWF_PRE_DOUBLES,
+                               W2.pbg, W2.gw, raw[tid], U[tid], JAC);
+            }
+        }
+    }
     __syncthreads();
-    // whitened residual
+    (void)W;
+    // whitened residual: lane k < 15 of each 16-lane group
     double rk = 0;
-    if (lane < 15) {
-        for (int k = 0; k < 15; k++) rk += SI[lane * 15 + k] * raw[k];
-        if (JAC) B.g_r[G.roff + lane] = rk;
+    if (act && sub < 15) {
+        for (int k = 0; k < 15; k++) rk += SI[fl][sub * 15 + k] * raw[fl][k];
+        if (JAC) B.g_r[G.roff + sub] = rk;
     }
-    double c = wave_sum(lane < 15 ? rk * rk : 0.0);
-    if (lane == 0) B.g_cost[f] = 0.5 * c;
-    if (!JAC) return;
-    // whitened Jacobian blocks, row-major 15 x ls at s_joff
+    double c = grp16_sum((act && sub < 15) ? rk * rk : 0.0);
+    if (act && sub == 0) B.g_cost[f] = 0.5 * c;
+    if (!JAC || !act) return;
     const int cb[4] = { 0, 6, 15, 21 }, ls[4] = { 6, 9, 6, 9 };
-    for (int e = lane; e < 450; e += 64) {
+    for (int e = sub; e < 450; e += 16) {
         int row = e / 30, col = e % 30;
         int sl = col < 6 ? 0 : col < 15 ? 1 : col < 21 ? 2 : 3;
         int jo = B.s_joff[G.slot0 + sl];
         if (jo < 0) continue;
         double a = 0;
-        for (int k = row; k < 15; k++) a += SI[row * 15 + k] * U[k * 30 + col];   // SI is upper triangular
+        for (int k = row; k < 15; k++) a += SI[fl][row * 15 + k] * U[fl][k * 30 + col];   // SI is upper triangular
         B.g_J[jo + row * ls[sl] + (col - cb[sl])] = a;
     }
 }
@@ -410,11 +438,6 @@ __global__ void __launch_bounds__(256) k_eval_prior(DevBatch B) {
 // aux = |J v|^2.  MODE 1: v = step, aux = (Jv).(r + Jv/2) (model cost change,
 // TrustRegionMinimizer::ComputeTrustRegionStep).
 // =========================================================================================
-__device__ __forceinline__ double grp16_sum(double v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 template <int MODE>
 __device__ __forceinline__ double vec_at(const DevBatch& B, const DevOpt& O, int loc) {
     if (MODE == 1) return B.step[loc];
@@ -561,23 +584,29 @@ __global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
         B.lm_Einv[3 * nl + L] = e11; B.lm_Einv[4 * nl + L] = e21; B.lm_Einv[5 * nl + L] = e22;
         B.lm_g[0 * nl + L] = g0; B.lm_g[1 * nl + L] = g1; B.lm_g[2 * nl + L] = g2;
     }
-    int ld = 6 * W.nF, col = B.lm_col[L];
-    double* Yt = B.Yt + W.YW_base; double* Wt = B.Wt + W.YW_base;
+    // per observation: W = Jp^T Jl, Y = W Einv, written as ONE contiguous 288-byte cell
+    // [Y(3x6) | W(3x6)] at (landmark, frame); plus Y g_l for the reduced right-hand side
+    double* cells = B.YW + W.YW_base + (size_t)(L - W.lm0) * W.nF * 36;
     for (int o = o0 + sub; o < o1; o += 16) {
         int f = B.p_fr[o];
         if (f < 0) continue;
         double a0 = B.p_Jl[0 * n + o], a1 = B.p_Jl[1 * n + o], a2 = B.p_Jl[2 * n + o];
         double b0 = B.p_Jl[3 * n + o], b1 = B.p_Jl[4 * n + o], b2 = B.p_Jl[5 * n + o];
+        double cy[18], cw[18];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             double pa = B.p_Jp[i * n + o], pb = B.p_Jp[(6 + i) * n + o];
             double w0 = pa * a0 + pb * b0, w1 = pa * a1 + pb * b1, w2 = pa * a2 + pb * b2;
-            size_t base = (size_t)col * ld + 6 * f + i;
-            Wt[base] = w0; Wt[base + ld] = w1; Wt[base + 2 * ld] = w2;
-            Yt[base] = w0 * e00 + w1 * e10 + w2 * e20;
-            Yt[base + ld] = w0 * e10 + w1 * e11 + w2 * e21;
-            Yt[base + 2 * ld] = w0 * e20 + w1 * e21 + w2 * e22;
+            cw[i] = w0; cw[6 + i] = w1; cw[12 + i] = w2;
+            double y0 = w0 * e00 + w1 * e10 + w2 * e20, y1 = w0 * e10 + w1 * e11 + w2 * e21, y2 = w0 * e20 + w1 * e21 + w2 * e22;
+            cy[i] = y0; cy[6 + i] = y1; cy[12 + i] = y2;
+            B.p_yg[i * n + o] = y0 * g0 + y1 * g1 + y2 * g2;
         }
+        double2* cell = (double2*)(cells + (size_t)f * 36);
+#pragma unroll
+        for (int k = 0; k < 9; k++) cell[k] = make_double2(cy[2 * k], cy[2 * k + 1]);
+#pragma unroll
+        for (int k = 0; k < 9; k++) cell[9 + k] = make_double2(cw[2 * k], cw[2 * k + 1]);
     }
 }
 
@@ -611,23 +640,13 @@ __global__ void __launch_bounds__(NT) k_clique_elim(DevBatch B, DevOpt O) {
     for (int e = tid; e < nrow * d; e += blockDim.x) Jc[e / d][e % d] = 0.0;
     if (tid == 0) fail = 0;
     __syncthreads();
-    // scatter the factors' Jacobian blocks into Jc: 8 groups of 32 lanes, one factor per group
-    {
-        constexpr int NG = NT / 32;
-        int grp = tid >> 5, gl = tid & 31;
-        for (int q = C.fac0 + grp; q < C.fac1; q += NG) {
-            const GFac& G = B.gf[B.cl_fac[q]];
-            int r0 = B.cl_frow[q];
-            for (int k = gl; k < G.nres; k += 32) rv[r0 + k] = B.g_r[G.roff + k];
-            for (int sl = 0; sl < G.nslot; sl++) {
-                int cc = B.s_ccol[G.slot0 + sl];
-                if (cc < 0) continue;
-                int l = B.s_ls[G.slot0 + sl];
-                const double* J = B.g_J + B.s_joff[G.slot0 + sl];
-                for (int e = gl; e < G.nres * l; e += 32) Jc[r0 + e / l][cc + e % l] = J[e];
-            }
-        }
+    // gather the factors' Jacobian blocks / residuals into Jc / rv through the host-built lists
+    // (dst, src): every load is independent, two dependent accesses deep (list entry -> value)
+    for (int e = C.gl0 + tid; e < C.gl1; e += blockDim.x) {
+        int dst = B.cg_dst[e];
+        Jc[dst >> 8][dst & 255] = B.g_J[B.cg_src[e]];
     }
+    for (int e = C.rl0 + tid; e < C.rl1; e += blockDim.x) rv[B.cr_dst[e]] = B.g_r[B.cr_src[e]];
     __syncthreads();
     // M = Jc^T Jc (lower half + mirror), gv = Jc^T r
     for (int e = tid; e < d * d; e += blockDim.x) {
@@ -691,48 +710,159 @@ __global__ void __launch_bounds__(NT) k_clique_elim(DevBatch B, DevOpt O) {
 }
 
 // =========================================================================================
-// P = Yt^T Wt per window: the landmark part of the reduced camera matrix as one dense
-// product over the static-sparsity slabs, on the fp64 matrix cores.  One wavefront per 16x16
-// output tile (lower triangle of tiles only; P is symmetric), v_mfma_f64_16x16x4_f64:
-//   A[i][k] = Yt[k0+k][r0+i], B[k][j] = Wt[k0+k][c0+j]  -> both operands are 16 contiguous
-//   doubles per k straight from memory (no LDS staging: every operand element feeds one lane).
-// f64 C/D layout: lane l, reg q holds D[row = (l>>4) + 4q][col = l&15].
+// Landmark part of the reduced camera matrix, P = sum_l Y_l W_l^T, on the fp64 matrix cores.
+// One workgroup per window.  The (landmark, frame) cells are staged through LDS in chunks of
+// whole landmarks (contiguous, each cell read from HBM exactly once); every wave owns a fixed
+// set of 16x16 tiles of the lower triangle of P and issues one v_mfma_f64_16x16x4_f64 per
+// (tile, landmark): the 4 k-slots of the MFMA are the landmark's 3 coordinates (+ one zero).
+// Tiles whose frame range the landmark does not observe are skipped (wave-uniform test on the
+// landmark's frame bit-mask), which removes ~2/3 of the dense work at mean track length K/2.
+// f64 MFMA layouts: A[i][k]: lane = i + 16k; B[k][j]: lane = j + 16k; D: lane l, reg q -> row (l>>4)+4q, col l&15.
 // =========================================================================================
 typedef double double4_t __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) k_lm_gemm(DevBatch B) {
-    int w = blockIdx.y;
+#define GEMM_LDS_DOUBLES 5760                 // one window's chunk buffer = 2 halves of 2880
+#define GEMM_SPLIT 4                          // fixed landmark split: partial products P_0..P_3, summed in order by k_assemble
+template <int NT, int TPW>
+__global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
+    __shared__ double Ls[2][GEMM_LDS_DOUBLES / 2];
+    __shared__ unsigned long long Ms[2][GEMM_LDS_DOUBLES / 72];
+    int w = blockIdx.x, sp = blockIdx.y;
     const WinRec& W = B.win[w];
     if (!B.ws[w].need_lin) return;
-    int m = 6 * W.nF, nt = (m + 15) / 16;
-    int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (t >= nt * (nt + 1) / 2) return;
-    int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) / 2.0);
-    while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
-    while (tr * (tr + 1) / 2 > t) tr--;
-    int tc = t - tr * (tr + 1) / 2;
-    int K = 3 * (W.lm1 - W.lm0);
-    const double* Yt = B.Yt + W.YW_base; const double* Wt = B.Wt + W.YW_base;
-    int li = lane & 15, lk = lane >> 4;
-    int ra = tr * 16 + li, cb = tc * 16 + li;
-    bool va = ra < m, vb = cb < m;
-    double4_t acc0 = { 0, 0, 0, 0 }, acc1 = { 0, 0, 0, 0 };
-    int k0 = 0;
-    for (; k0 + 8 <= K; k0 += 8) {
-        double a0 = va ? Yt[(size_t)(k0 + lk) * m + ra] : 0.0, b0 = vb ? Wt[(size_t)(k0 + lk) * m + cb] : 0.0;
-        double a1 = va ? Yt[(size_t)(k0 + 4 + lk) * m + ra] : 0.0, b1 = vb ? Wt[(size_t)(k0 + 4 + lk) * m + cb] : 0.0;
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
-    }
-    for (; k0 < K; k0 += 4) {
-        bool vk = (k0 + lk) < K;
-        double a0 = (va && vk) ? Yt[(size_t)(k0 + lk) * m + ra] : 0.0, b0 = (vb && vk) ? Wt[(size_t)(k0 + lk) * m + cb] : 0.0;
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-    }
-    double* P = B.P + W.P_base;
+    int nF = W.nF, m = 6 * nF, nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2;
+    if (m == 0) return;
+    int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    constexpr int NW = NT / 64;
+    int t_tr[TPW], t_tc[TPW], offA[TPW], offB[TPW];
+    unsigned long long mA[TPW], mB[TPW];
+    double4_t acc[TPW];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        int r = tr * 16 + lk + 4 * q, c = tc * 16 + li;
-        if (r < m && c < m) P[(size_t)r * m + c] = acc0[q] + acc1[q];
+    for (int sl = 0; sl < TPW; sl++) {
+        int t = wv + sl * NW;
+        int tr = 0, tc = 0;
+        if (t < ntiles) {
+            tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) / 2.0);
+            while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
+            while (tr * (tr + 1) / 2 > t) tr--;
+            tc = t - tr * (tr + 1) / 2;
+        }
+        t_tr[sl] = tr; t_tc[sl] = tc;
+        int ra = tr * 16 + li, cb = tc * 16 + li;
+        // element (row r, coordinate k) of landmark l sits at cell(l, r/6)[k*6 + r%6]; W is 18 further
+        offA[sl] = (ra < m && lk < 3 && t < ntiles) ? (ra / 6) * 36 + lk * 6 + ra % 6 : -1;
+        offB[sl] = (cb < m && lk < 3 && t < ntiles) ? (cb / 6) * 36 + 18 + lk * 6 + cb % 6 : -1;
+        int f0 = (tr * 16) / 6, f1 = (tr * 16 + 15) / 6; if (f1 > 63) f1 = 63;
+        int g0 = (tc * 16) / 6, g1 = (tc * 16 + 15) / 6; if (g1 > 63) g1 = 63;
+        mA[sl] = (t < ntiles && f0 < 64) ? ((~0ULL >> (63 - f1)) & (~0ULL << f0)) : 0ULL;
+        mB[sl] = (t < ntiles && g0 < 64) ? ((~0ULL >> (63 - g1)) & (~0ULL << g0)) : 0ULL;
+        acc[sl] = double4_t{ 0, 0, 0, 0 };
+    }
+    int row_d = nF * 36;                              // doubles per landmark
+    int LB = (GEMM_LDS_DOUBLES / 2) / row_d;          // landmarks per chunk
+    int nLw = W.lm1 - W.lm0;
+    int per = (nLw + GEMM_SPLIT - 1) / GEMM_SPLIT;
+    int lbeg = sp * per, lend = lbeg + per < nLw ? lbeg + per : nLw;
+    const double* src = B.YW + W.YW_base;
+    constexpr int PR = (GEMM_LDS_DOUBLES / 4 + NT - 1) / NT;     // double2 per thread per chunk
+    double2 pre[PR];
+    auto fetch = [&](int l0) {
+        int lb = (lend - l0) < LB ? (lend - l0) : LB;
+        const double2* s2 = (const double2*)(src + (size_t)l0 * row_d);
+#pragma unroll
+        for (int k = 0; k < PR; k++) { int e = tid + k * NT; pre[k] = (e < lb * row_d / 2) ? s2[e] : make_double2(0, 0); }
+    };
+    auto stash = [&](int buf, int l0) {
+        int lb = (lend - l0) < LB ? (lend - l0) : LB;
+        double2* d2 = (double2*)Ls[buf];
+#pragma unroll
+        for (int k = 0; k < PR; k++) { int e = tid + k * NT; if (e < lb * row_d / 2) d2[e] = pre[k]; }
+        for (int e = tid; e < lb; e += NT) Ms[buf][e] = B.lm_fmask[W.lm0 + l0 + e];
+    };
+    int cur = 0;
+    if (lbeg < lend) { fetch(lbeg); stash(0, lbeg); }
+    __syncthreads();
+    for (int l0 = lbeg; l0 < lend; l0 += LB) {
+        int lb = (lend - l0) < LB ? (lend - l0) : LB;
+        bool more = l0 + LB < lend;
+        if (more) fetch(l0 + LB);                       // next chunk's loads fly during the MFMAs
+        for (int l = 0; l < lb; l++) {
+            unsigned long long fm = Ms[cur][l];
+            const double* cell = Ls[cur] + l * row_d;
+#pragma unroll
+            for (int sl = 0; sl < TPW; sl++) {
+                if ((fm & mA[sl]) && (fm & mB[sl])) {
+                    double a = offA[sl] >= 0 ? cell[offA[sl]] : 0.0;
+                    double b = offB[sl] >= 0 ? cell[offB[sl]] : 0.0;
+                    acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[sl], 0, 0, 0);
+                }
+            }
+        }
+        if (more) stash(cur ^ 1, l0 + LB);
+        __syncthreads();
+        cur ^= 1;
+    }
+    double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)sp * m * m;
+#pragma unroll
+    for (int sl = 0; sl < TPW; sl++) {
+        int t = wv + sl * NW;
+        if (t >= ntiles) continue;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int r = t_tr[sl] * 16 + lk + 4 * q, c = t_tc[sl] * 16 + li;
+            if (r < m && c < m) P[(size_t)r * m + c] = acc[sl][q];
+        }
+    }
+}
+
+// =========================================================================================
+// Per-frame raw sums over the projection observations, level 1 of a two-level FIXED-ORDER
+// reduction.  Observations are landmark-major in memory, so a pose's observations are strided;
+// instead of gathering them (one 64-byte line per 8-byte value, PMC-measured 8x amplification),
+// every block of 256 consecutive observations is read coalesced, staged in LDS, and reduced per
+// frame through a host-built frame-sorted permutation of the block.  Output per (block, frame):
+//   33 doubles = lower(Jp^T Jp)(21) | Jp^T r (6) | Y g_l (6);   k_assemble<true> adds the blocks in order.
+// =========================================================================================
+#define FS_BLK 256
+#define FS_VAL 33
+__global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
+    __shared__ double V[FS_BLK][FS_VAL];      // 67.6 KB
+    int blk = blockIdx.x;
+    if (blk >= B.n_fsb) return;
+    int w = B.fsb_win[blk];
+    if (!B.ws[w].need_lin) return;
+    const WinRec& W = B.win[w];
+    int o_beg = B.fsb_obs0[blk], cnt = B.fsb_obs0[blk + 1] - o_beg, tid = threadIdx.x, n = B.n_proj;
+    if (tid < cnt) {
+        int o = o_beg + tid;
+        double a[6], b[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { a[i] = B.p_Jp[i * n + o]; b[i] = B.p_Jp[(6 + i) * n + o]; }
+        double r0 = B.p_r[o], r1 = B.p_r[n + o];
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) V[tid][k++] = a[i] * a[j] + b[i] * b[j];
+#pragma unroll
+        for (int i = 0; i < 6; i++) V[tid][21 + i] = a[i] * r0 + b[i] * r1;
+        bool lmv = B.lm_loc[B.p_lm[o]] >= 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) V[tid][27 + i] = lmv ? B.p_yg[i * n + o] : 0.0;
+    }
+    // frame-sorted permutation of the block and its per-frame offsets, staged once
+    __shared__ int perm[FS_BLK];
+    __shared__ int foff[168];
+    int nF = W.nF;
+    if (tid < cnt) perm[tid] = B.fsb_perm[o_beg + tid];
+    for (int e = tid; e <= nF; e += FS_BLK) foff[e] = B.fsb_foff[B.fsb_foff0[blk] + e];
+    __syncthreads();
+    // owner (frame f, value v) adds the block's observations of frame f in permutation order
+    double* out = B.fs_part + (size_t)B.fsb_out0[blk] * FS_VAL;
+    for (int e = tid; e < nF * FS_VAL; e += FS_BLK) {
+        int f = e / FS_VAL, v = e % FS_VAL;
+        double acc = 0;
+        for (int q = foff[f]; q < foff[f + 1]; q++) acc += V[perm[q]][v];
+        out[e] = acc;
     }
 }
 
@@ -756,64 +886,82 @@ __global__ void __launch_bounds__(256) k_assemble(DevBatch B, DevOpt O, int writ
     const WinRec& W = B.win[Pr.win];
     int la = Pr.la, lb = Pr.lb, n = W.n_red, m = 6 * W.nF;
     double* S = B.S + W.S_base;
-    const double* P = B.P + W.P_base;
+    const double* P = B.P + W.P_base * GEMM_SPLIT;
     double H[21], gr[6], qv[6];
     bool obs = DIAG && Pr.fa >= 0;
     if (obs) {
-        for (int k = 0; k < 21; k++) H[k] = 0;
-        for (int k = 0; k < 6; k++) { gr[k] = 0; qv[k] = 0; }
-        int fglob = W.fr_base + Pr.fa, np = B.n_proj, nl = B.n_lm;
-        const double* Yt = B.Yt + W.YW_base;
-        for (int q = B.fr_obs0[fglob] + lane; q < B.fr_obs0[fglob + 1]; q += 64) {
-            int o = B.fr_obs[q];
-            double a[6], b[6];
+        // level 2: lanes v < 33 add this frame's block partials in block order
+        double acc = 0;
+        if (lane < FS_VAL)
+            for (int bq = W.fsb0; bq < W.fsb1; bq++) acc += B.fs_part[((size_t)B.fsb_out0[bq] + Pr.fa) * FS_VAL + lane];
 #pragma unroll
-            for (int i = 0; i < 6; i++) { a[i] = B.p_Jp[i * np + o]; b[i] = B.p_Jp[(6 + i) * np + o]; }
-            double r0 = B.p_r[o], r1 = B.p_r[np + o];
-            int k = 0;
+        for (int k = 0; k < 21; k++) H[k] = __shfl(acc, k, 64);
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-#pragma unroll
-                for (int j = 0; j <= i; j++) H[k++] += a[i] * a[j] + b[i] * b[j];
-                gr[i] += a[i] * r0 + b[i] * r1;
-            }
-            int Lg = B.p_lm[o];
-            if (B.lm_loc[Lg] >= 0) {
-                double g0 = B.lm_g[Lg], g1 = B.lm_g[nl + Lg], g2 = B.lm_g[2 * nl + Lg];
-                size_t base = (size_t)B.lm_col[Lg] * m + 6 * Pr.fa;
-#pragma unroll
-                for (int i = 0; i < 6; i++) qv[i] += Yt[base + i] * g0 + Yt[base + m + i] * g1 + Yt[base + 2 * m + i] * g2;
-            }
-        }
-        for (int k = 0; k < 21; k++) H[k] = wave_sum(H[k]);
-        for (int k = 0; k < 6; k++) { gr[k] = wave_sum(gr[k]); qv[k] = wave_sum(qv[k]); }
+        for (int k = 0; k < 6; k++) { gr[k] = __shfl(acc, 21 + k, 64); qv[k] = __shfl(acc, 27 + k, 64); }
     }
+    // contribution descriptors: lane c of the group keeps descriptor c0 + c (+ G per round) in
+    // registers, so the value loads below do not chain behind descriptor loads
+    int gbase = DIAG ? 0 : (threadIdx.x & 48);            // first lane of my group inside the wave
+    int ncon = Pr.c1 - Pr.c0;
     // diagonal bookkeeping first (needed for damping)
     double dg_i = 0;    // lane i < la: raw diag of column i
-    if (DIAG && lane < la) {
+    if (DIAG) {
         double gi = 0, cs = 0;
-        if (obs) { int i = lane; gi = gr[i]; dg_i = H[i * (i + 1) / 2 + i]; cs = -qv[i]; }
-        for (int c = Pr.c0; c < Pr.c1; c++) {
-            int vo = B.pc_voff[c];
-            gi += B.cv_graw[vo + lane]; dg_i += B.cv_dgraw[vo + lane]; cs += B.cv_cs[vo + lane];
+        if (obs && lane < la) { int i = lane; gi = gr[i]; dg_i = H[i * (i + 1) / 2 + i]; cs = -qv[i]; }
+        for (int cb0 = 0; cb0 < ncon; cb0 += 64) {
+            int myv = (cb0 + lane < ncon) ? B.pc_voff[Pr.c0 + cb0 + lane] : 0;
+            int nn = (ncon - cb0) < 64 ? (ncon - cb0) : 64;
+#pragma unroll 4
+            for (int c = 0; c < nn; c++) {
+                int vo = __shfl(myv, c, 64);
+                if (lane < la) { gi += B.cv_graw[vo + lane]; dg_i += B.cv_dgraw[vo + lane]; cs += B.cv_cs[vo + lane]; }
+            }
         }
-        B.g[Pr.loc_a + lane] = gi; B.diag[Pr.loc_a + lane] = dg_i;
-        if (write_S) B.rhs[Pr.loc_a + lane] = gi + cs;
+        if (lane < la) {
+            B.g[Pr.loc_a + lane] = gi; B.diag[Pr.loc_a + lane] = dg_i;
+            if (write_S) B.rhs[Pr.loc_a + lane] = gi + cs;
+        }
     }
     if (!write_S) return;      // final pass: cost + gradient only, keep (S, rhs, L) of the last solve
     // damping source per entry, fetched in uniform control flow (la*lb <= 81 => two rounds)
     double dgs0 = 0, dgs1 = 0;
     if (DIAG) { dgs0 = __shfl(dg_i, (lane / lb) & 63, 64); dgs1 = __shfl(dg_i, ((lane + 64) / lb) & 63, 64); }
-    for (int e = lane; e < la * lb; e += G) {
+    // per-entry contribution sums; descriptors broadcast from the holding lane
+    int nent = la * lb;
+    int rounds = (nent + G - 1) / G;
+    double vsum[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) vsum[r] = 0;
+    for (int cb0 = 0; cb0 < ncon; cb0 += G) {
+        long long myo = (cb0 + lane < ncon) ? B.pc_coff[Pr.c0 + cb0 + lane] : 0;
+        int myl = (cb0 + lane < ncon) ? B.pc_cld[Pr.c0 + cb0 + lane] : 0;
+        int nn = (ncon - cb0) < G ? (ncon - cb0) : G;
+        for (int c = 0; c < nn; c++) {
+            long long co = __shfl(myo, gbase + c, 64);
+            int cl = __shfl(myl, gbase + c, 64);
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                int e = lane + r * G;
+                if (r < rounds && e < nent) vsum[r] += B.C[co + (size_t)(e / lb) * cl + (e % lb)];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        int e = lane + r * G;
+        if (r >= rounds || e >= nent) continue;
         int i = e / lb, j = e % lb;
-        if (DIAG && j > i) continue;                // lower half only; the mirror store fills the rest
-        double v = 0;
+        if (DIAG && j > i) continue;                // lower half only; the mirror is the host's job at export
+        double v = vsum[r];
         if (Pr.fa >= 0 && Pr.fb >= 0) {
             int pr = 6 * Pr.fa + i, pc = 6 * Pr.fb + j;
-            v -= (pr >= pc) ? P[(size_t)pr * m + pc] : P[(size_t)pc * m + pr];
+            size_t pi = (pr >= pc) ? (size_t)pr * m + pc : (size_t)pc * m + pr;
+            double ps = 0;
+#pragma unroll
+            for (int q = 0; q < GEMM_SPLIT; q++) ps += P[(size_t)q * m * m + pi];     // fixed order
+            v -= ps;
             if (obs) { int hi = i > j ? i : j, lo = i > j ? j : i; v += H[hi * (hi + 1) / 2 + lo]; }
         }
-        for (int c = Pr.c0; c < Pr.c1; c++) v += B.C[B.pc_coff[c] + (size_t)i * B.pc_cld[c] + j];
         if (DIAG && i == j) v += s.mu * clampd(e < 64 ? dgs0 : dgs1, O.min_diag, O.max_diag);
         S[(size_t)(Pr.ra + i) * n + Pr.rb + j] = v;      // lower triangle only; exports mirror on the host
     }

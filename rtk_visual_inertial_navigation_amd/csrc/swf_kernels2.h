@@ -261,18 +261,18 @@ __global__ void __launch_bounds__(256) k_backsub_lm(DevBatch B) {
     int loc = B.lm_loc[L];
     if (loc < 0) return;
     const WinRec& W = B.win[w];
-    int nl = B.n_lm, ld = 6 * W.nF, col = B.lm_col[L];
-    const double* Wt = B.Wt + W.YW_base;
+    int nl = B.n_lm;
+    const double* cells = B.YW + W.YW_base + (size_t)(L - W.lm0) * W.nF * 36;
     double t0 = B.lm_g[L], t1 = B.lm_g[nl + L], t2 = B.lm_g[2 * nl + L];
     for (int o = B.lm_obs0[L]; o < B.lm_obs0[L + 1]; o++) {
         int f = B.p_fr[o];
         if (f < 0) continue;
         int lp = B.p_lpose[o];
-        size_t base = (size_t)col * ld + 6 * f;
+        const double* cw = cells + (size_t)f * 36 + 18;          // W(3x6) of this observation
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             double yv = B.y[lp + i];
-            t0 -= Wt[base + i] * yv; t1 -= Wt[base + ld + i] * yv; t2 -= Wt[base + 2 * ld + i] * yv;
+            t0 -= cw[i] * yv; t1 -= cw[6 + i] * yv; t2 -= cw[12 + i] * yv;
         }
     }
     double e00 = B.lm_Einv[L], e10 = B.lm_Einv[nl + L], e20 = B.lm_Einv[2 * nl + L];
