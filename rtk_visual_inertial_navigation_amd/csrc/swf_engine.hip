@@ -8,6 +8,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -69,6 +70,8 @@ struct swf_batch {
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
     int max_tiles = 0, max_prior_dim = 0, max_red = 0;
+    bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
+    bool chol_rr1 = false;                // SWF_CHOL_RR1=1: first register-resident variant
     int timing = 0;                       // bitmask of SWF_K_* brackets
     swf_timing last{};
     std::vector<hipEvent_t> ev;           // event pool (pairs)
@@ -514,6 +517,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     if (B.n_x > 0x7fffffffLL || B.n_loc > 0x7fffffffLL) return fail(SWF_E_UNSUPPORTED, "batch too large for 32-bit offsets");
     swf_batch* b = new swf_batch();
     b->stream = (hipStream_t)stream;
+    b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
+    b->chol_rr1 = getenv("SWF_CHOL_RR1") != nullptr;
     b->win = B.win; b->hw = hw; b->max_tiles = B.max_tiles; b->max_prior_dim = B.max_prior_dim; b->jac_bytes = B.jac_bytes;
     b->proj_bytes = (int64_t)312 * (int64_t)B.p_win.size();
     for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); }
@@ -688,7 +693,10 @@ struct Launcher {
     void reduced() {
         DevBatch& D = b->D;
         Bracket t(*this, SWF_K_CHOL);
-        if (b->max_red + 1 <= 256) hipLaunchKernelGGL(k_chol_solve<256>, dim3(D.n_win), dim3(256), 0, st, D);
+        if (b->max_red <= 240 && !b->force_chol_v1 && !b->chol_rr1) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
+        else if (b->max_red <= 224 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_rr<8>, dim3(D.n_win), dim3(1024), 0, st, D);
+        else if (b->max_red <= 240 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_rr<9>, dim3(D.n_win), dim3(1024), 0, st, D);
+        else if (b->max_red + 1 <= 256) hipLaunchKernelGGL(k_chol_solve<256>, dim3(D.n_win), dim3(256), 0, st, D);
         else hipLaunchKernelGGL(k_chol_solve<1024>, dim3(D.n_win), dim3(1024), 0, st, D);
     }
     void step_rest() {
@@ -835,7 +843,9 @@ extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, doub
     if (L) {
         std::vector<double> Lt((n + 1) * (n + 1));
         HIPCHK(hipMemcpy(Lt.data(), b->D.L + W.Lt_base, Lt.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++) L[r * n + c] = (c <= r) ? Lt[c * (n + 1) + r] : 0.0;
+        bool rr = b->max_red <= 240 && !b->force_chol_v1;      // k_chol_rr writes row-major lower, ld = n
+        for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++)
+            L[r * n + c] = (c <= r) ? (rr ? Lt[r * n + c] : Lt[c * (n + 1) + r]) : 0.0;
     }
     return SWF_OK;
 }
@@ -858,3 +868,12 @@ extern "C" int swf_debug_chol_stamps(unsigned long long* out) {
     return SWF_OK;
 }
 #endif
+
+#ifdef SWF_PROFILE_GEMM
+extern "C" int swf_debug_gemm_stamps(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return SWF_E_NODEVICE;
+    return SWF_OK;
+}
+#endif
+

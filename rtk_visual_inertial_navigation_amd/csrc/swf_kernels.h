@@ -722,6 +722,14 @@ __global__ void __launch_bounds__(NT) k_clique_elim(DevBatch B, DevOpt O) {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 #define GEMM_LDS_DOUBLES 5760                 // one window's chunk buffer = 2 halves of 2880
 #define GEMM_SPLIT 4                          // fixed landmark split: partial products P_0..P_3, summed in order by k_assemble
+#ifdef SWF_PROFILE_GEMM
+__device__ unsigned long long g_gemm_stamps[16];
+#define GSTAMP_ACC(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_gemm_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define GNOW() __builtin_amdgcn_s_memtime()
+#else
+#define GSTAMP_ACC(i, t0)
+#define GNOW() 0ULL
+#endif
 template <int NT, int TPW>
 __global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
     __shared__ double Ls[2][GEMM_LDS_DOUBLES / 2];
@@ -733,6 +741,10 @@ __global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
     if (m == 0) return;
     int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     constexpr int NW = NT / 64;
+#ifdef SWF_PROFILE_GEMM
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) for (int i = 0; i < 16; i++) g_gemm_stamps[i] = 0;
+#endif
+    unsigned long long tg = GNOW(), tall = tg; (void)tg; (void)tall;
     int t_tr[TPW], t_tc[TPW], offA[TPW], offB[TPW];
     unsigned long long mA[TPW], mB[TPW];
     double4_t acc[TPW];
@@ -757,6 +769,12 @@ __global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
         mB[sl] = (t < ntiles && g0 < 64) ? ((~0ULL >> (63 - g1)) & (~0ULL << g0)) : 0ULL;
         acc[sl] = double4_t{ 0, 0, 0, 0 };
     }
+    unsigned long long mAs[TPW], mBs[TPW];            // wave-uniform -> SGPRs
+#pragma unroll
+    for (int sl = 0; sl < TPW; sl++) {
+        mAs[sl] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mA[sl] >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)mA[sl]);
+        mBs[sl] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mB[sl] >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)mB[sl]);
+    }
     int row_d = nF * 36;                              // doubles per landmark
     int LB = (GEMM_LDS_DOUBLES / 2) / row_d;          // landmarks per chunk
     int nLw = W.lm1 - W.lm0;
@@ -778,27 +796,54 @@ __global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
         for (int k = 0; k < PR; k++) { int e = tid + k * NT; if (e < lb * row_d / 2) d2[e] = pre[k]; }
         for (int e = tid; e < lb; e += NT) Ms[buf][e] = B.lm_fmask[W.lm0 + l0 + e];
     };
+    GSTAMP_ACC(0, tg); tg = GNOW();
     int cur = 0;
     if (lbeg < lend) { fetch(lbeg); stash(0, lbeg); }
     __syncthreads();
+    GSTAMP_ACC(1, tg);
     for (int l0 = lbeg; l0 < lend; l0 += LB) {
         int lb = (lend - l0) < LB ? (lend - l0) : LB;
         bool more = l0 + LB < lend;
+        tg = GNOW();
         if (more) fetch(l0 + LB);                       // next chunk's loads fly during the MFMAs
-        for (int l = 0; l < lb; l++) {
-            unsigned long long fm = Ms[cur][l];
-            const double* cell = Ls[cur] + l * row_d;
+        GSTAMP_ACC(2, tg); tg = GNOW();
+        // operands of landmark l+1 are read from LDS while the MFMAs of landmark l execute; the
+        // skip test is on SGPRs (readfirstlane), so a skipped tile costs one scalar branch
+        {
+            const double* base = Ls[cur];
+            double a0[TPW], b0[TPW], a1[TPW], b1[TPW];
+            auto ldops = [&](int l, double (&a)[TPW], double (&b)[TPW]) {
+                const double* cell = base + l * row_d;
 #pragma unroll
-            for (int sl = 0; sl < TPW; sl++) {
-                if ((fm & mA[sl]) && (fm & mB[sl])) {
-                    double a = offA[sl] >= 0 ? cell[offA[sl]] : 0.0;
-                    double b = offB[sl] >= 0 ? cell[offB[sl]] : 0.0;
-                    acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[sl], 0, 0, 0);
+                for (int sl = 0; sl < TPW; sl++) { a[sl] = offA[sl] >= 0 ? cell[offA[sl]] : 0.0; b[sl] = offB[sl] >= 0 ? cell[offB[sl]] : 0.0; }
+            };
+            auto fmask = [&](int l) {
+                unsigned long long v = Ms[cur][l];
+                unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+                return ((unsigned long long)hi << 32) | lo;
+            };
+            auto mf = [&](unsigned long long fm, double (&a)[TPW], double (&b)[TPW]) {
+#pragma unroll
+                for (int sl = 0; sl < TPW; sl++)
+                    if ((fm & mAs[sl]) && (fm & mBs[sl])) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sl], b[sl], acc[sl], 0, 0, 0);
+            };
+            ldops(0, a0, b0);
+            for (int l = 0; l < lb; l += 2) {
+                unsigned long long f0 = fmask(l);
+                if (l + 1 < lb) ldops(l + 1, a1, b1);
+                mf(f0, a0, b0);
+                if (l + 1 < lb) {
+                    unsigned long long f1 = fmask(l + 1);
+                    if (l + 2 < lb) ldops(l + 2, a0, b0);
+                    mf(f1, a1, b1);
                 }
             }
         }
+        GSTAMP_ACC(3, tg); tg = GNOW();
         if (more) stash(cur ^ 1, l0 + LB);
+        GSTAMP_ACC(4, tg); tg = GNOW();
         __syncthreads();
+        GSTAMP_ACC(5, tg);
         cur ^= 1;
     }
     double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)sp * m * m;
@@ -812,6 +857,7 @@ __global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
             if (r < m && c < m) P[(size_t)r * m + c] = acc[sl][q];
         }
     }
+    GSTAMP_ACC(6, tall);
 }
 
 // =========================================================================================

@@ -12,4 +12,4 @@ solver.lib().swf_debug_chol_stamps(out)
 s = list(out)
 print("n_red", bs.dims(0)["n_red"])
 print("factor total ticks", s[1] - s[0], "backward", s[2] - s[1], "(s_memtime ticks; 100 MHz const clock => x10 ns)")
-print("mfma+init", s[8], "transpose", s[9], "diag", s[10], "trsm", s[11])
+print("v1: mfma+init / rr: publish+sync", s[8], "| v1: transpose / rr: diag factor+inverse", s[9], "| v1: diag / rr: panel", s[10], "| v1: trsm / rr: trailing", s[11])
