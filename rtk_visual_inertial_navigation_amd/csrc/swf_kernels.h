@@ -24,6 +24,14 @@ struct DevOpt {
     double r0, max_r, min_r, min_rel_dec, ftol, gtol, ptol, min_mu, max_mu, mu_inc, min_diag, max_diag;
 };
 
+// 1/sqrt(x): hardware estimate + 3 Newton steps (full fp64 accuracy from any >= 2^-8 estimate)
+__device__ __forceinline__ double rsqrt_nr3(double x) {
+    double y = __builtin_amdgcn_rsq(x), h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
 __device__ __forceinline__ double grp16_sum(double v) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -565,14 +573,17 @@ __global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
     h00 += mu * clampd(h00, O.min_diag, O.max_diag);
     h11 += mu * clampd(h11, O.min_diag, O.max_diag);
     h22 += mu * clampd(h22, O.min_diag, O.max_diag);
-    // Cholesky inverse of the 3x3 (ceres InvertPSDMatrix)
-    double l00 = sqrt(h00), l10 = h10 / l00, l20 = h20 / l00;
+    // Cholesky inverse of the 3x3 (ceres InvertPSDMatrix), division-free: the reciprocal pivots
+    // come from v_rsq_f64 + Newton steps (the IEEE fp64 sqrt/div expansions made this kernel
+    // instruction-bound)
+    double i00 = rsqrt_nr3(h00);
+    double l10 = h10 * i00, l20 = h20 * i00;
     double d11 = h11 - l10 * l10;
-    double l11 = sqrt(d11), l21 = (h21 - l20 * l10) / l11;
+    double i11 = rsqrt_nr3(d11);
+    double l21 = (h21 - l20 * l10) * i11;
     double d22 = h22 - l20 * l20 - l21 * l21;
-    double l22 = sqrt(d22);
+    double i22 = rsqrt_nr3(d22);
     if (!(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0)) { if (sub == 0) s.lin_fail = 1; return; }
-    double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
     double i10 = -l10 * i00 * i11;
     double i21 = -l21 * i11 * i22;
     double i20 = -(l20 * i00 + l21 * i10) * i22;
@@ -730,6 +741,9 @@ __device__ unsigned long long g_gemm_stamps[16];
 #define GSTAMP_ACC(i, t0)
 #define GNOW() 0ULL
 #endif
+#ifndef GEMM_OCC
+#define GEMM_OCC 3
+#endif
 template <int NT, int TPW>
 __global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
     __shared__ double Ls[2][GEMM_LDS_DOUBLES / 2];
@@ -769,12 +783,6 @@ __global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
         mB[sl] = (t < ntiles && g0 < 64) ? ((~0ULL >> (63 - g1)) & (~0ULL << g0)) : 0ULL;
         acc[sl] = double4_t{ 0, 0, 0, 0 };
     }
-    unsigned long long mAs[TPW], mBs[TPW];            // wave-uniform -> SGPRs
-#pragma unroll
-    for (int sl = 0; sl < TPW; sl++) {
-        mAs[sl] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mA[sl] >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)mA[sl]);
-        mBs[sl] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mB[sl] >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)mB[sl]);
-    }
     int row_d = nF * 36;                              // doubles per landmark
     int LB = (GEMM_LDS_DOUBLES / 2) / row_d;          // landmarks per chunk
     int nLw = W.lm1 - W.lm0;
@@ -807,35 +815,17 @@ __global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
         tg = GNOW();
         if (more) fetch(l0 + LB);                       // next chunk's loads fly during the MFMAs
         GSTAMP_ACC(2, tg); tg = GNOW();
-        // operands of landmark l+1 are read from LDS while the MFMAs of landmark l execute; the
-        // skip test is on SGPRs (readfirstlane), so a skipped tile costs one scalar branch
-        {
-            const double* base = Ls[cur];
-            double a0[TPW], b0[TPW], a1[TPW], b1[TPW];
-            auto ldops = [&](int l, double (&a)[TPW], double (&b)[TPW]) {
-                const double* cell = base + l * row_d;
+        // (measured: hoisting/double-buffering the operand reads costs 80 VGPRs and one workgroup of
+        //  occupancy per CU, a net loss in batch mode; the per-tile test + read + MFMA form wins)
+        for (int l = 0; l < lb; l++) {
+            unsigned long long fm = Ms[cur][l];
+            const double* cell = Ls[cur] + l * row_d;
 #pragma unroll
-                for (int sl = 0; sl < TPW; sl++) { a[sl] = offA[sl] >= 0 ? cell[offA[sl]] : 0.0; b[sl] = offB[sl] >= 0 ? cell[offB[sl]] : 0.0; }
-            };
-            auto fmask = [&](int l) {
-                unsigned long long v = Ms[cur][l];
-                unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-                return ((unsigned long long)hi << 32) | lo;
-            };
-            auto mf = [&](unsigned long long fm, double (&a)[TPW], double (&b)[TPW]) {
-#pragma unroll
-                for (int sl = 0; sl < TPW; sl++)
-                    if ((fm & mAs[sl]) && (fm & mBs[sl])) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sl], b[sl], acc[sl], 0, 0, 0);
-            };
-            ldops(0, a0, b0);
-            for (int l = 0; l < lb; l += 2) {
-                unsigned long long f0 = fmask(l);
-                if (l + 1 < lb) ldops(l + 1, a1, b1);
-                mf(f0, a0, b0);
-                if (l + 1 < lb) {
-                    unsigned long long f1 = fmask(l + 1);
-                    if (l + 2 < lb) ldops(l + 2, a0, b0);
-                    mf(f1, a1, b1);
+            for (int sl = 0; sl < TPW; sl++) {
+                if ((fm & mA[sl]) && (fm & mB[sl])) {
+                    double a = offA[sl] >= 0 ? cell[offA[sl]] : 0.0;
+                    double b = offB[sl] >= 0 ? cell[offB[sl]] : 0.0;
+                    acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[sl], 0, 0, 0);
                 }
             }
         }
