@@ -24,6 +24,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; the guide lists no fp64 figure
+FP64_MATRIX_MEASURED_TFLOPS = 47.7  # tests/microbench/mfma_f64_peak.hip on the gpurun box (v_mfma_f64_16x16x4_f64, 4 waves/SIMD)
 
 
 def _gen(args):
@@ -39,6 +40,16 @@ def make_windows(cfg, seeds):
         return [_gen((cfg, s)) for s in seeds]
     with mp.get_context("fork").Pool(n) as pool:
         return pool.map(_gen, [(cfg, s) for s in seeds], chunksize=max(1, len(seeds) // (4 * n)))
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(windows, iters, budget_s=12.0, threads=4):
@@ -68,7 +79,7 @@ def cpu_baseline(windows, iters, budget_s=12.0, threads=4):
                 sample="%d of the benchmark's cfg3 windows, %d dogleg iterations each, %d windows solved concurrently "
                        "(one thread per window), %.1f s of wall time" % (len(sample), iters, threads, dt),
                 single_thread_us_per_iteration=1e6 * t1 / max(1, sm.num_iterations),
-                host_cores=os.cpu_count())
+                host_cores=os.cpu_count(), host_cpu_model=_cpu_model())
 
 
 def main():
@@ -82,25 +93,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # synthetic windows first: the generator forks a process pool, which must happen before this
+    # process touches HIP / RCCL
+    from rtk_visual_inertial_navigation_amd import synth, shard
+    B = a.windows
+    t0 = time.perf_counter()
+    windows = make_windows(a.config, shard.window_seeds(synth.BASE_SEED, a.config, B, rank))
+    t_gen = time.perf_counter() - t0
+
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     torch.cuda.set_device(local_rank)
-    from rtk_visual_inertial_navigation_amd import synth, solver
+    from rtk_visual_inertial_navigation_amd import solver
     from rtk_visual_inertial_navigation_amd.flat import default_options
     solver.set_device(local_rank)
-
-    from rtk_visual_inertial_navigation_amd import shard
-    B = a.windows
-    t0 = time.perf_counter()
-    windows = make_windows(a.config, shard.window_seeds(synth.BASE_SEED, a.config, B, rank))
-    t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     bs = solver.BatchSolver(windows)
     t_struct = time.perf_counter() - t0          # symbolic phase + one-off upload (reported, not timed)
@@ -141,19 +154,37 @@ def main():
     if rank == 0:
         def avg_ms(k):
             return acc[k]["ms"] / max(1, acc[k]["calls"])
-        # roofline of the dominant kernel (per launch over the whole per-GPU batch)
-        if dom == "chol_solve":
-            achieved = calib["chol_flops"] / (avg_ms(dom) * 1e-3) / 1e12
-            roof = dict(kernel="k_chol_solve", bound="mfma", achieved=achieved, peak=FP64_MATRIX_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=achieved / FP64_MATRIX_PEAK_TFLOPS, traffic=None,
-                        algorithmic="sum_w n_red^3/3 flops x2 (mul+add) per launch",
-                        avg_launch_ms=avg_ms(dom))
-            roof["achieved"] = 2 * achieved; roof["frac"] = 2 * achieved / FP64_MATRIX_PEAK_TFLOPS
+
+        # algorithmic work of ONE launch over this GPU's batch (DESIGN.md §3 states the per-unit figures)
+        work = {
+            "eval_proj": ("hbm", calib["proj_bytes"], "312 B per observation (152 read + 160 written)"),
+            "lm_elim": ("hbm", 496 * calib["n_obs"], "496 B per observation (Jp, Jl, r read = 160 B; Y|W cell + Y g_l written = 336 B)"),
+            "lm_gemm": ("mfma", calib["lm_schur_flops"], "sum over landmarks of 216 k^2 + 108 k flops (SURVEY.md 8d landmark Schur)"),
+            "chol_solve": ("mfma", 2 * calib["chol_flops"], "2 * sum_w n_red^3 / 3 flops"),
+        }
+        bound, units, what = work.get(dom, ("hbm", calib["jacobian_bytes"], "Jacobian bytes of the batch (SURVEY.md 8d formula)"))
+        knames = {"eval_proj": "k_eval_proj<true>", "lm_elim": "k_lm_elim", "lm_gemm": "k_lm_gemm<512, 5>", "chol_solve": "k_chol_rr2<9>"}
+        # HBM traffic from the committed PMC passes of the same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # separate passes; gfx950: FETCH_SIZE counts half of wide coalesced reads -> x2), if available
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "batch512_pmc_fetch_write.json")))
+            kn = knames.get(dom, "k_" + dom)
+            fk = [k for k in pmc["FETCH_SIZE"] if kn.split("<")[0] in k]
+            if fk and B == 512:
+                traffic = (2 * pmc["FETCH_SIZE"][fk[0]]["avg_kb_per_launch"] + pmc["WRITE_SIZE"][fk[0]]["avg_kb_per_launch"]) * 1024.0
+        except Exception:
+            traffic = None
+        if bound == "mfma":
+            achieved = units / (avg_ms(dom) * 1e-3) / 1e12
+            roof = dict(kernel=knames.get(dom, "k_" + dom), bound="mfma", achieved=achieved, peak=FP64_MATRIX_PEAK_TFLOPS,
+                        unit="TFLOP/s", frac=achieved / FP64_MATRIX_PEAK_TFLOPS, traffic=traffic, algorithmic=what,
+                        algorithmic_flops_per_launch=units, avg_launch_ms=avg_ms(dom),
+                        measured_fp64_mfma_ceiling_tflops=FP64_MATRIX_MEASURED_TFLOPS)
         else:
-            per_launch = {"eval_proj": calib["proj_bytes"]}.get(dom, calib["jacobian_bytes"])
-            achieved = per_launch / (avg_ms(dom) * 1e-3) / 1e9
-            roof = dict(kernel="k_" + dom, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, algorithmic_bytes_per_launch=per_launch,
+            achieved = units / (avg_ms(dom) * 1e-3) / 1e9
+            roof = dict(kernel=knames.get(dom, "k_" + dom), bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, algorithmic=what, algorithmic_bytes_per_launch=units,
                         avg_launch_ms=avg_ms(dom))
         jac = dict(kernel="k_eval_proj<true>", bound="hbm",
                    achieved=calib["proj_bytes"] / (avg_ms("eval_proj") * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",

@@ -77,7 +77,7 @@ struct swf_batch {
     std::vector<hipEvent_t> ev;           // event pool (pairs)
     std::vector<int> ev_kind;             // kernel id per recorded pair
     int ev_used = 0;
-    int64_t jac_bytes = 0, proj_bytes = 0, chol_flops = 0;
+    int64_t jac_bytes = 0, proj_bytes = 0, chol_flops = 0, lm_schur_flops = 0;
     int last_mode = -1;
 };
 
@@ -521,6 +521,10 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->chol_rr1 = getenv("SWF_CHOL_RR1") != nullptr;
     b->win = B.win; b->hw = hw; b->max_tiles = B.max_tiles; b->max_prior_dim = B.max_prior_dim; b->jac_bytes = B.jac_bytes;
     b->proj_bytes = (int64_t)312 * (int64_t)B.p_win.size();
+    for (size_t l = 0; l + 1 < B.lm_obs0.size() + 1 && l < B.lm_win.size(); l++) {
+        int64_t k = (l + 1 < B.lm_obs0.size() ? B.lm_obs0[l + 1] : (int)B.p_win.size()) - B.lm_obs0[l];
+        b->lm_schur_flops += 216 * k * k + 108 * k;
+    }
     for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); }
     DevBatch& D = b->D;
     DevPool& P = b->pool;
@@ -680,7 +684,7 @@ struct Launcher {
         }
         if (write_S && b->max_tiles) {
             Bracket t(*this, SWF_K_LM_GEMM);
-            if (b->max_tiles <= 36) hipLaunchKernelGGL((k_lm_gemm<256, 9>), dim3(D.n_win, GEMM_SPLIT), dim3(256), 0, st, D);
+            if (b->max_tiles <= 36) hipLaunchKernelGGL((k_lm_gemm<512, 5>), dim3(D.n_win, GEMM_SPLIT), dim3(512), 0, st, D);
             else hipLaunchKernelGGL((k_lm_gemm<1024, 8>), dim3(D.n_win, GEMM_SPLIT), dim3(1024), 0, st, D);
         }
         if (D.n_fsb) { Bracket t(*this, SWF_K_ASSEMBLE); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
@@ -764,6 +768,7 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
     HIPCHK(hipGetLastError());
     b->last = swf_timing{};
     b->last.jacobian_bytes = b->jac_bytes; b->last.proj_bytes = b->proj_bytes; b->last.chol_flops = b->chol_flops;
+    b->last.lm_schur_flops = b->lm_schur_flops; b->last.n_obs = b->D.n_proj;
     b->last.n_linearizations = nlin;
     b->last_mode = opt->step_mode;
     return SWF_OK;

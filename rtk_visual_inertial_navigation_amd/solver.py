@@ -25,7 +25,7 @@ K_NAMES = ["total", "eval_proj", "eval_imu", "eval_scalar", "eval_prior", "lm_el
 
 class TimingC(C.Structure):
     _fields_ = [("ms", C.c_double * 16), ("calls", C.c_int32 * 16), ("jacobian_bytes", C.c_int64),
-                ("proj_bytes", C.c_int64), ("chol_flops", C.c_int64),
+                ("proj_bytes", C.c_int64), ("chol_flops", C.c_int64), ("lm_schur_flops", C.c_int64), ("n_obs", C.c_int64),
                 ("n_linearizations", C.c_int32), ("reserved", C.c_int32)]
 
 
@@ -153,6 +153,7 @@ class BatchSolver:
         t = TimingC()
         _chk(lib().swf_batch_timing(self._h, C.byref(t)), "swf_batch_timing")
         d = dict(jacobian_bytes=t.jacobian_bytes, proj_bytes=t.proj_bytes, chol_flops=t.chol_flops,
+                 lm_schur_flops=t.lm_schur_flops, n_obs=t.n_obs,
                  n_linearizations=t.n_linearizations, total_ms=t.ms[0])
         d["kernels"] = {K_NAMES[k]: dict(ms=t.ms[k], calls=t.calls[k]) for k in range(16) if t.calls[k]}
         return d
