@@ -8,7 +8,7 @@ Host-side input producer: trajectory, landmarks, IMU samples + mid-point pre-int
 """
 import numpy as np
 
-from .flat import FlatWindow, PRE, PRE_DOUBLES, CP_DOUBLES, PR_DOUBLES
+from .flat import FlatWindow, PRE, PRE_DOUBLES, CP_DOUBLES, PR_DOUBLES, DOP_DOUBLES
 from .ordering import my_ordering
 
 # yaml/rtk_visual_inertial_config.yaml
@@ -325,15 +325,19 @@ def make_window(config_id=3, seed=None, K=None, F=None, S=None, prior=None, pert
             proj_uv.append([u + rng.normal(0, 1.0 / FOCAL_LENGTH), v + rng.normal(0, 1.0 / FOCAL_LENGTH)])
     proj_idx = np.array(proj_idx, np.int32).reshape(-1, 3); proj_uv = np.array(proj_uv).reshape(-1, 2)
 
-    # ---- scalars: [dummy blackvalue2] + S ambiguities + K clocks
-    n_sc = 1 + S + (K if S > 0 else 0)
+    # ---- scalars: [dummy blackvalue2] + S ambiguities + K clocks (+ 1 receiver clock drift with Doppler)
+    use_dop = bool(doppler) and S > 0
+    n_sc = 1 + S + (K if S > 0 else 0) + (1 if use_dop else 0)
     sc_t = np.zeros(n_sc)
     i_dummy = 0; i_amb0 = 1; i_clk0 = 1 + S
-    cp_idx, cp_dat, pr_idx, pr_dat = [], [], [], []
+    cp_idx, cp_dat, pr_idx, pr_dat, dop_idx, dop_dat = [], [], [], [], [], []
+    i_drift = 1 + S + K
     base = ANCHOR.copy()
     if S > 0:
         sc_t[i_amb0:i_amb0 + S] = np.rint(rng.normal(0, 20, S))
         sc_t[i_clk0:i_clk0 + K] = rng.uniform(-30, 30, K)
+        if use_dop:
+            sc_t[i_drift] = rng.uniform(-0.5, 0.5)
         up = Rwgw[:, 2]
         sat0, satv = [], []
         for s in range(S):
@@ -361,6 +365,16 @@ def make_window(config_id=3, seed=None, K=None, F=None, S=None, prior=None, pert
                 cp_dat.append([ps[0], ps[1], ps[2], L1_lam, LAM_L1, el, dt_br, sig_cp ** 2, 1.0])
                 pr_idx.append([k, i_clk0 + k])
                 pr_dat.append([ps[0], ps[1], ps[2], P1, el, dt_br, sig_pr ** 2])
+                if use_dop:
+                    # SppDopplerFactor(satellite_vel, satellite_pos, ., D*lam, istd, base) on
+                    # (speed_bias, clock drift para_gnss_dt[0]+12, pose): R/swf/swf_core.cpp:189-201
+                    vs = satv[s]; vr = sb_t[k, :3]
+                    rate = (vr - vs) @ e + OMGE / CLIGHT * (vs[1] * xg[0] + ps[1] * vr[0] - vs[0] * xg[1] - ps[0] * vr[1])
+                    sig_d = 0.05
+                    istd = sin_el * sin_el / sig_d
+                    D1_lam = -(rate + sc_t[i_drift]) + rng.normal(0, 1.0 / istd)
+                    dop_idx.append([k, i_drift, k])
+                    dop_dat.append([ps[0], ps[1], ps[2], vs[0], vs[1], vs[2], D1_lam, istd])
 
     # ---- initial guess = truth perturbed (5 cm / 0.5 deg / 5 cm/s / 1 % depth)
     pose = pose_t.copy(); sb = sb_t.copy(); lm = lm_t.copy(); sc = sc_t.copy()
@@ -381,6 +395,8 @@ def make_window(config_id=3, seed=None, K=None, F=None, S=None, prior=None, pert
         if S > 0:
             sc[i_amb0:i_amb0 + S] += rng.normal(0, 0.3, S)
             sc[i_clk0:i_clk0 + K] += rng.normal(0, 1.0, K)
+            if use_dop:
+                sc[i_drift] += rng.normal(0, 0.1)
 
     n_pose, n_sb = K + 1, K
     n_blocks = n_pose + n_sb + F + n_sc
@@ -422,6 +438,7 @@ def make_window(config_id=3, seed=None, K=None, F=None, S=None, prior=None, pert
                  speed_bias=[bid_sb(k) for k in range(K)], poses=[bid_pose(k) for k in range(K)],
                  extrinsics=[bid_pose(K)], rtk_ambiguities=[bid_sc(i_amb0 + s) for s in range(S)],
                  clocks=[bid_sc(i_clk0 + k) for k in range(K)] if S > 0 else [],
+                 pr_corrections=[bid_sc(i_drift)] if use_dop else [],   # the drift scalar takes its own later group
                  prior_kept=list(prior_blk), parameter_head=[])
     order_block, order_group, n_tail = my_ordering(roles, is_const)
 
@@ -433,6 +450,7 @@ def make_window(config_id=3, seed=None, K=None, F=None, S=None, prior=None, pert
         imu_idx=imu_idx, imu_pre=imu_pre,
         cp_idx=np.array(cp_idx, np.int32).reshape(-1, 3), cp_dat=np.array(cp_dat).reshape(-1, CP_DOUBLES),
         pr_idx=np.array(pr_idx, np.int32).reshape(-1, 2), pr_dat=np.array(pr_dat).reshape(-1, PR_DOUBLES),
+        dop_idx=np.array(dop_idx, np.int32).reshape(-1, 3), dop_dat=np.array(dop_dat).reshape(-1, DOP_DOUBLES),
         sp_idx=np.array([i_dummy], np.int32), sp_w=np.array([1.0]),
         prior_nblk=np.array([len(prior_blk)], np.int32), prior_dim=np.array([prior_dim], np.int32),
         prior_blk=np.array(prior_blk, np.int32), prior_J=Jp, prior_r0=r0, prior_x0=x0,

@@ -112,3 +112,24 @@ def test_ceres_shaped_cpp_example_runs_on_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Iterations:" in r.stdout
+
+
+def test_problem_bookkeeping_without_gpu():
+    """ceres::Problem bookkeeping semantics that need no device: implicit AddParameterBlock on
+    AddResidualBlock, HasParameterBlock / IsParameterBlockConstant / ParameterBlockSize, cascade of
+    RemoveParameterBlock, size mismatch refused."""
+    w = synth.make_window(3, K=4, F=6, S=2, seed=2)
+    P, blocks = solver.problem_from_window(w)
+    assert P.NumParameterBlocks() == w.n_blocks
+    n_fac = w.a["proj_idx"].size // 3 + 3 + 8 + 8 + 1 + 1
+    assert P.NumResidualBlocks() == n_fac
+    ex = blocks[w.bid_pose(4)]
+    assert P.IsParameterBlockConstant(ex) and P.ParameterBlockSize(ex) == 7
+    P.SetParameterBlockVariable(ex); assert not P.IsParameterBlockConstant(ex)
+    pose1 = blocks[w.bid_pose(1)]
+    n_touch = int((w.a["proj_idx"].reshape(-1, 3)[:, 0] == 1).sum()) + 2 + 2 + 2      # obs + 2 IMU + 2 CP + 2 PR
+    P.RemoveParameterBlock(pose1)
+    assert P.NumResidualBlocks() == n_fac - n_touch and not P.HasParameterBlock(pose1)
+    with pytest.raises(solver.SwfError):
+        P.AddProjection(blocks[w.bid_sb(0)], ex, blocks[w.bid_lm(0)], [0.0, 0.0])   # a 9-block where a pose is expected
+    P.close()
