@@ -707,7 +707,7 @@ struct Launcher {
         DevBatch& D = b->D;
         {
             Bracket t(*this, SWF_K_BACKSUB);
-            if (D.n_lm) hipLaunchKernelGGL(k_backsub_lm, GRID(D.n_lm, 256), dim3(256), 0, st, D);
+            if (D.n_lm) hipLaunchKernelGGL(k_backsub_lm, GRID((size_t)D.n_lm * 16, 256), dim3(256), 0, st, D);
             if (D.n_cle) hipLaunchKernelGGL(k_backsub_clique, GRID((size_t)D.n_cle * 16, 256), dim3(256), 0, st, D);
         }
         {

@@ -526,49 +526,38 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
         __syncthreads();                                   // A_0: tile (0,0) published
         for (int j = 0; j < Tc; j++) {
             double (*D)[17] = Dt[j & 1];
-            double d[16];
+            // Factor (lane = row: d[c] = A[lane][c]) and invert (lane = column: x[r] = Linv[r][lane]) in ONE
+            // sweep.  Column c of L is broadcast once per row c2 > c (v_readlane -> SGPR) and used twice:
+            // for the right-looking update of row lanes, and for the running sums sx[c2] += L[c2][c] x[c]
+            // of the forward substitutions — so the inverse adds no dependent chain of its own.
+            double d[16], sx[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) d[c] = (lane < 16 && c <= lane) ? D[lane][c] : 0.0;
+            for (int c = 0; c < 16; c++) { d[c] = (lane < 16 && c <= lane) ? D[lane][c] : 0.0; sx[c] = 0.0; }
             bool bad = false;
-            double ipv = 0;
+            double x[16];
 #pragma unroll
             for (int c = 0; c < 16; c++) {
                 double dp = readlane_d(d[c], c);
                 if (!(dp > 0.0)) bad = true;
                 double ip = rsqrt_nr(dp);
                 d[c] = (lane == c) ? dp * ip : (lane > c ? d[c] * ip : d[c]);
-                if (lane == c) ipv = ip;
+                // Linv[c][lane]: 1/L_cc on the diagonal, -(sum_k<c L[c][k] Linv[k][lane]) / L_cc left of it
+                double xc = (lane == c) ? ip : (lane < c ? -sx[c] * ip : 0.0);
+                x[c] = xc;
 #pragma unroll
                 for (int c2 = c + 1; c2 < 16; c2++) {
-                    double l2 = readlane_d(d[c], c2);
+                    double l2 = readlane_d(d[c], c2);        // L[c2][c]
                     if (lane >= c2) d[c2] -= d[c] * l2;
+                    sx[c2] += l2 * xc;
                 }
             }
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; c++) D[lane][c] = (c <= lane) ? d[c] : 0.0;
-            }
-            if (bad && lane == 0) fail = 1;
-            // inverse, lane = column: x[c] = 1/L_cc, x[r>c] = -(sum_k L[r][k] x[k]) / L_rr ;
-            // L[r][k] and 1/L_rr broadcast from lane r's registers (SGPR operands, no LDS on the chain)
-            double x[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = (r == lane) ? ipv : 0.0;
-#pragma unroll
-            for (int r = 1; r < 16; r++) {
-                double s0 = 0, s1 = 0;
-#pragma unroll
-                for (int k = 0; k < r; k += 2) {
-                    s0 += readlane_d(d[k], r) * x[k];
-                    if (k + 1 < r) s1 += readlane_d(d[k + 1], r) * x[k + 1];
-                }
-                double v = -(s0 + s1) * readlane_d(ipv, r);
-                x[r] = (r > lane) ? v : x[r];
-            }
-            if (lane < 16) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) Li[j][r][lane] = x[r];
             }
+            if (bad && lane == 0) fail = 1;
             __syncthreads();                               // B_j
             if (fail) { if (tid == 0) st.lin_fail = 1; return; }
             __syncthreads();                               // C_j
@@ -721,18 +710,20 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 // Back-substitution of the eliminated blocks: y_e = Einv (g_e - H_ef y_f)
 // =========================================================================================
 __global__ void __launch_bounds__(256) k_backsub_lm(DevBatch B) {
-    int L = blockIdx.x * blockDim.x + threadIdx.x;
-    if (L >= B.n_lm) return;
-    int w = B.lm_win[L];
+    // 16 lanes per landmark, one observation per lane and round: t = g_l - sum_o W_o^T y_pose(o)
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int L = gid >> 4, sub = threadIdx.x & 15;
+    bool valid = L < B.n_lm;
+    int Lc = valid ? L : B.n_lm - 1;
+    int w = B.lm_win[Lc];
     const WinState& s = B.ws[w];
-    if (!s.need_lin || s.lin_fail) return;
-    int loc = B.lm_loc[L];
-    if (loc < 0) return;
+    int loc = B.lm_loc[Lc];
+    bool act = valid && s.need_lin && !s.lin_fail && loc >= 0;
     const WinRec& W = B.win[w];
     int nl = B.n_lm;
-    const double* cells = B.YW + W.YW_base + (size_t)(L - W.lm0) * W.nF * 36;
-    double t0 = B.lm_g[L], t1 = B.lm_g[nl + L], t2 = B.lm_g[2 * nl + L];
-    for (int o = B.lm_obs0[L]; o < B.lm_obs0[L + 1]; o++) {
+    const double* cells = B.YW + W.YW_base + (size_t)(Lc - W.lm0) * W.nF * 36;
+    double t0 = 0, t1 = 0, t2 = 0;
+    if (act) for (int o = B.lm_obs0[Lc] + sub; o < B.lm_obs0[Lc + 1]; o += 16) {
         int f = B.p_fr[o];
         if (f < 0) continue;
         int lp = B.p_lpose[o];
@@ -743,6 +734,9 @@ __global__ void __launch_bounds__(256) k_backsub_lm(DevBatch B) {
             t0 -= cw[i] * yv; t1 -= cw[6 + i] * yv; t2 -= cw[12 + i] * yv;
         }
     }
+    t0 = grp16_sum(t0); t1 = grp16_sum(t1); t2 = grp16_sum(t2);
+    if (!act || sub != 0) return;
+    t0 += B.lm_g[L]; t1 += B.lm_g[nl + L]; t2 += B.lm_g[2 * nl + L];
     double e00 = B.lm_Einv[L], e10 = B.lm_Einv[nl + L], e20 = B.lm_Einv[2 * nl + L];
     double e11 = B.lm_Einv[3 * nl + L], e21 = B.lm_Einv[4 * nl + L], e22 = B.lm_Einv[5 * nl + L];
     B.y[loc] = e00 * t0 + e10 * t1 + e20 * t2;
