@@ -91,10 +91,18 @@ int swf_batch_dims(swf_batch* b, int32_t w, int32_t* n_loc, int32_t* n_e, int32_
 /* Timing of the last swf_batch_solve, measured with HIP events recorded on the batch stream
  * around individual kernel launches (valid after swf_batch_sync).  `mask` selects which
  * kernels get an event pair per launch (bit k = SWF_K_*); bit 0 brackets the whole solve.
- * ms[k] = summed duration, calls[k] = number of launches bracketed. */
-enum { SWF_K_TOTAL = 0, SWF_K_EVAL_PROJ = 1, SWF_K_EVAL_IMU = 2, SWF_K_EVAL_SCALAR = 3, SWF_K_EVAL_PRIOR = 4,
-       SWF_K_LM_ELIM = 5, SWF_K_CLIQUE_ELIM = 6, SWF_K_LM_GEMM = 7, SWF_K_ASSEMBLE = 8, SWF_K_CHOL = 9,
-       SWF_K_BACKSUB = 10, SWF_K_JTIMES = 11, SWF_K_DOGLEG = 12, SWF_K_CAND_EVAL = 13, SWF_K_DECIDE = 14,
+ * ms[k] = summed duration, calls[k] = number of launches bracketed.
+ * One id per distinct kernel.  Mutually independent small kernels run as segments of one fused grid:
+ *   LM_SCHUR    = k_lm_schur        landmark elimination + reduced-camera product (cells stay in LDS)
+ *   EVAL_PS     = k_eval_ps<true>   projection + scalar-factor residuals and Jacobians
+ *   POST_CHOL   = k_post_chol       back-substitution + |J D^-2 g|^2 of the Cauchy point
+ *   POST_DOGLEG = k_post_dogleg     J*step + candidate residuals of projection/scalar factors
+ *   CAND_EVAL   = k_eval_imu<false> + k_eval_prior<false> (candidate residuals)
+ *   CLIQUE_ELIM = the (up to three) size classes of k_clique_elim
+ *   ASSEMBLE    = k_assemble_all    diagonal + off-diagonal blocks of the reduced system */
+enum { SWF_K_TOTAL = 0, SWF_K_EVAL_PS = 1, SWF_K_EVAL_IMU = 2, SWF_K_FRAME_SUMS = 3, SWF_K_EVAL_PRIOR = 4,
+       SWF_K_LM_SCHUR = 5, SWF_K_CLIQUE_ELIM = 6, SWF_K_UNUSED7 = 7, SWF_K_ASSEMBLE = 8, SWF_K_CHOL = 9,
+       SWF_K_POST_CHOL = 10, SWF_K_POST_DOGLEG = 11, SWF_K_DOGLEG = 12, SWF_K_CAND_EVAL = 13, SWF_K_DECIDE = 14,
        SWF_K_COUNT = 16 };
 typedef struct swf_timing {
     double ms[SWF_K_COUNT];

@@ -24,7 +24,6 @@ struct WinRec {
     int lm0, lm1;                // landmark records
     int fr_base, nF;             // observing frames (pose blocks that carry observations)
     long long P_base;            // (6 nF)^2 landmark Schur product
-    long long YW_base;           // [nL][nF][36] cells: Y(3x6) | W(3x6) per (landmark, frame)
     int gf0, gf1;                // generic (non-projection) factors
     int cl0, cl1;                // cliques
     int pair0, pair1;            // reduced block pairs
@@ -102,7 +101,8 @@ struct DevBatch {
     int n_lm;
     const int* lm_win; const int* lm_obs0; const int* lm_loc; const int* lm_col;
     double* lm_Einv; double* lm_g;             // SoA stride n_lm: 6 / 3
-    double* YW; double* P;                     // landmark Schur cells, product
+    double* P;                                 // landmark Schur product, GEMM_SPLIT partials per window
+    const int* sch_c0; const int* sch_l;       // k_lm_schur chunk table: chunks of block (window, split); [l0, l1) per chunk
     const unsigned long long* lm_fmask;        // frames (slots < 64) each landmark is observed in
     // frames
     int n_fr;

@@ -107,7 +107,7 @@ struct Build {
     std::vector<Pair> pair;
     std::vector<long long> pc_coff;
     std::vector<int> pc_cld, pc_voff;
-    long long n_x = 0, n_loc = 0, S_tot = 0, Lt_tot = 0, P_tot = 0, YW_tot = 0, C_tot = 0;
+    long long n_x = 0, n_loc = 0, S_tot = 0, Lt_tot = 0, P_tot = 0, C_tot = 0;
     int v_tot = 0, e_tot = 0, r_tot = 0, j_tot = 0, n_fr = 0;
     int max_tiles = 0, max_prior_dim = 0;
     int64_t jac_bytes = 0;
@@ -196,6 +196,8 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
             int i = ord[q];
             int p = w->proj_idx[i * 3], ex = w->proj_idx[i * 3 + 1], l = w->proj_idx[i * 3 + 2];
             if (loc[bidP(ex)] >= 0) return fail(SWF_E_UNSUPPORTED, "variable camera extrinsic (ESTIMATE_EXTRINSIC) not supported by the kernels yet");
+            if (q > 0 && w->proj_idx[ord[q - 1] * 3 + 2] == l && w->proj_idx[ord[q - 1] * 3] == p && frame_of[p] >= 0)
+                return fail(SWF_E_UNSUPPORTED, "two projection factors of one landmark in the same frame");
             int gi = (int)B.p_win.size();
             B.p_win.push_back(wi);
             B.p_xpose.push_back(gx(bidP(p))); B.p_xex.push_back(gx(bidP(ex))); B.p_xlm.push_back(gx(bidL(l)));
@@ -247,12 +249,10 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     }
     R.fsb1 = (int)B.fsb_win.size();
     R.P_base = B.P_tot; B.P_tot += (long long)36 * R.nF * R.nF;       // x GEMM_SPLIT partial products at allocation
-    R.YW_base = B.YW_tot; B.YW_tot += (long long)nL * R.nF * 36;
-    if (R.nF * 36 > GEMM_LDS_DOUBLES) return fail(SWF_E_UNSUPPORTED, "more than 160 observing frames");
     {
         int m = 6 * R.nF, nt = (m + 15) / 16;
         B.max_tiles = std::max(B.max_tiles, nt * (nt + 1) / 2);
-        if (nt * (nt + 1) / 2 > 128) return fail(SWF_E_UNSUPPORTED, "more than 40 observing frames in one window");
+        if (nt * (nt + 1) / 2 > 120) return fail(SWF_E_UNSUPPORTED, "more than 40 observing frames in one window");
     }
 
     // ---- generic factors
@@ -539,6 +539,29 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     D.n_lm = (int)B.lm_win.size();
     B.lm_obs0.push_back(D.n_proj);
     PUT(lm_win, B.lm_win); PUT(lm_obs0, B.lm_obs0); PUT(lm_loc, B.lm_loc); PUT(lm_col, B.lm_col); PUT(lm_fmask, B.lm_fmask);
+    {
+        // k_lm_schur chunk table: every (window, split) block walks its landmark range in chunks of at most
+        // LPC landmarks and CAP observation cells (one LDS buffer of the kernel)
+        const int LPC = LS_LPC, CAP = LS_CAP;
+        std::vector<int> c0, cl;
+        for (auto& W : B.win) {
+            int nLw = W.lm1 - W.lm0, per = (nLw + GEMM_SPLIT - 1) / GEMM_SPLIT;
+            for (int sp = 0; sp < GEMM_SPLIT; sp++) {
+                c0.push_back((int)cl.size() / 2);
+                int lbeg = W.lm0 + std::min(sp * per, nLw), lend = W.lm0 + std::min(sp * per + per, nLw);
+                for (int l = lbeg; l < lend;) {
+                    int e = l;
+                    while (e < lend && e - l < LPC && B.lm_obs0[e + 1] - B.lm_obs0[l] <= CAP) e++;
+                    if (e == l) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "landmark with more observations than one LDS chunk holds"); }
+                    cl.push_back(l); cl.push_back(e);
+                    l = e;
+                }
+            }
+        }
+        c0.push_back((int)cl.size() / 2);
+        cl.push_back(0); cl.push_back(0);
+        PUT(sch_c0, c0); PUT(sch_l, cl);
+    }
     D.n_fr = B.n_fr;
     B.fr_obs0.push_back((int)B.fr_obs.size());
     PUT(fr_obs0, B.fr_obs0); PUT(fr_obs, B.fr_obs);
@@ -584,7 +607,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl); rc |= P.zeros(6 * np, &D.p_yg);
     rc |= P.zeros(np, &D.p_cost); rc |= P.zeros(np, &D.p_aux);
     rc |= P.zeros(6 * (size_t)D.n_lm, &D.lm_Einv); rc |= P.zeros(3 * (size_t)D.n_lm, &D.lm_g);
-    rc |= P.zeros(B.YW_tot, &D.YW); rc |= P.zeros(B.P_tot * GEMM_SPLIT, &D.P);
+    rc |= P.zeros(B.P_tot * GEMM_SPLIT, &D.P);
     rc |= P.zeros((size_t)B.r_tot, &D.g_r); rc |= P.zeros((size_t)B.j_tot, &D.g_J);
     rc |= P.zeros((size_t)D.n_gf, &D.g_cost); rc |= P.zeros((size_t)D.n_gf, &D.g_aux);
     {
@@ -666,33 +689,38 @@ struct Launcher {
         }
         ~Bracket() { if (slot >= 0) (void)hipEventRecord(L.b->ev[2 * slot + 1], L.st); }
     };
+    static int nb(size_t n, int per) { return (int)((n + per - 1) / per); }
     void lin_eval() {
         DevBatch& D = b->D;
-        if (D.n_proj) { Bracket t(*this, SWF_K_EVAL_PROJ); hipLaunchKernelGGL(k_eval_proj<true>, GRID(D.n_proj, 256), dim3(256), 0, st, D); }
+        if (D.n_proj + D.n_sc) {
+            Bracket t(*this, SWF_K_EVAL_PS);
+            Segs S{}; S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256);
+            hipLaunchKernelGGL(k_eval_ps<true>, dim3(S.e[1]), dim3(256), 0, st, D, S);
+        }
         if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * 16), 0, st, D); }
-        if (D.n_sc) { Bracket t(*this, SWF_K_EVAL_SCALAR); hipLaunchKernelGGL(k_eval_scalar<true>, GRID(D.n_sc, 256), dim3(256), 0, st, D); }
         if (D.n_prior) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
     }
     void lin_elim(int write_S) {
         DevBatch& D = b->D;
-        if (D.n_lm) { Bracket t(*this, SWF_K_LM_ELIM); hipLaunchKernelGGL(k_lm_elim, GRID((size_t)D.n_lm * 16, 256), dim3(256), 0, st, D, O); }
+        if (D.n_lm) {
+            Bracket t(*this, SWF_K_LM_SCHUR);
+            // size-specialised variants: <= 12 tiles (<= 10 frames), <= 36 tiles (<= 21 frames), <= 120 tiles (<= 40 frames)
+            if (b->max_tiles <= 12) hipLaunchKernelGGL(k_lm_schur<1>, dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT), 0, st, D, O, write_S);
+            else if (b->max_tiles <= 36) hipLaunchKernelGGL(k_lm_schur<3>, dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT), 0, st, D, O, write_S);
+            else hipLaunchKernelGGL(k_lm_schur<10>, dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT), 0, st, D, O, write_S);
+        }
         {
             Bracket t(*this, SWF_K_CLIQUE_ELIM);
             if (D.n_clc[0]) hipLaunchKernelGGL((k_clique_elim<48, 32, 64, 0>), dim3(D.n_clc[0]), dim3(64), 0, st, D, O);
             if (D.n_clc[1]) hipLaunchKernelGGL((k_clique_elim<32, 48, 256, 1>), dim3(D.n_clc[1]), dim3(256), 0, st, D, O);
             if (D.n_clc[2]) hipLaunchKernelGGL((k_clique_elim<64, 64, 256, 2>), dim3(D.n_clc[2]), dim3(256), 0, st, D, O);
         }
-        if (write_S && b->max_tiles) {
-            Bracket t(*this, SWF_K_LM_GEMM);
-            if (b->max_tiles <= 36) hipLaunchKernelGGL((k_lm_gemm<512, 5>), dim3(D.n_win, GEMM_SPLIT), dim3(512), 0, st, D);
-            else hipLaunchKernelGGL((k_lm_gemm<1024, 8>), dim3(D.n_win, GEMM_SPLIT), dim3(1024), 0, st, D);
-        }
-        if (D.n_fsb) { Bracket t(*this, SWF_K_ASSEMBLE); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
-        {
+        if (D.n_fsb) { Bracket t(*this, SWF_K_FRAME_SUMS); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
+        if (D.n_pd) {
             Bracket t(*this, SWF_K_ASSEMBLE);
-            if (D.n_pd) hipLaunchKernelGGL(k_assemble<true>, GRID((size_t)D.n_pd * 64, 256), dim3(256), 0, st, D, O, write_S);
+            Segs S{}; S.e[0] = nb((size_t)D.n_pd * 64, 256); S.e[1] = S.e[0] + (write_S ? nb((size_t)D.n_po * 16, 256) : 0);
+            hipLaunchKernelGGL(k_assemble_all, dim3(S.e[1]), dim3(256), 0, st, D, O, write_S, S);
         }
-        if (D.n_po && write_S) { Bracket t(*this, 15); hipLaunchKernelGGL(k_assemble<false>, GRID((size_t)D.n_po * 16, 256), dim3(256), 0, st, D, O, write_S); }
     }
     void reduced() {
         DevBatch& D = b->D;
@@ -706,33 +734,28 @@ struct Launcher {
     void step_rest() {
         DevBatch& D = b->D;
         {
-            Bracket t(*this, SWF_K_BACKSUB);
-            if (D.n_lm) hipLaunchKernelGGL(k_backsub_lm, GRID((size_t)D.n_lm * 16, 256), dim3(256), 0, st, D);
-            if (D.n_cle) hipLaunchKernelGGL(k_backsub_clique, GRID((size_t)D.n_cle * 16, 256), dim3(256), 0, st, D);
-        }
-        {
-            Bracket t(*this, SWF_K_JTIMES);
-            if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<0>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
-            if (D.n_sc) hipLaunchKernelGGL(k_jtimes_scalar<0>, GRID(D.n_sc, 256), dim3(256), 0, st, D, O);
-            if (D.n_imu) hipLaunchKernelGGL(k_jtimes_imu<0>, GRID((size_t)D.n_imu * 16, 256), dim3(256), 0, st, D, O);
-            if (D.n_prior) hipLaunchKernelGGL(k_jtimes_prior<0>, GRID((size_t)D.n_prior * 64, 256), dim3(256), 0, st, D, O);
+            Bracket t(*this, SWF_K_POST_CHOL);
+            Segs S{};
+            S.e[0] = nb((size_t)D.n_lm * 16, 256); S.e[1] = S.e[0] + nb((size_t)D.n_cle * 16, 256);
+            S.e[2] = S.e[1] + nb(D.n_proj, 256); S.e[3] = S.e[2] + nb(D.n_sc, 256);
+            S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + nb((size_t)D.n_prior * 64, 256);
+            if (S.e[5]) hipLaunchKernelGGL(k_post_chol, dim3(S.e[5]), dim3(256), 0, st, D, O, S);
         }
         { Bracket t(*this, SWF_K_DOGLEG); hipLaunchKernelGGL(k_dogleg, dim3(D.n_win), dim3(256), 0, st, D, O); }
-        {
-            Bracket t(*this, SWF_K_JTIMES);
-            if (D.n_proj) hipLaunchKernelGGL(k_jtimes_proj<1>, GRID(D.n_proj, 256), dim3(256), 0, st, D, O);
-            if (D.n_sc) hipLaunchKernelGGL(k_jtimes_scalar<1>, GRID(D.n_sc, 256), dim3(256), 0, st, D, O);
-            if (D.n_imu) hipLaunchKernelGGL(k_jtimes_imu<1>, GRID((size_t)D.n_imu * 16, 256), dim3(256), 0, st, D, O);
-            if (D.n_prior) hipLaunchKernelGGL(k_jtimes_prior<1>, GRID((size_t)D.n_prior * 64, 256), dim3(256), 0, st, D, O);
-        }
     }
     void cand_eval() {
         DevBatch& D = b->D;
         {
+            Bracket t(*this, SWF_K_POST_DOGLEG);
+            Segs S{};
+            S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256);
+            S.e[2] = S.e[1] + nb((size_t)D.n_imu * 16, 256); S.e[3] = S.e[2] + nb((size_t)D.n_prior * 64, 256);
+            S.e[4] = S.e[3] + nb(D.n_proj, 256); S.e[5] = S.e[4] + nb(D.n_sc, 256);
+            if (S.e[5]) hipLaunchKernelGGL(k_post_dogleg, dim3(S.e[5]), dim3(256), 0, st, D, O, S);
+        }
+        {
             Bracket t(*this, SWF_K_CAND_EVAL);
-            if (D.n_proj) hipLaunchKernelGGL(k_eval_proj<false>, GRID(D.n_proj, 256), dim3(256), 0, st, D);
             if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * 16), 0, st, D);
-            if (D.n_sc) hipLaunchKernelGGL(k_eval_scalar<false>, GRID(D.n_sc, 256), dim3(256), 0, st, D);
             if (D.n_prior) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
         }
         { Bracket t(*this, SWF_K_DECIDE); hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(256), 0, st, D, O); }

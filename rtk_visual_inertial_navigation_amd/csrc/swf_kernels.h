@@ -55,8 +55,8 @@ __device__ __forceinline__ double grp16_sum(double v) {
 // that every store instruction of a wave is one contiguous 512-byte run.
 // =========================================================================================
 template <bool JAC>
-__global__ void __launch_bounds__(256) k_eval_proj(DevBatch B) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void d_eval_proj(const DevBatch& B, int bid) {
+    int i = bid * blockDim.x + threadIdx.x;
     if (i >= B.n_proj) return;
     int w = B.p_win[i];
     const WinState& s = B.ws[w];
@@ -309,8 +309,8 @@ __device__ __forceinline__ double varerr2(double el, double dt, double mea_var) 
     return (mea_var / sinel / sinel) + b * b;
 }
 template <bool JAC>
-__global__ void __launch_bounds__(256) k_eval_scalar(DevBatch B) {
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
+    int q = bid * blockDim.x + threadIdx.x;
     if (q >= B.n_sc) return;
     int f = B.sc_gf[q];
     const GFac& G = B.gf[f];
@@ -452,8 +452,8 @@ __device__ __forceinline__ double vec_at(const DevBatch& B, const DevOpt& O, int
     return B.g[loc] / clampd(B.diag[loc], O.min_diag, O.max_diag);
 }
 template <int MODE>
-__global__ void __launch_bounds__(256) k_jtimes_proj(DevBatch B, DevOpt O) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void d_jtimes_proj(const DevBatch& B, const DevOpt& O, int bid) {
+    int i = bid * blockDim.x + threadIdx.x;
     if (i >= B.n_proj) return;
     const WinState& s = B.ws[B.p_win[i]];
     if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;
@@ -493,8 +493,8 @@ __device__ __forceinline__ double gf_row_term(const DevBatch& B, const GFac& G, 
 }
 // scalar (one-row) factors: one lane each
 template <int MODE>
-__global__ void __launch_bounds__(256) k_jtimes_scalar(DevBatch B, DevOpt O) {
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void d_jtimes_scalar(const DevBatch& B, const DevOpt& O, int bid) {
+    int q = bid * blockDim.x + threadIdx.x;
     if (q >= B.n_sc) return;
     int f = B.sc_gf[q];
     const GFac& G = B.gf[f];
@@ -504,8 +504,8 @@ __global__ void __launch_bounds__(256) k_jtimes_scalar(DevBatch B, DevOpt O) {
 }
 // IMU factors: 16 lanes per factor, one residual row per lane
 template <int MODE>
-__global__ void __launch_bounds__(256) k_jtimes_imu(DevBatch B, DevOpt O) {
-    int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+__device__ __forceinline__ void d_jtimes_imu(const DevBatch& B, const DevOpt& O, int bid) {
+    int q = (bid * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
     bool valid = q < B.n_imu;
     int f = B.imu_gf[valid ? q : B.n_imu - 1];
     const GFac& G = B.gf[f];
@@ -518,8 +518,8 @@ __global__ void __launch_bounds__(256) k_jtimes_imu(DevBatch B, DevOpt O) {
 }
 // priors: one wavefront per prior, lanes over residual rows
 template <int MODE>
-__global__ void __launch_bounds__(256) k_jtimes_prior(DevBatch B, DevOpt O) {
-    int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ void d_jtimes_prior(const DevBatch& B, const DevOpt& O, int bid) {
+    int q = (bid * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (q >= B.n_prior) return;
     int f = B.prior_gf[q];
     const GFac& G = B.gf[f];
@@ -532,93 +532,238 @@ __global__ void __launch_bounds__(256) k_jtimes_prior(DevBatch B, DevOpt O) {
 }
 
 // =========================================================================================
-// Landmark elimination (the bulk of group 0): one lane per landmark.
-//   H_ll = sum Jl^T Jl + mu*clamp(diag),  Einv = H_ll^-1,  W_o = Jp^T Jl,  Y_o = W_o Einv
-// Y/W are scattered into landmark-column-major [3 nL][6 nF] slabs whose zero pattern is
-// static, so the reduced-camera Schur term is the plain product P = Yt^T Wt (k_lm_gemm).
+// Landmark Schur elimination (the bulk of group 0), one fused kernel per linearisation:
+//   H_ll = sum Jl^T Jl + mu*clamp(diag),  Einv = H_ll^-1,  W_o = Jp^T Jl,  Y_o = W_o Einv,
+//   P = sum_l Y_l W_l^T   (the landmark part of the reduced camera matrix, fp64 matrix cores).
+// One workgroup per (window, landmark split).  It walks its landmarks in chunks of NT/16:
+//   phase A  16 lanes per landmark (one observation per lane and round, 16-lane butterflies for
+//            H_ll / g_l, division-free 3x3 inverse) build the [Y(3x6) | W(3x6)] cell of every
+//            observation IN LDS, plus a (landmark, frame) -> cell table; g_l, Einv, diag and Y g_l
+//            go to HBM (coalesced SoA) for the assembly and the back-substitution;
+//   phase B  every wave owns a fixed set of 16x16 tiles of the lower triangle of P and issues one
+//            v_mfma_f64_16x16x4_f64 per (tile, landmark): the 4 k-slots are the landmark's three
+//            coordinates (+ one zero).  Tiles whose frame range the landmark does not observe are
+//            skipped (wave-uniform test on the landmark's frame bit-mask).
+// The cells never touch HBM: per observation the kernel reads 160 B (Jp, Jl, r) and writes 48 B.
 // In-tree analogue of this arithmetic: MarginalizationInfo::marginalize,
 // R/factor/marginalization_factor.cpp:260-377; in Ceres it is SchurEliminator::Eliminate.
+// f64 MFMA layouts: A[i][k]: lane = i + 16k; B[k][j]: lane = j + 16k; D: lane l, reg q -> row (l>>4)+4q, col l&15.
 // =========================================================================================
-__global__ void __launch_bounds__(256) k_lm_elim(DevBatch B, DevOpt O) {
-    // 16 lanes per landmark: lanes stride over its observations (all loads of a round are in
-    // flight together), 16-lane butterflies reduce H_ll / g_l, every lane then owns whole
-    // observations for the W / Y products and stores.
-    int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    int L = gid >> 4, sub = threadIdx.x & 15;
-    bool valid = L < B.n_lm;
-    int Lc = valid ? L : B.n_lm - 1;
-    int w = B.lm_win[Lc];
+typedef double double4_t __attribute__((ext_vector_type(4)));
+#define GEMM_SPLIT 4                          // fixed landmark split: partial products P_0..P_3, summed in order by k_assemble
+#ifdef SWF_PROFILE_GEMM
+__device__ unsigned long long g_gemm_stamps[16];
+#define GSTAMP_ACC(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_gemm_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define GNOW() __builtin_amdgcn_s_memtime()
+#else
+#define GSTAMP_ACC(i, t0)
+#define GNOW() 0ULL
+#endif
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+#define LS_CS 37                              // LDS cell stride in doubles (36 + 1: conflict-free 16-lane cell writes)
+#define LS_NT 1024                            // 4 producer waves + 12 consumer waves
+#define LS_LPC 16                             // landmarks per chunk = 16-lane groups of the producer waves
+#define LS_CAP 192                            // observation cells per chunk and buffer (host chunk table honours both)
+#define LS_MAXF 40
+// TPW = tile slots per consumer wave (12 consumer waves): 1 (<= 12 tiles), 3 (<= 36), 10 (<= 120)
+template <int TPW>
+__global__ void __launch_bounds__(LS_NT) k_lm_schur(DevBatch B, DevOpt O, int do_gemm) {
+    constexpr int NPW = 4, NCW = 12;
+    __shared__ double cells[2][(LS_CAP + 1) * LS_CS];      // + one all-zero cell per buffer
+    __shared__ int tbl[2][LS_LPC][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
+    __shared__ unsigned long long Ms[2][LS_LPC];           // frame mask of the chunk's landmarks (0 = none / constant landmark)
+    constexpr int ZOFF = LS_CAP * LS_CS;
+    int w = blockIdx.x, sp = blockIdx.y;
     WinState& s = B.ws[w];
-    int loc = B.lm_loc[Lc];
-    bool act = valid && s.need_lin && loc >= 0;
+    if (!s.need_lin) return;
     const WinRec& W = B.win[w];
-    int n = B.n_proj, o0 = B.lm_obs0[Lc], o1 = B.lm_obs0[Lc + 1];
-    double h00 = 0, h10 = 0, h20 = 0, h11 = 0, h21 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
-    if (act) for (int o = o0 + sub; o < o1; o += 16) {
-        double a0 = B.p_Jl[0 * n + o], a1 = B.p_Jl[1 * n + o], a2 = B.p_Jl[2 * n + o];
-        double b0 = B.p_Jl[3 * n + o], b1 = B.p_Jl[4 * n + o], b2 = B.p_Jl[5 * n + o];
-        double r0 = B.p_r[o], r1 = B.p_r[n + o];
-        h00 += a0 * a0 + b0 * b0; h10 += a1 * a0 + b1 * b0; h20 += a2 * a0 + b2 * b0;
-        h11 += a1 * a1 + b1 * b1; h21 += a2 * a1 + b2 * b1; h22 += a2 * a2 + b2 * b2;
-        g0 += a0 * r0 + b0 * r1; g1 += a1 * r0 + b1 * r1; g2 += a2 * r0 + b2 * r1;
-    }
-    h00 = grp16_sum(h00); h10 = grp16_sum(h10); h20 = grp16_sum(h20); h11 = grp16_sum(h11); h21 = grp16_sum(h21); h22 = grp16_sum(h22);
-    g0 = grp16_sum(g0); g1 = grp16_sum(g1); g2 = grp16_sum(g2);
-    if (!act) return;
-    if (sub == 0) {
-        B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
-        B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
-    }
-    double mu = s.mu;
-    h00 += mu * clampd(h00, O.min_diag, O.max_diag);
-    h11 += mu * clampd(h11, O.min_diag, O.max_diag);
-    h22 += mu * clampd(h22, O.min_diag, O.max_diag);
-    // Cholesky inverse of the 3x3 (ceres InvertPSDMatrix), division-free: the reciprocal pivots
-    // come from v_rsq_f64 + Newton steps (the IEEE fp64 sqrt/div expansions made this kernel
-    // instruction-bound)
-    double i00 = rsqrt_nr3(h00);
-    double l10 = h10 * i00, l20 = h20 * i00;
-    double d11 = h11 - l10 * l10;
-    double i11 = rsqrt_nr3(d11);
-    double l21 = (h21 - l20 * l10) * i11;
-    double d22 = h22 - l20 * l20 - l21 * l21;
-    double i22 = rsqrt_nr3(d22);
-    if (!(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0)) { if (sub == 0) s.lin_fail = 1; return; }
-    double i10 = -l10 * i00 * i11;
-    double i21 = -l21 * i11 * i22;
-    double i20 = -(l20 * i00 + l21 * i10) * i22;
-    double e00 = i00 * i00 + i10 * i10 + i20 * i20, e10 = i10 * i11 + i20 * i21, e20 = i20 * i22;
-    double e11 = i11 * i11 + i21 * i21, e21 = i21 * i22, e22 = i22 * i22;
-    int nl = B.n_lm;
-    if (sub == 0) {
-        B.lm_Einv[0 * nl + L] = e00; B.lm_Einv[1 * nl + L] = e10; B.lm_Einv[2 * nl + L] = e20;
-        B.lm_Einv[3 * nl + L] = e11; B.lm_Einv[4 * nl + L] = e21; B.lm_Einv[5 * nl + L] = e22;
-        B.lm_g[0 * nl + L] = g0; B.lm_g[1 * nl + L] = g1; B.lm_g[2 * nl + L] = g2;
-    }
-    // per observation: W = Jp^T Jl, Y = W Einv, written as ONE contiguous 288-byte cell
-    // [Y(3x6) | W(3x6)] at (landmark, frame); plus Y g_l for the reduced right-hand side
-    double* cells = B.YW + W.YW_base + (size_t)(L - W.lm0) * W.nF * 36;
-    for (int o = o0 + sub; o < o1; o += 16) {
-        int f = B.p_fr[o];
-        if (f < 0) continue;
-        double a0 = B.p_Jl[0 * n + o], a1 = B.p_Jl[1 * n + o], a2 = B.p_Jl[2 * n + o];
-        double b0 = B.p_Jl[3 * n + o], b1 = B.p_Jl[4 * n + o], b2 = B.p_Jl[5 * n + o];
-        double cy[18], cw[18];
+    int nF = W.nF, m = 6 * nF, nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2;
+    int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    bool gemm = do_gemm && m > 0;
+    int blk = w * GEMM_SPLIT + sp;
+    int c0 = B.sch_c0[blk], c1 = B.sch_c0[blk + 1];
+    if (wv >= NPW) {
+        // =========================== consumer waves: P += Y W^T on the matrix cores ===========================
+        if (!gemm) return;
+        int cw = wv - NPW;
+        // tiles of this wave: tile index and frame masks (wave-uniform), per-lane operand addressing:
+        // table column of the lane's frame (column nF = the zero cell for lanes outside the matrix and the
+        // fourth k-slot) and offset inside the cell
+        int t_tr[TPW], t_tc[TPW], fA[TPW], fB[TPW], subA[TPW], subB[TPW];
+        unsigned long long mA[TPW], mB[TPW];
+        double4_t acc[TPW];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            double pa = B.p_Jp[i * n + o], pb = B.p_Jp[(6 + i) * n + o];
-            double w0 = pa * a0 + pb * b0, w1 = pa * a1 + pb * b1, w2 = pa * a2 + pb * b2;
-            cw[i] = w0; cw[6 + i] = w1; cw[12 + i] = w2;
-            double y0 = w0 * e00 + w1 * e10 + w2 * e20, y1 = w0 * e10 + w1 * e11 + w2 * e21, y2 = w0 * e20 + w1 * e21 + w2 * e22;
-            cy[i] = y0; cy[6 + i] = y1; cy[12 + i] = y2;
-            B.p_yg[i * n + o] = y0 * g0 + y1 * g1 + y2 * g2;
+        for (int sl = 0; sl < TPW; sl++) {
+            int t = cw + sl * NCW;
+            int tr = 0, tc = 0;
+            if (t < ntiles) {
+                while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
+                tc = t - tr * (tr + 1) / 2;
+            }
+            t_tr[sl] = tr; t_tc[sl] = tc;
+            int ra = tr * 16 + li, cb = tc * 16 + li;
+            bool okA = ra < m && lk < 3 && t < ntiles, okB = cb < m && lk < 3 && t < ntiles;
+            fA[sl] = okA ? ra / 6 : nF; subA[sl] = okA ? lk * 6 + ra % 6 : 0;
+            fB[sl] = okB ? cb / 6 : nF; subB[sl] = okB ? 18 + lk * 6 + cb % 6 : 0;
+            int f0 = (tr * 16) / 6, f1 = (tr * 16 + 15) / 6; if (f1 > 63) f1 = 63;
+            int g0 = (tc * 16) / 6, g1 = (tc * 16 + 15) / 6; if (g1 > 63) g1 = 63;
+            mA[sl] = (t < ntiles && f0 < 64) ? ((~0ULL >> (63 - f1)) & (~0ULL << f0)) : 0ULL;
+            mB[sl] = (t < ntiles && g0 < 64) ? ((~0ULL >> (63 - g1)) & (~0ULL << g0)) : 0ULL;
+            acc[sl] = double4_t{ 0, 0, 0, 0 };
         }
-        double2* cell = (double2*)(cells + (size_t)f * 36);
+        __syncthreads();                                    // chunk c0 produced
+        for (int c = c0; c < c1; c++) {
+            int buf = (c - c0) & 1;
+            int nlc = B.sch_l[2 * c + 1] - B.sch_l[2 * c];
+            // lane j keeps landmark j's mask; v_readlane broadcasts it into SGPRs, so tile skipping is scalar
+            unsigned long long fm_r = Ms[buf][lane & (LS_LPC - 1)];
+            const double* cb = cells[buf];
+            for (int l = 0; l < nlc; l++) {
+                unsigned long long fm = readlane_u64(fm_r, l);
+                const int* trow = tbl[buf][l];
+                bool hit[TPW];
+                int ia[TPW], ib[TPW];
+                double av[TPW], bv[TPW];
 #pragma unroll
-        for (int k = 0; k < 9; k++) cell[k] = make_double2(cy[2 * k], cy[2 * k + 1]);
+                for (int sl = 0; sl < TPW; sl++) {
+                    hit[sl] = (fm & mA[sl]) && (fm & mB[sl]);
+                    if (hit[sl]) { ia[sl] = trow[fA[sl]]; ib[sl] = trow[fB[sl]]; }
+                }
 #pragma unroll
-        for (int k = 0; k < 9; k++) cell[9 + k] = make_double2(cw[2 * k], cw[2 * k + 1]);
+                for (int sl = 0; sl < TPW; sl++)
+                    if (hit[sl]) { av[sl] = cb[ia[sl] + subA[sl]]; bv[sl] = cb[ib[sl] + subB[sl]]; }
+#pragma unroll
+                for (int sl = 0; sl < TPW; sl++)
+                    if (hit[sl]) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sl], bv[sl], acc[sl], 0, 0, 0);
+            }
+            __syncthreads();                                // chunk c consumed, chunk c+1 produced
+        }
+        double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)sp * m * m;
+#pragma unroll
+        for (int sl = 0; sl < TPW; sl++) {
+            int t = cw + sl * NCW;
+            if (t >= ntiles) continue;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int r = t_tr[sl] * 16 + lk + 4 * q, c = t_tc[sl] * 16 + li;
+                if (r < m && c < m) P[(size_t)r * m + c] = acc[sl][q];
+            }
+        }
+        return;
     }
+    // =========================== producer waves: eliminate the landmarks, chunk by chunk ===========================
+    int grp = tid >> 4, sub = tid & 15;
+    int n = B.n_proj, nl = B.n_lm;
+    double mu = s.mu;
+    if (gemm) for (int e = tid; e < 2 * LS_CS; e += NPW * 64) cells[e / LS_CS][ZOFF + e % LS_CS] = 0.0;
+    for (int c = c0; c < c1; c++) {
+        int buf = (c - c0) & 1;
+        int l0 = B.sch_l[2 * c], l1 = B.sch_l[2 * c + 1];
+        int oc0 = B.lm_obs0[l0];
+        int L = l0 + grp;
+        bool valid = L < l1;
+        int Lc = valid ? L : l0;
+        int loc = B.lm_loc[Lc];
+        bool act = valid && loc >= 0;
+        int o0 = B.lm_obs0[Lc], o1 = B.lm_obs0[Lc + 1];
+        // every load of the lane's first observation is issued up front (one exposure of the HBM latency);
+        // further rounds (tracks longer than 16 observations) re-load
+        int oF = o0 + sub;
+        bool has = act && oF < o1;
+        double jl[6], rr[2], jp[12];
+        int fF = -1;
+        if (has) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) jl[k] = B.p_Jl[k * n + oF];
+            rr[0] = B.p_r[oF]; rr[1] = B.p_r[n + oF];
+            fF = B.p_fr[oF];
+#pragma unroll
+            for (int k = 0; k < 12; k++) jp[k] = B.p_Jp[k * n + oF];
+        }
+        unsigned long long fmL = act ? B.lm_fmask[Lc] : 0ULL;
+        double h00 = 0, h10 = 0, h20 = 0, h11 = 0, h21 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
+        auto accum = [&](const double* a, const double* r) {
+            h00 += a[0] * a[0] + a[3] * a[3]; h10 += a[1] * a[0] + a[4] * a[3]; h20 += a[2] * a[0] + a[5] * a[3];
+            h11 += a[1] * a[1] + a[4] * a[4]; h21 += a[2] * a[1] + a[5] * a[4]; h22 += a[2] * a[2] + a[5] * a[5];
+            g0 += a[0] * r[0] + a[3] * r[1]; g1 += a[1] * r[0] + a[4] * r[1]; g2 += a[2] * r[0] + a[5] * r[1];
+        };
+        if (has) accum(jl, rr);
+        if (act) for (int o = oF + 16; o < o1; o += 16) {
+            double a[6], r[2];
+#pragma unroll
+            for (int k = 0; k < 6; k++) a[k] = B.p_Jl[k * n + o];
+            r[0] = B.p_r[o]; r[1] = B.p_r[n + o];
+            accum(a, r);
+        }
+        h00 = grp16_sum(h00); h10 = grp16_sum(h10); h20 = grp16_sum(h20); h11 = grp16_sum(h11); h21 = grp16_sum(h21); h22 = grp16_sum(h22);
+        g0 = grp16_sum(g0); g1 = grp16_sum(g1); g2 = grp16_sum(g2);
+        if (gemm) {
+            for (int f = sub; f <= nF; f += 16) tbl[buf][grp][f] = ZOFF;
+            if (sub == 0) Ms[buf][grp] = fmL;
+        }
+        if (act) {
+            if (sub == 0) {
+                B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
+                B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
+            }
+            h00 += mu * clampd(h00, O.min_diag, O.max_diag);
+            h11 += mu * clampd(h11, O.min_diag, O.max_diag);
+            h22 += mu * clampd(h22, O.min_diag, O.max_diag);
+            // Cholesky inverse of the 3x3 (ceres InvertPSDMatrix), division-free: the reciprocal pivots
+            // come from v_rsq_f64 + Newton steps (the IEEE fp64 sqrt/div expansions are instruction-bound)
+            double i00 = rsqrt_nr3(h00);
+            double l10 = h10 * i00, l20 = h20 * i00;
+            double d11 = h11 - l10 * l10;
+            double i11 = rsqrt_nr3(d11);
+            double l21 = (h21 - l20 * l10) * i11;
+            double d22 = h22 - l20 * l20 - l21 * l21;
+            double i22 = rsqrt_nr3(d22);
+            bool bad = !(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0);
+            if (bad) { if (sub == 0) s.lin_fail = 1; i00 = i11 = i22 = 0.0; }
+            double i10 = -l10 * i00 * i11;
+            double i21 = -l21 * i11 * i22;
+            double i20 = -(l20 * i00 + l21 * i10) * i22;
+            double e00 = i00 * i00 + i10 * i10 + i20 * i20, e10 = i10 * i11 + i20 * i21, e20 = i20 * i22;
+            double e11 = i11 * i11 + i21 * i21, e21 = i21 * i22, e22 = i22 * i22;
+            if (sub == 0) {
+                B.lm_Einv[0 * nl + L] = e00; B.lm_Einv[1 * nl + L] = e10; B.lm_Einv[2 * nl + L] = e20;
+                B.lm_Einv[3 * nl + L] = e11; B.lm_Einv[4 * nl + L] = e21; B.lm_Einv[5 * nl + L] = e22;
+                B.lm_g[0 * nl + L] = g0; B.lm_g[1 * nl + L] = g1; B.lm_g[2 * nl + L] = g2;
+            }
+            // per observation: W = Jp^T Jl, Y = W Einv as one [Y(3x6) | W(3x6)] LDS cell; Y g_l for the reduced rhs
+            auto emit = [&](int o, int f, const double* a, const double* p) {
+                double* cell = cells[buf] + (o - oc0) * LS_CS;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    double w0 = p[i] * a[0] + p[6 + i] * a[3], w1 = p[i] * a[1] + p[6 + i] * a[4], w2 = p[i] * a[2] + p[6 + i] * a[5];
+                    double y0 = w0 * e00 + w1 * e10 + w2 * e20, y1 = w0 * e10 + w1 * e11 + w2 * e21, y2 = w0 * e20 + w1 * e21 + w2 * e22;
+                    B.p_yg[i * n + o] = y0 * g0 + y1 * g1 + y2 * g2;
+                    if (gemm) {
+                        cell[i] = y0; cell[6 + i] = y1; cell[12 + i] = y2;
+                        cell[18 + i] = w0; cell[24 + i] = w1; cell[30 + i] = w2;
+                    }
+                }
+                if (gemm) tbl[buf][grp][f] = (o - oc0) * LS_CS;
+            };
+            if (has && fF >= 0) emit(oF, fF, jl, jp);
+            for (int o = oF + 16; o < o1; o += 16) {
+                int f = B.p_fr[o];
+                if (f < 0) continue;
+                double a[6], p[12];
+#pragma unroll
+                for (int k = 0; k < 6; k++) a[k] = B.p_Jl[k * n + o];
+#pragma unroll
+                for (int k = 0; k < 12; k++) p[k] = B.p_Jp[k * n + o];
+                emit(o, f, a, p);
+            }
+        }
+        if (gemm) __syncthreads();                          // chunk c produced (and chunk c-1 consumed)
+    }
+    if (gemm) __syncthreads();                              // pairs with the consumers' last barrier
 }
 
 // =========================================================================================
@@ -721,136 +866,6 @@ __global__ void __launch_bounds__(NT) k_clique_elim(DevBatch B, DevOpt O) {
 }
 
 // =========================================================================================
-// Landmark part of the reduced camera matrix, P = sum_l Y_l W_l^T, on the fp64 matrix cores.
-// One workgroup per window.  The (landmark, frame) cells are staged through LDS in chunks of
-// whole landmarks (contiguous, each cell read from HBM exactly once); every wave owns a fixed
-// set of 16x16 tiles of the lower triangle of P and issues one v_mfma_f64_16x16x4_f64 per
-// (tile, landmark): the 4 k-slots of the MFMA are the landmark's 3 coordinates (+ one zero).
-// Tiles whose frame range the landmark does not observe are skipped (wave-uniform test on the
-// landmark's frame bit-mask), which removes ~2/3 of the dense work at mean track length K/2.
-// f64 MFMA layouts: A[i][k]: lane = i + 16k; B[k][j]: lane = j + 16k; D: lane l, reg q -> row (l>>4)+4q, col l&15.
-// =========================================================================================
-typedef double double4_t __attribute__((ext_vector_type(4)));
-#define GEMM_LDS_DOUBLES 5760                 // one window's chunk buffer = 2 halves of 2880
-#define GEMM_SPLIT 4                          // fixed landmark split: partial products P_0..P_3, summed in order by k_assemble
-#ifdef SWF_PROFILE_GEMM
-__device__ unsigned long long g_gemm_stamps[16];
-#define GSTAMP_ACC(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_gemm_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
-#define GNOW() __builtin_amdgcn_s_memtime()
-#else
-#define GSTAMP_ACC(i, t0)
-#define GNOW() 0ULL
-#endif
-#ifndef GEMM_OCC
-#define GEMM_OCC 3
-#endif
-template <int NT, int TPW>
-__global__ void __launch_bounds__(NT) k_lm_gemm(DevBatch B) {
-    __shared__ double Ls[2][GEMM_LDS_DOUBLES / 2];
-    __shared__ unsigned long long Ms[2][GEMM_LDS_DOUBLES / 72];
-    int w = blockIdx.x, sp = blockIdx.y;
-    const WinRec& W = B.win[w];
-    if (!B.ws[w].need_lin) return;
-    int nF = W.nF, m = 6 * nF, nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2;
-    if (m == 0) return;
-    int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    constexpr int NW = NT / 64;
-#ifdef SWF_PROFILE_GEMM
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) for (int i = 0; i < 16; i++) g_gemm_stamps[i] = 0;
-#endif
-    unsigned long long tg = GNOW(), tall = tg; (void)tg; (void)tall;
-    int t_tr[TPW], t_tc[TPW], offA[TPW], offB[TPW];
-    unsigned long long mA[TPW], mB[TPW];
-    double4_t acc[TPW];
-#pragma unroll
-    for (int sl = 0; sl < TPW; sl++) {
-        int t = wv + sl * NW;
-        int tr = 0, tc = 0;
-        if (t < ntiles) {
-            tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) / 2.0);
-            while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
-            while (tr * (tr + 1) / 2 > t) tr--;
-            tc = t - tr * (tr + 1) / 2;
-        }
-        t_tr[sl] = tr; t_tc[sl] = tc;
-        int ra = tr * 16 + li, cb = tc * 16 + li;
-        // element (row r, coordinate k) of landmark l sits at cell(l, r/6)[k*6 + r%6]; W is 18 further
-        offA[sl] = (ra < m && lk < 3 && t < ntiles) ? (ra / 6) * 36 + lk * 6 + ra % 6 : -1;
-        offB[sl] = (cb < m && lk < 3 && t < ntiles) ? (cb / 6) * 36 + 18 + lk * 6 + cb % 6 : -1;
-        int f0 = (tr * 16) / 6, f1 = (tr * 16 + 15) / 6; if (f1 > 63) f1 = 63;
-        int g0 = (tc * 16) / 6, g1 = (tc * 16 + 15) / 6; if (g1 > 63) g1 = 63;
-        mA[sl] = (t < ntiles && f0 < 64) ? ((~0ULL >> (63 - f1)) & (~0ULL << f0)) : 0ULL;
-        mB[sl] = (t < ntiles && g0 < 64) ? ((~0ULL >> (63 - g1)) & (~0ULL << g0)) : 0ULL;
-        acc[sl] = double4_t{ 0, 0, 0, 0 };
-    }
-    int row_d = nF * 36;                              // doubles per landmark
-    int LB = (GEMM_LDS_DOUBLES / 2) / row_d;          // landmarks per chunk
-    int nLw = W.lm1 - W.lm0;
-    int per = (nLw + GEMM_SPLIT - 1) / GEMM_SPLIT;
-    int lbeg = sp * per, lend = lbeg + per < nLw ? lbeg + per : nLw;
-    const double* src = B.YW + W.YW_base;
-    constexpr int PR = (GEMM_LDS_DOUBLES / 4 + NT - 1) / NT;     // double2 per thread per chunk
-    double2 pre[PR];
-    auto fetch = [&](int l0) {
-        int lb = (lend - l0) < LB ? (lend - l0) : LB;
-        const double2* s2 = (const double2*)(src + (size_t)l0 * row_d);
-#pragma unroll
-        for (int k = 0; k < PR; k++) { int e = tid + k * NT; pre[k] = (e < lb * row_d / 2) ? s2[e] : make_double2(0, 0); }
-    };
-    auto stash = [&](int buf, int l0) {
-        int lb = (lend - l0) < LB ? (lend - l0) : LB;
-        double2* d2 = (double2*)Ls[buf];
-#pragma unroll
-        for (int k = 0; k < PR; k++) { int e = tid + k * NT; if (e < lb * row_d / 2) d2[e] = pre[k]; }
-        for (int e = tid; e < lb; e += NT) Ms[buf][e] = B.lm_fmask[W.lm0 + l0 + e];
-    };
-    GSTAMP_ACC(0, tg); tg = GNOW();
-    int cur = 0;
-    if (lbeg < lend) { fetch(lbeg); stash(0, lbeg); }
-    __syncthreads();
-    GSTAMP_ACC(1, tg);
-    for (int l0 = lbeg; l0 < lend; l0 += LB) {
-        int lb = (lend - l0) < LB ? (lend - l0) : LB;
-        bool more = l0 + LB < lend;
-        tg = GNOW();
-        if (more) fetch(l0 + LB);                       // next chunk's loads fly during the MFMAs
-        GSTAMP_ACC(2, tg); tg = GNOW();
-        // (measured: hoisting/double-buffering the operand reads costs 80 VGPRs and one workgroup of
-        //  occupancy per CU, a net loss in batch mode; the per-tile test + read + MFMA form wins)
-        for (int l = 0; l < lb; l++) {
-            unsigned long long fm = Ms[cur][l];
-            const double* cell = Ls[cur] + l * row_d;
-#pragma unroll
-            for (int sl = 0; sl < TPW; sl++) {
-                if ((fm & mA[sl]) && (fm & mB[sl])) {
-                    double a = offA[sl] >= 0 ? cell[offA[sl]] : 0.0;
-                    double b = offB[sl] >= 0 ? cell[offB[sl]] : 0.0;
-                    acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[sl], 0, 0, 0);
-                }
-            }
-        }
-        GSTAMP_ACC(3, tg); tg = GNOW();
-        if (more) stash(cur ^ 1, l0 + LB);
-        GSTAMP_ACC(4, tg); tg = GNOW();
-        __syncthreads();
-        GSTAMP_ACC(5, tg);
-        cur ^= 1;
-    }
-    double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)sp * m * m;
-#pragma unroll
-    for (int sl = 0; sl < TPW; sl++) {
-        int t = wv + sl * NW;
-        if (t >= ntiles) continue;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int r = t_tr[sl] * 16 + lk + 4 * q, c = t_tc[sl] * 16 + li;
-            if (r < m && c < m) P[(size_t)r * m + c] = acc[sl][q];
-        }
-    }
-    GSTAMP_ACC(6, tall);
-}
-
-// =========================================================================================
 // Per-frame raw sums over the projection observations, level 1 of a two-level FIXED-ORDER
 // reduction.  Observations are landmark-major in memory, so a pose's observations are strided;
 // instead of gathering them (one 64-byte line per 8-byte value, PMC-measured 8x amplification),
@@ -912,9 +927,9 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
 // DIAG = true : one wavefront per diagonal pair (needs wave reductions over the frame's observations)
 // DIAG = false: 16 lanes per off-diagonal pair (four pairs per wavefront; no cross-lane traffic)
 template <bool DIAG>
-__global__ void __launch_bounds__(256) k_assemble(DevBatch B, DevOpt O, int write_S) {
+__device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, int write_S, int bid) {
     constexpr int G = DIAG ? 64 : 16;
-    int gidx = (blockIdx.x * blockDim.x + threadIdx.x) / G, lane = threadIdx.x % G;
+    int gidx = (bid * blockDim.x + threadIdx.x) / G, lane = threadIdx.x % G;
     if (gidx >= (DIAG ? B.n_pd : B.n_po)) return;
     const Pair& Pr = B.pair[(DIAG ? B.pd_idx : B.po_idx)[gidx]];
     const WinState& s = B.ws[Pr.win];

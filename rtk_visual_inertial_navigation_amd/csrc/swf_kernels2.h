@@ -520,12 +520,21 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
     int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int Tc = (n + 15) >> 4, Tr = Tc + 1;
     if (tid == 0) fail = 0;
+#ifdef SWF_PROFILE_CHOL
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 64; i++) g_chol_stamps[i] = 0;
+    unsigned long long tq = 0;
+#endif
+    CHSTAMP(0);
     if (wv == 0) {
         // =============================== pivot wave ===============================
         __syncthreads();                                   // tables / fail initialised
         __syncthreads();                                   // A_0: tile (0,0) published
+        CHSTAMP(3);
         for (int j = 0; j < Tc; j++) {
             double (*D)[17] = Dt[j & 1];
+#ifdef SWF_PROFILE_CHOL
+            tq = __builtin_amdgcn_s_memtime();
+#endif
             // Factor (lane = row: d[c] = A[lane][c]) and invert (lane = column: x[r] = Linv[r][lane]) in ONE
             // sweep.  Column c of L is broadcast once per row c2 > c (v_readlane -> SGPR) and used twice:
             // for the right-looking update of row lanes, and for the running sums sx[c2] += L[c2][c] x[c]
@@ -558,12 +567,27 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
                 for (int r = 0; r < 16; r++) Li[j][r][lane] = x[r];
             }
             if (bad && lane == 0) fail = 1;
+            CHACC(9, tq);
+#ifdef SWF_PROFILE_CHOL
+            tq = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();                               // B_j
+            CHACC(8, tq);
+#ifdef SWF_PROFILE_CHOL
+            tq = __builtin_amdgcn_s_memtime();
+#endif
             if (fail) { if (tid == 0) st.lin_fail = 1; return; }
             __syncthreads();                               // C_j
+            CHACC(10, tq);
+#ifdef SWF_PROFILE_CHOL
+            tq = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();                               // A_{j+1}
+            CHACC(11, tq);
         }
+        CHSTAMP(1);
         __syncthreads();                                   // E: L exported, yv ready, zs cleared
+        CHSTAMP(4);
         // backward solve: small per-column solves
         for (int J = Tc - 1; J >= 0; J--) {
             __syncthreads();                               // P_J: partial sums of column J ready
@@ -581,6 +605,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
             if (lane < 16) zs[16 * J + lane] = z;
             __syncthreads();                               // Q_J
         }
+        CHSTAMP(2);
         return;
     }
     // =============================== tile waves ===============================
@@ -709,9 +734,10 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 // =========================================================================================
 // Back-substitution of the eliminated blocks: y_e = Einv (g_e - H_ef y_f)
 // =========================================================================================
-__global__ void __launch_bounds__(256) k_backsub_lm(DevBatch B) {
-    // 16 lanes per landmark, one observation per lane and round: t = g_l - sum_o W_o^T y_pose(o)
-    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void d_backsub_lm(const DevBatch& B, int bid) {
+    // 16 lanes per landmark, one observation per lane and round:
+    //   t = g_l - sum_o W_o^T y_pose(o),  W_o^T y = Jl_o^T (Jp_o y)   (the Jacobians are read coalesced; W is not stored)
+    int gid = bid * blockDim.x + threadIdx.x;
     int L = gid >> 4, sub = threadIdx.x & 15;
     bool valid = L < B.n_lm;
     int Lc = valid ? L : B.n_lm - 1;
@@ -719,20 +745,20 @@ __global__ void __launch_bounds__(256) k_backsub_lm(DevBatch B) {
     const WinState& s = B.ws[w];
     int loc = B.lm_loc[Lc];
     bool act = valid && s.need_lin && !s.lin_fail && loc >= 0;
-    const WinRec& W = B.win[w];
-    int nl = B.n_lm;
-    const double* cells = B.YW + W.YW_base + (size_t)(Lc - W.lm0) * W.nF * 36;
+    int nl = B.n_lm, n = B.n_proj;
     double t0 = 0, t1 = 0, t2 = 0;
     if (act) for (int o = B.lm_obs0[Lc] + sub; o < B.lm_obs0[Lc + 1]; o += 16) {
-        int f = B.p_fr[o];
-        if (f < 0) continue;
         int lp = B.p_lpose[o];
-        const double* cw = cells + (size_t)f * 36 + 18;          // W(3x6) of this observation
+        if (B.p_fr[o] < 0) continue;
+        double u0 = 0, u1 = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             double yv = B.y[lp + i];
-            t0 -= cw[i] * yv; t1 -= cw[6 + i] * yv; t2 -= cw[12 + i] * yv;
+            u0 += B.p_Jp[i * n + o] * yv; u1 += B.p_Jp[(6 + i) * n + o] * yv;
         }
+        t0 -= B.p_Jl[0 * n + o] * u0 + B.p_Jl[3 * n + o] * u1;
+        t1 -= B.p_Jl[1 * n + o] * u0 + B.p_Jl[4 * n + o] * u1;
+        t2 -= B.p_Jl[2 * n + o] * u0 + B.p_Jl[5 * n + o] * u1;
     }
     t0 = grp16_sum(t0); t1 = grp16_sum(t1); t2 = grp16_sum(t2);
     if (!act || sub != 0) return;
@@ -743,10 +769,10 @@ __global__ void __launch_bounds__(256) k_backsub_lm(DevBatch B) {
     B.y[loc + 1] = e10 * t0 + e11 * t1 + e21 * t2;
     B.y[loc + 2] = e20 * t0 + e21 * t1 + e22 * t2;
 }
-__global__ void __launch_bounds__(256) k_backsub_clique(DevBatch B) {
+__device__ __forceinline__ void d_backsub_clique(const DevBatch& B, int bid) {
     // 16 lanes per clique with an eliminated block (d_e <= 9): lane a forms t_a = g_e[a] - (M_ef y_f)_a,
     // the Einv product gathers the t's with 16-wide shuffles
-    int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15, lane = threadIdx.x & 63;
+    int q = (bid * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15, lane = threadIdx.x & 63;
     bool valid = q < B.n_cle;
     const Clique& C = B.cl[B.cle_idx[valid ? q : B.n_cle - 1]];
     const WinState& s = B.ws[C.win];
@@ -768,6 +794,49 @@ __global__ void __launch_bounds__(256) k_backsub_clique(DevBatch B) {
         if (act && sub < de && b < de) a += E[sub * de + b] * tb;
     }
     if (act && sub < de) B.y[C.e_loc + sub] = a;
+}
+
+
+// =========================================================================================
+// Fused launches.  Kernels that are mutually independent at the same point of the iteration
+// (no LDS, 256 threads) run as segments of ONE grid: the block id selects the segment.  On the
+// single-window latency path this removes ~12 dependent dispatches per iteration; in a batch
+// it lets the small segments fill the tail of the large ones.
+// =========================================================================================
+struct Segs { int e[8]; };     // exclusive end block of segment k (cumulative)
+
+// Jacobian/residual evaluation of the one-lane-per-factor families: projection + scalar GNSS/prior factors
+template <bool JAC>
+__global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
+    int bid = blockIdx.x;
+    if (bid < S.e[0]) d_eval_proj<JAC>(B, bid);
+    else d_eval_scalar<JAC>(B, bid - S.e[0]);
+}
+// after the reduced solve: back-substitution of the eliminated blocks, and |J D^-2 g|^2 for the Cauchy point
+__global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S) {
+    int bid = blockIdx.x;
+    if (bid < S.e[0]) d_backsub_lm(B, bid);
+    else if (bid < S.e[1]) d_backsub_clique(B, bid - S.e[0]);
+    else if (bid < S.e[2]) d_jtimes_proj<0>(B, O, bid - S.e[1]);
+    else if (bid < S.e[3]) d_jtimes_scalar<0>(B, O, bid - S.e[2]);
+    else if (bid < S.e[4]) d_jtimes_imu<0>(B, O, bid - S.e[3]);
+    else d_jtimes_prior<0>(B, O, bid - S.e[4]);
+}
+// after the dogleg step: model cost change J*step, and the candidate residuals of the one-lane families
+__global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs S) {
+    int bid = blockIdx.x;
+    if (bid < S.e[0]) d_jtimes_proj<1>(B, O, bid);
+    else if (bid < S.e[1]) d_jtimes_scalar<1>(B, O, bid - S.e[0]);
+    else if (bid < S.e[2]) d_jtimes_imu<1>(B, O, bid - S.e[1]);
+    else if (bid < S.e[3]) d_jtimes_prior<1>(B, O, bid - S.e[2]);
+    else if (bid < S.e[4]) d_eval_proj<false>(B, bid - S.e[3]);
+    else d_eval_scalar<false>(B, bid - S.e[4]);
+}
+// diagonal + off-diagonal block assembly of the reduced system
+__global__ void __launch_bounds__(256) k_assemble_all(DevBatch B, DevOpt O, int write_S, Segs S) {
+    int bid = blockIdx.x;
+    if (bid < S.e[0]) d_assemble<true>(B, O, write_S, bid);
+    else d_assemble<false>(B, O, write_S, bid - S.e[0]);
 }
 
 // =========================================================================================

@@ -19,8 +19,8 @@ class SwfError(RuntimeError):
     pass
 
 
-K_NAMES = ["total", "eval_proj", "eval_imu", "eval_scalar", "eval_prior", "lm_elim", "clique_elim", "lm_gemm",
-           "assemble", "chol_solve", "backsub", "jtimes", "dogleg", "cand_eval", "decide", "assemble_off"]
+K_NAMES = ["total", "eval_ps", "eval_imu", "frame_sums", "eval_prior", "lm_schur", "clique_elim", "unused7",
+           "assemble", "chol_solve", "post_chol", "post_dogleg", "dogleg", "cand_eval", "decide", "unused"]
 
 
 class TimingC(C.Structure):

@@ -13,3 +13,5 @@ s = list(out)
 print("n_red", bs.dims(0)["n_red"])
 print("factor total ticks", s[1] - s[0], "backward", s[2] - s[1], "(s_memtime ticks; 100 MHz const clock => x10 ns)")
 print("v1: mfma+init / rr: publish+sync", s[8], "| v1: transpose / rr: diag factor+inverse", s[9], "| v1: diag / rr: panel", s[10], "| v1: trsm / rr: trailing", s[11])
+print("rr2: start->A0 (load)", s[3] - s[0], "| factor loop", s[1] - s[3], "| export wait", s[4] - s[1], "| backward", s[2] - s[4])
+print("rr2 sums: pivot factor+inverse", s[9], "| wait B (trailing of others)", s[8], "| B->C (panel)", s[10], "| C->A (lookahead diag)", s[11])
