@@ -540,27 +540,37 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     B.lm_obs0.push_back(D.n_proj);
     PUT(lm_win, B.lm_win); PUT(lm_obs0, B.lm_obs0); PUT(lm_loc, B.lm_loc); PUT(lm_col, B.lm_col); PUT(lm_fmask, B.lm_fmask);
     {
-        // k_lm_schur chunk table: every (window, split) block walks its landmark range in chunks of at most
-        // LPC landmarks and CAP observation cells (one LDS buffer of the kernel)
-        const int LPC = LS_LPC, CAP = LS_CAP;
-        std::vector<int> c0, cl;
+        // k_lm_schur chunk table: every (window, split) block walks its landmark range in chunks of LS_LPC 16-lane
+        // groups and at most LS_CAP observation cells (one LDS buffer).  A landmark takes 1 / 2 / 4 adjacent, aligned
+        // groups (<= 16 / 32 / 64 observations).  Record of (chunk, group): L (-1 = empty), loc, first / end observation
+        // of this group, frame mask lo / hi, table row | G << 8 | first << 16, first LDS cell.
+        std::vector<int> c0, rec;
+        auto new_chunk = [&]() { size_t at = rec.size(); rec.resize(at + (size_t)LS_LPC * 8, 0); for (int g = 0; g < LS_LPC; g++) rec[at + g * 8] = -1; return at; };
         for (auto& W : B.win) {
             int nLw = W.lm1 - W.lm0, per = (nLw + GEMM_SPLIT - 1) / GEMM_SPLIT;
             for (int sp = 0; sp < GEMM_SPLIT; sp++) {
-                c0.push_back((int)cl.size() / 2);
+                c0.push_back((int)(rec.size() / (LS_LPC * 8)));
                 int lbeg = W.lm0 + std::min(sp * per, nLw), lend = W.lm0 + std::min(sp * per + per, nLw);
-                for (int l = lbeg; l < lend;) {
-                    int e = l;
-                    while (e < lend && e - l < LPC && B.lm_obs0[e + 1] - B.lm_obs0[l] <= CAP) e++;
-                    if (e == l) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "landmark with more observations than one LDS chunk holds"); }
-                    cl.push_back(l); cl.push_back(e);
-                    l = e;
+                size_t at = 0; int g = LS_LPC, cells = 0;          // force a new chunk at the first landmark
+                for (int l = lbeg; l < lend; l++) {
+                    int o0 = B.lm_obs0[l], k = B.lm_obs0[l + 1] - o0;
+                    if (k > 64) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "landmark with more than 64 observations"); }
+                    int G = k <= 16 ? 1 : k <= 32 ? 2 : 4;
+                    int ga = (g + G - 1) / G * G;
+                    if (ga + G > LS_LPC || cells + k > LS_CAP) { at = new_chunk(); ga = 0; cells = 0; }
+                    for (int h = 0; h < G; h++) {
+                        int* r = &rec[at + (size_t)(ga + h) * 8];
+                        r[0] = l; r[1] = B.lm_loc[l]; r[2] = o0 + 16 * h; r[3] = std::min(o0 + 16 * h + 16, o0 + k);
+                        r[4] = (int)(unsigned)(B.lm_fmask[l] & 0xffffffffULL); r[5] = (int)(unsigned)(B.lm_fmask[l] >> 32);
+                        r[6] = ga | (G << 8) | ((h == 0 ? 1 : 0) << 16); r[7] = cells + 16 * h;
+                    }
+                    g = ga + G; cells += k;
                 }
             }
         }
-        c0.push_back((int)cl.size() / 2);
-        cl.push_back(0); cl.push_back(0);
-        PUT(sch_c0, c0); PUT(sch_l, cl);
+        c0.push_back((int)(rec.size() / (LS_LPC * 8)));
+        rec.resize(rec.size() + (size_t)LS_LPC * 8 * 2, 0);         // pad: the pipeline never reads past the table, but keep slack
+        PUT(sch_c0, c0); PUT(sch_rec, rec);
     }
     D.n_fr = B.n_fr;
     B.fr_obs0.push_back((int)B.fr_obs.size());
@@ -704,10 +714,11 @@ struct Launcher {
         DevBatch& D = b->D;
         if (D.n_lm) {
             Bracket t(*this, SWF_K_LM_SCHUR);
-            // size-specialised variants: <= 12 tiles (<= 10 frames), <= 36 tiles (<= 21 frames), <= 120 tiles (<= 40 frames)
-            if (b->max_tiles <= 12) hipLaunchKernelGGL(k_lm_schur<1>, dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT), 0, st, D, O, write_S);
-            else if (b->max_tiles <= 36) hipLaunchKernelGGL(k_lm_schur<3>, dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT), 0, st, D, O, write_S);
-            else hipLaunchKernelGGL(k_lm_schur<10>, dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT), 0, st, D, O, write_S);
+            // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames)
+            static const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;     // debugging aid
+            if (b->max_tiles <= 16 && force < 1) hipLaunchKernelGGL((k_lm_schur<8, 2>), dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT(8)), 0, st, D, O, write_S);
+            else if (b->max_tiles <= 40 && force < 2) hipLaunchKernelGGL((k_lm_schur<8, 5>), dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT(8)), 0, st, D, O, write_S);
+            else hipLaunchKernelGGL((k_lm_schur<12, 10>), dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT(12)), 0, st, D, O, write_S);
         }
         {
             Bracket t(*this, SWF_K_CLIQUE_ELIM);

@@ -26,10 +26,11 @@ struct DevOpt {
 
 // 1/sqrt(x): hardware estimate + 3 Newton steps (full fp64 accuracy from any >= 2^-8 estimate)
 __device__ __forceinline__ double rsqrt_nr3(double x) {
+#pragma clang fp contract(off)      // explicit fma only: every inlined copy rounds identically
     double y = __builtin_amdgcn_rsq(x), h = 0.5 * x;
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
+    y = y * __builtin_fma(-(h * y), y, 1.5);
+    y = y * __builtin_fma(-(h * y), y, 1.5);
+    y = y * __builtin_fma(-(h * y), y, 1.5);
     return y;
 }
 __device__ __forceinline__ double grp16_sum(double v) {
@@ -553,7 +554,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define GEMM_SPLIT 4                          // fixed landmark split: partial products P_0..P_3, summed in order by k_assemble
 #ifdef SWF_PROFILE_GEMM
 __device__ unsigned long long g_gemm_stamps[16];
-#define GSTAMP_ACC(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_gemm_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define GSTAMP_ACC(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_gemm_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #define GNOW() __builtin_amdgcn_s_memtime()
 #else
 #define GSTAMP_ACC(i, t0)
@@ -564,14 +565,15 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 #define LS_CS 37                              // LDS cell stride in doubles (36 + 1: conflict-free 16-lane cell writes)
-#define LS_NT 1024                            // 4 producer waves + 12 consumer waves
+#define LS_NPW 4                              // producer waves (one per SIMD); NCW consumer waves follow
+#define LS_NT(NCW) ((LS_NPW + (NCW)) * 64)
 #define LS_LPC 16                             // landmarks per chunk = 16-lane groups of the producer waves
 #define LS_CAP 192                            // observation cells per chunk and buffer (host chunk table honours both)
 #define LS_MAXF 40
-// TPW = tile slots per consumer wave (12 consumer waves): 1 (<= 12 tiles), 3 (<= 36), 10 (<= 120)
-template <int TPW>
-__global__ void __launch_bounds__(LS_NT) k_lm_schur(DevBatch B, DevOpt O, int do_gemm) {
-    constexpr int NPW = 4, NCW = 12;
+// NCW consumer waves with TPW tile slots each: <8,2> (<= 16 tiles), <8,5> (<= 40), <12,10> (<= 120)
+template <int NCW, int TPW>
+__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int do_gemm) {
+    constexpr int NPW = LS_NPW;
     __shared__ double cells[2][(LS_CAP + 1) * LS_CS];      // + one all-zero cell per buffer
     __shared__ int tbl[2][LS_LPC][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
     __shared__ unsigned long long Ms[2][LS_LPC];           // frame mask of the chunk's landmarks (0 = none / constant landmark)
@@ -615,32 +617,41 @@ __global__ void __launch_bounds__(LS_NT) k_lm_schur(DevBatch B, DevOpt O, int do
             mB[sl] = (t < ntiles && g0 < 64) ? ((~0ULL >> (63 - g1)) & (~0ULL << g0)) : 0ULL;
             acc[sl] = double4_t{ 0, 0, 0, 0 };
         }
+        unsigned long long tg = GNOW(); (void)tg;
         __syncthreads();                                    // chunk c0 produced
+        if (cw == 0) GSTAMP_ACC(8, tg);
         for (int c = c0; c < c1; c++) {
             int buf = (c - c0) & 1;
-            int nlc = B.sch_l[2 * c + 1] - B.sch_l[2 * c];
-            // lane j keeps landmark j's mask; v_readlane broadcasts it into SGPRs, so tile skipping is scalar
+            tg = GNOW();
+            // lane j tests row j's frame mask against each tile slot; the ballot is the slot's hit list over the
+            // chunk's rows (wave-uniform).  Each slot then walks only its hits, in row order, software-pipelined:
+            // the table reads of the next hit are issued before the MFMA of the current one.
             unsigned long long fm_r = Ms[buf][lane & (LS_LPC - 1)];
             const double* cb = cells[buf];
-            for (int l = 0; l < nlc; l++) {
-                unsigned long long fm = readlane_u64(fm_r, l);
-                const int* trow = tbl[buf][l];
-                bool hit[TPW];
-                int ia[TPW], ib[TPW];
-                double av[TPW], bv[TPW];
+            const int* tb = &tbl[buf][0][0];
 #pragma unroll
-                for (int sl = 0; sl < TPW; sl++) {
-                    hit[sl] = (fm & mA[sl]) && (fm & mB[sl]);
-                    if (hit[sl]) { ia[sl] = trow[fA[sl]]; ib[sl] = trow[fB[sl]]; }
+            for (int sl = 0; sl < TPW; sl++) {
+                unsigned hits = (unsigned)__ballot((fm_r & mA[sl]) && (fm_r & mB[sl])) & ((1u << LS_LPC) - 1u);
+                if (!hits) continue;
+                int l = __builtin_ctz(hits); hits &= hits - 1;
+                int ia = tb[l * (LS_MAXF + 1) + fA[sl]], ib = tb[l * (LS_MAXF + 1) + fB[sl]];
+                double4_t c_ = acc[sl];
+                while (true) {
+                    double av = cb[ia + subA[sl]], bv = cb[ib + subB[sl]];
+                    bool more = hits != 0;
+                    if (more) {
+                        l = __builtin_ctz(hits); hits &= hits - 1;
+                        ia = tb[l * (LS_MAXF + 1) + fA[sl]]; ib = tb[l * (LS_MAXF + 1) + fB[sl]];
+                    }
+                    c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c_, 0, 0, 0);
+                    if (!more) break;
                 }
-#pragma unroll
-                for (int sl = 0; sl < TPW; sl++)
-                    if (hit[sl]) { av[sl] = cb[ia[sl] + subA[sl]]; bv[sl] = cb[ib[sl] + subB[sl]]; }
-#pragma unroll
-                for (int sl = 0; sl < TPW; sl++)
-                    if (hit[sl]) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sl], bv[sl], acc[sl], 0, 0, 0);
+                acc[sl] = c_;
             }
+            if (cw == 0) GSTAMP_ACC(9, tg);
+            tg = GNOW();
             __syncthreads();                                // chunk c consumed, chunk c+1 produced
+            if (cw == 0) GSTAMP_ACC(10, tg);
         }
         double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)sp * m * m;
 #pragma unroll
@@ -656,114 +667,143 @@ __global__ void __launch_bounds__(LS_NT) k_lm_schur(DevBatch B, DevOpt O, int do
         return;
     }
     // =========================== producer waves: eliminate the landmarks, chunk by chunk ===========================
+    // One 16-lane group per landmark (tracks of 17..32 / 33..64 observations take 2 / 4 adjacent groups and
+    // merge their sums with one / two more butterfly steps).  The host-built record of (chunk, group) makes
+    // the addressing one level deep, and the loads run as a 3-stage software pipeline: records two chunks
+    // ahead, Jl / r / frame one chunk ahead, Jp at the start of the chunk (it lands during sums + inverse).
+    {
+    // The arithmetic below is written with explicit fma() under contract(off): the kernel is instantiated per TPW,
+    // and a window must get bit-identical cells whichever instantiation its batch selects.
+#pragma clang fp contract(off)
     int grp = tid >> 4, sub = tid & 15;
     int n = B.n_proj, nl = B.n_lm;
     double mu = s.mu;
+#ifdef SWF_PROFILE_GEMM
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) for (int i = 0; i < 16; i++) g_gemm_stamps[i] = 0;
+#endif
+    unsigned long long tg = GNOW(), tall = tg; (void)tg; (void)tall;
     if (gemm) for (int e = tid; e < 2 * LS_CS; e += NPW * 64) cells[e / LS_CS][ZOFF + e % LS_CS] = 0.0;
+    struct Rec { int L, loc, o0, o1; unsigned fm_lo, fm_hi; int info, cell0; };   // info = row | G << 8 | first << 16
+    auto load_rec = [&](int c) {
+        Rec r; r.L = -1; r.loc = -1; r.o0 = r.o1 = 0; r.fm_lo = r.fm_hi = 0; r.info = 0; r.cell0 = 0;
+        if (c < c1) {
+            const int4* q = (const int4*)(B.sch_rec + ((size_t)c * LS_LPC + grp) * 8);
+            int4 a = q[0], b = q[1];
+            r.L = a.x; r.loc = a.y; r.o0 = a.z; r.o1 = a.w; r.fm_lo = (unsigned)b.x; r.fm_hi = (unsigned)b.y; r.info = b.z; r.cell0 = b.w;
+        }
+        return r;
+    };
+    struct Pre { double jl[6], rr[2]; int f; };
+    auto load_pre = [&](const Rec& r) {
+        Pre p;
+#pragma unroll
+        for (int k = 0; k < 6; k++) p.jl[k] = 0.0;
+        p.rr[0] = p.rr[1] = 0.0; p.f = -1;
+        int o = r.o0 + sub;
+        if (r.L >= 0 && r.loc >= 0 && o < r.o1) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) p.jl[k] = B.p_Jl[k * n + o];
+            p.rr[0] = B.p_r[o]; p.rr[1] = B.p_r[n + o];
+            p.f = B.p_fr[o];
+        }
+        return p;
+    };
+    Rec rc = load_rec(c0);
+    Pre pc = load_pre(rc);
+    Rec rn = load_rec(c0 + 1);
     for (int c = c0; c < c1; c++) {
         int buf = (c - c0) & 1;
-        int l0 = B.sch_l[2 * c], l1 = B.sch_l[2 * c + 1];
-        int oc0 = B.lm_obs0[l0];
-        int L = l0 + grp;
-        bool valid = L < l1;
-        int Lc = valid ? L : l0;
-        int loc = B.lm_loc[Lc];
-        bool act = valid && loc >= 0;
-        int o0 = B.lm_obs0[Lc], o1 = B.lm_obs0[Lc + 1];
-        // every load of the lane's first observation is issued up front (one exposure of the HBM latency);
-        // further rounds (tracks longer than 16 observations) re-load
-        int oF = o0 + sub;
-        bool has = act && oF < o1;
-        double jl[6], rr[2], jp[12];
-        int fF = -1;
+        tg = GNOW();
+        int L = rc.L, loc = rc.loc, o = rc.o0 + sub;
+        bool act = L >= 0 && loc >= 0, has = act && o < rc.o1;
+        int G = (rc.info >> 8) & 255, row = rc.info & 255;
+        bool first = (rc.info >> 16) & 1;
+        double jp[12];
         if (has) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) jl[k] = B.p_Jl[k * n + oF];
-            rr[0] = B.p_r[oF]; rr[1] = B.p_r[n + oF];
-            fF = B.p_fr[oF];
-#pragma unroll
-            for (int k = 0; k < 12; k++) jp[k] = B.p_Jp[k * n + oF];
+            for (int k = 0; k < 12; k++) jp[k] = B.p_Jp[k * n + o];
         }
-        unsigned long long fmL = act ? B.lm_fmask[Lc] : 0ULL;
-        double h00 = 0, h10 = 0, h20 = 0, h11 = 0, h21 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
-        auto accum = [&](const double* a, const double* r) {
-            h00 += a[0] * a[0] + a[3] * a[3]; h10 += a[1] * a[0] + a[4] * a[3]; h20 += a[2] * a[0] + a[5] * a[3];
-            h11 += a[1] * a[1] + a[4] * a[4]; h21 += a[2] * a[1] + a[5] * a[4]; h22 += a[2] * a[2] + a[5] * a[5];
-            g0 += a[0] * r[0] + a[3] * r[1]; g1 += a[1] * r[0] + a[4] * r[1]; g2 += a[2] * r[0] + a[5] * r[1];
+        Pre pn = load_pre(rn);
+        Rec rnn = load_rec(c + 2);
+        const double* a = pc.jl;
+#define FMA2(x0, y0, x1, y1) __builtin_fma(x0, y0, (x1) * (y1))
+#define FMA3(x0, y0, x1, y1, x2, y2) __builtin_fma(x0, y0, __builtin_fma(x1, y1, (x2) * (y2)))
+        double h00 = FMA2(a[0], a[0], a[3], a[3]), h10 = FMA2(a[1], a[0], a[4], a[3]), h20 = FMA2(a[2], a[0], a[5], a[3]);
+        double h11 = FMA2(a[1], a[1], a[4], a[4]), h21 = FMA2(a[2], a[1], a[5], a[4]), h22 = FMA2(a[2], a[2], a[5], a[5]);
+        double g0 = FMA2(a[0], pc.rr[0], a[3], pc.rr[1]), g1 = FMA2(a[1], pc.rr[0], a[4], pc.rr[1]), g2 = FMA2(a[2], pc.rr[0], a[5], pc.rr[1]);
+        auto red = [&](double v) {
+            v = grp16_sum(v);
+            double v2 = v + __shfl_xor(v, 16, 64);
+            v = G >= 2 ? v2 : v;
+            double v4 = v + __shfl_xor(v, 32, 64);
+            return G >= 4 ? v4 : v;
         };
-        if (has) accum(jl, rr);
-        if (act) for (int o = oF + 16; o < o1; o += 16) {
-            double a[6], r[2];
-#pragma unroll
-            for (int k = 0; k < 6; k++) a[k] = B.p_Jl[k * n + o];
-            r[0] = B.p_r[o]; r[1] = B.p_r[n + o];
-            accum(a, r);
-        }
-        h00 = grp16_sum(h00); h10 = grp16_sum(h10); h20 = grp16_sum(h20); h11 = grp16_sum(h11); h21 = grp16_sum(h21); h22 = grp16_sum(h22);
-        g0 = grp16_sum(g0); g1 = grp16_sum(g1); g2 = grp16_sum(g2);
+        h00 = red(h00); h10 = red(h10); h20 = red(h20); h11 = red(h11); h21 = red(h21); h22 = red(h22);
+        g0 = red(g0); g1 = red(g1); g2 = red(g2);
+        if (wv == 0) GSTAMP_ACC(0, tg);
+        tg = GNOW();
         if (gemm) {
-            for (int f = sub; f <= nF; f += 16) tbl[buf][grp][f] = ZOFF;
-            if (sub == 0) Ms[buf][grp] = fmL;
+            if (first || !act) for (int f = sub; f <= nF; f += 16) tbl[buf][grp][f] = ZOFF;
+            if (sub == 0) Ms[buf][grp] = (act && first) ? (((unsigned long long)rc.fm_hi << 32) | rc.fm_lo) : 0ULL;
         }
         if (act) {
-            if (sub == 0) {
+            bool lead = first && sub == 0;
+            if (lead) {
                 B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
                 B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
             }
-            h00 += mu * clampd(h00, O.min_diag, O.max_diag);
-            h11 += mu * clampd(h11, O.min_diag, O.max_diag);
-            h22 += mu * clampd(h22, O.min_diag, O.max_diag);
+            h00 = __builtin_fma(mu, clampd(h00, O.min_diag, O.max_diag), h00);
+            h11 = __builtin_fma(mu, clampd(h11, O.min_diag, O.max_diag), h11);
+            h22 = __builtin_fma(mu, clampd(h22, O.min_diag, O.max_diag), h22);
             // Cholesky inverse of the 3x3 (ceres InvertPSDMatrix), division-free: the reciprocal pivots
             // come from v_rsq_f64 + Newton steps (the IEEE fp64 sqrt/div expansions are instruction-bound)
             double i00 = rsqrt_nr3(h00);
             double l10 = h10 * i00, l20 = h20 * i00;
-            double d11 = h11 - l10 * l10;
+            double d11 = __builtin_fma(-l10, l10, h11);
             double i11 = rsqrt_nr3(d11);
-            double l21 = (h21 - l20 * l10) * i11;
-            double d22 = h22 - l20 * l20 - l21 * l21;
+            double l21 = __builtin_fma(-l20, l10, h21) * i11;
+            double d22 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, h22));
             double i22 = rsqrt_nr3(d22);
             bool bad = !(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0);
-            if (bad) { if (sub == 0) s.lin_fail = 1; i00 = i11 = i22 = 0.0; }
+            if (bad) { if (lead) s.lin_fail = 1; i00 = i11 = i22 = 0.0; }
             double i10 = -l10 * i00 * i11;
             double i21 = -l21 * i11 * i22;
-            double i20 = -(l20 * i00 + l21 * i10) * i22;
-            double e00 = i00 * i00 + i10 * i10 + i20 * i20, e10 = i10 * i11 + i20 * i21, e20 = i20 * i22;
-            double e11 = i11 * i11 + i21 * i21, e21 = i21 * i22, e22 = i22 * i22;
-            if (sub == 0) {
+            double i20 = -FMA2(l20, i00, l21, i10) * i22;
+            double e00 = FMA3(i00, i00, i10, i10, i20, i20), e10 = FMA2(i10, i11, i20, i21), e20 = i20 * i22;
+            double e11 = FMA2(i11, i11, i21, i21), e21 = i21 * i22, e22 = i22 * i22;
+            if (lead) {
                 B.lm_Einv[0 * nl + L] = e00; B.lm_Einv[1 * nl + L] = e10; B.lm_Einv[2 * nl + L] = e20;
                 B.lm_Einv[3 * nl + L] = e11; B.lm_Einv[4 * nl + L] = e21; B.lm_Einv[5 * nl + L] = e22;
                 B.lm_g[0 * nl + L] = g0; B.lm_g[1 * nl + L] = g1; B.lm_g[2 * nl + L] = g2;
             }
             // per observation: W = Jp^T Jl, Y = W Einv as one [Y(3x6) | W(3x6)] LDS cell; Y g_l for the reduced rhs
-            auto emit = [&](int o, int f, const double* a, const double* p) {
-                double* cell = cells[buf] + (o - oc0) * LS_CS;
+            if (has && pc.f >= 0) {
+                int ci = (rc.cell0 + sub) * LS_CS;
+                double* cell = cells[buf] + ci;
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
-                    double w0 = p[i] * a[0] + p[6 + i] * a[3], w1 = p[i] * a[1] + p[6 + i] * a[4], w2 = p[i] * a[2] + p[6 + i] * a[5];
-                    double y0 = w0 * e00 + w1 * e10 + w2 * e20, y1 = w0 * e10 + w1 * e11 + w2 * e21, y2 = w0 * e20 + w1 * e21 + w2 * e22;
-                    B.p_yg[i * n + o] = y0 * g0 + y1 * g1 + y2 * g2;
+                    double w0 = FMA2(jp[i], a[0], jp[6 + i], a[3]), w1 = FMA2(jp[i], a[1], jp[6 + i], a[4]), w2 = FMA2(jp[i], a[2], jp[6 + i], a[5]);
+                    double y0 = FMA3(w0, e00, w1, e10, w2, e20), y1 = FMA3(w0, e10, w1, e11, w2, e21), y2 = FMA3(w0, e20, w1, e21, w2, e22);
+                    B.p_yg[i * n + o] = FMA3(y0, g0, y1, g1, y2, g2);
                     if (gemm) {
                         cell[i] = y0; cell[6 + i] = y1; cell[12 + i] = y2;
                         cell[18 + i] = w0; cell[24 + i] = w1; cell[30 + i] = w2;
                     }
                 }
-                if (gemm) tbl[buf][grp][f] = (o - oc0) * LS_CS;
-            };
-            if (has && fF >= 0) emit(oF, fF, jl, jp);
-            for (int o = oF + 16; o < o1; o += 16) {
-                int f = B.p_fr[o];
-                if (f < 0) continue;
-                double a[6], p[12];
-#pragma unroll
-                for (int k = 0; k < 6; k++) a[k] = B.p_Jl[k * n + o];
-#pragma unroll
-                for (int k = 0; k < 12; k++) p[k] = B.p_Jp[k * n + o];
-                emit(o, f, a, p);
+                if (gemm) tbl[buf][row][pc.f] = ci;
             }
         }
+        if (wv == 0) GSTAMP_ACC(1, tg);
+        tg = GNOW();
         if (gemm) __syncthreads();                          // chunk c produced (and chunk c-1 consumed)
+        if (wv == 0) GSTAMP_ACC(2, tg);
+        rc = rn; pc = pn; rn = rnn;
     }
     if (gemm) __syncthreads();                              // pairs with the consumers' last barrier
+    if (wv == 0) GSTAMP_ACC(6, tall);
+#undef FMA2
+#undef FMA3
+    }
 }
 
 // =========================================================================================

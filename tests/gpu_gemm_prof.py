@@ -12,4 +12,4 @@ for _ in range(3):
 out = (C.c_ulonglong * 16)()
 solver.lib().swf_debug_gemm_stamps(out)
 s = list(out)
-print("windows", B, "| A1 sums (loads+reduce)", s[0], "| A2 inverse", s[1], "| A3 cells (loads+LDS)", s[2], "| sync", s[3], "| B mfma", s[4], "| sync", s[5], "| total", s[6], "(core clock cycles, block 0)")
+print("windows", B, "| producer: loads+sums", s[0], "inverse+cells", s[1], "barrier wait", s[2], "total", s[6], "| consumer wave 0: first wait", s[8], "mfma loops", s[9], "barrier wait", s[10], "(core clock cycles, block 0)")
