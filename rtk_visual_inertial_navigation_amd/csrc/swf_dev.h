@@ -223,11 +223,24 @@ __device__ __forceinline__ void pose_plus(const double* x, const double* d, doub
 }
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// wave-level all-reduce (butterfly: every lane ends with the total; fixed order => deterministic)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// value of lane (i + N) mod 16 of the same 16-lane row, through the DPP row-rotate path (no LDS crossbar).
+// On a value that is already symmetric under the coarser exchanges this equals the xor-N butterfly partner.
+template <int N>
+__device__ __forceinline__ double row_ror(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x120 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x120 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce over the 16 lanes of a row: the butterfly 8, 4, 2, 1 (fixed order => deterministic)
+__device__ __forceinline__ double grp16_sum(double v) {
+    v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
     return v;
+}
+// wave-level all-reduce (butterfly 32, 16, 8, 4, 2, 1: every lane ends with the total)
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64);
+    return grp16_sum(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll

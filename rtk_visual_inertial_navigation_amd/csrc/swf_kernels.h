@@ -33,11 +33,6 @@ __device__ __forceinline__ double rsqrt_nr3(double x) {
     y = y * __builtin_fma(-(h * y), y, 1.5);
     return y;
 }
-__device__ __forceinline__ double grp16_sum(double v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 
 // per-observation record (AoS, 256 B = 4 cache lines), written by k_eval_proj / k_lm_elim:
 //   [0..11] Jp (2x6 row-major)  [12..17] Jl (2x3)  [18..19] r  [20..25] Y g_l  [26..31] pad
@@ -624,8 +619,9 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             int buf = (c - c0) & 1;
             tg = GNOW();
             // lane j tests row j's frame mask against each tile slot; the ballot is the slot's hit list over the
-            // chunk's rows (wave-uniform).  Each slot then walks only its hits, in row order, software-pipelined:
-            // the table reads of the next hit are issued before the MFMA of the current one.
+            // chunk's rows (wave-uniform).  Each slot then walks only its hits, in row order; the table reads of the
+            // next hit are issued before the MFMA of the current one.  (Measured: the loop is instruction-issue
+            // bound at ~25 instructions per hit; deeper software pipelines and a lockstep multi-slot form were slower.)
             unsigned long long fm_r = Ms[buf][lane & (LS_LPC - 1)];
             const double* cb = cells[buf];
             const int* tb = &tbl[buf][0][0];
@@ -731,12 +727,16 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
         double h00 = FMA2(a[0], a[0], a[3], a[3]), h10 = FMA2(a[1], a[0], a[4], a[3]), h20 = FMA2(a[2], a[0], a[5], a[3]);
         double h11 = FMA2(a[1], a[1], a[4], a[4]), h21 = FMA2(a[2], a[1], a[5], a[4]), h22 = FMA2(a[2], a[2], a[5], a[5]);
         double g0 = FMA2(a[0], pc.rr[0], a[3], pc.rr[1]), g1 = FMA2(a[1], pc.rr[0], a[4], pc.rr[1]), g2 = FMA2(a[2], pc.rr[0], a[5], pc.rr[1]);
+        bool wide = __any(G >= 2);                          // some track of this wave spans several groups (rare)
         auto red = [&](double v) {
             v = grp16_sum(v);
-            double v2 = v + __shfl_xor(v, 16, 64);
-            v = G >= 2 ? v2 : v;
-            double v4 = v + __shfl_xor(v, 32, 64);
-            return G >= 4 ? v4 : v;
+            if (wide) {
+                double v2 = v + __shfl_xor(v, 16, 64);
+                v = G >= 2 ? v2 : v;
+                double v4 = v + __shfl_xor(v, 32, 64);
+                v = G >= 4 ? v4 : v;
+            }
+            return v;
         };
         h00 = red(h00); h10 = red(h10); h20 = red(h20); h11 = red(h11); h21 = red(h21); h22 = red(h22);
         g0 = red(g0); g1 = red(g1); g2 = red(g2);
