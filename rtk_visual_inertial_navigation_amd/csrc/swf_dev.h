@@ -223,6 +223,16 @@ __device__ __forceinline__ void pose_plus(const double* x, const double* d, doub
 }
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// 1/sqrt(x) without the IEEE sqrt/div expansions: v_rsq_f64 (measured 2^-24 relative) + 2 Newton steps
+// = 2.2 ulp worst case (a third step gives 1.9; tests/microbench/rsq_f64_accuracy.hip).  Explicit fma under
+// contract(off): every inlined copy rounds identically.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+#pragma clang fp contract(off)
+    double y = __builtin_amdgcn_rsq(x), h = 0.5 * x;
+    y = y * __builtin_fma(-(h * y), y, 1.5);
+    y = y * __builtin_fma(-(h * y), y, 1.5);
+    return y;
+}
 // value of lane (i + N) mod 16 of the same 16-lane row, through the DPP row-rotate path (no LDS crossbar).
 // On a value that is already symmetric under the coarser exchanges this equals the xor-N butterfly partner.
 template <int N>

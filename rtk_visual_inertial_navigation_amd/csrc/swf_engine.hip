@@ -142,7 +142,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     for (int b = 0; b < nb; b++) if (!w->is_const[b] && loc[b] < 0) return fail(SWF_E_INVALID, "ordering: variable block missing from ordering");
     R.n_loc = lo; R.n_e = ne; R.n_red = lo - ne;
     if (R.n_red + 1 > 1024) return fail(SWF_E_UNSUPPORTED, "reduced system larger than 1023");
-    R.S_base = B.S_tot; B.S_tot += (long long)R.n_red * R.n_red;
+    R.S_base = B.S_tot; B.S_tot += (long long)(R.n_red + 1) * R.n_red;      // n x n (lower used) + the reduced rhs as row n
     R.Lt_base = B.Lt_tot; B.Lt_tot += (long long)(R.n_red + 1) * (R.n_red + 1);
     {
         int td = 0;

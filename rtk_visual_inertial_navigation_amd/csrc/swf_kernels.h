@@ -24,15 +24,6 @@ struct DevOpt {
     double r0, max_r, min_r, min_rel_dec, ftol, gtol, ptol, min_mu, max_mu, mu_inc, min_diag, max_diag;
 };
 
-// 1/sqrt(x): hardware estimate + 3 Newton steps (full fp64 accuracy from any >= 2^-8 estimate)
-__device__ __forceinline__ double rsqrt_nr3(double x) {
-#pragma clang fp contract(off)      // explicit fma only: every inlined copy rounds identically
-    double y = __builtin_amdgcn_rsq(x), h = 0.5 * x;
-    y = y * __builtin_fma(-(h * y), y, 1.5);
-    y = y * __builtin_fma(-(h * y), y, 1.5);
-    y = y * __builtin_fma(-(h * y), y, 1.5);
-    return y;
-}
 
 // per-observation record (AoS, 256 B = 4 cache lines), written by k_eval_proj / k_lm_elim:
 //   [0..11] Jp (2x6 row-major)  [12..17] Jl (2x3)  [18..19] r  [20..25] Y g_l  [26..31] pad
@@ -757,13 +748,13 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             h22 = __builtin_fma(mu, clampd(h22, O.min_diag, O.max_diag), h22);
             // Cholesky inverse of the 3x3 (ceres InvertPSDMatrix), division-free: the reciprocal pivots
             // come from v_rsq_f64 + Newton steps (the IEEE fp64 sqrt/div expansions are instruction-bound)
-            double i00 = rsqrt_nr3(h00);
+            double i00 = rsqrt_nr(h00);
             double l10 = h10 * i00, l20 = h20 * i00;
             double d11 = __builtin_fma(-l10, l10, h11);
-            double i11 = rsqrt_nr3(d11);
+            double i11 = rsqrt_nr(d11);
             double l21 = __builtin_fma(-l20, l10, h21) * i11;
             double d22 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, h22));
-            double i22 = rsqrt_nr3(d22);
+            double i22 = rsqrt_nr(d22);
             bool bad = !(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0);
             if (bad) { if (lead) s.lin_fail = 1; i00 = i11 = i22 = 0.0; }
             double i10 = -l10 * i00 * i11;
@@ -1010,7 +1001,9 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
         }
         if (lane < la) {
             B.g[Pr.loc_a + lane] = gi; B.diag[Pr.loc_a + lane] = dg_i;
-            if (write_S) B.rhs[Pr.loc_a + lane] = gi + cs;
+            // the reduced rhs is kept twice: in the local-space vector, and as row n of the window's S storage
+            // (the Cholesky carries it as one more tile row with the same addressing as every other tile)
+            if (write_S) { B.rhs[Pr.loc_a + lane] = gi + cs; S[(size_t)n * n + Pr.ra + lane] = gi + cs; }
         }
     }
     if (!write_S) return;      // final pass: cost + gradient only, keep (S, rhs, L) of the last solve

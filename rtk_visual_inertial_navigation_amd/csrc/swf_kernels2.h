@@ -36,6 +36,23 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
     lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
 }
+// broadcast of lane N of each 16-lane row to the whole row (DPP row_newbcast, gfx90a+)
+__device__ __forceinline__ double row_newbcast_d(double v, int n) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (n) {
+#define NB_CASE(K) case K: lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + K, 0xf, 0xf, false); hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + K, 0xf, 0xf, false); break;
+        NB_CASE(0) NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4) NB_CASE(5) NB_CASE(6) NB_CASE(7)
+        NB_CASE(8) NB_CASE(9) NB_CASE(10) NB_CASE(11) NB_CASE(12) NB_CASE(13) NB_CASE(14) NB_CASE(15)
+#undef NB_CASE
+    }
+    return __hiloint2double(hi, lo);
+}
+// gather: every lane reads v from the lane whose index * 4 is idx_bytes
+__device__ __forceinline__ double bperm_d(double v, int idx_bytes) {
+    int lo = __builtin_amdgcn_ds_bpermute(idx_bytes, __double2loint(v));
+    int hi = __builtin_amdgcn_ds_bpermute(idx_bytes, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 #ifdef SWF_PROFILE_CHOL
 __device__ unsigned long long g_chol_stamps[64];
 #define CHSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -266,14 +283,6 @@ __global__ void __launch_bounds__(NT, NT == 256 ? CH_OCC : 4) k_chol_solve(DevBa
 // L is written row-major (lower) for the export.  The predefined elimination order is untouched:
 // this is the plain dense Cholesky of S in that order, only tiled.
 // =========================================================================================
-__device__ __forceinline__ double rsqrt_nr(double x) {
-    double y = __builtin_amdgcn_rsq(x);                 // v_rsq_f64 estimate
-    double h = 0.5 * x;
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
-    return y;
-}
 template <int RR_NS>
 __global__ void __launch_bounds__(1024) k_chol_rr(DevBatch B) {
     __shared__ double Pn[16][16][17];          // panel of the current column: tile row I -> L_Ij
@@ -535,36 +544,51 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
-            // Factor (lane = row: d[c] = A[lane][c]) and invert (lane = column: x[r] = Linv[r][lane]) in ONE
-            // sweep.  Column c of L is broadcast once per row c2 > c (v_readlane -> SGPR) and used twice:
-            // for the right-looking update of row lanes, and for the running sums sx[c2] += L[c2][c] x[c]
-            // of the forward substitutions — so the inverse adds no dependent chain of its own.
-            double d[16], sx[16];
+            // Factor and invert the 16x16 tile with all 64 lanes: the tile A and the running inverse R (starts as I)
+            // live in the MFMA C-layout (lane (li, lk), reg q <-> row lk+4q, column li; A is kept fully symmetric).
+            // Column c:  ip = 1/sqrt(A_cc);  column c of A reaches every lane of its row by one DPP row_newbcast,
+            // row c of A / R reaches every row by one ds_bpermute;  then, for rows r > c,
+            //   A[r][:] -= A[r][c] A[c][:] / A_cc      (right-looking Cholesky update)
+            //   R[r][:] -= A[r][c] R[c][:] / A_cc      (forward substitution of L X = I, same broadcasts)
+            // and column c of L = A[:][c] ip, row c of X = R[c][:] ip.  The only serial chain per column is
+            // readlane -> rsqrt -> fma; everything else is independent work for the wave's issue slots.
+            double A_[4], R_[4];
 #pragma unroll
-            for (int c = 0; c < 16; c++) { d[c] = (lane < 16 && c <= lane) ? D[lane][c] : 0.0; sx[c] = 0.0; }
+            for (int q = 0; q < 4; q++) { A_[q] = D[lk + 4 * q][li]; R_[q] = (lk + 4 * q == li) ? 1.0 : 0.0; }
             bool bad = false;
-            double x[16];
+            int bidx[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                double dp = readlane_d(d[c], c);
+                const int cq = c >> 2, cr = c & 3;
+                double dp = readlane_d(A_[cq], cr * 16 + c);
                 if (!(dp > 0.0)) bad = true;
                 double ip = rsqrt_nr(dp);
-                d[c] = (lane == c) ? dp * ip : (lane > c ? d[c] * ip : d[c]);
-                // Linv[c][lane]: 1/L_cc on the diagonal, -(sum_k<c L[c][k] Linv[k][lane]) / L_cc left of it
-                double xc = (lane == c) ? ip : (lane < c ? -sx[c] * ip : 0.0);
-                x[c] = xc;
+                double ip2 = ip * ip;
+                double rowA = bperm_d(A_[cq], bidx[cr]);          // A[c][li]
+                double rowR = bperm_d(R_[cq], bidx[cr]);          // R[c][li]
+                double sA = (li > c) ? rowA * ip2 : 0.0;          // columns <= c of A are final (L) already
+                double sR = rowR * ip2;
 #pragma unroll
-                for (int c2 = c + 1; c2 < 16; c2++) {
-                    double l2 = readlane_d(d[c], c2);        // L[c2][c]
-                    if (lane >= c2) d[c2] -= d[c] * l2;
-                    sx[c2] += l2 * xc;
+                for (int q = 0; q < 4; q++) {
+                    double col = row_newbcast_d(A_[q], c);        // A[lk+4q][c]
+                    if (lk + 4 * q > c) {
+                        A_[q] = __builtin_fma(-col, sA, A_[q]);
+                        R_[q] = __builtin_fma(-col, sR, R_[q]);
+                    }
                 }
+                if (li == c) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) A_[q] *= ip;      // column c of L (rows above the diagonal are zeroed at the store)
+                }
+                if (lk == cr) R_[cq] *= ip;                       // row c of X = L^-1
             }
-            if (lane < 16) {
 #pragma unroll
-                for (int c = 0; c < 16; c++) D[lane][c] = (c <= lane) ? d[c] : 0.0;
-#pragma unroll
-                for (int r = 0; r < 16; r++) Li[j][r][lane] = x[r];
+            for (int q = 0; q < 4; q++) {
+                int r = lk + 4 * q;
+                D[r][li] = (li <= r) ? A_[q] : 0.0;
+                Li[j][r][li] = (li <= r) ? R_[q] : 0.0;
             }
             if (bad && lane == 0) fail = 1;
             CHACC(9, tq);
@@ -612,35 +636,46 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
     const double* S = B.S + W.S_base;
     const double* rhs = B.rhs + W.loc_base + W.n_e;
     double* Lrm = B.L + W.Lt_base;
-    if (lane == 0) {
-        int cnt = 0;
-        for (int J = 0; J < Tc; J++)
-            for (int I = J; I < Tr; I++)
-                if (1 + (I + J) % 15 == wv && cnt < 10) { sI_t[wv][cnt] = I; sJ_t[wv][cnt] = J; cnt++; }
-        for (; cnt < 10; cnt++) { sI_t[wv][cnt] = -1; sJ_t[wv][cnt] = -1; }
+    // tile table of this wave, in closed form: wave wv owns the tiles with (I + J) mod 15 == wv - 1.  Column J (one
+    // lane each) has at most two of them: I0 = J + ((wv - 1 - 2J) mod 15) and I0 + 15; slots follow (J, I) order.
+    {
+        if (lane < 10) { sI_t[wv][lane] = -1; sJ_t[wv][lane] = -1; }
+        int k = wv - 1, J = lane;
+        int d = (k - 2 * J) % 15; if (d < 0) d += 15;
+        int I0 = J + d, I1 = I0 + 15;
+        bool c0 = J < Tc && I0 < Tr, c1 = J < Tc && I1 < Tr;
+        unsigned long long m0 = __ballot(c0), m1 = __ballot(c1), lt = (1ULL << lane) - 1ULL;
+        int slot = __popcll(m0 & lt) + __popcll(m1 & lt);
+        if (c0 && slot < 10) { sI_t[wv][slot] = I0; sJ_t[wv][slot] = J; }
+        if (c1 && slot + 1 < 10) { sI_t[wv][slot + 1] = I1; sJ_t[wv][slot + 1] = J; }
     }
     for (int e = tid - 64; e < 256; e += 960) zs[e] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
     int sI[RR_NS], sJ[RR_NS];
     double4_t acc[RR_NS];
+    // all loads of the wave's tiles are issued branch-free (clamped addresses, values selected afterwards):
+    // S is stored lower; diagonal tiles are loaded fully symmetric (the pivot wave needs both triangles);
+    // the extra tile row Tc carries the right-hand side in its first row; padding rows/columns are identity
+#pragma unroll
+    for (int s = 0; s < RR_NS; s++) {                          // wave-uniform: keep the tile coordinates in SGPRs
+        sI[s] = __builtin_amdgcn_readfirstlane(sI_t[wv][s]); sJ[s] = __builtin_amdgcn_readfirstlane(sJ_t[wv][s]);
+    }
 #pragma unroll
     for (int s = 0; s < RR_NS; s++) {
-        sI[s] = sI_t[wv][s]; sJ[s] = sJ_t[wv][s];
-        double4_t v = { 0, 0, 0, 0 };
-        if (sI[s] >= 0) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int r = 16 * sI[s] + lk + 4 * q, c = 16 * sJ[s] + li;
-                double x = 0;
-                if (sI[s] < Tc) {
-                    if (r < n && c < n) x = (c <= r) ? S[(size_t)r * n + c] : 0.0;
-                    else x = (r == c) ? 1.0 : 0.0;
-                } else if (lk + 4 * q == 0) x = (c < n) ? rhs[c] : 0.0;
-                v[q] = x;
-            }
+        for (int q = 0; q < 4; q++) {
+            int I = sI[s], J = sJ[s];
+            int r = 16 * I + lk + 4 * q, c = 16 * J + li;
+            bool rhs_el = I == Tc && lk + 4 * q == 0;                 // row n of the S storage = reduced rhs
+            int rr = rhs_el ? n : r;
+            bool inside = I >= 0 && c < n && (rhs_el || (r < n && (c <= r || I == J)));
+            int rc = rr < n ? rr : (rhs_el ? n : n - 1), cc = c < n ? c : n - 1;
+            if (I < 0) { rc = 0; cc = 0; }
+            int off = (cc > rc) ? cc * n + rc : rc * n + cc;          // 32-bit element offset from the one S base
+            double v = S[off];
+            acc[s][q] = inside ? v : ((I >= 0 && I < Tc && r == c) ? 1.0 : 0.0);
         }
-        acc[s] = v;
     }
     __syncthreads();                                       // tables / fail initialised (pairs with pivot)
 #pragma unroll
