@@ -517,7 +517,6 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
     __shared__ double dinv[16];
     __shared__ double zs[256];
     __shared__ double yv[256];
-    __shared__ double part[16][16];
     __shared__ int sI_t[16][10], sJ_t[16][10];
     __shared__ int fail;
     int w = blockIdx.x;
@@ -572,6 +571,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
                 double sR = rowR * ip2;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
+                    if (4 * q + 3 <= c) continue;                 // every row of this register is final already
                     double col = row_newbcast_d(A_[q], c);        // A[lk+4q][c]
                     if (lk + 4 * q > c) {
                         A_[q] = __builtin_fma(-col, sA, A_[q]);
@@ -612,22 +612,18 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
         CHSTAMP(1);
         __syncthreads();                                   // E: L exported, yv ready, zs cleared
         CHSTAMP(4);
-        // backward solve: small per-column solves
+        // backward solve y = L^-T z, right-looking: yv holds z; once y_J is known the tiles of row J subtract
+        // L_{J,J'}^T y_J from the pending blocks J' < J.  Here: y_J = Linv_JJ^T yv_J on all 64 lanes
+        // (lane (li, lk) sums the rows r = lk + 4q, then two cross-row steps).
         for (int J = Tc - 1; J >= 0; J--) {
-            __syncthreads();                               // P_J: partial sums of column J ready
-            double b = 0;
-            if (lane < 16) {
-                b = yv[16 * J + lane];
-                for (int I = J + 1; I < Tc; I++) b -= part[I][lane];
-            }
-            double z = 0;
+            double p = 0;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                double br = readlane_d(b, r);
-                if (lane < 16 && r >= lane) z += Li[J][r][lane] * br;     // (Linv^T b)_c = sum_{r>=c} Linv[r][c] b_r
-            }
-            if (lane < 16) zs[16 * J + lane] = z;
-            __syncthreads();                               // Q_J
+            for (int q = 0; q < 4; q++) p += Li[J][lk + 4 * q][li] * yv[16 * J + lk + 4 * q];
+            p += __shfl_xor(p, 16, 64);
+            p += __shfl_xor(p, 32, 64);
+            if (lk == 0) zs[16 * J + li] = p;
+            __syncthreads();                               // X_J: y_J published
+            __syncthreads();                               // Y_J: row J applied to the pending blocks
         }
         CHSTAMP(2);
         return;
@@ -748,19 +744,18 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
     }
     __syncthreads();                                       // E
     for (int J = Tc - 1; J >= 0; J--) {
+        __syncthreads();                                   // X_J: y_J published
 #pragma unroll
         for (int s = 0; s < RR_NS; s++) {
-            if (sJ[s] != J || sI[s] <= J || sI[s] >= Tc) continue;
-            int I = sI[s];
+            if (sI[s] != J || sJ[s] >= J) continue;        // tiles (J, J') of row J, J' < J: yv_J' -= L_{J,J'}^T y_J
             double p = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) p += acc[s][q] * zs[16 * I + lk + 4 * q];
+            for (int q = 0; q < 4; q++) p += acc[s][q] * zs[16 * J + lk + 4 * q];
             p += __shfl_xor(p, 16, 64);
             p += __shfl_xor(p, 32, 64);
-            if (lk == 0) part[I][li] = p;
+            if (lk == 0) yv[16 * sJ[s] + li] -= p;
         }
-        __syncthreads();                                   // P_J
-        __syncthreads();                                   // Q_J
+        __syncthreads();                                   // Y_J
     }
     double* y = B.y + W.loc_base + W.n_e;
     for (int e = tid - 64; e < n; e += 960) y[e] = zs[e];
