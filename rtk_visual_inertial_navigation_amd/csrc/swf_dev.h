@@ -223,6 +223,12 @@ __device__ __forceinline__ void pose_plus(const double* x, const double* d, doub
 }
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// broadcast a double from a compile-time-constant lane through SGPRs (v_readlane_b32 x2)
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
 // 1/sqrt(x) without the IEEE sqrt/div expansions: v_rsq_f64 (measured 2^-24 relative) + 2 Newton steps
 // = 2.2 ulp worst case (a third step gives 1.9; tests/microbench/rsq_f64_accuracy.hip).  Explicit fma under
 // contract(off): every inlined copy rounds identically.

@@ -722,9 +722,9 @@ struct Launcher {
         }
         {
             Bracket t(*this, SWF_K_CLIQUE_ELIM);
-            if (D.n_clc[0]) hipLaunchKernelGGL((k_clique_elim<48, 32, 64, 0>), dim3(D.n_clc[0]), dim3(64), 0, st, D, O);
-            if (D.n_clc[1]) hipLaunchKernelGGL((k_clique_elim<32, 48, 256, 1>), dim3(D.n_clc[1]), dim3(256), 0, st, D, O);
-            if (D.n_clc[2]) hipLaunchKernelGGL((k_clique_elim<64, 64, 256, 2>), dim3(D.n_clc[2]), dim3(256), 0, st, D, O);
+            if (D.n_clc[0]) hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, st, D, O);
+            if (D.n_clc[1]) hipLaunchKernelGGL((k_clique_elim<32, 48, 9, 1>), dim3(D.n_clc[1]), dim3(64), 0, st, D, O);
+            if (D.n_clc[2]) hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, st, D, O);
         }
         if (D.n_fsb) { Bracket t(*this, SWF_K_FRAME_SUMS); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
         if (D.n_pd) {
@@ -904,6 +904,14 @@ extern "C" int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, d
 extern "C" int swf_debug_chol_stamps(unsigned long long* out) {
     if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_stamps), 64 * sizeof(unsigned long long)) != hipSuccess) return SWF_E_NODEVICE;
+    return SWF_OK;
+}
+#endif
+
+#ifdef SWF_PROFILE_CLQ
+extern "C" int swf_debug_clq_stamps(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clq_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return SWF_E_NODEVICE;
     return SWF_OK;
 }
 #endif

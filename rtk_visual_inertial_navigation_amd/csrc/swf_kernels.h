@@ -807,93 +807,189 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
 // =========================================================================================
 #define CLQ_MAXD 64
 #define CLQ_MAXR 64
-// size classes (host-assigned): 0 = d_e<=1, <=48 rows, <=32 cols, one wavefront (receiver clocks,
-// dummy, small free groups); 1 = <=32 rows, <=48 cols (speed-bias cliques); 2 = up to 64 x 64
-template <int MAXR, int MAXD, int NT, int CLS>
-__global__ void __launch_bounds__(NT) k_clique_elim(DevBatch B, DevOpt O) {
-    __shared__ double Jc[MAXR][MAXD + 1];           // dense clique Jacobian: rows = residual rows, cols = [e | members]
-    __shared__ double M[MAXD][MAXD + 1];
+#ifdef SWF_PROFILE_CLQ
+__device__ unsigned long long g_clq_stamps[16];
+#define QST(i) do { if (CLS == 1 && blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_clq_stamps[i] += t_ - tq_; tq_ = t_; } } while (0)
+#else
+#define QST(i)
+#endif
+// size classes (host-assigned): 0 = d_e<=1, <=48 rows, <=32 cols (receiver clocks, dummy, small free groups);
+// 1 = <=32 rows, <=48 cols (speed-bias cliques); 2 = up to 64 x 64.
+// ONE WAVEFRONT PER CLIQUE (the kernel is latency-bound: what matters is how many cliques a CU keeps in flight).
+// The wave is synchronous with itself, so the phases need no workgroup barriers, and M_ff is never stored:
+// every lane forms 2x2 blocks of M_ff = J_f^T J_f in registers and applies the Schur correction in place.
+//   lane c:      column c of M_e* = J_e^T J  and  g_c = J_c^T r
+//   lanes < d_e: one row of [M_ee + mu D | I] each, Gauss-Jordan through v_readlane broadcasts of the pivot row
+//   lane j:      column j of T = Einv M_ef
+//   2x2 blocks:  C = M_ff - M_fe T  written straight to HBM
+template <int MAXR, int MAXD, int MAXE, int CLS>
+__global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
+    constexpr int LD = MAXD + 1;
+    __shared__ double Jc[MAXR][LD];                 // dense clique Jacobian: rows = residual rows, cols = [e | members]
+    __shared__ double Me[MAXE][LD];                 // M_e* = J_e^T J (rows of M that belong to e)
+    __shared__ double T[MAXE][LD];                  // Einv M_ef
+    __shared__ double Ei[MAXE][MAXE + 1];           // Einv
     __shared__ double rv[MAXR];
-    __shared__ double gv[MAXD];
-    __shared__ double A[9][19];                     // Gauss-Jordan work [M_ee | I]
-    __shared__ double T[9][MAXD + 1];
-    __shared__ double Eg[9];
-    __shared__ int fail;
+    __shared__ double Eg[MAXE];
+#ifdef SWF_PROFILE_CLQ
+    unsigned long long tq_ = __builtin_amdgcn_s_memtime();
+    if (CLS == 1 && blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < 16; i++) g_clq_stamps[i] = 0;
+#endif
     if ((int)blockIdx.x >= B.n_clc[CLS]) return;
     const Clique& C = B.cl[B.clc_idx[CLS][blockIdx.x]];
     WinState& s = B.ws[C.win];
     if (!s.need_lin) return;
-    int de = C.d_e, df = C.d_f, d = de + df, tid = threadIdx.x, nrow = C.n_rows;
-    for (int e = tid; e < nrow * d; e += blockDim.x) Jc[e / d][e % d] = 0.0;
-    if (tid == 0) fail = 0;
+    int de = C.d_e, df = C.d_f, d = de + df, lane = threadIdx.x, nrow = C.n_rows;
+    for (int e = lane; e < nrow * LD; e += 64) (&Jc[0][0])[e] = 0.0;
     __syncthreads();
-    // gather the factors' Jacobian blocks / residuals into Jc / rv through the host-built lists
-    // (dst, src): every load is independent, two dependent accesses deep (list entry -> value)
-    for (int e = C.gl0 + tid; e < C.gl1; e += blockDim.x) {
-        int dst = B.cg_dst[e];
-        Jc[dst >> 8][dst & 255] = B.g_J[B.cg_src[e]];
+    QST(0);
+    // gather the factors' Jacobian blocks / residuals into Jc / rv through the host-built lists (dst, src):
+    // list entries first, then the values, eight independent chains per lane in flight
+    for (int e0 = C.gl0; e0 < C.gl1; e0 += 8 * 64) {
+        int dst[8], src[8];
+        double val[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int e = e0 + lane + u * 64;
+            bool ok = e < C.gl1;
+            dst[u] = ok ? B.cg_dst[e] : -1; src[u] = ok ? B.cg_src[e] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) val[u] = B.g_J[src[u]];
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (dst[u] >= 0) Jc[dst[u] >> 8][dst[u] & 255] = val[u];
     }
-    for (int e = C.rl0 + tid; e < C.rl1; e += blockDim.x) rv[B.cr_dst[e]] = B.g_r[B.cr_src[e]];
+    for (int e = C.rl0 + lane; e < C.rl1; e += 64) rv[B.cr_dst[e]] = B.g_r[B.cr_src[e]];
     __syncthreads();
-    // M = Jc^T Jc (lower half + mirror), gv = Jc^T r
-    for (int e = tid; e < d * d; e += blockDim.x) {
-        int a = e / d, b = e % d;
-        if (b > a) continue;
-        double acc = 0;
-        for (int k = 0; k < nrow; k++) acc += Jc[k][a] * Jc[k][b];
-        M[a][b] = acc; M[b][a] = acc;
+    QST(1);
+    // lane c < d: column c of M_e* (k-ascending dot products), gradient entry g_c, and the diagonal M_cc
+    double me[MAXE], gc = 0, mcc = 0;
+#pragma unroll
+    for (int a2 = 0; a2 < MAXE; a2++) me[a2] = 0;
+    {
+        int c = lane < d ? lane : 0;
+#pragma unroll 4
+        for (int k = 0; k < nrow; k++) {
+            double x = Jc[k][c];
+            gc += x * rv[k]; mcc += x * x;
+#pragma unroll
+            for (int a2 = 0; a2 < MAXE; a2++) me[a2] += Jc[k][a2] * x;      // (rows a2 >= d_e are computed and dropped)
+        }
     }
-    if (tid < d) { double acc = 0; for (int k = 0; k < nrow; k++) acc += Jc[k][tid] * rv[k]; gv[tid] = acc; }
+    if (lane < d) {
+        // rows >= d_e of Me / Ei / T are kept at zero so the inner loops below need no d_e guards
+#pragma unroll
+        for (int a2 = 0; a2 < MAXE; a2++) Me[a2][lane] = a2 < de ? me[a2] : 0.0;
+        if (lane < de) { B.g[C.e_loc + lane] = gc; B.diag[C.e_loc + lane] = mcc; }
+        else { B.cv_graw[C.v_off + lane - de] = gc; B.cv_dgraw[C.v_off + lane - de] = mcc; }
+    }
     __syncthreads();
-    // raw gradient / diagonal
-    if (tid < de) { B.g[C.e_loc + tid] = gv[tid]; B.diag[C.e_loc + tid] = M[tid][tid]; }
-    if (tid >= de && tid < d) { B.cv_graw[C.v_off + tid - de] = gv[tid]; B.cv_dgraw[C.v_off + tid - de] = M[tid][tid]; }
+    QST(2);
     if (de > 0) {
-        // [M_ee + mu D | I] -> [I | Einv] by Gauss-Jordan (SPD: no pivoting), de*2de threads
-        int gi = tid / (2 * de), gj = tid % (2 * de);
-        bool on = tid < de * 2 * de;
-        if (on) {
-            double v = gj < de ? M[gi][gj] : ((gj - de) == gi ? 1.0 : 0.0);
-            if (gj == gi) v += s.mu * clampd(M[gi][gi], O.min_diag, O.max_diag);
-            A[gi][gj] = v;
+        // [M_ee + mu D | I] -> [I | Einv] by Gauss-Jordan (SPD: no pivoting).  Lane r < d_e keeps row r in registers;
+        // step k broadcasts the pivot row through SGPRs (v_readlane), so there is no LDS traffic and no barrier.
+        double row[2 * MAXE];
+#pragma unroll
+        for (int j = 0; j < MAXE; j++) {
+            double v = (lane < de && j < de) ? Me[lane][j] : 0.0;
+            if (j == lane) v += s.mu * clampd(v, O.min_diag, O.max_diag);
+            row[j] = v; row[MAXE + j] = (j == lane) ? 1.0 : 0.0;
+        }
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < MAXE; k++) {
+            if (k < de) {
+                double piv = readlane_d(row[k], k);
+                if (!(piv > 0.0)) bad = true;
+                // reciprocal by v_rcp_f64 + 2 Newton steps instead of the IEEE division expansion
+                double ip = __builtin_amdgcn_rcp(piv);
+                ip = ip * (2.0 - piv * ip); ip = ip * (2.0 - piv * ip);
+                double aik = row[k];
+#pragma unroll
+                for (int j = 0; j < 2 * MAXE; j++) {
+                    double akj = readlane_d(row[j], k) * ip;
+                    row[j] = (lane == k) ? akj : row[j] - aik * akj;
+                }
+            }
+        }
+        if (bad) { if (lane == 0) s.lin_fail = 1; return; }
+        if (lane < MAXE) {
+#pragma unroll
+            for (int j = 0; j < MAXE; j++) Ei[lane][j] = (lane < de && j < de) ? row[MAXE + j] : 0.0;
         }
         __syncthreads();
-        for (int k = 0; k < de; k++) {
-            double piv = A[k][k], aik = 0, akj = 0;
-            if (on) { aik = A[gi][k]; akj = A[k][gj]; }
-            __syncthreads();
-            if (tid == 0 && !(piv > 0.0)) fail = 1;
-            if (on) A[gi][gj] = (gi == k) ? akj / piv : A[gi][gj] - aik * (akj / piv);
-            __syncthreads();
+        QST(3);
+        // lane j < d_f: column j of T = Einv M_ef; lanes < d_e: Eg = Einv g_e
+        double gE = 0;
+        {
+            // g_e entries sit in lanes < d_e (gc): broadcast them
+            double tcol[MAXE];
+            int j = lane < df ? lane : 0;
+#pragma unroll
+            for (int a2 = 0; a2 < MAXE; a2++) {
+                double sv = 0, sg = 0;
+#pragma unroll
+                for (int b2 = 0; b2 < MAXE; b2++) { double ev = Ei[a2][b2]; sv += ev * Me[b2][de + j]; sg += ev * readlane_d(gc, b2); }
+                tcol[a2] = sv;
+                if (lane == a2) gE = sg;
+            }
+            if (lane < df) {
+#pragma unroll
+                for (int a2 = 0; a2 < MAXE; a2++) T[a2][lane] = tcol[a2];
+            }
+            if (lane < de) Eg[lane] = gE;
         }
-        if (fail) { if (tid == 0) s.lin_fail = 1; return; }
-        // T = Einv * M_ef ; Eg = Einv * g_e
-        for (int e = tid; e < de * df; e += blockDim.x) {
-            int a = e / df, j = e % df;
-            double sv = 0;
-            for (int b = 0; b < de; b++) sv += A[a][de + b] * M[b][de + j];
-            T[a][j] = sv;
-        }
-        if (tid < de) { double sv = 0; for (int b = 0; b < de; b++) sv += A[tid][de + b] * gv[b]; Eg[tid] = sv; }
         __syncthreads();
+        QST(4);
         double* E = B.cE + C.e_off;
-        for (int e = tid; e < de * de; e += blockDim.x) E[e] = A[e / de][de + e % de];
-        for (int e = tid; e < de * df; e += blockDim.x) E[de * de + e] = M[e / df][de + (e % df)];
-        if (tid < de) E[de * de + de * df + tid] = gv[tid];
+        for (int e = lane; e < de * de; e += 64) E[e] = Ei[e / de][e % de];
+        if (lane < df) {
+#pragma unroll
+            for (int a2 = 0; a2 < MAXE; a2++) if (a2 < de) E[de * de + a2 * df + lane] = Me[a2][de + lane];
+        }
+        if (lane < de) E[de * de + de * df + lane] = gc;
+        // cs_j = -(M_fe Eg)_j
+        if (lane < df) {
+            double v = 0;
+#pragma unroll
+            for (int a2 = 0; a2 < MAXE; a2++) v -= Me[a2][de + lane] * (a2 < de ? Eg[a2] : 0.0);
+            B.cv_cs[C.v_off + lane] = v;
+        }
+    } else {
+        if (lane < df) B.cv_cs[C.v_off + lane] = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 < MAXE; a2++) T[a2][lane < LD ? lane : 0] = 0.0;
+        __syncthreads();
     }
+    // C = M_ff - M_fe T in 2x2 blocks of the lower triangle: M_ff block from Jc (k-ascending sums), correction from Me / T
     double* Cm = B.C + C.C_off;
-    for (int e = tid; e < df * df; e += blockDim.x) {
-        int i = e / df, j = e % df;
-        if (j > i) continue;
-        double v = M[de + i][de + j];
-        for (int a = 0; a < de; a++) v -= M[de + i][a] * T[a][j];
-        Cm[i * df + j] = v; Cm[j * df + i] = v;
+    {
+        int nb = (df + 1) >> 1, nblk = nb * (nb + 1) / 2;
+        for (int t = lane; t < nblk; t += 64) {
+            int ba = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+            while ((ba + 1) * (ba + 2) / 2 <= t) ba++;
+            while (ba * (ba + 1) / 2 > t) ba--;
+            int bb = t - ba * (ba + 1) / 2;
+            int i0 = 2 * ba, j0 = 2 * bb;
+            double m00 = 0, m01 = 0, m10 = 0, m11 = 0;
+#pragma unroll 4
+            for (int k = 0; k < nrow; k++) {
+                double xa0 = Jc[k][de + i0], xa1 = Jc[k][de + i0 + 1], xb0 = Jc[k][de + j0], xb1 = Jc[k][de + j0 + 1];
+                m00 += xa0 * xb0; m01 += xa0 * xb1; m10 += xa1 * xb0; m11 += xa1 * xb1;
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < MAXE; a2++) {
+                double f0 = Me[a2][de + i0], f1 = Me[a2][de + i0 + 1], t0 = T[a2][j0], t1 = T[a2][j0 + 1];
+                m00 -= f0 * t0; m01 -= f0 * t1; m10 -= f1 * t0; m11 -= f1 * t1;
+            }
+            bool i1ok = i0 + 1 < df, j1ok = j0 + 1 < df;
+            Cm[i0 * df + j0] = m00; Cm[j0 * df + i0] = m00;
+            if (i1ok) { Cm[(i0 + 1) * df + j0] = m10; Cm[j0 * df + i0 + 1] = m10; }
+            if (ba != bb && j1ok) { Cm[i0 * df + j0 + 1] = m01; Cm[(j0 + 1) * df + i0] = m01; }
+            if (i1ok && j1ok) { Cm[(i0 + 1) * df + j0 + 1] = m11; Cm[(j0 + 1) * df + i0 + 1] = m11; }
+        }
     }
-    if (tid < df) {
-        double v = 0;
-        for (int a = 0; a < de; a++) v -= M[de + tid][a] * Eg[a];
-        B.cv_cs[C.v_off + tid] = v;
-    }
+    QST(5);
 }
 
 // =========================================================================================

@@ -30,12 +30,6 @@
 #ifndef CH_KU
 #define CH_KU 4
 #endif
-// broadcast a double from a compile-time-constant lane through SGPRs (v_readlane_b32 x2)
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
 // broadcast of lane N of each 16-lane row to the whole row (DPP row_newbcast, gfx90a+)
 __device__ __forceinline__ double row_newbcast_d(double v, int n) {
     int lo = __double2loint(v), hi = __double2hiint(v);

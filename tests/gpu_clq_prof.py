@@ -1,0 +1,15 @@
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from rtk_visual_inertial_navigation_amd import synth, solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+ws = bench.make_windows(4, [synth.BASE_SEED + 4 + i for i in range(B)])
+bs = solver.BatchSolver(ws)
+for _ in range(3):
+    bs.reset_state(); bs.solve(default_options(step_mode=1), download=False)
+out = (C.c_ulonglong * 16)()
+solver.lib().swf_debug_clq_stamps(out)
+s = list(out)
+print("windows", B, "| header+zero", s[0], "| gather", s[1], "| M = J^T J", s[2], "| Gauss-Jordan", s[3], "| T, Eg", s[4], "| outputs (C, cs, E)", s[5], "| total", sum(s[:6]), "(cycles, class-1 block 0)")
