@@ -47,6 +47,8 @@ struct GFac {
     int roff;                    // into g_r
     int data;                    // index into the type's data array (record index)
     int clique;                  // owning clique
+    int jld;                     // column stride of this factor's Jacobian blocks in g_J (= rows of the clique's dense column-major matrix)
+    int pad;
 };
 
 // ---- clique: a group-0 block (or none) + the factors touching it + its reduced neighbours
@@ -61,7 +63,8 @@ struct Clique {
     int e_off;                   // d_e*d_e Einv + d_e*d_f strip + d_e g_e   (offset into e-buffer)
     int is_static;               // 1: prior clique, C/dgraw precomputed; only graw changes
     int n_rows;                  // total residual rows of the clique's factors
-    int gl0, gl1, rl0, rl1;      // gather lists: Jacobian entries / residual rows
+    int j_off, r_off;            // the clique's dense column-major Jacobian [d_e + d_f][n_rows] in g_J, and its residual rows in g_r
+    int pad0, pad1;
 };
 
 // ---- reduced block pair (a >= b in elimination order): one wave assembles S[a,b] --------
@@ -110,7 +113,7 @@ struct DevBatch {
     // generic factors
     int n_gf;
     const GFac* gf;
-    const int* s_x; const int* s_loc; const int* s_ls; const int* s_joff; const int* s_ccol;
+    const int* s_x; const int* s_loc; const int* s_ls; const int* s_joff; const int* s_ccol;   // per slot: Jacobian block offset in g_J (column stride: GFac.jld)
     double* g_r; double* g_J; double* g_cost; double* g_aux;
     const double* imu_pre; const double* cp_dat; const double* pr_dat; const double* dop_dat; const double* sp_w;
     int n_imu; const int* imu_gf;              // generic-factor ids by kernel
@@ -126,7 +129,6 @@ struct DevBatch {
     const int* cm_loc; const int* cm_ls; const int* cm_col;
     double* C; double* cv_graw; double* cv_dgraw; double* cv_cs; double* cE;
     int n_clc[3]; const int* clc_idx[3];       // non-static cliques by size class
-    const int* cg_dst; const int* cg_src; const int* cr_dst; const int* cr_src;   // clique gather lists
     int n_cle; const int* cle_idx;             // cliques with an eliminated block (back-substitution)
     // pairs
     int n_pair;

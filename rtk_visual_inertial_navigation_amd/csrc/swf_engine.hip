@@ -102,7 +102,7 @@ struct Build {
     std::vector<long long> prior_Joff;
     std::vector<double> prior_J, prior_r0, prior_x0;
     std::vector<Clique> cl;
-    std::vector<int> cl_fac, cl_frow, cm_loc, cm_ls, cm_col, cg_dst, cg_src, cr_dst, cr_src;
+    std::vector<int> cl_fac, cl_frow, cm_loc, cm_ls, cm_col;
     std::vector<double> C_init, dgraw_init;      // static parts (prior cliques)
     std::vector<Pair> pair;
     std::vector<long long> pc_coff;
@@ -262,12 +262,11 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     auto add_gf = [&](int type, int nres, int data, const std::vector<int>& blks) {
         GFac G{};
         G.type = type; G.win = wi; G.nres = nres; G.nslot = (int)blks.size();
-        G.slot0 = (int)B.s_x.size(); G.roff = B.r_tot; G.data = data; G.clique = -1;
-        B.r_tot += nres;
+        G.slot0 = (int)B.s_x.size(); G.roff = -1; G.data = data; G.clique = -1;
         for (int b : blks) {
             B.s_x.push_back(gx(b)); B.s_loc.push_back(gloc(b)); B.s_ls.push_back(ls[b]);
-            if (loc[b] >= 0 && type != GF_PRIOR) { B.s_joff.push_back(B.j_tot); B.j_tot += nres * ls[b]; }
-            else B.s_joff.push_back(-1);
+            // Jacobian block placement (s_joff, s_jld) and the residual offset are assigned with the cliques below
+            B.s_joff.push_back((loc[b] >= 0 && type != GF_PRIOR) ? 0 : -1);
             B.s_ccol.push_back(-1);
         }
         B.gf.push_back(G);
@@ -416,24 +415,26 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
                 B.s_ccol[B.gf[f].slot0 + sl] = cc;
             }
         }
-        // gather lists for the dense clique Jacobian (row, column) <- g_J, and residual rows <- g_r
-        C.gl0 = (int)B.cg_dst.size(); C.rl0 = (int)B.cr_dst.size();
-        if (!t.is_static) {
-            int frow = 0;
+        // storage: a non-static clique owns a dense column-major Jacobian [d][n_rows] in g_J (each factor's blocks sit at
+        // their (row, column) position, column stride n_rows) and contiguous residual rows in g_r; factors of static cliques
+        // only need residual rows
+        C.r_off = B.r_tot; B.r_tot += nrows;
+        C.j_off = B.j_tot;
+        {
+            int dcl = C.d_e + df, frow = 0;
             for (int f : t.facs) {
-                const GFac& G = B.gf[f];
-                for (int k = 0; k < G.nres; k++) { B.cr_dst.push_back(frow + k); B.cr_src.push_back(G.roff + k); }
+                GFac& G = B.gf[f];
+                G.roff = C.r_off + frow; G.jld = nrows;
                 for (int sl = 0; sl < G.nslot; sl++) {
-                    int cc = B.s_ccol[G.slot0 + sl], jo = B.s_joff[G.slot0 + sl], l = B.s_ls[G.slot0 + sl];
-                    if (cc < 0 || jo < 0) continue;
-                    for (int k = 0; k < G.nres; k++) for (int j = 0; j < l; j++) {
-                        B.cg_dst.push_back(((frow + k) << 8) | (cc + j)); B.cg_src.push_back(jo + k * l + j);
-                    }
+                    int cc = B.s_ccol[G.slot0 + sl];
+                    if (B.s_joff[G.slot0 + sl] < 0) continue;
+                    if (t.is_static || cc < 0) { B.s_joff[G.slot0 + sl] = -1; continue; }
+                    B.s_joff[G.slot0 + sl] = C.j_off + cc * nrows + frow;
                 }
                 frow += G.nres;
             }
+            if (!t.is_static) B.j_tot += nrows * dcl;
         }
-        C.gl1 = (int)B.cg_dst.size(); C.rl1 = (int)B.cr_dst.size();
         // static prior clique: C = J^T J over member columns, dgraw = diag
         B.C_init.resize((size_t)B.C_tot, 0.0);
         B.dgraw_init.resize((size_t)B.v_tot, 0.0);
@@ -468,6 +469,8 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         B.cl.push_back(C);
     }
     R.cl1 = (int)B.cl.size();
+    // factors outside every clique (all blocks constant) still own residual rows (cost only)
+    for (int f = R.gf0; f < R.gf1; f++) if (B.gf[f].roff < 0) { B.gf[f].roff = B.r_tot; B.r_tot += B.gf[f].nres; }
 
     // ---- pairs: clique pairs, all frame pairs, a diagonal pair for every reduced block
     for (int p = 0; p < nP; p++) if (frame_of[p] >= 0)
@@ -588,7 +591,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     PUT(prior_dim, B.prior_dim); PUT(prior_Joff, B.prior_Joff); PUT(prior_roff, B.prior_roff); PUT(prior_x0off, B.prior_x0off);
     PUT(prior_J, B.prior_J); PUT(prior_r0, B.prior_r0); PUT(prior_x0, B.prior_x0);
     D.n_cl = (int)B.cl.size();
-    PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cl_frow, B.cl_frow); PUT(cg_dst, B.cg_dst); PUT(cg_src, B.cg_src); PUT(cr_dst, B.cr_dst); PUT(cr_src, B.cr_src); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
+    PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cl_frow, B.cl_frow); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
     D.n_pair = (int)B.pair.size();
     PUT(pair, B.pair); PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
     {

@@ -263,15 +263,23 @@ __global__ void __launch_bounds__(IMU_FPB * 16) k_eval_imu(DevBatch B) {
     double c = grp16_sum((act && sub < 15) ? rk * rk : 0.0);
     if (act && sub == 0) B.g_cost[f] = 0.5 * c;
     if (!JAC || !act) return;
-    const int cb[4] = { 0, 6, 15, 21 }, ls[4] = { 6, 9, 6, 9 };
+    const int cb[4] = { 0, 6, 15, 21 };
+    // whitened Jacobian SI * U, computed row-major (uniform trip counts, broadcast SI reads) and written back in place:
+    // entry (row, col) needs U[k >= row][col] only, and rows are finished in order, so the overwrite is safe
     for (int e = sub; e < 450; e += 16) {
-        int row = e / 30, col = e % 30;
-        int sl = col < 6 ? 0 : col < 15 ? 1 : col < 21 ? 2 : 3;
-        int jo = B.s_joff[G.slot0 + sl];
-        if (jo < 0) continue;
+        int row = e / 30, col = e - row * 30;
         double a = 0;
         for (int k = row; k < 15; k++) a += SI[fl][row * 15 + k] * U[fl][k * 30 + col];   // SI is upper triangular
-        B.g_J[jo + row * ls[sl] + (col - cb[sl])] = a;
+        U[fl][e] = a;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // the clique's dense Jacobian is column-major in HBM: lanes run over the rows of one column (coalesced stores)
+    for (int e = sub; e < 450; e += 16) {
+        int col = e / 15, row = e - col * 15;
+        int sl = col < 6 ? 0 : col < 15 ? 1 : col < 21 ? 2 : 3;
+        int jo = B.s_joff[G.slot0 + sl];
+        if (jo >= 0) B.g_J[jo + (col - cb[sl]) * G.jld + row] = U[fl][row * 30 + col];
     }
 }
 
@@ -305,7 +313,7 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
     if (JAC ? !s.need_lin : !s.eval_cand) return;
     const WinRec& W = B.win[G.win];
     const double* xs = JAC ? B.x : B.xc;
-    int s0 = G.slot0;
+    int s0 = G.slot0, ld = G.jld;          // column stride of the clique's dense column-major Jacobian
     double r;
     if (G.type == GF_CP) {
         const double* dat = B.cp_dat + (size_t)G.data * SWF_CP_DOUBLES;
@@ -318,7 +326,7 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
         r = wgt * (r1 - amb * dat[4] - dat[3] + clk);
         if (JAC) {
             int jo = B.s_joff[s0];
-            if (jo >= 0) { B.g_J[jo] = wgt * e[0]; B.g_J[jo + 1] = wgt * e[1]; B.g_J[jo + 2] = wgt * e[2]; B.g_J[jo + 3] = 0; B.g_J[jo + 4] = 0; B.g_J[jo + 5] = 0; }
+            if (jo >= 0) { B.g_J[jo] = wgt * e[0]; B.g_J[jo + 1 * ld] = wgt * e[1]; B.g_J[jo + 2 * ld] = wgt * e[2]; B.g_J[jo + 3 * ld] = 0; B.g_J[jo + 4 * ld] = 0; B.g_J[jo + 5 * ld] = 0; }
             jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = -wgt * dat[4];
             jo = B.s_joff[s0 + 2]; if (jo >= 0) B.g_J[jo] = wgt;
         }
@@ -332,7 +340,7 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
         r = wgt * (r1 - dat[3] + clk);
         if (JAC) {
             int jo = B.s_joff[s0];
-            if (jo >= 0) { B.g_J[jo] = wgt * e[0]; B.g_J[jo + 1] = wgt * e[1]; B.g_J[jo + 2] = wgt * e[2]; B.g_J[jo + 3] = 0; B.g_J[jo + 4] = 0; B.g_J[jo + 5] = 0; }
+            if (jo >= 0) { B.g_J[jo] = wgt * e[0]; B.g_J[jo + 1 * ld] = wgt * e[1]; B.g_J[jo + 2 * ld] = wgt * e[2]; B.g_J[jo + 3 * ld] = 0; B.g_J[jo + 4 * ld] = 0; B.g_J[jo + 5 * ld] = 0; }
             jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = wgt;
         }
     } else if (G.type == GF_DOP) {
@@ -351,10 +359,10 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
         r = istd * (rate + drift + dat[6]);
         if (JAC) {
             int jo = B.s_joff[s0];
-            if (jo >= 0) { for (int k = 0; k < 9; k++) B.g_J[jo + k] = 0; B.g_J[jo] = istd * e[0]; B.g_J[jo + 1] = istd * e[1]; B.g_J[jo + 2] = istd * e[2]; }
+            if (jo >= 0) { for (int k = 0; k < 9; k++) B.g_J[jo + k * ld] = 0; B.g_J[jo] = istd * e[0]; B.g_J[jo + 1 * ld] = istd * e[1]; B.g_J[jo + 2 * ld] = istd * e[2]; }
             jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = istd;
             jo = B.s_joff[s0 + 2];
-            if (jo >= 0) { for (int k = 0; k < 3; k++) { B.g_J[jo + k] = istd * (ev[k] - ee * e[k]) / rr; B.g_J[jo + 3 + k] = 0; } }
+            if (jo >= 0) { for (int k = 0; k < 3; k++) { B.g_J[jo + k * ld] = istd * (ev[k] - ee * e[k]) / rr; B.g_J[jo + (3 + k) * ld] = 0; } }
         }
     } else {   // GF_SP
         double wv = B.sp_w[G.data];
@@ -468,8 +476,8 @@ __device__ __forceinline__ double gf_row_dot(const DevBatch& B, const DevOpt& O,
             int jo = B.s_joff[G.slot0 + t];
             if (jo < 0) continue;
             int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
-            const double* row = B.g_J + jo + k * l;
-            for (int j = 0; j < l; j++) a += row[j] * vec_at<MODE>(B, O, lo + j);
+            const double* col0 = B.g_J + jo + k;                 // element (k, j) of the block: column stride G.jld
+            for (int j = 0; j < l; j++) a += col0[j * G.jld] * vec_at<MODE>(B, O, lo + j);
         }
     }
     return a;
@@ -840,26 +848,29 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
     WinState& s = B.ws[C.win];
     if (!s.need_lin) return;
     int de = C.d_e, df = C.d_f, d = de + df, lane = threadIdx.x, nrow = C.n_rows;
-    for (int e = lane; e < nrow * LD; e += 64) (&Jc[0][0])[e] = 0.0;
-    __syncthreads();
     QST(0);
-    // gather the factors' Jacobian blocks / residuals into Jc / rv through the host-built lists (dst, src):
-    // list entries first, then the values, eight independent chains per lane in flight
-    for (int e0 = C.gl0; e0 < C.gl1; e0 += 8 * 64) {
-        int dst[8], src[8];
-        double val[8];
+    // the clique's Jacobian is dense and column-major in HBM (the factor kernels write their blocks at their (row, column)
+    // position; the structural zeros are static): no gather lists, no indirection
+    {
+        const double* gJ = B.g_J + C.j_off;
+        int tot = nrow * d;
+        float rd = 1.0f / (float)nrow;
+        if (lane < nrow) rv[lane] = B.g_r[C.r_off + lane];
+        for (int k = lane; k < nrow; k += 64) Jc[k][d] = 0.0;                      // zero pad column (odd d, 2x2 blocks)
+        // flat, fully coalesced loads, all issued before the first use (one exposed round trip per 24 values)
+        for (int base = 0; base < tot; base += 24 * 64) {
+            double v[24];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            int e = e0 + lane + u * 64;
-            bool ok = e < C.gl1;
-            dst[u] = ok ? B.cg_dst[e] : -1; src[u] = ok ? B.cg_src[e] : 0;
+            for (int u = 0; u < 24; u++) { int e = base + u * 64 + lane; v[u] = e < tot ? gJ[e] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 24; u++) {
+                int e = base + u * 64 + lane;
+                int col = (int)((e + 0.5f) * rd);                                    // exact floor(e / nrow) for e < 4096, nrow <= 64
+                col += (e - col * nrow >= nrow) ? 1 : 0; col -= (e - col * nrow < 0) ? 1 : 0;   // (belt and braces)
+                if (e < tot) Jc[e - col * nrow][col] = v[u];
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) val[u] = B.g_J[src[u]];
-#pragma unroll
-        for (int u = 0; u < 8; u++) if (dst[u] >= 0) Jc[dst[u] >> 8][dst[u] & 255] = val[u];
     }
-    for (int e = C.rl0 + lane; e < C.rl1; e += 64) rv[B.cr_dst[e]] = B.g_r[B.cr_src[e]];
     __syncthreads();
     QST(1);
     // lane c < d: column c of M_e* (k-ascending dot products), gradient entry g_c, and the diagonal M_cc
@@ -964,29 +975,49 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
     // C = M_ff - M_fe T in 2x2 blocks of the lower triangle: M_ff block from Jc (k-ascending sums), correction from Me / T
     double* Cm = B.C + C.C_off;
     {
+        // two blocks per lane and pass (eight independent accumulators keep the LDS pipe busy)
         int nb = (df + 1) >> 1, nblk = nb * (nb + 1) / 2;
-        for (int t = lane; t < nblk; t += 64) {
-            int ba = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
-            while ((ba + 1) * (ba + 2) / 2 <= t) ba++;
-            while (ba * (ba + 1) / 2 > t) ba--;
-            int bb = t - ba * (ba + 1) / 2;
-            int i0 = 2 * ba, j0 = 2 * bb;
-            double m00 = 0, m01 = 0, m10 = 0, m11 = 0;
+        for (int t0 = lane; t0 < nblk; t0 += 128) {
+            int i0[2], j0[2];
+            bool diag[2], on[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                int t = t0 + 64 * u;
+                on[u] = t < nblk;
+                if (!on[u]) t = 0;
+                int ba = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+                while ((ba + 1) * (ba + 2) / 2 <= t) ba++;
+                while (ba * (ba + 1) / 2 > t) ba--;
+                int bb = t - ba * (ba + 1) / 2;
+                i0[u] = 2 * ba; j0[u] = 2 * bb; diag[u] = ba == bb;
+            }
+            double m[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
 #pragma unroll 4
             for (int k = 0; k < nrow; k++) {
-                double xa0 = Jc[k][de + i0], xa1 = Jc[k][de + i0 + 1], xb0 = Jc[k][de + j0], xb1 = Jc[k][de + j0 + 1];
-                m00 += xa0 * xb0; m01 += xa0 * xb1; m10 += xa1 * xb0; m11 += xa1 * xb1;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    double xa0 = Jc[k][de + i0[u]], xa1 = Jc[k][de + i0[u] + 1], xb0 = Jc[k][de + j0[u]], xb1 = Jc[k][de + j0[u] + 1];
+                    m[u][0] += xa0 * xb0; m[u][1] += xa0 * xb1; m[u][2] += xa1 * xb0; m[u][3] += xa1 * xb1;
+                }
             }
 #pragma unroll
             for (int a2 = 0; a2 < MAXE; a2++) {
-                double f0 = Me[a2][de + i0], f1 = Me[a2][de + i0 + 1], t0 = T[a2][j0], t1 = T[a2][j0 + 1];
-                m00 -= f0 * t0; m01 -= f0 * t1; m10 -= f1 * t0; m11 -= f1 * t1;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    double f0 = Me[a2][de + i0[u]], f1 = Me[a2][de + i0[u] + 1], t0_ = T[a2][j0[u]], t1_ = T[a2][j0[u] + 1];
+                    m[u][0] -= f0 * t0_; m[u][1] -= f0 * t1_; m[u][2] -= f1 * t0_; m[u][3] -= f1 * t1_;
+                }
             }
-            bool i1ok = i0 + 1 < df, j1ok = j0 + 1 < df;
-            Cm[i0 * df + j0] = m00; Cm[j0 * df + i0] = m00;
-            if (i1ok) { Cm[(i0 + 1) * df + j0] = m10; Cm[j0 * df + i0 + 1] = m10; }
-            if (ba != bb && j1ok) { Cm[i0 * df + j0 + 1] = m01; Cm[(j0 + 1) * df + i0] = m01; }
-            if (i1ok && j1ok) { Cm[(i0 + 1) * df + j0 + 1] = m11; Cm[(j0 + 1) * df + i0 + 1] = m11; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (!on[u]) continue;
+                int i = i0[u], j = j0[u];
+                bool i1ok = i + 1 < df, j1ok = j + 1 < df;
+                Cm[i * df + j] = m[u][0]; Cm[j * df + i] = m[u][0];
+                if (i1ok) { Cm[(i + 1) * df + j] = m[u][2]; Cm[j * df + i + 1] = m[u][2]; }
+                if (!diag[u] && j1ok) { Cm[i * df + j + 1] = m[u][1]; Cm[(j + 1) * df + i] = m[u][1]; }
+                if (i1ok && j1ok) { Cm[(i + 1) * df + j + 1] = m[u][3]; Cm[(j + 1) * df + i + 1] = m[u][3]; }
+            }
         }
     }
     QST(5);
