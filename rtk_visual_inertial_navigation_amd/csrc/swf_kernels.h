@@ -1100,9 +1100,18 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
     bool obs = DIAG && Pr.fa >= 0;
     if (obs) {
         // level 2: lanes v < 33 add this frame's block partials in block order
+        // (block offsets fetched lane-parallel and broadcast, so the value loads do not chain behind index loads)
         double acc = 0;
-        if (lane < FS_VAL)
-            for (int bq = W.fsb0; bq < W.fsb1; bq++) acc += B.fs_part[((size_t)B.fsb_out0[bq] + Pr.fa) * FS_VAL + lane];
+        for (int b0 = W.fsb0; b0 < W.fsb1; b0 += 64) {
+            int myoff = (b0 + lane < W.fsb1) ? B.fsb_out0[b0 + lane] : 0;
+            int nn = (W.fsb1 - b0) < 64 ? (W.fsb1 - b0) : 64;
+#pragma unroll 4
+            for (int c = 0; c < nn; c++) {
+                int off = __shfl(myoff, c, 64);
+                double v = B.fs_part[((size_t)off + Pr.fa) * FS_VAL + (lane < FS_VAL ? lane : 0)];
+                acc += lane < FS_VAL ? v : 0.0;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 21; k++) H[k] = __shfl(acc, k, 64);
 #pragma unroll
@@ -1139,29 +1148,42 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
     if (DIAG) { dgs0 = __shfl(dg_i, (lane / lb) & 63, 64); dgs1 = __shfl(dg_i, ((lane + 64) / lb) & 63, 64); }
     // per-entry contribution sums; descriptors broadcast from the holding lane
     int nent = la * lb;
-    int rounds = (nent + G - 1) / G;
-    double vsum[6];
+    constexpr int NR = DIAG ? 2 : 6;               // la * lb <= 81 entries over G lanes
+    // entry (i, j) of every round, computed once (the divisions used to sit in the contribution loop)
+    int ei[NR], ej[NR];
+    bool ev[NR];
 #pragma unroll
-    for (int r = 0; r < 6; r++) vsum[r] = 0;
+    for (int r = 0; r < NR; r++) {
+        int e = lane + r * G;
+        ev[r] = e < nent;
+        int i = ev[r] ? e / lb : 0;
+        ei[r] = i; ej[r] = ev[r] ? e - i * lb : 0;
+    }
+    double vsum[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) vsum[r] = 0;
     for (int cb0 = 0; cb0 < ncon; cb0 += G) {
         long long myo = (cb0 + lane < ncon) ? B.pc_coff[Pr.c0 + cb0 + lane] : 0;
         int myl = (cb0 + lane < ncon) ? B.pc_cld[Pr.c0 + cb0 + lane] : 0;
         int nn = (ncon - cb0) < G ? (ncon - cb0) : G;
+        // loads are unconditional (invalid lanes read entry (0,0)) so several contributions are in flight;
+        // every entry is still summed in contribution order
+#pragma unroll 4
         for (int c = 0; c < nn; c++) {
             long long co = __shfl(myo, gbase + c, 64);
             int cl = __shfl(myl, gbase + c, 64);
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                int e = lane + r * G;
-                if (r < rounds && e < nent) vsum[r] += B.C[co + (size_t)(e / lb) * cl + (e % lb)];
+            for (int r = 0; r < NR; r++) {
+                double cv = B.C[co + (size_t)ei[r] * cl + ej[r]];
+                vsum[r] += ev[r] ? cv : 0.0;
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
+    for (int r = 0; r < NR; r++) {
         int e = lane + r * G;
-        if (r >= rounds || e >= nent) continue;
-        int i = e / lb, j = e % lb;
+        if (!ev[r]) continue;
+        int i = ei[r], j = ej[r];
         if (DIAG && j > i) continue;                // lower half only; the mirror is the host's job at export
         double v = vsum[r];
         if (Pr.fa >= 0 && Pr.fb >= 0) {
