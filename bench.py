@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--iters", type=int, default=8, help="max_num_iterations (yaml MAX_NUM_ITERATIONS = 8)")
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-window", action="store_true",
+                    help="skip the single-window latency leg (its launches share kernel names with the batch and would dilute rocprofv3 per-kernel averages)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,14 +159,18 @@ def main():
             return acc[k]["ms"] / max(1, acc[k]["calls"])
 
         # algorithmic work of ONE launch over this GPU's batch (DESIGN.md §3 states the per-unit figures)
+        n_obs = calib["n_obs"]
         work = {
             "eval_ps": ("hbm", calib["proj_bytes"], "312 B per observation (152 read + 160 written)"),
-            "lm_elim": ("hbm", 496 * calib["n_obs"], "496 B per observation (Jp, Jl, r read = 160 B; Y|W cell + Y g_l written = 336 B)"),
-            "lm_gemm": ("mfma", calib["lm_schur_flops"], "sum over landmarks of 216 k^2 + 108 k flops (SURVEY.md 8d landmark Schur)"),
+            "lm_schur": ("mfma", calib["lm_schur_flops"], "sum over landmarks of 216 k^2 + 108 k flops (SURVEY.md 8d landmark Schur); "
+                         "HBM side: 208 B per observation (Jp, Jl, r read = 160 B, Y g_l written = 48 B) + the P partials"),
             "chol_solve": ("mfma", 2 * calib["chol_flops"], "2 * sum_w n_red^3 / 3 flops"),
+            "frame_sums": ("hbm", 160 * n_obs, "160 B per observation (Jp, r, Y g_l read)"),
+            "post_chol": ("hbm", 2 * 144 * n_obs, "Jp, Jl (144 B per observation) read by the back-substitution and by J D^-2 g"),
+            "post_dogleg": ("hbm", (144 + 152 + 16) * n_obs, "Jp, Jl read for J*step; candidate residuals: 152 B read + 16 B written per observation"),
         }
         bound, units, what = work.get(dom, ("hbm", calib["jacobian_bytes"], "Jacobian bytes of the batch (SURVEY.md 8d formula)"))
-        knames = {"eval_ps": "k_eval_ps<true>", "assemble": "k_assemble_all", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "lm_elim": "k_lm_elim", "lm_gemm": "k_lm_gemm<512, 5>", "chol_solve": "k_chol_rr2<9>"}
+        knames = {"eval_ps": "k_eval_ps<true>", "lm_schur": "k_lm_schur<8, 5>", "assemble": "k_assemble_all", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr2<9>"}
         # HBM traffic from the committed PMC passes of the same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate passes; gfx950: FETCH_SIZE counts half of wide coalesced reads -> x2), if available
         traffic = None
@@ -182,6 +188,11 @@ def main():
                         unit="TFLOP/s", frac=achieved / FP64_MATRIX_PEAK_TFLOPS, traffic=traffic, algorithmic=what,
                         algorithmic_flops_per_launch=units, avg_launch_ms=avg_ms(dom),
                         measured_fp64_mfma_ceiling_tflops=FP64_MATRIX_MEASURED_TFLOPS)
+            if dom == "lm_schur":      # the same kernel is also the elimination pass over the observations: report its HBM side too
+                hb = 208 * n_obs
+                roof["hbm_side"] = dict(algorithmic_bytes_per_launch=hb, achieved_GBs=hb / (avg_ms(dom) * 1e-3) / 1e9,
+                                        frac_of_hbm_peak=hb / (avg_ms(dom) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        note="208 B per observation (Jp, Jl, r read = 160 B; Y g_l written = 48 B); the Y|W cells stay in LDS")
         else:
             achieved = units / (avg_ms(dom) * 1e-3) / 1e9
             roof = dict(kernel=knames.get(dom, "k_" + dom), bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
@@ -192,18 +203,20 @@ def main():
                    algorithmic_bytes_per_launch=calib["proj_bytes"], avg_launch_ms=avg_ms("eval_ps"))
         jac["frac"] = jac["achieved"] / HBM_PEAK_GBS
         # single-window latency path (rank 0, extra information)
-        one = solver.BatchSolver([windows[0].copy()])
-        one.enable_timing(1)
-        for _ in range(3):
-            one.reset_state(); one.solve_async(opt); one.sync()
-        lat = []
-        for _ in range(20):
-            one.reset_state(); one.solve_async(opt); one.sync()
-            lat.append(one.timing()["total_ms"])
-        it1 = one.summaries()[0].num_iterations
-        one.close()
-        single = dict(us_per_iteration=1e3 * float(np.median(lat)) / max(1, it1), iterations_per_s=max(1, it1) / (1e-3 * float(np.median(lat))),
-                      solve_ms_median=float(np.median(lat)), solve_ms_p10=float(np.percentile(lat, 10)), solve_ms_p90=float(np.percentile(lat, 90)))
+        single = None
+        if not a.no_single_window:
+            one = solver.BatchSolver([windows[0].copy()])
+            one.enable_timing(1)
+            for _ in range(3):
+                one.reset_state(); one.solve_async(opt); one.sync()
+            lat = []
+            for _ in range(20):
+                one.reset_state(); one.solve_async(opt); one.sync()
+                lat.append(one.timing()["total_ms"])
+            it1 = one.summaries()[0].num_iterations
+            one.close()
+            single = dict(us_per_iteration=1e3 * float(np.median(lat)) / max(1, it1), iterations_per_s=max(1, it1) / (1e-3 * float(np.median(lat))),
+                          solve_ms_median=float(np.median(lat)), solve_ms_p10=float(np.percentile(lat, 10)), solve_ms_p90=float(np.percentile(lat, 90)))
         out = {
             "metric": "gauss_newton_iterations_per_sec", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -224,7 +237,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(windows, a.iters)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-            out["single_window"]["speedup_vs_cpu_single_thread"] = out["cpu_baseline"]["single_thread_us_per_iteration"] / single["us_per_iteration"]
+            if single:
+                out["single_window"]["speedup_vs_cpu_single_thread"] = out["cpu_baseline"]["single_thread_us_per_iteration"] / single["us_per_iteration"]
         print(json.dumps(out))
     bs.close()
     if world > 1:
