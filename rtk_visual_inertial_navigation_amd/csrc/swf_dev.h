@@ -276,6 +276,27 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     for (int i = 0; i < nw; i++) s += scratch[i];
     return s;
 }
+// several block-level reductions behind ONE barrier pair: v[0..NS) are summed, v[NS..NS+NM) maximised; every
+// thread gets all results.  Same order as block_sum / block_max (wave butterfly, then waves in order).
+// scratch >= 16 * (NS + NM) doubles of LDS.
+template <int NS, int NM>
+__device__ __forceinline__ void block_reduce(double* v, double* scratch) {
+#pragma unroll
+    for (int k = 0; k < NS; k++) v[k] = wave_sum(v[k]);
+#pragma unroll
+    for (int k = 0; k < NM; k++) v[NS + k] = wave_max(v[NS + k]);
+    int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NS + NM; k++) scratch[k * 16 + wid] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NS; k++) { double s = 0; for (int i = 0; i < nw; i++) s += scratch[k * 16 + i]; v[k] = s; }
+#pragma unroll
+    for (int k = 0; k < NM; k++) { double s = scratch[(NS + k) * 16]; for (int i = 1; i < nw; i++) s = scratch[(NS + k) * 16 + i] > s ? scratch[(NS + k) * 16 + i] : s; v[NS + k] = s; }
+}
 __device__ __forceinline__ double block_max(double v, double* scratch) {
     v = wave_max(v);
     int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;

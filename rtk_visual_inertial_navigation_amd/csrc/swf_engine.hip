@@ -911,6 +911,14 @@ extern "C" int swf_debug_chol_stamps(unsigned long long* out) {
 }
 #endif
 
+#ifdef SWF_PROFILE_DOG
+extern "C" int swf_debug_dog_stamps(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dog_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return SWF_E_NODEVICE;
+    return SWF_OK;
+}
+#endif
+
 #ifdef SWF_PROFILE_CLQ
 extern "C" int swf_debug_clq_stamps(unsigned long long* out) {
     if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;

@@ -171,7 +171,7 @@ __device__ void imu_unwhitened(const double* pi, const double* sbi, const double
     raw[3] = 2 * e[0]; raw[4] = 2 * e[1]; raw[5] = 2 * e[2];
     if (!jac) return;
     // U: 15 x 30 row-major, columns [pose_i(6) | sb_i(9) | pose_j(6) | sb_j(9)]
-    for (int k = 0; k < 15 * 30; k++) U[k] = 0.0;
+    // (U was zeroed by the factor's 16 lanes before this serial part)
     double Ri_inv[9], Rj[9], M[9], S[9], N[9], tmpq[4], tmpq2[4], Qj_inv[4], Spbg[9], RiRj[9];
     q2R(Qi_inv, Ri_inv);
     q2R(Qj, Rj);
@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(IMU_FPB * 16) k_eval_imu(DevBatch B) {
     __shared__ double U[IMU_FPB][450];
     __shared__ double raw[IMU_FPB][16];
     __shared__ double st[IMU_FPB][32];
+    __shared__ double pr[IMU_FPB][SWF_PRE_SQRTINFO + 6];     // record head (dp .. gyr_j) | pbg | gw, staged by the factor's 16 lanes
     int tid = threadIdx.x, fl = tid >> 4, sub = tid & 15;
     int q = blockIdx.x * IMU_FPB + fl;
     bool valid = q < B.n_imu;
@@ -231,6 +232,9 @@ __global__ void __launch_bounds__(IMU_FPB * 16) k_eval_imu(DevBatch B) {
     const double* xs = JAC ? B.x : B.xc;
     const double* pre = B.imu_pre + (size_t)G.data * SWF_PRE_DOUBLES;
     if (act) {
+        for (int k = sub; k < SWF_PRE_SQRTINFO; k += 16) pr[fl][k] = pre[k];
+        if (sub < 3) { pr[fl][SWF_PRE_SQRTINFO + sub] = W.pbg[sub]; pr[fl][SWF_PRE_SQRTINFO + 3 + sub] = W.gw[sub]; }
+        if (JAC) for (int k = sub; k < 450; k += 16) U[fl][k] = 0.0;          // the serial lane only fills the non-zero blocks
         for (int k = sub; k < 225; k += 16) SI[fl][k] = pre[SWF_PRE_SQRTINFO + k];
         for (int k = sub; k < 32; k += 16) {
             int sl = k < 7 ? 0 : k < 16 ? 1 : k < 23 ? 2 : 3;
@@ -246,9 +250,8 @@ __global__ void __launch_bounds__(IMU_FPB * 16) k_eval_imu(DevBatch B) {
             const GFac& G2 = B.gf[B.imu_gf[q2]];
             const WinState& s2 = B.ws[G2.win];
             if (JAC ? s2.need_lin : s2.eval_cand) {
-                const WinRec& W2 = B.win[G2.win];
-                imu_unwhitened(st[tid], st[tid] + 7, st[tid] + 16, st[tid] + 23, B.imu_pre + (size_t)G2.data * SWF_PRE_DOUBLES,
-                               W2.pbg, W2.gw, raw[tid], U[tid], JAC);
+                imu_unwhitened(st[tid], st[tid] + 7, st[tid] + 16, st[tid] + 23, pr[tid],
+                               pr[tid] + SWF_PRE_SQRTINFO, pr[tid] + SWF_PRE_SQRTINFO + 3, raw[tid], U[tid], JAC);
             }
         }
     }

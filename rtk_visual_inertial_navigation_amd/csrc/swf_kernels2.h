@@ -878,6 +878,14 @@ __device__ __forceinline__ double win_aux_sum(const DevBatch& B, const WinRec& W
     for (int i = W.gf0 + threadIdx.x; i < W.gf1; i += blockDim.x) a += B.g_aux[i];
     return block_sum(a, red);
 }
+// per-thread partials (no reduction): cost and model term in one pass over the window's factors
+__device__ __forceinline__ void win_cost_aux_part(const DevBatch& B, const WinRec& W, double& c, double& a) {
+    c = 0; a = 0;
+#pragma unroll 4
+    for (int i = W.proj0 + threadIdx.x; i < W.proj1; i += blockDim.x) { c += B.p_cost[i]; a += B.p_aux[i]; }
+#pragma unroll 4
+    for (int i = W.gf0 + threadIdx.x; i < W.gf1; i += blockDim.x) { c += B.g_cost[i]; a += B.g_aux[i]; }
+}
 // || x ||_2 over variable blocks (ambient coordinates)
 __device__ __forceinline__ double win_x_norm(const DevBatch& B, const WinRec& W, const double* x, double* red) {
     double a = 0;
@@ -888,7 +896,7 @@ __device__ __forceinline__ double win_x_norm(const DevBatch& B, const WinRec& W,
     return sqrt(block_sum(a, red));
 }
 // gradient_max_norm = || x - Plus(x, -g) ||_inf (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-__device__ __forceinline__ double win_gmax(const DevBatch& B, const WinRec& W, double* red) {
+__device__ __forceinline__ double win_gmax_part(const DevBatch& B, const WinRec& W) {
     double m = 0;
     for (int b = W.blk_base + threadIdx.x; b < W.blk_base + W.n_blk; b += blockDim.x) {
         int lo = B.blk_loc[b];
@@ -903,8 +911,9 @@ __device__ __forceinline__ double win_gmax(const DevBatch& B, const WinRec& W, d
             for (int k = 0; k < B.blk_gs[b]; k++) { double v = fabs(B.g[lo + k]); m = v > m ? v : m; }
         }
     }
-    return block_max(m, red);
+    return m;
 }
+__device__ __forceinline__ double win_gmax(const DevBatch& B, const WinRec& W, double* red) { return block_max(win_gmax_part(B, W), red); }
 
 __global__ void __launch_bounds__(256) k_init(DevBatch B, DevOpt O) {
     __shared__ double red[16];
@@ -924,9 +933,19 @@ __global__ void __launch_bounds__(256) k_init(DevBatch B, DevOpt O) {
 }
 
 // DoglegStrategy::ComputeStep (+ the bookkeeping of FinalizeIterationAndCheckIfMinimizerCanContinue)
+#ifdef SWF_PROFILE_DOG
+__device__ unsigned long long g_dog_stamps[16];
+#define DST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_dog_stamps[i] += t_ - td_; td_ = t_; } } while (0)
+#else
+#define DST(i)
+#endif
 __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
-    __shared__ double red[16];
+    __shared__ double red[16 * 6];
     __shared__ int go;
+#ifdef SWF_PROFILE_DOG
+    unsigned long long td_ = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < 16; i++) g_dog_stamps[i] = 0;
+#endif
     int w = blockIdx.x, tid = threadIdx.x;
     WinState& s = B.ws[w];
     if (s.status != SWF_RUNNING) return;
@@ -934,23 +953,31 @@ __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
     swf_iteration* tr = B.trace + (size_t)w * B.max_iter_trace;
     int fresh = s.need_lin;
     double x_cost = s.x_cost, gmax = s.gmax, jg_sq = s.jg_sq;
-    if (fresh) {
-        x_cost = win_cost_sum(B, W, red);
-        if (!s.lin_fail) {
-            gmax = win_gmax(B, W, red);
-            jg_sq = win_aux_sum(B, W, red);
-        }
-    }
     const double* g = B.g + W.loc_base; const double* dg = B.diag + W.loc_base; const double* y = B.y + W.loc_base;
     double* step = B.step + W.loc_base;
     int n = W.n_loc;
-    // scalars of the scaled problem: |g/d|, |d y|, (g/d).(−d y)
-    double a_g = 0, a_y = 0, a_d = 0;
+    // one pass, one barrier pair: cost, |J D^-2 g|^2, gradient max-norm (fresh linearisation only) and the scalars of the
+    // scaled problem |g/d|^2, |d y|^2, (g/d).(-d y)
+    double v[6] = { 0, 0, 0, 0, 0, 0 };
+    DST(0);
+    if (fresh) {
+        win_cost_aux_part(B, W, v[0], v[1]);
+        DST(1);
+        if (!s.lin_fail) v[5] = win_gmax_part(B, W);
+        DST(2);
+    }
+#pragma unroll 4
     for (int i = tid; i < n; i += blockDim.x) {
         double dc = clampd(dg[i], O.min_diag, O.max_diag);
-        a_g += g[i] * g[i] / dc; a_y += dc * y[i] * y[i]; a_d += -g[i] * y[i];
+        double ir = rsqrt_nr(dc);                     // 1 / sqrt(d): no IEEE sqrt / division expansions in these loops
+        double gs = g[i] * ir;
+        v[2] += gs * gs; v[3] += dc * y[i] * y[i]; v[4] += -g[i] * y[i];
     }
-    double gsq = block_sum(a_g, red), ynn = block_sum(a_y, red), gdot = block_sum(a_d, red);
+    DST(3);
+    block_reduce<5, 1>(v, red);
+    DST(4);
+    if (fresh) { x_cost = v[0]; if (!s.lin_fail) { jg_sq = v[1]; gmax = v[5]; } }
+    double gsq = v[2], ynn = v[3], gdot = v[4];
     __syncthreads();
     if (tid == 0) {
         go = 0;
@@ -983,6 +1010,7 @@ __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
         }
     }
     __syncthreads();
+    DST(5);
     if (!go) return;
     // ComputeTraditionalDoglegStep in the scaled space, un-scaled on the fly
     double gnorm = sqrt(gsq), gnn = sqrt(ynn), alpha = s.alpha, radius = s.radius;
@@ -1000,47 +1028,53 @@ __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
         mode = 2; c1 = -alpha * (1.0 - beta); c2 = -beta; dnorm = -1.0;
     }
     double a_s = 0;
+#pragma unroll 4
     for (int i = tid; i < n; i += blockDim.x) {
         double dc = clampd(dg[i], O.min_diag, O.max_diag);
-        double ds = sqrt(dc);
-        // scaled step, then / dsqrt
-        double sc = c1 * (g[i] / ds) + c2 * (ds * y[i]);
+        double ir = rsqrt_nr(dc);
+        // scaled step c1 g / sqrt(d) + c2 sqrt(d) y, then un-scaled (/ sqrt(d))
+        double sc = c1 * (g[i] * ir) + c2 * (dc * ir * y[i]);
         a_s += sc * sc;
-        step[i] = sc / ds;
+        step[i] = sc * ir;
     }
-    double sn = block_sum(a_s, red);
-    if (mode == 2) dnorm = sqrt(sn);
-    // candidate = Plus(x, step)
-    for (int i = W.x_base + tid; i < W.x_base + W.x_n; i += blockDim.x) B.xc[i] = B.x[i];
-    __syncthreads();
+    DST(6);
+    __syncthreads();                                   // step visible to the block-wise Plus below
+    // candidate = Plus(x, step); constant blocks are copied
     double a_n = 0;
     for (int b = W.blk_base + tid; b < W.blk_base + W.n_blk; b += blockDim.x) {
         int lo = B.blk_loc[b];
-        if (lo < 0) continue;
-        int xo = B.blk_xoff[b];
-        if (B.blk_gs[b] == 7) {
+        int xo = B.blk_xoff[b], gs = B.blk_gs[b];
+        if (lo < 0) { for (int k = 0; k < gs; k++) B.xc[xo + k] = B.x[xo + k]; continue; }
+        if (gs == 7) {
             double o[7];
             pose_plus(B.x + xo, B.step + lo, o);
-            for (int k = 0; k < 7; k++) { B.xc[xo + k] = o[k]; double v = B.x[xo + k] - o[k]; a_n += v * v; }
+            for (int k = 0; k < 7; k++) { B.xc[xo + k] = o[k]; double dv = B.x[xo + k] - o[k]; a_n += dv * dv; }
         } else {
-            for (int k = 0; k < B.blk_gs[b]; k++) { double v = B.x[xo + k] + B.step[lo + k]; B.xc[xo + k] = v; double dv = B.x[xo + k] - v; a_n += dv * dv; }
+            for (int k = 0; k < gs; k++) { double xv = B.x[xo + k] + B.step[lo + k]; B.xc[xo + k] = xv; double dv = B.x[xo + k] - xv; a_n += dv * dv; }
         }
     }
-    double stepn = sqrt(block_sum(a_n, red));
+    DST(7);
+    double r2[2] = { a_s, a_n };
+    block_reduce<2, 0>(r2, red);
+    if (mode == 2) dnorm = sqrt(r2[0]);
+    double stepn = sqrt(r2[1]);
     if (tid == 0) { s.dogleg_step_norm = dnorm; s.step_norm = stepn; s.eval_cand = 1; }
+    DST(8);
 }
 
 // acceptance test + trust-region update (TrustRegionMinimizer::Minimize loop body,
 // DoglegStrategy::StepAccepted / StepRejected / StepIsInvalid)
 __global__ void __launch_bounds__(256) k_decide(DevBatch B, DevOpt O) {
-    __shared__ double red[16];
+    __shared__ double red[16 * 2];
     __shared__ int accept;
     int w = blockIdx.x, tid = threadIdx.x;
     WinState& s = B.ws[w];
     if (s.status != SWF_RUNNING || !s.eval_cand) return;
     const WinRec& W = B.win[w];
-    double cand = win_cost_sum(B, W, red);
-    double model_cost_change = -win_aux_sum(B, W, red);
+    double ca[2];
+    win_cost_aux_part(B, W, ca[0], ca[1]);
+    block_reduce<2, 0>(ca, red);
+    double cand = ca[0], model_cost_change = -ca[1];
     if (!(cand == cand) || cand > 1.7976931348623157e308) cand = 1.7976931348623157e308;
     __syncthreads();
     if (tid == 0) {
