@@ -45,6 +45,9 @@ CASES = [
     dict(config_id=3, K=7, F=33, S=12, seed=9),       # ragged sizes (nothing a multiple of 16/32/64)
     dict(config_id=5, K=14, F=40, S=4, seed=10),      # dense marginalisation prior over 13 poses
     dict(config_id=3, K=6, F=30, S=6, seed=5, doppler=True),   # + Doppler factors and a clock-drift state
+    dict(config_id=3, K=26, F=40, S=5, seed=11),      # > 21 frames: the 12-consumer-wave k_lm_schur variant; tracks of 17..26
+                                                      # observations span two 16-lane groups; n_red > 240: fallback Cholesky
+    dict(config_id=2, K=38, F=24, S=0, seed=12),      # tracks of 33..38 observations span four groups (a whole producer wave)
 ]
 
 
