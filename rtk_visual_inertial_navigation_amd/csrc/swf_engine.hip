@@ -710,7 +710,7 @@ struct Launcher {
             Segs S{}; S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256);
             hipLaunchKernelGGL(k_eval_ps<true>, dim3(S.e[1]), dim3(256), 0, st, D, S);
         }
-        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * 16), 0, st, D); }
+        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF(true)), 0, st, D); }
         if (D.n_prior) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
     }
     void lin_elim(int write_S) {
@@ -769,7 +769,7 @@ struct Launcher {
         }
         {
             Bracket t(*this, SWF_K_CAND_EVAL);
-            if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * 16), 0, st, D);
+            if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF(false)), 0, st, D);
             if (D.n_prior) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
         }
         { Bracket t(*this, SWF_K_DECIDE); hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(256), 0, st, D, O); }

@@ -121,9 +121,11 @@ __device__ __forceinline__ void d_eval_proj(const DevBatch& B, int bid) {
 // un-whitened residual and the sparse 15x30 Jacobian in LDS, all 64 lanes apply the 15x15
 // sqrt-information (the 6.7k-MAC part) and write the whitened blocks row-major.
 // =========================================================================================
+// part 0: residual + d/d pose_i;  1: d/d sb_i;  2: d/d pose_j;  3: d/d sb_j.  The parts run on different waves of the
+// block (they share only cheap prefixes), which cuts the lane-serial critical path of the kernel.
 __device__ void imu_unwhitened(const double* pi, const double* sbi, const double* pj, const double* sbj,
                                const double* pre, const double* pbg, const double* gw,
-                               double* raw, double* U, bool jac) {
+                               double* raw, double* U, bool jac, int part) {
     const double* Pi = pi; const double* Qi = pi + 3;
     const double* Vi = sbi; const double* Bai = sbi + 3; const double* Bgi = sbi + 6;
     const double* Pj = pj; const double* Qj = pj + 3;
@@ -135,93 +137,118 @@ __device__ void imu_unwhitened(const double* pi, const double* sbi, const double
     const double* dv_dbg = pre + SWF_PRE_DV_DBG;
     double T = pre[SWF_PRE_SUMDT];
     const double* gyri = pre + SWF_PRE_GYRI; const double* gyrj = pre + SWF_PRE_GYRJ;
-    double dba[3], dbg[3], th[3], dqc[4], cq[4], cv[3], cp[3], t1[3], t2[3];
-    for (int k = 0; k < 3; k++) { dba[k] = Bai[k] - lba[k]; dbg[k] = Bgi[k] - lbg[k]; }
-    mat3vec(dq_dbg, dbg, th);
-    dqc[0] = th[0] / 2; dqc[1] = th[1] / 2; dqc[2] = th[2] / 2; dqc[3] = 1.0;
-    qmul(dq, dqc, cq);
-    mat3vec(dv_dba, dba, t1); mat3vec(dv_dbg, dbg, t2);
-    for (int k = 0; k < 3; k++) cv[k] = dv[k] + t1[k] + t2[k];
-    mat3vec(dp_dba, dba, t1); mat3vec(dp_dbg, dbg, t2);
-    for (int k = 0; k < 3; k++) cp[k] = dp[k] + t1[k] + t2[k];
-    double Qi_inv[4], QjPbg[3], wi[3], wj[3], wiPbg[3], wjPbg[3], QjwjPbg[3];
+    double Qi_inv[4];
     qinv(Qi, Qi_inv);
-    qrot(Qj, pbg, QjPbg);
-    for (int k = 0; k < 3; k++) { wi[k] = gyri[k] - Bgi[k]; wj[k] = gyrj[k] - Bgj[k]; }
-    cross3(wi, pbg, wiPbg);
-    cross3(wj, pbg, wjPbg);
-    qrot(Qj, wjPbg, QjwjPbg);
-    double ap[3], av[3], rp[3], rv[3];
-    for (int k = 0; k < 3; k++) {
-        ap[k] = 0.5 * gw[k] * T * T + ((Pj[k] - Pi[k]) - QjPbg[k]) - Vi[k] * T;
-        av[k] = gw[k] * T + (Vj[k] - QjwjPbg[k]) - Vi[k];
-    }
-    qrot(Qi_inv, ap, rp);
-    qrot(Qi_inv, av, rv);
-    for (int k = 0; k < 3; k++) {
-        raw[0 + k] = rp[k] - cp[k] + pbg[k] + wiPbg[k] * T;
-        raw[6 + k] = rv[k] - cv[k] + wiPbg[k];
-        raw[9 + k] = Baj[k] - Bai[k];
-        raw[12 + k] = Bgj[k] - Bgi[k];
-    }
-    double cq_inv[4], qij[4], e[4];
-    qinv(cq, cq_inv);
-    qmul(Qi_inv, Qj, qij);
-    qmul(cq_inv, qij, e);
-    raw[3] = 2 * e[0]; raw[4] = 2 * e[1]; raw[5] = 2 * e[2];
-    if (!jac) return;
-    // U: 15 x 30 row-major, columns [pose_i(6) | sb_i(9) | pose_j(6) | sb_j(9)]
-    // (U was zeroed by the factor's 16 lanes before this serial part)
-    double Ri_inv[9], Rj[9], M[9], S[9], N[9], tmpq[4], tmpq2[4], Qj_inv[4], Spbg[9], RiRj[9];
-    q2R(Qi_inv, Ri_inv);
-    q2R(Qj, Rj);
-    qinv(Qj, Qj_inv);
-    skew3(pbg, Spbg);
-    mat3mul(Ri_inv, Rj, RiRj);
 #define SETU(R0, C0, MAT, SGN) for (int i_ = 0; i_ < 3; i_++) for (int j_ = 0; j_ < 3; j_++) U[(R0 + i_) * 30 + C0 + j_] = SGN * MAT[i_ * 3 + j_];
-    // d/d pose_i
-    SETU(0, 0, Ri_inv, -1.0)
-    skew3(rp, S); SETU(0, 3, S, 1.0)
-    qmul(Qj_inv, Qi, tmpq);
-    qleft_qright_br(tmpq, cq, M); SETU(3, 3, M, -1.0)
-    skew3(rv, S); SETU(6, 3, S, 1.0)
-    // d/d sb_i  (columns 6..14)
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-        U[(0 + i) * 30 + 6 + j] = -Ri_inv[i * 3 + j] * T;
-        U[(0 + i) * 30 + 9 + j] = -dp_dba[i * 3 + j];
-        U[(0 + i) * 30 + 12 + j] = -dp_dbg[i * 3 + j] + Spbg[i * 3 + j] * T;
-        U[(6 + i) * 30 + 6 + j] = -Ri_inv[i * 3 + j];
-        U[(6 + i) * 30 + 9 + j] = -dv_dba[i * 3 + j];
-        U[(6 + i) * 30 + 12 + j] = -dv_dbg[i * 3 + j] + Spbg[i * 3 + j];
+    // U: 15 x 30 row-major, columns [pose_i(6) | sb_i(9) | pose_j(6) | sb_j(9)]; zeroed by the factor's lanes beforehand
+    if (part == 0 || part == 2) {
+        // corrected delta rotation and w_j x p_bg
+        double dbg[3], th[3], dqc[4], cq[4], cq_inv[4], wj[3], wjPbg[3];
+        for (int k = 0; k < 3; k++) { dbg[k] = Bgi[k] - lbg[k]; wj[k] = gyrj[k] - Bgj[k]; }
+        mat3vec(dq_dbg, dbg, th);
+        dqc[0] = th[0] / 2; dqc[1] = th[1] / 2; dqc[2] = th[2] / 2; dqc[3] = 1.0;
+        qmul(dq, dqc, cq);
+        cross3(wj, pbg, wjPbg);
+        qinv(cq, cq_inv);
+        if (part == 0) {
+            double dba[3], cv[3], cp[3], t1[3], t2[3], QjPbg[3], wi[3], wiPbg[3], QjwjPbg[3];
+            for (int k = 0; k < 3; k++) { dba[k] = Bai[k] - lba[k]; wi[k] = gyri[k] - Bgi[k]; }
+            mat3vec(dv_dba, dba, t1); mat3vec(dv_dbg, dbg, t2);
+            for (int k = 0; k < 3; k++) cv[k] = dv[k] + t1[k] + t2[k];
+            mat3vec(dp_dba, dba, t1); mat3vec(dp_dbg, dbg, t2);
+            for (int k = 0; k < 3; k++) cp[k] = dp[k] + t1[k] + t2[k];
+            qrot(Qj, pbg, QjPbg);
+            cross3(wi, pbg, wiPbg);
+            qrot(Qj, wjPbg, QjwjPbg);
+            double ap[3], av[3], rp[3], rv[3];
+            for (int k = 0; k < 3; k++) {
+                ap[k] = 0.5 * gw[k] * T * T + ((Pj[k] - Pi[k]) - QjPbg[k]) - Vi[k] * T;
+                av[k] = gw[k] * T + (Vj[k] - QjwjPbg[k]) - Vi[k];
+            }
+            qrot(Qi_inv, ap, rp);
+            qrot(Qi_inv, av, rv);
+            for (int k = 0; k < 3; k++) {
+                raw[0 + k] = rp[k] - cp[k] + pbg[k] + wiPbg[k] * T;
+                raw[6 + k] = rv[k] - cv[k] + wiPbg[k];
+                raw[9 + k] = Baj[k] - Bai[k];
+                raw[12 + k] = Bgj[k] - Bgi[k];
+            }
+            double qij[4], e[4];
+            qmul(Qi_inv, Qj, qij);
+            qmul(cq_inv, qij, e);
+            raw[3] = 2 * e[0]; raw[4] = 2 * e[1]; raw[5] = 2 * e[2];
+            if (!jac) return;
+            // d/d pose_i
+            double Ri_inv[9], M[9], S[9], tmpq[4], Qj_inv[4];
+            q2R(Qi_inv, Ri_inv);
+            qinv(Qj, Qj_inv);
+            SETU(0, 0, Ri_inv, -1.0)
+            skew3(rp, S); SETU(0, 3, S, 1.0)
+            qmul(Qj_inv, Qi, tmpq);
+            qleft_qright_br(tmpq, cq, M); SETU(3, 3, M, -1.0)
+            skew3(rv, S); SETU(6, 3, S, 1.0)
+        } else {
+            if (!jac) return;
+            // d/d pose_j (columns 15..20)
+            double Ri_inv[9], Rj[9], M[9], S[9], N[9], tmpq[4], tmpq2[4], Spbg[9], RiRj[9];
+            q2R(Qi_inv, Ri_inv);
+            q2R(Qj, Rj);
+            skew3(pbg, Spbg);
+            mat3mul(Ri_inv, Rj, RiRj);
+            SETU(0, 15, Ri_inv, 1.0)
+            mat3mul(RiRj, Spbg, N); SETU(0, 18, N, 1.0)
+            qmul(cq_inv, Qi_inv, tmpq);
+            qmul(tmpq, Qj, tmpq2);
+            qleft_br(tmpq2, M); SETU(3, 18, M, 1.0)
+            skew3(wjPbg, S);
+            mat3mul(RiRj, S, N); SETU(6, 18, N, 1.0)
+        }
+    } else if (part == 1) {
+        if (!jac) return;
+        // d/d sb_i  (columns 6..14)
+        double Ri_inv[9], M[9], N[9], tmpq[4], tmpq2[4], Qj_inv[4], Spbg[9];
+        q2R(Qi_inv, Ri_inv);
+        qinv(Qj, Qj_inv);
+        skew3(pbg, Spbg);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            U[(0 + i) * 30 + 6 + j] = -Ri_inv[i * 3 + j] * T;
+            U[(0 + i) * 30 + 9 + j] = -dp_dba[i * 3 + j];
+            U[(0 + i) * 30 + 12 + j] = -dp_dbg[i * 3 + j] + Spbg[i * 3 + j] * T;
+            U[(6 + i) * 30 + 6 + j] = -Ri_inv[i * 3 + j];
+            U[(6 + i) * 30 + 9 + j] = -dv_dba[i * 3 + j];
+            U[(6 + i) * 30 + 12 + j] = -dv_dbg[i * 3 + j] + Spbg[i * 3 + j];
+        }
+        qmul(Qj_inv, Qi, tmpq);
+        qmul(tmpq, dq, tmpq2);
+        qleft_br(tmpq2, M);
+        mat3mul(M, dq_dbg, N); SETU(3, 12, N, -1.0)
+        for (int k = 0; k < 3; k++) { U[(9 + k) * 30 + 9 + k] = -1.0; U[(12 + k) * 30 + 12 + k] = -1.0; }
+    } else {
+        if (!jac) return;
+        // d/d sb_j (columns 21..29)
+        double Ri_inv[9], Rj[9], N[9], Spbg[9], RiRj[9];
+        q2R(Qi_inv, Ri_inv);
+        q2R(Qj, Rj);
+        skew3(pbg, Spbg);
+        mat3mul(Ri_inv, Rj, RiRj);
+        SETU(6, 21, Ri_inv, 1.0)
+        mat3mul(RiRj, Spbg, N); SETU(6, 27, N, -1.0)
+        for (int k = 0; k < 3; k++) { U[(9 + k) * 30 + 24 + k] = 1.0; U[(12 + k) * 30 + 27 + k] = 1.0; }
     }
-    qmul(tmpq, dq, tmpq2);
-    qleft_br(tmpq2, M);
-    mat3mul(M, dq_dbg, N); SETU(3, 12, N, -1.0)
-    for (int k = 0; k < 3; k++) { U[(9 + k) * 30 + 9 + k] = -1.0; U[(12 + k) * 30 + 12 + k] = -1.0; }
-    // d/d pose_j (columns 15..20)
-    SETU(0, 15, Ri_inv, 1.0)
-    mat3mul(RiRj, Spbg, N); SETU(0, 18, N, 1.0)
-    qmul(cq_inv, Qi_inv, tmpq);
-    qmul(tmpq, Qj, tmpq2);
-    qleft_br(tmpq2, M); SETU(3, 18, M, 1.0)
-    skew3(wjPbg, S);
-    mat3mul(RiRj, S, N); SETU(6, 18, N, 1.0)
-    // d/d sb_j (columns 21..29)
-    SETU(6, 21, Ri_inv, 1.0)
-    mat3mul(RiRj, Spbg, N); SETU(6, 27, N, -1.0)
-    for (int k = 0; k < 3; k++) { U[(9 + k) * 30 + 24 + k] = 1.0; U[(12 + k) * 30 + 27 + k] = 1.0; }
 #undef SETU
 }
 
-#define IMU_FPB 8          // factors per block: 8 lanes run the un-whitened part side by side, 16 lanes per factor whiten
+#define IMU_FPB 8          // factors per block
+#define IMU_LPF(JAC) ((JAC) ? 32 : 16)   // lanes per factor: linearisation = 4 waves (one per un-whitened part), residual only = 2
 template <bool JAC>
-__global__ void __launch_bounds__(IMU_FPB * 16) k_eval_imu(DevBatch B) {
+__global__ void __launch_bounds__(IMU_FPB * IMU_LPF(JAC)) k_eval_imu(DevBatch B) {
+    constexpr int LPF = IMU_LPF(JAC);
     __shared__ double SI[IMU_FPB][225];
     __shared__ double U[IMU_FPB][450];
     __shared__ double raw[IMU_FPB][16];
     __shared__ double st[IMU_FPB][32];
     __shared__ double pr[IMU_FPB][SWF_PRE_SQRTINFO + 6];     // record head (dp .. gyr_j) | pbg | gw, staged by the factor's 16 lanes
-    int tid = threadIdx.x, fl = tid >> 4, sub = tid & 15;
+    int tid = threadIdx.x, fl = tid / LPF, sub = tid % LPF;
     int q = blockIdx.x * IMU_FPB + fl;
     bool valid = q < B.n_imu;
     int f = B.imu_gf[valid ? q : B.n_imu - 1];
@@ -232,32 +259,33 @@ __global__ void __launch_bounds__(IMU_FPB * 16) k_eval_imu(DevBatch B) {
     const double* xs = JAC ? B.x : B.xc;
     const double* pre = B.imu_pre + (size_t)G.data * SWF_PRE_DOUBLES;
     if (act) {
-        for (int k = sub; k < SWF_PRE_SQRTINFO; k += 16) pr[fl][k] = pre[k];
+        for (int k = sub; k < SWF_PRE_SQRTINFO; k += LPF) pr[fl][k] = pre[k];
         if (sub < 3) { pr[fl][SWF_PRE_SQRTINFO + sub] = W.pbg[sub]; pr[fl][SWF_PRE_SQRTINFO + 3 + sub] = W.gw[sub]; }
-        if (JAC) for (int k = sub; k < 450; k += 16) U[fl][k] = 0.0;          // the serial lane only fills the non-zero blocks
-        for (int k = sub; k < 225; k += 16) SI[fl][k] = pre[SWF_PRE_SQRTINFO + k];
-        for (int k = sub; k < 32; k += 16) {
+        if (JAC) for (int k = sub; k < 450; k += LPF) U[fl][k] = 0.0;          // the serial lane only fills the non-zero blocks
+        for (int k = sub; k < 225; k += LPF) SI[fl][k] = pre[SWF_PRE_SQRTINFO + k];
+        for (int k = sub; k < 32; k += LPF) {
             int sl = k < 7 ? 0 : k < 16 ? 1 : k < 23 ? 2 : 3;
             int o = k < 7 ? k : k < 16 ? k - 7 : k < 23 ? k - 16 : k - 23;
             st[fl][k] = xs[B.s_x[G.slot0 + sl] + o];
         }
     }
     __syncthreads();
-    // lanes 0..7 of the block: one factor each
-    if (tid < IMU_FPB) {
-        int q2 = blockIdx.x * IMU_FPB + tid;
+    // lanes 0..7 of each wave: one factor each, wave p = part p (residual-only evaluation: part 0 alone)
+    if ((tid & 63) < IMU_FPB && (JAC || tid < 64)) {
+        int part = tid >> 6, fq = tid & 63;
+        int q2 = blockIdx.x * IMU_FPB + fq;
         if (q2 < B.n_imu) {
             const GFac& G2 = B.gf[B.imu_gf[q2]];
             const WinState& s2 = B.ws[G2.win];
             if (JAC ? s2.need_lin : s2.eval_cand) {
-                imu_unwhitened(st[tid], st[tid] + 7, st[tid] + 16, st[tid] + 23, pr[tid],
-                               pr[tid] + SWF_PRE_SQRTINFO, pr[tid] + SWF_PRE_SQRTINFO + 3, raw[tid], U[tid], JAC);
+                imu_unwhitened(st[fq], st[fq] + 7, st[fq] + 16, st[fq] + 23, pr[fq],
+                               pr[fq] + SWF_PRE_SQRTINFO, pr[fq] + SWF_PRE_SQRTINFO + 3, raw[fq], U[fq], JAC, part);
             }
         }
     }
     __syncthreads();
     (void)W;
-    // whitened residual: lane k < 15 of each 16-lane group
+    // whitened residual: lane k < 15 of each factor's lanes (all within one 16-lane row)
     double rk = 0;
     if (act && sub < 15) {
         for (int k = 0; k < 15; k++) rk += SI[fl][sub * 15 + k] * raw[fl][k];
@@ -269,7 +297,7 @@ __global__ void __launch_bounds__(IMU_FPB * 16) k_eval_imu(DevBatch B) {
     const int cb[4] = { 0, 6, 15, 21 };
     // whitened Jacobian SI * U, computed row-major (uniform trip counts, broadcast SI reads) and written back in place:
     // entry (row, col) needs U[k >= row][col] only, and rows are finished in order, so the overwrite is safe
-    for (int e = sub; e < 450; e += 16) {
+    for (int e = sub; e < 450; e += LPF) {
         int row = e / 30, col = e - row * 30;
         double a = 0;
         for (int k = row; k < 15; k++) a += SI[fl][row * 15 + k] * U[fl][k * 30 + col];   // SI is upper triangular
@@ -278,7 +306,7 @@ __global__ void __launch_bounds__(IMU_FPB * 16) k_eval_imu(DevBatch B) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
     // the clique's dense Jacobian is column-major in HBM: lanes run over the rows of one column (coalesced stores)
-    for (int e = sub; e < 450; e += 16) {
+    for (int e = sub; e < 450; e += LPF) {
         int col = e / 15, row = e - col * 15;
         int sl = col < 6 ? 0 : col < 15 ? 1 : col < 21 ? 2 : 3;
         int jo = B.s_joff[G.slot0 + sl];
