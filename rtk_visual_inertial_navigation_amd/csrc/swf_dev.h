@@ -86,6 +86,7 @@ struct DevBatch {
     double* x; double* xc; double* x0;
     // local-space vectors
     double* g; double* diag; double* rhs; double* y; double* step;
+    double* vc;                                // D^-2 g = g / clamp(diag): written next to g / diag by their producers (Cauchy direction)
     // reduced matrices
     double* S; double* L;
     // tables

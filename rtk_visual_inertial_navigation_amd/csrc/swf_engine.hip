@@ -612,7 +612,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
 #undef PUT
     // mutable buffers
     rc |= P.zeros(B.n_x, &D.x); rc |= P.zeros(B.n_x, &D.xc); rc |= P.zeros(B.n_x, &D.x0);
-    rc |= P.zeros(B.n_loc, &D.g); rc |= P.zeros(B.n_loc, &D.diag); rc |= P.zeros(B.n_loc, &D.rhs);
+    rc |= P.zeros(B.n_loc, &D.g); rc |= P.zeros(B.n_loc, &D.diag); rc |= P.zeros(B.n_loc, &D.rhs); rc |= P.zeros(B.n_loc, &D.vc);
     rc |= P.zeros(B.n_loc, &D.y); rc |= P.zeros(B.n_loc, &D.step);
     rc |= P.zeros(B.S_tot, &D.S); rc |= P.zeros(B.Lt_tot, &D.L);
     rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
@@ -751,7 +751,7 @@ struct Launcher {
             Bracket t(*this, SWF_K_POST_CHOL);
             Segs S{};
             S.e[0] = nb((size_t)D.n_lm * 16, 256); S.e[1] = S.e[0] + nb((size_t)D.n_cle * 16, 256);
-            S.e[2] = S.e[1] + nb(D.n_proj, 256); S.e[3] = S.e[2] + nb(D.n_sc, 256);
+            S.e[2] = S.e[1]; S.e[3] = S.e[2] + nb(D.n_sc, 256);                                 // (J D^-2 g of the projections rides in segment 0)
             S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + nb((size_t)D.n_prior * 64, 256);
             if (S.e[5]) hipLaunchKernelGGL(k_post_chol, dim3(S.e[5]), dim3(256), 0, st, D, O, S);
         }

@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256) k_eval_prior(DevBatch B) {
 template <int MODE>
 __device__ __forceinline__ double vec_at(const DevBatch& B, const DevOpt& O, int loc) {
     if (MODE == 1) return B.step[loc];
-    return B.g[loc] / clampd(B.diag[loc], O.min_diag, O.max_diag);
+    return B.vc[loc];                  // g / clamp(diag), stored by the producers of g and diag
 }
 template <int MODE>
 __device__ __forceinline__ void d_jtimes_proj(const DevBatch& B, const DevOpt& O, int bid) {
@@ -781,6 +781,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             if (lead) {
                 B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
                 B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
+                B.vc[loc] = g0 / clampd(h00, O.min_diag, O.max_diag); B.vc[loc + 1] = g1 / clampd(h11, O.min_diag, O.max_diag); B.vc[loc + 2] = g2 / clampd(h22, O.min_diag, O.max_diag);
             }
             h00 = __builtin_fma(mu, clampd(h00, O.min_diag, O.max_diag), h00);
             h11 = __builtin_fma(mu, clampd(h11, O.min_diag, O.max_diag), h11);
@@ -922,7 +923,7 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
         // rows >= d_e of Me / Ei / T are kept at zero so the inner loops below need no d_e guards
 #pragma unroll
         for (int a2 = 0; a2 < MAXE; a2++) Me[a2][lane] = a2 < de ? me[a2] : 0.0;
-        if (lane < de) { B.g[C.e_loc + lane] = gc; B.diag[C.e_loc + lane] = mcc; }
+        if (lane < de) { B.g[C.e_loc + lane] = gc; B.diag[C.e_loc + lane] = mcc; B.vc[C.e_loc + lane] = gc / clampd(mcc, O.min_diag, O.max_diag); }
         else { B.cv_graw[C.v_off + lane - de] = gc; B.cv_dgraw[C.v_off + lane - de] = mcc; }
     }
     __syncthreads();
@@ -1167,7 +1168,7 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
             }
         }
         if (lane < la) {
-            B.g[Pr.loc_a + lane] = gi; B.diag[Pr.loc_a + lane] = dg_i;
+            B.g[Pr.loc_a + lane] = gi; B.diag[Pr.loc_a + lane] = dg_i; B.vc[Pr.loc_a + lane] = gi / clampd(dg_i, O.min_diag, O.max_diag);
             // the reduced rhs is kept twice: in the local-space vector, and as row n of the window's S storage
             // (the Cholesky carries it as one more tile row with the same addressing as every other tile)
             if (write_S) { B.rhs[Pr.loc_a + lane] = gi + cs; S[(size_t)n * n + Pr.ra + lane] = gi + cs; }

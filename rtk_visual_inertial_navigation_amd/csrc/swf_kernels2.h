@@ -758,9 +758,10 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 // =========================================================================================
 // Back-substitution of the eliminated blocks: y_e = Einv (g_e - H_ef y_f)
 // =========================================================================================
-__device__ __forceinline__ void d_backsub_lm(const DevBatch& B, int bid) {
-    // 16 lanes per landmark, one observation per lane and round:
-    //   t = g_l - sum_o W_o^T y_pose(o),  W_o^T y = Jl_o^T (Jp_o y)   (the Jacobians are read coalesced; W is not stored)
+__device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O, int bid) {
+    // 16 lanes per landmark, one observation per lane and round.  Two things share the observation's Jacobians here:
+    //   back-substitution  t = g_l - sum_o W_o^T y_pose(o),  W_o^T y = Jl_o^T (Jp_o y)   (W is not stored)
+    //   Cauchy point       aux_o = |Jp_o v_pose + Jl_o v_l|^2,  v = D^-2 g            (the projection part of |J D^-2 g|^2)
     int gid = bid * blockDim.x + threadIdx.x;
     int L = gid >> 4, sub = threadIdx.x & 15;
     bool valid = L < B.n_lm;
@@ -768,21 +769,29 @@ __device__ __forceinline__ void d_backsub_lm(const DevBatch& B, int bid) {
     int w = B.lm_win[Lc];
     const WinState& s = B.ws[w];
     int loc = B.lm_loc[Lc];
-    bool act = valid && s.need_lin && !s.lin_fail && loc >= 0;
+    bool lin = valid && s.need_lin;
+    bool act = lin && !s.lin_fail && loc >= 0;
     int nl = B.n_lm, n = B.n_proj;
+    double vl0 = 0, vl1 = 0, vl2 = 0;
+    if (lin && loc >= 0) { vl0 = vec_at<0>(B, O, loc); vl1 = vec_at<0>(B, O, loc + 1); vl2 = vec_at<0>(B, O, loc + 2); }
     double t0 = 0, t1 = 0, t2 = 0;
-    if (act) for (int o = B.lm_obs0[Lc] + sub; o < B.lm_obs0[Lc + 1]; o += 16) {
+    if (lin) for (int o = B.lm_obs0[Lc] + sub; o < B.lm_obs0[Lc + 1]; o += 16) {
         int lp = B.p_lpose[o];
-        if (B.p_fr[o] < 0) continue;
-        double u0 = 0, u1 = 0;
+        double jl0 = B.p_Jl[0 * n + o], jl1 = B.p_Jl[1 * n + o], jl2 = B.p_Jl[2 * n + o];
+        double jl3 = B.p_Jl[3 * n + o], jl4 = B.p_Jl[4 * n + o], jl5 = B.p_Jl[5 * n + o];
+        double u0 = 0, u1 = 0;                                     // Jp y
+        double a0 = jl0 * vl0 + jl1 * vl1 + jl2 * vl2, a1 = jl3 * vl0 + jl4 * vl1 + jl5 * vl2;   // J v
+        if (lp >= 0) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            double yv = B.y[lp + i];
-            u0 += B.p_Jp[i * n + o] * yv; u1 += B.p_Jp[(6 + i) * n + o] * yv;
+            for (int i = 0; i < 6; i++) {
+                double ja = B.p_Jp[i * n + o], jb = B.p_Jp[(6 + i) * n + o];
+                double yv = B.y[lp + i], vv = vec_at<0>(B, O, lp + i);
+                u0 += ja * yv; u1 += jb * yv;
+                a0 += ja * vv; a1 += jb * vv;
+            }
         }
-        t0 -= B.p_Jl[0 * n + o] * u0 + B.p_Jl[3 * n + o] * u1;
-        t1 -= B.p_Jl[1 * n + o] * u0 + B.p_Jl[4 * n + o] * u1;
-        t2 -= B.p_Jl[2 * n + o] * u0 + B.p_Jl[5 * n + o] * u1;
+        B.p_aux[o] = a0 * a0 + a1 * a1;
+        if (B.p_fr[o] >= 0) { t0 -= jl0 * u0 + jl3 * u1; t1 -= jl1 * u0 + jl4 * u1; t2 -= jl2 * u0 + jl5 * u1; }
     }
     t0 = grp16_sum(t0); t1 = grp16_sum(t1); t2 = grp16_sum(t2);
     if (!act || sub != 0) return;
@@ -839,9 +848,8 @@ __global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
 // after the reduced solve: back-substitution of the eliminated blocks, and |J D^-2 g|^2 for the Cauchy point
 __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S) {
     int bid = blockIdx.x;
-    if (bid < S.e[0]) d_backsub_lm(B, bid);
+    if (bid < S.e[0]) d_backsub_lm(B, O, bid);                 // also the projection part of |J D^-2 g|^2
     else if (bid < S.e[1]) d_backsub_clique(B, bid - S.e[0]);
-    else if (bid < S.e[2]) d_jtimes_proj<0>(B, O, bid - S.e[1]);
     else if (bid < S.e[3]) d_jtimes_scalar<0>(B, O, bid - S.e[2]);
     else if (bid < S.e[4]) d_jtimes_imu<0>(B, O, bid - S.e[3]);
     else d_jtimes_prior<0>(B, O, bid - S.e[4]);
