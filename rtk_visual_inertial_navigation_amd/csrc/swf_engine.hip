@@ -69,7 +69,7 @@ struct swf_batch {
     hipStream_t stream = nullptr;
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
-    int max_tiles = 0, max_prior_dim = 0, max_red = 0;
+    int max_tiles = 0, max_prior_dim = 0, max_red = 0, n_cu = 256;
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
     bool chol_rr1 = false;                // SWF_CHOL_RR1=1: first register-resident variant
     int timing = 0;                       // bitmask of SWF_K_* brackets
@@ -520,6 +520,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     if (B.n_x > 0x7fffffffLL || B.n_loc > 0x7fffffffLL) return fail(SWF_E_UNSUPPORTED, "batch too large for 32-bit offsets");
     swf_batch* b = new swf_batch();
     b->stream = (hipStream_t)stream;
+    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
     b->chol_rr1 = getenv("SWF_CHOL_RR1") != nullptr;
     b->win = B.win; b->hw = hw; b->max_tiles = B.max_tiles; b->max_prior_dim = B.max_prior_dim; b->jac_bytes = B.jac_bytes;
@@ -717,11 +718,16 @@ struct Launcher {
         DevBatch& D = b->D;
         if (D.n_lm) {
             Bracket t(*this, SWF_K_LM_SCHUR);
-            // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames)
-            static const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;     // debugging aid
-            if (b->max_tiles <= 16 && force < 1) hipLaunchKernelGGL((k_lm_schur<8, 2>), dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT(8)), 0, st, D, O, write_S);
-            else if (b->max_tiles <= 40 && force < 2) hipLaunchKernelGGL((k_lm_schur<8, 5>), dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT(8)), 0, st, D, O, write_S);
-            else hipLaunchKernelGGL((k_lm_schur<12, 10>), dim3(D.n_win, GEMM_SPLIT), dim3(LS_NT(12)), 0, st, D, O, write_S);
+            // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames);
+            // quarters per block: as many as still leave >= 2 blocks per CU (the result does not depend on it)
+            const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;     // test / debugging aids, read per launch
+            const int force_qpb = getenv("SWF_LS_QPB") ? atoi(getenv("SWF_LS_QPB")) : 0;
+            int qpb = D.n_win >= 2 * b->n_cu ? 4 : D.n_win >= b->n_cu ? 2 : 1;
+            if (force_qpb == 1 || force_qpb == 2 || force_qpb == 4) qpb = force_qpb;
+            dim3 grid(D.n_win, GEMM_SPLIT / qpb);
+            if (b->max_tiles <= 16 && force < 1) hipLaunchKernelGGL((k_lm_schur<8, 2>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb);
+            else if (b->max_tiles <= 40 && force < 2) hipLaunchKernelGGL((k_lm_schur<8, 5>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb);
+            else hipLaunchKernelGGL((k_lm_schur<12, 10>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb);
         }
         {
             Bracket t(*this, SWF_K_CLIQUE_ELIM);

@@ -597,13 +597,16 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 #define LS_MAXF 40
 // NCW consumer waves with TPW tile slots each: <8,2> (<= 16 tiles), <8,5> (<= 40), <12,10> (<= 120)
 template <int NCW, int TPW>
-__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int do_gemm) {
+__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int do_gemm, int qpb) {
     constexpr int NPW = LS_NPW;
     __shared__ double cells[2][(LS_CAP + 1) * LS_CS];      // + one all-zero cell per buffer
     __shared__ int tbl[2][LS_LPC][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
     __shared__ unsigned long long Ms[2][LS_LPC];           // frame mask of the chunk's landmarks (0 = none / constant landmark)
     constexpr int ZOFF = LS_CAP * LS_CS;
-    int w = blockIdx.x, sp = blockIdx.y;
+    // a block covers qpb consecutive landmark quarters of its window (qpb = 1, 2 or 4; large batches use 4 so the
+    // producer / consumer pipeline fills once per block).  Every quarter still gets its own partial product, so the
+    // result does not depend on qpb.
+    int w = blockIdx.x, sp0 = blockIdx.y * qpb;
     WinState& s = B.ws[w];
     if (!s.need_lin) return;
     const WinRec& W = B.win[w];
@@ -611,8 +614,8 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
     int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     bool gemm = do_gemm && m > 0;
-    int blk = w * GEMM_SPLIT + sp;
-    int c0 = B.sch_c0[blk], c1 = B.sch_c0[blk + 1];
+    int blk = w * GEMM_SPLIT + sp0;
+    int c0 = B.sch_c0[blk], c1 = B.sch_c0[blk + qpb];
     if (wv >= NPW) {
         // =========================== consumer waves: P += Y W^T on the matrix cores ===========================
         if (!gemm) return;
@@ -645,7 +648,9 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
         unsigned long long tg = GNOW(); (void)tg;
         __syncthreads();                                    // chunk c0 produced
         if (cw == 0) GSTAMP_ACC(8, tg);
-        for (int c = c0; c < c1; c++) {
+        for (int sq = 0; sq < qpb; sq++) {
+        int cq1 = B.sch_c0[blk + sq + 1];
+        for (int c = (sq == 0 ? c0 : B.sch_c0[blk + sq]); c < cq1; c++) {
             int buf = (c - c0) & 1;
             tg = GNOW();
             // lane j tests row j's frame mask against each tile slot; the ballot is the slot's hit list over the
@@ -679,16 +684,20 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             __syncthreads();                                // chunk c consumed, chunk c+1 produced
             if (cw == 0) GSTAMP_ACC(10, tg);
         }
-        double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)sp * m * m;
+        // flush this quarter's partial product and start the next one from zero
+        double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)(sp0 + sq) * m * m;
 #pragma unroll
         for (int sl = 0; sl < TPW; sl++) {
             int t = cw + sl * NCW;
-            if (t >= ntiles) continue;
+            if (t < ntiles) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int r = t_tr[sl] * 16 + lk + 4 * q, c = t_tc[sl] * 16 + li;
-                if (r < m && c < m) P[(size_t)r * m + c] = acc[sl][q];
+                for (int q = 0; q < 4; q++) {
+                    int r = t_tr[sl] * 16 + lk + 4 * q, c = t_tc[sl] * 16 + li;
+                    if (r < m && c < m) P[(size_t)r * m + c] = acc[sl][q];
+                }
             }
+            acc[sl] = double4_t{ 0, 0, 0, 0 };
+        }
         }
         return;
     }

@@ -146,6 +146,30 @@ def test_batch_equals_single_window_solves_bitwise():
     bs.close()
 
 
+def test_landmark_quarters_per_block_and_kernel_variant_do_not_change_results(monkeypatch):
+    """k_lm_schur lets one workgroup process 1, 2 or 4 landmark quarters (chosen from the batch size) and is
+    instantiated per tile count; every quarter keeps its own partial product and the arithmetic is pinned, so all
+    of these must give bit-identical solves."""
+    ws = [synth.make_window(3, K=9, F=50, S=6, seed=60 + i) for i in range(3)]
+    ref = None
+    for env in ({}, {"SWF_LS_QPB": "1"}, {"SWF_LS_QPB": "2"}, {"SWF_LS_QPB": "4"}, {"SWF_LS_VARIANT": "1"}, {"SWF_LS_VARIANT": "2", "SWF_LS_QPB": "4"}):
+        for k in ("SWF_LS_QPB", "SWF_LS_VARIANT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        batch = [w.copy() for w in ws]
+        bs = solver.BatchSolver(batch)
+        sms = bs.solve(default_options())
+        got = ([[r["cost"] for r in sm.rows()] for sm in sms], [np.concatenate([b.a[k].ravel() for k in ("pose", "sb", "lm", "sc")]) for b in batch])
+        bs.close()
+        if ref is None:
+            ref = got
+        else:
+            assert got[0] == ref[0], env
+            for x, y in zip(got[1], ref[1]):
+                assert np.array_equal(x, y), env
+
+
 def test_full_size_properties_cfg5_and_batch():
     """At BASELINE's full sizes (where the oracle is slow) check size-independent properties:
     monotone accepted costs, S = L L^T, S symmetric, gradient consistency g_f - H_fe y_e-part,
