@@ -89,6 +89,7 @@ struct DevBatch {
     double* vc;                                // D^-2 g = g / clamp(diag): written next to g / diag by their producers (Cauchy direction)
     // reduced matrices
     double* S; double* L;
+    double* Linv;                              // inverse diagonal tiles of k_chol_big: [window][32][16][16] (allocated when max n_red > 240)
     // tables
     const WinRec* win; WinState* ws; swf_iteration* trace;
     const int* blk_xoff; const int* blk_loc; const int* blk_gs;

@@ -616,6 +616,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     rc |= P.zeros(B.n_loc, &D.g); rc |= P.zeros(B.n_loc, &D.diag); rc |= P.zeros(B.n_loc, &D.rhs); rc |= P.zeros(B.n_loc, &D.vc);
     rc |= P.zeros(B.n_loc, &D.y); rc |= P.zeros(B.n_loc, &D.step);
     rc |= P.zeros(B.S_tot, &D.S); rc |= P.zeros(B.Lt_tot, &D.L);
+    if (b->max_red > 240 && b->max_red <= 512) rc |= P.zeros((size_t)n * (CB_MAXT - 1) * 256, &D.Linv);
     rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
     size_t np = (size_t)D.n_proj;
     rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl); rc |= P.zeros(6 * np, &D.p_yg);
@@ -748,6 +749,7 @@ struct Launcher {
         if (b->max_red <= 240 && !b->force_chol_v1 && !b->chol_rr1) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
         else if (b->max_red <= 224 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_rr<8>, dim3(D.n_win), dim3(1024), 0, st, D);
         else if (b->max_red <= 240 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_rr<9>, dim3(D.n_win), dim3(1024), 0, st, D);
+        else if (b->max_red <= 512 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_big, dim3(D.n_win), dim3(1024), 0, st, D);
         else if (b->max_red + 1 <= 256) hipLaunchKernelGGL(k_chol_solve<256>, dim3(D.n_win), dim3(256), 0, st, D);
         else hipLaunchKernelGGL(k_chol_solve<1024>, dim3(D.n_win), dim3(1024), 0, st, D);
     }
@@ -891,7 +893,7 @@ extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, doub
     if (L) {
         std::vector<double> Lt((n + 1) * (n + 1));
         HIPCHK(hipMemcpy(Lt.data(), b->D.L + W.Lt_base, Lt.size() * sizeof(double), hipMemcpyDeviceToHost));
-        bool rr = b->max_red <= 240 && !b->force_chol_v1;      // k_chol_rr writes row-major lower, ld = n
+        bool rr = b->max_red <= 512 && !b->force_chol_v1;      // k_chol_rr2 / k_chol_big write row-major lower, ld = n
         for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++)
             L[r * n + c] = (c <= r) ? (rr ? Lt[r * n + c] : Lt[c * (n + 1) + r]) : 0.0;
     }

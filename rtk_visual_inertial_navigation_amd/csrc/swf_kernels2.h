@@ -492,6 +492,60 @@ __global__ void __launch_bounds__(1024) k_chol_rr(DevBatch B) {
     CHSTAMP(2);
 }
 
+// Factor and invert one 16x16 SPD tile with the 64 lanes of one wavefront (shared by k_chol_rr2 and k_chol_big).
+// D: the full symmetric tile in LDS, overwritten by L (lower, zeros above); LiJ: receives L^-1 (lower).  Returns
+// true if a pivot was not positive.
+__device__ __forceinline__ bool chol_pivot_tile(double (*D)[17], double (*LiJ)[17], int li, int lk) {
+    // Factor and invert the 16x16 tile with all 64 lanes: the tile A and the running inverse R (starts as I)
+    // live in the MFMA C-layout (lane (li, lk), reg q <-> row lk+4q, column li; A is kept fully symmetric).
+    // Column c:  ip = 1/sqrt(A_cc);  column c of A reaches every lane of its row by one DPP row_newbcast,
+    // row c of A / R reaches every row by one ds_bpermute;  then, for rows r > c,
+    //   A[r][:] -= A[r][c] A[c][:] / A_cc      (right-looking Cholesky update)
+    //   R[r][:] -= A[r][c] R[c][:] / A_cc      (forward substitution of L X = I, same broadcasts)
+    // and column c of L = A[:][c] ip, row c of X = R[c][:] ip.  The only serial chain per column is
+    // readlane -> rsqrt -> fma; everything else is independent work for the wave's issue slots.
+    double A_[4], R_[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { A_[q] = D[lk + 4 * q][li]; R_[q] = (lk + 4 * q == li) ? 1.0 : 0.0; }
+    bool bad = false;
+    int bidx[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const int cq = c >> 2, cr = c & 3;
+        double dp = readlane_d(A_[cq], cr * 16 + c);
+        if (!(dp > 0.0)) bad = true;
+        double ip = rsqrt_nr(dp);
+        double ip2 = ip * ip;
+        double rowA = bperm_d(A_[cq], bidx[cr]);          // A[c][li]
+        double rowR = bperm_d(R_[cq], bidx[cr]);          // R[c][li]
+        double sA = (li > c) ? rowA * ip2 : 0.0;          // columns <= c of A are final (L) already
+        double sR = rowR * ip2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (4 * q + 3 <= c) continue;                 // every row of this register is final already
+            double col = row_newbcast_d(A_[q], c);        // A[lk+4q][c]
+            if (lk + 4 * q > c) {
+                A_[q] = __builtin_fma(-col, sA, A_[q]);
+                R_[q] = __builtin_fma(-col, sR, R_[q]);
+            }
+        }
+        if (li == c) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) A_[q] *= ip;      // column c of L (rows above the diagonal are zeroed at the store)
+        }
+        if (lk == cr) R_[cq] *= ip;                       // row c of X = L^-1
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int r = lk + 4 * q;
+        D[r][li] = (li <= r) ? A_[q] : 0.0;
+        LiJ[r][li] = (li <= r) ? R_[q] : 0.0;
+    }
+    return bad;
+}
+
 // =========================================================================================
 // k_chol_rr2 — the register-resident tiled Cholesky with ROLE-SPECIALISED waves and lookahead.
 //   wave 0       "pivot wave": factors + inverts the 16x16 diagonal tiles (lane = row / column,
@@ -537,53 +591,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
-            // Factor and invert the 16x16 tile with all 64 lanes: the tile A and the running inverse R (starts as I)
-            // live in the MFMA C-layout (lane (li, lk), reg q <-> row lk+4q, column li; A is kept fully symmetric).
-            // Column c:  ip = 1/sqrt(A_cc);  column c of A reaches every lane of its row by one DPP row_newbcast,
-            // row c of A / R reaches every row by one ds_bpermute;  then, for rows r > c,
-            //   A[r][:] -= A[r][c] A[c][:] / A_cc      (right-looking Cholesky update)
-            //   R[r][:] -= A[r][c] R[c][:] / A_cc      (forward substitution of L X = I, same broadcasts)
-            // and column c of L = A[:][c] ip, row c of X = R[c][:] ip.  The only serial chain per column is
-            // readlane -> rsqrt -> fma; everything else is independent work for the wave's issue slots.
-            double A_[4], R_[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { A_[q] = D[lk + 4 * q][li]; R_[q] = (lk + 4 * q == li) ? 1.0 : 0.0; }
-            bool bad = false;
-            int bidx[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const int cq = c >> 2, cr = c & 3;
-                double dp = readlane_d(A_[cq], cr * 16 + c);
-                if (!(dp > 0.0)) bad = true;
-                double ip = rsqrt_nr(dp);
-                double ip2 = ip * ip;
-                double rowA = bperm_d(A_[cq], bidx[cr]);          // A[c][li]
-                double rowR = bperm_d(R_[cq], bidx[cr]);          // R[c][li]
-                double sA = (li > c) ? rowA * ip2 : 0.0;          // columns <= c of A are final (L) already
-                double sR = rowR * ip2;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (4 * q + 3 <= c) continue;                 // every row of this register is final already
-                    double col = row_newbcast_d(A_[q], c);        // A[lk+4q][c]
-                    if (lk + 4 * q > c) {
-                        A_[q] = __builtin_fma(-col, sA, A_[q]);
-                        R_[q] = __builtin_fma(-col, sR, R_[q]);
-                    }
-                }
-                if (li == c) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) A_[q] *= ip;      // column c of L (rows above the diagonal are zeroed at the store)
-                }
-                if (lk == cr) R_[cq] *= ip;                       // row c of X = L^-1
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int r = lk + 4 * q;
-                D[r][li] = (li <= r) ? A_[q] : 0.0;
-                Li[j][r][li] = (li <= r) ? R_[q] : 0.0;
-            }
+            bool bad = chol_pivot_tile(D, Li[j], li, lk);
             if (bad && lane == 0) fail = 1;
             CHACC(9, tq);
 #ifdef SWF_PROFILE_CHOL
@@ -748,6 +756,241 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
             p += __shfl_xor(p, 16, 64);
             p += __shfl_xor(p, 32, 64);
             if (lk == 0) yv[16 * sJ[s] + li] -= p;
+        }
+        __syncthreads();                                   // Y_J
+    }
+    double* y = B.y + W.loc_base + W.n_e;
+    for (int e = tid - 64; e < n; e += 960) y[e] = zs[e];
+}
+
+// =========================================================================================
+// k_chol_big — the same pivot / panel / look-ahead pipeline as k_chol_rr2 for 240 < n_red <= 512, where the factor
+// (n^2/2 doubles, up to 1 MB) no longer fits the register file.  The tiles live in HBM/L2 in the window's L buffer
+// (row-major, ld = n, the reduced rhs as row n) and are streamed through registers step by step:
+//   wave 0        pivot wave: chol_pivot_tile on the published diagonal tile, Linv_jj kept in LDS for the panel and
+//                 stored to the window's Linv slab for the backward pass
+//   waves 1..15   own the tiles, owner(I, J) = 1 + (I + J) mod 15.  Ownership is static down to the lane (lane
+//                 (li, lk), reg q <-> row lk+4q, column li), so every global read-after-write is same-thread.
+// Step j:  B_j  [panel column j: tile -> LDS -> X = tile Linv^T on MFMA -> LDS (operands) + HBM (final L)]  C_j
+//          [look-ahead: tile (j+1, j+1) updated first and published]  A_{j+1}  [remaining trailing tiles: load,
+//          4 MFMAs with the panel operands from LDS, store; the next tile's loads are issued before the MFMAs].
+// Step 0 reads S (lower; diagonal tiles mirrored), later steps read the L buffer.  Right-looking backward pass.
+// =========================================================================================
+#define CB_MAXT 33                      // tile rows: 32 of the matrix (n <= 512) + the rhs row
+__global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
+    __shared__ double Pn[CB_MAXT][16][17];     // panel of the current column, tile row I -> L_Ij (72 KB)
+    __shared__ double Lic[16][17];             // Linv_jj of the current column
+    __shared__ double Dt[2][16][17];           // published diagonal tiles, double-buffered
+    __shared__ double zs[528];
+    __shared__ double yv[528];
+    __shared__ int fail;
+    int w = blockIdx.x;
+    WinState& st = B.ws[w];
+    if (!st.need_lin || st.lin_fail) return;
+    const WinRec& W = B.win[w];
+    int n = W.n_red, tid = threadIdx.x;
+    if (n <= 0) return;
+    int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    int Tc = (n + 15) >> 4, Tr = Tc + 1;
+    const double* S = B.S + W.S_base;
+    double* Lw = B.L + W.Lt_base;
+    double* LinvG = B.Linv + (size_t)w * (CB_MAXT - 1) * 256;
+    if (tid == 0) fail = 0;
+    for (int e = tid; e < 528; e += 1024) yv[e] = 0.0;     // padded entries must be exact zeros (they meet identity rows of Linv)
+    // tile I/O in the C-layout.  first = true: from S (lower, mirrored inside diagonal tiles, rhs = row n of S)
+    // interior tiles (all 16 rows inside the matrix, not a mirrored first read): scalar tile base + per-lane offset
+    const int lane_off = lk * n + li;
+    auto load_tile = [&](int I, int J, bool first) {
+        double4_t v;
+        const double* src = first ? S : Lw;
+        if (16 * I + 16 <= n && !(first && I == J)) {
+            const double* t0 = src + (size_t)(16 * I) * n + 16 * J + lane_off;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = t0[(size_t)(4 * q) * n];
+            return v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int r = 16 * I + lk + 4 * q, c = 16 * J + li;
+            bool rhs_el = I == Tc && lk + 4 * q == 0;
+            int rr = rhs_el ? n : r;
+            bool inside = c < n && (rhs_el || (r < n && (c <= r || I == J)));
+            int rc = rr < n ? rr : (rhs_el ? n : n - 1), cc = c < n ? c : n - 1;
+            int off = (first && cc > rc) ? cc * n + rc : rc * n + cc;
+            double x = src[off];
+            v[q] = inside ? x : ((I < Tc && r == c) ? 1.0 : 0.0);
+        }
+        return v;
+    };
+    auto store_tile = [&](int I, int J, double4_t v, bool lower_only) {
+        if (16 * I + 16 <= n && !lower_only) {
+            double* t0 = Lw + (size_t)(16 * I) * n + 16 * J + lane_off;
+#pragma unroll
+            for (int q = 0; q < 4; q++) t0[(size_t)(4 * q) * n] = v[q];
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int r = 16 * I + lk + 4 * q, c = 16 * J + li;
+            bool rhs_el = I == Tc && lk + 4 * q == 0;
+            if (rhs_el) { if (c < n) Lw[(size_t)n * n + c] = v[q]; }
+            else if (I < Tc && r < n && c < n) Lw[(size_t)r * n + c] = (lower_only && c > r) ? 0.0 : v[q];
+        }
+    };
+    if (wv == 0) {
+        // =============================== pivot wave ===============================
+#ifdef SWF_PROFILE_CHOL
+        if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 64; i++) g_chol_stamps[i] = 0;
+        unsigned long long tq = 0;
+#endif
+        CHSTAMP(0);
+        __syncthreads();                                   // A_0: tile (0,0) published
+        CHSTAMP(3);
+        for (int j = 0; j < Tc; j++) {
+#ifdef SWF_PROFILE_CHOL
+            tq = __builtin_amdgcn_s_memtime();
+#endif
+            bool bad = chol_pivot_tile(Dt[j & 1], Lic, li, lk);
+#pragma unroll
+            for (int q = 0; q < 4; q++) LinvG[(size_t)j * 256 + (lk + 4 * q) * 16 + li] = Lic[lk + 4 * q][li];
+            if (bad && lane == 0) fail = 1;
+            CHACC(9, tq);
+#ifdef SWF_PROFILE_CHOL
+            tq = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads();                               // B_j
+            CHACC(8, tq);
+#ifdef SWF_PROFILE_CHOL
+            tq = __builtin_amdgcn_s_memtime();
+#endif
+            if (fail) { if (tid == 0) st.lin_fail = 1; return; }
+            __syncthreads();                               // C_j
+            CHACC(10, tq);
+#ifdef SWF_PROFILE_CHOL
+            tq = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads();                               // A_{j+1}
+            CHACC(11, tq);
+        }
+        CHSTAMP(1);
+        __syncthreads();                                   // E: yv ready
+        CHSTAMP(4);
+        // backward solve y = L^-T z, right-looking (see k_chol_rr2); Linv_JJ comes back from the slab
+        for (int J = Tc - 1; J >= 0; J--) {
+            double p = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) p += LinvG[(size_t)J * 256 + (lk + 4 * q) * 16 + li] * yv[16 * J + lk + 4 * q];
+            p += __shfl_xor(p, 16, 64);
+            p += __shfl_xor(p, 32, 64);
+            if (lk == 0) zs[16 * J + li] = p;
+            __syncthreads();                               // X_J: y_J published
+            __syncthreads();                               // Y_J: row J applied to the pending blocks
+        }
+        CHSTAMP(2);
+        return;
+    }
+    // =============================== tile waves ===============================
+    int kq = wv - 1;                                       // owns the tiles with (I + J) mod 15 == kq
+    // first row I >= J of column J owned by this wave (then I + 15, I + 30)
+    auto first_row = [&](int J) { int d = (kq - 2 * J) % 15; if (d < 0) d += 15; return J + d; };
+    if (first_row(0) == 0) {                               // owner of (0,0): publish it
+        double4_t v = load_tile(0, 0, true);
+#pragma unroll
+        for (int q = 0; q < 4; q++) Dt[0][lk + 4 * q][li] = v[q];
+    }
+    __syncthreads();                                       // A_0
+    for (int j = 0; j < Tc; j++) {
+        bool first = j == 0;
+        __syncthreads();                                   // B_j: L_jj, Linv_jj ready
+        if (fail) return;
+        // ---- panel of column j: tiles (I, j), I > j, and the final L_jj
+        for (int I = first_row(j); I < Tr; I += 15) {
+            if (I == j) {
+                double4_t v;
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = Dt[j & 1][lk + 4 * q][li];
+                store_tile(j, j, v, true);
+                continue;
+            }
+            double4_t v = load_tile(I, j, first);
+#pragma unroll
+            for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = v[q];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            double4_t X = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[I][li][lk + 4 * kk], Lic[li][lk + 4 * kk], X, 0, 0, 0);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = X[q];
+            store_tile(I, j, X, false);
+        }
+        __syncthreads();                                   // C_j: panel published
+        // ---- look-ahead: the next diagonal tile first, published for the pivot wave
+        if (j + 1 < Tc && first_row(j + 1) == j + 1) {
+            double4_t v = load_tile(j + 1, j + 1, first);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) v = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[j + 1][li][lk + 4 * kk], Pn[j + 1][li][lk + 4 * kk], v, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) Dt[(j + 1) & 1][lk + 4 * q][li] = v[q];
+            store_tile(j + 1, j + 1, v, false);
+        }
+        __syncthreads();                                   // A_{j+1}
+        // ---- remaining trailing tiles (I, J), J > j, I >= J (the rhs row included), in groups of four: independent
+        //      accumulators (a dependent fp64 MFMA chain costs 184 cycles per link) and the next group's loads in flight
+        {
+            int J = j + 1, I = J < Tc ? first_row(J) : Tr;
+            auto settle = [&]() {                                   // move to the next owned tile, skipping the look-ahead tile
+                while (J < Tc && (I >= Tr || (I == j + 1 && J == j + 1))) {
+                    if (I >= Tr) { J++; I = J < Tc ? first_row(J) : Tr; } else I += 15;
+                }
+            };
+            settle();
+            int Ic[4], Jc[4], nc = 0;
+            double4_t vc[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { vc[t] = double4_t{ 0, 0, 0, 0 }; Ic[t] = 0; Jc[t] = 0; }
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (J < Tc) { Ic[t] = I; Jc[t] = J; vc[t] = load_tile(I, J, first); nc = t + 1; I += 15; settle(); }
+            while (nc) {
+                int In[4], Jn[4], nn = 0;
+                double4_t vn[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) { vn[t] = double4_t{ 0, 0, 0, 0 }; In[t] = 0; Jn[t] = 0; }
+#pragma unroll
+                for (int t = 0; t < 4; t++) if (J < Tc) { In[t] = I; Jn[t] = J; vn[t] = load_tile(I, J, first); nn = t + 1; I += 15; settle(); }
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if (t < nc) vc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[Ic[t]][li][lk + 4 * kk], Pn[Jc[t]][li][lk + 4 * kk], vc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; t++) if (t < nc) store_tile(Ic[t], Jc[t], vc[t], false);
+#pragma unroll
+                for (int t = 0; t < 4; t++) { Ic[t] = In[t]; Jc[t] = Jn[t]; vc[t] = vn[t]; }
+                nc = nn;
+            }
+        }
+    }
+    // z = L^-1 rhs sits in row n of the L buffer: this wave's tiles of the rhs row -> yv
+    for (int J = 0; J < Tc; J++)
+        if ((Tc + J) % 15 == kq && lk == 0 && 16 * J + li < n) yv[16 * J + li] = Lw[(size_t)n * n + 16 * J + li];
+    for (int e = tid - 64; e < 528; e += 960) zs[e] = 0.0;
+    __syncthreads();                                       // E
+    for (int J = Tc - 1; J >= 0; J--) {
+        // tiles (J, J') of row J, J' < J, owned by this wave: J' = (kq - J) mod 15, + 15, + 30
+        double4_t t[3];
+        int Jp[3], nt_ = 0;
+        { int d = (kq - J) % 15; if (d < 0) d += 15; for (int Jq = d; Jq < J && nt_ < 3; Jq += 15) { Jp[nt_] = Jq; t[nt_] = load_tile(J, Jq, false); nt_++; } }
+        __syncthreads();                                   // X_J: y_J published
+        for (int u = 0; u < nt_; u++) {
+            double p = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) p += t[u][q] * zs[16 * J + lk + 4 * q];
+            p += __shfl_xor(p, 16, 64);
+            p += __shfl_xor(p, 32, 64);
+            if (lk == 0) yv[16 * Jp[u] + li] -= p;
         }
         __syncthreads();                                   // Y_J
     }
