@@ -719,7 +719,8 @@ struct Launcher {
         DevBatch& D = b->D;
         if (D.n_lm) {
             Bracket t(*this, SWF_K_LM_SCHUR);
-            // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames);
+            // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames; this one
+            // spills under the 128-VGPR cap of a 1024-thread block — an <8,15> variant in 768 threads was measured: worse);
             // quarters per block: as many as still leave >= 2 blocks per CU (the result does not depend on it)
             const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;     // test / debugging aids, read per launch
             const int force_qpb = getenv("SWF_LS_QPB") ? atoi(getenv("SWF_LS_QPB")) : 0;

@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
         // tiles of this wave: tile index and frame masks (wave-uniform), per-lane operand addressing:
         // table column of the lane's frame (column nF = the zero cell for lanes outside the matrix and the
         // fourth k-slot) and offset inside the cell
-        int t_tr[TPW], t_tc[TPW], fA[TPW], fB[TPW], subA[TPW], subB[TPW];
+        int t_tr[TPW], t_tc[TPW], pk[TPW];                 // pk = fA | fB << 8 | subA << 16 | subB << 24 (one VGPR per slot)
         unsigned long long mA[TPW], mB[TPW];
         double4_t acc[TPW];
 #pragma unroll
@@ -637,8 +637,9 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             t_tr[sl] = tr; t_tc[sl] = tc;
             int ra = tr * 16 + li, cb = tc * 16 + li;
             bool okA = ra < m && lk < 3 && t < ntiles, okB = cb < m && lk < 3 && t < ntiles;
-            fA[sl] = okA ? ra / 6 : nF; subA[sl] = okA ? lk * 6 + ra % 6 : 0;
-            fB[sl] = okB ? cb / 6 : nF; subB[sl] = okB ? 18 + lk * 6 + cb % 6 : 0;
+            int fA_ = okA ? ra / 6 : nF, subA_ = okA ? lk * 6 + ra % 6 : 0;
+            int fB_ = okB ? cb / 6 : nF, subB_ = okB ? 18 + lk * 6 + cb % 6 : 0;
+            pk[sl] = fA_ | (fB_ << 8) | (subA_ << 16) | (subB_ << 24);
             int f0 = (tr * 16) / 6, f1 = (tr * 16 + 15) / 6; if (f1 > 63) f1 = 63;
             int g0 = (tc * 16) / 6, g1 = (tc * 16 + 15) / 6; if (g1 > 63) g1 = 63;
             mA[sl] = (t < ntiles && f0 < 64) ? ((~0ULL >> (63 - f1)) & (~0ULL << f0)) : 0ULL;
@@ -665,14 +666,15 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
                 unsigned hits = (unsigned)__ballot((fm_r & mA[sl]) && (fm_r & mB[sl])) & ((1u << LS_LPC) - 1u);
                 if (!hits) continue;
                 int l = __builtin_ctz(hits); hits &= hits - 1;
-                int ia = tb[l * (LS_MAXF + 1) + fA[sl]], ib = tb[l * (LS_MAXF + 1) + fB[sl]];
+                const int fA = pk[sl] & 255, fB = (pk[sl] >> 8) & 255, subA = (pk[sl] >> 16) & 255, subB = (pk[sl] >> 24) & 255;
+                int ia = tb[l * (LS_MAXF + 1) + fA], ib = tb[l * (LS_MAXF + 1) + fB];
                 double4_t c_ = acc[sl];
                 while (true) {
-                    double av = cb[ia + subA[sl]], bv = cb[ib + subB[sl]];
+                    double av = cb[ia + subA], bv = cb[ib + subB];
                     bool more = hits != 0;
                     if (more) {
                         l = __builtin_ctz(hits); hits &= hits - 1;
-                        ia = tb[l * (LS_MAXF + 1) + fA[sl]]; ib = tb[l * (LS_MAXF + 1) + fB[sl]];
+                        ia = tb[l * (LS_MAXF + 1) + fA]; ib = tb[l * (LS_MAXF + 1) + fB];
                     }
                     c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c_, 0, 0, 0);
                     if (!more) break;
