@@ -707,13 +707,14 @@ struct Launcher {
     static int nb(size_t n, int per) { return (int)((n + per - 1) / per); }
     void lin_eval() {
         DevBatch& D = b->D;
-        if (D.n_proj + D.n_sc) {
+        if (D.n_proj + D.n_sc + D.n_prior) {
             Bracket t(*this, SWF_K_EVAL_PS);
-            Segs S{}; S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256);
-            hipLaunchKernelGGL(k_eval_ps<true>, dim3(S.e[1]), dim3(256), 0, st, D, S);
+            bool pf = b->max_prior_dim <= PRIOR_LDS_DIM;          // priors fused as a segment
+            Segs S{}; S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
+            hipLaunchKernelGGL(k_eval_ps<true>, dim3(S.e[2]), dim3(256), 0, st, D, S);
         }
         if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF(true)), 0, st, D); }
-        if (D.n_prior) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
+        if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
     }
     void lin_elim(int write_S) {
         DevBatch& D = b->D;
@@ -774,12 +775,13 @@ struct Launcher {
             S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256);
             S.e[2] = S.e[1] + nb((size_t)D.n_imu * 16, 256); S.e[3] = S.e[2] + nb((size_t)D.n_prior * 64, 256);
             S.e[4] = S.e[3] + nb(D.n_proj, 256); S.e[5] = S.e[4] + nb(D.n_sc, 256);
-            if (S.e[5]) hipLaunchKernelGGL(k_post_dogleg, dim3(S.e[5]), dim3(256), 0, st, D, O, S);
+            S.e[6] = S.e[5] + (b->max_prior_dim <= PRIOR_LDS_DIM ? D.n_prior : 0);
+            if (S.e[6]) hipLaunchKernelGGL(k_post_dogleg, dim3(S.e[6]), dim3(256), 0, st, D, O, S);
         }
         {
             Bracket t(*this, SWF_K_CAND_EVAL);
             if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF(false)), 0, st, D);
-            if (D.n_prior) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
+            if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
         }
         { Bracket t(*this, SWF_K_DECIDE); hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(256), 0, st, D, O); }
     }

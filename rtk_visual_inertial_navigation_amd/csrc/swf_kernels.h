@@ -418,10 +418,9 @@ __device__ __forceinline__ void prior_block_dx(const double* x, const double* x0
     double sg = (dq[3] >= 0) ? 2.0 : -2.0;
     dx[3] = sg * dq[0]; dx[4] = sg * dq[1]; dx[5] = sg * dq[2];
 }
+#define PRIOR_LDS_DIM 512               // priors up to this dimension ride as a segment of the fused evaluation grids
 template <bool JAC>
-__global__ void __launch_bounds__(256) k_eval_prior(DevBatch B) {
-    extern __shared__ double sm[];      // dx[n] | r[n] | red[16]
-    int q = blockIdx.x;
+__device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* sm) {      // sm: dx[n] | r[n] | red[16]
     if (q >= B.n_prior) return;
     int f = B.prior_gf[q];
     const GFac& G = B.gf[f];
@@ -465,6 +464,13 @@ __global__ void __launch_bounds__(256) k_eval_prior(DevBatch B) {
         int cc = B.s_ccol[G.slot0 + m];
         if (cc >= 0) B.cv_graw[C.v_off + cc + within] = a;
     }
+}
+
+// stand-alone launch for priors larger than PRIOR_LDS_DIM (dynamic LDS)
+template <bool JAC>
+__global__ void __launch_bounds__(256) k_eval_prior(DevBatch B) {
+    extern __shared__ double sm_dyn[];
+    d_eval_prior<JAC>(B, blockIdx.x, sm_dyn);
 }
 
 // =========================================================================================

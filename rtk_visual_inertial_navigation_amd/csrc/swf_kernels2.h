@@ -1084,9 +1084,11 @@ struct Segs { int e[8]; };     // exclusive end block of segment k (cumulative)
 // Jacobian/residual evaluation of the one-lane-per-factor families: projection + scalar GNSS/prior factors
 template <bool JAC>
 __global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
+    __shared__ double sm_prior[2 * PRIOR_LDS_DIM + 16];
     int bid = blockIdx.x;
     if (bid < S.e[0]) d_eval_proj<JAC>(B, bid);
-    else d_eval_scalar<JAC>(B, bid - S.e[0]);
+    else if (bid < S.e[1]) d_eval_scalar<JAC>(B, bid - S.e[0]);
+    else d_eval_prior<JAC>(B, bid - S.e[1], sm_prior);        // one workgroup per prior (segment empty for large priors)
 }
 // after the reduced solve: back-substitution of the eliminated blocks, and |J D^-2 g|^2 for the Cauchy point
 __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S) {
@@ -1099,13 +1101,15 @@ __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S)
 }
 // after the dogleg step: model cost change J*step, and the candidate residuals of the one-lane families
 __global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs S) {
+    __shared__ double sm_prior[2 * PRIOR_LDS_DIM + 16];
     int bid = blockIdx.x;
     if (bid < S.e[0]) d_jtimes_proj<1>(B, O, bid);
     else if (bid < S.e[1]) d_jtimes_scalar<1>(B, O, bid - S.e[0]);
     else if (bid < S.e[2]) d_jtimes_imu<1>(B, O, bid - S.e[1]);
     else if (bid < S.e[3]) d_jtimes_prior<1>(B, O, bid - S.e[2]);
     else if (bid < S.e[4]) d_eval_proj<false>(B, bid - S.e[3]);
-    else d_eval_scalar<false>(B, bid - S.e[4]);
+    else if (bid < S.e[5]) d_eval_scalar<false>(B, bid - S.e[4]);
+    else d_eval_prior<false>(B, bid - S.e[5], sm_prior);
 }
 // diagonal + off-diagonal block assembly of the reduced system
 __global__ void __launch_bounds__(256) k_assemble_all(DevBatch B, DevOpt O, int write_S, Segs S) {
