@@ -713,7 +713,7 @@ struct Launcher {
             Segs S{}; S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
             hipLaunchKernelGGL(k_eval_ps<true>, dim3(S.e[2]), dim3(256), 0, st, D, S);
         }
-        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF(true)), 0, st, D); }
+        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, st, D); }
         if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
     }
     void lin_elim(int write_S) {
@@ -776,11 +776,16 @@ struct Launcher {
             S.e[2] = S.e[1] + nb((size_t)D.n_imu * 16, 256); S.e[3] = S.e[2] + nb((size_t)D.n_prior * 64, 256);
             S.e[4] = S.e[3] + nb(D.n_proj, 256); S.e[5] = S.e[4] + nb(D.n_sc, 256);
             S.e[6] = S.e[5] + (b->max_prior_dim <= PRIOR_LDS_DIM ? D.n_prior : 0);
-            if (S.e[6]) hipLaunchKernelGGL(k_post_dogleg, dim3(S.e[6]), dim3(256), 0, st, D, O, S);
+            // small batches (latency path): the candidate IMU residuals ride along as a segment; large batches keep them in
+            // their own launch (the segment's LDS would cost the memory-bound segments occupancy).  Same results either way.
+            bool fuse_imu = D.n_win < b->n_cu;
+            S.e[7] = S.e[6] + (fuse_imu ? nb(D.n_imu, IMU_FPB) : 0);
+            if (S.e[7] && fuse_imu) hipLaunchKernelGGL(k_post_dogleg<true>, dim3(S.e[7]), dim3(256), 0, st, D, O, S);
+            else if (S.e[7]) hipLaunchKernelGGL(k_post_dogleg<false>, dim3(S.e[7]), dim3(256), 0, st, D, O, S);
+            if (!fuse_imu && D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, st, D);
         }
         {
             Bracket t(*this, SWF_K_CAND_EVAL);
-            if (D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF(false)), 0, st, D);
             if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
         }
         { Bracket t(*this, SWF_K_DECIDE); hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(256), 0, st, D, O); }

@@ -239,17 +239,17 @@ __device__ void imu_unwhitened(const double* pi, const double* sbi, const double
 }
 
 #define IMU_FPB 8          // factors per block
-#define IMU_LPF(JAC) ((JAC) ? 32 : 16)   // lanes per factor: linearisation = 4 waves (one per un-whitened part), residual only = 2
+#define IMU_LPF 32         // lanes per factor: 256-thread blocks = 4 waves, one per un-whitened part (residual only: part 0 alone)
 template <bool JAC>
-__global__ void __launch_bounds__(IMU_FPB * IMU_LPF(JAC)) k_eval_imu(DevBatch B) {
-    constexpr int LPF = IMU_LPF(JAC);
+__device__ __forceinline__ void d_eval_imu(const DevBatch& B, int bid) {
+    constexpr int LPF = IMU_LPF;
     __shared__ double SI[IMU_FPB][225];
-    __shared__ double U[IMU_FPB][450];
+    __shared__ double U[JAC ? IMU_FPB : 1][JAC ? 450 : 1];    // Jacobian scratch: linearisation only
     __shared__ double raw[IMU_FPB][16];
     __shared__ double st[IMU_FPB][32];
     __shared__ double pr[IMU_FPB][SWF_PRE_SQRTINFO + 6];     // record head (dp .. gyr_j) | pbg | gw, staged by the factor's 16 lanes
     int tid = threadIdx.x, fl = tid / LPF, sub = tid % LPF;
-    int q = blockIdx.x * IMU_FPB + fl;
+    int q = bid * IMU_FPB + fl;
     bool valid = q < B.n_imu;
     int f = B.imu_gf[valid ? q : B.n_imu - 1];
     const GFac& G = B.gf[f];
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(IMU_FPB * IMU_LPF(JAC)) k_eval_imu(DevBatch B)
     if (act) {
         for (int k = sub; k < SWF_PRE_SQRTINFO; k += LPF) pr[fl][k] = pre[k];
         if (sub < 3) { pr[fl][SWF_PRE_SQRTINFO + sub] = W.pbg[sub]; pr[fl][SWF_PRE_SQRTINFO + 3 + sub] = W.gw[sub]; }
-        if (JAC) for (int k = sub; k < 450; k += LPF) U[fl][k] = 0.0;          // the serial lane only fills the non-zero blocks
+        if (JAC) for (int k = sub; k < 450; k += LPF) U[JAC ? fl : 0][k] = 0.0;          // the serial lane only fills the non-zero blocks
         for (int k = sub; k < 225; k += LPF) SI[fl][k] = pre[SWF_PRE_SQRTINFO + k];
         for (int k = sub; k < 32; k += LPF) {
             int sl = k < 7 ? 0 : k < 16 ? 1 : k < 23 ? 2 : 3;
@@ -273,13 +273,13 @@ __global__ void __launch_bounds__(IMU_FPB * IMU_LPF(JAC)) k_eval_imu(DevBatch B)
     // lanes 0..7 of each wave: one factor each, wave p = part p (residual-only evaluation: part 0 alone)
     if ((tid & 63) < IMU_FPB && (JAC || tid < 64)) {
         int part = tid >> 6, fq = tid & 63;
-        int q2 = blockIdx.x * IMU_FPB + fq;
+        int q2 = bid * IMU_FPB + fq;
         if (q2 < B.n_imu) {
             const GFac& G2 = B.gf[B.imu_gf[q2]];
             const WinState& s2 = B.ws[G2.win];
             if (JAC ? s2.need_lin : s2.eval_cand) {
                 imu_unwhitened(st[fq], st[fq] + 7, st[fq] + 16, st[fq] + 23, pr[fq],
-                               pr[fq] + SWF_PRE_SQRTINFO, pr[fq] + SWF_PRE_SQRTINFO + 3, raw[fq], U[fq], JAC, part);
+                               pr[fq] + SWF_PRE_SQRTINFO, pr[fq] + SWF_PRE_SQRTINFO + 3, raw[fq], U[JAC ? fq : 0], JAC, part);
             }
         }
     }
@@ -313,6 +313,9 @@ __global__ void __launch_bounds__(IMU_FPB * IMU_LPF(JAC)) k_eval_imu(DevBatch B)
         if (jo >= 0) B.g_J[jo + (col - cb[sl]) * G.jld + row] = U[fl][row * 30 + col];
     }
 }
+
+template <bool JAC>
+__global__ void __launch_bounds__(IMU_FPB * IMU_LPF) k_eval_imu(DevBatch B) { d_eval_imu<JAC>(B, blockIdx.x); }
 
 // =========================================================================================
 // scalar factors, one lane each:

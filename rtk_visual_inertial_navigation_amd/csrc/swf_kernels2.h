@@ -1099,7 +1099,8 @@ __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S)
     else if (bid < S.e[4]) d_jtimes_imu<0>(B, O, bid - S.e[3]);
     else d_jtimes_prior<0>(B, O, bid - S.e[4]);
 }
-// after the dogleg step: model cost change J*step, and the candidate residuals of the one-lane families
+// after the dogleg step: model cost change J*step, and the candidate residuals of every factor family
+template <bool WITH_IMU>
 __global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs S) {
     __shared__ double sm_prior[2 * PRIOR_LDS_DIM + 16];
     int bid = blockIdx.x;
@@ -1109,7 +1110,8 @@ __global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs 
     else if (bid < S.e[3]) d_jtimes_prior<1>(B, O, bid - S.e[2]);
     else if (bid < S.e[4]) d_eval_proj<false>(B, bid - S.e[3]);
     else if (bid < S.e[5]) d_eval_scalar<false>(B, bid - S.e[4]);
-    else d_eval_prior<false>(B, bid - S.e[5], sm_prior);
+    else if (bid < S.e[6]) d_eval_prior<false>(B, bid - S.e[5], sm_prior);
+    else if (WITH_IMU) d_eval_imu<false>(B, bid - S.e[6]);    // candidate IMU residuals (8 factors per workgroup), small batches only
 }
 // diagonal + off-diagonal block assembly of the reduced system
 __global__ void __launch_bounds__(256) k_assemble_all(DevBatch B, DevOpt O, int write_S, Segs S) {
