@@ -1138,10 +1138,23 @@ __device__ __forceinline__ double win_aux_sum(const DevBatch& B, const WinRec& W
 // per-thread partials (no reduction): cost and model term in one pass over the window's factors
 __device__ __forceinline__ void win_cost_aux_part(const DevBatch& B, const WinRec& W, double& c, double& a) {
     c = 0; a = 0;
-#pragma unroll 4
-    for (int i = W.proj0 + threadIdx.x; i < W.proj1; i += blockDim.x) { c += B.p_cost[i]; a += B.p_aux[i]; }
-#pragma unroll 4
-    for (int i = W.gf0 + threadIdx.x; i < W.gf1; i += blockDim.x) { c += B.g_cost[i]; a += B.g_aux[i]; }
+    // twelve guarded loads of each array in flight per thread (a 3000-observation window is one round); the adds
+    // stay in index order
+    constexpr int U = 12;
+    for (int base = W.proj0 + threadIdx.x; base < W.proj1; base += U * blockDim.x) {
+        double cv[U], av[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { int i = base + u * blockDim.x; bool ok = i < W.proj1; cv[u] = ok ? B.p_cost[i] : 0.0; av[u] = ok ? B.p_aux[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { c += cv[u]; a += av[u]; }
+    }
+    for (int base = W.gf0 + threadIdx.x; base < W.gf1; base += 4 * blockDim.x) {
+        double cv[4], av[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { int i = base + u * blockDim.x; bool ok = i < W.gf1; cv[u] = ok ? B.g_cost[i] : 0.0; av[u] = ok ? B.g_aux[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { c += cv[u]; a += av[u]; }
+    }
 }
 // || x ||_2 over variable blocks (ambient coordinates)
 __device__ __forceinline__ double win_x_norm(const DevBatch& B, const WinRec& W, const double* x, double* red) {
