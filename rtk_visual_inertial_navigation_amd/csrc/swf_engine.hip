@@ -687,6 +687,7 @@ static DevOpt to_devopt(const swf_options* o) {
 namespace {
 struct Launcher {
     swf_batch* b; DevOpt O; hipStream_t st;
+    bool lm_folded = false;     // k_lm_schur of the current linearisation wrote ONE folded product (else GEMM_SPLIT partials)
     // optional event pair around one launch
     struct Bracket {
         Launcher& L; int slot;
@@ -728,8 +729,10 @@ struct Launcher {
             int qpb = D.n_win >= 2 * b->n_cu ? 4 : D.n_win >= b->n_cu ? 2 : 1;
             if (force_qpb == 1 || force_qpb == 2 || force_qpb == 4) qpb = force_qpb;
             dim3 grid(D.n_win, GEMM_SPLIT / qpb);
-            if (b->max_tiles <= 16 && force < 1) hipLaunchKernelGGL((k_lm_schur<8, 2>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb);
-            else if (b->max_tiles <= 40 && force < 2) hipLaunchKernelGGL((k_lm_schur<8, 5>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb);
+            int tpw = (b->max_tiles <= 16 && force < 1) ? 2 : (b->max_tiles <= 40 && force < 2) ? 5 : 10;
+            lm_folded = qpb == GEMM_SPLIT && tpw <= 5;          // must mirror CAN_FOLD in k_lm_schur
+            if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb);
+            else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb);
             else hipLaunchKernelGGL((k_lm_schur<12, 10>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb);
         }
         {
@@ -742,7 +745,7 @@ struct Launcher {
         if (D.n_pd) {
             Bracket t(*this, SWF_K_ASSEMBLE);
             Segs S{}; S.e[0] = nb((size_t)D.n_pd * 64, 256); S.e[1] = S.e[0] + (write_S ? nb((size_t)D.n_po * 16, 256) : 0);
-            hipLaunchKernelGGL(k_assemble_all, dim3(S.e[1]), dim3(256), 0, st, D, O, write_S, S);
+            hipLaunchKernelGGL(k_assemble_all, dim3(S.e[1]), dim3(256), 0, st, D, O, write_S, S, lm_folded ? 1 : GEMM_SPLIT);
         }
     }
     void reduced() {

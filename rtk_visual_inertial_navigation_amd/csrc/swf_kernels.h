@@ -634,9 +634,11 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
         // fourth k-slot) and offset inside the cell
         int t_tr[TPW], t_tc[TPW], pk[TPW];                 // pk = fA | fB << 8 | subA << 16 | subB << 24 (one VGPR per slot)
         unsigned long long mA[TPW], mB[TPW];
-        double4_t acc[TPW];
+        constexpr bool CAN_FOLD = TPW <= 5;                 // the 10-slot variant has no registers to spare for the folded product
+        double4_t acc[TPW], tot[CAN_FOLD ? TPW : 1];
 #pragma unroll
         for (int sl = 0; sl < TPW; sl++) {
+            if (CAN_FOLD) tot[sl] = double4_t{ 0, 0, 0, 0 };
             int t = cw + sl * NCW;
             int tr = 0, tc = 0;
             if (t < ntiles) {
@@ -695,8 +697,17 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             __syncthreads();                                // chunk c consumed, chunk c+1 produced
             if (cw == 0) GSTAMP_ACC(10, tg);
         }
-        // flush this quarter's partial product and start the next one from zero
-        double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)(sp0 + sq) * m * m;
+        // end of a quarter.  A block that covers all four quarters folds them in registers in exactly the order
+        // k_assemble adds partials, ((P0 + P1) + P2) + P3 with every Pq summed from zero, and writes ONE product
+        // (slot 0; k_assemble is told to read one partial): same bits, a quarter of the P traffic.  Otherwise
+        // each quarter's partial product is flushed to its own slot.
+        bool fold = CAN_FOLD && qpb == GEMM_SPLIT;
+        if (fold) {
+#pragma unroll
+            for (int sl = 0; sl < TPW; sl++) { tot[CAN_FOLD ? sl : 0] = sq == 0 ? acc[sl] : tot[CAN_FOLD ? sl : 0] + acc[sl]; acc[sl] = double4_t{ 0, 0, 0, 0 }; }
+            if (sq + 1 < qpb) continue;
+        }
+        double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)(fold ? 0 : sp0 + sq) * m * m;
 #pragma unroll
         for (int sl = 0; sl < TPW; sl++) {
             int t = cw + sl * NCW;
@@ -704,7 +715,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     int r = t_tr[sl] * 16 + lk + 4 * q, c = t_tc[sl] * 16 + li;
-                    if (r < m && c < m) P[(size_t)r * m + c] = acc[sl][q];
+                    if (r < m && c < m) P[(size_t)r * m + c] = fold ? tot[CAN_FOLD ? sl : 0][q] : acc[sl][q];
                 }
             }
             acc[sl] = double4_t{ 0, 0, 0, 0 };
@@ -1137,7 +1148,7 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
 // DIAG = true : one wavefront per diagonal pair (needs wave reductions over the frame's observations)
 // DIAG = false: 16 lanes per off-diagonal pair (four pairs per wavefront; no cross-lane traffic)
 template <bool DIAG>
-__device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, int write_S, int bid) {
+__device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, int write_S, int bid, int n_part) {
     constexpr int G = DIAG ? 64 : 16;
     int gidx = (bid * blockDim.x + threadIdx.x) / G, lane = threadIdx.x % G;
     if (gidx >= (DIAG ? B.n_pd : B.n_po)) return;
@@ -1243,7 +1254,7 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
             size_t pi = (pr >= pc) ? (size_t)pr * m + pc : (size_t)pc * m + pr;
             double ps = 0;
 #pragma unroll
-            for (int q = 0; q < GEMM_SPLIT; q++) ps += P[(size_t)q * m * m + pi];     // fixed order
+            for (int q = 0; q < GEMM_SPLIT; q++) if (q < n_part) ps += P[(size_t)q * m * m + pi];     // fixed order (n_part = 1: folded by k_lm_schur)
             v -= ps;
             if (obs) { int hi = i > j ? i : j, lo = i > j ? j : i; v += H[hi * (hi + 1) / 2 + lo]; }
         }
