@@ -1281,3 +1281,117 @@ done:
     sum->minimizer_time_in_seconds = now_sec() - t0;
     return rc;
 }
+
+/* =====================================================================================
+ * Marginalisation consumer: what the reference does with the export of
+ * an is_optimize=false solve.
+ *   SWFOptimization::UpdateSchur            R/swf/swf_gnss.cpp:25-61
+ *   MarginalizationInfo::setmarginalizeinfo R/factor/marginalization_factor.cpp:449-488 (Sqrt = true)
+ * Eigen::SelfAdjointEigenSolver is restated as a cyclic two-sided Jacobi iteration with the
+ * eigenvalues returned in ascending order (Eigen's order).  Sign convention of rhs: b = J^T r,
+ * as in the in-tree MarginalizationInfo (ThreadsConstructA, marginalization_factor.cpp:97-121),
+ * so that the prior r = r0 + J dx has gradient J^T r0 = b.
+ * ===================================================================================== */
+static void sym_eig_jacobi(int n, double* A, double* V, double* w) {
+    /* A: n x n symmetric row-major (destroyed); V: columns = eigenvectors; w ascending */
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++) { diag += A[i * n + i] * A[i * n + i]; for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j]; }
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                double app = A[p * n + p], aqq = A[q * n + q];
+                double theta = (aqq - app) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {            /* columns p, q */
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {            /* rows p, q */
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+    for (int i = 0; i < n - 1; i++) {                    /* selection sort, ascending */
+        int k = i;
+        for (int j = i + 1; j < n; j++) if (w[j] < w[k]) k = j;
+        if (k != i) {
+            double t = w[i]; w[i] = w[k]; w[k] = t;
+            for (int r = 0; r < n; r++) { double v = V[r * n + i]; V[r * n + i] = V[r * n + k]; V[r * n + k] = v; }
+        }
+    }
+}
+
+/* S: hs x hs full symmetric row-major, rhs: hs; the trailing n_tail dims are the parameter_head states.
+ * Outputs (any may be NULL): A (n x n), b (n): the marginal system; J (n x n row-major), r0 (n): the prior;
+ * rank = number of eigenvalues of A above eps.  eps_mm is the pseudo-inverse threshold of UpdateSchur (1e-8 in
+ * the reference), eps that of setmarginalizeinfo (MarginalizationInfo::eps = 1e-8). */
+int oracle_marginalize(const double* S, const double* rhs, int32_t hs, int32_t n_tail, double eps_mm, double eps,
+                       double* A_out, double* b_out, double* J_out, double* r0_out, int32_t* rank_out) {
+    int n = n_tail, m = hs - n_tail;
+    if (n <= 0 || m < 0) return -1;
+    double* A = (double*)calloc((size_t)n * n, sizeof(double));
+    double* b = (double*)calloc((size_t)n, sizeof(double));
+    for (int i = 0; i < n; i++) { b[i] = rhs[m + i]; for (int j = 0; j < n; j++) A[i * n + j] = S[(size_t)(m + i) * hs + m + j]; }
+    if (m > 0) {
+        double* Amm = (double*)malloc(sizeof(double) * m * m);
+        double* V = (double*)malloc(sizeof(double) * m * m);
+        double* w = (double*)malloc(sizeof(double) * m);
+        double* T = (double*)malloc(sizeof(double) * m * (n + 1));      /* V^T [Amn | bm], then scaled */
+        for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Amm[i * m + j] = (j <= i) ? S[(size_t)i * hs + j] : S[(size_t)j * hs + i];
+        sym_eig_jacobi(m, Amm, V, w);
+        for (int k = 0; k < m; k++) {
+            double inv = w[k] > eps_mm ? 1.0 / w[k] : 0.0;
+            for (int j = 0; j <= n; j++) {
+                double acc = 0;
+                for (int i = 0; i < m; i++) acc += V[i * m + k] * (j < n ? S[(size_t)i * hs + m + j] : rhs[i]);
+                T[k * (n + 1) + j] = inv * acc;
+            }
+        }
+        /* X = V T = pinv(Amm) [Amn | bm];  A -= Anm X(:, :n),  b -= Anm X(:, n) */
+        double* X = (double*)malloc(sizeof(double) * m * (n + 1));
+        for (int i = 0; i < m; i++) for (int j = 0; j <= n; j++) {
+            double acc = 0;
+            for (int k = 0; k < m; k++) acc += V[i * m + k] * T[k * (n + 1) + j];
+            X[i * (n + 1) + j] = acc;
+        }
+        for (int r = 0; r < n; r++) {
+            for (int j = 0; j < n; j++) { double acc = 0; for (int i = 0; i < m; i++) acc += S[(size_t)(m + r) * hs + i] * X[i * (n + 1) + j]; A[r * n + j] -= acc; }
+            double acc = 0; for (int i = 0; i < m; i++) acc += S[(size_t)(m + r) * hs + i] * X[i * (n + 1) + n];
+            b[r] -= acc;
+        }
+        free(Amm); free(V); free(w); free(T); free(X);
+    }
+    if (A_out) memcpy(A_out, A, sizeof(double) * n * n);
+    if (b_out) memcpy(b_out, b, sizeof(double) * n);
+    {
+        double* Aw = (double*)malloc(sizeof(double) * n * n);
+        double* V = (double*)malloc(sizeof(double) * n * n);
+        double* w = (double*)malloc(sizeof(double) * n);
+        /* Eigen's SelfAdjointEigenSolver references the lower triangle only (A is symmetric up to rounding) */
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Aw[i * n + j] = (j <= i) ? A[i * n + j] : A[j * n + i];
+        sym_eig_jacobi(n, Aw, V, w);
+        int rank = 0;
+        for (int k = 0; k < n; k++) {
+            int keep = w[k] > eps;
+            rank += keep;
+            double sq = keep ? sqrt(w[k]) : 0.0, isq = keep ? sqrt(1.0 / w[k]) : 0.0, acc = 0;
+            for (int i = 0; i < n; i++) { if (J_out) J_out[k * n + i] = sq * V[i * n + k]; acc += V[i * n + k] * b[i]; }
+            if (r0_out) r0_out[k] = isq * acc;
+        }
+        if (rank_out) *rank_out = rank;
+        free(Aw); free(V); free(w);
+    }
+    free(A); free(b);
+    return 0;
+}

@@ -148,3 +148,19 @@ def cauchy_correct(a, r, J):
     r = np.array(r, dtype=np.float64); J = np.array(J, dtype=np.float64)
     cost = lib().oracle_cauchy_correct(C.c_double(a), _p(r), C.c_int(r.size), _p(J), C.c_int(J.shape[1]))
     return cost, r, J
+
+
+def marginalize(S, rhs, n_tail, eps_mm=1e-8, eps=1e-8):
+    """oracle_marginalize: UpdateSchur + setmarginalizeinfo(Sqrt=true).  Returns dict(A, b, J, r0, rank)."""
+    S = np.ascontiguousarray(S, dtype=np.float64); rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+    hs = S.shape[0]; n = int(n_tail)
+    A = np.zeros((n, n)); b = np.zeros(n); J = np.zeros((n, n)); r0 = np.zeros(n); rank = C.c_int32(0)
+    dp = C.POINTER(C.c_double)
+    f = lib().oracle_marginalize
+    f.restype = C.c_int
+    f.argtypes = [dp, dp, C.c_int32, C.c_int32, C.c_double, C.c_double, dp, dp, dp, dp, C.POINTER(C.c_int32)]
+    rc = f(S.ctypes.data_as(dp), rhs.ctypes.data_as(dp), hs, n, eps_mm, eps, A.ctypes.data_as(dp), b.ctypes.data_as(dp),
+           J.ctypes.data_as(dp), r0.ctypes.data_as(dp), C.byref(rank))
+    if rc != 0:
+        raise RuntimeError("oracle_marginalize failed")
+    return dict(A=A, b=b, J=J, r0=r0, rank=int(rank.value))

@@ -173,3 +173,61 @@ def test_golden_vectors():
         assert _rel(costs, gold["costs"]) < 1e-12
         assert np.array_equal(np.array([r["step_is_successful"] for r in sm.rows()]), gold["ok"])
         assert _rel(w.a["pose"], gold["pose"]) < 1e-10
+
+
+def _np_marginalize(S, rhs, n, eps_mm=1e-8, eps=1e-8):
+    """Independent restatement with LAPACK eigh (R/swf/swf_gnss.cpp:25-61, R/factor/marginalization_factor.cpp:449-488)."""
+    hs = S.shape[0]; m = hs - n
+    A = S[m:, m:].copy(); b = rhs[m:].copy()
+    if m:
+        w, V = np.linalg.eigh(S[:m, :m])
+        inv = np.where(w > eps_mm, 1.0 / np.where(w > eps_mm, w, 1.0), 0.0)
+        pinv = (V * inv) @ V.T
+        A = A - S[m:, :m] @ pinv @ S[:m, m:]
+        b = b - S[m:, :m] @ pinv @ rhs[:m]
+    w, V = np.linalg.eigh(A)
+    keep = w > eps
+    sq = np.where(keep, np.sqrt(np.where(keep, w, 0.0)), 0.0)
+    isq = np.where(keep, 1.0 / np.sqrt(np.where(keep, w, 1.0)), 0.0)
+    return dict(A=A, b=b, J=sq[:, None] * V.T, r0=isq * (V.T @ b), rank=int(keep.sum()), w=w)
+
+
+def test_marginalize_matches_numpy_on_a_reduced_system_and_on_rank_deficient_input():
+    # (1) the reduced system of a real RTK window, tail = the ambiguity states (parameter_head)
+    w = synth.make_window(3, K=6, F=30, S=6, seed=21)
+    so, ex = ob.solve(w.copy(), default_options(step_mode=1))
+    n_tail = 6
+    o = ob.marginalize(ex["S"], ex["rhs"], n_tail)
+    r = _np_marginalize(ex["S"], ex["rhs"], n_tail)
+    sc = np.abs(r["A"]).max()
+    # A = Ann - Anm pinv(Amm) Amn cancels large terms: both eigen-based evaluations carry ~1e-18 * cond(Amm)
+    # relative error (cond ~ 2.6e12 here: measured 1.4e-8 for the Jacobi restatement, 3.8e-7 for LAPACK eigh,
+    # both against the Cholesky form below)
+    m = ex["S"].shape[0] - n_tail
+    ev = np.linalg.eigvalsh(ex["S"][:m, :m])
+    tol = max(1e-10, 1e-18 * ev[-1] / ev[0])
+    scb = np.abs(ex["S"][m:, :m] @ np.linalg.solve(ex["S"][:m, :m], ex["rhs"][:m])).max() + np.abs(ex["rhs"][m:]).max()   # size of the cancelling terms
+    assert np.abs(o["A"] - r["A"]).max() <= tol * sc and np.abs(o["b"] - r["b"]).max() <= tol * scb
+    assert o["rank"] == r["rank"] == n_tail
+    # the square root is unique up to the sign of each eigenvector row: compare the invariants
+    Al = np.tril(o["A"]) + np.tril(o["A"], -1).T          # the solver references the lower triangle (as Eigen does)
+    assert np.abs(o["J"].T @ o["J"] - Al).max() <= 1e-12 * sc
+    assert np.abs(o["J"].T @ o["r0"] - o["b"]).max() <= 1e-10 * np.abs(o["b"]).max()
+    assert np.abs(o["J"].T @ o["J"] - r["J"].T @ r["J"]).max() <= tol * sc
+    assert np.allclose((o["J"] ** 2).sum(1), np.where(r["w"] > 1e-8, r["w"], 0.0), rtol=10 * tol, atol=tol * sc)   # row norms = eigenvalues, ascending
+    # A is also what the Cholesky factor of the export gives: L_nn L_nn^T (R/swf/swf_gnss.cpp:85-87)
+    L = ex["L"]
+    assert np.abs(L[m:, m:] @ L[m:, m:].T - o["A"]).max() <= tol * sc
+    # (2) rank-deficient: eigenvalues below the threshold are dropped in both stages
+    rng = np.random.default_rng(5)
+    for hs, n, rk in ((14, 6, 4), (9, 9, 5), (20, 8, 8)):
+        G = rng.standard_normal((hs + 3, hs)); G[:, :2] = 0.0          # two null directions in the m-block
+        if n == hs:
+            G = rng.standard_normal((rk, hs))                          # rank rk < n, no m-block
+        S = G.T @ G; rhs = S @ rng.standard_normal(hs)
+        o = ob.marginalize(S, rhs, n); r = _np_marginalize(S, rhs, n)
+        sc = np.abs(r["A"]).max()
+        assert o["rank"] == r["rank"]
+        assert np.abs(o["A"] - r["A"]).max() <= 1e-10 * sc
+        assert np.abs(o["J"].T @ o["J"] - r["J"].T @ r["J"]).max() <= 1e-10 * sc
+        assert np.abs(o["J"].T @ o["r0"] - r["J"].T @ r["r0"]).max() <= 1e-9 * max(1.0, np.abs(r["b"]).max())
