@@ -88,6 +88,26 @@ int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, double* rhs, do
 int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, double* diag, double* y);
 int swf_batch_dims(swf_batch* b, int32_t w, int32_t* n_loc, int32_t* n_e, int32_t* n_red);
 
+/* Marginalisation consumer: what the reference does with the export of an is_optimize = false solve —
+ * SWFOptimization::UpdateSchur (R/swf/swf_gnss.cpp:25-61) followed by MarginalizationInfo::setmarginalizeinfo(..., Sqrt =
+ * true) (R/factor/marginalization_factor.cpp:449-488).  Valid after a solve with step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY.
+ * For every window, with n = the local dimension of its parameter_head tail:
+ *   A  n x n   marginal information of the tail  (= S_nn - S_nm S_mm^-1 S_mn = L_nn L_nn^T)
+ *   bv n       its right-hand side               (= b_n  - S_nm S_mm^-1 b_m), sign convention b = J^T r
+ *   J  n x n, r0 n : the new linear prior r = r0 + J dx with J^T J = A, J^T r0 = bv:
+ *     SWF_PRIOR_EIGEN     J = sqrt(Lambda+) V^T (rows by ascending eigenvalue), r0 = Lambda+^-1/2 V^T bv, eigenvalues <= eps
+ *                         dropped — the reference's form; rank = number kept.  Eigenvector signs are not defined.
+ *     SWF_PRIOR_CHOLESKY  J = L_nn^T, r0 = L_nn^T y_n: the same quadratic without an eigen-decomposition (rank = n).
+ * The reference pseudo-inverts S_mm through an eigen-decomposition with threshold 1e-8; this library uses the Cholesky
+ * factor of the solve, which is the same thing whenever S_mm is positive definite.  If the factorisation failed the
+ * window's rank is reported as -1 (no silent fallback).  SWF_PRIOR_EIGEN: n <= 128 (the Jacobi iteration keeps M in LDS);
+ * SWF_PRIOR_CHOLESKY: n <= 512.  Asynchronous on the batch stream. */
+enum { SWF_PRIOR_EIGEN = 0, SWF_PRIOR_CHOLESKY = 1 };
+int swf_batch_marginalize(swf_batch* b, double eps, int32_t form);
+/* Results of the last swf_batch_marginalize for window w (synchronises).  Any pointer may be NULL; eig receives the n
+ * eigenvalues (ascending; for SWF_PRIOR_CHOLESKY the squared diagonal of L_nn). */
+int swf_batch_get_prior(swf_batch* b, int32_t w, double* A, double* bv, double* J, double* r0, double* eig, int32_t* n, int32_t* rank);
+
 /* Timing of the last swf_batch_solve, measured with HIP events recorded on the batch stream
  * around individual kernel launches (valid after swf_batch_sync).  `mask` selects which
  * kernels get an event pair per launch (bit k = SWF_K_*); bit 0 brackets the whole solve.
@@ -180,6 +200,12 @@ int swf_set_export_tail(swf_problem* p, double* const* keys, int32_t n);
 
 /* ceres::Solve(options, &problem, &summary) */
 int swf_problem_solve(swf_problem* p, const swf_options* opt, swf_summary* summary);
+/* UpdateSchur + setmarginalizeinfo(Sqrt = true) on the problem's export tail (R/swf/swf_image.cpp:404-418: is_optimize =
+ * false, Solve, UpdateSchur, setmarginalizeinfo): valid after swf_problem_solve with step_mode =
+ * SWF_ASSEMBLE_ELIMINATE_ONLY.  See swf_batch_marginalize for the outputs; buffers are solver-owned (n x n row-major / n),
+ * valid until the next solve, marginalize or destroy.  Any out pointer may be NULL. */
+int swf_problem_marginalize(swf_problem* p, double eps, int32_t form, const double** J, const double** r0,
+                            const double** A, const double** bv, int32_t* n, int32_t* rank);
 /* lhs_out / rhs_out / lhs_out2 / hs_row of the last solve; buffers solver-owned, valid until the
  * next solve or destroy. */
 int swf_get_reduced(swf_problem* p, const double** S, const double** rhs, const double** L, int32_t* hs_row);

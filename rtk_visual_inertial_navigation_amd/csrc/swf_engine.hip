@@ -15,6 +15,7 @@
 #include <vector>
 #include "../../include/swf_solver.h"
 #include "swf_kernels2.h"
+#include "swf_kernels3.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -70,6 +71,9 @@ struct swf_batch {
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
     int max_tiles = 0, max_prior_dim = 0, max_red = 0, n_cu = 256;
+    // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
+    int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr;
+    bool mg_valid = false; int mg_ld = 0;
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
     bool chol_rr1 = false;                // SWF_CHOL_RR1=1: first register-resident variant
     int timing = 0;                       // bitmask of SWF_K_* brackets
@@ -908,6 +912,47 @@ extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, doub
         for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++)
             L[r * n + c] = (c <= r) ? (rr ? Lt[r * n + c] : Lt[c * (n + 1) + r]) : 0.0;
     }
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
+    if (!b || (form != SWF_PRIOR_EIGEN && form != SWF_PRIOR_CHOLESKY) || !(eps >= 0.0)) return fail(SWF_E_INVALID, "swf_batch_marginalize: bad arguments");
+    if (b->last_mode != SWF_ASSEMBLE_ELIMINATE_ONLY) return fail(SWF_E_STATE, "swf_batch_marginalize needs a preceding solve with step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY");
+    if (b->max_red > 512 || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "marginalisation needs the row-major Cholesky factor (n_red <= 512)");
+    int nw = (int)b->win.size(), ldn = 1;
+    for (int w = 0; w < nw; w++) ldn = std::max(ldn, b->hw[w].tail_dim);
+    if (form == SWF_PRIOR_EIGEN && ldn > MG_MAXN) return fail(SWF_E_UNSUPPORTED, "eigen square root: parameter_head tail larger than 128 dimensions (use SWF_PRIOR_CHOLESKY)");
+    b->mg_ld = ldn;
+    if (!b->mg_A) {
+        std::vector<int> td(nw);
+        for (int w = 0; w < nw; w++) td[w] = b->hw[w].tail_dim;
+        const int* tdp = nullptr;
+        int rc = b->pool.put(td, &tdp);
+        b->mg_tail = (int*)tdp;
+        rc |= b->pool.zeros((size_t)nw * ldn * ldn, &b->mg_A); rc |= b->pool.zeros((size_t)nw * ldn * ldn, &b->mg_J);
+        rc |= b->pool.zeros((size_t)nw * ldn, &b->mg_b); rc |= b->pool.zeros((size_t)nw * ldn, &b->mg_r0); rc |= b->pool.zeros((size_t)nw * ldn, &b->mg_w);
+        rc |= b->pool.zeros((size_t)nw, &b->mg_rank);
+        if (rc) return fail(SWF_E_NODEVICE, "device allocation failed");
+    }
+    hipLaunchKernelGGL(k_marginalize, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
+                       b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank);
+    HIPCHK(hipGetLastError());
+    b->mg_valid = true;
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_get_prior(swf_batch* b, int32_t w, double* A, double* bv, double* J, double* r0, double* eig, int32_t* n_out, int32_t* rank) {
+    if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
+    if (!b->mg_valid) return fail(SWF_E_STATE, "swf_batch_get_prior before swf_batch_marginalize");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    size_t n = (size_t)b->hw[w].tail_dim, o2 = (size_t)w * b->mg_ld * b->mg_ld, o1 = (size_t)w * b->mg_ld;
+    if (n_out) *n_out = (int32_t)n;
+    if (A) HIPCHK(hipMemcpy(A, b->mg_A + o2, n * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (J) HIPCHK(hipMemcpy(J, b->mg_J + o2, n * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (bv) HIPCHK(hipMemcpy(bv, b->mg_b + o1, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (r0) HIPCHK(hipMemcpy(r0, b->mg_r0 + o1, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (eig) HIPCHK(hipMemcpy(eig, b->mg_w + o1, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (rank) HIPCHK(hipMemcpy(rank, b->mg_rank + w, sizeof(int32_t), hipMemcpyDeviceToHost));
     return SWF_OK;
 }
 

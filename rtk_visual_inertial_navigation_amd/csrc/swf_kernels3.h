@@ -1,0 +1,150 @@
+// swf_kernels3.h — marginalisation consumer: what the reference does with the export of an
+// is_optimize = false solve,
+//   SWFOptimization::UpdateSchur              R/swf/swf_gnss.cpp:25-61      A = S_nn - S_nm pinv(S_mm) S_mn, b likewise
+//   MarginalizationInfo::setmarginalizeinfo   R/factor/marginalization_factor.cpp:449-488 (Sqrt = true)
+//                                             J = sqrt(Lambda+) V^T,  r0 = Lambda+^-1/2 V^T b,  eigenvalues <= eps dropped
+// re-designed around what the solve already left on the device.  With S = L L^T in elimination order (parameter_head
+// last), the Schur complement onto the trailing n states IS L_nn L_nn^T, and b = A y_n with y = S^-1 rhs — no m x m
+// eigen-decomposition (the reference's pseudo-inverse equals the inverse whenever S_mm is positive definite, which
+// the successful Cholesky certifies; a failed factorisation is reported, not papered over).  The eigen square root of
+// A = M^T M, M = L_nn^T, comes from a ONE-SIDED (Hestenes) Jacobi on the columns of M held in LDS: it never forms A
+// for the iteration, works to high relative accuracy, and parallelises as n/2 independent column pairs per step.
+#pragma once
+#include "swf_dev.h"
+
+#define MG_MAXN 128                       // trailing dimension handled in one workgroup (M = 128 KB of LDS)
+#define MG_NT 1024                        // 64 sixteen-lane groups = 64 column pairs per step
+// form: 0 = eigen square root (the reference's prior), 1 = Cholesky square root J = L_nn^T, r0 = L_nn^T y_n (same quadratic)
+// ldn = leading dimension of the per-window output slabs (>= every window's tail dimension)
+__global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* tail_dim, double eps, int form, int ldn,
+                                                        double* outA, double* outb, double* outJ, double* outr0,
+                                                        double* outw, int* outrank) {
+    __shared__ double Mc[MG_MAXN][MG_MAXN];          // column c of M = L_nn^T, i.e. row c of L_nn (zero above its diagonal)
+    __shared__ double lam[MG_MAXN];
+    __shared__ double bv[MG_MAXN];
+    __shared__ int nrot;
+    int w = blockIdx.x, tid = threadIdx.x;
+    const WinRec& W = B.win[w];
+    const WinState& s = B.ws[w];
+    int n = tail_dim[w], nr = W.n_red, m = nr - n;
+    size_t o2 = (size_t)w * ldn * ldn, o1 = (size_t)w * ldn;
+    if (n <= 0 || n > ldn || m < 0 || s.lin_fail || (form == 0 && n > MG_MAXN)) { if (tid == 0) outrank[w] = -1; return; }
+    const double* L = B.L + W.Lt_base;                // row-major lower, ld = n_red (k_chol_rr2 / k_chol_big)
+    const double* y = B.y + W.loc_base + W.n_e + m;   // tail of the solution of S y = rhs
+    if (form == 1) {
+        // Cholesky square root, straight from the L buffer (no LDS residency, any tail up to ldn):
+        //   A = L_nn L_nn^T, b = A y_n = L_nn (L_nn^T y_n), J = L_nn^T, r0 = L_nn^T y_n;  J^T J = A, J^T r0 = b
+        const double* Ln = L + (size_t)m * nr + m;     // L_nn[i][r] = Ln[i * nr + r]
+        for (int e = tid; e < n * n; e += MG_NT) {
+            int i = e / n, j = e - i * n, k = i < j ? i : j;
+            double a = 0;
+            for (int r = 0; r <= k; r++) a += Ln[(size_t)i * nr + r] * Ln[(size_t)j * nr + r];
+            outA[o2 + e] = a;
+            outJ[o2 + e] = (j >= i) ? Ln[(size_t)j * nr + i] : 0.0;
+        }
+        for (int r = tid; r < n; r += MG_NT) {
+            double a = 0;
+            for (int c = r; c < n; c++) a += Ln[(size_t)c * nr + r] * y[c];
+            outr0[o1 + r] = a; outw[o1 + r] = Ln[(size_t)r * nr + r] * Ln[(size_t)r * nr + r];
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += MG_NT) {
+            double a = 0;
+            for (int r = 0; r <= i; r++) a += Ln[(size_t)i * nr + r] * outr0[o1 + r];
+            outb[o1 + i] = a;
+        }
+        if (tid == 0) outrank[w] = n;
+        return;
+    }
+    for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Mc[c][r] = (r <= c) ? L[(size_t)(m + c) * nr + m + r] : 0.0; }
+    __syncthreads();
+    // A = M^T M (= L_nn L_nn^T, the marginal information of the tail), b = A y_n
+    for (int e = tid; e < n * n; e += MG_NT) {
+        int i = e / n, j = e - i * n, k = i < j ? i : j;
+        double a = 0;
+        for (int r = 0; r <= k; r++) a += Mc[i][r] * Mc[j][r];
+        outA[o2 + e] = a;
+    }
+    __syncthreads();
+    // b = A y_n evaluated as L_nn (L_nn^T y_n), the same two triangular products as the Cholesky form (bit-identical b)
+    for (int r = tid; r < n; r += MG_NT) { double a = 0; for (int c = r; c < n; c++) a += Mc[c][r] * y[c]; lam[r] = a; }
+    __syncthreads();
+    for (int i = tid; i < n; i += MG_NT) {
+        double a = 0;
+        for (int r = 0; r <= i; r++) a += Mc[i][r] * lam[r];
+        bv[i] = a; outb[o1 + i] = a;
+    }
+    __syncthreads();
+    // ---- one-sided Jacobi: rotate column pairs of M until all columns are mutually orthogonal (M V = U Sigma).
+    // V is accumulated explicitly (same rotations applied to I): it stays orthogonal to machine precision, whereas
+    // U = M V / sigma loses orthogonality like eps * sqrt(cond) — measured 1.5e-9 in J^T r0 - b.  V lives in the
+    // window's J buffer (column c contiguous, L2-resident working set) until the final permuted write-out.
+    double* Vg = outJ + o2;
+    for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Vg[e] = (r == c) ? 1.0 : 0.0; }
+    __syncthreads();
+    int grp = tid >> 4, sub = tid & 15;
+    int ne = (n + 1) & ~1;                            // even number of players in the round-robin (a bye if n is odd)
+    for (int sweep = 0; sweep < 40; sweep++) {
+        if (tid == 0) nrot = 0;
+        __syncthreads();
+        for (int st = 0; st < ne - 1; st++) {
+            // circle method: player ne-1 is fixed, the others rotate; group k plays pair k of this step
+            int p = -1, q = -1;
+            if (grp < ne / 2) {
+                if (grp == 0) { p = ne - 1; q = st; }
+                else { p = (st + grp) % (ne - 1); q = (st - grp + (ne - 1)) % (ne - 1); }
+                if (p > q) { int t = p; p = q; q = t; }
+                if (q >= n) p = -1;                   // the bye
+            }
+            double al = 0, be = 0, ga = 0;
+            if (p >= 0) for (int r = sub; r < n; r += 16) { double a = Mc[p][r], b2 = Mc[q][r]; al += a * a; be += b2 * b2; ga += a * b2; }
+            al = grp16_sum(al); be = grp16_sum(be); ga = grp16_sum(ga);
+            if (p >= 0 && fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
+                double zeta = (be - al) / (2.0 * ga);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                double* vp = Vg + (size_t)p * n; double* vq = Vg + (size_t)q * n;
+                for (int r = sub; r < n; r += 16) {
+                    double a = Mc[p][r], b2 = Mc[q][r]; Mc[p][r] = c * a - sn * b2; Mc[q][r] = sn * a + c * b2;
+                    double va = vp[r], vb = vq[r]; vp[r] = c * va - sn * vb; vq[r] = sn * va + c * vb;
+                }
+                if (sub == 0) atomicAdd(&nrot, 1);
+            }
+            __syncthreads();
+        }
+        int done = nrot == 0;
+        __syncthreads();
+        if (done) break;
+    }
+    // eigenvalues = squared column norms of M V; J = Sigma V^T (row c = sigma_c v_c^T), r0 = Sigma^-1 V^T b; rows ordered
+    // by ascending eigenvalue as Eigen returns them.  The scaled columns are staged through LDS (M is done) because
+    // the sorted write-out permutes the buffer V sits in.
+    for (int c = grp; c < n; c += MG_NT / 16) {
+        double a = 0;
+        for (int r = sub; r < n; r += 16) a += Mc[c][r] * Mc[c][r];
+        a = grp16_sum(a);
+        if (sub == 0) lam[c] = a;
+    }
+    __syncthreads();
+    int rank = 0;
+    for (int c = 0; c < n; c++) rank += lam[c] > eps;                 // (cheap, every thread)
+    if (tid == 0) outrank[w] = rank;
+    for (int c = grp; c < n; c += MG_NT / 16) {
+        double lc = lam[c];
+        bool keep = lc > eps;
+        double sg = keep ? sqrt(lc) : 0.0;
+        double dotb = 0;
+        for (int j = sub; j < n; j += 16) { double v = Vg[(size_t)c * n + j]; Mc[c][j] = sg * v; dotb += v * bv[j]; }
+        dotb = grp16_sum(dotb);
+        int pos = 0;
+        for (int k = 0; k < n; k++) pos += (lam[k] < lc) || (lam[k] == lc && k < c);
+        if (sub == 0) { outr0[o1 + pos] = keep ? dotb / sg : 0.0; outw[o1 + pos] = lc; }
+    }
+    __syncthreads();
+    for (int c = grp; c < n; c += MG_NT / 16) {
+        double lc = lam[c];
+        int pos = 0;
+        for (int k = 0; k < n; k++) pos += (lam[k] < lc) || (lam[k] == lc && k < c);
+        for (int j = sub; j < n; j += 16) outJ[o2 + (size_t)pos * n + j] = Mc[c][j];
+    }
+}

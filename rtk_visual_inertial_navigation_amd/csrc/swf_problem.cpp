@@ -48,6 +48,7 @@ struct swf_problem {
     std::vector<double> proj_uv, imu_pre, cp_dat, pr_dat, dop_dat, sp_w, prior_J, prior_r0, prior_x0;
     // exports
     std::vector<double> S, rhs, L;
+    std::vector<double> mgA, mgb, mgJ, mgr0;      // swf_problem_marginalize outputs
     int hs_row = 0;
     bool solved = false;
 };
@@ -323,6 +324,21 @@ int swf_problem_solve(swf_problem* p, const swf_options* opt, swf_summary* summa
     p->S.assign(n * n, 0); p->rhs.assign(n, 0); p->L.assign(n * n, 0);
     if ((rc = swf_batch_export_reduced(p->batch, 0, p->S.data(), p->rhs.data(), p->L.data())) != SWF_OK) return rc;
     p->solved = true;
+    return SWF_OK;
+}
+
+int swf_problem_marginalize(swf_problem* p, double eps, int32_t form, const double** J, const double** r0,
+                            const double** A, const double** bv, int32_t* n_out, int32_t* rank) {
+    if (!p) return SWF_E_INVALID;
+    if (!p->solved || !p->batch) return SWF_E_STATE;
+    int rc;
+    if ((rc = swf_batch_marginalize(p->batch, eps, form)) != SWF_OK) return rc;
+    int32_t n = 0, rk = 0;
+    if ((rc = swf_batch_get_prior(p->batch, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &n, &rk)) != SWF_OK) return rc;
+    p->mgA.assign((size_t)n * n, 0); p->mgJ.assign((size_t)n * n, 0); p->mgb.assign((size_t)n, 0); p->mgr0.assign((size_t)n, 0);
+    if ((rc = swf_batch_get_prior(p->batch, 0, p->mgA.data(), p->mgb.data(), p->mgJ.data(), p->mgr0.data(), nullptr, &n, &rk)) != SWF_OK) return rc;
+    if (J) *J = p->mgJ.data(); if (r0) *r0 = p->mgr0.data(); if (A) *A = p->mgA.data(); if (bv) *bv = p->mgb.data();
+    if (n_out) *n_out = n; if (rank) *rank = rk;
     return SWF_OK;
 }
 

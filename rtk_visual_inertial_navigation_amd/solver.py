@@ -41,7 +41,8 @@ EXPORTED = [
     "swf_num_residual_blocks", "swf_add_projection", "swf_add_imu", "swf_add_rtk_carrier_phase",
     "swf_add_rtk_pseudorange", "swf_add_doppler", "swf_add_scalar_prior", "swf_add_linear_prior",
     "swf_remove_factor", "swf_factor_set_enabled", "swf_set_constants", "swf_set_ordering",
-    "swf_set_export_tail", "swf_problem_solve", "swf_get_reduced",
+    "swf_set_export_tail", "swf_problem_solve", "swf_get_reduced", "swf_problem_marginalize",
+    "swf_batch_marginalize", "swf_batch_get_prior",
 ]
 
 
@@ -141,6 +142,22 @@ class BatchSolver:
         _chk(lib().swf_batch_export_vectors(self._h, C.c_int32(w), g.ctypes.data_as(_pd), d.ctypes.data_as(_pd),
                                             y.ctypes.data_as(_pd)), "swf_batch_export_vectors")
         return g, d, y
+
+    PRIOR_EIGEN, PRIOR_CHOLESKY = 0, 1
+
+    def marginalize(self, eps=1e-8, form=0):
+        """UpdateSchur + setmarginalizeinfo(Sqrt=true) for every window, on the device, from the last
+        ASSEMBLE_ELIMINATE_ONLY solve (R/swf/swf_gnss.cpp:25-61, R/factor/marginalization_factor.cpp:449-488)."""
+        _chk(lib().swf_batch_marginalize(self._h, C.c_double(eps), C.c_int32(form)), "swf_batch_marginalize")
+
+    def get_prior(self, w=0):
+        n, rank = C.c_int32(0), C.c_int32(0)
+        _chk(lib().swf_batch_get_prior(self._h, C.c_int32(w), None, None, None, None, None, C.byref(n), C.byref(rank)), "swf_batch_get_prior")
+        k = n.value
+        A, J, b, r0, eig = np.zeros((k, k)), np.zeros((k, k)), np.zeros(k), np.zeros(k), np.zeros(k)
+        _chk(lib().swf_batch_get_prior(self._h, C.c_int32(w), A.ctypes.data_as(_pd), b.ctypes.data_as(_pd), J.ctypes.data_as(_pd),
+                                       r0.ctypes.data_as(_pd), eig.ctypes.data_as(_pd), C.byref(n), C.byref(rank)), "swf_batch_get_prior")
+        return dict(A=A, b=b, J=J, r0=r0, eig=eig, n=k, rank=rank.value)
 
     def enable_timing(self, mask=1):
         """mask: bit k brackets kernel K_NAMES[k] with a HIP event pair per launch (bit 0 = whole solve);
@@ -280,6 +297,16 @@ class Problem:
         sm = SummaryC()
         _chk(lib().swf_problem_solve(self._h, C.byref(opt), C.byref(sm)), "Solve")
         return sm
+
+    def Marginalize(self, eps=1e-8, form=0):
+        """UpdateSchur + setmarginalizeinfo(Sqrt=true) over the parameter_head blocks, after Solve with
+        step_mode = ASSEMBLE_ELIMINATE_ONLY (R/swf/swf_image.cpp:404-418).  Returns dict(J, r0, A, b, n, rank)."""
+        J, r0, A, b, n, rk = _pd(), _pd(), _pd(), _pd(), C.c_int32(), C.c_int32()
+        _chk(lib().swf_problem_marginalize(self._h, C.c_double(eps), C.c_int32(form), C.byref(J), C.byref(r0), C.byref(A), C.byref(b),
+                                           C.byref(n), C.byref(rk)), "Marginalize")
+        n = n.value
+        return dict(J=np.ctypeslib.as_array(J, (n, n)).copy(), r0=np.ctypeslib.as_array(r0, (n,)).copy(),
+                    A=np.ctypeslib.as_array(A, (n, n)).copy(), b=np.ctypeslib.as_array(b, (n,)).copy(), n=n, rank=rk.value)
 
     def GetReduced(self):
         S, r, L, n = _pd(), _pd(), _pd(), C.c_int32()

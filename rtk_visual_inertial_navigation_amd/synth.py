@@ -243,7 +243,7 @@ def _track_lengths(rng, F, K):
 
 # ------------------------------------------------------------------ window generator
 def make_window(config_id=3, seed=None, K=None, F=None, S=None, prior=None, perturb=True,
-                dt_kf=0.2, imu_rate=400, doppler=False):
+                dt_kf=0.2, imu_rate=400, doppler=False, head=None):
     """Build one synthetic window.  Returns a FlatWindow whose state is the (perturbed)
     initial guess; meta['truth'] holds the noise-free state."""
     cfg = dict(CONFIGS.get(config_id, CONFIGS[3]))
@@ -440,6 +440,16 @@ def make_window(config_id=3, seed=None, K=None, F=None, S=None, prior=None, pert
                  clocks=[bid_sc(i_clk0 + k) for k in range(K)] if S > 0 else [],
                  pr_corrections=[bid_sc(i_drift)] if use_dop else [],   # the drift scalar takes its own later group
                  prior_kept=list(prior_blk), parameter_head=[])
+    # ceres::internal::parameter_head (ordered last and exported / kept by the marginalisation consumer):
+    #   "ambiguities": the RTK ambiguity states (UpdateNParameterHead, R/swf/swf_gnss.cpp:100-116)
+    #   "frames":      every pose and speed-bias but the oldest frame's, plus the ambiguities — the neighbours a
+    #                  GlobalMarge of frame 0 keeps (R/swf/swf_image.cpp:343-433)
+    if head == "ambiguities":
+        roles["parameter_head"] = [bid_sc(i_amb0 + s) for s in range(S)]
+    elif head == "frames":
+        roles["parameter_head"] = ([bid_pose(k) for k in range(1, K)] + [bid_sb(k) for k in range(1, K)]
+                                   + [bid_sc(i_amb0 + s) for s in range(S)])
+    roles["parameter_head"] = [b for b in roles["parameter_head"] if b not in set(prior_blk)]
     order_block, order_group, n_tail = my_ordering(roles, is_const)
 
     win = FlatWindow(

@@ -170,6 +170,83 @@ def test_landmark_quarters_per_block_and_kernel_variant_do_not_change_results(mo
                 assert np.array_equal(x, y), env
 
 
+def test_marginalisation_consumer_matches_oracle():
+    """the new prior over the parameter_head states from an ASSEMBLE_ELIMINATE_ONLY solve.  The oracle
+    follows the reference literally (eigen pseudo-inverse of S_mm, eigen square root); the device path uses L_nn and a
+    one-sided Jacobi.  A square root is unique only up to the sign of each row, so the comparison is on A, b, the
+    eigenvalues, the rank and the invariants J^T J, J^T r0; tolerances carry cond(S_mm) as in the oracle's own test."""
+    for kw in (dict(config_id=3, K=6, F=30, S=6, seed=21, head="ambiguities"), dict(config_id=3, head="ambiguities"),
+               dict(config_id=3, K=6, F=40, S=7, seed=31, head="frames"), dict(config_id=2, K=9, F=60, S=0, seed=32, head="frames")):
+        w0 = synth.make_window(**kw)
+        so, eo = ob.solve(w0.copy(), default_options(step_mode=1))
+        bs, sg = gpu_solve(w0.copy(), default_options(step_mode=1))
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+        g = bs.get_prior(0)
+        n = g["n"]
+        assert n > 0
+        o = ob.marginalize(eo["S"], eo["rhs"], n)
+        m = eo["S"].shape[0] - n
+        ev = np.linalg.eigvalsh(eo["S"][:m, :m])
+        tol = max(1e-9, 1e-17 * ev[-1] / ev[0])
+        sc = np.abs(o["A"]).max()
+        scb = np.abs(eo["S"][m:, :m] @ np.linalg.solve(eo["S"][:m, :m], eo["rhs"][:m])).max() + np.abs(eo["rhs"][m:]).max()
+        assert np.abs(g["A"] - o["A"]).max() <= tol * sc
+        assert np.abs(g["b"] - o["b"]).max() <= tol * scb
+        assert g["rank"] == o["rank"]
+        lam_o = (o["J"] ** 2).sum(1)
+        assert np.allclose(g["eig"], lam_o, rtol=10 * tol, atol=tol * sc)
+        # the prior itself: exact square root of the device's own A, b, ascending rows
+        assert np.abs(g["J"].T @ g["J"] - g["A"]).max() <= 1e-12 * sc
+        assert np.abs(g["J"].T @ g["r0"] - g["b"]).max() <= 1e-9 * np.abs(g["b"]).max() + 1e-12 * scb
+        assert np.allclose((g["J"] ** 2).sum(1), g["eig"], rtol=1e-10) and np.all(np.diff(g["eig"]) >= 0)
+        assert np.abs(g["J"].T @ g["J"] - o["J"].T @ o["J"]).max() <= tol * sc
+        # rows agree with the oracle's up to sign wherever the eigenvalue is well separated
+        gap = np.minimum(np.diff(lam_o, prepend=-np.inf), np.diff(lam_o, append=np.inf))
+        for i in range(n):
+            if gap[i] > 1e-3 * lam_o[i]:
+                sgn = np.sign(g["J"][i] @ o["J"][i])
+                assert np.abs(sgn * g["J"][i] - o["J"][i]).max() <= 1e3 * tol * np.sqrt(lam_o[-1]) * lam_o[i] / gap[i]
+        # the Cholesky form is the same quadratic
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_CHOLESKY)
+        c = bs.get_prior(0)
+        assert np.array_equal(c["A"], g["A"]) and np.array_equal(c["b"], g["b"]) and c["rank"] == n
+        assert np.abs(c["J"].T @ c["J"] - c["A"]).max() <= 1e-12 * sc
+        assert np.abs(c["J"].T @ c["r0"] - c["b"]).max() <= 1e-9 * np.abs(c["b"]).max() + 1e-12 * scb
+        assert np.allclose(np.triu(c["J"]), c["J"])
+        bs.close()
+    # the ceres-shaped surface: GlobalMarge's sequence is_optimize = false; Solve; UpdateSchur; setmarginalizeinfo
+    w0 = synth.make_window(3, K=6, F=40, S=7, seed=31, head="frames")
+    P, blocks = solver.problem_from_window(w0.copy())
+    P.Solve(default_options(step_mode=1))
+    pm = P.Marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+    bs, _ = gpu_solve(w0.copy(), default_options(step_mode=1))
+    bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+    g = bs.get_prior(0)
+    assert pm["n"] == g["n"] and pm["rank"] == g["rank"]
+    for k in ("A", "b", "J", "r0"):
+        assert np.array_equal(pm[k], g[k]), k
+    bs.close(); P.close()
+    # a tail beyond the Jacobi kernel's LDS capacity: the Cholesky form still applies, the eigen form says so
+    wl = synth.make_window(3, K=12, F=60, S=6, seed=33, head="frames")
+    bs, _ = gpu_solve(wl.copy(), default_options(step_mode=1))
+    with pytest.raises(Exception):
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+    bs.marginalize(1e-8, solver.BatchSolver.PRIOR_CHOLESKY)
+    c = bs.get_prior(0)
+    S_, rhs_, L_ = bs.export_reduced(0)
+    m = S_.shape[0] - c["n"]
+    assert c["n"] > 128 and c["rank"] == c["n"]
+    assert np.abs(c["A"] - L_[m:, m:] @ L_[m:, m:].T).max() <= 1e-12 * np.abs(c["A"]).max()
+    assert np.abs(c["J"].T @ c["J"] - c["A"]).max() <= 1e-12 * np.abs(c["A"]).max()
+    assert np.abs(c["J"].T @ c["r0"] - c["b"]).max() <= 1e-10 * np.abs(c["b"]).max()
+    bs.close()
+    # call-order errors are reported
+    bs, _ = gpu_solve(synth.make_window(3, K=4, F=9, S=5, seed=8), default_options())
+    with pytest.raises(Exception):
+        bs.marginalize()
+    bs.close()
+
+
 def test_full_size_properties_cfg5_and_batch():
     """At BASELINE's full sizes (where the oracle is slow) check size-independent properties:
     monotone accepted costs, S = L L^T, S symmetric, gradient consistency g_f - H_fe y_e-part,

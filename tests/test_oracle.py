@@ -194,7 +194,7 @@ def _np_marginalize(S, rhs, n, eps_mm=1e-8, eps=1e-8):
 
 def test_marginalize_matches_numpy_on_a_reduced_system_and_on_rank_deficient_input():
     # (1) the reduced system of a real RTK window, tail = the ambiguity states (parameter_head)
-    w = synth.make_window(3, K=6, F=30, S=6, seed=21)
+    w = synth.make_window(3, K=6, F=30, S=6, seed=21, head="ambiguities")
     so, ex = ob.solve(w.copy(), default_options(step_mode=1))
     n_tail = 6
     o = ob.marginalize(ex["S"], ex["rhs"], n_tail)
