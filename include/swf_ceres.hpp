@@ -198,4 +198,24 @@ inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* s) {
     if (rc == SWF_OK) swf_get_reduced(p->handle(), &e.lhs_out, &e.rhs_out, &e.lhs_out2, &e.hs_row);
 }
 
+// The marginalisation consumer in one call: what SWFOptimization::UpdateSchur (R/swf/swf_gnss.cpp:25-61) followed by
+// MarginalizationInfo::setmarginalizeinfo(addr, sizes, A, b, true) (R/factor/marginalization_factor.cpp:449-488)
+// compute from the export of an is_optimize = false Solve.  Call it right after that Solve (GlobalMarge,
+// R/swf/swf_image.cpp:404-418).  linearized_jacobians / linearized_residuals are n x n row-major / n, solver-owned,
+// valid until the next Solve; A / b are the marginal system UpdateSchur leaves in SWFOptimization::A, b.
+struct MarginalPrior {
+    const double* linearized_jacobians = nullptr; const double* linearized_residuals = nullptr;
+    const double* A = nullptr; const double* b = nullptr;
+    int n = 0, rank = 0;
+};
+// eigen = true: the reference's eigen square root (n <= 128); false: the Cholesky square root (same quadratic, cheaper)
+inline bool UpdateSchurAndSetMarginalizeInfo(Problem* p, MarginalPrior* out, bool eigen = true, double eps = 1e-8) {
+    int32_t n = 0, rank = 0;
+    int rc = swf_problem_marginalize(p->handle(), eps, eigen ? SWF_PRIOR_EIGEN : SWF_PRIOR_CHOLESKY, &out->linearized_jacobians,
+                                     &out->linearized_residuals, &out->A, &out->b, &n, &rank);
+    out->n = n; out->rank = rank;
+    internal::parameter_head.clear();                       // as the reference's reader does (swf_gnss.cpp:58)
+    return rc == SWF_OK && rank >= 0;
+}
+
 }  // namespace swf_ceres

@@ -243,6 +243,14 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     y = y * __builtin_fma(-(h * y), y, 1.5);
     return y;
 }
+// 1/x: v_rcp_f64 + 2 Newton steps (same accuracy class as rsqrt_nr)
+__device__ __forceinline__ double rcp_nr(double x) {
+#pragma clang fp contract(off)
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * __builtin_fma(-x, r, 2.0);
+    r = r * __builtin_fma(-x, r, 2.0);
+    return r;
+}
 // value of lane (i + N) mod 16 of the same 16-lane row, through the DPP row-rotate path (no LDS crossbar).
 // On a value that is already symmetric under the coarser exchanges this equals the xor-N butterfly partner.
 template <int N>

@@ -14,12 +14,14 @@
 
 #define MG_MAXN 128                       // trailing dimension handled in one workgroup (M = 128 KB of LDS)
 #define MG_NT 1024                        // 64 sixteen-lane groups = 64 column pairs per step
+#define MG_LDS_DOUBLES 19712              // 154 KB: M for n <= 128 (16384), M and V together for n <= 99
+#define Mc(c, r) lds[(c) * n + (r)]
 // form: 0 = eigen square root (the reference's prior), 1 = Cholesky square root J = L_nn^T, r0 = L_nn^T y_n (same quadratic)
 // ldn = leading dimension of the per-window output slabs (>= every window's tail dimension)
 __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* tail_dim, double eps, int form, int ldn,
                                                         double* outA, double* outb, double* outJ, double* outr0,
                                                         double* outw, int* outrank) {
-    __shared__ double Mc[MG_MAXN][MG_MAXN];          // column c of M = L_nn^T, i.e. row c of L_nn (zero above its diagonal)
+    __shared__ double lds[MG_LDS_DOUBLES];           // M (n x n, column c contiguous: row c of L_nn) | V (n x n) if both fit
     __shared__ double lam[MG_MAXN];
     __shared__ double bv[MG_MAXN];
     __shared__ int nrot;
@@ -56,22 +58,22 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         if (tid == 0) outrank[w] = n;
         return;
     }
-    for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Mc[c][r] = (r <= c) ? L[(size_t)(m + c) * nr + m + r] : 0.0; }
+    for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Mc(c, r) = (r <= c) ? L[(size_t)(m + c) * nr + m + r] : 0.0; }
     __syncthreads();
     // A = M^T M (= L_nn L_nn^T, the marginal information of the tail), b = A y_n
     for (int e = tid; e < n * n; e += MG_NT) {
         int i = e / n, j = e - i * n, k = i < j ? i : j;
         double a = 0;
-        for (int r = 0; r <= k; r++) a += Mc[i][r] * Mc[j][r];
+        for (int r = 0; r <= k; r++) a += Mc(i, r) * Mc(j, r);
         outA[o2 + e] = a;
     }
     __syncthreads();
     // b = A y_n evaluated as L_nn (L_nn^T y_n), the same two triangular products as the Cholesky form (bit-identical b)
-    for (int r = tid; r < n; r += MG_NT) { double a = 0; for (int c = r; c < n; c++) a += Mc[c][r] * y[c]; lam[r] = a; }
+    for (int r = tid; r < n; r += MG_NT) { double a = 0; for (int c = r; c < n; c++) a += Mc(c, r) * y[c]; lam[r] = a; }
     __syncthreads();
     for (int i = tid; i < n; i += MG_NT) {
         double a = 0;
-        for (int r = 0; r <= i; r++) a += Mc[i][r] * lam[r];
+        for (int r = 0; r <= i; r++) a += Mc(i, r) * lam[r];
         bv[i] = a; outb[o1 + i] = a;
     }
     __syncthreads();
@@ -79,12 +81,14 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     // V is accumulated explicitly (same rotations applied to I): it stays orthogonal to machine precision, whereas
     // U = M V / sigma loses orthogonality like eps * sqrt(cond) — measured 1.5e-9 in J^T r0 - b.  V lives in the
     // window's J buffer (column c contiguous, L2-resident working set) until the final permuted write-out.
-    double* Vg = outJ + o2;
+    double* Vg = (2 * n * n <= MG_LDS_DOUBLES) ? lds + n * n : outJ + o2;      // LDS-resident V when it fits (n <= 99)
     for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Vg[e] = (r == c) ? 1.0 : 0.0; }
     __syncthreads();
     int grp = tid >> 4, sub = tid & 15;
     int ne = (n + 1) & ~1;                            // even number of players in the round-robin (a bye if n is odd)
+    int sweeps_done = 0;
     for (int sweep = 0; sweep < 40; sweep++) {
+        sweeps_done = sweep + 1;
         if (tid == 0) nrot = 0;
         __syncthreads();
         for (int st = 0; st < ne - 1; st++) {
@@ -92,20 +96,22 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
             int p = -1, q = -1;
             if (grp < ne / 2) {
                 if (grp == 0) { p = ne - 1; q = st; }
-                else { p = (st + grp) % (ne - 1); q = (st - grp + (ne - 1)) % (ne - 1); }
+                else { p = st + grp; if (p >= ne - 1) p -= ne - 1; q = st - grp; if (q < 0) q += ne - 1; }
                 if (p > q) { int t = p; p = q; q = t; }
                 if (q >= n) p = -1;                   // the bye
             }
             double al = 0, be = 0, ga = 0;
-            if (p >= 0) for (int r = sub; r < n; r += 16) { double a = Mc[p][r], b2 = Mc[q][r]; al += a * a; be += b2 * b2; ga += a * b2; }
+            if (p >= 0) for (int r = sub; r < n; r += 16) { double a = Mc(p, r), b2 = Mc(q, r); al += a * a; be += b2 * b2; ga += a * b2; }
             al = grp16_sum(al); be = grp16_sum(be); ga = grp16_sum(ga);
-            if (p >= 0 && fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
-                double zeta = (be - al) / (2.0 * ga);
-                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+            if (p >= 0 && ga * ga > 1e-30 * (al * be) && ga != 0.0) {
+                // rotation from v_rcp / v_rsq + Newton steps: this scalar chain is the critical path of a step
+                double zeta = (be - al) * (0.5 * rcp_nr(ga));
+                double hz = 1.0 + zeta * zeta;
+                double t = (zeta >= 0 ? 1.0 : -1.0) * rcp_nr(fabs(zeta) + hz * rsqrt_nr(hz));
+                double c = rsqrt_nr(1.0 + t * t), sn = c * t;
                 double* vp = Vg + (size_t)p * n; double* vq = Vg + (size_t)q * n;
                 for (int r = sub; r < n; r += 16) {
-                    double a = Mc[p][r], b2 = Mc[q][r]; Mc[p][r] = c * a - sn * b2; Mc[q][r] = sn * a + c * b2;
+                    double a = Mc(p, r), b2 = Mc(q, r); Mc(p, r) = c * a - sn * b2; Mc(q, r) = sn * a + c * b2;
                     double va = vp[r], vb = vq[r]; vp[r] = c * va - sn * vb; vq[r] = sn * va + c * vb;
                 }
                 if (sub == 0) atomicAdd(&nrot, 1);
@@ -121,20 +127,24 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     // the sorted write-out permutes the buffer V sits in.
     for (int c = grp; c < n; c += MG_NT / 16) {
         double a = 0;
-        for (int r = sub; r < n; r += 16) a += Mc[c][r] * Mc[c][r];
+        for (int r = sub; r < n; r += 16) a += Mc(c, r) * Mc(c, r);
         a = grp16_sum(a);
         if (sub == 0) lam[c] = a;
     }
     __syncthreads();
     int rank = 0;
     for (int c = 0; c < n; c++) rank += lam[c] > eps;                 // (cheap, every thread)
+#ifdef MG_DEBUG_SWEEPS
+    if (tid == 0) outrank[w] = sweeps_done;
+#else
     if (tid == 0) outrank[w] = rank;
+#endif
     for (int c = grp; c < n; c += MG_NT / 16) {
         double lc = lam[c];
         bool keep = lc > eps;
         double sg = keep ? sqrt(lc) : 0.0;
         double dotb = 0;
-        for (int j = sub; j < n; j += 16) { double v = Vg[(size_t)c * n + j]; Mc[c][j] = sg * v; dotb += v * bv[j]; }
+        for (int j = sub; j < n; j += 16) { double v = Vg[(size_t)c * n + j]; Mc(c, j) = sg * v; dotb += v * bv[j]; }
         dotb = grp16_sum(dotb);
         int pos = 0;
         for (int k = 0; k < n; k++) pos += (lam[k] < lc) || (lam[k] == lc && k < c);
@@ -145,6 +155,6 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         double lc = lam[c];
         int pos = 0;
         for (int k = 0; k < n; k++) pos += (lam[k] < lc) || (lam[k] == lc && k < c);
-        for (int j = sub; j < n; j += 16) outJ[o2 + (size_t)pos * n + j] = Mc[c][j];
+        for (int j = sub; j < n; j += 16) outJ[o2 + (size_t)pos * n + j] = Mc(c, j);
     }
 }

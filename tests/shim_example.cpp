@@ -1,5 +1,6 @@
 // Compile-only example: estimator code in the reference's style against include/swf_ceres.hpp.
 // (tests/test_host.py compiles it with g++ and links libswf_hip.so; it is only RUN on a GPU box.)
+#include <cmath>
 #include <cstdio>
 #include <vector>
 #include "swf_ceres.hpp"
@@ -40,5 +41,33 @@ int main() {
     ceres::Solver::Summary summary;
     ceres::Solve(my_options, &my_problem, &summary);
     std::printf("%s\n", summary.BriefReport().c_str());
-    return summary.final_cost > 1e10;
+    if (summary.final_cost > 1e10) return 1;
+    // GlobalMarge's sequence (R/swf/swf_image.cpp:404-418): keep pose1 as parameter_head, assemble + eliminate only,
+    // then UpdateSchur + setmarginalizeinfo in one call
+    // (two landmarks are held constant: 4 points seen from a fixed and a free camera give 8 constraints on the free
+    //  pose and the depths; with fewer than two fixed points the marginal information of pose1 is rank-deficient)
+    my_problem.SetParameterBlockConstant(pt[0]);
+    my_problem.SetParameterBlockConstant(pt[1]);
+    ordering->Clear();
+    ordering->AddElementToGroup(&blackvalue2, 0);
+    for (int i = 2; i < 4; i++) ordering->AddElementToGroup(pt[i], 0);
+    ordering->AddElementToGroup(pose1, 1);
+    ceres::internal::parameter_head.push_back(pose1);
+    ceres::internal::is_optimize = false;
+    ceres::Solve(my_options, &my_problem, &summary);
+    ceres::internal::is_optimize = true;
+    ceres::MarginalPrior mp;
+    if (!ceres::UpdateSchurAndSetMarginalizeInfo(&my_problem, &mp) || mp.n != 6 || mp.rank != 6) {
+        std::printf("marginalisation failed: n = %d rank = %d (%s)\n", mp.n, mp.rank, swf_last_error());
+        return 2;
+    }
+    // J^T J must reproduce the marginal information of pose1
+    double err = 0, sc = 0;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
+        double a = 0;
+        for (int k = 0; k < 6; k++) a += mp.linearized_jacobians[k * 6 + i] * mp.linearized_jacobians[k * 6 + j];
+        err = std::fmax(err, std::fabs(a - mp.A[i * 6 + j])); sc = std::fmax(sc, std::fabs(mp.A[i * 6 + j]));
+    }
+    std::printf("marginal prior: n = %d rank = %d  |J^T J - A| / |A| = %.2e\n", mp.n, mp.rank, err / sc);
+    return err > 1e-10 * sc;
 }

@@ -1,0 +1,35 @@
+"""Time the marginalisation consumer on the GPU against the oracle on one host thread.
+   python tools/bench_marginalize.py [windows]
+Workloads: (a) cfg3 windows, tail = the 10 RTK ambiguities (the ambiguity hand-off, UpdateNParameterHead);
+           (b) 7- and 8-keyframe windows, tail = every pose / speed-bias but the oldest frame's + ambiguities (a GlobalMarge)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_binding as ob
+from rtk_visual_inertial_navigation_amd import synth, solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+out = {}
+for name, kw in (("cfg3_ambiguities", dict(config_id=3, head="ambiguities")),
+                 ("kf7_frames", dict(config_id=3, K=7, F=100, S=8, head="frames")),
+                 ("kf8_frames", dict(config_id=3, K=8, F=120, S=8, head="frames"))):
+    ws = [synth.make_window(seed=synth.BASE_SEED + 100 + i, **kw) for i in range(B)]
+    bs = solver.BatchSolver(ws)
+    opt = default_options(step_mode=1)
+    res = {}
+    for form, fname in ((0, "eigen"), (1, "cholesky")):
+        for rep in range(3):
+            bs.reset_state(); bs.solve_async(opt); bs.sync()
+            t0 = time.perf_counter(); bs.marginalize(1e-8, form); bs.sync(); dt = time.perf_counter() - t0
+        res[fname + "_ms_per_batch"] = 1e3 * dt
+    g = bs.get_prior(0)
+    # oracle: export of window 0 -> UpdateSchur + setmarginalizeinfo on one host thread
+    so, ex = ob.solve(ws[0].copy(), opt)
+    t0 = time.perf_counter(); o = ob.marginalize(ex["S"], ex["rhs"], g["n"]); dt_o = time.perf_counter() - t0
+    res.update(windows=B, tail_dim=g["n"], reduced_dim=int(ex["S"].shape[0]), rank=g["rank"], oracle_ms_per_window_1thread=1e3 * dt_o,
+               gpu_us_per_window_eigen=1e3 * res["eigen_ms_per_batch"] / B, gpu_us_per_window_cholesky=1e3 * res["cholesky_ms_per_batch"] / B)
+    out[name] = res
+    bs.close()
+print(json.dumps(out))
