@@ -208,7 +208,7 @@ struct MarginalPrior {
     const double* A = nullptr; const double* b = nullptr;
     int n = 0, rank = 0;
 };
-// eigen = true: the reference's eigen square root (n <= 128); false: the Cholesky square root (same quadratic, cheaper)
+// eigen = true: the reference's eigen square root (n <= 140); false: the Cholesky square root (same quadratic, cheaper)
 inline bool UpdateSchurAndSetMarginalizeInfo(Problem* p, MarginalPrior* out, bool eigen = true, double eps = 1e-8) {
     int32_t n = 0, rank = 0;
     int rc = swf_problem_marginalize(p->handle(), eps, eigen ? SWF_PRIOR_EIGEN : SWF_PRIOR_CHOLESKY, &out->linearized_jacobians,

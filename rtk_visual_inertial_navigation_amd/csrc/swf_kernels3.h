@@ -12,9 +12,9 @@
 #pragma once
 #include "swf_dev.h"
 
-#define MG_MAXN 128                       // trailing dimension handled in one workgroup (M = 128 KB of LDS)
+#define MG_MAXN 140                       // trailing dimension handled in one workgroup (M = 153 KB of LDS)
 #define MG_NT 1024                        // 64 sixteen-lane groups = 64 column pairs per step
-#define MG_LDS_DOUBLES 19712              // 154 KB: M for n <= 128 (16384), M and V together for n <= 99
+#define MG_LDS_DOUBLES 19600              // 153 KB: M for n <= 140, M and V together for n <= 98
 #define Mc(c, r) lds[(c) * n + (r)]
 // form: 0 = eigen square root (the reference's prior), 1 = Cholesky square root J = L_nn^T, r0 = L_nn^T y_n (same quadratic)
 // ldn = leading dimension of the per-window output slabs (>= every window's tail dimension)
@@ -92,29 +92,29 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         if (tid == 0) nrot = 0;
         __syncthreads();
         for (int st = 0; st < ne - 1; st++) {
-            // circle method: player ne-1 is fixed, the others rotate; group k plays pair k of this step
-            int p = -1, q = -1;
-            if (grp < ne / 2) {
-                if (grp == 0) { p = ne - 1; q = st; }
-                else { p = st + grp; if (p >= ne - 1) p -= ne - 1; q = st - grp; if (q < 0) q += ne - 1; }
+            // circle method: player ne-1 is fixed, the others rotate; group k plays pair k (and k + 64) of this step
+            for (int pr = grp; pr < ne / 2; pr += MG_NT / 16) {
+                int p, q;
+                if (pr == 0) { p = ne - 1; q = st; }
+                else { p = st + pr; if (p >= ne - 1) p -= ne - 1; q = st - pr; if (q < 0) q += ne - 1; }
                 if (p > q) { int t = p; p = q; q = t; }
-                if (q >= n) p = -1;                   // the bye
-            }
-            double al = 0, be = 0, ga = 0;
-            if (p >= 0) for (int r = sub; r < n; r += 16) { double a = Mc(p, r), b2 = Mc(q, r); al += a * a; be += b2 * b2; ga += a * b2; }
-            al = grp16_sum(al); be = grp16_sum(be); ga = grp16_sum(ga);
-            if (p >= 0 && ga * ga > 1e-30 * (al * be) && ga != 0.0) {
-                // rotation from v_rcp / v_rsq + Newton steps: this scalar chain is the critical path of a step
-                double zeta = (be - al) * (0.5 * rcp_nr(ga));
-                double hz = 1.0 + zeta * zeta;
-                double t = (zeta >= 0 ? 1.0 : -1.0) * rcp_nr(fabs(zeta) + hz * rsqrt_nr(hz));
-                double c = rsqrt_nr(1.0 + t * t), sn = c * t;
-                double* vp = Vg + (size_t)p * n; double* vq = Vg + (size_t)q * n;
-                for (int r = sub; r < n; r += 16) {
-                    double a = Mc(p, r), b2 = Mc(q, r); Mc(p, r) = c * a - sn * b2; Mc(q, r) = sn * a + c * b2;
-                    double va = vp[r], vb = vq[r]; vp[r] = c * va - sn * vb; vq[r] = sn * va + c * vb;
+                if (q >= n) continue;                 // the bye (odd n)
+                double al = 0, be = 0, ga = 0;
+                for (int r = sub; r < n; r += 16) { double a = Mc(p, r), b2 = Mc(q, r); al += a * a; be += b2 * b2; ga += a * b2; }
+                al = grp16_sum(al); be = grp16_sum(be); ga = grp16_sum(ga);
+                if (ga * ga > 1e-30 * (al * be) && ga != 0.0) {
+                    // rotation from v_rcp / v_rsq + Newton steps: this scalar chain is the critical path of a step
+                    double zeta = (be - al) * (0.5 * rcp_nr(ga));
+                    double hz = 1.0 + zeta * zeta;
+                    double t = (zeta >= 0 ? 1.0 : -1.0) * rcp_nr(fabs(zeta) + hz * rsqrt_nr(hz));
+                    double c = rsqrt_nr(1.0 + t * t), sn = c * t;
+                    double* vp = Vg + (size_t)p * n; double* vq = Vg + (size_t)q * n;
+                    for (int r = sub; r < n; r += 16) {
+                        double a = Mc(p, r), b2 = Mc(q, r); Mc(p, r) = c * a - sn * b2; Mc(q, r) = sn * a + c * b2;
+                        double va = vp[r], vb = vq[r]; vp[r] = c * va - sn * vb; vq[r] = sn * va + c * vb;
+                    }
+                    if (sub == 0) atomicAdd(&nrot, 1);
                 }
-                if (sub == 0) atomicAdd(&nrot, 1);
             }
             __syncthreads();
         }
