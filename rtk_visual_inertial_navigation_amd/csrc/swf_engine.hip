@@ -75,7 +75,6 @@ struct swf_batch {
     int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr;
     bool mg_valid = false; int mg_ld = 0;
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
-    bool chol_rr1 = false;                // SWF_CHOL_RR1=1: first register-resident variant
     int timing = 0;                       // bitmask of SWF_K_* brackets
     swf_timing last{};
     std::vector<hipEvent_t> ev;           // event pool (pairs)
@@ -526,7 +525,6 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->stream = (hipStream_t)stream;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
-    b->chol_rr1 = getenv("SWF_CHOL_RR1") != nullptr;
     b->win = B.win; b->hw = hw; b->max_tiles = B.max_tiles; b->max_prior_dim = B.max_prior_dim; b->jac_bytes = B.jac_bytes;
     b->proj_bytes = (int64_t)312 * (int64_t)B.p_win.size();
     for (size_t l = 0; l + 1 < B.lm_obs0.size() + 1 && l < B.lm_win.size(); l++) {
@@ -755,9 +753,7 @@ struct Launcher {
     void reduced() {
         DevBatch& D = b->D;
         Bracket t(*this, SWF_K_CHOL);
-        if (b->max_red <= 240 && !b->force_chol_v1 && !b->chol_rr1) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
-        else if (b->max_red <= 224 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_rr<8>, dim3(D.n_win), dim3(1024), 0, st, D);
-        else if (b->max_red <= 240 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_rr<9>, dim3(D.n_win), dim3(1024), 0, st, D);
+        if (b->max_red <= 240 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
         else if (b->max_red <= 512 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_big, dim3(D.n_win), dim3(1024), 0, st, D);
         else if (b->max_red + 1 <= 256) hipLaunchKernelGGL(k_chol_solve<256>, dim3(D.n_win), dim3(256), 0, st, D);
         else hipLaunchKernelGGL(k_chol_solve<1024>, dim3(D.n_win), dim3(1024), 0, st, D);

@@ -25,13 +25,6 @@ struct DevOpt {
 };
 
 
-// per-observation record (AoS, 256 B = 4 cache lines), written by k_eval_proj / k_lm_elim:
-//   [0..11] Jp (2x6 row-major)  [12..17] Jl (2x3)  [18..19] r  [20..25] Y g_l  [26..31] pad
-#define PREC 32
-#define PREC_JP 0
-#define PREC_JL 12
-#define PREC_R 18
-#define PREC_YG 20
 
 #define CLIGHT_D 299792458.0
 #define OMGE_D 7.2921151467E-5

@@ -260,238 +260,6 @@ __global__ void __launch_bounds__(NT, NT == 256 ? CH_OCC : 4) k_chol_solve(DevBa
     CHSTAMP(2);
 }
 
-// =========================================================================================
-// Register-resident tiled Cholesky for n_red <= 240 (the BASELINE cfg2/cfg3 sizes), one
-// 16-wave workgroup per window.  Right-looking over 16x16 tiles:
-//   * every lower tile (I,J) of the matrix — plus one extra tile row carrying the right-hand
-//     side — lives in the registers of wave (I+J) mod 16 for the whole factorisation, in the
-//     fp64 MFMA C/D layout (lane l, reg q -> row (l>>4)+4q, col l&15): <= 9 tiles per wave;
-//   * step j: (1) the owner drops diagonal tile (j,j) into LDS; (2) wave 0 factors it in
-//     registers (lane = row, v_readlane broadcasts, hardware rsq + Newton for the pivots) and
-//     forms its inverse (lane = column, independent forward substitutions); (3) panel tiles
-//     L_ij = A_ij Linv_jj^T and (4) trailing updates A_ik -= L_ij L_kj^T both run on
-//     v_mfma_f64_16x16x4_f64 with operands read from the LDS panel (A[m][k]: lane = m+16k,
-//     B[k][n]: lane = n+16k);
-//   * the forward solve falls out of the extra tile row; the backward solve walks the
-//     register-resident tiles bottom-up using the stored inverse diagonal tiles.
-// L is written row-major (lower) for the export.  The predefined elimination order is untouched:
-// this is the plain dense Cholesky of S in that order, only tiled.
-// =========================================================================================
-template <int RR_NS>
-__global__ void __launch_bounds__(1024) k_chol_rr(DevBatch B) {
-    __shared__ double Pn[16][16][17];          // panel of the current column: tile row I -> L_Ij
-    __shared__ double Li[16][16][17];          // inverse diagonal tiles, Li[j][r][c] = Linv_jj[r][c]
-    __shared__ double Dt[16][17];              // diagonal tile in flight
-    __shared__ double dinv[16];
-    __shared__ double zs[256];
-    __shared__ double yv[256];
-    __shared__ double part[16][16];
-    __shared__ int sI_t[16][9], sJ_t[16][9];
-    __shared__ int fail;
-    int w = blockIdx.x;
-    WinState& st = B.ws[w];
-    if (!st.need_lin || st.lin_fail) return;
-    const WinRec& W = B.win[w];
-    int n = W.n_red, tid = threadIdx.x;
-    if (n <= 0) return;
-    int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    int Tc = (n + 15) >> 4, Tr = Tc + 1;       // column tiles; row tiles incl. the rhs tile row
-    const double* S = B.S + W.S_base;
-    const double* rhs = B.rhs + W.loc_base + W.n_e;
-    double* Lrm = B.L + W.Lt_base;             // row-major lower L, leading dimension n
-    // ---- my tiles: column J holds at most one tile of this wave, I = J + ((wv - 2J) & 15)
-    if (lane == 0) {
-        int cnt = 0;
-        for (int J = 0; J < Tc; J++) { int I = J + ((wv - 2 * J) & 15); if (I < Tr && cnt < 9) { sI_t[wv][cnt] = I; sJ_t[wv][cnt] = J; cnt++; } }
-        for (; cnt < 9; cnt++) { sI_t[wv][cnt] = -1; sJ_t[wv][cnt] = -1; }
-    }
-    if (tid == 0) fail = 0;
-    __syncthreads();
-    int sI[RR_NS], sJ[RR_NS];
-    double4_t acc[RR_NS];
-#pragma unroll
-    for (int s = 0; s < RR_NS; s++) {
-        sI[s] = sI_t[wv][s]; sJ[s] = sJ_t[wv][s];
-        double4_t v = { 0, 0, 0, 0 };
-        if (sI[s] >= 0) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int r = 16 * sI[s] + lk + 4 * q, c = 16 * sJ[s] + li;
-                double x = 0;
-                if (sI[s] < Tc) {
-                    if (r < n && c < n) x = (c <= r) ? S[(size_t)r * n + c] : 0.0;
-                    else x = (r == c) ? 1.0 : 0.0;                       // padding: unit diagonal
-                } else if (lk + 4 * q == 0) x = (c < n) ? rhs[c] : 0.0;  // rhs rides in row 0 of tile row Tc
-                v[q] = x;
-            }
-        }
-        acc[s] = v;
-    }
-#ifdef SWF_PROFILE_CHOL
-    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 64; i++) g_chol_stamps[i] = 0;
-    unsigned long long tph = __builtin_amdgcn_s_memtime();
-    CHSTAMP(0);
-#endif
-    // ---- factorisation
-    for (int j = 0; j < Tc; j++) {
-#ifdef SWF_PROFILE_CHOL
-        tph = __builtin_amdgcn_s_memtime();
-#endif
-        // (1) owner publishes the diagonal tile
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++)
-            if (sI[s] == j && sJ[s] == j) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) Dt[lk + 4 * q][li] = acc[s][q];
-            }
-        __syncthreads();
-#ifdef SWF_PROFILE_CHOL
-        CHACC(8, tph); tph = __builtin_amdgcn_s_memtime();
-#endif
-        // (2) wave 0: factor (lane = row) and invert (lane = column)
-        if (wv == 0) {
-            double d[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) d[c] = (lane < 16 && c <= lane) ? Dt[lane][c] : 0.0;
-            bool bad = false;
-            double ipv = 0;
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                double dp = readlane_d(d[c], c);
-                if (!(dp > 0.0)) bad = true;
-                double ip = rsqrt_nr(dp);
-                d[c] = (lane == c) ? dp * ip : (lane > c ? d[c] * ip : d[c]);
-                if (lane == c) ipv = ip;
-#pragma unroll
-                for (int c2 = c + 1; c2 < 16; c2++) {
-                    double l2 = readlane_d(d[c], c2);
-                    if (lane >= c2) d[c2] -= d[c] * l2;
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; c++) Dt[lane][c] = (c <= lane) ? d[c] : 0.0;
-                dinv[lane] = ipv;
-            }
-            if (bad && lane == 0) fail = 1;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            // column c of Linv by forward substitution (lane = column): x[c] = 1/L_cc,
-            // x[r>c] = -(sum_k L[r][k] x[k]) / L_rr ; L is read back from LDS (uniform addresses)
-            double x[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = (r == lane) ? ipv : 0.0;
-#pragma unroll
-            for (int r = 1; r < 16; r++) {
-                double s0 = 0, s1 = 0;
-#pragma unroll
-                for (int k = 0; k < r; k += 2) { s0 += Dt[r][k] * x[k]; if (k + 1 < r) s1 += Dt[r][k + 1] * x[k + 1]; }
-                double v = -(s0 + s1) * dinv[r];
-                x[r] = (r > lane) ? v : x[r];
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) Li[j][r][lane] = x[r];
-            }
-        }
-        __syncthreads();
-#ifdef SWF_PROFILE_CHOL
-        CHACC(9, tph); tph = __builtin_amdgcn_s_memtime();
-#endif
-        if (fail) { if (tid == 0) st.lin_fail = 1; return; }
-        // (3) panel tiles of column j: L_ij = A_ij * Linv^T ; diagonal owner takes L_jj back
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++) {
-            if (sJ[s] != j) continue;
-            int I = sI[s];
-            if (I == j) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) acc[s][q] = Dt[lk + 4 * q][li];
-                continue;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = acc[s][q];
-        }
-        // same-wave hand-off through LDS (C-layout store -> A-layout load): make the stores land
-        // and pin the compiler's order; no workgroup barrier needed, only this wave touches Pn[I]
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++) {
-            if (sJ[s] != j || sI[s] == j) continue;
-            int I = sI[s];
-            double4_t X = { 0, 0, 0, 0 };
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[I][li][lk + 4 * kk], Li[j][li][lk + 4 * kk], X, 0, 0, 0);
-            acc[s] = X;
-#pragma unroll
-            for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = X[q];
-        }
-        __syncthreads();
-#ifdef SWF_PROFILE_CHOL
-        CHACC(10, tph); tph = __builtin_amdgcn_s_memtime();
-#endif
-        // (4) trailing update of my tiles to the right of column j
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++) {
-            int J = sJ[s], I = sI[s];
-            if (J <= j || I < 0) continue;
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[I][li][lk + 4 * kk], Pn[J][li][lk + 4 * kk], acc[s], 0, 0, 0);
-        }
-        // no barrier needed here: the next step touches Dt / Li before Pn is rewritten, behind two barriers
-        // no barrier needed here: the next step touches Dt / Li before Pn is rewritten, behind two barriers
-#ifdef SWF_PROFILE_CHOL
-        CHACC(11, tph);
-#endif
-    }
-    CHSTAMP(1);
-    // ---- export L (row-major lower) and collect y = L^-1 rhs from the rhs tile row
-#pragma unroll
-    for (int s = 0; s < RR_NS; s++) {
-        int I = sI[s], J = sJ[s];
-        if (I < 0) continue;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int r = 16 * I + lk + 4 * q, c = 16 * J + li;
-            if (I < Tc) { if (r < n && c <= r) Lrm[(size_t)r * n + c] = acc[s][q]; }
-            else if (lk + 4 * q == 0) yv[c] = acc[s][q];
-        }
-    }
-    for (int e = tid; e < 256; e += 1024) zs[e] = 0.0;
-    __syncthreads();
-    // ---- backward solve L^T z = y, tile columns from the right
-    for (int J = Tc - 1; J >= 0; J--) {
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++) {
-            if (sJ[s] != J || sI[s] <= J || sI[s] >= Tc) continue;
-            int I = sI[s];
-            double p = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) p += acc[s][q] * zs[16 * I + lk + 4 * q];
-            p += __shfl_xor(p, 16, 64);
-            p += __shfl_xor(p, 32, 64);
-            if (lk == 0) part[I][li] = p;
-        }
-        __syncthreads();
-        if (tid < 16) {
-            double b = yv[16 * J + tid];
-            for (int I = J + 1; I < Tc; I++) b -= part[I][tid];
-            Dt[0][tid] = b;
-        }
-        __syncthreads();
-        if (tid < 16) {
-            double z = 0;
-            for (int r = tid; r < 16; r++) z += Li[J][r][tid] * Dt[0][r];      // Linv^T b
-            zs[16 * J + tid] = z;
-        }
-        __syncthreads();
-    }
-    double* y = B.y + W.loc_base + W.n_e;
-    for (int e = tid; e < n; e += 1024) y[e] = zs[e];
-    CHSTAMP(2);
-}
-
 // Factor and invert one 16x16 SPD tile with the 64 lanes of one wavefront (shared by k_chol_rr2 and k_chol_big).
 // D: the full symmetric tile in LDS, overwritten by L (lower, zeros above); LiJ: receives L^-1 (lower).  Returns
 // true if a pivot was not positive.
@@ -555,7 +323,7 @@ __device__ __forceinline__ bool chol_pivot_tile(double (*D)[17], double (*LiJ)[1
 // Step j:  [pivot: factor tile j]  B_j  [panel column j on MFMA]  C_j  [owner updates tile
 // (j+1,j+1) first and publishes it]  A_{j+1}  [remaining trailing updates  ||  pivot: factor
 // tile j+1].  Three workgroup barriers per step; every wave executes the same barrier sequence.
-// Same arithmetic as k_chol_rr (plain dense Cholesky in the predefined order, tiled).
+// Plain dense Cholesky of S in the predefined elimination order, only tiled.
 // =========================================================================================
 template <int RR_NS>
 __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
