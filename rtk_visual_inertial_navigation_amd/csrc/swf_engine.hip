@@ -723,8 +723,7 @@ struct Launcher {
         DevBatch& D = b->D;
         if (D.n_lm) {
             Bracket t(*this, SWF_K_LM_SCHUR);
-            // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames; this one
-            // spills under the 128-VGPR cap of a 1024-thread block — an <8,15> variant in 768 threads was measured: worse);
+            // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames);
             // quarters per block: as many as still leave >= 2 blocks per CU (the result does not depend on it)
             const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;     // test / debugging aids, read per launch
             const int force_qpb = getenv("SWF_LS_QPB") ? atoi(getenv("SWF_LS_QPB")) : 0;
@@ -732,10 +731,14 @@ struct Launcher {
             if (force_qpb == 1 || force_qpb == 2 || force_qpb == 4) qpb = force_qpb;
             dim3 grid(D.n_win, GEMM_SPLIT / qpb);
             int tpw = (b->max_tiles <= 16 && force < 1) ? 2 : (b->max_tiles <= 40 && force < 2) ? 5 : 10;
-            lm_folded = qpb == GEMM_SPLIT && tpw <= 5;          // must mirror CAN_FOLD in k_lm_schur
-            if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb);
-            else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb);
-            else hipLaunchKernelGGL((k_lm_schur<12, 10>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb);
+            lm_folded = qpb == GEMM_SPLIT && tpw <= 5;          // must mirror CAN_FOLD in k_lm_schur (tpw 10 = the 1024-thread variant: no fold)
+            if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb, 0);
+            else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb, 0);
+            else {
+                // up to 120 tiles: two launches of the 12-consumer-wave, 5-slot variant (tiles 0..59, 60..119)
+                hipLaunchKernelGGL((k_lm_schur<12, 5>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb, 0);
+                if (write_S && b->max_tiles > 60) hipLaunchKernelGGL((k_lm_schur<12, 5>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb, 60);
+            }
         }
         {
             Bracket t(*this, SWF_K_CLIQUE_ELIM);

@@ -597,9 +597,11 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 #define LS_LPC 16                             // landmarks per chunk = 16-lane groups of the producer waves
 #define LS_CAP 192                            // observation cells per chunk and buffer (host chunk table honours both)
 #define LS_MAXF 40
-// NCW consumer waves with TPW tile slots each: <8,2> (<= 16 tiles), <8,5> (<= 40), <12,10> (<= 120)
+// NCW consumer waves with TPW tile slots each, tiles tile_base + [0, NCW * TPW): <8,2> (<= 16 tiles), <8,5> (<= 40),
+// <12,5> twice (<= 120: tile_base 0 and 60; a single 10-slot variant spills under the 128-VGPR cap of 1024 threads —
+// both launches redo the cheap producer work instead)
 template <int NCW, int TPW>
-__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int do_gemm, int qpb) {
+__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int do_gemm, int qpb, int tile_base) {
     constexpr int NPW = LS_NPW;
     __shared__ double cells[2][(LS_CAP + 1) * LS_CS];      // + one all-zero cell per buffer
     __shared__ int tbl[2][LS_LPC][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
@@ -627,12 +629,12 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
         // fourth k-slot) and offset inside the cell
         int t_tr[TPW], t_tc[TPW], pk[TPW];                 // pk = fA | fB << 8 | subA << 16 | subB << 24 (one VGPR per slot)
         unsigned long long mA[TPW], mB[TPW];
-        constexpr bool CAN_FOLD = TPW <= 5;                 // the 10-slot variant has no registers to spare for the folded product
+        constexpr bool CAN_FOLD = TPW <= 5 && NCW == 8;     // 768-thread blocks have the registers for the folded product
         double4_t acc[TPW], tot[CAN_FOLD ? TPW : 1];
 #pragma unroll
         for (int sl = 0; sl < TPW; sl++) {
             if (CAN_FOLD) tot[sl] = double4_t{ 0, 0, 0, 0 };
-            int t = cw + sl * NCW;
+            int t = tile_base + cw + sl * NCW;
             int tr = 0, tc = 0;
             if (t < ntiles) {
                 while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
@@ -703,7 +705,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
         double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)(fold ? 0 : sp0 + sq) * m * m;
 #pragma unroll
         for (int sl = 0; sl < TPW; sl++) {
-            int t = cw + sl * NCW;
+            int t = tile_base + cw + sl * NCW;
             if (t < ntiles) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {

@@ -47,10 +47,10 @@ CASES = [
     dict(config_id=5, K=14, F=40, S=4, seed=10),      # dense marginalisation prior over 13 poses
     dict(config_id=3, K=6, F=30, S=6, seed=5, doppler=True),   # + Doppler factors and a clock-drift state
     dict(config_id=3, K=26, F=40, S=5, seed=11),      # > 21 frames: the 12-consumer-wave k_lm_schur variant; tracks of 17..26
-                                                      # observations span two 16-lane groups; n_red > 240: fallback Cholesky
+                                                      # observations span two 16-lane groups; n_red > 240: the streaming Cholesky
     dict(config_id=2, K=38, F=24, S=0, seed=12),      # tracks of 33..38 observations span four groups (a whole producer wave)
     dict(config_id=5),                                # the full stress configuration: 40 KF / 1000 features / 20 sats / dense prior,
-                                                      # n_red = 440 (k_chol_big), 120 tiles (the 10-slot k_lm_schur variant)
+                                                      # n_red = 440 (k_chol_big), 120 tiles (two launches of the 12-consumer-wave k_lm_schur variant)
 ]
 
 
