@@ -74,6 +74,13 @@ struct swf_batch {
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
     int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr;
     bool mg_valid = false; int mg_ld = 0;
+    // latency path (small batches): an auxiliary stream runs the IMU / clique branch of a linearisation next to the
+    // projection / landmark branch; three reusable events carry the dependencies
+    hipStream_t aux = nullptr; hipEvent_t ev_fork[3] = { nullptr, nullptr, nullptr };
+    ~swf_batch() {
+        if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+        for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
+    }
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
     int timing = 0;                       // bitmask of SWF_K_* brackets
     swf_timing last{};
@@ -525,6 +532,11 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->stream = (hipStream_t)stream;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
+    if (n * 16 <= b->n_cu && !getenv("SWF_NO_AUX_STREAM")) {            // latency path: fork / join inside a linearisation
+        bool ok = hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&b->ev_fork[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { if (b->aux) (void)hipStreamDestroy(b->aux); b->aux = nullptr; }
+    }
     b->win = B.win; b->hw = hw; b->max_tiles = B.max_tiles; b->max_prior_dim = B.max_prior_dim; b->jac_bytes = B.jac_bytes;
     b->proj_bytes = (int64_t)312 * (int64_t)B.p_win.size();
     for (size_t l = 0; l + 1 < B.lm_obs0.size() + 1 && l < B.lm_win.size(); l++) {
@@ -644,6 +656,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
 
 extern "C" int swf_batch_destroy(swf_batch* b) {
     if (!b) return SWF_OK;
+    (void)hipStreamSynchronize(b->stream);
     for (auto& e : b->ev) (void)hipEventDestroy(e);
     b->pool.release();
     delete b;
@@ -692,8 +705,8 @@ struct Launcher {
     bool lm_folded = false;     // k_lm_schur of the current linearisation wrote ONE folded product (else GEMM_SPLIT partials)
     // optional event pair around one launch
     struct Bracket {
-        Launcher& L; int slot;
-        Bracket(Launcher& l, int kind) : L(l), slot(-1) {
+        Launcher& L; int slot; hipStream_t bst;
+        Bracket(Launcher& l, int kind, hipStream_t on = nullptr) : L(l), slot(-1), bst(on ? on : l.st) {
             swf_batch* b = L.b;
             if (!(b->timing & (1 << kind))) return;
             if ((size_t)(b->ev_used + 1) * 2 > b->ev.size()) {
@@ -703,20 +716,26 @@ struct Launcher {
             }
             slot = b->ev_used++;
             b->ev_kind.push_back(kind);
-            (void)hipEventRecord(b->ev[2 * slot], L.st);
+            (void)hipEventRecord(b->ev[2 * slot], bst);
         }
-        ~Bracket() { if (slot >= 0) (void)hipEventRecord(L.b->ev[2 * slot + 1], L.st); }
+        ~Bracket() { if (slot >= 0) (void)hipEventRecord(L.b->ev[2 * slot + 1], bst); }
     };
     static int nb(size_t n, int per) { return (int)((n + per - 1) / per); }
+    // One linearisation.  Dependencies: the cliques need the IMU and the scalar-factor Jacobians (k_eval_imu, k_eval_ps);
+    // k_lm_schur needs k_eval_ps; k_frame_sums needs k_lm_schur (Y g_l); k_assemble_all needs everything.  With an auxiliary
+    // stream (small batches) the IMU / clique branch runs next to the projection / landmark branch.
     void lin_eval() {
         DevBatch& D = b->D;
+        hipStream_t sa = b->aux ? b->aux : st;
+        if (b->aux) { (void)hipEventRecord(b->ev_fork[0], st); (void)hipStreamWaitEvent(b->aux, b->ev_fork[0], 0); }
         if (D.n_proj + D.n_sc + D.n_prior) {
             Bracket t(*this, SWF_K_EVAL_PS);
             bool pf = b->max_prior_dim <= PRIOR_LDS_DIM;          // priors fused as a segment
             Segs S{}; S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
             hipLaunchKernelGGL(k_eval_ps<true>, dim3(S.e[2]), dim3(256), 0, st, D, S);
         }
-        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, st, D); }
+        if (b->aux) (void)hipEventRecord(b->ev_fork[1], st);
+        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU, sa); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, sa, D); }
         if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
     }
     void lin_elim(int write_S) {
@@ -741,12 +760,18 @@ struct Launcher {
             }
         }
         {
-            Bracket t(*this, SWF_K_CLIQUE_ELIM);
-            if (D.n_clc[0]) hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, st, D, O);
-            if (D.n_clc[1]) hipLaunchKernelGGL((k_clique_elim<32, 48, 9, 1>), dim3(D.n_clc[1]), dim3(64), 0, st, D, O);
-            if (D.n_clc[2]) hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, st, D, O);
+            hipStream_t sa = b->aux ? b->aux : st;
+            if (b->aux) (void)hipStreamWaitEvent(b->aux, b->ev_fork[1], 0);          // scalar-factor Jacobians (k_eval_ps)
+            {
+                Bracket t(*this, SWF_K_CLIQUE_ELIM, sa);
+                if (D.n_clc[1]) hipLaunchKernelGGL((k_clique_elim<32, 48, 9, 1>), dim3(D.n_clc[1]), dim3(64), 0, sa, D, O);
+                if (D.n_clc[0]) hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, sa, D, O);
+                if (D.n_clc[2]) hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, sa, D, O);
+            }
+            if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);
         }
         if (D.n_fsb) { Bracket t(*this, SWF_K_FRAME_SUMS); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
+        if (b->aux) (void)hipStreamWaitEvent(st, b->ev_fork[2], 0);                  // join before the assembly
         if (D.n_pd) {
             Bracket t(*this, SWF_K_ASSEMBLE);
             Segs S{}; S.e[0] = nb((size_t)D.n_pd * 64, 256); S.e[1] = S.e[0] + (write_S ? nb((size_t)D.n_po * 16, 256) : 0);
