@@ -565,26 +565,26 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         std::vector<int> c0, rec;
         auto new_chunk = [&]() { size_t at = rec.size(); rec.resize(at + (size_t)LS_LPC * 8, 0); for (int g = 0; g < LS_LPC; g++) rec[at + g * 8] = -1; return at; };
         for (auto& W : B.win) {
-            int nLw = W.lm1 - W.lm0, per = (nLw + GEMM_SPLIT - 1) / GEMM_SPLIT;
-            for (int sp = 0; sp < GEMM_SPLIT; sp++) {
-                c0.push_back((int)(rec.size() / (LS_LPC * 8)));
-                int lbeg = W.lm0 + std::min(sp * per, nLw), lend = W.lm0 + std::min(sp * per + per, nLw);
-                size_t at = 0; int g = LS_LPC, cells = 0;          // force a new chunk at the first landmark
-                for (int l = lbeg; l < lend; l++) {
-                    int o0 = B.lm_obs0[l], k = B.lm_obs0[l + 1] - o0;
-                    if (k > 64) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "landmark with more than 64 observations"); }
-                    int G = k <= 16 ? 1 : k <= 32 ? 2 : 4;
-                    int ga = (g + G - 1) / G * G;
-                    if (ga + G > LS_LPC || cells + k > LS_CAP) { at = new_chunk(); ga = 0; cells = 0; }
-                    for (int h = 0; h < G; h++) {
-                        int* r = &rec[at + (size_t)(ga + h) * 8];
-                        r[0] = l; r[1] = B.lm_loc[l]; r[2] = o0 + 16 * h; r[3] = std::min(o0 + 16 * h + 16, o0 + k);
-                        r[4] = (int)(unsigned)(B.lm_fmask[l] & 0xffffffffULL); r[5] = (int)(unsigned)(B.lm_fmask[l] >> 32);
-                        r[6] = ga | (G << 8) | ((h == 0 ? 1 : 0) << 16); r[7] = cells + 16 * h;
-                    }
-                    g = ga + G; cells += k;
+            // the window's chunks first (greedy: every chunk but the last is full), then consecutive chunks are dealt to the
+            // GEMM_SPLIT parts in equal shares — a part never ends in a nearly empty chunk; trailing parts may be empty
+            int first_chunk = (int)(rec.size() / (LS_LPC * 8));
+            size_t at = 0; int g = LS_LPC, cells = 0;              // force a new chunk at the first landmark
+            for (int l = W.lm0; l < W.lm1; l++) {
+                int o0 = B.lm_obs0[l], k = B.lm_obs0[l + 1] - o0;
+                if (k > 64) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "landmark with more than 64 observations"); }
+                int G = k <= 16 ? 1 : k <= 32 ? 2 : 4;
+                int ga = (g + G - 1) / G * G;
+                if (ga + G > LS_LPC || cells + k > LS_CAP) { at = new_chunk(); ga = 0; cells = 0; }
+                for (int h = 0; h < G; h++) {
+                    int* r = &rec[at + (size_t)(ga + h) * 8];
+                    r[0] = l; r[1] = B.lm_loc[l]; r[2] = o0 + 16 * h; r[3] = std::min(o0 + 16 * h + 16, o0 + k);
+                    r[4] = (int)(unsigned)(B.lm_fmask[l] & 0xffffffffULL); r[5] = (int)(unsigned)(B.lm_fmask[l] >> 32);
+                    r[6] = ga | (G << 8) | ((h == 0 ? 1 : 0) << 16); r[7] = cells + 16 * h;
                 }
+                g = ga + G; cells += k;
             }
+            int nch = (int)(rec.size() / (LS_LPC * 8)) - first_chunk, cpp = (nch + GEMM_SPLIT - 1) / GEMM_SPLIT;
+            for (int sp = 0; sp < GEMM_SPLIT; sp++) c0.push_back(first_chunk + std::min(sp * cpp, nch));
         }
         c0.push_back((int)(rec.size() / (LS_LPC * 8)));
         rec.resize(rec.size() + (size_t)LS_LPC * 8 * 2, 0);         // pad: the pipeline never reads past the table, but keep slack
@@ -743,11 +743,11 @@ struct Launcher {
         if (D.n_lm) {
             Bracket t(*this, SWF_K_LM_SCHUR);
             // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames);
-            // quarters per block: as many as still leave >= 2 blocks per CU (the result does not depend on it)
             const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;     // test / debugging aids, read per launch
             const int force_qpb = getenv("SWF_LS_QPB") ? atoi(getenv("SWF_LS_QPB")) : 0;
-            int qpb = D.n_win >= 2 * b->n_cu ? 4 : D.n_win >= b->n_cu ? 2 : 1;
-            if (force_qpb == 1 || force_qpb == 2 || force_qpb == 4) qpb = force_qpb;
+            int qpb = 1;                                        // parts per block: as many as still leave >= 2 blocks per CU
+            while (qpb < GEMM_SPLIT && (long long)D.n_win * GEMM_SPLIT / (2 * qpb) >= 2LL * b->n_cu) qpb *= 2;
+            if (force_qpb >= 1 && force_qpb <= GEMM_SPLIT && (force_qpb & (force_qpb - 1)) == 0) qpb = force_qpb;
             dim3 grid(D.n_win, GEMM_SPLIT / qpb);
             int tpw = (b->max_tiles <= 16 && force < 1) ? 2 : (b->max_tiles <= 40 && force < 2) ? 5 : 10;
             lm_folded = qpb == GEMM_SPLIT && tpw <= 5;          // must mirror CAN_FOLD in k_lm_schur (tpw 10 = the 1024-thread variant: no fold)

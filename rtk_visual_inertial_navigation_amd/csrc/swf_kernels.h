@@ -578,7 +578,8 @@ __device__ __forceinline__ void d_jtimes_prior(const DevBatch& B, const DevOpt& 
 // f64 MFMA layouts: A[i][k]: lane = i + 16k; B[k][j]: lane = j + 16k; D: lane l, reg q -> row (l>>4)+4q, col l&15.
 // =========================================================================================
 typedef double double4_t __attribute__((ext_vector_type(4)));
-#define GEMM_SPLIT 4                          // fixed landmark split: partial products P_0..P_3, summed in order by k_assemble
+#define GEMM_SPLIT 16                         // fixed landmark split: partial products P_0..P_15, summed in order (by k_lm_schur
+                                              // itself when one block covers them all, else by k_assemble)
 #ifdef SWF_PROFILE_GEMM
 __device__ unsigned long long g_gemm_stamps[16];
 #define GSTAMP_ACC(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_gemm_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
@@ -607,9 +608,9 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
     __shared__ int tbl[2][LS_LPC][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
     __shared__ unsigned long long Ms[2][LS_LPC];           // frame mask of the chunk's landmarks (0 = none / constant landmark)
     constexpr int ZOFF = LS_CAP * LS_CS;
-    // a block covers qpb consecutive landmark quarters of its window (qpb = 1, 2 or 4; large batches use 4 so the
-    // producer / consumer pipeline fills once per block).  Every quarter still gets its own partial product, so the
-    // result does not depend on qpb.
+    // a block covers qpb consecutive landmark parts of its window (qpb = 1, 2, 4, 8 or 16; a single window spreads over 16
+    // workgroups, large batches use 16 so the producer / consumer pipeline fills once per block).  Every part still gets
+    // its own partial product, so the result does not depend on qpb.
     int w = blockIdx.x, sp0 = blockIdx.y * qpb;
     WinState& s = B.ws[w];
     if (!s.need_lin) return;
@@ -692,10 +693,10 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             __syncthreads();                                // chunk c consumed, chunk c+1 produced
             if (cw == 0) GSTAMP_ACC(10, tg);
         }
-        // end of a quarter.  A block that covers all four quarters folds them in registers in exactly the order
-        // k_assemble adds partials, ((P0 + P1) + P2) + P3 with every Pq summed from zero, and writes ONE product
-        // (slot 0; k_assemble is told to read one partial): same bits, a quarter of the P traffic.  Otherwise
-        // each quarter's partial product is flushed to its own slot.
+        // end of a part.  A block that covers all GEMM_SPLIT parts folds them in registers in exactly the order
+        // k_assemble adds partials, ((P0 + P1) + P2) + ... with every Pq summed from zero, and writes ONE product
+        // (slot 0; k_assemble is told to read one partial): same bits, 1/GEMM_SPLIT of the P traffic.  Otherwise
+        // each part's partial product is flushed to its own slot.
         bool fold = CAN_FOLD && qpb == GEMM_SPLIT;
         if (fold) {
 #pragma unroll

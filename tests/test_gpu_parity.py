@@ -149,12 +149,13 @@ def test_batch_equals_single_window_solves_bitwise():
 
 
 def test_landmark_quarters_per_block_and_kernel_variant_do_not_change_results(monkeypatch):
-    """k_lm_schur lets one workgroup process 1, 2 or 4 landmark quarters (chosen from the batch size) and is
+    """k_lm_schur lets one workgroup process 1 .. 16 landmark parts (chosen from the batch size) and is
     instantiated per tile count; every quarter keeps its own partial product and the arithmetic is pinned, so all
     of these must give bit-identical solves."""
     ws = [synth.make_window(3, K=9, F=50, S=6, seed=60 + i) for i in range(3)]
     ref = None
-    for env in ({}, {"SWF_LS_QPB": "1"}, {"SWF_LS_QPB": "2"}, {"SWF_LS_QPB": "4"}, {"SWF_LS_VARIANT": "1"}, {"SWF_LS_VARIANT": "2", "SWF_LS_QPB": "4"}):
+    for env in ({}, {"SWF_LS_QPB": "1"}, {"SWF_LS_QPB": "2"}, {"SWF_LS_QPB": "4"}, {"SWF_LS_QPB": "8"}, {"SWF_LS_QPB": "16"},
+                {"SWF_LS_VARIANT": "1"}, {"SWF_LS_VARIANT": "2", "SWF_LS_QPB": "16"}):
         for k in ("SWF_LS_QPB", "SWF_LS_VARIANT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
