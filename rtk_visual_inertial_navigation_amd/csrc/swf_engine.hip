@@ -532,7 +532,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->stream = (hipStream_t)stream;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
-    if (n * 16 <= b->n_cu && !getenv("SWF_NO_AUX_STREAM")) {            // latency path: fork / join inside a linearisation
+    if ((n * 16 <= b->n_cu || getenv("SWF_AUX_STREAM_ALWAYS")) && !getenv("SWF_NO_AUX_STREAM")) {            // latency path: fork / join inside a linearisation
         bool ok = hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&b->ev_fork[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { if (b->aux) (void)hipStreamDestroy(b->aux); b->aux = nullptr; }
