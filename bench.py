@@ -108,10 +108,16 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # SWF_BENCH_SHARE_GPU=1 (testing the multi-rank path on a box with fewer GPUs than ranks): ranks share the
+    # devices round-robin and the harness collectives run over gloo on host tensors; never set it for a measurement
+    share = os.environ.get("SWF_BENCH_SHARE_GPU") == "1"
+    cdev = "cpu" if share else "cuda"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if share else "nccl")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     from rtk_visual_inertial_navigation_amd import solver
     from rtk_visual_inertial_navigation_amd.flat import default_options
@@ -148,10 +154,10 @@ def main():
             d = acc.setdefault(k, dict(ms=0.0, calls=0)); d["ms"] += v["ms"]; d["calls"] += v["calls"]
     barrier()
     dt = time.perf_counter() - t0
-    dt = shard.allreduce([dt], "max", device="cuda")[0]          # RCCL all-reduce (harness only)
+    dt = shard.allreduce([dt], "max", device=cdev)[0]          # RCCL all-reduce (harness only)
     sms = bs.summaries()
-    its_total = shard.allreduce([float(sum(s.num_iterations for s in sms))], "sum", device="cuda")[0]
-    job = shard.gather_summaries(np.array([[s.final_cost, s.num_iterations, s.termination] for s in sms]), device="cuda")
+    its_total = shard.allreduce([float(sum(s.num_iterations for s in sms))], "sum", device=cdev)[0]
+    job = shard.gather_summaries(np.array([[s.final_cost, s.num_iterations, s.termination] for s in sms]), device=cdev)
     value = its_total * a.steps / dt
 
     if rank == 0:
