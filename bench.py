@@ -170,7 +170,7 @@ def main():
             "eval_ps": ("hbm", calib["proj_bytes"], "312 B per observation (152 read + 160 written)"),
             "lm_schur": ("mfma", calib["lm_schur_flops"], "sum over landmarks of 216 k^2 + 108 k flops (SURVEY.md 8d landmark Schur); "
                          "HBM side: 208 B per observation (Jp, Jl, r read = 160 B, Y g_l written = 48 B) + the P partials"),
-            "chol_solve": ("mfma", 2 * calib["chol_flops"], "2 * sum_w n_red^3 / 3 flops"),
+            "chol_solve": ("mfma", calib["chol_flops"], "sum_w n_red^3 / 3 flops (n_red^3 / 6 multiply-adds)"),
             "frame_sums": ("hbm", 160 * n_obs, "160 B per observation (Jp, r, Y g_l read)"),
             "post_chol": ("hbm", 2 * 144 * n_obs, "Jp, Jl (144 B per observation) read by the back-substitution and by J D^-2 g"),
             "post_dogleg": ("hbm", (144 + 152 + 16) * n_obs, "Jp, Jl read for J*step; candidate residuals: 152 B read + 16 B written per observation"),

@@ -129,7 +129,7 @@ typedef struct swf_timing {
     int32_t calls[SWF_K_COUNT];
     int64_t jacobian_bytes;  /* algorithmic bytes of ONE Jacobian evaluation of the batch */
     int64_t proj_bytes;      /* the projection-factor share of it (312 B per observation) */
-    int64_t chol_flops;      /* sum over windows of n_red^3 / 3 multiply-adds (one factorisation of the batch) */
+    int64_t chol_flops;      /* sum over windows of n_red^3 / 3 flops = n_red^3 / 6 multiply-adds (one factorisation of the batch) */
     int64_t lm_schur_flops;  /* landmark Schur product: sum over landmarks of 216 k^2 + 108 k flops */
     int64_t n_obs;           /* projection observations in the batch */
     int32_t n_linearizations;/* Jacobian evaluations enqueued per window in the last solve */

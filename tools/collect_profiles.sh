@@ -4,6 +4,7 @@
 #  1. --kernel-trace --stats of the batch-only workload (512 windows, tests/gpu_batch_prof.py)
 #  2. --kernel-trace --stats of the single-window workload (tests/gpu_single_prof.py)
 #  3. --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (TCC slot limit; never combined with tracing)
+#  4. --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (matrix-core utilisation per kernel)
 # Summaries (csv / json) land in <out_dir>; copy them to profiles/<round>/ to have them judged.
 set -u
 OUT=$(realpath -m "${1:-gpurun_out/prof}")
@@ -21,6 +22,9 @@ cp "$(find /tmp/swfprof/bench -name '*kernel_stats.csv' | head -1)" "$OUT/bench_
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d /tmp/swfprof/pmc_$C -o p -- python "$ROOT/tests/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_$C.log 2>&1
 done
+# 4. matrix-core counters in their own pass: instructions, busy cycles, GPU-active cycles -> MFMA utilisation per kernel
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swfprof/pmc_mfma -o p -- python "$ROOT/tests/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_mfma.log 2>&1
+python "$ROOT/tools/summarize_mfma_pmc.py" "$(find /tmp/swfprof/pmc_mfma -name '*counter_collection.csv' | head -1)" "$OUT/batch512_pmc_mfma.json"
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
