@@ -16,6 +16,9 @@
 //   RTKCarrierPhaseFactor(...)                  R/factor/gnss_factor.h:8-40           -> swf_add_rtk_carrier_phase
 //   RTKPseudorangeFactor(...)                   R/factor/gnss_factor.h:43-66          -> swf_add_rtk_pseudorange
 //   SppDopplerFactor(...)                       R/factor/gnss_factor.h:108-131        -> swf_add_doppler
+//   SppPseudorangeFactor(...)                   R/factor/gnss_factor.h:70-83          -> swf_add_spp_pseudorange
+//   SppCarrierPhaseFactor(...)                  R/factor/gnss_factor.h:88-104         -> swf_add_spp_carrier_phase
+//   FixedIntegerFactor(N21, istd)               R/factor/gnss_factor.h:135-143        -> swf_add_fixed_integer
 //   InitialBlackFactor(istd)                    R/factor/initial_factor.h:42-48       -> swf_add_scalar_prior
 //   MarginalizationFactor(info)                 R/factor/marginalization_factor.h:104-110 -> swf_add_linear_prior
 //   ceres::internal::{parameter_head,is_optimize,lhs_out,rhs_out,lhs_out2,hs_row}
@@ -71,6 +74,19 @@ struct SppDopplerFactor : CostFunction {
         dat[6] = D1_lam; dat[7] = istd;
     }
 };
+struct SppPseudorangeFactor : CostFunction {
+    double dat[SWF_SPR_DOUBLES];
+    SppPseudorangeFactor(const double* sat, double P1, double istd, const double* /*base_pos*/) {
+        dat[0] = sat[0]; dat[1] = sat[1]; dat[2] = sat[2]; dat[3] = P1; dat[4] = istd;
+    }
+};
+struct SppCarrierPhaseFactor : CostFunction {
+    double dat[SWF_SCP_DOUBLES];
+    SppCarrierPhaseFactor(const double* sat, double L1_lam, double istd, const double* /*base_pos*/, double lam) {
+        dat[0] = sat[0]; dat[1] = sat[1]; dat[2] = sat[2]; dat[3] = L1_lam; dat[4] = istd; dat[5] = lam;
+    }
+};
+struct FixedIntegerFactor : CostFunction { double N21, istd; FixedIntegerFactor(double N21_, double istd_) : N21(N21_), istd(istd_) {} };
 struct InitialBlackFactor : CostFunction { double istd; explicit InitialBlackFactor(double w) : istd(w) {} };
 // MarginalizationInfo's product: the linearised prior (J, r0, x0) over its kept blocks
 struct MarginalizationFactor : CostFunction {
@@ -140,6 +156,15 @@ class Problem {
     }
     ResidualBlockId AddResidualBlock(SppDopplerFactor* f, LossFunction* loss, double* sb, double* drift, double* pose) {
         ResidualBlockId id = swf_add_doppler(h_, sb, drift, pose, f->dat); delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(SppPseudorangeFactor* f, LossFunction* loss, double* pose, double* clk) {
+        ResidualBlockId id = swf_add_spp_pseudorange(h_, pose, clk, f->dat); delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(SppCarrierPhaseFactor* f, LossFunction* loss, double* pose, double* clk, double* amb) {
+        ResidualBlockId id = swf_add_spp_carrier_phase(h_, pose, clk, amb, f->dat); delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(FixedIntegerFactor* f, LossFunction* loss, double* n_a, double* n_b) {
+        ResidualBlockId id = swf_add_fixed_integer(h_, n_a, n_b, f->N21, f->istd); delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(InitialBlackFactor* f, LossFunction* loss, double* scalar) {
         ResidualBlockId id = swf_add_scalar_prior(h_, scalar, f->istd); delete f; delete loss; return ck(id);

@@ -180,6 +180,14 @@ swf_factor_id swf_add_rtk_pseudorange(swf_problem* p, double* pose, double* cloc
 /* SppDopplerFactor (R/swf/swf_core.cpp:197-201); dat = SWF_DOP_DOUBLES record */
 swf_factor_id swf_add_doppler(swf_problem* p, double* speed_bias, double* clock_drift, double* pose,
                               const double* dat);
+/* SppPseudorangeFactor (R/swf/swf_core.cpp:157-163); dat = SWF_SPR_DOUBLES record (sat[3] P1 istd) */
+swf_factor_id swf_add_spp_pseudorange(swf_problem* p, double* pose, double* clock, const double* dat);
+/* SppCarrierPhaseFactor (R/swf/swf_core.cpp:170-190); block order pose, clock, ambiguity as in the reference;
+ * dat = SWF_SCP_DOUBLES record (sat[3] L1_lam istd lam) */
+swf_factor_id swf_add_spp_carrier_phase(swf_problem* p, double* pose, double* clock, double* ambiguity,
+                                        const double* dat);
+/* FixedIntegerFactor(N21, istd) (R/swf/swf_lambda.cpp:318-330): r = istd ((*n_b - *n_a) - N21) */
+swf_factor_id swf_add_fixed_integer(swf_problem* p, double* n_a, double* n_b, double N21, double istd);
 /* InitialBlackFactor(w) (R/swf/swf_core.cpp:553-556) */
 swf_factor_id swf_add_scalar_prior(swf_problem* p, double* scalar, double w);
 /* MarginalizationFactor(info) (R/swf/swf_core.cpp:551-552): kept blocks `keys` (sizes from the

@@ -50,6 +50,12 @@ enum { SWF_CP_DOUBLES = 9 };
 enum { SWF_PR_DOUBLES = 7 };
 /* Doppler record doubles: sat[3] satvel[3] D1_lam istd       (R/factor/gnss_factor.h:108-131) */
 enum { SWF_DOP_DOUBLES = 8 };
+/* rover-only pseudorange record doubles: sat[3] P1 istd       (ctor of SppPseudorangeFactor, R/factor/gnss_factor.h:70-83) */
+enum { SWF_SPR_DOUBLES = 5 };
+/* rover-only carrier-phase record doubles: sat[3] L1_lam istd lam   (SppCarrierPhaseFactor, R/factor/gnss_factor.h:88-104) */
+enum { SWF_SCP_DOUBLES = 6 };
+/* fixed-integer record doubles: N21 istd                      (FixedIntegerFactor, R/factor/gnss_factor.h:135-139) */
+enum { SWF_FIX_DOUBLES = 2 };
 
 typedef struct swf_flat_window {
     /* ---- parameter pools: caller-owned; read at solve start, written back at solve end */
@@ -100,6 +106,24 @@ typedef struct swf_flat_window {
     int32_t n_sp;
     const int32_t* sp_idx;           /* [n_sp] scalar pool index */
     const double*  sp_w;             /* [n_sp] */
+
+    /* ---- rover-only pseudorange factors, SppPseudorangeFactor<1,7,1> (R/factor/gnss_factor.cpp:9-39):
+     *      r = istd (range + clock - P1) */
+    int32_t n_spr;
+    const int32_t* spr_idx;          /* [n_spr][2] pose, receiver clock (scalar pool) */
+    const double*  spr_dat;          /* [n_spr][SWF_SPR_DOUBLES] */
+
+    /* ---- rover-only carrier-phase factors, SppCarrierPhaseFactor<1,7,1,1> (R/factor/gnss_factor.cpp:45-80):
+     *      r = istd (range + clock - N lam - L1_lam); NB block order pose, clock, ambiguity (RTK: pose, ambiguity, clock) */
+    int32_t n_scp;
+    const int32_t* scp_idx;          /* [n_scp][3] pose, receiver clock, ambiguity */
+    const double*  scp_dat;          /* [n_scp][SWF_SCP_DOUBLES] */
+
+    /* ---- fixed-integer factors, FixedIntegerFactor<1,1,1> (R/factor/gnss_factor.cpp:85-96):
+     *      r = istd ((N_b - N_a) - N21), injected by the ambiguity resolution (R/swf/swf_lambda.cpp) */
+    int32_t n_fix;
+    const int32_t* fix_idx;          /* [n_fix][2] scalar a, scalar b */
+    const double*  fix_dat;          /* [n_fix][SWF_FIX_DOUBLES] */
 
     /* ---- linearised priors, MarginalizationFactor (R/factor/marginalization_factor.cpp:410-446):
      *      r = r0 + J*dx, dx per kept block = x-x0, or [p-p0 ; +-2 vec(q0^-1 q)] for poses.

@@ -407,6 +407,34 @@ void oracle_eval_pr(const double* pose, double clk, const double* dat, const dou
     if (Jpose) { Jpose[0] = w * e[0]; Jpose[1] = w * e[1]; Jpose[2] = w * e[2]; Jpose[3] = Jpose[4] = Jpose[5] = 0; }
     if (Jclk) *Jclk = w;
 }
+/* SppPseudorangeFactor::Evaluate, R/factor/gnss_factor.cpp:9-39: fixed weight istd, J = [istd e | 0], +istd wrt clock */
+void oracle_eval_spr(const double* pose, double clk, const double* dat, const double* base,
+                     double* r, double* Jpose /*6*/, double* Jclk) {
+    double xg[3] = { pose[0] + base[0], pose[1] + base[1], pose[2] + base[2] }, e[3];
+    double r1 = gnss_distance(xg, dat, e);
+    double P1 = dat[3], w = dat[4];
+    *r = w * (r1 + clk - P1);
+    if (Jpose) { Jpose[0] = w * e[0]; Jpose[1] = w * e[1]; Jpose[2] = w * e[2]; Jpose[3] = Jpose[4] = Jpose[5] = 0; }
+    if (Jclk) *Jclk = w * 1;
+}
+/* SppCarrierPhaseFactor::Evaluate, R/factor/gnss_factor.cpp:45-80 (blocks: pose, clock, ambiguity) */
+void oracle_eval_scp(const double* pose, double clk, double amb, const double* dat, const double* base,
+                     double* r, double* Jpose /*6*/, double* Jclk, double* Jamb) {
+    double xg[3] = { pose[0] + base[0], pose[1] + base[1], pose[2] + base[2] }, e[3];
+    double r1 = gnss_distance(xg, dat, e);
+    double L1_lam = dat[3], w = dat[4], lam = dat[5];
+    *r = w * (r1 + clk - amb * lam - L1_lam);
+    if (Jpose) { Jpose[0] = w * e[0]; Jpose[1] = w * e[1]; Jpose[2] = w * e[2]; Jpose[3] = Jpose[4] = Jpose[5] = 0; }
+    if (Jclk) *Jclk = w * 1;
+    if (Jamb) *Jamb = -w * lam;
+}
+/* FixedIntegerFactor::Evaluate, R/factor/gnss_factor.cpp:85-96: r = istd ((N_b - N_a) - N21) */
+void oracle_eval_fix(double na, double nb, const double* dat, double* r, double* Ja, double* Jb) {
+    double N21 = dat[0], w = dat[1];
+    *r = w * ((nb - na) - N21);
+    if (Ja) *Ja = -w;
+    if (Jb) *Jb = w;
+}
 /* SppDopplerFactor::Evaluate, R/factor/gnss_factor.cpp:174-212 with velecitydistance(),
  * R/gnss/src/common_function.cpp:411-421 */
 void oracle_eval_dop(const double* sb, double drift, const double* pose, const double* dat, const double* base,
@@ -610,7 +638,7 @@ void oracle_preintegrate(const double* samples, int n, const double* ba, const d
 }
 
 /* ------------------------------------------------------------------ solver */
-enum { F_PROJ = 0, F_IMU, F_CP, F_PR, F_DOP, F_SP, F_PRIOR };
+enum { F_PROJ = 0, F_IMU, F_CP, F_PR, F_DOP, F_SP, F_PRIOR, F_SPR, F_SCP, F_FIX };
 
 typedef struct {
     int type, idx, nres, nblk;
@@ -692,10 +720,10 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
     c->n_loc = lo; c->n_e = ne; c->n_red = lo - ne; c->n_eblk = neb;
 
     /* factors */
-    int nf = w->n_proj + w->n_imu + w->n_cp + w->n_pr + w->n_dop + w->n_sp + w->n_prior;
+    int nf = w->n_proj + w->n_imu + w->n_cp + w->n_pr + w->n_dop + w->n_sp + w->n_spr + w->n_scp + w->n_fix + w->n_prior;
     c->n_fac = nf;
     c->fac = (fac_t*)calloc(nf > 0 ? nf : 1, sizeof(fac_t));
-    int nslots = w->n_proj * 3 + w->n_imu * 4 + w->n_cp * 3 + w->n_pr * 2 + w->n_dop * 3 + w->n_sp;
+    int nslots = w->n_proj * 3 + w->n_imu * 4 + w->n_cp * 3 + w->n_pr * 2 + w->n_dop * 3 + w->n_sp + w->n_spr * 2 + w->n_scp * 3 + w->n_fix * 2;
     c->prior_blk_off = (int*)malloc(sizeof(int) * (w->n_prior + 1));
     c->prior_J_off = (int*)malloc(sizeof(int) * (w->n_prior + 1));
     c->prior_r_off = (int*)malloc(sizeof(int) * (w->n_prior + 1));
@@ -721,6 +749,9 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
     for (int i = 0; i < w->n_pr; i++) { ADDF(F_PR, i, 1, 2) ADDS(BID_POSE(w, w->pr_idx[i * 2])) ADDS(BID_SC(w, w->pr_idx[i * 2 + 1])) }
     for (int i = 0; i < w->n_dop; i++) { ADDF(F_DOP, i, 1, 3) ADDS(BID_SB(w, w->dop_idx[i * 3])) ADDS(BID_SC(w, w->dop_idx[i * 3 + 1])) ADDS(BID_POSE(w, w->dop_idx[i * 3 + 2])) }
     for (int i = 0; i < w->n_sp; i++) { ADDF(F_SP, i, 1, 1) ADDS(BID_SC(w, w->sp_idx[i])) }
+    for (int i = 0; i < w->n_spr; i++) { ADDF(F_SPR, i, 1, 2) ADDS(BID_POSE(w, w->spr_idx[i * 2])) ADDS(BID_SC(w, w->spr_idx[i * 2 + 1])) }
+    for (int i = 0; i < w->n_scp; i++) { ADDF(F_SCP, i, 1, 3) ADDS(BID_POSE(w, w->scp_idx[i * 3])) ADDS(BID_SC(w, w->scp_idx[i * 3 + 1])) ADDS(BID_SC(w, w->scp_idx[i * 3 + 2])) }
+    for (int i = 0; i < w->n_fix; i++) { ADDF(F_FIX, i, 1, 2) ADDS(BID_SC(w, w->fix_idx[i * 2])) ADDS(BID_SC(w, w->fix_idx[i * 2 + 1])) }
     for (int k = 0; k < w->n_prior; k++) {
         ADDF(F_PRIOR, k, w->prior_dim[k], w->prior_nblk[k])
         for (int q = 0; q < w->prior_nblk[k]; q++) ADDS(w->prior_blk[c->prior_blk_off[k] + q])
@@ -833,6 +864,9 @@ static double eval_factor(ctx_t* c, const fac_t* f, const double* x, int want_ja
     case F_PR: oracle_eval_pr(XP(0), *XP(1), w->pr_dat + f->idx * SWF_PR_DOUBLES, w->base, r, JP(0), JP(1)); return 0.5 * r[0] * r[0];
     case F_DOP: oracle_eval_dop(XP(0), *XP(1), XP(2), w->dop_dat + f->idx * SWF_DOP_DOUBLES, w->base, r, JP(0), JP(1), JP(2)); return 0.5 * r[0] * r[0];
     case F_SP: { r[0] = w->sp_w[f->idx] * (*XP(0)); double* J = JP(0); if (J) J[0] = w->sp_w[f->idx]; return 0.5 * r[0] * r[0]; }
+    case F_SPR: oracle_eval_spr(XP(0), *XP(1), w->spr_dat + f->idx * SWF_SPR_DOUBLES, w->base, r, JP(0), JP(1)); return 0.5 * r[0] * r[0];
+    case F_SCP: oracle_eval_scp(XP(0), *XP(1), *XP(2), w->scp_dat + f->idx * SWF_SCP_DOUBLES, w->base, r, JP(0), JP(1), JP(2)); return 0.5 * r[0] * r[0];
+    case F_FIX: oracle_eval_fix(*XP(0), *XP(1), w->fix_dat + f->idx * SWF_FIX_DOUBLES, r, JP(0), JP(1)); return 0.5 * r[0] * r[0];
     case F_PRIOR: {
         int k = f->idx, n = f->nres;
         const double* Jp = w->prior_J + c->prior_J_off[k];

@@ -40,7 +40,7 @@ struct WinState {
 };
 
 // ---- generic factor (everything except projection) --------------------------------------
-enum { GF_IMU = 1, GF_CP = 2, GF_PR = 3, GF_DOP = 4, GF_SP = 5, GF_PRIOR = 6 };
+enum { GF_IMU = 1, GF_CP = 2, GF_PR = 3, GF_DOP = 4, GF_SP = 5, GF_PRIOR = 6, GF_SPR = 7, GF_SCP = 8, GF_FIX = 9 };
 struct GFac {
     int type, win, nres, nslot;
     int slot0;                   // into slot arrays
@@ -118,6 +118,7 @@ struct DevBatch {
     const int* s_x; const int* s_loc; const int* s_ls; const int* s_joff; const int* s_ccol;   // per slot: Jacobian block offset in g_J (column stride: GFac.jld)
     double* g_r; double* g_J; double* g_cost; double* g_aux;
     const double* imu_pre; const double* cp_dat; const double* pr_dat; const double* dop_dat; const double* sp_w;
+    const double* gx_dat;            // records of the rover-only / fixed-integer scalar factors (GFac.data = offset in doubles)
     int n_imu; const int* imu_gf;              // generic-factor ids by kernel
     int n_sc;  const int* sc_gf;
     int n_prior; const int* prior_gf;

@@ -106,7 +106,7 @@ struct Build {
     std::vector<int> fr_obs0, fr_obs;
     std::vector<GFac> gf;
     std::vector<int> s_x, s_loc, s_ls, s_joff, s_ccol;
-    std::vector<double> imu_pre, cp_dat, pr_dat, dop_dat, sp_w;
+    std::vector<double> imu_pre, cp_dat, pr_dat, dop_dat, sp_w, gx_dat;
     std::vector<int> imu_gf, sc_gf, prior_gf;
     std::vector<int> prior_dim, prior_roff, prior_x0off;
     std::vector<long long> prior_Joff;
@@ -318,6 +318,29 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         B.sp_w.push_back(w->sp_w[i]);
         B.sc_gf.push_back(add_gf(GF_SP, 1, data, { bidC(w->sp_idx[i]) }));
     }
+    // rover-only pseudorange / carrier phase and fixed-integer factors share one record pool (GFac.data = offset in doubles)
+    for (int i = 0; i < w->n_spr; i++) {
+        const int* ix = w->spr_idx + i * 2;
+        CHK(ix[0], nP, "spp pseudorange") CHK(ix[1], nC, "spp pseudorange")
+        int data = (int)B.gx_dat.size();
+        B.gx_dat.insert(B.gx_dat.end(), w->spr_dat + i * SWF_SPR_DOUBLES, w->spr_dat + (i + 1) * SWF_SPR_DOUBLES);
+        B.sc_gf.push_back(add_gf(GF_SPR, 1, data, { bidP(ix[0]), bidC(ix[1]) }));
+    }
+    for (int i = 0; i < w->n_scp; i++) {
+        const int* ix = w->scp_idx + i * 3;
+        CHK(ix[0], nP, "spp carrier phase") CHK(ix[1], nC, "spp carrier phase") CHK(ix[2], nC, "spp carrier phase")
+        int data = (int)B.gx_dat.size();
+        B.gx_dat.insert(B.gx_dat.end(), w->scp_dat + i * SWF_SCP_DOUBLES, w->scp_dat + (i + 1) * SWF_SCP_DOUBLES);
+        B.sc_gf.push_back(add_gf(GF_SCP, 1, data, { bidP(ix[0]), bidC(ix[1]), bidC(ix[2]) }));
+    }
+    for (int i = 0; i < w->n_fix; i++) {
+        const int* ix = w->fix_idx + i * 2;
+        CHK(ix[0], nC, "fixed integer") CHK(ix[1], nC, "fixed integer")
+        if (ix[0] == ix[1]) return fail(SWF_E_INVALID, "fixed integer: both blocks are the same scalar");
+        int data = (int)B.gx_dat.size();
+        B.gx_dat.insert(B.gx_dat.end(), w->fix_dat + i * SWF_FIX_DOUBLES, w->fix_dat + (i + 1) * SWF_FIX_DOUBLES);
+        B.sc_gf.push_back(add_gf(GF_FIX, 1, data, { bidC(ix[0]), bidC(ix[1]) }));
+    }
     std::vector<int> prior_first_gf;
     {
         int bo = 0; long long jo = 0; int ro = 0, x0o = 0;
@@ -508,7 +531,8 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     {
         int64_t pb = 0;
         for (int k = 0; k < w->n_prior; k++) { int64_t n = w->prior_dim[k]; pb += 8 * (n * n + 4 * n); }
-        B.jac_bytes += (int64_t)312 * w->n_proj + (int64_t)5480 * w->n_imu + (int64_t)176 * w->n_cp + (int64_t)152 * w->n_pr + (int64_t)208 * w->n_dop + pb;
+        B.jac_bytes += (int64_t)312 * w->n_proj + (int64_t)5480 * w->n_imu + (int64_t)176 * w->n_cp + (int64_t)152 * w->n_pr + (int64_t)208 * w->n_dop
+                     + (int64_t)136 * w->n_spr + (int64_t)160 * w->n_scp + (int64_t)56 * w->n_fix + pb;
     }
     B.win.push_back(R);
     return SWF_OK;
@@ -600,7 +624,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     D.n_gf = (int)B.gf.size();
     PUT(gf, B.gf);
     PUT(s_x, B.s_x); PUT(s_loc, B.s_loc); PUT(s_ls, B.s_ls); PUT(s_joff, B.s_joff); PUT(s_ccol, B.s_ccol);
-    PUT(imu_pre, B.imu_pre); PUT(cp_dat, B.cp_dat); PUT(pr_dat, B.pr_dat); PUT(dop_dat, B.dop_dat); PUT(sp_w, B.sp_w);
+    PUT(imu_pre, B.imu_pre); PUT(cp_dat, B.cp_dat); PUT(pr_dat, B.pr_dat); PUT(dop_dat, B.dop_dat); PUT(sp_w, B.sp_w); PUT(gx_dat, B.gx_dat);
     D.n_imu = (int)B.imu_gf.size(); D.n_sc = (int)B.sc_gf.size(); D.n_prior = (int)B.prior_gf.size();
     PUT(imu_gf, B.imu_gf); PUT(sc_gf, B.sc_gf); PUT(prior_gf, B.prior_gf);
     PUT(prior_dim, B.prior_dim); PUT(prior_Joff, B.prior_Joff); PUT(prior_roff, B.prior_roff); PUT(prior_x0off, B.prior_x0off);

@@ -315,6 +315,7 @@ __global__ void __launch_bounds__(IMU_FPB * IMU_LPF) k_eval_imu(DevBatch B) { d_
 //   RTKCarrierPhaseFactor  R/factor/gnss_factor.cpp:105-138     RTKPseudorangeFactor :140-168
 //   SppDopplerFactor       :174-212 (+ velecitydistance, R/gnss/src/common_function.cpp:411-421)
 //   InitialBlackFactor     R/factor/initial_factor.cpp:81-87
+//   SppPseudorangeFactor   gnss_factor.cpp:9-39   SppCarrierPhaseFactor :45-80   FixedIntegerFactor :85-96
 //   distance() R/gnss/src/common_function.cpp:126-134 ; varerr2() gnss_factor.cpp:98-103 (sinf!)
 // =========================================================================================
 __device__ __forceinline__ double gnss_distance(const double* rr, const double* rs, double* e) {
@@ -390,6 +391,41 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
             jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = istd;
             jo = B.s_joff[s0 + 2];
             if (jo >= 0) { for (int k = 0; k < 3; k++) { B.g_J[jo + k * ld] = istd * (ev[k] - ee * e[k]) / rr; B.g_J[jo + (3 + k) * ld] = 0; } }
+        }
+    } else if (G.type == GF_SPR) {
+        const double* dat = B.gx_dat + G.data;          // sat[3] P1 istd
+        const double* pose = xs + B.s_x[s0];
+        double clk = xs[B.s_x[s0 + 1]];
+        double xg[3] = { pose[0] + W.base[0], pose[1] + W.base[1], pose[2] + W.base[2] }, e[3];
+        double r1 = gnss_distance(xg, dat, e);
+        double wgt = dat[4];
+        r = wgt * (r1 + clk - dat[3]);
+        if (JAC) {
+            int jo = B.s_joff[s0];
+            if (jo >= 0) { B.g_J[jo] = wgt * e[0]; B.g_J[jo + 1 * ld] = wgt * e[1]; B.g_J[jo + 2 * ld] = wgt * e[2]; B.g_J[jo + 3 * ld] = 0; B.g_J[jo + 4 * ld] = 0; B.g_J[jo + 5 * ld] = 0; }
+            jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = wgt;
+        }
+    } else if (G.type == GF_SCP) {
+        const double* dat = B.gx_dat + G.data;          // sat[3] L1_lam istd lam ; blocks pose, clock, ambiguity
+        const double* pose = xs + B.s_x[s0];
+        double clk = xs[B.s_x[s0 + 1]], amb = xs[B.s_x[s0 + 2]];
+        double xg[3] = { pose[0] + W.base[0], pose[1] + W.base[1], pose[2] + W.base[2] }, e[3];
+        double r1 = gnss_distance(xg, dat, e);
+        double wgt = dat[4];
+        r = wgt * (r1 + clk - amb * dat[5] - dat[3]);
+        if (JAC) {
+            int jo = B.s_joff[s0];
+            if (jo >= 0) { B.g_J[jo] = wgt * e[0]; B.g_J[jo + 1 * ld] = wgt * e[1]; B.g_J[jo + 2 * ld] = wgt * e[2]; B.g_J[jo + 3 * ld] = 0; B.g_J[jo + 4 * ld] = 0; B.g_J[jo + 5 * ld] = 0; }
+            jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = wgt;
+            jo = B.s_joff[s0 + 2]; if (jo >= 0) B.g_J[jo] = -wgt * dat[5];
+        }
+    } else if (G.type == GF_FIX) {
+        const double* dat = B.gx_dat + G.data;          // N21 istd
+        double na = xs[B.s_x[s0]], nb2 = xs[B.s_x[s0 + 1]];
+        r = dat[1] * ((nb2 - na) - dat[0]);
+        if (JAC) {
+            int jo = B.s_joff[s0]; if (jo >= 0) B.g_J[jo] = -dat[1];
+            jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = dat[1];
         }
     } else {   // GF_SP
         double wv = B.sp_w[G.data];

@@ -19,7 +19,7 @@
 
 namespace {
 struct PBlock { int size; int manifold; bool constant; long seq; };
-enum FType { FT_PROJ, FT_IMU, FT_CP, FT_PR, FT_DOP, FT_SP, FT_PRIOR };
+enum FType { FT_PROJ, FT_IMU, FT_CP, FT_PR, FT_DOP, FT_SP, FT_PRIOR, FT_SPR, FT_SCP, FT_FIX };
 struct PFactor {
     FType type; bool alive, enabled;
     std::vector<double*> keys;
@@ -44,8 +44,8 @@ struct swf_problem {
     std::vector<double*> kpose, ksb, klm, ksc;       // key per pool slot
     std::vector<uint8_t> is_const;
     std::vector<int32_t> order_block, order_group;
-    std::vector<int32_t> proj_idx, imu_idx, cp_idx, pr_idx, dop_idx, sp_idx, prior_nblk, prior_dim, prior_blk;
-    std::vector<double> proj_uv, imu_pre, cp_dat, pr_dat, dop_dat, sp_w, prior_J, prior_r0, prior_x0;
+    std::vector<int32_t> proj_idx, imu_idx, cp_idx, pr_idx, dop_idx, sp_idx, spr_idx, scp_idx, fix_idx, prior_nblk, prior_dim, prior_blk;
+    std::vector<double> proj_uv, imu_pre, cp_dat, pr_dat, dop_dat, sp_w, spr_dat, scp_dat, fix_dat, prior_J, prior_r0, prior_x0;
     // exports
     std::vector<double> S, rhs, L;
     std::vector<double> mgA, mgb, mgJ, mgr0;      // swf_problem_marginalize outputs
@@ -154,6 +154,17 @@ swf_factor_id swf_add_doppler(swf_problem* p, double* sbp, double* drift, double
 swf_factor_id swf_add_scalar_prior(swf_problem* p, double* scalar, double w) {
     return add_factor(p, FT_SP, { scalar }, { 1 }, &w, 1);
 }
+swf_factor_id swf_add_spp_pseudorange(swf_problem* p, double* pose, double* clk, const double* dat) {
+    return add_factor(p, FT_SPR, { pose, clk }, { 7, 1 }, dat, SWF_SPR_DOUBLES);
+}
+swf_factor_id swf_add_spp_carrier_phase(swf_problem* p, double* pose, double* clk, double* amb, const double* dat) {
+    return add_factor(p, FT_SCP, { pose, clk, amb }, { 7, 1, 1 }, dat, SWF_SCP_DOUBLES);
+}
+swf_factor_id swf_add_fixed_integer(swf_problem* p, double* na, double* nb, double N21, double istd) {
+    if (na == nb) return pfail(SWF_E_INVALID, "fixed integer: both blocks are the same scalar");
+    double dat[SWF_FIX_DOUBLES] = { N21, istd };
+    return add_factor(p, FT_FIX, { na, nb }, { 1, 1 }, dat, SWF_FIX_DOUBLES);
+}
 swf_factor_id swf_add_linear_prior(swf_problem* p, double* const* keys, int32_t n_keys, const double* J, const double* r0, const double* x0) {
     if (!p || !keys || n_keys <= 0 || !J || !r0 || !x0) return SWF_E_INVALID;
     std::vector<double*> k(keys, keys + n_keys);
@@ -239,6 +250,7 @@ static int flatten(swf_problem* p) {
     // factors
     p->proj_idx.clear(); p->proj_uv.clear(); p->imu_idx.clear(); p->imu_pre.clear(); p->cp_idx.clear(); p->cp_dat.clear();
     p->pr_idx.clear(); p->pr_dat.clear(); p->dop_idx.clear(); p->dop_dat.clear(); p->sp_idx.clear(); p->sp_w.clear();
+    p->spr_idx.clear(); p->spr_dat.clear(); p->scp_idx.clear(); p->scp_dat.clear(); p->fix_idx.clear(); p->fix_dat.clear();
     p->prior_nblk.clear(); p->prior_dim.clear(); p->prior_blk.clear(); p->prior_J.clear(); p->prior_r0.clear(); p->prior_x0.clear();
     double sqrt_info = 0, loss_a = 0; bool have_proj = false;
     for (auto& f : p->factors) {
@@ -256,6 +268,9 @@ static int flatten(swf_problem* p) {
         case FT_PR: for (double* k : f.keys) p->pr_idx.push_back(pool_idx[k]); p->pr_dat.insert(p->pr_dat.end(), f.data.begin(), f.data.end()); break;
         case FT_DOP: for (double* k : f.keys) p->dop_idx.push_back(pool_idx[k]); p->dop_dat.insert(p->dop_dat.end(), f.data.begin(), f.data.end()); break;
         case FT_SP: p->sp_idx.push_back(pool_idx[f.keys[0]]); p->sp_w.push_back(f.data[0]); break;
+        case FT_SPR: for (double* k : f.keys) p->spr_idx.push_back(pool_idx[k]); p->spr_dat.insert(p->spr_dat.end(), f.data.begin(), f.data.end()); break;
+        case FT_SCP: for (double* k : f.keys) p->scp_idx.push_back(pool_idx[k]); p->scp_dat.insert(p->scp_dat.end(), f.data.begin(), f.data.end()); break;
+        case FT_FIX: for (double* k : f.keys) p->fix_idx.push_back(pool_idx[k]); p->fix_dat.insert(p->fix_dat.end(), f.data.begin(), f.data.end()); break;
         case FT_PRIOR: {
             int dim = f.dim, gsum = 0;
             p->prior_nblk.push_back((int)f.keys.size()); p->prior_dim.push_back(dim);
@@ -279,6 +294,9 @@ static int flatten(swf_problem* p) {
     w.n_pr = (int)p->pr_idx.size() / 2; w.pr_idx = p->pr_idx.data(); w.pr_dat = p->pr_dat.data();
     w.n_dop = (int)p->dop_idx.size() / 3; w.dop_idx = p->dop_idx.data(); w.dop_dat = p->dop_dat.data();
     w.n_sp = (int)p->sp_idx.size(); w.sp_idx = p->sp_idx.data(); w.sp_w = p->sp_w.data();
+    w.n_spr = (int)p->spr_idx.size() / 2; w.spr_idx = p->spr_idx.data(); w.spr_dat = p->spr_dat.data();
+    w.n_scp = (int)p->scp_idx.size() / 3; w.scp_idx = p->scp_idx.data(); w.scp_dat = p->scp_dat.data();
+    w.n_fix = (int)p->fix_idx.size() / 2; w.fix_idx = p->fix_idx.data(); w.fix_dat = p->fix_dat.data();
     w.n_prior = (int)p->prior_nblk.size(); w.prior_nblk = p->prior_nblk.data(); w.prior_dim = p->prior_dim.data();
     w.prior_blk = p->prior_blk.data(); w.prior_J = p->prior_J.data(); w.prior_r0 = p->prior_r0.data(); w.prior_x0 = p->prior_x0.data();
     for (int k = 0; k < 3; k++) { w.pbg[k] = p->pbg[k]; w.gw[k] = p->gw[k]; w.base[k] = p->base[k]; }

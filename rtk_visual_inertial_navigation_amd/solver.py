@@ -43,6 +43,7 @@ EXPORTED = [
     "swf_remove_factor", "swf_factor_set_enabled", "swf_set_constants", "swf_set_ordering",
     "swf_set_export_tail", "swf_problem_solve", "swf_get_reduced", "swf_problem_marginalize",
     "swf_batch_marginalize", "swf_batch_get_prior",
+    "swf_add_spp_pseudorange", "swf_add_spp_carrier_phase", "swf_add_fixed_integer",
 ]
 
 
@@ -269,6 +270,17 @@ class Problem:
         a, pa = self._d(dat)
         return self._fid(lib().swf_add_doppler(self._h, self._p(sb), self._p(drift), self._p(pose), pa), "AddDoppler")
 
+    def AddSppPseudorange(self, pose, clk, dat):
+        a, pa = self._d(dat)
+        return self._fid(lib().swf_add_spp_pseudorange(self._h, self._p(pose), self._p(clk), pa), "AddSppPseudorange")
+
+    def AddSppCarrierPhase(self, pose, clk, amb, dat):
+        a, pa = self._d(dat)
+        return self._fid(lib().swf_add_spp_carrier_phase(self._h, self._p(pose), self._p(clk), self._p(amb), pa), "AddSppCarrierPhase")
+
+    def AddFixedInteger(self, n_a, n_b, N21, istd):
+        return self._fid(lib().swf_add_fixed_integer(self._h, self._p(n_a), self._p(n_b), C.c_double(N21), C.c_double(istd)), "AddFixedInteger")
+
     def AddScalarPrior(self, scalar, w):
         return self._fid(lib().swf_add_scalar_prior(self._h, self._p(scalar), C.c_double(w)), "AddScalarPrior")
 
@@ -342,6 +354,12 @@ def problem_from_window(w):
         P.AddDoppler(sb[ix[0]], sc[ix[1]], pose[ix[2]], d)
     for i, wv in zip(a["sp_idx"], a["sp_w"]):
         P.AddScalarPrior(sc[i], wv)
+    for ix, d in zip(a["spr_idx"].reshape(-1, 2), a["spr_dat"].reshape(-1, 5)):
+        P.AddSppPseudorange(pose[ix[0]], sc[ix[1]], d)
+    for ix, d in zip(a["scp_idx"].reshape(-1, 3), a["scp_dat"].reshape(-1, 6)):
+        P.AddSppCarrierPhase(pose[ix[0]], sc[ix[1]], sc[ix[2]], d)
+    for ix, d in zip(a["fix_idx"].reshape(-1, 2), a["fix_dat"].reshape(-1, 2)):
+        P.AddFixedInteger(sc[ix[0]], sc[ix[1]], d[0], d[1])
     bo = jo = ro = xo = 0
     for nb, dim in zip(a["prior_nblk"], a["prior_dim"]):
         ids = a["prior_blk"][bo:bo + nb]

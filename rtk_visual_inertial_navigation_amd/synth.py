@@ -470,6 +470,45 @@ def make_window(config_id=3, seed=None, K=None, F=None, S=None, prior=None, pert
     return win
 
 
+def with_spp_and_fixed(win, seed=7, n_fix=4, spp_stride=2):
+    """Copy of an RTK window with rover-only and fixed-integer factors added on its existing blocks
+    (a separate random stream, so the base window and the goldens made from it do not change):
+      * SppPseudorangeFactor on (pose k, clock k) and SppCarrierPhaseFactor on (pose k, clock k, ambiguity s) for every
+        `spp_stride`-th (epoch, satellite) pair — istd as the reference forms it for rover-only measurements, a fixed
+        number per measurement (R/swf/swf_core.cpp:157-190);
+      * `n_fix` FixedIntegerFactor(N21, 1/0.03) between ambiguity pairs, N21 = the rounded true difference
+        (what the LAMBDA consumer injects after a successful fix, R/swf/swf_lambda.cpp:318-330)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    w = win.copy()
+    K, S = win.meta["K"], win.meta["S"]
+    if S <= 0:
+        raise ValueError("with_spp_and_fixed needs a window with satellites")
+    tr = win.meta["truth"]
+    i_amb0, i_clk0 = 1, 1 + S
+    cp_idx = win.a["cp_idx"].reshape(-1, 3); cp_dat = win.a["cp_dat"].reshape(-1, CP_DOUBLES)
+    spr_idx, spr_dat, scp_idx, scp_dat = [], [], [], []
+    for i in range(0, cp_idx.shape[0], spp_stride):
+        k, ia, ic = (int(v) for v in cp_idx[i])
+        ps = cp_dat[i, :3]
+        xg = tr["pose"][k, :3] + win.base
+        r = np.linalg.norm(xg - ps)
+        rho = r + OMGE * (ps[0] * xg[1] - ps[1] * xg[0]) / CLIGHT
+        istd_p, istd_l = float(rng.uniform(0.5, 3.0)), float(rng.uniform(20.0, 200.0))
+        spr_idx.append([k, ic]); spr_dat.append([ps[0], ps[1], ps[2], rho + tr["sc"][ic] + rng.normal(0, 1.0 / istd_p), istd_p])
+        scp_idx.append([k, ic, ia])
+        scp_dat.append([ps[0], ps[1], ps[2], rho + tr["sc"][ic] - LAM_L1 * tr["sc"][ia] + rng.normal(0, 1.0 / istd_l), istd_l, LAM_L1])
+    fix_idx, fix_dat = [], []
+    for j in range(min(n_fix, S - 1)):
+        a_, b_ = i_amb0 + j, i_amb0 + ((j + 1 + int(rng.integers(0, S - 1))) % S)
+        if a_ == b_:
+            b_ = i_amb0 + (j + 1) % S
+        fix_idx.append([a_, b_]); fix_dat.append([float(np.rint(tr["sc"][b_] - tr["sc"][a_])), 1 / 0.03])
+    w.a["spr_idx"] = np.array(spr_idx, np.int32).reshape(-1, 2); w.a["spr_dat"] = np.array(spr_dat, np.float64).reshape(-1, 5)
+    w.a["scp_idx"] = np.array(scp_idx, np.int32).reshape(-1, 3); w.a["scp_dat"] = np.array(scp_dat, np.float64).reshape(-1, 6)
+    w.a["fix_idx"] = np.array(fix_idx, np.int32).reshape(-1, 2); w.a["fix_dat"] = np.array(fix_dat, np.float64).reshape(-1, 2)
+    return w
+
+
 def make_batch(n_windows, config_id=4, seed0=None):
     """cfg4: n independent windows = cfg3 with seeds seed+i."""
     if seed0 is None:

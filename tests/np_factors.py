@@ -91,6 +91,21 @@ def pr_residual(pose, clk, dat, base):
     return w * (gnss_range(pose[:3] + base, dat[:3]) - dat[3] + clk)
 
 
+def spr_residual(pose, clk, dat, base):
+    """SppPseudorangeFactor, gnss_factor.cpp:9-39; dat = sat[3] P1 istd."""
+    return dat[4] * (gnss_range(pose[:3] + base, dat[:3]) + clk - dat[3])
+
+
+def scp_residual(pose, clk, amb, dat, base):
+    """SppCarrierPhaseFactor, gnss_factor.cpp:45-80; dat = sat[3] L1_lam istd lam."""
+    return dat[4] * (gnss_range(pose[:3] + base, dat[:3]) + clk - amb * dat[5] - dat[3])
+
+
+def fix_residual(na, nb, dat):
+    """FixedIntegerFactor, gnss_factor.cpp:85-96; dat = N21 istd."""
+    return dat[1] * ((nb - na) - dat[0])
+
+
 def dop_residual(sb, drift, pose, dat, base):
     xg = pose[:3] + base; rs, vs = dat[:3], dat[3:6]
     e = (xg - rs) / np.linalg.norm(xg - rs)

@@ -121,6 +121,28 @@ def eval_pr(pose, clk, dat, base):
     return r.value, Jp, Jc.value
 
 
+def eval_spr(pose, clk, dat, base):
+    r, Jp, Jc = C.c_double(), np.zeros(6), C.c_double()
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pose, dat, base)]
+    lib().oracle_eval_spr(_p(a[0]), C.c_double(clk), _p(a[1]), _p(a[2]), C.byref(r), _p(Jp), C.byref(Jc))
+    return r.value, Jp, Jc.value
+
+
+def eval_scp(pose, clk, amb, dat, base):
+    r, Jp, Jc, Ja = C.c_double(), np.zeros(6), C.c_double(), C.c_double()
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pose, dat, base)]
+    lib().oracle_eval_scp(_p(a[0]), C.c_double(clk), C.c_double(amb), _p(a[1]), _p(a[2]),
+                          C.byref(r), _p(Jp), C.byref(Jc), C.byref(Ja))
+    return r.value, Jp, Jc.value, Ja.value
+
+
+def eval_fix(na, nb, dat):
+    r, Ja, Jb = C.c_double(), C.c_double(), C.c_double()
+    d = np.ascontiguousarray(dat, dtype=np.float64)
+    lib().oracle_eval_fix(C.c_double(na), C.c_double(nb), _p(d), C.byref(r), C.byref(Ja), C.byref(Jb))
+    return r.value, Ja.value, Jb.value
+
+
 def eval_dop(sb, drift, pose, dat, base):
     r, Jsb, Jd, Jp = C.c_double(), np.zeros(9), C.c_double(), np.zeros(6)
     a = [np.ascontiguousarray(x, dtype=np.float64) for x in (sb, pose, dat, base)]

@@ -49,14 +49,23 @@ CASES = [
     dict(config_id=3, K=26, F=40, S=5, seed=11),      # > 21 frames: the 12-consumer-wave k_lm_schur variant; tracks of 17..26
                                                       # observations span two 16-lane groups; n_red > 240: the streaming Cholesky
     dict(config_id=2, K=38, F=24, S=0, seed=12),      # tracks of 33..38 observations span four groups (a whole producer wave)
+    dict(config_id=3, K=7, F=33, S=12, seed=9, spp=True),          # + rover-only pseudorange / carrier phase and fixed-integer factors
+    dict(config_id=3, K=5, F=14, S=6, seed=4, spp=True, head="ambiguities"),   # the same with the ambiguities as parameter_head
     dict(config_id=5),                                # the full stress configuration: 40 KF / 1000 features / 20 sats / dense prior,
                                                       # n_red = 440 (k_chol_big), 120 tiles (two launches of the 12-consumer-wave k_lm_schur variant)
 ]
 
 
+def make_case(kw):
+    kw = dict(kw)
+    spp = kw.pop("spp", False)
+    w = synth.make_window(**kw)
+    return synth.with_spp_and_fixed(w, seed=kw.get("seed", 1) + 100) if spp else w
+
+
 @pytest.mark.parametrize("kw", CASES)
 def test_linearisation_and_reduced_system_match_oracle(kw):
-    w0 = synth.make_window(**kw)
+    w0 = make_case(kw)
     wo, wg = w0.copy(), w0.copy()
     so, eo = ob.solve(wo, default_options(step_mode=1))
     bs, sg = gpu_solve(wg, default_options(step_mode=1))
@@ -81,7 +90,7 @@ def test_linearisation_and_reduced_system_match_oracle(kw):
 
 @pytest.mark.parametrize("kw", CASES)
 def test_dogleg_cost_and_step_sequence_matches_oracle(kw):
-    w0 = synth.make_window(**kw)
+    w0 = make_case(kw)
     wo, wg = w0.copy(), w0.copy()
     so, _ = ob.solve(wo, default_options(max_num_iterations=8), export=False)
     bs, sg = gpu_solve(wg, default_options(max_num_iterations=8))
@@ -321,7 +330,8 @@ def test_problem_api_equals_batch_path_and_exports_tail_information():
     (R/swf/swf_gnss.cpp:65-94): with the parameter_head states ordered last,
     L_nn L_nn^T = marginal information of those states = Schur complement of S onto them."""
     from rtk_visual_inertial_navigation_amd.ordering import my_ordering
-    w = synth.make_window(3, K=6, F=30, S=5, seed=21)
+    # rover-only + fixed-integer factors included: every typed AddResidualBlock of the surface is exercised
+    w = synth.with_spp_and_fixed(synth.make_window(3, K=6, F=30, S=5, seed=21), seed=5, n_fix=2)
     roles = dict(w.meta["roles"]); roles["parameter_head"] = list(roles["rtk_ambiguities"])
     ob_, og_, nt = my_ordering(roles, w.a["is_const"])
     w.a["order_block"] = ob_; w.a["order_group"] = og_; w.n_tail = nt

@@ -83,6 +83,37 @@ def test_gnss_factors_vs_numpy_and_fd(win3):
         assert abs(r - rn) < 1e-7 * abs(Jc) + 1e-9
 
 
+def test_spp_and_fixed_integer_factors_vs_numpy_and_fd():
+    """SppPseudorange / SppCarrierPhase / FixedInteger (gnss_factor.cpp:9-96): residual against the numpy restatement,
+    Jacobians against finite differences (the analytic position Jacobian omits the Sagnac derivative, as in the reference)."""
+    rng = np.random.default_rng(11)
+    base = synth.ANCHOR
+    sag = nf.OMGE / nf.CLIGHT
+    for t in range(6):
+        pose = np.concatenate([rng.normal(0, 30, 3), [0, 0, 0, 1.0]])
+        sat = base + rng.normal(0, 1, 3) * 3e6 + np.array([1.1e7, -0.9e7, 1.8e7])
+        clk, amb, istd, lam = rng.normal(0, 50), rng.normal(0, 20), rng.uniform(0.2, 30), 0.1903
+        rng_m = nf.gnss_range(pose[:3] + base, sat)
+        dat = np.concatenate([sat, [rng_m + clk + rng.normal(0, 2), istd]])
+        r, Jp, Jc = ob.eval_spr(pose, clk, dat, base)
+        f = lambda P, Cc: nf.spr_residual(P, Cc[0], dat, base)
+        blocks = [pose, np.array([clk])]
+        assert abs(r - f(*blocks)) < 1e-7 * istd
+        sd = istd * sag * np.array([-sat[1], sat[0], 0.0])
+        assert np.abs(Jp[:3] + sd - nf.fd_jac(f, blocks, 0, 0.5)[0][:3]).max() < 1e-6 * istd and np.all(Jp[3:] == 0)
+        assert Jc == istd
+        dat2 = np.concatenate([sat, [rng_m + clk - amb * lam + rng.normal(0, 0.01), istd, lam]])
+        r, Jp2, Jc, Ja = ob.eval_scp(pose, clk, amb, dat2, base)
+        f2 = lambda P, Cc, A: nf.scp_residual(P, Cc[0], A[0], dat2, base)
+        blocks2 = [pose, np.array([clk]), np.array([amb])]
+        assert abs(r - f2(*blocks2)) < 1e-7 * istd
+        assert np.array_equal(Jp2, Jp) and Jc == istd and Ja == -istd * lam
+        assert abs(Ja - nf.fd_jac(f2, blocks2, 2, 100.0)[0, 0]) < 1e-6 * abs(Ja)
+        na, nb, dat3 = rng.normal(0, 9), rng.normal(0, 9), np.array([float(rng.integers(-20, 20)), rng.uniform(1, 1e3)])
+        r, Ja, Jb = ob.eval_fix(na, nb, dat3)
+        assert r == nf.fix_residual(na, nb, dat3) and Ja == -dat3[1] and Jb == dat3[1]
+
+
 def test_doppler_factor_vs_numpy_and_fd():
     rng = np.random.default_rng(5)
     base = synth.ANCHOR
@@ -143,6 +174,31 @@ def test_oracle_solver_invariants(win3):
     # every quaternion stays normalised
     q = w.a["pose"].reshape(-1, 7)[:, 3:]
     assert np.abs(np.linalg.norm(q, axis=1) - 1).max() < 1e-14
+
+
+def test_oracle_window_with_spp_and_fixed_integer_factors():
+    """The rover-only and fixed-integer factor kinds inside a whole solve: they change the cost by exactly their numpy
+    residuals, the solve still converges, and the fixed-integer constraints hold at the solution."""
+    base = synth.make_window(config_id=3, K=5, F=14, S=6, seed=4)
+    w = synth.with_spp_and_fixed(base, seed=3, n_fix=3)
+    c = w.counts()
+    assert c["n_spr"] == c["n_scp"] == 15 and c["n_fix"] == 3
+    s0, _ = ob.solve(base.copy(), default_options(step_mode=1))
+    s1, _ = ob.solve(w.copy(), default_options(step_mode=1))
+    pose, sc = w.a["pose"].reshape(-1, 7), w.a["sc"]
+    extra = 0.0
+    for ix, d in zip(w.a["spr_idx"].reshape(-1, 2), w.a["spr_dat"].reshape(-1, 5)):
+        extra += 0.5 * nf.spr_residual(pose[ix[0]], sc[ix[1]], d, w.base) ** 2
+    for ix, d in zip(w.a["scp_idx"].reshape(-1, 3), w.a["scp_dat"].reshape(-1, 6)):
+        extra += 0.5 * nf.scp_residual(pose[ix[0]], sc[ix[1]], sc[ix[2]], d, w.base) ** 2
+    for ix, d in zip(w.a["fix_idx"].reshape(-1, 2), w.a["fix_dat"].reshape(-1, 2)):
+        extra += 0.5 * nf.fix_residual(sc[ix[0]], sc[ix[1]], d) ** 2
+    assert abs((s1.initial_cost - s0.initial_cost) - extra) < 1e-9 * s1.initial_cost
+    ws = w.copy()
+    sm, _ = ob.solve(ws, default_options(max_num_iterations=8), export=False)
+    assert sm.final_cost < 1e-2 * sm.initial_cost
+    for ix, d in zip(ws.a["fix_idx"].reshape(-1, 2), ws.a["fix_dat"].reshape(-1, 2)):
+        assert abs((ws.a["sc"][ix[1]] - ws.a["sc"][ix[0]]) - d[0]) < 0.05
 
 
 def test_oracle_schur_equals_dense_normal_equations(win3):
