@@ -139,6 +139,24 @@ int swf_batch_enable_timing(swf_batch* b, int32_t mask);
 int swf_batch_timing(swf_batch* b, swf_timing* out);
 
 /* =====================================================================================
+ * Input producer: batched IMU pre-integration
+ *
+ * IntegrationBase ctor / push_back / propagate / midPointIntegration / get_sqrtinfo
+ * (R/factor/integration_base.cpp:5-142) for n_intervals keyframe intervals, one wavefront each.
+ *   samples  [first[n_intervals]][7]  dt, acc(3), gyr(3).  The first sample of an interval seeds acc_0 / gyr_0 (its dt
+ *            is ignored, as the reference's constructor takes no dt); every further sample is one push_back(dt, acc, gyr).
+ *   first    [n_intervals + 1]        sample offsets (interval i owns samples first[i] .. first[i+1]-1)
+ *   bias     [n_intervals][6]         linearisation biases ba, bg
+ *   noise    ACC_N, GYR_N, ACC_W, GYR_W (yaml; R/parameter/parameters.cpp)
+ *   pre      [n_intervals][SWF_PRE_DOUBLES] records, the layout swf_add_imu / swf_flat_window::imu_pre take.
+ *            A covariance that is not positive definite (an interval with no push_back) leaves sqrt_info zero.
+ * on_device = 0: all pointers are host memory; the call copies in, runs, copies out and synchronises.
+ * on_device = 1: all pointers are device memory; the kernel is enqueued on `stream` and the call returns.
+ * ===================================================================================== */
+int swf_preintegrate_batch(const double* samples, const int32_t* first, int32_t n_intervals, const double* bias,
+                           const double noise[4], double* pre, int32_t on_device, void* stream);
+
+/* =====================================================================================
  * (2) ceres::Problem-shaped single-window surface
  *
  * Parameter blocks are identified BY ADDRESS like in Ceres; values are read through the

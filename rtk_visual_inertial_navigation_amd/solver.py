@@ -44,6 +44,7 @@ EXPORTED = [
     "swf_set_export_tail", "swf_problem_solve", "swf_get_reduced", "swf_problem_marginalize",
     "swf_batch_marginalize", "swf_batch_get_prior",
     "swf_add_spp_pseudorange", "swf_add_spp_carrier_phase", "swf_add_fixed_integer",
+    "swf_preintegrate_batch",
 ]
 
 
@@ -326,6 +327,24 @@ class Problem:
         n = n.value
         return (np.ctypeslib.as_array(S, (n, n)).copy(), np.ctypeslib.as_array(r, (n,)).copy(),
                 np.ctypeslib.as_array(L, (n, n)).copy())
+
+
+def preintegrate_batch(samples, biases, noise):
+    """IntegrationBase for a batch of keyframe intervals on the device (R/factor/integration_base.cpp:5-142).
+    samples: list of [n_i][7] arrays (dt, acc, gyr; the first row seeds acc_0 / gyr_0); biases [n][6] (ba, bg);
+    noise = (ACC_N, GYR_N, ACC_W, GYR_W).  Returns the [n][PRE_DOUBLES] records AddImu / imu_pre take."""
+    n = len(samples)
+    first = np.zeros(n + 1, np.int32)
+    for i, s_ in enumerate(samples):
+        first[i + 1] = first[i] + np.asarray(s_).reshape(-1, 7).shape[0]
+    flat = (np.ascontiguousarray(np.concatenate([np.asarray(s_, np.float64).reshape(-1, 7) for s_ in samples]))
+            if n and first[n] else np.zeros((1, 7)))
+    b = np.ascontiguousarray(np.asarray(biases, np.float64).reshape(n, 6))
+    nz = (C.c_double * 4)(*[float(v) for v in noise])
+    out = np.zeros((n, 293))
+    _chk(lib().swf_preintegrate_batch(flat.ctypes.data_as(_pd), first.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(n),
+                                      b.ctypes.data_as(_pd), nz, out.ctypes.data_as(_pd), C.c_int32(0), None), "preintegrate_batch")
+    return out
 
 
 def problem_from_window(w):

@@ -1,0 +1,66 @@
+"""Time the batched IMU pre-integration kernel on the GPU against the oracle on one host thread.
+   python tools/bench_preintegrate.py [windows] [samples_per_interval]
+Workload: cfg4-shaped — `windows` x 19 keyframe intervals, each with `samples_per_interval` IMU samples (400 Hz x 0.1 s = 41
+with the seeding sample), inputs resident in HBM, HIP-event timing on the launch stream."""
+import ctypes as C, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import oracle_binding as ob
+from rtk_visual_inertial_navigation_amd import synth, solver
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+NS = int(sys.argv[2]) if len(sys.argv) > 2 else 41
+n_int = W * 19
+rng = np.random.default_rng(5)
+smp = np.zeros((n_int, NS, 7))
+smp[:, :, 0] = 0.0025
+smp[:, :, 1:4] = np.array([0, 0, 9.8]) + rng.normal(0, 0.5, (n_int, NS, 3))
+smp[:, :, 4:7] = rng.normal(0, 0.2, (n_int, NS, 3))
+bias = np.concatenate([rng.normal(0, 0.05, (n_int, 3)), rng.normal(0, 0.005, (n_int, 3))], axis=1)
+first = (np.arange(n_int + 1) * NS).astype(np.int32)
+noise = (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W)
+dev = torch.device("cuda:0")
+d_s = torch.from_numpy(smp.reshape(-1, 7)).to(dev); d_f = torch.from_numpy(first).to(dev); d_b = torch.from_numpy(bias).to(dev)
+d_o = torch.zeros((n_int, 293), dtype=torch.float64, device=dev)
+nz = (C.c_double * 4)(*noise)
+_pd = C.POINTER(C.c_double)
+lib = solver.lib()
+st = torch.cuda.current_stream()
+
+
+def launch():
+    rc = lib.swf_preintegrate_batch(C.cast(d_s.data_ptr(), _pd), C.cast(d_f.data_ptr(), C.POINTER(C.c_int32)), C.c_int32(n_int),
+                                    C.cast(d_b.data_ptr(), _pd), nz, C.cast(d_o.data_ptr(), _pd), C.c_int32(1), C.c_void_p(st.cuda_stream))
+    assert rc == 0, rc
+
+
+for _ in range(3):
+    launch()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+R = 20
+e0.record(st)
+for _ in range(R):
+    launch()
+e1.record(st); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / R
+got = d_o.cpu().numpy()
+# host-boundary variant (copies in and out)
+t0 = time.perf_counter(); host = solver.preintegrate_batch(list(smp), bias, noise); t_host = time.perf_counter() - t0
+assert np.array_equal(host, got)
+# oracle on one thread, bounded sample
+m = min(n_int, 2000)
+t0 = time.perf_counter()
+for i in range(m):
+    ref = ob.preintegrate(smp[i], bias[i, :3], bias[i, 3:], *noise)
+t_or = (time.perf_counter() - t0) / m
+assert np.abs(got[m - 1][:68] - ref[:68]).max() < 1e-12
+pushes = n_int * (NS - 1)
+# dense flop count of what the reference does per push_back: F jac, F cov, (F cov) F^T (2 * 15^3 each), V Q V^T (2 * 15 * 15 * 18 + 15 * 18)
+flop_dense = 3 * 2 * 15 ** 3 + 2 * 15 * 15 * 18 + 15 * 18
+print(json.dumps(dict(windows=W, intervals=n_int, samples_per_interval=NS, gpu_ms_per_launch=ms, gpu_intervals_per_s=n_int / (ms * 1e-3),
+                      gpu_ns_per_push_back=1e6 * ms / pushes, dense_equivalent_gflops=pushes * flop_dense / (ms * 1e-3) / 1e9,
+                      host_boundary_ms=1e3 * t_host, oracle_us_per_interval_1thread=1e6 * t_or, oracle_sample_intervals=m,
+                      speedup_vs_1thread=t_or * n_int / (ms * 1e-3))))
