@@ -38,133 +38,153 @@ struct PreintArgs {
     int n_int;
 };
 
-#define F9(i, j) sF[(i) * 15 + (j)]
-#define V9(i, j) sV[(i) * 12 + (j)]
+// broadcast of lane N of each 16-lane row to the whole row (DPP row_newbcast)
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + N, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// the matrices F is made of for one push_back (integration_base.cpp:48-75), identical in the 16 lanes of an interval
+struct StepMats { double Ms[9], Rs[9], M1[9], ImRw[9], dt; };
+
+// x <- F x for one 15-vector held in registers.  F = [I F01 I*dt F03 F04; 0 ImRw 0 0 -I*dt; 0 F21 I F23 F24; 0 0 0 I 0; 0 0 0 0 I] with
+// F01 = -dt^2/4 (M0 + M2), F03 = -dt^2/4 (R0 + R1), F04 = dt^3/4 M1, F21 = -dt/2 (M0 + M2), F23 = -dt/2 (R0 + R1), F24 = dt^2/2 M1
+__device__ __forceinline__ void apply_F(const StepMats& S, double* x) {
+    double pa[3], pb[3], pc[3], pw[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        pa[a] = S.Ms[a * 3] * x[3] + S.Ms[a * 3 + 1] * x[4] + S.Ms[a * 3 + 2] * x[5];
+        pb[a] = S.Rs[a * 3] * x[9] + S.Rs[a * 3 + 1] * x[10] + S.Rs[a * 3 + 2] * x[11];
+        pc[a] = S.M1[a * 3] * x[12] + S.M1[a * 3 + 1] * x[13] + S.M1[a * 3 + 2] * x[14];
+        pw[a] = S.ImRw[a * 3] * x[3] + S.ImRw[a * 3 + 1] * x[4] + S.ImRw[a * 3 + 2] * x[5];
+    }
+    const double dt = S.dt, k1 = -0.25 * dt * dt, k3 = 0.25 * dt * dt * dt, h1 = -0.5 * dt, h3 = 0.5 * dt * dt;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double x0 = x[a] + dt * x[6 + a] + k1 * (pa[a] + pb[a]) + k3 * pc[a];
+        double x6 = x[6 + a] + h1 * (pa[a] + pb[a]) + h3 * pc[a];
+        double x3 = pw[a] - dt * x[12 + a];
+        x[a] = x0; x[3 + a] = x3; x[6 + a] = x6;
+    }
+}
+
+#define PI_GROUPS 4            // intervals per wavefront (16 lanes each: lane c < 15 owns column c of the Jacobian and of the covariance)
+#define PI_TLD 17              // padded row of the transpose buffer
 
 __global__ void __launch_bounds__(64) k_preintegrate(PreintArgs A) {
-    __shared__ double jac[225], cov[225], sF[135], sV[108], Tc[135], sU[225];
-    const int it = blockIdx.x, lane = threadIdx.x;
-    if (it >= A.n_int) return;
-    const int s0 = A.first[it], s1 = A.first[it + 1];
+    __shared__ double sT[PI_GROUPS][15 * PI_TLD];
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int it = blockIdx.x * PI_GROUPS + g;
+    const bool live = it < A.n_int;
+    const int itc = live ? it : A.n_int - 1;
+    const int s0 = A.first[itc], n = live ? A.first[itc + 1] - s0 : 0;
     const double* __restrict__ smp = A.samples + (size_t)s0 * 7;
-    const int n = s1 - s0;
-    const double* bb = A.bias + (size_t)it * 6;
+    const double* bb = A.bias + (size_t)itc * 6;
     const double ba[3] = { bb[0], bb[1], bb[2] }, bg[3] = { bb[3], bb[4], bb[5] };
-    for (int e = lane; e < 225; e += 64) { int i = e / 15, j = e - i * 15; jac[e] = (i == j) ? 1.0 : 0.0; cov[e] = 0.0; }
-    for (int e = lane; e < 135; e += 64) { int i = e / 15, j = e - i * 15; sF[e] = (i == j && (i < 3 || i >= 6)) ? 1.0 : 0.0; }
-    for (int e = lane; e < 108; e += 64) sV[e] = 0.0;
-    __syncthreads();
+    int nmax = n;
+    nmax = max(nmax, __shfl_xor(nmax, 16)); nmax = max(nmax, __shfl_xor(nmax, 32));
+    double jc[15], cc[15];                                  // column c of jacobian / covariance
+#pragma unroll
+    for (int i = 0; i < 15; i++) { jc[i] = (i == c) ? 1.0 : 0.0; cc[i] = 0.0; }
     double dp[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 1 }, dv[3] = { 0, 0, 0 }, sum_dt = 0;
     double acc0[3] = { 0, 0, 0 }, gyr0[3] = { 0, 0, 0 };
     if (n > 0) { acc0[0] = smp[1]; acc0[1] = smp[2]; acc0[2] = smp[3]; gyr0[0] = smp[4]; gyr0[1] = smp[5]; gyr0[2] = smp[6]; }
     const double gyri[3] = { gyr0[0], gyr0[1], gyr0[2] };
-    const int bi = lane / 3, bj = lane - bi * 3;          // lanes 0..8 own entry (bi, bj) of every dynamic 3x3 block
-    const double nz[12] = { A.acc_n2, A.acc_n2, A.acc_n2, A.gyr_n2, A.gyr_n2, A.gyr_n2, A.acc_n2, A.acc_n2, A.acc_n2, A.gyr_n2, A.gyr_n2, A.gyr_n2 };
-    for (int s = 1; s < n; s++) {
-        const double dt = smp[s * 7];
-        const double acc1[3] = { smp[s * 7 + 1], smp[s * 7 + 2], smp[s * 7 + 3] }, gyr1[3] = { smp[s * 7 + 4], smp[s * 7 + 5], smp[s * 7 + 6] };
-        double a0[3], a1[3], w[3], un0[3], un1[3], rq[4], hq[4], rp[3], rv[3];
+    double* T = sT[g];
+    const int bj = c / 3, b = c - bj * 3;                   // block column / column inside the block of this lane's covariance column
+    double nx[7];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { a0[k] = acc0[k] - ba[k]; a1[k] = acc1[k] - ba[k]; w[k] = 0.5 * (gyr0[k] + gyr1[k]) - bg[k]; }
-        qrot(dq, a0, un0);
-        hq[0] = w[0] * dt / 2; hq[1] = w[1] * dt / 2; hq[2] = w[2] * dt / 2; hq[3] = 1;
-        qmul(dq, hq, rq);
-        qrot(rq, a1, un1);
+    for (int k = 0; k < 7; k++) nx[k] = (n > 1) ? smp[7 + k] : 0.0;
+    for (int s = 1; s < nmax; s++) {
+        const bool act = s < n;
+        double cur[7];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            double un = 0.5 * (un0[k] + un1[k]);
-            rp[k] = dp[k] + dv[k] * dt + 0.5 * un * dt * dt;
-            rv[k] = dv[k] + un * dt;
+        for (int k = 0; k < 7; k++) cur[k] = nx[k];
+        if (s + 1 < n) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) nx[k] = smp[(s + 1) * 7 + k];       // prefetch the next sample under this step's arithmetic
         }
-        // F, V (integration_base.cpp:48-94); only the entries that change are rewritten
-        double R0[9], R1[9], Rw[9], Ra0[9], Ra1[9], ImRw[9], M0[9], M1[9], M2[9];
-        q2R(dq, R0); q2R(rq, R1);
-        skew3(w, Rw); skew3(a0, Ra0); skew3(a1, Ra1);
+        if (act) {
+            const double dt = cur[0];
+            const double* acc1 = cur + 1; const double* gyr1 = cur + 4;
+            double a0[3], a1[3], w[3], un0[3], un1[3], rq[4], hq[4], rp[3], rv[3];
 #pragma unroll
-        for (int i = 0; i < 9; i++) ImRw[i] = -Rw[i] * dt;
-        ImRw[0] += 1; ImRw[4] += 1; ImRw[8] += 1;
-        mat3mul(R0, Ra0, M0);             // R0 [a0]x
-        mat3mul(R1, Ra1, M1);             // R1 [a1]x
-        mat3mul(M1, ImRw, M2);            // R1 [a1]x (I - [w]x dt)
-        if (lane < 9) {
-            const int q = bi * 3 + bj;
-            const double I = (bi == bj) ? 1.0 : 0.0;
-            F9(0 + bi, 3 + bj) = -0.25 * M0[q] * dt * dt + -0.25 * M2[q] * dt * dt;
-            F9(0 + bi, 6 + bj) = I * dt;
-            F9(0 + bi, 9 + bj) = -0.25 * (R0[q] + R1[q]) * dt * dt;
-            F9(0 + bi, 12 + bj) = -0.25 * M1[q] * dt * dt * -dt;
-            F9(3 + bi, 3 + bj) = ImRw[q];
-            F9(3 + bi, 12 + bj) = -1.0 * I * dt;
-            F9(6 + bi, 3 + bj) = -0.5 * M0[q] * dt + -0.5 * M2[q] * dt;
-            F9(6 + bi, 9 + bj) = -0.5 * (R0[q] + R1[q]) * dt;
-            F9(6 + bi, 12 + bj) = -0.5 * M1[q] * dt * -dt;
-            const double v03 = 0.25 * -M1[q] * dt * dt * 0.5 * dt, v23 = 0.5 * -M1[q] * dt * 0.5 * dt;
-            V9(0 + bi, 0 + bj) = 0.25 * R0[q] * dt * dt;
-            V9(0 + bi, 3 + bj) = v03;
-            V9(0 + bi, 6 + bj) = 0.25 * R1[q] * dt * dt;
-            V9(0 + bi, 9 + bj) = v03;
-            V9(3 + bi, 3 + bj) = 0.5 * I * dt;
-            V9(3 + bi, 9 + bj) = 0.5 * I * dt;
-            V9(6 + bi, 0 + bj) = 0.5 * R0[q] * dt;
-            V9(6 + bi, 3 + bj) = v23;
-            V9(6 + bi, 6 + bj) = 0.5 * R1[q] * dt;
-            V9(6 + bi, 9 + bj) = v23;
-        }
-        __syncthreads();
-        // phase A: first nine rows of F jac and F cov (270 elements, <= 5 per lane)
-        double t[5];
+            for (int k = 0; k < 3; k++) { a0[k] = acc0[k] - ba[k]; a1[k] = acc1[k] - ba[k]; w[k] = 0.5 * (gyr0[k] + gyr1[k]) - bg[k]; }
+            qrot(dq, a0, un0);
+            hq[0] = w[0] * dt / 2; hq[1] = w[1] * dt / 2; hq[2] = w[2] * dt / 2; hq[3] = 1;
+            qmul(dq, hq, rq);
+            qrot(rq, a1, un1);
 #pragma unroll
-        for (int u = 0; u < 5; u++) {
-            int e = lane + 64 * u;
-            t[u] = 0;
-            if (e < 270) {
-                const double* X = e < 135 ? jac : cov;
-                int ee = e < 135 ? e : e - 135;
-                int i = ee / 15, j = ee - i * 15;
-                double acc = 0;
-#pragma unroll
-                for (int k = 0; k < 15; k++) acc += F9(i, k) * X[k * 15 + j];
-                t[u] = acc;
+            for (int k = 0; k < 3; k++) {
+                double un = 0.5 * (un0[k] + un1[k]);
+                rp[k] = dp[k] + dv[k] * dt + 0.5 * un * dt * dt;
+                rv[k] = dv[k] + un * dt;
             }
-        }
-        __syncthreads();
+            StepMats S;
+            double R0[9], R1[9], Rw[9], Ra0[9], Ra1[9], M0[9], M2[9];
+            q2R(dq, R0); q2R(rq, R1);
+            skew3(w, Rw); skew3(a0, Ra0); skew3(a1, Ra1);
 #pragma unroll
-        for (int u = 0; u < 5; u++) {
-            int e = lane + 64 * u;
-            if (e < 135) jac[e] = t[u];
-            else if (e < 270) {
-                int ee = e - 135, i = ee / 15, j = ee - i * 15;
-                Tc[ee] = t[u];
-                if (j >= 9) { cov[i * 15 + j] = t[u]; cov[j * 15 + i] = t[u]; }     // unit rows of F: (F cov F^T)[i][j>=9] = (F cov)[i][j]
+            for (int i = 0; i < 9; i++) S.ImRw[i] = -Rw[i] * dt;
+            S.ImRw[0] += 1; S.ImRw[4] += 1; S.ImRw[8] += 1;
+            mat3mul(R0, Ra0, M0);             // R0 [a0]x
+            mat3mul(R1, Ra1, S.M1);           // R1 [a1]x
+            mat3mul(S.M1, S.ImRw, M2);        // R1 [a1]x (I - [w]x dt)
+#pragma unroll
+            for (int i = 0; i < 9; i++) { S.Ms[i] = M0[i] + M2[i]; S.Rs[i] = R0[i] + R1[i]; }
+            S.dt = dt;
+            // jacobian = F jacobian ; T = F cov, both column by column in registers
+            apply_F(S, jc);
+            apply_F(S, cc);
+            // cov symmetric => row c of (F cov) is column c of cov F^T: transpose through LDS, then F (cov F^T)
+#pragma unroll
+            for (int i = 0; i < 15; i++) if (c < 15) T[i * PI_TLD + c] = cc[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 15; k++) cc[k] = T[(c < 15 ? c : 0) * PI_TLD + k];
+            __builtin_amdgcn_wave_barrier();
+            apply_F(S, cc);
+            // + V Q V^T (integration_base.cpp:76-97).  With W = [R0 | -dt/2 M1 | R1 | -dt/2 M1]: V rows 0-2 = dt^2/4 W, rows 6-8 = dt/2 W,
+            // rows 3-5 = dt/2 [0 I 0 I];  G = W Q W^T = an (R0 R0^T + R1 R1^T) + gn dt^2/2 M1 M1^T,  H = W Q [0 I 0 I]^T = -gn dt M1
+            double gcol[3], hcol[3], hrow[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                double gv[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    double rr = R0[a * 3] * R0[q * 3] + R0[a * 3 + 1] * R0[q * 3 + 1] + R0[a * 3 + 2] * R0[q * 3 + 2]
+                              + R1[a * 3] * R1[q * 3] + R1[a * 3 + 1] * R1[q * 3 + 1] + R1[a * 3 + 2] * R1[q * 3 + 2];
+                    double mm = S.M1[a * 3] * S.M1[q * 3] + S.M1[a * 3 + 1] * S.M1[q * 3 + 1] + S.M1[a * 3 + 2] * S.M1[q * 3 + 2];
+                    gv[q] = A.acc_n2 * rr + 0.5 * A.gyr_n2 * dt * dt * mm;
+                }
+                gcol[a] = b == 0 ? gv[0] : b == 1 ? gv[1] : gv[2];
+                hcol[a] = -A.gyr_n2 * dt * (b == 0 ? S.M1[a * 3] : b == 1 ? S.M1[a * 3 + 1] : S.M1[a * 3 + 2]);
+                hrow[a] = -A.gyr_n2 * dt * (b == 0 ? S.M1[a] : b == 1 ? S.M1[3 + a] : S.M1[6 + a]);
             }
-        }
-        if (lane < 6) cov[(9 + lane) * 15 + 9 + lane] += (lane < 3 ? A.acc_w2 : A.gyr_w2) * dt * dt;    // V Q V^T of the bias-walk rows
-        __syncthreads();
-        // phase B: leading 9x9 block  (F cov) F^T + V Q V^T
+            const double d2 = dt * dt, d3 = d2 * dt;
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            int e = lane + 64 * u;
-            if (e < 81) {
-                int i = e / 9, j = e - i * 9;
-                double acc = 0;
-#pragma unroll
-                for (int k = 0; k < 15; k++) acc += Tc[i * 15 + k] * F9(j, k);
-#pragma unroll
-                for (int k = 0; k < 12; k++) acc += V9(i, k) * nz[k] * V9(j, k);
-                cov[i * 15 + j] = acc;
+            for (int a = 0; a < 3; a++) {
+                double eb = (a == b) ? 0.5 * A.gyr_n2 * d2 : 0.0;
+                double n0 = bj == 0 ? 0.0625 * d2 * d2 * gcol[a] : bj == 1 ? 0.125 * d3 * hcol[a] : 0.125 * d3 * gcol[a];
+                double n3 = bj == 0 ? 0.125 * d3 * hrow[a] : bj == 1 ? eb : 0.25 * d2 * hrow[a];
+                double n6 = bj == 0 ? 0.125 * d3 * gcol[a] : bj == 1 ? 0.25 * d2 * hcol[a] : 0.25 * d2 * gcol[a];
+                if (c < 9) { cc[a] += n0; cc[3 + a] += n3; cc[6 + a] += n6; }
             }
+#pragma unroll
+            for (int m = 0; m < 6; m++) if (c == 9 + m) cc[9 + m] += (m < 3 ? A.acc_w2 : A.gyr_w2) * d2;
+            // propagate(): integration_base.cpp:131-141
+            double nq = sqrt(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { dp[k] = rp[k]; dv[k] = rv[k]; acc0[k] = acc1[k]; gyr0[k] = gyr1[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) dq[k] = rq[k] / nq;
+            sum_dt += dt;
         }
-        // propagate(): integration_base.cpp:131-141
-        double nq = sqrt(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { dp[k] = rp[k]; dv[k] = rv[k]; acc0[k] = acc1[k]; gyr0[k] = gyr1[k]; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) dq[k] = rq[k] / nq;
-        sum_dt += dt;
-        __syncthreads();
     }
-    double* out = A.pre + (size_t)it * SWF_PRE_DOUBLES;
-    if (lane == 0) {
+    double* out = A.pre + (size_t)itc * SWF_PRE_DOUBLES;
+    if (live && c == 0) {
         for (int k = 0; k < 3; k++) {
             out[SWF_PRE_DP + k] = dp[k]; out[SWF_PRE_DV + k] = dv[k]; out[SWF_PRE_LBA + k] = ba[k]; out[SWF_PRE_LBG + k] = bg[k];
             out[SWF_PRE_GYRI + k] = gyri[k]; out[SWF_PRE_GYRJ + k] = gyr0[k];
@@ -172,39 +192,64 @@ __global__ void __launch_bounds__(64) k_preintegrate(PreintArgs A) {
         for (int k = 0; k < 4; k++) out[SWF_PRE_DQ + k] = dq[k];
         out[SWF_PRE_SUMDT] = sum_dt;
     }
-    if (lane < 45) {
-        int blk = lane / 9, q = lane - blk * 9, i = q / 3, j = q - i * 3;
-        const int rb[5] = { 0, 0, 3, 6, 6 }, cb[5] = { 9, 12, 12, 9, 12 };
-        out[SWF_PRE_DP_DBA + lane] = jac[(rb[blk] + i) * 15 + cb[blk] + j];      // the five 3x3 blocks are contiguous in the record
+    if (live && c >= 9 && c < 15) {                         // the five 3x3 bias-Jacobian blocks: columns 9-11 (ba) and 12-14 (bg)
+        const int cb = c >= 12 ? c - 12 : c - 9;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if (c < 12) { out[SWF_PRE_DP_DBA + a * 3 + cb] = jc[a]; out[SWF_PRE_DV_DBA + a * 3 + cb] = jc[6 + a]; }
+            else { out[SWF_PRE_DP_DBG + a * 3 + cb] = jc[a]; out[SWF_PRE_DQ_DBG + a * 3 + cb] = jc[3 + a]; out[SWF_PRE_DV_DBG + a * 3 + cb] = jc[6 + a]; }
+        }
     }
-    // get_sqrtinfo: cov = R R^T (R upper, built from the last column backwards), sqrt_info = R^-1
+    // get_sqrtinfo: cov = R R^T with R upper triangular, built from the last column backwards; lane k holds column k (= row k) of
+    // the trailing matrix, so the pivot column comes from lane j by row broadcast and R[k][j] from the lane's own row j
     bool ok = true;
-    for (int j = 14; j >= 0; j--) {
-        double d = cov[j * 15 + j];
-        if (!(d > 0) || !(d < 1e300)) { ok = false; break; }       // uniform: every lane reads the same value
-        double sd = sqrt(d);
-        __syncthreads();
-        if (lane <= j) cov[lane * 15 + j] = (lane == j) ? sd : cov[lane * 15 + j] / sd;
-        __syncthreads();
-        for (int e = lane; e < 225; e += 64) {
-            int i = e / 15, k = e - i * 15;
-            if (i <= k && k < j) cov[i * 15 + k] -= cov[i * 15 + j] * cov[k * 15 + j];
-        }
-        __syncthreads();
+#define PI_CHOL_STEP(J) { \
+        double d = row_bcast<J>(cc[J]); \
+        ok = ok && (d > 0) && (d < 1e300); \
+        double sd = sqrt(ok ? d : 1.0), inv = 1.0 / sd; \
+        double rk = cc[J] * inv; \
+        _Pragma("unroll") for (int i = 0; i < J; i++) { \
+            double rij = row_bcast<J>(cc[i]) * inv; \
+            if (c < J) cc[i] -= rij * rk; \
+            else if (c == J) cc[i] = rij; \
+        } \
+        if (c == J) cc[J] = sd; }
+    PI_CHOL_STEP(14) PI_CHOL_STEP(13) PI_CHOL_STEP(12) PI_CHOL_STEP(11) PI_CHOL_STEP(10) PI_CHOL_STEP(9) PI_CHOL_STEP(8) PI_CHOL_STEP(7)
+    PI_CHOL_STEP(6) PI_CHOL_STEP(5) PI_CHOL_STEP(4) PI_CHOL_STEP(3) PI_CHOL_STEP(2) PI_CHOL_STEP(1) PI_CHOL_STEP(0)
+#undef PI_CHOL_STEP
+    // U = R^-1: lane c solves R u = e_c backwards; R[i][k] (k > i) is element i of lane k
+    double u[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) u[i] = 0.0;
+#define PI_BACK_ROW(I) { \
+        double acc = 0; \
+        PI_BACK_TERMS_##I \
+        double rii = row_bcast<I>(cc[I]); \
+        u[I] = (c == I) ? 1.0 / rii : (c > I ? -acc / rii : 0.0); }
+#define PI_T(I, K) acc += row_bcast<K>(cc[I]) * u[K];
+#define PI_BACK_TERMS_14
+#define PI_BACK_TERMS_13 PI_T(13, 14)
+#define PI_BACK_TERMS_12 PI_T(12, 13) PI_T(12, 14)
+#define PI_BACK_TERMS_11 PI_T(11, 12) PI_T(11, 13) PI_T(11, 14)
+#define PI_BACK_TERMS_10 PI_T(10, 11) PI_T(10, 12) PI_T(10, 13) PI_T(10, 14)
+#define PI_BACK_TERMS_9 PI_T(9, 10) PI_T(9, 11) PI_T(9, 12) PI_T(9, 13) PI_T(9, 14)
+#define PI_BACK_TERMS_8 PI_T(8, 9) PI_T(8, 10) PI_T(8, 11) PI_T(8, 12) PI_T(8, 13) PI_T(8, 14)
+#define PI_BACK_TERMS_7 PI_T(7, 8) PI_T(7, 9) PI_T(7, 10) PI_T(7, 11) PI_T(7, 12) PI_T(7, 13) PI_T(7, 14)
+#define PI_BACK_TERMS_6 PI_T(6, 7) PI_T(6, 8) PI_T(6, 9) PI_T(6, 10) PI_T(6, 11) PI_T(6, 12) PI_T(6, 13) PI_T(6, 14)
+#define PI_BACK_TERMS_5 PI_T(5, 6) PI_T(5, 7) PI_T(5, 8) PI_T(5, 9) PI_T(5, 10) PI_T(5, 11) PI_T(5, 12) PI_T(5, 13) PI_T(5, 14)
+#define PI_BACK_TERMS_4 PI_T(4, 5) PI_T(4, 6) PI_T(4, 7) PI_T(4, 8) PI_T(4, 9) PI_T(4, 10) PI_T(4, 11) PI_T(4, 12) PI_T(4, 13) PI_T(4, 14)
+#define PI_BACK_TERMS_3 PI_T(3, 4) PI_T(3, 5) PI_T(3, 6) PI_T(3, 7) PI_T(3, 8) PI_T(3, 9) PI_T(3, 10) PI_T(3, 11) PI_T(3, 12) PI_T(3, 13) PI_T(3, 14)
+#define PI_BACK_TERMS_2 PI_T(2, 3) PI_T(2, 4) PI_T(2, 5) PI_T(2, 6) PI_T(2, 7) PI_T(2, 8) PI_T(2, 9) PI_T(2, 10) PI_T(2, 11) PI_T(2, 12) PI_T(2, 13) PI_T(2, 14)
+#define PI_BACK_TERMS_1 PI_T(1, 2) PI_T(1, 3) PI_T(1, 4) PI_T(1, 5) PI_T(1, 6) PI_T(1, 7) PI_T(1, 8) PI_T(1, 9) PI_T(1, 10) PI_T(1, 11) PI_T(1, 12) PI_T(1, 13) PI_T(1, 14)
+#define PI_BACK_TERMS_0 PI_T(0, 1) PI_T(0, 2) PI_T(0, 3) PI_T(0, 4) PI_T(0, 5) PI_T(0, 6) PI_T(0, 7) PI_T(0, 8) PI_T(0, 9) PI_T(0, 10) PI_T(0, 11) PI_T(0, 12) PI_T(0, 13) PI_T(0, 14)
+    PI_BACK_ROW(14) PI_BACK_ROW(13) PI_BACK_ROW(12) PI_BACK_ROW(11) PI_BACK_ROW(10) PI_BACK_ROW(9) PI_BACK_ROW(8) PI_BACK_ROW(7)
+    PI_BACK_ROW(6) PI_BACK_ROW(5) PI_BACK_ROW(4) PI_BACK_ROW(3) PI_BACK_ROW(2) PI_BACK_ROW(1) PI_BACK_ROW(0)
+#undef PI_T
+#undef PI_BACK_ROW
+    if (live && c < 15) {
+#pragma unroll
+        for (int i = 0; i < 15; i++) out[SWF_PRE_SQRTINFO + i * 15 + c] = ok ? u[i] : 0.0;
     }
-    for (int e = lane; e < 225; e += 64) sU[e] = 0.0;
-    __syncthreads();
-    if (ok && lane < 15) {
-        const int c = lane;                                        // column c of U = R^-1
-        sU[c * 15 + c] = 1.0 / cov[c * 15 + c];
-        for (int i = c - 1; i >= 0; i--) {
-            double acc = 0;
-            for (int k = i + 1; k <= c; k++) acc += cov[i * 15 + k] * sU[k * 15 + c];
-            sU[i * 15 + c] = -acc / cov[i * 15 + i];
-        }
-    }
-    __syncthreads();
-    for (int e = lane; e < 225; e += 64) out[SWF_PRE_SQRTINFO + e] = sU[e];
 }
 
 }  // namespace
@@ -220,7 +265,7 @@ extern "C" int swf_preintegrate_batch(const double* samples, const int32_t* firs
     A.n_int = n_intervals;
     if (on_device) {
         A.samples = samples; A.first = first; A.bias = bias; A.pre = pre;
-        hipLaunchKernelGGL(k_preintegrate, dim3(n_intervals), dim3(64), 0, st, A);
+        hipLaunchKernelGGL(k_preintegrate, dim3((n_intervals + PI_GROUPS - 1) / PI_GROUPS), dim3(64), 0, st, A);
         PI_HIPCHK(hipGetLastError());
         return SWF_OK;
     }
@@ -240,7 +285,7 @@ extern "C" int swf_preintegrate_batch(const double* samples, const int32_t* firs
     PI_TRY(hipMemcpyAsync(d_b, bias, (size_t)n_intervals * 6 * sizeof(double), hipMemcpyHostToDevice, st));
     PI_TRY(hipMemcpyAsync(d_f, rel.data(), rel.size() * sizeof(int), hipMemcpyHostToDevice, st));
     A.samples = d_s; A.first = d_f; A.bias = d_b; A.pre = d_o;
-    hipLaunchKernelGGL(k_preintegrate, dim3(n_intervals), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_preintegrate, dim3((n_intervals + PI_GROUPS - 1) / PI_GROUPS), dim3(64), 0, st, A);
     PI_TRY(hipGetLastError());
     PI_TRY(hipMemcpyAsync(pre, d_o, (size_t)n_intervals * SWF_PRE_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, st));
     PI_TRY(hipStreamSynchronize(st));
