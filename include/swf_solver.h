@@ -100,7 +100,7 @@ int swf_batch_dims(swf_batch* b, int32_t w, int32_t* n_loc, int32_t* n_e, int32_
  *     SWF_PRIOR_CHOLESKY  J = L_nn^T, r0 = L_nn^T y_n: the same quadratic without an eigen-decomposition (rank = n).
  * The reference pseudo-inverts S_mm through an eigen-decomposition with threshold 1e-8; this library uses the Cholesky
  * factor of the solve, which is the same thing whenever S_mm is positive definite.  If the factorisation failed the
- * window's rank is reported as -1 (no silent fallback).  SWF_PRIOR_EIGEN: n <= 140 (the Jacobi iteration keeps M in LDS);
+ * window's rank is reported as -1 (no silent fallback).  SWF_PRIOR_EIGEN: n <= 256 (the Jacobi iteration keeps M in LDS up to n = 140, in an HBM scratch above);
  * SWF_PRIOR_CHOLESKY: n <= 512.  Asynchronous on the batch stream. */
 enum { SWF_PRIOR_EIGEN = 0, SWF_PRIOR_CHOLESKY = 1 };
 int swf_batch_marginalize(swf_batch* b, double eps, int32_t form);

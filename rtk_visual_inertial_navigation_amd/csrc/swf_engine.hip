@@ -72,7 +72,7 @@ struct swf_batch {
     std::vector<HostWin> hw;
     int max_tiles = 0, max_prior_dim = 0, max_red = 0, n_cu = 256;
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
-    int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr;
+    int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr; double* mg_M = nullptr;
     bool mg_valid = false; int mg_ld = 0;
     // latency path (small batches): an auxiliary stream runs the IMU / clique branch of a linearisation next to the
     // projection / landmark branch; three reusable events carry the dependencies
@@ -969,7 +969,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
     if (b->max_red > 512 || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "marginalisation needs the row-major Cholesky factor (n_red <= 512)");
     int nw = (int)b->win.size(), ldn = 1;
     for (int w = 0; w < nw; w++) ldn = std::max(ldn, b->hw[w].tail_dim);
-    if (form == SWF_PRIOR_EIGEN && ldn > MG_MAXN) return fail(SWF_E_UNSUPPORTED, "eigen square root: parameter_head tail larger than 140 dimensions (use SWF_PRIOR_CHOLESKY)");
+    if (form == SWF_PRIOR_EIGEN && ldn > MG_BIGN) return fail(SWF_E_UNSUPPORTED, "eigen square root: parameter_head tail larger than 256 dimensions (use SWF_PRIOR_CHOLESKY)");
     b->mg_ld = ldn;
     if (!b->mg_A) {
         std::vector<int> td(nw);
@@ -982,8 +982,13 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
         rc |= b->pool.zeros((size_t)nw, &b->mg_rank);
         if (rc) return fail(SWF_E_NODEVICE, "device allocation failed");
     }
-    hipLaunchKernelGGL(k_marginalize, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
-                       b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank);
+    const bool big = form == SWF_PRIOR_EIGEN && ldn > MG_MAXN;
+    if (big && !b->mg_M && b->pool.zeros((size_t)nw * ldn * ldn, &b->mg_M)) return fail(SWF_E_NODEVICE, "device allocation failed");
+    hipLaunchKernelGGL(k_marginalize<false>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
+                       b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, (double*)nullptr);
+    if (big)
+        hipLaunchKernelGGL(k_marginalize<true>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
+                           b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M);
     HIPCHK(hipGetLastError());
     b->mg_valid = true;
     return SWF_OK;

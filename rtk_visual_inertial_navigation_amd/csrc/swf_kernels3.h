@@ -12,25 +12,31 @@
 #pragma once
 #include "swf_dev.h"
 
-#define MG_MAXN 140                       // trailing dimension handled in one workgroup (M = 153 KB of LDS)
+#define MG_MAXN 140                       // largest tail whose M is LDS-resident (153 KB)
+#define MG_BIGN 256                       // largest tail of the eigen form: above MG_MAXN, M lives in a per-window HBM / L2 scratch
 #define MG_NT 1024                        // 64 sixteen-lane groups = 64 column pairs per step
 #define MG_LDS_DOUBLES 19600              // 153 KB: M for n <= 140, M and V together for n <= 98
-#define Mc(c, r) lds[(c) * n + (r)]
+#define Mc(c, r) Mm[(c) * n + (r)]
 // form: 0 = eigen square root (the reference's prior), 1 = Cholesky square root J = L_nn^T, r0 = L_nn^T y_n (same quadratic)
 // ldn = leading dimension of the per-window output slabs (>= every window's tail dimension)
+// GM = false: tails up to MG_MAXN, M in LDS (and every Cholesky-form request); GM = true: eigen form for MG_MAXN < n <= MG_BIGN with M
+// in Mscr (same algorithm, same rotation order).  A batch launches both; each instantiation skips the other's windows.
+template <bool GM>
 __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* tail_dim, double eps, int form, int ldn,
                                                         double* outA, double* outb, double* outJ, double* outr0,
-                                                        double* outw, int* outrank) {
-    __shared__ double lds[MG_LDS_DOUBLES];           // M (n x n, column c contiguous: row c of L_nn) | V (n x n) if both fit
-    __shared__ double lam[MG_MAXN];
-    __shared__ double bv[MG_MAXN];
+                                                        double* outw, int* outrank, double* Mscr) {
+    __shared__ double lds[GM ? 16 : MG_LDS_DOUBLES];  // M (n x n, column c contiguous: row c of L_nn) | V (n x n) if both fit
+    __shared__ double lam[MG_BIGN];
+    __shared__ double bv[MG_BIGN];
     __shared__ int nrot;
     int w = blockIdx.x, tid = threadIdx.x;
     const WinRec& W = B.win[w];
     const WinState& s = B.ws[w];
     int n = tail_dim[w], nr = W.n_red, m = nr - n;
     size_t o2 = (size_t)w * ldn * ldn, o1 = (size_t)w * ldn;
-    if (n <= 0 || n > ldn || m < 0 || s.lin_fail || (form == 0 && n > MG_MAXN)) { if (tid == 0) outrank[w] = -1; return; }
+    if (GM != (form == 0 && n > MG_MAXN)) return;     // the other instantiation's window
+    if (n <= 0 || n > ldn || m < 0 || s.lin_fail || (form == 0 && n > MG_BIGN)) { if (tid == 0) outrank[w] = -1; return; }
+    double* Mm = GM ? Mscr + o2 : lds;
     const double* L = B.L + W.Lt_base;                // row-major lower, ld = n_red (k_chol_rr2 / k_chol_big)
     const double* y = B.y + W.loc_base + W.n_e + m;   // tail of the solution of S y = rhs
     if (form == 1) {
@@ -81,7 +87,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     // V is accumulated explicitly (same rotations applied to I): it stays orthogonal to machine precision, whereas
     // U = M V / sigma loses orthogonality like eps * sqrt(cond) — measured 1.5e-9 in J^T r0 - b.  V lives in the
     // window's J buffer (column c contiguous, L2-resident working set) until the final permuted write-out.
-    double* Vg = (2 * n * n <= MG_LDS_DOUBLES) ? lds + n * n : outJ + o2;      // LDS-resident V when it fits (n <= 99)
+    double* Vg = (!GM && 2 * n * n <= MG_LDS_DOUBLES) ? lds + n * n : outJ + o2;      // LDS-resident V when it fits (n <= 98)
     for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Vg[e] = (r == c) ? 1.0 : 0.0; }
     __syncthreads();
     int grp = tid >> 4, sub = tid & 15;

@@ -255,19 +255,51 @@ def test_marginalisation_consumer_matches_oracle():
     g1 = singles[2]
     assert np.abs(g1["J"].T @ g1["J"] - g1["A"]).max() <= 1e-12 * np.abs(g1["A"]).max() and np.abs(g1["J"].T @ g1["r0"] - g1["b"]).max() <= 1e-10 * np.abs(g1["b"]).max()
     bs.close()
-    # a tail beyond the Jacobi kernel's LDS capacity: the Cholesky form still applies, the eigen form says so
+    # a tail beyond the LDS capacity of the Jacobi kernel (n = 171 > 140): M moves to an HBM scratch, same algorithm; both forms
+    # against the oracle / the exported factor
     wl = synth.make_window(3, K=12, F=60, S=6, seed=33, head="frames")
+    so, eo = ob.solve(wl.copy(), default_options(step_mode=1))
     bs, _ = gpu_solve(wl.copy(), default_options(step_mode=1))
+    bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+    g = bs.get_prior(0)
+    n = g["n"]
+    assert n == 171 and g["rank"] == n
+    o = ob.marginalize(eo["S"], eo["rhs"], n)
+    m = eo["S"].shape[0] - n
+    ev = np.linalg.eigvalsh(eo["S"][:m, :m])
+    tol = max(1e-9, 1e-17 * ev[-1] / ev[0])
+    sc = np.abs(o["A"]).max()
+    assert np.abs(g["A"] - o["A"]).max() <= tol * sc and g["rank"] == o["rank"]
+    assert np.allclose(g["eig"], (o["J"] ** 2).sum(1), rtol=10 * tol, atol=tol * sc)
+    assert np.all(np.diff(g["eig"]) >= 0)
+    assert np.abs(g["J"].T @ g["J"] - g["A"]).max() <= 1e-12 * sc
+    assert np.abs(g["J"].T @ g["r0"] - g["b"]).max() <= 1e-10 * np.abs(g["b"]).max()
+    bs.marginalize(1e-8, solver.BatchSolver.PRIOR_CHOLESKY)
+    c = bs.get_prior(0)
+    S_, rhs_, L_ = bs.export_reduced(0)
+    assert c["n"] == n and c["rank"] == n
+    assert np.abs(c["A"] - L_[m:, m:] @ L_[m:, m:].T).max() <= 1e-12 * np.abs(c["A"]).max()
+    assert np.array_equal(c["A"], g["A"]) and np.array_equal(c["b"], g["b"])
+    assert np.abs(c["J"].T @ c["J"] - c["A"]).max() <= 1e-12 * np.abs(c["A"]).max()
+    assert np.abs(c["J"].T @ c["r0"] - c["b"]).max() <= 1e-10 * np.abs(c["b"]).max()
+    bs.close()
+    # mixed batch (LDS-resident and HBM-resident tails side by side) == the windows alone, bit for bit
+    bs = solver.BatchSolver([hw[0].copy(), wl.copy(), hw[1].copy()]); bs.solve(default_options(step_mode=1)); bs.marginalize()
+    for i, g1 in ((0, singles[0]), (1, g), (2, singles[1])):
+        gb = bs.get_prior(i)
+        assert gb["n"] == g1["n"] and gb["rank"] == g1["rank"]
+        for k in ("A", "b", "J", "r0", "eig"):
+            assert np.array_equal(gb[k], g1[k]), (i, k)
+    bs.close()
+    # beyond 256 dimensions the eigen form says so; the Cholesky form still applies
+    wx = synth.make_window(3, K=18, F=40, S=6, seed=35, head="frames")
+    bs, _ = gpu_solve(wx.copy(), default_options(step_mode=1))
     with pytest.raises(Exception):
         bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
     bs.marginalize(1e-8, solver.BatchSolver.PRIOR_CHOLESKY)
     c = bs.get_prior(0)
-    S_, rhs_, L_ = bs.export_reduced(0)
-    m = S_.shape[0] - c["n"]
-    assert c["n"] > 140 and c["rank"] == c["n"]
-    assert np.abs(c["A"] - L_[m:, m:] @ L_[m:, m:].T).max() <= 1e-12 * np.abs(c["A"]).max()
+    assert c["n"] == 261 and c["rank"] == 261
     assert np.abs(c["J"].T @ c["J"] - c["A"]).max() <= 1e-12 * np.abs(c["A"]).max()
-    assert np.abs(c["J"].T @ c["r0"] - c["b"]).max() <= 1e-10 * np.abs(c["b"]).max()
     bs.close()
     # call-order errors are reported
     bs, _ = gpu_solve(synth.make_window(3, K=4, F=9, S=5, seed=8), default_options())

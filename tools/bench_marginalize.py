@@ -14,7 +14,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 out = {}
 for name, kw in (("cfg3_ambiguities", dict(config_id=3, head="ambiguities")),
                  ("kf7_frames", dict(config_id=3, K=7, F=100, S=8, head="frames")),
-                 ("kf8_frames", dict(config_id=3, K=8, F=120, S=8, head="frames"))):
+                 ("kf8_frames", dict(config_id=3, K=8, F=120, S=8, head="frames")),
+                 ("kf11_frames_hbm_resident", dict(config_id=3, K=11, F=120, S=8, head="frames"))):
     ws = [synth.make_window(seed=synth.BASE_SEED + 100 + i, **kw) for i in range(B)]
     bs = solver.BatchSolver(ws)
     opt = default_options(step_mode=1)
