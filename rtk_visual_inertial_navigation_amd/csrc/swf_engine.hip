@@ -70,7 +70,7 @@ struct swf_batch {
     hipStream_t stream = nullptr;
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
-    int max_tiles = 0, max_prior_dim = 0, max_red = 0, n_cu = 256;
+    int max_tiles = 0, max_prior_dim = 0, max_red = 0, min_red = 1 << 30, n_cu = 256;
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
     int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr; double* mg_M = nullptr;
     bool mg_valid = false; int mg_ld = 0;
@@ -567,7 +567,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         int64_t k = (l + 1 < B.lm_obs0.size() ? B.lm_obs0[l + 1] : (int)B.p_win.size()) - B.lm_obs0[l];
         b->lm_schur_flops += 216 * k * k + 108 * k;
     }
-    for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); }
+    for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); b->min_red = std::min(b->min_red, W.n_red); }
     DevBatch& D = b->D;
     DevPool& P = b->pool;
     int rc = 0;
@@ -805,8 +805,11 @@ struct Launcher {
     void reduced() {
         DevBatch& D = b->D;
         Bracket t(*this, SWF_K_CHOL);
-        if (b->max_red <= 240 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
-        else if (b->max_red <= 512 && !b->force_chol_v1) hipLaunchKernelGGL(k_chol_big, dim3(D.n_win), dim3(1024), 0, st, D);
+        if (b->max_red <= 512 && !b->force_chol_v1) {
+            // per-window choice (each kernel skips the other's windows): register-resident tiles up to 240 dimensions, streamed above
+            if (b->min_red <= 240) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
+            if (b->max_red > 240) hipLaunchKernelGGL(k_chol_big, dim3(D.n_win), dim3(1024), 0, st, D);
+        }
         else if (b->max_red + 1 <= 256) hipLaunchKernelGGL(k_chol_solve<256>, dim3(D.n_win), dim3(256), 0, st, D);
         else hipLaunchKernelGGL(k_chol_solve<1024>, dim3(D.n_win), dim3(1024), 0, st, D);
     }

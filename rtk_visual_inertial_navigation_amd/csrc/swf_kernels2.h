@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
     if (!st.need_lin || st.lin_fail) return;
     const WinRec& W = B.win[w];
     int n = W.n_red, tid = threadIdx.x;
-    if (n <= 0) return;
+    if (n <= 0 || n > 240) return;                 // larger windows of a mixed batch belong to k_chol_big (launched next to this one)
     int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int Tc = (n + 15) >> 4, Tr = Tc + 1;
     if (tid == 0) fail = 0;
@@ -557,7 +557,8 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     if (!st.need_lin || st.lin_fail) return;
     const WinRec& W = B.win[w];
     int n = W.n_red, tid = threadIdx.x;
-    if (n <= 0) return;
+    if (n <= 240) return;                          // the register-resident kernel's windows: the kernel is chosen per WINDOW, so a
+                                                   // window's arithmetic does not depend on what else is in the batch
     int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int Tc = (n + 15) >> 4, Tr = Tc + 1;
     const double* S = B.S + W.S_base;

@@ -136,7 +136,10 @@ def test_batch_equals_single_window_solves_bitwise():
     (bit for bit) what solving each alone gives, and repeated solves must be bit-reproducible
     (fixed accumulation order, no float atomics)."""
     ws = [synth.make_window(3, K=6, F=30, S=5, seed=40), synth.make_window(2, K=5, F=20, S=0, seed=41),
-          synth.make_window(3, K=8, F=45, S=6, seed=42), synth.make_window(5, K=14, F=35, S=4, seed=43)]
+          synth.make_window(3, K=8, F=45, S=6, seed=42), synth.make_window(5, K=14, F=35, S=4, seed=43),
+          # n_red > 240: this window takes the streaming Cholesky kernel, the others the register-resident one — the kernel is
+          # chosen per window, so mixing them must not change anybody's arithmetic
+          synth.make_window(3, K=26, F=40, S=5, seed=11)]
     singles = []
     for w in ws:
         c = w.copy()
