@@ -156,6 +156,21 @@ int swf_batch_timing(swf_batch* b, swf_timing* out);
 int swf_preintegrate_batch(const double* samples, const int32_t* first, int32_t n_intervals, const double* bias,
                            const double noise[4], double* pre, int32_t on_device, void* stream);
 
+/* Input producer: two-view landmark triangulation for a batch of features — FeatureManager::triangulate, the branch every
+ * feature with >= 2 observations takes (R/feature/feature_manager.cpp:285-316), with triangulatePoint (:148-161).
+ *   Ps [n_frames][3], Rs [n_frames][9] (row-major)  frame positions / rotations as the reference passes them
+ *   tic, ric (row-major), pbg                        camera extrinsic and the IMU->antenna lever arm
+ *   start_frame [n]                                  first observing frame i of each feature (the second view is i + 1);
+ *                                                    concatenate the frames of many windows and use absolute indices
+ *   pt0, pt1 [n][2]                                  normalised image coordinates in frames i and i + 1
+ *   depth [n]                                        depth in camera i; init_depth (INIT_DEPTH, R/parameter/parameters.h:29) when the
+ *                                                    triangulated depth is not positive; -1 for an out-of-range start_frame
+ *   pts_world [n][3]                                 Rs[i] (ric (pt0 depth) + tic - pbg) + Ps[i], the landmark block's initial value
+ * on_device as for swf_preintegrate_batch. */
+int swf_triangulate_batch(const double* Ps, const double* Rs, int32_t n_frames, const double tic[3], const double ric[9],
+                          const double pbg[3], const int32_t* start_frame, const double* pt0, const double* pt1, int32_t n,
+                          double init_depth, double* depth, double* pts_world, int32_t on_device, void* stream);
+
 /* =====================================================================================
  * (2) ceres::Problem-shaped single-window surface
  *

@@ -517,6 +517,67 @@ static void pose_plus(const double* x, const double* d, double* o) {
 }
 void oracle_pose_plus(const double* x, const double* d, double* o) { pose_plus(x, d, o); }
 
+/* ------------------------------------------------------------------ two-view triangulation
+ * FeatureManager::triangulate, the >= 2 observations branch (R/feature/feature_manager.cpp:285-316), with
+ * triangulatePoint (:148-161): DLT design matrix of the first two observing frames, right singular vector of the
+ * smallest singular value (one-sided Jacobi here; Eigen's jacobiSvd in the reference), depth in the first camera
+ * (INIT_DEPTH when not positive), world point Rs[i] (ric (pt / idepth) + tic - Pbg) + Ps[i]. */
+static void tri_cam_pose(const double* P, const double* R, const double* tic, const double* ric, double* Rt, double* mt) {
+    double t[3], Rc[9];
+    for (int i = 0; i < 3; i++) t[i] = P[i] + R[i * 3] * tic[0] + R[i * 3 + 1] * tic[1] + R[i * 3 + 2] * tic[2];
+    mat3mul(R, ric, Rc);
+    mat3T(Rc, Rt);
+    for (int i = 0; i < 3; i++) mt[i] = -(Rt[i * 3] * t[0] + Rt[i * 3 + 1] * t[1] + Rt[i * 3 + 2] * t[2]);
+}
+void oracle_triangulate(const double* Ps, const double* Rs, int n_frames, const double* tic, const double* ric, const double* pbg,
+                        const int* start, const double* pt0, const double* pt1, int n, double init_depth,
+                        double* depth_out, double* world) {
+    for (int f = 0; f < n; f++) {
+        int f0 = start[f];
+        if (f0 < 0 || f0 + 1 >= n_frames) { depth_out[f] = -1.0; world[f * 3] = world[f * 3 + 1] = world[f * 3 + 2] = 0.0; continue; }
+        double R0t[9], m0[3], R1t[9], m1[3], D[4][4], V[4][4];
+        tri_cam_pose(Ps + f0 * 3, Rs + f0 * 9, tic, ric, R0t, m0);
+        tri_cam_pose(Ps + (f0 + 1) * 3, Rs + (f0 + 1) * 9, tic, ric, R1t, m1);
+        double u0 = pt0[f * 2], v0 = pt0[f * 2 + 1], u1 = pt1[f * 2], v1 = pt1[f * 2 + 1];
+        for (int c = 0; c < 4; c++) {
+            double a0 = c < 3 ? R0t[c] : m0[0], a1 = c < 3 ? R0t[3 + c] : m0[1], a2 = c < 3 ? R0t[6 + c] : m0[2];
+            double b0 = c < 3 ? R1t[c] : m1[0], b1 = c < 3 ? R1t[3 + c] : m1[1], b2 = c < 3 ? R1t[6 + c] : m1[2];
+            D[0][c] = u0 * a2 - a0; D[1][c] = v0 * a2 - a1; D[2][c] = u1 * b2 - b0; D[3][c] = v1 * b2 - b1;
+            for (int r = 0; r < 4; r++) V[r][c] = (r == c);
+        }
+        for (int sweep = 0; sweep < 30; sweep++) {
+            int rot = 0;
+            for (int p = 0; p < 3; p++) for (int q = p + 1; q < 4; q++) {
+                double al = 0, be = 0, ga = 0;
+                for (int r = 0; r < 4; r++) { al += D[r][p] * D[r][p]; be += D[r][q] * D[r][q]; ga += D[r][p] * D[r][q]; }
+                if (ga == 0.0 || ga * ga <= 1e-30 * (al * be)) continue;
+                double zeta = (be - al) / (2.0 * ga);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int r = 0; r < 4; r++) {
+                    double a = D[r][p], b = D[r][q]; D[r][p] = c * a - sn * b; D[r][q] = sn * a + c * b;
+                    double va = V[r][p], vb = V[r][q]; V[r][p] = c * va - sn * vb; V[r][q] = sn * va + c * vb;
+                }
+                rot = 1;
+            }
+            if (!rot) break;
+        }
+        int k = 0; double best = 0;
+        for (int c = 0; c < 4; c++) {
+            double nr = 0; for (int r = 0; r < 4; r++) nr += D[r][c] * D[r][c];
+            if (c == 0 || nr < best) { best = nr; k = c; }
+        }
+        double X[3] = { V[0][k] / V[3][k], V[1][k] / V[3][k], V[2][k] / V[3][k] };
+        double depth = R0t[6] * X[0] + R0t[7] * X[1] + R0t[8] * X[2] + m0[2];
+        if (!(depth > 0)) depth = init_depth;
+        const double* P = Ps + f0 * 3; const double* R = Rs + f0 * 9;
+        double pc[3] = { u0 * depth, v0 * depth, depth }, pb[3];
+        for (int r = 0; r < 3; r++) pb[r] = ric[r * 3] * pc[0] + ric[r * 3 + 1] * pc[1] + ric[r * 3 + 2] * pc[2] + tic[r] - pbg[r];
+        depth_out[f] = depth;
+        for (int r = 0; r < 3; r++) world[f * 3 + r] = R[r * 3] * pb[0] + R[r * 3 + 1] * pb[1] + R[r * 3 + 2] * pb[2] + P[r];
+    }
+}
+
 /* ------------------------------------------------------------------ pre-integration
  * IntegrationBase ctor / push_back / propagate / midPointIntegration / get_sqrtinfo,
  * R/factor/integration_base.cpp:5-142.  samples: [n][7] = dt, acc(3), gyr(3); the first

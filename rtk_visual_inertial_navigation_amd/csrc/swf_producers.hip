@@ -1,4 +1,8 @@
-// swf_preint.hip — batched IMU pre-integration: the input producer of the IMU factor.
+// swf_producers.hip — the input producers of the hot path as batched kernels:
+//   (1) IMU pre-integration (§8a row a6), the producer of the IMU factor's record;
+//   (2) two-view landmark triangulation, the producer of the landmark blocks' initial values (end of this file).
+//
+// ---- (1) batched IMU pre-integration
 //
 // Restates IntegrationBase::{ctor, push_back, propagate, midPointIntegration, get_sqrtinfo}
 // (R/factor/integration_base.cpp:5-142) for many keyframe intervals at once: one wavefront per interval, the 15x15
@@ -290,6 +294,135 @@ extern "C" int swf_preintegrate_batch(const double* samples, const int32_t* firs
     PI_TRY(hipMemcpyAsync(pre, d_o, (size_t)n_intervals * SWF_PRE_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, st));
     PI_TRY(hipStreamSynchronize(st));
 #undef PI_TRY
+    cleanup();
+    return SWF_OK;
+}
+
+// =====================================================================================================================
+// (2) two-view landmark triangulation: FeatureManager::triangulate, the branch every feature with >= 2 observations takes
+// (R/feature/feature_manager.cpp:285-316), with triangulatePoint (:148-161): the DLT design matrix of the first two
+// observing frames, its right singular vector of the smallest singular value, depth in the first camera (INIT_DEPTH if not
+// positive), and the world point  Rs[i] (ric (pt / idepth) + tic - Pbg) + Ps[i].
+// One lane per feature.  The singular vector comes from a one-sided (Hestenes) Jacobi on the four columns of the 4x4
+// matrix in registers (Eigen's JacobiSVD is the two-sided variant; the vector is the same up to sign, and the sign
+// cancels in the division by its fourth component).
+// =====================================================================================================================
+namespace {
+struct TriArgs {
+    const double* Ps; const double* Rs;        // [n_frames][3], [n_frames][9] row-major
+    const int* start; const double* pt0; const double* pt1;   // [n], [n][2], [n][2]
+    double* depth; double* world;              // [n], [n][3]
+    double tic[3], ric[9], pbg[3], init_depth;
+    int n, n_frames;
+};
+
+__device__ __forceinline__ void tri_cam_pose(const TriArgs& A, int f, double* Rt /*R^T, 9*/, double* mt /*-R^T t, 3*/) {
+    const double* P = A.Ps + (size_t)f * 3; const double* R = A.Rs + (size_t)f * 9;
+    double t[3], Rc[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = P[i] + R[i * 3] * A.tic[0] + R[i * 3 + 1] * A.tic[1] + R[i * 3 + 2] * A.tic[2];
+    mat3mul(R, A.ric, Rc);
+    mat3T(Rc, Rt);
+#pragma unroll
+    for (int i = 0; i < 3; i++) mt[i] = -(Rt[i * 3] * t[0] + Rt[i * 3 + 1] * t[1] + Rt[i * 3 + 2] * t[2]);
+}
+
+#define TRI_ROT(p, q) { \
+        double al = 0, be = 0, ga = 0; \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) { al += D[r][p] * D[r][p]; be += D[r][q] * D[r][q]; ga += D[r][p] * D[r][q]; } \
+        if (ga != 0.0 && ga * ga > 1e-30 * (al * be)) { \
+            double zeta = (be - al) / (2.0 * ga); \
+            double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta)); \
+            double c = 1.0 / sqrt(1.0 + t * t), sn = c * t; \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) { \
+                double a = D[r][p], b = D[r][q]; D[r][p] = c * a - sn * b; D[r][q] = sn * a + c * b; \
+                double va = V[r][p], vb = V[r][q]; V[r][p] = c * va - sn * vb; V[r][q] = sn * va + c * vb; } \
+            rot = true; } }
+
+__global__ void __launch_bounds__(256) k_triangulate(TriArgs A) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    int f0 = A.start[i];
+    if (f0 < 0 || f0 + 1 >= A.n_frames) { A.depth[i] = -1.0; A.world[i * 3] = A.world[i * 3 + 1] = A.world[i * 3 + 2] = 0.0; return; }
+    double R0t[9], m0[3], R1t[9], m1[3];
+    tri_cam_pose(A, f0, R0t, m0);
+    tri_cam_pose(A, f0 + 1, R1t, m1);
+    const double u0 = A.pt0[i * 2], v0 = A.pt0[i * 2 + 1], u1 = A.pt1[i * 2], v1 = A.pt1[i * 2 + 1];
+    double D[4][4], V[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        double p0r0 = c < 3 ? R0t[c] : m0[0], p0r1 = c < 3 ? R0t[3 + c] : m0[1], p0r2 = c < 3 ? R0t[6 + c] : m0[2];
+        double p1r0 = c < 3 ? R1t[c] : m1[0], p1r1 = c < 3 ? R1t[3 + c] : m1[1], p1r2 = c < 3 ? R1t[6 + c] : m1[2];
+        D[0][c] = u0 * p0r2 - p0r0; D[1][c] = v0 * p0r2 - p0r1; D[2][c] = u1 * p1r2 - p1r0; D[3][c] = v1 * p1r2 - p1r1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) V[r][c] = (r == c) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool rot = false;
+        TRI_ROT(0, 1) TRI_ROT(0, 2) TRI_ROT(0, 3) TRI_ROT(1, 2) TRI_ROT(1, 3) TRI_ROT(2, 3)
+        if (!rot) break;
+    }
+    double nr[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) nr[c] = D[0][c] * D[0][c] + D[1][c] * D[1][c] + D[2][c] * D[2][c] + D[3][c] * D[3][c];
+    int k = 0;
+#pragma unroll
+    for (int c = 1; c < 4; c++) if (nr[c] < nr[k]) k = c;
+    double x[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = k == 0 ? V[r][0] : k == 1 ? V[r][1] : k == 2 ? V[r][2] : V[r][3];
+    double X[3] = { x[0] / x[3], x[1] / x[3], x[2] / x[3] };
+    double depth = R0t[6] * X[0] + R0t[7] * X[1] + R0t[8] * X[2] + m0[2];
+    if (!(depth > 0)) depth = A.init_depth;           // the reference tests depth <= 0; a NaN (x[3] = 0) also takes the default
+    const double* P = A.Ps + (size_t)f0 * 3; const double* R = A.Rs + (size_t)f0 * 9;
+    double pc[3] = { u0 * depth, v0 * depth, depth }, pb[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) pb[r] = A.ric[r * 3] * pc[0] + A.ric[r * 3 + 1] * pc[1] + A.ric[r * 3 + 2] * pc[2] + A.tic[r] - A.pbg[r];
+    A.depth[i] = depth;
+#pragma unroll
+    for (int r = 0; r < 3; r++) A.world[i * 3 + r] = R[r * 3] * pb[0] + R[r * 3 + 1] * pb[1] + R[r * 3 + 2] * pb[2] + P[r];
+}
+#undef TRI_ROT
+}  // namespace
+
+extern "C" int swf_triangulate_batch(const double* Ps, const double* Rs, int32_t n_frames, const double tic[3], const double ric[9],
+                                     const double pbg[3], const int32_t* start_frame, const double* pt0, const double* pt1, int32_t n,
+                                     double init_depth, double* depth, double* pts_world, int32_t on_device, void* stream) {
+    if (!Ps || !Rs || !tic || !ric || !pbg || !start_frame || !pt0 || !pt1 || !depth || !pts_world || n < 0 || n_frames < 0)
+        return pi_fail(SWF_E_INVALID, "swf_triangulate_batch: null argument");
+    if (n == 0) return SWF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    TriArgs A{};
+    for (int k = 0; k < 3; k++) { A.tic[k] = tic[k]; A.pbg[k] = pbg[k]; }
+    for (int k = 0; k < 9; k++) A.ric[k] = ric[k];
+    A.init_depth = init_depth; A.n = n; A.n_frames = n_frames;
+    if (on_device) {
+        A.Ps = Ps; A.Rs = Rs; A.start = start_frame; A.pt0 = pt0; A.pt1 = pt1; A.depth = depth; A.world = pts_world;
+        hipLaunchKernelGGL(k_triangulate, dim3((n + 255) / 256), dim3(256), 0, st, A);
+        PI_HIPCHK(hipGetLastError());
+        return SWF_OK;
+    }
+    double* d = nullptr; int* d_s = nullptr;
+    const size_t nf = (size_t)std::max(1, n_frames);
+    const size_t doubles = nf * 12 + (size_t)n * 8;        // Ps | Rs | pt0 | pt1 | depth | world
+    auto cleanup = [&]() { (void)hipFree(d); (void)hipFree(d_s); };
+#define TR_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return pi_fail(SWF_E_NODEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    TR_TRY(hipMalloc(&d, doubles * sizeof(double)));
+    TR_TRY(hipMalloc(&d_s, (size_t)n * sizeof(int)));
+    double* dPs = d; double* dRs = dPs + nf * 3; double* dp0 = dRs + nf * 9; double* dp1 = dp0 + (size_t)n * 2;
+    double* ddep = dp1 + (size_t)n * 2; double* dw = ddep + n;
+    TR_TRY(hipMemcpyAsync(dPs, Ps, (size_t)n_frames * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    TR_TRY(hipMemcpyAsync(dRs, Rs, (size_t)n_frames * 9 * sizeof(double), hipMemcpyHostToDevice, st));
+    TR_TRY(hipMemcpyAsync(dp0, pt0, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, st));
+    TR_TRY(hipMemcpyAsync(dp1, pt1, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, st));
+    TR_TRY(hipMemcpyAsync(d_s, start_frame, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    A.Ps = dPs; A.Rs = dRs; A.start = d_s; A.pt0 = dp0; A.pt1 = dp1; A.depth = ddep; A.world = dw;
+    hipLaunchKernelGGL(k_triangulate, dim3((n + 255) / 256), dim3(256), 0, st, A);
+    TR_TRY(hipGetLastError());
+    TR_TRY(hipMemcpyAsync(depth, ddep, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    TR_TRY(hipMemcpyAsync(pts_world, dw, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    TR_TRY(hipStreamSynchronize(st));
+#undef TR_TRY
     cleanup();
     return SWF_OK;
 }

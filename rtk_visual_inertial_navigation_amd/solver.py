@@ -44,7 +44,7 @@ EXPORTED = [
     "swf_set_export_tail", "swf_problem_solve", "swf_get_reduced", "swf_problem_marginalize",
     "swf_batch_marginalize", "swf_batch_get_prior",
     "swf_add_spp_pseudorange", "swf_add_spp_carrier_phase", "swf_add_fixed_integer",
-    "swf_preintegrate_batch",
+    "swf_preintegrate_batch", "swf_triangulate_batch",
 ]
 
 
@@ -345,6 +345,22 @@ def preintegrate_batch(samples, biases, noise):
     _chk(lib().swf_preintegrate_batch(flat.ctypes.data_as(_pd), first.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(n),
                                       b.ctypes.data_as(_pd), nz, out.ctypes.data_as(_pd), C.c_int32(0), None), "preintegrate_batch")
     return out
+
+
+def triangulate_batch(Ps, Rs, tic, ric, pbg, start_frame, pt0, pt1, init_depth=5.0):
+    """FeatureManager::triangulate (two-view branch, R/feature/feature_manager.cpp:285-316) for a batch of features on
+    the device.  Ps [F][3], Rs [F][3][3]; start_frame [n]; pt0 / pt1 [n][2] normalised coordinates in frames i, i + 1.
+    Returns (depth [n], pts_world [n][3])."""
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (Ps, Rs, tic, ric, pbg, pt0, pt1)]
+    st = np.ascontiguousarray(start_frame, dtype=np.int32)
+    n = st.size
+    depth, world = np.zeros(n), np.zeros((n, 3))
+    _chk(lib().swf_triangulate_batch(a[0].ctypes.data_as(_pd), a[1].ctypes.data_as(_pd), C.c_int32(a[0].size // 3),
+                                     a[2].ctypes.data_as(_pd), a[3].ctypes.data_as(_pd), a[4].ctypes.data_as(_pd),
+                                     st.ctypes.data_as(C.POINTER(C.c_int32)), a[5].ctypes.data_as(_pd), a[6].ctypes.data_as(_pd),
+                                     C.c_int32(n), C.c_double(init_depth), depth.ctypes.data_as(_pd), world.ctypes.data_as(_pd),
+                                     C.c_int32(0), None), "triangulate_batch")
+    return depth, world
 
 
 def problem_from_window(w):

@@ -126,3 +126,18 @@ def fd_jac(fun, blocks, which, h):
         bm[which] = pose_plus(x, -d) if x.size == 7 else x - d
         J[:, j] = (np.atleast_1d(fun(*bp)) - np.atleast_1d(fun(*bm))) / (2 * h)
     return J
+
+
+def triangulate_two_view(Ps, Rs, tic, ric, pbg, f0, pt0, pt1, init_depth=5.0):
+    """FeatureManager::triangulate two-view branch + triangulatePoint (feature_manager.cpp:148-161, 285-316) with LAPACK's SVD."""
+    def pose(f):
+        t = Ps[f] + Rs[f] @ tic; R = Rs[f] @ ric
+        return np.hstack([R.T, (-R.T @ t)[:, None]])
+    P0, P1 = pose(f0), pose(f0 + 1)
+    D = np.stack([pt0[0] * P0[2] - P0[0], pt0[1] * P0[2] - P0[1], pt1[0] * P1[2] - P1[0], pt1[1] * P1[2] - P1[1]])
+    v = np.linalg.svd(D)[2][-1]
+    X = v[:3] / v[3]
+    depth = (P0[:, :3] @ X + P0[:, 3])[2]
+    if not depth > 0:
+        depth = init_depth
+    return depth, Rs[f0] @ (ric @ (np.array([pt0[0], pt0[1], 1.0]) * depth) + tic - pbg) + Ps[f0]

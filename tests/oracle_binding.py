@@ -159,6 +159,17 @@ def preintegrate(samples, ba, bg, acc_n, gyr_n, acc_w, gyr_w):
     return pre
 
 
+def triangulate(Ps, Rs, tic, ric, pbg, start, pt0, pt1, init_depth=5.0):
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (Ps, Rs, tic, ric, pbg, pt0, pt1)]
+    st = np.ascontiguousarray(start, dtype=np.int32)
+    n = st.size
+    depth, world = np.zeros(n), np.zeros((n, 3))
+    lib().oracle_triangulate(_p(a[0]), _p(a[1]), C.c_int(a[0].size // 3), _p(a[2]), _p(a[3]), _p(a[4]),
+                             st.ctypes.data_as(C.POINTER(C.c_int)), _p(a[5]), _p(a[6]), C.c_int(n), C.c_double(init_depth),
+                             _p(depth), _p(world))
+    return depth, world
+
+
 def pose_plus(x, d):
     o = np.zeros(7)
     a = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, d)]

@@ -477,3 +477,26 @@ def test_batched_preintegration_matches_oracle():
     so, _ = ob.solve(wo, default_options(step_mode=1))
     assert abs(sg.initial_cost - so.initial_cost) <= 1e-9 * so.initial_cost
     bs.close()
+
+
+def test_batched_triangulation_matches_oracle():
+    """SURVEY 8f rank 4: FeatureManager::triangulate (two-view branch) for a batch of features, one lane each, against the
+    oracle: same one-sided Jacobi, same formulas -> agreement at rounding level scaled by the depth; the degenerate and
+    out-of-range cases take the same branches."""
+    from test_oracle import _triangulation_scene
+    rng = np.random.default_rng(9)
+    Ps, Rs, tic, ric, pbg, start, pt0, pt1, Xw = _triangulation_scene(rng, n_frames=40, n_feat=5000, pbg=np.array([0.1, -0.3, 0.2]))
+    pt0 += rng.normal(0, 1e-3, pt0.shape); pt1 += rng.normal(0, 1e-3, pt1.shape)
+    # a few degenerate rows: identical observations in both frames (zero parallax), behind-the-camera, out-of-range frames
+    pt1[:5] = pt0[:5]; pt0[5:10] = -3 * pt0[5:10] + 1.0; pt1[5:10] = -2.0
+    start[10] = len(Ps) - 1; start[11] = -1
+    do, Wo = ob.triangulate(Ps, Rs, tic, ric, pbg, start, pt0, pt1)
+    dg, Wg = solver.triangulate_batch(Ps, Rs, tic, ric, pbg, start, pt0, pt1)
+    assert np.array_equal(dg[10:12], [-1.0, -1.0]) and np.array_equal(do[10:12], dg[10:12])
+    ok = np.ones(len(start), bool); ok[:12] = False
+    # well-posed features: relative agreement of depth and of the point
+    assert np.abs(dg[ok] - do[ok]).max() <= 1e-9 * np.abs(do[ok]).max()
+    assert np.abs(Wg[ok] - Wo[ok]).max() <= 1e-9 * np.abs(do[ok]).max()
+    # degenerate ones: same branch (INIT_DEPTH or a positive depth), finite output
+    assert np.all(np.isfinite(Wg)) and np.all(dg[:10] > 0)
+    assert np.array_equal(dg[5:10] == 5.0, do[5:10] == 5.0)

@@ -159,6 +159,44 @@ def test_pose_plus_and_preintegration_vs_numpy_producer():
     assert np.allclose(np.tril(So, -1), 0)
 
 
+def _triangulation_scene(rng, n_frames=12, n_feat=200, pbg=None):
+    """Frames along a gently curving path, features in front of consecutive frame pairs; noise-free normalised observations."""
+    from scipy.spatial.transform import Rotation
+    Ps = np.cumsum(rng.normal([0.6, 0.05, 0.0], 0.05, (n_frames, 3)), axis=0) + np.array([3e6, -1e6, 2e6]) * 0   # local frame
+    Rs = np.stack([Rotation.from_rotvec(rng.normal(0, 0.05, 3) + np.array([0, 0, 0.02 * k])).as_matrix() for k in range(n_frames)])
+    ric = Rotation.from_euler("xyz", [-1.5, 0.02, -1.55]).as_matrix()
+    tic = np.array([0.05, -0.02, 0.1])
+    pbg = np.zeros(3) if pbg is None else pbg
+    start = rng.integers(0, n_frames - 1, n_feat).astype(np.int32)
+    Xw, pt0, pt1 = np.zeros((n_feat, 3)), np.zeros((n_feat, 2)), np.zeros((n_feat, 2))
+    for i, f in enumerate(start):
+        pc = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3), 1.0]) * rng.uniform(3, 40)
+        Xw[i] = Rs[f] @ (ric @ pc + tic) + Ps[f]
+        for pts, ff in ((pt0, f), (pt1, f + 1)):
+            q = ric.T @ (Rs[ff].T @ (Xw[i] - Ps[ff]) - tic)
+            pts[i] = q[:2] / q[2]
+    return Ps, Rs, tic, ric, pbg, start, pt0, pt1, Xw
+
+
+def test_two_view_triangulation_vs_lapack_svd_and_truth():
+    rng = np.random.default_rng(8)
+    Ps, Rs, tic, ric, pbg, start, pt0, pt1, Xw = _triangulation_scene(rng)
+    d, W = ob.triangulate(Ps, Rs, tic, ric, pbg, start, pt0, pt1)
+    assert np.abs(W - Xw).max() < 1e-7                      # noise-free observations: the point itself (lever arm zero)
+    # with a lever arm and noisy observations: against the LAPACK restatement of the reference's lines
+    pbg = np.array([0.1, -0.3, 0.2])
+    pt0n, pt1n = pt0 + rng.normal(0, 1e-3, pt0.shape), pt1 + rng.normal(0, 1e-3, pt1.shape)
+    d, W = ob.triangulate(Ps, Rs, tic, ric, pbg, start, pt0n, pt1n)
+    for i in range(len(start)):
+        dn, Wn = nf.triangulate_two_view(Ps, Rs, tic, ric, pbg, int(start[i]), pt0n[i], pt1n[i])
+        assert abs(d[i] - dn) <= 1e-9 * max(1.0, abs(dn)) * 100 and np.abs(W[i] - Wn).max() <= 1e-7 * max(1.0, abs(dn))
+    # behind-the-camera solutions take INIT_DEPTH; out-of-range frames are flagged
+    d2, W2 = ob.triangulate(Ps, Rs, tic, ric, pbg, start[:4], -pt0[:4] * 3 + 1.0, pt1[:4] * 0 - 2.0, init_depth=5.0)
+    assert np.all((d2 > 0))
+    d3, _ = ob.triangulate(Ps, Rs, tic, ric, pbg, np.array([len(Ps) - 1, -1], np.int32), pt0[:2], pt1[:2])
+    assert np.all(d3 == -1.0)
+
+
 def test_oracle_solver_invariants(win3):
     w = win3.copy()
     sm, ex = ob.solve(w, default_options(max_num_iterations=8))
