@@ -243,4 +243,15 @@ inline bool UpdateSchurAndSetMarginalizeInfo(Problem* p, MarginalPrior* out, boo
     return rc == SWF_OK && rank >= 0;
 }
 
+// SWFOptimization::UpdateSchurHessianOnly (R/swf/swf_gnss.cpp:65-94) after an optimising Solve: A = A3 A3^T over the
+// parameter_head states, plus the covariance Qy = A^-1 LambdaSearch computes from it (R/swf/swf_lambda.cpp:94-99).
+struct TailCovariance { const double* A = nullptr; const double* Qy = nullptr; int n = 0; };
+inline bool UpdateSchurHessianOnly(Problem* p, TailCovariance* out) {
+    int32_t n = 0;
+    int rc = swf_problem_tail_covariance(p->handle(), &out->A, &out->Qy, &n);
+    out->n = n;
+    internal::parameter_head.clear();                       // swf_gnss.cpp:91
+    return rc == SWF_OK && n > 0;
+}
+
 }  // namespace swf_ceres

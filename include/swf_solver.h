@@ -108,6 +108,18 @@ int swf_batch_marginalize(swf_batch* b, double eps, int32_t form);
  * eigenvalues (ascending; for SWF_PRIOR_CHOLESKY the squared diagonal of L_nn). */
 int swf_batch_get_prior(swf_batch* b, int32_t w, double* A, double* bv, double* J, double* r0, double* eig, int32_t* n, int32_t* rank);
 
+/* Ambiguity covariance hand-off, for every window of the batch, after ANY solve:
+ *   A  = L_nn L_nn^T   information of the parameter_head states — what SWFOptimization::UpdateSchurHessianOnly forms from
+ *                      lhs_out2 (R/swf/swf_gnss.cpp:65-94);
+ *   Qy = A^-1          their covariance — what SWFOptimization::LambdaSearch computes next (R/swf/swf_lambda.cpp:94-99) and feeds,
+ *                      with the float ambiguities, to the LAMBDA search (which stays on the host: integer least squares is
+ *                      sequential and branchy).
+ * L is the Cholesky factor of the last linear solve of each window (it includes the dogleg's mu * diag regularisation, as the
+ * exported lhs_out2 does).  n_red <= 512.  swf_batch_tail_covariance is asynchronous; the getter synchronises; both matrices
+ * are n x n row-major, n = tail dimension; *n = -1 and SWF_E_STATE for a window without a valid factor. */
+int swf_batch_tail_covariance(swf_batch* b);
+int swf_batch_get_tail_covariance(swf_batch* b, int32_t w, double* A, double* Qy, int32_t* n);
+
 /* Timing of the last swf_batch_solve, measured with HIP events recorded on the batch stream
  * around individual kernel launches (valid after swf_batch_sync).  `mask` selects which
  * kernels get an event pair per launch (bit k = SWF_K_*); bit 0 brackets the whole solve.
@@ -249,6 +261,9 @@ int swf_problem_marginalize(swf_problem* p, double eps, int32_t form, const doub
                             const double** A, const double** bv, int32_t* n, int32_t* rank);
 /* lhs_out / rhs_out / lhs_out2 / hs_row of the last solve; buffers solver-owned, valid until the
  * next solve or destroy. */
+/* UpdateSchurHessianOnly + the covariance LambdaSearch takes from it (see swf_batch_tail_covariance); pointers are owned by
+ * the problem and valid until the next call / solve. */
+int swf_problem_tail_covariance(swf_problem* p, const double** A, const double** Qy, int32_t* n);
 int swf_get_reduced(swf_problem* p, const double** S, const double** rhs, const double** L, int32_t* hs_row);
 
 #ifdef __cplusplus

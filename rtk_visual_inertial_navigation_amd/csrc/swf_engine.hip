@@ -74,6 +74,8 @@ struct swf_batch {
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
     int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr; double* mg_M = nullptr;
     bool mg_valid = false; int mg_ld = 0;
+    // ambiguity covariance hand-off outputs (allocated at the first swf_batch_tail_covariance)
+    int* tc_tail = nullptr; double* tc_A = nullptr; double* tc_Q = nullptr; double* tc_X = nullptr; int* tc_rank = nullptr; bool tc_valid = false; int tc_ld = 0;
     // latency path (small batches): an auxiliary stream runs the IMU / clique branch of a linearisation next to the
     // projection / landmark branch; three reusable events carry the dependencies
     hipStream_t aux = nullptr; hipEvent_t ev_fork[3] = { nullptr, nullptr, nullptr };
@@ -881,7 +883,7 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
     b->last.jacobian_bytes = b->jac_bytes; b->last.proj_bytes = b->proj_bytes; b->last.chol_flops = b->chol_flops;
     b->last.lm_schur_flops = b->lm_schur_flops; b->last.n_obs = b->D.n_proj;
     b->last.n_linearizations = nlin;
-    b->last_mode = opt->step_mode;
+    b->last_mode = opt->step_mode; b->mg_valid = false; b->tc_valid = false;      // consumer outputs belong to the previous solve
     return SWF_OK;
 }
 
@@ -994,6 +996,44 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                            b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M);
     HIPCHK(hipGetLastError());
     b->mg_valid = true;
+    return SWF_OK;
+}
+
+// ambiguity covariance hand-off: information and covariance of the parameter_head tail from the factor of the last linear solve
+extern "C" int swf_batch_tail_covariance(swf_batch* b) {
+    if (!b) return fail(SWF_E_INVALID, "swf_batch_tail_covariance: null batch");
+    if (b->last_mode < 0) return fail(SWF_E_STATE, "swf_batch_tail_covariance needs a preceding solve");
+    if (b->max_red > 512 || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "the tail covariance needs the row-major Cholesky factor (n_red <= 512)");
+    int nw = (int)b->win.size(), ldn = 1;
+    for (int w = 0; w < nw; w++) ldn = std::max(ldn, b->hw[w].tail_dim);
+    if (!b->tc_A) {
+        std::vector<int> td(nw);
+        for (int w = 0; w < nw; w++) td[w] = b->hw[w].tail_dim;
+        const int* tdp = nullptr;
+        int rc = b->pool.put(td, &tdp);
+        b->tc_tail = (int*)tdp;
+        rc |= b->pool.zeros((size_t)nw * ldn * ldn, &b->tc_A); rc |= b->pool.zeros((size_t)nw * ldn * ldn, &b->tc_Q);
+        rc |= b->pool.zeros((size_t)nw * ldn * ldn, &b->tc_X); rc |= b->pool.zeros((size_t)nw, &b->tc_rank);
+        if (rc) return fail(SWF_E_NODEVICE, "device allocation failed");
+    }
+    b->tc_ld = ldn;
+    hipLaunchKernelGGL(k_tail_cov, dim3(nw), dim3(256), 0, b->stream, b->D, (const int*)b->tc_tail, ldn, b->tc_A, b->tc_Q, b->tc_X, b->tc_rank);
+    HIPCHK(hipGetLastError());
+    b->tc_valid = true;
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_get_tail_covariance(swf_batch* b, int32_t w, double* A, double* Qy, int32_t* n_out) {
+    if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
+    if (!b->tc_valid) return fail(SWF_E_STATE, "swf_batch_get_tail_covariance before swf_batch_tail_covariance");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    size_t n = (size_t)b->hw[w].tail_dim, o2 = (size_t)w * b->tc_ld * b->tc_ld;
+    int32_t rk = 0;
+    HIPCHK(hipMemcpy(&rk, b->tc_rank + w, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_out) *n_out = rk < 0 ? -1 : (int32_t)n;
+    if (rk < 0) return fail(SWF_E_STATE, "tail covariance: the window has no valid factor (failed linear solve or empty tail)");
+    if (A) HIPCHK(hipMemcpy(A, b->tc_A + o2, n * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (Qy) HIPCHK(hipMemcpy(Qy, b->tc_Q + o2, n * n * sizeof(double), hipMemcpyDeviceToHost));
     return SWF_OK;
 }
 

@@ -164,3 +164,42 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         for (int j = sub; j < n; j += 16) outJ[o2 + (size_t)pos * n + j] = Mc(c, j);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ambiguity covariance hand-off: what the integer-ambiguity consumer reads after a solve,
+//   SWFOptimization::UpdateSchurHessianOnly  R/swf/swf_gnss.cpp:65-94    A = A3 A3^T, A3 = trailing n x n block of lhs_out2
+//   SWFOptimization::LambdaSearch            R/swf/swf_lambda.cpp:94-99  Qy = A^-1 (the float ambiguities' covariance)
+// A = L_nn L_nn^T, Qy = L_nn^-T L_nn^-1: one thread per column solves L z = e_j forwards and L^T q = z backwards (no explicit
+// inverse of A; error eps * cond(L) instead of eps * cond(A)).  X = per-window scratch (column j contiguous).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tail_cov(DevBatch B, const int* tail_dim, int ldn, double* outA, double* outQ, double* X, int* outrank) {
+    int w = blockIdx.x, tid = threadIdx.x;
+    const WinRec& W = B.win[w];
+    const WinState& s = B.ws[w];
+    int n = tail_dim[w], nr = W.n_red, m = nr - n;
+    size_t o2 = (size_t)w * ldn * ldn;
+    if (n <= 0 || n > ldn || m < 0 || s.lin_fail) { if (tid == 0) outrank[w] = -1; return; }
+    const double* Ln = B.L + W.Lt_base + (size_t)m * nr + m;     // L_nn[i][r] = Ln[i * nr + r]
+    for (int e = tid; e < n * n; e += blockDim.x) {
+        int i = e / n, j = e - i * n, k = i < j ? i : j;
+        double a = 0;
+        for (int r = 0; r <= k; r++) a += Ln[(size_t)i * nr + r] * Ln[(size_t)j * nr + r];
+        outA[o2 + e] = a;
+    }
+    for (int j = tid; j < n; j += blockDim.x) {
+        double* z = X + o2 + (size_t)j * n;
+        for (int i = 0; i < j; i++) z[i] = 0.0;
+        for (int i = j; i < n; i++) {                 // L z = e_j
+            double a = (i == j) ? 1.0 : 0.0;
+            for (int k = j; k < i; k++) a -= Ln[(size_t)i * nr + k] * z[k];
+            z[i] = a / Ln[(size_t)i * nr + i];
+        }
+        for (int i = n - 1; i >= 0; i--) {            // L^T q = z, in place
+            double a = z[i];
+            for (int k = i + 1; k < n; k++) a -= Ln[(size_t)k * nr + i] * z[k];
+            z[i] = a / Ln[(size_t)i * nr + i];
+        }
+        for (int i = 0; i < n; i++) outQ[o2 + (size_t)i * n + j] = z[i];
+    }
+    if (tid == 0) outrank[w] = n;
+}

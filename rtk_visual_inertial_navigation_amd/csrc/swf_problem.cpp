@@ -49,6 +49,7 @@ struct swf_problem {
     // exports
     std::vector<double> S, rhs, L;
     std::vector<double> mgA, mgb, mgJ, mgr0;      // swf_problem_marginalize outputs
+    std::vector<double> tcA, tcQ;                 // swf_problem_tail_covariance outputs
     int hs_row = 0;
     bool solved = false;
 };
@@ -357,6 +358,19 @@ int swf_problem_marginalize(swf_problem* p, double eps, int32_t form, const doub
     if ((rc = swf_batch_get_prior(p->batch, 0, p->mgA.data(), p->mgb.data(), p->mgJ.data(), p->mgr0.data(), nullptr, &n, &rk)) != SWF_OK) return rc;
     if (J) *J = p->mgJ.data(); if (r0) *r0 = p->mgr0.data(); if (A) *A = p->mgA.data(); if (bv) *bv = p->mgb.data();
     if (n_out) *n_out = n; if (rank) *rank = rk;
+    return SWF_OK;
+}
+
+int swf_problem_tail_covariance(swf_problem* p, const double** A, const double** Qy, int32_t* n_out) {
+    if (!p) return SWF_E_INVALID;
+    if (!p->solved || !p->batch) return SWF_E_STATE;
+    int rc;
+    if ((rc = swf_batch_tail_covariance(p->batch)) != SWF_OK) return rc;
+    int32_t n = 0;
+    if ((rc = swf_batch_get_tail_covariance(p->batch, 0, nullptr, nullptr, &n)) != SWF_OK) return rc;
+    p->tcA.assign((size_t)n * n, 0); p->tcQ.assign((size_t)n * n, 0);
+    if ((rc = swf_batch_get_tail_covariance(p->batch, 0, p->tcA.data(), p->tcQ.data(), &n)) != SWF_OK) return rc;
+    if (A) *A = p->tcA.data(); if (Qy) *Qy = p->tcQ.data(); if (n_out) *n_out = n;
     return SWF_OK;
 }
 

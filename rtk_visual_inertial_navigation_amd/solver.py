@@ -45,6 +45,7 @@ EXPORTED = [
     "swf_batch_marginalize", "swf_batch_get_prior",
     "swf_add_spp_pseudorange", "swf_add_spp_carrier_phase", "swf_add_fixed_integer",
     "swf_preintegrate_batch", "swf_triangulate_batch",
+    "swf_batch_tail_covariance", "swf_batch_get_tail_covariance", "swf_problem_tail_covariance",
 ]
 
 
@@ -160,6 +161,22 @@ class BatchSolver:
         _chk(lib().swf_batch_get_prior(self._h, C.c_int32(w), A.ctypes.data_as(_pd), b.ctypes.data_as(_pd), J.ctypes.data_as(_pd),
                                        r0.ctypes.data_as(_pd), eig.ctypes.data_as(_pd), C.byref(n), C.byref(rank)), "swf_batch_get_prior")
         return dict(A=A, b=b, J=J, r0=r0, eig=eig, n=k, rank=rank.value)
+
+    def tail_covariance(self, w=None):
+        """UpdateSchurHessianOnly + LambdaSearch's covariance (R/swf/swf_gnss.cpp:65-94, swf_lambda.cpp:94-99): information A and
+        covariance Qy = A^-1 of the parameter_head states of every window, from the factor of the last linear solve.
+        w = None: list over windows; else one window's dict(A, Qy, n)."""
+        _chk(lib().swf_batch_tail_covariance(self._h), "swf_batch_tail_covariance")
+
+        def one(i):
+            n = C.c_int32(0)
+            _chk(lib().swf_batch_get_tail_covariance(self._h, C.c_int32(i), None, None, C.byref(n)), "swf_batch_get_tail_covariance")
+            k = n.value
+            A, Q = np.zeros((k, k)), np.zeros((k, k))
+            _chk(lib().swf_batch_get_tail_covariance(self._h, C.c_int32(i), A.ctypes.data_as(_pd), Q.ctypes.data_as(_pd), C.byref(n)),
+                 "swf_batch_get_tail_covariance")
+            return dict(A=A, Qy=Q, n=k)
+        return [one(i) for i in range(len(self._structs))] if w is None else one(w)
 
     def enable_timing(self, mask=1):
         """mask: bit k brackets kernel K_NAMES[k] with a HIP event pair per launch (bit 0 = whole solve);
@@ -320,6 +337,13 @@ class Problem:
         n = n.value
         return dict(J=np.ctypeslib.as_array(J, (n, n)).copy(), r0=np.ctypeslib.as_array(r0, (n,)).copy(),
                     A=np.ctypeslib.as_array(A, (n, n)).copy(), b=np.ctypeslib.as_array(b, (n,)).copy(), n=n, rank=rk.value)
+
+    def TailCovariance(self):
+        """UpdateSchurHessianOnly (R/swf/swf_gnss.cpp:65-94) + Qy = A^-1 (R/swf/swf_lambda.cpp:94-99) after Solve."""
+        A, Q, n = _pd(), _pd(), C.c_int32()
+        _chk(lib().swf_problem_tail_covariance(self._h, C.byref(A), C.byref(Q), C.byref(n)), "TailCovariance")
+        n = n.value
+        return dict(A=np.ctypeslib.as_array(A, (n, n)).copy(), Qy=np.ctypeslib.as_array(Q, (n, n)).copy(), n=n)
 
     def GetReduced(self):
         S, r, L, n = _pd(), _pd(), _pd(), C.c_int32()

@@ -500,3 +500,41 @@ def test_batched_triangulation_matches_oracle():
     # degenerate ones: same branch (INIT_DEPTH or a positive depth), finite output
     assert np.all(np.isfinite(Wg)) and np.all(dg[:10] > 0)
     assert np.array_equal(dg[5:10] == 5.0, do[5:10] == 5.0)
+
+
+def test_ambiguity_covariance_hand_off():
+    """after an optimising solve with the RTK ambiguities as parameter_head, the information A = L_nn L_nn^T
+    (UpdateSchurHessianOnly, R/swf/swf_gnss.cpp:65-94) and the covariance Qy = A^-1 (LambdaSearch, swf_lambda.cpp:94-99) of the
+    float ambiguities.  Checked against the exported factor and reduced matrix with numpy; batch == Problem surface bit for bit."""
+    w0 = synth.make_window(3, K=6, F=30, S=7, seed=23, head="ambiguities")
+    bs, sm = gpu_solve(w0.copy(), default_options())
+    assert sm.tail_dim == 7
+    t = bs.tail_covariance(0)
+    S, rhs, L = bs.export_reduced(0)
+    n = t["n"]; m = S.shape[0] - n
+    assert n == 7
+    Lnn = L[m:, m:]
+    assert np.abs(t["A"] - Lnn @ Lnn.T).max() <= 1e-13 * np.abs(t["A"]).max()
+    cond = np.linalg.cond(t["A"])
+    assert np.abs(t["A"] @ t["Qy"] - np.eye(n)).max() <= 1e-14 * cond
+    assert np.abs(t["Qy"] - t["Qy"].T).max() <= 1e-14 * np.abs(t["Qy"]).max() * np.sqrt(cond)
+    # it is the marginal covariance of the tail: the trailing block of the inverse of the factorised matrix L L^T
+    full = np.linalg.inv(L @ L.T)[m:, m:]
+    assert np.abs(t["Qy"] - full).max() <= 1e-15 * np.linalg.cond(L @ L.T) * np.abs(full).max() + 1e-12 * np.abs(full).max()
+    bs.close()
+    P, blocks = solver.problem_from_window(w0.copy())
+    P.Solve(default_options())
+    tp = P.TailCovariance()
+    assert tp["n"] == n and np.array_equal(tp["A"], t["A"]) and np.array_equal(tp["Qy"], t["Qy"])
+    P.close()
+    # every window of a batch, and the call-order errors
+    ws = [synth.make_window(3, K=5, F=20, S=5 + i, seed=50 + i, head="ambiguities") for i in range(3)]
+    bs = solver.BatchSolver(ws)
+    with pytest.raises(Exception):
+        bs.tail_covariance()
+    bs.solve(default_options())
+    ts = bs.tail_covariance()
+    assert [x["n"] for x in ts] == [5, 6, 7]
+    for x in ts:
+        assert np.abs(x["A"] @ x["Qy"] - np.eye(x["n"])).max() <= 1e-14 * np.linalg.cond(x["A"])
+    bs.close()
