@@ -71,6 +71,7 @@ struct swf_batch {
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
     int max_tiles = 0, max_prior_dim = 0, max_red = 0, min_red = 1 << 30, n_cu = 256;
+    bool clc_imu[3] = { false, false, false };    // clique class holds IMU factors (its elimination must follow k_eval_imu)
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
     int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr; double* mg_M = nullptr;
     bool mg_valid = false; int mg_ld = 0;
@@ -645,6 +646,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             int d = c.d_e + c.d_f;
             int cls = (c.d_e <= 1 && d <= 32 && c.n_rows <= 48) ? 0 : (c.n_rows <= 32 && d <= 48) ? 1 : 2;
             clc[cls].push_back((int)i);
+            for (int q = c.fac0; q < c.fac1; q++) if (B.gf[B.cl_fac[q]].type == GF_IMU) b->clc_imu[cls] = true;
         }
         D.n_pd = (int)pd.size(); D.n_po = (int)po.size(); D.n_cle = (int)cle.size();
         PUT(pd_idx, pd); PUT(po_idx, po); PUT(cle_idx, cle);
@@ -788,12 +790,11 @@ struct Launcher {
         {
             hipStream_t sa = b->aux ? b->aux : st;
             if (b->aux) (void)hipStreamWaitEvent(b->aux, b->ev_fork[1], 0);          // scalar-factor Jacobians (k_eval_ps)
-            {
-                Bracket t(*this, SWF_K_CLIQUE_ELIM, sa);
-                if (D.n_clc[1]) hipLaunchKernelGGL((k_clique_elim<32, 48, 9, 1>), dim3(D.n_clc[1]), dim3(64), 0, sa, D, O);
-                if (D.n_clc[0]) hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, sa, D, O);
-                if (D.n_clc[2]) hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, sa, D, O);
-            }
+            // latency path: a class without IMU factors needs only k_eval_ps and runs on the main stream, next to the IMU branch
+            auto cstream = [&](int cls) { return (b->aux && !b->clc_imu[cls]) ? st : sa; };
+            if (D.n_clc[1]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(1)); hipLaunchKernelGGL((k_clique_elim<32, 48, 9, 1>), dim3(D.n_clc[1]), dim3(64), 0, cstream(1), D, O); }
+            if (D.n_clc[0]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(0)); hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, cstream(0), D, O); }
+            if (D.n_clc[2]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(2)); hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, cstream(2), D, O); }
             if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);
         }
         if (D.n_fsb) { Bracket t(*this, SWF_K_FRAME_SUMS); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
