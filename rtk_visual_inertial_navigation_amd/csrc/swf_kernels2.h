@@ -263,15 +263,17 @@ __global__ void __launch_bounds__(NT, NT == 256 ? CH_OCC : 4) k_chol_solve(DevBa
 // Factor and invert one 16x16 SPD tile with the 64 lanes of one wavefront (shared by k_chol_rr2 and k_chol_big).
 // D: the full symmetric tile in LDS, overwritten by L (lower, zeros above); LiJ: receives L^-1 (lower).  Returns
 // true if a pivot was not positive.
-__device__ __forceinline__ bool chol_pivot_tile(double (*D)[17], double (*LiJ)[17], int li, int lk) {
+__device__ __forceinline__ bool chol_pivot_tile(double (*D)[17], double (*LiJ)[17], int li, int lk, double* ipb /* LDS, 16 doubles */) {
     // Factor and invert the 16x16 tile with all 64 lanes: the tile A and the running inverse R (starts as I)
     // live in the MFMA C-layout (lane (li, lk), reg q <-> row lk+4q, column li; A is kept fully symmetric).
     // Column c:  ip = 1/sqrt(A_cc);  column c of A reaches every lane of its row by one DPP row_newbcast,
     // row c of A / R reaches every row by one ds_bpermute;  then, for rows r > c,
     //   A[r][:] -= A[r][c] A[c][:] / A_cc      (right-looking Cholesky update)
     //   R[r][:] -= A[r][c] R[c][:] / A_cc      (forward substitution of L X = I, same broadcasts)
-    // and column c of L = A[:][c] ip, row c of X = R[c][:] ip.  The only serial chain per column is
-    // readlane -> rsqrt -> fma; everything else is independent work for the wave's issue slots.
+    // Column c of L = A[:][c] ip_c and row c of X = R[c][:] ip_c are never read again inside the loop, so their scalings
+    // are deferred to one pass at the end (ip_c parked in LDS): the wave is bound by its own instruction issue
+    // (~50 instructions per column, measured ~8 cycles each), and the per-column scaling with its exec-mask
+    // bookkeeping was a quarter of them.  Same multiplications, same operands: bit-identical to scaling in place.
     double A_[4], R_[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) { A_[q] = D[lk + 4 * q][li]; R_[q] = (lk + 4 * q == li) ? 1.0 : 0.0; }
@@ -286,6 +288,7 @@ __device__ __forceinline__ bool chol_pivot_tile(double (*D)[17], double (*LiJ)[1
         if (!(dp > 0.0)) bad = true;
         double ip = rsqrt_nr(dp);
         double ip2 = ip * ip;
+        ipb[c] = ip;                                      // every lane writes the same value
         double rowA = bperm_d(A_[cq], bidx[cr]);          // A[c][li]
         double rowR = bperm_d(R_[cq], bidx[cr]);          // R[c][li]
         double sA = (li > c) ? rowA * ip2 : 0.0;          // columns <= c of A are final (L) already
@@ -299,17 +302,15 @@ __device__ __forceinline__ bool chol_pivot_tile(double (*D)[17], double (*LiJ)[1
                 R_[q] = __builtin_fma(-col, sR, R_[q]);
             }
         }
-        if (li == c) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) A_[q] *= ip;      // column c of L (rows above the diagonal are zeroed at the store)
-        }
-        if (lk == cr) R_[cq] *= ip;                       // row c of X = L^-1
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const double ipc = ipb[li];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         int r = lk + 4 * q;
-        D[r][li] = (li <= r) ? A_[q] : 0.0;
-        LiJ[r][li] = (li <= r) ? R_[q] : 0.0;
+        D[r][li] = (li <= r) ? A_[q] * ipc : 0.0;         // column li of L
+        LiJ[r][li] = (li <= r) ? R_[q] * ipb[r] : 0.0;    // row r of X = L^-1
     }
     return bad;
 }
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
-            bool bad = chol_pivot_tile(D, Li[j], li, lk);
+            bool bad = chol_pivot_tile(D, Li[j], li, lk, dinv);
             if (bad && lane == 0) fail = 1;
             CHACC(9, tq);
 #ifdef SWF_PROFILE_CHOL
@@ -548,6 +549,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     __shared__ double Pn[CB_MAXT][16][17];     // panel of the current column, tile row I -> L_Ij (72 KB)
     __shared__ double Lic[16][17];             // Linv_jj of the current column
+    __shared__ double ipiv[16];                // 1/sqrt(pivot) of the tile being factored (chol_pivot_tile scratch)
     __shared__ double Dt[2][16][17];           // published diagonal tiles, double-buffered
     __shared__ double zs[528];
     __shared__ double yv[528];
@@ -619,7 +621,7 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
-            bool bad = chol_pivot_tile(Dt[j & 1], Lic, li, lk);
+            bool bad = chol_pivot_tile(Dt[j & 1], Lic, li, lk, ipiv);
 #pragma unroll
             for (int q = 0; q < 4; q++) LinvG[(size_t)j * 256 + (lk + 4 * q) * 16 + li] = Lic[lk + 4 * q][li];
             if (bad && lane == 0) fail = 1;
