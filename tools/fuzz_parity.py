@@ -1,0 +1,63 @@
+"""Randomised GPU-vs-oracle parity sweep (not part of the test suite; run on a GPU box):
+   python tools/fuzz_parity.py [n_cases] [seed]
+Random window shapes (keyframes, features, satellites, Doppler, SPP / fixed-integer factors, parameter_head choice); for each:
+linearisation + reduced system against the oracle, the 8-iteration dogleg sequence, and batch == single bitwise."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_binding as ob
+from rtk_visual_inertial_navigation_amd import synth, solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+rel = lambda a, b: np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+bad = 0
+wins = []
+for t in range(N):
+    vi = rng.random() < 0.3
+    if os.environ.get("FUZZ_LARGE"):       # n_red > 240 (streaming Cholesky), the 12-consumer-wave landmark kernel, long tracks
+        K = int(rng.integers(17, 35)); F = int(rng.integers(60, 260)); S = 0 if vi else int(rng.integers(5, 16))
+    else:
+        K = int(rng.integers(3, 17)); F = int(rng.integers(max(4, K), 70)); S = 0 if vi else int(rng.integers(5, 13))
+    kw = dict(config_id=2 if vi else 3, K=K, F=F, S=S, seed=int(rng.integers(1, 10 ** 6)))
+    if S and rng.random() < 0.3: kw["doppler"] = True
+    if rng.random() < 0.4: kw["head"] = "ambiguities" if (S and rng.random() < 0.5) else "frames"
+    w = synth.make_window(**kw)
+    if S and rng.random() < 0.4:
+        w = synth.with_spp_and_fixed(w, seed=int(rng.integers(1, 1000)), n_fix=int(rng.integers(0, 4)))
+    msg = []
+    try:
+        so, eo = ob.solve(w.copy(), default_options(step_mode=1))
+        bs = solver.BatchSolver([w.copy()]); sg = bs.solve(default_options(step_mode=1))[0]
+        Sg, rg, Lg = bs.export_reduced(0); g, dg, y = bs.export_vectors(0)
+        if rel(g, eo["grad"]) > 1e-11 or rel(Sg, eo["S"]) > 1e-11 or rel(rg, eo["rhs"]) > 1e-10: msg.append("linearisation")
+        if rel(Lg @ Lg.T, Sg) > 1e-12: msg.append("LLt")
+        bs.close()
+        wo, wg = w.copy(), w.copy()
+        so, _ = ob.solve(wo, default_options(), export=False)
+        bs = solver.BatchSolver([wg]); sg = bs.solve(default_options())[0]
+        ro, rg_ = so.rows(), sg.rows()
+        if sg.termination != so.termination or len(ro) != len(rg_): msg.append("termination %d vs %d" % (sg.termination, so.termination))
+        else:
+            if [r["step_is_successful"] for r in rg_] != [r["step_is_successful"] for r in ro]: msg.append("accept sequence")
+            for a, b in zip(rg_, ro):
+                if abs(a["cost"] - b["cost"]) > 5e-7 * abs(b["cost"]) + 5e-5: msg.append("cost %.3e vs %.3e" % (a["cost"], b["cost"])); break
+            if np.abs(wg.a["pose"] - wo.a["pose"]).max() > 1e-6: msg.append("pose")
+        wins.append((w, wg, [r["cost"] for r in rg_]))
+        bs.close()
+    except Exception as e:
+        msg.append("exception " + repr(e)[:200])
+    print(t, kw, "spp" if w.a["spr_idx"].size else "", "OK" if not msg else "FAIL " + "; ".join(msg), flush=True)
+    bad += bool(msg)
+# the whole set as one heterogeneous batch == the singles, bit for bit
+if wins:
+    batch = [w.copy() for w, _, _ in wins]
+    bs = solver.BatchSolver(batch); sms = bs.solve(default_options())
+    for i, ((w, wg, costs), wb, sm) in enumerate(zip(wins, batch, sms)):
+        same = [r["cost"] for r in sm.rows()] == costs and all(np.array_equal(wg.a[k], wb.a[k]) for k in ("pose", "sb", "lm", "sc"))
+        if not same: print("batch != single for case", i); bad += 1
+    bs.close()
+print("fuzz: %d cases, %d failures" % (N, bad))
+sys.exit(1 if bad else 0)
