@@ -1,9 +1,9 @@
 """Time the marginalisation consumer on the GPU against the oracle on one host thread.
-   python tools/bench_marginalize.py [windows]
+   python tests/perf/bench_marginalize.py [windows]
 Workloads: (a) cfg3 windows, tail = the 10 RTK ambiguities (the ambiguity hand-off, UpdateNParameterHead);
            (b) 7- and 8-keyframe windows, tail = every pose / speed-bias but the oldest frame's + ambiguities (a GlobalMarge)."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_binding as ob

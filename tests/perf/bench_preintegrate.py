@@ -1,9 +1,9 @@
 """Time the batched IMU pre-integration kernel on the GPU against the oracle on one host thread.
-   python tools/bench_preintegrate.py [windows] [samples_per_interval]
+   python tests/perf/bench_preintegrate.py [windows] [samples_per_interval]
 Workload: cfg4-shaped — `windows` x 19 keyframe intervals, each with `samples_per_interval` IMU samples (400 Hz x 0.1 s = 41
 with the seeding sample), inputs resident in HBM, HIP-event timing on the launch stream."""
 import ctypes as C, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

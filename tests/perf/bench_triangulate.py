@@ -1,8 +1,8 @@
 """Time the batched two-view triangulation on the GPU against the oracle on one host thread.
-   python tools/bench_triangulate.py [windows] [features_per_window]
+   python tests/perf/bench_triangulate.py [windows] [features_per_window]
 Workload: `windows` x 20 frames, `features_per_window` features each (cfg4: 512 x 300), inputs resident in HBM."""
 import ctypes as C, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

@@ -1,9 +1,9 @@
 """Randomised GPU-vs-oracle parity sweep (not part of the test suite; run on a GPU box):
-   python tools/fuzz_parity.py [n_cases] [seed]
+   python tests/perf/fuzz_parity.py [n_cases] [seed]
 Random window shapes (keyframes, features, satellites, Doppler, SPP / fixed-integer factors, parameter_head choice); for each:
 linearisation + reduced system against the oracle, the 8-iteration dogleg sequence, and batch == single bitwise."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_binding as ob
