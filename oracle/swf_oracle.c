@@ -1490,3 +1490,241 @@ int oracle_marginalize(const double* S, const double* rhs, int32_t hs, int32_t n
     free(A); free(b);
     return 0;
 }
+
+/* =====================================================================================================================
+ * Composite IMU-GNSS factor: IMUFactor::Evaluate2 (R/factor/imu_factor.cpp:103-195) and
+ * IMUGNSSBase (R/factor/gnss_imu_factor.cpp): the GNSS-epoch states between two visual frames are hidden behind a sequential
+ * block-tridiagonal elimination; the factor exposes a (30+N)-row linearised residual over [pose_i sb_i | pose_j sb_j | N
+ * ambiguities], re-eliminates at every Jacobian evaluation (after back-substituting the hidden states from the outer
+ * increment) and answers cost-only evaluations from the linear model r = r_lin - J INC.
+ * Block indices follow the reference's enum HessianOrder { O_Pose1 = 0, O_Pose2, O_N, O_Pose0 } (gnss_imu_factor.h:7-14).
+ * ===================================================================================================================== */
+/* a5: Evaluate2 = the residual of Evaluate with the Jacobians merged per frame, columns [P(3) R(3) | V BA BG (9)] */
+void oracle_eval_imu2(const double* pi, const double* sbi, const double* pj, const double* sbj, const double* pre,
+                      const double* pbg, const double* gw, double* r, double* J1 /*15x15*/, double* J2 /*15x15*/) {
+    double Jpi[90], Jsi[135], Jpj[90], Jsj[135];
+    oracle_eval_imu(pi, sbi, pj, sbj, pre, pbg, gw, r, Jpi, Jsi, Jpj, Jsj);
+    for (int i = 0; i < 15; i++) {
+        for (int k = 0; k < 6; k++) { J1[i * 15 + k] = Jpi[i * 6 + k]; J2[i * 15 + k] = Jpj[i * 6 + k]; }
+        for (int k = 0; k < 9; k++) { J1[i * 15 + 6 + k] = Jsi[i * 9 + k]; J2[i * 15 + 6 + k] = Jsj[i * 9 + k]; }
+    }
+}
+
+enum { CO_POSE1 = 0, CO_POSE2 = 1, CO_N = 2, CO_POSE0 = 3, CO_SIZE = 4 };
+typedef struct oracle_composite {
+    int M, N;
+    double *pose, *sb;                         /* hidden GNSS-epoch states [M][7], [M][9] (gnss_poses / gnss_speed_bias) */
+    double *pose_lin, *sb_lin;                 /* linearisation points of the per-epoch GNSS priors */
+    double *Hpp, *HpN, *rhs_p, *HNN, *rhsN;    /* pose_hessians [M][225], pose_phase_biases_hessians [M][15 N], pose_rhses [M][15],
+                                                  phase_biases_hessians [N N], phase_biases_rhs [N]  (AddMargInfo :245-352) */
+    double *pre;                               /* [M+1] pre-integration records: frame_i->e_0, e_k-1->e_k, e_M-1->frame_j */
+    double pbg[3], gw[3];
+    int hs[CO_SIZE];                           /* hessian_size */
+    double *H[CO_SIZE * CO_SIZE], *rhs[CO_SIZE], *delta[CO_SIZE];      /* hessian55 (j >= i), rhs5, delta5 */
+    double *hmn[CO_SIZE], *rhsmn;              /* hmn_save[k][i] = block (Pose1, k) at the elimination of epoch i; rhsmn_save */
+    double *J, *r, *INC;                       /* schur_jacobian (G x G row-major), schur_residual, INC;  G = 30 + N */
+    double Pi_old[7], Bi_old[9], Pj_old[7], Bj_old[9], *N_old;
+    int history;
+} oracle_composite;
+
+oracle_composite* oracle_composite_create(int M, int N, const double* pose, const double* sb, const double* pose_lin, const double* sb_lin,
+                                          const double* Hpp, const double* HpN, const double* rhs_p, const double* HNN, const double* rhsN,
+                                          const double* pre, const double* pbg, const double* gw) {
+    oracle_composite* c = (oracle_composite*)calloc(1, sizeof(oracle_composite));
+    c->M = M; c->N = N;
+#define CO_DUP(dst, src, cnt) { c->dst = (double*)malloc(sizeof(double) * ((cnt) > 0 ? (cnt) : 1)); memcpy(c->dst, src, sizeof(double) * (cnt)); }
+    CO_DUP(pose, pose, M * 7) CO_DUP(sb, sb, M * 9) CO_DUP(pose_lin, pose_lin, M * 7) CO_DUP(sb_lin, sb_lin, M * 9)
+    CO_DUP(Hpp, Hpp, M * 225) CO_DUP(HpN, HpN, M * 15 * N) CO_DUP(rhs_p, rhs_p, M * 15) CO_DUP(HNN, HNN, N * N) CO_DUP(rhsN, rhsN, N)
+    CO_DUP(pre, pre, (M + 1) * SWF_PRE_DOUBLES)
+#undef CO_DUP
+    for (int k = 0; k < 3; k++) { c->pbg[k] = pbg[k]; c->gw[k] = gw[k]; }
+    c->hs[CO_POSE1] = 15; c->hs[CO_POSE2] = 15; c->hs[CO_N] = N; c->hs[CO_POSE0] = 15;     /* InitHessianRhs :63-72 */
+    for (int i = 0; i < CO_SIZE; i++) {
+        c->rhs[i] = (double*)calloc(c->hs[i] + 1, sizeof(double)); c->delta[i] = (double*)calloc(c->hs[i] + 1, sizeof(double));
+        for (int j = i; j < CO_SIZE; j++) c->H[i * CO_SIZE + j] = (double*)calloc(c->hs[i] * c->hs[j] + 1, sizeof(double));
+        c->hmn[i] = (double*)calloc((size_t)M * 15 * c->hs[i] + 1, sizeof(double));
+    }
+    c->rhsmn = (double*)calloc(M * 15 + 1, sizeof(double));
+    int G = 30 + N;
+    c->J = (double*)calloc(G * G, sizeof(double)); c->r = (double*)calloc(G, sizeof(double)); c->INC = (double*)calloc(G, sizeof(double));
+    c->N_old = (double*)calloc(N + 1, sizeof(double));
+    c->history = 0;
+    return c;
+}
+void oracle_composite_destroy(oracle_composite* c) {
+    if (!c) return;
+    free(c->pose); free(c->sb); free(c->pose_lin); free(c->sb_lin); free(c->Hpp); free(c->HpN); free(c->rhs_p); free(c->HNN); free(c->rhsN); free(c->pre);
+    for (int i = 0; i < CO_SIZE; i++) { free(c->rhs[i]); free(c->delta[i]); free(c->hmn[i]); for (int j = i; j < CO_SIZE; j++) free(c->H[i * CO_SIZE + j]); }
+    free(c->rhsmn); free(c->J); free(c->r); free(c->INC); free(c->N_old); free(c);
+}
+void oracle_composite_hidden(const oracle_composite* c, double* pose, double* sb) {
+    memcpy(pose, c->pose, sizeof(double) * c->M * 7); memcpy(sb, c->sb, sizeof(double) * c->M * 9);
+}
+
+/* x (-) x0 on pose + speed-bias: [p - p0, +-2 vec(q0^-1 q), sb - sb0]  (GetInc :654-670; sign flips the rotation part when w < 0) */
+static void co_inc15(const double* P, const double* B, const double* P0, const double* B0, double sgn, double* dx) {
+    double q0i[4], dq[4];
+    for (int k = 0; k < 3; k++) dx[k] = sgn * (P[k] - P0[k]);
+    qinv(P0 + 3, q0i); qmul(q0i, P + 3, dq);
+    double s2 = (dq[3] >= 0) ? 2.0 : -2.0;
+    for (int k = 0; k < 3; k++) dx[3 + k] = sgn * s2 * dq[k];
+    for (int k = 0; k < 9; k++) dx[6 + k] = sgn * (B[k] - B0[k]);
+}
+/* y (m) += sign * A (m x n) x   /   y (n) += A^T (m x n) x */
+static void co_mv(const double* A, int m, int n, const double* x, double sign, double* y) { for (int i = 0; i < m; i++) { double s = 0; for (int k = 0; k < n; k++) s += A[i * n + k] * x[k]; y[i] += sign * s; } }
+static void co_mtv(const double* A, int m, int n, const double* x, double* y) { for (int j = 0; j < n; j++) { double s = 0; for (int i = 0; i < m; i++) s += A[i * n + j] * x[i]; y[j] += s; } }
+/* C (15 x nb) += A^T B,  A 15 x 15 (residual rows x columns), B 15 x nb */
+static void co_atb(const double* A, const double* B, int nb, double* C) {
+    for (int i = 0; i < 15; i++) for (int j = 0; j < nb; j++) { double s = 0; for (int k = 0; k < 15; k++) s += A[k * 15 + i] * B[k * nb + j]; C[i * nb + j] += s; }
+}
+/* JacobianResidualUpdateHessianRhs :354-378 for two 15-column blocks with hessian indices ia, ib */
+static void co_accumulate(oracle_composite* c, int ia, int ib, const double* Ja, const double* Jb, const double* res) {
+    const int idx[2] = { ia, ib }; const double* Jv[2] = { Ja, Jb };
+    for (int i = 0; i < 2; i++) {
+        co_mtv(Jv[i], 15, 15, res, c->rhs[idx[i]]);
+        for (int j = 0; j < 2; j++) {
+            if (idx[j] < idx[i]) continue;
+            co_atb(Jv[i], Jv[j], 15, c->H[idx[i] * CO_SIZE + idx[j]]);
+        }
+    }
+}
+/* MargPose1 :403-433: eliminate block Pose1 onto Pose2, N, Pose0; the (Pose1, Pose1) block is replaced by its inverse
+ * (ceres::internal::InvertPSDMatrix<15>(assume_full_rank): LLT solve of the identity) */
+static int co_marg_pose1(oracle_composite* c) {
+    double L[225], Ainv[225];
+    memcpy(L, c->H[0], sizeof(L));
+    for (int i = 0; i < 15; i++) for (int j = i + 1; j < 15; j++) L[j * 15 + i] = L[i * 15 + j];     /* the accumulations fill i <= j exactly; LLT reads the lower */
+    if (chol_lower(L, 15, 15) != 0) return -1;
+    for (int col = 0; col < 15; col++) {
+        double z[15];
+        for (int i = 0; i < 15; i++) { double s = (i == col) ? 1.0 : 0.0; for (int k = 0; k < i; k++) s -= L[i * 15 + k] * z[k]; z[i] = s / L[i * 15 + i]; }
+        for (int i = 14; i >= 0; i--) { double s = z[i]; for (int k = i + 1; k < 15; k++) s -= L[k * 15 + i] * z[k]; z[i] = s / L[i * 15 + i]; }
+        for (int i = 0; i < 15; i++) Ainv[i * 15 + col] = z[i];
+    }
+    memcpy(c->H[0], Ainv, sizeof(Ainv));
+    for (int i = CO_POSE1 + 1; i < CO_SIZE; i++) {
+        int sn = c->hs[i];
+        if (sn == 0) continue;
+        double* T = (double*)calloc(sn * 15, sizeof(double));                  /* Anm Amm^-1 = H[0,i]^T Ainv  (sn x 15) */
+        const double* H0i = c->H[0 * CO_SIZE + i];
+        for (int a = 0; a < sn; a++) for (int b = 0; b < 15; b++) { double s = 0; for (int k = 0; k < 15; k++) s += H0i[k * sn + a] * Ainv[k * 15 + b]; T[a * 15 + b] = s; }
+        co_mv(T, sn, 15, c->rhs[0], -1.0, c->rhs[i]);
+        for (int j = i; j < CO_SIZE; j++) {
+            int sv = c->hs[j];
+            const double* H0j = c->H[0 * CO_SIZE + j]; double* Hij = c->H[i * CO_SIZE + j];
+            for (int a = 0; a < sn; a++) for (int b = 0; b < sv; b++) { double s = 0; for (int k = 0; k < 15; k++) s += T[a * 15 + k] * H0j[k * sv + b]; Hij[a * sv + b] -= s; }
+        }
+        free(T);
+    }
+    return 0;
+}
+/* MoveHessianData :435-452 */
+static void co_move(oracle_composite* c, int e) {
+    memcpy(c->rhsmn + e * 15, c->rhs[0], sizeof(double) * 15);
+    for (int k = CO_POSE1; k < CO_SIZE; k++) memcpy(c->hmn[k] + (size_t)e * 15 * c->hs[k], c->H[0 * CO_SIZE + k], sizeof(double) * 15 * c->hs[k]);
+    memcpy(c->H[0], c->H[1 * CO_SIZE + 1], sizeof(double) * 225); memset(c->H[1 * CO_SIZE + 1], 0, sizeof(double) * 225);
+    memcpy(c->rhs[0], c->rhs[1], sizeof(double) * 15); memset(c->rhs[1], 0, sizeof(double) * 15);
+    for (int k = CO_POSE2 + 1; k < CO_SIZE; k++) {
+        memcpy(c->H[0 * CO_SIZE + k], c->H[1 * CO_SIZE + k], sizeof(double) * 15 * c->hs[k]);
+        memset(c->H[1 * CO_SIZE + k], 0, sizeof(double) * 15 * c->hs[k]);
+    }
+    memset(c->H[0 * CO_SIZE + 1], 0, sizeof(double) * 225);
+}
+/* UpdateHiddenState :601-632: back-substitute the hidden epochs, newest first, from the outer increments in delta[] */
+static void co_update_hidden(oracle_composite* c) {
+    for (int i = c->M - 1; i >= 0; i--) {
+        double* rm = c->rhsmn + i * 15;
+        for (int j = CO_POSE2; j < CO_SIZE; j++) co_mv(c->hmn[j] + (size_t)i * 15 * c->hs[j], 15, c->hs[j], c->delta[j], -1.0, rm);
+        double d[15]; memset(d, 0, sizeof(d));
+        co_mv(c->hmn[CO_POSE1] + (size_t)i * 225, 15, 15, rm, 1.0, d);
+        memcpy(c->delta[CO_POSE2], d, sizeof(d));
+        double* P = c->pose + i * 7; double* B = c->sb + i * 9;
+        for (int k = 0; k < 3; k++) P[k] -= d[k];
+        double th[3] = { -d[3], -d[4], -d[5] }, dq[4], q[4];
+        deltaQ(th, dq); qmul(P + 3, dq, q);
+        double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (int k = 0; k < 4; k++) P[3 + k] = q[k] / nq;
+        for (int k = 0; k < 9; k++) B[k] -= d[6 + k];
+    }
+}
+/* UpdateSchurComponent :454-488: dense (30+N) system in the order [Pose0 | Pose1 (= frame j after the shifts) | N], eigen square root */
+static void co_schur_component(oracle_composite* c) {
+    const int map[3] = { CO_POSE0, CO_POSE1, CO_N };
+    int G = 30 + c->N, hidx[3] = { 0, 15, 30 };
+    double* Hd = (double*)calloc(G * G, sizeof(double)); double* rd = (double*)calloc(G, sizeof(double));
+    for (int i = 0; i < 3; i++) {
+        int i2 = map[i];
+        memcpy(rd + hidx[i], c->rhs[i2], sizeof(double) * c->hs[i2]);
+        for (int j = i; j < 3; j++) {
+            int j2 = map[j];
+            for (int a = 0; a < c->hs[i2]; a++) for (int b = 0; b < c->hs[j2]; b++)
+                Hd[(hidx[i] + a) * G + hidx[j] + b] = (j2 >= i2) ? c->H[i2 * CO_SIZE + j2][a * c->hs[j2] + b] : c->H[j2 * CO_SIZE + i2][b * c->hs[i2] + a];
+        }
+    }
+    for (int a = 0; a < G; a++) for (int b = 0; b < a; b++) Hd[a * G + b] = Hd[b * G + a];          /* selfadjointView<Upper> */
+    double* V = (double*)malloc(sizeof(double) * G * G); double* w = (double*)malloc(sizeof(double) * G);
+    sym_eig_jacobi(G, Hd, V, w);
+    for (int k = 0; k < G; k++) {
+        double lam = w[k] > 1e-8 ? w[k] : 0.0, sq = sqrt(lam), isq = lam > 0 ? 1.0 / sqrt(lam) : 0.0;
+        double dot = 0;
+        for (int a = 0; a < G; a++) { c->J[k * G + a] = sq * V[a * G + k]; dot += V[a * G + k] * rd[a]; }
+        c->r[k] = isq * dot;
+    }
+    free(Hd); free(rd); free(V); free(w);
+}
+
+/* IMUGNSSBase::Evaluate :678-799.  residual: G doubles; jac (may be NULL): G x G row-major over the outer local coordinates
+ * [pose_i(6) sb_i(9) | pose_j(6) sb_j(9) | N] — what UpdateJacobResidual :490-525 slices into the parameter blocks.
+ * Returns 0, or -1 if an epoch's 15 x 15 block was not positive definite. */
+int oracle_composite_evaluate(oracle_composite* c, const double* Pi, const double* Bi, const double* Pj, const double* Bj, const double* Nv,
+                              int want_jac, double* residual, double* jac) {
+    const int N = c->N, M = c->M, G = 30 + N;
+    if (!c->history) { memcpy(c->Pi_old, Pi, 56); memcpy(c->Bi_old, Bi, 72); memcpy(c->Pj_old, Pj, 56); memcpy(c->Bj_old, Bj, 72); memcpy(c->N_old, Nv, sizeof(double) * N); }
+    /* UpdateDeltaValues :560-598: increments old (-) new */
+    co_inc15(Pj, Bj, c->Pj_old, c->Bj_old, -1.0, c->delta[CO_POSE2]);
+    for (int k = 0; k < N; k++) c->delta[CO_N][k] = c->N_old[k] - Nv[k];
+    co_inc15(Pi, Bi, c->Pi_old, c->Bi_old, -1.0, c->delta[CO_POSE0]);
+    memcpy(c->INC, c->delta[CO_POSE0], sizeof(double) * 15); memcpy(c->INC + 15, c->delta[CO_POSE2], sizeof(double) * 15);
+    memcpy(c->INC + 30, c->delta[CO_N], sizeof(double) * N);
+    const int update = want_jac != 0;
+    if (c->history && update) co_update_hidden(c);
+    if (!c->history || update) {
+        c->history = 1;
+        memcpy(c->Pi_old, Pi, 56); memcpy(c->Bi_old, Bi, 72); memcpy(c->Pj_old, Pj, 56); memcpy(c->Bj_old, Bj, 72); memcpy(c->N_old, Nv, sizeof(double) * N);
+        for (int i = 0; i < CO_SIZE; i++) { memset(c->rhs[i], 0, sizeof(double) * c->hs[i]); for (int j = i; j < CO_SIZE; j++) memset(c->H[i * CO_SIZE + j], 0, sizeof(double) * c->hs[i] * c->hs[j]); }
+        memcpy(c->H[CO_N * CO_SIZE + CO_N], c->HNN, sizeof(double) * N * N);
+        memcpy(c->rhs[CO_N], c->rhsN, sizeof(double) * N);
+        co_mv(c->HNN, N, N, Nv, 1.0, c->rhs[CO_N]);                                               /* UpdateRhsN */
+        double res[15], J1[225], J2[225];
+        oracle_eval_imu2(Pi, Bi, c->pose, c->sb, c->pre, c->pbg, c->gw, res, J1, J2);
+        co_accumulate(c, CO_POSE0, CO_POSE1, J1, J2, res);
+        for (int i = 0; i < M; i++) {
+            const double* pa = c->pose + i * 7; const double* ba = c->sb + i * 9;
+            const double* pb = (i != M - 1) ? c->pose + (i + 1) * 7 : Pj; const double* bb = (i != M - 1) ? c->sb + (i + 1) * 9 : Bj;
+            oracle_eval_imu2(pa, ba, pb, bb, c->pre + (size_t)(i + 1) * SWF_PRE_DOUBLES, c->pbg, c->gw, res, J1, J2);
+            co_accumulate(c, CO_POSE1, CO_POSE2, J1, J2, res);
+            /* UpdateRhsPose :535-556 + the epoch's GNSS prior blocks :775-778 */
+            double dx[15];
+            co_inc15(pa, ba, c->pose_lin + i * 7, c->sb_lin + i * 9, 1.0, dx);
+            co_mv(c->Hpp + (size_t)i * 225, 15, 15, dx, 1.0, c->rhs[CO_POSE1]);
+            co_mv(c->HpN + (size_t)i * 15 * N, 15, N, Nv, 1.0, c->rhs[CO_POSE1]);
+            co_mtv(c->HpN + (size_t)i * 15 * N, 15, N, dx, c->rhs[CO_N]);
+            for (int k = 0; k < 225; k++) c->H[0][k] += c->Hpp[(size_t)i * 225 + k];
+            for (int k = 0; k < 15 * N; k++) c->H[0 * CO_SIZE + CO_N][k] += c->HpN[(size_t)i * 15 * N + k];
+            for (int k = 0; k < 15; k++) c->rhs[CO_POSE1][k] += c->rhs_p[i * 15 + k];
+            if (co_marg_pose1(c) != 0) return -1;
+            co_move(c, i);
+        }
+        co_schur_component(c);
+    }
+    /* UpdateJacobResidual :490-525 */
+    if (residual) {
+        for (int k = 0; k < G; k++) {
+            double v = c->r[k];
+            if (!update) { double s = 0; for (int a = 0; a < G; a++) s += c->J[k * G + a] * c->INC[a]; v -= s; }
+            residual[k] = v;
+        }
+    }
+    if (jac) memcpy(jac, c->J, sizeof(double) * G * G);
+    return 0;
+}

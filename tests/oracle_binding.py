@@ -159,6 +159,49 @@ def preintegrate(samples, ba, bg, acc_n, gyr_n, acc_w, gyr_w):
     return pre
 
 
+def eval_imu2(pi, sbi, pj, sbj, pre, pbg, gw):
+    """IMUFactor::Evaluate2: residual + the two merged 15x15 Jacobians (row a5)."""
+    r, J1, J2 = np.zeros(15), np.zeros((15, 15)), np.zeros((15, 15))
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pi, sbi, pj, sbj, pre, pbg, gw)]
+    lib().oracle_eval_imu2(*[_p(x) for x in a], _p(r), _p(J1), _p(J2))
+    return r, J1, J2
+
+
+class Composite:
+    """IMUGNSSBase / IMUGNSSFactor restatement (row a10): a stateful factor over [pose_i sb_i | pose_j sb_j | N ambiguities]."""
+
+    def __init__(self, pose, sb, pose_lin, sb_lin, Hpp, HpN, rhs_p, HNN, rhsN, pre, pbg, gw):
+        self.M, self.N = int(np.asarray(pose).reshape(-1, 7).shape[0]), int(np.asarray(rhsN).size)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pose, sb, pose_lin, sb_lin, Hpp, HpN, rhs_p, HNN, rhsN, pre, pbg, gw)]
+        f = lib().oracle_composite_create
+        f.restype = C.c_void_p
+        self._h = C.c_void_p(f(C.c_int(self.M), C.c_int(self.N), *[_p(x) for x in a]))
+
+    def evaluate(self, Pi, Bi, Pj, Bj, Nv, want_jac):
+        G = 30 + self.N
+        r, J = np.zeros(G), np.zeros((G, G))
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (Pi, Bi, Pj, Bj, Nv if self.N else np.zeros(1))]
+        rc = lib().oracle_composite_evaluate(self._h, *[_p(x) for x in a], C.c_int(1 if want_jac else 0), _p(r), _p(J) if want_jac else None)
+        if rc != 0:
+            raise RuntimeError("oracle_composite_evaluate: a hidden epoch's block is not positive definite")
+        return (r, J) if want_jac else r
+
+    def hidden(self):
+        pose, sb = np.zeros((self.M, 7)), np.zeros((self.M, 9))
+        lib().oracle_composite_hidden(self._h, _p(pose), _p(sb))
+        return pose, sb
+
+    def close(self):
+        if self._h:
+            lib().oracle_composite_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def triangulate(Ps, Rs, tic, ric, pbg, start, pt0, pt1, init_depth=5.0):
     a = [np.ascontiguousarray(v, dtype=np.float64) for v in (Ps, Rs, tic, ric, pbg, pt0, pt1)]
     st = np.ascontiguousarray(start, dtype=np.int32)

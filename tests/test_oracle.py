@@ -197,6 +197,50 @@ def test_two_view_triangulation_vs_lapack_svd_and_truth():
     assert np.all(d3 == -1.0)
 
 
+def test_composite_imu_gnss_factor_equals_dense_elimination_of_its_hidden_states():
+    """Rows a5 / a10: IMUGNSSBase (R/factor/gnss_imu_factor.cpp) restated.  The reference cannot be run here, so the oracle is
+    pinned on what the algorithm defines: (1) J^T J and J^T r of the exposed factor are the Schur complement / reduced gradient
+    of the dense system over [outer | hidden epochs]; (2) a cost-only evaluation is the linear model r_lin - J INC;
+    (3) re-linearising after an outer step moves the hidden epochs by the dense back-substitution."""
+    import composite_gen as cg
+    rng = np.random.default_rng(12)
+    for (M, N) in ((1, 4), (3, 6), (8, 10), (5, 0)):
+        c = cg.make_chain(rng, M, N)
+        F = ob.Composite(c["pose"], c["sb"], c["pose_lin"], c["sb_lin"], c["Hpp"], c["HpN"], c["rhs_p"], c["HNN"], c["rhsN"], c["pre"], c["pbg"], c["gw"])
+        G = 30 + N
+        r, J = F.evaluate(c["Pi"], c["Bi"], c["Pj"], c["Bj"], c["Nv"], True)
+        H, g = cg.dense_system(c, c["Pi"], c["Bi"], c["Pj"], c["Bj"], c["Nv"], c["pose"], c["sb"])
+        Hoo, Hoh, Hhh = H[:G, :G], H[:G, G:], H[G:, G:]
+        S = Hoo - Hoh @ np.linalg.solve(Hhh, Hoh.T); gr = g[:G] - Hoh @ np.linalg.solve(Hhh, g[G:])
+        sc = np.abs(S).max()
+        assert np.abs(J.T @ J - S).max() <= 1e-9 * sc, (M, N)
+        assert np.abs(J.T @ r - gr).max() <= 1e-9 * np.abs(gr).max() + 1e-9 * sc
+        # (2) cost-only evaluations: linear in the reference's increment old (-) new
+        d = rng.normal(0, 1e-2, G)
+        Pi2, Pj2 = nf.pose_plus(c["Pi"], d[0:6]), nf.pose_plus(c["Pj"], d[15:21])
+        Bi2, Bj2, Nv2 = c["Bi"] + d[6:15], c["Bj"] + d[21:30], c["Nv"] + d[30:]
+        inc = np.concatenate([-cg.inc15(Pi2, Bi2, c["Pi"], c["Bi"]), -cg.inc15(Pj2, Bj2, c["Pj"], c["Bj"]), c["Nv"] - Nv2])
+        rc = F.evaluate(Pi2, Bi2, Pj2, Bj2, Nv2, False)
+        assert np.abs(rc - (r - J @ inc)).max() <= 1e-12 * (np.abs(r).max() + np.abs(J).max())
+        assert np.abs(F.evaluate(c["Pi"], c["Bi"], c["Pj"], c["Bj"], c["Nv"], False) - r).max() <= 1e-13 * np.abs(r).max()   # back at the point
+        hp0, hs0 = F.hidden()
+        assert np.array_equal(hp0, c["pose"]) and np.array_equal(hs0, c["sb"])          # cost-only calls never touch the hidden states
+        # (3) accept the step: the hidden epochs follow the dense solution  dz_h = -H_hh^-1 (g_h + H_ho dz_o)
+        r2, J2 = F.evaluate(Pi2, Bi2, Pj2, Bj2, Nv2, True)
+        dzo = -inc
+        dzh = -np.linalg.solve(Hhh, g[G:] + Hoh.T @ dzo)
+        hp1, hs1 = F.hidden()
+        for k in range(M):
+            e = dzh[15 * k:15 * k + 15]
+            assert np.abs(hp1[k] - nf.pose_plus(c["pose"][k], e[:6])).max() <= 1e-9 * max(1.0, np.abs(e).max()), (M, N, k)
+            assert np.abs(hs1[k] - (c["sb"][k] + e[6:])).max() <= 1e-9 * max(1.0, np.abs(e).max())
+        # and the new linearisation is again the Schur complement of the dense system at the moved states
+        H2, g2 = cg.dense_system(c, Pi2, Bi2, Pj2, Bj2, Nv2, hp1, hs1)
+        S2 = H2[:G, :G] - H2[:G, G:] @ np.linalg.solve(H2[G:, G:], H2[:G, G:].T)
+        assert np.abs(J2.T @ J2 - S2).max() <= 1e-9 * np.abs(S2).max()
+        F.close()
+
+
 def test_oracle_solver_invariants(win3):
     w = win3.copy()
     sm, ex = ob.solve(w, default_options(max_num_iterations=8))
