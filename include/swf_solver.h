@@ -184,6 +184,34 @@ int swf_triangulate_batch(const double* Ps, const double* Rs, int32_t n_frames, 
                           double init_depth, double* depth, double* pts_world, int32_t on_device, void* stream);
 
 /* =====================================================================================
+ * Composite IMU-GNSS factors as a batched, stateful device operator
+ *
+ * IMUGNSSBase / IMUGNSSFactor (R/factor/gnss_imu_factor.cpp): n factors, each hiding M[f] GNSS-epoch states between two
+ * visual frames behind N[f] <= 24 ambiguities.  Arrays are concatenated over the factors in order:
+ *   pose, sb            [sum M][7], [sum M][9]   hidden epochs (gnss_poses / gnss_speed_bias), copied: the handle owns them
+ *   pose_lin, sb_lin    linearisation points of the per-epoch GNSS priors
+ *   Hpp [sum M][225], HpN [sum 15 M N], rhs_p [sum M][15], HNN [sum N N], rhsN [sum N]   the blocks AddMargInfo :245-352 keeps
+ *   pre                 [sum M + n][SWF_PRE_DOUBLES]: factor f owns M[f] + 1 records: frame_i -> e_0, ..., e_M-1 -> frame_j
+ * swf_composite_evaluate = IMUGNSSBase::Evaluate (:678-799) for all factors at once:
+ *   outer [n][32] = pose_i(7) sb_i(9) pose_j(7) sb_j(9), Nv [sum N] = the ambiguity values
+ *   want_jac != 0: back-substitute the hidden epochs from the outer increment, re-eliminate, return the (30+N)-vector
+ *                  residual and the (30+N)^2 Jacobian (row-major, columns = local [pose_i sb_i | pose_j sb_j | N]) of each factor;
+ *   want_jac == 0: the linear model r_lin - J INC of the last linearisation (the first call linearises).
+ * The Jacobian is the Cholesky square root L^T of the remaining system (the reference takes the eigen square root: same
+ * J^T J and J^T r whenever the remainder is positive definite; status[f] = -1 reports a factor where it was not).
+ * Hd / rd (optional) receive the remaining system itself ((30+N)^2, 30+N per factor).  Host pointers; synchronous.
+ * ===================================================================================== */
+typedef struct swf_composite swf_composite;
+int swf_composite_create(int32_t n, const int32_t* M, const int32_t* N, const double* pose, const double* sb,
+                         const double* pose_lin, const double* sb_lin, const double* Hpp, const double* HpN,
+                         const double* rhs_p, const double* HNN, const double* rhsN, const double* pre,
+                         const double pbg[3], const double gw[3], void* stream, swf_composite** out);
+int swf_composite_evaluate(swf_composite* c, const double* outer, const double* Nv, int32_t want_jac,
+                           double* residual, double* jac, double* Hd, double* rd, int32_t* status);
+int swf_composite_hidden(swf_composite* c, double* pose, double* sb);
+int swf_composite_destroy(swf_composite* c);
+
+/* =====================================================================================
  * (2) ceres::Problem-shaped single-window surface
  *
  * Parameter blocks are identified BY ADDRESS like in Ceres; values are read through the

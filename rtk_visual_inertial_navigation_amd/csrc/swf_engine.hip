@@ -12,10 +12,12 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <memory>
 #include <vector>
 #include "../../include/swf_solver.h"
 #include "swf_kernels2.h"
 #include "swf_kernels3.h"
+#include "swf_kernels4.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -1096,3 +1098,95 @@ extern "C" int swf_debug_gemm_stamps(unsigned long long* out) {
 }
 #endif
 
+
+// =====================================================================================================================
+// Composite IMU-GNSS factors as a batched operator (include/swf_solver.h, swf_kernels4.h).  Stateful like the reference's
+// IMUGNSSBase: the handle owns the hidden epochs, the saved elimination blocks and the last linearisation.
+// =====================================================================================================================
+struct swf_composite {
+    CompArgs A{};
+    std::vector<void*> bufs;
+    int n = 0; long long sumM = 0, sumN = 0, sumG = 0, sumG2 = 0;
+    hipStream_t stream = nullptr;
+    ~swf_composite() { for (void* p : bufs) (void)hipFree(p); }
+};
+
+extern "C" int swf_composite_destroy(swf_composite* c) { delete c; return SWF_OK; }
+
+extern "C" int swf_composite_create(int32_t n, const int32_t* M, const int32_t* N, const double* pose, const double* sb,
+                                    const double* pose_lin, const double* sb_lin, const double* Hpp, const double* HpN,
+                                    const double* rhs_p, const double* HNN, const double* rhsN, const double* pre,
+                                    const double pbg[3], const double gw[3], void* stream, swf_composite** out) {
+    if (!out || n <= 0 || !M || !N || !pose || !sb || !pose_lin || !sb_lin || !Hpp || !HpN || !rhs_p || !HNN || !rhsN || !pre || !pbg || !gw)
+        return fail(SWF_E_INVALID, "swf_composite_create: null argument");
+    std::vector<int> eo(n + 1, 0), no(n + 1, 0);
+    std::vector<long long> pno(n + 1, 0), nno(n + 1, 0), go(n + 1, 0), g2o(n + 1, 0);
+    for (int f = 0; f < n; f++) {
+        if (M[f] < 1) return fail(SWF_E_INVALID, "composite factor without hidden epochs");
+        if (N[f] < 0 || N[f] > CO_MAXN) return fail(SWF_E_UNSUPPORTED, "composite factor with more than 24 ambiguities");
+        eo[f + 1] = eo[f] + M[f]; no[f + 1] = no[f] + N[f];
+        pno[f + 1] = pno[f] + 15LL * M[f] * N[f]; nno[f + 1] = nno[f] + (long long)N[f] * N[f];
+        go[f + 1] = go[f] + 30 + N[f]; g2o[f + 1] = g2o[f] + (long long)(30 + N[f]) * (30 + N[f]);
+    }
+    std::unique_ptr<swf_composite> c(new swf_composite());
+    c->n = n; c->sumM = eo[n]; c->sumN = no[n]; c->sumG = go[n]; c->sumG2 = g2o[n]; c->stream = (hipStream_t)stream;
+    bool bad = false;
+    auto up = [&](const void* src, size_t bytes) -> void* {
+        void* d = nullptr;
+        if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) { bad = true; return nullptr; }
+        c->bufs.push_back(d);
+        if (src) { if (hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) bad = true; }
+        else if (hipMemset(d, 0, std::max<size_t>(bytes, 8)) != hipSuccess) bad = true;
+        return d;
+    };
+    CompArgs& A = c->A;
+    const size_t D = sizeof(double);
+    A.n = n;
+    A.M = (const int*)up(M, n * sizeof(int)); A.N = (const int*)up(N, n * sizeof(int));
+    A.e_off = (const int*)up(eo.data(), (n + 1) * sizeof(int)); A.n_off = (const int*)up(no.data(), (n + 1) * sizeof(int));
+    A.pn_off = (const long long*)up(pno.data(), (n + 1) * sizeof(long long)); A.nn_off = (const long long*)up(nno.data(), (n + 1) * sizeof(long long));
+    A.g_off = (const long long*)up(go.data(), (n + 1) * sizeof(long long)); A.g2_off = (const long long*)up(g2o.data(), (n + 1) * sizeof(long long));
+    A.pose = (double*)up(pose, c->sumM * 7 * D); A.sb = (double*)up(sb, c->sumM * 9 * D);
+    A.pose_lin = (const double*)up(pose_lin, c->sumM * 7 * D); A.sb_lin = (const double*)up(sb_lin, c->sumM * 9 * D);
+    A.Hpp = (const double*)up(Hpp, c->sumM * 225 * D); A.HpN = (const double*)up(HpN, pno[n] * D); A.rhs_p = (const double*)up(rhs_p, c->sumM * 15 * D);
+    A.HNN = (const double*)up(HNN, nno[n] * D); A.rhsN = (const double*)up(rhsN, c->sumN * D);
+    A.pre = (const double*)up(pre, (size_t)(c->sumM + n) * SWF_PRE_DOUBLES * D);
+    for (int k = 0; k < 3; k++) { A.pbg[k] = pbg[k]; A.gw[k] = gw[k]; }
+    A.hmn_inv = (double*)up(nullptr, c->sumM * 225 * D); A.hmn_2 = (double*)up(nullptr, c->sumM * 225 * D); A.hmn_0 = (double*)up(nullptr, c->sumM * 225 * D);
+    A.hmn_N = (double*)up(nullptr, pno[n] * D); A.rhsmn = (double*)up(nullptr, c->sumM * 15 * D);
+    A.Hd = (double*)up(nullptr, c->sumG2 * D); A.rd = (double*)up(nullptr, c->sumG * D); A.Ld = (double*)up(nullptr, c->sumG2 * D); A.r0 = (double*)up(nullptr, c->sumG * D);
+    A.old = (double*)up(nullptr, (size_t)n * 32 * D); A.N_old = (double*)up(nullptr, c->sumN * D);
+    A.history = (int*)up(nullptr, n * sizeof(int)); A.status = (int*)up(nullptr, n * sizeof(int));
+    A.outer = (const double*)up(nullptr, (size_t)n * 32 * D); A.Nv = (const double*)up(nullptr, c->sumN * D);
+    A.res_out = (double*)up(nullptr, c->sumG * D); A.jac_out = (double*)up(nullptr, c->sumG2 * D);
+    if (bad) return fail(SWF_E_NODEVICE, "swf_composite_create: device allocation / upload failed");
+    *out = c.release();
+    return SWF_OK;
+}
+
+extern "C" int swf_composite_evaluate(swf_composite* c, const double* outer, const double* Nv, int32_t want_jac,
+                                      double* residual, double* jac, double* Hd, double* rd, int32_t* status) {
+    if (!c || !outer || (!Nv && c->sumN) || !residual) return fail(SWF_E_INVALID, "swf_composite_evaluate: null argument");
+    hipStream_t st = c->stream;
+    HIPCHK(hipMemcpyAsync((void*)c->A.outer, outer, (size_t)c->n * 32 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (c->sumN) HIPCHK(hipMemcpyAsync((void*)c->A.Nv, Nv, c->sumN * sizeof(double), hipMemcpyHostToDevice, st));
+    CompArgs A = c->A;
+    A.want_jac = want_jac ? 1 : 0;
+    hipLaunchKernelGGL(k_composite, dim3(c->n), dim3(256), 0, st, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(residual, c->A.res_out, c->sumG * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (jac && want_jac) HIPCHK(hipMemcpyAsync(jac, c->A.jac_out, c->sumG2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (Hd) HIPCHK(hipMemcpyAsync(Hd, c->A.Hd, c->sumG2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (rd) HIPCHK(hipMemcpyAsync(rd, c->A.rd, c->sumG * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (status) HIPCHK(hipMemcpyAsync(status, c->A.status, c->n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return SWF_OK;
+}
+
+extern "C" int swf_composite_hidden(swf_composite* c, double* pose, double* sb) {
+    if (!c || !pose || !sb) return fail(SWF_E_INVALID, "swf_composite_hidden: null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(pose, c->A.pose, c->sumM * 7 * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sb, c->A.sb, c->sumM * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    return SWF_OK;
+}

@@ -1,0 +1,300 @@
+// swf_kernels4.h — the composite IMU-GNSS factor (8f rank 2) as a batched device operator.
+//
+// IMUGNSSBase (R/factor/gnss_imu_factor.cpp) hides the GNSS-epoch states between two visual frames: at every Jacobian
+// evaluation it (i) back-substitutes the hidden epochs from the outer increment (UpdateHiddenState :601-632), (ii) rebuilds
+// the block-tridiagonal normal equations epoch by epoch — IMUFactor::Evaluate2 (R/factor/imu_factor.cpp:103-195), the epoch's
+// linearised GNSS prior (:775-778) — eliminating each epoch as it goes (MargPose1 :403-433, MoveHessianData :435-452), and
+// (iii) turns the remaining (30+N)^2 system over [pose_i sb_i | pose_j sb_j | N ambiguities] into a residual / Jacobian pair
+// (UpdateSchurComponent :454-488); cost-only evaluations use the linear model r = r_lin - J INC (:490-497).
+//
+// Here: one 256-thread workgroup per composite factor, the ten Hessian blocks of the running elimination in LDS, the epochs
+// sequential (they are a chain), everything inside an epoch spread over the threads; composite factors of all windows in
+// one launch.  The square root of the (30+N)^2 remainder is its Cholesky factor (J = L^T, r = L^-1 rhs): J^T J and J^T r —
+// all a Gauss-Newton solver consumes — are those of the reference's eigen square root whenever the remainder is positive
+// definite (certified by the factorisation; a failure is reported per factor), at a fraction of a symmetric eigensolve.
+#pragma once
+#include "swf_kernels.h"
+
+#define CO_MAXN 24                         // ambiguities per composite factor
+#define CO_MAXG (30 + CO_MAXN)
+
+struct CompArgs {
+    int n;
+    const int* M; const int* N;                        // [n]
+    const int* e_off; const int* n_off;                // [n+1] prefix sums of M, N
+    const long long* pn_off; const long long* nn_off;  // [n+1] prefix sums of 15 M N, N N
+    const long long* g_off; const long long* g2_off;   // [n+1] prefix sums of G, G G
+    double* pose; double* sb;                          // hidden epochs [sum M][7], [sum M][9]
+    const double* pose_lin; const double* sb_lin;
+    const double* Hpp; const double* HpN; const double* rhs_p; const double* HNN; const double* rhsN;
+    const double* pre;                                 // [sum M + n][SWF_PRE_DOUBLES]; factor f owns records e_off[f] + f ...
+    double pbg[3], gw[3];
+    double* hmn_inv; double* hmn_2; double* hmn_0; double* hmn_N; double* rhsmn;      // saved at each elimination
+    double* Hd; double* rd; double* Ld; double* r0;                                      // dense remainder, its factor, L^-1 rhs
+    double* old; double* N_old;                        // [n][32] outer states of the last linearisation, [sum N]
+    int* history; int* status;
+    const double* outer; const double* Nv;             // this call: [n][32] = pose_i sb_i pose_j sb_j, [sum N]
+    int want_jac;
+    double* res_out; double* jac_out;                  // [sum G], [sum G G] (row-major, upper triangular = L^T)
+};
+
+// x (-) x0 = sgn [p - p0, +-2 vec(q0^-1 q), sb - sb0]   (GetInc :654-670, UpdateDeltaValues :560-598 with sgn = -1)
+__device__ __forceinline__ void co_inc15(const double* P, const double* Bv, const double* P0, const double* B0, double sgn, double* dx) {
+    double q0i[4], dq[4];
+    for (int k = 0; k < 3; k++) dx[k] = sgn * (P[k] - P0[k]);
+    qinv(P0 + 3, q0i); qmul(q0i, P + 3, dq);
+    double s2 = (dq[3] >= 0) ? 2.0 : -2.0;
+    for (int k = 0; k < 3; k++) dx[3 + k] = sgn * s2 * dq[k];
+    for (int k = 0; k < 9; k++) dx[6 + k] = sgn * (Bv[k] - B0[k]);
+}
+
+__global__ void __launch_bounds__(256) k_composite(CompArgs A) {
+    const int f = blockIdx.x, t = threadIdx.x;
+    if (f >= A.n) return;
+    const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
+    const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
+    // running elimination: blocks (Pose1, Pose2, N, Pose0) x (>=), reference enum HessianOrder
+    __shared__ double H00[225], H01[225], H0N[15 * CO_MAXN], H03[225], H11[225], H1N[15 * CO_MAXN], H13[225],
+                      HNN[CO_MAXN * CO_MAXN], HN3[15 * CO_MAXN], H33[225];
+    __shared__ double r0b[15], r1b[15], rNb[CO_MAXN], r3b[15];
+    __shared__ double dl2[15], dlN[CO_MAXN], dl0[15];                      // delta5[Pose2], [N], [Pose0]
+    __shared__ double sU[450], sJ[450], sRaw[16], sRes[16], sSI[225], sPr[SWF_PRE_SQRTINFO + 6], sSt[32];
+    __shared__ double sAinv[225], sL[225], T2[225], TN[15 * CO_MAXN], T0[225];
+    __shared__ double sD[CO_MAXG * CO_MAXG], sz[CO_MAXG];
+    __shared__ double sOut[32], sNv[CO_MAXN], sOld[32], sNold[CO_MAXN], sDx[16], sRm[16];
+    __shared__ int sBad;
+    const int hist = A.history[f];
+    if (t < 32) { sOut[t] = A.outer[(size_t)f * 32 + t]; sOld[t] = hist ? A.old[(size_t)f * 32 + t] : A.outer[(size_t)f * 32 + t]; }
+    if (t < N) { sNv[t] = A.Nv[n0 + t]; sNold[t] = hist ? A.N_old[n0 + t] : A.Nv[n0 + t]; }
+    if (t == 0) sBad = 0;
+    __syncthreads();
+    const double* Pi = sOut; const double* Bi = sOut + 7; const double* Pj = sOut + 16; const double* Bj = sOut + 23;
+    // UpdateDeltaValues: increments old (-) new
+    if (t == 0) co_inc15(Pj, Bj, sOld + 16, sOld + 23, -1.0, dl2);
+    if (t == 64) co_inc15(Pi, Bi, sOld, sOld + 7, -1.0, dl0);
+    if (t >= 128 && t - 128 < N) dlN[t - 128] = sNold[t - 128] - sNv[t - 128];
+    __syncthreads();
+    const int update = A.want_jac != 0;
+    if (hist && !update) {
+        // UpdateJacobResidual, cost-only: r = r_lin - J INC with J = L^T, INC = [dl0 | dl2 | dlN]
+        const double* Ld = A.Ld + g20;
+        for (int k = t; k < G; k += 256) {
+            double s = 0;
+            for (int a = k; a < G; a++) { double inc = a < 15 ? dl0[a] : a < 30 ? dl2[a - 15] : dlN[a - 30]; s += Ld[(size_t)a * G + k] * inc; }
+            A.res_out[g0 + k] = A.r0[g0 + k] - s;
+        }
+        return;
+    }
+    if (hist && update) {
+        // UpdateHiddenState: newest epoch first; delta5[Pose2] becomes the epoch's own increment for its older neighbour
+        for (int i = M - 1; i >= 0; i--) {
+            const double* h2 = A.hmn_2 + (size_t)(e0 + i) * 225; const double* h0 = A.hmn_0 + (size_t)(e0 + i) * 225;
+            const double* hN = A.hmn_N + pn0 + (size_t)i * 15 * N; const double* hi = A.hmn_inv + (size_t)(e0 + i) * 225;
+            if (t < 15) {
+                double s = A.rhsmn[(size_t)(e0 + i) * 15 + t];
+                for (int k = 0; k < 15; k++) s -= h2[t * 15 + k] * dl2[k];
+                for (int k = 0; k < N; k++) s -= hN[t * N + k] * dlN[k];
+                for (int k = 0; k < 15; k++) s -= h0[t * 15 + k] * dl0[k];
+                sRm[t] = s;
+            }
+            __syncthreads();
+            if (t < 15) { double s = 0; for (int k = 0; k < 15; k++) s += hi[t * 15 + k] * sRm[k]; sDx[t] = s; }
+            __syncthreads();
+            if (t < 15) dl2[t] = sDx[t];
+            double* P = A.pose + (size_t)(e0 + i) * 7; double* Bv = A.sb + (size_t)(e0 + i) * 9;
+            if (t == 32) {
+                for (int k = 0; k < 3; k++) P[k] -= sDx[k];
+                double q[4], dq[4] = { -sDx[3] / 2, -sDx[4] / 2, -sDx[5] / 2, 1.0 };
+                qmul(P + 3, dq, q);
+                double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                for (int k = 0; k < 4; k++) P[3 + k] = q[k] / nq;
+            }
+            if (t >= 64 && t < 73) Bv[t - 64] -= sDx[6 + t - 64];
+            __syncthreads();
+        }
+        __threadfence_block();
+    }
+    // ---- re-elimination at the current outer / hidden states
+    for (int e = t; e < 225; e += 256) { H00[e] = 0; H01[e] = 0; H03[e] = 0; H11[e] = 0; H13[e] = 0; H33[e] = 0; }
+    for (int e = t; e < 15 * N; e += 256) { H0N[e] = 0; H1N[e] = 0; HN3[e] = 0; }
+    for (int e = t; e < N * N; e += 256) HNN[e] = A.HNN[nn0 + e];
+    if (t < 15) { r0b[t] = 0; r1b[t] = 0; r3b[t] = 0; }
+    __syncthreads();
+    if (t < N) { double s = A.rhsN[n0 + t]; for (int k = 0; k < N; k++) s += HNN[t * N + k] * sNv[k]; rNb[t] = s; }       // UpdateRhsN
+    // IMU factor k of the chain links state k-1 -> k (k = 0: frame_i -> e_0, k = M: e_M-1 -> frame_j)
+    for (int k = 0; k <= M; k++) {
+        const double* pre = A.pre + (size_t)(e0 + f + k) * SWF_PRE_DOUBLES;
+        // stage the two states, the record head, sqrt_info; zero the sparse Jacobian scratch
+        if (t < 32) {
+            int sl = t < 7 ? 0 : t < 16 ? 1 : t < 23 ? 2 : 3, o = t < 7 ? t : t < 16 ? t - 7 : t < 23 ? t - 16 : t - 23;
+            bool first = sl < 2;                        // state k-1 (frame_i for k = 0), else state k (frame_j for k = M)
+            int hidx = first ? k - 1 : k;
+            double v;
+            if (hidx < 0) v = (sl == 0) ? Pi[o] : Bi[o];
+            else if (hidx >= M) v = (sl == 2) ? Pj[o] : Bj[o];
+            else v = (sl & 1) ? A.sb[(size_t)(e0 + hidx) * 9 + o] : A.pose[(size_t)(e0 + hidx) * 7 + o];
+            sSt[t] = v;
+        }
+        for (int e = t; e < SWF_PRE_SQRTINFO; e += 256) sPr[e] = pre[e];
+        if (t < 3) { sPr[SWF_PRE_SQRTINFO + t] = A.pbg[t]; sPr[SWF_PRE_SQRTINFO + 3 + t] = A.gw[t]; }
+        for (int e = t; e < 225; e += 256) sSI[e] = pre[SWF_PRE_SQRTINFO + e];
+        for (int e = t; e < 450; e += 256) sU[e] = 0.0;
+        __syncthreads();
+        if ((t & 63) == 0) imu_unwhitened(sSt, sSt + 7, sSt + 16, sSt + 23, sPr, sPr + SWF_PRE_SQRTINFO, sPr + SWF_PRE_SQRTINFO + 3, sRaw, sU, true, t >> 6);
+        __syncthreads();
+        if (t < 15) { double s = 0; for (int q = 0; q < 15; q++) s += sSI[t * 15 + q] * sRaw[q]; sRes[t] = s; }
+        for (int e = t; e < 450; e += 256) {
+            int row = e / 30, col = e - row * 30;
+            double a = 0;
+            for (int q = row; q < 15; q++) a += sSI[row * 15 + q] * sU[q * 30 + col];       // sqrt_info is upper triangular
+            sJ[e] = a;
+        }
+        __syncthreads();
+        // JacobianResidualUpdateHessianRhs: Ja = columns 0..14 (older state), Jb = columns 15..29 (newer state)
+        //   k = 0 : blocks (Pose0, Pose1):  H33 += Ja^T Ja, H03 += Jb^T Ja, H00 += Jb^T Jb
+        //   k > 0 : blocks (Pose1, Pose2):  H00 += Ja^T Ja, H01 += Ja^T Jb, H11 += Jb^T Jb
+        {
+            double* Haa = k == 0 ? H33 : H00; double* Hx = k == 0 ? H03 : H01; double* Hbb = k == 0 ? H00 : H11;
+            double* ra = k == 0 ? r3b : r0b; double* rb = k == 0 ? r0b : r1b;
+            for (int e = t; e < 675; e += 256) {
+                int blk = e / 225, ee = e - blk * 225, i = ee / 15, j = ee - i * 15;
+                double s = 0;
+                if (blk == 0) { for (int q = 0; q < 15; q++) s += sJ[q * 30 + i] * sJ[q * 30 + j]; Haa[ee] += s; }
+                else if (blk == 2) { for (int q = 0; q < 15; q++) s += sJ[q * 30 + 15 + i] * sJ[q * 30 + 15 + j]; Hbb[ee] += s; }
+                else if (k == 0) { for (int q = 0; q < 15; q++) s += sJ[q * 30 + 15 + i] * sJ[q * 30 + j]; Hx[ee] += s; }        // Jb^T Ja
+                else { for (int q = 0; q < 15; q++) s += sJ[q * 30 + i] * sJ[q * 30 + 15 + j]; Hx[ee] += s; }                   // Ja^T Jb
+            }
+            if (t < 30) {
+                int j = t < 15 ? t : t - 15; double s = 0;
+                for (int q = 0; q < 15; q++) s += sJ[q * 30 + t] * sRes[q];
+                if (t < 15) ra[j] += s; else rb[j] += s;
+            }
+        }
+        __syncthreads();
+        if (k == 0) continue;
+        // ---- epoch i = k - 1 is complete: its GNSS prior, then eliminate it
+        const int i = k - 1;
+        if (t == 0) co_inc15(A.pose + (size_t)(e0 + i) * 7, A.sb + (size_t)(e0 + i) * 9, A.pose_lin + (size_t)(e0 + i) * 7, A.sb_lin + (size_t)(e0 + i) * 9, 1.0, sDx);
+        __syncthreads();
+        const double* Hpp = A.Hpp + (size_t)(e0 + i) * 225; const double* HpN = A.HpN + pn0 + (size_t)i * 15 * N;
+        if (t < 15) {                                   // UpdateRhsPose + RhsUpdateRhs
+            double s = A.rhs_p[(size_t)(e0 + i) * 15 + t];
+            for (int q = 0; q < 15; q++) s += Hpp[t * 15 + q] * sDx[q];
+            for (int q = 0; q < N; q++) s += HpN[t * N + q] * sNv[q];
+            r0b[t] += s;
+        }
+        if (t >= 64 && t - 64 < N) { int a = t - 64; double s = 0; for (int q = 0; q < 15; q++) s += HpN[q * N + a] * sDx[q]; rNb[a] += s; }
+        for (int e = t; e < 225; e += 256) H00[e] += Hpp[e];
+        for (int e = t; e < 15 * N; e += 256) H0N[e] += HpN[e];
+        __syncthreads();
+        // MargPose1: Ainv = (H00)^-1 by Cholesky (InvertPSDMatrix<15>, assume_full_rank)
+        for (int e = t; e < 225; e += 256) { int a = e / 15, b = e - a * 15; sL[e] = (b <= a) ? H00[b * 15 + a] : 0.0; }     // lower from the upper triangle
+        __syncthreads();
+        for (int j = 0; j < 15; j++) {
+            double d = sL[j * 15 + j];
+            if (!(d > 0.0)) { if (t == 0) sBad = 1; d = 1.0; }
+            double sd = sqrt(d);
+            __syncthreads();
+            if (t < 15 && t >= j) sL[t * 15 + j] = (t == j) ? sd : sL[t * 15 + j] / sd;
+            __syncthreads();
+            if (t < 225) { int a = t / 15, b = t - a * 15; if (b > j && a >= b) sL[a * 15 + b] -= sL[a * 15 + j] * sL[b * 15 + j]; }
+            __syncthreads();
+        }
+        if (t < 15) {
+            double z[15];
+            for (int a = 0; a < 15; a++) { double s = (a == t) ? 1.0 : 0.0; for (int q = 0; q < a; q++) s -= sL[a * 15 + q] * z[q]; z[a] = s / sL[a * 15 + a]; }
+            for (int a = 14; a >= 0; a--) { double s = z[a]; for (int q = a + 1; q < 15; q++) s -= sL[q * 15 + a] * z[q]; z[a] = s / sL[a * 15 + a]; }
+            for (int a = 0; a < 15; a++) sAinv[a * 15 + t] = z[a];
+        }
+        __syncthreads();
+        // T_blk = H0blk^T Ainv for blk = Pose2 (15), N, Pose0 (15)
+        for (int e = t; e < 450 + 15 * N; e += 256) {
+            const double* Hs; double* Td; int sn, ee;
+            if (e < 225) { Hs = H01; Td = T2; sn = 15; ee = e; } else if (e < 450) { Hs = H03; Td = T0; sn = 15; ee = e - 225; } else { Hs = H0N; Td = TN; sn = N; ee = e - 450; }
+            int a = ee / 15, b = ee - a * 15;
+            double s = 0;
+            for (int q = 0; q < 15; q++) s += Hs[q * sn + a] * sAinv[q * 15 + b];
+            Td[a * 15 + b] = s;
+        }
+        __syncthreads();
+        // rhs_blk -= T_blk rhs0 ;  H[blk][j >= blk] -= T_blk H0j   (blocks Pose2, N, Pose0 in that order)
+        if (t < 15) { double s = 0; for (int q = 0; q < 15; q++) s += T2[t * 15 + q] * r0b[q]; r1b[t] -= s; }
+        else if (t >= 32 && t < 47) { int a = t - 32; double s = 0; for (int q = 0; q < 15; q++) s += T0[a * 15 + q] * r0b[q]; r3b[a] -= s; }
+        else if (t >= 64 && t - 64 < N) { int a = t - 64; double s = 0; for (int q = 0; q < 15; q++) s += TN[a * 15 + q] * r0b[q]; rNb[a] -= s; }
+        {
+            const int nA = 225, nB = 15 * N, nC = 225, nD = N * N, nE = 15 * N, nF = 225;     // (2,2) (2,N) (2,0) (N,N) (N,0) (0,0)
+            for (int e = t; e < nA + nB + nC + nD + nE + nF; e += 256) {
+                const double* Tm; const double* Hs; double* Hd_; int sv, ee;
+                if (e < nA) { Tm = T2; Hs = H01; Hd_ = H11; sv = 15; ee = e; }
+                else if (e < nA + nB) { Tm = T2; Hs = H0N; Hd_ = H1N; sv = N; ee = e - nA; }
+                else if (e < nA + nB + nC) { Tm = T2; Hs = H03; Hd_ = H13; sv = 15; ee = e - nA - nB; }
+                else if (e < nA + nB + nC + nD) { Tm = TN; Hs = H0N; Hd_ = HNN; sv = N; ee = e - nA - nB - nC; }
+                else if (e < nA + nB + nC + nD + nE) { Tm = TN; Hs = H03; Hd_ = HN3; sv = 15; ee = e - nA - nB - nC - nD; }
+                else { Tm = T0; Hs = H03; Hd_ = H33; sv = 15; ee = e - nA - nB - nC - nD - nE; }
+                int a = ee / sv, b = ee - a * sv;
+                double s = 0;
+                for (int q = 0; q < 15; q++) s += Tm[a * 15 + q] * Hs[q * sv + b];
+                Hd_[a * sv + b] -= s;
+            }
+        }
+        __syncthreads();
+        // MoveHessianData: save what UpdateHiddenState needs, shift Pose2 -> Pose1
+        {
+            double* s_inv = A.hmn_inv + (size_t)(e0 + i) * 225; double* s_2 = A.hmn_2 + (size_t)(e0 + i) * 225; double* s_0 = A.hmn_0 + (size_t)(e0 + i) * 225;
+            double* s_N = A.hmn_N + pn0 + (size_t)i * 15 * N;
+            for (int e = t; e < 225; e += 256) { s_inv[e] = sAinv[e]; s_2[e] = H01[e]; s_0[e] = H03[e]; }
+            for (int e = t; e < 15 * N; e += 256) s_N[e] = H0N[e];
+            if (t < 15) A.rhsmn[(size_t)(e0 + i) * 15 + t] = r0b[t];
+        }
+        __syncthreads();
+        for (int e = t; e < 225; e += 256) { H00[e] = H11[e]; H11[e] = 0; H03[e] = H13[e]; H13[e] = 0; H01[e] = 0; }
+        for (int e = t; e < 15 * N; e += 256) { H0N[e] = H1N[e]; H1N[e] = 0; }
+        if (t < 15) { r0b[t] = r1b[t]; r1b[t] = 0; }
+        __syncthreads();
+    }
+    // UpdateSchurComponent: dense remainder in the order [Pose0 | Pose1 (= frame j) | N]
+    for (int e = t; e < G * G; e += 256) {
+        int a = e / G, b = e - a * G;
+        int lo = a < b ? a : b, hi = a < b ? b : a;     // symmetric: take the upper entry (selfadjointView<Upper>)
+        int bl = lo < 15 ? 0 : lo < 30 ? 1 : 2, bh = hi < 15 ? 0 : hi < 30 ? 1 : 2;
+        int il = lo - (bl == 0 ? 0 : bl == 1 ? 15 : 30), ih = hi - (bh == 0 ? 0 : bh == 1 ? 15 : 30);
+        double v;
+        if (bl == 0 && bh == 0) v = H33[il * 15 + ih];
+        else if (bl == 0 && bh == 1) v = H03[ih * 15 + il];          // (Pose0, Pose1) = H[Pose1, Pose0]^T
+        else if (bl == 0 && bh == 2) v = HN3[ih * 15 + il];          // (Pose0, N) = H[N, Pose0]^T
+        else if (bl == 1 && bh == 1) v = H00[il * 15 + ih];
+        else if (bl == 1 && bh == 2) v = H0N[il * N + ih];
+        else v = HNN[il * N + ih];
+        sD[a * G + b] = v;
+        A.Hd[g20 + e] = v;
+    }
+    if (t < G) { double v = t < 15 ? r3b[t] : t < 30 ? r0b[t - 15] : rNb[t - 30]; sz[t] = v; A.rd[g0 + t] = v; }
+    __syncthreads();
+    // Cholesky of the remainder (lower, in place), then r0 = L^-1 rhs
+    for (int j = 0; j < G; j++) {
+        double d = sD[j * G + j];
+        if (!(d > 0.0)) { if (t == 0) sBad = 1; d = 1.0; }
+        double sd = sqrt(d);
+        __syncthreads();
+        for (int a = j + t; a < G; a += 256) sD[a * G + j] = (a == j) ? sd : sD[a * G + j] / sd;
+        __syncthreads();
+        for (int e = t; e < G * G; e += 256) { int a = e / G, b = e - a * G; if (b > j && a >= b) sD[e] -= sD[a * G + j] * sD[b * G + j]; }
+        __syncthreads();
+    }
+    for (int j = 0; j < G; j++) {
+        if (t == 0) sz[j] = sz[j] / sD[j * G + j];
+        __syncthreads();
+        for (int a = j + 1 + t; a < G; a += 256) sz[a] -= sD[a * G + j] * sz[j];
+        __syncthreads();
+    }
+    for (int e = t; e < G * G; e += 256) {
+        int a = e / G, b = e - a * G;
+        double l = (b <= a) ? sD[e] : 0.0;
+        A.Ld[g20 + e] = l;
+        if (A.jac_out) A.jac_out[g20 + (size_t)b * G + a] = l;        // J = L^T
+    }
+    if (t < G) { A.r0[g0 + t] = sz[t]; A.res_out[g0 + t] = sz[t]; }
+    if (t < 32) A.old[(size_t)f * 32 + t] = sOut[t];
+    if (t < N) A.N_old[n0 + t] = sNv[t];
+    if (t == 0) { A.history[f] = 1; A.status[f] = sBad ? -1 : 0; }
+}

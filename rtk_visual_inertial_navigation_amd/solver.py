@@ -46,6 +46,7 @@ EXPORTED = [
     "swf_add_spp_pseudorange", "swf_add_spp_carrier_phase", "swf_add_fixed_integer",
     "swf_preintegrate_batch", "swf_triangulate_batch",
     "swf_batch_tail_covariance", "swf_batch_get_tail_covariance", "swf_problem_tail_covariance",
+    "swf_composite_create", "swf_composite_evaluate", "swf_composite_hidden", "swf_composite_destroy",
 ]
 
 
@@ -351,6 +352,62 @@ class Problem:
         n = n.value
         return (np.ctypeslib.as_array(S, (n, n)).copy(), np.ctypeslib.as_array(r, (n,)).copy(),
                 np.ctypeslib.as_array(L, (n, n)).copy())
+
+
+class CompositeBatch:
+    """n composite IMU-GNSS factors (IMUGNSSBase, R/factor/gnss_imu_factor.cpp) evaluated together on the device.
+    `factors`: list of dicts with pose [M][7], sb [M][9], pose_lin, sb_lin, Hpp [M][15][15], HpN [M][15][N], rhs_p [M][15],
+    HNN [N][N], rhsN [N], pre [M+1][PRE_DOUBLES]; pbg, gw shared."""
+
+    def __init__(self, factors, pbg, gw):
+        cat = lambda k: np.ascontiguousarray(np.concatenate([np.asarray(f[k], np.float64).ravel() for f in factors]) if factors else np.zeros(0))
+        self.M = np.array([np.asarray(f["pose"]).reshape(-1, 7).shape[0] for f in factors], np.int32)
+        self.N = np.array([np.asarray(f["rhsN"]).size for f in factors], np.int32)
+        self.n = len(factors)
+        arrs = [cat(k) for k in ("pose", "sb", "pose_lin", "sb_lin", "Hpp", "HpN", "rhs_p", "HNN", "rhsN", "pre")]
+        arrs = [a if a.size else np.zeros(1) for a in arrs]
+        pb, g = np.ascontiguousarray(pbg, np.float64), np.ascontiguousarray(gw, np.float64)
+        self._h = C.c_void_p()
+        pi = C.POINTER(C.c_int32)
+        _chk(lib().swf_composite_create(C.c_int32(self.n), self.M.ctypes.data_as(pi), self.N.ctypes.data_as(pi),
+                                        *[a.ctypes.data_as(_pd) for a in arrs], pb.ctypes.data_as(_pd), g.ctypes.data_as(_pd), None,
+                                        C.byref(self._h)), "swf_composite_create")
+        self.G = 30 + self.N
+        self.g_off = np.concatenate([[0], np.cumsum(self.G)]); self.g2_off = np.concatenate([[0], np.cumsum(self.G.astype(np.int64) ** 2)])
+
+    def evaluate(self, outer, Nv, want_jac):
+        """outer [n][32] (pose_i sb_i pose_j sb_j), Nv: list of per-factor ambiguity vectors.  Returns per-factor lists
+        (residual, J, H, rhs, status) — J is None for a cost-only call."""
+        o = np.ascontiguousarray(np.asarray(outer, np.float64).reshape(self.n, 32))
+        nv = np.ascontiguousarray(np.concatenate([np.asarray(v, np.float64).ravel() for v in Nv]) if int(self.N.sum()) else np.zeros(1))
+        res = np.zeros(int(self.g_off[-1])); jac = np.zeros(int(self.g2_off[-1])); Hd = np.zeros_like(jac); rd = np.zeros_like(res)
+        st = np.zeros(self.n, np.int32)
+        _chk(lib().swf_composite_evaluate(self._h, o.ctypes.data_as(_pd), nv.ctypes.data_as(_pd), C.c_int32(1 if want_jac else 0),
+                                          res.ctypes.data_as(_pd), jac.ctypes.data_as(_pd), Hd.ctypes.data_as(_pd), rd.ctypes.data_as(_pd),
+                                          st.ctypes.data_as(C.POINTER(C.c_int32))), "swf_composite_evaluate")
+        out = []
+        for f in range(self.n):
+            G = int(self.G[f]); a, b = int(self.g_off[f]), int(self.g2_off[f])
+            out.append(dict(r=res[a:a + G].copy(), J=jac[b:b + G * G].reshape(G, G).copy() if want_jac else None,
+                            H=Hd[b:b + G * G].reshape(G, G).copy(), rhs=rd[a:a + G].copy(), status=int(st[f])))
+        return out
+
+    def hidden(self):
+        m = int(self.M.sum())
+        pose, sb = np.zeros((m, 7)), np.zeros((m, 9))
+        _chk(lib().swf_composite_hidden(self._h, pose.ctypes.data_as(_pd), sb.ctypes.data_as(_pd)), "swf_composite_hidden")
+        e = np.concatenate([[0], np.cumsum(self.M)])
+        return [(pose[e[f]:e[f + 1]], sb[e[f]:e[f + 1]]) for f in range(self.n)]
+
+    def close(self):
+        if self._h:
+            lib().swf_composite_destroy(self._h); self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def preintegrate_batch(samples, biases, noise):
