@@ -125,6 +125,25 @@ typedef struct swf_flat_window {
     const int32_t* fix_idx;          /* [n_fix][2] scalar a, scalar b */
     const double*  fix_dat;          /* [n_fix][SWF_FIX_DOUBLES] */
 
+    /* ---- composite IMU-GNSS factors, IMUGNSSFactor over IMUGNSSBase (R/factor/gnss_imu_factor.cpp:802-820, :678-799):
+     *      factor f hides comp_M[f] GNSS epochs between two frames behind comp_N[f] ambiguities; residual dim 30 + N.
+     *      Arrays are concatenated over the factors (layouts as in swf_composite_create, swf_solver.h).  The hidden epochs are
+     *      caller-owned parameter memory like the pools: read at solve start, written back at solve end (the reference
+     *      updates gnss_poses / gnss_speed_bias in place, UpdateHiddenState :601-632). */
+    int32_t n_comp;
+    const int32_t* comp_M;           /* [n_comp] */
+    const int32_t* comp_N;           /* [n_comp] */
+    const int32_t* comp_idx;         /* per factor: pose_i, sb_i, pose_j, sb_j (pool indices), then its N scalar pool indices */
+    double* comp_pose;               /* [sum M][7] */
+    double* comp_sb;                 /* [sum M][9] */
+    const double* comp_pose_lin; const double* comp_sb_lin;
+    const double* comp_Hpp;          /* [sum M][225] */
+    const double* comp_HpN;          /* [sum 15 M N] */
+    const double* comp_rhs_p;        /* [sum M][15] */
+    const double* comp_HNN;          /* [sum N N] */
+    const double* comp_rhsN;         /* [sum N] */
+    const double* comp_pre;          /* [sum M + n_comp][SWF_PRE_DOUBLES] */
+
     /* ---- linearised priors, MarginalizationFactor (R/factor/marginalization_factor.cpp:410-446):
      *      r = r0 + J*dx, dx per kept block = x-x0, or [p-p0 ; +-2 vec(q0^-1 q)] for poses.
      *      Records are concatenated; prior k owns prior_nblk[k] entries of prior_blk,

@@ -699,7 +699,17 @@ void oracle_preintegrate(const double* samples, int n, const double* ba, const d
 }
 
 /* ------------------------------------------------------------------ solver */
-enum { F_PROJ = 0, F_IMU, F_CP, F_PR, F_DOP, F_SP, F_PRIOR, F_SPR, F_SCP, F_FIX };
+/* composite IMU-GNSS factor (defined at the end of this file) */
+typedef struct oracle_composite oracle_composite;
+oracle_composite* oracle_composite_create(int M, int N, const double* pose, const double* sb, const double* pose_lin, const double* sb_lin,
+                                          const double* Hpp, const double* HpN, const double* rhs_p, const double* HNN, const double* rhsN,
+                                          const double* pre, const double* pbg, const double* gw);
+void oracle_composite_destroy(oracle_composite* c);
+void oracle_composite_hidden(const oracle_composite* c, double* pose, double* sb);
+int oracle_composite_evaluate(oracle_composite* c, const double* Pi, const double* Bi, const double* Pj, const double* Bj, const double* Nv,
+                              int want_jac, double* residual, double* jac);
+
+enum { F_PROJ = 0, F_IMU, F_CP, F_PR, F_DOP, F_SP, F_PRIOR, F_SPR, F_SCP, F_FIX, F_COMP };
 
 typedef struct {
     int type, idx, nres, nblk;
@@ -725,6 +735,8 @@ typedef struct {
     int* blk2e;                              /* global block -> e index or -1 */
     /* prior bookkeeping */
     int* prior_blk_off; int* prior_J_off; int* prior_r_off; int* prior_x0_off;
+    /* composite IMU-GNSS factors: stateful handles, offsets into the concatenated window arrays */
+    oracle_composite** comp; int* comp_e_off; int* comp_idx_off;
     /* work buffers */
     double* x; double* xc;                   /* current / candidate ambient state */
     double* res; double* jac;
@@ -781,7 +793,7 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
     c->n_loc = lo; c->n_e = ne; c->n_red = lo - ne; c->n_eblk = neb;
 
     /* factors */
-    int nf = w->n_proj + w->n_imu + w->n_cp + w->n_pr + w->n_dop + w->n_sp + w->n_spr + w->n_scp + w->n_fix + w->n_prior;
+    int nf = w->n_proj + w->n_imu + w->n_cp + w->n_pr + w->n_dop + w->n_sp + w->n_spr + w->n_scp + w->n_fix + w->n_prior + w->n_comp;
     c->n_fac = nf;
     c->fac = (fac_t*)calloc(nf > 0 ? nf : 1, sizeof(fac_t));
     int nslots = w->n_proj * 3 + w->n_imu * 4 + w->n_cp * 3 + w->n_pr * 2 + w->n_dop * 3 + w->n_sp + w->n_spr * 2 + w->n_scp * 3 + w->n_fix * 2;
@@ -798,6 +810,21 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
             nslots += w->prior_nblk[k];
         }
         c->prior_blk_off[w->n_prior] = bo;
+    }
+    /* composite factors: one stateful restatement of IMUGNSSBase each, on copies of the window's arrays */
+    c->comp = (oracle_composite**)calloc(w->n_comp + 1, sizeof(oracle_composite*));
+    c->comp_e_off = (int*)calloc(w->n_comp + 2, sizeof(int)); c->comp_idx_off = (int*)calloc(w->n_comp + 2, sizeof(int));
+    {
+        long long pn = 0, nn = 0; int no = 0;
+        for (int k = 0; k < w->n_comp; k++) {
+            int M = w->comp_M[k], N = w->comp_N[k], e0 = c->comp_e_off[k];
+            c->comp[k] = oracle_composite_create(M, N, w->comp_pose + (size_t)e0 * 7, w->comp_sb + (size_t)e0 * 9, w->comp_pose_lin + (size_t)e0 * 7,
+                                                 w->comp_sb_lin + (size_t)e0 * 9, w->comp_Hpp + (size_t)e0 * 225, w->comp_HpN + pn, w->comp_rhs_p + (size_t)e0 * 15,
+                                                 w->comp_HNN + nn, w->comp_rhsN + no, w->comp_pre + (size_t)(e0 + k) * SWF_PRE_DOUBLES, w->pbg, w->gw);
+            c->comp_e_off[k + 1] = e0 + M; c->comp_idx_off[k + 1] = c->comp_idx_off[k] + 4 + N;
+            pn += 15LL * M * N; nn += (long long)N * N; no += N;
+            nslots += 4 + N;
+        }
     }
     c->n_slots = nslots;
     c->fblk = (int*)malloc(sizeof(int) * (nslots + 1)); c->fjoff = (int*)malloc(sizeof(int) * (nslots + 1));
@@ -816,6 +843,13 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
     for (int k = 0; k < w->n_prior; k++) {
         ADDF(F_PRIOR, k, w->prior_dim[k], w->prior_nblk[k])
         for (int q = 0; q < w->prior_nblk[k]; q++) ADDS(w->prior_blk[c->prior_blk_off[k] + q])
+    }
+    for (int k = 0; k < w->n_comp; k++) {
+        const int* ix = w->comp_idx + c->comp_idx_off[k];
+        int N = w->comp_N[k];
+        ADDF(F_COMP, k, 30 + N, 4 + N)
+        ADDS(BID_POSE(w, ix[0])) ADDS(BID_SB(w, ix[1])) ADDS(BID_POSE(w, ix[2])) ADDS(BID_SB(w, ix[3]))
+        for (int q = 0; q < N; q++) ADDS(BID_SC(w, ix[4 + q]))
     }
 #undef ADDF
 #undef ADDS
@@ -879,6 +913,8 @@ static void ctx_free(ctx_t* c) {
     free(c->gsize); free(c->lsize); free(c->xoff); free(c->loc_off); free(c->group); free(c->blk2e); free(c->eblk);
     free(c->fac); free(c->fblk); free(c->fjoff); free(c->e_fac_off); free(c->e_fac);
     free(c->prior_blk_off); free(c->prior_J_off); free(c->prior_r_off); free(c->prior_x0_off);
+    if (c->comp) { for (int k = 0; k < c->w->n_comp; k++) oracle_composite_destroy(c->comp[k]); free(c->comp); }
+    free(c->comp_e_off); free(c->comp_idx_off);
     free(c->x); free(c->xc); free(c->res); free(c->jac); free(c->g); free(c->diag);
     free(c->S); free(c->L); free(c->Sexp); free(c->rhs); free(c->gn); free(c->grad_s); free(c->step); free(c->delta);
     free(c->einv); free(c->estrip); free(c->estrip_off); free(c->e_nbr_off); free(c->e_nbr); free(c->einv_off);
@@ -899,6 +935,8 @@ static void ctx_store_state(ctx_t* c) {
     memcpy(w->sb, x, sizeof(double) * 9 * w->n_sb); x += 9 * w->n_sb;
     memcpy(w->lm, x, sizeof(double) * 3 * w->n_lm); x += 3 * w->n_lm;
     memcpy(w->sc, x, sizeof(double) * w->n_sc);
+    for (int k = 0; k < w->n_comp; k++)          /* the hidden GNSS epochs are parameter memory too (gnss_poses / gnss_speed_bias) */
+        oracle_composite_hidden(c->comp[k], w->comp_pose + (size_t)c->comp_e_off[k] * 7, w->comp_sb + (size_t)c->comp_e_off[k] * 9);
 }
 
 /* evaluate one factor at ambient state x; Jacobians (local, corrected) into c->jac if want_jac.
@@ -928,6 +966,26 @@ static double eval_factor(ctx_t* c, const fac_t* f, const double* x, int want_ja
     case F_SPR: oracle_eval_spr(XP(0), *XP(1), w->spr_dat + f->idx * SWF_SPR_DOUBLES, w->base, r, JP(0), JP(1)); return 0.5 * r[0] * r[0];
     case F_SCP: oracle_eval_scp(XP(0), *XP(1), *XP(2), w->scp_dat + f->idx * SWF_SCP_DOUBLES, w->base, r, JP(0), JP(1), JP(2)); return 0.5 * r[0] * r[0];
     case F_FIX: oracle_eval_fix(*XP(0), *XP(1), w->fix_dat + f->idx * SWF_FIX_DOUBLES, r, JP(0), JP(1)); return 0.5 * r[0] * r[0];
+    case F_COMP: {
+        /* IMUGNSSFactor::Evaluate -> IMUGNSSBase::Evaluate; UpdateJacobResidual slices the (30+N)^2 Jacobian per block */
+        int k = f->idx, N = w->comp_N[k], G = 30 + N;
+        double Nv[64];
+        for (int q = 0; q < N; q++) Nv[q] = *XP(4 + q);
+        double* Jd = want_jac ? (double*)malloc(sizeof(double) * G * G) : NULL;
+        if (oracle_composite_evaluate(c->comp[k], XP(0), XP(1), XP(2), XP(3), Nv, want_jac, r, Jd) != 0) { free(Jd); return 1e300; }
+        double s = 0; for (int i = 0; i < G; i++) s += r[i] * r[i];
+        if (want_jac) {
+            const int col0[4] = { 0, 6, 15, 21 }, ls4[4] = { 6, 9, 6, 9 };
+            for (int q = 0; q < f->nblk; q++) {
+                double* J = JP(q);
+                if (!J) continue;
+                int c0 = q < 4 ? col0[q] : 30 + (q - 4), ls = q < 4 ? ls4[q] : 1;
+                for (int i = 0; i < G; i++) for (int j = 0; j < ls; j++) J[i * ls + j] = Jd[i * G + c0 + j];
+            }
+            free(Jd);
+        }
+        return 0.5 * s;
+    }
     case F_PRIOR: {
         int k = f->idx, n = f->nres;
         const double* Jp = w->prior_J + c->prior_J_off[k];
@@ -1511,7 +1569,7 @@ void oracle_eval_imu2(const double* pi, const double* sbi, const double* pj, con
 }
 
 enum { CO_POSE1 = 0, CO_POSE2 = 1, CO_N = 2, CO_POSE0 = 3, CO_SIZE = 4 };
-typedef struct oracle_composite {
+struct oracle_composite {
     int M, N;
     double *pose, *sb;                         /* hidden GNSS-epoch states [M][7], [M][9] (gnss_poses / gnss_speed_bias) */
     double *pose_lin, *sb_lin;                 /* linearisation points of the per-epoch GNSS priors */
@@ -1525,7 +1583,7 @@ typedef struct oracle_composite {
     double *J, *r, *INC;                       /* schur_jacobian (G x G row-major), schur_residual, INC;  G = 30 + N */
     double Pi_old[7], Bi_old[9], Pj_old[7], Bj_old[9], *N_old;
     int history;
-} oracle_composite;
+};
 
 oracle_composite* oracle_composite_create(int M, int N, const double* pose, const double* sb, const double* pose_lin, const double* sb_lin,
                                           const double* Hpp, const double* HpN, const double* rhs_p, const double* HNN, const double* rhsN,

@@ -20,7 +20,81 @@ def _small_q(rng, s):
 def make_chain(rng, M, N, dt=0.1):
     """States of frame_i, M hidden epochs, frame_j (pose [p q], sb [v ba bg]) and M + 1 pre-integration records whose IMU
     residuals are small but not zero."""
-    K = M + 2
+    pose, sb, pre, pbg, gw = _chain_states(rng, M + 2, dt)
+    pr = _gnss_priors(rng, M, N)
+    hid_pose, hid_sb = pose[1:-1].copy(), sb[1:-1].copy()
+    pose_lin, sb_lin = _lin_points(rng, hid_pose, hid_sb)
+    Nv = rng.normal(0, 3.0, N)
+    return dict(M=M, N=N, Pi=pose[0], Bi=sb[0], Pj=pose[-1], Bj=sb[-1], Nv=Nv, pose=hid_pose, sb=hid_sb, pose_lin=pose_lin, sb_lin=sb_lin,
+                pre=pre, pbg=pbg, gw=gw, **pr)
+
+
+def _lin_points(rng, hid_pose, hid_sb):
+    pose_lin, sb_lin = hid_pose.copy(), hid_sb.copy()
+    for k in range(hid_pose.shape[0]):
+        pose_lin[k] = nf.pose_plus(hid_pose[k], rng.normal(0, 0.02, 6)); sb_lin[k] = hid_sb[k] + rng.normal(0, 0.01, 9)
+    return pose_lin, sb_lin
+
+
+def _gnss_priors(rng, M, N):
+    Hpp, HpN, rhs_p = np.zeros((M, 15, 15)), np.zeros((M, 15, N)), np.zeros((M, 15))
+    HNN, rhsN = np.zeros((N, N)), np.zeros(N)
+    scale = np.concatenate([np.full(3, 30.0), np.full(3, 3.0), np.full(9, 1.0), np.full(N, 5.0)])
+    for k in range(M):
+        A = rng.normal(0, 1, (2 * (15 + N), 15 + N))
+        A = (A.T @ A / (2 * (15 + N)) + 0.05 * np.eye(15 + N)) * np.outer(scale, scale)
+        b = rng.normal(0, 1.0, 15 + N) * scale
+        Hpp[k] = A[:15, :15]; HpN[k] = A[:15, 15:]; HNN += A[15:, 15:]; rhs_p[k] = b[:15]; rhsN += b[15:]
+    return dict(Hpp=Hpp, HpN=HpN, rhs_p=rhs_p, HNN=HNN, rhsN=rhsN)
+
+
+def make_window(rng, K, M, N, dt=0.1):
+    """A sliding window whose K visual frames are linked ONLY by composite IMU-GNSS factors (M hidden GNSS epochs per gap, N
+    shared ambiguities), plus the gauge prior on frame 0 and the dummy anchor: what an RTK window of the reference looks like
+    once UpdateImuGnssFactor (R/swf/swf.cpp:713-730) has folded the GNSS epochs away.  Returns a FlatWindow."""
+    from rtk_visual_inertial_navigation_amd.flat import FlatWindow
+    T = K + (K - 1) * M
+    pose_t, sb_t, pre, pbg, gw = _chain_states(rng, T, dt)
+    vis = [k * (M + 1) for k in range(K)]
+    pose = np.stack([nf.pose_plus(pose_t[v], rng.normal(0, [0.03] * 3 + [0.005] * 3)) for v in vis])
+    sb = np.stack([sb_t[v] + rng.normal(0, [0.03] * 3 + [0.003] * 3 + [0.0003] * 3) for v in vis])
+    sc = np.concatenate([[0.0], rng.normal(0, 3.0, N)])             # dummy + ambiguities
+    comp = dict(M=[], N=[], idx=[], pose=[], sb=[], pose_lin=[], sb_lin=[], Hpp=[], HpN=[], rhs_p=[], HNN=[], rhsN=[], pre=[])
+    for g in range(K - 1):
+        h0 = vis[g] + 1
+        hp = np.stack([nf.pose_plus(pose_t[h0 + i], rng.normal(0, [0.02] * 3 + [0.004] * 3)) for i in range(M)])
+        hs = sb_t[h0:h0 + M] + rng.normal(0, 0.01, (M, 9))
+        pl, sl = _lin_points(rng, hp, hs)
+        pr = _gnss_priors(rng, M, N)
+        comp["M"].append(M); comp["N"].append(N); comp["idx"].append([g, g, g + 1, g + 1] + [1 + q for q in range(N)])
+        comp["pose"].append(hp); comp["sb"].append(hs); comp["pose_lin"].append(pl); comp["sb_lin"].append(sl)
+        for k_ in ("Hpp", "HpN", "rhs_p", "HNN", "rhsN"):
+            comp[k_].append(pr[k_])
+        comp["pre"].append(pre[vis[g]:vis[g] + M + 1])
+    n_blocks = 2 * K + 1 + N
+    bid_pose = lambda i: i; bid_sb = lambda i: K + i; bid_sc = lambda i: 2 * K + i
+    order_block = [bid_sc(0)]; order_group = [0]
+    grp = 1
+    for k in range(K):
+        for b in (bid_pose(k), bid_sb(k)):
+            order_block.append(b); order_group.append(grp); grp += 1
+    for q in range(N):
+        order_block.append(bid_sc(1 + q)); order_group.append(grp); grp += 1
+    d = np.concatenate([np.full(3, 2e2), np.full(3, 2e2), np.full(3, 1e1), np.full(3, 1e1), np.full(3, 1e2)])
+    cat = lambda key: np.concatenate([np.asarray(a, np.float64).ravel() for a in comp[key]]) if comp[key] else np.zeros(0)
+    return FlatWindow(
+        pose=pose, sb=sb, lm=np.zeros((0, 3)), sc=sc, is_const=np.zeros(n_blocks, np.uint8),
+        order_block=np.array(order_block, np.int32), order_group=np.array(order_group, np.int32), n_tail=0,
+        sp_idx=np.array([0], np.int32), sp_w=np.array([1.0]),
+        prior_nblk=np.array([2], np.int32), prior_dim=np.array([15], np.int32), prior_blk=np.array([bid_pose(0), bid_sb(0)], np.int32),
+        prior_J=np.diag(d), prior_r0=np.zeros(15), prior_x0=np.concatenate([pose[0], sb[0]]),
+        comp_M=np.array(comp["M"], np.int32), comp_N=np.array(comp["N"], np.int32), comp_idx=np.concatenate([np.array(i, np.int32) for i in comp["idx"]]),
+        comp_pose=cat("pose"), comp_sb=cat("sb"), comp_pose_lin=cat("pose_lin"), comp_sb_lin=cat("sb_lin"), comp_Hpp=cat("Hpp"), comp_HpN=cat("HpN"),
+        comp_rhs_p=cat("rhs_p"), comp_HNN=cat("HNN"), comp_rhsN=cat("rhsN"), comp_pre=cat("pre"),
+        pbg=pbg, gw=gw, base=np.zeros(3), meta=dict(K=K, M=M, N=N))
+
+
+def _chain_states(rng, K, dt=0.1):
     pose, sb = np.zeros((K, 7)), np.zeros((K, 9))
     q = _small_q(rng, 0.3); v = rng.normal(0, 1.0, 3) + np.array([3.0, 0.5, 0.0]); p = rng.normal(0, 5, 3)
     ba, bg = rng.normal(0, 0.02, 3), rng.normal(0, 0.002, 3)
@@ -49,22 +123,7 @@ def make_chain(rng, M, N, dt=0.1):
         pre[k] = rec
         r1, _ = ob.eval_imu(pose[k], sb[k], pose[k + 1], sb[k + 1], rec, pbg, gw)
         assert np.abs(r1).max() < 5.0, np.abs(r1).max()
-    # per-epoch GNSS priors
-    Hpp, HpN, rhs_p = np.zeros((M, 15, 15)), np.zeros((M, 15, N)), np.zeros((M, 15))
-    HNN, rhsN = np.zeros((N, N)), np.zeros(N)
-    scale = np.concatenate([np.full(3, 30.0), np.full(3, 3.0), np.full(9, 1.0), np.full(N, 5.0)])
-    for k in range(M):
-        A = rng.normal(0, 1, (2 * (15 + N), 15 + N))
-        A = (A.T @ A / (2 * (15 + N)) + 0.05 * np.eye(15 + N)) * np.outer(scale, scale)
-        b = rng.normal(0, 1.0, 15 + N) * scale
-        Hpp[k] = A[:15, :15]; HpN[k] = A[:15, 15:]; HNN += A[15:, 15:]; rhs_p[k] = b[:15]; rhsN += b[15:]
-    hid_pose, hid_sb = pose[1:-1].copy(), sb[1:-1].copy()
-    pose_lin, sb_lin = hid_pose.copy(), hid_sb.copy()
-    for k in range(M):
-        pose_lin[k] = nf.pose_plus(hid_pose[k], rng.normal(0, 0.02, 6)); sb_lin[k] = hid_sb[k] + rng.normal(0, 0.01, 9)
-    Nv = rng.normal(0, 3.0, N)
-    return dict(M=M, N=N, Pi=pose[0], Bi=sb[0], Pj=pose[-1], Bj=sb[-1], Nv=Nv, pose=hid_pose, sb=hid_sb, pose_lin=pose_lin, sb_lin=sb_lin,
-                Hpp=Hpp, HpN=HpN, rhs_p=rhs_p, HNN=HNN, rhsN=rhsN, pre=pre, pbg=pbg, gw=gw)
+    return pose, sb, pre, pbg, gw
 
 
 def inc15(P, B, P0, B0):
