@@ -64,6 +64,8 @@ struct HostWin {       // what the host keeps per window for state transfer / ex
     double *pose, *sb, *lm, *sc;
     int n_pose, n_sb, n_lm, n_sc;
     int tail_dim;
+    double *comp_pose = nullptr, *comp_sb = nullptr;    // hidden epochs of the window's composite factors (caller memory)
+    int comp_e0 = 0, comp_ne = 0;                       // their range in the batch-wide hidden-epoch arrays
 };
 
 struct swf_batch {
@@ -73,7 +75,10 @@ struct swf_batch {
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
     int max_tiles = 0, max_prior_dim = 0, max_red = 0, min_red = 1 << 30, n_cu = 256;
-    bool clc_imu[3] = { false, false, false };    // clique class holds IMU factors (its elimination must follow k_eval_imu)
+    bool clc_imu[3] = { false, false, false };
+    // composite IMU-GNSS factors of the batch (swf_kernels4.h): operator arguments, solver-side bookkeeping, initial hidden epochs
+    CompArgs CA{}; CompMeta CM{}; int n_comp = 0; long long comp_ne = 0;
+    double* co_pose0 = nullptr; double* co_sb0 = nullptr;    // clique class holds IMU factors (its elimination must follow k_eval_imu)
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
     int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr; double* mg_M = nullptr;
     bool mg_valid = false; int mg_ld = 0;
@@ -119,6 +124,9 @@ struct Build {
     std::vector<Clique> cl;
     std::vector<int> cl_fac, cl_frow, cm_loc, cm_ls, cm_col;
     std::vector<double> C_init, dgraw_init;      // static parts (prior cliques)
+    // composite factors (concatenated over the batch)
+    std::vector<int> co_M, co_N, co_gf, co_win, co_xo, co_xo_off{ 0 };
+    std::vector<double> co_pose, co_sb, co_pose_lin, co_sb_lin, co_Hpp, co_HpN, co_rhs_p, co_HNN, co_rhsN, co_pre, co_pbgw;
     std::vector<Pair> pair;
     std::vector<long long> pc_coff;
     std::vector<int> pc_cld, pc_voff;
@@ -369,6 +377,55 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
             B.max_prior_dim = std::max(B.max_prior_dim, dim);
             bo += nbk; jo += (long long)dim * dim; ro += dim; x0o += gsum;
         }
+    }
+    // composite IMU-GNSS factors: carried as prior-type factors whose record k_comp_scatter rewrites at every linearisation
+    hw.comp_pose = w->comp_pose; hw.comp_sb = w->comp_sb; hw.comp_e0 = (int)(B.co_pose.size() / 7);
+    {
+        int io = 0; long long pn = 0, nn = 0; int no = 0, e0 = 0;
+        for (int k = 0; k < w->n_comp; k++) {
+            const int M = w->comp_M[k], N = w->comp_N[k], G = 30 + N;
+            if (M < 1) return fail(SWF_E_INVALID, "composite factor without hidden epochs");
+            if (N < 0 || N > CO_MAXN) return fail(SWF_E_UNSUPPORTED, "composite factor with more than 24 ambiguities");
+            const int* ix = w->comp_idx + io;
+            CHK(ix[0], nP, "composite") CHK(ix[1], nS, "composite") CHK(ix[2], nP, "composite") CHK(ix[3], nS, "composite")
+            std::vector<int> blks = { bidP(ix[0]), bidS(ix[1]), bidP(ix[2]), bidS(ix[3]) };
+            for (int q = 0; q < N; q++) { CHK(ix[4 + q], nC, "composite") blks.push_back(bidC(ix[4 + q])); }
+            for (size_t a = 0; a < blks.size(); a++) {
+                if (loc[blks[a]] < 0) return fail(SWF_E_UNSUPPORTED, "composite factor on a constant parameter block");
+                if (is_e(blks[a])) return fail(SWF_E_UNSUPPORTED, "composite factor on a block of elimination group 0");
+                for (size_t c2 = 0; c2 < a; c2++) if (blks[c2] == blks[a]) return fail(SWF_E_INVALID, "composite factor: repeated parameter block");
+            }
+            int data = (int)B.prior_dim.size();
+            B.prior_dim.push_back(G);
+            B.prior_Joff.push_back((long long)B.prior_J.size()); B.prior_roff.push_back((int)B.prior_r0.size()); B.prior_x0off.push_back((int)B.prior_x0.size());
+            B.prior_J.resize(B.prior_J.size() + (size_t)G * G, 0.0); B.prior_r0.resize(B.prior_r0.size() + G, 0.0);
+            {   // a valid linearisation point until the first k_comp_scatter: the blocks' current values
+                const double* src[4] = { w->pose + 7 * ix[0], w->sb + 9 * ix[1], w->pose + 7 * ix[2], w->sb + 9 * ix[3] };
+                const int gsz[4] = { 7, 9, 7, 9 };
+                for (int a = 0; a < 4; a++) B.prior_x0.insert(B.prior_x0.end(), src[a], src[a] + gsz[a]);
+                for (int q = 0; q < N; q++) B.prior_x0.push_back(w->sc[ix[4 + q]]);
+            }
+            int g = add_gf(GF_PRIOR, G, data, blks);
+            B.prior_gf.push_back(g);
+            B.max_prior_dim = std::max(B.max_prior_dim, G);
+            B.co_M.push_back(M); B.co_N.push_back(N); B.co_gf.push_back(g); B.co_win.push_back(wi);
+            for (int b : blks) B.co_xo.push_back(gx(b));
+            B.co_xo_off.push_back((int)B.co_xo.size());
+            B.co_pose.insert(B.co_pose.end(), w->comp_pose + (size_t)e0 * 7, w->comp_pose + (size_t)(e0 + M) * 7);
+            B.co_sb.insert(B.co_sb.end(), w->comp_sb + (size_t)e0 * 9, w->comp_sb + (size_t)(e0 + M) * 9);
+            B.co_pose_lin.insert(B.co_pose_lin.end(), w->comp_pose_lin + (size_t)e0 * 7, w->comp_pose_lin + (size_t)(e0 + M) * 7);
+            B.co_sb_lin.insert(B.co_sb_lin.end(), w->comp_sb_lin + (size_t)e0 * 9, w->comp_sb_lin + (size_t)(e0 + M) * 9);
+            B.co_Hpp.insert(B.co_Hpp.end(), w->comp_Hpp + (size_t)e0 * 225, w->comp_Hpp + (size_t)(e0 + M) * 225);
+            B.co_HpN.insert(B.co_HpN.end(), w->comp_HpN + pn, w->comp_HpN + pn + 15LL * M * N);
+            B.co_rhs_p.insert(B.co_rhs_p.end(), w->comp_rhs_p + (size_t)e0 * 15, w->comp_rhs_p + (size_t)(e0 + M) * 15);
+            B.co_HNN.insert(B.co_HNN.end(), w->comp_HNN + nn, w->comp_HNN + nn + (long long)N * N);
+            B.co_rhsN.insert(B.co_rhsN.end(), w->comp_rhsN + no, w->comp_rhsN + no + N);
+            B.co_pre.insert(B.co_pre.end(), w->comp_pre + (size_t)(e0 + k) * SWF_PRE_DOUBLES, w->comp_pre + (size_t)(e0 + k + M + 1) * SWF_PRE_DOUBLES);
+            for (int q = 0; q < 3; q++) B.co_pbgw.push_back(w->pbg[q]);
+            for (int q = 0; q < 3; q++) B.co_pbgw.push_back(w->gw[q]);
+            io += 4 + N; pn += 15LL * M * N; nn += (long long)N * N; no += N; e0 += M;
+        }
+        hw.comp_ne = e0;
     }
 #undef CHK
     R.gf1 = (int)B.gf.size();
@@ -677,6 +734,42 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     }
     rc |= P.zeros((size_t)B.v_tot, &D.cv_graw); rc |= P.zeros((size_t)B.v_tot, &D.cv_cs);
     rc |= P.zeros((size_t)B.e_tot, &D.cE);
+    // composite IMU-GNSS factors: operator arguments over the whole batch + where each factor's prior record and clique live
+    b->n_comp = (int)B.co_M.size();
+    if (b->n_comp) {
+        const int nc = b->n_comp;
+        std::vector<int> eo(nc + 1, 0), no(nc + 1, 0), roff(nc), x0off(nc), voff(nc);
+        std::vector<long long> pno(nc + 1, 0), nno(nc + 1, 0), go(nc + 1, 0), g2o(nc + 1, 0), Joff(nc), Coff(nc);
+        for (int f = 0; f < nc; f++) {
+            const int M = B.co_M[f], N = B.co_N[f], G = 30 + N;
+            eo[f + 1] = eo[f] + M; no[f + 1] = no[f] + N; pno[f + 1] = pno[f] + 15LL * M * N; nno[f + 1] = nno[f] + (long long)N * N;
+            go[f + 1] = go[f] + G; g2o[f + 1] = g2o[f] + (long long)G * G;
+            const GFac& Gf = B.gf[B.co_gf[f]];
+            const Clique& Cq = B.cl[Gf.clique];
+            if (!Cq.is_static || Cq.d_f != G || Cq.d_e != 0) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "composite factor: its blocks must all be variable and outside group 0"); }
+            Joff[f] = B.prior_Joff[Gf.data]; roff[f] = B.prior_roff[Gf.data]; x0off[f] = B.prior_x0off[Gf.data];
+            Coff[f] = Cq.C_off; voff[f] = Cq.v_off;
+        }
+        b->comp_ne = eo[nc];
+        CompArgs& A = b->CA; CompMeta& Mt = b->CM;
+        A.n = nc; A.want_jac = 1;
+        rc |= P.put(B.co_M, &A.M); rc |= P.put(B.co_N, &A.N); rc |= P.put(eo, &A.e_off); rc |= P.put(no, &A.n_off);
+        rc |= P.put(pno, &A.pn_off); rc |= P.put(nno, &A.nn_off); rc |= P.put(go, &A.g_off); rc |= P.put(g2o, &A.g2_off);
+        { const double* t1 = nullptr; const double* t2 = nullptr; rc |= P.put(B.co_pose, &t1); rc |= P.put(B.co_sb, &t2); A.pose = (double*)t1; A.sb = (double*)t2; }
+        { const double* t1 = nullptr; const double* t2 = nullptr; rc |= P.put(B.co_pose, &t1); rc |= P.put(B.co_sb, &t2); b->co_pose0 = (double*)t1; b->co_sb0 = (double*)t2; }
+        rc |= P.put(B.co_pose_lin, &A.pose_lin); rc |= P.put(B.co_sb_lin, &A.sb_lin); rc |= P.put(B.co_Hpp, &A.Hpp); rc |= P.put(B.co_HpN, &A.HpN);
+        rc |= P.put(B.co_rhs_p, &A.rhs_p); rc |= P.put(B.co_HNN, &A.HNN); rc |= P.put(B.co_rhsN, &A.rhsN); rc |= P.put(B.co_pre, &A.pre); rc |= P.put(B.co_pbgw, &A.pbgw);
+        rc |= P.zeros((size_t)eo[nc] * 225, &A.hmn_inv); rc |= P.zeros((size_t)eo[nc] * 225, &A.hmn_2); rc |= P.zeros((size_t)eo[nc] * 225, &A.hmn_0);
+        rc |= P.zeros((size_t)pno[nc], &A.hmn_N); rc |= P.zeros((size_t)eo[nc] * 15, &A.rhsmn);
+        rc |= P.zeros((size_t)g2o[nc], &A.Hd); rc |= P.zeros((size_t)go[nc], &A.rd); rc |= P.zeros((size_t)g2o[nc], &A.Ld); rc |= P.zeros((size_t)go[nc], &A.r0);
+        rc |= P.zeros((size_t)nc * 32, &A.old); rc |= P.zeros((size_t)no[nc], &A.N_old); rc |= P.zeros((size_t)nc, &A.history); rc |= P.zeros((size_t)nc, &A.status);
+        rc |= P.zeros((size_t)nc * 32, &Mt.outer); rc |= P.zeros((size_t)no[nc], &Mt.Nv); rc |= P.zeros((size_t)nc, &Mt.active);
+        A.outer = Mt.outer; A.Nv = Mt.Nv; A.active = Mt.active;
+        rc |= P.zeros((size_t)go[nc], &A.res_out); rc |= P.zeros((size_t)g2o[nc], &A.jac_out);
+        rc |= P.put(B.co_win, &Mt.win); rc |= P.put(B.co_xo_off, &Mt.xo_off); rc |= P.put(B.co_xo, &Mt.xo);
+        rc |= P.put(Joff, &Mt.Joff); rc |= P.put(roff, &Mt.roff); rc |= P.put(x0off, &Mt.x0off); rc |= P.put(Coff, &Mt.Coff); rc |= P.put(voff, &Mt.voff);
+        Mt.prior_J = (double*)D.prior_J; Mt.prior_r0 = (double*)D.prior_r0; Mt.prior_x0 = (double*)D.prior_x0;
+    }
     if (rc) { P.release(); delete b; return fail(SWF_E_NODEVICE, "device allocation / upload failed"); }
     *out = b;
     int urc = swf_batch_upload_state(b);
@@ -706,7 +799,22 @@ extern "C" int swf_batch_upload_state(swf_batch* b) {
     }
     HIPCHK(hipMemcpyAsync(b->D.x, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->D.x0, b->D.x, x.size() * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));     // x is a stack-lifetime staging buffer
+    std::vector<double> hp, hs;
+    if (b->n_comp) {
+        hp.resize((size_t)b->comp_ne * 7); hs.resize((size_t)b->comp_ne * 9);
+        for (size_t i = 0; i < b->win.size(); i++) {
+            const HostWin& h = b->hw[i];
+            if (!h.comp_ne) continue;
+            memcpy(hp.data() + (size_t)h.comp_e0 * 7, h.comp_pose, sizeof(double) * 7 * h.comp_ne);
+            memcpy(hs.data() + (size_t)h.comp_e0 * 9, h.comp_sb, sizeof(double) * 9 * h.comp_ne);
+        }
+        HIPCHK(hipMemcpyAsync(b->co_pose0, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->co_sb0, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->CA.pose, b->co_pose0, hp.size() * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->CA.sb, b->co_sb0, hs.size() * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+        HIPCHK(hipMemsetAsync(b->CA.history, 0, (size_t)b->n_comp * sizeof(int), b->stream));
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));     // staging buffers have stack lifetime
     return SWF_OK;
 }
 
@@ -715,6 +823,11 @@ extern "C" int swf_batch_reset_state(swf_batch* b) {
     int n = b->D.n_x;
     hipLaunchKernelGGL(k_copy, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->D.x, (const double*)b->D.x0, n);
     HIPCHK(hipGetLastError());
+    if (b->n_comp) {       // hidden epochs back to the uploaded values, composite factors forget their last linearisation
+        HIPCHK(hipMemcpyAsync(b->CA.pose, b->co_pose0, (size_t)b->comp_ne * 7 * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->CA.sb, b->co_sb0, (size_t)b->comp_ne * 9 * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+        HIPCHK(hipMemsetAsync(b->CA.history, 0, (size_t)b->n_comp * sizeof(int), b->stream));
+    }
     return SWF_OK;
 }
 
@@ -756,6 +869,12 @@ struct Launcher {
     // stream (small batches) the IMU / clique branch runs next to the projection / landmark branch.
     void lin_eval() {
         DevBatch& D = b->D;
+        if (b->n_comp) {
+            // composite IMU-GNSS factors of the windows that re-linearise: hidden epochs move, re-elimination, prior records rewritten
+            hipLaunchKernelGGL(k_comp_gather, dim3(b->n_comp), dim3(64), 0, st, D, b->CA, b->CM);
+            hipLaunchKernelGGL(k_composite, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            hipLaunchKernelGGL(k_comp_scatter, dim3(b->n_comp), dim3(256), 0, st, D, b->CA, b->CM);
+        }
         hipStream_t sa = b->aux ? b->aux : st;
         if (b->aux) { (void)hipEventRecord(b->ev_fork[0], st); (void)hipStreamWaitEvent(b->aux, b->ev_fork[0], 0); }
         if (D.n_proj + D.n_sc + D.n_prior) {
@@ -919,6 +1038,17 @@ extern "C" int swf_batch_download_state(swf_batch* b) {
         memcpy(h.sb, p, sizeof(double) * 9 * h.n_sb); p += 9 * h.n_sb;
         memcpy(h.lm, p, sizeof(double) * 3 * h.n_lm); p += 3 * h.n_lm;
         memcpy(h.sc, p, sizeof(double) * h.n_sc);
+    }
+    if (b->n_comp) {       // the hidden GNSS epochs are parameter memory too
+        std::vector<double> hp((size_t)b->comp_ne * 7), hs((size_t)b->comp_ne * 9);
+        HIPCHK(hipMemcpy(hp.data(), b->CA.pose, hp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hs.data(), b->CA.sb, hs.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < b->win.size(); i++) {
+            const HostWin& h = b->hw[i];
+            if (!h.comp_ne) continue;
+            memcpy(h.comp_pose, hp.data() + (size_t)h.comp_e0 * 7, sizeof(double) * 7 * h.comp_ne);
+            memcpy(h.comp_sb, hs.data() + (size_t)h.comp_e0 * 9, sizeof(double) * 9 * h.comp_ne);
+        }
     }
     return SWF_OK;
 }
@@ -1151,7 +1281,12 @@ extern "C" int swf_composite_create(int32_t n, const int32_t* M, const int32_t* 
     A.Hpp = (const double*)up(Hpp, c->sumM * 225 * D); A.HpN = (const double*)up(HpN, pno[n] * D); A.rhs_p = (const double*)up(rhs_p, c->sumM * 15 * D);
     A.HNN = (const double*)up(HNN, nno[n] * D); A.rhsN = (const double*)up(rhsN, c->sumN * D);
     A.pre = (const double*)up(pre, (size_t)(c->sumM + n) * SWF_PRE_DOUBLES * D);
-    for (int k = 0; k < 3; k++) { A.pbg[k] = pbg[k]; A.gw[k] = gw[k]; }
+    {
+        std::vector<double> pg((size_t)n * 6);
+        for (int f = 0; f < n; f++) for (int k = 0; k < 3; k++) { pg[(size_t)f * 6 + k] = pbg[k]; pg[(size_t)f * 6 + 3 + k] = gw[k]; }
+        A.pbgw = (const double*)up(pg.data(), pg.size() * D);
+    }
+    A.active = nullptr;
     A.hmn_inv = (double*)up(nullptr, c->sumM * 225 * D); A.hmn_2 = (double*)up(nullptr, c->sumM * 225 * D); A.hmn_0 = (double*)up(nullptr, c->sumM * 225 * D);
     A.hmn_N = (double*)up(nullptr, pno[n] * D); A.rhsmn = (double*)up(nullptr, c->sumM * 15 * D);
     A.Hd = (double*)up(nullptr, c->sumG2 * D); A.rd = (double*)up(nullptr, c->sumG * D); A.Ld = (double*)up(nullptr, c->sumG2 * D); A.r0 = (double*)up(nullptr, c->sumG * D);

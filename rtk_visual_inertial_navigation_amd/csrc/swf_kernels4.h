@@ -28,7 +28,8 @@ struct CompArgs {
     const double* pose_lin; const double* sb_lin;
     const double* Hpp; const double* HpN; const double* rhs_p; const double* HNN; const double* rhsN;
     const double* pre;                                 // [sum M + n][SWF_PRE_DOUBLES]; factor f owns records e_off[f] + f ...
-    double pbg[3], gw[3];
+    const double* pbgw;                                // [n][6] lever arm and gravity of the factor's window
+    const int* active;                                 // [n] or null: 0 = skip the factor in this launch (its window does not re-linearise)
     double* hmn_inv; double* hmn_2; double* hmn_0; double* hmn_N; double* rhsmn;      // saved at each elimination
     double* Hd; double* rd; double* Ld; double* r0;                                      // dense remainder, its factor, L^-1 rhs
     double* old; double* N_old;                        // [n][32] outer states of the last linearisation, [sum N]
@@ -50,7 +51,7 @@ __device__ __forceinline__ void co_inc15(const double* P, const double* Bv, cons
 
 __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
     const int f = blockIdx.x, t = threadIdx.x;
-    if (f >= A.n) return;
+    if (f >= A.n || (A.active && !A.active[f])) return;
     const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
     const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
     // running elimination: blocks (Pose1, Pose2, N, Pose0) x (>=), reference enum HessianOrder
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
             sSt[t] = v;
         }
         for (int e = t; e < SWF_PRE_SQRTINFO; e += 256) sPr[e] = pre[e];
-        if (t < 3) { sPr[SWF_PRE_SQRTINFO + t] = A.pbg[t]; sPr[SWF_PRE_SQRTINFO + 3 + t] = A.gw[t]; }
+        if (t < 6) sPr[SWF_PRE_SQRTINFO + t] = A.pbgw[(size_t)f * 6 + t];
         for (int e = t; e < 225; e += 256) sSI[e] = pre[SWF_PRE_SQRTINFO + e];
         for (int e = t; e < 450; e += 256) sU[e] = 0.0;
         __syncthreads();
@@ -297,4 +298,50 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
     if (t < 32) A.old[(size_t)f * 32 + t] = sOut[t];
     if (t < N) A.N_old[n0 + t] = sNv[t];
     if (t == 0) { A.history[f] = 1; A.status[f] = sBad ? -1 : 0; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Inside the solver a composite factor IS a linearised prior that is rewritten at every linearisation: between two Jacobian
+// evaluations the reference answers from r_lin - J INC, with INC = old (-) new in exactly the coordinates of
+// MarginalizationFactor::Evaluate (p - p0, +-2 vec(q0^-1 q), x - x0).  So the engine carries it as a prior-type factor with
+// a static clique; at every linearisation of its window  k_comp_gather  collects the outer blocks,  k_composite  moves the
+// hidden epochs and re-eliminates, and  k_comp_scatter  rewrites the prior's (J, r0, x0) and its clique's J^T J / diagonal.
+// Evaluation, J v products, candidate cost and assembly are the prior's own code, unchanged.
+// ---------------------------------------------------------------------------------------------------------------------
+struct CompMeta {
+    const int* win;                 // [n] window of the factor
+    const int* xo_off;              // [n+1] prefix sums of 4 + N
+    const int* xo;                  // ambient x offsets of the outer blocks: pose_i, sb_i, pose_j, sb_j, N scalars
+    const long long* Joff; const int* roff; const int* x0off;      // the factor's prior record
+    const long long* Coff; const int* voff;                        // its static clique: C (G x G), dgraw
+    double* prior_J; double* prior_r0; double* prior_x0;
+    int* active;
+    double* outer; double* Nv;      // = CompArgs.outer / .Nv
+};
+
+__global__ void __launch_bounds__(64) k_comp_gather(DevBatch B, CompArgs A, CompMeta Mt) {
+    int f = blockIdx.x, t = threadIdx.x;
+    if (f >= A.n) return;
+    const WinState& s = B.ws[Mt.win[f]];
+    int act = (s.status == SWF_RUNNING && s.need_lin) ? 1 : 0;
+    if (t == 0) Mt.active[f] = act;
+    if (!act) return;
+    const int* xo = Mt.xo + Mt.xo_off[f];
+    int N = A.N[f];
+    if (t < 32) { int sl = t < 7 ? 0 : t < 16 ? 1 : t < 23 ? 2 : 3, o = t < 7 ? t : t < 16 ? t - 7 : t < 23 ? t - 16 : t - 23; Mt.outer[(size_t)f * 32 + t] = B.x[xo[sl] + o]; }
+    if (t >= 32 && t - 32 < N) Mt.Nv[A.n_off[f] + t - 32] = B.x[xo[4 + t - 32]];
+}
+
+__global__ void __launch_bounds__(256) k_comp_scatter(DevBatch B, CompArgs A, CompMeta Mt) {
+    int f = blockIdx.x, t = threadIdx.x;
+    if (f >= A.n || !Mt.active[f]) return;
+    const int N = A.N[f], G = 30 + N;
+    const double* J = A.jac_out + A.g2_off[f]; const double* H = A.Hd + A.g2_off[f]; const double* r = A.res_out + A.g_off[f];
+    double* pJ = Mt.prior_J + Mt.Joff[f]; double* C = B.C + Mt.Coff[f];
+    for (int e = t; e < G * G; e += 256) { pJ[e] = J[e]; C[e] = H[e]; }
+    for (int e = t; e < G; e += 256) { Mt.prior_r0[Mt.roff[f] + e] = r[e]; B.cv_dgraw[Mt.voff[f] + e] = H[(size_t)e * G + e]; }
+    double* x0 = Mt.prior_x0 + Mt.x0off[f];
+    if (t < 32) x0[t] = A.outer[(size_t)f * 32 + t];
+    if (t >= 32 && t - 32 < N) x0[t] = A.Nv[A.n_off[f] + t - 32];
+    if (t == 0 && A.status[f] != 0) B.ws[Mt.win[f]].lin_fail = 1;       // a hidden epoch or the remainder was not positive definite
 }

@@ -34,6 +34,7 @@ for t in range(N):
         Sg, rg, Lg = bs.export_reduced(0); g, dg, y = bs.export_vectors(0)
         if rel(g, eo["grad"]) > 1e-11 or rel(Sg, eo["S"]) > 1e-11 or rel(rg, eo["rhs"]) > 1e-10: msg.append("linearisation")
         if rel(Lg @ Lg.T, Sg) > 1e-12: msg.append("LLt")
+        condS = np.linalg.cond(eo["S"])
         bs.close()
         wo, wg = w.copy(), w.copy()
         so, _ = ob.solve(wo, default_options(), export=False)
@@ -43,7 +44,8 @@ for t in range(N):
         else:
             if [r["step_is_successful"] for r in rg_] != [r["step_is_successful"] for r in ro]: msg.append("accept sequence")
             for a, b in zip(rg_, ro):
-                if abs(a["cost"] - b["cost"]) > 5e-7 * abs(b["cost"]) + 5e-5: msg.append("cost %.3e vs %.3e" % (a["cost"], b["cost"])); break
+                # a Gauss-Newton step carries eps * cond(S) relative error; the cost sequences of two correct solvers drift apart by that
+                if abs(a["cost"] - b["cost"]) > (5e-7 + 1e-17 * condS) * abs(b["cost"]) + 5e-5: msg.append("cost %.12e vs %.12e (rel %.2e) at iteration %d of %d, cond(S) %.2e" % (a["cost"], b["cost"], abs(a["cost"] - b["cost"]) / abs(b["cost"]), rg_.index(a), len(rg_), condS)); break
             if np.abs(wg.a["pose"] - wo.a["pose"]).max() > 1e-6: msg.append("pose")
         wins.append((w, wg, [r["cost"] for r in rg_]))
         bs.close()

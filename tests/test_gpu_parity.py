@@ -597,3 +597,45 @@ def test_composite_imu_gnss_factors_match_oracle():
     Fg.close()
     for F in Fo:
         F.close()
+
+
+def test_windows_with_composite_factors_match_oracle_solver():
+    """Rows a5 / a10 inside the solve loop: windows whose visual frames are linked only by composite IMU-GNSS factors (the
+    state of an RTK window after UpdateImuGnssFactor), solved by the engine — where a composite factor is a prior-type
+    record rewritten at every linearisation — against the oracle solver with its stateful restatement of IMUGNSSBase:
+    same accept / reject sequence, costs, radii, final states, and the hidden GNSS epochs (parameter memory the factor
+    itself updates) written back; batch == single bit for bit; a second solve continues from the written-back state."""
+    import composite_gen as cg
+    rng = np.random.default_rng(44)
+    shapes = [(3, 2, 4), (5, 4, 10), (4, 9, 6), (6, 1, 0), (3, 12, 24)]
+    wins = [cg.make_window(rng, K, M, N) for (K, M, N) in shapes]
+    singles = []
+    for w in wins:
+        wo, wg = w.copy(), w.copy()
+        so, _ = ob.solve(wo, default_options(max_num_iterations=8), export=False)
+        bs, sg = gpu_solve(wg, default_options(max_num_iterations=8))
+        ro, rg = so.rows(), sg.rows()
+        assert sg.termination == so.termination and sg.num_iterations == so.num_iterations, (sg.termination, so.termination, len(rg), len(ro))
+        assert [r["step_is_successful"] for r in rg] == [r["step_is_successful"] for r in ro]
+        for a, b in zip(rg, ro):
+            assert abs(a["cost"] - b["cost"]) <= 1e-6 * abs(b["cost"]) + 1e-6, (a["cost"], b["cost"])
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * b["trust_region_radius"]
+        assert np.abs(wg.a["pose"] - wo.a["pose"]).max() < 1e-6 and np.abs(wg.a["sb"] - wo.a["sb"]).max() < 1e-6
+        assert np.abs(wg.a["sc"] - wo.a["sc"]).max() < 1e-5
+        assert np.abs(wg.a["comp_pose"] - wo.a["comp_pose"]).max() < 1e-6 and np.abs(wg.a["comp_sb"] - wo.a["comp_sb"]).max() < 1e-6
+        assert np.abs(wg.a["comp_pose"] - w.a["comp_pose"]).max() > 1e-6          # the hidden epochs did move
+        singles.append((wg, [r["cost"] for r in rg]))
+        bs.close()
+    batch = [w.copy() for w in wins]
+    bs = solver.BatchSolver(batch); sms = bs.solve(default_options(max_num_iterations=8))
+    for (wg, costs), wb, sm in zip(singles, batch, sms):
+        assert [r["cost"] for r in sm.rows()] == costs
+        for k in ("pose", "sb", "sc", "comp_pose", "comp_sb"):
+            assert np.array_equal(wg.a[k], wb.a[k]), k
+    bs.reset_state(); sms2 = bs.solve(default_options(max_num_iterations=8))
+    assert [[r["cost"] for r in s.rows()] for s in sms2] == [[r["cost"] for r in s.rows()] for s in sms]   # reset restores the hidden epochs
+    bs.close()
+    # the unsupported placements are refused, not ignored
+    bad = wins[0].copy(); bad.a["is_const"][0] = 1
+    with pytest.raises(solver.SwfError):
+        solver.BatchSolver([bad])
