@@ -19,6 +19,7 @@
 //   SppPseudorangeFactor(...)                   R/factor/gnss_factor.h:70-83          -> swf_add_spp_pseudorange
 //   SppCarrierPhaseFactor(...)                  R/factor/gnss_factor.h:88-104         -> swf_add_spp_carrier_phase
 //   FixedIntegerFactor(N21, istd)               R/factor/gnss_factor.h:135-143        -> swf_add_fixed_integer
+//   IMUGNSSFactor(IMUGNSSBase*)                 R/factor/gnss_imu_factor.h:19-151     -> swf_add_imu_gnss (IMUGNSSInfo below)
 //   InitialBlackFactor(istd)                    R/factor/initial_factor.h:42-48       -> swf_add_scalar_prior
 //   MarginalizationFactor(info)                 R/factor/marginalization_factor.h:104-110 -> swf_add_linear_prior
 //   ceres::internal::{parameter_head,is_optimize,lhs_out,rhs_out,lhs_out2,hs_row}
@@ -87,6 +88,16 @@ struct SppCarrierPhaseFactor : CostFunction {
     }
 };
 struct FixedIntegerFactor : CostFunction { double N21, istd; FixedIntegerFactor(double N21_, double istd_) : N21(N21_), istd(istd_) {} };
+// What IMUGNSSBase holds when SetLastImuFactor adds its factor (R/factor/gnss_imu_factor.cpp:99-119), as plain arrays: a maintainer
+// fills it from gnss_poses / gnss_speed_bias (the hidden epochs' parameter memory, updated in place by every Solve), their
+// *_lin points, pose_hessians, pose_phase_biases_hessians, pose_rhses, phase_biases_hessians, phase_biases_rhs and the M + 1
+// pre-integrations (imu_factors[k]->pre_integration, last_imu_factor) in SWF_PRE_DOUBLES records.
+struct IMUGNSSInfo {
+    int M = 0;                                     // hidden GNSS epochs
+    double* hidden_pose = nullptr; double* hidden_sb = nullptr;        // [M][7], [M][9]
+    std::vector<double> pose_lin, sb_lin, Hpp, HpN, rhs_p, HNN, rhsN, pre;
+};
+struct IMUGNSSFactor : CostFunction { IMUGNSSInfo* info; explicit IMUGNSSFactor(IMUGNSSInfo* i) : info(i) {} };
 struct InitialBlackFactor : CostFunction { double istd; explicit InitialBlackFactor(double w) : istd(w) {} };
 // MarginalizationInfo's product: the linearised prior (J, r0, x0) over its kept blocks
 struct MarginalizationFactor : CostFunction {
@@ -165,6 +176,14 @@ class Problem {
     }
     ResidualBlockId AddResidualBlock(FixedIntegerFactor* f, LossFunction* loss, double* n_a, double* n_b) {
         ResidualBlockId id = swf_add_fixed_integer(h_, n_a, n_b, f->N21, f->istd); delete f; delete loss; return ck(id);
+    }
+    // param = { pose_i, speed_bias_i, pose_j, speed_bias_j, ambiguity_0 .. ambiguity_N-1 } as SetLastImuFactor builds it
+    ResidualBlockId AddResidualBlock(IMUGNSSFactor* f, LossFunction* loss, const std::vector<double*>& param) {
+        const IMUGNSSInfo& I = *f->info;
+        const int N = (int)param.size() - 4;
+        ResidualBlockId id = swf_add_imu_gnss(h_, param[0], param[1], param[2], param[3], param.data() + 4, N, I.M, I.hidden_pose, I.hidden_sb,
+                                              I.pose_lin.data(), I.sb_lin.data(), I.Hpp.data(), I.HpN.data(), I.rhs_p.data(), I.HNN.data(), I.rhsN.data(), I.pre.data());
+        delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(InitialBlackFactor* f, LossFunction* loss, double* scalar) {
         ResidualBlockId id = swf_add_scalar_prior(h_, scalar, f->istd); delete f; delete loss; return ck(id);

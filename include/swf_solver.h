@@ -261,6 +261,14 @@ swf_factor_id swf_add_spp_carrier_phase(swf_problem* p, double* pose, double* cl
                                         const double* dat);
 /* FixedIntegerFactor(N21, istd) (R/swf/swf_lambda.cpp:318-330): r = istd ((*n_b - *n_a) - N21) */
 swf_factor_id swf_add_fixed_integer(swf_problem* p, double* n_a, double* n_b, double N21, double istd);
+/* IMUGNSSFactor(IMUGNSS_info) (R/swf/swf.cpp:713-730, R/factor/gnss_imu_factor.cpp:99-119): the composite factor over
+ * (pose_i, sb_i, pose_j, sb_j, N ambiguities) hiding M GNSS epochs.  hidden_pose [M][7] / hidden_sb [M][9] are the epochs'
+ * parameter memory (gnss_poses / gnss_speed_bias): read at every solve, updated in place by it.  The other arrays (copied)
+ * are laid out as in swf_composite_create for one factor; pre holds M + 1 records.  Its blocks must be variable and outside
+ * elimination group 0; N <= 24. */
+swf_factor_id swf_add_imu_gnss(swf_problem* p, double* pose_i, double* sb_i, double* pose_j, double* sb_j, double* const* ambiguities,
+                               int32_t N, int32_t M, double* hidden_pose, double* hidden_sb, const double* pose_lin, const double* sb_lin,
+                               const double* Hpp, const double* HpN, const double* rhs_p, const double* HNN, const double* rhsN, const double* pre);
 /* InitialBlackFactor(w) (R/swf/swf_core.cpp:553-556) */
 swf_factor_id swf_add_scalar_prior(swf_problem* p, double* scalar, double w);
 /* MarginalizationFactor(info) (R/swf/swf_core.cpp:551-552): kept blocks `keys` (sizes from the

@@ -19,13 +19,15 @@
 
 namespace {
 struct PBlock { int size; int manifold; bool constant; long seq; };
-enum FType { FT_PROJ, FT_IMU, FT_CP, FT_PR, FT_DOP, FT_SP, FT_PRIOR, FT_SPR, FT_SCP, FT_FIX };
+enum FType { FT_PROJ, FT_IMU, FT_CP, FT_PR, FT_DOP, FT_SP, FT_PRIOR, FT_SPR, FT_SCP, FT_FIX, FT_COMP };
 struct PFactor {
     FType type; bool alive, enabled;
     std::vector<double*> keys;
     std::vector<double> data;      // type-specific record
     double sqrt_info = 0, loss_a = 0;
     int dim = 0;                   // prior
+    int M = 0, N = 0;              // composite IMU-GNSS factor: hidden epochs, ambiguities
+    double* hid_pose = nullptr; double* hid_sb = nullptr;     // its hidden epochs: caller memory, [M][7] / [M][9]
 };
 }  // namespace
 
@@ -50,6 +52,10 @@ struct swf_problem {
     std::vector<double> S, rhs, L;
     std::vector<double> mgA, mgb, mgJ, mgr0;      // swf_problem_marginalize outputs
     std::vector<double> tcA, tcQ;                 // swf_problem_tail_covariance outputs
+    // composite IMU-GNSS factors, flattened
+    std::vector<int32_t> comp_M, comp_N, comp_idx;
+    std::vector<double> comp_pose, comp_sb, comp_pose_lin, comp_sb_lin, comp_Hpp, comp_HpN, comp_rhs_p, comp_HNN, comp_rhsN, comp_pre;
+    std::vector<const PFactor*> comp_fac;
     int hs_row = 0;
     bool solved = false;
 };
@@ -166,6 +172,23 @@ swf_factor_id swf_add_fixed_integer(swf_problem* p, double* na, double* nb, doub
     double dat[SWF_FIX_DOUBLES] = { N21, istd };
     return add_factor(p, FT_FIX, { na, nb }, { 1, 1 }, dat, SWF_FIX_DOUBLES);
 }
+swf_factor_id swf_add_imu_gnss(swf_problem* p, double* pose_i, double* sb_i, double* pose_j, double* sb_j, double* const* ambiguities,
+                               int32_t N, int32_t M, double* hidden_pose, double* hidden_sb, const double* pose_lin, const double* sb_lin,
+                               const double* Hpp, const double* HpN, const double* rhs_p, const double* HNN, const double* rhsN, const double* pre) {
+    if (!p || M < 1 || N < 0 || (N && !ambiguities) || !hidden_pose || !hidden_sb || !pose_lin || !sb_lin || !Hpp || (N && (!HpN || !HNN || !rhsN)) || !rhs_p || !pre)
+        return pfail(SWF_E_INVALID, "swf_add_imu_gnss: bad arguments");
+    std::vector<double*> keys = { pose_i, sb_i, pose_j, sb_j };
+    std::vector<int> sizes = { 7, 9, 7, 9 };
+    for (int q = 0; q < N; q++) { keys.push_back(ambiguities[q]); sizes.push_back(1); }
+    // record: pose_lin [M][7] | sb_lin [M][9] | Hpp [M][225] | HpN [M][15 N] | rhs_p [M][15] | HNN [N N] | rhsN [N] | pre [M+1][SWF_PRE_DOUBLES]
+    std::vector<double> rec;
+    auto app = [&](const double* src, size_t n) { if (n) rec.insert(rec.end(), src, src + n); };
+    app(pose_lin, (size_t)M * 7); app(sb_lin, (size_t)M * 9); app(Hpp, (size_t)M * 225); app(HpN, (size_t)M * 15 * N); app(rhs_p, (size_t)M * 15);
+    app(HNN, (size_t)N * N); app(rhsN, (size_t)N); app(pre, (size_t)(M + 1) * SWF_PRE_DOUBLES);
+    swf_factor_id id = add_factor(p, FT_COMP, keys, sizes, rec.data(), rec.size());
+    if (id >= 0) { PFactor& f = p->factors[id]; f.M = M; f.N = N; f.hid_pose = hidden_pose; f.hid_sb = hidden_sb; }
+    return id;
+}
 swf_factor_id swf_add_linear_prior(swf_problem* p, double* const* keys, int32_t n_keys, const double* J, const double* r0, const double* x0) {
     if (!p || !keys || n_keys <= 0 || !J || !r0 || !x0) return SWF_E_INVALID;
     std::vector<double*> k(keys, keys + n_keys);
@@ -252,6 +275,8 @@ static int flatten(swf_problem* p) {
     p->proj_idx.clear(); p->proj_uv.clear(); p->imu_idx.clear(); p->imu_pre.clear(); p->cp_idx.clear(); p->cp_dat.clear();
     p->pr_idx.clear(); p->pr_dat.clear(); p->dop_idx.clear(); p->dop_dat.clear(); p->sp_idx.clear(); p->sp_w.clear();
     p->spr_idx.clear(); p->spr_dat.clear(); p->scp_idx.clear(); p->scp_dat.clear(); p->fix_idx.clear(); p->fix_dat.clear();
+    p->comp_M.clear(); p->comp_N.clear(); p->comp_idx.clear(); p->comp_pose.clear(); p->comp_sb.clear(); p->comp_pose_lin.clear(); p->comp_sb_lin.clear();
+    p->comp_Hpp.clear(); p->comp_HpN.clear(); p->comp_rhs_p.clear(); p->comp_HNN.clear(); p->comp_rhsN.clear(); p->comp_pre.clear(); p->comp_fac.clear();
     p->prior_nblk.clear(); p->prior_dim.clear(); p->prior_blk.clear(); p->prior_J.clear(); p->prior_r0.clear(); p->prior_x0.clear();
     double sqrt_info = 0, loss_a = 0; bool have_proj = false;
     for (auto& f : p->factors) {
@@ -272,6 +297,18 @@ static int flatten(swf_problem* p) {
         case FT_SPR: for (double* k : f.keys) p->spr_idx.push_back(pool_idx[k]); p->spr_dat.insert(p->spr_dat.end(), f.data.begin(), f.data.end()); break;
         case FT_SCP: for (double* k : f.keys) p->scp_idx.push_back(pool_idx[k]); p->scp_dat.insert(p->scp_dat.end(), f.data.begin(), f.data.end()); break;
         case FT_FIX: for (double* k : f.keys) p->fix_idx.push_back(pool_idx[k]); p->fix_dat.insert(p->fix_dat.end(), f.data.begin(), f.data.end()); break;
+        case FT_COMP: {
+            const int M = f.M, N = f.N;
+            p->comp_M.push_back(M); p->comp_N.push_back(N); p->comp_fac.push_back(&f);
+            for (double* k : f.keys) p->comp_idx.push_back(pool_idx[k]);
+            p->comp_pose.insert(p->comp_pose.end(), f.hid_pose, f.hid_pose + (size_t)M * 7);
+            p->comp_sb.insert(p->comp_sb.end(), f.hid_sb, f.hid_sb + (size_t)M * 9);
+            const double* d = f.data.data();
+            auto take = [&](std::vector<double>& dst, size_t n) { dst.insert(dst.end(), d, d + n); d += n; };
+            take(p->comp_pose_lin, (size_t)M * 7); take(p->comp_sb_lin, (size_t)M * 9); take(p->comp_Hpp, (size_t)M * 225); take(p->comp_HpN, (size_t)M * 15 * N);
+            take(p->comp_rhs_p, (size_t)M * 15); take(p->comp_HNN, (size_t)N * N); take(p->comp_rhsN, (size_t)N); take(p->comp_pre, (size_t)(M + 1) * SWF_PRE_DOUBLES);
+            break;
+        }
         case FT_PRIOR: {
             int dim = f.dim, gsum = 0;
             p->prior_nblk.push_back((int)f.keys.size()); p->prior_dim.push_back(dim);
@@ -298,6 +335,10 @@ static int flatten(swf_problem* p) {
     w.n_spr = (int)p->spr_idx.size() / 2; w.spr_idx = p->spr_idx.data(); w.spr_dat = p->spr_dat.data();
     w.n_scp = (int)p->scp_idx.size() / 3; w.scp_idx = p->scp_idx.data(); w.scp_dat = p->scp_dat.data();
     w.n_fix = (int)p->fix_idx.size() / 2; w.fix_idx = p->fix_idx.data(); w.fix_dat = p->fix_dat.data();
+    w.n_comp = (int)p->comp_M.size(); w.comp_M = p->comp_M.data(); w.comp_N = p->comp_N.data(); w.comp_idx = p->comp_idx.data();
+    w.comp_pose = p->comp_pose.data(); w.comp_sb = p->comp_sb.data(); w.comp_pose_lin = p->comp_pose_lin.data(); w.comp_sb_lin = p->comp_sb_lin.data();
+    w.comp_Hpp = p->comp_Hpp.data(); w.comp_HpN = p->comp_HpN.data(); w.comp_rhs_p = p->comp_rhs_p.data(); w.comp_HNN = p->comp_HNN.data();
+    w.comp_rhsN = p->comp_rhsN.data(); w.comp_pre = p->comp_pre.data();
     w.n_prior = (int)p->prior_nblk.size(); w.prior_nblk = p->prior_nblk.data(); w.prior_dim = p->prior_dim.data();
     w.prior_blk = p->prior_blk.data(); w.prior_J = p->prior_J.data(); w.prior_r0 = p->prior_r0.data(); w.prior_x0 = p->prior_x0.data();
     for (int k = 0; k < 3; k++) { w.pbg[k] = p->pbg[k]; w.gw[k] = p->gw[k]; w.base[k] = p->base[k]; }
@@ -309,6 +350,8 @@ static void gather_values(swf_problem* p) {      // Vector2Double direction: cal
     for (size_t i = 0; i < p->ksb.size(); i++) memcpy(&p->sb[9 * i], p->ksb[i], 9 * sizeof(double));
     for (size_t i = 0; i < p->klm.size(); i++) memcpy(&p->lm[3 * i], p->klm[i], 3 * sizeof(double));
     for (size_t i = 0; i < p->ksc.size(); i++) p->sc[i] = *p->ksc[i];
+    size_t e = 0;                                  // hidden epochs of the composite factors (gnss_poses / gnss_speed_bias)
+    for (const PFactor* f : p->comp_fac) { memcpy(&p->comp_pose[7 * e], f->hid_pose, (size_t)f->M * 7 * sizeof(double)); memcpy(&p->comp_sb[9 * e], f->hid_sb, (size_t)f->M * 9 * sizeof(double)); e += f->M; }
 }
 static void scatter_values(swf_problem* p) {     // Double2Vector direction; constant blocks are never written
     auto cst = [&](double* k) { return p->blocks[k].constant; };
@@ -316,6 +359,8 @@ static void scatter_values(swf_problem* p) {     // Double2Vector direction; con
     for (size_t i = 0; i < p->ksb.size(); i++) if (!cst(p->ksb[i])) memcpy(p->ksb[i], &p->sb[9 * i], 9 * sizeof(double));
     for (size_t i = 0; i < p->klm.size(); i++) if (!cst(p->klm[i])) memcpy(p->klm[i], &p->lm[3 * i], 3 * sizeof(double));
     for (size_t i = 0; i < p->ksc.size(); i++) if (!cst(p->ksc[i])) *p->ksc[i] = p->sc[i];
+    size_t e = 0;
+    for (const PFactor* f : p->comp_fac) { memcpy(f->hid_pose, &p->comp_pose[7 * e], (size_t)f->M * 7 * sizeof(double)); memcpy(f->hid_sb, &p->comp_sb[9 * e], (size_t)f->M * 9 * sizeof(double)); e += f->M; }
 }
 
 int swf_problem_solve(swf_problem* p, const swf_options* opt, swf_summary* summary) {

@@ -46,7 +46,7 @@ EXPORTED = [
     "swf_add_spp_pseudorange", "swf_add_spp_carrier_phase", "swf_add_fixed_integer",
     "swf_preintegrate_batch", "swf_triangulate_batch",
     "swf_batch_tail_covariance", "swf_batch_get_tail_covariance", "swf_problem_tail_covariance",
-    "swf_composite_create", "swf_composite_evaluate", "swf_composite_hidden", "swf_composite_destroy",
+    "swf_composite_create", "swf_composite_evaluate", "swf_composite_hidden", "swf_composite_destroy", "swf_add_imu_gnss",
 ]
 
 
@@ -300,6 +300,16 @@ class Problem:
     def AddFixedInteger(self, n_a, n_b, N21, istd):
         return self._fid(lib().swf_add_fixed_integer(self._h, self._p(n_a), self._p(n_b), C.c_double(N21), C.c_double(istd)), "AddFixedInteger")
 
+    def AddImuGnss(self, pose_i, sb_i, pose_j, sb_j, ambiguities, hidden_pose, hidden_sb, pose_lin, sb_lin, Hpp, HpN, rhs_p, HNN, rhsN, pre):
+        """IMUGNSSFactor: hidden_pose [M][7] / hidden_sb [M][9] are caller-owned numpy arrays the solve updates in place."""
+        N, M = len(ambiguities), int(np.asarray(hidden_pose).reshape(-1, 7).shape[0])
+        assert hidden_pose.dtype == np.float64 and hidden_pose.flags["C_CONTIGUOUS"] and hidden_sb.dtype == np.float64 and hidden_sb.flags["C_CONTIGUOUS"]
+        self._keep[hidden_pose.ctypes.data] = hidden_pose; self._keep[hidden_sb.ctypes.data] = hidden_sb
+        keys = (_pd * max(1, N))(*[self._p(a) for a in ambiguities])
+        arrs = [self._d(x) for x in (pose_lin, sb_lin, Hpp, HpN if N else np.zeros(1), rhs_p, HNN if N else np.zeros(1), rhsN if N else np.zeros(1), pre)]
+        return self._fid(lib().swf_add_imu_gnss(self._h, self._p(pose_i), self._p(sb_i), self._p(pose_j), self._p(sb_j), keys, C.c_int32(N), C.c_int32(M),
+                                                 hidden_pose.ctypes.data_as(_pd), hidden_sb.ctypes.data_as(_pd), *[a[1] for a in arrs]), "AddImuGnss")
+
     def AddScalarPrior(self, scalar, w):
         return self._fid(lib().swf_add_scalar_prior(self._h, self._p(scalar), C.c_double(w)), "AddScalarPrior")
 
@@ -476,6 +486,19 @@ def problem_from_window(w):
         P.AddSppCarrierPhase(pose[ix[0]], sc[ix[1]], sc[ix[2]], d)
     for ix, d in zip(a["fix_idx"].reshape(-1, 2), a["fix_dat"].reshape(-1, 2)):
         P.AddFixedInteger(sc[ix[0]], sc[ix[1]], d[0], d[1])
+    hidden = []
+    io = e0 = pn = nn = no = 0
+    for k in range(a["comp_M"].size):
+        M, N = int(a["comp_M"][k]), int(a["comp_N"][k])
+        ix = a["comp_idx"][io:io + 4 + N]
+        hp = a["comp_pose"].reshape(-1, 7)[e0:e0 + M].copy(); hs = a["comp_sb"].reshape(-1, 9)[e0:e0 + M].copy()
+        hidden.append((hp, hs))
+        P.AddImuGnss(pose[ix[0]], sb[ix[1]], pose[ix[2]], sb[ix[3]], [sc[i] for i in ix[4:]], hp, hs,
+                     a["comp_pose_lin"].reshape(-1, 7)[e0:e0 + M], a["comp_sb_lin"].reshape(-1, 9)[e0:e0 + M], a["comp_Hpp"].reshape(-1, 225)[e0:e0 + M],
+                     a["comp_HpN"][pn:pn + 15 * M * N], a["comp_rhs_p"].reshape(-1, 15)[e0:e0 + M], a["comp_HNN"][nn:nn + N * N], a["comp_rhsN"][no:no + N],
+                     a["comp_pre"].reshape(-1, 293)[e0 + k:e0 + k + M + 1])
+        io += 4 + N; e0 += M; pn += 15 * M * N; nn += N * N; no += N
+    P.hidden = hidden
     bo = jo = ro = xo = 0
     for nb, dim in zip(a["prior_nblk"], a["prior_dim"]):
         ids = a["prior_blk"][bo:bo + nb]

@@ -635,6 +635,16 @@ def test_windows_with_composite_factors_match_oracle_solver():
     bs.reset_state(); sms2 = bs.solve(default_options(max_num_iterations=8))
     assert [[r["cost"] for r in s.rows()] for s in sms2] == [[r["cost"] for r in s.rows()] for s in sms]   # reset restores the hidden epochs
     bs.close()
+    # the ceres::Problem-shaped surface: AddResidualBlock(IMUGNSSFactor) with the hidden epochs as caller memory
+    w0 = wins[1]
+    P, blocks = solver.problem_from_window(w0.copy())
+    sm = P.Solve(default_options(max_num_iterations=8))
+    wg, costs = singles[1]
+    assert [r["cost"] for r in sm.rows()] == costs
+    assert np.array_equal(np.concatenate(blocks[:w0.n_pose]), wg.a["pose"].ravel())
+    assert np.array_equal(np.concatenate([hp.ravel() for hp, hs in P.hidden]), wg.a["comp_pose"])       # updated in place
+    assert np.array_equal(np.concatenate([hs.ravel() for hp, hs in P.hidden]), wg.a["comp_sb"])
+    P.close()
     # the unsupported placements are refused, not ignored
     bad = wins[0].copy(); bad.a["is_const"][0] = 1
     with pytest.raises(solver.SwfError):
