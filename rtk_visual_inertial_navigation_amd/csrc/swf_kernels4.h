@@ -54,14 +54,21 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
     if (f >= A.n || (A.active && !A.active[f])) return;
     const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
     const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
-    // running elimination: blocks (Pose1, Pose2, N, Pose0) x (>=), reference enum HessianOrder
-    __shared__ double H00[225], H01[225], H0N[15 * CO_MAXN], H03[225], H11[225], H1N[15 * CO_MAXN], H13[225],
-                      HNN[CO_MAXN * CO_MAXN], HN3[15 * CO_MAXN], H33[225];
+    // running elimination: blocks (Pose1, Pose2, N, Pose0) x (>=), reference enum HessianOrder.  LDS is what bounds the number of
+    // factors in flight per CU, so the buffers are packed: the ten blocks share one pool that later holds the dense
+    // remainder (+ its rhs row), the IMU scratch (sU, sJ) aliases the elimination scratch (Ainv, L, T) it never meets.
+    __shared__ double pool[6 * 225 + 3 * 15 * CO_MAXN + CO_MAXN * CO_MAXN];            // 3006 doubles >= (G + 1) G for G <= 54
+    double* const H00 = pool; double* const H01 = pool + 225; double* const H03 = pool + 450; double* const H11 = pool + 675;
+    double* const H13 = pool + 900; double* const H33 = pool + 1125; double* const H0N = pool + 1350; double* const H1N = H0N + 15 * CO_MAXN;
+    double* const HN3 = H1N + 15 * CO_MAXN; double* const HNN = HN3 + 15 * CO_MAXN;
+    double* const sD = pool;
     __shared__ double r0b[15], r1b[15], rNb[CO_MAXN], r3b[15];
     __shared__ double dl2[15], dlN[CO_MAXN], dl0[15];                      // delta5[Pose2], [N], [Pose0]
-    __shared__ double sU[450], sJ[450], sRaw[16], sRes[16], sSI[225], sPr[SWF_PRE_SQRTINFO + 6], sSt[32];
-    __shared__ double sAinv[225], sL[225], T2[225], TN[15 * CO_MAXN], T0[225];
-    __shared__ double sD[CO_MAXG * CO_MAXG], sz[CO_MAXG];
+    __shared__ double scratch[1260];                                       // IMU phase: sU | sJ ; elimination phase: Ainv | L | T2 | T0 | TN
+    double* const sU = scratch; double* const sJ = scratch + 450;
+    double* const sAinv = scratch; double* const sL = scratch + 225; double* const T2 = scratch + 450; double* const T0 = scratch + 675; double* const TN = scratch + 900;
+    __shared__ double sRaw[16], sRes[16], sSI[225], sPr[SWF_PRE_SQRTINFO + 6], sSt[32];
+    __shared__ double sz[CO_MAXG], sdinv[CO_MAXG];
     __shared__ double sOut[32], sNv[CO_MAXN], sOld[32], sNold[CO_MAXN], sDx[16], sRm[16];
     __shared__ int sBad;
     const int hist = A.history[f];
@@ -192,13 +199,18 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
         for (int e = t; e < 225; e += 256) { int a = e / 15, b = e - a * 15; sL[e] = (b <= a) ? H00[b * 15 + a] : 0.0; }     // lower from the upper triangle
         __syncthreads();
         for (int j = 0; j < 15; j++) {
+            // column j is final but unscaled (L[a][j] sqrt(d_j)); the trailing update needs only it and 1 / d_j: one barrier per column
             double d = sL[j * 15 + j];
             if (!(d > 0.0)) { if (t == 0) sBad = 1; d = 1.0; }
-            double sd = sqrt(d);
+            double inv = 1.0 / d;
+            if (t < 225) { int a = t / 15, b = t - a * 15; if (b > j && a >= b) sL[a * 15 + b] -= sL[a * 15 + j] * sL[b * 15 + j] * inv; }
             __syncthreads();
-            if (t < 15 && t >= j) sL[t * 15 + j] = (t == j) ? sd : sL[t * 15 + j] / sd;
+        }
+        {
+            double vv = 0, dd = 1; bool low = false;
+            if (t < 225) { int a = t / 15, b = t - a * 15; low = a >= b; if (low) { dd = sL[b * 15 + b]; vv = sL[t]; } }
             __syncthreads();
-            if (t < 225) { int a = t / 15, b = t - a * 15; if (b > j && a >= b) sL[a * 15 + b] -= sL[a * 15 + j] * sL[b * 15 + j]; }
+            if (low) { int a = t / 15, b = t - a * 15; dd = dd > 0.0 ? dd : 1.0; sL[t] = (a == b) ? sqrt(dd) : vv / sqrt(dd); }
             __syncthreads();
         }
         if (t < 15) {
@@ -253,7 +265,8 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
         if (t < 15) { r0b[t] = r1b[t]; r1b[t] = 0; }
         __syncthreads();
     }
-    // UpdateSchurComponent: dense remainder in the order [Pose0 | Pose1 (= frame j) | N]
+    // UpdateSchurComponent: dense remainder in the order [Pose0 | Pose1 (= frame j) | N], written to HBM first (it is an output, and
+    // the LDS pool it is gathered from is about to be reused for the factorisation)
     for (int e = t; e < G * G; e += 256) {
         int a = e / G, b = e - a * G;
         int lo = a < b ? a : b, hi = a < b ? b : a;     // symmetric: take the upper entry (selfadjointView<Upper>)
@@ -266,35 +279,31 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
         else if (bl == 1 && bh == 1) v = H00[il * 15 + ih];
         else if (bl == 1 && bh == 2) v = H0N[il * N + ih];
         else v = HNN[il * N + ih];
-        sD[a * G + b] = v;
         A.Hd[g20 + e] = v;
     }
-    if (t < G) { double v = t < 15 ? r3b[t] : t < 30 ? r0b[t - 15] : rNb[t - 30]; sz[t] = v; A.rd[g0 + t] = v; }
+    if (t < G) { double v = t < 15 ? r3b[t] : t < 30 ? r0b[t - 15] : rNb[t - 30]; A.rd[g0 + t] = v; }
     __syncthreads();
-    // Cholesky of the remainder (lower, in place), then r0 = L^-1 rhs
+    for (int e = t; e < G * G; e += 256) sD[e] = A.Hd[g20 + e];
+    if (t < G) sD[G * G + t] = A.rd[g0 + t];                          // the rhs rides along as row G: its factor row is L^-1 rhs
+    __syncthreads();
+    // Cholesky of the remainder, right-looking with the columns left unscaled inside the loop (column j holds L[:, j] sqrt(d_j)): the
+    // trailing update needs only column j and 1 / d_j, so a column costs one barrier; the scaling happens at the write-out
     for (int j = 0; j < G; j++) {
         double d = sD[j * G + j];
         if (!(d > 0.0)) { if (t == 0) sBad = 1; d = 1.0; }
-        double sd = sqrt(d);
-        __syncthreads();
-        for (int a = j + t; a < G; a += 256) sD[a * G + j] = (a == j) ? sd : sD[a * G + j] / sd;
-        __syncthreads();
-        for (int e = t; e < G * G; e += 256) { int a = e / G, b = e - a * G; if (b > j && a >= b) sD[e] -= sD[a * G + j] * sD[b * G + j]; }
+        double inv = 1.0 / d;
+        for (int e = j * G + t; e < (G + 1) * G; e += 256) { int a = e / G, b = e - a * G; if (b > j && a >= b) sD[e] -= sD[a * G + j] * sD[b * G + j] * inv; }
         __syncthreads();
     }
-    for (int j = 0; j < G; j++) {
-        if (t == 0) sz[j] = sz[j] / sD[j * G + j];
-        __syncthreads();
-        for (int a = j + 1 + t; a < G; a += 256) sz[a] -= sD[a * G + j] * sz[j];
-        __syncthreads();
-    }
+    if (t < G) { double d = sD[t * G + t]; sdinv[t] = 1.0 / sqrt(d > 0.0 ? d : 1.0); }
+    __syncthreads();
     for (int e = t; e < G * G; e += 256) {
         int a = e / G, b = e - a * G;
-        double l = (b <= a) ? sD[e] : 0.0;
+        double l = (b < a) ? sD[e] * sdinv[b] : (a == b ? 1.0 / sdinv[b] : 0.0);
         A.Ld[g20 + e] = l;
         if (A.jac_out) A.jac_out[g20 + (size_t)b * G + a] = l;        // J = L^T
     }
-    if (t < G) { A.r0[g0 + t] = sz[t]; A.res_out[g0 + t] = sz[t]; }
+    if (t < G) { double y = sD[G * G + t] * sdinv[t]; A.r0[g0 + t] = y; A.res_out[g0 + t] = y; }
     if (t < 32) A.old[(size_t)f * 32 + t] = sOut[t];
     if (t < N) A.N_old[n0 + t] = sNv[t];
     if (t == 0) { A.history[f] = 1; A.status[f] = sBad ? -1 : 0; }
