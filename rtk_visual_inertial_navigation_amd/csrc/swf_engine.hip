@@ -766,6 +766,13 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         rc |= P.zeros((size_t)nc * 32, &Mt.outer); rc |= P.zeros((size_t)no[nc], &Mt.Nv); rc |= P.zeros((size_t)nc, &Mt.active);
         A.outer = Mt.outer; A.Nv = Mt.Nv; A.active = Mt.active;
         rc |= P.zeros((size_t)go[nc], &A.res_out); rc |= P.zeros((size_t)g2o[nc], &A.jac_out);
+        rc |= P.zeros((size_t)(eo[nc] + nc) * 450, &A.Jw); rc |= P.zeros((size_t)(eo[nc] + nc) * 16, &A.rw);
+        {
+            std::vector<int> qf, qk;
+            for (int f = 0; f < nc; f++) for (int k = 0; k <= B.co_M[f]; k++) { qf.push_back(f); qk.push_back(k); }
+            A.n_iq = (int)qf.size();
+            rc |= P.put(qf, &A.iq_f); rc |= P.put(qk, &A.iq_k); rc |= P.zeros((size_t)nc, &A.todo);
+        }
         rc |= P.put(B.co_win, &Mt.win); rc |= P.put(B.co_xo_off, &Mt.xo_off); rc |= P.put(B.co_xo, &Mt.xo);
         rc |= P.put(Joff, &Mt.Joff); rc |= P.put(roff, &Mt.roff); rc |= P.put(x0off, &Mt.x0off); rc |= P.put(Coff, &Mt.Coff); rc |= P.put(voff, &Mt.voff);
         Mt.prior_J = (double*)D.prior_J; Mt.prior_r0 = (double*)D.prior_r0; Mt.prior_x0 = (double*)D.prior_x0;
@@ -872,7 +879,9 @@ struct Launcher {
         if (b->n_comp) {
             // composite IMU-GNSS factors of the windows that re-linearise: hidden epochs move, re-elimination, prior records rewritten
             hipLaunchKernelGGL(k_comp_gather, dim3(b->n_comp), dim3(64), 0, st, D, b->CA, b->CM);
-            hipLaunchKernelGGL(k_composite, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            hipLaunchKernelGGL(k_comp_prep, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            hipLaunchKernelGGL(k_comp_imu, dim3((b->CA.n_iq + 7) / 8), dim3(256), 0, st, b->CA);
+            hipLaunchKernelGGL(k_comp_elim, dim3(b->n_comp), dim3(256), 0, st, b->CA);
             hipLaunchKernelGGL(k_comp_scatter, dim3(b->n_comp), dim3(256), 0, st, D, b->CA, b->CM);
         }
         hipStream_t sa = b->aux ? b->aux : st;
@@ -1294,6 +1303,14 @@ extern "C" int swf_composite_create(int32_t n, const int32_t* M, const int32_t* 
     A.history = (int*)up(nullptr, n * sizeof(int)); A.status = (int*)up(nullptr, n * sizeof(int));
     A.outer = (const double*)up(nullptr, (size_t)n * 32 * D); A.Nv = (const double*)up(nullptr, c->sumN * D);
     A.res_out = (double*)up(nullptr, c->sumG * D); A.jac_out = (double*)up(nullptr, c->sumG2 * D);
+    A.Jw = (double*)up(nullptr, (size_t)(c->sumM + n) * 450 * D); A.rw = (double*)up(nullptr, (size_t)(c->sumM + n) * 16 * D);
+    {
+        std::vector<int> qf, qk;
+        for (int f = 0; f < n; f++) for (int k = 0; k <= M[f]; k++) { qf.push_back(f); qk.push_back(k); }
+        A.n_iq = (int)qf.size();
+        A.iq_f = (const int*)up(qf.data(), qf.size() * sizeof(int)); A.iq_k = (const int*)up(qk.data(), qk.size() * sizeof(int));
+        A.todo = (int*)up(nullptr, n * sizeof(int));
+    }
     if (bad) return fail(SWF_E_NODEVICE, "swf_composite_create: device allocation / upload failed");
     *out = c.release();
     return SWF_OK;
@@ -1307,7 +1324,9 @@ extern "C" int swf_composite_evaluate(swf_composite* c, const double* outer, con
     if (c->sumN) HIPCHK(hipMemcpyAsync((void*)c->A.Nv, Nv, c->sumN * sizeof(double), hipMemcpyHostToDevice, st));
     CompArgs A = c->A;
     A.want_jac = want_jac ? 1 : 0;
-    hipLaunchKernelGGL(k_composite, dim3(c->n), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_comp_prep, dim3(c->n), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_comp_imu, dim3((A.n_iq + 7) / 8), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_comp_elim, dim3(c->n), dim3(256), 0, st, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(residual, c->A.res_out, c->sumG * sizeof(double), hipMemcpyDeviceToHost, st));
     if (jac && want_jac) HIPCHK(hipMemcpyAsync(jac, c->A.jac_out, c->sumG2 * sizeof(double), hipMemcpyDeviceToHost, st));

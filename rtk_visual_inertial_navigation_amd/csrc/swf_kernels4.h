@@ -37,6 +37,9 @@ struct CompArgs {
     const double* outer; const double* Nv;             // this call: [n][32] = pose_i sb_i pose_j sb_j, [sum N]
     int want_jac;
     double* res_out; double* jac_out;                  // [sum G], [sum G G] (row-major, upper triangular = L^T)
+    double* Jw; double* rw;                            // scratch: whitened IMU Jacobians [sum M + n][450] and residuals [sum M + n][16]
+    const int* iq_f; const int* iq_k; int n_iq;        // the chains' IMU factors, flattened: owner factor and position k (0 .. M)
+    int* todo;                                         // [n] set by k_comp_prep: 1 = this launch re-eliminates the factor
 };
 
 // x (-) x0 = sgn [p - p0, +-2 vec(q0^-1 q), sb - sb0]   (GetInc :654-670, UpdateDeltaValues :560-598 with sgn = -1)
@@ -49,9 +52,11 @@ __device__ __forceinline__ void co_inc15(const double* P, const double* Bv, cons
     for (int k = 0; k < 9; k++) dx[6 + k] = sgn * (Bv[k] - B0[k]);
 }
 
-__global__ void __launch_bounds__(256) k_composite(CompArgs A) {
+// phase 1 of an evaluation: increments, the cost-only answer, or the back-substitution of the hidden epochs
+__global__ void __launch_bounds__(256) k_comp_prep(CompArgs A) {
     const int f = blockIdx.x, t = threadIdx.x;
-    if (f >= A.n || (A.active && !A.active[f])) return;
+    if (f >= A.n) return;
+    if (A.active && !A.active[f]) { if (t == 0) A.todo[f] = 0; return; }
     const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
     const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
     // running elimination: blocks (Pose1, Pose2, N, Pose0) x (>=), reference enum HessianOrder.  LDS is what bounds the number of
@@ -67,7 +72,7 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
     __shared__ double scratch[1260];                                       // IMU phase: sU | sJ ; elimination phase: Ainv | L | T2 | T0 | TN
     double* const sU = scratch; double* const sJ = scratch + 450;
     double* const sAinv = scratch; double* const sL = scratch + 225; double* const T2 = scratch + 450; double* const T0 = scratch + 675; double* const TN = scratch + 900;
-    __shared__ double sRaw[16], sRes[16], sSI[225], sPr[SWF_PRE_SQRTINFO + 6], sSt[32];
+    __shared__ double sRes[16];
     __shared__ double sz[CO_MAXG], sdinv[CO_MAXG];
     __shared__ double sOut[32], sNv[CO_MAXN], sOld[32], sNold[CO_MAXN], sDx[16], sRm[16];
     __shared__ int sBad;
@@ -91,8 +96,10 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
             for (int a = k; a < G; a++) { double inc = a < 15 ? dl0[a] : a < 30 ? dl2[a - 15] : dlN[a - 30]; s += Ld[(size_t)a * G + k] * inc; }
             A.res_out[g0 + k] = A.r0[g0 + k] - s;
         }
+        if (t == 0) A.todo[f] = 0;
         return;
     }
+    if (t == 0) A.todo[f] = 1;
     if (hist && update) {
         // UpdateHiddenState: newest epoch first; delta5[Pose2] becomes the epoch's own increment for its older neighbour
         for (int i = M - 1; i >= 0; i--) {
@@ -122,6 +129,78 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
         }
         __threadfence_block();
     }
+}
+
+// phase 2: every IMU factor of every chain that re-eliminates, IMUFactor::Evaluate2 — 8 factors per workgroup, the four un-whitened
+// parts on one lane each (part p on wave p, as in k_eval_imu), then 32 lanes per factor whiten; whitened J (15 x 30) and r to scratch
+__global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
+    __shared__ double U[8][450], raw[8][16], st[8][32], pr[8][SWF_PRE_SQRTINFO + 6];
+    const int t = threadIdx.x, fl = t >> 5, sub = t & 31;
+    const int q = blockIdx.x * 8 + fl;
+    const bool valid = q < A.n_iq;
+    const int f = A.iq_f[valid ? q : A.n_iq - 1], k = A.iq_k[valid ? q : A.n_iq - 1];
+    const bool act = valid && A.todo[f];
+    const int M = A.M[f], e0 = A.e_off[f];
+    const double* pre = A.pre + (size_t)(e0 + f + k) * SWF_PRE_DOUBLES;
+    if (act) {
+        const double* outer = A.outer + (size_t)f * 32;
+        {
+            int sl = sub < 7 ? 0 : sub < 16 ? 1 : sub < 23 ? 2 : 3, o = sub < 7 ? sub : sub < 16 ? sub - 7 : sub < 23 ? sub - 16 : sub - 23;
+            int hidx = sl < 2 ? k - 1 : k;                  // older state (frame_i for k = 0) / newer state (frame_j for k = M)
+            double v;
+            if (hidx < 0) v = outer[(sl == 0 ? 0 : 7) + o];
+            else if (hidx >= M) v = outer[(sl == 2 ? 16 : 23) + o];
+            else v = (sl & 1) ? A.sb[(size_t)(e0 + hidx) * 9 + o] : A.pose[(size_t)(e0 + hidx) * 7 + o];
+            st[fl][sub] = v;
+        }
+        for (int e = sub; e < SWF_PRE_SQRTINFO; e += 32) pr[fl][e] = pre[e];
+        if (sub < 6) pr[fl][SWF_PRE_SQRTINFO + sub] = A.pbgw[(size_t)f * 6 + sub];
+        for (int e = sub; e < 450; e += 32) U[fl][e] = 0.0;
+    }
+    __syncthreads();
+    if ((t & 63) < 8) {
+        int fq = t & 63, q2 = blockIdx.x * 8 + fq;
+        if (q2 < A.n_iq && A.todo[A.iq_f[q2]])
+            imu_unwhitened(st[fq], st[fq] + 7, st[fq] + 16, st[fq] + 23, pr[fq], pr[fq] + SWF_PRE_SQRTINFO, pr[fq] + SWF_PRE_SQRTINFO + 3, raw[fq], U[fq], true, t >> 6);
+    }
+    __syncthreads();
+    if (!act) return;
+    const double* SI = pre + SWF_PRE_SQRTINFO;              // upper triangular
+    for (int e = sub; e < 465; e += 32) {
+        if (e < 450) {
+            int row = e / 30, col = e - row * 30;
+            double a = 0;
+            for (int j = row; j < 15; j++) a += SI[row * 15 + j] * U[fl][j * 30 + col];
+            A.Jw[(size_t)(e0 + f + k) * 450 + e] = a;
+        } else {
+            int row = e - 450; double a = 0;
+            for (int j = 0; j < 15; j++) a += SI[row * 15 + j] * raw[fl][j];
+            A.rw[(size_t)(e0 + f + k) * 16 + row] = a;
+        }
+    }
+}
+
+// phase 3: re-elimination of the hidden epochs from the whitened IMU Jacobians of phase 2, remainder, square root
+__global__ void __launch_bounds__(256) k_comp_elim(CompArgs A) {
+    const int f = blockIdx.x, t = threadIdx.x;
+    if (f >= A.n || !A.todo[f]) return;
+    const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
+    const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
+    __shared__ double pool[6 * 225 + 3 * 15 * CO_MAXN + CO_MAXN * CO_MAXN];            // ten elimination blocks, later the dense remainder + rhs row
+    double* const H00 = pool; double* const H01 = pool + 225; double* const H03 = pool + 450; double* const H11 = pool + 675;
+    double* const H13 = pool + 900; double* const H33 = pool + 1125; double* const H0N = pool + 1350; double* const H1N = H0N + 15 * CO_MAXN;
+    double* const HN3 = H1N + 15 * CO_MAXN; double* const HNN = HN3 + 15 * CO_MAXN;
+    double* const sD = pool;
+    __shared__ double r0b[15], r1b[15], rNb[CO_MAXN], r3b[15];
+    __shared__ double scratch[1260];                                       // sJ ; then Ainv | L | T2 | T0 | TN
+    double* const sJ = scratch + 450;
+    double* const sAinv = scratch; double* const sL = scratch + 225; double* const T2 = scratch + 450; double* const T0 = scratch + 675; double* const TN = scratch + 900;
+    __shared__ double sRes[16], sdinv[CO_MAXG], sOut[32], sNv[CO_MAXN], sDx[16];
+    __shared__ int sBad;
+    if (t < 32) sOut[t] = A.outer[(size_t)f * 32 + t];
+    if (t < N) sNv[t] = A.Nv[n0 + t];
+    if (t == 0) sBad = 0;
+    __syncthreads();
     // ---- re-elimination at the current outer / hidden states
     for (int e = t; e < 225; e += 256) { H00[e] = 0; H01[e] = 0; H03[e] = 0; H11[e] = 0; H13[e] = 0; H33[e] = 0; }
     for (int e = t; e < 15 * N; e += 256) { H0N[e] = 0; H1N[e] = 0; HN3[e] = 0; }
@@ -131,32 +210,8 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
     if (t < N) { double s = A.rhsN[n0 + t]; for (int k = 0; k < N; k++) s += HNN[t * N + k] * sNv[k]; rNb[t] = s; }       // UpdateRhsN
     // IMU factor k of the chain links state k-1 -> k (k = 0: frame_i -> e_0, k = M: e_M-1 -> frame_j)
     for (int k = 0; k <= M; k++) {
-        const double* pre = A.pre + (size_t)(e0 + f + k) * SWF_PRE_DOUBLES;
-        // stage the two states, the record head, sqrt_info; zero the sparse Jacobian scratch
-        if (t < 32) {
-            int sl = t < 7 ? 0 : t < 16 ? 1 : t < 23 ? 2 : 3, o = t < 7 ? t : t < 16 ? t - 7 : t < 23 ? t - 16 : t - 23;
-            bool first = sl < 2;                        // state k-1 (frame_i for k = 0), else state k (frame_j for k = M)
-            int hidx = first ? k - 1 : k;
-            double v;
-            if (hidx < 0) v = (sl == 0) ? Pi[o] : Bi[o];
-            else if (hidx >= M) v = (sl == 2) ? Pj[o] : Bj[o];
-            else v = (sl & 1) ? A.sb[(size_t)(e0 + hidx) * 9 + o] : A.pose[(size_t)(e0 + hidx) * 7 + o];
-            sSt[t] = v;
-        }
-        for (int e = t; e < SWF_PRE_SQRTINFO; e += 256) sPr[e] = pre[e];
-        if (t < 6) sPr[SWF_PRE_SQRTINFO + t] = A.pbgw[(size_t)f * 6 + t];
-        for (int e = t; e < 225; e += 256) sSI[e] = pre[SWF_PRE_SQRTINFO + e];
-        for (int e = t; e < 450; e += 256) sU[e] = 0.0;
-        __syncthreads();
-        if ((t & 63) == 0) imu_unwhitened(sSt, sSt + 7, sSt + 16, sSt + 23, sPr, sPr + SWF_PRE_SQRTINFO, sPr + SWF_PRE_SQRTINFO + 3, sRaw, sU, true, t >> 6);
-        __syncthreads();
-        if (t < 15) { double s = 0; for (int q = 0; q < 15; q++) s += sSI[t * 15 + q] * sRaw[q]; sRes[t] = s; }
-        for (int e = t; e < 450; e += 256) {
-            int row = e / 30, col = e - row * 30;
-            double a = 0;
-            for (int q = row; q < 15; q++) a += sSI[row * 15 + q] * sU[q * 30 + col];       // sqrt_info is upper triangular
-            sJ[e] = a;
-        }
+        for (int e = t; e < 450; e += 256) sJ[e] = A.Jw[(size_t)(e0 + f + k) * 450 + e];
+        if (t < 15) sRes[t] = A.rw[(size_t)(e0 + f + k) * 16 + t];
         __syncthreads();
         // JacobianResidualUpdateHessianRhs: Ja = columns 0..14 (older state), Jb = columns 15..29 (newer state)
         //   k = 0 : blocks (Pose0, Pose1):  H33 += Ja^T Ja, H03 += Jb^T Ja, H00 += Jb^T Jb
@@ -214,10 +269,12 @@ __global__ void __launch_bounds__(256) k_composite(CompArgs A) {
             __syncthreads();
         }
         if (t < 15) {
-            double z[15];
-            for (int a = 0; a < 15; a++) { double s = (a == t) ? 1.0 : 0.0; for (int q = 0; q < a; q++) s -= sL[a * 15 + q] * z[q]; z[a] = s / sL[a * 15 + a]; }
-            for (int a = 14; a >= 0; a--) { double s = z[a]; for (int q = a + 1; q < 15; q++) s -= sL[q * 15 + a] * z[q]; z[a] = s / sL[a * 15 + a]; }
-            for (int a = 0; a < 15; a++) sAinv[a * 15 + t] = z[a];
+            // column t of the inverse, solved in place in LDS (sAinv column t is this thread's alone)
+            double* z = sAinv + t;                          // z[a] = sAinv[a * 15 + t]
+#pragma unroll 1
+            for (int a = 0; a < 15; a++) { double s = (a == t) ? 1.0 : 0.0; for (int q = 0; q < a; q++) s -= sL[a * 15 + q] * z[q * 15]; z[a * 15] = s / sL[a * 15 + a]; }
+#pragma unroll 1
+            for (int a = 14; a >= 0; a--) { double s = z[a * 15]; for (int q = a + 1; q < 15; q++) s -= sL[q * 15 + a] * z[q * 15]; z[a * 15] = s / sL[a * 15 + a]; }
         }
         __syncthreads();
         // T_blk = H0blk^T Ainv for blk = Pose2 (15), N, Pose0 (15)
