@@ -7,7 +7,7 @@
 // (iii) turns the remaining (30+N)^2 system over [pose_i sb_i | pose_j sb_j | N ambiguities] into a residual / Jacobian pair
 // (UpdateSchurComponent :454-488); cost-only evaluations use the linear model r = r_lin - J INC (:490-497).
 //
-// Here: one 256-thread workgroup per composite factor, the ten Hessian blocks of the running elimination in LDS, the epochs
+// Here: three kernels (k_comp_prep, k_comp_imu, k_comp_elim); in the elimination one 256-thread workgroup per factor, the ten Hessian blocks in LDS, the epochs
 // sequential (they are a chain), everything inside an epoch spread over the threads; composite factors of all windows in
 // one launch.  The square root of the (30+N)^2 remainder is its Cholesky factor (J = L^T, r = L^-1 rhs): J^T J and J^T r —
 // all a Gauss-Newton solver consumes — are those of the reference's eigen square root whenever the remainder is positive
