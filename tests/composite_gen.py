@@ -48,10 +48,13 @@ def _gnss_priors(rng, M, N):
     return dict(Hpp=Hpp, HpN=HpN, rhs_p=rhs_p, HNN=HNN, rhsN=rhsN)
 
 
-def make_window(rng, K, M, N, dt=0.1):
+def make_window(rng, K, M, N, dt=0.1, F=0):
     """A sliding window whose K visual frames are linked ONLY by composite IMU-GNSS factors (M hidden GNSS epochs per gap, N
     shared ambiguities), plus the gauge prior on frame 0 and the dummy anchor: what an RTK window of the reference looks like
-    once UpdateImuGnssFactor (R/swf/swf.cpp:713-730) has folded the GNSS epochs away.  Returns a FlatWindow."""
+    once UpdateImuGnssFactor (R/swf/swf.cpp:713-730) has folded the GNSS epochs away.  F > 0 adds F landmarks observed from
+    2..K consecutive frames through a constant camera extrinsic (projection factors + Cauchy loss, landmarks in elimination
+    group 0), so the composite factors' static cliques meet the landmark Schur complement on the same pose blocks.
+    Returns a FlatWindow."""
     from rtk_visual_inertial_navigation_amd.flat import FlatWindow
     T = K + (K - 1) * M
     pose_t, sb_t, pre, pbg, gw = _chain_states(rng, T, dt)
@@ -71,9 +74,37 @@ def make_window(rng, K, M, N, dt=0.1):
         for k_ in ("Hpp", "HpN", "rhs_p", "HNN", "rhsN"):
             comp[k_].append(pr[k_])
         comp["pre"].append(pre[vis[g]:vis[g] + M + 1])
-    n_blocks = 2 * K + 1 + N
-    bid_pose = lambda i: i; bid_sb = lambda i: K + i; bid_sc = lambda i: 2 * K + i
-    order_block = [bid_sc(0)]; order_group = [0]
+    # optional visual part: extrinsic = pose pool entry K (constant), landmarks in front of the cameras
+    n_pose = K + (1 if F else 0)
+    lm = np.zeros((F, 3)); proj_idx, proj_uv = [], []
+    if F:
+        ric = synth.BODY_T_CAM0[:3, :3]; tic = synth.BODY_T_CAM0[:3, 3]
+        qic = synth.R_to_q(ric); ric = synth.q_to_R(qic)
+        pose = np.vstack([pose, np.concatenate([tic, qic])[None, :]])
+        Rw = [synth.q_to_R(pose_t[v, 3:]) for v in vis]; Pw = [pose_t[v, :3] for v in vis]
+        for f in range(F):
+            for _ in range(200):
+                L = int(rng.integers(2, K + 1)); start = int(rng.integers(0, K - L + 1)); mid = start + L // 2
+                depth = rng.uniform(4.0, 30.0); uvn = rng.uniform(-0.4, 0.4, 2)
+                pc = np.array([uvn[0] * depth, uvn[1] * depth, depth])
+                X = Rw[mid] @ (ric @ pc + tic - pbg) + Pw[mid]
+                obs, ok = [], True
+                for j in range(start, start + L):
+                    pcj = ric.T @ (Rw[j].T @ (X - Pw[j]) + pbg - tic)
+                    if pcj[2] < 1.0 or abs(pcj[0] / pcj[2]) > 1.2 or abs(pcj[1] / pcj[2]) > 1.0:
+                        ok = False; break
+                    obs.append((j, pcj[0] / pcj[2], pcj[1] / pcj[2]))
+                if ok:
+                    break
+            lm[f] = X + rng.normal(0, 0.05, 3)
+            for (j, u, v) in obs:
+                proj_idx.append([j, K, f]); proj_uv.append([u + rng.normal(0, 1e-3), v + rng.normal(0, 1e-3)])
+    n_blocks = n_pose + K + F + 1 + N
+    bid_pose = lambda i: i; bid_sb = lambda i: n_pose + i; bid_lm = lambda i: n_pose + K + i; bid_sc = lambda i: n_pose + K + F + i
+    is_const = np.zeros(n_blocks, np.uint8)
+    if F:
+        is_const[K] = 1
+    order_block = [bid_sc(0)] + [bid_lm(f) for f in range(F)]; order_group = [0] * (1 + F)
     grp = 1
     for k in range(K):
         for b in (bid_pose(k), bid_sb(k)):
@@ -83,15 +114,16 @@ def make_window(rng, K, M, N, dt=0.1):
     d = np.concatenate([np.full(3, 2e2), np.full(3, 2e2), np.full(3, 1e1), np.full(3, 1e1), np.full(3, 1e2)])
     cat = lambda key: np.concatenate([np.asarray(a, np.float64).ravel() for a in comp[key]]) if comp[key] else np.zeros(0)
     return FlatWindow(
-        pose=pose, sb=sb, lm=np.zeros((0, 3)), sc=sc, is_const=np.zeros(n_blocks, np.uint8),
+        pose=pose, sb=sb, lm=lm, sc=sc, is_const=is_const,
         order_block=np.array(order_block, np.int32), order_group=np.array(order_group, np.int32), n_tail=0,
+        proj_idx=np.array(proj_idx, np.int32).reshape(-1, 3), proj_uv=np.array(proj_uv).reshape(-1, 2),
         sp_idx=np.array([0], np.int32), sp_w=np.array([1.0]),
         prior_nblk=np.array([2], np.int32), prior_dim=np.array([15], np.int32), prior_blk=np.array([bid_pose(0), bid_sb(0)], np.int32),
         prior_J=np.diag(d), prior_r0=np.zeros(15), prior_x0=np.concatenate([pose[0], sb[0]]),
         comp_M=np.array(comp["M"], np.int32), comp_N=np.array(comp["N"], np.int32), comp_idx=np.concatenate([np.array(i, np.int32) for i in comp["idx"]]),
         comp_pose=cat("pose"), comp_sb=cat("sb"), comp_pose_lin=cat("pose_lin"), comp_sb_lin=cat("sb_lin"), comp_Hpp=cat("Hpp"), comp_HpN=cat("HpN"),
         comp_rhs_p=cat("rhs_p"), comp_HNN=cat("HNN"), comp_rhsN=cat("rhsN"), comp_pre=cat("pre"),
-        pbg=pbg, gw=gw, base=np.zeros(3), meta=dict(K=K, M=M, N=N))
+        pbg=pbg, gw=gw, base=np.zeros(3), meta=dict(K=K, M=M, N=N, F=F))
 
 
 def _chain_states(rng, K, dt=0.1):

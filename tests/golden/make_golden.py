@@ -20,6 +20,8 @@ CASES = {
     "vi_k4_f12": dict(config_id=2, K=4, F=12, S=0, seed=101),
     "rtk_k5_f16_s4": dict(config_id=3, K=5, F=16, S=4, seed=202),
     "dense_prior_k14_f30_s4": dict(config_id=5, K=14, F=30, S=4, seed=303),
+    # frames linked by composite IMU-GNSS factors (3 hidden GNSS epochs per gap, 5 ambiguities) + 24 landmarks: tests/composite_gen.py
+    "composite_k4_m3_n5_f24": dict(composite=dict(K=4, M=3, N=5, F=24), seed=404),
 }
 ITERS = 6
 
@@ -43,8 +45,15 @@ def load_case(path):
 
 if __name__ == "__main__":
     import oracle_binding as ob
+    force = "--force" in sys.argv
     for name, kw in CASES.items():
-        w0 = synth.make_window(**kw)
+        if os.path.exists(os.path.join(HERE, name + ".npz")) and not force:
+            print(name, "exists (use --force to re-mint)"); continue
+        if "composite" in kw:
+            import composite_gen as cg
+            w0 = cg.make_window(np.random.default_rng(kw["seed"]), **kw["composite"])
+        else:
+            w0 = synth.make_window(**kw)
         w = w0.copy()
         sm, ex = ob.solve(w, default_options(max_num_iterations=ITERS))
         wa = w0.copy()
@@ -54,7 +63,7 @@ if __name__ == "__main__":
                     ok=np.array([r["step_is_successful"] for r in rows]),
                     radius=np.array([r["trust_region_radius"] for r in rows]),
                     step_norm=np.array([r["step_norm"] for r in rows]),
-                    pose=w.a["pose"], sb=w.a["sb"], lm=w.a["lm"], sc=w.a["sc"],
+                    pose=w.a["pose"], sb=w.a["sb"], lm=w.a["lm"], sc=w.a["sc"], comp_pose=w.a["comp_pose"], comp_sb=w.a["comp_sb"],
                     S0=ea["S"], rhs0=ea["rhs"], L0=ea["L"], termination=sm.termination)
         save_case(os.path.join(HERE, name + ".npz"), w0, gold)
         print(name, os.path.getsize(os.path.join(HERE, name + ".npz")), "bytes; final cost", sm.final_cost)

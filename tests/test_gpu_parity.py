@@ -129,6 +129,8 @@ def test_golden_fixtures():
         assert np.abs(costs - gold["costs"]).max() <= 5e-7 * np.abs(gold["costs"]).min() + 1e-7 * 0 or rel(costs / gold["costs"], np.ones_like(costs)) < 5e-7
         assert np.array_equal(np.array([r["step_is_successful"] for r in sm.rows()]), gold["ok"])
         assert np.abs(w.a["pose"] - gold["pose"]).max() < 1e-6
+        if "comp_pose" in gold and gold["comp_pose"].size:
+            assert np.abs(w.a["comp_pose"] - gold["comp_pose"]).max() < 1e-6 and np.abs(w.a["comp_sb"] - gold["comp_sb"]).max() < 1e-6
         bs.close()
 
 
@@ -607,8 +609,9 @@ def test_windows_with_composite_factors_match_oracle_solver():
     itself updates) written back; batch == single bit for bit; a second solve continues from the written-back state."""
     import composite_gen as cg
     rng = np.random.default_rng(44)
-    shapes = [(3, 2, 4), (5, 4, 10), (4, 9, 6), (6, 1, 0), (3, 12, 24)]
-    wins = [cg.make_window(rng, K, M, N) for (K, M, N) in shapes]
+    shapes = [(3, 2, 4, 0), (5, 4, 10, 0), (4, 9, 6, 0), (6, 1, 0, 0), (3, 12, 24, 0),
+              (5, 3, 6, 40), (9, 2, 8, 120)]            # the last two: + landmarks on the same poses (static composite cliques next to the landmark Schur complement)
+    wins = [cg.make_window(rng, K, M, N, F=F) for (K, M, N, F) in shapes]
     singles = []
     for w in wins:
         wo, wg = w.copy(), w.copy()
@@ -630,7 +633,7 @@ def test_windows_with_composite_factors_match_oracle_solver():
     bs = solver.BatchSolver(batch); sms = bs.solve(default_options(max_num_iterations=8))
     for (wg, costs), wb, sm in zip(singles, batch, sms):
         assert [r["cost"] for r in sm.rows()] == costs
-        for k in ("pose", "sb", "sc", "comp_pose", "comp_sb"):
+        for k in ("pose", "sb", "lm", "sc", "comp_pose", "comp_sb"):
             assert np.array_equal(wg.a[k], wb.a[k]), k
     bs.reset_state(); sms2 = bs.solve(default_options(max_num_iterations=8))
     assert [[r["cost"] for r in s.rows()] for s in sms2] == [[r["cost"] for r in s.rows()] for s in sms]   # reset restores the hidden epochs
