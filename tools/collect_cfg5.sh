@@ -1,0 +1,37 @@
+#!/bin/bash
+# BASELINE config 5 (stress: 40 keyframes / 1000 features / 20 satellites / dense prior, single window) under rocprofv3:
+#   tools/collect_cfg5.sh <out_dir>
+# kernel trace + the HBM (FETCH_SIZE, WRITE_SIZE: separate passes) and fp64 matrix-core counters, summarised per kernel.
+set -u
+OUT=$(realpath -m "${1:-gpurun_out/prof}")
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/swf5 && mkdir -p /tmp/swf5
+export PYTHONPATH="$ROOT"
+( cd "$ROOT" && python tests/gpu_cfg5_prof.py ) > "$OUT/cfg5_single_window.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swf5/kt -o k -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/kt.log 2>&1
+cp "$(find /tmp/swf5/kt -name '*kernel_stats.csv' | head -1)" "$OUT/cfg5_kernel_stats.csv"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d /tmp/swf5/pmc_$C -o p -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/pmc_$C.log 2>&1
+done
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swf5/pmc_mfma -o p -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/pmc_mfma.log 2>&1
+python "$ROOT/tools/summarize_mfma_pmc.py" "$(find /tmp/swf5/pmc_mfma -name '*counter_collection.csv' | head -1)" "$OUT/cfg5_pmc_mfma.json"
+python - "$OUT" <<'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = {"note": "BASELINE cfg5 (one window: 40 keyframes, 1000 features, 20000 observations, 20 satellites, 107-dim dense prior; n_red = 440), "
+               "tests/gpu_cfg5_run.py = 3 solves of 8 dogleg iterations; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; unit KB; "
+               "gfx950: hbm_read_bytes ~= 2 * FETCH_SIZE * 1024 for streaming reads (MI355X_MICROARCH.md).  A single window lives in L2 / Infinity Cache: "
+               "these are traffic counts, not a bandwidth claim."}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"/tmp/swf5/pmc_{c}/**/*counter_collection.csv", recursive=True)
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            if r.get("Counter_Name") != c: continue
+            a = acc[r["Kernel_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    res[c] = {k: {"launches": v[0], "avg_kb_per_launch": v[1] / max(1, v[0])} for k, v in acc.items()}
+json.dump(res, open(out + "/cfg5_pmc_fetch_write.json", "w"), indent=1)
+PY
+head -14 "$OUT/cfg5_kernel_stats.csv" | cut -c1-150
