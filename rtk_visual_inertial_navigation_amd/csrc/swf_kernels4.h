@@ -212,6 +212,8 @@ __global__ void __launch_bounds__(256) k_comp_elim(CompArgs A) {
     for (int k = 0; k <= M; k++) {
         for (int e = t; e < 450; e += 256) sJ[e] = A.Jw[(size_t)(e0 + f + k) * 450 + e];
         if (t < 15) sRes[t] = A.rw[(size_t)(e0 + f + k) * 16 + t];
+        if (k > 0 && t == 255)       // GetInc of the epoch that this factor completes (its GNSS prior is added in the same pass below)
+            co_inc15(A.pose + (size_t)(e0 + k - 1) * 7, A.sb + (size_t)(e0 + k - 1) * 9, A.pose_lin + (size_t)(e0 + k - 1) * 7, A.sb_lin + (size_t)(e0 + k - 1) * 9, 1.0, sDx);
         __syncthreads();
         // JacobianResidualUpdateHessianRhs: Ja = columns 0..14 (older state), Jb = columns 15..29 (newer state)
         //   k = 0 : blocks (Pose0, Pose1):  H33 += Ja^T Ja, H03 += Jb^T Ja, H00 += Jb^T Jb
@@ -233,12 +235,10 @@ __global__ void __launch_bounds__(256) k_comp_elim(CompArgs A) {
                 if (t < 15) ra[j] += s; else rb[j] += s;
             }
         }
-        __syncthreads();
-        if (k == 0) continue;
-        // ---- epoch i = k - 1 is complete: its GNSS prior, then eliminate it
+        if (k == 0) { __syncthreads(); continue; }
+        // ---- epoch i = k - 1 is complete: its GNSS prior in the same pass (every element below is touched by the thread that
+        // accumulated it above), then eliminate it
         const int i = k - 1;
-        if (t == 0) co_inc15(A.pose + (size_t)(e0 + i) * 7, A.sb + (size_t)(e0 + i) * 9, A.pose_lin + (size_t)(e0 + i) * 7, A.sb_lin + (size_t)(e0 + i) * 9, 1.0, sDx);
-        __syncthreads();
         const double* Hpp = A.Hpp + (size_t)(e0 + i) * 225; const double* HpN = A.HpN + pn0 + (size_t)i * 15 * N;
         if (t < 15) {                                   // UpdateRhsPose + RhsUpdateRhs
             double s = A.rhs_p[(size_t)(e0 + i) * 15 + t];
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) k_comp_elim(CompArgs A) {
             for (int e = t; e < 15 * N; e += 256) s_N[e] = H0N[e];
             if (t < 15) A.rhsmn[(size_t)(e0 + i) * 15 + t] = r0b[t];
         }
-        __syncthreads();
+        // (same element -> same thread in the save above and the shift below: no barrier between them)
         for (int e = t; e < 225; e += 256) { H00[e] = H11[e]; H11[e] = 0; H03[e] = H13[e]; H13[e] = 0; H01[e] = 0; }
         for (int e = t; e < 15 * N; e += 256) { H0N[e] = H1N[e]; H1N[e] = 0; }
         if (t < 15) { r0b[t] = r1b[t]; r1b[t] = 0; }
