@@ -183,6 +183,18 @@ int swf_triangulate_batch(const double* Ps, const double* Rs, int32_t n_frames, 
                           const double pbg[3], const int32_t* start_frame, const double* pt0, const double* pt1, int32_t n,
                           double init_depth, double* depth, double* pts_world, int32_t on_device, void* stream);
 
+/* Inverse-depth projection factors for a batch, one lane per factor — an evaluator with parity against the
+ * oracle; the Schur path of the solver takes world-point landmarks only (the reference's default, USE_INVERSE_DEPTH 0).
+ *   kind [n]      0 ProjectionTwoFrameOneCamFactor (R/factor/projection_factor.cpp:179-256): pose_i, pose_j, ex, lambda
+ *                 1 ProjectionTwoFrameTwoCamFactor (:77-166): pose_i, pose_j, ex, ex2, lambda
+ *                 2 ProjectionOneFrameTwoCamFactor (:269-329): ex, ex2, lambda
+ *   idx  [n][5]   pose_i, pose_j, ex, ex2 (rows of poses [n_pose][7]; ignored where the kind has none), lambda (row of lambda [n_lambda])
+ *   pts  [n][6]   pts_i (3), pts_j (3): the normalised observations in the anchor and in the second view
+ *   r    [n][2];  J [n][50] = d r / d pose_i (2x6, local) | pose_j | ex | ex2 | lambda (2); blocks a kind does not have are zero */
+int swf_eval_inverse_depth_batch(const int32_t* kind, const int32_t* idx, int32_t n, const double* poses, int32_t n_pose,
+                                 const double* lambda, int32_t n_lambda, const double* pts, double sqrt_info, const double pbg[3],
+                                 double* r, double* J, int32_t on_device, void* stream);
+
 /* =====================================================================================
  * Composite IMU-GNSS factors as a batched, stateful device operator
  *

@@ -517,6 +517,81 @@ static void pose_plus(const double* x, const double* d, double* o) {
 }
 void oracle_pose_plus(const double* x, const double* d, double* o) { pose_plus(x, d, o); }
 
+/* ------------------------------------------------------------------ inverse-depth projection factors
+ * ProjectionTwoFrameOneCamFactor (R/factor/projection_factor.cpp:179-256), ProjectionTwoFrameTwoCamFactor (:77-166),
+ * ProjectionOneFrameTwoCamFactor (:269-329): the landmark is an inverse depth along its first observation pts_i in the anchor
+ * frame i.  kind 0 = two frames one camera  (pose_i, pose_j, ex, lambda)
+ *        kind 1 = two frames two cameras (pose_i, pose_j, ex, ex2, lambda)
+ *        kind 2 = one frame two cameras  (ex, ex2, lambda)  — no lever arm, no frame poses
+ * sqrt_info is the reference's static 2x2 (a multiple of the identity, FOCAL_LENGTH / 1.5).  Jacobians 2x6 (local pose), 2x1. */
+void oracle_eval_proj_idepth(int kind, const double* Pi_, const double* Pj_, const double* ex, const double* ex2, double inv_dep,
+                             const double* pts_i, const double* pts_j, double sqrt_info, const double* pbg,
+                             double* r, double* Ji /*2x6*/, double* Jj /*2x6*/, double* Jex /*2x6*/, double* Jex2 /*2x6*/, double* Jl /*2*/) {
+    const double* e2 = (kind == 0) ? ex : ex2;                       /* the camera the point is projected into */
+    double pci[3] = { pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep }, pimu_i[3], pimu_j[3], t[3], pcj[3], q_inv[4];
+    qrot(ex + 3, pci, pimu_i);
+    for (int k = 0; k < 3; k++) pimu_i[k] += ex[k] - (kind == 2 ? 0.0 : pbg[k]);
+    if (kind == 2) { for (int k = 0; k < 3; k++) pimu_j[k] = pimu_i[k]; }
+    else {
+        double w[3];
+        qrot(Pi_ + 3, pimu_i, w);
+        for (int k = 0; k < 3; k++) w[k] += Pi_[k] - Pj_[k];
+        qinv(Pj_ + 3, q_inv); qrot(q_inv, w, pimu_j);
+    }
+    for (int k = 0; k < 3; k++) t[k] = pimu_j[k] + (kind == 2 ? 0.0 : pbg[k]) - e2[k];
+    qinv(e2 + 3, q_inv); qrot(q_inv, t, pcj);
+    double dep = pcj[2];
+    r[0] = sqrt_info * (pcj[0] / dep - pts_j[0]);
+    r[1] = sqrt_info * (pcj[1] / dep - pts_j[1]);
+    if (!Ji && !Jj && !Jex && !Jex2 && !Jl) return;
+    double red[6] = { sqrt_info * (1. / dep), 0, sqrt_info * (-pcj[0] / (dep * dep)), 0, sqrt_info * (1. / dep), sqrt_info * (-pcj[1] / (dep * dep)) };
+    double Ri[9], Rj[9], ric[9], ric2[9], ric2T[9], RjT[9], A[9], B[9], C[9], S[9], M[9];
+    double I3[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    q2R(ex + 3, ric); q2R(e2 + 3, ric2); mat3T(ric2, ric2T);
+    if (kind == 2) { memcpy(Ri, I3, sizeof(I3)); memcpy(Rj, I3, sizeof(I3)); } else { q2R(Pi_ + 3, Ri); q2R(Pj_ + 3, Rj); }
+    mat3T(Rj, RjT);
+    mat3mul(ric2T, RjT, A);                 /* ric2^T Rj^T */
+    mat3mul(A, Ri, B);                      /* ric2^T Rj^T Ri */
+    mat3mul(B, ric, C);                     /* ric2^T Rj^T Ri ric */
+#define RED_OUT(J, COL, MAT, SGN) for (int i_ = 0; i_ < 2; i_++) for (int j_ = 0; j_ < 3; j_++) { double a_ = 0; for (int k_ = 0; k_ < 3; k_++) a_ += red[i_ * 3 + k_] * (SGN) * MAT[k_ * 3 + j_]; J[i_ * 6 + COL + j_] = a_; }
+    if (Ji && kind != 2) {
+        skew(pimu_i, S); mat3mul(B, S, M);
+        RED_OUT(Ji, 0, A, 1.0) RED_OUT(Ji, 3, M, -1.0)
+    }
+    if (Jj && kind != 2) {
+        skew(pimu_j, S); mat3mul(ric2T, S, M);
+        RED_OUT(Jj, 0, A, -1.0) RED_OUT(Jj, 3, M, 1.0)
+    }
+    if (Jex) {
+        if (kind == 0) {
+            /* one camera: the extrinsic enters twice (:232-240) */
+            double T1[9], tmp[3], v[3], w2[3], u[3], S1[9], S2[9], S3[9], L[9];
+            for (int k = 0; k < 9; k++) T1[k] = B[k] - ric2T[k];                 /* ric^T (Rj^T Ri - I) */
+            mat3vec(C, pci, tmp);
+            skew(pci, S1); mat3mul(C, S1, L); skew(tmp, S2);
+            for (int k = 0; k < 3; k++) v[k] = ex[k] - pbg[k];
+            mat3vec(Ri, v, w2); for (int k = 0; k < 3; k++) w2[k] += Pi_[k] - Pj_[k];
+            mat3vec(RjT, w2, u); for (int k = 0; k < 3; k++) u[k] += pbg[k] - ex[k];
+            mat3vec(ric2T, u, v); skew(v, S3);
+            for (int k = 0; k < 9; k++) M[k] = -L[k] + S2[k] + S3[k];
+            RED_OUT(Jex, 0, T1, 1.0) RED_OUT(Jex, 3, M, 1.0)
+        } else {
+            skew(pci, S); mat3mul(C, S, M);
+            RED_OUT(Jex, 0, B, 1.0) RED_OUT(Jex, 3, M, -1.0)
+        }
+    }
+    if (Jex2 && kind != 0) {
+        skew(pcj, S);
+        RED_OUT(Jex2, 0, ric2T, -1.0) RED_OUT(Jex2, 3, S, 1.0)
+    }
+#undef RED_OUT
+    if (Jl) {
+        double v[3];
+        mat3vec(C, pts_i, v);
+        for (int i = 0; i < 2; i++) Jl[i] = (red[i * 3] * v[0] + red[i * 3 + 1] * v[1] + red[i * 3 + 2] * v[2]) * -1.0 / (inv_dep * inv_dep);
+    }
+}
+
 /* ------------------------------------------------------------------ two-view triangulation
  * FeatureManager::triangulate, the >= 2 observations branch (R/feature/feature_manager.cpp:285-316), with
  * triangulatePoint (:148-161): DLT design matrix of the first two observing frames, right singular vector of the

@@ -426,3 +426,147 @@ extern "C" int swf_triangulate_batch(const double* Ps, const double* Rs, int32_t
     cleanup();
     return SWF_OK;
 }
+
+// =====================================================================================================================
+// (3) inverse-depth projection factors, evaluated for a batch, one lane per factor:
+//     ProjectionTwoFrameOneCamFactor (R/factor/projection_factor.cpp:179-256)   kind 0: pose_i, pose_j, ex, lambda
+//     ProjectionTwoFrameTwoCamFactor (:77-166)                                  kind 1: pose_i, pose_j, ex, ex2, lambda
+//     ProjectionOneFrameTwoCamFactor (:269-329)                                 kind 2: ex, ex2, lambda (no lever arm)
+// The reference compiles them out by default (USE_INVERSE_DEPTH 0, R/parameter/parameters.h:25); here they are an evaluator
+// with parity against the oracle, not yet a landmark type of the Schur path (that needs a one-dimensional landmark block
+// whose every observation also touches the anchor pose).
+// =====================================================================================================================
+namespace {
+struct IdepthArgs {
+    const int* kind; const int* idx;           // [n], [n][5] = pose_i, pose_j, ex, ex2, lambda (-1 where the kind has none)
+    const double* poses; const double* lambda; const double* pts;     // [n_pose][7], [n_lambda], [n][6] = pts_i, pts_j
+    double* r; double* J;                      // [n][2], [n][50] = J_pose_i (2x6) | J_pose_j | J_ex | J_ex2 | J_lambda (2)
+    double sqrt_info, pbg[3];
+    int n;
+};
+
+__device__ __forceinline__ void red_out(const double* red, const double* Mx, double sgn, double* Jd, int col) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Jd[i * 6 + col + j] = sgn * (red[i * 3] * Mx[j] + red[i * 3 + 1] * Mx[3 + j] + red[i * 3 + 2] * Mx[6 + j]);
+}
+
+__global__ void __launch_bounds__(128) k_eval_idepth(IdepthArgs A) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= A.n) return;
+    const int kind = A.kind[q];
+    const int* ix = A.idx + (size_t)q * 5;
+    const double zero7[7] = { 0, 0, 0, 0, 0, 0, 1 };
+    const double* Pi = kind == 2 ? zero7 : A.poses + (size_t)ix[0] * 7;
+    const double* Pj = kind == 2 ? zero7 : A.poses + (size_t)ix[1] * 7;
+    const double* ex = A.poses + (size_t)ix[2] * 7;
+    const double* e2 = kind == 0 ? ex : A.poses + (size_t)ix[3] * 7;
+    const double inv_dep = A.lambda[ix[4]];
+    const double* pts_i = A.pts + (size_t)q * 6; const double* pts_j = pts_i + 3;
+    const double lever[3] = { kind == 2 ? 0.0 : A.pbg[0], kind == 2 ? 0.0 : A.pbg[1], kind == 2 ? 0.0 : A.pbg[2] };
+    double pci[3] = { pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep }, pimu_i[3], pimu_j[3], t[3], pcj[3], qi[4], w[3];
+    qrot(ex + 3, pci, pimu_i);
+#pragma unroll
+    for (int k = 0; k < 3; k++) pimu_i[k] += ex[k] - lever[k];
+    if (kind == 2) { pimu_j[0] = pimu_i[0]; pimu_j[1] = pimu_i[1]; pimu_j[2] = pimu_i[2]; }
+    else {
+        qrot(Pi + 3, pimu_i, w);
+#pragma unroll
+        for (int k = 0; k < 3; k++) w[k] += Pi[k] - Pj[k];
+        qinv(Pj + 3, qi); qrot(qi, w, pimu_j);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = pimu_j[k] + lever[k] - e2[k];
+    qinv(e2 + 3, qi); qrot(qi, t, pcj);
+    const double dep = pcj[2], si = A.sqrt_info;
+    A.r[(size_t)q * 2] = si * (pcj[0] / dep - pts_j[0]);
+    A.r[(size_t)q * 2 + 1] = si * (pcj[1] / dep - pts_j[1]);
+    double red[6] = { si * (1. / dep), 0, si * (-pcj[0] / (dep * dep)), 0, si * (1. / dep), si * (-pcj[1] / (dep * dep)) };
+    double Ri[9], Rj[9], ric[9], ric2[9], ric2T[9], RjT[9], Am[9], Bm[9], Cm[9], S[9], M[9];
+    q2R(ex + 3, ric); q2R(e2 + 3, ric2); mat3T(ric2, ric2T);
+    q2R(Pi + 3, Ri); q2R(Pj + 3, Rj);                   // identities for kind 2 (zero7 is the identity pose)
+    mat3T(Rj, RjT);
+    mat3mul(ric2T, RjT, Am); mat3mul(Am, Ri, Bm); mat3mul(Bm, ric, Cm);
+    double* Jq = A.J + (size_t)q * 50;
+    for (int k = 0; k < 50; k++) Jq[k] = 0.0;
+    if (kind != 2) {
+        skew3(pimu_i, S); mat3mul(Bm, S, M);
+        red_out(red, Am, 1.0, Jq, 0); red_out(red, M, -1.0, Jq, 3);
+        skew3(pimu_j, S); mat3mul(ric2T, S, M);
+        red_out(red, Am, -1.0, Jq + 12, 0); red_out(red, M, 1.0, Jq + 12, 3);
+    }
+    if (kind == 0) {
+        double T1[9], tmp[3], v[3], w2[3], u[3], S2[9], S3[9], L[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) T1[k] = Bm[k] - ric2T[k];
+        mat3vec(Cm, pci, tmp);
+        skew3(pci, S); mat3mul(Cm, S, L); skew3(tmp, S2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = ex[k] - A.pbg[k];
+        mat3vec(Ri, v, w2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) w2[k] += Pi[k] - Pj[k];
+        mat3vec(RjT, w2, u);
+#pragma unroll
+        for (int k = 0; k < 3; k++) u[k] += A.pbg[k] - ex[k];
+        mat3vec(ric2T, u, v); skew3(v, S3);
+#pragma unroll
+        for (int k = 0; k < 9; k++) M[k] = -L[k] + S2[k] + S3[k];
+        red_out(red, T1, 1.0, Jq + 24, 0); red_out(red, M, 1.0, Jq + 24, 3);
+    } else {
+        skew3(pci, S); mat3mul(Cm, S, M);
+        red_out(red, Bm, 1.0, Jq + 24, 0); red_out(red, M, -1.0, Jq + 24, 3);
+        skew3(pcj, S);
+        red_out(red, ric2T, -1.0, Jq + 36, 0); red_out(red, S, 1.0, Jq + 36, 3);
+    }
+    double v3[3];
+    mat3vec(Cm, pts_i, v3);
+#pragma unroll
+    for (int i = 0; i < 2; i++) Jq[48 + i] = (red[i * 3] * v3[0] + red[i * 3 + 1] * v3[1] + red[i * 3 + 2] * v3[2]) * -1.0 / (inv_dep * inv_dep);
+}
+}  // namespace
+
+extern "C" int swf_eval_inverse_depth_batch(const int32_t* kind, const int32_t* idx, int32_t n, const double* poses, int32_t n_pose,
+                                            const double* lambda, int32_t n_lambda, const double* pts, double sqrt_info, const double pbg[3],
+                                            double* r, double* J, int32_t on_device, void* stream) {
+    if (!kind || !idx || !poses || !lambda || !pts || !pbg || !r || !J || n < 0 || n_pose <= 0 || n_lambda <= 0)
+        return pi_fail(SWF_E_INVALID, "swf_eval_inverse_depth_batch: bad arguments");
+    if (n == 0) return SWF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    IdepthArgs A{};
+    A.sqrt_info = sqrt_info; A.n = n;
+    for (int k = 0; k < 3; k++) A.pbg[k] = pbg[k];
+    if (on_device) {
+        A.kind = kind; A.idx = idx; A.poses = poses; A.lambda = lambda; A.pts = pts; A.r = r; A.J = J;
+        hipLaunchKernelGGL(k_eval_idepth, dim3((n + 127) / 128), dim3(128), 0, st, A);
+        PI_HIPCHK(hipGetLastError());
+        return SWF_OK;
+    }
+    for (int q = 0; q < n; q++) {
+        const int32_t* ix = idx + (size_t)q * 5;
+        const int k = kind[q];
+        if (k < 0 || k > 2) return pi_fail(SWF_E_INVALID, "swf_eval_inverse_depth_batch: kind must be 0, 1 or 2");
+        auto okp = [&](int v) { return v >= 0 && v < n_pose; };
+        if ((k != 2 && (!okp(ix[0]) || !okp(ix[1]))) || !okp(ix[2]) || (k != 0 && !okp(ix[3])) || ix[4] < 0 || ix[4] >= n_lambda)
+            return pi_fail(SWF_E_INVALID, "swf_eval_inverse_depth_batch: index out of range");
+    }
+    void* bufs[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    auto cleanup = [&]() { for (void* b_ : bufs) (void)hipFree(b_); };
+    const size_t sz[7] = { (size_t)n * sizeof(int), (size_t)n * 5 * sizeof(int), (size_t)n_pose * 7 * sizeof(double), (size_t)n_lambda * sizeof(double),
+                           (size_t)n * 6 * sizeof(double), (size_t)n * 2 * sizeof(double), (size_t)n * 50 * sizeof(double) };
+    const void* src[5] = { kind, idx, poses, lambda, pts };
+#define ID_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return pi_fail(SWF_E_NODEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    for (int b_ = 0; b_ < 7; b_++) ID_TRY(hipMalloc(&bufs[b_], sz[b_]));
+    for (int b_ = 0; b_ < 5; b_++) ID_TRY(hipMemcpyAsync(bufs[b_], src[b_], sz[b_], hipMemcpyHostToDevice, st));
+    A.kind = (const int*)bufs[0]; A.idx = (const int*)bufs[1]; A.poses = (const double*)bufs[2]; A.lambda = (const double*)bufs[3];
+    A.pts = (const double*)bufs[4]; A.r = (double*)bufs[5]; A.J = (double*)bufs[6];
+    hipLaunchKernelGGL(k_eval_idepth, dim3((n + 127) / 128), dim3(128), 0, st, A);
+    ID_TRY(hipGetLastError());
+    ID_TRY(hipMemcpyAsync(r, bufs[5], sz[5], hipMemcpyDeviceToHost, st));
+    ID_TRY(hipMemcpyAsync(J, bufs[6], sz[6], hipMemcpyDeviceToHost, st));
+    ID_TRY(hipStreamSynchronize(st));
+#undef ID_TRY
+    cleanup();
+    return SWF_OK;
+}

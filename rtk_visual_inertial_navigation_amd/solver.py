@@ -47,6 +47,7 @@ EXPORTED = [
     "swf_preintegrate_batch", "swf_triangulate_batch",
     "swf_batch_tail_covariance", "swf_batch_get_tail_covariance", "swf_problem_tail_covariance",
     "swf_composite_create", "swf_composite_evaluate", "swf_composite_hidden", "swf_composite_destroy", "swf_add_imu_gnss",
+    "swf_eval_inverse_depth_batch",
 ]
 
 
@@ -418,6 +419,22 @@ class CompositeBatch:
             self.close()
         except Exception:
             pass
+
+
+def eval_inverse_depth_batch(kind, idx, poses, lam, pts, sqrt_info, pbg):
+    """Inverse-depth projection factors (R/factor/projection_factor.cpp:77-329) for a batch on the device.
+    kind [n] (0 TwoFrameOneCam, 1 TwoFrameTwoCam, 2 OneFrameTwoCam), idx [n][5] = pose_i, pose_j, ex, ex2, lambda rows,
+    poses [P][7], lam [L], pts [n][6].  Returns r [n][2], J [n][50] (pose_i | pose_j | ex | ex2 | lambda)."""
+    k = np.ascontiguousarray(kind, np.int32); ix = np.ascontiguousarray(idx, np.int32).reshape(-1, 5)
+    ps = np.ascontiguousarray(poses, np.float64).reshape(-1, 7); lm = np.ascontiguousarray(lam, np.float64).ravel()
+    pt = np.ascontiguousarray(pts, np.float64).reshape(-1, 6); pb = np.ascontiguousarray(pbg, np.float64)
+    n = k.size
+    r, J = np.zeros((n, 2)), np.zeros((n, 50))
+    pi = C.POINTER(C.c_int32)
+    _chk(lib().swf_eval_inverse_depth_batch(k.ctypes.data_as(pi), ix.ctypes.data_as(pi), C.c_int32(n), ps.ctypes.data_as(_pd), C.c_int32(ps.shape[0]),
+                                            lm.ctypes.data_as(_pd), C.c_int32(lm.size), pt.ctypes.data_as(_pd), C.c_double(sqrt_info), pb.ctypes.data_as(_pd),
+                                            r.ctypes.data_as(_pd), J.ctypes.data_as(_pd), C.c_int32(0), None), "eval_inverse_depth_batch")
+    return r, J
 
 
 def preintegrate_batch(samples, biases, noise):

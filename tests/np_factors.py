@@ -39,6 +39,16 @@ def proj_residual(pose, ex, lm, uv, sqrt_info, pbg):
     return sqrt_info * (pc[:2] / pc[2] - uv)
 
 
+def proj_idepth_residual(kind, Pi, Pj, ex, ex2, inv_dep, pts_i, pts_j, sqrt_info, pbg):
+    """projection_factor.cpp:77-329 residuals; kind 0 TwoFrameOneCam, 1 TwoFrameTwoCam, 2 OneFrameTwoCam."""
+    e2 = ex if kind == 0 else ex2
+    lever = np.zeros(3) if kind == 2 else pbg
+    p_imu_i = q2R(ex[3:]) @ (pts_i / inv_dep) + ex[:3] - lever
+    p_imu_j = p_imu_i if kind == 2 else q2R(Pj[3:]).T @ (q2R(Pi[3:]) @ p_imu_i + Pi[:3] - Pj[:3])
+    pc = q2R(e2[3:]).T @ (p_imu_j + lever - e2[:3])
+    return sqrt_info * (pc[:2] / pc[2] - pts_j[:2])
+
+
 def imu_residual(pi, sbi, pj, sbj, pre, pbg, gw):
     dp, dq, dv = pre[0:3], pre[3:7], pre[7:10]
     lba, lbg = pre[10:13], pre[13:16]

@@ -159,6 +159,15 @@ def preintegrate(samples, ba, bg, acc_n, gyr_n, acc_w, gyr_w):
     return pre
 
 
+def eval_proj_idepth(kind, Pi, Pj, ex, ex2, inv_dep, pts_i, pts_j, sqrt_info, pbg):
+    """Inverse-depth projection factors (row a2): kind 0 TwoFrameOneCam, 1 TwoFrameTwoCam, 2 OneFrameTwoCam."""
+    r, Ji, Jj, Jex, Jex2, Jl = np.zeros(2), np.zeros((2, 6)), np.zeros((2, 6)), np.zeros((2, 6)), np.zeros((2, 6)), np.zeros(2)
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (Pi, Pj, ex, ex2, pts_i, pts_j, pbg)]
+    lib().oracle_eval_proj_idepth(C.c_int(kind), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), C.c_double(inv_dep), _p(a[4]), _p(a[5]),
+                                  C.c_double(sqrt_info), _p(a[6]), _p(r), _p(Ji), _p(Jj), _p(Jex), _p(Jex2), _p(Jl))
+    return r, Ji, Jj, Jex, Jex2, Jl
+
+
 def eval_imu2(pi, sbi, pj, sbj, pre, pbg, gw):
     """IMUFactor::Evaluate2: residual + the two merged 15x15 Jacobians (row a5)."""
     r, J1, J2 = np.zeros(15), np.zeros((15, 15)), np.zeros((15, 15))

@@ -652,3 +652,33 @@ def test_windows_with_composite_factors_match_oracle_solver():
     bad = wins[0].copy(); bad.a["is_const"][0] = 1
     with pytest.raises(solver.SwfError):
         solver.BatchSolver([bad])
+
+
+def test_inverse_depth_projection_factors_match_oracle():
+    """Row a2: the three inverse-depth projection factors evaluated for a batch on the device against the oracle's restatement
+    (same formulas: agreement at rounding level), all kinds mixed in one launch; blocks a kind does not have come back zero."""
+    from test_oracle import _idepth_scene
+    rng = np.random.default_rng(52)
+    pbg = synth.PBG; si = synth.FOCAL_LENGTH / synth.FEATUREWEIGHTINVERSE
+    n = 600
+    poses, lam, kind, idx, pts, ref = [], [], [], [], [], []
+    for q in range(n):
+        k = q % 3
+        Pi, Pj, ex, ex2, pts_i, inv_dep = _idepth_scene(rng)
+        pj = nf.proj_idepth_residual(k, Pi, Pj, ex, ex2, inv_dep, pts_i, np.zeros(3), si, pbg) / si + rng.normal(0, 1e-3, 2)
+        pts_j = np.array([pj[0], pj[1], 1.0])
+        b = len(poses)
+        poses += [Pi, Pj, ex, ex2]; lam.append(inv_dep); kind.append(k); idx.append([b, b + 1, b + 2, b + 3, q]); pts.append(np.concatenate([pts_i, pts_j]))
+        ref.append(ob.eval_proj_idepth(k, Pi, Pj, ex, ex2, inv_dep, pts_i, pts_j, si, pbg))
+    r, J = solver.eval_inverse_depth_batch(kind, idx, np.array(poses), np.array(lam), np.array(pts), si, pbg)
+    for q in range(n):
+        ro, Ji, Jj, Jex, Jex2, Jl = ref[q]
+        k = kind[q]
+        sc = max(1.0, np.abs(Jl).max())
+        assert np.abs(r[q] - ro).max() <= 1e-12 * si
+        got = (J[q, 0:12].reshape(2, 6), J[q, 12:24].reshape(2, 6), J[q, 24:36].reshape(2, 6), J[q, 36:48].reshape(2, 6), J[q, 48:50])
+        exp = (Ji if k != 2 else np.zeros((2, 6)), Jj if k != 2 else np.zeros((2, 6)), Jex, Jex2 if k != 0 else np.zeros((2, 6)), Jl)
+        for g, e in zip(got, exp):
+            assert np.abs(g - e).max() <= 1e-11 * sc, (q, k)
+    with pytest.raises(solver.SwfError):
+        solver.eval_inverse_depth_batch([3], [[0, 1, 2, 3, 0]], np.array(poses[:4]), [0.1], np.zeros((1, 6)), si, pbg)

@@ -114,6 +114,39 @@ def test_spp_and_fixed_integer_factors_vs_numpy_and_fd():
         assert r == nf.fix_residual(na, nb, dat3) and Ja == -dat3[1] and Jb == dat3[1]
 
 
+def _idepth_scene(rng):
+    """Two body poses a short step apart, two camera extrinsics (stereo pair), a point a few metres ahead."""
+    q = lambda s: (lambda v: v / np.linalg.norm(v))(np.concatenate([rng.normal(0, s, 3) / 2, [1.0]]))
+    Pi = np.concatenate([rng.normal(0, 5, 3), q(0.3)]); Pj = nf.pose_plus(Pi, np.concatenate([rng.normal(0, 0.3, 3), rng.normal(0, 0.05, 3)]))
+    qic = synth.R_to_q(synth.BODY_T_CAM0[:3, :3])
+    ex = np.concatenate([synth.BODY_T_CAM0[:3, 3], qic]); ex2 = nf.pose_plus(ex, np.array([0.12, 0.0, 0.0, 0.01, -0.02, 0.005]))
+    pts_i = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3), 1.0]); inv_dep = 1.0 / rng.uniform(3, 25)
+    return Pi, Pj, ex, ex2, pts_i, inv_dep
+
+
+def test_inverse_depth_projection_factors_vs_numpy_and_fd():
+    """Row a2: the three inverse-depth projection factors (projection_factor.cpp:77-329): residuals against the numpy restatement,
+    every Jacobian block against central differences on the manifold."""
+    rng = np.random.default_rng(21)
+    pbg = synth.PBG; si = synth.FOCAL_LENGTH / synth.FEATUREWEIGHTINVERSE
+    for kind in (0, 1, 2):
+        for t in range(4):
+            Pi, Pj, ex, ex2, pts_i, inv_dep = _idepth_scene(rng)
+            f = lambda A, B, E, E2, L: nf.proj_idepth_residual(kind, A, B, E, E2, L[0], pts_i, pts_j, si, pbg)
+            pts_j = np.zeros(3)
+            pts_j = np.concatenate([f(Pi, Pj, ex, ex2, np.array([inv_dep])) / si + rng.normal(0, 1e-3, 2), [1.0]])     # observation = prediction + noise
+            blocks = [Pi, Pj, ex, ex2, np.array([inv_dep])]
+            r, Ji, Jj, Jex, Jex2, Jl = ob.eval_proj_idepth(kind, Pi, Pj, ex, ex2, inv_dep, pts_i, pts_j, si, pbg)
+            assert np.abs(r - f(*blocks)).max() < 1e-9 * si
+            sc = max(1.0, np.abs(Jl).max())
+            if kind != 2:
+                assert np.abs(Ji - nf.fd_jac(f, blocks, 0, 1e-6)).max() < 1e-5 * sc and np.abs(Jj - nf.fd_jac(f, blocks, 1, 1e-6)).max() < 1e-5 * sc
+            assert np.abs(Jex - nf.fd_jac(f, blocks, 2, 1e-6)).max() < 1e-5 * sc
+            if kind != 0:
+                assert np.abs(Jex2 - nf.fd_jac(f, blocks, 3, 1e-6)).max() < 1e-5 * sc
+            assert np.abs(Jl - nf.fd_jac(f, blocks, 4, 1e-7 * inv_dep)[:, 0]).max() < 1e-5 * np.abs(Jl).max()
+
+
 def test_doppler_factor_vs_numpy_and_fd():
     rng = np.random.default_rng(5)
     base = synth.ANCHOR
