@@ -59,27 +59,11 @@ __global__ void __launch_bounds__(256) k_comp_prep(CompArgs A) {
     if (A.active && !A.active[f]) { if (t == 0) A.todo[f] = 0; return; }
     const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
     const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
-    // running elimination: blocks (Pose1, Pose2, N, Pose0) x (>=), reference enum HessianOrder.  LDS is what bounds the number of
-    // factors in flight per CU, so the buffers are packed: the ten blocks share one pool that later holds the dense
-    // remainder (+ its rhs row), the IMU scratch (sU, sJ) aliases the elimination scratch (Ainv, L, T) it never meets.
-    __shared__ double pool[6 * 225 + 3 * 15 * CO_MAXN + CO_MAXN * CO_MAXN];            // 3006 doubles >= (G + 1) G for G <= 54
-    double* const H00 = pool; double* const H01 = pool + 225; double* const H03 = pool + 450; double* const H11 = pool + 675;
-    double* const H13 = pool + 900; double* const H33 = pool + 1125; double* const H0N = pool + 1350; double* const H1N = H0N + 15 * CO_MAXN;
-    double* const HN3 = H1N + 15 * CO_MAXN; double* const HNN = HN3 + 15 * CO_MAXN;
-    double* const sD = pool;
-    __shared__ double r0b[15], r1b[15], rNb[CO_MAXN], r3b[15];
     __shared__ double dl2[15], dlN[CO_MAXN], dl0[15];                      // delta5[Pose2], [N], [Pose0]
-    __shared__ double scratch[1260];                                       // IMU phase: sU | sJ ; elimination phase: Ainv | L | T2 | T0 | TN
-    double* const sU = scratch; double* const sJ = scratch + 450;
-    double* const sAinv = scratch; double* const sL = scratch + 225; double* const T2 = scratch + 450; double* const T0 = scratch + 675; double* const TN = scratch + 900;
-    __shared__ double sRes[16];
-    __shared__ double sz[CO_MAXG], sdinv[CO_MAXG];
     __shared__ double sOut[32], sNv[CO_MAXN], sOld[32], sNold[CO_MAXN], sDx[16], sRm[16];
-    __shared__ int sBad;
     const int hist = A.history[f];
     if (t < 32) { sOut[t] = A.outer[(size_t)f * 32 + t]; sOld[t] = hist ? A.old[(size_t)f * 32 + t] : A.outer[(size_t)f * 32 + t]; }
     if (t < N) { sNv[t] = A.Nv[n0 + t]; sNold[t] = hist ? A.N_old[n0 + t] : A.Nv[n0 + t]; }
-    if (t == 0) sBad = 0;
     __syncthreads();
     const double* Pi = sOut; const double* Bi = sOut + 7; const double* Pj = sOut + 16; const double* Bj = sOut + 23;
     // UpdateDeltaValues: increments old (-) new
@@ -370,8 +354,8 @@ __global__ void __launch_bounds__(256) k_comp_elim(CompArgs A) {
 // Inside the solver a composite factor IS a linearised prior that is rewritten at every linearisation: between two Jacobian
 // evaluations the reference answers from r_lin - J INC, with INC = old (-) new in exactly the coordinates of
 // MarginalizationFactor::Evaluate (p - p0, +-2 vec(q0^-1 q), x - x0).  So the engine carries it as a prior-type factor with
-// a static clique; at every linearisation of its window  k_comp_gather  collects the outer blocks,  k_composite  moves the
-// hidden epochs and re-eliminates, and  k_comp_scatter  rewrites the prior's (J, r0, x0) and its clique's J^T J / diagonal.
+// a static clique; at every linearisation of its window  k_comp_gather  collects the outer blocks,  k_comp_prep / k_comp_imu / k_comp_elim  move the
+// hidden epochs and re-eliminate, and  k_comp_scatter  rewrites the prior's (J, r0, x0) and its clique's J^T J / diagonal.
 // Evaluation, J v products, candidate cost and assembly are the prior's own code, unchanged.
 // ---------------------------------------------------------------------------------------------------------------------
 struct CompMeta {
