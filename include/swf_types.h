@@ -125,6 +125,17 @@ typedef struct swf_flat_window {
     const int32_t* fix_idx;          /* [n_fix][2] scalar a, scalar b */
     const double*  fix_dat;          /* [n_fix][SWF_FIX_DOUBLES] */
 
+    /* ---- inverse-depth projection factors (R/factor/projection_factor.cpp:77-329; USE_INVERSE_DEPTH builds of the reference):
+     *      the landmark is a scalar-pool block lambda = inverse depth along pts_i in the anchor frame, normally in elimination
+     *      group 0.  idp_kind: 0 ProjectionTwoFrameOneCamFactor <2,7,7,7,1>   blocks pose_i, pose_j, ex, lambda
+     *                1 ProjectionTwoFrameTwoCamFactor <2,7,7,7,7,1>           blocks pose_i, pose_j, ex, ex2, lambda
+     *                2 ProjectionOneFrameTwoCamFactor <2,7,7,1>               blocks ex, ex2, lambda
+     *      Same sqrt_info / CauchyLoss as the world-point projection factors (proj_sqrt_info, proj_loss_a). */
+    int32_t n_idp;
+    const int32_t* idp_kind;         /* [n_idp] */
+    const int32_t* idp_idx;          /* [n_idp][5] pose_i, pose_j, ex, ex2 (pose pool; ignored where the kind has none), lambda (scalar pool) */
+    const double*  idp_pts;          /* [n_idp][6] pts_i (3), pts_j (3) normalised observations */
+
     /* ---- composite IMU-GNSS factors, IMUGNSSFactor over IMUGNSSBase (R/factor/gnss_imu_factor.cpp:802-820, :678-799):
      *      factor f hides comp_M[f] GNSS epochs between two frames behind comp_N[f] ambiguities; residual dim 30 + N.
      *      Arrays are concatenated over the factors (layouts as in swf_composite_create, swf_solver.h).  The hidden epochs are

@@ -784,7 +784,7 @@ void oracle_composite_hidden(const oracle_composite* c, double* pose, double* sb
 int oracle_composite_evaluate(oracle_composite* c, const double* Pi, const double* Bi, const double* Pj, const double* Bj, const double* Nv,
                               int want_jac, double* residual, double* jac);
 
-enum { F_PROJ = 0, F_IMU, F_CP, F_PR, F_DOP, F_SP, F_PRIOR, F_SPR, F_SCP, F_FIX, F_COMP };
+enum { F_PROJ = 0, F_IMU, F_CP, F_PR, F_DOP, F_SP, F_PRIOR, F_SPR, F_SCP, F_FIX, F_COMP, F_IDP };
 
 typedef struct {
     int type, idx, nres, nblk;
@@ -868,7 +868,7 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
     c->n_loc = lo; c->n_e = ne; c->n_red = lo - ne; c->n_eblk = neb;
 
     /* factors */
-    int nf = w->n_proj + w->n_imu + w->n_cp + w->n_pr + w->n_dop + w->n_sp + w->n_spr + w->n_scp + w->n_fix + w->n_prior + w->n_comp;
+    int nf = w->n_proj + w->n_imu + w->n_cp + w->n_pr + w->n_dop + w->n_sp + w->n_spr + w->n_scp + w->n_fix + w->n_prior + w->n_comp + w->n_idp;
     c->n_fac = nf;
     c->fac = (fac_t*)calloc(nf > 0 ? nf : 1, sizeof(fac_t));
     int nslots = w->n_proj * 3 + w->n_imu * 4 + w->n_cp * 3 + w->n_pr * 2 + w->n_dop * 3 + w->n_sp + w->n_spr * 2 + w->n_scp * 3 + w->n_fix * 2;
@@ -886,6 +886,7 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
         }
         c->prior_blk_off[w->n_prior] = bo;
     }
+    for (int i = 0; i < w->n_idp; i++) nslots += w->idp_kind[i] == 0 ? 4 : w->idp_kind[i] == 1 ? 5 : 3;
     /* composite factors: one stateful restatement of IMUGNSSBase each, on copies of the window's arrays */
     c->comp = (oracle_composite**)calloc(w->n_comp + 1, sizeof(oracle_composite*));
     c->comp_e_off = (int*)calloc(w->n_comp + 2, sizeof(int)); c->comp_idx_off = (int*)calloc(w->n_comp + 2, sizeof(int));
@@ -918,6 +919,14 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
     for (int k = 0; k < w->n_prior; k++) {
         ADDF(F_PRIOR, k, w->prior_dim[k], w->prior_nblk[k])
         for (int q = 0; q < w->prior_nblk[k]; q++) ADDS(w->prior_blk[c->prior_blk_off[k] + q])
+    }
+    for (int i = 0; i < w->n_idp; i++) {          /* inverse-depth projection factors: blocks in the reference's parameter order */
+        const int* ix = w->idp_idx + i * 5; int kd = w->idp_kind[i];
+        ADDF(F_IDP, i, 2, kd == 0 ? 4 : kd == 1 ? 5 : 3)
+        if (kd != 2) { ADDS(BID_POSE(w, ix[0])) ADDS(BID_POSE(w, ix[1])) }
+        ADDS(BID_POSE(w, ix[2]))
+        if (kd != 0) ADDS(BID_POSE(w, ix[3]))
+        ADDS(BID_SC(w, ix[4]))
     }
     for (int k = 0; k < w->n_comp; k++) {
         const int* ix = w->comp_idx + c->comp_idx_off[k];
@@ -1041,6 +1050,27 @@ static double eval_factor(ctx_t* c, const fac_t* f, const double* x, int want_ja
     case F_SPR: oracle_eval_spr(XP(0), *XP(1), w->spr_dat + f->idx * SWF_SPR_DOUBLES, w->base, r, JP(0), JP(1)); return 0.5 * r[0] * r[0];
     case F_SCP: oracle_eval_scp(XP(0), *XP(1), *XP(2), w->scp_dat + f->idx * SWF_SCP_DOUBLES, w->base, r, JP(0), JP(1), JP(2)); return 0.5 * r[0] * r[0];
     case F_FIX: oracle_eval_fix(*XP(0), *XP(1), w->fix_dat + f->idx * SWF_FIX_DOUBLES, r, JP(0), JP(1)); return 0.5 * r[0] * r[0];
+    case F_IDP: {
+        int kd = w->idp_kind[f->idx];
+        const double* pts = w->idp_pts + (size_t)f->idx * 6;
+        /* slots: kind 0: Pi Pj ex l ; kind 1: Pi Pj ex ex2 l ; kind 2: ex ex2 l */
+        int s_pi = kd == 2 ? -1 : 0, s_pj = kd == 2 ? -1 : 1, s_ex = kd == 2 ? 0 : 2, s_ex2 = kd == 0 ? -1 : (kd == 1 ? 3 : 1), s_l = f->nblk - 1;
+        double Jb[4][12], Jl2[2];
+        double* Jp[5] = { s_pi >= 0 ? JP(s_pi) : NULL, s_pj >= 0 ? JP(s_pj) : NULL, JP(s_ex), s_ex2 >= 0 ? JP(s_ex2) : NULL, JP(s_l) };
+        const double* ident = XP(s_ex);
+        oracle_eval_proj_idepth(kd, s_pi >= 0 ? XP(s_pi) : ident, s_pj >= 0 ? XP(s_pj) : ident, XP(s_ex), s_ex2 >= 0 ? XP(s_ex2) : XP(s_ex), *XP(s_l), pts, pts + 3,
+                                w->proj_sqrt_info, w->pbg, r, want_jac ? Jb[0] : NULL, want_jac ? Jb[1] : NULL, want_jac ? Jb[2] : NULL, want_jac ? Jb[3] : NULL, want_jac ? Jl2 : NULL);
+        if (want_jac) {
+            for (int q = 0; q < 4; q++) if (Jp[q]) memcpy(Jp[q], Jb[q], sizeof(double) * 12);
+            if (Jp[4]) { Jp[4][0] = Jl2[0]; Jp[4][1] = Jl2[1]; }
+        }
+        if (w->proj_loss_a > 0) {
+            double* Jv[5]; int nc[5]; int nj = 0;
+            for (int q = 0; q < 5; q++) if (want_jac && Jp[q]) { Jv[nj] = Jp[q]; nc[nj] = q < 4 ? 6 : 1; nj++; }
+            return cauchy_correct(w->proj_loss_a, r, 2, Jv, nc, nj);
+        }
+        return 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    }
     case F_COMP: {
         /* IMUGNSSFactor::Evaluate -> IMUGNSSBase::Evaluate; UpdateJacobResidual slices the (30+N)^2 Jacobian per block */
         int k = f->idx, N = w->comp_N[k], G = 30 + N;

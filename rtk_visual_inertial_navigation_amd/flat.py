@@ -36,6 +36,7 @@ class FlatWindowC(C.Structure):
         ("n_spr", C.c_int32), ("spr_idx", _pi), ("spr_dat", _pd),
         ("n_scp", C.c_int32), ("scp_idx", _pi), ("scp_dat", _pd),
         ("n_fix", C.c_int32), ("fix_idx", _pi), ("fix_dat", _pd),
+        ("n_idp", C.c_int32), ("idp_kind", _pi), ("idp_idx", _pi), ("idp_pts", _pd),
         ("n_comp", C.c_int32), ("comp_M", _pi), ("comp_N", _pi), ("comp_idx", _pi), ("comp_pose", _pd), ("comp_sb", _pd),
         ("comp_pose_lin", _pd), ("comp_sb_lin", _pd), ("comp_Hpp", _pd), ("comp_HpN", _pd), ("comp_rhs_p", _pd),
         ("comp_HNN", _pd), ("comp_rhsN", _pd), ("comp_pre", _pd),
@@ -108,10 +109,10 @@ TERMINATION = {0: "RUNNING", 1: "CONVERGED_GRADIENT", 2: "CONVERGED_PARAMETER",
                6: "LINEAR_SOLVER_FAILURE", 7: "ASSEMBLED_ONLY"}
 
 _F64 = ("pose", "sb", "lm", "sc", "proj_uv", "imu_pre", "cp_dat", "pr_dat", "dop_dat", "sp_w",
-        "spr_dat", "scp_dat", "fix_dat", "comp_pose", "comp_sb", "comp_pose_lin", "comp_sb_lin", "comp_Hpp", "comp_HpN", "comp_rhs_p",
+        "spr_dat", "scp_dat", "fix_dat", "idp_pts", "comp_pose", "comp_sb", "comp_pose_lin", "comp_sb_lin", "comp_Hpp", "comp_HpN", "comp_rhs_p",
         "comp_HNN", "comp_rhsN", "comp_pre", "prior_J", "prior_r0", "prior_x0")
 _I32 = ("order_block", "order_group", "proj_idx", "imu_idx", "cp_idx", "pr_idx", "dop_idx",
-        "sp_idx", "spr_idx", "scp_idx", "fix_idx", "comp_M", "comp_N", "comp_idx", "prior_nblk", "prior_dim", "prior_blk")
+        "sp_idx", "spr_idx", "scp_idx", "fix_idx", "idp_kind", "idp_idx", "comp_M", "comp_N", "comp_idx", "prior_nblk", "prior_dim", "prior_blk")
 
 
 class FlatWindow:
@@ -194,6 +195,7 @@ class FlatWindow:
         s.n_scp = a["scp_idx"].size // 3
         s.n_fix = a["fix_idx"].size // 2
         s.n_comp = a["comp_M"].size
+        s.n_idp = a["idp_kind"].size
         s.n_prior = a["prior_nblk"].size
         s.proj_sqrt_info, s.proj_loss_a = self.proj_sqrt_info, self.proj_loss_a
         for i in range(3):
@@ -206,6 +208,6 @@ class FlatWindow:
                     n_proj=a["proj_idx"].size // 3, n_imu=a["imu_idx"].size // 4,
                     n_cp=a["cp_idx"].size // 3, n_pr=a["pr_idx"].size // 2,
                     n_dop=a["dop_idx"].size // 3, n_sp=a["sp_idx"].size,
-                    n_spr=a["spr_idx"].size // 2, n_scp=a["scp_idx"].size // 3, n_fix=a["fix_idx"].size // 2, n_comp=a["comp_M"].size,
+                    n_spr=a["spr_idx"].size // 2, n_scp=a["scp_idx"].size // 3, n_fix=a["fix_idx"].size // 2, n_comp=a["comp_M"].size, n_idp=a["idp_kind"].size,
                     n_prior=a["prior_nblk"].size,
                     prior_dim=[int(x) for x in a["prior_dim"]])

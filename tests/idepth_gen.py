@@ -1,0 +1,61 @@
+"""Windows with inverse-depth landmarks for the parity tests: a synthetic VI / RTK window of synth.py whose
+short feature tracks are re-parametrised the way a USE_INVERSE_DEPTH build of the reference holds them — one scalar block
+lambda = inverse depth along the first observation in the anchor frame, ProjectionTwoFrameOneCamFactor per further
+observation, no residual for the anchor observation itself — while the long tracks stay world points."""
+import numpy as np
+from rtk_visual_inertial_navigation_amd import synth
+from rtk_visual_inertial_navigation_amd.flat import FlatWindow
+from rtk_visual_inertial_navigation_amd.ordering import my_ordering
+
+
+def convert_short_tracks(w, max_track=7):
+    a = w.a
+    K = w.meta["K"]
+    n_pose, n_sb, n_lm, n_sc = w.n_pose, w.n_sb, w.n_lm, w.n_sc
+    pidx = a["proj_idx"].reshape(-1, 3); puv = a["proj_uv"].reshape(-1, 2)
+    pose = a["pose"].reshape(-1, 7); lm = a["lm"].reshape(-1, 3)
+    keep_lm, conv = [], []
+    for f in range(n_lm):
+        obs = np.nonzero(pidx[:, 2] == f)[0]
+        (conv if 2 <= obs.size <= max_track else keep_lm).append((f, obs))
+    new_lm = np.array([lm[f] for f, _ in keep_lm]).reshape(-1, 3)
+    lm_map = {f: i for i, (f, _) in enumerate(keep_lm)}
+    proj_idx, proj_uv = [], []
+    for f, obs in keep_lm:
+        for o in obs:
+            proj_idx.append([pidx[o, 0], pidx[o, 1], lm_map[f]]); proj_uv.append(puv[o])
+    sc = list(a["sc"]); idp_kind, idp_idx, idp_pts = [], [], []
+    for f, obs in conv:
+        o0 = obs[0]; fi, ex = int(pidx[o0, 0]), int(pidx[o0, 1])
+        Ri, ric = synth.q_to_R(pose[fi, 3:]), synth.q_to_R(pose[ex, 3:])
+        pc = ric.T @ (Ri.T @ (lm[f] - pose[fi, :3]) + w.pbg - pose[ex, :3])           # the point in the anchor camera (current estimates)
+        lam_i = len(sc); sc.append(1.0 / pc[2])
+        pts_i = np.array([puv[o0, 0], puv[o0, 1], 1.0])
+        for o in obs[1:]:
+            idp_kind.append(0); idp_idx.append([fi, int(pidx[o, 0]), ex, -1, lam_i]); idp_pts.append(np.concatenate([pts_i, [puv[o, 0], puv[o, 1], 1.0]]))
+    n_lm2, n_sc2 = new_lm.shape[0], len(sc)
+    # global block ids shift: lm pool shrinks, scalar pool grows
+    def remap(b):
+        if b < n_pose + n_sb: return b
+        if b < n_pose + n_sb + n_lm: return n_pose + n_sb + lm_map[b - n_pose - n_sb] if (b - n_pose - n_sb) in lm_map else None
+        return n_pose + n_sb + n_lm2 + (b - n_pose - n_sb - n_lm)
+    n_blocks = n_pose + n_sb + n_lm2 + n_sc2
+    is_const = np.zeros(n_blocks, np.uint8)
+    for b, c in enumerate(a["is_const"]):
+        nb = remap(b)
+        if nb is not None: is_const[nb] = c
+    roles = {}
+    for k, v in w.meta["roles"].items():
+        if isinstance(v, list): roles[k] = [remap(b) for b in v if remap(b) is not None]
+        else: roles[k] = remap(v) if v is not None else None
+    lam_blocks = [n_pose + n_sb + n_lm2 + i for i in range(n_sc, n_sc2)]
+    roles["landmarks"] = roles["landmarks"] + lam_blocks                 # the inverse depths are the feature blocks of the policy
+    order_block, order_group, n_tail = my_ordering(roles, is_const)
+    prior_blk = np.array([remap(int(b)) for b in a["prior_blk"]], np.int32)
+    kw = {k: a[k] for k in ("pose", "sb", "imu_idx", "imu_pre", "cp_idx", "cp_dat", "pr_idx", "pr_dat", "dop_idx", "dop_dat", "sp_idx", "sp_w",
+                            "prior_nblk", "prior_dim", "prior_J", "prior_r0", "prior_x0")}
+    return FlatWindow(lm=new_lm, sc=np.array(sc), is_const=is_const, order_block=order_block, order_group=order_group, n_tail=n_tail,
+                      proj_idx=np.array(proj_idx, np.int32).reshape(-1, 3), proj_uv=np.array(proj_uv).reshape(-1, 2),
+                      idp_kind=np.array(idp_kind, np.int32), idp_idx=np.array(idp_idx, np.int32).reshape(-1, 5), idp_pts=np.array(idp_pts).reshape(-1, 6),
+                      prior_blk=prior_blk, proj_sqrt_info=w.proj_sqrt_info, proj_loss_a=w.proj_loss_a, pbg=w.pbg, gw=w.gw, base=w.base,
+                      meta=dict(w.meta, roles=roles, n_idepth_landmarks=len(conv)), **kw)
