@@ -40,7 +40,7 @@ struct WinState {
 };
 
 // ---- generic factor (everything except projection) --------------------------------------
-enum { GF_IMU = 1, GF_CP = 2, GF_PR = 3, GF_DOP = 4, GF_SP = 5, GF_PRIOR = 6, GF_SPR = 7, GF_SCP = 8, GF_FIX = 9 };
+enum { GF_IMU = 1, GF_CP = 2, GF_PR = 3, GF_DOP = 4, GF_SP = 5, GF_PRIOR = 6, GF_SPR = 7, GF_SCP = 8, GF_FIX = 9, GF_IDP = 10 };
 struct GFac {
     int type, win, nres, nslot;
     int slot0;                   // into slot arrays
@@ -317,4 +317,82 @@ __device__ __forceinline__ double block_max(double v, double* scratch) {
     double s = scratch[0];
     for (int i = 1; i < nw; i++) s = scratch[i] > s ? scratch[i] : s;
     return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Inverse-depth projection factors, one evaluation:
+//   kind 0 ProjectionTwoFrameOneCamFactor (R/factor/projection_factor.cpp:179-256), 1 ProjectionTwoFrameTwoCamFactor (:77-166),
+//   kind 2 ProjectionOneFrameTwoCamFactor (:269-329; Pi = Pj = identity pose, no lever arm).  e2 = the camera projected into
+//   (= ex for kind 0).  J (if jac): d r / d pose_i (2x6 local, row-major) | pose_j | ex | ex2 | lambda (2) = 50 doubles.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void red_out(const double* red, const double* Mx, double sgn, double* Jd, int col) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Jd[i * 6 + col + j] = sgn * (red[i * 3] * Mx[j] + red[i * 3 + 1] * Mx[3 + j] + red[i * 3 + 2] * Mx[6 + j]);
+}
+
+__device__ __forceinline__ void d_idepth_eval(int kind, const double* Pi, const double* Pj, const double* ex, const double* e2, double inv_dep,
+                                              const double* pts, double si, const double* pbg, double* r, double* Jq, bool jac) {
+    const double* pts_i = pts; const double* pts_j = pts + 3;
+    const double lever[3] = { kind == 2 ? 0.0 : pbg[0], kind == 2 ? 0.0 : pbg[1], kind == 2 ? 0.0 : pbg[2] };
+    double pci[3] = { pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep }, pimu_i[3], pimu_j[3], t[3], pcj[3], qi[4], w[3];
+    qrot(ex + 3, pci, pimu_i);
+#pragma unroll
+    for (int k = 0; k < 3; k++) pimu_i[k] += ex[k] - lever[k];
+    if (kind == 2) { pimu_j[0] = pimu_i[0]; pimu_j[1] = pimu_i[1]; pimu_j[2] = pimu_i[2]; }
+    else {
+        qrot(Pi + 3, pimu_i, w);
+#pragma unroll
+        for (int k = 0; k < 3; k++) w[k] += Pi[k] - Pj[k];
+        qinv(Pj + 3, qi); qrot(qi, w, pimu_j);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = pimu_j[k] + lever[k] - e2[k];
+    qinv(e2 + 3, qi); qrot(qi, t, pcj);
+    const double dep = pcj[2];
+    r[0] = si * (pcj[0] / dep - pts_j[0]);
+    r[1] = si * (pcj[1] / dep - pts_j[1]);
+    if (!jac) return;
+    double red[6] = { si * (1. / dep), 0, si * (-pcj[0] / (dep * dep)), 0, si * (1. / dep), si * (-pcj[1] / (dep * dep)) };
+    double Ri[9], Rj[9], ric[9], ric2[9], ric2T[9], RjT[9], Am[9], Bm[9], Cm[9], S[9], M[9];
+    q2R(ex + 3, ric); q2R(e2 + 3, ric2); mat3T(ric2, ric2T);
+    q2R(Pi + 3, Ri); q2R(Pj + 3, Rj);                   // identities for kind 2
+    mat3T(Rj, RjT);
+    mat3mul(ric2T, RjT, Am); mat3mul(Am, Ri, Bm); mat3mul(Bm, ric, Cm);
+    for (int k = 0; k < 50; k++) Jq[k] = 0.0;
+    if (kind != 2) {
+        skew3(pimu_i, S); mat3mul(Bm, S, M);
+        red_out(red, Am, 1.0, Jq, 0); red_out(red, M, -1.0, Jq, 3);
+        skew3(pimu_j, S); mat3mul(ric2T, S, M);
+        red_out(red, Am, -1.0, Jq + 12, 0); red_out(red, M, 1.0, Jq + 12, 3);
+    }
+    if (kind == 0) {
+        double T1[9], tmp[3], v[3], w2[3], u[3], S2[9], S3[9], L[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) T1[k] = Bm[k] - ric2T[k];
+        mat3vec(Cm, pci, tmp);
+        skew3(pci, S); mat3mul(Cm, S, L); skew3(tmp, S2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = ex[k] - pbg[k];
+        mat3vec(Ri, v, w2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) w2[k] += Pi[k] - Pj[k];
+        mat3vec(RjT, w2, u);
+#pragma unroll
+        for (int k = 0; k < 3; k++) u[k] += pbg[k] - ex[k];
+        mat3vec(ric2T, u, v); skew3(v, S3);
+#pragma unroll
+        for (int k = 0; k < 9; k++) M[k] = -L[k] + S2[k] + S3[k];
+        red_out(red, T1, 1.0, Jq + 24, 0); red_out(red, M, 1.0, Jq + 24, 3);
+    } else {
+        skew3(pci, S); mat3mul(Cm, S, M);
+        red_out(red, Bm, 1.0, Jq + 24, 0); red_out(red, M, -1.0, Jq + 24, 3);
+        skew3(pcj, S);
+        red_out(red, ric2T, -1.0, Jq + 36, 0); red_out(red, S, 1.0, Jq + 36, 3);
+    }
+    double v3[3];
+    mat3vec(Cm, pts_i, v3);
+#pragma unroll
+    for (int i = 0; i < 2; i++) Jq[48 + i] = (red[i * 3] * v3[0] + red[i * 3 + 1] * v3[1] + red[i * 3 + 2] * v3[2]) * -1.0 / (inv_dep * inv_dep);
 }

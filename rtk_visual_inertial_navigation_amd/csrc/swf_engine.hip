@@ -354,6 +354,22 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         B.gx_dat.insert(B.gx_dat.end(), w->fix_dat + i * SWF_FIX_DOUBLES, w->fix_dat + (i + 1) * SWF_FIX_DOUBLES);
         B.sc_gf.push_back(add_gf(GF_FIX, 1, data, { bidC(ix[0]), bidC(ix[1]) }));
     }
+    // inverse-depth projection factors: two residual rows, evaluated one lane each with the scalar factors; record = kind | pts (6)
+    for (int i = 0; i < w->n_idp; i++) {
+        const int* ix = w->idp_idx + i * 5; const int kd = w->idp_kind[i];
+        if (kd < 0 || kd > 2) return fail(SWF_E_INVALID, "inverse-depth projection: kind must be 0, 1 or 2");
+        std::vector<int> blks;
+        if (kd != 2) { CHK(ix[0], nP, "inverse-depth projection") CHK(ix[1], nP, "inverse-depth projection") blks.push_back(bidP(ix[0])); blks.push_back(bidP(ix[1])); }
+        CHK(ix[2], nP, "inverse-depth projection") blks.push_back(bidP(ix[2]));
+        if (kd != 0) { CHK(ix[3], nP, "inverse-depth projection") blks.push_back(bidP(ix[3])); }
+        CHK(ix[4], nC, "inverse-depth projection") blks.push_back(bidC(ix[4]));
+        for (size_t a = 0; a < blks.size(); a++) for (size_t c2 = 0; c2 < a; c2++)
+            if (blks[a] == blks[c2]) return fail(SWF_E_INVALID, "inverse-depth projection: repeated parameter block");
+        int data = (int)B.gx_dat.size();
+        B.gx_dat.push_back((double)kd);
+        B.gx_dat.insert(B.gx_dat.end(), w->idp_pts + (size_t)i * 6, w->idp_pts + (size_t)(i + 1) * 6);
+        B.sc_gf.push_back(add_gf(GF_IDP, 2, data, blks));
+    }
     std::vector<int> prior_first_gf;
     {
         int bo = 0; long long jo = 0; int ro = 0, x0o = 0;
@@ -594,7 +610,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         int64_t pb = 0;
         for (int k = 0; k < w->n_prior; k++) { int64_t n = w->prior_dim[k]; pb += 8 * (n * n + 4 * n); }
         B.jac_bytes += (int64_t)312 * w->n_proj + (int64_t)5480 * w->n_imu + (int64_t)176 * w->n_cp + (int64_t)152 * w->n_pr + (int64_t)208 * w->n_dop
-                     + (int64_t)136 * w->n_spr + (int64_t)160 * w->n_scp + (int64_t)56 * w->n_fix + pb;
+                     + (int64_t)136 * w->n_spr + (int64_t)160 * w->n_scp + (int64_t)56 * w->n_fix + (int64_t)584 * w->n_idp + pb;
     }
     B.win.push_back(R);
     return SWF_OK;

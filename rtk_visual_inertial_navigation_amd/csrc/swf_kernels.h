@@ -427,6 +427,39 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
             int jo = B.s_joff[s0]; if (jo >= 0) B.g_J[jo] = -dat[1];
             jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = dat[1];
         }
+    } else if (G.type == GF_IDP) {
+        // inverse-depth projection factor (2 residual rows): record = kind | pts_i (3) | pts_j (3); slots in the reference's block order
+        const double* dat = B.gx_dat + G.data;
+        const int kind = (int)dat[0];
+        const double zero7[7] = { 0, 0, 0, 0, 0, 0, 1 };
+        const int s_ex = kind == 2 ? 0 : 2, s_ex2 = kind == 0 ? -1 : (kind == 1 ? 3 : 1), s_l = G.nslot - 1;
+        const double* Pi = kind == 2 ? zero7 : xs + B.s_x[s0];
+        const double* Pj = kind == 2 ? zero7 : xs + B.s_x[s0 + 1];
+        const double* ex = xs + B.s_x[s0 + s_ex];
+        const double* e2 = kind == 0 ? ex : xs + B.s_x[s0 + s_ex2];
+        double r2[2], Jq[50];
+        d_idepth_eval(kind, Pi, Pj, ex, e2, xs[B.s_x[s0 + s_l]], dat + 1, W.proj_sqrt_info, W.pbg, r2, Jq, JAC);
+        // CauchyLoss as on the world-point projection factors: rho'' < 0 => scale r and J by sqrt(rho'), block cost = rho(s) / 2
+        double sr = 1.0, cost, sq = r2[0] * r2[0] + r2[1] * r2[1];
+        if (W.proj_loss_a > 0) {
+            double b = W.proj_loss_a * W.proj_loss_a, c = 1.0 / b;
+            double sum = 1.0 + sq * c, inv = 1.0 / sum;
+            cost = 0.5 * b * log(sum);
+            sr = sqrt(inv > 2.2250738585072014e-308 ? inv : 2.2250738585072014e-308);
+        } else cost = 0.5 * sq;
+        B.g_cost[f] = cost;
+        if (JAC) {
+            B.g_r[G.roff] = r2[0] * sr; B.g_r[G.roff + 1] = r2[1] * sr;
+            // Jq blocks: pose_i | pose_j | ex | ex2 | lambda  ->  the slots this kind has
+            const int blk_of_slot[5] = { kind == 2 ? 2 : 0, kind == 2 ? 3 : 1, kind == 2 ? 4 : 2, kind == 0 ? 4 : 3, 4 };
+            for (int t = 0; t < G.nslot; t++) {
+                int jo = B.s_joff[s0 + t];
+                if (jo < 0) continue;
+                int bq = blk_of_slot[t], l = bq == 4 ? 1 : 6;
+                for (int j = 0; j < l; j++) { B.g_J[jo + j * ld] = (bq == 4 ? Jq[48] : Jq[bq * 12 + j]) * sr; B.g_J[jo + j * ld + 1] = (bq == 4 ? Jq[49] : Jq[bq * 12 + 6 + j]) * sr; }
+            }
+        }
+        return;
     } else {   // GF_SP
         double wv = B.sp_w[G.data];
         r = wv * xs[B.s_x[s0]];
@@ -564,7 +597,9 @@ __device__ __forceinline__ void d_jtimes_scalar(const DevBatch& B, const DevOpt&
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
     if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;
-    B.g_aux[f] = gf_row_term<MODE>(B, G, 0, gf_row_dot<MODE>(B, O, G, 0));
+    double a = 0;
+    for (int k = 0; k < G.nres; k++) a += gf_row_term<MODE>(B, G, k, gf_row_dot<MODE>(B, O, G, k));     // nres = 1, or 2 for the inverse-depth projections
+    B.g_aux[f] = a;
 }
 // IMU factors: 16 lanes per factor, one residual row per lane
 template <int MODE>

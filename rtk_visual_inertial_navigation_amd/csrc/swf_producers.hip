@@ -445,13 +445,6 @@ struct IdepthArgs {
     int n;
 };
 
-__device__ __forceinline__ void red_out(const double* red, const double* Mx, double sgn, double* Jd, int col) {
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) Jd[i * 6 + col + j] = sgn * (red[i * 3] * Mx[j] + red[i * 3 + 1] * Mx[3 + j] + red[i * 3 + 2] * Mx[6 + j]);
-}
-
 __global__ void __launch_bounds__(128) k_eval_idepth(IdepthArgs A) {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= A.n) return;
@@ -462,68 +455,10 @@ __global__ void __launch_bounds__(128) k_eval_idepth(IdepthArgs A) {
     const double* Pj = kind == 2 ? zero7 : A.poses + (size_t)ix[1] * 7;
     const double* ex = A.poses + (size_t)ix[2] * 7;
     const double* e2 = kind == 0 ? ex : A.poses + (size_t)ix[3] * 7;
-    const double inv_dep = A.lambda[ix[4]];
-    const double* pts_i = A.pts + (size_t)q * 6; const double* pts_j = pts_i + 3;
-    const double lever[3] = { kind == 2 ? 0.0 : A.pbg[0], kind == 2 ? 0.0 : A.pbg[1], kind == 2 ? 0.0 : A.pbg[2] };
-    double pci[3] = { pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep }, pimu_i[3], pimu_j[3], t[3], pcj[3], qi[4], w[3];
-    qrot(ex + 3, pci, pimu_i);
-#pragma unroll
-    for (int k = 0; k < 3; k++) pimu_i[k] += ex[k] - lever[k];
-    if (kind == 2) { pimu_j[0] = pimu_i[0]; pimu_j[1] = pimu_i[1]; pimu_j[2] = pimu_i[2]; }
-    else {
-        qrot(Pi + 3, pimu_i, w);
-#pragma unroll
-        for (int k = 0; k < 3; k++) w[k] += Pi[k] - Pj[k];
-        qinv(Pj + 3, qi); qrot(qi, w, pimu_j);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) t[k] = pimu_j[k] + lever[k] - e2[k];
-    qinv(e2 + 3, qi); qrot(qi, t, pcj);
-    const double dep = pcj[2], si = A.sqrt_info;
-    A.r[(size_t)q * 2] = si * (pcj[0] / dep - pts_j[0]);
-    A.r[(size_t)q * 2 + 1] = si * (pcj[1] / dep - pts_j[1]);
-    double red[6] = { si * (1. / dep), 0, si * (-pcj[0] / (dep * dep)), 0, si * (1. / dep), si * (-pcj[1] / (dep * dep)) };
-    double Ri[9], Rj[9], ric[9], ric2[9], ric2T[9], RjT[9], Am[9], Bm[9], Cm[9], S[9], M[9];
-    q2R(ex + 3, ric); q2R(e2 + 3, ric2); mat3T(ric2, ric2T);
-    q2R(Pi + 3, Ri); q2R(Pj + 3, Rj);                   // identities for kind 2 (zero7 is the identity pose)
-    mat3T(Rj, RjT);
-    mat3mul(ric2T, RjT, Am); mat3mul(Am, Ri, Bm); mat3mul(Bm, ric, Cm);
-    double* Jq = A.J + (size_t)q * 50;
-    for (int k = 0; k < 50; k++) Jq[k] = 0.0;
-    if (kind != 2) {
-        skew3(pimu_i, S); mat3mul(Bm, S, M);
-        red_out(red, Am, 1.0, Jq, 0); red_out(red, M, -1.0, Jq, 3);
-        skew3(pimu_j, S); mat3mul(ric2T, S, M);
-        red_out(red, Am, -1.0, Jq + 12, 0); red_out(red, M, 1.0, Jq + 12, 3);
-    }
-    if (kind == 0) {
-        double T1[9], tmp[3], v[3], w2[3], u[3], S2[9], S3[9], L[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) T1[k] = Bm[k] - ric2T[k];
-        mat3vec(Cm, pci, tmp);
-        skew3(pci, S); mat3mul(Cm, S, L); skew3(tmp, S2);
-#pragma unroll
-        for (int k = 0; k < 3; k++) v[k] = ex[k] - A.pbg[k];
-        mat3vec(Ri, v, w2);
-#pragma unroll
-        for (int k = 0; k < 3; k++) w2[k] += Pi[k] - Pj[k];
-        mat3vec(RjT, w2, u);
-#pragma unroll
-        for (int k = 0; k < 3; k++) u[k] += A.pbg[k] - ex[k];
-        mat3vec(ric2T, u, v); skew3(v, S3);
-#pragma unroll
-        for (int k = 0; k < 9; k++) M[k] = -L[k] + S2[k] + S3[k];
-        red_out(red, T1, 1.0, Jq + 24, 0); red_out(red, M, 1.0, Jq + 24, 3);
-    } else {
-        skew3(pci, S); mat3mul(Cm, S, M);
-        red_out(red, Bm, 1.0, Jq + 24, 0); red_out(red, M, -1.0, Jq + 24, 3);
-        skew3(pcj, S);
-        red_out(red, ric2T, -1.0, Jq + 36, 0); red_out(red, S, 1.0, Jq + 36, 3);
-    }
-    double v3[3];
-    mat3vec(Cm, pts_i, v3);
-#pragma unroll
-    for (int i = 0; i < 2; i++) Jq[48 + i] = (red[i * 3] * v3[0] + red[i * 3 + 1] * v3[1] + red[i * 3 + 2] * v3[2]) * -1.0 / (inv_dep * inv_dep);
+    double r2[2], J[50];
+    d_idepth_eval(kind, Pi, Pj, ex, e2, A.lambda[ix[4]], A.pts + (size_t)q * 6, A.sqrt_info, A.pbg, r2, J, true);
+    A.r[(size_t)q * 2] = r2[0]; A.r[(size_t)q * 2 + 1] = r2[1];
+    for (int k = 0; k < 50; k++) A.J[(size_t)q * 50 + k] = J[k];
 }
 }  // namespace
 

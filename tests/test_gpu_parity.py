@@ -682,3 +682,46 @@ def test_inverse_depth_projection_factors_match_oracle():
             assert np.abs(g - e).max() <= 1e-11 * sc, (q, k)
     with pytest.raises(solver.SwfError):
         solver.eval_inverse_depth_batch([3], [[0, 1, 2, 3, 0]], np.array(poses[:4]), [0.1], np.zeros((1, 6)), si, pbg)
+
+
+def test_windows_with_inverse_depth_landmarks_match_oracle_solver():
+    """Row a2 inside the solve loop: short feature tracks held as inverse-depth landmarks (scalar blocks in elimination group 0,
+    ProjectionTwoFrameOneCamFactor per further observation, Cauchy loss), long tracks as world points, in VI and RTK windows:
+    linearisation, reduced system and the dogleg sequence against the oracle solver; batch == single bit for bit."""
+    import idepth_gen as ig
+    cases = [(dict(config_id=2, K=8, F=40, S=0, seed=3), 4), (dict(config_id=2, K=6, F=25, S=0, seed=5), 7),
+             (dict(config_id=3, K=7, F=33, S=6, seed=9), 5), (dict(config_id=2, K=10, F=60, S=0, seed=13), 9)]
+    wins = []
+    for kw, mt in cases:
+        w = ig.convert_short_tracks(synth.make_window(**kw), max_track=mt)
+        assert w.counts()["n_idp"] > 0
+        wins.append(w)
+        so, eo = ob.solve(w.copy(), default_options(step_mode=1))
+        bs, sg = gpu_solve(w.copy(), default_options(step_mode=1))
+        d = bs.dims(0)
+        assert (d["n_loc"], d["n_e"], d["n_red"]) == (eo["n_loc"], eo["n_e"], eo["n_red"])
+        assert abs(sg.initial_cost - so.initial_cost) <= 1e-12 * so.initial_cost
+        g, dg, y = bs.export_vectors(0); S, rhs, L = bs.export_reduced(0)
+        assert rel(g, eo["grad"]) < 1e-11 and rel(dg, eo["diag"]) < 1e-11
+        assert rel(S, eo["S"]) < 1e-11 and rel(rhs, eo["rhs"]) < 1e-10
+        condS = np.linalg.cond(eo["S"])
+        bs.close()
+        wo, wg = w.copy(), w.copy()
+        so, _ = ob.solve(wo, default_options(), export=False)
+        bs, sg = gpu_solve(wg, default_options())
+        ro, rg = so.rows(), sg.rows()
+        assert sg.termination == so.termination and [r["step_is_successful"] for r in rg] == [r["step_is_successful"] for r in ro]
+        for a, b in zip(rg, ro):       # a Gauss-Newton step carries eps * cond(S): two correct solvers drift apart by that much
+            assert abs(a["cost"] - b["cost"]) <= (5e-7 + 1e-17 * condS) * abs(b["cost"]) + 5e-5, (a["cost"], b["cost"], condS)
+        assert np.abs(wg.a["pose"] - wo.a["pose"]).max() < 1e-6 + 1e-16 * condS and np.abs(wg.a["sc"] - wo.a["sc"]).max() < (1e-6 + 1e-16 * condS) * max(1.0, np.abs(wo.a["sc"]).max())
+        bs.close()
+    singles = []
+    for w in wins:
+        c = w.copy(); bs, sm = gpu_solve(c, default_options()); singles.append((c, [r["cost"] for r in sm.rows()])); bs.close()
+    batch = [w.copy() for w in wins]
+    bs = solver.BatchSolver(batch); sms = bs.solve(default_options())
+    for (c, costs), wb, sm in zip(singles, batch, sms):
+        assert [r["cost"] for r in sm.rows()] == costs
+        for k in ("pose", "sb", "lm", "sc"):
+            assert np.array_equal(c.a[k], wb.a[k])
+    bs.close()
