@@ -19,6 +19,8 @@
 //   SppPseudorangeFactor(...)                   R/factor/gnss_factor.h:70-83          -> swf_add_spp_pseudorange
 //   SppCarrierPhaseFactor(...)                  R/factor/gnss_factor.h:88-104         -> swf_add_spp_carrier_phase
 //   FixedIntegerFactor(N21, istd)               R/factor/gnss_factor.h:135-143        -> swf_add_fixed_integer
+//   ProjectionTwoFrameOneCamFactor(pts_i, pts_j) / TwoFrameTwoCam / OneFrameTwoCam
+//                                               R/factor/projection_factor.h:33-66    -> swf_add_projection_inverse_depth
 //   IMUGNSSFactor(IMUGNSSBase*)                 R/factor/gnss_imu_factor.h:19-151     -> swf_add_imu_gnss (IMUGNSSInfo below)
 //   InitialBlackFactor(istd)                    R/factor/initial_factor.h:42-48       -> swf_add_scalar_prior
 //   MarginalizationFactor(info)                 R/factor/marginalization_factor.h:104-110 -> swf_add_linear_prior
@@ -92,6 +94,21 @@ struct FixedIntegerFactor : CostFunction { double N21, istd; FixedIntegerFactor(
 // fills it from gnss_poses / gnss_speed_bias (the hidden epochs' parameter memory, updated in place by every Solve), their
 // *_lin points, pose_hessians, pose_phase_biases_hessians, pose_rhses, phase_biases_hessians, phase_biases_rhs and the M + 1
 // pre-integrations (imu_factors[k]->pre_integration, last_imu_factor) in SWF_PRE_DOUBLES records.
+struct ProjectionTwoFrameOneCamFactor : CostFunction {
+    static double sqrt_info; double pi[3], pj[3];
+    ProjectionTwoFrameOneCamFactor(const double* pts_i, const double* pts_j) { for (int k = 0; k < 3; k++) { pi[k] = pts_i[k]; pj[k] = pts_j[k]; } }
+};
+inline double ProjectionTwoFrameOneCamFactor::sqrt_info = 0;
+struct ProjectionTwoFrameTwoCamFactor : CostFunction {
+    static double sqrt_info; double pi[3], pj[3];
+    ProjectionTwoFrameTwoCamFactor(const double* pts_i, const double* pts_j) { for (int k = 0; k < 3; k++) { pi[k] = pts_i[k]; pj[k] = pts_j[k]; } }
+};
+inline double ProjectionTwoFrameTwoCamFactor::sqrt_info = 0;
+struct ProjectionOneFrameTwoCamFactor : CostFunction {
+    static double sqrt_info; double pi[3], pj[3];
+    ProjectionOneFrameTwoCamFactor(const double* pts_i, const double* pts_j) { for (int k = 0; k < 3; k++) { pi[k] = pts_i[k]; pj[k] = pts_j[k]; } }
+};
+inline double ProjectionOneFrameTwoCamFactor::sqrt_info = 0;
 struct IMUGNSSInfo {
     int M = 0;                                     // hidden GNSS epochs
     double* hidden_pose = nullptr; double* hidden_sb = nullptr;        // [M][7], [M][9]
@@ -176,6 +193,18 @@ class Problem {
     }
     ResidualBlockId AddResidualBlock(FixedIntegerFactor* f, LossFunction* loss, double* n_a, double* n_b) {
         ResidualBlockId id = swf_add_fixed_integer(h_, n_a, n_b, f->N21, f->istd); delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(ProjectionTwoFrameOneCamFactor* f, LossFunction* loss, double* pose_i, double* pose_j, double* ex, double* inv_depth) {
+        ResidualBlockId id = swf_add_projection_inverse_depth(h_, 0, pose_i, pose_j, ex, nullptr, inv_depth, f->pi, f->pj, ProjectionTwoFrameOneCamFactor::sqrt_info, loss ? loss->a() : 0.0);
+        delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(ProjectionTwoFrameTwoCamFactor* f, LossFunction* loss, double* pose_i, double* pose_j, double* ex, double* ex2, double* inv_depth) {
+        ResidualBlockId id = swf_add_projection_inverse_depth(h_, 1, pose_i, pose_j, ex, ex2, inv_depth, f->pi, f->pj, ProjectionTwoFrameTwoCamFactor::sqrt_info, loss ? loss->a() : 0.0);
+        delete f; delete loss; return ck(id);
+    }
+    ResidualBlockId AddResidualBlock(ProjectionOneFrameTwoCamFactor* f, LossFunction* loss, double* ex, double* ex2, double* inv_depth) {
+        ResidualBlockId id = swf_add_projection_inverse_depth(h_, 2, nullptr, nullptr, ex, ex2, inv_depth, f->pi, f->pj, ProjectionOneFrameTwoCamFactor::sqrt_info, loss ? loss->a() : 0.0);
+        delete f; delete loss; return ck(id);
     }
     // param = { pose_i, speed_bias_i, pose_j, speed_bias_j, ambiguity_0 .. ambiguity_N-1 } as SetLastImuFactor builds it
     ResidualBlockId AddResidualBlock(IMUGNSSFactor* f, LossFunction* loss, const std::vector<double*>& param) {

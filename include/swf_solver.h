@@ -273,6 +273,12 @@ swf_factor_id swf_add_spp_carrier_phase(swf_problem* p, double* pose, double* cl
                                         const double* dat);
 /* FixedIntegerFactor(N21, istd) (R/swf/swf_lambda.cpp:318-330): r = istd ((*n_b - *n_a) - N21) */
 swf_factor_id swf_add_fixed_integer(swf_problem* p, double* n_a, double* n_b, double N21, double istd);
+/* ProjectionTwoFrameOneCamFactor (kind 0) / ProjectionTwoFrameTwoCamFactor (1) / ProjectionOneFrameTwoCamFactor (2)
+ * (R/factor/projection_factor.h:33-66, USE_INVERSE_DEPTH builds) + CauchyLoss(loss_a): inv_depth is a one-dimensional block (the
+ * feature's inverse depth along pts_i in the anchor frame), normally ordered into group 0 like the world-point landmarks.
+ * Blocks a kind does not have are ignored.  sqrt_info / loss_a must equal those of the other projection factors. */
+swf_factor_id swf_add_projection_inverse_depth(swf_problem* p, int32_t kind, double* pose_i, double* pose_j, double* ex, double* ex2,
+                                               double* inv_depth, const double pts_i[3], const double pts_j[3], double sqrt_info, double loss_a);
 /* IMUGNSSFactor(IMUGNSS_info) (R/swf/swf.cpp:713-730, R/factor/gnss_imu_factor.cpp:99-119): the composite factor over
  * (pose_i, sb_i, pose_j, sb_j, N ambiguities) hiding M GNSS epochs.  hidden_pose [M][7] / hidden_sb [M][9] are the epochs'
  * parameter memory (gnss_poses / gnss_speed_bias): read at every solve, updated in place by it.  The other arrays (copied)

@@ -19,7 +19,7 @@
 
 namespace {
 struct PBlock { int size; int manifold; bool constant; long seq; };
-enum FType { FT_PROJ, FT_IMU, FT_CP, FT_PR, FT_DOP, FT_SP, FT_PRIOR, FT_SPR, FT_SCP, FT_FIX, FT_COMP };
+enum FType { FT_PROJ, FT_IMU, FT_CP, FT_PR, FT_DOP, FT_SP, FT_PRIOR, FT_SPR, FT_SCP, FT_FIX, FT_COMP, FT_IDP };
 struct PFactor {
     FType type; bool alive, enabled;
     std::vector<double*> keys;
@@ -56,6 +56,7 @@ struct swf_problem {
     std::vector<int32_t> comp_M, comp_N, comp_idx;
     std::vector<double> comp_pose, comp_sb, comp_pose_lin, comp_sb_lin, comp_Hpp, comp_HpN, comp_rhs_p, comp_HNN, comp_rhsN, comp_pre;
     std::vector<const PFactor*> comp_fac;
+    std::vector<int32_t> idp_kind, idp_idx; std::vector<double> idp_pts;      // inverse-depth projection factors, flattened
     int hs_row = 0;
     bool solved = false;
 };
@@ -172,6 +173,20 @@ swf_factor_id swf_add_fixed_integer(swf_problem* p, double* na, double* nb, doub
     double dat[SWF_FIX_DOUBLES] = { N21, istd };
     return add_factor(p, FT_FIX, { na, nb }, { 1, 1 }, dat, SWF_FIX_DOUBLES);
 }
+swf_factor_id swf_add_projection_inverse_depth(swf_problem* p, int32_t kind, double* pose_i, double* pose_j, double* ex, double* ex2,
+                                               double* inv_depth, const double pts_i[3], const double pts_j[3], double sqrt_info, double loss_a) {
+    if (!p || kind < 0 || kind > 2 || !ex || !inv_depth || !pts_i || !pts_j || (kind != 2 && (!pose_i || !pose_j)) || (kind != 0 && !ex2))
+        return pfail(SWF_E_INVALID, "swf_add_projection_inverse_depth: bad arguments");
+    std::vector<double*> keys; std::vector<int> sizes;
+    if (kind != 2) { keys.push_back(pose_i); keys.push_back(pose_j); sizes.push_back(7); sizes.push_back(7); }
+    keys.push_back(ex); sizes.push_back(7);
+    if (kind != 0) { keys.push_back(ex2); sizes.push_back(7); }
+    keys.push_back(inv_depth); sizes.push_back(1);
+    double rec[7] = { (double)kind, pts_i[0], pts_i[1], pts_i[2], pts_j[0], pts_j[1], pts_j[2] };
+    swf_factor_id id = add_factor(p, FT_IDP, keys, sizes, rec, 7);
+    if (id >= 0) { p->factors[id].sqrt_info = sqrt_info; p->factors[id].loss_a = loss_a; }
+    return id;
+}
 swf_factor_id swf_add_imu_gnss(swf_problem* p, double* pose_i, double* sb_i, double* pose_j, double* sb_j, double* const* ambiguities,
                                int32_t N, int32_t M, double* hidden_pose, double* hidden_sb, const double* pose_lin, const double* sb_lin,
                                const double* Hpp, const double* HpN, const double* rhs_p, const double* HNN, const double* rhsN, const double* pre) {
@@ -275,6 +290,7 @@ static int flatten(swf_problem* p) {
     p->proj_idx.clear(); p->proj_uv.clear(); p->imu_idx.clear(); p->imu_pre.clear(); p->cp_idx.clear(); p->cp_dat.clear();
     p->pr_idx.clear(); p->pr_dat.clear(); p->dop_idx.clear(); p->dop_dat.clear(); p->sp_idx.clear(); p->sp_w.clear();
     p->spr_idx.clear(); p->spr_dat.clear(); p->scp_idx.clear(); p->scp_dat.clear(); p->fix_idx.clear(); p->fix_dat.clear();
+    p->idp_kind.clear(); p->idp_idx.clear(); p->idp_pts.clear();
     p->comp_M.clear(); p->comp_N.clear(); p->comp_idx.clear(); p->comp_pose.clear(); p->comp_sb.clear(); p->comp_pose_lin.clear(); p->comp_sb_lin.clear();
     p->comp_Hpp.clear(); p->comp_HpN.clear(); p->comp_rhs_p.clear(); p->comp_HNN.clear(); p->comp_rhsN.clear(); p->comp_pre.clear(); p->comp_fac.clear();
     p->prior_nblk.clear(); p->prior_dim.clear(); p->prior_blk.clear(); p->prior_J.clear(); p->prior_r0.clear(); p->prior_x0.clear();
@@ -297,6 +313,19 @@ static int flatten(swf_problem* p) {
         case FT_SPR: for (double* k : f.keys) p->spr_idx.push_back(pool_idx[k]); p->spr_dat.insert(p->spr_dat.end(), f.data.begin(), f.data.end()); break;
         case FT_SCP: for (double* k : f.keys) p->scp_idx.push_back(pool_idx[k]); p->scp_dat.insert(p->scp_dat.end(), f.data.begin(), f.data.end()); break;
         case FT_FIX: for (double* k : f.keys) p->fix_idx.push_back(pool_idx[k]); p->fix_dat.insert(p->fix_dat.end(), f.data.begin(), f.data.end()); break;
+        case FT_IDP: {
+            if (have_proj && (f.sqrt_info != sqrt_info || f.loss_a != loss_a))
+                return pfail(SWF_E_UNSUPPORTED, "projection factors must share sqrt_info and loss (static member in the reference)");
+            have_proj = true; sqrt_info = f.sqrt_info; loss_a = f.loss_a;
+            const int kd = (int)f.data[0];
+            int ix[5] = { -1, -1, -1, -1, -1 }, q = 0;
+            if (kd != 2) { ix[0] = pool_idx[f.keys[q++]]; ix[1] = pool_idx[f.keys[q++]]; }
+            ix[2] = pool_idx[f.keys[q++]];
+            if (kd != 0) ix[3] = pool_idx[f.keys[q++]];
+            ix[4] = pool_idx[f.keys[q++]];
+            p->idp_kind.push_back(kd); p->idp_idx.insert(p->idp_idx.end(), ix, ix + 5); p->idp_pts.insert(p->idp_pts.end(), f.data.begin() + 1, f.data.end());
+            break;
+        }
         case FT_COMP: {
             const int M = f.M, N = f.N;
             p->comp_M.push_back(M); p->comp_N.push_back(N); p->comp_fac.push_back(&f);
@@ -335,6 +364,7 @@ static int flatten(swf_problem* p) {
     w.n_spr = (int)p->spr_idx.size() / 2; w.spr_idx = p->spr_idx.data(); w.spr_dat = p->spr_dat.data();
     w.n_scp = (int)p->scp_idx.size() / 3; w.scp_idx = p->scp_idx.data(); w.scp_dat = p->scp_dat.data();
     w.n_fix = (int)p->fix_idx.size() / 2; w.fix_idx = p->fix_idx.data(); w.fix_dat = p->fix_dat.data();
+    w.n_idp = (int)p->idp_kind.size(); w.idp_kind = p->idp_kind.data(); w.idp_idx = p->idp_idx.data(); w.idp_pts = p->idp_pts.data();
     w.n_comp = (int)p->comp_M.size(); w.comp_M = p->comp_M.data(); w.comp_N = p->comp_N.data(); w.comp_idx = p->comp_idx.data();
     w.comp_pose = p->comp_pose.data(); w.comp_sb = p->comp_sb.data(); w.comp_pose_lin = p->comp_pose_lin.data(); w.comp_sb_lin = p->comp_sb_lin.data();
     w.comp_Hpp = p->comp_Hpp.data(); w.comp_HpN = p->comp_HpN.data(); w.comp_rhs_p = p->comp_rhs_p.data(); w.comp_HNN = p->comp_HNN.data();

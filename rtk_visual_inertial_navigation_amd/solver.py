@@ -47,7 +47,7 @@ EXPORTED = [
     "swf_preintegrate_batch", "swf_triangulate_batch",
     "swf_batch_tail_covariance", "swf_batch_get_tail_covariance", "swf_problem_tail_covariance",
     "swf_composite_create", "swf_composite_evaluate", "swf_composite_hidden", "swf_composite_destroy", "swf_add_imu_gnss",
-    "swf_eval_inverse_depth_batch",
+    "swf_eval_inverse_depth_batch", "swf_add_projection_inverse_depth",
 ]
 
 
@@ -301,6 +301,12 @@ class Problem:
     def AddFixedInteger(self, n_a, n_b, N21, istd):
         return self._fid(lib().swf_add_fixed_integer(self._h, self._p(n_a), self._p(n_b), C.c_double(N21), C.c_double(istd)), "AddFixedInteger")
 
+    def AddProjectionInverseDepth(self, kind, pose_i, pose_j, ex, ex2, inv_depth, pts_i, pts_j, sqrt_info, loss_a):
+        pi = (C.c_double * 3)(*[float(v) for v in pts_i]); pj = (C.c_double * 3)(*[float(v) for v in pts_j])
+        pp = lambda a: self._p(a) if a is not None else None
+        return self._fid(lib().swf_add_projection_inverse_depth(self._h, C.c_int32(kind), pp(pose_i), pp(pose_j), pp(ex), pp(ex2), self._p(inv_depth), pi, pj,
+                                                                 C.c_double(sqrt_info), C.c_double(loss_a)), "AddProjectionInverseDepth")
+
     def AddImuGnss(self, pose_i, sb_i, pose_j, sb_j, ambiguities, hidden_pose, hidden_sb, pose_lin, sb_lin, Hpp, HpN, rhs_p, HNN, rhsN, pre):
         """IMUGNSSFactor: hidden_pose [M][7] / hidden_sb [M][9] are caller-owned numpy arrays the solve updates in place."""
         N, M = len(ambiguities), int(np.asarray(hidden_pose).reshape(-1, 7).shape[0])
@@ -503,6 +509,9 @@ def problem_from_window(w):
         P.AddSppCarrierPhase(pose[ix[0]], sc[ix[1]], sc[ix[2]], d)
     for ix, d in zip(a["fix_idx"].reshape(-1, 2), a["fix_dat"].reshape(-1, 2)):
         P.AddFixedInteger(sc[ix[0]], sc[ix[1]], d[0], d[1])
+    for kd, ix, pt in zip(a["idp_kind"], a["idp_idx"].reshape(-1, 5), a["idp_pts"].reshape(-1, 6)):
+        P.AddProjectionInverseDepth(int(kd), pose[ix[0]] if kd != 2 else None, pose[ix[1]] if kd != 2 else None, pose[ix[2]], pose[ix[3]] if kd != 0 else None,
+                                    sc[ix[4]], pt[:3], pt[3:], w.proj_sqrt_info, w.proj_loss_a)
     hidden = []
     io = e0 = pn = nn = no = 0
     for k in range(a["comp_M"].size):

@@ -725,3 +725,12 @@ def test_windows_with_inverse_depth_landmarks_match_oracle_solver():
         for k in ("pose", "sb", "lm", "sc"):
             assert np.array_equal(c.a[k], wb.a[k])
     bs.close()
+    # the ceres::Problem-shaped surface: AddResidualBlock(ProjectionTwoFrameOneCamFactor, CauchyLoss, pose_i, pose_j, ex, inv_depth)
+    P, blocks = solver.problem_from_window(wins[0].copy())
+    sm = P.Solve(default_options())
+    c, costs = singles[0]
+    assert [r["cost"] for r in sm.rows()] == costs
+    assert np.array_equal(np.concatenate(blocks[:wins[0].n_pose]), c.a["pose"].ravel())
+    sc_blocks = blocks[wins[0].n_pose + wins[0].n_sb + wins[0].n_lm:]
+    assert np.array_equal(np.concatenate(sc_blocks), c.a["sc"])
+    P.close()
