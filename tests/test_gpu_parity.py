@@ -725,6 +725,11 @@ def test_windows_with_inverse_depth_landmarks_match_oracle_solver():
         for k in ("pose", "sb", "lm", "sc"):
             assert np.array_equal(c.a[k], wb.a[k])
     bs.close()
+    # a feature seen from more frames than a 64-column clique holds is refused, not mis-solved
+    long_w = ig.convert_short_tracks(synth.make_window(2, K=14, F=30, S=0, seed=17), max_track=14)
+    if max(np.bincount(long_w.a["idp_idx"].reshape(-1, 5)[:, 4])) >= 11:
+        with pytest.raises(solver.SwfError):
+            solver.BatchSolver([long_w])
     # the ceres::Problem-shaped surface: AddResidualBlock(ProjectionTwoFrameOneCamFactor, CauchyLoss, pose_i, pose_j, ex, inv_depth)
     P, blocks = solver.problem_from_window(wins[0].copy())
     sm = P.Solve(default_options())
