@@ -22,6 +22,8 @@ CASES = {
     "dense_prior_k14_f30_s4": dict(config_id=5, K=14, F=30, S=4, seed=303),
     # frames linked by composite IMU-GNSS factors (3 hidden GNSS epochs per gap, 5 ambiguities) + 24 landmarks: tests/composite_gen.py
     "composite_k4_m3_n5_f24": dict(composite=dict(K=4, M=3, N=5, F=24), seed=404),
+    # short tracks held as inverse-depth landmarks (ProjectionTwoFrameOneCamFactor), long ones as world points: tests/idepth_gen.py
+    "idepth_k8_f30": dict(idepth=dict(config_id=2, K=8, F=30, S=0, seed=505), max_track=4),
 }
 ITERS = 6
 
@@ -52,6 +54,9 @@ if __name__ == "__main__":
         if "composite" in kw:
             import composite_gen as cg
             w0 = cg.make_window(np.random.default_rng(kw["seed"]), **kw["composite"])
+        elif "idepth" in kw:
+            import idepth_gen as ig
+            w0 = ig.convert_short_tracks(synth.make_window(**kw["idepth"]), max_track=kw["max_track"])
         else:
             w0 = synth.make_window(**kw)
         w = w0.copy()
