@@ -120,6 +120,7 @@ struct DevBatch {
     const double* imu_pre; const double* cp_dat; const double* pr_dat; const double* dop_dat; const double* sp_w;
     const double* gx_dat;            // records of the rover-only / fixed-integer scalar factors (GFac.data = offset in doubles)
     int n_imu; const int* imu_gf;              // generic-factor ids by kernel
+    int n_idp; const int* idp_gf;              // inverse-depth projection factors (also members of sc_gf for the J v products)
     int n_sc;  const int* sc_gf;
     int n_prior; const int* prior_gf;
     // priors

@@ -117,7 +117,7 @@ struct Build {
     std::vector<GFac> gf;
     std::vector<int> s_x, s_loc, s_ls, s_joff, s_ccol;
     std::vector<double> imu_pre, cp_dat, pr_dat, dop_dat, sp_w, gx_dat;
-    std::vector<int> imu_gf, sc_gf, prior_gf;
+    std::vector<int> imu_gf, sc_gf, prior_gf, idp_gf;
     std::vector<int> prior_dim, prior_roff, prior_x0off;
     std::vector<long long> prior_Joff;
     std::vector<double> prior_J, prior_r0, prior_x0;
@@ -368,7 +368,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         int data = (int)B.gx_dat.size();
         B.gx_dat.push_back((double)kd);
         B.gx_dat.insert(B.gx_dat.end(), w->idp_pts + (size_t)i * 6, w->idp_pts + (size_t)(i + 1) * 6);
-        B.sc_gf.push_back(add_gf(GF_IDP, 2, data, blks));
+        { int g = add_gf(GF_IDP, 2, data, blks); B.sc_gf.push_back(g); B.idp_gf.push_back(g); }
     }
     std::vector<int> prior_first_gf;
     {
@@ -704,7 +704,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     PUT(s_x, B.s_x); PUT(s_loc, B.s_loc); PUT(s_ls, B.s_ls); PUT(s_joff, B.s_joff); PUT(s_ccol, B.s_ccol);
     PUT(imu_pre, B.imu_pre); PUT(cp_dat, B.cp_dat); PUT(pr_dat, B.pr_dat); PUT(dop_dat, B.dop_dat); PUT(sp_w, B.sp_w); PUT(gx_dat, B.gx_dat);
     D.n_imu = (int)B.imu_gf.size(); D.n_sc = (int)B.sc_gf.size(); D.n_prior = (int)B.prior_gf.size();
-    PUT(imu_gf, B.imu_gf); PUT(sc_gf, B.sc_gf); PUT(prior_gf, B.prior_gf);
+    PUT(imu_gf, B.imu_gf); PUT(sc_gf, B.sc_gf); PUT(prior_gf, B.prior_gf); D.n_idp = (int)B.idp_gf.size(); PUT(idp_gf, B.idp_gf);
     PUT(prior_dim, B.prior_dim); PUT(prior_Joff, B.prior_Joff); PUT(prior_roff, B.prior_roff); PUT(prior_x0off, B.prior_x0off);
     PUT(prior_J, B.prior_J); PUT(prior_r0, B.prior_r0); PUT(prior_x0, B.prior_x0);
     D.n_cl = (int)B.cl.size();
@@ -908,6 +908,7 @@ struct Launcher {
             Segs S{}; S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
             hipLaunchKernelGGL(k_eval_ps<true>, dim3(S.e[2]), dim3(256), 0, st, D, S);
         }
+        if (D.n_idp) hipLaunchKernelGGL(k_eval_idp<true>, GRID(D.n_idp, 128), dim3(128), 0, st, D);
         if (b->aux) (void)hipEventRecord(b->ev_fork[1], st);
         if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU, sa); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, sa, D); }
         if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
@@ -990,6 +991,7 @@ struct Launcher {
             if (S.e[7] && fuse_imu) hipLaunchKernelGGL(k_post_dogleg<true>, dim3(S.e[7]), dim3(256), 0, st, D, O, S);
             else if (S.e[7]) hipLaunchKernelGGL(k_post_dogleg<false>, dim3(S.e[7]), dim3(256), 0, st, D, O, S);
             if (!fuse_imu && D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, st, D);
+            if (D.n_idp) hipLaunchKernelGGL(k_eval_idp<false>, GRID(D.n_idp, 128), dim3(128), 0, st, D);
         }
         {
             Bracket t(*this, SWF_K_CAND_EVAL);

@@ -339,6 +339,7 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
     if (JAC ? !s.need_lin : !s.eval_cand) return;
+    if (G.type == GF_IDP) return;          // two-row inverse-depth projections: their own kernel (k_eval_idp), they only share the J v code
     const WinRec& W = B.win[G.win];
     const double* xs = JAC ? B.x : B.xc;
     int s0 = G.slot0, ld = G.jld;          // column stride of the clique's dense column-major Jacobian
@@ -427,7 +428,31 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
             int jo = B.s_joff[s0]; if (jo >= 0) B.g_J[jo] = -dat[1];
             jo = B.s_joff[s0 + 1]; if (jo >= 0) B.g_J[jo] = dat[1];
         }
-    } else if (G.type == GF_IDP) {
+    } else {   // GF_SP
+        double wv = B.sp_w[G.data];
+        r = wv * xs[B.s_x[s0]];
+        if (JAC) { int jo = B.s_joff[s0]; if (jo >= 0) B.g_J[jo] = wv; }
+    }
+    B.g_cost[f] = 0.5 * r * r;
+    if (JAC) B.g_r[G.roff] = r;
+}
+
+// =========================================================================================
+// Inverse-depth projection factors (R/factor/projection_factor.cpp:77-329), one lane each, in their own
+// kernel: the evaluation is register-hungry and must not drag down the occupancy of the fused k_eval_ps grid.
+// =========================================================================================
+template <bool JAC>
+__global__ void __launch_bounds__(128) k_eval_idp(DevBatch B) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= B.n_idp) return;
+    int f = B.idp_gf[q];
+    const GFac& G = B.gf[f];
+    const WinState& s = B.ws[G.win];
+    if (JAC ? !s.need_lin : !s.eval_cand) return;
+    const WinRec& W = B.win[G.win];
+    const double* xs = JAC ? B.x : B.xc;
+    int s0 = G.slot0, ld = G.jld;
+    {
         // inverse-depth projection factor (2 residual rows): record = kind | pts_i (3) | pts_j (3); slots in the reference's block order
         const double* dat = B.gx_dat + G.data;
         const int kind = (int)dat[0];
@@ -459,14 +484,7 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
                 for (int j = 0; j < l; j++) { B.g_J[jo + j * ld] = (bq == 4 ? Jq[48] : Jq[bq * 12 + j]) * sr; B.g_J[jo + j * ld + 1] = (bq == 4 ? Jq[49] : Jq[bq * 12 + 6 + j]) * sr; }
             }
         }
-        return;
-    } else {   // GF_SP
-        double wv = B.sp_w[G.data];
-        r = wv * xs[B.s_x[s0]];
-        if (JAC) { int jo = B.s_joff[s0]; if (jo >= 0) B.g_J[jo] = wv; }
     }
-    B.g_cost[f] = 0.5 * r * r;
-    if (JAC) B.g_r[G.roff] = r;
 }
 
 // =========================================================================================
