@@ -1244,12 +1244,11 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
     int la = Pr.la, lb = Pr.lb, n = W.n_red, m = 6 * W.nF;
     double* S = B.S + W.S_base;
     const double* P = B.P + W.P_base * GEMM_SPLIT;
-    double H[21], gr[6], qv[6];
+    double acc = 0;                                   // lane k of a diagonal pair's wave: frame sum k (H 0..20 | g 21..26 | q 27..32)
     bool obs = DIAG && Pr.fa >= 0;
     if (obs) {
         // level 2: lanes v < 33 add this frame's block partials in block order
         // (block offsets fetched lane-parallel and broadcast, so the value loads do not chain behind index loads)
-        double acc = 0;
         for (int b0 = W.fsb0; b0 < W.fsb1; b0 += 64) {
             int myoff = (b0 + lane < W.fsb1) ? B.fsb_out0[b0 + lane] : 0;
             int nn = (W.fsb1 - b0) < 64 ? (W.fsb1 - b0) : 64;
@@ -1260,10 +1259,6 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
                 acc += lane < FS_VAL ? v : 0.0;
             }
         }
-#pragma unroll
-        for (int k = 0; k < 21; k++) H[k] = __shfl(acc, k, 64);
-#pragma unroll
-        for (int k = 0; k < 6; k++) { gr[k] = __shfl(acc, 21 + k, 64); qv[k] = __shfl(acc, 27 + k, 64); }
     }
     // contribution descriptors: lane c of the group keeps descriptor c0 + c (+ G per round) in
     // registers, so the value loads below do not chain behind descriptor loads
@@ -1273,7 +1268,12 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
     double dg_i = 0;    // lane i < la: raw diag of column i
     if (DIAG) {
         double gi = 0, cs = 0;
-        if (obs && lane < la) { int i = lane; gi = gr[i]; dg_i = H[i * (i + 1) / 2 + i]; cs = -qv[i]; }
+        if (obs) {
+            // the frame sums stay in their lanes: each use is one ds_bpermute (a register array indexed by lane spilled to scratch)
+            int i = lane < 6 ? lane : 0;
+            double g0 = __shfl(acc, 21 + i, 64), h0 = __shfl(acc, i * (i + 1) / 2 + i, 64), q0 = __shfl(acc, 27 + i, 64);
+            if (lane < la) { gi = g0; dg_i = h0; cs = -q0; }
+        }
         for (int cb0 = 0; cb0 < ncon; cb0 += 64) {
             int myv = (cb0 + lane < ncon) ? B.pc_voff[Pr.c0 + cb0 + lane] : 0;
             int nn = (ncon - cb0) < 64 ? (ncon - cb0) : 64;
@@ -1307,9 +1307,12 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
         int i = ev[r] ? e / lb : 0;
         ei[r] = i; ej[r] = ev[r] ? e - i * lb : 0;
     }
-    double vsum[NR];
+    double vsum[NR], hsum[NR];
 #pragma unroll
-    for (int r = 0; r < NR; r++) vsum[r] = 0;
+    for (int r = 0; r < NR; r++) {
+        vsum[r] = 0; hsum[r] = 0;
+        if (obs) { int i = ei[r] < 6 ? ei[r] : 0, j = ej[r] < 6 ? ej[r] : 0, hi = i > j ? i : j, lo = i > j ? j : i; hsum[r] = __shfl(acc, hi * (hi + 1) / 2 + lo, 64); }
+    }
     for (int cb0 = 0; cb0 < ncon; cb0 += G) {
         long long myo = (cb0 + lane < ncon) ? B.pc_coff[Pr.c0 + cb0 + lane] : 0;
         int myl = (cb0 + lane < ncon) ? B.pc_cld[Pr.c0 + cb0 + lane] : 0;
@@ -1341,7 +1344,7 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
 #pragma unroll
             for (int q = 0; q < GEMM_SPLIT; q++) if (q < n_part) ps += P[(size_t)q * m * m + pi];     // fixed order (n_part = 1: folded by k_lm_schur)
             v -= ps;
-            if (obs) { int hi = i > j ? i : j, lo = i > j ? j : i; v += H[hi * (hi + 1) / 2 + lo]; }
+            if (obs) v += hsum[r];
         }
         if (DIAG && i == j) v += s.mu * clampd(e < 64 ? dgs0 : dgs1, O.min_diag, O.max_diag);
         S[(size_t)(Pr.ra + i) * n + Pr.rb + j] = v;      // lower triangle only; exports mirror on the host
