@@ -10,7 +10,6 @@ from rtk_visual_inertial_navigation_amd.ordering import my_ordering
 
 def convert_short_tracks(w, max_track=7):
     a = w.a
-    K = w.meta["K"]
     n_pose, n_sb, n_lm, n_sc = w.n_pose, w.n_sb, w.n_lm, w.n_sc
     pidx = a["proj_idx"].reshape(-1, 3); puv = a["proj_uv"].reshape(-1, 2)
     pose = a["pose"].reshape(-1, 7); lm = a["lm"].reshape(-1, 3)
@@ -44,18 +43,33 @@ def convert_short_tracks(w, max_track=7):
     for b, c in enumerate(a["is_const"]):
         nb = remap(b)
         if nb is not None: is_const[nb] = c
-    roles = {}
-    for k, v in w.meta["roles"].items():
-        if isinstance(v, list): roles[k] = [remap(b) for b in v if remap(b) is not None]
-        else: roles[k] = remap(v) if v is not None else None
     lam_blocks = [n_pose + n_sb + n_lm2 + i for i in range(n_sc, n_sc2)]
-    roles["landmarks"] = roles["landmarks"] + lam_blocks                 # the inverse depths are the feature blocks of the policy
-    order_block, order_group, n_tail = my_ordering(roles, is_const)
+    roles = None
+    if "roles" in w.meta:
+        roles = {}
+        for k, v in w.meta["roles"].items():
+            if isinstance(v, list): roles[k] = [remap(b) for b in v if remap(b) is not None]
+            else: roles[k] = remap(v) if v is not None else None
+        roles["landmarks"] = roles["landmarks"] + lam_blocks             # the inverse depths are the feature blocks of the policy
+        order_block, order_group, n_tail = my_ordering(roles, is_const)
+    else:
+        # no policy description: keep the window's own order, the inverse depths join group 0 behind its other members
+        ob_, og_ = [], []
+        for b, g in zip(a["order_block"], a["order_group"]):
+            nb = remap(int(b))
+            if nb is not None and g == 0: ob_.append(nb); og_.append(0)
+        ob_ += lam_blocks; og_ += [0] * len(lam_blocks)
+        for b, g in zip(a["order_block"], a["order_group"]):
+            nb = remap(int(b))
+            if nb is not None and g != 0: ob_.append(nb); og_.append(int(g))
+        order_block, order_group, n_tail = np.array(ob_, np.int32), np.array(og_, np.int32), w.n_tail
     prior_blk = np.array([remap(int(b)) for b in a["prior_blk"]], np.int32)
     kw = {k: a[k] for k in ("pose", "sb", "imu_idx", "imu_pre", "cp_idx", "cp_dat", "pr_idx", "pr_dat", "dop_idx", "dop_dat", "sp_idx", "sp_w",
-                            "prior_nblk", "prior_dim", "prior_J", "prior_r0", "prior_x0")}
+                            "prior_nblk", "prior_dim", "prior_J", "prior_r0", "prior_x0", "spr_idx", "spr_dat", "scp_idx", "scp_dat", "fix_idx", "fix_dat",
+                            "comp_M", "comp_N", "comp_idx", "comp_pose", "comp_sb", "comp_pose_lin", "comp_sb_lin", "comp_Hpp", "comp_HpN", "comp_rhs_p",
+                            "comp_HNN", "comp_rhsN", "comp_pre")}
     return FlatWindow(lm=new_lm, sc=np.array(sc), is_const=is_const, order_block=order_block, order_group=order_group, n_tail=n_tail,
                       proj_idx=np.array(proj_idx, np.int32).reshape(-1, 3), proj_uv=np.array(proj_uv).reshape(-1, 2),
                       idp_kind=np.array(idp_kind, np.int32), idp_idx=np.array(idp_idx, np.int32).reshape(-1, 5), idp_pts=np.array(idp_pts).reshape(-1, 6),
                       prior_blk=prior_blk, proj_sqrt_info=w.proj_sqrt_info, proj_loss_a=w.proj_loss_a, pbg=w.pbg, gw=w.gw, base=w.base,
-                      meta=dict(w.meta, roles=roles, n_idepth_landmarks=len(conv)), **kw)
+                      meta=dict(w.meta, n_idepth_landmarks=len(conv), **({"roles": roles} if roles is not None else {})), **kw)

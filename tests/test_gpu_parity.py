@@ -725,6 +725,19 @@ def test_windows_with_inverse_depth_landmarks_match_oracle_solver():
         for k in ("pose", "sb", "lm", "sc"):
             assert np.array_equal(c.a[k], wb.a[k])
     bs.close()
+    # everything at once: frames linked by composite IMU-GNSS factors, short tracks as inverse depths, long tracks as world points
+    import composite_gen as cg
+    wk = ig.convert_short_tracks(cg.make_window(np.random.default_rng(8), 6, 3, 6, F=60), max_track=3)
+    ck = wk.counts()
+    assert ck["n_comp"] == 5 and ck["n_idp"] > 0 and ck["n_proj"] > 0
+    wo, wg = wk.copy(), wk.copy()
+    so, _ = ob.solve(wo, default_options(), export=False)
+    bs, sg = gpu_solve(wg, default_options())
+    assert sg.termination == so.termination and [r["step_is_successful"] for r in sg.rows()] == [r["step_is_successful"] for r in so.rows()]
+    for a, b in zip(sg.rows(), so.rows()):
+        assert abs(a["cost"] - b["cost"]) <= 1e-6 * abs(b["cost"]) + 1e-6
+    assert np.abs(wg.a["pose"] - wo.a["pose"]).max() < 1e-6 and np.abs(wg.a["comp_pose"] - wo.a["comp_pose"]).max() < 1e-6
+    bs.close()
     # a feature seen from more frames than a 64-column clique holds is refused, not mis-solved
     long_w = ig.convert_short_tracks(synth.make_window(2, K=14, F=30, S=0, seed=17), max_track=14)
     if max(np.bincount(long_w.a["idp_idx"].reshape(-1, 5)[:, 4])) >= 11:
