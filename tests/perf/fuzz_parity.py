@@ -1,12 +1,14 @@
 """Randomised GPU-vs-oracle parity sweep (not part of the test suite; run on a GPU box):
    python tests/perf/fuzz_parity.py [n_cases] [seed]
-Random window shapes (keyframes, features, satellites, Doppler, SPP / fixed-integer factors, parameter_head choice); for each:
+Random window shapes (keyframes, features, satellites, Doppler, SPP / fixed-integer factors, inverse-depth landmarks,
+parameter_head choice); for each:
 linearisation + reduced system against the oracle, the 8-iteration dogleg sequence, and batch == single bitwise."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_binding as ob
+import idepth_gen as ig
 from rtk_visual_inertial_navigation_amd import synth, solver
 from rtk_visual_inertial_navigation_amd.flat import default_options
 
@@ -27,6 +29,9 @@ for t in range(N):
     w = synth.make_window(**kw)
     if S and rng.random() < 0.4:
         w = synth.with_spp_and_fixed(w, seed=int(rng.integers(1, 1000)), n_fix=int(rng.integers(0, 4)))
+    idp = False
+    if not os.environ.get("FUZZ_LARGE") and rng.random() < 0.35:         # short tracks as inverse-depth landmarks (row a2)
+        w = ig.convert_short_tracks(w, max_track=int(rng.integers(2, 8))); idp = w.counts()["n_idp"] > 0
     msg = []
     try:
         so, eo = ob.solve(w.copy(), default_options(step_mode=1))
@@ -51,7 +56,7 @@ for t in range(N):
         bs.close()
     except Exception as e:
         msg.append("exception " + repr(e)[:200])
-    print(t, kw, "spp" if w.a["spr_idx"].size else "", "OK" if not msg else "FAIL " + "; ".join(msg), flush=True)
+    print(t, kw, "spp" if w.a["spr_idx"].size else "", "idepth" if idp else "", "OK" if not msg else "FAIL " + "; ".join(msg), flush=True)
     bad += bool(msg)
 # the whole set as one heterogeneous batch == the singles, bit for bit
 if wins:
