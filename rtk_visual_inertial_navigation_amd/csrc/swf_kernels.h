@@ -1189,8 +1189,13 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
     if (!B.ws[w].need_lin) return;
     const WinRec& W = B.win[w];
     int o_beg = B.fsb_obs0[blk], cnt = B.fsb_obs0[blk + 1] - o_beg, tid = threadIdx.x, n = B.n_proj;
+    // thread q stages the observation at frame-sorted position q: the block's cache lines are all
+    // consumed either way, and the owner loop below then walks V sequentially (no index chase)
+    __shared__ int foff[168];
+    int nF = W.nF;
+    for (int e = tid; e <= nF; e += FS_BLK) foff[e] = B.fsb_foff[B.fsb_foff0[blk] + e];
     if (tid < cnt) {
-        int o = o_beg + tid;
+        int o = o_beg + B.fsb_perm[o_beg + tid];
         double a[6], b[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) { a[i] = B.p_Jp[i * n + o]; b[i] = B.p_Jp[(6 + i) * n + o]; }
@@ -1206,19 +1211,19 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
 #pragma unroll
         for (int i = 0; i < 6; i++) V[tid][27 + i] = lmv ? B.p_yg[i * n + o] : 0.0;
     }
-    // frame-sorted permutation of the block and its per-frame offsets, staged once
-    __shared__ int perm[FS_BLK];
-    __shared__ int foff[168];
-    int nF = W.nF;
-    if (tid < cnt) perm[tid] = B.fsb_perm[o_beg + tid];
-    for (int e = tid; e <= nF; e += FS_BLK) foff[e] = B.fsb_foff[B.fsb_foff0[blk] + e];
     __syncthreads();
-    // owner (frame f, value v) adds the block's observations of frame f in permutation order
+    // owner (frame f, value v) adds the block's observations of frame f in permutation order;
+    // loads are issued four at a time, the additions keep their order
     double* out = B.fs_part + (size_t)B.fsb_out0[blk] * FS_VAL;
     for (int e = tid; e < nF * FS_VAL; e += FS_BLK) {
         int f = e / FS_VAL, v = e % FS_VAL;
         double acc = 0;
-        for (int q = foff[f]; q < foff[f + 1]; q++) acc += V[perm[q]][v];
+        int q = foff[f], q1 = foff[f + 1];
+        for (; q + 4 <= q1; q += 4) {
+            double v0 = V[q][v], v1 = V[q + 1][v], v2 = V[q + 2][v], v3 = V[q + 3][v];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; q < q1; q++) acc += V[q][v];
         out[e] = acc;
     }
 }
