@@ -475,13 +475,19 @@ __global__ void __launch_bounds__(128) k_eval_idp(DevBatch B) {
         B.g_cost[f] = cost;
         if (JAC) {
             B.g_r[G.roff] = r2[0] * sr; B.g_r[G.roff + 1] = r2[1] * sr;
-            // Jq blocks: pose_i | pose_j | ex | ex2 | lambda  ->  the slots this kind has
-            const int blk_of_slot[5] = { kind == 2 ? 2 : 0, kind == 2 ? 3 : 1, kind == 2 ? 4 : 2, kind == 0 ? 4 : 3, 4 };
-            for (int t = 0; t < G.nslot; t++) {
+            // Jq blocks: pose_i | pose_j | ex | ex2 | lambda  ->  the slot this kind keeps each of them in (-1: absent).
+            // The block loop is unrolled so that Jq is indexed by constants and stays in registers.
+#pragma unroll
+            for (int bq = 0; bq < 5; bq++) {
+                int t = kind == 1 ? bq : (kind == 0 ? (bq == 3 ? -1 : (bq == 4 ? 3 : bq)) : bq - 2);
+                if (t < 0) continue;
                 int jo = B.s_joff[s0 + t];
                 if (jo < 0) continue;
-                int bq = blk_of_slot[t], l = bq == 4 ? 1 : 6;
-                for (int j = 0; j < l; j++) { B.g_J[jo + j * ld] = (bq == 4 ? Jq[48] : Jq[bq * 12 + j]) * sr; B.g_J[jo + j * ld + 1] = (bq == 4 ? Jq[49] : Jq[bq * 12 + 6 + j]) * sr; }
+                if (bq == 4) { B.g_J[jo] = Jq[48] * sr; B.g_J[jo + 1] = Jq[49] * sr; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { B.g_J[jo + j * ld] = Jq[bq * 12 + j] * sr; B.g_J[jo + j * ld + 1] = Jq[bq * 12 + 6 + j] * sr; }
+                }
             }
         }
     }

@@ -788,6 +788,9 @@ __device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O,
     int nl = B.n_lm, n = B.n_proj;
     double vl0 = 0, vl1 = 0, vl2 = 0;
     if (lin && loc >= 0) { vl0 = vec_at<0>(B, O, loc); vl1 = vec_at<0>(B, O, loc + 1); vl2 = vec_at<0>(B, O, loc + 2); }
+    // g_l and Einv of the landmark are fetched up front by lanes 0..8 of the group (one load, off the dependent chain)
+    double pre = 0;
+    if (act && sub < 9) pre = sub < 3 ? B.lm_g[sub * nl + L] : B.lm_Einv[(sub - 3) * nl + L];
     double t0 = 0, t1 = 0, t2 = 0;
     if (lin) for (int o = B.lm_obs0[Lc] + sub; o < B.lm_obs0[Lc + 1]; o += 16) {
         int lp = B.p_lpose[o];
@@ -808,17 +811,22 @@ __device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O,
         if (B.p_fr[o] >= 0) { t0 -= jl0 * u0 + jl3 * u1; t1 -= jl1 * u0 + jl4 * u1; t2 -= jl2 * u0 + jl5 * u1; }
     }
     t0 = grp16_sum(t0); t1 = grp16_sum(t1); t2 = grp16_sum(t2);
+    int g0 = (threadIdx.x & 63) & ~15;
+    double pv[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) pv[k] = __shfl(pre, g0 + k, 64);
     if (!act || sub != 0) return;
-    t0 += B.lm_g[L]; t1 += B.lm_g[nl + L]; t2 += B.lm_g[2 * nl + L];
-    double e00 = B.lm_Einv[L], e10 = B.lm_Einv[nl + L], e20 = B.lm_Einv[2 * nl + L];
-    double e11 = B.lm_Einv[3 * nl + L], e21 = B.lm_Einv[4 * nl + L], e22 = B.lm_Einv[5 * nl + L];
+    t0 += pv[0]; t1 += pv[1]; t2 += pv[2];
+    double e00 = pv[3], e10 = pv[4], e20 = pv[5], e11 = pv[6], e21 = pv[7], e22 = pv[8];
     B.y[loc] = e00 * t0 + e10 * t1 + e20 * t2;
     B.y[loc + 1] = e10 * t0 + e11 * t1 + e21 * t2;
     B.y[loc + 2] = e20 * t0 + e21 * t1 + e22 * t2;
 }
 __device__ __forceinline__ void d_backsub_clique(const DevBatch& B, int bid) {
-    // 16 lanes per clique with an eliminated block (d_e <= 9): lane a forms t_a = g_e[a] - (M_ef y_f)_a,
-    // the Einv product gathers the t's with 16-wide shuffles
+    // 16 lanes per clique with an eliminated block (d_e <= 9).  The strip product M_ef y_f is split by column over the
+    // lanes (lane s takes columns s, s+16, ...: coalesced rows of the strip, the member list is walked once), the 16
+    // partials of each row are added by the fixed butterfly, then lane a holds t_a = g_e[a] - (M_ef y_f)_a and the
+    // Einv product gathers the t's with 16-wide shuffles.
     int q = (bid * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15, lane = threadIdx.x & 63;
     bool valid = q < B.n_cle;
     const Clique& C = B.cl[B.cle_idx[valid ? q : B.n_cle - 1]];
@@ -826,21 +834,30 @@ __device__ __forceinline__ void d_backsub_clique(const DevBatch& B, int bid) {
     bool act = valid && s.need_lin && !s.lin_fail;
     int de = C.d_e, df = C.d_f;
     const double* E = B.cE + C.e_off;
-    double t = 0;
-    if (act && sub < de) {
-        t = E[de * de + de * df + sub];
-        for (int m = C.mem0; m < C.mem1; m++) {
-            int lo = B.cm_loc[m], l = B.cm_ls[m], cc = B.cm_col[m];
-            for (int j = 0; j < l; j++) t -= E[de * de + sub * df + cc + j] * B.y[lo + j];
+    const double* M = E + de * de;
+    double part[9];
+#pragma unroll
+    for (int a = 0; a < 9; a++) part[a] = 0;
+    if (act && df > 0) {
+        int m = C.mem0, cc = B.cm_col[m], l = B.cm_ls[m], lo = B.cm_loc[m];
+        for (int c = sub; c < df; c += 16) {
+            while (c >= cc + l) { m++; cc = B.cm_col[m]; l = B.cm_ls[m]; lo = B.cm_loc[m]; }
+            double yv = B.y[lo + c - cc];
+#pragma unroll
+            for (int a = 0; a < 9; a++) if (a < de) part[a] += M[a * df + c] * yv;
         }
     }
-    double a = 0;
+    double t = 0;
+#pragma unroll
+    for (int a = 0; a < 9; a++) { double pa = grp16_sum(part[a]); if (sub == a) t = pa; }
+    if (act && sub < de) t = M[de * df + sub] - t;
+    double acc = 0;
 #pragma unroll
     for (int b = 0; b < 9; b++) {
         double tb = __shfl(t, (lane & ~15) + b, 64);
-        if (act && sub < de && b < de) a += E[sub * de + b] * tb;
+        if (act && sub < de && b < de) acc += E[sub * de + b] * tb;
     }
-    if (act && sub < de) B.y[C.e_loc + sub] = a;
+    if (act && sub < de) B.y[C.e_loc + sub] = acc;
 }
 
 
@@ -861,11 +878,15 @@ __global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
     else if (bid < S.e[1]) d_eval_scalar<JAC>(B, bid - S.e[0]);
     else d_eval_prior<JAC>(B, bid - S.e[1], sm_prior);        // one workgroup per prior (segment empty for large priors)
 }
-// after the reduced solve: back-substitution of the eliminated blocks, and |J D^-2 g|^2 for the Cauchy point
+// after the reduced solve: back-substitution of the eliminated blocks, and |J D^-2 g|^2 for the Cauchy point.
+// PART 0: every segment in one grid (latency path).  Large batches launch the landmark segment (PART 1, the
+// HBM-bound one) apart from the rest (PART 2) so that it keeps its own, lower register count and full occupancy.
+template <int PART>
 __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S) {
-    int bid = blockIdx.x;
-    if (bid < S.e[0]) d_backsub_lm(B, O, bid);                 // also the projection part of |J D^-2 g|^2
-    else if (bid < S.e[1]) d_backsub_clique(B, bid - S.e[0]);
+    int bid = blockIdx.x + (PART == 2 ? S.e[0] : 0);
+    if (PART != 2 && bid < S.e[0]) { d_backsub_lm(B, O, bid); return; }   // also the projection part of |J D^-2 g|^2
+    if (PART == 1) return;
+    if (bid < S.e[1]) d_backsub_clique(B, bid - S.e[0]);
     else if (bid < S.e[3]) d_jtimes_scalar<0>(B, O, bid - S.e[2]);
     else if (bid < S.e[4]) d_jtimes_imu<0>(B, O, bid - S.e[3]);
     else d_jtimes_prior<0>(B, O, bid - S.e[4]);
