@@ -706,6 +706,14 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     D.n_imu = (int)B.imu_gf.size(); D.n_sc = (int)B.sc_gf.size(); D.n_prior = (int)B.prior_gf.size();
     PUT(imu_gf, B.imu_gf); PUT(sc_gf, B.sc_gf); PUT(prior_gf, B.prior_gf); D.n_idp = (int)B.idp_gf.size(); PUT(idp_gf, B.idp_gf);
     PUT(prior_dim, B.prior_dim); PUT(prior_Joff, B.prior_Joff); PUT(prior_roff, B.prior_roff); PUT(prior_x0off, B.prior_x0off);
+    {   // transposed copies of the prior records for the J v products
+        std::vector<double> Jt(B.prior_J.size());
+        for (size_t k = 0; k < B.prior_dim.size(); k++) {
+            const size_t n = (size_t)B.prior_dim[k]; const double* J = B.prior_J.data() + B.prior_Joff[k]; double* T = Jt.data() + B.prior_Joff[k];
+            for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++) T[c * n + r] = J[r * n + c];
+        }
+        PUT(prior_Jt, Jt);
+    }
     PUT(prior_J, B.prior_J); PUT(prior_r0, B.prior_r0); PUT(prior_x0, B.prior_x0);
     D.n_cl = (int)B.cl.size();
     PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cl_frow, B.cl_frow); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
@@ -791,7 +799,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         }
         rc |= P.put(B.co_win, &Mt.win); rc |= P.put(B.co_xo_off, &Mt.xo_off); rc |= P.put(B.co_xo, &Mt.xo);
         rc |= P.put(Joff, &Mt.Joff); rc |= P.put(roff, &Mt.roff); rc |= P.put(x0off, &Mt.x0off); rc |= P.put(Coff, &Mt.Coff); rc |= P.put(voff, &Mt.voff);
-        Mt.prior_J = (double*)D.prior_J; Mt.prior_r0 = (double*)D.prior_r0; Mt.prior_x0 = (double*)D.prior_x0;
+        Mt.prior_J = (double*)D.prior_J; Mt.prior_Jt = (double*)D.prior_Jt; Mt.prior_r0 = (double*)D.prior_r0; Mt.prior_x0 = (double*)D.prior_x0;
     }
     if (rc) { P.release(); delete b; return fail(SWF_E_NODEVICE, "device allocation / upload failed"); }
     *out = b;
@@ -992,8 +1000,12 @@ struct Launcher {
             // their own launch (the segment's LDS would cost the memory-bound segments occupancy).  Same results either way.
             bool fuse_imu = D.n_win < b->n_cu;
             S.e[7] = S.e[6] + (fuse_imu ? nb(D.n_imu, IMU_FPB) : 0);
-            if (S.e[7] && fuse_imu) hipLaunchKernelGGL(k_post_dogleg<true>, dim3(S.e[7]), dim3(256), 0, st, D, O, S);
-            else if (S.e[7]) hipLaunchKernelGGL(k_post_dogleg<false>, dim3(S.e[7]), dim3(256), 0, st, D, O, S);
+            if (S.e[7] && fuse_imu) hipLaunchKernelGGL((k_post_dogleg<true, 0>), dim3(S.e[7]), dim3(256), 0, st, D, O, S);
+            else if (S.e[7]) {
+                // S.e[4] - S.e[3] == S.e[0]: both projection segments have nb(n_proj) blocks
+                if (S.e[0]) hipLaunchKernelGGL((k_post_dogleg<false, 1>), dim3(2 * S.e[0]), dim3(256), 0, st, D, O, S);
+                if (S.e[7] > 2 * S.e[0]) hipLaunchKernelGGL((k_post_dogleg<false, 2>), dim3(S.e[7] - 2 * S.e[0]), dim3(256), 0, st, D, O, S);
+            }
             if (!fuse_imu && D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, st, D);
             if (D.n_idp) hipLaunchKernelGGL(k_eval_idp<false>, GRID(D.n_idp, 128), dim3(128), 0, st, D);
         }

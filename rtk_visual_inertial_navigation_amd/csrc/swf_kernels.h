@@ -519,6 +519,7 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
     int k = G.data, n = G.nres;
     double* dx = sm; double* rr = sm + n; double* red = sm + 2 * n;
     const double* Jp = B.prior_J + B.prior_Joff[k];
+    const double* Jt = B.prior_Jt + B.prior_Joff[k];
     const double* r0 = B.prior_r0 + B.prior_roff[k];
     const double* x0 = B.prior_x0 + B.prior_x0off[k];
     // one thread per kept block computes its dx segment (x0 offsets are prefix sums of sizes)
@@ -534,8 +535,15 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
     double part = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         double a = r0[i];
-        const double* row = Jp + (size_t)i * n;
-        for (int j = 0; j < n; j++) a += row[j] * dx[j];
+        // transposed record: adjacent threads read adjacent rows; eight guarded loads in flight, additions in column order
+        const double* cj = Jt + i;
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            double c[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) c[j] = j0 + j < n ? cj[(size_t)(j0 + j) * n] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (j0 + j < n) a += c[j] * dx[j0 + j];
+        }
         rr[i] = a; part += a * a;
         if (JAC) B.g_r[G.roff + i] = a;
     }
@@ -590,11 +598,19 @@ template <int MODE>
 __device__ __forceinline__ double gf_row_dot(const DevBatch& B, const DevOpt& O, const GFac& G, int k) {
     double a = 0;
     if (G.type == GF_PRIOR) {
-        const double* row = B.prior_J + B.prior_Joff[G.data] + (size_t)k * G.nres;
+        // row k of the transposed record: lanes over rows read adjacent elements; nine guarded loads per block in flight
+        const int n = G.nres;
+        const double* ck = B.prior_Jt + B.prior_Joff[G.data] + k;
         int col = 0;
         for (int t = 0; t < G.nslot; t++) {
             int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
-            if (lo >= 0) for (int j = 0; j < l; j++) a += row[col + j] * vec_at<MODE>(B, O, lo + j);
+            if (lo >= 0) for (int j0 = 0; j0 < l; j0 += 9) {
+                double c[9], v[9];
+#pragma unroll
+                for (int j = 0; j < 9; j++) { bool ok = j0 + j < l; c[j] = ok ? ck[(size_t)(col + j0 + j) * n] : 0.0; v[j] = ok ? vec_at<MODE>(B, O, lo + j0 + j) : 0.0; }
+#pragma unroll
+                for (int j = 0; j < 9; j++) if (j0 + j < l) a += c[j] * v[j];
+            }
             col += l;
         }
     } else {
@@ -603,7 +619,13 @@ __device__ __forceinline__ double gf_row_dot(const DevBatch& B, const DevOpt& O,
             if (jo < 0) continue;
             int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
             const double* col0 = B.g_J + jo + k;                 // element (k, j) of the block: column stride G.jld
-            for (int j = 0; j < l; j++) a += col0[j * G.jld] * vec_at<MODE>(B, O, lo + j);
+            for (int j0 = 0; j0 < l; j0 += 9) {                  // nine guarded loads in flight, additions in column order
+                double c[9], v[9];
+#pragma unroll
+                for (int j = 0; j < 9; j++) { bool ok = j0 + j < l; c[j] = ok ? col0[(j0 + j) * G.jld] : 0.0; v[j] = ok ? vec_at<MODE>(B, O, lo + j0 + j) : 0.0; }
+#pragma unroll
+                for (int j = 0; j < 9; j++) if (j0 + j < l) a += c[j] * v[j];
+            }
         }
     }
     return a;

@@ -891,16 +891,24 @@ __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S)
     else if (bid < S.e[4]) d_jtimes_imu<0>(B, O, bid - S.e[3]);
     else d_jtimes_prior<0>(B, O, bid - S.e[4]);
 }
-// after the dogleg step: model cost change J*step, and the candidate residuals of every factor family
-template <bool WITH_IMU>
+// after the dogleg step: model cost change J*step, and the candidate residuals of every factor family.
+// PART 0: every segment in one grid (latency path).  Large batches launch the two projection segments (PART 1, the
+// HBM-bound ones, at their own register count) apart from the small latency-bound families (PART 2).
+template <bool WITH_IMU, int PART>
 __global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs S) {
-    __shared__ double sm_prior[2 * PRIOR_LDS_DIM + 16];
+    __shared__ double sm_prior[PART == 1 ? 1 : 2 * PRIOR_LDS_DIM + 16];
     int bid = blockIdx.x;
-    if (bid < S.e[0]) d_jtimes_proj<1>(B, O, bid);
+    if (PART == 1) {                                           // grid = 2 * S.e[0]
+        if (bid < S.e[0]) d_jtimes_proj<1>(B, O, bid);
+        else d_eval_proj<false>(B, bid - S.e[0]);
+        return;
+    }
+    if (PART == 2) { bid += S.e[0]; if (bid >= S.e[3]) bid += S.e[4] - S.e[3]; }      // skip the projection segments
+    if (PART == 0 && bid < S.e[0]) d_jtimes_proj<1>(B, O, bid);
     else if (bid < S.e[1]) d_jtimes_scalar<1>(B, O, bid - S.e[0]);
     else if (bid < S.e[2]) d_jtimes_imu<1>(B, O, bid - S.e[1]);
     else if (bid < S.e[3]) d_jtimes_prior<1>(B, O, bid - S.e[2]);
-    else if (bid < S.e[4]) d_eval_proj<false>(B, bid - S.e[3]);
+    else if (PART == 0 && bid < S.e[4]) d_eval_proj<false>(B, bid - S.e[3]);
     else if (bid < S.e[5]) d_eval_scalar<false>(B, bid - S.e[4]);
     else if (bid < S.e[6]) d_eval_prior<false>(B, bid - S.e[5], sm_prior);
     else if (WITH_IMU) d_eval_imu<false>(B, bid - S.e[6]);    // candidate IMU residuals (8 factors per workgroup), small batches only

@@ -364,7 +364,7 @@ struct CompMeta {
     const int* xo;                  // ambient x offsets of the outer blocks: pose_i, sb_i, pose_j, sb_j, N scalars
     const long long* Joff; const int* roff; const int* x0off;      // the factor's prior record
     const long long* Coff; const int* voff;                        // its static clique: C (G x G), dgraw
-    double* prior_J; double* prior_r0; double* prior_x0;
+    double* prior_J; double* prior_Jt; double* prior_r0; double* prior_x0;
     int* active;
     double* outer; double* Nv;      // = CompArgs.outer / .Nv
 };
@@ -388,7 +388,8 @@ __global__ void __launch_bounds__(256) k_comp_scatter(DevBatch B, CompArgs A, Co
     const int N = A.N[f], G = 30 + N;
     const double* J = A.jac_out + A.g2_off[f]; const double* H = A.Hd + A.g2_off[f]; const double* r = A.res_out + A.g_off[f];
     double* pJ = Mt.prior_J + Mt.Joff[f]; double* C = B.C + Mt.Coff[f];
-    for (int e = t; e < G * G; e += 256) { pJ[e] = J[e]; C[e] = H[e]; }
+    double* pJt = Mt.prior_Jt + Mt.Joff[f];
+    for (int e = t; e < G * G; e += 256) { double v = J[e]; pJ[e] = v; pJt[(size_t)(e % G) * G + e / G] = v; C[e] = H[e]; }
     for (int e = t; e < G; e += 256) { Mt.prior_r0[Mt.roff[f] + e] = r[e]; B.cv_dgraw[Mt.voff[f] + e] = H[(size_t)e * G + e]; }
     double* x0 = Mt.prior_x0 + Mt.x0off[f];
     if (t < 32) x0[t] = A.outer[(size_t)f * 32 + t];
