@@ -519,7 +519,6 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
     int k = G.data, n = G.nres;
     double* dx = sm; double* rr = sm + n; double* red = sm + 2 * n;
     const double* Jp = B.prior_J + B.prior_Joff[k];
-    const double* Jt = B.prior_Jt + B.prior_Joff[k];
     const double* r0 = B.prior_r0 + B.prior_roff[k];
     const double* x0 = B.prior_x0 + B.prior_x0off[k];
     // one thread per kept block computes its dx segment (x0 offsets are prefix sums of sizes)
@@ -535,15 +534,8 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
     double part = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         double a = r0[i];
-        // transposed record: adjacent threads read adjacent rows; eight guarded loads in flight, additions in column order
-        const double* cj = Jt + i;
-        for (int j0 = 0; j0 < n; j0 += 8) {
-            double c[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) c[j] = j0 + j < n ? cj[(size_t)(j0 + j) * n] : 0.0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) if (j0 + j < n) a += c[j] * dx[j0 + j];
-        }
+        const double* row = Jp + (size_t)i * n;
+        for (int j = 0; j < n; j++) a += row[j] * dx[j];
         rr[i] = a; part += a * a;
         if (JAC) B.g_r[G.roff + i] = a;
     }

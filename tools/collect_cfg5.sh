@@ -10,12 +10,12 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/swf5 && mkdir -p /tmp/swf5
 export PYTHONPATH="$ROOT"
 ( cd "$ROOT" && python tests/gpu_cfg5_prof.py ) > "$OUT/cfg5_single_window.txt" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swf5/kt -o k -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/kt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swf5/kt -o k -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/kt.log 2>&1
 cp "$(find /tmp/swf5/kt -name '*kernel_stats.csv' | head -1)" "$OUT/cfg5_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d /tmp/swf5/pmc_$C -o p -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/pmc_$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/swf5/pmc_$C -o p -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/pmc_$C.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swf5/pmc_mfma -o p -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/pmc_mfma.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swf5/pmc_mfma -o p -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/pmc_mfma.log 2>&1
 python "$ROOT/tools/summarize_mfma_pmc.py" "$(find /tmp/swf5/pmc_mfma -name '*counter_collection.csv' | head -1)" "$OUT/cfg5_pmc_mfma.json"
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections

@@ -12,18 +12,18 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/swfprof && mkdir -p /tmp/swfprof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/batch -o b -- python "$ROOT/tests/gpu_batch_prof.py" 512 4 > /tmp/swfprof/batch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/batch -o b -- python "$ROOT/tests/gpu_batch_prof.py" 512 4 > /tmp/swfprof/batch.log 2>&1
 cp "$(find /tmp/swfprof/batch -name '*kernel_stats.csv' | head -1)" "$OUT/batch512_kernel_stats.csv"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/single -o s -- python "$ROOT/tests/gpu_single_prof.py" 20 > /tmp/swfprof/single.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/single -o s -- python "$ROOT/tests/gpu_single_prof.py" 20 > /tmp/swfprof/single.log 2>&1
 cp "$(find /tmp/swfprof/single -name '*kernel_stats.csv' | head -1)" "$OUT/single_window_kernel_stats.csv"
 # 2b. the bench command itself, without the single-window / CPU legs (same kernel names would dilute the averages)
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/bench -o n -- python "$ROOT/bench.py" --no-single-window --no-cpu-baseline > "$OUT/bench_nosingle.json" 2> /tmp/swfprof/bench.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/bench -o n -- python "$ROOT/bench.py" --no-single-window --no-cpu-baseline > "$OUT/bench_nosingle.json" 2> /tmp/swfprof/bench.log
 cp "$(find /tmp/swfprof/bench -name '*kernel_stats.csv' | head -1)" "$OUT/bench_nosingle_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d /tmp/swfprof/pmc_$C -o p -- python "$ROOT/tests/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/swfprof/pmc_$C -o p -- python "$ROOT/tests/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_$C.log 2>&1
 done
 # 4. matrix-core counters in their own pass: instructions, busy cycles, GPU-active cycles -> MFMA utilisation per kernel
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swfprof/pmc_mfma -o p -- python "$ROOT/tests/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_mfma.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swfprof/pmc_mfma -o p -- python "$ROOT/tests/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_mfma.log 2>&1
 python "$ROOT/tools/summarize_mfma_pmc.py" "$(find /tmp/swfprof/pmc_mfma -name '*counter_collection.csv' | head -1)" "$OUT/batch512_pmc_mfma.json"
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
