@@ -824,7 +824,7 @@ __device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O,
 }
 __device__ __forceinline__ void d_backsub_clique(const DevBatch& B, int bid) {
     // 16 lanes per clique with an eliminated block (d_e <= 9).  The strip product M_ef y_f is split by column over the
-    // lanes (lane s takes columns s, s+16, ...: coalesced rows of the strip, the member list is walked once), the 16
+    // lanes (lane s takes columns s, s+16, ...: coalesced rows of the strip), the 16
     // partials of each row are added by the fixed butterfly, then lane a holds t_a = g_e[a] - (M_ef y_f)_a and the
     // Einv product gathers the t's with 16-wide shuffles.
     int q = (bid * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15, lane = threadIdx.x & 63;
@@ -838,10 +838,28 @@ __device__ __forceinline__ void d_backsub_clique(const DevBatch& B, int bid) {
     double part[9];
 #pragma unroll
     for (int a = 0; a < 9; a++) part[a] = 0;
-    if (act && df > 0) {
-        int m = C.mem0, cc = B.cm_col[m], l = B.cm_ls[m], lo = B.cm_loc[m];
-        for (int c = sub; c < df; c += 16) {
-            while (c >= cc + l) { m++; cc = B.cm_col[m]; l = B.cm_ls[m]; lo = B.cm_loc[m]; }
+    // member records are fetched lane-parallel (16 per round) and searched with shuffles: a lane's column -> reduced
+    // index lookup costs one load level whatever the member count.  Uniform control flow (all 64 lanes shuffle).
+    const int nm = act ? C.mem1 - C.mem0 : 0, g0 = lane & ~15;
+    int nmx = nm;                                            // the wave iterates to its largest member / column count
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) { int t = __shfl_xor(nmx, o, 64); nmx = t > nmx ? t : nmx; }
+    int dfx = act ? df : 0;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) { int t = __shfl_xor(dfx, o, 64); dfx = t > dfx ? t : dfx; }
+    for (int c0 = 0; c0 < dfx; c0 += 16) {
+        const int c = c0 + sub;
+        int cc = 0, lo = 0;                                  // member holding column c: the last one with cm_col <= c
+        for (int m0 = 0; m0 < nmx; m0 += 16) {
+            bool have = m0 + sub < nm;
+            int mc = have ? B.cm_col[C.mem0 + m0 + sub] : 0x7fffffff, ml = have ? B.cm_loc[C.mem0 + m0 + sub] : 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                int kc = __shfl(mc, g0 + k, 64), kl = __shfl(ml, g0 + k, 64);
+                if (kc <= c) { cc = kc; lo = kl; }
+            }
+        }
+        if (act && c < df) {
             double yv = B.y[lo + c - cc];
 #pragma unroll
             for (int a = 0; a < 9; a++) if (a < de) part[a] += M[a * df + c] * yv;
