@@ -163,6 +163,37 @@ def test_batch_equals_single_window_solves_bitwise():
     bs.close()
 
 
+def test_large_batch_launch_shape_equals_single_window_solves_bitwise():
+    """From n_CU windows on, the engine changes its launch shape (one k_lm_schur workgroup per window with the parts
+    folded, the landmark / projection segments of k_post_chol / k_post_dogleg launched apart from the small families,
+    candidate IMU residuals in their own launch, no auxiliary stream).  None of that may change a window's arithmetic:
+    320 windows (copies of five different ones, one of them on the streaming Cholesky) against each solved alone."""
+    ws = [synth.make_window(3, K=6, F=30, S=5, seed=140), synth.make_window(2, K=5, F=20, S=0, seed=141),
+          synth.make_window(3, K=8, F=45, S=6, seed=142, doppler=True), synth.with_spp_and_fixed(synth.make_window(3, K=7, F=25, S=6, seed=143), seed=3, n_fix=2),
+          synth.make_window(3, K=26, F=40, S=5, seed=111)]
+    import composite_gen as cg
+    import idepth_gen as ig
+    ws.append(cg.make_window(np.random.default_rng(45), 5, 3, 6, F=40))                       # composite IMU-GNSS factors + landmarks
+    ws.append(ig.convert_short_tracks(synth.make_window(2, K=7, F=40, seed=146), max_track=5))  # inverse-depth landmarks
+    assert ws[-1].counts()["n_idp"] > 0 and ws[-2].counts()["n_comp"] > 0
+    keys = ("pose", "sb", "lm", "sc", "comp_pose", "comp_sb")
+    singles = []
+    for w in ws:
+        c = w.copy()
+        bs, sm = gpu_solve(c, default_options())
+        singles.append((c, [r["cost"] for r in sm.rows()]))
+        bs.close()
+    batch = [ws[i % len(ws)].copy() for i in range(322)]
+    bs = solver.BatchSolver(batch)
+    sms = bs.solve(default_options())
+    for i, (wb, sm) in enumerate(zip(batch, sms)):
+        c, costs = singles[i % len(ws)]
+        assert [r["cost"] for r in sm.rows()] == costs, i
+        for k in keys:
+            assert np.array_equal(c.a[k], wb.a[k]), (i, k)
+    bs.close()
+
+
 def test_landmark_quarters_per_block_and_kernel_variant_do_not_change_results(monkeypatch):
     """k_lm_schur lets one workgroup process 1 .. 16 landmark parts (chosen from the batch size) and is
     instantiated per tile count; every quarter keeps its own partial product and the arithmetic is pinned, so all
