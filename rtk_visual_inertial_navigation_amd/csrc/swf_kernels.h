@@ -233,6 +233,49 @@ __device__ void imu_unwhitened(const double* pi, const double* sbi, const double
 
 #define IMU_FPB 8          // factors per block
 #define IMU_LPF 32         // lanes per factor: 256-thread blocks = 4 waves, one per un-whitened part (residual only: part 0 alone)
+// Whitening of one IMU factor by its IMU_LPF lanes:
+// r = SI raw, cost, and (JAC) the whitened Jacobian SI * U written into the clique's dense column-major Jacobian.
+template <bool JAC>
+__device__ __forceinline__ void imu_whiten_store(const DevBatch& B, const GFac& G, int f, bool act, int sub,
+                                                 const double* SIf, double* Uf, const double* rawf) {
+    constexpr int LPF = IMU_LPF;
+    // whitened residual: lane k < 15 of each factor's lanes (all within one 16-lane row)
+    double rk = 0;
+    if (act && sub < 15) {
+        for (int k = 0; k < 15; k++) rk += SIf[sub * 15 + k] * rawf[k];
+        if (JAC) B.g_r[G.roff + sub] = rk;
+    }
+    double c = grp16_sum((act && sub < 15) ? rk * rk : 0.0);
+    if (act && sub == 0) B.g_cost[f] = 0.5 * c;
+    if (!JAC || !act) return;
+    const int cb[4] = { 0, 6, 15, 21 };
+    // Jacobian block positions of the four parameter blocks, fetched before the products (off the store loop's chain)
+    const int jo0 = B.s_joff[G.slot0], jo1 = B.s_joff[G.slot0 + 1], jo2 = B.s_joff[G.slot0 + 2], jo3 = B.s_joff[G.slot0 + 3];
+    // whitened Jacobian SI * U: lane c < 30 owns column c, holds it in registers and forms the 15 rows from broadcast
+    // SI reads at constant offsets (120 multiply-adds, fully unrolled; SI is upper triangular, k ascending from the row)
+    if (sub < 30) {
+        double u[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) u[k] = Uf[k * 30 + sub];
+#pragma unroll
+        for (int row = 0; row < 15; row++) {
+            double a = 0;
+#pragma unroll
+            for (int k = row; k < 15; k++) a += SIf[row * 15 + k] * u[k];
+            Uf[row * 30 + sub] = a;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // the clique's dense Jacobian is column-major in HBM: lanes run over the rows of one column (coalesced stores)
+    for (int e = sub; e < 450; e += LPF) {
+        int col = e / 15, row = e - col * 15;
+        int sl = col < 6 ? 0 : col < 15 ? 1 : col < 21 ? 2 : 3;
+        int jo = sl == 0 ? jo0 : sl == 1 ? jo1 : sl == 2 ? jo2 : jo3;
+        if (jo >= 0) B.g_J[jo + (col - cb[sl]) * G.jld + row] = Uf[row * 30 + col];
+    }
+}
+
 template <bool JAC>
 __device__ __forceinline__ void d_eval_imu(const DevBatch& B, int bid) {
     constexpr int LPF = IMU_LPF;
@@ -278,33 +321,7 @@ __device__ __forceinline__ void d_eval_imu(const DevBatch& B, int bid) {
     }
     __syncthreads();
     (void)W;
-    // whitened residual: lane k < 15 of each factor's lanes (all within one 16-lane row)
-    double rk = 0;
-    if (act && sub < 15) {
-        for (int k = 0; k < 15; k++) rk += SI[fl][sub * 15 + k] * raw[fl][k];
-        if (JAC) B.g_r[G.roff + sub] = rk;
-    }
-    double c = grp16_sum((act && sub < 15) ? rk * rk : 0.0);
-    if (act && sub == 0) B.g_cost[f] = 0.5 * c;
-    if (!JAC || !act) return;
-    const int cb[4] = { 0, 6, 15, 21 };
-    // whitened Jacobian SI * U, computed row-major (uniform trip counts, broadcast SI reads) and written back in place:
-    // entry (row, col) needs U[k >= row][col] only, and rows are finished in order, so the overwrite is safe
-    for (int e = sub; e < 450; e += LPF) {
-        int row = e / 30, col = e - row * 30;
-        double a = 0;
-        for (int k = row; k < 15; k++) a += SI[fl][row * 15 + k] * U[fl][k * 30 + col];   // SI is upper triangular
-        U[fl][e] = a;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    // the clique's dense Jacobian is column-major in HBM: lanes run over the rows of one column (coalesced stores)
-    for (int e = sub; e < 450; e += LPF) {
-        int col = e / 15, row = e - col * 15;
-        int sl = col < 6 ? 0 : col < 15 ? 1 : col < 21 ? 2 : 3;
-        int jo = B.s_joff[G.slot0 + sl];
-        if (jo >= 0) B.g_J[jo + (col - cb[sl]) * G.jld + row] = U[fl][row * 30 + col];
-    }
+    imu_whiten_store<JAC>(B, G, f, act, sub, SI[fl], U[JAC ? fl : 0], raw[fl]);
 }
 
 template <bool JAC>

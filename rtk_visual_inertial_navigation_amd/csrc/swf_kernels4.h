@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) k_comp_prep(CompArgs A) {
 // phase 2: every IMU factor of every chain that re-eliminates, IMUFactor::Evaluate2 — 8 factors per workgroup, the four un-whitened
 // parts on one lane each (part p on wave p, as in k_eval_imu), then 32 lanes per factor whiten; whitened J (15 x 30) and r to scratch
 __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
-    __shared__ double U[8][450], raw[8][16], st[8][32], pr[8][SWF_PRE_SQRTINFO + 6];
+    __shared__ double U[8][450], SIs[8][225], raw[8][16], st[8][32], pr[8][SWF_PRE_SQRTINFO + 6];
     const int t = threadIdx.x, fl = t >> 5, sub = t & 31;
     const int q = blockIdx.x * 8 + fl;
     const bool valid = q < A.n_iq;
@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
         for (int e = sub; e < SWF_PRE_SQRTINFO; e += 32) pr[fl][e] = pre[e];
         if (sub < 6) pr[fl][SWF_PRE_SQRTINFO + sub] = A.pbgw[(size_t)f * 6 + sub];
         for (int e = sub; e < 450; e += 32) U[fl][e] = 0.0;
+        for (int e = sub; e < 225; e += 32) SIs[fl][e] = pre[SWF_PRE_SQRTINFO + e];
     }
     __syncthreads();
     if ((t & 63) < 8) {
@@ -149,18 +150,26 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
     }
     __syncthreads();
     if (!act) return;
-    const double* SI = pre + SWF_PRE_SQRTINFO;              // upper triangular
-    for (int e = sub; e < 465; e += 32) {
-        if (e < 450) {
-            int row = e / 30, col = e - row * 30;
+    // whitening as in imu_whiten_store: lane c < 30 owns column c of the 15x30 block (registers), SI (upper triangular) is read
+    // as LDS broadcasts at constant offsets, k ascending from the row; lanes < 15 also whiten one residual row each
+    const double* SI = SIs[fl];
+    if (sub < 30) {
+        double u[15];
+#pragma unroll
+        for (int j = 0; j < 15; j++) u[j] = U[fl][j * 30 + sub];
+#pragma unroll
+        for (int row = 0; row < 15; row++) {
             double a = 0;
-            for (int j = row; j < 15; j++) a += SI[row * 15 + j] * U[fl][j * 30 + col];
-            A.Jw[(size_t)(e0 + f + k) * 450 + e] = a;
-        } else {
-            int row = e - 450; double a = 0;
-            for (int j = 0; j < 15; j++) a += SI[row * 15 + j] * raw[fl][j];
-            A.rw[(size_t)(e0 + f + k) * 16 + row] = a;
+#pragma unroll
+            for (int j = row; j < 15; j++) a += SI[row * 15 + j] * u[j];
+            A.Jw[(size_t)(e0 + f + k) * 450 + row * 30 + sub] = a;
         }
+    }
+    if (sub < 15) {
+        double a = 0;
+#pragma unroll
+        for (int j = 0; j < 15; j++) a += SI[sub * 15 + j] * raw[fl][j];
+        A.rw[(size_t)(e0 + f + k) * 16 + sub] = a;
     }
 }
 
