@@ -262,13 +262,15 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         B.fsb_out0.push_back((int)B.fs_tot); B.fs_tot += R.nF;
         std::vector<std::vector<int>> byf(R.nF);
         for (int t = 0; t < cnt; t++) { int f = B.p_fr[o0 + t]; if (f >= 0) byf[f].push_back(t); }
+        // fsb_perm[o] = rank of observation o in the block's frame-sorted order (observations of constant poses go last)
         int pos = 0;
-        B.fsb_perm.resize((size_t)o0 + cnt, 0);
+        B.fsb_perm.resize((size_t)o0 + cnt, -1);
         for (int f = 0; f < R.nF; f++) {
             B.fsb_foff.push_back(pos);
-            for (int t : byf[f]) B.fsb_perm[(size_t)o0 + pos++] = t;
+            for (int t : byf[f]) B.fsb_perm[(size_t)o0 + t] = pos++;
         }
         B.fsb_foff.push_back(pos);
+        for (int t = 0; t < cnt; t++) if (B.fsb_perm[(size_t)o0 + t] < 0) B.fsb_perm[(size_t)o0 + t] = pos++;
     }
     R.fsb1 = (int)B.fsb_win.size();
     R.P_base = B.P_tot; B.P_tot += (long long)36 * R.nF * R.nF;       // x GEMM_SPLIT partial products at allocation

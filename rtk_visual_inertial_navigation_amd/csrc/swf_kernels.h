@@ -1226,13 +1226,14 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
     if (!B.ws[w].need_lin) return;
     const WinRec& W = B.win[w];
     int o_beg = B.fsb_obs0[blk], cnt = B.fsb_obs0[blk + 1] - o_beg, tid = threadIdx.x, n = B.n_proj;
-    // thread q stages the observation at frame-sorted position q: the block's cache lines are all
-    // consumed either way, and the owner loop below then walks V sequentially (no index chase)
+    // thread t loads observation t (coalesced) and stages it at its frame-sorted rank, so that the owner loop below
+    // walks V sequentially (no index chase)
     __shared__ int foff[168];
     int nF = W.nF;
     for (int e = tid; e <= nF; e += FS_BLK) foff[e] = B.fsb_foff[B.fsb_foff0[blk] + e];
     if (tid < cnt) {
-        int o = o_beg + B.fsb_perm[o_beg + tid];
+        int o = o_beg + tid;
+        const int rk = B.fsb_perm[o];
         double a[6], b[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) { a[i] = B.p_Jp[i * n + o]; b[i] = B.p_Jp[(6 + i) * n + o]; }
@@ -1241,12 +1242,12 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = 0; j <= i; j++) V[tid][k++] = a[i] * a[j] + b[i] * b[j];
+            for (int j = 0; j <= i; j++) V[rk][k++] = a[i] * a[j] + b[i] * b[j];
 #pragma unroll
-        for (int i = 0; i < 6; i++) V[tid][21 + i] = a[i] * r0 + b[i] * r1;
+        for (int i = 0; i < 6; i++) V[rk][21 + i] = a[i] * r0 + b[i] * r1;
         bool lmv = B.lm_loc[B.p_lm[o]] >= 0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) V[tid][27 + i] = lmv ? B.p_yg[i * n + o] : 0.0;
+        for (int i = 0; i < 6; i++) V[rk][27 + i] = lmv ? B.p_yg[i * n + o] : 0.0;
     }
     __syncthreads();
     // owner (frame f, value v) adds the block's observations of frame f in permutation order;
