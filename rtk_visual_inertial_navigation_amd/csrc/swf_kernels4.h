@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
 }
 
 // phase 3: re-elimination of the hidden epochs from the whitened IMU Jacobians of phase 2, remainder, square root
-__global__ void __launch_bounds__(256) k_comp_elim(CompArgs A) {
+__global__ void __launch_bounds__(256, 4) k_comp_elim(CompArgs A) {
     const int f = blockIdx.x, t = threadIdx.x;
     if (f >= A.n || !A.todo[f]) return;
     const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
@@ -262,12 +262,28 @@ __global__ void __launch_bounds__(256) k_comp_elim(CompArgs A) {
             __syncthreads();
         }
         if (t < 15) {
-            // column t of the inverse, solved in place in LDS (sAinv column t is this thread's alone)
-            double* z = sAinv + t;                          // z[a] = sAinv[a * 15 + t]
-#pragma unroll 1
-            for (int a = 0; a < 15; a++) { double s = (a == t) ? 1.0 : 0.0; for (int q = 0; q < a; q++) s -= sL[a * 15 + q] * z[q * 15]; z[a * 15] = s / sL[a * 15 + a]; }
-#pragma unroll 1
-            for (int a = 14; a >= 0; a--) { double s = z[a * 15]; for (int q = a + 1; q < 15; q++) s -= sL[q * 15 + a] * z[q * 15]; z[a * 15] = s / sL[a * 15 + a]; }
+            // column t of the inverse: forward and backward substitution fully unrolled, the column in registers (constant
+            // indices), L read row by row as LDS broadcasts that do not depend on the chain; same operations in the same order
+            // as the in-place LDS solve this replaces
+            double z[15];
+#pragma unroll
+            for (int a = 0; a < 15; a++) {
+                asm volatile("" ::: "memory");              // one row of L in flight at a time (hoisting all 120 reads costs 240 VGPRs)
+                double s = (a == t) ? 1.0 : 0.0;
+#pragma unroll
+                for (int q = 0; q < a; q++) s -= sL[a * 15 + q] * z[q];
+                z[a] = s / sL[a * 15 + a];
+            }
+#pragma unroll
+            for (int a = 14; a >= 0; a--) {
+                asm volatile("" ::: "memory");
+                double s = z[a];
+#pragma unroll
+                for (int q = a + 1; q < 15; q++) s -= sL[q * 15 + a] * z[q];
+                z[a] = s / sL[a * 15 + a];
+            }
+#pragma unroll
+            for (int a = 0; a < 15; a++) sAinv[a * 15 + t] = z[a];
         }
         __syncthreads();
         // T_blk = H0blk^T Ainv for blk = Pose2 (15), N, Pose0 (15)
