@@ -724,6 +724,10 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     {
         std::vector<int> pd, po, clc[3], cle;
         for (size_t i = 0; i < B.pair.size(); i++) (B.pair[i].is_diag ? pd : po).push_back((int)i);
+        // off-diagonal pairs by descending entry rounds (16 entries per round): k_assemble_all's waves (four pairs each) become
+        // homogeneous and skip the rounds none of their pairs has; every pair is still written once, by the same arithmetic
+        std::stable_sort(po.begin(), po.end(), [&](int a, int c) {
+            return (B.pair[a].la * B.pair[a].lb + 15) / 16 > (B.pair[c].la * B.pair[c].lb + 15) / 16; });
         for (size_t i = 0; i < B.cl.size(); i++) {
             const Clique& c = B.cl[i];
             if (c.d_e > 0) cle.push_back((int)i);

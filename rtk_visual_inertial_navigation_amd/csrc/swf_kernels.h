@@ -1350,6 +1350,12 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
         int i = ev[r] ? e / lb : 0;
         ei[r] = i; ej[r] = ev[r] ? e - i * lb : 0;
     }
+    // rounds this wave needs: the largest entry count of its pairs (the host sorts the off-diagonal pairs by size, so the
+    // waves are homogeneous and a wave of 1x6 / 1x1 pairs runs one round instead of six); wave-uniform, from ballots
+    int nrw = 0;
+#pragma unroll
+    for (int r = NR - 1; r >= 0; r--) if (nrw == 0 && __ballot(nent > r * G) != 0ULL) nrw = r + 1;
+    nrw = __builtin_amdgcn_readfirstlane(nrw);
     double vsum[NR], hsum[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) {
@@ -1368,8 +1374,10 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
             int cl = __shfl(myl, gbase + c, 64);
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                double cv = B.C[co + (size_t)ei[r] * cl + ej[r]];
-                vsum[r] += ev[r] ? cv : 0.0;
+                if (r < nrw) {
+                    double cv = B.C[co + (size_t)ei[r] * cl + ej[r]];
+                    vsum[r] += ev[r] ? cv : 0.0;
+                }
             }
         }
     }
