@@ -75,7 +75,9 @@ struct Pair {
     int c0, c1;                  // contribution list range
     int is_diag;
     int loc_a;                   // local offset of block a (for g/diag/rhs of diagonal pairs)
-    int pad;
+    int fsb0, fsb1;              // the window's frame-sum blocks (diagonal pairs of observing poses)
+    int n, m;                    // the window's n_red and 6 * nF, and its S / P slabs: the record is self-contained,
+    long long S_base, P_base;    // no load of the pair's data depends on a second record
 };
 
 struct DevBatch {
@@ -137,9 +139,8 @@ struct DevBatch {
     int n_cle; const int* cle_idx;             // cliques with an eliminated block (back-substitution)
     // pairs
     int n_pair;
-    const Pair* pair;
     const long long* pc_coff; const int* pc_cld; const int* pc_voff;
-    int n_pd, n_po; const int* pd_idx; const int* po_idx;   // diagonal / off-diagonal pair lists
+    int n_pd, n_po; const Pair* pair_d; const Pair* pair_o;   // diagonal / off-diagonal pair records (the latter sorted by size)
 };
 
 // ------------------------------------------------------------------ device math

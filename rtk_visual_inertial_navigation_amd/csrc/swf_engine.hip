@@ -720,10 +720,14 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     D.n_cl = (int)B.cl.size();
     PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cl_frow, B.cl_frow); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
     D.n_pair = (int)B.pair.size();
-    PUT(pair, B.pair); PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
+    PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
     {
         std::vector<int> pd, po, clc[3], cle;
-        for (size_t i = 0; i < B.pair.size(); i++) (B.pair[i].is_diag ? pd : po).push_back((int)i);
+        for (size_t i = 0; i < B.pair.size(); i++) {
+            Pair& Pq = B.pair[i]; const WinRec& Rw = B.win[Pq.win];      // self-contained records (see Pair)
+            Pq.fsb0 = Rw.fsb0; Pq.fsb1 = Rw.fsb1; Pq.n = Rw.n_red; Pq.m = 6 * Rw.nF; Pq.S_base = Rw.S_base; Pq.P_base = Rw.P_base;
+            (Pq.is_diag ? pd : po).push_back((int)i);
+        }
         // off-diagonal pairs by descending entry rounds (16 entries per round): k_assemble_all's waves (four pairs each) become
         // homogeneous and skip the rounds none of their pairs has; every pair is still written once, by the same arithmetic
         std::stable_sort(po.begin(), po.end(), [&](int a, int c) {
@@ -738,7 +742,13 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             for (int q = c.fac0; q < c.fac1; q++) if (B.gf[B.cl_fac[q]].type == GF_IMU) b->clc_imu[cls] = true;
         }
         D.n_pd = (int)pd.size(); D.n_po = (int)po.size(); D.n_cle = (int)cle.size();
-        PUT(pd_idx, pd); PUT(po_idx, po); PUT(cle_idx, cle);
+        {
+            std::vector<Pair> vd, vo;
+            for (int i : pd) vd.push_back(B.pair[i]);
+            for (int i : po) vo.push_back(B.pair[i]);
+            PUT(pair_d, vd); PUT(pair_o, vo);
+        }
+        PUT(cle_idx, cle);
         for (int k = 0; k < 3; k++) { D.n_clc[k] = (int)clc[k].size(); rc |= P.put(clc[k], &D.clc_idx[k]); }
     }
 #undef PUT

@@ -1280,21 +1280,20 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
     constexpr int G = DIAG ? 64 : 16;
     int gidx = (bid * blockDim.x + threadIdx.x) / G, lane = threadIdx.x % G;
     if (gidx >= (DIAG ? B.n_pd : B.n_po)) return;
-    const Pair& Pr = B.pair[(DIAG ? B.pd_idx : B.po_idx)[gidx]];
+    const Pair& Pr = (DIAG ? B.pair_d : B.pair_o)[gidx];
     const WinState& s = B.ws[Pr.win];
     if (!s.need_lin) return;
-    const WinRec& W = B.win[Pr.win];
-    int la = Pr.la, lb = Pr.lb, n = W.n_red, m = 6 * W.nF;
-    double* S = B.S + W.S_base;
-    const double* P = B.P + W.P_base * GEMM_SPLIT;
+    int la = Pr.la, lb = Pr.lb, n = Pr.n, m = Pr.m;
+    double* S = B.S + Pr.S_base;
+    const double* P = B.P + Pr.P_base * GEMM_SPLIT;
     double acc = 0;                                   // lane k of a diagonal pair's wave: frame sum k (H 0..20 | g 21..26 | q 27..32)
     bool obs = DIAG && Pr.fa >= 0;
     if (obs) {
         // level 2: lanes v < 33 add this frame's block partials in block order
         // (block offsets fetched lane-parallel and broadcast, so the value loads do not chain behind index loads)
-        for (int b0 = W.fsb0; b0 < W.fsb1; b0 += 64) {
-            int myoff = (b0 + lane < W.fsb1) ? B.fsb_out0[b0 + lane] : 0;
-            int nn = (W.fsb1 - b0) < 64 ? (W.fsb1 - b0) : 64;
+        for (int b0 = Pr.fsb0; b0 < Pr.fsb1; b0 += 64) {
+            int myoff = (b0 + lane < Pr.fsb1) ? B.fsb_out0[b0 + lane] : 0;
+            int nn = (Pr.fsb1 - b0) < 64 ? (Pr.fsb1 - b0) : 64;
 #pragma unroll 4
             for (int c = 0; c < nn; c++) {
                 int off = __shfl(myoff, c, 64);
