@@ -135,8 +135,8 @@ struct DevBatch {
     const int* cl_fac; const int* cl_frow;     // factor ids and their first row in the clique Jacobian
     const int* cm_loc; const int* cm_ls; const int* cm_col;
     double* C; double* cv_graw; double* cv_dgraw; double* cv_cs; double* cE;
-    int n_clc[3]; const int* clc_idx[3];       // non-static cliques by size class
-    int n_cle; const int* cle_idx;             // cliques with an eliminated block (back-substitution)
+    int n_clc[3]; const Clique* clc_rec[3];    // non-static cliques by size class (copies of the records: no index indirection)
+    int n_cle; const Clique* cle_rec;          // cliques with an eliminated block (back-substitution), likewise
     // pairs
     int n_pair;
     const long long* pc_coff; const int* pc_cld; const int* pc_voff;

@@ -748,8 +748,16 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             for (int i : po) vo.push_back(B.pair[i]);
             PUT(pair_d, vd); PUT(pair_o, vo);
         }
-        PUT(cle_idx, cle);
-        for (int k = 0; k < 3; k++) { D.n_clc[k] = (int)clc[k].size(); rc |= P.put(clc[k], &D.clc_idx[k]); }
+        {
+            std::vector<Clique> v;
+            for (int i : cle) v.push_back(B.cl[i]);
+            PUT(cle_rec, v);
+            for (int k = 0; k < 3; k++) {
+                v.clear();
+                for (int i : clc[k]) v.push_back(B.cl[i]);
+                D.n_clc[k] = (int)clc[k].size(); rc |= P.put(v, &D.clc_rec[k]);
+            }
+        }
     }
 #undef PUT
     // mutable buffers

@@ -1029,7 +1029,7 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
     if (CLS == 1 && blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < 16; i++) g_clq_stamps[i] = 0;
 #endif
     if ((int)blockIdx.x >= B.n_clc[CLS]) return;
-    const Clique& C = B.cl[B.clc_idx[CLS][blockIdx.x]];
+    const Clique& C = B.clc_rec[CLS][blockIdx.x];
     WinState& s = B.ws[C.win];
     if (!s.need_lin) return;
     int de = C.d_e, df = C.d_f, d = de + df, lane = threadIdx.x, nrow = C.n_rows;

@@ -829,7 +829,7 @@ __device__ __forceinline__ void d_backsub_clique(const DevBatch& B, int bid) {
     // Einv product gathers the t's with 16-wide shuffles.
     int q = (bid * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15, lane = threadIdx.x & 63;
     bool valid = q < B.n_cle;
-    const Clique& C = B.cl[B.cle_idx[valid ? q : B.n_cle - 1]];
+    const Clique& C = B.cle_rec[valid ? q : B.n_cle - 1];
     const WinState& s = B.ws[C.win];
     bool act = valid && s.need_lin && !s.lin_fail;
     int de = C.d_e, df = C.d_f;
