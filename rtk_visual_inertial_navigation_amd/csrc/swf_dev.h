@@ -91,6 +91,7 @@ struct DevBatch {
     double* vc;                                // D^-2 g = g / clamp(diag): written next to g / diag by their producers (Cauchy direction)
     // reduced matrices
     double* S; double* L;
+    double* Wk;                                // working copy of the trailing matrix for k_chol_col (latency path, max n_red > 240), laid out like L
     double* Linv;                              // inverse diagonal tiles of k_chol_big: [window][32][16][16] (allocated when max n_red > 240)
     // tables
     const WinRec* win; WinState* ws; swf_iteration* trace;

@@ -766,6 +766,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     rc |= P.zeros(B.n_loc, &D.y); rc |= P.zeros(B.n_loc, &D.step);
     rc |= P.zeros(B.S_tot, &D.S); rc |= P.zeros(B.Lt_tot, &D.L);
     if (b->max_red > 240 && b->max_red <= 512) rc |= P.zeros((size_t)n * (CB_MAXT - 1) * 256, &D.Linv);
+    // latency path with a streamed-Cholesky window: the factorisation is spread over the chip column by column (k_chol_col)
+    if (b->max_red > 240 && b->max_red <= 512 && n * 16 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);
     rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
     size_t np = (size_t)D.n_proj;
     rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl); rc |= P.zeros(6 * np, &D.p_yg);
@@ -990,7 +992,11 @@ struct Launcher {
         if (b->max_red <= 512 && !b->force_chol_v1) {
             // per-window choice (each kernel skips the other's windows): register-resident tiles up to 240 dimensions, streamed above
             if (b->min_red <= 240) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
-            if (b->max_red > 240) hipLaunchKernelGGL(k_chol_big, dim3(D.n_win), dim3(1024), 0, st, D);
+            if (b->max_red > 240 && D.Wk) {
+                const int Tc = (b->max_red + 15) / 16;
+                for (int j = 0; j < Tc; j++) hipLaunchKernelGGL(k_chol_col, dim3(D.n_win, CC_NB), dim3(CC_NT), 0, st, D, j);
+                hipLaunchKernelGGL(k_chol_big<true>, dim3(D.n_win), dim3(1024), 0, st, D);      // backward substitution
+            } else if (b->max_red > 240) hipLaunchKernelGGL(k_chol_big<false>, dim3(D.n_win), dim3(1024), 0, st, D);
         }
         else if (b->max_red + 1 <= 256) hipLaunchKernelGGL(k_chol_solve<256>, dim3(D.n_win), dim3(256), 0, st, D);
         else hipLaunchKernelGGL(k_chol_solve<1024>, dim3(D.n_win), dim3(1024), 0, st, D);

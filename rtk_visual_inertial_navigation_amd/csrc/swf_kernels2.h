@@ -546,6 +546,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 // Step 0 reads S (lower; diagonal tiles mirrored), later steps read the L buffer.  Right-looking backward pass.
 // =========================================================================================
 #define CB_MAXT 33                      // tile rows: 32 of the matrix (n <= 512) + the rhs row
+template <bool BACK_ONLY>
 __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     __shared__ double Pn[CB_MAXT][16][17];     // panel of the current column, tile row I -> L_Ij (72 KB)
     __shared__ double Lic[16][17];             // Linv_jj of the current column
@@ -615,9 +616,9 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
         unsigned long long tq = 0;
 #endif
         CHSTAMP(0);
-        __syncthreads();                                   // A_0: tile (0,0) published
+        if (!BACK_ONLY) __syncthreads();                   // A_0: tile (0,0) published
         CHSTAMP(3);
-        for (int j = 0; j < Tc; j++) {
+        for (int j = 0; j < (BACK_ONLY ? 0 : Tc); j++) {
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
@@ -664,13 +665,13 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     int kq = wv - 1;                                       // owns the tiles with (I + J) mod 15 == kq
     // first row I >= J of column J owned by this wave (then I + 15, I + 30)
     auto first_row = [&](int J) { int d = (kq - 2 * J) % 15; if (d < 0) d += 15; return J + d; };
-    if (first_row(0) == 0) {                               // owner of (0,0): publish it
+    if (!BACK_ONLY && first_row(0) == 0) {                 // owner of (0,0): publish it
         double4_t v = load_tile(0, 0, true);
 #pragma unroll
         for (int q = 0; q < 4; q++) Dt[0][lk + 4 * q][li] = v[q];
     }
-    __syncthreads();                                       // A_0
-    for (int j = 0; j < Tc; j++) {
+    if (!BACK_ONLY) __syncthreads();                       // A_0
+    for (int j = 0; j < (BACK_ONLY ? 0 : Tc); j++) {
         bool first = j == 0;
         __syncthreads();                                   // B_j: L_jj, Linv_jj ready
         if (fail) return;
@@ -767,6 +768,159 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     }
     double* y = B.y + W.loc_base + W.n_e;
     for (int e = tid - 64; e < n; e += 960) y[e] = zs[e];
+}
+
+// k_chol_col — one tile column of the k_chol_big factorisation spread over CC_NB workgroups per window, for the latency
+// path (a single cfg5-class window would otherwise factor on one CU): every workgroup re-factors the 16x16 pivot tile and
+// re-forms the whole panel (cheap, and bit-identical in each), then updates its static share of the trailing tiles.  The
+// trailing matrix lives in a working copy (B.Wk) and the finished columns go to the L buffer, so no workgroup overwrites
+// what another still reads; one launch per column, k_chol_big<true> does the backward substitution.  Every tile sees the
+// same MFMA sequence as in k_chol_big: the two paths give bit-identical factors.
+#define CC_NB 16
+#define CC_NT 512
+__global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
+    __shared__ double Pn[CB_MAXT][16][17];
+    __shared__ double Lic[16][17];
+    __shared__ double ipiv[16];
+    __shared__ double Dt[16][17];
+    __shared__ int fail;
+    const int w = blockIdx.x, g = blockIdx.y;
+    WinState& st = B.ws[w];
+    if (!st.need_lin || st.lin_fail) return;
+    const WinRec& W = B.win[w];
+    const int n = W.n_red, tid = threadIdx.x;
+    if (n <= 240) return;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int Tc = (n + 15) >> 4, Tr = Tc + 1;
+    if (j >= Tc) return;
+    const bool first = j == 0;
+    const double* S = B.S + W.S_base;
+    double* Lw = B.L + W.Lt_base;
+    double* Wk = B.Wk + W.Lt_base;
+    double* LinvG = B.Linv + (size_t)w * (CB_MAXT - 1) * 256;
+    if (tid == 0) fail = 0;
+    const int lane_off = lk * n + li;
+    auto load_tile = [&](int I, int J) {
+        double4_t v;
+        const double* src = first ? S : Wk;
+        if (16 * I + 16 <= n && !(first && I == J)) {
+            const double* t0 = src + (size_t)(16 * I) * n + 16 * J + lane_off;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = t0[(size_t)(4 * q) * n];
+            return v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int r = 16 * I + lk + 4 * q, c = 16 * J + li;
+            bool rhs_el = I == Tc && lk + 4 * q == 0;
+            int rr = rhs_el ? n : r;
+            bool inside = c < n && (rhs_el || (r < n && (c <= r || I == J)));
+            int rc = rr < n ? rr : (rhs_el ? n : n - 1), cc = c < n ? c : n - 1;
+            int off = (first && cc > rc) ? cc * n + rc : rc * n + cc;
+            double x = src[off];
+            v[q] = inside ? x : ((I < Tc && r == c) ? 1.0 : 0.0);
+        }
+        return v;
+    };
+    auto store_tile = [&](double* dst, int I, int J, double4_t v, bool lower_only) {
+        if (16 * I + 16 <= n && !lower_only) {
+            double* t0 = dst + (size_t)(16 * I) * n + 16 * J + lane_off;
+#pragma unroll
+            for (int q = 0; q < 4; q++) t0[(size_t)(4 * q) * n] = v[q];
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int r = 16 * I + lk + 4 * q, c = 16 * J + li;
+            bool rhs_el = I == Tc && lk + 4 * q == 0;
+            if (rhs_el) { if (c < n) dst[(size_t)n * n + c] = v[q]; }
+            else if (I < Tc && r < n && c < n) dst[(size_t)r * n + c] = (lower_only && c > r) ? 0.0 : v[q];
+        }
+    };
+    // ---- the loads that do not depend on the pivot go out first: this wave's panel tiles and its first trailing tiles
+    constexpr int NW = CC_NT / 64;                         // waves per workgroup
+    constexpr int PPW = (CB_MAXT - 1 + NW - 1) / NW;        // panel tiles per wave, at most
+    double4_t pv[PPW];
+#pragma unroll
+    for (int u = 0; u < PPW; u++) { int I = j + 1 + wv + NW * u; if (I < Tr) pv[u] = load_tile(I, j); }
+    // trailing tiles (I, J), J > j, I >= J (the rhs row included): tile (I, J) belongs to wave (I + 33 J) mod (NW CC_NB) of
+    // the window, so a wave owns at most one tile per column and finds it without walking the others; four in flight
+    constexpr int NWT = NW * CC_NB;
+    const int me = g * NW + wv;
+    int tJ = j + 1;                                        // column cursor
+    auto next_owned = [&](int& I, int& J) {                // advance to this wave's next tile; false when exhausted
+        while (tJ < Tc) {
+            int c = tJ++;
+            int r = (me - 33 * c) % NWT; if (r < 0) r += NWT;
+            if (r >= c && r < Tr) { I = r; J = c; return true; }
+        }
+        return false;
+    };
+    int Ia[4], Ja[4], na = 0;
+    double4_t va[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { Ia[u] = 0; Ja[u] = 0; va[u] = double4_t{ 0, 0, 0, 0 }; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (na == u && next_owned(Ia[u], Ja[u])) { va[u] = load_tile(Ia[u], Ja[u]); na = u + 1; }
+    __syncthreads();                                       // fail = 0 visible
+    // ---- pivot tile (every workgroup; wave 0)
+    if (wv == 0) {
+        double4_t v = load_tile(j, j);
+#pragma unroll
+        for (int q = 0; q < 4; q++) Dt[lk + 4 * q][li] = v[q];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        bool bad = chol_pivot_tile(Dt, Lic, li, lk, ipiv);
+        if (bad && lane == 0) fail = 1;
+        if (g == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) LinvG[(size_t)j * 256 + (lk + 4 * q) * 16 + li] = Lic[lk + 4 * q][li];
+            double4_t l;
+#pragma unroll
+            for (int q = 0; q < 4; q++) l[q] = Dt[lk + 4 * q][li];
+            store_tile(Lw, j, j, l, true);
+        }
+    }
+    __syncthreads();
+    if (fail) { if (g == 0 && tid == 0) st.lin_fail = 1; return; }
+    // ---- panel (every workgroup forms all of it; tile I is stored to L by workgroup I mod CC_NB)
+#pragma unroll
+    for (int u = 0; u < PPW; u++) {
+        int I = j + 1 + wv + NW * u;
+        if (I >= Tr) break;
+#pragma unroll
+        for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = pv[u][q];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        double4_t X = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[I][li][lk + 4 * kk], Lic[li][lk + 4 * kk], X, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = X[q];
+        if (I % CC_NB == g) store_tile(Lw, I, j, X, false);
+    }
+    __syncthreads();
+    // ---- trailing updates, groups of four independent accumulators, the next group's loads in flight
+    while (na) {
+        int In[4], Jn[4], nn = 0;
+        double4_t vn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { In[u] = 0; Jn[u] = 0; vn[u] = double4_t{ 0, 0, 0, 0 }; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (nn == u && next_owned(In[u], Jn[u])) { vn[u] = load_tile(In[u], Jn[u]); nn = u + 1; }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (u < na) va[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[Ia[u]][li][lk + 4 * kk], Pn[Ja[u]][li][lk + 4 * kk], va[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (u < na) store_tile(Wk, Ia[u], Ja[u], va[u], false);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { Ia[u] = In[u]; Ja[u] = Jn[u]; va[u] = vn[u]; }
+        na = nn;
+    }
 }
 
 // =========================================================================================
