@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
 // trailing matrix lives in a working copy (B.Wk) and the finished columns go to the L buffer, so no workgroup overwrites
 // what another still reads; one launch per column, k_chol_big<true> does the backward substitution.  Every tile sees the
 // same MFMA sequence as in k_chol_big: the two paths give bit-identical factors.
-#define CC_NB 16
+#define CC_NB 32
 #define CC_NT 512
 __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
     __shared__ double Pn[CB_MAXT][16][17];
