@@ -750,13 +750,25 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
         if ((Tc + J) % 15 == kq && lk == 0 && 16 * J + li < n) yv[16 * J + li] = Lw[(size_t)n * n + 16 * J + li];
     for (int e = tid - 64; e < 528; e += 960) zs[e] = 0.0;
     __syncthreads();                                       // E
+    // tiles (J, J') of row J, J' < J, owned by this wave: J' = (kq - J) mod 15, + 15, + 30.  The tiles of row J - 1 are
+    // requested before row J is applied (L is final: the loads do not depend on y), so no step waits for its loads
+    double4_t t[3], tn[3];
+    int Jp[3], Jpn[3], nt_ = 0, ntn = 0;
+#pragma unroll
+    for (int u = 0; u < 3; u++) { t[u] = double4_t{ 0, 0, 0, 0 }; tn[u] = t[u]; Jp[u] = 0; Jpn[u] = 0; }
+    auto fetch_row = [&](int J, double4_t* tv, int* jp, int& cnt) {
+        cnt = 0;
+        if (J < 0) return;
+        int d = (kq - J) % 15; if (d < 0) d += 15;
+#pragma unroll
+        for (int u = 0; u < 3; u++) { int Jq = d + 15 * u; if (Jq < J) { jp[u] = Jq; tv[u] = load_tile(J, Jq, false); cnt = u + 1; } }
+    };
+    fetch_row(Tc - 1, t, Jp, nt_);
     for (int J = Tc - 1; J >= 0; J--) {
-        // tiles (J, J') of row J, J' < J, owned by this wave: J' = (kq - J) mod 15, + 15, + 30
-        double4_t t[3];
-        int Jp[3], nt_ = 0;
-        { int d = (kq - J) % 15; if (d < 0) d += 15; for (int Jq = d; Jq < J && nt_ < 3; Jq += 15) { Jp[nt_] = Jq; t[nt_] = load_tile(J, Jq, false); nt_++; } }
+        fetch_row(J - 1, tn, Jpn, ntn);
         __syncthreads();                                   // X_J: y_J published
-        for (int u = 0; u < nt_; u++) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) if (u < nt_) {
             double p = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) p += t[u][q] * zs[16 * J + lk + 4 * q];
@@ -765,6 +777,9 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
             if (lk == 0) yv[16 * Jp[u] + li] -= p;
         }
         __syncthreads();                                   // Y_J
+#pragma unroll
+        for (int u = 0; u < 3; u++) { t[u] = tn[u]; Jp[u] = Jpn[u]; }
+        nt_ = ntn;
     }
     double* y = B.y + W.loc_base + W.n_e;
     for (int e = tid - 64; e < n; e += 960) y[e] = zs[e];
