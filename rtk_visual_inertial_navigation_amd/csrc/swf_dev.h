@@ -130,6 +130,7 @@ struct DevBatch {
     const int* prior_dim; const long long* prior_Joff; const int* prior_roff; const int* prior_x0off;
     const double* prior_J; const double* prior_r0; const double* prior_x0;
     const double* prior_Jt;          // the same records transposed (element (k, c) at c * n + k): the J v products read these, lanes over rows
+    const int* prior_colloc;         // per prior column (at prior_roff + c): reduced-local index of the column's variable, -1 if constant
     // cliques
     int n_cl;
     const Clique* cl;

@@ -715,6 +715,18 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++) T[c * n + r] = J[r * n + c];
         }
         PUT(prior_Jt, Jt);
+        // column -> local index of every prior record (the J v products walk the columns flat, eight at a time)
+        std::vector<int> cl(B.prior_r0.size(), -1);
+        for (const GFac& G : B.gf) {
+            if (G.type != GF_PRIOR) continue;
+            int col = 0;
+            for (int t = 0; t < G.nslot; t++) {
+                int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
+                for (int q = 0; q < l; q++) cl[(size_t)B.prior_roff[G.data] + col + q] = lo >= 0 ? lo + q : -1;
+                col += l;
+            }
+        }
+        PUT(prior_colloc, cl);
     }
     PUT(prior_J, B.prior_J); PUT(prior_r0, B.prior_r0); PUT(prior_x0, B.prior_x0);
     D.n_cl = (int)B.cl.size();

@@ -607,21 +607,22 @@ template <int MODE>
 __device__ __forceinline__ double gf_row_dot(const DevBatch& B, const DevOpt& O, const GFac& G, int k) {
     double a = 0;
     if (G.type == GF_PRIOR) {
-        // row k of the transposed record: lanes over rows read adjacent elements; nine guarded loads per block in flight
+        // row k of the transposed record: lanes over rows read adjacent elements; the columns are walked flat through the
+        // host-built column -> local index map, eight loads in flight, additions in column order (constant columns skipped)
         const int n = G.nres;
         const double* ck = B.prior_Jt + B.prior_Joff[G.data] + k;
-        int col = 0;
-        for (int t = 0; t < G.nslot; t++) {
-            int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
-            if (lo >= 0) for (int j0 = 0; j0 < l; j0 += 9) {
-                double c[9], v[9];
+        const int* cl = B.prior_colloc + B.prior_roff[G.data];
+        int c = 0;
+        for (; c + 8 <= n; c += 8) {
+            int lo[8]; double cv[8], vv[8];
 #pragma unroll
-                for (int j = 0; j < 9; j++) { bool ok = j0 + j < l; c[j] = ok ? ck[(size_t)(col + j0 + j) * n] : 0.0; v[j] = ok ? vec_at<MODE>(B, O, lo + j0 + j) : 0.0; }
+            for (int u = 0; u < 8; u++) lo[u] = cl[c + u];
 #pragma unroll
-                for (int j = 0; j < 9; j++) if (j0 + j < l) a += c[j] * v[j];
-            }
-            col += l;
+            for (int u = 0; u < 8; u++) { cv[u] = ck[(size_t)(c + u) * n]; vv[u] = lo[u] >= 0 ? vec_at<MODE>(B, O, lo[u]) : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (lo[u] >= 0) a += cv[u] * vv[u];
         }
+        for (; c < n; c++) { int lo = cl[c]; if (lo >= 0) a += ck[(size_t)c * n] * vec_at<MODE>(B, O, lo); }
     } else {
         for (int t = 0; t < G.nslot; t++) {
             int jo = B.s_joff[G.slot0 + t];
