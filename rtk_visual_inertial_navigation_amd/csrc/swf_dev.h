@@ -131,6 +131,8 @@ struct DevBatch {
     const double* prior_J; const double* prior_r0; const double* prior_x0;
     const double* prior_Jt;          // the same records transposed (element (k, c) at c * n + k): the J v products read these, lanes over rows
     const int* prior_colloc;         // per prior column (at prior_roff + c): reduced-local index of the column's variable, -1 if constant
+    const int* prior_colcc;          // likewise: the column's position in the prior clique's vectors, -1 if constant
+    const int* s_pcol; const int* s_pxo;   // prior slots only: first column of the block / its offset in the record's x0
     // cliques
     int n_cl;
     const Clique* cl;

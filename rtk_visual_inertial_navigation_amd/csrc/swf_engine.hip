@@ -716,17 +716,21 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         }
         PUT(prior_Jt, Jt);
         // column -> local index of every prior record (the J v products walk the columns flat, eight at a time)
-        std::vector<int> cl(B.prior_r0.size(), -1);
+        std::vector<int> cl(B.prior_r0.size(), -1), cc(B.prior_r0.size(), -1), pcol(B.s_ls.size(), 0), pxo(B.s_ls.size(), 0);
         for (const GFac& G : B.gf) {
             if (G.type != GF_PRIOR) continue;
-            int col = 0;
+            int col = 0, xo = 0;
             for (int t = 0; t < G.nslot; t++) {
-                int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t];
-                for (int q = 0; q < l; q++) cl[(size_t)B.prior_roff[G.data] + col + q] = lo >= 0 ? lo + q : -1;
-                col += l;
+                int l = B.s_ls[G.slot0 + t], lo = B.s_loc[G.slot0 + t], mc = B.s_ccol[G.slot0 + t];
+                pcol[G.slot0 + t] = col; pxo[G.slot0 + t] = xo;
+                for (int q = 0; q < l; q++) {
+                    cl[(size_t)B.prior_roff[G.data] + col + q] = lo >= 0 ? lo + q : -1;
+                    cc[(size_t)B.prior_roff[G.data] + col + q] = mc >= 0 ? mc + q : -1;
+                }
+                col += l; xo += (l == 6 ? 7 : l);
             }
         }
-        PUT(prior_colloc, cl);
+        PUT(prior_colloc, cl); PUT(prior_colcc, cc); PUT(s_pcol, pcol); PUT(s_pxo, pxo);
     }
     PUT(prior_J, B.prior_J); PUT(prior_r0, B.prior_r0); PUT(prior_x0, B.prior_x0);
     D.n_cl = (int)B.cl.size();

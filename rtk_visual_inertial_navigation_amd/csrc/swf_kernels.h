@@ -540,8 +540,7 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
     const double* x0 = B.prior_x0 + B.prior_x0off[k];
     // one thread per kept block computes its dx segment (x0 offsets are prefix sums of sizes)
     for (int sl = threadIdx.x; sl < G.nslot; sl += blockDim.x) {
-        int col = 0, xo = 0;
-        for (int t = 0; t < sl; t++) { int l = B.s_ls[G.slot0 + t]; col += l; xo += (l == 6 ? 7 : l); }
+        int col = B.s_pcol[G.slot0 + sl], xo = B.s_pxo[G.slot0 + sl];        // host-built prefix sums
         int l = B.s_ls[G.slot0 + sl];
         double tmp[9];
         prior_block_dx(xs + B.s_x[G.slot0 + sl], x0 + xo, l == 6 ? 7 : l, tmp);
@@ -564,11 +563,9 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         double a = 0;
         for (int i = 0; i < n; i++) a += Jp[(size_t)i * n + j] * rr[i];
-        // column j of the prior -> member column (constant blocks are not members)
-        int col = 0, m = -1, within = 0;
-        for (int t = 0; t < G.nslot; t++) { int l = B.s_ls[G.slot0 + t]; if (j < col + l) { m = t; within = j - col; break; } col += l; }
-        int cc = B.s_ccol[G.slot0 + m];
-        if (cc >= 0) B.cv_graw[C.v_off + cc + within] = a;
+        // column j of the prior -> member column (constant blocks are not members): host-built map
+        int mc = B.prior_colcc[B.prior_roff[k] + j];
+        if (mc >= 0) B.cv_graw[C.v_off + mc] = a;
     }
 }
 
