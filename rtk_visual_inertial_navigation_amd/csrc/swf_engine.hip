@@ -1010,7 +1010,7 @@ struct Launcher {
             if (b->min_red <= 240) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
             if (b->max_red > 240 && D.Wk) {
                 const int Tc = (b->max_red + 15) / 16;
-                for (int j = 0; j < Tc; j++) hipLaunchKernelGGL(k_chol_col, dim3(D.n_win, CC_NB), dim3(CC_NT), 0, st, D, j);
+                for (int j = 0; j < Tc; j += 2) hipLaunchKernelGGL(k_chol_col, dim3(D.n_win, CC_NB), dim3(CC_NT), 0, st, D, j);
                 hipLaunchKernelGGL(k_chol_big<true>, dim3(D.n_win), dim3(1024), 0, st, D);      // backward substitution
             } else if (b->max_red > 240) hipLaunchKernelGGL(k_chol_big<false>, dim3(D.n_win), dim3(1024), 0, st, D);
         }

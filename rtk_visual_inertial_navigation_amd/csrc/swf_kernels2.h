@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     for (int e = tid - 64; e < n; e += 960) y[e] = zs[e];
 }
 
-// k_chol_col — one tile column of the k_chol_big factorisation spread over CC_NB workgroups per window, for the latency
+// k_chol_col — two tile columns (j, j + 1) of the k_chol_big factorisation per launch, spread over CC_NB workgroups per window, for the latency
 // path (a single cfg5-class window would otherwise factor on one CU): every workgroup re-factors the 16x16 pivot tile and
 // re-forms the whole panel (cheap, and bit-identical in each), then updates its static share of the trailing tiles.  The
 // trailing matrix lives in a working copy (B.Wk) and the finished columns go to the L buffer, so no workgroup overwrites
@@ -794,7 +794,8 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
 #define CC_NB 32
 #define CC_NT 512
 __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
-    __shared__ double Pn[CB_MAXT][16][17];
+    __shared__ double Pn[CB_MAXT][16][17];      // panel of column j
+    __shared__ double Pn2[CB_MAXT][16][17];     // panel of column j + 1 (2 x 72 KB)
     __shared__ double Lic[16][17];
     __shared__ double ipiv[16];
     __shared__ double Dt[16][17];
@@ -852,17 +853,24 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
             else if (I < Tc && r < n && c < n) dst[(size_t)r * n + c] = (lower_only && c > r) ? 0.0 : v[q];
         }
     };
-    // ---- the loads that do not depend on the pivot go out first: this wave's panel tiles and its first trailing tiles
+    // ---- the loads that do not depend on the pivots go out first: this wave's tiles of columns j and j + 1 and its first
+    //      trailing tiles
     constexpr int NW = CC_NT / 64;                         // waves per workgroup
-    constexpr int PPW = (CB_MAXT - 1 + NW - 1) / NW;        // panel tiles per wave, at most
-    double4_t pv[PPW];
+    constexpr int PPW = (CB_MAXT - 1 + NW - 1) / NW;        // column tiles per wave, at most
+    const bool two = j + 1 < Tc;                           // this launch also finishes column j + 1
+    const int jt = two ? j + 2 : j + 1;                    // first trailing column
+    double4_t pv[PPW], pw[PPW];
 #pragma unroll
-    for (int u = 0; u < PPW; u++) { int I = j + 1 + wv + NW * u; if (I < Tr) pv[u] = load_tile(I, j); }
-    // trailing tiles (I, J), J > j, I >= J (the rhs row included): tile (I, J) belongs to wave (I + 33 J) mod (NW CC_NB) of
+    for (int u = 0; u < PPW; u++) {
+        int I = j + 1 + wv + NW * u;
+        pv[u] = double4_t{ 0, 0, 0, 0 }; pw[u] = pv[u];
+        if (I < Tr) { pv[u] = load_tile(I, j); if (two) pw[u] = load_tile(I, j + 1); }
+    }
+    // trailing tiles (I, J), J >= jt, I >= J (the rhs row included): tile (I, J) belongs to wave (I + 33 J) mod (NW CC_NB) of
     // the window, so a wave owns at most one tile per column and finds it without walking the others; four in flight
     constexpr int NWT = NW * CC_NB;
     const int me = g * NW + wv;
-    int tJ = j + 1;                                        // column cursor
+    int tJ = jt;                                           // column cursor
     auto next_owned = [&](int& I, int& J) {                // advance to this wave's next tile; false when exhausted
         while (tJ < Tc) {
             int c = tJ++;
@@ -878,46 +886,73 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
 #pragma unroll
     for (int u = 0; u < 4; u++) if (na == u && next_owned(Ia[u], Ja[u])) { va[u] = load_tile(Ia[u], Ja[u]); na = u + 1; }
     __syncthreads();                                       // fail = 0 visible
-    // ---- pivot tile (every workgroup; wave 0)
+    // pivot of column c from the tile in Dt (every workgroup, wave 0); workgroup 0 keeps Linv_cc and L_cc
+    auto pivot = [&](int c) {
+        bool bad = chol_pivot_tile(Dt, Lic, li, lk, ipiv);
+        if (bad && lane == 0) fail = 1;
+        if (g == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) LinvG[(size_t)c * 256 + (lk + 4 * q) * 16 + li] = Lic[lk + 4 * q][li];
+            double4_t l;
+#pragma unroll
+            for (int q = 0; q < 4; q++) l[q] = Dt[lk + 4 * q][li];
+            store_tile(Lw, c, c, l, true);
+        }
+    };
+    // panel tile I of column c: X = A Linv_cc^T, left in Pc[I]; stored to L by workgroup I mod CC_NB
+    auto panel = [&](double (*Pc)[16][17], int I, int c, double4_t a) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) Pc[I][lk + 4 * q][li] = a[q];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        double4_t X = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Pc[I][li][lk + 4 * kk], Lic[li][lk + 4 * kk], X, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; q++) Pc[I][lk + 4 * q][li] = X[q];
+        if (I % CC_NB == g) store_tile(Lw, I, c, X, false);
+    };
+    // ---- column j
     if (wv == 0) {
         double4_t v = load_tile(j, j);
 #pragma unroll
         for (int q = 0; q < 4; q++) Dt[lk + 4 * q][li] = v[q];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        bool bad = chol_pivot_tile(Dt, Lic, li, lk, ipiv);
-        if (bad && lane == 0) fail = 1;
-        if (g == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) LinvG[(size_t)j * 256 + (lk + 4 * q) * 16 + li] = Lic[lk + 4 * q][li];
-            double4_t l;
-#pragma unroll
-            for (int q = 0; q < 4; q++) l[q] = Dt[lk + 4 * q][li];
-            store_tile(Lw, j, j, l, true);
-        }
+        pivot(j);
     }
     __syncthreads();
     if (fail) { if (g == 0 && tid == 0) st.lin_fail = 1; return; }
-    // ---- panel (every workgroup forms all of it; tile I is stored to L by workgroup I mod CC_NB)
 #pragma unroll
-    for (int u = 0; u < PPW; u++) {
-        int I = j + 1 + wv + NW * u;
-        if (I >= Tr) break;
-#pragma unroll
-        for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = pv[u][q];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        double4_t X = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[I][li][lk + 4 * kk], Lic[li][lk + 4 * kk], X, 0, 0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = X[q];
-        if (I % CC_NB == g) store_tile(Lw, I, j, X, false);
-    }
+    for (int u = 0; u < PPW; u++) { int I = j + 1 + wv + NW * u; if (I < Tr) panel(Pn, I, j, pv[u]); }
     __syncthreads();
-    // ---- trailing updates, groups of four independent accumulators, the next group's loads in flight
+    if (two) {
+        // ---- column j + 1: its tiles take the update of column j (the same four MFMAs as any trailing tile), the diagonal
+        //      one goes to the pivot wave, the others become the panel of column j + 1
+#pragma unroll
+        for (int u = 0; u < PPW; u++) {
+            int I = j + 1 + wv + NW * u;
+            if (I < Tr) {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) pw[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[I][li][lk + 4 * kk], Pn[j + 1][li][lk + 4 * kk], pw[u], 0, 0, 0);
+                if (I == j + 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) Dt[lk + 4 * q][li] = pw[u][q];
+                }
+            }
+        }
+        __syncthreads();                                   // the updated diagonal tile is in Dt (written by wave 0 itself: I = j + 1)
+        if (wv == 0) pivot(j + 1);
+        __syncthreads();
+        if (fail) { if (g == 0 && tid == 0) st.lin_fail = 1; return; }
+#pragma unroll
+        for (int u = 0; u < PPW; u++) { int I = j + 1 + wv + NW * u; if (I > j + 1 && I < Tr) panel(Pn2, I, j + 1, pw[u]); }
+        __syncthreads();
+    }
+    // ---- trailing updates (both columns' rank-16 updates, column j first: the order of k_chol_big), groups of four
+    //      independent accumulators, the next group's loads in flight
     while (na) {
         int In[4], Jn[4], nn = 0;
         double4_t vn[4];
@@ -930,6 +965,13 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (u < na) va[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[Ia[u]][li][lk + 4 * kk], Pn[Ja[u]][li][lk + 4 * kk], va[u], 0, 0, 0);
+        if (two) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (u < na) va[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn2[Ia[u]][li][lk + 4 * kk], Pn2[Ja[u]][li][lk + 4 * kk], va[u], 0, 0, 0);
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) if (u < na) store_tile(Wk, Ia[u], Ja[u], va[u], false);
 #pragma unroll
