@@ -194,6 +194,32 @@ def test_large_batch_launch_shape_equals_single_window_solves_bitwise():
     bs.close()
 
 
+def test_streamed_cholesky_over_the_chip_equals_the_single_workgroup_kernel_bitwise(monkeypatch):
+    """Windows above 240 reduced dimensions: on the latency path the factorisation runs two tile columns per launch over 32
+    workgroups (k_chol_col), in large batches (or with SWF_NO_CHOL_COL) as one workgroup (k_chol_big).  Same MFMA sequence
+    per tile => the same factor, solution and solve, bit for bit; odd and even tile-column counts are both covered."""
+    parities = set()
+    for K, seed in ((24, 301), (25, 302), (26, 303), (27, 304)):
+        w = synth.make_window(3, K=K, F=40, S=5, seed=seed)
+        got = []
+        for off in (False, True):
+            monkeypatch.delenv("SWF_NO_CHOL_COL", raising=False)
+            if off:
+                monkeypatch.setenv("SWF_NO_CHOL_COL", "1")
+            c = w.copy()
+            bs = solver.BatchSolver([c]); sm = bs.solve(default_options())[0]
+            n = bs.dims(0)["n_red"]
+            S, rhs, L = bs.export_reduced(0)
+            got.append(([r["cost"] for r in sm.rows()], L.copy(), np.concatenate([c.a[k].ravel() for k in ("pose", "sb", "lm", "sc")])))
+            bs.close()
+        monkeypatch.delenv("SWF_NO_CHOL_COL", raising=False)
+        assert n > 240
+        parities.add(((n + 15) // 16) % 2)
+        assert got[0][0] == got[1][0], K
+        assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2]), K
+    assert parities == {0, 1}
+
+
 def test_landmark_quarters_per_block_and_kernel_variant_do_not_change_results(monkeypatch):
     """k_lm_schur lets one workgroup process 1 .. 16 landmark parts (chosen from the batch size) and is
     instantiated per tile count; every quarter keeps its own partial product and the arithmetic is pinned, so all
