@@ -919,6 +919,7 @@ namespace {
 struct Launcher {
     swf_batch* b; DevOpt O; hipStream_t st;
     bool lm_folded = false;     // k_lm_schur of the current linearisation wrote ONE folded product (else GEMM_SPLIT partials)
+    bool lm_second = false; int lm_qpb = 1;      // a second tile range of k_lm_schur<12, 5> is pending (launched with the clique kernels)
     // optional event pair around one launch
     struct Bracket {
         Launcher& L; int slot; hipStream_t bst;
@@ -973,7 +974,7 @@ struct Launcher {
             int qpb = 1;                                        // parts per block: as many as still leave >= 2 blocks per CU
             while (qpb < GEMM_SPLIT && (long long)D.n_win * GEMM_SPLIT / (2 * qpb) >= 2LL * b->n_cu) qpb *= 2;
             if (force_qpb >= 1 && force_qpb <= GEMM_SPLIT && (force_qpb & (force_qpb - 1)) == 0) qpb = force_qpb;
-            dim3 grid(D.n_win, GEMM_SPLIT / qpb);
+            dim3 grid(D.n_win, GEMM_SPLIT / qpb); lm_qpb = qpb;
             int tpw = (b->max_tiles <= 16 && force < 1) ? 2 : (b->max_tiles <= 40 && force < 2) ? 5 : 10;
             lm_folded = qpb == GEMM_SPLIT && tpw <= 5;          // must mirror CAN_FOLD in k_lm_schur (tpw 10 = the 1024-thread variant: no fold)
             if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb, 0);
@@ -981,7 +982,7 @@ struct Launcher {
             else {
                 // up to 120 tiles: two launches of the 12-consumer-wave, 5-slot variant (tiles 0..59, 60..119)
                 hipLaunchKernelGGL((k_lm_schur<12, 5>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb, 0);
-                if (write_S && b->max_tiles > 60) hipLaunchKernelGGL((k_lm_schur<12, 5>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb, 60);
+                lm_second = write_S && b->max_tiles > 60;       // tiles 60..119: launched below, on the auxiliary stream when there is one
             }
         }
         {
@@ -992,6 +993,14 @@ struct Launcher {
             if (D.n_clc[1]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(1)); hipLaunchKernelGGL((k_clique_elim<32, 48, 9, 1>), dim3(D.n_clc[1]), dim3(64), 0, cstream(1), D, O); }
             if (D.n_clc[0]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(0)); hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, cstream(0), D, O); }
             if (D.n_clc[2]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(2)); hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, cstream(2), D, O); }
+            if (lm_second) {
+                // the second tile range writes nothing but its tiles of P (k_lm_schur: outs), so on the latency path it runs behind the
+                // IMU / clique branch, next to the first range
+                int qpb2 = lm_qpb; dim3 grid2(D.n_win, GEMM_SPLIT / qpb2);
+                Bracket t(*this, SWF_K_LM_SCHUR, sa);
+                hipLaunchKernelGGL((k_lm_schur<12, 5>), grid2, dim3(LS_NT(12)), 0, sa, D, O, write_S, qpb2, 60);
+                lm_second = false;
+            }
             if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);
         }
         if (D.n_fsb) { Bracket t(*this, SWF_K_FRAME_SUMS); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }

@@ -736,6 +736,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
     // workgroups, large batches use 16 so the producer / consumer pipeline fills once per block).  Every part still gets
     // its own partial product, so the result does not depend on qpb.
     int w = blockIdx.x, sp0 = blockIdx.y * qpb;
+    const bool outs = tile_base == 0;                  // the launch of the second tile range only adds its tiles of P: it may run next to the first
     WinState& s = B.ws[w];
     if (!s.need_lin) return;
     const WinRec& W = B.win[w];
@@ -929,7 +930,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
         }
         if (act) {
             bool lead = first && sub == 0;
-            if (lead) {
+            if (lead && outs) {
                 B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
                 B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
                 B.vc[loc] = g0 / clampd(h00, O.min_diag, O.max_diag); B.vc[loc + 1] = g1 / clampd(h11, O.min_diag, O.max_diag); B.vc[loc + 2] = g2 / clampd(h22, O.min_diag, O.max_diag);
@@ -947,13 +948,13 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             double d22 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, h22));
             double i22 = rsqrt_nr(d22);
             bool bad = !(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0);
-            if (bad) { if (lead) s.lin_fail = 1; i00 = i11 = i22 = 0.0; }
+            if (bad) { if (lead && outs) s.lin_fail = 1; i00 = i11 = i22 = 0.0; }
             double i10 = -l10 * i00 * i11;
             double i21 = -l21 * i11 * i22;
             double i20 = -FMA2(l20, i00, l21, i10) * i22;
             double e00 = FMA3(i00, i00, i10, i10, i20, i20), e10 = FMA2(i10, i11, i20, i21), e20 = i20 * i22;
             double e11 = FMA2(i11, i11, i21, i21), e21 = i21 * i22, e22 = i22 * i22;
-            if (lead) {
+            if (lead && outs) {
                 B.lm_Einv[0 * nl + L] = e00; B.lm_Einv[1 * nl + L] = e10; B.lm_Einv[2 * nl + L] = e20;
                 B.lm_Einv[3 * nl + L] = e11; B.lm_Einv[4 * nl + L] = e21; B.lm_Einv[5 * nl + L] = e22;
                 B.lm_g[0 * nl + L] = g0; B.lm_g[1 * nl + L] = g1; B.lm_g[2 * nl + L] = g2;
@@ -966,7 +967,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
                 for (int i = 0; i < 6; i++) {
                     double w0 = FMA2(jp[i], a[0], jp[6 + i], a[3]), w1 = FMA2(jp[i], a[1], jp[6 + i], a[4]), w2 = FMA2(jp[i], a[2], jp[6 + i], a[5]);
                     double y0 = FMA3(w0, e00, w1, e10, w2, e20), y1 = FMA3(w0, e10, w1, e11, w2, e21), y2 = FMA3(w0, e20, w1, e21, w2, e22);
-                    B.p_yg[i * n + o] = FMA3(y0, g0, y1, g1, y2, g2);
+                    if (outs) B.p_yg[i * n + o] = FMA3(y0, g0, y1, g1, y2, g2);
                     if (gemm) {
                         cell[i] = y0; cell[6 + i] = y1; cell[12 + i] = y2;
                         cell[18 + i] = w0; cell[24 + i] = w1; cell[30 + i] = w2;
