@@ -785,12 +785,13 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     for (int e = tid - 64; e < n; e += 960) y[e] = zs[e];
 }
 
-// k_chol_col — two tile columns (j, j + 1) of the k_chol_big factorisation per launch, spread over CC_NB workgroups per window, for the latency
-// path (a single cfg5-class window would otherwise factor on one CU): every workgroup re-factors the 16x16 pivot tile and
-// re-forms the whole panel (cheap, and bit-identical in each), then updates its static share of the trailing tiles.  The
-// trailing matrix lives in a working copy (B.Wk) and the finished columns go to the L buffer, so no workgroup overwrites
-// what another still reads; one launch per column, k_chol_big<true> does the backward substitution.  Every tile sees the
-// same MFMA sequence as in k_chol_big: the two paths give bit-identical factors.
+// k_chol_col — two tile columns (j, j + 1) of the k_chol_big factorisation per launch, spread over CC_NB workgroups per
+// window, for the latency path (a single cfg5-class window would otherwise factor on one CU): every workgroup re-factors
+// the two 16x16 pivot tiles and re-forms both panels (cheap, and bit-identical in each; the tiles of column j + 1 take
+// column j's update in registers), then applies both rank-16 updates to its share of the trailing tiles.  The trailing
+// matrix lives in a working copy (B.Wk) and the finished columns go to the L buffer, so no workgroup overwrites what
+// another still reads; k_chol_big<true> does the backward substitution.  Every tile sees the same MFMA sequence as in
+// k_chol_big: the two paths give bit-identical factors.
 #define CC_NB 32
 #define CC_NT 512
 __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
