@@ -782,8 +782,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     rc |= P.zeros(B.n_loc, &D.y); rc |= P.zeros(B.n_loc, &D.step);
     rc |= P.zeros(B.S_tot, &D.S); rc |= P.zeros(B.Lt_tot, &D.L);
     if (b->max_red > 240 && b->max_red <= 512) rc |= P.zeros((size_t)n * (CB_MAXT - 1) * 256, &D.Linv);
-    // latency path with a streamed-Cholesky window: the factorisation is spread over the chip column by column (k_chol_col)
-    if (b->max_red > 240 && b->max_red <= 512 && n * 16 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);
+    // few windows, one of them on the streamed Cholesky: the factorisation is spread over the chip, two tile columns per launch (k_chol_col)
+    if (b->max_red > 240 && b->max_red <= 512 && n * 4 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);      // >= 4 workgroups per window
     rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
     size_t np = (size_t)D.n_proj;
     rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl); rc |= P.zeros(6 * np, &D.p_yg);
@@ -1019,7 +1019,8 @@ struct Launcher {
             if (b->min_red <= 240) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
             if (b->max_red > 240 && D.Wk) {
                 const int Tc = (b->max_red + 15) / 16;
-                for (int j = 0; j < Tc; j += 2) hipLaunchKernelGGL(k_chol_col, dim3(D.n_win, CC_NB), dim3(CC_NT), 0, st, D, j);
+                const int nbw = std::max(1, std::min(CC_NB, b->n_cu / D.n_win));       // the chip divided by the windows
+                for (int j = 0; j < Tc; j += 2) hipLaunchKernelGGL(k_chol_col, dim3(D.n_win, nbw), dim3(CC_NT), 0, st, D, j);
                 hipLaunchKernelGGL(k_chol_big<true>, dim3(D.n_win), dim3(1024), 0, st, D);      // backward substitution
             } else if (b->max_red > 240) hipLaunchKernelGGL(k_chol_big<false>, dim3(D.n_win), dim3(1024), 0, st, D);
         }

@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
 // matrix lives in a working copy (B.Wk) and the finished columns go to the L buffer, so no workgroup overwrites what
 // another still reads; k_chol_big<true> does the backward substitution.  Every tile sees the same MFMA sequence as in
 // k_chol_big: the two paths give bit-identical factors.
-#define CC_NB 32
+#define CC_NB 32                        // workgroups per window, at most (the engine divides the chip by the window count)
 #define CC_NT 512
 __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
     __shared__ double Pn[CB_MAXT][16][17];      // panel of column j
@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
     __shared__ double ipiv[16];
     __shared__ double Dt[16][17];
     __shared__ int fail;
-    const int w = blockIdx.x, g = blockIdx.y;
+    const int w = blockIdx.x, g = blockIdx.y, nbw = gridDim.y;      // nbw workgroups share the window (ownership only: the arithmetic of a tile does not depend on it)
     WinState& st = B.ws[w];
     if (!st.need_lin || st.lin_fail) return;
     const WinRec& W = B.win[w];
@@ -867,9 +867,9 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
         pv[u] = double4_t{ 0, 0, 0, 0 }; pw[u] = pv[u];
         if (I < Tr) { pv[u] = load_tile(I, j); if (two) pw[u] = load_tile(I, j + 1); }
     }
-    // trailing tiles (I, J), J >= jt, I >= J (the rhs row included): tile (I, J) belongs to wave (I + 33 J) mod (NW CC_NB) of
+    // trailing tiles (I, J), J >= jt, I >= J (the rhs row included): tile (I, J) belongs to wave (I + 33 J) mod (NW nbw) of
     // the window, so a wave owns at most one tile per column and finds it without walking the others; four in flight
-    constexpr int NWT = NW * CC_NB;
+    const int NWT = NW * nbw;
     const int me = g * NW + wv;
     int tJ = jt;                                           // column cursor
     auto next_owned = [&](int& I, int& J) {                // advance to this wave's next tile; false when exhausted
@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
             store_tile(Lw, c, c, l, true);
         }
     };
-    // panel tile I of column c: X = A Linv_cc^T, left in Pc[I]; stored to L by workgroup I mod CC_NB
+    // panel tile I of column c: X = A Linv_cc^T, left in Pc[I]; stored to L by workgroup I mod nbw
     auto panel = [&](double (*Pc)[16][17], int I, int c, double4_t a) {
 #pragma unroll
         for (int q = 0; q < 4; q++) Pc[I][lk + 4 * q][li] = a[q];
@@ -913,7 +913,7 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; q++) Pc[I][lk + 4 * q][li] = X[q];
-        if (I % CC_NB == g) store_tile(Lw, I, c, X, false);
+        if (I % nbw == g) store_tile(Lw, I, c, X, false);
     };
     // ---- column j
     if (wv == 0) {

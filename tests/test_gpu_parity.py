@@ -218,6 +218,14 @@ def test_streamed_cholesky_over_the_chip_equals_the_single_workgroup_kernel_bitw
         assert got[0][0] == got[1][0], K
         assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2]), K
     assert parities == {0, 1}
+    # a medium batch: the chip is divided by the window count (10 workgroups per window here instead of 32); same bits
+    w = synth.make_window(3, K=26, F=40, S=5, seed=303)
+    one = w.copy(); bs = solver.BatchSolver([one]); sm1 = bs.solve(default_options())[0]; bs.close()
+    many = [w.copy() for _ in range(24)]
+    bs = solver.BatchSolver(many); sms = bs.solve(default_options()); bs.close()
+    for c, sm in zip(many, sms):
+        assert [r["cost"] for r in sm.rows()] == [r["cost"] for r in sm1.rows()]
+        assert all(np.array_equal(c.a[k], one.a[k]) for k in ("pose", "sb", "lm", "sc"))
 
 
 def test_landmark_quarters_per_block_and_kernel_variant_do_not_change_results(monkeypatch):
