@@ -183,8 +183,9 @@ int swf_triangulate_batch(const double* Ps, const double* Rs, int32_t n_frames, 
                           const double pbg[3], const int32_t* start_frame, const double* pt0, const double* pt1, int32_t n,
                           double init_depth, double* depth, double* pts_world, int32_t on_device, void* stream);
 
-/* Inverse-depth projection factors for a batch, one lane per factor — an evaluator with parity against the
- * oracle; the Schur path of the solver takes world-point landmarks only (the reference's default, USE_INVERSE_DEPTH 0).
+/* Inverse-depth projection factors for a batch, one lane per factor — the stand-alone evaluator (parity
+ * against the oracle).  Inside the solver the same factors are a factor type of the loop: swf_flat_window::idp_* /
+ * swf_add_projection_inverse_depth, the inverse depth being a scalar block of elimination group 0.
  *   kind [n]      0 ProjectionTwoFrameOneCamFactor (R/factor/projection_factor.cpp:179-256): pose_i, pose_j, ex, lambda
  *                 1 ProjectionTwoFrameTwoCamFactor (:77-166): pose_i, pose_j, ex, ex2, lambda
  *                 2 ProjectionOneFrameTwoCamFactor (:269-329): ex, ex2, lambda

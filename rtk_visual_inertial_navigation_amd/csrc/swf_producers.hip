@@ -432,9 +432,9 @@ extern "C" int swf_triangulate_batch(const double* Ps, const double* Rs, int32_t
 //     ProjectionTwoFrameOneCamFactor (R/factor/projection_factor.cpp:179-256)   kind 0: pose_i, pose_j, ex, lambda
 //     ProjectionTwoFrameTwoCamFactor (:77-166)                                  kind 1: pose_i, pose_j, ex, ex2, lambda
 //     ProjectionOneFrameTwoCamFactor (:269-329)                                 kind 2: ex, ex2, lambda (no lever arm)
-// The reference compiles them out by default (USE_INVERSE_DEPTH 0, R/parameter/parameters.h:25); here they are an evaluator
-// with parity against the oracle, not yet a landmark type of the Schur path (that needs a one-dimensional landmark block
-// whose every observation also touches the anchor pose).
+// The reference compiles them out by default (USE_INVERSE_DEPTH 0, R/parameter/parameters.h:25).  This is the stand-alone batched
+// evaluator; inside the solve loop the same d_idepth_eval (swf_dev.h) runs as a segment of k_eval_ps / k_eval_idp and the feature is
+// a scalar group-0 block eliminated by k_clique_elim (swf_add_projection_inverse_depth).
 // =====================================================================================================================
 namespace {
 struct IdepthArgs {

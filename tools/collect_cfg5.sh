@@ -9,19 +9,19 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/swf5 && mkdir -p /tmp/swf5
 export PYTHONPATH="$ROOT"
-( cd "$ROOT" && python tests/gpu_cfg5_prof.py ) > "$OUT/cfg5_single_window.txt" 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swf5/kt -o k -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/kt.log 2>&1
+( cd "$ROOT" && python tools/prof/gpu_cfg5_prof.py ) > "$OUT/cfg5_single_window.txt" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swf5/kt -o k -- python "$ROOT/tools/prof/gpu_cfg5_run.py" > /tmp/swf5/kt.log 2>&1
 cp "$(find /tmp/swf5/kt -name '*kernel_stats.csv' | head -1)" "$OUT/cfg5_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/swf5/pmc_$C -o p -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/pmc_$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/swf5/pmc_$C -o p -- python "$ROOT/tools/prof/gpu_cfg5_run.py" > /tmp/swf5/pmc_$C.log 2>&1
 done
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swf5/pmc_mfma -o p -- python "$ROOT/tests/gpu_cfg5_run.py" > /tmp/swf5/pmc_mfma.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swf5/pmc_mfma -o p -- python "$ROOT/tools/prof/gpu_cfg5_run.py" > /tmp/swf5/pmc_mfma.log 2>&1
 python "$ROOT/tools/summarize_mfma_pmc.py" "$(find /tmp/swf5/pmc_mfma -name '*counter_collection.csv' | head -1)" "$OUT/cfg5_pmc_mfma.json"
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
 res = {"note": "BASELINE cfg5 (one window: 40 keyframes, 1000 features, 20000 observations, 20 satellites, 107-dim dense prior; n_red = 440), "
-               "tests/gpu_cfg5_run.py = 3 solves of 8 dogleg iterations; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; unit KB; "
+               "tools/prof/gpu_cfg5_run.py = 3 solves of 8 dogleg iterations; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; unit KB; "
                "gfx950: hbm_read_bytes ~= 2 * FETCH_SIZE * 1024 for streaming reads (MI355X_MICROARCH.md).  A single window lives in L2 / Infinity Cache: "
                "these are traffic counts, not a bandwidth claim."}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):

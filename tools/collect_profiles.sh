@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py / DESIGN.md cite, on a GPU box:
 #   tools/collect_profiles.sh <out_dir>          (e.g. gpurun_out/r01)
-#  1. --kernel-trace --stats of the batch-only workload (512 windows, tests/gpu_batch_prof.py)
-#  2. --kernel-trace --stats of the single-window workload (tests/gpu_single_prof.py)
+#  1. --kernel-trace --stats of the batch-only workload (512 windows, tools/prof/gpu_batch_prof.py)
+#  2. --kernel-trace --stats of the single-window workload (tools/prof/gpu_single_prof.py)
 #  3. --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (TCC slot limit; never combined with tracing)
 #  4. --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (matrix-core utilisation per kernel)
 # Summaries (csv / json) land in <out_dir>; copy them to profiles/<round>/ to have them judged.
@@ -12,23 +12,23 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/swfprof && mkdir -p /tmp/swfprof
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/batch -o b -- python "$ROOT/tests/gpu_batch_prof.py" 512 4 > /tmp/swfprof/batch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/batch -o b -- python "$ROOT/tools/prof/gpu_batch_prof.py" 512 4 > /tmp/swfprof/batch.log 2>&1
 cp "$(find /tmp/swfprof/batch -name '*kernel_stats.csv' | head -1)" "$OUT/batch512_kernel_stats.csv"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/single -o s -- python "$ROOT/tests/gpu_single_prof.py" 20 > /tmp/swfprof/single.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/single -o s -- python "$ROOT/tools/prof/gpu_single_prof.py" 20 > /tmp/swfprof/single.log 2>&1
 cp "$(find /tmp/swfprof/single -name '*kernel_stats.csv' | head -1)" "$OUT/single_window_kernel_stats.csv"
 # 2b. the bench command itself, without the single-window / CPU legs (same kernel names would dilute the averages)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/bench -o n -- python "$ROOT/bench.py" --no-single-window --no-cpu-baseline > "$OUT/bench_nosingle.json" 2> /tmp/swfprof/bench.log
 cp "$(find /tmp/swfprof/bench -name '*kernel_stats.csv' | head -1)" "$OUT/bench_nosingle_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/swfprof/pmc_$C -o p -- python "$ROOT/tests/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/swfprof/pmc_$C -o p -- python "$ROOT/tools/prof/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_$C.log 2>&1
 done
 # 4. matrix-core counters in their own pass: instructions, busy cycles, GPU-active cycles -> MFMA utilisation per kernel
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swfprof/pmc_mfma -o p -- python "$ROOT/tests/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_mfma.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/swfprof/pmc_mfma -o p -- python "$ROOT/tools/prof/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_mfma.log 2>&1
 python "$ROOT/tools/summarize_mfma_pmc.py" "$(find /tmp/swfprof/pmc_mfma -name '*counter_collection.csv' | head -1)" "$OUT/batch512_pmc_mfma.json"
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
-res = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (TCC slot limit), workload tests/gpu_batch_prof.py 512 2 "
+res = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (TCC slot limit), workload tools/prof/gpu_batch_prof.py 512 2 "
                "(512 cfg4 windows, 8 dogleg iterations, batch only).  Counter unit = KB.  Per MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE "
                "reports 1/2 of the bytes of wide coalesced reads, so hbm_read_bytes ~= 2 * FETCH_SIZE * 1024 for streaming kernels; "
                "WRITE_SIZE is uncalibrated.  Infinity-Cache hits are counted."}

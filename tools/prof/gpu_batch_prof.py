@@ -1,7 +1,7 @@
 """Batch-only workload for rocprofv3 (no single-window runs, no event brackets):
-   rocprofv3 --kernel-trace --stats -- python tests/gpu_batch_prof.py [windows] [solves]"""
+   rocprofv3 --kernel-trace --stats -- python tools/prof/gpu_batch_prof.py [windows] [solves]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
 from rtk_visual_inertial_navigation_amd import synth, solver

@@ -1,6 +1,6 @@
 """BASELINE cfg5 stress window, solve only (workload for rocprofv3; no oracle, no event brackets)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rtk_visual_inertial_navigation_amd import synth, solver
 from rtk_visual_inertial_navigation_amd.flat import default_options

@@ -1,5 +1,5 @@
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from rtk_visual_inertial_navigation_amd import synth, solver
 from rtk_visual_inertial_navigation_amd.flat import default_options

@@ -1,12 +1,12 @@
 """Verbose GPU-vs-oracle diagnostics (developer tool; the pytest parity tests are in
-test_gpu_parity.py).  Usage: python tests/gpu_diag.py [cfg ...]"""
+test_gpu_parity.py).  Usage: python tools/prof/gpu_diag.py [cfg ...]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from rtk_visual_inertial_navigation_amd import synth, solver          # noqa: E402
 from rtk_visual_inertial_navigation_amd.flat import default_options, TERMINATION  # noqa: E402

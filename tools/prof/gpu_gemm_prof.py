@@ -1,5 +1,5 @@
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
 from rtk_visual_inertial_navigation_amd import synth, solver
@@ -10,6 +10,6 @@ bs = solver.BatchSolver(ws)
 for _ in range(3):
     bs.reset_state(); bs.solve(default_options(step_mode=1), download=False)
 out = (C.c_ulonglong * 16)()
-solver.lib().swf_debug_clq_stamps(out)
+solver.lib().swf_debug_gemm_stamps(out)
 s = list(out)
-print("windows", B, "| header+zero", s[0], "| gather", s[1], "| M = J^T J", s[2], "| Gauss-Jordan", s[3], "| T, Eg", s[4], "| outputs (C, cs, E)", s[5], "| total", sum(s[:6]), "(cycles, class-1 block 0)")
+print("windows", B, "| producer: loads+sums", s[0], "inverse+cells", s[1], "barrier wait", s[2], "total", s[6], "| consumer wave 0: first wait", s[8], "mfma loops", s[9], "barrier wait", s[10], "(core clock cycles, block 0)")

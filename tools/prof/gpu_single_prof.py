@@ -1,6 +1,6 @@
 """Single-window latency workload for rocprofv3."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rtk_visual_inertial_navigation_amd import synth, solver
 from rtk_visual_inertial_navigation_amd.flat import default_options

@@ -1,6 +1,6 @@
 """Experiment: same 512 windows as 1, 2 or 4 independent batches on separate HIP streams."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench
