@@ -28,6 +28,7 @@
 //                                               R/swf/swf_gnss.cpp:25-94              -> swf_ceres::internal::* below
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -39,7 +40,7 @@
 namespace swf_ceres {
 
 enum LinearSolverType { DENSE_SCHUR };
-enum TrustRegionStrategyType { DOGLEG };
+enum TrustRegionStrategyType { LEVENBERG_MARQUARDT, DOGLEG };      // ceres' default is LEVENBERG_MARQUARDT; R/swf/swf.cpp:26 sets DOGLEG
 
 class LossFunction { public: virtual ~LossFunction() {} virtual double a() const = 0; };
 class CauchyLoss : public LossFunction { public: explicit CauchyLoss(double a) : a_(a) {} double a() const override { return a_; } private: double a_; };
@@ -133,22 +134,30 @@ class ParameterBlockOrdering {
     std::vector<double*> keys_; std::vector<int32_t> groups_;
 };
 
+class Problem;
 namespace internal {
-// the modified Ceres' private globals, as the reference uses them (R/swf/swf_gnss.cpp:25-94)
-inline std::vector<double*>& parameter_head_ref() { static std::vector<double*> v; return v; }
-inline bool& is_optimize_ref() { static bool v = true; return v; }
-#define parameter_head parameter_head_ref()
-#define is_optimize is_optimize_ref()
-struct Exports { const double* lhs_out = nullptr; const double* rhs_out = nullptr; const double* lhs_out2 = nullptr; int hs_row = 0; };
+// the modified Ceres' private globals, as the reference uses them (R/swf/swf_gnss.cpp:25-94): C++17 inline variables, so the
+// names are ordinary identifiers of this namespace (no macros leak into the including translation unit)
+inline std::vector<double*> parameter_head;
+inline bool is_optimize = true;
+// lhs_out / rhs_out / lhs_out2 / hs_row of the LAST successful Solve; reset by a failed Solve and by the destruction of the
+// Problem they point into
+struct Exports { const double* lhs_out = nullptr; const double* rhs_out = nullptr; const double* lhs_out2 = nullptr; int hs_row = 0; const Problem* owner = nullptr; };
 inline Exports& exports() { static Exports e; return e; }
+// ceres::internal::ResidualBlock as the estimator sees it: a handle whose public is_use flag it flips directly
+// (R/swf/swf_image.cpp:353-365,422; R/swf/swf_gnss.cpp:653).  Solve() carries the flags over to swf_factor_set_enabled.
+struct ResidualBlock { bool is_use = true; swf_factor_id id = -1; };
 }  // namespace internal
 
-typedef int32_t ResidualBlockId;
+typedef internal::ResidualBlock* ResidualBlockId;
 
 class Problem {
   public:
     Problem() { if (swf_problem_create(&h_) != SWF_OK) throw std::runtime_error("swf_problem_create"); }
-    ~Problem() { swf_problem_destroy(h_); }
+    ~Problem() {
+        if (internal::exports().owner == this) internal::exports() = internal::Exports();
+        swf_problem_destroy(h_);
+    }
     Problem(const Problem&) = delete;
     swf_problem* handle() { return h_; }
 
@@ -164,111 +173,164 @@ class Problem {
     int ParameterBlockSize(const double* p) const { return swf_parameter_block_size(h_, p); }
     int NumParameterBlocks() const { return swf_num_parameter_blocks(h_); }
     int NumResidualBlocks() const { return swf_num_residual_blocks(h_); }
-    void RemoveResidualBlock(ResidualBlockId id) { chk(swf_remove_factor(h_, id), "RemoveResidualBlock"); }
-    void SetResidualBlockUse(ResidualBlockId id, bool is_use) { chk(swf_factor_set_enabled(h_, id, is_use), "is_use"); }
+    void RemoveResidualBlock(ResidualBlockId rb) { chk(swf_remove_factor(h_, rb->id), "RemoveResidualBlock"); }
+    // the query surface GlobalMarge / FeatureManager walk (R/swf/swf_image.cpp:350-367, R/swf/swf.cpp:413-422)
+    void GetResidualBlocks(std::vector<ResidualBlockId>* out) const {
+        int32_t n = 0; chk(swf_get_residual_blocks(h_, nullptr, 0, &n), "GetResidualBlocks");
+        std::vector<swf_factor_id> ids((size_t)n); chk(swf_get_residual_blocks(h_, ids.data(), n, &n), "GetResidualBlocks");
+        out->clear(); for (swf_factor_id i : ids) out->push_back(rb_[(size_t)i].get());
+    }
+    void GetResidualBlocksForParameterBlock(const double* p, std::vector<ResidualBlockId>* out) const {
+        int32_t n = 0; chk(swf_get_residual_blocks_for_parameter_block(h_, p, nullptr, 0, &n), "GetResidualBlocksForParameterBlock");
+        std::vector<swf_factor_id> ids((size_t)n); chk(swf_get_residual_blocks_for_parameter_block(h_, p, ids.data(), n, &n), "GetResidualBlocksForParameterBlock");
+        out->clear(); for (swf_factor_id i : ids) out->push_back(rb_[(size_t)i].get());
+    }
+    void GetParameterBlocks(std::vector<double*>* out) const {
+        int32_t n = 0; chk(swf_get_parameter_blocks(h_, nullptr, 0, &n), "GetParameterBlocks");
+        out->assign((size_t)n, nullptr); chk(swf_get_parameter_blocks(h_, out->data(), n, &n), "GetParameterBlocks");
+    }
+    void GetParameterBlocksForResidualBlock(const ResidualBlockId rb, std::vector<double*>* out) const {
+        int32_t n = 0; chk(swf_get_parameter_blocks_for_residual_block(h_, rb->id, nullptr, 0, &n), "GetParameterBlocksForResidualBlock");
+        out->assign((size_t)n, nullptr); chk(swf_get_parameter_blocks_for_residual_block(h_, rb->id, out->data(), n, &n), "GetParameterBlocksForResidualBlock");
+    }
+    // ResidualBlock::is_use -> swf_factor_set_enabled for every live residual block (called by Solve)
+    int SyncIsUse() {
+        int32_t n = 0; int rc = swf_get_residual_blocks(h_, nullptr, 0, &n);
+        if (rc != SWF_OK) return rc;
+        std::vector<swf_factor_id> ids((size_t)n);
+        if ((rc = swf_get_residual_blocks(h_, ids.data(), n, &n)) != SWF_OK) return rc;
+        for (swf_factor_id i : ids) if ((rc = swf_factor_set_enabled(h_, i, rb_[(size_t)i]->is_use ? 1 : 0)) != SWF_OK) return rc;
+        return SWF_OK;
+    }
     void SetConstants(const double* pbg, const double* gw, const double* base) { chk(swf_set_constants(h_, pbg, gw, base), "SetConstants"); }
 
     // AddResidualBlock overloads by cost-function type; Problem takes ownership of cost and loss
     ResidualBlockId AddResidualBlock(projection_factor* f, LossFunction* loss, double* pose, double* ex, double* pt) {
-        ResidualBlockId id = swf_add_projection(h_, pose, ex, pt, f->uv, projection_factor::sqrt_info(), loss ? loss->a() : 0.0);
+        swf_factor_id id = swf_add_projection(h_, pose, ex, pt, f->uv, projection_factor::sqrt_info(), loss ? loss->a() : 0.0);
         delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(IMUFactor* f, LossFunction* loss, double* pi, double* si, double* pj, double* sj) {
-        ResidualBlockId id = swf_add_imu(h_, pi, si, pj, sj, f->pre.data()); delete f; delete loss; return ck(id);
+        swf_factor_id id = swf_add_imu(h_, pi, si, pj, sj, f->pre.data()); delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(RTKCarrierPhaseFactor* f, LossFunction* loss, double* pose, double* amb, double* clk) {
-        ResidualBlockId id = swf_add_rtk_carrier_phase(h_, pose, amb, clk, f->dat); delete f; delete loss; return ck(id);
+        swf_factor_id id = swf_add_rtk_carrier_phase(h_, pose, amb, clk, f->dat); delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(RTKPseudorangeFactor* f, LossFunction* loss, double* pose, double* clk) {
-        ResidualBlockId id = swf_add_rtk_pseudorange(h_, pose, clk, f->dat); delete f; delete loss; return ck(id);
+        swf_factor_id id = swf_add_rtk_pseudorange(h_, pose, clk, f->dat); delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(SppDopplerFactor* f, LossFunction* loss, double* sb, double* drift, double* pose) {
-        ResidualBlockId id = swf_add_doppler(h_, sb, drift, pose, f->dat); delete f; delete loss; return ck(id);
+        swf_factor_id id = swf_add_doppler(h_, sb, drift, pose, f->dat); delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(SppPseudorangeFactor* f, LossFunction* loss, double* pose, double* clk) {
-        ResidualBlockId id = swf_add_spp_pseudorange(h_, pose, clk, f->dat); delete f; delete loss; return ck(id);
+        swf_factor_id id = swf_add_spp_pseudorange(h_, pose, clk, f->dat); delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(SppCarrierPhaseFactor* f, LossFunction* loss, double* pose, double* clk, double* amb) {
-        ResidualBlockId id = swf_add_spp_carrier_phase(h_, pose, clk, amb, f->dat); delete f; delete loss; return ck(id);
+        swf_factor_id id = swf_add_spp_carrier_phase(h_, pose, clk, amb, f->dat); delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(FixedIntegerFactor* f, LossFunction* loss, double* n_a, double* n_b) {
-        ResidualBlockId id = swf_add_fixed_integer(h_, n_a, n_b, f->N21, f->istd); delete f; delete loss; return ck(id);
+        swf_factor_id id = swf_add_fixed_integer(h_, n_a, n_b, f->N21, f->istd); delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(ProjectionTwoFrameOneCamFactor* f, LossFunction* loss, double* pose_i, double* pose_j, double* ex, double* inv_depth) {
-        ResidualBlockId id = swf_add_projection_inverse_depth(h_, 0, pose_i, pose_j, ex, nullptr, inv_depth, f->pi, f->pj, ProjectionTwoFrameOneCamFactor::sqrt_info, loss ? loss->a() : 0.0);
+        swf_factor_id id = swf_add_projection_inverse_depth(h_, 0, pose_i, pose_j, ex, nullptr, inv_depth, f->pi, f->pj, ProjectionTwoFrameOneCamFactor::sqrt_info, loss ? loss->a() : 0.0);
         delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(ProjectionTwoFrameTwoCamFactor* f, LossFunction* loss, double* pose_i, double* pose_j, double* ex, double* ex2, double* inv_depth) {
-        ResidualBlockId id = swf_add_projection_inverse_depth(h_, 1, pose_i, pose_j, ex, ex2, inv_depth, f->pi, f->pj, ProjectionTwoFrameTwoCamFactor::sqrt_info, loss ? loss->a() : 0.0);
+        swf_factor_id id = swf_add_projection_inverse_depth(h_, 1, pose_i, pose_j, ex, ex2, inv_depth, f->pi, f->pj, ProjectionTwoFrameTwoCamFactor::sqrt_info, loss ? loss->a() : 0.0);
         delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(ProjectionOneFrameTwoCamFactor* f, LossFunction* loss, double* ex, double* ex2, double* inv_depth) {
-        ResidualBlockId id = swf_add_projection_inverse_depth(h_, 2, nullptr, nullptr, ex, ex2, inv_depth, f->pi, f->pj, ProjectionOneFrameTwoCamFactor::sqrt_info, loss ? loss->a() : 0.0);
+        swf_factor_id id = swf_add_projection_inverse_depth(h_, 2, nullptr, nullptr, ex, ex2, inv_depth, f->pi, f->pj, ProjectionOneFrameTwoCamFactor::sqrt_info, loss ? loss->a() : 0.0);
         delete f; delete loss; return ck(id);
     }
     // param = { pose_i, speed_bias_i, pose_j, speed_bias_j, ambiguity_0 .. ambiguity_N-1 } as SetLastImuFactor builds it
     ResidualBlockId AddResidualBlock(IMUGNSSFactor* f, LossFunction* loss, const std::vector<double*>& param) {
         const IMUGNSSInfo& I = *f->info;
         const int N = (int)param.size() - 4;
-        ResidualBlockId id = swf_add_imu_gnss(h_, param[0], param[1], param[2], param[3], param.data() + 4, N, I.M, I.hidden_pose, I.hidden_sb,
+        swf_factor_id id = swf_add_imu_gnss(h_, param[0], param[1], param[2], param[3], param.data() + 4, N, I.M, I.hidden_pose, I.hidden_sb,
                                               I.pose_lin.data(), I.sb_lin.data(), I.Hpp.data(), I.HpN.data(), I.rhs_p.data(), I.HNN.data(), I.rhsN.data(), I.pre.data());
         delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(InitialBlackFactor* f, LossFunction* loss, double* scalar) {
-        ResidualBlockId id = swf_add_scalar_prior(h_, scalar, f->istd); delete f; delete loss; return ck(id);
+        swf_factor_id id = swf_add_scalar_prior(h_, scalar, f->istd); delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(MarginalizationFactor* f, LossFunction* loss, const std::vector<double*>& blocks) {
-        ResidualBlockId id = swf_add_linear_prior(h_, blocks.data(), (int32_t)blocks.size(), f->J.data(), f->r0.data(), f->x0.data());
+        swf_factor_id id = swf_add_linear_prior(h_, blocks.data(), (int32_t)blocks.size(), f->J.data(), f->r0.data(), f->x0.data());
         delete f; delete loss; return ck(id);
     }
 
   private:
     static void chk(int rc, const char* what) { if (rc != SWF_OK) throw std::runtime_error(std::string(what) + ": " + swf_last_error()); }
-    static ResidualBlockId ck(ResidualBlockId id) { if (id < 0) throw std::runtime_error(std::string("AddResidualBlock: ") + swf_last_error()); return id; }
+    // factor id -> the handle the caller holds; handles live as long as the Problem (a removed block's handle dangles
+    // logically, as in ceres, but never physically)
+    ResidualBlockId ck(swf_factor_id id) {
+        if (id < 0) throw std::runtime_error(std::string("AddResidualBlock: ") + swf_last_error());
+        if (rb_.size() <= (size_t)id) rb_.resize((size_t)id + 1);
+        rb_[(size_t)id].reset(new internal::ResidualBlock());
+        rb_[(size_t)id]->id = id;
+        return rb_[(size_t)id].get();
+    }
     swf_problem* h_ = nullptr;
+    std::vector<std::unique_ptr<internal::ResidualBlock>> rb_;
 };
 
 struct Solver {
     struct Options {
         LinearSolverType linear_solver_type = DENSE_SCHUR;
-        TrustRegionStrategyType trust_region_strategy_type = DOGLEG;
-        int max_num_iterations = 8;
-        int num_threads = 4;                 // accepted, unused: the device decides its own parallelism
-        bool jacobi_scaling = false;         // the reference sets 0 (R/swf/swf.cpp:27); scaling is not implemented
+        TrustRegionStrategyType trust_region_strategy_type = LEVENBERG_MARQUARDT;      // ceres' default; the window solves set DOGLEG
+        int max_num_iterations = 50;         // ceres' default; R/swf/swf.cpp:25 sets MAX_NUM_ITERATIONS
+        int num_threads = 1;                 // accepted, unused: the device decides its own parallelism
+        bool jacobi_scaling = false;         // the reference sets 0 everywhere it matters (R/swf/swf.cpp:27); true is refused
         double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16;
-        std::shared_ptr<ParameterBlockOrdering> linear_solver_ordering;
+        std::shared_ptr<ParameterBlockOrdering> linear_solver_ordering;      // null: automatic ordering (swf_set_ordering, n = 0)
     };
     struct Summary {
         double initial_cost = 0, final_cost = 0, minimizer_time_in_seconds = 0;
         int num_successful_steps = 0, num_unsuccessful_steps = 0, termination = 0;
+        std::string message;                 // swf_last_error() of a failed Solve, empty otherwise
         swf_summary raw;
         std::string BriefReport() const {
             char b[256];
             snprintf(b, sizeof b, "swf (MI355X) Report: Iterations: %d, Initial cost: %e, Final cost: %e, Termination: %d",
                      raw.num_iterations, initial_cost, final_cost, termination);
-            return b;
+            return message.empty() ? std::string(b) : std::string(b) + " [" + message + "]";
         }
     };
 };
 
-// ceres::Solve(options, &problem, &summary) — R/swf/swf_image.cpp:219
+// ceres::Solve(options, &problem, &summary) — R/swf/swf_image.cpp:219.  Ceres reports failures through the summary, never by
+// throwing, and the estimator only tests summary.final_cost > 1e10: a failed solve therefore sets final_cost = 1e300, keeps the
+// reason in summary.message, prints it to stderr and clears the exports (UpdateSchur must not read a previous solve's buffers).
 inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* s) {
     swf_options opt; swf_options_default(&opt);
     opt.max_num_iterations = o.max_num_iterations;
     opt.initial_trust_region_radius = o.initial_trust_region_radius;
     opt.max_trust_region_radius = o.max_trust_region_radius;
     opt.step_mode = internal::is_optimize ? SWF_OPTIMIZE : SWF_ASSEMBLE_ELIMINATE_ONLY;
-    if (o.linear_solver_ordering)
-        swf_set_ordering(p->handle(), o.linear_solver_ordering->keys_.data(), o.linear_solver_ordering->groups_.data(), o.linear_solver_ordering->NumElements());
-    swf_set_export_tail(p->handle(), internal::parameter_head.data(), (int32_t)internal::parameter_head.size());
+    opt.trust_region_strategy = o.trust_region_strategy_type == DOGLEG ? SWF_DOGLEG : SWF_LEVENBERG_MARQUARDT;
     std::memset(&s->raw, 0, sizeof(s->raw));
-    int rc = swf_problem_solve(p->handle(), &opt, &s->raw);
+    s->message.clear();
+    int rc = SWF_OK;
+    if (o.jacobi_scaling) { rc = SWF_E_UNSUPPORTED; s->message = "jacobi_scaling = true is not implemented (the reference sets it to false)"; }
+    if (rc == SWF_OK) rc = p->SyncIsUse();
+    if (rc == SWF_OK) {
+        const ParameterBlockOrdering* ord = o.linear_solver_ordering.get();
+        rc = swf_set_ordering(p->handle(), ord ? ord->keys_.data() : nullptr, ord ? ord->groups_.data() : nullptr, ord ? ord->NumElements() : 0);
+    }
+    if (rc == SWF_OK) rc = swf_set_export_tail(p->handle(), internal::parameter_head.data(), (int32_t)internal::parameter_head.size());
+    if (rc == SWF_OK) rc = swf_problem_solve(p->handle(), &opt, &s->raw);
+    internal::Exports& e = internal::exports();
+    if (rc == SWF_OK) {
+        e = internal::Exports();
+        if (swf_get_reduced(p->handle(), &e.lhs_out, &e.rhs_out, &e.lhs_out2, &e.hs_row) == SWF_OK) e.owner = p; else e = internal::Exports();
+    } else {
+        if (s->message.empty()) s->message = swf_last_error();
+        std::fprintf(stderr, "swf_ceres::Solve failed (%d): %s\n", rc, s->message.c_str());
+        e = internal::Exports();
+    }
     s->initial_cost = s->raw.initial_cost; s->final_cost = rc == SWF_OK ? s->raw.final_cost : 1e300;   // callers test final_cost > 1e10
     s->minimizer_time_in_seconds = s->raw.minimizer_time_in_seconds;
     s->num_successful_steps = s->raw.num_successful_steps; s->num_unsuccessful_steps = s->raw.num_unsuccessful_steps;
     s->termination = s->raw.termination;
-    internal::Exports& e = internal::exports();
-    if (rc == SWF_OK) swf_get_reduced(p->handle(), &e.lhs_out, &e.rhs_out, &e.lhs_out2, &e.hs_row);
 }
 
 // The marginalisation consumer in one call: what SWFOptimization::UpdateSchur (R/swf/swf_gnss.cpp:25-61) followed by

@@ -238,8 +238,10 @@ enum { SWF_MANIFOLD_NONE = 0, SWF_MANIFOLD_POSE = 1 };   /* PoseLocalParameteriz
 int swf_problem_create(swf_problem** out);                      /* ceres::Problem()            */
 int swf_problem_destroy(swf_problem* p);
 
-/* ceres::Problem::AddParameterBlock(ptr, size, LocalParameterization*).  size in {7,9,3,1};
- * calling it on an existing block only (re)attaches the manifold (R/swf/swf_core.cpp:53-56). */
+/* ceres::Problem::AddParameterBlock(ptr, size, LocalParameterization*).  size in {7,9,3,1}.  The manifold is fixed by the
+ * size — a 7-block is a pose on PoseLocalParameterization whether or not `manifold` says so, everything else is Euclidean —
+ * so calling it on an existing block to (re)attach the parameterization (R/swf/swf_core.cpp:53-56) is accepted and changes
+ * nothing. */
 int swf_add_parameter_block(swf_problem* p, double* key, int32_t size, int32_t manifold);
 int swf_has_parameter_block(swf_problem* p, const double* key);           /* 1 / 0             */
 int swf_remove_parameter_block(swf_problem* p, double* key);    /* cascades to its factors     */
@@ -296,12 +298,27 @@ swf_factor_id swf_add_linear_prior(swf_problem* p, double* const* keys, int32_t 
                                    const double* J, const double* r0, const double* x0);
 int swf_remove_factor(swf_problem* p, swf_factor_id id);                  /* RemoveResidualBlock */
 int swf_factor_set_enabled(swf_problem* p, swf_factor_id id, int32_t on); /* ResidualBlock::is_use */
+int swf_factor_is_enabled(swf_problem* p, swf_factor_id id);              /* 1 / 0; SWF_E_NOTFOUND */
+
+/* The query surface of ceres::Problem the estimator walks when it marginalises through the solver (GlobalMarge,
+ * R/swf/swf_image.cpp:350-367), re-attaches landmark blocks (R/swf/swf.cpp:413-422, R/feature/feature_manager.cpp:456-461)
+ * and finds the dummy anchor's block (R/swf/swf_gnss.cpp:651).  Each getter writes the total count to *n and fills at most
+ * `cap` entries (call with cap = 0 to size the buffer).  Residual blocks are reported in creation order, parameter blocks in
+ * insertion order, the blocks of a residual block in the order of its AddResidualBlock call.
+ *   Problem::GetResidualBlocks / GetResidualBlocksForParameterBlock / GetParameterBlocks / GetParameterBlocksForResidualBlock */
+int swf_get_residual_blocks(swf_problem* p, swf_factor_id* ids, int32_t cap, int32_t* n);
+int swf_get_residual_blocks_for_parameter_block(swf_problem* p, const double* key, swf_factor_id* ids, int32_t cap, int32_t* n);
+int swf_get_parameter_blocks(swf_problem* p, double** keys, int32_t cap, int32_t* n);
+int swf_get_parameter_blocks_for_residual_block(swf_problem* p, swf_factor_id id, double** keys, int32_t cap, int32_t* n);
 
 /* window constants the factors read from globals in the reference (Pbg, Rwgw*G, base_xyz) */
 int swf_set_constants(swf_problem* p, const double pbg[3], const double gw[3], const double base[3]);
 
 /* options.linear_solver_ordering: ParameterBlockOrdering::AddElementToGroup() per entry
- * (R/swf/swf_gnss.cpp:629-783).  Replaces any previous ordering. */
+ * (R/swf/swf_gnss.cpp:629-783).  Replaces any previous ordering; setting the ordering it already has is free (no structure
+ * change).  n = 0 (= a null linear_solver_ordering, the default Solver::Options of R/swf/swf_gnss.cpp:200-216, 562-572) asks
+ * for an automatic ordering: every landmark and a greedy independent set of scalars in group 0, one group per remaining
+ * variable block in insertion order, the export tail last. */
 int swf_set_ordering(swf_problem* p, double* const* keys, const int32_t* groups, int32_t n);
 /* ceres::internal::parameter_head: blocks ordered last and exported (R/swf/swf_gnss.cpp:116) */
 int swf_set_export_tail(swf_problem* p, double* const* keys, int32_t n);

@@ -179,7 +179,8 @@ typedef struct swf_options {
     int32_t max_num_iterations;          /* yaml MAX_NUM_ITERATIONS = 8 */
     int32_t step_mode;                   /* SWF_OPTIMIZE / SWF_ASSEMBLE_ELIMINATE_ONLY (= is_optimize) */
     int32_t num_threads;                 /* CPU oracle only */
-    int32_t reserved;
+    int32_t trust_region_strategy;       /* SWF_DOGLEG (what R/swf/swf.cpp:26 sets) / SWF_LEVENBERG_MARQUARDT (the ceres default the
+                                            Solver::Options of R/swf/swf_gnss.cpp:200-216, 562-572 run with) */
     double initial_trust_region_radius;  /* 1e4 */
     double max_trust_region_radius;      /* 1e16 */
     double min_trust_region_radius;      /* 1e-32 */
@@ -192,6 +193,7 @@ typedef struct swf_options {
 } swf_options;
 
 enum { SWF_OPTIMIZE = 0, SWF_ASSEMBLE_ELIMINATE_ONLY = 1 };
+enum { SWF_DOGLEG = 0, SWF_LEVENBERG_MARQUARDT = 1 };
 
 /* termination codes */
 enum {
@@ -239,7 +241,7 @@ static inline void swf_options_default(swf_options* o) {
     o->max_num_iterations = 8;
     o->step_mode = SWF_OPTIMIZE;
     o->num_threads = 1;
-    o->reserved = 0;
+    o->trust_region_strategy = SWF_DOGLEG;
     o->initial_trust_region_radius = 1e4;
     o->max_trust_region_radius = 1e16;
     o->min_trust_region_radius = 1e-32;

@@ -1407,6 +1407,8 @@ int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* 
     }
 
     double radius = opt->initial_trust_region_radius, mu = opt->min_mu;
+    const int lm = opt->trust_region_strategy == SWF_LEVENBERG_MARQUARDT;
+    double lm_decrease = 2.0;        /* LevenbergMarquardtStrategy::decrease_factor_ */
     int reuse = 0, invalid_run = 0;
     double alpha = 0, dogleg_step_norm = 0;
     sum->termination = SWF_RUNNING;
@@ -1422,6 +1424,24 @@ int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* 
 
         /* DoglegStrategy::ComputeStep */
         int lin_ok = 1;
+        if (lm) {
+            /* LevenbergMarquardtStrategy::ComputeStep (public ceres 2.x): lm_diagonal = sqrt(clamp(diag(J^T J)) / radius), the
+             * step minimises |J d + r|^2 + |lm_diagonal d|^2, i.e. (J^T J + D^2 / radius) d = -g.  A failed factorisation is an
+             * invalid step: StepIsInvalid = StepRejected(0). */
+            for (int i = 0; i < n; i++) {
+                double d = c->diag[i];
+                d = d < opt->min_diagonal ? opt->min_diagonal : d; d = d > opt->max_diagonal ? opt->max_diagonal : d;
+                dclamp[i] = d;
+            }
+            if (linear_solve(c, dclamp, 1.0 / radius, c->gn) != 0) {
+                rec->step_is_valid = 0; rec->cost = x_cost;
+                if (++invalid_run >= 5) { rec->trust_region_radius = radius; sum->termination = SWF_LINEAR_SOLVER_FAILURE; break; }
+                radius /= lm_decrease; lm_decrease *= 2.0;
+                rec->trust_region_radius = radius;
+                continue;
+            }
+            for (int i = 0; i < n; i++) c->step[i] = -c->gn[i];
+        } else
         if (!reuse) {
             for (int i = 0; i < n; i++) {
                 double d = c->diag[i];
@@ -1450,7 +1470,7 @@ int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* 
             continue;
         }
         /* ComputeTraditionalDoglegStep */
-        {
+        if (!lm) {
             double gnorm = 0, gnn = 0, gdot = 0;
             for (int i = 0; i < n; i++) { gnorm += c->grad_s[i] * c->grad_s[i]; gnn += c->gn[i] * c->gn[i]; gdot += c->grad_s[i] * c->gn[i]; }
             gnorm = sqrt(gnorm); gnn = sqrt(gnn);
@@ -1476,7 +1496,8 @@ int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* 
         if (!(model_cost_change > 0.0)) {
             rec->step_is_valid = 0; rec->cost = x_cost; rec->trust_region_radius = radius;
             if (++invalid_run >= 5) { sum->termination = SWF_LINEAR_SOLVER_FAILURE; break; }
-            mu *= opt->mu_increase_factor; reuse = 0;
+            if (lm) { radius /= lm_decrease; lm_decrease *= 2.0; rec->trust_region_radius = radius; }
+            else { mu *= opt->mu_increase_factor; reuse = 0; }
             continue;
         }
         rec->step_is_valid = 1; invalid_run = 0;
@@ -1508,15 +1529,24 @@ int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* 
             gmax = var_maxnorm_diff(c, c->x, xt);
             rec->step_is_successful = 1; rec->cost = x_cost; rec->gradient_max_norm = gmax;
             sum->num_successful_steps++;
+            if (lm) {
+                /* LevenbergMarquardtStrategy::StepAccepted */
+                double q = 2.0 * rec->relative_decrease - 1.0, f = 1.0 - q * q * q;
+                radius = radius / (f > 1.0 / 3.0 ? f : 1.0 / 3.0);
+                radius = radius < opt->max_trust_region_radius ? radius : opt->max_trust_region_radius;
+                lm_decrease = 2.0;
+            } else {
             /* DoglegStrategy::StepAccepted */
             if (rec->relative_decrease < 0.25) radius *= 0.5;
             if (rec->relative_decrease > 0.75) radius = radius > 3.0 * dogleg_step_norm ? radius : 3.0 * dogleg_step_norm;
             mu = opt->min_mu > 2.0 * mu / opt->mu_increase_factor ? opt->min_mu : 2.0 * mu / opt->mu_increase_factor;
             reuse = 0;
+            }
         } else {
             rec->step_is_successful = 0; rec->cost = x_cost;
             sum->num_unsuccessful_steps++;
-            radius *= 0.5; reuse = 1;         /* StepRejected */
+            if (lm) { radius /= lm_decrease; lm_decrease *= 2.0; }      /* LevenbergMarquardtStrategy::StepRejected */
+            else { radius *= 0.5; reuse = 1; }         /* StepRejected */
         }
         rec->trust_region_radius = radius;
     }

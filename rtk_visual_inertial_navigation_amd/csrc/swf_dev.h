@@ -36,6 +36,7 @@ struct WinRec {
 struct WinState {
     double radius, mu, x_cost, x_norm, alpha, dogleg_step_norm, step_norm, gmax;
     double jg_sq, initial_cost;
+    double lm_dec;               // LevenbergMarquardtStrategy::decrease_factor_ (SWF_LEVENBERG_MARQUARDT only)
     int status, iter, need_lin, reuse, eval_cand, lin_fail, invalid_run, nsucc, nunsucc, pad;
 };
 

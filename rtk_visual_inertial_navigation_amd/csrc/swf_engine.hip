@@ -906,7 +906,7 @@ extern "C" int swf_batch_reset_state(swf_batch* b) {
 
 static DevOpt to_devopt(const swf_options* o) {
     DevOpt d{};
-    d.max_iter = o->max_num_iterations; d.step_mode = o->step_mode;
+    d.max_iter = o->max_num_iterations; d.step_mode = o->step_mode; d.strategy = o->trust_region_strategy;
     d.r0 = o->initial_trust_region_radius; d.max_r = o->max_trust_region_radius; d.min_r = o->min_trust_region_radius;
     d.min_rel_dec = o->min_relative_decrease; d.ftol = o->function_tolerance; d.gtol = o->gradient_tolerance;
     d.ptol = o->parameter_tolerance; d.min_mu = o->min_mu; d.max_mu = o->max_mu; d.mu_inc = o->mu_increase_factor;
@@ -1077,6 +1077,7 @@ struct Launcher {
 extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
     if (!b || !opt) return fail(SWF_E_INVALID, "swf_batch_solve: bad arguments");
     if (opt->max_num_iterations < 0 || opt->max_num_iterations >= SWF_MAX_TRACE) return fail(SWF_E_INVALID, "max_num_iterations out of range");
+    if (opt->trust_region_strategy != SWF_DOGLEG && opt->trust_region_strategy != SWF_LEVENBERG_MARQUARDT) return fail(SWF_E_INVALID, "unknown trust_region_strategy");
     DevBatch& D = b->D;
     Launcher L{ b, to_devopt(opt), b->stream };
     hipStream_t st = b->stream;

@@ -20,7 +20,7 @@
 #include "swf_dev.h"
 
 struct DevOpt {
-    int max_iter, step_mode;
+    int max_iter, step_mode, strategy, pad;      // strategy: SWF_DOGLEG / SWF_LEVENBERG_MARQUARDT
     double r0, max_r, min_r, min_rel_dec, ftol, gtol, ptol, min_mu, max_mu, mu_inc, min_diag, max_diag;
 };
 

@@ -1224,7 +1224,9 @@ __global__ void __launch_bounds__(256) k_init(DevBatch B, DevOpt O) {
         ((double*)(B.trace + (size_t)w * B.max_iter_trace))[k] = 0.0;
     if (threadIdx.x == 0) {
         WinState& s = B.ws[w];
-        s.radius = O.r0; s.mu = (O.step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) ? 0.0 : O.min_mu;
+        // Levenberg-Marquardt: the damping of the linear solve is D^2 / radius, i.e. mu = 1 / radius on the clamped diagonal
+        s.radius = O.r0; s.mu = (O.step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) ? 0.0 : (O.strategy == SWF_LEVENBERG_MARQUARDT ? 1.0 / O.r0 : O.min_mu);
+        s.lm_dec = 2.0;
         s.x_cost = 0; s.x_norm = xn; s.alpha = 0; s.dogleg_step_norm = 0; s.step_norm = 0; s.gmax = 0;
         s.jg_sq = 0; s.initial_cost = 0;
         s.status = SWF_RUNNING; s.iter = 0; s.need_lin = 1; s.reuse = 0; s.eval_cand = 0; s.lin_fail = 0;
@@ -1300,8 +1302,15 @@ __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
                 // Gauss-Newton solve failed: DoglegStrategy raises mu; HandleInvalidStep
                 rec.step_is_valid = 0; rec.cost = s.x_cost; rec.trust_region_radius = s.radius;
                 s.lin_fail = 0; s.eval_cand = 0;
-                s.mu *= O.mu_inc; s.reuse = 0; s.need_lin = 1;
-                if (++s.invalid_run >= 5 || s.mu >= O.max_mu) s.status = SWF_LINEAR_SOLVER_FAILURE;
+                s.reuse = 0; s.need_lin = 1;
+                if (O.strategy == SWF_LEVENBERG_MARQUARDT) {
+                    // LevenbergMarquardtStrategy::StepIsInvalid = StepRejected(0)
+                    if (++s.invalid_run >= 5) s.status = SWF_LINEAR_SOLVER_FAILURE;
+                    else { s.radius /= s.lm_dec; s.lm_dec *= 2.0; s.mu = 1.0 / s.radius; rec.trust_region_radius = s.radius; }
+                } else {
+                    s.mu *= O.mu_inc;
+                    if (++s.invalid_run >= 5 || s.mu >= O.max_mu) s.status = SWF_LINEAR_SOLVER_FAILURE;
+                }
             } else {
                 if (!s.reuse) s.alpha = gsq / jg_sq;
                 s.reuse = 1;
@@ -1316,7 +1325,8 @@ __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
     double gnorm = sqrt(gsq), gnn = sqrt(ynn), alpha = s.alpha, radius = s.radius;
     int mode; double c1 = 0, c2 = 0;          // step = c1 * g / dclamp + c2 * y
     double dnorm;
-    if (gnn <= radius) { mode = 0; c1 = 0; c2 = -1.0; dnorm = gnn; }
+    if (O.strategy == SWF_LEVENBERG_MARQUARDT) { mode = 0; c1 = 0; c2 = -1.0; dnorm = gnn; }      // the damped step itself
+    else if (gnn <= radius) { mode = 0; c1 = 0; c2 = -1.0; dnorm = gnn; }
     else if (gnorm * alpha >= radius) { mode = 1; c1 = -(radius / gnorm); c2 = 0; dnorm = radius; }
     else {
         double b_dot_a = -alpha * gdot;
@@ -1385,8 +1395,10 @@ __global__ void __launch_bounds__(256) k_decide(DevBatch B, DevOpt O) {
         rec.model_cost_change = model_cost_change;
         if (!(model_cost_change > 0.0)) {
             rec.step_is_valid = 0; rec.cost = s.x_cost; rec.trust_region_radius = s.radius;
-            s.mu *= O.mu_inc; s.reuse = 0; s.need_lin = 1;
+            s.reuse = 0; s.need_lin = 1;
             if (++s.invalid_run >= 5) s.status = SWF_LINEAR_SOLVER_FAILURE;
+            else if (O.strategy == SWF_LEVENBERG_MARQUARDT) { s.radius /= s.lm_dec; s.lm_dec *= 2.0; s.mu = 1.0 / s.radius; rec.trust_region_radius = s.radius; }
+            else s.mu *= O.mu_inc;
         } else {
             rec.step_is_valid = 1; s.invalid_run = 0;
             rec.step_norm = s.step_norm;
@@ -1400,14 +1412,26 @@ __global__ void __launch_bounds__(256) k_decide(DevBatch B, DevOpt O) {
                 if (rec.relative_decrease > O.min_rel_dec) {
                     accept = 1;
                     rec.step_is_successful = 1; rec.cost = cand; s.x_cost = cand; s.nsucc++;
-                    if (rec.relative_decrease < 0.25) s.radius *= 0.5;
-                    if (rec.relative_decrease > 0.75) s.radius = s.radius > 3.0 * s.dogleg_step_norm ? s.radius : 3.0 * s.dogleg_step_norm;
-                    double m2 = 2.0 * s.mu / O.mu_inc;
-                    s.mu = O.min_mu > m2 ? O.min_mu : m2;
+                    if (O.strategy == SWF_LEVENBERG_MARQUARDT) {
+                        // LevenbergMarquardtStrategy::StepAccepted
+                        double q = 2.0 * rec.relative_decrease - 1.0, f = 1.0 - q * q * q;
+                        s.radius = s.radius / (f > 1.0 / 3.0 ? f : 1.0 / 3.0);
+                        s.radius = s.radius < O.max_r ? s.radius : O.max_r;
+                        s.lm_dec = 2.0; s.mu = 1.0 / s.radius;
+                    } else {
+                        if (rec.relative_decrease < 0.25) s.radius *= 0.5;
+                        if (rec.relative_decrease > 0.75) s.radius = s.radius > 3.0 * s.dogleg_step_norm ? s.radius : 3.0 * s.dogleg_step_norm;
+                        double m2 = 2.0 * s.mu / O.mu_inc;
+                        s.mu = O.min_mu > m2 ? O.min_mu : m2;
+                    }
                     s.reuse = 0; s.need_lin = 1;
                 } else {
                     rec.step_is_successful = 0; rec.cost = s.x_cost; s.nunsucc++;
-                    s.radius *= 0.5; s.reuse = 1;
+                    if (O.strategy == SWF_LEVENBERG_MARQUARDT) {
+                        // LevenbergMarquardtStrategy::StepRejected: the same Jacobian is damped harder — the window re-linearises at
+                        // the unchanged point (bit-identical Jacobians) so that the assembly picks up the new mu
+                        s.radius /= s.lm_dec; s.lm_dec *= 2.0; s.mu = 1.0 / s.radius; s.reuse = 0; s.need_lin = 1;
+                    } else { s.radius *= 0.5; s.reuse = 1; }
                 }
                 rec.trust_region_radius = s.radius;
             }

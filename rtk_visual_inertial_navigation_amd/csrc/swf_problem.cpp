@@ -18,7 +18,7 @@
 #include "../../include/swf_solver.h"
 
 namespace {
-struct PBlock { int size; int manifold; bool constant; long seq; };
+struct PBlock { int size; bool constant; long seq; };
 enum FType { FT_PROJ, FT_IMU, FT_CP, FT_PR, FT_DOP, FT_SP, FT_PRIOR, FT_SPR, FT_SCP, FT_FIX, FT_COMP, FT_IDP };
 struct PFactor {
     FType type; bool alive, enabled;
@@ -80,10 +80,11 @@ int swf_add_parameter_block(swf_problem* p, double* key, int32_t size, int32_t m
     auto it = p->blocks.find(key);
     if (it != p->blocks.end()) {
         if (it->second.size != size) return pfail(SWF_E_INVALID, "parameter block re-added with a different size");
-        it->second.manifold = manifold;
-        return SWF_OK;
+        return SWF_OK;          // re-attaching the parameterization (R/swf/swf_core.cpp:53-56) changes nothing: see below
     }
-    p->blocks[key] = PBlock{ size, manifold, false, p->seq++ };
+    // the kernels fix the manifold by size: a 7-block is [p, q] on PoseLocalParameterization, everything else is Euclidean
+    if (manifold == SWF_MANIFOLD_POSE && size != 7) return pfail(SWF_E_UNSUPPORTED, "SWF_MANIFOLD_POSE on a block that is not 7-dimensional");
+    p->blocks[key] = PBlock{ size, false, p->seq++ };
     p->dirty = true;
     return SWF_OK;
 }
@@ -234,21 +235,72 @@ int swf_factor_set_enabled(swf_problem* p, swf_factor_id id, int32_t on) {
     if (p->factors[id].enabled != b) { p->factors[id].enabled = b; p->dirty = true; }
     return SWF_OK;
 }
+int swf_factor_is_enabled(swf_problem* p, swf_factor_id id) {
+    if (!p || id < 0 || id >= (int)p->factors.size() || !p->factors[id].alive) return SWF_E_NOTFOUND;
+    return p->factors[id].enabled ? 1 : 0;
+}
+// ---- the query surface of ceres::Problem: every getter reports the full count in *n and fills at most cap
+// entries, so a caller may size its buffer with a first call (cap = 0)
+int swf_get_residual_blocks(swf_problem* p, swf_factor_id* ids, int32_t cap, int32_t* n) {
+    if (!p || !n || (cap > 0 && !ids)) return SWF_E_INVALID;
+    int c = 0;
+    for (size_t i = 0; i < p->factors.size(); i++) if (p->factors[i].alive) { if (c < cap) ids[c] = (swf_factor_id)i; c++; }
+    *n = c;
+    return SWF_OK;
+}
+int swf_get_residual_blocks_for_parameter_block(swf_problem* p, const double* key, swf_factor_id* ids, int32_t cap, int32_t* n) {
+    if (!p || !n || (cap > 0 && !ids)) return SWF_E_INVALID;
+    if (!p->blocks.count((double*)key)) return pfail(SWF_E_NOTFOUND, "GetResidualBlocksForParameterBlock: unknown parameter block");
+    int c = 0;
+    for (size_t i = 0; i < p->factors.size(); i++) {
+        const PFactor& f = p->factors[i];
+        if (!f.alive || std::find(f.keys.begin(), f.keys.end(), (double*)key) == f.keys.end()) continue;
+        if (c < cap) ids[c] = (swf_factor_id)i;
+        c++;
+    }
+    *n = c;
+    return SWF_OK;
+}
+int swf_get_parameter_blocks(swf_problem* p, double** keys, int32_t cap, int32_t* n) {
+    if (!p || !n || (cap > 0 && !keys)) return SWF_E_INVALID;
+    std::map<long, double*> by_seq;                   // insertion order, as ceres::Problem::GetParameterBlocks reports it
+    for (auto& kv : p->blocks) by_seq[kv.second.seq] = kv.first;
+    int c = 0;
+    for (auto& kv : by_seq) { if (c < cap) keys[c] = kv.second; c++; }
+    *n = c;
+    return SWF_OK;
+}
+int swf_get_parameter_blocks_for_residual_block(swf_problem* p, swf_factor_id id, double** keys, int32_t cap, int32_t* n) {
+    if (!p || !n || (cap > 0 && !keys)) return SWF_E_INVALID;
+    if (id < 0 || id >= (int)p->factors.size() || !p->factors[id].alive) return pfail(SWF_E_NOTFOUND, "GetParameterBlocksForResidualBlock: unknown residual block");
+    const PFactor& f = p->factors[id];
+    for (int i = 0; i < (int)f.keys.size() && i < cap; i++) keys[i] = f.keys[i];
+    *n = (int32_t)f.keys.size();
+    return SWF_OK;
+}
 int swf_set_constants(swf_problem* p, const double pbg[3], const double gw[3], const double base[3]) {
     if (!p) return SWF_E_INVALID;
-    for (int k = 0; k < 3; k++) { if (pbg) p->pbg[k] = pbg[k]; if (gw) p->gw[k] = gw[k]; if (base) p->base[k] = base[k]; }
-    p->dirty = true;
+    for (int k = 0; k < 3; k++) {
+        if (pbg && p->pbg[k] != pbg[k]) { p->pbg[k] = pbg[k]; p->dirty = true; }
+        if (gw && p->gw[k] != gw[k]) { p->gw[k] = gw[k]; p->dirty = true; }
+        if (base && p->base[k] != base[k]) { p->base[k] = base[k]; p->dirty = true; }
+    }
     return SWF_OK;
 }
 int swf_set_ordering(swf_problem* p, double* const* keys, const int32_t* groups, int32_t n) {
     if (!p || (n > 0 && (!keys || !groups))) return SWF_E_INVALID;
-    p->order_keys.assign(keys, keys + n); p->order_groups.assign(groups, groups + n);
+    // ceres::Solve through the adapter sets the ordering before every solve: only a CHANGE is a structure change
+    if ((int32_t)p->order_keys.size() == n && (n == 0 || (std::equal(keys, keys + n, p->order_keys.begin()) && std::equal(groups, groups + n, p->order_groups.begin()))))
+        return SWF_OK;
+    if (n > 0) { p->order_keys.assign(keys, keys + n); p->order_groups.assign(groups, groups + n); }
+    else { p->order_keys.clear(); p->order_groups.clear(); }
     p->dirty = true;
     return SWF_OK;
 }
 int swf_set_export_tail(swf_problem* p, double* const* keys, int32_t n) {
     if (!p || (n > 0 && !keys)) return SWF_E_INVALID;
-    p->tail_keys.assign(keys, keys + n);
+    if ((int32_t)p->tail_keys.size() == n && (n == 0 || std::equal(keys, keys + n, p->tail_keys.begin()))) return SWF_OK;
+    if (n > 0) p->tail_keys.assign(keys, keys + n); else p->tail_keys.clear();
     p->dirty = true;
     return SWF_OK;
 }
@@ -274,10 +326,50 @@ static int flatten(swf_problem* p) {
     // ordering: keep the caller's (group, position) for used variable blocks; the tail is whatever
     // the caller listed in parameter_head, expected at the end of the ordering
     p->order_block.clear(); p->order_group.clear();
-    for (size_t i = 0; i < p->order_keys.size(); i++) {
-        auto it = bid.find(p->order_keys[i]);
+    std::vector<double*> auto_keys; std::vector<int> auto_groups;
+    const bool automatic = p->order_keys.empty();
+    if (automatic) {
+        // options.linear_solver_ordering == nullptr (the default-constructed Solver::Options of GnssPreprocess / GnssProcess,
+        // R/swf/swf_gnss.cpp:200-216, 562-572): ceres then picks an independent set itself.  Here: group 0 = every landmark and,
+        // greedily in insertion order, every scalar that shares no factor with a block already in group 0 (and whose clique
+        // stays within the one-wavefront limits); every other variable block gets a group of its own, parameter_head last.
+        std::unordered_map<double*, std::vector<const PFactor*>> touch;
+        for (auto& f : p->factors) if (f.alive && f.enabled) for (double* k : f.keys) touch[k].push_back(&f);
+        std::unordered_map<double*, char> in0;
+        auto variable = [&](double* k) { return !p->blocks[k].constant; };
+        for (double* k : p->klm) if (variable(k)) {
+            bool ok = true;
+            for (const PFactor* f : touch[k]) if (f->type != FT_PROJ) ok = false;
+            if (ok) { in0[k] = 1; auto_keys.push_back(k); auto_groups.push_back(0); }
+        }
+        for (double* k : p->ksc) if (variable(k)) {
+            bool ok = true; int rows = 0, cols = 1;
+            std::vector<double*> nb;
+            for (const PFactor* f : touch[k]) {
+                if (f->type == FT_PRIOR || f->type == FT_COMP) { ok = false; break; }
+                rows += f->type == FT_IDP ? 2 : 1;
+                for (double* q : f->keys) if (q != k && variable(q)) {
+                    if (in0.count(q)) ok = false;
+                    if (std::find(nb.begin(), nb.end(), q) == nb.end()) { nb.push_back(q); int sz = p->blocks[q].size; cols += sz == 7 ? 6 : sz; }
+                }
+            }
+            if (ok && rows <= 48 && cols <= 32) { in0[k] = 1; auto_keys.push_back(k); auto_groups.push_back(0); }
+        }
+        int g = 1;
+        auto is_tail = [&](double* k) { return std::find(p->tail_keys.begin(), p->tail_keys.end(), k) != p->tail_keys.end(); };
+        for (int pass = 0; pass < 2; pass++)
+            for (auto& kv : used) {
+                double* k = kv.second;
+                if (!variable(k) || in0.count(k) || (is_tail(k) != (pass == 1))) continue;
+                auto_keys.push_back(k); auto_groups.push_back(g++);
+            }
+    }
+    const std::vector<double*>& okeys = automatic ? auto_keys : p->order_keys;
+    const std::vector<int>& ogroups = automatic ? auto_groups : p->order_groups;
+    for (size_t i = 0; i < okeys.size(); i++) {
+        auto it = bid.find(okeys[i]);
         if (it == bid.end() || p->is_const[it->second]) continue;
-        p->order_block.push_back(it->second); p->order_group.push_back(p->order_groups[i]);
+        p->order_block.push_back(it->second); p->order_group.push_back(ogroups[i]);
     }
     int n_tail = 0;
     for (int i = (int)p->order_block.size() - 1; i >= 0; i--) {

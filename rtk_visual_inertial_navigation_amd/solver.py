@@ -48,6 +48,8 @@ EXPORTED = [
     "swf_batch_tail_covariance", "swf_batch_get_tail_covariance", "swf_problem_tail_covariance",
     "swf_composite_create", "swf_composite_evaluate", "swf_composite_hidden", "swf_composite_destroy", "swf_add_imu_gnss",
     "swf_eval_inverse_depth_batch", "swf_add_projection_inverse_depth",
+    "swf_factor_is_enabled", "swf_get_residual_blocks", "swf_get_residual_blocks_for_parameter_block",
+    "swf_get_parameter_blocks", "swf_get_parameter_blocks_for_residual_block",
 ]
 
 
@@ -263,6 +265,39 @@ class Problem:
     def SetResidualBlockUsed(self, fid, on):          # ResidualBlock::is_use of the modified Ceres
         _chk(lib().swf_factor_set_enabled(self._h, C.c_int32(fid), C.c_int32(1 if on else 0)), "is_use")
 
+    def IsResidualBlockUsed(self, fid):
+        rc = lib().swf_factor_is_enabled(self._h, C.c_int32(fid))
+        if rc < 0:
+            raise SwfError("is_use: unknown residual block %d" % fid)
+        return bool(rc)
+
+    # --- the query surface (GlobalMarge, R/swf/swf_image.cpp:350-367)
+    def _ids(self, fn, what, *head):
+        n = C.c_int32(0)
+        _chk(fn(self._h, *head, None, C.c_int32(0), C.byref(n)), what)
+        buf = (C.c_int32 * max(1, n.value))()
+        _chk(fn(self._h, *head, buf, C.c_int32(n.value), C.byref(n)), what)
+        return [int(buf[i]) for i in range(n.value)]
+
+    def _blocks(self, fn, what, *head):
+        n = C.c_int32(0)
+        _chk(fn(self._h, *head, None, C.c_int32(0), C.byref(n)), what)
+        buf = (_pd * max(1, n.value))()
+        _chk(fn(self._h, *head, buf, C.c_int32(n.value), C.byref(n)), what)
+        return [self._keep[C.cast(buf[i], C.c_void_p).value] for i in range(n.value)]
+
+    def GetResidualBlocks(self):
+        return self._ids(lib().swf_get_residual_blocks, "GetResidualBlocks")
+
+    def GetResidualBlocksForParameterBlock(self, arr):
+        return self._ids(lib().swf_get_residual_blocks_for_parameter_block, "GetResidualBlocksForParameterBlock", arr.ctypes.data_as(_pd))
+
+    def GetParameterBlocks(self):
+        return self._blocks(lib().swf_get_parameter_blocks, "GetParameterBlocks")
+
+    def GetParameterBlocksForResidualBlock(self, fid):
+        return self._blocks(lib().swf_get_parameter_blocks_for_residual_block, "GetParameterBlocksForResidualBlock", C.c_int32(fid))
+
     # --- typed AddResidualBlock()s
     def _fid(self, rc, what):
         if rc < 0:
@@ -331,7 +366,8 @@ class Problem:
         _chk(lib().swf_set_constants(self._h, pa, pb, pc), "SetConstants")
 
     def SetOrdering(self, blocks, groups):
-        keys = (_pd * len(blocks))(*[b.ctypes.data_as(_pd) for b in blocks])
+        """blocks = [] asks for the automatic ordering (a null linear_solver_ordering)."""
+        keys = (_pd * max(1, len(blocks)))(*[b.ctypes.data_as(_pd) for b in blocks])
         g = np.ascontiguousarray(groups, dtype=np.int32)
         _chk(lib().swf_set_ordering(self._h, keys, g.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(len(blocks))), "SetOrdering")
 

@@ -133,3 +133,38 @@ def test_problem_bookkeeping_without_gpu():
     with pytest.raises(solver.SwfError):
         P.AddProjection(blocks[w.bid_sb(0)], ex, blocks[w.bid_lm(0)], [0.0, 0.0])   # a 9-block where a pose is expected
     P.close()
+
+
+def test_problem_query_surface_without_gpu():
+    """GetResidualBlocks / GetResidualBlocksForParameterBlock / GetParameterBlocks / GetParameterBlocksForResidualBlock and the
+    is_use flag, as GlobalMarge walks them (R/swf/swf_image.cpp:350-367): creation / insertion order, removed blocks disappear,
+    RemoveParameterBlock cascades."""
+    w = synth.make_window(3, K=4, F=6, S=2, seed=2)
+    P, blocks = solver.problem_from_window(w)
+    ids = P.GetResidualBlocks()
+    assert ids == sorted(ids) and len(ids) == P.NumResidualBlocks()
+    pb = P.GetParameterBlocks()
+    assert len(pb) == P.NumParameterBlocks() == w.n_blocks
+    assert all(any(q is b for q in blocks) for b in pb)
+    # the first residual block is the first projection factor: pose, extrinsic, landmark in AddResidualBlock order
+    p_, e_, l_ = w.a["proj_idx"].reshape(-1, 3)[0]
+    got = P.GetParameterBlocksForResidualBlock(ids[0])
+    assert got[0] is blocks[w.bid_pose(p_)] and got[1] is blocks[w.bid_pose(e_)] and got[2] is blocks[w.bid_lm(l_)]
+    # per parameter block: every factor listed for a block lists the block back
+    lm0 = blocks[w.bid_lm(0)]
+    f_lm0 = P.GetResidualBlocksForParameterBlock(lm0)
+    assert len(f_lm0) == int((w.a["proj_idx"].reshape(-1, 3)[:, 2] == 0).sum()) and len(f_lm0) > 0
+    for f in f_lm0:
+        assert any(q is lm0 for q in P.GetParameterBlocksForResidualBlock(f))
+    # is_use round trip; removal
+    assert P.IsResidualBlockUsed(f_lm0[0])
+    P.SetResidualBlockUsed(f_lm0[0], False); assert not P.IsResidualBlockUsed(f_lm0[0])
+    P.RemoveResidualBlock(f_lm0[0])
+    assert f_lm0[0] not in P.GetResidualBlocks() and P.GetResidualBlocksForParameterBlock(lm0) == f_lm0[1:]
+    with pytest.raises(solver.SwfError):
+        P.GetParameterBlocksForResidualBlock(f_lm0[0])
+    P.RemoveParameterBlock(lm0)
+    assert not any(q is lm0 for q in P.GetParameterBlocks())
+    with pytest.raises(solver.SwfError):
+        P.GetResidualBlocksForParameterBlock(lm0)
+    P.close()
