@@ -2,12 +2,16 @@
 """bench.py — Gauss-Newton iterations/sec of the sliding-window solver on MI355X.
 
 One "step" = one full solve (<= 8 dogleg iterations, each = Jacobian evaluation of every block +
-J^T J assembly + Schur + dense reduced solve + step + cost re-evaluation + accept/reject) of a
-batch of independent BASELINE-cfg3 windows (20 keyframes / 300 features / 10 satellites) that is
-already resident in HBM.  Windows shard across GPUs with no data-path collective (weak scaling:
---windows per GPU).  value = whole-job Gauss-Newton iterations per second.
+J^T J assembly + Schur + dense reduced solve + step + cost re-evaluation + accept/reject) of BASELINE
+cfg4: a batch of 512 independent cfg3 windows (20 keyframes / 300 features / 10 satellites) whose
+structure and state are already resident in HBM.  The windows shard across the GPUs in contiguous
+blocks with no data-path collective — STRONG scaling by default, as SURVEY.md 8e specifies (512 windows
+over the job, 512 / N per rank; --scaling weak gives every rank --windows of its own).
+value = whole-job Gauss-Newton iterations per second.
 
-Driver contract: python bench.py --gpus N --steps K --warmup W   (N > 1 via torch.distributed.run)
+Driver contract: python bench.py --gpus N --steps K --warmup W.  When launched plainly with N > 1 this
+script re-executes itself under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1); when
+the driver has already launched it that way (RANK / WORLD_SIZE in the environment) it just runs its rank.
 """
 import argparse
 import json
@@ -52,34 +56,135 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(windows, iters, budget_s=12.0, threads=4):
-    """The oracle (a plain-C port of the reference path, oracle/swf_oracle.c) timed on the host's
-    cores on a bounded sample of the SAME windows; `threads` windows are solved concurrently (the
-    reference's num_threads = 4, R/swf/swf.cpp:29, parallelises inside one solve instead)."""
+def _physical_cores():
+    """Physical cores from lscpu (sockets x cores per socket); falls back to os.cpu_count()."""
+    import subprocess
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = dict((l.split(":", 1)[0].strip(), l.split(":", 1)[1].strip()) for l in txt.splitlines() if ":" in l)
+        return int(kv["Socket(s)"]) * int(kv["Core(s) per socket"]), kv.get("Model name", _cpu_model())
+    except Exception:
+        return os.cpu_count() or 1, _cpu_model()
+
+
+def cpu_baseline(windows, iters, budget_s=24.0):
+    """The reference's CPU path cannot be built here (no Eigen / Ceres / ROS in the image), so the CPU leg is the oracle — a plain,
+    UNVECTORISED C port of the same algorithm (oracle/swf_oracle.c, kind "port") — timed on this host on a bounded sample of the
+    SAME cfg3 windows, as SURVEY.md 8d prescribes: the reference's configuration first (num_threads = 4 INSIDE one solve,
+    R/swf/swf.cpp:29: OpenMP over factor evaluation and over the group-0 elimination), then one thread and every physical core,
+    >= 50 warm solves per row where the budget allows, median / p10 / p90 of us per Gauss-Newton iteration.  `value` is the
+    4-threads-inside-one-solve rate (iterations/s of ONE solve at a time).  The last row is a throughput figure only: one
+    single-threaded solve per core, many windows at once — not how the reference runs."""
     import oracle_binding as ob
     from concurrent.futures import ThreadPoolExecutor
     from rtk_visual_inertial_navigation_amd.flat import default_options
     ob.lib()
-    t0 = time.perf_counter()
-    probe = windows[0].copy()
-    sm, _ = ob.solve(probe, default_options(max_num_iterations=iters), export=False)
-    t1 = time.perf_counter() - t0
-    n = int(max(threads, min(len(windows), budget_s / max(t1, 1e-4) * threads * 0.8)))
+    cores, model = _physical_cores()
+    rows = {}
+    per_row = budget_s / 4.0
+
+    def timed(nthreads):
+        opt = default_options(max_num_iterations=iters, num_threads=nthreads)
+        ob.solve(windows[0].copy(), opt, export=False)                       # warm
+        us, t_all, k = [], time.perf_counter(), 0
+        while k < 50 or (time.perf_counter() - t_all < per_row and k < 400):
+            w = windows[k % len(windows)].copy()
+            t0 = time.perf_counter()
+            sm, _ = ob.solve(w, opt, export=False)
+            us.append(1e6 * (time.perf_counter() - t0) / max(1, sm.num_iterations)); k += 1
+            if time.perf_counter() - t_all > 2.0 * per_row:
+                break
+        us = np.array(us)
+        return dict(threads=nthreads, solves=int(us.size), us_per_iteration_median=float(np.median(us)), us_per_iteration_p10=float(np.percentile(us, 10)),
+                    us_per_iteration_p90=float(np.percentile(us, 90)), iterations_per_s=float(1e6 / np.median(us)))
+
+    rows["threads_4_inside_one_solve"] = timed(4)
+    rows["threads_1"] = timed(1)
+    rows["threads_all_cores_inside_one_solve"] = timed(cores)
+    # throughput mode: `cores` independent single-threaded solves at a time
+    n = int(min(len(windows), max(cores, 2 * cores)))
     sample = [w.copy() for w in windows[:n]]
 
     def run(w):
-        s, _ = ob.solve(w, default_options(max_num_iterations=iters), export=False)
-        return s.num_iterations
-
+        s_, _ = ob.solve(w, default_options(max_num_iterations=iters), export=False)
+        return s_.num_iterations
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
+    with ThreadPoolExecutor(cores) as ex:
         its = list(ex.map(run, sample))
-    dt = time.perf_counter() - t0
-    return dict(value=sum(its) / dt, unit="gauss_newton_iterations/s", cores=threads, kind="port",
-                sample="%d of the benchmark's cfg3 windows, %d dogleg iterations each, %d windows solved concurrently "
-                       "(one thread per window), %.1f s of wall time" % (len(sample), iters, threads, dt),
-                single_thread_us_per_iteration=1e6 * t1 / max(1, sm.num_iterations),
-                host_cores=os.cpu_count(), host_cpu_model=_cpu_model())
+    dtp = time.perf_counter() - t0
+    rows["independent_windows_one_thread_each"] = dict(threads=cores, windows=n, iterations_per_s=sum(its) / dtp, wall_s=dtp)
+    r4 = rows["threads_4_inside_one_solve"]
+    return dict(value=r4["iterations_per_s"], unit="gauss_newton_iterations/s", cores=4, kind="port",
+                sample="%d warm solves of the benchmark's cfg3 windows (%d dogleg iterations each) with 4 OpenMP threads inside one solve; "
+                       "unvectorised plain-C port of the reference's algorithm (the reference itself is unbuildable here)" % (r4["solves"], iters),
+                rows=rows, single_thread_us_per_iteration=rows["threads_1"]["us_per_iteration_median"],
+                host_physical_cores=cores, host_logical_cpus=os.cpu_count(), host_cpu_model=model)
+
+
+def structure_change_leg(w0, iters, reps=5, n_swap=30):
+    """The pointer-keyed ceres::Problem surface on ONE cfg3 window, timed the way the estimator drives it: a first Solve (symbolic
+    phase + upload), Solves where only parameter values changed, and Solves after the per-frame structure change of the
+    reference (R/swf/swf_image.cpp:65-114, R/feature/feature_manager.cpp:122-139): `n_swap` landmarks removed with their
+    projection factors (RemoveParameterBlock cascades) and as many new ones added with their observations, ordering re-issued.
+    Wall-clock milliseconds of swf_problem_solve, host bookkeeping, transfers and synchronisation included."""
+    from rtk_visual_inertial_navigation_amd import solver
+    from rtk_visual_inertial_navigation_amd.flat import default_options
+    P, blocks = solver.problem_from_window(w0)
+    opt = default_options(max_num_iterations=iters)
+    saved = [b.copy() for b in blocks]
+
+    def restore():
+        for b, s_ in zip(blocks, saved):
+            b[...] = s_
+
+    def solve_ms():
+        t0 = time.perf_counter()
+        sm = P.Solve(opt)
+        return 1e3 * (time.perf_counter() - t0), sm
+    first, sm0 = solve_ms()
+    values_only = []
+    for _ in range(reps):
+        restore(); values_only.append(solve_ms()[0])
+    a = w0.a
+    pidx, puv = a["proj_idx"].reshape(-1, 3), a["proj_uv"].reshape(-1, 2)
+    order_blocks = [blocks[i] for i in a["order_block"]]; order_groups = list(a["order_group"])
+    pos = {id(b): k for k, b in enumerate(order_blocks)}
+    lm_ids = list(range(min(n_swap, w0.n_lm)))
+    cur = {l: blocks[w0.bid_lm(l)] for l in lm_ids}
+    changed = []
+    for _ in range(reps):
+        restore()
+        t_edit = time.perf_counter()
+        for l in lm_ids:
+            old = cur[l]
+            P.RemoveParameterBlock(old)
+            new = saved[w0.bid_lm(l)].copy()
+            for (p_, e_, l_), uv in zip(pidx[pidx[:, 2] == l], puv[pidx[:, 2] == l]):
+                P.AddProjection(blocks[w0.bid_pose(p_)], blocks[w0.bid_pose(e_)], new, uv, w0.proj_sqrt_info, w0.proj_loss_a)
+            order_blocks[pos[id(old)]] = new; pos[id(new)] = pos.pop(id(old)); cur[l] = new
+        P.SetOrdering(order_blocks, order_groups)
+        t_edit = 1e3 * (time.perf_counter() - t_edit)
+        ms, sm = solve_ms()
+        changed.append((ms, t_edit))
+    P.close()
+    med = lambda v: float(np.median(v))
+    return dict(first_solve_ms=first, values_only_solve_ms=med(values_only), after_structure_change_solve_ms=med([c[0] for c in changed]),
+                python_side_edit_ms=med([c[1] for c in changed]), landmarks_swapped=len(lm_ids), iterations=int(sm0.num_iterations),
+                note="wall clock of swf_problem_solve on one cfg3 window through the ceres::Problem-shaped C-ABI")
+
+
+def relaunch_under_torchrun(n):
+    """python bench.py --gpus N (N > 1) without a launcher: become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`."""
+    import socket
+    import subprocess
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -87,7 +192,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=512, help="windows per GPU (BASELINE cfg4 = 512 over the job)")
+    ap.add_argument("--windows", type=int, default=512, help="windows of the whole job (strong scaling, BASELINE cfg4 = 512) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--iters", type=int, default=8, help="max_num_iterations (yaml MAX_NUM_ITERATIONS = 8)")
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,15 +201,20 @@ def main():
                     help="skip the single-window latency leg (its launches share kernel names with the batch and would dilute rocprofv3 per-kernel averages)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_under_torchrun(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, a.gpus):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE = %d" % (a.gpus, world))
     # synthetic windows first: the generator forks a process pool, which must happen before this
     # process touches HIP / RCCL
     from rtk_visual_inertial_navigation_amd import synth, shard
-    B = a.windows
+    first, B = shard.partition(a.windows, world, rank) if a.scaling == "strong" else (rank * a.windows, a.windows)
+    job_windows = a.windows if a.scaling == "strong" else a.windows * world
     t0 = time.perf_counter()
-    windows = make_windows(a.config, shard.window_seeds(synth.BASE_SEED, a.config, B, rank))
+    windows = make_windows(a.config, shard.window_seeds(synth.BASE_SEED, a.config, B, first=first))
     t_gen = time.perf_counter() - t0
 
     import torch
@@ -159,6 +270,14 @@ def main():
     its_total = shard.allreduce([float(sum(s.num_iterations for s in sms))], "sum", device=cdev)[0]
     job = shard.gather_summaries(np.array([[s.final_cost, s.num_iterations, s.termination] for s in sms]), device=cdev)
     value = its_total * a.steps / dt
+    # the same steps with the parameter blocks coming from the host each time (SURVEY.md 8d "uploads of state included"): the
+    # PCIe-inclusive rate; never `value`, which is quoted with the inputs resident in HBM
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        bs.upload_state(); bs.solve_async(opt); bs.sync()
+    barrier()
+    dt_up = shard.allreduce([time.perf_counter() - t0], "max", device=cdev)[0]
 
     if rank == 0:
         def avg_ms(k):
@@ -226,13 +345,16 @@ def main():
         out = {
             "metric": "gauss_newton_iterations_per_sec", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg4: batch of independent cfg3 windows (20 keyframes, 300 features, 3000 observations, "
-                                   "19 IMU factors, 10 satellites x 20 epochs carrier-phase+pseudorange, gauge prior), "
-                                   "%d windows per GPU, %d dogleg iterations per solve" % (B, a.iters),
-                       "windows_per_gpu": B, "max_num_iterations": a.iters, "sharding": "independent windows, no data-path collective"},
-            "windows_per_sec": world * B * a.steps / dt,
-            "iterations_per_window": its_total / (world * B),
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg4: batch of %d independent cfg3 windows (20 keyframes, 300 features, 3000 observations, "
+                                   "19 IMU factors, 10 satellites x 20 epochs carrier-phase+pseudorange, gauge prior) over the job, "
+                                   "%d dogleg iterations per solve" % (job_windows, a.iters),
+                       "windows": job_windows, "windows_rank0": B, "max_num_iterations": a.iters,
+                       "sharding": "independent windows in contiguous blocks, no data-path collective; harness-only all-reduce / all-gather"},
+            "windows_per_sec": job_windows * a.steps / dt,
+            "iterations_per_window": its_total / job_windows,
+            "with_state_upload": {"ms_per_step": 1e3 * dt_up / a.steps, "value": its_total * a.steps / dt_up,
+                                  "note": "parameter blocks re-uploaded from pageable host memory before every solve (PCIe-inclusive)"},
             "job_final_cost_mean": float(job[:, 0].mean()), "job_windows": int(job.shape[0]),
             "roofline": roof,
             "roofline_jacobian": jac,
@@ -240,6 +362,8 @@ def main():
             "single_window": single,
             "setup": {"generate_s": t_gen, "structure_upload_s": t_struct},
         }
+        if not a.no_single_window:
+            out["problem_surface"] = structure_change_leg(windows[0].copy(), a.iters)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(windows, a.iters)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -87,6 +87,16 @@ int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, double* rhs, do
  * order): gradient J^T r, squared column norms, and y = (J^T J + D)^-1 J^T r. */
 int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, double* diag, double* y);
 int swf_batch_dims(swf_batch* b, int32_t w, int32_t* n_loc, int32_t* n_e, int32_t* n_red);
+/* Debug/parity export of the LAST linearisation of window w, factor by factor: the residual vector r [n_res] and the dense
+ * Jacobian J [n_res][n_loc] (row-major; columns = local coordinates in elimination order, as swf_batch_export_vectors) exactly
+ * as the device holds them — loss-corrected (CauchyLoss corrector, R/factor/marginalization_factor.cpp:23-45), whitened.
+ * Rows: the window's projection factors in the caller's order (2 rows each), then imu (15 each), cp, pr, dop, sp, spr, scp,
+ * fix (1 each), idp (2 each), the linear priors (dim each), the composite factors (30 + N each, as rewritten by their last
+ * re-elimination).  Columns of constant blocks do not exist.  r / J may be NULL (then only the sizes are returned).  A solve
+ * with step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY leaves the linearisation at the uploaded state.  Not on any solve path: this is
+ * what the parity tests compare with numpy factor code and finite differences, and what their dense normal equations are
+ * assembled from. */
+int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, double* J, int32_t* n_res, int32_t* n_loc);
 
 /* Marginalisation consumer: what the reference does with the export of an is_optimize = false solve —
  * SWFOptimization::UpdateSchur (R/swf/swf_gnss.cpp:25-61) followed by MarginalizationInfo::setmarginalizeinfo(..., Sqrt =

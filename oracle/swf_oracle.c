@@ -815,6 +815,8 @@ typedef struct {
     /* work buffers */
     double* x; double* xc;                   /* current / candidate ambient state */
     double* res; double* jac;
+    double* res_c;                           /* residuals of cost-only (candidate) evaluations: they must not touch res, which the model of a
+                                                rejected iteration's successor still needs (found by the numpy trust-region restatement) */
     double* g; double* diag;                 /* n_loc */
     double* S; double* L; double* rhs;       /* reduced */
     double* Sexp;                            /* copy of S before factorisation (export) */
@@ -981,6 +983,7 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
     }
     c->x = (double*)calloc(c->n_x + 1, sizeof(double)); c->xc = (double*)calloc(c->n_x + 1, sizeof(double));
     c->res = (double*)calloc(c->n_res + 1, sizeof(double)); c->jac = (double*)calloc(c->n_jac + 1, sizeof(double));
+    c->res_c = (double*)calloc(c->n_res + 1, sizeof(double));
     c->g = (double*)calloc(c->n_loc + 1, sizeof(double)); c->diag = (double*)calloc(c->n_loc + 1, sizeof(double));
     size_t nr2 = (size_t)c->n_red * c->n_red + 1;
     c->S = (double*)calloc(nr2, sizeof(double)); c->L = (double*)calloc(nr2, sizeof(double)); c->Sexp = (double*)calloc(nr2, sizeof(double));
@@ -999,7 +1002,7 @@ static void ctx_free(ctx_t* c) {
     free(c->prior_blk_off); free(c->prior_J_off); free(c->prior_r_off); free(c->prior_x0_off);
     if (c->comp) { for (int k = 0; k < c->w->n_comp; k++) oracle_composite_destroy(c->comp[k]); free(c->comp); }
     free(c->comp_e_off); free(c->comp_idx_off);
-    free(c->x); free(c->xc); free(c->res); free(c->jac); free(c->g); free(c->diag);
+    free(c->x); free(c->xc); free(c->res); free(c->res_c); free(c->jac); free(c->g); free(c->diag);
     free(c->S); free(c->L); free(c->Sexp); free(c->rhs); free(c->gn); free(c->grad_s); free(c->step); free(c->delta);
     free(c->einv); free(c->estrip); free(c->estrip_off); free(c->e_nbr_off); free(c->e_nbr); free(c->einv_off);
     free(c);
@@ -1132,7 +1135,7 @@ static double evaluate(ctx_t* c, const double* x, int want_jac) {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) reduction(+:cost) num_threads(c->nthreads) if (c->nthreads > 1)
 #endif
-    for (int i = 0; i < c->n_fac; i++) cost += eval_factor(c, &c->fac[i], x, want_jac, c->res, c->jac);
+    for (int i = 0; i < c->n_fac; i++) cost += eval_factor(c, &c->fac[i], x, want_jac, want_jac ? c->res : c->res_c, c->jac);
     return cost;
 }
 
@@ -1155,38 +1158,10 @@ static void gradient_and_diag(ctx_t* c) {
     }
 }
 
-/* Schur elimination of group 0 with LM damping D^2 = mu * clamp(diag) (mu may be 0):
- * S = F^T F + D_f^2 - sum_e H_fe (H_ee + D_e^2)^-1 H_ef ; rhs likewise (ceres SchurEliminator).
- * dclamp = clamped squared column norms. */
-static int eliminate(ctx_t* c, const double* dclamp, double mu) {
-    int n = c->n_red, ne = c->n_e;
-    memset(c->S, 0, sizeof(double) * (size_t)n * n);
-    for (int i = 0; i < n; i++) { c->S[(size_t)i * n + i] = mu * dclamp[ne + i]; c->rhs[i] = c->g[ne + i]; }
-    /* F^T F from every factor over pairs of reduced blocks */
-    for (int i = 0; i < c->n_fac; i++) {
-        const fac_t* f = &c->fac[i];
-        for (int s = 0; s < f->nblk; s++) {
-            int jo1 = c->fjoff[f->blk_off + s]; int b1 = c->fblk[f->blk_off + s];
-            if (jo1 < 0 || c->blk2e[b1] >= 0) continue;
-            int l1 = c->lsize[b1], o1 = c->loc_off[b1] - ne;
-            const double* J1 = c->jac + jo1;
-            for (int t = 0; t < f->nblk; t++) {
-                int jo2 = c->fjoff[f->blk_off + t]; int b2 = c->fblk[f->blk_off + t];
-                if (jo2 < 0 || c->blk2e[b2] >= 0) continue;
-                int l2 = c->lsize[b2], o2 = c->loc_off[b2] - ne;
-                if (o2 > o1) continue;            /* lower triangle (block level) */
-                const double* J2 = c->jac + jo2;
-                for (int a = 0; a < l1; a++) for (int b = 0; b < l2; b++) {
-                    double sum = 0;
-                    for (int k = 0; k < f->nres; k++) sum += J1[k * l1 + a] * J2[k * l2 + b];
-                    c->S[(size_t)(o1 + a) * n + o2 + b] += sum;
-                }
-            }
-        }
-    }
-    /* e-blocks */
-    int fail = 0;
-    for (int e = 0; e < c->n_eblk; e++) {
+/* Schur contribution of one group-0 block e: S -= H_fe (H_ee + mu D_e^2)^-1 H_ef, rhs likewise; Einv / strip are kept for the
+ * back-substitution.  S / rhs: the reduced system itself (serial path) or a thread's private accumulator (OpenMP path). */
+static int eliminate_block(ctx_t* c, int e, const double* dclamp, double mu, double* S, double* rhs) {
+    const int n = c->n_red, ne = c->n_e;
         int be = c->eblk[e], le = c->lsize[be], loe = c->loc_off[be];
         double Hee[81], ge[9];
         memset(Hee, 0, sizeof(Hee));
@@ -1218,7 +1193,7 @@ static int eliminate(ctx_t* c, const double* dclamp, double mu) {
             }
         }
         double* Einv = c->einv + c->einv_off[e];
-        if (inv_spd(Hee, le, Einv)) { fail = 1; continue; }
+        if (inv_spd(Hee, le, Einv)) return -1;
         /* Y = Einv * strip (le x wsum); S -= strip^T Y ; rhs -= strip^T Einv ge */
         double Y[9 * 512], Eg[9];
         for (int a = 0; a < le; a++) {
@@ -1230,17 +1205,78 @@ static int eliminate(ctx_t* c, const double* dclamp, double mu) {
             int o1 = c->loc_off[nbr[t1]] - ne, l1 = c->lsize[nbr[t1]];
             for (int a = 0; a < l1; a++) {
                 double s = 0; for (int k = 0; k < le; k++) s += strip[k * wsum + coloff[t1] + a] * Eg[k];
-                c->rhs[o1 + a] -= s;
+                rhs[o1 + a] -= s;
             }
             for (int t2 = 0; t2 < nn; t2++) {
                 int o2 = c->loc_off[nbr[t2]] - ne, l2 = c->lsize[nbr[t2]];
                 if (o2 > o1) continue;
                 for (int a = 0; a < l1; a++) for (int b = 0; b < l2; b++) {
                     double s = 0; for (int k = 0; k < le; k++) s += strip[k * wsum + coloff[t1] + a] * Y[k * wsum + coloff[t2] + b];
-                    c->S[(size_t)(o1 + a) * n + o2 + b] -= s;
+                    S[(size_t)(o1 + a) * n + o2 + b] -= s;
                 }
             }
         }
+        return 0;
+}
+
+/* Schur elimination of group 0 with LM damping D^2 = mu * clamp(diag) (mu may be 0):
+ * S = F^T F + D_f^2 - sum_e H_fe (H_ee + D_e^2)^-1 H_ef ; rhs likewise (ceres SchurEliminator).
+ * dclamp = clamped squared column norms. */
+static int eliminate(ctx_t* c, const double* dclamp, double mu) {
+    int n = c->n_red, ne = c->n_e;
+    memset(c->S, 0, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; i++) { c->S[(size_t)i * n + i] = mu * dclamp[ne + i]; c->rhs[i] = c->g[ne + i]; }
+    /* F^T F from every factor over pairs of reduced blocks */
+    for (int i = 0; i < c->n_fac; i++) {
+        const fac_t* f = &c->fac[i];
+        for (int s = 0; s < f->nblk; s++) {
+            int jo1 = c->fjoff[f->blk_off + s]; int b1 = c->fblk[f->blk_off + s];
+            if (jo1 < 0 || c->blk2e[b1] >= 0) continue;
+            int l1 = c->lsize[b1], o1 = c->loc_off[b1] - ne;
+            const double* J1 = c->jac + jo1;
+            for (int t = 0; t < f->nblk; t++) {
+                int jo2 = c->fjoff[f->blk_off + t]; int b2 = c->fblk[f->blk_off + t];
+                if (jo2 < 0 || c->blk2e[b2] >= 0) continue;
+                int l2 = c->lsize[b2], o2 = c->loc_off[b2] - ne;
+                if (o2 > o1) continue;            /* lower triangle (block level) */
+                const double* J2 = c->jac + jo2;
+                for (int a = 0; a < l1; a++) for (int b = 0; b < l2; b++) {
+                    double sum = 0;
+                    for (int k = 0; k < f->nres; k++) sum += J1[k * l1 + a] * J2[k * l2 + b];
+                    c->S[(size_t)(o1 + a) * n + o2 + b] += sum;
+                }
+            }
+        }
+    }
+    /* e-blocks.  One thread: in order, straight into S (this is the parity path, bit-reproducible).  num_threads > 1 (the
+     * reference runs ceres with num_threads = 4, R/swf/swf.cpp:29; ceres' SchurEliminator likewise parallelises over chunks
+     * of e-blocks): every thread subtracts into a private accumulator, the accumulators are added in thread order. */
+    int fail = 0;
+    if (c->nthreads <= 1) {
+        for (int e = 0; e < c->n_eblk; e++) if (eliminate_block(c, e, dclamp, mu, c->S, c->rhs)) fail = 1;
+    } else {
+#ifdef _OPENMP
+        const int nt = c->nthreads;
+        double* acc = (double*)calloc((size_t)nt * ((size_t)n * n + n) + 1, sizeof(double));
+#pragma omp parallel num_threads(nt)
+        {
+            int t = omp_get_thread_num();
+            double* Sl = acc + (size_t)t * ((size_t)n * n + n); double* rl = Sl + (size_t)n * n;
+#pragma omp for schedule(dynamic, 16)
+            for (int e = 0; e < c->n_eblk; e++) if (eliminate_block(c, e, dclamp, mu, Sl, rl)) {
+#pragma omp atomic write
+                fail = 1;
+            }
+        }
+        for (int t = 0; t < nt; t++) {
+            const double* Sl = acc + (size_t)t * ((size_t)n * n + n); const double* rl = Sl + (size_t)n * n;
+            for (size_t i = 0; i < (size_t)n * n; i++) c->S[i] += Sl[i];
+            for (int i = 0; i < n; i++) c->rhs[i] += rl[i];
+        }
+        free(acc);
+#else
+        for (int e = 0; e < c->n_eblk; e++) if (eliminate_block(c, e, dclamp, mu, c->S, c->rhs)) fail = 1;
+#endif
     }
     return fail ? -1 : 0;
 }
@@ -1364,6 +1400,37 @@ int oracle_evaluate(const swf_flat_window* w, double* cost, double* res) {
 /* The trust-region loop: public Ceres 2.x TrustRegionMinimizer::Minimize with
  * DoglegStrategy(TRADITIONAL_DOGLEG) and DENSE_SCHUR, jacobi_scaling=false
  * (call site R/swf/swf_image.cpp:198-251; options R/swf/swf.cpp:25-30). */
+/* The linearisation at the window's current state, factor by factor: residual vector r [n_res] and dense Jacobian
+ * J [n_res][n_loc] (row-major, local coordinates in elimination order), rows in the order swf_batch_export_jacobian documents
+ * (include/swf_solver.h): proj, imu, cp, pr, dop, sp, spr, scp, fix, idp, prior, composite.  J may be NULL.  Test
+ * infrastructure for the numpy dense normal equations / trust-region restatement (tests/np_dense.py). */
+int oracle_export_jacobian(const swf_flat_window* w, double* r, double* J) {
+    ctx_t* c = ctx_build(w);
+    if (!c) return -1;
+    ctx_load_state(c);
+    evaluate(c, c->x, 1);
+    const int nl = c->n_loc;
+    if (J) memset(J, 0, sizeof(double) * (size_t)c->n_res * nl);
+    /* the context keeps priors ahead of the inverse-depth factors; the export order has them behind */
+    int row = 0;
+    for (int pass = 0; pass < 3; pass++)
+        for (int i = 0; i < c->n_fac; i++) {
+            const fac_t* f = &c->fac[i];
+            int cls = f->type == F_PRIOR ? 1 : f->type == F_COMP ? 2 : 0;
+            if (cls != pass) continue;
+            for (int k = 0; k < f->nres; k++) r[row + k] = c->res[f->r_off + k];
+            if (J) for (int s = 0; s < f->nblk; s++) {
+                int jo = c->fjoff[f->blk_off + s];
+                if (jo < 0) continue;
+                int b = c->fblk[f->blk_off + s], ls = c->lsize[b], lo = c->loc_off[b];
+                for (int k = 0; k < f->nres; k++) for (int j = 0; j < ls; j++) J[(size_t)(row + k) * nl + lo + j] = c->jac[jo + k * ls + j];
+            }
+            row += f->nres;
+        }
+    ctx_free(c);
+    return 0;
+}
+
 int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* sum, oracle_export* ex) {
     double t0 = now_sec();
     ctx_t* c = ctx_build(w);

@@ -66,6 +66,7 @@ struct HostWin {       // what the host keeps per window for state transfer / ex
     int tail_dim;
     double *comp_pose = nullptr, *comp_sb = nullptr;    // hidden epochs of the window's composite factors (caller memory)
     int comp_e0 = 0, comp_ne = 0;                       // their range in the batch-wide hidden-epoch arrays
+    std::vector<int> p_orig;                            // device observation (proj0 + q) -> the caller's projection factor index
 };
 
 struct swf_batch {
@@ -212,6 +213,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     }
     R.proj0 = (int)B.p_win.size();
     R.lm0 = (int)B.lm_win.size();
+    hw.p_orig = ord;
     {
         std::vector<std::vector<int>> fobs(R.nF);
         std::vector<int> lm_first(nL + 1, 0);
@@ -1293,6 +1295,76 @@ extern "C" int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, d
     if (grad) HIPCHK(hipMemcpy(grad, b->D.g + W.loc_base, n * sizeof(double), hipMemcpyDeviceToHost));
     if (diag) HIPCHK(hipMemcpy(diag, b->D.diag + W.loc_base, n * sizeof(double), hipMemcpyDeviceToHost));
     if (y) HIPCHK(hipMemcpy(y, b->D.y + W.loc_base, n * sizeof(double), hipMemcpyDeviceToHost));
+    return SWF_OK;
+}
+
+// Debug / parity export: residual vector and dense Jacobian of window w as the device holds them after its last
+// linearisation (see include/swf_solver.h).  Host-side gather of the device buffers; nothing here is on the solve path.
+extern "C" int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, double* J, int32_t* n_res_out, int32_t* n_loc_out) {
+    if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
+    const WinRec& W = b->win[w];
+    const DevBatch& D = b->D;
+    const int ngf = W.gf1 - W.gf0, nobs = W.proj1 - W.proj0;
+    std::vector<GFac> gf((size_t)std::max(ngf, 0));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (ngf > 0) HIPCHK(hipMemcpy(gf.data(), D.gf + W.gf0, (size_t)ngf * sizeof(GFac), hipMemcpyDeviceToHost));
+    int nres = 2 * nobs;
+    for (const GFac& G : gf) nres += G.nres;
+    if (n_res_out) *n_res_out = nres;
+    if (n_loc_out) *n_loc_out = W.n_loc;
+    if (!r && !J) return SWF_OK;
+    if (b->last_mode < 0) return fail(SWF_E_STATE, "swf_batch_export_jacobian before any solve");
+    const size_t nl = (size_t)W.n_loc, N = (size_t)D.n_proj;
+    if (J) memset(J, 0, (size_t)nres * nl * sizeof(double));
+    auto dl = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+    bool ok = true;
+    if (nobs > 0) {
+        std::vector<double> pr(2 * (size_t)nobs), Jp(12 * (size_t)nobs), Jl(6 * (size_t)nobs);
+        std::vector<int> lp((size_t)nobs), ll((size_t)nobs);
+        for (int k = 0; k < 2; k++) ok &= dl(pr.data() + (size_t)k * nobs, D.p_r + k * N + W.proj0, (size_t)nobs * 8);
+        for (int k = 0; k < 12; k++) ok &= dl(Jp.data() + (size_t)k * nobs, D.p_Jp + k * N + W.proj0, (size_t)nobs * 8);
+        for (int k = 0; k < 6; k++) ok &= dl(Jl.data() + (size_t)k * nobs, D.p_Jl + k * N + W.proj0, (size_t)nobs * 8);
+        ok &= dl(lp.data(), D.p_lpose + W.proj0, (size_t)nobs * 4); ok &= dl(ll.data(), D.p_llm + W.proj0, (size_t)nobs * 4);
+        if (!ok) return fail(SWF_E_NODEVICE, "download failed");
+        for (int q = 0; q < nobs; q++) {
+            const size_t row = 2 * (size_t)b->hw[w].p_orig[q];
+            for (int a = 0; a < 2; a++) {
+                if (r) r[row + a] = pr[(size_t)a * nobs + q];
+                if (!J) continue;
+                if (lp[q] >= 0) for (int c = 0; c < 6; c++) J[(row + a) * nl + (lp[q] - W.loc_base) + c] = Jp[(size_t)(a * 6 + c) * nobs + q];
+                if (ll[q] >= 0) for (int c = 0; c < 3; c++) J[(row + a) * nl + (ll[q] - W.loc_base) + c] = Jl[(size_t)(a * 3 + c) * nobs + q];
+            }
+        }
+    }
+    size_t row = 2 * (size_t)nobs;
+    for (const GFac& G : gf) {
+        std::vector<int> sloc((size_t)G.nslot), sls((size_t)G.nslot), sj((size_t)G.nslot), spc((size_t)G.nslot);
+        ok &= dl(sloc.data(), D.s_loc + G.slot0, (size_t)G.nslot * 4); ok &= dl(sls.data(), D.s_ls + G.slot0, (size_t)G.nslot * 4);
+        ok &= dl(sj.data(), D.s_joff + G.slot0, (size_t)G.nslot * 4); ok &= dl(spc.data(), D.s_pcol + G.slot0, (size_t)G.nslot * 4);
+        if (r) ok &= dl(r + row, D.g_r + G.roff, (size_t)G.nres * 8);
+        if (J && G.type == GF_PRIOR) {
+            // linearised prior (and composite factors, whose record k_comp_scatter rewrites): the constant row-major J of the record
+            int dim = 0; long long jo = 0;
+            ok &= dl(&dim, D.prior_dim + G.data, 4); ok &= dl(&jo, D.prior_Joff + G.data, 8);
+            std::vector<double> PJ((size_t)dim * dim);
+            ok &= dl(PJ.data(), D.prior_J + jo, PJ.size() * 8);
+            for (int sl = 0; sl < G.nslot; sl++) {
+                if (sloc[sl] < 0) continue;
+                for (int k = 0; k < G.nres; k++) for (int c = 0; c < sls[sl]; c++)
+                    J[(row + k) * nl + (sloc[sl] - W.loc_base) + c] = PJ[(size_t)k * dim + spc[sl] + c];
+            }
+        } else if (J) {
+            for (int sl = 0; sl < G.nslot; sl++) {
+                if (sloc[sl] < 0 || sj[sl] < 0) continue;
+                std::vector<double> blk((size_t)sls[sl] * G.jld);
+                ok &= dl(blk.data(), D.g_J + sj[sl], (((size_t)sls[sl] - 1) * G.jld + G.nres) * 8);
+                for (int k = 0; k < G.nres; k++) for (int c = 0; c < sls[sl]; c++)
+                    J[(row + k) * nl + (sloc[sl] - W.loc_base) + c] = blk[(size_t)c * G.jld + k];
+            }
+        }
+        row += G.nres;
+    }
+    if (!ok) return fail(SWF_E_NODEVICE, "download failed");
     return SWF_OK;
 }
 

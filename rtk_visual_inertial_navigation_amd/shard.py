@@ -15,10 +15,18 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def window_seeds(base_seed, config_id, windows_per_rank, rank):
-    """cfg4: window i of the job uses seed base+config+i; rank r owns i in [r*B, (r+1)*B)."""
-    s0 = base_seed + config_id + rank * windows_per_rank
-    return [s0 + i for i in range(windows_per_rank)]
+def partition(n_windows, world, rank):
+    """Static block distribution of the job's windows over the ranks (512 windows, 64 per GPU at 8):
+    (first window, count) of `rank`; the first n_windows % world ranks take one more."""
+    q, r = divmod(n_windows, world)
+    return rank * q + min(rank, r), q + (1 if rank < r else 0)
+
+
+def window_seeds(base_seed, config_id, count, rank=0, first=None):
+    """cfg4: window i of the job uses seed base+config+i; this rank owns `count` windows starting at `first`
+    (default: rank * count, the weak-scaling layout)."""
+    s0 = base_seed + config_id + (rank * count if first is None else first)
+    return [s0 + i for i in range(count)]
 
 
 def _dist():

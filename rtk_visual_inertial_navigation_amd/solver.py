@@ -49,7 +49,7 @@ EXPORTED = [
     "swf_composite_create", "swf_composite_evaluate", "swf_composite_hidden", "swf_composite_destroy", "swf_add_imu_gnss",
     "swf_eval_inverse_depth_batch", "swf_add_projection_inverse_depth",
     "swf_factor_is_enabled", "swf_get_residual_blocks", "swf_get_residual_blocks_for_parameter_block",
-    "swf_get_parameter_blocks", "swf_get_parameter_blocks_for_residual_block",
+    "swf_get_parameter_blocks", "swf_get_parameter_blocks_for_residual_block", "swf_batch_export_jacobian",
 ]
 
 
@@ -149,6 +149,15 @@ class BatchSolver:
         _chk(lib().swf_batch_export_vectors(self._h, C.c_int32(w), g.ctypes.data_as(_pd), d.ctypes.data_as(_pd),
                                             y.ctypes.data_as(_pd)), "swf_batch_export_vectors")
         return g, d, y
+
+    def export_jacobian(self, w=0):
+        """(r [n_res], J [n_res][n_loc]) of window w's last linearisation as the device holds it (swf_batch_export_jacobian)."""
+        nr, nl = C.c_int32(), C.c_int32()
+        _chk(lib().swf_batch_export_jacobian(self._h, C.c_int32(w), None, None, C.byref(nr), C.byref(nl)), "swf_batch_export_jacobian")
+        r, J = np.zeros(nr.value), np.zeros((nr.value, nl.value))
+        _chk(lib().swf_batch_export_jacobian(self._h, C.c_int32(w), r.ctypes.data_as(_pd), J.ctypes.data_as(_pd), C.byref(nr), C.byref(nl)),
+             "swf_batch_export_jacobian")
+        return r, J
 
     PRIOR_EIGEN, PRIOR_CHOLESKY = 0, 1
 

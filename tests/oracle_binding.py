@@ -68,6 +68,17 @@ def evaluate(win):
     return cost.value, res
 
 
+def export_jacobian(win):
+    """(r [n_res], J [n_res][n_loc]) at the window's current state, rows / columns as swf_batch_export_jacobian."""
+    d = dims(win)
+    r, J = np.zeros(d["n_res"]), np.zeros((d["n_res"], d["n_loc"]))
+    s = win.c_struct()
+    f = lib().oracle_export_jacobian
+    f.restype = C.c_int
+    assert f(C.byref(s), _p(r), _p(J)) == 0
+    return r, J
+
+
 def solve(win, opt=None, export=True):
     """Runs the oracle solve IN PLACE on win's state. Returns (summary, export dict)."""
     if opt is None:

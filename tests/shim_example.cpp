@@ -42,6 +42,18 @@ int main() {
     ceres::Solve(my_options, &my_problem, &summary);
     std::printf("%s\n", summary.BriefReport().c_str());
     if (summary.final_cost > 1e10) return 1;
+    {   // a default-constructed Solver::Options, as GnssPreprocess / GnssProcess use it (R/swf/swf_gnss.cpp:200-216, 562-572):
+        // LEVENBERG_MARQUARDT, no linear_solver_ordering (the solver orders the blocks itself), results never inspected
+        ceres::Solver::Options options;
+        options.linear_solver_type = ceres::DENSE_SCHUR;
+        options.initial_trust_region_radius = options.max_trust_region_radius = 1e15;
+        options.max_num_iterations = 2;
+        options.num_threads = 1;
+        ceres::Solver::Summary s2;
+        ceres::Solve(options, &my_problem, &s2);
+        std::printf("%s\n", s2.BriefReport().c_str());
+        if (s2.final_cost > 1e10 || s2.final_cost > summary.final_cost * (1 + 1e-9)) return 3;
+    }
     // GlobalMarge's sequence (R/swf/swf_image.cpp:404-418): keep pose1 as parameter_head, assemble + eliminate only,
     // then UpdateSchur + setmarginalizeinfo in one call
     // (two landmarks are held constant: 4 points seen from a fixed and a free camera give 8 constraints on the free

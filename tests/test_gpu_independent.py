@@ -1,0 +1,162 @@
+"""GPU parity against the INDEPENDENT second opinion (numpy), not against the oracle's twin code:
+
+* every factor family's device residuals and Jacobians (swf_batch_export_jacobian, through the C-ABI) against
+  tests/np_factors.py and central differences on the manifold;
+* the device's block assembly, Schur elimination, Cholesky factor and Gauss-Newton solution against numpy dense normal
+  equations assembled from the device's own per-factor Jacobians (nothing eliminated);
+* the device's trust-region loop (DOGLEG and LEVENBERG_MARQUARDT) against the numpy restatement of ceres'
+  TrustRegionMinimizer, by trajectory replay (tests/np_dense.py::replay): each iteration's damped solution comes from the
+  device, is judged by its backward error, and everything else must agree at rounding level — which is also the
+  demonstration that the loose tolerances of the device-vs-oracle sequence test are eps * cond(S) and nothing else;
+* BASELINE cfg4 at full size: 512 windows in one batch, a sample solved alone bit for bit and against the oracle.
+"""
+import numpy as np
+import pytest
+
+import np_dense as nd
+import oracle_binding as ob
+from rtk_visual_inertial_navigation_amd import synth, solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+from np_dense import TR_CASES, tr_case_window, check_replay
+
+pytestmark = pytest.mark.gpu
+
+
+def device_linearize(w):
+    """(r, J) of the window's current state from the device: ASSEMBLE_ELIMINATE_ONLY leaves the linearisation at the uploaded state."""
+    bs = solver.BatchSolver([w.copy()])
+    bs.solve(default_options(step_mode=1), download=False)
+    r, J = bs.export_jacobian(0)
+    bs.close()
+    return r, J
+
+
+def _family_windows():
+    import idepth_gen
+    return [("rtk", synth.make_window(3, K=6, F=40, S=5)),
+            ("vi", synth.make_window(2, K=5, F=30, S=0, seed=9)),
+            ("doppler", synth.make_window(3, K=4, F=10, S=4, seed=5, doppler=True)),
+            ("spp+fixed", synth.with_spp_and_fixed(synth.make_window(3, K=5, F=14, S=6, seed=4), seed=3, n_fix=3)),
+            ("inverse depth", idepth_gen.convert_short_tracks(synth.make_window(2, K=8, F=30, S=0, seed=4))),
+            ("dense prior", synth.make_window(5, K=14, F=40, S=4, seed=10)),
+            ("cfg3", synth.make_window(3))]
+
+
+@pytest.mark.parametrize("name,w", _family_windows(), ids=[n for n, _ in _family_windows()])
+def test_device_factor_residuals_and_jacobians_vs_numpy_and_finite_differences(name, w):
+    r, J = device_linearize(w)
+    n = nd.check_linearization(w, r, J, "device:" + name)
+    assert n > 0
+    # and the device's cost is the numpy cost
+    bs = solver.BatchSolver([w.copy()])
+    sm = bs.solve(default_options(step_mode=1), download=False)[0]
+    bs.close()
+    assert abs(sm.initial_cost - nd.window_cost(w)) <= 1e-9 * sm.initial_cost
+
+
+@pytest.mark.parametrize("name,w", _family_windows(), ids=[n for n, _ in _family_windows()])
+def test_device_reduced_system_and_solution_vs_numpy_dense_normal_equations(name, w):
+    """H = J^T J from the device's own per-factor Jacobians, nothing eliminated, solved densely in numpy: the device's gradient,
+    diagonal, Schur complement S, reduced right-hand side, Cholesky factor and full solution y must be what that dense system
+    gives.  y is conditioning-limited, so it is judged twice: forward error against an extended-precision solution within
+    20 eps cond(Jacobi-scaled H), and backward error at O(n eps)."""
+    bs = solver.BatchSolver([w.copy()])
+    bs.solve(default_options(step_mode=1), download=False)
+    r, J = bs.export_jacobian(0)
+    g, dg, y = bs.export_vectors(0)
+    S, rhs, L = bs.export_reduced(0)
+    n_e = bs.dims(0)["n_e"]
+    bs.close()
+    d = nd.dense_system(r, J, n_e, mu=0.0)
+    sc = lambda v: np.abs(v).max()
+    assert np.abs(g - d["g"]).max() <= 1e-12 * sc(d["g"]) and np.abs(dg - d["diag"]).max() <= 1e-12 * sc(d["diag"])
+    assert np.abs(S - d["S"]).max() <= 1e-11 * sc(d["S"])
+    assert np.abs(rhs - d["rhs"]).max() <= 1e-10 * sc(d["rhs"])
+    cond = np.linalg.cond(d["S"])
+    assert np.abs(L - d["L"]).max() <= (1e-15 * cond + 1e-12) * sc(d["L"])
+    assert np.abs(L @ L.T - S).max() <= 1e-12 * sc(S)
+    H = d["H"]
+    D = np.sqrt(np.diag(H))
+    cond_s = np.linalg.cond(H / np.outer(D, D))
+    err = np.abs((y - d["y"]) * D).max() / np.abs(d["y"] * D).max()
+    assert err <= 20 * np.finfo(float).eps * cond_s + 1e-13, (name, err, cond_s)
+    assert nd.backward_error(H, y, d["g"]) <= 1e-12
+
+
+@pytest.mark.parametrize("strategy", ["dogleg", "lm"])
+@pytest.mark.parametrize("ci", range(len(TR_CASES)))
+def test_device_trust_region_loop_replayed_by_numpy(ci, strategy):
+    cs = TR_CASES[ci]
+    w0 = tr_case_window(cs)
+
+    def run(w, k):
+        opt = default_options(max_num_iterations=k, strategy=1 if strategy == "lm" else 0)
+        opt.initial_trust_region_radius = cs["r0"]
+        bs = solver.BatchSolver([w])
+        sm = bs.solve(opt)[0]
+        y = bs.export_vectors(0)[2]
+        bs.close()
+        run.final = w
+        return sm.rows(), ("raw", y)
+
+    rows, impl_rows, berr, wn = nd.replay(w0, run, device_linearize, strategy=strategy, initial_radius=cs["r0"])
+    hard = bool(cs.get("hard"))
+    check_replay(rows, impl_rows, berr, noise=nd.gnss_residual_noise(w0), berr_tol=1e-9 if hard else 1e-12, gtol=1e-6 if hard else 1e-8,
+                 rtol_radius=1e-6 if strategy == "lm" else 1e-9)
+    assert np.abs(run.final.a["pose"] - wn.a["pose"]).max() <= (1e-9 if hard else 1e-11)
+
+
+@pytest.mark.parametrize("ci", range(len(TR_CASES)))
+def test_device_levenberg_marquardt_sequence_matches_oracle(ci):
+    """The LEVENBERG_MARQUARDT strategy of the device loop against the oracle's: same accept / reject sequence, conditioning-limited
+    costs (see test_gpu_parity.py's header for the bound)."""
+    cs = TR_CASES[ci]
+    w0 = tr_case_window(cs)
+    opt = default_options(max_num_iterations=8, strategy=1)
+    opt.initial_trust_region_radius = cs["r0"]
+    wo, wg = w0.copy(), w0.copy()
+    so, _ = ob.solve(wo, opt, export=False)
+    bs = solver.BatchSolver([wg])
+    sg = bs.solve(opt)[0]
+    bs.close()
+    ro, rg = so.rows(), sg.rows()
+    assert sg.termination == so.termination and len(ro) == len(rg)
+    assert [r["step_is_successful"] for r in rg] == [r["step_is_successful"] for r in ro]
+    assert [r["step_is_valid"] for r in rg] == [r["step_is_valid"] for r in ro]
+    for a, b in zip(rg, ro):
+        assert abs(a["cost"] - b["cost"]) <= 2e-6 * abs(b["cost"]) + 5e-5
+        assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-4 * b["trust_region_radius"]
+
+
+def test_cfg4_full_size_batch_equals_single_windows_and_the_oracle():
+    """BASELINE cfg4 at full size on one GPU: 512 independent cfg3 windows (20 keyframes / 300 features / 10 satellites) solved
+    as one batch; a sample of 8 windows solved alone gives the batch's results BIT FOR BIT, and the same 8 match the oracle's
+    cost / accept sequence within the conditioning-limited bound.  Every window converges to a cost the generator's noise
+    level explains."""
+    import bench
+    B = 512
+    seeds = [synth.BASE_SEED + 4 + i for i in range(B)]
+    ws = bench.make_windows(4, seeds)
+    batch = [w.copy() for w in ws]
+    bs = solver.BatchSolver(batch)
+    sms = bs.solve(default_options(max_num_iterations=8))
+    bs.close()
+    assert all(s.termination in (1, 2, 3, 4) for s in sms)
+    fc = np.array([s.final_cost for s in sms]); ic = np.array([s.initial_cost for s in sms])
+    assert np.all(fc < 1e-3 * ic) and np.all(np.isfinite(fc))
+    for i in (0, 1, 63, 64, 200, 255, 256, 511):
+        wi = ws[i].copy()
+        b1 = solver.BatchSolver([wi])
+        s1 = b1.solve(default_options(max_num_iterations=8))[0]
+        b1.close()
+        for k in ("pose", "sb", "lm", "sc"):
+            assert np.array_equal(wi.a[k], batch[i].a[k]), (i, k)
+        r1, rb = s1.rows(), sms[i].rows()
+        assert len(r1) == len(rb) and all(a["cost"] == b["cost"] and a["trust_region_radius"] == b["trust_region_radius"] for a, b in zip(r1, rb))
+        wo = ws[i].copy()
+        so, _ = ob.solve(wo, default_options(max_num_iterations=8), export=False)
+        ro = so.rows()
+        assert [r["step_is_successful"] for r in rb] == [r["step_is_successful"] for r in ro] and sms[i].termination == so.termination
+        for a, b in zip(rb, ro):
+            assert abs(a["cost"] - b["cost"]) <= 5e-7 * abs(b["cost"]) + 5e-5
+        assert np.abs(wo.a["pose"] - batch[i].a["pose"]).max() < 1e-6
