@@ -303,7 +303,17 @@ def trust_region(w, linearize, cost, strategy="dogleg", damped_solver=None, max_
     gmax = grad_max_norm(g)
     x_norm = np.linalg.norm(variable_state(w))
     # rounding floor of the gradient J^T r (sums of cancelling terms once the iteration has converged): a few eps |J|^T |r|
-    g_noise = lambda: 8 * np.finfo(float).eps * float((np.abs(J).T @ np.abs(r)).max())
+    # plus what one ulp of the state does to it: |H| |x| eps (lambda_max(H) is ~1e11 in these windows, so late in a solve the
+    # gradient of a few units is the difference of numbers 1e10 times larger)
+    def g_noise():
+        loc, n_loc, _ = local_layout(w)
+        _, l = w.block_sizes()
+        sx = np.ones(n_loc)
+        for b, blk in enumerate(blocks_of(w)):
+            if loc[b] >= 0:
+                sx[loc[b]:loc[b] + l[b]] = max(1.0, float(np.abs(blk).max()))
+        eps = np.finfo(float).eps
+        return 8 * eps * float((np.abs(J).T @ np.abs(r)).max()) + 8 * eps * float((np.abs(J.T @ J) @ sx).max())
     rows = [dict(cost=x_cost, radius=initial_radius, accepted=True, valid=True, step_norm=0.0, gradient_max_norm=gmax, relative_decrease=0.0, gradient_noise=g_noise())]
     radius, mu, reuse, invalid_run, lm_dec = initial_radius, min_mu, False, 0, 2.0
     it = 0

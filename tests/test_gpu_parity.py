@@ -98,6 +98,15 @@ def test_dogleg_cost_and_step_sequence_matches_oracle(kw):
     ro, rg = so.rows(), sg.rows()
     assert sg.termination == so.termination and sg.num_iterations == so.num_iterations
     assert [r["step_is_successful"] for r in rg] == [r["step_is_successful"] for r in ro]
+    # iteration 0 is the linearisation at the uploaded state: rounding-level agreement, asserted as such
+    assert abs(rg[0]["cost"] - ro[0]["cost"]) <= 1e-12 * ro[0]["cost"]
+    assert abs(rg[0]["gradient_max_norm"] - ro[0]["gradient_max_norm"]) <= 1e-11 * ro[0]["gradient_max_norm"]
+    assert rg[0]["trust_region_radius"] == ro[0]["trust_region_radius"]
+    # from iteration 1 on the two trajectories have gone through different (both backward-stable) linear solves of a system with
+    # cond ~1e16 (1e10 Jacobi-scaled): steps agree to ~eps cond = 1e-7..1e-8, and everything downstream inherits that.  That
+    # this, and nothing else, is where the slack goes is PROVEN by tests/test_gpu_independent.py::test_device_trust_region_loop_
+    # replayed_by_numpy (with the device's own solutions every other quantity of the loop agrees with numpy at 1e-10) and
+    # ::test_device_reduced_system_and_solution_vs_numpy_dense_normal_equations (forward error <= 20 eps cond, backward 1e-12).
     for a, b in zip(rg, ro):
         assert abs(a["cost"] - b["cost"]) <= 5e-7 * abs(b["cost"]) + 5e-5      # + lambda_max*dx^2 floor
         assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * b["trust_region_radius"]
