@@ -41,7 +41,8 @@ struct WinState {
 };
 
 // ---- generic factor (everything except projection) --------------------------------------
-enum { GF_IMU = 1, GF_CP = 2, GF_PR = 3, GF_DOP = 4, GF_SP = 5, GF_PRIOR = 6, GF_SPR = 7, GF_SCP = 8, GF_FIX = 9, GF_IDP = 10 };
+enum { GF_IMU = 1, GF_CP = 2, GF_PR = 3, GF_DOP = 4, GF_SP = 5, GF_PRIOR = 6, GF_SPR = 7, GF_SCP = 8, GF_FIX = 9, GF_IDP = 10,
+       GF_PROJX = 11 };      // GF_PROJX: a world-point projection factor on the generic clique path (variable extrinsic, or a landmark outside group 0)
 struct GFac {
     int type, win, nres, nslot;
     int slot0;                   // into slot arrays
@@ -49,7 +50,7 @@ struct GFac {
     int data;                    // index into the type's data array (record index)
     int clique;                  // owning clique
     int jld;                     // column stride of this factor's Jacobian blocks in g_J (= rows of the clique's dense column-major matrix)
-    int pad;
+    int pad;                     // GF_PROJX: the caller's projection-factor index (row order of the Jacobian export)
 };
 
 // ---- clique: a group-0 block (or none) + the factors touching it + its reduced neighbours
@@ -124,7 +125,7 @@ struct DevBatch {
     const double* imu_pre; const double* cp_dat; const double* pr_dat; const double* dop_dat; const double* sp_w;
     const double* gx_dat;            // records of the rover-only / fixed-integer scalar factors (GFac.data = offset in doubles)
     int n_imu; const int* imu_gf;              // generic-factor ids by kernel
-    int n_idp; const int* idp_gf;              // inverse-depth projection factors (also members of sc_gf for the J v products)
+    int n_idp; const int* idp_gf;              // two-row projection factors of the generic path: inverse-depth (GF_IDP) and world-point (GF_PROJX) ones (also members of sc_gf for the J v products)
     int n_sc;  const int* sc_gf;
     int n_prior; const int* prior_gf;
     // priors
@@ -140,7 +141,7 @@ struct DevBatch {
     const int* cl_fac; const int* cl_frow;     // factor ids and their first row in the clique Jacobian
     const int* cm_loc; const int* cm_ls; const int* cm_col;
     double* C; double* cv_graw; double* cv_dgraw; double* cv_cs; double* cE;
-    int n_clc[3]; const Clique* clc_rec[3];    // non-static cliques by size class (copies of the records: no index indirection)
+    int n_clc[4]; const Clique* clc_rec[4];    // non-static cliques by size class (copies of the records: no index indirection); 3 = k_clique_big
     int n_cle; const Clique* cle_rec;          // cliques with an eliminated block (back-substitution), likewise
     // pairs
     int n_pair;

@@ -67,6 +67,7 @@ struct HostWin {       // what the host keeps per window for state transfer / ex
     double *comp_pose = nullptr, *comp_sb = nullptr;    // hidden epochs of the window's composite factors (caller memory)
     int comp_e0 = 0, comp_ne = 0;                       // their range in the batch-wide hidden-epoch arrays
     std::vector<int> p_orig;                            // device observation (proj0 + q) -> the caller's projection factor index
+    int n_proj_all = 0;                                 // the caller's projection factors, fast path + generic path (GF_PROJX)
 };
 
 struct swf_batch {
@@ -76,7 +77,7 @@ struct swf_batch {
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
     int max_tiles = 0, max_prior_dim = 0, max_red = 0, min_red = 1 << 30, n_cu = 256;
-    bool clc_imu[3] = { false, false, false };
+    bool clc_imu[4] = { false, false, false, false };
     // composite IMU-GNSS factors of the batch (swf_kernels4.h): operator arguments, solver-side bookkeeping, initial hidden epochs
     CompArgs CA{}; CompMeta CM{}; int n_comp = 0; long long comp_ne = 0;
     double* co_pose0 = nullptr; double* co_sb0 = nullptr;    // clique class holds IMU factors (its elimination must follow k_eval_imu)
@@ -186,9 +187,20 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     auto gloc = [&](int b) { return loc[b] >= 0 ? R.loc_base + loc[b] : -1; };
     auto gx = [&](int b) { return R.x_base + xo[b]; };
 
-    // ---- projection observations sorted by (landmark, pose)
-    std::vector<int> ord(w->n_proj);
-    for (int i = 0; i < w->n_proj; i++) ord[i] = i;
+    // ---- which landmarks leave the fast path (k_lm_schur: world point in group 0, constant extrinsic, one factor per frame)
+    // for the generic one (GF_PROJX factors in cliques): a variable extrinsic on any of its factors — the reference's
+    // marginalisation solves un-freeze para_ex_Pose (R/swf/swf_image.cpp:384-389) — or a variable landmark outside group 0
+    std::vector<char> lm_generic(nL, 0);
+    for (int i = 0; i < w->n_proj; i++) {
+        int p = w->proj_idx[i * 3], ex = w->proj_idx[i * 3 + 1], l = w->proj_idx[i * 3 + 2];
+        if (p < 0 || p >= nP || ex < 0 || ex >= nP || l < 0 || l >= nL) return fail(SWF_E_INVALID, "projection factor: index out of range");
+        if (loc[bidP(ex)] >= 0 || (loc[bidL(l)] >= 0 && !is_e(bidL(l)))) lm_generic[l] = 1;
+    }
+    hw.n_proj_all = w->n_proj;
+    // ---- projection observations of the fast path sorted by (landmark, pose)
+    std::vector<int> ord;
+    for (int i = 0; i < w->n_proj; i++) if (!lm_generic[w->proj_idx[i * 3 + 2]]) ord.push_back(i);
+    const int n_fast = (int)ord.size();
     std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
         int la = w->proj_idx[a * 3 + 2], lb = w->proj_idx[b * 3 + 2];
         if (la != lb) return la < lb;
@@ -198,12 +210,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     std::vector<int> frame_of(nP, -1);
     {
         std::vector<char> seen(nP, 0);
-        for (int i = 0; i < w->n_proj; i++) {
-            int p = w->proj_idx[i * 3];
-            if (p < 0 || p >= nP || w->proj_idx[i * 3 + 1] < 0 || w->proj_idx[i * 3 + 1] >= nP || w->proj_idx[i * 3 + 2] < 0 || w->proj_idx[i * 3 + 2] >= nL)
-                return fail(SWF_E_INVALID, "projection factor: index out of range");
-            seen[p] = 1;
-        }
+        for (int i : ord) seen[w->proj_idx[i * 3]] = 1;
         int nf = 0;
         for (int p = 0; p < nP; p++) if (seen[p] && loc[bidP(p)] >= 0) {
             if (is_e(bidP(p))) return fail(SWF_E_UNSUPPORTED, "pose block in elimination group 0");
@@ -217,10 +224,9 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     {
         std::vector<std::vector<int>> fobs(R.nF);
         std::vector<int> lm_first(nL + 1, 0);
-        for (int q = 0; q < w->n_proj; q++) {
+        for (int q = 0; q < n_fast; q++) {
             int i = ord[q];
             int p = w->proj_idx[i * 3], ex = w->proj_idx[i * 3 + 1], l = w->proj_idx[i * 3 + 2];
-            if (loc[bidP(ex)] >= 0) return fail(SWF_E_UNSUPPORTED, "variable camera extrinsic (ESTIMATE_EXTRINSIC) not supported by the kernels yet");
             if (q > 0 && w->proj_idx[ord[q - 1] * 3 + 2] == l && w->proj_idx[ord[q - 1] * 3] == p && frame_of[p] >= 0)
                 return fail(SWF_E_UNSUPPORTED, "two projection factors of one landmark in the same frame");
             int gi = (int)B.p_win.size();
@@ -235,10 +241,9 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         for (int l = 0; l < nL; l++) lm_first[l + 1] += lm_first[l];
         for (int l = 0; l < nL; l++) {
             int b = bidL(l);
-            if (loc[b] >= 0 && !is_e(b)) return fail(SWF_E_UNSUPPORTED, "variable landmark outside elimination group 0");
             B.lm_win.push_back(wi);
             B.lm_obs0.push_back(R.proj0 + lm_first[l]);
-            B.lm_loc.push_back(gloc(b));
+            B.lm_loc.push_back(lm_generic[l] ? -1 : gloc(b));        // a generic-path landmark has no observations here: an inactive record
             B.lm_col.push_back(3 * l);
             B.lm_fmask.push_back(0ULL);
         }
@@ -374,6 +379,16 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         B.gx_dat.insert(B.gx_dat.end(), w->idp_pts + (size_t)i * 6, w->idp_pts + (size_t)(i + 1) * 6);
         { int g = add_gf(GF_IDP, 2, data, blks); B.sc_gf.push_back(g); B.idp_gf.push_back(g); }
     }
+    // world-point projection factors of the generic path (GF_PROJX): record = uv; GFac.pad = the caller's factor index
+    for (int i = 0; i < w->n_proj; i++) {
+        const int* ix = w->proj_idx + i * 3;
+        if (!lm_generic[ix[2]]) continue;
+        int data = (int)B.gx_dat.size();
+        B.gx_dat.push_back(w->proj_uv[i * 2]); B.gx_dat.push_back(w->proj_uv[i * 2 + 1]);
+        int g = add_gf(GF_PROJX, 2, data, { bidP(ix[0]), bidP(ix[1]), bidL(ix[2]) });
+        B.gf[g].pad = i;
+        B.sc_gf.push_back(g); B.idp_gf.push_back(g);
+    }
     std::vector<int> prior_first_gf;
     {
         int bo = 0; long long jo = 0; int ro = 0, x0o = 0;
@@ -460,7 +475,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     for (int i = 0; i < w->n_order; i++) {
         int b = w->order_block[i];
         if (w->order_group[i] != 0) break;
-        if (b >= nP + nS && b < nP + nS + nL) continue;
+        if (b >= nP + nS && b < nP + nS + nL && !lm_generic[b - nP - nS]) continue;      // fast-path landmarks: k_lm_schur
         e_clique[b] = (int)tc.size();
         tc.push_back(TmpC{ b, {}, {}, false });
     }
@@ -471,7 +486,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
             if (loc[b] < 0) continue;
             if (first_var < 0) first_var = b;
             if (is_e(b)) {
-                if (b >= nP + nS && b < nP + nS + nL) return fail(SWF_E_UNSUPPORTED, "non-projection factor on a landmark");
+                if (b >= nP + nS && b < nP + nS + nL && !lm_generic[b - nP - nS]) return fail(SWF_E_UNSUPPORTED, "non-projection factor on a landmark");
                 if (e >= 0 && e != b) return fail(SWF_E_INVALID, "elimination group 0 is not an independent set");
                 e = b;
             }
@@ -505,7 +520,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         for (int f : t.facs) { B.cl_fac.push_back(f); B.cl_frow.push_back(nrows); nrows += B.gf[f].nres; B.gf[f].clique = (int)B.cl.size(); }
         C.fac1 = (int)B.cl_fac.size();
         C.n_rows = nrows;
-        if (!t.is_static && nrows > CLQ_MAXR) return fail(SWF_E_UNSUPPORTED, "clique with more than 64 residual rows");
+
         C.mem0 = (int)B.cm_loc.size();
         int df = 0;
         std::map<int, int> colof;
@@ -515,7 +530,8 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         }
         C.mem1 = (int)B.cm_loc.size();
         C.d_f = df;
-        if (!t.is_static && C.d_e + df > CLQ_MAXD) return fail(SWF_E_UNSUPPORTED, "clique larger than 64 columns");
+        if (!t.is_static && C.d_e + df > CB_MAXD) return fail(SWF_E_UNSUPPORTED, "clique with more than 768 columns");
+        if (!t.is_static && C.d_e > 9) return fail(SWF_E_UNSUPPORTED, "group-0 block larger than 9 dimensions");
         C.C_off = B.C_tot; B.C_tot += (long long)df * df;
         C.v_off = B.v_tot; B.v_tot += df;
         C.e_off = B.e_tot; B.e_tot += C.d_e * C.d_e + C.d_e * df + C.d_e;
@@ -740,7 +756,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     D.n_pair = (int)B.pair.size();
     PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
     {
-        std::vector<int> pd, po, clc[3], cle;
+        std::vector<int> pd, po, clc[4], cle;
         for (size_t i = 0; i < B.pair.size(); i++) {
             Pair& Pq = B.pair[i]; const WinRec& Rw = B.win[Pq.win];      // self-contained records (see Pair)
             Pq.fsb0 = Rw.fsb0; Pq.fsb1 = Rw.fsb1; Pq.n = Rw.n_red; Pq.m = 6 * Rw.nF; Pq.S_base = Rw.S_base; Pq.P_base = Rw.P_base;
@@ -755,7 +771,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             if (c.d_e > 0) cle.push_back((int)i);
             if (c.is_static) continue;
             int d = c.d_e + c.d_f;
-            int cls = (c.d_e <= 1 && d <= 32 && c.n_rows <= 48) ? 0 : (c.n_rows <= 32 && d <= 48) ? 1 : 2;
+            // one wavefront per clique up to 64 x 64 (three size classes); anything larger takes the workgroup kernel (class 3)
+            int cls = (c.d_e <= 1 && d <= 32 && c.n_rows <= 48) ? 0 : (c.n_rows <= 32 && d <= 48) ? 1 : (c.n_rows <= CLQ_MAXR && d <= CLQ_MAXD) ? 2 : 3;
             clc[cls].push_back((int)i);
             for (int q = c.fac0; q < c.fac1; q++) if (B.gf[B.cl_fac[q]].type == GF_IMU) b->clc_imu[cls] = true;
         }
@@ -770,7 +787,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             std::vector<Clique> v;
             for (int i : cle) v.push_back(B.cl[i]);
             PUT(cle_rec, v);
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < 4; k++) {
                 v.clear();
                 for (int i : clc[k]) v.push_back(B.cl[i]);
                 D.n_clc[k] = (int)clc[k].size(); rc |= P.put(v, &D.clc_rec[k]);
@@ -995,6 +1012,7 @@ struct Launcher {
             if (D.n_clc[1]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(1)); hipLaunchKernelGGL((k_clique_elim<32, 48, 9, 1>), dim3(D.n_clc[1]), dim3(64), 0, cstream(1), D, O); }
             if (D.n_clc[0]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(0)); hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, cstream(0), D, O); }
             if (D.n_clc[2]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(2)); hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, cstream(2), D, O); }
+            if (D.n_clc[3]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(3)); hipLaunchKernelGGL(k_clique_big, dim3(D.n_clc[3]), dim3(256), 0, cstream(3), D, O); }
             if (lm_second) {
                 // the second tile range writes nothing but its tiles of P (k_lm_schur: outs), so on the latency path it runs behind the
                 // IMU / clique branch, next to the first range
@@ -1308,8 +1326,9 @@ extern "C" int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, dou
     std::vector<GFac> gf((size_t)std::max(ngf, 0));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (ngf > 0) HIPCHK(hipMemcpy(gf.data(), D.gf + W.gf0, (size_t)ngf * sizeof(GFac), hipMemcpyDeviceToHost));
-    int nres = 2 * nobs;
-    for (const GFac& G : gf) nres += G.nres;
+    const int nproj_all = b->hw[w].n_proj_all;
+    int nres = 2 * nproj_all;
+    for (const GFac& G : gf) if (G.type != GF_PROJX) nres += G.nres;
     if (n_res_out) *n_res_out = nres;
     if (n_loc_out) *n_loc_out = W.n_loc;
     if (!r && !J) return SWF_OK;
@@ -1336,8 +1355,10 @@ extern "C" int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, dou
             }
         }
     }
-    size_t row = 2 * (size_t)nobs;
+    size_t row_seq = 2 * (size_t)nproj_all;
     for (const GFac& G : gf) {
+        // generic-path projection factors sit at the caller's projection index; every other family follows in factor order
+        const size_t row = G.type == GF_PROJX ? 2 * (size_t)G.pad : row_seq;
         std::vector<int> sloc((size_t)G.nslot), sls((size_t)G.nslot), sj((size_t)G.nslot), spc((size_t)G.nslot);
         ok &= dl(sloc.data(), D.s_loc + G.slot0, (size_t)G.nslot * 4); ok &= dl(sls.data(), D.s_ls + G.slot0, (size_t)G.nslot * 4);
         ok &= dl(sj.data(), D.s_joff + G.slot0, (size_t)G.nslot * 4); ok &= dl(spc.data(), D.s_pcol + G.slot0, (size_t)G.nslot * 4);
@@ -1362,7 +1383,7 @@ extern "C" int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, dou
                     J[(row + k) * nl + (sloc[sl] - W.loc_base) + c] = blk[(size_t)c * G.jld + k];
             }
         }
-        row += G.nres;
+        if (G.type != GF_PROJX) row_seq += G.nres;
     }
     if (!ok) return fail(SWF_E_NODEVICE, "download failed");
     return SWF_OK;

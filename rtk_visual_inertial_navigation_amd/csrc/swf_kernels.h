@@ -356,7 +356,7 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
     if (JAC ? !s.need_lin : !s.eval_cand) return;
-    if (G.type == GF_IDP) return;          // two-row inverse-depth projections: their own kernel (k_eval_idp), they only share the J v code
+    if (G.type == GF_IDP || G.type == GF_PROJX) return;          // two-row projection factors: their own kernel (k_eval_idp), they only share the J v code
     const WinRec& W = B.win[G.win];
     const double* xs = JAC ? B.x : B.xc;
     int s0 = G.slot0, ld = G.jld;          // column stride of the clique's dense column-major Jacobian
@@ -469,6 +469,63 @@ __global__ void __launch_bounds__(128) k_eval_idp(DevBatch B) {
     const WinRec& W = B.win[G.win];
     const double* xs = JAC ? B.x : B.xc;
     int s0 = G.slot0, ld = G.jld;
+    if (G.type == GF_PROJX) {
+        // projection_factor::Evaluate (R/factor/projection_factor.cpp:13-65) with ALL THREE Jacobian blocks: pose_j, the camera
+        // extrinsic (:50-57) and the landmark.  This is the generic-path twin of d_eval_proj: same residual, same corrector; used
+        // when the extrinsic is variable (GlobalMarge un-freezes it, R/swf/swf_image.cpp:384-389) or the landmark is not in group 0.
+        const double* dat = B.gx_dat + G.data;          // uv
+        const double* pose = xs + B.s_x[s0]; const double* ex = xs + B.s_x[s0 + 1]; const double* lm = xs + B.s_x[s0 + 2];
+        double Qj_inv[4], qic_inv[4], d[3], pts_imu[3], t[3], pc[3];
+        qinv(pose + 3, Qj_inv); qinv(ex + 3, qic_inv);
+        d[0] = lm[0] - pose[0]; d[1] = lm[1] - pose[1]; d[2] = lm[2] - pose[2];
+        qrot(Qj_inv, d, pts_imu);
+        t[0] = pts_imu[0] + W.pbg[0] - ex[0]; t[1] = pts_imu[1] + W.pbg[1] - ex[1]; t[2] = pts_imu[2] + W.pbg[2] - ex[2];
+        qrot(qic_inv, t, pc);
+        double dep = pc[2], si = W.proj_sqrt_info;
+        double r0 = si * (pc[0] / dep - dat[0]), r1 = si * (pc[1] / dep - dat[1]);
+        double sr = 1.0, cost, sq = r0 * r0 + r1 * r1;
+        if (W.proj_loss_a > 0) {
+            double b = W.proj_loss_a * W.proj_loss_a, c = 1.0 / b;
+            double sum = 1.0 + sq * c, inv = 1.0 / sum;
+            cost = 0.5 * b * log(sum);
+            sr = sqrt(inv > 2.2250738585072014e-308 ? inv : 2.2250738585072014e-308);
+        } else cost = 0.5 * sq;
+        B.g_cost[f] = cost;
+        if (!JAC) return;
+        B.g_r[G.roff] = r0 * sr; B.g_r[G.roff + 1] = r1 * sr;
+        double Rj[9], ric[9], ricT[9], RjT[9], A[9], S[9], Bm[9];
+        q2R(pose + 3, Rj); q2R(ex + 3, ric);
+        mat3T(ric, ricT); mat3T(Rj, RjT);
+        double red[6] = { si * (1. / dep), 0, si * (-pc[0] / (dep * dep)), 0, si * (1. / dep), si * (-pc[1] / (dep * dep)) };
+        mat3mul(ricT, RjT, A);
+        int jo = B.s_joff[s0];
+        if (jo >= 0) {
+            skew3(pts_imu, S); mat3mul(ricT, S, Bm);
+            for (int a = 0; a < 2; a++) for (int j = 0; j < 3; j++) {
+                double u = 0, v = 0;
+                for (int k = 0; k < 3; k++) { u += red[a * 3 + k] * -A[k * 3 + j]; v += red[a * 3 + k] * Bm[k * 3 + j]; }
+                B.g_J[jo + j * ld + a] = u * sr; B.g_J[jo + (3 + j) * ld + a] = v * sr;
+            }
+        }
+        jo = B.s_joff[s0 + 1];
+        if (jo >= 0) {
+            skew3(pc, S);
+            for (int a = 0; a < 2; a++) for (int j = 0; j < 3; j++) {
+                double u = 0, v = 0;
+                for (int k = 0; k < 3; k++) { u += red[a * 3 + k] * -ricT[k * 3 + j]; v += red[a * 3 + k] * S[k * 3 + j]; }
+                B.g_J[jo + j * ld + a] = u * sr; B.g_J[jo + (3 + j) * ld + a] = v * sr;
+            }
+        }
+        jo = B.s_joff[s0 + 2];
+        if (jo >= 0) {
+            for (int a = 0; a < 2; a++) for (int j = 0; j < 3; j++) {
+                double u = 0;
+                for (int k = 0; k < 3; k++) u += red[a * 3 + k] * A[k * 3 + j];
+                B.g_J[jo + j * ld + a] = u * sr;
+            }
+        }
+        return;
+    }
     {
         // inverse-depth projection factor (2 residual rows): record = kind | pts_i (3) | pts_j (3); slots in the reference's block order
         const double* dat = B.gx_dat + G.data;
@@ -1205,6 +1262,113 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
         }
     }
     QST(5);
+}
+
+// =========================================================================================
+// Cliques beyond one wavefront's reach (more than 64 residual rows or 64 columns): the group-0 block of a landmark with a
+// long track on the generic path — an inverse-depth feature seen from ten or more frames (2 rows and 6 columns per
+// frame), or a world-point landmark whose factors also touch a VARIABLE camera extrinsic, as in the reference's
+// marginalisation solves (GlobalMarge un-freezes para_ex_Pose, R/swf/swf_image.cpp:384-389).  Same outputs as
+// k_clique_elim, one 256-thread workgroup per clique, the dense column-major Jacobian staged in LDS when it fits and read
+// from L2 otherwise.  This is the general path, not the fast one: the fast paths are k_lm_schur (world points, constant
+// extrinsic) and k_clique_elim (everything up to 64 x 64).
+//   thread c:       column c of M_e* = J_e^T J, g_c = J_c^T r, M_cc
+//   thread 0:       (M_ee + mu D)^-1 by Gauss-Jordan (d_e <= 9)
+//   thread j:       column j of T = Einv M_ef
+//   thread (i, j):  C_ij = J_i . J_j - M_ei . T_j over the lower triangle
+// =========================================================================================
+#define CB_MAXD 768                           // columns of a big clique (d_e + d_f)
+#define CB_LDS_J 12288                        // doubles of Jacobian staged in LDS (96 KB); larger ones are read through L2
+__global__ void __launch_bounds__(256) k_clique_big(DevBatch B, DevOpt O) {
+    __shared__ double Me[9][CB_MAXD];         // rows of M that belong to e; 54 KB
+    __shared__ double Ei[9][10];
+    __shared__ double Eg[9], ge[9];
+    __shared__ int bad_s;
+    __shared__ double Jl[CB_LDS_J];           // the staged Jacobian [d][nrow], when it fits
+    if ((int)blockIdx.x >= B.n_clc[3]) return;
+    const Clique& C = B.clc_rec[3][blockIdx.x];
+    WinState& s = B.ws[C.win];
+    if (!s.need_lin) return;
+    const int de = C.d_e, df = C.d_f, d = de + df, nrow = C.n_rows, tid = threadIdx.x;
+    const double* gJ = B.g_J + C.j_off;
+    const double* rv = B.g_r + C.r_off;
+    const bool staged = (long long)nrow * d <= CB_LDS_J;
+    if (staged) for (int e = tid; e < nrow * d; e += 256) Jl[e] = gJ[e];
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    const double* Jc = staged ? Jl : gJ;
+    // 1. M_e*, gradient, diagonal: one column per thread and round
+    for (int c = tid; c < d; c += 256) {
+        const double* col = Jc + (size_t)c * nrow;
+        double gc = 0, mcc = 0, me[9];
+#pragma unroll
+        for (int a = 0; a < 9; a++) me[a] = 0;
+        for (int k = 0; k < nrow; k++) {
+            double x = col[k];
+            gc += x * rv[k]; mcc += x * x;
+#pragma unroll
+            for (int a = 0; a < 9; a++) if (a < de) me[a] += Jc[(size_t)a * nrow + k] * x;
+        }
+#pragma unroll
+        for (int a = 0; a < 9; a++) Me[a][c] = a < de ? me[a] : 0.0;
+        if (c < de) { B.g[C.e_loc + c] = gc; B.diag[C.e_loc + c] = mcc; B.vc[C.e_loc + c] = gc / clampd(mcc, O.min_diag, O.max_diag); ge[c] = gc; }
+        else { B.cv_graw[C.v_off + c - de] = gc; B.cv_dgraw[C.v_off + c - de] = mcc; }
+    }
+    __syncthreads();
+    double* Cm = B.C + C.C_off;
+    if (de > 0) {
+        // 2. Einv = (M_ee + mu D)^-1, Gauss-Jordan without pivoting (SPD), one thread
+        if (tid == 0) {
+            double A[9][18];
+            for (int i = 0; i < de; i++) for (int j = 0; j < de; j++) { A[i][j] = Me[i][j]; A[i][9 + j] = i == j ? 1.0 : 0.0; }
+            for (int i = 0; i < de; i++) A[i][i] += s.mu * clampd(A[i][i], O.min_diag, O.max_diag);
+            bool bad = false;
+            for (int k = 0; k < de; k++) {
+                double piv = A[k][k];
+                if (!(piv > 0.0)) { bad = true; break; }
+                double ip = 1.0 / piv;
+                for (int j = 0; j < de; j++) { A[k][j] *= ip; A[k][9 + j] *= ip; }
+                for (int i = 0; i < de; i++) {
+                    if (i == k) continue;
+                    double f = A[i][k];
+                    for (int j = 0; j < de; j++) { A[i][j] -= f * A[k][j]; A[i][9 + j] -= f * A[k][9 + j]; }
+                }
+            }
+            if (bad) { s.lin_fail = 1; bad_s = 1; }
+            for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) Ei[i][j] = (!bad && i < de && j < de) ? A[i][9 + j] : 0.0;
+            for (int i = 0; i < 9; i++) { double v = 0; for (int j = 0; j < de; j++) v += Ei[i][j] * ge[j]; Eg[i] = v; }
+        }
+        __syncthreads();
+        if (bad_s) return;
+        // 3. what the back-substitution needs (Einv | M_ef | g_e) and cs = -M_fe Einv g_e
+        double* E = B.cE + C.e_off;
+        for (int e = tid; e < de * de; e += 256) E[e] = Ei[e / de][e % de];
+        for (int j = tid; j < df; j += 256) {
+            double v = 0;
+            for (int a = 0; a < de; a++) { E[de * de + a * df + j] = Me[a][de + j]; v -= Me[a][de + j] * Eg[a]; }
+            B.cv_cs[C.v_off + j] = v;
+        }
+        if (tid < de) E[de * de + de * df + tid] = ge[tid];
+    } else {
+        for (int j = tid; j < df; j += 256) B.cv_cs[C.v_off + j] = 0.0;
+    }
+    // 4. C = M_ff - M_fe Einv M_ef over the lower triangle (mirrored on write); T_j = Einv M_e,j formed on the fly
+    const long long ntri = (long long)df * (df + 1) / 2;
+    for (long long t = tid; t < ntri; t += 256) {
+        int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long long)(i + 1) * (i + 2) / 2 <= t) i++;
+        while ((long long)i * (i + 1) / 2 > t) i--;
+        int j = (int)(t - (long long)i * (i + 1) / 2);
+        const double* ci = Jc + (size_t)(de + i) * nrow; const double* cj = Jc + (size_t)(de + j) * nrow;
+        double m = 0;
+        for (int k = 0; k < nrow; k++) m += ci[k] * cj[k];
+        for (int a = 0; a < de; a++) {
+            double tj = 0;
+            for (int b2 = 0; b2 < de; b2++) tj += Ei[a][b2] * Me[b2][de + j];
+            m -= Me[a][de + i] * tj;
+        }
+        Cm[(size_t)i * df + j] = m; Cm[(size_t)j * df + i] = m;
+    }
 }
 
 // =========================================================================================

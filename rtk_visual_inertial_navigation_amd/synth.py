@@ -470,6 +470,25 @@ def make_window(config_id=3, seed=None, K=None, F=None, S=None, prior=None, pert
     return win
 
 
+def with_variable_extrinsic(win, head=False):
+    """The same window with the camera extrinsic un-frozen, as the reference's marginalisation solves have it (GlobalMarge sets
+    every parameter_head block variable, para_ex_Pose among them: R/swf/swf_image.cpp:384-389) and as ESTIMATE_EXTRINSIC = 1
+    builds optimise it (R/swf/swf_image.cpp:168-177).  MyOrdering places it behind the poses (:712-718), or in the
+    parameter_head tail with head = True."""
+    w = win.copy()
+    roles = {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in w.meta["roles"].items()}
+    is_const = w.a["is_const"].copy()
+    for b in roles["extrinsics"]:
+        is_const[b] = 0
+    if head:
+        roles["parameter_head"] = list(roles["parameter_head"]) + list(roles["extrinsics"])
+    ob, og, nt = my_ordering(roles, is_const)
+    w.a["is_const"] = np.ascontiguousarray(is_const, np.uint8)
+    w.a["order_block"], w.a["order_group"], w.n_tail = ob, og, int(nt)
+    w.meta["roles"] = roles
+    return w
+
+
 def with_spp_and_fixed(win, seed=7, n_fix=4, spp_stride=2):
     """Copy of an RTK window with rover-only and fixed-integer factors added on its existing blocks
     (a separate random stream, so the base window and the goldens made from it do not change):

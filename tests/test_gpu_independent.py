@@ -39,7 +39,12 @@ def _family_windows():
             ("spp+fixed", synth.with_spp_and_fixed(synth.make_window(3, K=5, F=14, S=6, seed=4), seed=3, n_fix=3)),
             ("inverse depth", idepth_gen.convert_short_tracks(synth.make_window(2, K=8, F=30, S=0, seed=4))),
             ("dense prior", synth.make_window(5, K=14, F=40, S=4, seed=10)),
-            ("cfg3", synth.make_window(3))]
+            ("cfg3", synth.make_window(3)),
+            # the generic clique path: world-point landmarks whose factors touch a VARIABLE extrinsic (what GlobalMarge solves), and
+            # inverse-depth features tracked over the whole window (cliques beyond one wavefront: k_clique_big)
+            ("variable extrinsic", synth.with_variable_extrinsic(synth.make_window(2, K=6, F=30, S=0, seed=13))),
+            ("variable extrinsic in parameter_head", synth.with_variable_extrinsic(synth.make_window(3, K=6, F=30, S=5, seed=14), head=True)),
+            ("long inverse-depth tracks", idepth_gen.convert_short_tracks(synth.make_window(2, K=16, F=30, S=0, seed=6), max_track=16))]
 
 
 @pytest.mark.parametrize("name,w", _family_windows(), ids=[n for n, _ in _family_windows()])

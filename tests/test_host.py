@@ -82,12 +82,12 @@ def test_no_cpu_fallback_without_gpu():
         solver.BatchSolver([w])
 
 
-def _compile_shim_example(tmp_path):
+def _compile_shim_example(tmp_path, name="shim_example"):
     import subprocess
     build.build()
-    exe = os.path.join(str(tmp_path), "shim_example")
+    exe = os.path.join(str(tmp_path), name)
     libdir = os.path.dirname(solver.LIB_PATH)
-    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "shim_example.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", name + ".cpp"),
                            "-o", exe, "-L" + libdir, "-lswf_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-lamdhip64",
                            "-Wl,-rpath,/opt/rocm/lib"])
     return exe
@@ -103,6 +103,22 @@ def test_ceres_shaped_cpp_header_compiles_and_fails_loudly_without_gpu(tmp_path)
         pytest.skip("a GPU is present (the run is covered by the gpu test)")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "Final cost: 1.000000e+300" in r.stdout
+
+
+def test_globalmarge_sequence_compiles_against_the_adapter(tmp_path):
+    """SWFOptimization::GlobalMarge (R/swf/swf_image.cpp:343-433) statement by statement — GetParameterBlocks, GetResidualBlocks,
+    ->is_use, GetResidualBlocksForParameterBlock, GetParameterBlocksForResidualBlock, parameter_head, is_optimize — compiles
+    against include/swf_ceres.hpp (it runs on the GPU tier)."""
+    _compile_shim_example(tmp_path, "shim_globalmarge")
+
+
+@pytest.mark.gpu
+def test_globalmarge_sequence_runs_on_gpu(tmp_path):
+    import subprocess
+    exe = _compile_shim_example(tmp_path, "shim_globalmarge")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GlobalMarge: 4 kept blocks, prior n = 24" in r.stdout and "position error after the slide" in r.stdout
 
 
 @pytest.mark.gpu
