@@ -109,8 +109,12 @@ int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, double* J, int
  *                         dropped — the reference's form; rank = number kept.  Eigenvector signs are not defined.
  *     SWF_PRIOR_CHOLESKY  J = L_nn^T, r0 = L_nn^T y_n: the same quadratic without an eigen-decomposition (rank = n).
  * The reference pseudo-inverts S_mm through an eigen-decomposition with threshold 1e-8; this library uses the Cholesky
- * factor of the solve, which is the same thing whenever S_mm is positive definite.  If the factorisation failed the
- * window's rank is reported as -1 (no silent fallback).  SWF_PRIOR_EIGEN: n <= 256 (the Jacobi iteration keeps M in LDS up to n = 140, in an HBM scratch above);
+ * factor of the solve, which is the same thing whenever S_mm is positive definite.  A marginal that is SINGULAR on the kept
+ * states (an unobservable extrinsic, a direction nobody measured) is normal in the reference — its eigen square root drops
+ * the null directions — while the factorisation of the whole S breaks down in the tail of such a window (the solve reports
+ * SWF_LINEAR_SOLVER_FAILURE): SWF_PRIOR_EIGEN then re-factors the first m columns only and takes a rank-revealing factor of
+ * A (rank < n is reported, the prior is valid); SWF_PRIOR_CHOLESKY has no such variant and reports rank -1.  A breakdown
+ * inside S_mm itself is a failure in both forms (rank -1, no silent fallback).  SWF_PRIOR_EIGEN: n <= 256 (the Jacobi iteration keeps M in LDS up to n = 140, in an HBM scratch above);
  * SWF_PRIOR_CHOLESKY: n <= 512.  Asynchronous on the batch stream. */
 enum { SWF_PRIOR_EIGEN = 0, SWF_PRIOR_CHOLESKY = 1 };
 int swf_batch_marginalize(swf_batch* b, double eps, int32_t form);

@@ -84,6 +84,7 @@ struct swf_batch {
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
     int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr; double* mg_M = nullptr;
     bool mg_valid = false; int mg_ld = 0;
+    double* mg_resM = nullptr; double* mg_resb = nullptr; int* mg_resok = nullptr;      // k_marg_rescue outputs (rank-deficient tails)
     // ambiguity covariance hand-off outputs (allocated at the first swf_batch_tail_covariance)
     int* tc_tail = nullptr; double* tc_A = nullptr; double* tc_Q = nullptr; double* tc_X = nullptr; int* tc_rank = nullptr; bool tc_valid = false; int tc_ld = 0;
     // latency path (small batches): an auxiliary stream runs the IMU / clique branch of a linearisation next to the
@@ -1238,15 +1239,22 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
         rc |= b->pool.zeros((size_t)nw * ldn * ldn, &b->mg_A); rc |= b->pool.zeros((size_t)nw * ldn * ldn, &b->mg_J);
         rc |= b->pool.zeros((size_t)nw * ldn, &b->mg_b); rc |= b->pool.zeros((size_t)nw * ldn, &b->mg_r0); rc |= b->pool.zeros((size_t)nw * ldn, &b->mg_w);
         rc |= b->pool.zeros((size_t)nw, &b->mg_rank);
+        rc |= b->pool.zeros((size_t)nw * ldn * ldn, &b->mg_resM); rc |= b->pool.zeros((size_t)nw * ldn, &b->mg_resb); rc |= b->pool.zeros((size_t)nw, &b->mg_resok);
         if (rc) return fail(SWF_E_NODEVICE, "device allocation failed");
     }
     const bool big = form == SWF_PRIOR_EIGEN && ldn > MG_MAXN;
     if (big && !b->mg_M && b->pool.zeros((size_t)nw * ldn * ldn, &b->mg_M)) return fail(SWF_E_NODEVICE, "device allocation failed");
+    // windows whose factorisation broke down in the tail (a marginal that is singular on the kept states): partial factorisation +
+    // rank-revealing factor of A; every other window leaves this kernel at once
+    if (form == SWF_PRIOR_EIGEN)
+        hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), 0, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok);
     hipLaunchKernelGGL(k_marginalize<false>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
-                       b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, (double*)nullptr);
+                       b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, (double*)nullptr,
+                       (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok);
     if (big)
         hipLaunchKernelGGL(k_marginalize<true>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
-                           b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M);
+                           b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M,
+                           (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok);
     HIPCHK(hipGetLastError());
     b->mg_valid = true;
     return SWF_OK;

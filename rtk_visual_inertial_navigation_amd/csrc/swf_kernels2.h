@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? CH_OCC : 4) k_chol_solve(DevBa
 #ifdef SWF_PROFILE_CHOL
         CHACC(10, tph); tph = __builtin_amdgcn_s_memtime();
 #endif
-        if (fail) { if (tid == 0) s.lin_fail = 1; return; }
+        if (fail) { if (tid == 0) { s.lin_fail = 1; s.chol_fail = 1; } return; }
         // triangular solve for the rows below the block: x L_d^T = acc
         if (active && r >= J0 + nb) {
 #pragma unroll
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
-            if (fail) { if (tid == 0) st.lin_fail = 1; return; }
+            if (fail) { if (tid == 0) { st.lin_fail = 1; st.chol_fail = 1; } return; }
             __syncthreads();                               // C_j
             CHACC(10, tq);
 #ifdef SWF_PROFILE_CHOL
@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
-            if (fail) { if (tid == 0) st.lin_fail = 1; return; }
+            if (fail) { if (tid == 0) { st.lin_fail = 1; st.chol_fail = 1; } return; }
             __syncthreads();                               // C_j
             CHACC(10, tq);
 #ifdef SWF_PROFILE_CHOL
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
         pivot(j);
     }
     __syncthreads();
-    if (fail) { if (g == 0 && tid == 0) st.lin_fail = 1; return; }
+    if (fail) { if (g == 0 && tid == 0) { st.lin_fail = 1; st.chol_fail = 1; } return; }
 #pragma unroll
     for (int u = 0; u < PPW; u++) { int I = j + 1 + wv + NW * u; if (I < Tr) panel(Pn, I, j, pv[u]); }
     __syncthreads();
@@ -947,7 +947,7 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
         __syncthreads();                                   // the updated diagonal tile is in Dt (written by wave 0 itself: I = j + 1)
         if (wv == 0) pivot(j + 1);
         __syncthreads();
-        if (fail) { if (g == 0 && tid == 0) st.lin_fail = 1; return; }
+        if (fail) { if (g == 0 && tid == 0) { st.lin_fail = 1; st.chol_fail = 1; } return; }
 #pragma unroll
         for (int u = 0; u < PPW; u++) { int I = j + 1 + wv + NW * u; if (I > j + 1 && I < Tr) panel(Pn2, I, j + 1, pw[u]); }
         __syncthreads();
@@ -1229,7 +1229,7 @@ __global__ void __launch_bounds__(256) k_init(DevBatch B, DevOpt O) {
         s.lm_dec = 2.0;
         s.x_cost = 0; s.x_norm = xn; s.alpha = 0; s.dogleg_step_norm = 0; s.step_norm = 0; s.gmax = 0;
         s.jg_sq = 0; s.initial_cost = 0;
-        s.status = SWF_RUNNING; s.iter = 0; s.need_lin = 1; s.reuse = 0; s.eval_cand = 0; s.lin_fail = 0;
+        s.status = SWF_RUNNING; s.iter = 0; s.need_lin = 1; s.reuse = 0; s.eval_cand = 0; s.lin_fail = 0; s.chol_fail = 0;
         s.invalid_run = 0; s.nsucc = 0; s.nunsucc = 0;
     }
 }
@@ -1301,7 +1301,7 @@ __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
             if (s.lin_fail) {
                 // Gauss-Newton solve failed: DoglegStrategy raises mu; HandleInvalidStep
                 rec.step_is_valid = 0; rec.cost = s.x_cost; rec.trust_region_radius = s.radius;
-                s.lin_fail = 0; s.eval_cand = 0;
+                s.lin_fail = 0; s.chol_fail = 0; s.eval_cand = 0;
                 s.reuse = 0; s.need_lin = 1;
                 if (O.strategy == SWF_LEVENBERG_MARQUARDT) {
                     // LevenbergMarquardtStrategy::StepIsInvalid = StepRejected(0)

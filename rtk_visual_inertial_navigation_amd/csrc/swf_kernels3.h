@@ -21,10 +21,94 @@
 // ldn = leading dimension of the per-window output slabs (>= every window's tail dimension)
 // GM = false: tails up to MG_MAXN, M in LDS (and every Cholesky-form request); GM = true: eigen form for MG_MAXN < n <= MG_BIGN with M
 // in Mscr (same algorithm, same rotation order).  A batch launches both; each instantiation skips the other's windows.
+// ---------------------------------------------------------------------------------------------------------------------
+// Rank-deficient tails.  The reference pseudo-inverts only S_mm (UpdateSchur) and lets the eigen square root drop the null
+// directions of A (setmarginalizeinfo): a marginal that is singular on the kept states — an unobservable camera extrinsic, a
+// yaw nobody measured — is business as usual there.  The Cholesky of ALL of S fails on such a window (in its last n columns),
+// and L_nn with it.  This kernel steps in for exactly those windows (WinState::chol_fail): a right-looking Cholesky of the
+// first m columns only, in the window's (now free) L buffer, leaves the Schur complement A and the reduced right-hand side b
+// in the trailing block; a diagonally pivoted outer-product Cholesky of A then yields rows v_r with sum_r v_r v_r^T = A up to
+// the pivots it drops (rank-revealing: it stops at pivots below 1e-14 of the largest).  k_marginalize takes M = [v_r] and b
+// from here instead of L_nn / y_n.  A non-positive pivot among the first m columns is a real failure (rank -1).
+// One 1024-thread workgroup per window; this is the slow, rare path.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tail_dim, int ldn, double* resM, double* resb, int* res_ok) {
+    __shared__ double red_v[16]; __shared__ int red_i[16];
+    __shared__ double piv_s; __shared__ int piv_i, stop_s;
+    int w = blockIdx.x, tid = threadIdx.x;
+    const WinRec& W = B.win[w];
+    const WinState& s = B.ws[w];
+    if (tid == 0) res_ok[w] = 0;
+    if (!s.chol_fail) return;
+    const int n = tail_dim[w], nr = W.n_red, m = nr - n;
+    if (n <= 0 || n > ldn || m < 0) return;
+    double* Wk = B.L + W.Lt_base;                       // (nr + 1) rows x nr columns, row-major; row nr carries the right-hand side
+    const double* S = B.S + W.S_base;
+    for (size_t e = tid; e < (size_t)(nr + 1) * nr; e += 1024) Wk[e] = S[e];
+    __syncthreads();
+    for (int j = 0; j < m; j++) {
+        double piv = Wk[(size_t)j * nr + j];
+        if (!(piv > 0.0)) return;                        // uniform: every thread reads the same value
+        double id = 1.0 / sqrt(piv);
+        __syncthreads();
+        for (int i = j + tid; i <= nr; i += 1024) Wk[(size_t)i * nr + j] = i == j ? sqrt(piv) : Wk[(size_t)i * nr + j] * id;
+        __syncthreads();
+        // trailing update of the lower triangle (and of the right-hand-side row): rows i in (j, nr], columns k in (j, min(i, nr - 1)]
+        const int rem = nr - j;                          // rows j+1 .. nr  ->  rem rows
+        for (long long t = tid; t < (long long)rem * (rem - 1 + 1); t += 1024) {
+            int ii = (int)(t / rem), kk = (int)(t - (long long)ii * rem);   // ii: 0..rem-1 -> row j+1+ii ; kk: 0..rem-1 -> column j+1+kk
+            int i = j + 1 + ii, k = j + 1 + kk;
+            if (k > i || k >= nr) continue;
+            Wk[(size_t)i * nr + k] -= Wk[(size_t)i * nr + j] * Wk[(size_t)k * nr + j];
+        }
+        __syncthreads();
+    }
+    // A = trailing n x n block (lower), b = right-hand-side row; mirror A into the scratch as a full symmetric matrix
+    double* M = resM + (size_t)w * ldn * ldn;           // first the working copy of A (full symmetric, ld = n), finally the rows v_r
+    for (int e = tid; e < n * n; e += 1024) { int i = e / n, k = e - i * n; M[e] = i >= k ? Wk[(size_t)(m + i) * nr + m + k] : Wk[(size_t)(m + k) * nr + m + i]; }
+    for (int i = tid; i < n; i += 1024) resb[(size_t)w * ldn + i] = Wk[(size_t)nr * nr + m + i];
+    __syncthreads();
+    // pivoted outer-product Cholesky on M (full symmetric n x n); row r of the result goes to V = Wk (n x n, ld = n; Wk has
+    // (nr + 1) * nr >= n * n doubles since nr >= n)
+    double* V = Wk;
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 1024) V[e] = 0.0;
+    if (tid == 0) stop_s = 0;
+    __syncthreads();
+    double d0 = 0;
+    for (int r = 0; r < n; r++) {
+        // arg max of the remaining diagonal (first index wins ties: deterministic)
+        double bv = -1.0; int bi = -1;
+        for (int i = tid; i < n; i += 1024) { double v = M[(size_t)i * n + i]; if (v > bv) { bv = v; bi = i; } }
+        for (int o = 32; o > 0; o >>= 1) { double ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64); if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; } }
+        if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double v = red_v[0]; int ix = red_i[0];
+            for (int q = 1; q < 16; q++) if (red_v[q] > v || (red_v[q] == v && red_i[q] >= 0 && (ix < 0 || red_i[q] < ix))) { v = red_v[q]; ix = red_i[q]; }
+            piv_s = v; piv_i = ix;
+        }
+        __syncthreads();
+        if (r == 0) d0 = piv_s;
+        if (!(piv_s > 1e-14 * d0) || !(piv_s > 0.0)) break;          // numerically zero remainder: rank r
+        const int p = piv_i; const double isq = 1.0 / sqrt(piv_s);
+        for (int i = tid; i < n; i += 1024) V[(size_t)r * n + i] = M[(size_t)i * n + p] * isq;
+        __syncthreads();
+        for (int e = tid; e < n * n; e += 1024) { int i = e / n, k = e - i * n; M[e] -= V[(size_t)r * n + i] * V[(size_t)r * n + k]; }
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) { M[(size_t)i * n + p] = 0.0; M[(size_t)p * n + i] = 0.0; }      // the eliminated index is exactly done
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 1024) M[e] = V[e];
+    if (tid == 0) res_ok[w] = 1;
+}
+
 template <bool GM>
 __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* tail_dim, double eps, int form, int ldn,
                                                         double* outA, double* outb, double* outJ, double* outr0,
-                                                        double* outw, int* outrank, double* Mscr) {
+                                                        double* outw, int* outrank, double* Mscr,
+                                                        const double* resM, const double* resb, const int* res_ok) {
     __shared__ double lds[GM ? 16 : MG_LDS_DOUBLES];  // M (n x n, column c contiguous: row c of L_nn) | V (n x n) if both fit
     __shared__ double lam[MG_BIGN];
     __shared__ double bv[MG_BIGN];
@@ -35,7 +119,8 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     int n = tail_dim[w], nr = W.n_red, m = nr - n;
     size_t o2 = (size_t)w * ldn * ldn, o1 = (size_t)w * ldn;
     if (GM != (form == 0 && n > MG_MAXN)) return;     // the other instantiation's window
-    if (n <= 0 || n > ldn || m < 0 || s.lin_fail || (form == 0 && n > MG_BIGN)) { if (tid == 0) outrank[w] = -1; return; }
+    const bool rescued = s.lin_fail && s.chol_fail && form == 0 && res_ok[w];       // k_marg_rescue supplied M (M^T M = A) and b
+    if (n <= 0 || n > ldn || m < 0 || (s.lin_fail && !rescued) || (form == 0 && n > MG_BIGN)) { if (tid == 0) outrank[w] = -1; return; }
     double* Mm = GM ? Mscr + o2 : lds;
     const double* L = B.L + W.Lt_base;                // row-major lower, ld = n_red (k_chol_rr2 / k_chol_big)
     const double* y = B.y + W.loc_base + W.n_e + m;   // tail of the solution of S y = rhs
@@ -64,6 +149,20 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         if (tid == 0) outrank[w] = n;
         return;
     }
+    if (rescued) {
+        // the rank-revealing factor of A from k_marg_rescue: row r of resM is v_r (sum_r v_r v_r^T = A), b comes with it
+        const double* Rm = resM + o2;
+        for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Mc(c, r) = Rm[(size_t)r * n + c]; }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += MG_NT) {
+            int i = e / n, j = e - i * n;
+            double a = 0;
+            for (int r = 0; r < n; r++) a += Mc(i, r) * Mc(j, r);
+            outA[o2 + e] = a;
+        }
+        for (int i = tid; i < n; i += MG_NT) { double a = resb[o1 + i]; bv[i] = a; outb[o1 + i] = a; }
+        __syncthreads();
+    } else {
     for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Mc(c, r) = (r <= c) ? L[(size_t)(m + c) * nr + m + r] : 0.0; }
     __syncthreads();
     // A = M^T M (= L_nn L_nn^T, the marginal information of the tail), b = A y_n
@@ -83,6 +182,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         bv[i] = a; outb[o1 + i] = a;
     }
     __syncthreads();
+    }
     // ---- one-sided Jacobi: rotate column pairs of M until all columns are mutually orthogonal (M V = U Sigma).
     // V is accumulated explicitly (same rotations applied to I): it stays orthogonal to machine precision, whereas
     // U = M V / sigma loses orthogonality like eps * sqrt(cond) — measured 1.5e-9 in J^T r0 - b.  V lives in the

@@ -309,6 +309,56 @@ def test_landmark_quarters_per_block_and_kernel_variant_do_not_change_results(mo
                 assert np.array_equal(x, y), env
 
 
+def _with_unobservable_pair(w0, istd=40.0):
+    """Two extra scalars constrained only through their difference (one FixedIntegerFactor), appended to parameter_head: their
+    marginal istd^2 [[1, -1], [-1, 1]] is exactly singular — the shape of an unobservable camera extrinsic or a yaw nobody measured."""
+    from rtk_visual_inertial_navigation_amd.flat import FlatWindow
+    w = w0.copy()
+    n_sc = w.n_sc
+    a = {k: v.copy() for k, v in w.a.items()}
+    a["sc"] = np.concatenate([a["sc"], [0.3, -0.2]])
+    a["is_const"] = np.concatenate([a["is_const"], [0, 0]]).astype(np.uint8)
+    a["fix_idx"] = np.concatenate([a["fix_idx"].ravel(), [n_sc, n_sc + 1]]).astype(np.int32)
+    a["fix_dat"] = np.concatenate([a["fix_dat"].ravel(), [2.0, istd]])
+    nb = w.n_blocks
+    g = int(a["order_group"].max()) + 1
+    a["order_block"] = np.concatenate([a["order_block"], [nb, nb + 1]]).astype(np.int32)
+    a["order_group"] = np.concatenate([a["order_group"], [g, g + 1]]).astype(np.int32)
+    return FlatWindow(n_tail=w.n_tail + 2, proj_sqrt_info=w.proj_sqrt_info, proj_loss_a=w.proj_loss_a, pbg=w.pbg, gw=w.gw, base=w.base, meta=dict(w.meta), **a)
+
+
+def test_marginalisation_of_a_rank_deficient_tail():
+    """The reference pseudo-inverts only S_mm and lets the eigen square root drop the null directions of A (UpdateSchur +
+    setmarginalizeinfo): a marginal that is singular on the kept states is business as usual there.  On the device the Cholesky
+    of all of S breaks down in the tail of such a window; k_marg_rescue then factors the first m columns only and hands
+    k_marginalize a rank-revealing factor of A.  Against the oracle's literal restatement: A, b, rank, J^T J, J^T r0."""
+    for kw in (dict(config_id=3, K=6, F=30, S=6, seed=21, head="ambiguities"), dict(config_id=2, K=7, F=40, S=0, seed=33, head="frames")):
+        w0 = _with_unobservable_pair(synth.make_window(**kw))
+        so, eo = ob.solve(w0.copy(), default_options(step_mode=1))
+        bs, sg = gpu_solve(w0.copy(), default_options(step_mode=1))
+        assert sg.termination == 6                                   # LINEAR_SOLVER_FAILURE: the full factorisation does break down ...
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+        g = bs.get_prior(0)                                          # ... and the marginalisation consumer still delivers
+        n = g["n"]
+        assert n == sg.tail_dim and g["rank"] == n - 1
+        S, rhs, _ = bs.export_reduced(0)
+        o = ob.marginalize(S, rhs, n)
+        assert o["rank"] == n - 1
+        m = S.shape[0] - n
+        ev = np.linalg.eigvalsh(S[:m, :m])
+        tol = max(1e-9, 1e-17 * ev[-1] / ev[0])
+        sc = np.abs(o["A"]).max()
+        scb = np.abs(S[m:, :m] @ np.linalg.solve(S[:m, :m], rhs[:m])).max() + np.abs(rhs[m:]).max()
+        assert np.abs(g["A"] - o["A"]).max() <= tol * sc and np.abs(g["b"] - o["b"]).max() <= tol * scb
+        assert np.abs(g["J"].T @ g["J"] - g["A"]).max() <= 1e-9 * sc                 # one eigenvalue (the null direction) dropped
+        assert np.abs(g["J"].T @ g["r0"] - g["b"]).max() <= 1e-8 * max(1.0, np.abs(g["b"]).max())
+        assert np.abs(np.sort(g["eig"]) - np.sort(np.linalg.eigvalsh(o["A"]))).max() <= max(tol, 1e-10) * sc
+        # the Cholesky form has no rank-deficient variant: it reports the failure instead of inventing a factor
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_CHOLESKY)
+        assert bs.get_prior(0)["rank"] == -1
+        bs.close()
+
+
 def test_marginalisation_consumer_matches_oracle():
     """the new prior over the parameter_head states from an ASSEMBLE_ELIMINATE_ONLY solve.  The oracle
     follows the reference literally (eigen pseudo-inverse of S_mm, eigen square root); the device path uses L_nn and a
