@@ -1246,15 +1246,16 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
     if (big && !b->mg_M && b->pool.zeros((size_t)nw * ldn * ldn, &b->mg_M)) return fail(SWF_E_NODEVICE, "device allocation failed");
     // windows whose factorisation broke down in the tail (a marginal that is singular on the kept states): partial factorisation +
     // rank-revealing factor of A; every other window leaves this kernel at once
+    const int force = getenv("SWF_FORCE_MARG_RESCUE") ? 1 : 0;      // testing aid: healthy windows through the rank-deficient path too
     if (form == SWF_PRIOR_EIGEN)
-        hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), 0, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok);
+        hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), 0, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok, force);
     hipLaunchKernelGGL(k_marginalize<false>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
                        b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, (double*)nullptr,
-                       (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok);
+                       (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force);
     if (big)
         hipLaunchKernelGGL(k_marginalize<true>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
                            b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M,
-                           (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok);
+                           (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force);
     HIPCHK(hipGetLastError());
     b->mg_valid = true;
     return SWF_OK;

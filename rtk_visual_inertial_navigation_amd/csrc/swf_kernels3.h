@@ -32,14 +32,14 @@
 // from here instead of L_nn / y_n.  A non-positive pivot among the first m columns is a real failure (rank -1).
 // One 1024-thread workgroup per window; this is the slow, rare path.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tail_dim, int ldn, double* resM, double* resb, int* res_ok) {
+__global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tail_dim, int ldn, double* resM, double* resb, int* res_ok, int force) {
     __shared__ double red_v[16]; __shared__ int red_i[16];
     __shared__ double piv_s; __shared__ int piv_i, stop_s;
     int w = blockIdx.x, tid = threadIdx.x;
     const WinRec& W = B.win[w];
     const WinState& s = B.ws[w];
     if (tid == 0) res_ok[w] = 0;
-    if (!s.chol_fail) return;
+    if (!s.chol_fail && !(force && !s.lin_fail)) return;      // force: testing aid (SWF_FORCE_MARG_RESCUE), every healthy window takes this path
     const int n = tail_dim[w], nr = W.n_red, m = nr - n;
     if (n <= 0 || n > ldn || m < 0) return;
     double* Wk = B.L + W.Lt_base;                       // (nr + 1) rows x nr columns, row-major; row nr carries the right-hand side
@@ -108,7 +108,7 @@ template <bool GM>
 __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* tail_dim, double eps, int form, int ldn,
                                                         double* outA, double* outb, double* outJ, double* outr0,
                                                         double* outw, int* outrank, double* Mscr,
-                                                        const double* resM, const double* resb, const int* res_ok) {
+                                                        const double* resM, const double* resb, const int* res_ok, int force) {
     __shared__ double lds[GM ? 16 : MG_LDS_DOUBLES];  // M (n x n, column c contiguous: row c of L_nn) | V (n x n) if both fit
     __shared__ double lam[MG_BIGN];
     __shared__ double bv[MG_BIGN];
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     int n = tail_dim[w], nr = W.n_red, m = nr - n;
     size_t o2 = (size_t)w * ldn * ldn, o1 = (size_t)w * ldn;
     if (GM != (form == 0 && n > MG_MAXN)) return;     // the other instantiation's window
-    const bool rescued = s.lin_fail && s.chol_fail && form == 0 && res_ok[w];       // k_marg_rescue supplied M (M^T M = A) and b
+    const bool rescued = ((s.lin_fail && s.chol_fail) || (force && !s.lin_fail)) && form == 0 && res_ok[w];       // k_marg_rescue supplied M (M^T M = A) and b
     if (n <= 0 || n > ldn || m < 0 || (s.lin_fail && !rescued) || (form == 0 && n > MG_BIGN)) { if (tid == 0) outrank[w] = -1; return; }
     double* Mm = GM ? Mscr + o2 : lds;
     const double* L = B.L + W.Lt_base;                // row-major lower, ld = n_red (k_chol_rr2 / k_chol_big)
@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
                 double al = 0, be = 0, ga = 0;
                 for (int r = sub; r < n; r += 16) { double a = Mc(p, r), b2 = Mc(q, r); al += a * a; be += b2 * b2; ga += a * b2; }
                 al = grp16_sum(al); be = grp16_sum(be); ga = grp16_sum(ga);
-                if (ga * ga > 1e-30 * (al * be) && ga != 0.0) {
+                // (the second test keeps zeta^2 finite when a column is numerically null — rank-deficient tails, k_marg_rescue)
+                if (ga * ga > 1e-30 * (al * be) && fabs(ga) > 1e-140 * (al + be)) {
                     // rotation from v_rcp / v_rsq + Newton steps: this scalar chain is the critical path of a step
                     double zeta = (be - al) * (0.5 * rcp_nr(ga));
                     double hz = 1.0 + zeta * zeta;
