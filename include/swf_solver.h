@@ -239,6 +239,33 @@ int swf_composite_hidden(swf_composite* c, double* pose, double* sb);
 int swf_composite_destroy(swf_composite* c);
 
 /* =====================================================================================
+ * The construction side of the composite factor: per-epoch GNSS pre-elimination and AddMargInfo
+ *
+ * swf_batch_marginal_priors: MarginalizationInfo::marginalize (R/factor/marginalization_factor.cpp:260-377) for n small problems
+ * at once — what GnssPreprocess runs for every GNSS epoch (R/swf/swf_gnss.cpp:504-532: the epoch's raw factors, receiver clocks
+ * dropped, {pose, speed-bias, ambiguities, dummy} kept).  Each problem is a flat window whose KEPT blocks are its parameter_head
+ * tail (n_tail) and whose dropped blocks are ordered before it (independent ones, the clocks, in group 0); one batch through the
+ * engine with step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY, then swf_batch_marginalize(eps, form).  Outputs, concatenated over the
+ * problems in order: dims[i] = dimension of prior i (sum of the kept blocks' local sizes, in tail order), ranks[i], A (dims^2,
+ * row-major), b, J, r0 (see swf_batch_marginalize).  A / b / J / r0 / ranks may be NULL (dims only: a sizing call).  Host
+ * pointers; synchronous.  The priors are linearised at the windows' current values (the reference zeroes the ambiguities
+ * first, PhaseBiasSaveAndReset, R/swf/swf_gnss.cpp:516: do the same in the windows you pass).
+ *
+ * swf_composite_assemble: IMUGNSSBase::AddMargInfo (R/factor/gnss_imu_factor.cpp:245-352) for a chain of M epochs — pure host
+ * bookkeeping.  Epoch e keeps n_kept[e] blocks; kept_size (7 / 9 / 1) and kept_key (the block's address; only the scalars' are
+ * looked at) are concatenated over the epochs in prior order, as are A (dim_e^2) and b (dim_e).  The scalar blocks become the
+ * factor's ambiguities in first-seen order: *N_out of them, their keys in N_keys.  Hpp [M][225], HpN [M][15][N], rhs_p [M][15],
+ * HNN [N][N], rhsN [N] receive what swf_add_imu_gnss / swf_flat_window::comp_* expect (pose rows 0..5, speed-bias rows 6..14 of
+ * an epoch's 15-block; the N x N block and its right-hand side accumulate over the epochs).  Passing Hpp = NULL only counts
+ * (*N_out).  N_cap = the N the caller sized HpN / HNN / rhsN / N_keys for.
+ * ===================================================================================== */
+int swf_batch_marginal_priors(const swf_flat_window* const* windows, int32_t n, double eps, int32_t form,
+                              int32_t* dims, int32_t* ranks, double* A, double* b, double* J, double* r0, void* stream);
+int swf_composite_assemble(int32_t M, const int32_t* n_kept, const int32_t* kept_size, double* const* kept_key,
+                           const double* A, const double* b, int32_t N_cap, double** N_keys, int32_t* N_out,
+                           double* Hpp, double* HpN, double* rhs_p, double* HNN, double* rhsN);
+
+/* =====================================================================================
  * (2) ceres::Problem-shaped single-window surface
  *
  * Parameter blocks are identified BY ADDRESS like in Ceres; values are read through the

@@ -1,0 +1,118 @@
+// swf_gnss_epochs.cpp — the construction side of the composite IMU-GNSS factor (second half).
+//
+// What the reference does per GNSS epoch before the window ever sees it (GnssPreprocess, R/swf/swf_gnss.cpp:504-532): the
+// epoch's raw factors go into a private MarginalizationInfo, marginalize() (R/factor/marginalization_factor.cpp:260-377)
+// eliminates the receiver clocks, and the linear prior over {pose, speed-bias, ambiguities, dummy} that remains is what
+// IMUGNSSBase::AddMargInfo (R/factor/gnss_imu_factor.cpp:245-352) files into the composite factor's per-epoch arrays.
+//
+// Here:
+//   swf_batch_marginal_priors  the elimination, for ALL epochs at once: every epoch is a (tiny) flat window whose kept blocks
+//                              are its parameter_head tail; one batch through the engine — factor kernels, clique elimination
+//                              of the clocks, dense factorisation — and the marginalisation consumer (k_marginalize) on top.
+//   swf_composite_assemble     AddMargInfo's bookkeeping for a chain of epochs, on the host: the union of the ambiguity blocks in
+//                              first-seen order, and the priors' blocks scattered into Hpp / HpN / rhs_p / HNN / rhsN — exactly
+//                              the arrays swf_add_imu_gnss / swf_flat_window::comp_* take.
+// Host orchestration only; all arithmetic of the elimination runs in the HIP kernels (no CPU path).
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/swf_solver.h"
+
+void swf_internal_set_error(const std::string& m);
+static int efail(int code, const std::string& m) { swf_internal_set_error(m); return code; }
+
+extern "C" {
+
+int swf_batch_marginal_priors(const swf_flat_window* const* windows, int32_t n, double eps, int32_t form,
+                              int32_t* dims, int32_t* ranks, double* A, double* b, double* J, double* r0, void* stream) {
+    if (!windows || n <= 0 || !dims) return efail(SWF_E_INVALID, "swf_batch_marginal_priors: bad arguments");
+    swf_batch* bt = nullptr;
+    int rc = swf_batch_create(windows, n, stream, &bt);
+    if (rc != SWF_OK) return rc;
+    swf_options opt; swf_options_default(&opt);
+    opt.step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY;
+    std::vector<swf_summary> sm((size_t)n);
+    if ((rc = swf_batch_solve(bt, &opt)) == SWF_OK && (rc = swf_batch_sync(bt)) == SWF_OK && (rc = swf_batch_summaries(bt, sm.data())) == SWF_OK) {
+        for (int i = 0; i < n; i++) dims[i] = sm[(size_t)i].tail_dim;
+        if (A || b || J || r0 || ranks) {
+            if ((rc = swf_batch_marginalize(bt, eps, form)) == SWF_OK) {
+                size_t o2 = 0, o1 = 0;
+                for (int i = 0; i < n && rc == SWF_OK; i++) {
+                    int32_t d = 0, rk = 0;
+                    rc = swf_batch_get_prior(bt, i, A ? A + o2 : nullptr, b ? b + o1 : nullptr, J ? J + o2 : nullptr, r0 ? r0 + o1 : nullptr, nullptr, &d, &rk);
+                    if (ranks) ranks[i] = rk;
+                    o2 += (size_t)d * d; o1 += (size_t)d;
+                }
+            }
+        }
+    }
+    swf_batch_destroy(bt);
+    return rc;
+}
+
+int swf_composite_assemble(int32_t M, const int32_t* n_kept, const int32_t* kept_size, double* const* kept_key,
+                           const double* A, const double* b, int32_t N_cap, double** N_keys, int32_t* N_out,
+                           double* Hpp, double* HpN, double* rhs_p, double* HNN, double* rhsN) {
+    if (M < 1 || !n_kept || !kept_size || !kept_key || !A || !b || !N_out) return efail(SWF_E_INVALID, "swf_composite_assemble: bad arguments");
+    // pass 1: the ambiguity (scalar) blocks in first-seen order over the epochs — gnss_phase_biases (:268-283)
+    std::vector<double*> keys;
+    {
+        size_t q = 0;
+        for (int e = 0; e < M; e++)
+            for (int k = 0; k < n_kept[e]; k++, q++) {
+                const int sz = kept_size[q];
+                if (sz != 7 && sz != 9 && sz != 1) return efail(SWF_E_INVALID, "swf_composite_assemble: kept blocks must be poses (7), speed-biases (9) or scalars (1)");
+                if (sz != 1) continue;
+                bool seen = false;
+                for (double* p : keys) if (p == kept_key[q]) { seen = true; break; }
+                if (!seen) keys.push_back(kept_key[q]);
+            }
+    }
+    const int N = (int)keys.size();
+    *N_out = N;
+    if (!Hpp || !HpN || !rhs_p || !HNN || !rhsN) return SWF_OK;          // sizing call
+    if (N > N_cap) return efail(SWF_E_INVALID, "swf_composite_assemble: more ambiguity blocks than the caller's buffers hold");
+    if (N_keys) for (int i = 0; i < N; i++) N_keys[i] = keys[(size_t)i];
+    memset(Hpp, 0, sizeof(double) * (size_t)M * 225); memset(HpN, 0, sizeof(double) * (size_t)M * 15 * N); memset(rhs_p, 0, sizeof(double) * (size_t)M * 15);
+    memset(HNN, 0, sizeof(double) * (size_t)N * N); memset(rhsN, 0, sizeof(double) * (size_t)N);
+    // pass 2: scatter every epoch's prior (A_e over its kept blocks' local coordinates, b_e) — :299-347
+    size_t q0 = 0, oA = 0, ob = 0;
+    for (int e = 0; e < M; e++) {
+        const int nk = n_kept[e];
+        // local offset of every kept block inside the prior, and where it goes: pose -> rows 0..5 of the 15-block, speed-bias -> rows
+        // 6..14, scalar -> its index among the ambiguities
+        std::vector<int> off((size_t)nk), dst((size_t)nk), len((size_t)nk);
+        int dim = 0, n_pose = 0, n_sb = 0;
+        for (int k = 0; k < nk; k++) {
+            const int sz = kept_size[q0 + k];
+            off[(size_t)k] = dim; len[(size_t)k] = sz == 7 ? 6 : sz; dim += len[(size_t)k];
+            if (sz == 7) { dst[(size_t)k] = -1; n_pose++; }
+            else if (sz == 9) { dst[(size_t)k] = -2; n_sb++; }
+            else { int ix = 0; while (keys[(size_t)ix] != kept_key[q0 + k]) ix++; dst[(size_t)k] = ix; }
+        }
+        if (n_pose > 1 || n_sb > 1) return efail(SWF_E_INVALID, "swf_composite_assemble: an epoch's prior keeps more than one pose or speed-bias");
+        const double* Ae = A + oA; const double* be = b + ob;
+        double* Hp = Hpp + (size_t)e * 225; double* HN = HpN + (size_t)e * 15 * N; double* rp = rhs_p + (size_t)e * 15;
+        for (int k1 = 0; k1 < nk; k1++) {
+            const int d1 = dst[(size_t)k1], s1 = d1 == -1 ? 0 : 6;            // row shift inside the 15-block
+            for (int i = 0; i < len[(size_t)k1]; i++) {
+                const int r = off[(size_t)k1] + i;
+                if (d1 >= 0) rhsN[d1] += be[r]; else rp[s1 + i] += be[r];
+                for (int k2 = 0; k2 < nk; k2++) {
+                    const int d2 = dst[(size_t)k2], s2 = d2 == -1 ? 0 : 6;
+                    for (int j = 0; j < len[(size_t)k2]; j++) {
+                        const double v = Ae[(size_t)r * dim + off[(size_t)k2] + j];
+                        if (d1 >= 0 && d2 >= 0) HNN[(size_t)d1 * N + d2] += v;
+                        else if (d1 < 0 && d2 < 0) Hp[(s1 + i) * 15 + s2 + j] += v;
+                        else if (d1 < 0 && d2 >= 0) HN[(size_t)(s1 + i) * N + d2] += v;
+                        // (d1 >= 0, d2 < 0) is the transpose of the case above: the factor stores H_pN only
+                    }
+                }
+            }
+        }
+        q0 += (size_t)nk; oA += (size_t)dim * dim; ob += (size_t)dim;
+    }
+    return SWF_OK;
+}
+
+}  // extern "C"

@@ -50,6 +50,7 @@ EXPORTED = [
     "swf_eval_inverse_depth_batch", "swf_add_projection_inverse_depth",
     "swf_factor_is_enabled", "swf_get_residual_blocks", "swf_get_residual_blocks_for_parameter_block",
     "swf_get_parameter_blocks", "swf_get_parameter_blocks_for_residual_block", "swf_batch_export_jacobian",
+    "swf_batch_marginal_priors", "swf_composite_assemble",
 ]
 
 
@@ -470,6 +471,65 @@ class CompositeBatch:
             self.close()
         except Exception:
             pass
+
+
+def marginal_priors(windows, eps=1e-8, form=0):
+    """swf_batch_marginal_priors: the linear prior over each window's parameter_head tail with everything else eliminated
+    (GnssPreprocess's per-epoch marginalize, R/swf/swf_gnss.cpp:504-532), for all windows in one batch on the device.
+    Returns a list of dict(n, rank, A, b, J, r0)."""
+    structs = [w.c_struct() for w in windows]
+    arr = (C.POINTER(FlatWindowC) * len(structs))(*[C.pointer(s) for s in structs])
+    n = len(structs)
+    dims = np.zeros(n, np.int32)
+    pi = C.POINTER(C.c_int32)
+    _chk(lib().swf_batch_marginal_priors(arr, C.c_int32(n), C.c_double(eps), C.c_int32(form), dims.ctypes.data_as(pi), None, None, None, None, None, None),
+         "swf_batch_marginal_priors")
+    n2, n1 = int((dims.astype(np.int64) ** 2).sum()), int(dims.sum())
+    A, J, b, r0, ranks = np.zeros(max(n2, 1)), np.zeros(max(n2, 1)), np.zeros(max(n1, 1)), np.zeros(max(n1, 1)), np.zeros(n, np.int32)
+    _chk(lib().swf_batch_marginal_priors(arr, C.c_int32(n), C.c_double(eps), C.c_int32(form), dims.ctypes.data_as(pi), ranks.ctypes.data_as(pi),
+                                         A.ctypes.data_as(_pd), b.ctypes.data_as(_pd), J.ctypes.data_as(_pd), r0.ctypes.data_as(_pd), None), "swf_batch_marginal_priors")
+    out, o2, o1 = [], 0, 0
+    for i in range(n):
+        d = int(dims[i])
+        out.append(dict(n=d, rank=int(ranks[i]), A=A[o2:o2 + d * d].reshape(d, d).copy(), b=b[o1:o1 + d].copy(),
+                        J=J[o2:o2 + d * d].reshape(d, d).copy(), r0=r0[o1:o1 + d].copy()))
+        o2 += d * d; o1 += d
+    return out
+
+
+def composite_assemble(epochs):
+    """swf_composite_assemble: IMUGNSSBase::AddMargInfo (R/factor/gnss_imu_factor.cpp:245-352) for a chain of epochs.
+    epochs: list of dict(kept = [(size, key)] in prior order — key = the numpy array of a scalar block, anything for poses /
+    speed-biases —, A, b).  Returns dict(N, keys (the scalar blocks in first-seen order), Hpp [M][15][15], HpN [M][15][N],
+    rhs_p [M][15], HNN [N][N], rhsN [N])."""
+    M = len(epochs)
+    n_kept = np.array([len(e["kept"]) for e in epochs], np.int32)
+    sizes = np.array([s for e in epochs for (s, _) in e["kept"]], np.int32)
+    keep_alive, ptrs = {}, []
+    for e in epochs:
+        for (s, k) in e["kept"]:
+            if s == 1:
+                assert isinstance(k, np.ndarray) and k.dtype == np.float64
+                keep_alive[k.ctypes.data] = k; ptrs.append(k.ctypes.data_as(_pd))
+            else:
+                ptrs.append(_pd())
+    keys = (_pd * max(1, len(ptrs)))(*ptrs)
+    A = np.ascontiguousarray(np.concatenate([np.asarray(e["A"], np.float64).ravel() for e in epochs]))
+    b = np.ascontiguousarray(np.concatenate([np.asarray(e["b"], np.float64).ravel() for e in epochs]))
+    pi = C.POINTER(C.c_int32)
+    N = C.c_int32(0)
+    _chk(lib().swf_composite_assemble(C.c_int32(M), n_kept.ctypes.data_as(pi), sizes.ctypes.data_as(pi), keys, A.ctypes.data_as(_pd), b.ctypes.data_as(_pd),
+                                      C.c_int32(0), None, C.byref(N), None, None, None, None, None), "swf_composite_assemble")
+    n = N.value
+    Hpp, HpN, rhs_p, HNN, rhsN = np.zeros((M, 15, 15)), np.zeros((M, 15, max(n, 1))), np.zeros((M, 15)), np.zeros((max(n, 1), max(n, 1))), np.zeros(max(n, 1))
+    HpN_buf = np.zeros(M * 15 * max(n, 1))
+    nk = (_pd * max(1, n))()
+    _chk(lib().swf_composite_assemble(C.c_int32(M), n_kept.ctypes.data_as(pi), sizes.ctypes.data_as(pi), keys, A.ctypes.data_as(_pd), b.ctypes.data_as(_pd),
+                                      C.c_int32(n), nk, C.byref(N), Hpp.ctypes.data_as(_pd), HpN_buf.ctypes.data_as(_pd), rhs_p.ctypes.data_as(_pd),
+                                      HNN.ctypes.data_as(_pd), rhsN.ctypes.data_as(_pd)), "swf_composite_assemble")
+    HpN = HpN_buf[:M * 15 * n].reshape(M, 15, n) if n else np.zeros((M, 15, 0))
+    return dict(N=n, keys=[keep_alive[C.cast(nk[i], C.c_void_p).value] for i in range(n)], Hpp=Hpp, HpN=HpN, rhs_p=rhs_p,
+                HNN=HNN[:n, :n].copy(), rhsN=rhsN[:n].copy())
 
 
 def eval_inverse_depth_batch(kind, idx, poses, lam, pts, sqrt_info, pbg):

@@ -1,0 +1,139 @@
+"""SURVEY.md 8f rank 2, second half: the reference's own RTK topology end to end — per-epoch GNSS pre-elimination
+(GnssPreprocess + MarginalizationInfo::marginalize), AddMargInfo's bookkeeping, composite factors — against the explicit
+problem it stands for.  The CPU tests pin the construction with the oracle; the gpu tests run the device path."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import rtk_topology_gen as rt
+from rtk_visual_inertial_navigation_amd import solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+
+CASES = [dict(K_vis=4, M=2, F=24, S=6, seed=7), dict(K_vis=3, M=4, F=16, S=5, seed=11)]
+
+
+def oracle_epoch_priors(ews):
+    """The epoch windows eliminate only their clock (group 0) and keep everything else, so the oracle's reduced system IS the
+    prior: A = S, b = rhs (sign convention b = J^T r, as MarginalizationInfo::marginalize builds it)."""
+    out = []
+    for e in ews:
+        sm, ex = ob.solve(e.copy(), default_options(step_mode=1))
+        assert sm.tail_dim == ex["S"].shape[0]
+        out.append(dict(A=ex["S"], b=ex["rhs"]))
+    return out
+
+
+def plug_into_explicit(wx, wc, clocks_from):
+    """The composite window's solution written into the explicit window's state (visual frames, hidden epochs, landmarks,
+    ambiguities); the receiver clocks, which the composite topology eliminated, come from `clocks_from`."""
+    m = wx.meta
+    w2 = clocks_from.copy()
+    P, B = w2.a["pose"].reshape(-1, 7), w2.a["sb"].reshape(-1, 9)
+    pc, bc = wc.a["pose"].reshape(-1, 7), wc.a["sb"].reshape(-1, 9)
+    for k, v in enumerate(m["vis"]):
+        P[v] = pc[k]; B[v] = bc[k]
+    hp, hs = wc.a["comp_pose"].reshape(-1, 7), wc.a["comp_sb"].reshape(-1, 9)
+    for i, h in enumerate(m["hidden"]):
+        P[h] = hp[i]; B[h] = hs[i]
+    w2.a["lm"][...] = wc.a["lm"]
+    w2.a["sc"][1:1 + m["S"]] = wc.a["sc"][1:1 + m["S"]]
+    return w2
+
+
+def build_chains(wx, kept, pri, assemble):
+    M, K = wx.meta["M"], wx.meta["K_vis"]
+    return [assemble(M, kept[g * M:(g + 1) * M], pri[g * M:(g + 1) * M]) for g in range(K - 1)]
+
+
+def host_assemble(M, kept, pri):
+    """swf_composite_assemble (the product's host code) with numpy scalars standing in for the ambiguity blocks."""
+    ids = sorted({k for e in kept for (s, k) in e if s == 1})
+    blocks = {k: np.zeros(1) for k in ids}
+    eps = [dict(kept=[(s, blocks[k] if s == 1 else None) for (s, k) in kept[e]], A=pri[e]["A"], b=pri[e]["b"]) for e in range(M)]
+    c = solver.composite_assemble(eps)
+    inv = {id(v): k for k, v in blocks.items()}
+    c["ids"] = [inv[id(b)] for b in c["keys"]]
+    return c
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_add_marg_info_bookkeeping_equals_numpy_restatement(kw):
+    wx, vis, hid = rt.explicit_window(**kw)
+    ews, kept = rt.epoch_windows(wx)
+    pri = oracle_epoch_priors(ews)
+    M = wx.meta["M"]
+    for g in range(wx.meta["K_vis"] - 1):
+        a = rt.assemble_np(M, kept[g * M:(g + 1) * M], pri[g * M:(g + 1) * M])
+        c = host_assemble(M, kept[g * M:(g + 1) * M], pri[g * M:(g + 1) * M])
+        assert c["ids"] == a["ids"]
+        for key in ("Hpp", "HpN", "rhs_p", "HNN", "rhsN"):
+            assert np.array_equal(c[key], a[key]), key
+    # epochs that see different satellite subsets: the union grows in first-seen order and absent blocks stay zero
+    rng = np.random.default_rng(3)
+    k2 = [[(7, None), (1, 4), (1, 2)], [(9, None), (7, None), (1, 2), (1, 9)]]
+    p2 = []
+    for e in k2:
+        n = sum(6 if s == 7 else s for s, _ in e)
+        G = rng.normal(0, 1, (n + 3, n)); p2.append(dict(A=G.T @ G, b=rng.normal(0, 1, n)))
+    a, c = rt.assemble_np(2, k2, p2), host_assemble(2, k2, p2)
+    assert c["ids"] == a["ids"] == [4, 2, 9]
+    for key in ("Hpp", "HpN", "rhs_p", "HNN", "rhsN"):
+        assert np.array_equal(c[key], a[key]), key
+    assert not a["Hpp"][0][6:, :].any() and a["Hpp"][1][6:, 6:].any()          # epoch 0 kept no speed-bias, epoch 1 did
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_composite_topology_has_the_minimiser_of_the_explicit_problem_oracle(kw):
+    """The window in the reference's topology (per-epoch priors + composite factors) and the window that carries every GNSS epoch
+    as an explicit frame with raw factors are the same least-squares problem: the composite solution, written into the explicit
+    window, is stationary there (one more explicit iteration moves nothing) and its cost is not above what the explicit solver
+    reached on its own."""
+    wx, vis, hid = rt.explicit_window(**kw)
+    ews, kept = rt.epoch_windows(wx)
+    chains = build_chains(wx, kept, oracle_epoch_priors(ews), rt.assemble_np)
+    wc = rt.composite_window(wx, chains)
+    sc, _ = ob.solve(wc, default_options(max_num_iterations=30), export=False)
+    assert sc.termination in (1, 2, 3)
+    we = wx.copy()
+    se, _ = ob.solve(we, default_options(max_num_iterations=60), export=False)
+    w2 = plug_into_explicit(wx, wc, we)
+    before = w2.a["pose"].copy()
+    s2, _ = ob.solve(w2, default_options(max_num_iterations=10), export=False)
+    assert s2.final_cost <= se.final_cost * (1 + 1e-6)
+    assert np.abs(w2.a["pose"] - before).max() < 5e-3       # millimetres along the weakly determined global-position direction (gauge prior 1e-3); the explicit solver on its own is centimetres away after 60 iterations
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", CASES)
+def test_device_epoch_priors_and_composite_topology(kw):
+    """The device path of the same construction: swf_batch_marginal_priors over all GNSS epochs in one batch (clock eliminated by
+    the clique kernels, prior by k_marginalize) against the oracle's priors; the composite window built from the DEVICE priors
+    solved on the device against the oracle's solve of the oracle-built window; and the minimiser check on the device."""
+    wx, vis, hid = rt.explicit_window(**kw)
+    ews, kept = rt.epoch_windows(wx)
+    po = oracle_epoch_priors(ews)
+    pd = solver.marginal_priors(ews, 1e-8, solver.BatchSolver.PRIOR_EIGEN)
+    for o, d in zip(po, pd):
+        sc_ = np.abs(o["A"]).max()
+        assert d["n"] == o["A"].shape[0] and d["rank"] == d["n"]
+        assert np.abs(d["A"] - o["A"]).max() <= 1e-10 * sc_ and np.abs(d["b"] - o["b"]).max() <= 1e-9 * np.abs(o["b"]).max()
+        assert np.abs(d["J"].T @ d["J"] - d["A"]).max() <= 1e-11 * sc_ and np.abs(d["J"].T @ d["r0"] - d["b"]).max() <= 1e-9 * np.abs(d["b"]).max()
+    wd = rt.composite_window(wx, build_chains(wx, kept, pd, host_assemble))
+    wo = rt.composite_window(wx, build_chains(wx, kept, po, rt.assemble_np))
+    so, _ = ob.solve(wo, default_options(max_num_iterations=30), export=False)
+    bs = solver.BatchSolver([wd])
+    sd = bs.solve(default_options(max_num_iterations=30))[0]
+    bs.close()
+    assert sd.termination == so.termination
+    assert [r["step_is_successful"] for r in sd.rows()] == [r["step_is_successful"] for r in so.rows()]
+    for a, b in zip(sd.rows(), so.rows()):
+        assert abs(a["cost"] - b["cost"]) <= 1e-6 * abs(b["cost"]) + 1e-5
+    assert np.abs(wd.a["pose"] - wo.a["pose"]).max() < 1e-6 and np.abs(wd.a["comp_pose"] - wo.a["comp_pose"]).max() < 1e-6
+    # minimiser of the explicit problem, on the device
+    we = wx.copy()
+    b2 = solver.BatchSolver([we]); se = b2.solve(default_options(max_num_iterations=60))[0]; b2.close()
+    w2 = plug_into_explicit(wx, wd, we)
+    before = w2.a["pose"].copy()
+    b3 = solver.BatchSolver([w2]); s2 = b3.solve(default_options(max_num_iterations=10))[0]; b3.close()
+    assert s2.final_cost <= se.final_cost * (1 + 1e-6)
+    assert np.abs(w2.a["pose"] - before).max() < 5e-3       # millimetres along the weakly determined global-position direction (gauge prior 1e-3); the explicit solver on its own is centimetres away after 60 iterations
