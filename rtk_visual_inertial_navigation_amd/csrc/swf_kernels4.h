@@ -36,7 +36,7 @@ struct CompArgs {
     int* history; int* status;
     const double* outer; const double* Nv;             // this call: [n][32] = pose_i sb_i pose_j sb_j, [sum N]
     int want_jac;
-    double* res_out; double* jac_out;                  // [sum G], [sum G G] (row-major, upper triangular = L^T)
+    double* res_out; double* jac_out;                  // [sum G], [sum G G] (row-major: row r = v_r of the pivoted square root, zero beyond the rank)
     double* Jw; double* rw;                            // scratch: whitened IMU Jacobians [sum M + n][450] and residuals [sum M + n][16]
     const int* iq_f; const int* iq_k; int n_iq;        // the chains' IMU factors, flattened: owner factor and position k (0 .. M)
     int* todo;                                         // [n] set by k_comp_prep: 1 = this launch re-eliminates the factor
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) k_comp_prep(CompArgs A) {
         const double* Ld = A.Ld + g20;
         for (int k = t; k < G; k += 256) {
             double s = 0;
-            for (int a = k; a < G; a++) { double inc = a < 15 ? dl0[a] : a < 30 ? dl2[a - 15] : dlN[a - 30]; s += Ld[(size_t)a * G + k] * inc; }
+            for (int a = 0; a < G; a++) { double inc = a < 15 ? dl0[a] : a < 30 ? dl2[a - 15] : dlN[a - 30]; s += Ld[(size_t)a * G + k] * inc; }      // (column k of Ld is row k of J; not triangular: pivoted factor)
             A.res_out[g0 + k] = A.r0[g0 + k] - s;
         }
         if (t == 0) A.todo[f] = 0;
@@ -352,24 +352,45 @@ __global__ void __launch_bounds__(256, 4) k_comp_elim(CompArgs A) {
     for (int e = t; e < G * G; e += 256) sD[e] = A.Hd[g20 + e];
     if (t < G) sD[G * G + t] = A.rd[g0 + t];                          // the rhs rides along as row G: its factor row is L^-1 rhs
     __syncthreads();
-    // Cholesky of the remainder, right-looking with the columns left unscaled inside the loop (column j holds L[:, j] sqrt(d_j)): the
-    // trailing update needs only column j and 1 / d_j, so a column costs one barrier; the scaling happens at the write-out
-    for (int j = 0; j < G; j++) {
-        double d = sD[j * G + j];
-        if (!(d > 0.0)) { if (t == 0) sBad = 1; d = 1.0; }
-        double inv = 1.0 / d;
-        for (int e = j * G + t; e < (G + 1) * G; e += 256) { int a = e / G, b = e - a * G; if (b > j && a >= b) sD[e] -= sD[a * G + j] * sD[b * G + j] * inv; }
+    // Square root of the remainder.  The remainder of ONE factor is only positive SEMI-definite in general — between two visual
+    // frames nothing in the chain pins, say, the heading — which is why the reference takes an eigen square root here
+    // (UpdateSchurComponent, R/factor/gnss_imu_factor.cpp:454-488, eigenvalues <= 1e-8 dropped).  A Gauss-Newton solver consumes
+    // J^T J, J^T r and |r|^2 only, so any J with J^T J = H does: here a diagonally pivoted outer-product Cholesky, which is
+    // rank-revealing and needs no eigen-solve.  Step r takes the largest remaining diagonal entry H_pp as pivot:
+    //   v_r = H[:, p] / sqrt(H_pp)   (row r of J),   rho_r = rhs_p / sqrt(H_pp)   (entry r of the residual),
+    //   H -= v_r v_r^T,  rhs -= v_r rho_r,
+    // and stops when the remaining diagonal is below 1e-14 of the first pivot or 1e-8 absolute (the reference's eigenvalue
+    // threshold): the rows beyond the rank are zero.  sum_r v_r v_r^T = H and sum_r v_r rho_r = rhs on the retained range.
+    {
+        __shared__ int sPiv, sStop; __shared__ double sPv;
+        for (int e = t; e < G * G; e += 256) { A.Ld[g20 + e] = 0.0; if (A.jac_out) A.jac_out[g20 + e] = 0.0; }
+        if (t < G) { A.r0[g0 + t] = 0.0; A.res_out[g0 + t] = 0.0; }
+        if (t == 0) sStop = 0;
         __syncthreads();
+        double d0 = 0.0;
+        for (int r = 0; r < G; r++) {
+            if (t < 64) {                                // wave 0: arg max of the diagonal (first index wins ties)
+                double bv = -1.0; int bi = -1;
+                for (int i = t; i < G; i += 64) { double v = sD[i * G + i]; if (v > bv) { bv = v; bi = i; } }
+                for (int o = 32; o > 0; o >>= 1) {
+                    double ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
+                    if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
+                }
+                if (t == 0) { sPv = bv; sPiv = bi; }
+            }
+            __syncthreads();
+            if (r == 0) d0 = sPv;
+            if (!(sPv > 1e-14 * d0) || !(sPv > 1e-8)) break;            // uniform
+            const int p = sPiv; const double isq = 1.0 / sqrt(sPv);
+            double vr = 0.0;
+            if (t < G) { vr = sD[t * G + p] * isq; A.Ld[g20 + (size_t)t * G + r] = vr; if (A.jac_out) A.jac_out[g20 + (size_t)r * G + t] = vr; sdinv[t] = vr; }
+            if (t == 255) { double rho = sD[G * G + p] * isq; A.r0[g0 + r] = rho; A.res_out[g0 + r] = rho; sRes[0] = rho; }
+            __syncthreads();
+            for (int e = t; e < G * G; e += 256) { int a = e / G, b2 = e - a * G; sD[e] = (a == p || b2 == p) ? 0.0 : sD[e] - sdinv[a] * sdinv[b2]; }
+            if (t < G) sD[G * G + t] = t == p ? 0.0 : sD[G * G + t] - sdinv[t] * sRes[0];
+            __syncthreads();
+        }
     }
-    if (t < G) { double d = sD[t * G + t]; sdinv[t] = 1.0 / sqrt(d > 0.0 ? d : 1.0); }
-    __syncthreads();
-    for (int e = t; e < G * G; e += 256) {
-        int a = e / G, b = e - a * G;
-        double l = (b < a) ? sD[e] * sdinv[b] : (a == b ? 1.0 / sdinv[b] : 0.0);
-        A.Ld[g20 + e] = l;
-        if (A.jac_out) A.jac_out[g20 + (size_t)b * G + a] = l;        // J = L^T
-    }
-    if (t < G) { double y = sD[G * G + t] * sdinv[t]; A.r0[g0 + t] = y; A.res_out[g0 + t] = y; }
     if (t < 32) A.old[(size_t)f * 32 + t] = sOut[t];
     if (t < N) A.N_old[n0 + t] = sNv[t];
     if (t == 0) { A.history[f] = 1; A.status[f] = sBad ? -1 : 0; }
