@@ -37,6 +37,7 @@ struct WinState {
     double radius, mu, x_cost, x_norm, alpha, dogleg_step_norm, step_norm, gmax;
     double jg_sq, initial_cost;
     double lm_dec;               // LevenbergMarquardtStrategy::decrease_factor_ (SWF_LEVENBERG_MARQUARDT only)
+    double model_cost_change;    // of the step k_dogleg proposed (from vectors alone, see k_dogleg)
     int status, iter, need_lin, reuse, eval_cand, lin_fail, invalid_run, nsucc, nunsucc;
     int chol_fail;               // lin_fail came from the dense factorisation (S itself is valid): the marginalisation consumer can still work
 };

@@ -1070,18 +1070,15 @@ struct Launcher {
             Bracket t(*this, SWF_K_POST_DOGLEG);
             Segs S{};
             S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256);
-            S.e[2] = S.e[1] + nb((size_t)D.n_imu * 16, 256); S.e[3] = S.e[2] + nb((size_t)D.n_prior * 64, 256);
-            S.e[4] = S.e[3] + nb(D.n_proj, 256); S.e[5] = S.e[4] + nb(D.n_sc, 256);
-            S.e[6] = S.e[5] + (b->max_prior_dim <= PRIOR_LDS_DIM ? D.n_prior : 0);
+            S.e[2] = S.e[1] + (b->max_prior_dim <= PRIOR_LDS_DIM ? D.n_prior : 0);
             // small batches (latency path): the candidate IMU residuals ride along as a segment; large batches keep them in
             // their own launch (the segment's LDS would cost the memory-bound segments occupancy).  Same results either way.
             bool fuse_imu = D.n_win < b->n_cu;
-            S.e[7] = S.e[6] + (fuse_imu ? nb(D.n_imu, IMU_FPB) : 0);
-            if (S.e[7] && fuse_imu) hipLaunchKernelGGL((k_post_dogleg<true, 0>), dim3(S.e[7]), dim3(256), 0, st, D, O, S);
-            else if (S.e[7]) {
-                // S.e[4] - S.e[3] == S.e[0]: both projection segments have nb(n_proj) blocks
-                if (S.e[0]) hipLaunchKernelGGL((k_post_dogleg<false, 1>), dim3(2 * S.e[0]), dim3(256), 0, st, D, O, S);
-                if (S.e[7] > 2 * S.e[0]) hipLaunchKernelGGL((k_post_dogleg<false, 2>), dim3(S.e[7] - 2 * S.e[0]), dim3(256), 0, st, D, O, S);
+            S.e[3] = S.e[2] + (fuse_imu ? nb(D.n_imu, IMU_FPB) : 0);
+            if (S.e[3] && fuse_imu) hipLaunchKernelGGL((k_post_dogleg<true, 0>), dim3(S.e[3]), dim3(256), 0, st, D, O, S);
+            else if (S.e[3]) {
+                if (S.e[0]) hipLaunchKernelGGL((k_post_dogleg<false, 1>), dim3(S.e[0]), dim3(256), 0, st, D, O, S);
+                if (S.e[3] > S.e[0]) hipLaunchKernelGGL((k_post_dogleg<false, 2>), dim3(S.e[3] - S.e[0]), dim3(256), 0, st, D, O, S);
             }
             if (!fuse_imu && D.n_imu) hipLaunchKernelGGL(k_eval_imu<false>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, st, D);
             if (D.n_idp) hipLaunchKernelGGL(k_eval_idp<false>, GRID(D.n_idp, 128), dim3(128), 0, st, D);

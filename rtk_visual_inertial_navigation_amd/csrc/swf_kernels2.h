@@ -1121,27 +1121,20 @@ __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S)
     else if (bid < S.e[4]) d_jtimes_imu<0>(B, O, bid - S.e[3]);
     else d_jtimes_prior<0>(B, O, bid - S.e[4]);
 }
-// after the dogleg step: model cost change J*step, and the candidate residuals of every factor family.
-// PART 0: every segment in one grid (latency path).  Large batches launch the two projection segments (PART 1, the
-// HBM-bound ones, at their own register count) apart from the small latency-bound families (PART 2).
+// after the dogleg step: the candidate residuals (costs) of every factor family.  The model cost change needs no pass over the
+// Jacobians any more: k_dogleg gets it from vectors alone (see there).
+// PART 0: every segment in one grid (latency path).  Large batches launch the projection segment (PART 1, the HBM-bound one,
+// at its own register count) apart from the small latency-bound families (PART 2).
 template <bool WITH_IMU, int PART>
 __global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs S) {
     __shared__ double sm_prior[PART == 1 ? 1 : 2 * PRIOR_LDS_DIM + 16];
     int bid = blockIdx.x;
-    if (PART == 1) {                                           // grid = 2 * S.e[0]
-        if (bid < S.e[0]) d_jtimes_proj<1>(B, O, bid);
-        else d_eval_proj<false>(B, bid - S.e[0]);
-        return;
-    }
-    if (PART == 2) { bid += S.e[0]; if (bid >= S.e[3]) bid += S.e[4] - S.e[3]; }      // skip the projection segments
-    if (PART == 0 && bid < S.e[0]) d_jtimes_proj<1>(B, O, bid);
-    else if (bid < S.e[1]) d_jtimes_scalar<1>(B, O, bid - S.e[0]);
-    else if (bid < S.e[2]) d_jtimes_imu<1>(B, O, bid - S.e[1]);
-    else if (bid < S.e[3]) d_jtimes_prior<1>(B, O, bid - S.e[2]);
-    else if (PART == 0 && bid < S.e[4]) d_eval_proj<false>(B, bid - S.e[3]);
-    else if (bid < S.e[5]) d_eval_scalar<false>(B, bid - S.e[4]);
-    else if (bid < S.e[6]) d_eval_prior<false>(B, bid - S.e[5], sm_prior);
-    else if (WITH_IMU) d_eval_imu<false>(B, bid - S.e[6]);    // candidate IMU residuals (8 factors per workgroup), small batches only
+    if (PART == 1) { d_eval_proj<false>(B, bid); return; }     // grid = S.e[0]
+    if (PART == 2) bid += S.e[0];                              // skip the projection segment
+    if (PART == 0 && bid < S.e[0]) d_eval_proj<false>(B, bid);
+    else if (bid < S.e[1]) d_eval_scalar<false>(B, bid - S.e[0]);
+    else if (bid < S.e[2]) d_eval_prior<false>(B, bid - S.e[1], sm_prior);
+    else if (WITH_IMU) d_eval_imu<false>(B, bid - S.e[2]);    // candidate IMU residuals (8 factors per workgroup), small batches only
 }
 // diagonal + off-diagonal block assembly of the reduced system
 __global__ void __launch_bounds__(256) k_assemble_all(DevBatch B, DevOpt O, int write_S, Segs S, int n_part) {
@@ -1337,6 +1330,17 @@ __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
         double beta = (cc <= 0) ? (dd - cc) / bma_sq : (radius * radius - a_sq) / (dd + cc);
         mode = 2; c1 = -alpha * (1.0 - beta); c2 = -beta; dnorm = -1.0;
     }
+    // Model cost change of the step s = c1 v + c2 y (v = D^-2 g, the Cauchy direction; y = the damped solution) WITHOUT touching a
+    // Jacobian: ceres evaluates -(J s).(r + J s / 2) = -(g.s + s^T H s / 2) with H = J^T J; here
+    //   v^T H v = |J v|^2 = jg_sq   (formed once per linearisation, with the back-substitution pass),
+    //   H y = g - mu D^2 y          (y solves the damped system)  =>  v^T H y = |g / D|^2 - mu g.y,   y^T H y = g.y - mu |D y|^2,
+    // and g.v = |g / D|^2: every term is one of the sums of the pass above.  (The identity holds to the backward error of the linear
+    // solve, 1e-12 of the terms; round 1 re-read every Jacobian for this — 73 + 35 us per iteration of the cfg4 batch.)
+    if (tid == 0) {
+        const double gy = -gdot, mu = s.mu;
+        const double sHs = c1 * c1 * jg_sq + 2.0 * c1 * c2 * (gsq - mu * gy) + c2 * c2 * (gy - mu * ynn);
+        s.model_cost_change = -(c1 * gsq + c2 * gy + 0.5 * sHs);
+    }
     double a_s = 0;
 #pragma unroll 4
     for (int i = tid; i < n; i += blockDim.x) {
@@ -1381,10 +1385,27 @@ __global__ void __launch_bounds__(256) k_decide(DevBatch B, DevOpt O) {
     WinState& s = B.ws[w];
     if (s.status != SWF_RUNNING || !s.eval_cand) return;
     const WinRec& W = B.win[w];
-    double ca[2];
-    win_cost_aux_part(B, W, ca[0], ca[1]);
+    double ca[2] = { 0.0, 0.0 };
+    {
+        // candidate cost: the same guarded load groups and index-ordered additions as win_cost_aux_part, costs only
+        constexpr int U = 12;
+        for (int base = W.proj0 + threadIdx.x; base < W.proj1; base += U * blockDim.x) {
+            double cv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { int i = base + u * blockDim.x; cv[u] = i < W.proj1 ? B.p_cost[i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < U; u++) ca[0] += cv[u];
+        }
+        for (int base = W.gf0 + threadIdx.x; base < W.gf1; base += 4 * blockDim.x) {
+            double cv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { int i = base + u * blockDim.x; cv[u] = i < W.gf1 ? B.g_cost[i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) ca[0] += cv[u];
+        }
+    }
     block_reduce<2, 0>(ca, red);
-    double cand = ca[0], model_cost_change = -ca[1];
+    double cand = ca[0], model_cost_change = s.model_cost_change;
     if (!(cand == cand) || cand > 1.7976931348623157e308) cand = 1.7976931348623157e308;
     __syncthreads();
     if (tid == 0) {
