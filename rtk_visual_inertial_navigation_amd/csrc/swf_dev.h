@@ -119,6 +119,7 @@ struct DevBatch {
     // frames
     int n_fr;
     const int* fr_obs0; const int* fr_obs;     // CSR of observations per frame
+    const int* fr_red;                         // per frame slot: offset of its pose block in the reduced system
     // generic factors
     int n_gf;
     const GFac* gf;

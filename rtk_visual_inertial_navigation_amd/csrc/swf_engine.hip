@@ -95,6 +95,7 @@ struct swf_batch {
         for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
     }
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
+    int ls_qpb = 1, ls_tpw = 2; bool ls_folded = false, s_direct = false;     // k_lm_schur launch shape, fixed at creation (the pair lists depend on it)
     int timing = 0;                       // bitmask of SWF_K_* brackets
     swf_timing last{};
     std::vector<hipEvent_t> ev;           // event pool (pairs)
@@ -116,7 +117,7 @@ struct Build {
     std::vector<unsigned long long> lm_fmask;
     std::vector<int> fsb_win, fsb_obs0, fsb_perm, fsb_foff, fsb_foff0, fsb_out0;
     long long fs_tot = 0;
-    std::vector<int> fr_obs0, fr_obs;
+    std::vector<int> fr_obs0, fr_obs, fr_red;
     std::vector<GFac> gf;
     std::vector<int> s_x, s_loc, s_ls, s_joff, s_ccol;
     std::vector<double> imu_pre, cp_dat, pr_dat, dop_dat, sp_w, gx_dat;
@@ -216,6 +217,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         for (int p = 0; p < nP; p++) if (seen[p] && loc[bidP(p)] >= 0) {
             if (is_e(bidP(p))) return fail(SWF_E_UNSUPPORTED, "pose block in elimination group 0");
             frame_of[p] = nf++;
+            B.fr_red.push_back(loc[bidP(p)] - ne);
         }
         R.nF = nf; R.fr_base = B.n_fr;
     }
@@ -715,7 +717,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     }
     D.n_fr = B.n_fr;
     B.fr_obs0.push_back((int)B.fr_obs.size());
-    PUT(fr_obs0, B.fr_obs0); PUT(fr_obs, B.fr_obs);
+    PUT(fr_obs0, B.fr_obs0); PUT(fr_obs, B.fr_obs); PUT(fr_red, B.fr_red);
     D.n_fsb = (int)B.fsb_win.size();
     B.fsb_obs0.push_back(D.n_proj); B.fsb_perm.resize((size_t)D.n_proj + 1, 0);
     PUT(fsb_win, B.fsb_win); PUT(fsb_obs0, B.fsb_obs0); PUT(fsb_perm, B.fsb_perm); PUT(fsb_foff, B.fsb_foff); PUT(fsb_foff0, B.fsb_foff0); PUT(fsb_out0, B.fsb_out0);
@@ -758,9 +760,25 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
     {
         std::vector<int> pd, po, clc[4], cle;
+        {
+            // k_lm_schur's launch shape: size-specialised variants (<= 16 tiles / <= 10 frames, <= 40 tiles / <= 21 frames, <= 120 tiles /
+            // <= 40 frames) and the landmark parts per block — as many as still leave >= 2 blocks per CU.  SWF_LS_VARIANT / SWF_LS_QPB:
+            // test / debugging aids.  A block that covers all parts folds them in registers (ls_folded) and, in that case, writes -P
+            // straight into S (s_direct); the off-diagonal frame pairs without any other contribution then leave the assembly's list.
+            const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;
+            const int force_qpb = getenv("SWF_LS_QPB") ? atoi(getenv("SWF_LS_QPB")) : 0;
+            int qpb = 1;
+            while (qpb < GEMM_SPLIT && (long long)n * GEMM_SPLIT / (2 * qpb) >= 2LL * b->n_cu) qpb *= 2;
+            if (force_qpb >= 1 && force_qpb <= GEMM_SPLIT && (force_qpb & (force_qpb - 1)) == 0) qpb = force_qpb;
+            b->ls_qpb = qpb;
+            b->ls_tpw = (b->max_tiles <= 16 && force < 1) ? 2 : (b->max_tiles <= 40 && force < 2) ? 5 : 10;
+            b->ls_folded = qpb == GEMM_SPLIT && b->ls_tpw <= 5;          // must mirror CAN_FOLD in k_lm_schur (tpw 10 = the 1024-thread variant: no fold)
+            b->s_direct = b->ls_folded && !getenv("SWF_NO_S_DIRECT");
+        }
         for (size_t i = 0; i < B.pair.size(); i++) {
             Pair& Pq = B.pair[i]; const WinRec& Rw = B.win[Pq.win];      // self-contained records (see Pair)
             Pq.fsb0 = Rw.fsb0; Pq.fsb1 = Rw.fsb1; Pq.n = Rw.n_red; Pq.m = 6 * Rw.nF; Pq.S_base = Rw.S_base; Pq.P_base = Rw.P_base;
+            if (b->s_direct && !Pq.is_diag && Pq.fa >= 0 && Pq.fb >= 0 && Pq.c0 == Pq.c1) continue;       // -P is already in S, nothing to add
             (Pq.is_diag ? pd : po).push_back((int)i);
         }
         // off-diagonal pairs by descending entry rounds (16 entries per round): k_assemble_all's waves (four pairs each) become
@@ -989,19 +1007,14 @@ struct Launcher {
         if (D.n_lm) {
             Bracket t(*this, SWF_K_LM_SCHUR);
             // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames);
-            const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;     // test / debugging aids, read per launch
-            const int force_qpb = getenv("SWF_LS_QPB") ? atoi(getenv("SWF_LS_QPB")) : 0;
-            int qpb = 1;                                        // parts per block: as many as still leave >= 2 blocks per CU
-            while (qpb < GEMM_SPLIT && (long long)D.n_win * GEMM_SPLIT / (2 * qpb) >= 2LL * b->n_cu) qpb *= 2;
-            if (force_qpb >= 1 && force_qpb <= GEMM_SPLIT && (force_qpb & (force_qpb - 1)) == 0) qpb = force_qpb;
+            const int qpb = b->ls_qpb, tpw = b->ls_tpw, sd = b->s_direct ? 1 : 0;       // fixed at creation (swf_batch_create)
             dim3 grid(D.n_win, GEMM_SPLIT / qpb); lm_qpb = qpb;
-            int tpw = (b->max_tiles <= 16 && force < 1) ? 2 : (b->max_tiles <= 40 && force < 2) ? 5 : 10;
-            lm_folded = qpb == GEMM_SPLIT && tpw <= 5;          // must mirror CAN_FOLD in k_lm_schur (tpw 10 = the 1024-thread variant: no fold)
-            if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb, 0);
-            else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb, 0);
+            lm_folded = b->ls_folded;
+            if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb, 0, sd);
+            else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb, 0, sd);
             else {
                 // up to 120 tiles: two launches of the 12-consumer-wave, 5-slot variant (tiles 0..59, 60..119)
-                hipLaunchKernelGGL((k_lm_schur<12, 5>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb, 0);
+                hipLaunchKernelGGL((k_lm_schur<12, 5>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb, 0, 0);
                 lm_second = write_S && b->max_tiles > 60;       // tiles 60..119: launched below, on the auxiliary stream when there is one
             }
         }
@@ -1019,7 +1032,7 @@ struct Launcher {
                 // IMU / clique branch, next to the first range
                 int qpb2 = lm_qpb; dim3 grid2(D.n_win, GEMM_SPLIT / qpb2);
                 Bracket t(*this, SWF_K_LM_SCHUR, sa);
-                hipLaunchKernelGGL((k_lm_schur<12, 5>), grid2, dim3(LS_NT(12)), 0, sa, D, O, write_S, qpb2, 60);
+                hipLaunchKernelGGL((k_lm_schur<12, 5>), grid2, dim3(LS_NT(12)), 0, sa, D, O, write_S, qpb2, 60, 0);
                 lm_second = false;
             }
             if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);
@@ -1029,7 +1042,7 @@ struct Launcher {
         if (D.n_pd) {
             Bracket t(*this, SWF_K_ASSEMBLE);
             Segs S{}; S.e[0] = nb((size_t)D.n_pd * 64, 256); S.e[1] = S.e[0] + (write_S ? nb((size_t)D.n_po * 16, 256) : 0);
-            hipLaunchKernelGGL(k_assemble_all, dim3(S.e[1]), dim3(256), 0, st, D, O, write_S, S, lm_folded ? 1 : GEMM_SPLIT);
+            hipLaunchKernelGGL(k_assemble_all, dim3(S.e[1]), dim3(256), 0, st, D, O, write_S, S, b->s_direct ? 0 : lm_folded ? 1 : GEMM_SPLIT);
         }
     }
     void reduced() {

@@ -783,7 +783,7 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 // <12,5> twice (<= 120: tile_base 0 and 60; a single 10-slot variant spills under the 128-VGPR cap of 1024 threads —
 // both launches redo the cheap producer work instead)
 template <int NCW, int TPW>
-__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int do_gemm, int qpb, int tile_base) {
+__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int do_gemm, int qpb, int tile_base, int s_direct) {
     constexpr int NPW = LS_NPW;
     __shared__ double cells[2][(LS_CAP + 1) * LS_CS];      // + one all-zero cell per buffer
     __shared__ int tbl[2][LS_LPC][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
@@ -886,6 +886,30 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             if (sq + 1 < qpb) continue;
         }
         double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)(fold ? 0 : sp0 + sq) * m * m;
+        if (fold && s_direct) {
+            // large batches: the folded product goes straight to where it ends up, S_pp = -P in the reduced system's own order
+            // (k_assemble_all then adds the few other contributions on top and never touches a frame pair that has none — 171 of the
+            // 190 pose pairs of a cfg3 window).  -P + c == c - P bit for bit, so the result is that of the P route.
+            double* Sw = B.S + W.S_base; const int nr = W.n_red; const int* fred = B.fr_red + W.fr_base;
+#pragma unroll
+            for (int sl = 0; sl < TPW; sl++) {
+                int t = tile_base + cw + sl * NCW;
+                if (t < ntiles) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        int r = t_tr[sl] * 16 + lk + 4 * q, c = t_tc[sl] * 16 + li;
+                        if (r < m && c < m && r >= c) {
+                            int fa = r / 6, fb = c / 6;
+                            int row = fred[fa] + (r - 6 * fa), col = fred[fb] + (c - 6 * fb);
+                            if (row < col) { int tt = row; row = col; col = tt; }
+                            Sw[(size_t)row * nr + col] = -tot[CAN_FOLD ? sl : 0][q];
+                        }
+                    }
+                }
+                acc[sl] = double4_t{ 0, 0, 0, 0 };
+            }
+            continue;
+        }
 #pragma unroll
         for (int sl = 0; sl < TPW; sl++) {
             int t = tile_base + cw + sl * NCW;
@@ -1553,10 +1577,13 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
         if (Pr.fa >= 0 && Pr.fb >= 0) {
             int pr = 6 * Pr.fa + i, pc = 6 * Pr.fb + j;
             size_t pi = (pr >= pc) ? (size_t)pr * m + pc : (size_t)pc * m + pr;
-            double ps = 0;
+            if (n_part == 0) v = S[(size_t)(Pr.ra + i) * n + Pr.rb + j] + v;         // k_lm_schur left -P in place (s_direct): -P + c == c - P
+            else {
+                double ps = 0;
 #pragma unroll
-            for (int q = 0; q < GEMM_SPLIT; q++) if (q < n_part) ps += P[(size_t)q * m * m + pi];     // fixed order (n_part = 1: folded by k_lm_schur)
-            v -= ps;
+                for (int q = 0; q < GEMM_SPLIT; q++) if (q < n_part) ps += P[(size_t)q * m * m + pi];     // fixed order (n_part = 1: folded by k_lm_schur)
+                v -= ps;
+            }
             if (obs) v += hsum[r];
         }
         if (DIAG && i == j) v += s.mu * clampd(e < 64 ? dgs0 : dgs1, O.min_diag, O.max_diag);
