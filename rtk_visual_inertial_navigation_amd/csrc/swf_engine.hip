@@ -36,28 +36,99 @@ extern "C" int swf_device_count(int32_t* n) {
 extern "C" int swf_set_device(int32_t d) { HIPCHK(hipSetDevice(d)); return SWF_OK; }
 
 // ------------------------------------------------------------------ device buffer helper
-struct DevPool {
-    std::vector<void*> ptrs;
-    template <class T> int put(const std::vector<T>& h, const T** out, size_t min_elems = 1) {
-        size_t n = std::max(h.size(), min_elems);
+// Every buffer of a batch is carved out of a few slabs (bump allocation, 256-byte aligned): buffers with initial data share
+// "data" slabs that are mirrored in one host staging area and reach the device in ONE copy per slab (flush); zero-initialised
+// buffers share "zero" slabs that get one memset each.  Released slabs go to a process-wide cache instead of hipFree: the
+// ceres::Problem surface rebuilds its batch at every structure change (the estimator adds and removes landmarks every frame,
+// R/swf/swf_image.cpp:65-114), and ~100 hipMalloc + hipMemcpy + hipMemset calls per rebuild were most of that path's cost.
+// After flush() the pool is sealed: later allocations (the marginalisation consumer's outputs) are initialised on the spot.
+#include <mutex>
+namespace {
+struct SlabCache {
+    std::mutex mu; std::vector<std::pair<void*, size_t>> free_; size_t held = 0;
+    void* acquire(size_t& bytes) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            int best = -1;
+            for (int i = 0; i < (int)free_.size(); i++)
+                if (free_[i].second >= bytes && free_[i].second <= 4 * bytes && (best < 0 || free_[i].second < free_[best].second)) best = i;
+            if (best >= 0) { void* p = free_[best].first; bytes = free_[best].second; held -= bytes; free_.erase(free_.begin() + best); return p; }
+        }
         void* p = nullptr;
-        if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return -1;
-        ptrs.push_back(p);
-        if (hipMemset(p, 0, n * sizeof(T)) != hipSuccess) return -1;
-        if (!h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            trim(0);                                       // give the cache back and try once more
+            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        }
+        return p;
+    }
+    void give(void* p, size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        if (held + bytes > (size_t)2 << 30 || free_.size() >= 32) { (void)hipFree(p); return; }
+        free_.push_back({ p, bytes }); held += bytes;
+    }
+    void trim(size_t keep) {
+        std::lock_guard<std::mutex> g(mu);
+        while (held > keep && !free_.empty()) { held -= free_.back().second; (void)hipFree(free_.back().first); free_.pop_back(); }
+    }
+};
+// never destroyed: a ceres::Problem with static storage duration may release its batch after this file's statics are gone
+SlabCache& slab_cache() { static SlabCache* c = new SlabCache(); return *c; }
+}  // namespace
+
+struct DevPool {
+    struct Slab { char* dev = nullptr; size_t cap = 0, used = 0, flushed = 0; std::vector<char> host; };
+    std::vector<Slab> data, zero;
+    bool sealed = false;
+    void* bump(std::vector<Slab>& v, size_t bytes, bool mirrored, size_t first) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (v.empty() || v.back().used + bytes > v.back().cap) {
+            size_t want = std::max(bytes, v.empty() ? first : std::min<size_t>(2 * v.back().cap, (size_t)256 << 20));
+            Slab sl;
+            sl.dev = (char*)slab_cache().acquire(want);
+            if (!sl.dev) return nullptr;
+            sl.cap = want;
+            if (mirrored) sl.host.assign(want, 0);
+            v.push_back(std::move(sl));
+        }
+        Slab& sl = v.back();
+        void* p = sl.dev + sl.used;
+        sl.used += bytes;
+        return p;
+    }
+    template <class T> int put(const std::vector<T>& h, const T** out, size_t min_elems = 1) {
+        size_t n = std::max(h.size(), min_elems), bytes = n * sizeof(T);
+        void* p = bump(data, bytes, true, (size_t)4 << 20);
+        if (!p) return -1;
+        Slab& sl = data.back();
+        char* m = sl.host.data() + ((char*)p - sl.dev);
+        if (!h.empty()) memcpy(m, h.data(), h.size() * sizeof(T));
+        if (sealed) {                                      // late allocation: initialise now
+            if (hipMemcpy(p, m, (bytes + 255) & ~(size_t)255, hipMemcpyHostToDevice) != hipSuccess) return -1;
+            sl.flushed = sl.used;
+        }
         *out = (const T*)p;
         return 0;
     }
     template <class T> int zeros(size_t n, T** out) {
         n = std::max<size_t>(n, 1);
-        void* p = nullptr;
-        if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return -1;
-        ptrs.push_back(p);
-        if (hipMemset(p, 0, n * sizeof(T)) != hipSuccess) return -1;
+        void* p = bump(zero, n * sizeof(T), false, (size_t)16 << 20);
+        if (!p) return -1;
+        if (sealed) { if (hipMemset(p, 0, n * sizeof(T)) != hipSuccess) return -1; zero.back().flushed = zero.back().used; }
         *out = (T*)p;
         return 0;
     }
-    void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+    // one host-to-device copy per data slab, one memset per zero slab
+    int flush() {
+        for (Slab& sl : data) if (sl.used > sl.flushed) { if (hipMemcpy(sl.dev + sl.flushed, sl.host.data() + sl.flushed, sl.used - sl.flushed, hipMemcpyHostToDevice) != hipSuccess) return -1; sl.flushed = sl.used; }
+        for (Slab& sl : zero) if (sl.used > sl.flushed) { if (hipMemset(sl.dev + sl.flushed, 0, sl.used - sl.flushed) != hipSuccess) return -1; sl.flushed = sl.used; }
+        sealed = true;
+        return 0;
+    }
+    void release() {
+        for (Slab& sl : data) slab_cache().give(sl.dev, sl.cap);
+        for (Slab& sl : zero) slab_cache().give(sl.dev, sl.cap);
+        data.clear(); zero.clear(); sealed = false;
+    }
 };
 
 struct HostWin {       // what the host keeps per window for state transfer / export
@@ -881,6 +952,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         rc |= P.put(Joff, &Mt.Joff); rc |= P.put(roff, &Mt.roff); rc |= P.put(x0off, &Mt.x0off); rc |= P.put(Coff, &Mt.Coff); rc |= P.put(voff, &Mt.voff);
         Mt.prior_J = (double*)D.prior_J; Mt.prior_Jt = (double*)D.prior_Jt; Mt.prior_r0 = (double*)D.prior_r0; Mt.prior_x0 = (double*)D.prior_x0;
     }
+    if (!rc) rc = P.flush();
     if (rc) { P.release(); delete b; return fail(SWF_E_NODEVICE, "device allocation / upload failed"); }
     *out = b;
     int urc = swf_batch_upload_state(b);
