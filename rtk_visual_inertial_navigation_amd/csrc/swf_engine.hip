@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -73,6 +74,37 @@ struct SlabCache {
 };
 // never destroyed: a ceres::Problem with static storage duration may release its batch after this file's statics are gone
 SlabCache& slab_cache() { static SlabCache* c = new SlabCache(); return *c; }
+}  // namespace
+
+// streams and events are as expensive to create and destroy as device memory (milliseconds for a non-blocking stream): the
+// auxiliary stream + fork / join events of the latency path, and the timing events, are recycled the same way
+namespace {
+struct HandleCache {
+    std::mutex mu; std::vector<hipStream_t> streams; std::vector<hipEvent_t> sync_events, timing_events;
+    hipStream_t stream() {
+        { std::lock_guard<std::mutex> g(mu); if (!streams.empty()) { hipStream_t s_ = streams.back(); streams.pop_back(); return s_; } }
+        hipStream_t s_ = nullptr;
+        return hipStreamCreateWithFlags(&s_, hipStreamNonBlocking) == hipSuccess ? s_ : nullptr;
+    }
+    hipEvent_t event(bool timing) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto& v = timing ? timing_events : sync_events;
+            if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
+        }
+        hipEvent_t e = nullptr;
+        hipError_t rc = timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        return rc == hipSuccess ? e : nullptr;
+    }
+    void give(hipStream_t s_) { if (!s_) return; std::lock_guard<std::mutex> g(mu); if (streams.size() < 16) streams.push_back(s_); else (void)hipStreamDestroy(s_); }
+    void give(hipEvent_t e, bool timing) {
+        if (!e) return;
+        std::lock_guard<std::mutex> g(mu);
+        auto& v = timing ? timing_events : sync_events;
+        if (v.size() < 4096) v.push_back(e); else (void)hipEventDestroy(e);
+    }
+};
+HandleCache& handle_cache() { static HandleCache* c = new HandleCache(); return *c; }
 }  // namespace
 
 struct DevPool {
@@ -162,8 +194,8 @@ struct swf_batch {
     // projection / landmark branch; three reusable events carry the dependencies
     hipStream_t aux = nullptr; hipEvent_t ev_fork[3] = { nullptr, nullptr, nullptr };
     ~swf_batch() {
-        if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
-        for (auto& e : ev_fork) if (e) (void)hipEventDestroy(e);
+        if (aux) { (void)hipStreamSynchronize(aux); handle_cache().give(aux); }
+        for (auto& e : ev_fork) handle_cache().give(e, false);
     }
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
     int ls_qpb = 1, ls_tpw = 2; bool ls_folded = false, s_direct = false;     // k_lm_schur launch shape, fixed at creation (the pair lists depend on it)
@@ -719,19 +751,23 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         return fail(SWF_E_NODEVICE, "no HIP device: this library has no CPU fallback");
     Build B;
     std::vector<HostWin> hw(n);
+    const bool trace = getenv("SWF_TRACE_REBUILD") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tc0 = now();
     for (int i = 0; i < n; i++) {
         int rc = build_window(B, windows[i], i, hw[i]);
         if (rc != SWF_OK) return rc;
     }
+    const double tc1 = now();
     if (B.n_x > 0x7fffffffLL || B.n_loc > 0x7fffffffLL) return fail(SWF_E_UNSUPPORTED, "batch too large for 32-bit offsets");
     swf_batch* b = new swf_batch();
     b->stream = (hipStream_t)stream;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
     if ((n * 16 <= b->n_cu || getenv("SWF_AUX_STREAM_ALWAYS")) && !getenv("SWF_NO_AUX_STREAM")) {            // latency path: fork / join inside a linearisation
-        bool ok = hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&b->ev_fork[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { if (b->aux) (void)hipStreamDestroy(b->aux); b->aux = nullptr; }
+        bool ok = (b->aux = handle_cache().stream()) != nullptr;
+        for (int i = 0; i < 3 && ok; i++) ok = (b->ev_fork[i] = handle_cache().event(false)) != nullptr;
+        if (!ok) { handle_cache().give(b->aux); b->aux = nullptr; }
     }
     b->win = B.win; b->hw = hw; b->max_tiles = B.max_tiles; b->max_prior_dim = B.max_prior_dim; b->jac_bytes = B.jac_bytes;
     b->proj_bytes = (int64_t)312 * (int64_t)B.p_win.size();
@@ -952,10 +988,13 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         rc |= P.put(Joff, &Mt.Joff); rc |= P.put(roff, &Mt.roff); rc |= P.put(x0off, &Mt.x0off); rc |= P.put(Coff, &Mt.Coff); rc |= P.put(voff, &Mt.voff);
         Mt.prior_J = (double*)D.prior_J; Mt.prior_Jt = (double*)D.prior_Jt; Mt.prior_r0 = (double*)D.prior_r0; Mt.prior_x0 = (double*)D.prior_x0;
     }
+    const double tc2 = now();
     if (!rc) rc = P.flush();
     if (rc) { P.release(); delete b; return fail(SWF_E_NODEVICE, "device allocation / upload failed"); }
     *out = b;
+    const double tc3 = now();
     int urc = swf_batch_upload_state(b);
+    if (trace) fprintf(stderr, "[swf] batch_create: symbolic %.3f ms, tables %.3f ms, flush %.3f ms, upload_state %.3f ms\n", tc1 - tc0, tc2 - tc1, tc3 - tc2, now() - tc3);
     if (urc != SWF_OK) { swf_batch_destroy(b); *out = nullptr; return urc; }
     return SWF_OK;
 }
@@ -963,7 +1002,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
 extern "C" int swf_batch_destroy(swf_batch* b) {
     if (!b) return SWF_OK;
     (void)hipStreamSynchronize(b->stream);
-    for (auto& e : b->ev) (void)hipEventDestroy(e);
+    for (auto& e : b->ev) handle_cache().give(e, true);
     b->pool.release();
     delete b;
     return SWF_OK;
@@ -1039,7 +1078,7 @@ struct Launcher {
             if ((size_t)(b->ev_used + 1) * 2 > b->ev.size()) {
                 size_t old = b->ev.size();
                 b->ev.resize(old + 64);
-                for (size_t i = old; i < b->ev.size(); i++) (void)hipEventCreate(&b->ev[i]);
+                for (size_t i = old; i < b->ev.size(); i++) b->ev[i] = handle_cache().event(true);
             }
             slot = b->ev_used++;
             b->ev_kind.push_back(kind);

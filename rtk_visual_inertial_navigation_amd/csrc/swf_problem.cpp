@@ -10,6 +10,9 @@
 // failures surface through the return code AND summary.termination.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -488,13 +491,19 @@ static void scatter_values(swf_problem* p) {     // Double2Vector direction; con
 int swf_problem_solve(swf_problem* p, const swf_options* opt, swf_summary* summary) {
     if (!p || !opt || !summary) return SWF_E_INVALID;
     int rc;
+    const bool trace = getenv("SWF_TRACE_REBUILD") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     if (p->dirty || !p->batch) {
         if (p->batch) { swf_batch_destroy(p->batch); p->batch = nullptr; }
+        double t1 = now();
         if ((rc = flatten(p)) != SWF_OK) return rc;
         gather_values(p);
+        double t2 = now();
         const swf_flat_window* wp = &p->fw;
         if ((rc = swf_batch_create(&wp, 1, nullptr, &p->batch)) != SWF_OK) return rc;
         p->dirty = false;
+        if (trace) fprintf(stderr, "[swf] rebuild: destroy %.3f ms, flatten %.3f ms, batch_create %.3f ms\n", t1 - t0, t2 - t1, now() - t2);
     } else {
         gather_values(p);
         if ((rc = swf_batch_upload_state(p->batch)) != SWF_OK) return rc;
