@@ -114,7 +114,7 @@ int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, double* J, int
  * the null directions — while the factorisation of the whole S breaks down in the tail of such a window (the solve reports
  * SWF_LINEAR_SOLVER_FAILURE): SWF_PRIOR_EIGEN then re-factors the first m columns only and takes a rank-revealing factor of
  * A (rank < n is reported, the prior is valid); SWF_PRIOR_CHOLESKY has no such variant and reports rank -1.  A breakdown
- * inside S_mm itself is a failure in both forms (rank -1, no silent fallback).  SWF_PRIOR_EIGEN: n <= 256 (the Jacobi iteration keeps M in LDS up to n = 140, in an HBM scratch above);
+ * inside S_mm itself is a failure in both forms (rank -1, no silent fallback).  SWF_PRIOR_EIGEN: n <= 384 (the Jacobi iteration keeps M in LDS up to n = 140, in an HBM scratch above);
  * SWF_PRIOR_CHOLESKY: n <= 512.  Asynchronous on the batch stream. */
 enum { SWF_PRIOR_EIGEN = 0, SWF_PRIOR_CHOLESKY = 1 };
 int swf_batch_marginalize(swf_batch* b, double eps, int32_t form);

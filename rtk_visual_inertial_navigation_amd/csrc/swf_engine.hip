@@ -1349,7 +1349,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
     if (b->max_red > 512 || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "marginalisation needs the row-major Cholesky factor (n_red <= 512)");
     int nw = (int)b->win.size(), ldn = 1;
     for (int w = 0; w < nw; w++) ldn = std::max(ldn, b->hw[w].tail_dim);
-    if (form == SWF_PRIOR_EIGEN && ldn > MG_BIGN) return fail(SWF_E_UNSUPPORTED, "eigen square root: parameter_head tail larger than 256 dimensions (use SWF_PRIOR_CHOLESKY)");
+    if (form == SWF_PRIOR_EIGEN && ldn > MG_BIGN) return fail(SWF_E_UNSUPPORTED, "eigen square root: parameter_head tail larger than 384 dimensions (use SWF_PRIOR_CHOLESKY)");
     b->mg_ld = ldn;
     if (!b->mg_A) {
         std::vector<int> td(nw);

@@ -13,7 +13,7 @@
 #include "swf_dev.h"
 
 #define MG_MAXN 140                       // largest tail whose M is LDS-resident (153 KB)
-#define MG_BIGN 256                       // largest tail of the eigen form: above MG_MAXN, M lives in a per-window HBM / L2 scratch
+#define MG_BIGN 384                       // largest tail of the eigen form: above MG_MAXN, M lives in a per-window HBM / L2 scratch
 #define MG_NT 1024                        // 64 sixteen-lane groups = 64 column pairs per step
 #define MG_LDS_DOUBLES 19600              // 153 KB: M for n <= 140, M and V together for n <= 98
 #define Mc(c, r) Mm[(c) * n + (r)]

@@ -17,6 +17,11 @@ import numpy as np
 
 from rtk_visual_inertial_navigation_amd import synth
 from rtk_visual_inertial_navigation_amd.flat import FlatWindow, PRE_DOUBLES
+
+
+def _own(w):
+    """A window that owns its arrays (FlatWindow keeps views of contiguous slices: solving one in place would move its siblings)."""
+    return w.copy()
 from rtk_visual_inertial_navigation_amd.ordering import my_ordering
 
 
@@ -56,7 +61,7 @@ def explicit_window(K_vis=4, M=2, F=24, S=6, seed=7):
                     sp_idx=a["sp_idx"], sp_w=a["sp_w"], prior_nblk=a["prior_nblk"], prior_dim=a["prior_dim"],
                     prior_blk=np.array([0, n_pose], np.int32), prior_J=a["prior_J"], prior_r0=a["prior_r0"], prior_x0=a["prior_x0"],
                     pbg=w.pbg, gw=w.gw, base=w.base, meta=dict(K_vis=K_vis, M=M, S=S, T=T, vis=vis, hidden=hidden))
-    return wx, vis, hidden
+    return _own(wx), vis, hidden
 
 
 def epoch_windows(wx):
@@ -151,7 +156,7 @@ def composite_window(wx, chains):
             comp[k_].append(ch[k_])
         comp["pre"].append(pre_all[vis[gi]:vis[gi] + M + 1])
     cat = lambda key: np.concatenate([np.asarray(x, np.float64).ravel() for x in comp[key]])
-    return FlatWindow(pose=pose, sb=sb, lm=a["lm"], sc=sc, is_const=is_const,
+    return _own(FlatWindow(pose=pose, sb=sb, lm=a["lm"], sc=sc, is_const=is_const,
                       order_block=np.array(order_block, np.int32), order_group=np.array(order_group, np.int32), n_tail=0,
                       proj_idx=pi, proj_uv=a["proj_uv"], proj_sqrt_info=wx.proj_sqrt_info, proj_loss_a=wx.proj_loss_a,
                       sp_idx=np.array([0], np.int32), sp_w=a["sp_w"],
@@ -160,4 +165,4 @@ def composite_window(wx, chains):
                       comp_M=np.array(comp["M"], np.int32), comp_N=np.array(comp["N"], np.int32), comp_idx=np.concatenate([np.array(i, np.int32) for i in comp["idx"]]),
                       comp_pose=cat("pose"), comp_sb=cat("sb"), comp_pose_lin=cat("pose"), comp_sb_lin=cat("sb"),
                       comp_Hpp=cat("Hpp"), comp_HpN=cat("HpN"), comp_rhs_p=cat("rhs_p"), comp_HNN=cat("HNN"), comp_rhsN=cat("rhsN"), comp_pre=cat("pre"),
-                      pbg=wx.pbg, gw=wx.gw, base=wx.base, meta=dict(K=K, M=M, N=S, F=F))
+                      pbg=wx.pbg, gw=wx.gw, base=wx.base, meta=dict(K=K, M=M, N=S, F=F)))

@@ -491,14 +491,14 @@ def test_marginalisation_consumer_matches_oracle():
         for k in ("A", "b", "J", "r0", "eig"):
             assert np.array_equal(gb[k], g1[k]), (i, k)
     bs.close()
-    # beyond 256 dimensions the eigen form says so; the Cholesky form still applies
-    wx = synth.make_window(3, K=18, F=40, S=6, seed=35, head="frames")
+    # beyond 384 dimensions the eigen form says so; the Cholesky form still applies
+    wx = synth.make_window(3, K=28, F=40, S=6, seed=35, head="frames")
     bs, _ = gpu_solve(wx.copy(), default_options(step_mode=1))
     with pytest.raises(Exception):
         bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
     bs.marginalize(1e-8, solver.BatchSolver.PRIOR_CHOLESKY)
     c = bs.get_prior(0)
-    assert c["n"] == 261 and c["rank"] == 261
+    assert c["n"] == 411 and c["rank"] == 411
     assert np.abs(c["J"].T @ c["J"] - c["A"]).max() <= 1e-12 * np.abs(c["A"]).max()
     bs.close()
     # call-order errors are reported
@@ -506,6 +506,43 @@ def test_marginalisation_consumer_matches_oracle():
     with pytest.raises(Exception):
         bs.marginalize()
     bs.close()
+
+
+def test_cfg5_prior_obtained_by_marginalising_a_41st_frame():
+    """cfg5's dense prior "obtained by actually marginalising a 41st frame and its landmarks" — through the device
+    (ASSEMBLE_ELIMINATE_ONLY solve of GlobalMarge's sub-problem + swf_batch_marginalize), then the slid 40-frame window solved
+    against the oracle.  Small instance against the oracle's literal marginalisation first, then the full-size stress window."""
+    import cfg5_marg_gen as cg
+    full = synth.make_window(5, K=9, F=60, S=5, prior="gauge", seed=3)
+    wm, head = cg.marginalisation_window(full)
+    so, eo = ob.solve(wm.copy(), default_options(step_mode=1))
+    o = ob.marginalize(eo["S"], eo["rhs"], so.tail_dim)
+    bs, sg = gpu_solve(wm.copy(), default_options(step_mode=1))
+    bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+    g = bs.get_prior(0)
+    bs.close()
+    sc = np.abs(o["A"]).max()
+    m = eo["S"].shape[0] - so.tail_dim
+    ev = np.linalg.eigvalsh(eo["S"][:m, :m])
+    tol = max(1e-8, 1e-17 * ev[-1] / ev[0])         # the oracle's eigen pseudo-inverse of S_mm against the device's Cholesky route
+    assert g["n"] == so.tail_dim == 6 * sum(1 for b in head if b < 10) + 9 + 5 and g["rank"] == o["rank"]
+    assert np.abs(g["A"] - o["A"]).max() <= tol * sc and np.abs(g["J"].T @ g["J"] - g["A"]).max() <= 1e-11 * sc
+    wd, wo = cg.slid_window(full, head, g["J"], g["r0"]), cg.slid_window(full, head, o["J"], o["r0"])
+    s_o, _ = ob.solve(wo, default_options(), export=False)
+    bs, s_d = gpu_solve(wd, default_options())
+    bs.close()
+    assert [r["step_is_successful"] for r in s_d.rows()] == [r["step_is_successful"] for r in s_o.rows()]
+    for a, b in zip(s_d.rows(), s_o.rows()):
+        assert abs(a["cost"] - b["cost"]) <= 2e-6 * abs(b["cost"]) + 5e-5
+    assert np.abs(wd.a["pose"] - wo.a["pose"]).max() < 1e-6
+    # full size: 40 keyframes / 1000 features / 20 satellites, the prior over the ~20 poses that share landmarks with the 41st frame
+    w5, info = cg.make_cfg5_with_marginalised_prior(solver)
+    assert info["rank"] == info["prior_dim"] and info["prior_dim"] >= 6 + 9 + 20 + 6 * 8
+    c = w5.counts()
+    assert c["n_pose"] == 41 and c["n_lm"] > 900 and c["n_cp"] == 800
+    bs, s5 = gpu_solve(w5, default_options())
+    bs.close()
+    assert s5.termination in (1, 2, 3, 4) and s5.final_cost < 1e-3 * s5.initial_cost
 
 
 def test_full_size_properties_cfg5_and_batch():

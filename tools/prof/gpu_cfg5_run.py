@@ -1,10 +1,34 @@
-"""BASELINE cfg5 stress window, solve only (workload for rocprofv3; no oracle, no event brackets)."""
+"""BASELINE cfg5 stress window(s), solve only (workload for rocprofv3; no oracle, no event brackets).
+   python tools/prof/gpu_cfg5_run.py [windows = 1] [solves = 3]
+The prior of every window is OBTAINED by marginalising a 41st frame on the device (tests/cfg5_marg_gen.py)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
-from rtk_visual_inertial_navigation_amd import synth, solver
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import multiprocessing as mp
+from rtk_visual_inertial_navigation_amd import synth
+import cfg5_marg_gen as cg
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+jobs = [(40, 1000, 20, synth.BASE_SEED + 5 + i) for i in range(B + max(2, B // 4))]      # a few spares: see below
+if B >= 4:                                    # the 41-frame windows come from a process pool, forked before this process touches HIP
+    with mp.get_context("fork").Pool(min(B, 32, os.cpu_count() or 2)) as pool:
+        fulls = pool.map(cg.make_full, jobs)
+else:
+    fulls = [cg.make_full(j) for j in jobs]
+from rtk_visual_inertial_navigation_amd import solver
 from rtk_visual_inertial_navigation_amd.flat import default_options
-bs = solver.BatchSolver([synth.make_window(5)])
-for _ in range(3):
+ws = []
+for f in fulls:
+    # a 41-frame window in which a landmark of the marginalised frame is tracked to the very last frame has 41 observing frames — one
+    # more than the landmark kernel's tile budget (40); such a seed is skipped
+    try:
+        ws.append(cg.make_cfg5_with_marginalised_prior(solver, full=f)[0])
+    except solver.SwfError as e:
+        print("skipped a seed:", e)
+    if len(ws) == B:
+        break
+assert len(ws) == B
+bs = solver.BatchSolver(ws)
+for _ in range(n):
     bs.reset_state(); bs.solve_async(default_options()); bs.sync()
-print("cfg5 done", bs.summaries()[0].num_iterations)
+print("cfg5 done", B, [s.num_iterations for s in bs.summaries()[:4]], "prior dims", [w.meta["prior_dim"] for w in ws[:4]], "n_red", bs.dims(0)["n_red"])

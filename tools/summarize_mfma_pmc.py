@@ -15,12 +15,13 @@ import csv, json, sys, collections
 
 XCDS, SIMDS, CLK_GHZ = 8, 1024, 2.4
 src, dst = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "tools/prof/gpu_batch_prof.py 512 2 (512 cfg4 windows, batch only)"
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in csv.DictReader(open(src)):
     acc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE": cnt[r["Kernel_Name"]] += 1
 res = {"note": "rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE in its own pass (no tracing), workload "
-               "tools/prof/gpu_batch_prof.py 512 2 (512 cfg4 windows, batch only); per-launch averages.  See tools/summarize_mfma_pmc.py for the "
+               + workload + "; per-launch averages.  See tools/summarize_mfma_pmc.py for the "
                "normalisation.  Durations under counter collection are a few % longer than in the kernel trace.", "kernels": {}}
 for k, v in acc.items():
     n = max(1, cnt[k]); ins = v.get("SQ_INSTS_VALU_MFMA_F64", 0.0) / n
