@@ -292,7 +292,7 @@ def main():
             "chol_solve": ("mfma", calib["chol_flops"], "sum_w n_red^3 / 3 flops (n_red^3 / 6 multiply-adds)"),
             "frame_sums": ("hbm", 160 * n_obs, "160 B per observation (Jp, r, Y g_l read)"),
             "post_chol": ("hbm", 2 * 144 * n_obs, "Jp, Jl (144 B per observation) read by the back-substitution and by J D^-2 g"),
-            "post_dogleg": ("hbm", (144 + 152 + 16) * n_obs, "Jp, Jl read for J*step; candidate residuals: 152 B read + 16 B written per observation"),
+            "post_dogleg": ("hbm", (152 + 16) * n_obs, "candidate residuals: 152 B read + 16 B written per observation (the model cost change comes from k_dogleg's vector sums)"),
         }
         bound, units, what = work.get(dom, ("hbm", calib["jacobian_bytes"], "Jacobian bytes of the batch (SURVEY.md 8d formula)"))
         knames = {"eval_ps": "k_eval_ps<true>", "lm_schur": "k_lm_schur<8, 5>", "assemble": "k_assemble_all", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr2<9>"}
@@ -300,7 +300,8 @@ def main():
         # separate passes; gfx950: FETCH_SIZE counts half of wide coalesced reads -> x2), if available
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "batch512_pmc_fetch_write.json")))
+            rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "batch512_pmc_fetch_write.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "batch512_pmc_fetch_write.json")))
             kn = knames.get(dom, "k_" + dom)
             fk = [k for k in pmc["FETCH_SIZE"] if kn.split("<")[0] in k]
             if fk and B == 512:

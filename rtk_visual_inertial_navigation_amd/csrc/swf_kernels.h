@@ -788,6 +788,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
     __shared__ double cells[2][(LS_CAP + 1) * LS_CS];      // + one all-zero cell per buffer
     __shared__ int tbl[2][LS_LPC][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
     __shared__ unsigned long long Ms[2][LS_LPC];           // frame mask of the chunk's landmarks (0 = none / constant landmark)
+    __shared__ int freds[LS_MAXF];                         // first reduced row of every frame's pose (s_direct write-out)
     constexpr int ZOFF = LS_CAP * LS_CS;
     // a block covers qpb consecutive landmark parts of its window (qpb = 1, 2, 4, 8 or 16; a single window spreads over 16
     // workgroups, large batches use 16 so the producer / consumer pipeline fills once per block).  Every part still gets
@@ -810,7 +811,12 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
         // tiles of this wave: tile index and frame masks (wave-uniform), per-lane operand addressing:
         // table column of the lane's frame (column nF = the zero cell for lanes outside the matrix and the
         // fourth k-slot) and offset inside the cell
-        int t_tr[TPW], t_tc[TPW], pk[TPW];                 // pk = fA | fB << 8 | subA << 16 | subB << 24 (one VGPR per slot)
+        int pk[TPW];                                       // pk = fA | fB << 8 | subA << 16 | subB << 24 (one VGPR per slot)
+        auto tile_rc = [&](int t, int& tr, int& tc) {      // (row, column) of lower-triangle tile t; recomputed at write-out: a register pair per slot spilled
+            tr = 0;
+            while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
+            tc = t - tr * (tr + 1) / 2;
+        };
         unsigned long long mA[TPW], mB[TPW];
         constexpr bool CAN_FOLD = TPW <= 5 && NCW == 8;     // 768-thread blocks have the registers for the folded product
         double4_t acc[TPW], tot[CAN_FOLD ? TPW : 1];
@@ -819,11 +825,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             if (CAN_FOLD) tot[sl] = double4_t{ 0, 0, 0, 0 };
             int t = tile_base + cw + sl * NCW;
             int tr = 0, tc = 0;
-            if (t < ntiles) {
-                while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
-                tc = t - tr * (tr + 1) / 2;
-            }
-            t_tr[sl] = tr; t_tc[sl] = tc;
+            if (t < ntiles) tile_rc(t, tr, tc);
             int ra = tr * 16 + li, cb = tc * 16 + li;
             bool okA = ra < m && lk < 3 && t < ntiles, okB = cb < m && lk < 3 && t < ntiles;
             int fA_ = okA ? ra / 6 : nF, subA_ = okA ? lk * 6 + ra % 6 : 0;
@@ -836,6 +838,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             acc[sl] = double4_t{ 0, 0, 0, 0 };
         }
         unsigned long long tg = GNOW(); (void)tg;
+        if (s_direct) { int e = tid - NPW * 64; if (e < nF) freds[e] = B.fr_red[W.fr_base + e]; }
         __syncthreads();                                    // chunk c0 produced
         if (cw == 0) GSTAMP_ACC(8, tg);
         for (int sq = 0; sq < qpb; sq++) {
@@ -880,6 +883,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
         // (slot 0; k_assemble is told to read one partial): same bits, 1/GEMM_SPLIT of the P traffic.  Otherwise
         // each part's partial product is flushed to its own slot.
         bool fold = CAN_FOLD && qpb == GEMM_SPLIT;
+        tg = GNOW();
         if (fold) {
 #pragma unroll
             for (int sl = 0; sl < TPW; sl++) { tot[CAN_FOLD ? sl : 0] = sq == 0 ? acc[sl] : tot[CAN_FOLD ? sl : 0] + acc[sl]; acc[sl] = double4_t{ 0, 0, 0, 0 }; }
@@ -890,14 +894,15 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
             // large batches: the folded product goes straight to where it ends up, S_pp = -P in the reduced system's own order
             // (k_assemble_all then adds the few other contributions on top and never touches a frame pair that has none — 171 of the
             // 190 pose pairs of a cfg3 window).  -P + c == c - P bit for bit, so the result is that of the P route.
-            double* Sw = B.S + W.S_base; const int nr = W.n_red; const int* fred = B.fr_red + W.fr_base;
+            double* Sw = B.S + W.S_base; const int nr = W.n_red; const int* fred = freds;
 #pragma unroll
             for (int sl = 0; sl < TPW; sl++) {
                 int t = tile_base + cw + sl * NCW;
                 if (t < ntiles) {
+                    int tr, tc; tile_rc(t, tr, tc);
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        int r = t_tr[sl] * 16 + lk + 4 * q, c = t_tc[sl] * 16 + li;
+                        int r = tr * 16 + lk + 4 * q, c = tc * 16 + li;
                         if (r < m && c < m && r >= c) {
                             int fa = r / 6, fb = c / 6;
                             int row = fred[fa] + (r - 6 * fa), col = fred[fb] + (c - 6 * fb);
@@ -908,15 +913,17 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
                 }
                 acc[sl] = double4_t{ 0, 0, 0, 0 };
             }
+            if (cw == 0) GSTAMP_ACC(11, tg);
             continue;
         }
 #pragma unroll
         for (int sl = 0; sl < TPW; sl++) {
             int t = tile_base + cw + sl * NCW;
             if (t < ntiles) {
+                int tr, tc; tile_rc(t, tr, tc);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    int r = t_tr[sl] * 16 + lk + 4 * q, c = t_tc[sl] * 16 + li;
+                    int r = tr * 16 + lk + 4 * q, c = tc * 16 + li;
                     if (r < m && c < m) P[(size_t)r * m + c] = fold ? tot[CAN_FOLD ? sl : 0][q] : acc[sl][q];
                 }
             }
