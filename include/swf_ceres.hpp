@@ -114,6 +114,7 @@ struct IMUGNSSInfo {
     int M = 0;                                     // hidden GNSS epochs
     double* hidden_pose = nullptr; double* hidden_sb = nullptr;        // [M][7], [M][9]
     std::vector<double> pose_lin, sb_lin, Hpp, HpN, rhs_p, HNN, rhsN, pre;
+    int mid = 0; std::vector<double> H12;          // AddMidMargInfo's product (gnss_Index, pose1_pose2_hessians): link mid in 1..M-1, 15 x 15; 0 = none
 };
 struct IMUGNSSFactor : CostFunction { IMUGNSSInfo* info; explicit IMUGNSSFactor(IMUGNSSInfo* i) : info(i) {} };
 struct InitialBlackFactor : CostFunction { double istd; explicit InitialBlackFactor(double w) : istd(w) {} };
@@ -248,6 +249,7 @@ class Problem {
         const int N = (int)param.size() - 4;
         swf_factor_id id = swf_add_imu_gnss(h_, param[0], param[1], param[2], param[3], param.data() + 4, N, I.M, I.hidden_pose, I.hidden_sb,
                                               I.pose_lin.data(), I.sb_lin.data(), I.Hpp.data(), I.HpN.data(), I.rhs_p.data(), I.HNN.data(), I.rhsN.data(), I.pre.data());
+        if (id >= 0 && I.mid > 0 && swf_set_imu_gnss_mid_link(h_, id, I.mid, I.H12.data()) != SWF_OK) throw std::runtime_error(swf_last_error());
         delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(InitialBlackFactor* f, LossFunction* loss, double* scalar) {

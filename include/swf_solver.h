@@ -236,6 +236,10 @@ int swf_composite_create(int32_t n, const int32_t* M, const int32_t* N, const do
 int swf_composite_evaluate(swf_composite* c, const double* outer, const double* Nv, int32_t want_jac,
                            double* residual, double* jac, double* Hd, double* rd, int32_t* status);
 int swf_composite_hidden(swf_composite* c, double* pose, double* sb);
+/* The middle-marginalisation branch (AddMidMargInfo :121-240, Evaluate :738-759): mid[f] = k in 1..M[f]-1 replaces the IMU factor of
+ * the link e_k-1 -> e_k by the cross block H12[f] (15 x 15 row-major, rows = e_k-1, columns = e_k) of a marginalised stretch of
+ * epochs; 0 = none.  Call before the first evaluation. */
+int swf_composite_set_mid_links(swf_composite* c, const int32_t* mid, const double* H12);
 int swf_composite_destroy(swf_composite* c);
 
 /* =====================================================================================
@@ -264,6 +268,17 @@ int swf_batch_marginal_priors(const swf_flat_window* const* windows, int32_t n, 
 int swf_composite_assemble(int32_t M, const int32_t* n_kept, const int32_t* kept_size, double* const* kept_key,
                            const double* A, const double* b, int32_t N_cap, double** N_keys, int32_t* N_out,
                            double* Hpp, double* HpN, double* rhs_p, double* HNN, double* rhsN);
+/* swf_composite_add_mid_prior: IMUGNSSBase::AddMidMargInfo (R/factor/gnss_imu_factor.cpp:121-240) — host bookkeeping.  The prior
+ * (A, b) of a marginalised stretch of GNSS epochs (MargGNSSFrames, R/swf/swf_core.cpp:570-641) keeps n_kept blocks: the pose (7) and
+ * speed-bias (9) of the two epochs either side of the stretch — kept_epoch[q] = k-1 or k for those blocks (ignored for scalars) — and
+ * ambiguities (1, identified by kept_key).  Its diagonal / ambiguity blocks are ADDED into the factor's arrays (laid out for N_cap
+ * ambiguities per row: HpN [M][15][N_cap], HNN [N_cap][N_cap], rhsN [N_cap]; N_keys holds *N_io keys on entry), ambiguities it
+ * sees first are appended (*N_io grows; SWF_E_INVALID beyond N_cap), and the cross block between the two epochs is returned in
+ * H12 (15 x 15 row-major, rows = e_k-1): pass k and H12 on as comp_mid / comp_H12 (swf_set_imu_gnss_mid_link,
+ * swf_composite_set_mid_links).  Compact HpN / HNN to stride *N_io afterwards if N_cap was larger. */
+int swf_composite_add_mid_prior(int32_t M, int32_t k, int32_t n_kept, const int32_t* kept_size, const int32_t* kept_epoch,
+                                double* const* kept_key, const double* A, const double* b, int32_t N_cap, double** N_keys,
+                                int32_t* N_io, double* Hpp, double* HpN, double* rhs_p, double* HNN, double* rhsN, double* H12);
 
 /* =====================================================================================
  * (2) ceres::Problem-shaped single-window surface
@@ -331,6 +346,8 @@ swf_factor_id swf_add_projection_inverse_depth(swf_problem* p, int32_t kind, dou
 swf_factor_id swf_add_imu_gnss(swf_problem* p, double* pose_i, double* sb_i, double* pose_j, double* sb_j, double* const* ambiguities,
                                int32_t N, int32_t M, double* hidden_pose, double* hidden_sb, const double* pose_lin, const double* sb_lin,
                                const double* Hpp, const double* HpN, const double* rhs_p, const double* HNN, const double* rhsN, const double* pre);
+/* the factor's middle-marginalisation link (IMUGNSSBase::AddMidMargInfo): see swf_flat_window::comp_mid / comp_H12.  k = 0 clears it. */
+int swf_set_imu_gnss_mid_link(swf_problem* p, swf_factor_id id, int32_t k, const double* H12);
 /* InitialBlackFactor(w) (R/swf/swf_core.cpp:553-556) */
 swf_factor_id swf_add_scalar_prior(swf_problem* p, double* scalar, double w);
 /* MarginalizationFactor(info) (R/swf/swf_core.cpp:551-552): kept blocks `keys` (sizes from the

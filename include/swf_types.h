@@ -154,6 +154,13 @@ typedef struct swf_flat_window {
     const double* comp_HNN;          /* [sum N N] */
     const double* comp_rhsN;         /* [sum N] */
     const double* comp_pre;          /* [sum M + n_comp][SWF_PRE_DOUBLES] */
+    /*      middle-marginalisation branch (AddMidMargInfo :121-240, Evaluate :738-759), optional (both NULL = no factor has one):
+     *      comp_mid[f] = k in 1..M-1: the link e_k-1 -> e_k carries the cross block pose1_pose2_hessians of a marginalised
+     *      stretch of epochs instead of an IMU factor (its pre-integration record is ignored); 0 = none.  comp_H12[f] = that block,
+     *      15 x 15 row-major, rows = e_k-1, columns = e_k.  The prior's other blocks are expected inside comp_Hpp / HpN / HNN /
+     *      rhs_p / rhsN already (swf_composite_add_mid_prior files them). */
+    const int32_t* comp_mid;         /* [n_comp] or NULL */
+    const double* comp_H12;          /* [n_comp][225] or NULL */
 
     /* ---- linearised priors, MarginalizationFactor (R/factor/marginalization_factor.cpp:410-446):
      *      r = r0 + J*dx, dx per kept block = x-x0, or [p-p0 ; +-2 vec(q0^-1 q)] for poses.

@@ -780,6 +780,7 @@ oracle_composite* oracle_composite_create(int M, int N, const double* pose, cons
                                           const double* Hpp, const double* HpN, const double* rhs_p, const double* HNN, const double* rhsN,
                                           const double* pre, const double* pbg, const double* gw);
 void oracle_composite_destroy(oracle_composite* c);
+int oracle_composite_set_mid(oracle_composite* c, int mid, const double* H12);
 void oracle_composite_hidden(const oracle_composite* c, double* pose, double* sb);
 int oracle_composite_evaluate(oracle_composite* c, const double* Pi, const double* Bi, const double* Pj, const double* Bj, const double* Nv,
                               int want_jac, double* residual, double* jac);
@@ -899,6 +900,7 @@ static ctx_t* ctx_build(const swf_flat_window* w) {
             c->comp[k] = oracle_composite_create(M, N, w->comp_pose + (size_t)e0 * 7, w->comp_sb + (size_t)e0 * 9, w->comp_pose_lin + (size_t)e0 * 7,
                                                  w->comp_sb_lin + (size_t)e0 * 9, w->comp_Hpp + (size_t)e0 * 225, w->comp_HpN + pn, w->comp_rhs_p + (size_t)e0 * 15,
                                                  w->comp_HNN + nn, w->comp_rhsN + no, w->comp_pre + (size_t)(e0 + k) * SWF_PRE_DOUBLES, w->pbg, w->gw);
+            if (w->comp_mid && w->comp_H12 && w->comp_mid[k]) oracle_composite_set_mid(c->comp[k], w->comp_mid[k], w->comp_H12 + (size_t)k * 225);
             c->comp_e_off[k + 1] = e0 + M; c->comp_idx_off[k + 1] = c->comp_idx_off[k] + 4 + N;
             pn += 15LL * M * N; nn += (long long)N * N; no += N;
             nslots += 4 + N;
@@ -1785,6 +1787,8 @@ struct oracle_composite {
     double *J, *r, *INC;                       /* schur_jacobian (G x G row-major), schur_residual, INC;  G = 30 + N */
     double Pi_old[7], Bi_old[9], Pj_old[7], Bj_old[9], *N_old;
     int history;
+    int mid; double H12[225];                  /* AddMidMargInfo :121-240: link `mid` (epoch mid-1 -> epoch mid, 1 <= mid <= M-1) carries the
+                                                  cross block pose1_pose2_hessians of a middle marginalisation instead of an IMU factor; 0 = none */
 };
 
 oracle_composite* oracle_composite_create(int M, int N, const double* pose, const double* sb, const double* pose_lin, const double* sb_lin,
@@ -1810,6 +1814,15 @@ oracle_composite* oracle_composite_create(int M, int N, const double* pose, cons
     c->N_old = (double*)calloc(N + 1, sizeof(double));
     c->history = 0;
     return c;
+}
+/* the middle-marginalisation branch (Evaluate :738-759): gnss_Index = mid, pose1_pose2_hessians = H12 (15 x 15 row-major, rows = epoch
+ * mid-1, columns = epoch mid).  The diagonal / ambiguity parts of that prior are expected inside Hpp / HpN / HNN / rhs_p / rhsN already,
+ * as AddMidMargInfo files them. */
+int oracle_composite_set_mid(oracle_composite* c, int mid, const double* H12) {
+    if (mid != 0 && (mid < 1 || mid > c->M - 1)) return -1;
+    c->mid = mid;
+    if (mid) memcpy(c->H12, H12, sizeof(c->H12));
+    return 0;
 }
 void oracle_composite_destroy(oracle_composite* c) {
     if (!c) return;
@@ -1961,11 +1974,20 @@ int oracle_composite_evaluate(oracle_composite* c, const double* Pi, const doubl
         for (int i = 0; i < M; i++) {
             const double* pa = c->pose + i * 7; const double* ba = c->sb + i * 9;
             const double* pb = (i != M - 1) ? c->pose + (i + 1) * 7 : Pj; const double* bb = (i != M - 1) ? c->sb + (i + 1) * 9 : Bj;
-            oracle_eval_imu2(pa, ba, pb, bb, c->pre + (size_t)(i + 1) * SWF_PRE_DOUBLES, c->pbg, c->gw, res, J1, J2);
-            co_accumulate(c, CO_POSE1, CO_POSE2, J1, J2, res);
-            /* UpdateRhsPose :535-556 + the epoch's GNSS prior blocks :775-778 */
             double dx[15];
-            co_inc15(pa, ba, c->pose_lin + i * 7, c->sb_lin + i * 9, 1.0, dx);
+            co_inc15(pa, ba, c->pose_lin + i * 7, c->sb_lin + i * 9, 1.0, dx);                     /* GetInc(i) */
+            if (c->mid && i + 1 == c->mid) {
+                /* :742-758: no IMU factor on this link; the marginalised cross term of the two epochs' increments */
+                double dx2[15];
+                co_inc15(pb, bb, c->pose_lin + (i + 1) * 7, c->sb_lin + (i + 1) * 9, 1.0, dx2);    /* GetInc(i + 1) */
+                co_mv(c->H12, 15, 15, dx2, 1.0, c->rhs[CO_POSE1]);
+                co_mtv(c->H12, 15, 15, dx, c->rhs[CO_POSE2]);
+                for (int k = 0; k < 225; k++) c->H[CO_POSE1 * CO_SIZE + CO_POSE2][k] += c->H12[k];
+            } else {
+                oracle_eval_imu2(pa, ba, pb, bb, c->pre + (size_t)(i + 1) * SWF_PRE_DOUBLES, c->pbg, c->gw, res, J1, J2);
+                co_accumulate(c, CO_POSE1, CO_POSE2, J1, J2, res);
+            }
+            /* UpdateRhsPose :535-556 + the epoch's GNSS prior blocks :775-778 */
             co_mv(c->Hpp + (size_t)i * 225, 15, 15, dx, 1.0, c->rhs[CO_POSE1]);
             co_mv(c->HpN + (size_t)i * 15 * N, 15, N, Nv, 1.0, c->rhs[CO_POSE1]);
             co_mtv(c->HpN + (size_t)i * 15 * N, 15, N, dx, c->rhs[CO_N]);

@@ -233,7 +233,8 @@ struct Build {
     std::vector<double> C_init, dgraw_init;      // static parts (prior cliques)
     // composite factors (concatenated over the batch)
     std::vector<int> co_M, co_N, co_gf, co_win, co_xo, co_xo_off{ 0 };
-    std::vector<double> co_pose, co_sb, co_pose_lin, co_sb_lin, co_Hpp, co_HpN, co_rhs_p, co_HNN, co_rhsN, co_pre, co_pbgw;
+    std::vector<double> co_pose, co_sb, co_pose_lin, co_sb_lin, co_Hpp, co_HpN, co_rhs_p, co_HNN, co_rhsN, co_pre, co_pbgw, co_H12;
+    std::vector<int> co_mid;
     std::vector<Pair> pair;
     std::vector<long long> pc_coff;
     std::vector<int> pc_cld, pc_voff;
@@ -562,6 +563,13 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
             B.co_HNN.insert(B.co_HNN.end(), w->comp_HNN + nn, w->comp_HNN + nn + (long long)N * N);
             B.co_rhsN.insert(B.co_rhsN.end(), w->comp_rhsN + no, w->comp_rhsN + no + N);
             B.co_pre.insert(B.co_pre.end(), w->comp_pre + (size_t)(e0 + k) * SWF_PRE_DOUBLES, w->comp_pre + (size_t)(e0 + k + M + 1) * SWF_PRE_DOUBLES);
+            {   // middle-marginalisation link (AddMidMargInfo): optional
+                int mid = w->comp_mid ? w->comp_mid[k] : 0;
+                if (mid != 0 && (mid < 1 || mid > M - 1 || !w->comp_H12)) return fail(SWF_E_INVALID, "composite factor: comp_mid must be 0 or a link between two hidden epochs (1..M-1), with comp_H12 given");
+                B.co_mid.push_back(mid);
+                if (mid) B.co_H12.insert(B.co_H12.end(), w->comp_H12 + (size_t)k * 225, w->comp_H12 + (size_t)(k + 1) * 225);
+                else B.co_H12.resize(B.co_H12.size() + 225, 0.0);
+            }
             for (int q = 0; q < 3; q++) B.co_pbgw.push_back(w->pbg[q]);
             for (int q = 0; q < 3; q++) B.co_pbgw.push_back(w->gw[q]);
             io += 4 + N; pn += 15LL * M * N; nn += (long long)N * N; no += N; e0 += M;
@@ -970,6 +978,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         { const double* t1 = nullptr; const double* t2 = nullptr; rc |= P.put(B.co_pose, &t1); rc |= P.put(B.co_sb, &t2); b->co_pose0 = (double*)t1; b->co_sb0 = (double*)t2; }
         rc |= P.put(B.co_pose_lin, &A.pose_lin); rc |= P.put(B.co_sb_lin, &A.sb_lin); rc |= P.put(B.co_Hpp, &A.Hpp); rc |= P.put(B.co_HpN, &A.HpN);
         rc |= P.put(B.co_rhs_p, &A.rhs_p); rc |= P.put(B.co_HNN, &A.HNN); rc |= P.put(B.co_rhsN, &A.rhsN); rc |= P.put(B.co_pre, &A.pre); rc |= P.put(B.co_pbgw, &A.pbgw);
+        rc |= P.put(B.co_mid, &A.mid); rc |= P.put(B.co_H12, &A.H12);
         rc |= P.zeros((size_t)eo[nc] * 225, &A.hmn_inv); rc |= P.zeros((size_t)eo[nc] * 225, &A.hmn_2); rc |= P.zeros((size_t)eo[nc] * 225, &A.hmn_0);
         rc |= P.zeros((size_t)pno[nc], &A.hmn_N); rc |= P.zeros((size_t)eo[nc] * 15, &A.rhsmn);
         rc |= P.zeros((size_t)g2o[nc], &A.Hd); rc |= P.zeros((size_t)go[nc], &A.rd); rc |= P.zeros((size_t)g2o[nc], &A.Ld); rc |= P.zeros((size_t)go[nc], &A.r0);
@@ -1560,6 +1569,7 @@ struct swf_composite {
     CompArgs A{};
     std::vector<void*> bufs;
     int n = 0; long long sumM = 0, sumN = 0, sumG = 0, sumG2 = 0;
+    std::vector<int> M;
     hipStream_t stream = nullptr;
     ~swf_composite() { for (void* p : bufs) (void)hipFree(p); }
 };
@@ -1625,6 +1635,8 @@ extern "C" int swf_composite_create(int32_t n, const int32_t* M, const int32_t* 
         A.iq_f = (const int*)up(qf.data(), qf.size() * sizeof(int)); A.iq_k = (const int*)up(qk.data(), qk.size() * sizeof(int));
         A.todo = (int*)up(nullptr, n * sizeof(int));
     }
+    A.mid = (const int*)up(nullptr, n * sizeof(int)); A.H12 = (const double*)up(nullptr, (size_t)n * 225 * D);
+    c->M.assign(M, M + n);
     if (bad) return fail(SWF_E_NODEVICE, "swf_composite_create: device allocation / upload failed");
     *out = c.release();
     return SWF_OK;
@@ -1648,6 +1660,16 @@ extern "C" int swf_composite_evaluate(swf_composite* c, const double* outer, con
     if (rd) HIPCHK(hipMemcpyAsync(rd, c->A.rd, c->sumG * sizeof(double), hipMemcpyDeviceToHost, st));
     if (status) HIPCHK(hipMemcpyAsync(status, c->A.status, c->n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    return SWF_OK;
+}
+
+extern "C" int swf_composite_set_mid_links(swf_composite* c, const int32_t* mid, const double* H12) {
+    if (!c || !mid || !H12) return fail(SWF_E_INVALID, "swf_composite_set_mid_links: null argument");
+    for (int f = 0; f < c->n; f++)
+        if (mid[f] != 0 && (mid[f] < 1 || mid[f] > c->M[(size_t)f] - 1)) return fail(SWF_E_INVALID, "swf_composite_set_mid_links: a link must lie between two hidden epochs (1..M-1)");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy((void*)c->A.mid, mid, (size_t)c->n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy((void*)c->A.H12, H12, (size_t)c->n * 225 * sizeof(double), hipMemcpyHostToDevice));
     return SWF_OK;
 }
 

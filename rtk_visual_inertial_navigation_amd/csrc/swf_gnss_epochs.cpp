@@ -115,4 +115,52 @@ int swf_composite_assemble(int32_t M, const int32_t* n_kept, const int32_t* kept
     return SWF_OK;
 }
 
+int swf_composite_add_mid_prior(int32_t M, int32_t k, int32_t n_kept, const int32_t* kept_size, const int32_t* kept_epoch,
+                                double* const* kept_key, const double* A, const double* b, int32_t N_cap, double** N_keys,
+                                int32_t* N_io, double* Hpp, double* HpN, double* rhs_p, double* HNN, double* rhsN, double* H12) {
+    if (M < 2 || k < 1 || k > M - 1 || n_kept < 1 || !kept_size || !kept_key || !A || !b || !N_io || !Hpp || !HpN || !rhs_p || !HNN || !rhsN || !H12 || (N_cap > 0 && !N_keys))
+        return efail(SWF_E_INVALID, "swf_composite_add_mid_prior: bad arguments");
+    int N = *N_io;
+    // where every kept block goes: epoch k-1 / k (pose rows 0..5, speed-bias rows 6..14 of the epoch's 15-block) or an ambiguity
+    std::vector<int> off((size_t)n_kept), len((size_t)n_kept), dst((size_t)n_kept), shift((size_t)n_kept);   // dst: -1 epoch k-1, -2 epoch k, >= 0 ambiguity
+    int dim = 0;
+    for (int q = 0; q < n_kept; q++) {
+        const int sz = kept_size[q];
+        off[(size_t)q] = dim; len[(size_t)q] = sz == 7 ? 6 : sz; dim += len[(size_t)q]; shift[(size_t)q] = sz == 9 ? 6 : 0;
+        if (sz == 7 || sz == 9) {
+            if (!kept_epoch || (kept_epoch[q] != k - 1 && kept_epoch[q] != k)) return efail(SWF_E_INVALID, "swf_composite_add_mid_prior: a pose / speed-bias block must belong to epoch k-1 or k");
+            dst[(size_t)q] = kept_epoch[q] == k - 1 ? -1 : -2;
+        } else if (sz == 1) {
+            int ix = 0;
+            while (ix < N && N_keys[ix] != kept_key[q]) ix++;
+            if (ix == N) {                                        // first seen here: appended (N_size_external, :141-176)
+                if (N >= N_cap) return efail(SWF_E_INVALID, "swf_composite_add_mid_prior: more ambiguity blocks than the caller's buffers hold");
+                N_keys[N++] = kept_key[q];
+            }
+            dst[(size_t)q] = ix;
+        } else return efail(SWF_E_INVALID, "swf_composite_add_mid_prior: kept blocks must be poses (7), speed-biases (9) or scalars (1)");
+    }
+    *N_io = N;
+    memset(H12, 0, sizeof(double) * 225);
+    double* Hp[2] = { Hpp + (size_t)(k - 1) * 225, Hpp + (size_t)k * 225 };
+    double* HN[2] = { HpN + (size_t)(k - 1) * 15 * N_cap, HpN + (size_t)k * 15 * N_cap };
+    double* rp[2] = { rhs_p + (size_t)(k - 1) * 15, rhs_p + (size_t)k * 15 };
+    for (int q1 = 0; q1 < n_kept; q1++)
+        for (int i = 0; i < len[(size_t)q1]; i++) {
+            const int r = off[(size_t)q1] + i, d1 = dst[(size_t)q1], s1 = shift[(size_t)q1];
+            if (d1 >= 0) rhsN[d1] += b[r]; else rp[-1 - d1][s1 + i] += b[r];
+            for (int q2 = 0; q2 < n_kept; q2++)
+                for (int j = 0; j < len[(size_t)q2]; j++) {
+                    const int d2 = dst[(size_t)q2], s2 = shift[(size_t)q2];
+                    const double v = A[(size_t)r * dim + off[(size_t)q2] + j];
+                    if (d1 >= 0 && d2 >= 0) HNN[(size_t)d1 * N_cap + d2] += v;
+                    else if (d1 < 0 && d2 >= 0) HN[-1 - d1][(size_t)(s1 + i) * N_cap + d2] += v;
+                    else if (d1 < 0 && d2 < 0 && d1 == d2) Hp[-1 - d1][(s1 + i) * 15 + s2 + j] += v;
+                    else if (d1 == -1 && d2 == -2) H12[(s1 + i) * 15 + s2 + j] = v;           // pose1_pose2_hessians (:224)
+                    // (ambiguity, epoch) and (epoch k, epoch k-1) are the transposes of cases above
+                }
+        }
+    return SWF_OK;
+}
+
 }  // extern "C"

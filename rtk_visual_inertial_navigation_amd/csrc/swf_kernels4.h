@@ -40,6 +40,8 @@ struct CompArgs {
     double* Jw; double* rw;                            // scratch: whitened IMU Jacobians [sum M + n][450] and residuals [sum M + n][16]
     const int* iq_f; const int* iq_k; int n_iq;        // the chains' IMU factors, flattened: owner factor and position k (0 .. M)
     int* todo;                                         // [n] set by k_comp_prep: 1 = this launch re-eliminates the factor
+    const int* mid; const double* H12;                 // [n], [n][225]: middle-marginalisation link (AddMidMargInfo :121-240): link mid[f] in 1..M-1
+                                                       // carries the cross block H12[f] instead of an IMU factor; 0 = none
 };
 
 // x (-) x0 = sgn [p - p0, +-2 vec(q0^-1 q), sb - sb0]   (GetInc :654-670, UpdateDeltaValues :560-598 with sgn = -1)
@@ -123,8 +125,9 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
     const int q = blockIdx.x * 8 + fl;
     const bool valid = q < A.n_iq;
     const int f = A.iq_f[valid ? q : A.n_iq - 1], k = A.iq_k[valid ? q : A.n_iq - 1];
-    const bool act = valid && A.todo[f];
     const int M = A.M[f], e0 = A.e_off[f];
+    // the link of a middle marginalisation has no IMU factor (Evaluate :738): its scratch rows stay zero, as allocated
+    const bool act = valid && A.todo[f] && !(k > 0 && k == A.mid[f]);
     const double* pre = A.pre + (size_t)(e0 + f + k) * SWF_PRE_DOUBLES;
     if (act) {
         const double* outer = A.outer + (size_t)f * 32;
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
     __syncthreads();
     if ((t & 63) < 8) {
         int fq = t & 63, q2 = blockIdx.x * 8 + fq;
-        if (q2 < A.n_iq && A.todo[A.iq_f[q2]])
+        if (q2 < A.n_iq && A.todo[A.iq_f[q2]] && !(A.iq_k[q2] > 0 && A.iq_k[q2] == A.mid[A.iq_f[q2]]))
             imu_unwhitened(st[fq], st[fq] + 7, st[fq] + 16, st[fq] + 23, pr[fq], pr[fq] + SWF_PRE_SQRTINFO, pr[fq] + SWF_PRE_SQRTINFO + 3, raw[fq], U[fq], true, t >> 6);
     }
     __syncthreads();
@@ -188,8 +191,9 @@ __global__ void __launch_bounds__(256, 4) k_comp_elim(CompArgs A) {
     __shared__ double scratch[1260];                                       // sJ ; then Ainv | L | T2 | T0 | TN
     double* const sJ = scratch + 450;
     double* const sAinv = scratch; double* const sL = scratch + 225; double* const T2 = scratch + 450; double* const T0 = scratch + 675; double* const TN = scratch + 900;
-    __shared__ double sRes[16], sdinv[CO_MAXG], sOut[32], sNv[CO_MAXN], sDx[16];
+    __shared__ double sRes[16], sdinv[CO_MAXG], sOut[32], sNv[CO_MAXN], sDx[16], sDx2[16];
     __shared__ int sBad;
+    const int midk = A.mid[f]; const double* H12 = A.H12 + (size_t)f * 225;
     if (t < 32) sOut[t] = A.outer[(size_t)f * 32 + t];
     if (t < N) sNv[t] = A.Nv[n0 + t];
     if (t == 0) sBad = 0;
@@ -207,6 +211,8 @@ __global__ void __launch_bounds__(256, 4) k_comp_elim(CompArgs A) {
         if (t < 15) sRes[t] = A.rw[(size_t)(e0 + f + k) * 16 + t];
         if (k > 0 && t == 255)       // GetInc of the epoch that this factor completes (its GNSS prior is added in the same pass below)
             co_inc15(A.pose + (size_t)(e0 + k - 1) * 7, A.sb + (size_t)(e0 + k - 1) * 9, A.pose_lin + (size_t)(e0 + k - 1) * 7, A.sb_lin + (size_t)(e0 + k - 1) * 9, 1.0, sDx);
+        const bool midl = midk > 0 && k == midk;        // Evaluate :738-759: this link is the cross term of a middle marginalisation (its IMU scratch is zero)
+        if (midl && t == 254) co_inc15(A.pose + (size_t)(e0 + k) * 7, A.sb + (size_t)(e0 + k) * 9, A.pose_lin + (size_t)(e0 + k) * 7, A.sb_lin + (size_t)(e0 + k) * 9, 1.0, sDx2);
         __syncthreads();
         // JacobianResidualUpdateHessianRhs: Ja = columns 0..14 (older state), Jb = columns 15..29 (newer state)
         //   k = 0 : blocks (Pose0, Pose1):  H33 += Ja^T Ja, H03 += Jb^T Ja, H00 += Jb^T Jb
@@ -220,11 +226,15 @@ __global__ void __launch_bounds__(256, 4) k_comp_elim(CompArgs A) {
                 if (blk == 0) { for (int q = 0; q < 15; q++) s += sJ[q * 30 + i] * sJ[q * 30 + j]; Haa[ee] += s; }
                 else if (blk == 2) { for (int q = 0; q < 15; q++) s += sJ[q * 30 + 15 + i] * sJ[q * 30 + 15 + j]; Hbb[ee] += s; }
                 else if (k == 0) { for (int q = 0; q < 15; q++) s += sJ[q * 30 + 15 + i] * sJ[q * 30 + j]; Hx[ee] += s; }        // Jb^T Ja
-                else { for (int q = 0; q < 15; q++) s += sJ[q * 30 + i] * sJ[q * 30 + 15 + j]; Hx[ee] += s; }                   // Ja^T Jb
+                else { for (int q = 0; q < 15; q++) s += sJ[q * 30 + i] * sJ[q * 30 + 15 + j]; if (midl) s += H12[ee]; Hx[ee] += s; }    // Ja^T Jb (+ pose1_pose2_hessians)
             }
             if (t < 30) {
                 int j = t < 15 ? t : t - 15; double s = 0;
                 for (int q = 0; q < 15; q++) s += sJ[q * 30 + t] * sRes[q];
+                if (midl) {                                 // rhs(Pose1) += H12 inc(e_k), rhs(Pose2) += H12^T inc(e_k-1)
+                    if (t < 15) for (int q = 0; q < 15; q++) s += H12[j * 15 + q] * sDx2[q];
+                    else for (int q = 0; q < 15; q++) s += H12[q * 15 + j] * sDx[q];
+                }
                 if (t < 15) ra[j] += s; else rb[j] += s;
             }
         }

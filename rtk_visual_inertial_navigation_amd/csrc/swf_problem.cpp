@@ -31,6 +31,7 @@ struct PFactor {
     int dim = 0;                   // prior
     int M = 0, N = 0;              // composite IMU-GNSS factor: hidden epochs, ambiguities
     double* hid_pose = nullptr; double* hid_sb = nullptr;     // its hidden epochs: caller memory, [M][7] / [M][9]
+    int mid = 0; std::vector<double> H12;                     // its middle-marginalisation link (swf_set_imu_gnss_mid_link)
 };
 }  // namespace
 
@@ -59,6 +60,7 @@ struct swf_problem {
     std::vector<int32_t> comp_M, comp_N, comp_idx;
     std::vector<double> comp_pose, comp_sb, comp_pose_lin, comp_sb_lin, comp_Hpp, comp_HpN, comp_rhs_p, comp_HNN, comp_rhsN, comp_pre;
     std::vector<const PFactor*> comp_fac;
+    std::vector<int32_t> comp_mid; std::vector<double> comp_H12;
     std::vector<int32_t> idp_kind, idp_idx; std::vector<double> idp_pts;      // inverse-depth projection factors, flattened
     int hs_row = 0;
     bool solved = false;
@@ -207,6 +209,15 @@ swf_factor_id swf_add_imu_gnss(swf_problem* p, double* pose_i, double* sb_i, dou
     swf_factor_id id = add_factor(p, FT_COMP, keys, sizes, rec.data(), rec.size());
     if (id >= 0) { PFactor& f = p->factors[id]; f.M = M; f.N = N; f.hid_pose = hidden_pose; f.hid_sb = hidden_sb; }
     return id;
+}
+int swf_set_imu_gnss_mid_link(swf_problem* p, swf_factor_id id, int32_t k, const double* H12) {
+    if (!p || id < 0 || id >= (swf_factor_id)p->factors.size() || p->factors[id].type != FT_COMP || !p->factors[id].alive) return pfail(SWF_E_INVALID, "swf_set_imu_gnss_mid_link: not a composite factor of this problem");
+    PFactor& f = p->factors[id];
+    if (k != 0 && (k < 1 || k > f.M - 1 || !H12)) return pfail(SWF_E_INVALID, "swf_set_imu_gnss_mid_link: the link must lie between two hidden epochs (1..M-1)");
+    f.mid = k;
+    if (k) f.H12.assign(H12, H12 + 225); else f.H12.clear();
+    p->dirty = true;
+    return SWF_OK;
 }
 swf_factor_id swf_add_linear_prior(swf_problem* p, double* const* keys, int32_t n_keys, const double* J, const double* r0, const double* x0) {
     if (!p || !keys || n_keys <= 0 || !J || !r0 || !x0) return SWF_E_INVALID;
@@ -387,7 +398,7 @@ static int flatten(swf_problem* p) {
     p->spr_idx.clear(); p->spr_dat.clear(); p->scp_idx.clear(); p->scp_dat.clear(); p->fix_idx.clear(); p->fix_dat.clear();
     p->idp_kind.clear(); p->idp_idx.clear(); p->idp_pts.clear();
     p->comp_M.clear(); p->comp_N.clear(); p->comp_idx.clear(); p->comp_pose.clear(); p->comp_sb.clear(); p->comp_pose_lin.clear(); p->comp_sb_lin.clear();
-    p->comp_Hpp.clear(); p->comp_HpN.clear(); p->comp_rhs_p.clear(); p->comp_HNN.clear(); p->comp_rhsN.clear(); p->comp_pre.clear(); p->comp_fac.clear();
+    p->comp_Hpp.clear(); p->comp_HpN.clear(); p->comp_rhs_p.clear(); p->comp_HNN.clear(); p->comp_rhsN.clear(); p->comp_pre.clear(); p->comp_fac.clear(); p->comp_mid.clear(); p->comp_H12.clear();
     p->prior_nblk.clear(); p->prior_dim.clear(); p->prior_blk.clear(); p->prior_J.clear(); p->prior_r0.clear(); p->prior_x0.clear();
     double sqrt_info = 0, loss_a = 0; bool have_proj = false;
     for (auto& f : p->factors) {
@@ -431,6 +442,8 @@ static int flatten(swf_problem* p) {
             auto take = [&](std::vector<double>& dst, size_t n) { dst.insert(dst.end(), d, d + n); d += n; };
             take(p->comp_pose_lin, (size_t)M * 7); take(p->comp_sb_lin, (size_t)M * 9); take(p->comp_Hpp, (size_t)M * 225); take(p->comp_HpN, (size_t)M * 15 * N);
             take(p->comp_rhs_p, (size_t)M * 15); take(p->comp_HNN, (size_t)N * N); take(p->comp_rhsN, (size_t)N); take(p->comp_pre, (size_t)(M + 1) * SWF_PRE_DOUBLES);
+            p->comp_mid.push_back(f.mid);
+            if (f.mid) p->comp_H12.insert(p->comp_H12.end(), f.H12.begin(), f.H12.end()); else p->comp_H12.resize(p->comp_H12.size() + 225, 0.0);
             break;
         }
         case FT_PRIOR: {
@@ -463,7 +476,7 @@ static int flatten(swf_problem* p) {
     w.n_comp = (int)p->comp_M.size(); w.comp_M = p->comp_M.data(); w.comp_N = p->comp_N.data(); w.comp_idx = p->comp_idx.data();
     w.comp_pose = p->comp_pose.data(); w.comp_sb = p->comp_sb.data(); w.comp_pose_lin = p->comp_pose_lin.data(); w.comp_sb_lin = p->comp_sb_lin.data();
     w.comp_Hpp = p->comp_Hpp.data(); w.comp_HpN = p->comp_HpN.data(); w.comp_rhs_p = p->comp_rhs_p.data(); w.comp_HNN = p->comp_HNN.data();
-    w.comp_rhsN = p->comp_rhsN.data(); w.comp_pre = p->comp_pre.data();
+    w.comp_rhsN = p->comp_rhsN.data(); w.comp_pre = p->comp_pre.data(); w.comp_mid = p->comp_mid.data(); w.comp_H12 = p->comp_H12.data();
     w.n_prior = (int)p->prior_nblk.size(); w.prior_nblk = p->prior_nblk.data(); w.prior_dim = p->prior_dim.data();
     w.prior_blk = p->prior_blk.data(); w.prior_J = p->prior_J.data(); w.prior_r0 = p->prior_r0.data(); w.prior_x0 = p->prior_x0.data();
     for (int k = 0; k < 3; k++) { w.pbg[k] = p->pbg[k]; w.gw[k] = p->gw[k]; w.base[k] = p->base[k]; }

@@ -39,7 +39,7 @@ class FlatWindowC(C.Structure):
         ("n_idp", C.c_int32), ("idp_kind", _pi), ("idp_idx", _pi), ("idp_pts", _pd),
         ("n_comp", C.c_int32), ("comp_M", _pi), ("comp_N", _pi), ("comp_idx", _pi), ("comp_pose", _pd), ("comp_sb", _pd),
         ("comp_pose_lin", _pd), ("comp_sb_lin", _pd), ("comp_Hpp", _pd), ("comp_HpN", _pd), ("comp_rhs_p", _pd),
-        ("comp_HNN", _pd), ("comp_rhsN", _pd), ("comp_pre", _pd),
+        ("comp_HNN", _pd), ("comp_rhsN", _pd), ("comp_pre", _pd), ("comp_mid", _pi), ("comp_H12", _pd),
         ("n_prior", C.c_int32), ("prior_nblk", _pi), ("prior_dim", _pi), ("prior_blk", _pi),
         ("prior_J", _pd), ("prior_r0", _pd), ("prior_x0", _pd),
         ("pbg", C.c_double * 3), ("gw", C.c_double * 3), ("base", C.c_double * 3),
@@ -111,9 +111,9 @@ TERMINATION = {0: "RUNNING", 1: "CONVERGED_GRADIENT", 2: "CONVERGED_PARAMETER",
 
 _F64 = ("pose", "sb", "lm", "sc", "proj_uv", "imu_pre", "cp_dat", "pr_dat", "dop_dat", "sp_w",
         "spr_dat", "scp_dat", "fix_dat", "idp_pts", "comp_pose", "comp_sb", "comp_pose_lin", "comp_sb_lin", "comp_Hpp", "comp_HpN", "comp_rhs_p",
-        "comp_HNN", "comp_rhsN", "comp_pre", "prior_J", "prior_r0", "prior_x0")
+        "comp_HNN", "comp_rhsN", "comp_pre", "comp_H12", "prior_J", "prior_r0", "prior_x0")
 _I32 = ("order_block", "order_group", "proj_idx", "imu_idx", "cp_idx", "pr_idx", "dop_idx",
-        "sp_idx", "spr_idx", "scp_idx", "fix_idx", "idp_kind", "idp_idx", "comp_M", "comp_N", "comp_idx", "prior_nblk", "prior_dim", "prior_blk")
+        "sp_idx", "spr_idx", "scp_idx", "fix_idx", "idp_kind", "idp_idx", "comp_M", "comp_N", "comp_idx", "comp_mid", "prior_nblk", "prior_dim", "prior_blk")
 
 
 class FlatWindow:
@@ -183,6 +183,8 @@ class FlatWindow:
             setattr(s, k, a[k].ctypes.data_as(_pd))
         for k in _I32:
             setattr(s, k, a[k].ctypes.data_as(_pi))
+        if a["comp_mid"].size == 0 or a["comp_H12"].size == 0:      # optional: no composite factor has a middle-marginalisation link
+            s.comp_mid = None; s.comp_H12 = None
         s.is_const = a["is_const"].ctypes.data_as(_pu8)
         s.n_order = a["order_block"].size
         s.n_tail = self.n_tail

@@ -51,6 +51,7 @@ EXPORTED = [
     "swf_factor_is_enabled", "swf_get_residual_blocks", "swf_get_residual_blocks_for_parameter_block",
     "swf_get_parameter_blocks", "swf_get_parameter_blocks_for_residual_block", "swf_batch_export_jacobian",
     "swf_batch_marginal_priors", "swf_composite_assemble",
+    "swf_composite_set_mid_links", "swf_composite_add_mid_prior", "swf_set_imu_gnss_mid_link",
 ]
 
 
@@ -362,6 +363,11 @@ class Problem:
         return self._fid(lib().swf_add_imu_gnss(self._h, self._p(pose_i), self._p(sb_i), self._p(pose_j), self._p(sb_j), keys, C.c_int32(N), C.c_int32(M),
                                                  hidden_pose.ctypes.data_as(_pd), hidden_sb.ctypes.data_as(_pd), *[a[1] for a in arrs]), "AddImuGnss")
 
+    def SetImuGnssMidLink(self, fid, k, H12):
+        """IMUGNSSBase::AddMidMargInfo's product: link k (1..M-1) of composite factor `fid` carries the cross block H12 (15x15); k = 0 clears."""
+        a, pa = self._d(H12 if k else np.zeros(225))
+        _chk(lib().swf_set_imu_gnss_mid_link(self._h, C.c_int32(fid), C.c_int32(k), pa), "SetImuGnssMidLink")
+
     def AddScalarPrior(self, scalar, w):
         return self._fid(lib().swf_add_scalar_prior(self._h, self._p(scalar), C.c_double(w)), "AddScalarPrior")
 
@@ -455,6 +461,11 @@ class CompositeBatch:
                             H=Hd[b:b + G * G].reshape(G, G).copy(), rhs=rd[a:a + G].copy(), status=int(st[f])))
         return out
 
+    def set_mid_links(self, mid, H12):
+        """IMUGNSSBase::AddMidMargInfo's product per factor: mid[f] = link 1..M-1 carrying the cross block H12[f] (15x15), 0 = none."""
+        m = np.ascontiguousarray(mid, np.int32); h = np.ascontiguousarray(np.asarray(H12, np.float64).reshape(self.n, 225))
+        _chk(lib().swf_composite_set_mid_links(self._h, m.ctypes.data_as(C.POINTER(C.c_int32)), h.ctypes.data_as(_pd)), "swf_composite_set_mid_links")
+
     def hidden(self):
         m = int(self.M.sum())
         pose, sb = np.zeros((m, 7)), np.zeros((m, 9))
@@ -530,6 +541,42 @@ def composite_assemble(epochs):
     HpN = HpN_buf[:M * 15 * n].reshape(M, 15, n) if n else np.zeros((M, 15, 0))
     return dict(N=n, keys=[keep_alive[C.cast(nk[i], C.c_void_p).value] for i in range(n)], Hpp=Hpp, HpN=HpN, rhs_p=rhs_p,
                 HNN=HNN[:n, :n].copy(), rhsN=rhsN[:n].copy())
+
+
+def composite_add_mid_prior(fac, k, kept, A, b):
+    """swf_composite_add_mid_prior: IMUGNSSBase::AddMidMargInfo (R/factor/gnss_imu_factor.cpp:121-240).  `fac` = what composite_assemble
+    returned (N, keys, Hpp, HpN, rhs_p, HNN, rhsN); kept = [(size, epoch or key)] of the marginalised stretch's prior (A, b): poses (7) and
+    speed-biases (9) carry the epoch index k-1 or k, scalars (1) their numpy block.  Returns the updated dict plus mid = k and H12."""
+    M = fac["Hpp"].shape[0]; N0 = int(fac["N"])
+    n_new = sum(1 for (sz, _) in kept if sz == 1)
+    cap = N0 + n_new
+    sizes = np.array([sz for (sz, _) in kept], np.int32)
+    epochs = np.array([int(e) if sz != 1 else -1 for (sz, e) in kept], np.int32)
+    keep_alive = {kk.ctypes.data: kk for kk in fac["keys"]}
+    ptrs = []
+    for (sz, kk) in kept:
+        if sz == 1:
+            assert isinstance(kk, np.ndarray) and kk.dtype == np.float64
+            keep_alive[kk.ctypes.data] = kk; ptrs.append(kk.ctypes.data_as(_pd))
+        else:
+            ptrs.append(_pd())
+    keys = (_pd * max(1, len(ptrs)))(*ptrs)
+    nk = (_pd * max(1, cap))(*[kk.ctypes.data_as(_pd) for kk in fac["keys"]])
+    Hpp = np.ascontiguousarray(fac["Hpp"], np.float64).copy(); rhs_p = np.ascontiguousarray(fac["rhs_p"], np.float64).copy()
+    HpN = np.zeros((M, 15, max(cap, 1))); HpN[:, :, :N0] = fac["HpN"]
+    HNN = np.zeros((max(cap, 1), max(cap, 1))); HNN[:N0, :N0] = fac["HNN"]
+    rhsN = np.zeros(max(cap, 1)); rhsN[:N0] = fac["rhsN"]
+    H12 = np.zeros((15, 15))
+    A_ = np.ascontiguousarray(A, np.float64); b_ = np.ascontiguousarray(b, np.float64)
+    N = C.c_int32(N0)
+    pi = C.POINTER(C.c_int32)
+    _chk(lib().swf_composite_add_mid_prior(C.c_int32(M), C.c_int32(k), C.c_int32(len(kept)), sizes.ctypes.data_as(pi), epochs.ctypes.data_as(pi), keys,
+                                           A_.ctypes.data_as(_pd), b_.ctypes.data_as(_pd), C.c_int32(cap), nk, C.byref(N), Hpp.ctypes.data_as(_pd),
+                                           HpN.ctypes.data_as(_pd), rhs_p.ctypes.data_as(_pd), HNN.ctypes.data_as(_pd), rhsN.ctypes.data_as(_pd),
+                                           H12.ctypes.data_as(_pd)), "swf_composite_add_mid_prior")
+    n = N.value
+    return dict(N=n, keys=[keep_alive[C.cast(nk[i], C.c_void_p).value] for i in range(n)], Hpp=Hpp, HpN=HpN[:, :, :n].copy(), rhs_p=rhs_p,
+                HNN=HNN[:n, :n].copy(), rhsN=rhsN[:n].copy(), mid=k, H12=H12)
 
 
 def eval_inverse_depth_batch(kind, idx, poses, lam, pts, sqrt_info, pbg):
@@ -624,10 +671,12 @@ def problem_from_window(w):
         ix = a["comp_idx"][io:io + 4 + N]
         hp = a["comp_pose"].reshape(-1, 7)[e0:e0 + M].copy(); hs = a["comp_sb"].reshape(-1, 9)[e0:e0 + M].copy()
         hidden.append((hp, hs))
-        P.AddImuGnss(pose[ix[0]], sb[ix[1]], pose[ix[2]], sb[ix[3]], [sc[i] for i in ix[4:]], hp, hs,
+        fid = P.AddImuGnss(pose[ix[0]], sb[ix[1]], pose[ix[2]], sb[ix[3]], [sc[i] for i in ix[4:]], hp, hs,
                      a["comp_pose_lin"].reshape(-1, 7)[e0:e0 + M], a["comp_sb_lin"].reshape(-1, 9)[e0:e0 + M], a["comp_Hpp"].reshape(-1, 225)[e0:e0 + M],
                      a["comp_HpN"][pn:pn + 15 * M * N], a["comp_rhs_p"].reshape(-1, 15)[e0:e0 + M], a["comp_HNN"][nn:nn + N * N], a["comp_rhsN"][no:no + N],
                      a["comp_pre"].reshape(-1, 293)[e0 + k:e0 + k + M + 1])
+        if a["comp_mid"].size and a["comp_mid"][k]:
+            P.SetImuGnssMidLink(fid, int(a["comp_mid"][k]), a["comp_H12"].reshape(-1, 225)[k])
         io += 4 + N; e0 += M; pn += 15 * M * N; nn += N * N; no += N
     P.hidden = hidden
     bo = jo = ro = xo = 0

@@ -17,16 +17,47 @@ def _small_q(rng, s):
     return q / np.linalg.norm(q)
 
 
-def make_chain(rng, M, N, dt=0.1):
+def make_chain(rng, M, N, dt=0.1, mid=0):
     """States of frame_i, M hidden epochs, frame_j (pose [p q], sb [v ba bg]) and M + 1 pre-integration records whose IMU
-    residuals are small but not zero."""
+    residuals are small but not zero.  mid = k in 1..M-1: the link e_k-1 -> e_k is the product of a middle marginalisation
+    (AddMidMargInfo, gnss_imu_factor.cpp:121-240) — no IMU factor there (its record is NaN to prove nobody reads it), a dense prior
+    over (e_k-1, e_k, N) instead, filed the way the reference files it."""
     pose, sb, pre, pbg, gw = _chain_states(rng, M + 2, dt)
     pr = _gnss_priors(rng, M, N)
     hid_pose, hid_sb = pose[1:-1].copy(), sb[1:-1].copy()
     pose_lin, sb_lin = _lin_points(rng, hid_pose, hid_sb)
     Nv = rng.normal(0, 3.0, N)
-    return dict(M=M, N=N, Pi=pose[0], Bi=sb[0], Pj=pose[-1], Bj=sb[-1], Nv=Nv, pose=hid_pose, sb=hid_sb, pose_lin=pose_lin, sb_lin=sb_lin,
-                pre=pre, pbg=pbg, gw=gw, **pr)
+    out = dict(M=M, N=N, Pi=pose[0], Bi=sb[0], Pj=pose[-1], Bj=sb[-1], Nv=Nv, pose=hid_pose, sb=hid_sb, pose_lin=pose_lin, sb_lin=sb_lin,
+               pre=pre, pbg=pbg, gw=gw, mid=0, H12=np.zeros((15, 15)), **pr)
+    if mid:
+        add_mid_link(rng, out, mid)
+    return out
+
+
+def mid_prior(rng, N):
+    """A dense symmetric positive definite prior over (e_k-1 (15), e_k (15), N ambiguities) with the strength of an IMU link."""
+    n = 30 + N
+    scale = np.concatenate([np.full(3, 30.0), np.full(3, 10.0), np.full(3, 10.0), np.full(6, 3.0)] * 2 + [np.full(N, 2.0)])
+    B = rng.normal(0, 1, (2 * n, n))
+    # an IMU-like coupling: the two epochs' states are tied to each other
+    B[:15, 15:30] = -B[:15, :15] + 0.1 * rng.normal(0, 1, (15, 15))
+    A = (B.T @ B / (2 * n) + 0.05 * np.eye(n)) * np.outer(scale, scale)
+    b = rng.normal(0, 1.0, n) * scale
+    return A, b
+
+
+def add_mid_link(rng, c, k, Ab=None):
+    """File the prior (A, b) over (e_k-1, e_k, N) into the chain's arrays as AddMidMargInfo does: diagonal / ambiguity parts added to
+    Hpp / HpN / HNN / rhs_p / rhsN, the cross block kept apart as H12."""
+    N = c["N"]
+    A, b = mid_prior(rng, N) if Ab is None else Ab
+    c["Hpp"][k - 1] += A[:15, :15]; c["Hpp"][k] += A[15:30, 15:30]
+    c["HpN"][k - 1] += A[:15, 30:]; c["HpN"][k] += A[15:30, 30:]
+    c["HNN"] += A[30:, 30:]
+    c["rhs_p"][k - 1] += b[:15]; c["rhs_p"][k] += b[15:30]; c["rhsN"] += b[30:]
+    c["mid"] = k; c["H12"] = A[:15, 15:30].copy()
+    c["pre"] = c["pre"].copy(); c["pre"][k] = np.nan
+    return A, b
 
 
 def _lin_points(rng, hid_pose, hid_sb):
@@ -40,15 +71,17 @@ def _gnss_priors(rng, M, N):
     Hpp, HpN, rhs_p = np.zeros((M, 15, 15)), np.zeros((M, 15, N)), np.zeros((M, 15))
     HNN, rhsN = np.zeros((N, N)), np.zeros(N)
     scale = np.concatenate([np.full(3, 30.0), np.full(3, 3.0), np.full(9, 1.0), np.full(N, 5.0)])
+    per = []                                    # every epoch's own (N x N block, rhs): what a marginalisation of that epoch's factors needs
     for k in range(M):
         A = rng.normal(0, 1, (2 * (15 + N), 15 + N))
         A = (A.T @ A / (2 * (15 + N)) + 0.05 * np.eye(15 + N)) * np.outer(scale, scale)
         b = rng.normal(0, 1.0, 15 + N) * scale
         Hpp[k] = A[:15, :15]; HpN[k] = A[:15, 15:]; HNN += A[15:, 15:]; rhs_p[k] = b[:15]; rhsN += b[15:]
-    return dict(Hpp=Hpp, HpN=HpN, rhs_p=rhs_p, HNN=HNN, rhsN=rhsN)
+        per.append((A[15:, 15:].copy(), b[15:].copy()))
+    return dict(Hpp=Hpp, HpN=HpN, rhs_p=rhs_p, HNN=HNN, rhsN=rhsN, per_epoch_NN=per)
 
 
-def make_window(rng, K, M, N, dt=0.1, F=0):
+def make_window(rng, K, M, N, dt=0.1, F=0, mid=False):
     """A sliding window whose K visual frames are linked ONLY by composite IMU-GNSS factors (M hidden GNSS epochs per gap, N
     shared ambiguities), plus the gauge prior on frame 0 and the dummy anchor: what an RTK window of the reference looks like
     once UpdateImuGnssFactor (R/swf/swf.cpp:713-730) has folded the GNSS epochs away.  F > 0 adds F landmarks observed from
@@ -62,7 +95,7 @@ def make_window(rng, K, M, N, dt=0.1, F=0):
     pose = np.stack([nf.pose_plus(pose_t[v], rng.normal(0, [0.03] * 3 + [0.005] * 3)) for v in vis])
     sb = np.stack([sb_t[v] + rng.normal(0, [0.03] * 3 + [0.003] * 3 + [0.0003] * 3) for v in vis])
     sc = np.concatenate([[0.0], rng.normal(0, 3.0, N)])             # dummy + ambiguities
-    comp = dict(M=[], N=[], idx=[], pose=[], sb=[], pose_lin=[], sb_lin=[], Hpp=[], HpN=[], rhs_p=[], HNN=[], rhsN=[], pre=[])
+    comp = dict(M=[], N=[], idx=[], pose=[], sb=[], pose_lin=[], sb_lin=[], Hpp=[], HpN=[], rhs_p=[], HNN=[], rhsN=[], pre=[], mid=[], H12=[])
     for g in range(K - 1):
         h0 = vis[g] + 1
         hp = np.stack([nf.pose_plus(pose_t[h0 + i], rng.normal(0, [0.02] * 3 + [0.004] * 3)) for i in range(M)])
@@ -71,9 +104,17 @@ def make_window(rng, K, M, N, dt=0.1, F=0):
         pr = _gnss_priors(rng, M, N)
         comp["M"].append(M); comp["N"].append(N); comp["idx"].append([g, g, g + 1, g + 1] + [1 + q for q in range(N)])
         comp["pose"].append(hp); comp["sb"].append(hs); comp["pose_lin"].append(pl); comp["sb_lin"].append(sl)
+        cpre = pre[vis[g]:vis[g] + M + 1]
+        if mid and M >= 2 and g % 2 == 0:          # every other gap carries a middle-marginalisation link (mid = True)
+            cc = dict(N=N, pre=cpre, **pr)
+            add_mid_link(rng, cc, 1 + (g // 2) % (M - 1))
+            cpre = np.nan_to_num(cc["pre"], nan=0.0)       # (the golden .npz round trip keeps NaN, but zeros make the window printable)
+            comp["mid"].append(cc["mid"]); comp["H12"].append(cc["H12"])
+        else:
+            comp["mid"].append(0); comp["H12"].append(np.zeros((15, 15)))
         for k_ in ("Hpp", "HpN", "rhs_p", "HNN", "rhsN"):
             comp[k_].append(pr[k_])
-        comp["pre"].append(pre[vis[g]:vis[g] + M + 1])
+        comp["pre"].append(cpre)
     # optional visual part: extrinsic = pose pool entry K (constant), landmarks in front of the cameras
     n_pose = K + (1 if F else 0)
     lm = np.zeros((F, 3)); proj_idx, proj_uv = [], []
@@ -123,6 +164,7 @@ def make_window(rng, K, M, N, dt=0.1, F=0):
         comp_M=np.array(comp["M"], np.int32), comp_N=np.array(comp["N"], np.int32), comp_idx=np.concatenate([np.array(i, np.int32) for i in comp["idx"]]),
         comp_pose=cat("pose"), comp_sb=cat("sb"), comp_pose_lin=cat("pose_lin"), comp_sb_lin=cat("sb_lin"), comp_Hpp=cat("Hpp"), comp_HpN=cat("HpN"),
         comp_rhs_p=cat("rhs_p"), comp_HNN=cat("HNN"), comp_rhsN=cat("rhsN"), comp_pre=cat("pre"),
+        **(dict(comp_mid=np.array(comp["mid"], np.int32), comp_H12=cat("H12")) if mid else {}),
         pbg=pbg, gw=gw, base=np.zeros(3), meta=dict(K=K, M=M, N=N, F=F))
 
 
@@ -176,6 +218,12 @@ def dense_system(c, Pi, Bi, Pj, Bj, Nv, hid_pose, hid_sb):
     chain = [(Pi, Bi, 0)] + [(hid_pose[k], hid_sb[k], off(k)) for k in range(M)] + [(Pj, Bj, 15)]
     for k in range(M + 1):
         (pa, ba, oa), (pb, bb, obf) = chain[k], chain[k + 1]
+        if c.get("mid", 0) and k == c["mid"]:
+            # the cross term inc(e_k-1)^T H12 inc(e_k) of the middle marginalisation's quadratic (its other blocks sit in Hpp / HpN / HNN)
+            d1 = inc15(pa, ba, c["pose_lin"][k - 1], c["sb_lin"][k - 1]); d2 = inc15(pb, bb, c["pose_lin"][k], c["sb_lin"][k])
+            H[oa:oa + 15, obf:obf + 15] += c["H12"]; H[obf:obf + 15, oa:oa + 15] += c["H12"].T
+            g[oa:oa + 15] += c["H12"] @ d2; g[obf:obf + 15] += c["H12"].T @ d1
+            continue
         r, J1, J2 = ob.eval_imu2(pa, ba, pb, bb, c["pre"][k], c["pbg"], c["gw"])
         J = np.zeros((15, n)); J[:, oa:oa + 15] = J1; J[:, obf:obf + 15] = J2
         H += J.T @ J; g += J.T @ r
@@ -187,3 +235,33 @@ def dense_system(c, Pi, Bi, Pj, Bj, Nv, hid_pose, hid_sb):
         g[30:G] += c["HpN"][k].T @ dx
     H[30:G, 30:G] += c["HNN"]; g[30:G] += c["rhsN"] + c["HNN"] @ Nv
     return H, g
+
+
+def stretch_window(c, a, b_):
+    """What MargGNSSFrames (R/swf/swf.cpp:491-530) hands to marginalize(): the hidden epochs a..b_ of chain c (a, b_ = the epochs either
+    side of the stretch, kept; a+1..b_-1 marginalised) with the IMU factors between them and the GNSS priors of the marginalised epochs
+    as linear priors; ambiguities at zero (PhaseBiasSaveAndReset).  Returns a FlatWindow whose tail is [pose_a, sb_a, pose_b, sb_b, N...]."""
+    from rtk_visual_inertial_navigation_amd.flat import FlatWindow
+    N = c["N"]; n = b_ - a + 1
+    pose = c["pose"][a:b_ + 1].copy(); sb = c["sb"][a:b_ + 1].copy()
+    sc = np.zeros(1 + N)                                            # dummy anchor + the ambiguities (zeroed)
+    bid_pose = lambda i: i; bid_sb = lambda i: n + i; bid_sc = lambda i: 2 * n + i
+    imu_idx = [[i, i, i + 1, i + 1] for i in range(n - 1)]
+    imu_pre = c["pre"][a + 1:b_ + 1]                                # record k links hidden k-1 -> k
+    pn, pd, pb, pJ, pr0, px0 = [], [], [], [], [], []
+    for e in range(a + 1, b_):
+        Hn, rn = c["per_epoch_NN"][e]
+        A = np.block([[c["Hpp"][e], c["HpN"][e]], [c["HpN"][e].T, Hn]]); g = np.concatenate([c["rhs_p"][e], rn])
+        L = np.linalg.cholesky(A)                                   # J = L^T, J^T r0 = g
+        pn.append(2 + N); pd.append(15 + N); pb += [bid_pose(e - a), bid_sb(e - a)] + [bid_sc(1 + q) for q in range(N)]
+        pJ.append(L.T.ravel()); pr0.append(np.linalg.solve(L, g)); px0.append(np.concatenate([c["pose_lin"][e], c["sb_lin"][e], np.zeros(N)]))
+    inner = [x for e in range(1, n - 1) for x in (bid_pose(e), bid_sb(e))]
+    tail = [bid_pose(0), bid_sb(0), bid_pose(n - 1), bid_sb(n - 1)] + [bid_sc(1 + q) for q in range(N)]
+    order_block = [bid_sc(0)] + inner + tail
+    order_group = [0] + list(range(1, 1 + len(inner) + len(tail)))
+    return FlatWindow(pose=pose, sb=sb, lm=np.zeros((0, 3)), sc=sc, is_const=np.zeros(2 * n + 1 + N, np.uint8),
+                      order_block=np.array(order_block, np.int32), order_group=np.array(order_group, np.int32), n_tail=len(tail),
+                      imu_idx=np.array(imu_idx, np.int32), imu_pre=imu_pre, sp_idx=np.array([0], np.int32), sp_w=np.array([1.0]),
+                      prior_nblk=np.array(pn, np.int32), prior_dim=np.array(pd, np.int32), prior_blk=np.array(pb, np.int32),
+                      prior_J=np.concatenate(pJ), prior_r0=np.concatenate(pr0), prior_x0=np.concatenate(px0),
+                      pbg=c["pbg"], gw=c["gw"], base=np.zeros(3), meta=dict(a=a, b=b_))

@@ -206,6 +206,11 @@ class Composite:
             raise RuntimeError("oracle_composite_evaluate: a hidden epoch's block is not positive definite")
         return (r, J) if want_jac else r
 
+    def set_mid(self, mid, H12):
+        h = np.ascontiguousarray(H12, np.float64)
+        if lib().oracle_composite_set_mid(self._h, C.c_int(int(mid)), _p(h)) != 0:
+            raise ValueError("oracle_composite_set_mid: the link must lie between two hidden epochs")
+
     def hidden(self):
         pose, sb = np.zeros((self.M, 7)), np.zeros((self.M, 9))
         lib().oracle_composite_hidden(self._h, _p(pose), _p(sb))

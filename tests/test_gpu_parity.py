@@ -783,10 +783,16 @@ def test_composite_imu_gnss_factors_match_oracle():
     J^T J, J^T r, |r|^2 (what a Gauss-Newton solver consumes), the remaining system itself, and the hidden states."""
     import composite_gen as cg
     rng = np.random.default_rng(31)
-    shapes = [(1, 4), (3, 6), (8, 10), (5, 0), (12, 24), (2, 1), (30, 12)]
-    cs = [cg.make_chain(rng, M, N) for (M, N) in shapes]
+    # (M, N, mid): mid > 0 = the middle-marginalisation branch (AddMidMargInfo :121-240, Evaluate :738-759): link e_mid-1 -> e_mid carries the
+    # cross block of a marginalised stretch of epochs instead of an IMU factor (its pre-integration record is NaN: nobody may read it)
+    shapes = [(1, 4, 0), (3, 6, 0), (8, 10, 0), (5, 0, 0), (12, 24, 0), (2, 1, 0), (30, 12, 0), (4, 5, 2), (8, 10, 5), (2, 0, 1), (30, 24, 15), (6, 3, 1)]
+    cs = [cg.make_chain(rng, M, N, mid=mid) for (M, N, mid) in shapes]
     Fo = [ob.Composite(c["pose"], c["sb"], c["pose_lin"], c["sb_lin"], c["Hpp"], c["HpN"], c["rhs_p"], c["HNN"], c["rhsN"], c["pre"], c["pbg"], c["gw"]) for c in cs]
+    for F, c in zip(Fo, cs):
+        if c["mid"]:
+            F.set_mid(c["mid"], c["H12"])
     Fg = solver.CompositeBatch(cs, cs[0]["pbg"], cs[0]["gw"])
+    Fg.set_mid_links([c["mid"] for c in cs], np.stack([c["H12"] for c in cs]))
     outer = lambda c, d: np.concatenate([nf.pose_plus(c["Pi"], d[0:6]), c["Bi"] + d[6:15], nf.pose_plus(c["Pj"], d[15:21]), c["Bj"] + d[21:30]])
     zero = [np.zeros(30 + c["N"]) for c in cs]
 
@@ -832,6 +838,60 @@ def test_composite_imu_gnss_factors_match_oracle():
         F.close()
 
 
+def test_middle_marginalisation_of_a_long_gnss_chain_on_the_device():
+    """MiddleMargGnssFrame (R/swf/swf_core.cpp:570-641) end to end: a composite factor hides six GNSS epochs; the stretch e_2, e_3 is
+    marginalised ON THE DEVICE (swf_batch_marginal_priors over the window MargGNSSFrames builds: the IMU factors into, inside and out of
+    the stretch, the stretch epochs' GNSS priors, ambiguities zeroed), AddMidMargInfo files the result (swf_composite_add_mid_prior), and
+    the factor continues with four hidden epochs and a middle-marginalisation link.  At the marginalisation point the shortened factor
+    must present the same remaining system over [pose_i sb_i | pose_j sb_j | N] as the full one (nested Schur complements), and after
+    an outer step its linear model of the stretch replaces the IMU factors it absorbed (agreement to second order in the step)."""
+    import composite_gen as cg
+    rng = np.random.default_rng(77)
+    M, N, a, b_ = 6, 4, 1, 4
+    c = cg.make_chain(rng, M, N)
+    c["pose_lin"][a] = c["pose"][a]; c["sb_lin"][a] = c["sb"][a]; c["pose_lin"][b_] = c["pose"][b_]; c["sb_lin"][b_] = c["sb"][b_]   # ResetLinearizationPoint :636-637
+    full = solver.CompositeBatch([c], c["pbg"], c["gw"])
+    x0 = np.concatenate([c["Pi"], c["Bi"], c["Pj"], c["Bj"]])
+    gf = full.evaluate([x0], [c["Nv"]], True)[0]
+    # the stretch's prior, by the device
+    ws = cg.stretch_window(c, a, b_)
+    pri = solver.marginal_priors([ws], 1e-8, solver.BatchSolver.PRIOR_CHOLESKY)[0]
+    assert pri["rank"] == 30 + N and pri["A"].shape == (30 + N, 30 + N)
+    # the shortened chain: epochs e_0, e_1, e_4, e_5
+    keep = [0, 1, 4, 5]
+    amb = [np.zeros(1) for _ in range(N)]
+    HNN = sum(c["per_epoch_NN"][e][0] for e in keep); rhsN = sum(c["per_epoch_NN"][e][1] for e in keep)
+    fac = dict(N=N, keys=amb, Hpp=c["Hpp"][keep], HpN=c["HpN"][keep], rhs_p=c["rhs_p"][keep], HNN=HNN, rhsN=rhsN)
+    k = 2
+    kept = [(7, k - 1), (9, k - 1), (7, k), (9, k)] + [(1, x) for x in amb]
+    out = solver.composite_add_mid_prior(fac, k, kept, pri["A"], pri["b"])
+    pre = np.stack([c["pre"][0], c["pre"][1], np.full(c["pre"].shape[1], np.nan), c["pre"][5], c["pre"][6]])
+    cs = dict(pose=c["pose"][keep], sb=c["sb"][keep], pose_lin=c["pose_lin"][keep], sb_lin=c["sb_lin"][keep], Hpp=out["Hpp"], HpN=out["HpN"],
+              rhs_p=out["rhs_p"], HNN=out["HNN"], rhsN=out["rhsN"], pre=pre)
+    short = solver.CompositeBatch([cs], c["pbg"], c["gw"])
+    short.set_mid_links([k], out["H12"][None])
+    gs = short.evaluate([x0], [c["Nv"]], True)[0]
+    assert gs["status"] == 0 and gf["status"] == 0
+    sc = np.abs(gf["H"]).max()
+    assert np.abs(gs["H"] - gf["H"]).max() <= 1e-8 * sc, np.abs(gs["H"] - gf["H"]).max() / sc
+    assert np.abs(gs["rhs"] - gf["rhs"]).max() <= 1e-8 * (np.abs(gf["rhs"]).max() + 1e-3 * sc)
+    assert np.abs(gs["J"].T @ gs["J"] - gf["J"].T @ gf["J"]).max() <= 1e-8 * sc
+    # the oracle's restatement of the branch on the same inputs
+    Fo = ob.Composite(cs["pose"], cs["sb"], cs["pose_lin"], cs["sb_lin"], cs["Hpp"], cs["HpN"], cs["rhs_p"], cs["HNN"], cs["rhsN"], np.nan_to_num(pre), c["pbg"], c["gw"])
+    Fo.set_mid(k, out["H12"])
+    ro, Jo = Fo.evaluate(c["Pi"], c["Bi"], c["Pj"], c["Bj"], c["Nv"], True)
+    assert np.abs(Jo.T @ Jo - gs["H"]).max() <= 1e-9 * sc and np.abs(Jo.T @ ro - gs["J"].T @ gs["r"]).max() <= 1e-9 * (np.abs(Jo.T @ ro).max() + 1e-3 * sc)
+    # an outer step: both factors re-linearise; the shortened one carries the stretch as a quadratic, the full one re-evaluates its IMU factors
+    d = rng.normal(0, 2e-3, 30 + N)
+    x1 = np.concatenate([nf.pose_plus(c["Pi"], d[0:6]), c["Bi"] + d[6:15], nf.pose_plus(c["Pj"], d[15:21]), c["Bj"] + d[21:30]])
+    g1f = full.evaluate([x1], [c["Nv"] + d[30:]], True)[0]; g1s = short.evaluate([x1], [c["Nv"] + d[30:]], True)[0]
+    assert np.abs(g1s["H"] - g1f["H"]).max() <= 0.1 * sc                           # first order in the step
+    assert np.abs(g1s["H"] - g1f["H"]).max() > 1e-12 * sc                          # ... and it IS an approximation now
+    (hpf, hsf), (hps, hss) = full.hidden()[0], short.hidden()[0]
+    assert np.abs(hps - hpf[keep]).max() <= 1e-4 and np.abs(hss - hsf[keep]).max() <= 1e-4      # the kept epochs moved alike
+    full.close(); short.close(); Fo.close()
+
+
 def test_windows_with_composite_factors_match_oracle_solver():
     """Rows a5 / a10 inside the solve loop: windows whose visual frames are linked only by composite IMU-GNSS factors (the
     state of an RTK window after UpdateImuGnssFactor), solved by the engine — where a composite factor is a prior-type
@@ -843,6 +903,8 @@ def test_windows_with_composite_factors_match_oracle_solver():
     shapes = [(3, 2, 4, 0), (5, 4, 10, 0), (4, 9, 6, 0), (6, 1, 0, 0), (3, 12, 24, 0),
               (5, 3, 6, 40), (9, 2, 8, 120)]            # the last two: + landmarks on the same poses (static composite cliques next to the landmark Schur complement)
     wins = [cg.make_window(rng, K, M, N, F=F) for (K, M, N, F) in shapes]
+    # + windows whose composite factors carry a middle-marginalisation link in every other gap (AddMidMargInfo)
+    wins += [cg.make_window(rng, K, M, N, F=F, mid=True) for (K, M, N, F) in [(4, 5, 6, 0), (5, 3, 8, 30)]]
     singles = []
     for w in wins:
         wo, wg = w.copy(), w.copy()
@@ -878,6 +940,14 @@ def test_windows_with_composite_factors_match_oracle_solver():
     assert np.array_equal(np.concatenate(blocks[:w0.n_pose]), wg.a["pose"].ravel())
     assert np.array_equal(np.concatenate([hp.ravel() for hp, hs in P.hidden]), wg.a["comp_pose"])       # updated in place
     assert np.array_equal(np.concatenate([hs.ravel() for hp, hs in P.hidden]), wg.a["comp_sb"])
+    P.close()
+    # ... and with middle-marginalisation links (swf_set_imu_gnss_mid_link)
+    w1 = wins[-1]
+    assert w1.a["comp_mid"].max() > 0
+    P, blocks = solver.problem_from_window(w1.copy())
+    sm = P.Solve(default_options(max_num_iterations=8))
+    assert [r["cost"] for r in sm.rows()] == singles[-1][1]
+    assert np.array_equal(np.concatenate([hp.ravel() for hp, hs in P.hidden]), singles[-1][0].a["comp_pose"])
     P.close()
     # the unsupported placements are refused, not ignored
     bad = wins[0].copy(); bad.a["is_const"][0] = 1

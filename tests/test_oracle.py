@@ -237,9 +237,12 @@ def test_composite_imu_gnss_factor_equals_dense_elimination_of_its_hidden_states
     (3) re-linearising after an outer step moves the hidden epochs by the dense back-substitution."""
     import composite_gen as cg
     rng = np.random.default_rng(12)
-    for (M, N) in ((1, 4), (3, 6), (8, 10), (5, 0)):
-        c = cg.make_chain(rng, M, N)
+    # (M, N, mid): mid > 0 = the middle-marginalisation branch (AddMidMargInfo :121-240, Evaluate :738-759) on link e_mid-1 -> e_mid
+    for (M, N, mid) in ((1, 4, 0), (3, 6, 0), (8, 10, 0), (5, 0, 0), (4, 5, 2), (8, 10, 5), (2, 0, 1), (6, 3, 1)):
+        c = cg.make_chain(rng, M, N, mid=mid)
         F = ob.Composite(c["pose"], c["sb"], c["pose_lin"], c["sb_lin"], c["Hpp"], c["HpN"], c["rhs_p"], c["HNN"], c["rhsN"], c["pre"], c["pbg"], c["gw"])
+        if mid:
+            F.set_mid(mid, c["H12"])
         G = 30 + N
         r, J = F.evaluate(c["Pi"], c["Bi"], c["Pj"], c["Bj"], c["Nv"], True)
         H, g = cg.dense_system(c, c["Pi"], c["Bi"], c["Pj"], c["Bj"], c["Nv"], c["pose"], c["sb"])

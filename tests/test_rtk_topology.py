@@ -147,3 +147,59 @@ def test_device_epoch_priors_and_composite_topology(kw):
     b3 = solver.BatchSolver([w2]); s2 = b3.solve(default_options(max_num_iterations=10))[0]; b3.close()
     assert s2.final_cost <= se.final_cost * (1 + 1e-6)
     assert np.abs(w2.a["pose"] - before).max() < 5e-3       # millimetres along the weakly determined global-position direction (gauge prior 1e-3); the explicit solver on its own is centimetres away after 60 iterations
+
+
+def test_add_mid_marg_info_bookkeeping_equals_numpy_restatement():
+    """swf_composite_add_mid_prior = IMUGNSSBase::AddMidMargInfo (R/factor/gnss_imu_factor.cpp:121-240): the prior of a marginalised
+    stretch of GNSS epochs over (pose / speed-bias of the epochs either side, ambiguities — one of them new to the factor, in a
+    scrambled block order) is filed into the factor's arrays; the cross block comes back as H12.  Host code only (no GPU)."""
+    rng = np.random.default_rng(8)
+    M, k = 5, 3
+    amb = {i: np.zeros(1) for i in (4, 2, 9, 7)}
+    # the factor as composite_assemble leaves it: three ambiguities known
+    fac = dict(N=3, keys=[amb[4], amb[2], amb[9]], Hpp=rng.normal(0, 1, (M, 15, 15)), HpN=rng.normal(0, 1, (M, 15, 3)), rhs_p=rng.normal(0, 1, (M, 15)),
+               HNN=rng.normal(0, 1, (3, 3)), rhsN=rng.normal(0, 1, 3))
+    kept = [(1, amb[2]), (9, k), (7, k - 1), (1, amb[7]), (9, k - 1), (7, k), (1, amb[4])]
+    n = sum(6 if s == 7 else s for s, _ in kept)
+    Gm = rng.normal(0, 1, (n + 4, n)); A = Gm.T @ Gm; b = rng.normal(0, 1, n)
+    out = solver.composite_add_mid_prior(fac, k, kept, A, b)
+    assert out["N"] == 4 and [id(x) for x in out["keys"]] == [id(amb[4]), id(amb[2]), id(amb[9]), id(amb[7])] and out["mid"] == k
+    # numpy restatement: positions of every kept block inside the prior, and inside the factor
+    off, o = [], 0
+    for s, _ in kept:
+        off.append(o); o += 6 if s == 7 else s
+    col = {id(amb[4]): 0, id(amb[2]): 1, id(amb[9]): 2, id(amb[7]): 3}
+    Hpp, rhs_p = fac["Hpp"].copy(), fac["rhs_p"].copy()
+    HpN = np.zeros((M, 15, 4)); HpN[:, :, :3] = fac["HpN"]
+    HNN = np.zeros((4, 4)); HNN[:3, :3] = fac["HNN"]; rhsN = np.zeros(4); rhsN[:3] = fac["rhsN"]
+    H12 = np.zeros((15, 15))
+    def place(q):
+        s, e = kept[q]
+        if s == 1:
+            return ("N", col[id(e)], 1)
+        return (e, 0 if s == 7 else 6, 6 if s == 7 else 9)
+    for q1 in range(len(kept)):
+        t1, s1, l1 = place(q1)
+        r1 = slice(off[q1], off[q1] + l1)
+        if t1 == "N":
+            rhsN[s1] += b[r1][0]
+        else:
+            rhs_p[t1, s1:s1 + l1] += b[r1]
+        for q2 in range(len(kept)):
+            t2, s2, l2 = place(q2)
+            blk = A[r1, off[q2]:off[q2] + l2]
+            if t1 == "N" and t2 == "N":
+                HNN[s1, s2] += blk[0, 0]
+            elif t1 != "N" and t2 == "N":
+                HpN[t1, s1:s1 + l1, s2] += blk[:, 0]
+            elif t1 != "N" and t2 != "N" and t1 == t2:
+                Hpp[t1, s1:s1 + l1, s2:s2 + l2] += blk
+            elif t1 == k - 1 and t2 == k:
+                H12[s1:s1 + l1, s2:s2 + l2] = blk
+    for key, ref in (("Hpp", Hpp), ("HpN", HpN), ("rhs_p", rhs_p), ("HNN", HNN), ("rhsN", rhsN), ("H12", H12)):
+        assert np.array_equal(out[key], ref), key
+    # a block of a third epoch, or a link outside 1..M-1, is refused
+    with pytest.raises(solver.SwfError):
+        solver.composite_add_mid_prior(fac, k, [(7, k - 2), (9, k)], np.eye(15), np.zeros(15))
+    with pytest.raises(solver.SwfError):
+        solver.composite_add_mid_prior(fac, M, [(7, M - 1), (9, M - 1)], np.eye(15), np.zeros(15))
