@@ -240,6 +240,13 @@ int swf_composite_hidden(swf_composite* c, double* pose, double* sb);
  * the link e_k-1 -> e_k by the cross block H12[f] (15 x 15 row-major, rows = e_k-1, columns = e_k) of a marginalised stretch of
  * epochs; 0 = none.  Call before the first evaluation. */
 int swf_composite_set_mid_links(swf_composite* c, const int32_t* mid, const double* H12);
+/* Which square root of the remaining system the factor exposes.  SWF_ROOT_PIVOTED_CHOLESKY (default): rows v_r of a diagonally pivoted
+ * outer-product Cholesky.  SWF_ROOT_EIGEN: the reference's own (UpdateSchurComponent :454-488): J = sqrt(lam+) V^T, r = lam+^-1/2 V^T rhs,
+ * eigenvalues <= 1e-8 dropped, rows in ascending eigenvalue order — the reference's residual vector up to the sign of each eigenvector.
+ * Both give the same J^T J, J^T r and |r|^2.  Inside a solve (swf_flat_window::comp_*) the environment variable SWF_COMP_EIGEN_ROOT=1
+ * selects the eigen form for every composite factor of batches created while it is set. */
+enum { SWF_ROOT_PIVOTED_CHOLESKY = 0, SWF_ROOT_EIGEN = 1 };
+int swf_composite_set_root(swf_composite* c, int32_t form);
 int swf_composite_destroy(swf_composite* c);
 
 /* =====================================================================================

@@ -183,6 +183,7 @@ struct swf_batch {
     bool clc_imu[4] = { false, false, false, false };
     // composite IMU-GNSS factors of the batch (swf_kernels4.h): operator arguments, solver-side bookkeeping, initial hidden epochs
     CompArgs CA{}; CompMeta CM{}; int n_comp = 0; long long comp_ne = 0;
+    bool comp_eigen_root = false;                      // SWF_COMP_EIGEN_ROOT=1 at create: the composite factors expose the reference's eigen square root
     double* co_pose0 = nullptr; double* co_sb0 = nullptr;    // clique class holds IMU factors (its elimination must follow k_eval_imu)
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
     int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr; double* mg_M = nullptr;
@@ -970,6 +971,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             Coff[f] = Cq.C_off; voff[f] = Cq.v_off;
         }
         b->comp_ne = eo[nc];
+        { const char* ev = getenv("SWF_COMP_EIGEN_ROOT"); b->comp_eigen_root = ev && ev[0] == '1'; }
         CompArgs& A = b->CA; CompMeta& Mt = b->CM;
         A.n = nc; A.want_jac = 1;
         rc |= P.put(B.co_M, &A.M); rc |= P.put(B.co_N, &A.N); rc |= P.put(eo, &A.e_off); rc |= P.put(no, &A.n_off);
@@ -1107,6 +1109,7 @@ struct Launcher {
             hipLaunchKernelGGL(k_comp_prep, dim3(b->n_comp), dim3(256), 0, st, b->CA);
             hipLaunchKernelGGL(k_comp_imu, dim3((b->CA.n_iq + 7) / 8), dim3(256), 0, st, b->CA);
             hipLaunchKernelGGL(k_comp_elim, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            if (b->comp_eigen_root) hipLaunchKernelGGL(k_comp_eigroot, dim3(b->n_comp), dim3(256), 0, st, b->CA);
             hipLaunchKernelGGL(k_comp_scatter, dim3(b->n_comp), dim3(256), 0, st, D, b->CA, b->CM);
         }
         hipStream_t sa = b->aux ? b->aux : st;
@@ -1570,6 +1573,7 @@ struct swf_composite {
     std::vector<void*> bufs;
     int n = 0; long long sumM = 0, sumN = 0, sumG = 0, sumG2 = 0;
     std::vector<int> M;
+    bool eigen_root = false;
     hipStream_t stream = nullptr;
     ~swf_composite() { for (void* p : bufs) (void)hipFree(p); }
 };
@@ -1653,6 +1657,7 @@ extern "C" int swf_composite_evaluate(swf_composite* c, const double* outer, con
     hipLaunchKernelGGL(k_comp_prep, dim3(c->n), dim3(256), 0, st, A);
     hipLaunchKernelGGL(k_comp_imu, dim3((A.n_iq + 7) / 8), dim3(256), 0, st, A);
     hipLaunchKernelGGL(k_comp_elim, dim3(c->n), dim3(256), 0, st, A);
+    if (c->eigen_root) hipLaunchKernelGGL(k_comp_eigroot, dim3(c->n), dim3(256), 0, st, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(residual, c->A.res_out, c->sumG * sizeof(double), hipMemcpyDeviceToHost, st));
     if (jac && want_jac) HIPCHK(hipMemcpyAsync(jac, c->A.jac_out, c->sumG2 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1660,6 +1665,12 @@ extern "C" int swf_composite_evaluate(swf_composite* c, const double* outer, con
     if (rd) HIPCHK(hipMemcpyAsync(rd, c->A.rd, c->sumG * sizeof(double), hipMemcpyDeviceToHost, st));
     if (status) HIPCHK(hipMemcpyAsync(status, c->A.status, c->n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    return SWF_OK;
+}
+
+extern "C" int swf_composite_set_root(swf_composite* c, int32_t form) {
+    if (!c || (form != SWF_ROOT_PIVOTED_CHOLESKY && form != SWF_ROOT_EIGEN)) return fail(SWF_E_INVALID, "swf_composite_set_root: bad arguments");
+    c->eigen_root = form == SWF_ROOT_EIGEN;
     return SWF_OK;
 }
 

@@ -406,6 +406,71 @@ __global__ void __launch_bounds__(256, 4) k_comp_elim(CompArgs A) {
     if (t == 0) { A.history[f] = 1; A.status[f] = sBad ? -1 : 0; }
 }
 
+// Optional phase 4: the reference's square root itself (UpdateSchurComponent, R/factor/gnss_imu_factor.cpp:454-488):
+//   H = V diag(lam) V^T,  J = sqrt(lam+) V^T,  r = lam+^-1/2 V^T rhs,  eigenvalues <= 1e-8 dropped, rows in ascending eigenvalue order
+// — for callers that want the residual VECTOR of the reference (up to the sign of each eigenvector), not only J^T J, J^T r and |r|^2.
+// The pivoted factor of phase 3 is a square root R (rows v_r, R^T R = H on the retained range), so the eigenvectors of H are the right
+// singular vectors of R: a one-sided (Hestenes) Jacobi on the columns of R — G columns of length rank, 8 lanes per column pair,
+// round-robin pairing, V accumulated — never forms H again and keeps small eigenvalues to high relative accuracy.  One 256-thread
+// workgroup per factor; off by default (swf_composite_set_root / SWF_COMP_EIGEN_ROOT): it costs a few sweeps of G - 1 barrier steps.
+__global__ void __launch_bounds__(256) k_comp_eigroot(CompArgs A) {
+    const int f = blockIdx.x, t = threadIdx.x;
+    if (f >= A.n || !A.todo[f]) return;
+    const int N = A.N[f], G = 30 + N;
+    const long long g0 = A.g_off[f], g20 = A.g2_off[f];
+    __shared__ double Rm[CO_MAXG * CO_MAXG], Vm[CO_MAXG * CO_MAXG];      // column-major: column c at [c * G, c * G + G)
+    __shared__ double lam[CO_MAXG], rho[CO_MAXG], srd[CO_MAXG];
+    __shared__ int srank[CO_MAXG];
+    for (int e = t; e < G * G; e += 256) { Rm[e] = A.Ld[g20 + e]; int c = e / G, r = e - c * G; Vm[e] = c == r ? 1.0 : 0.0; }   // Ld[a * G + r] = component a of row r
+    if (t < G) srd[t] = A.rd[g0 + t];
+    __syncthreads();
+    const int Ge = (G + 1) & ~1, np = Ge / 2;            // round-robin over an even number of players (a bye when G is odd)
+    const int pi = t >> 3, ln = t & 7;
+    for (int sweep = 0; sweep < 40; sweep++) {
+        int rotated = 0;
+        for (int step = 0; step < Ge - 1; step++) {
+            // circle method: player Ge-1 stays, the others rotate; pair pi plays (a, b)
+            int p = -1, q = -1;
+            if (pi < np) {
+                int a = pi == 0 ? Ge - 1 : (step + pi) % (Ge - 1), b = (step + Ge - 1 - pi) % (Ge - 1);
+                p = a < b ? a : b; q = a < b ? b : a;
+                if (q >= G) p = -1;                      // the bye
+            }
+            double al = 0, be = 0, ga = 0;
+            if (p >= 0) for (int r = ln; r < G; r += 8) { double x = Rm[p * G + r], y = Rm[q * G + r]; al += x * x; be += y * y; ga += x * y; }
+            for (int o = 4; o > 0; o >>= 1) { al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64); }
+            if (p >= 0 && fabs(ga) > 1e-15 * sqrt(al * be) && fabs(ga) > 1e-300) {
+                double zeta = (be - al) / (2.0 * ga);
+                double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
+                for (int r = ln; r < G; r += 8) {
+                    double x = Rm[p * G + r], y = Rm[q * G + r]; Rm[p * G + r] = c * x - sn * y; Rm[q * G + r] = sn * x + c * y;
+                    double u = Vm[p * G + r], v = Vm[q * G + r]; Vm[p * G + r] = c * u - sn * v; Vm[q * G + r] = sn * u + c * v;
+                }
+                rotated = 1;
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(rotated)) break;
+    }
+    // eigenvalues = squared column norms; rows of the output in ascending eigenvalue order (Eigen's SelfAdjointEigenSolver order)
+    if (t < G) {
+        double s2 = 0, d = 0;
+        for (int r = 0; r < G; r++) { double x = Rm[t * G + r]; s2 += x * x; d += Vm[t * G + r] * srd[r]; }
+        lam[t] = s2; rho[t] = d;
+    }
+    __syncthreads();
+    if (t < G) { int rk = 0; for (int j = 0; j < G; j++) if (lam[j] < lam[t] || (lam[j] == lam[t] && j < t)) rk++; srank[t] = rk; }
+    __syncthreads();
+    for (int e = t; e < G * G; e += 256) {
+        int k = e / G, a = e - k * G, row = srank[k];
+        double v = lam[k] > 1e-8 ? sqrt(lam[k]) * Vm[k * G + a] : 0.0;
+        A.Ld[g20 + (size_t)a * G + row] = v;
+        if (A.jac_out) A.jac_out[g20 + (size_t)row * G + a] = v;
+    }
+    if (t < G) { double v = lam[t] > 1e-8 ? rho[t] / sqrt(lam[t]) : 0.0; A.r0[g0 + srank[t]] = v; A.res_out[g0 + srank[t]] = v; }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Inside the solver a composite factor IS a linearised prior that is rewritten at every linearisation: between two Jacobian
 // evaluations the reference answers from r_lin - J INC, with INC = old (-) new in exactly the coordinates of

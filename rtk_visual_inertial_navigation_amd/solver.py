@@ -51,7 +51,7 @@ EXPORTED = [
     "swf_factor_is_enabled", "swf_get_residual_blocks", "swf_get_residual_blocks_for_parameter_block",
     "swf_get_parameter_blocks", "swf_get_parameter_blocks_for_residual_block", "swf_batch_export_jacobian",
     "swf_batch_marginal_priors", "swf_composite_assemble",
-    "swf_composite_set_mid_links", "swf_composite_add_mid_prior", "swf_set_imu_gnss_mid_link",
+    "swf_composite_set_mid_links", "swf_composite_add_mid_prior", "swf_set_imu_gnss_mid_link", "swf_composite_set_root",
 ]
 
 
@@ -460,6 +460,12 @@ class CompositeBatch:
             out.append(dict(r=res[a:a + G].copy(), J=jac[b:b + G * G].reshape(G, G).copy() if want_jac else None,
                             H=Hd[b:b + G * G].reshape(G, G).copy(), rhs=rd[a:a + G].copy(), status=int(st[f])))
         return out
+
+    ROOT_PIVOTED_CHOLESKY, ROOT_EIGEN = 0, 1
+
+    def set_root(self, form):
+        """ROOT_EIGEN: the reference's eigen square root (rows in ascending eigenvalue order); default: pivoted Cholesky rows."""
+        _chk(lib().swf_composite_set_root(self._h, C.c_int32(form)), "swf_composite_set_root")
 
     def set_mid_links(self, mid, H12):
         """IMUGNSSBase::AddMidMargInfo's product per factor: mid[f] = link 1..M-1 carrying the cross block H12[f] (15x15), 0 = none."""

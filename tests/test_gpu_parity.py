@@ -838,6 +838,54 @@ def test_composite_imu_gnss_factors_match_oracle():
         F.close()
 
 
+def test_composite_factor_eigen_square_root_is_the_references_residual_vector():
+    """Row a10, UpdateSchurComponent (R/factor/gnss_imu_factor.cpp:454-488): with SWF_ROOT_EIGEN the device exposes the reference's own
+    square root — J = sqrt(lam+) V^T, r = lam+^-1/2 V^T rhs, ascending eigenvalues, eigenvalues <= 1e-8 dropped — so the residual VECTOR
+    and the Jacobian ROWS can be compared with the oracle's literal restatement (eigenvector signs are free; rows of near-degenerate
+    eigenvalues are compared as a subspace through J^T J).  Cost-only evaluations answer from the same rows."""
+    import composite_gen as cg
+    rng = np.random.default_rng(61)
+    shapes = [(1, 4, 0), (3, 6, 0), (8, 10, 0), (5, 0, 0), (12, 24, 0), (4, 5, 2)]
+    cs = [cg.make_chain(rng, M, N, mid=mid) for (M, N, mid) in shapes]
+    Fo = [ob.Composite(c["pose"], c["sb"], c["pose_lin"], c["sb_lin"], c["Hpp"], c["HpN"], c["rhs_p"], c["HNN"], c["rhsN"], c["pre"], c["pbg"], c["gw"]) for c in cs]
+    for F, c in zip(Fo, cs):
+        if c["mid"]:
+            F.set_mid(c["mid"], c["H12"])
+    Fg = solver.CompositeBatch(cs, cs[0]["pbg"], cs[0]["gw"])
+    Fg.set_mid_links([c["mid"] for c in cs], np.stack([c["H12"] for c in cs]))
+    Fg.set_root(solver.CompositeBatch.ROOT_EIGEN)
+    outer = lambda c, d: np.concatenate([nf.pose_plus(c["Pi"], d[0:6]), c["Bi"] + d[6:15], nf.pose_plus(c["Pj"], d[15:21]), c["Bj"] + d[21:30]])
+    g = Fg.evaluate([outer(c, np.zeros(30)) for c in cs], [c["Nv"] for c in cs], True)
+    n_rows = 0
+    for i, (gi, c, F) in enumerate(zip(g, cs, Fo)):
+        ro, Jo = F.evaluate(c["Pi"], c["Bi"], c["Pj"], c["Bj"], c["Nv"], True)
+        G = 30 + c["N"]
+        lo, lg = np.sum(Jo * Jo, axis=1), np.sum(gi["J"] * gi["J"], axis=1)                 # eigenvalues = squared row norms
+        assert np.all(np.diff(lg) >= -1e-9 * lg.max())                                      # ascending
+        assert np.abs(lg - lo).max() <= 1e-9 * lo.max(), i
+        assert np.abs(gi["J"].T @ gi["J"] - Jo.T @ Jo).max() <= 1e-9 * np.abs(Jo.T @ Jo).max()
+        for k in range(G):
+            gap = min(abs(lo[k] - lo[j]) for j in range(G) if j != k)
+            if lo[k] <= 1e-8 or gap < 1e-6 * lo.max():
+                continue                                                                    # dropped, or not separated: no canonical row
+            sg = 1.0 if gi["J"][k] @ Jo[k] >= 0 else -1.0
+            tol = 1e-10 * lo.max() / gap
+            assert np.abs(sg * gi["J"][k] - Jo[k]).max() <= tol * np.abs(Jo[k]).max() + 1e-12, (i, k)
+            assert abs(sg * gi["r"][k] - ro[k]) <= tol * (abs(ro[k]) + np.abs(ro).max() * 1e-3) + 1e-12, (i, k)
+            n_rows += 1
+    assert n_rows > 100
+    # cost-only evaluations: the linear model on the eigen rows, against the oracle's
+    d1 = [rng.normal(0, 1e-2, 30 + c["N"]) for c in cs]
+    g1 = Fg.evaluate([outer(c, d) for c, d in zip(cs, d1)], [c["Nv"] + d[30:] for c, d in zip(cs, d1)], False)
+    for gi, g0, c, d, F in zip(g1, g, cs, d1, Fo):
+        x = outer(c, d)
+        rc = F.evaluate(x[0:7], x[7:16], x[16:23], x[23:32], c["Nv"] + d[30:], False)
+        assert abs(gi["r"] @ gi["r"] - rc @ rc) <= 1e-8 * (rc @ rc) + 1e-12
+    Fg.close()
+    for F in Fo:
+        F.close()
+
+
 def test_middle_marginalisation_of_a_long_gnss_chain_on_the_device():
     """MiddleMargGnssFrame (R/swf/swf_core.cpp:570-641) end to end: a composite factor hides six GNSS epochs; the stretch e_2, e_3 is
     marginalised ON THE DEVICE (swf_batch_marginal_priors over the window MargGNSSFrames builds: the IMU factors into, inside and out of
