@@ -824,8 +824,11 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
                 }
                 g = ga + G; cells += k;
             }
-            int nch = (int)(rec.size() / (LS_LPC * 8)) - first_chunk, cpp = (nch + GEMM_SPLIT - 1) / GEMM_SPLIT;
-            for (int sp = 0; sp < GEMM_SPLIT; sp++) c0.push_back(first_chunk + std::min(sp * cpp, nch));
+            // part sp = chunks [sp nch / 16, (sp + 1) nch / 16): the parts differ by at most one chunk, so any grouping of consecutive parts
+            // into workgroups (qpb = 1 .. 16, by batch size) is balanced (dealing ceil(nch / 16) chunks to the leading parts left 16 + 3 chunks
+            // on the two workgroups of a cfg3 window at 256 windows)
+            int nch = (int)(rec.size() / (LS_LPC * 8)) - first_chunk;
+            for (int sp = 0; sp < GEMM_SPLIT; sp++) c0.push_back(first_chunk + (int)((long long)sp * nch / GEMM_SPLIT));
         }
         c0.push_back((int)(rec.size() / (LS_LPC * 8)));
         rec.resize(rec.size() + (size_t)LS_LPC * 8 * 2, 0);         // pad: the pipeline never reads past the table, but keep slack
@@ -885,6 +888,10 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             const int force_qpb = getenv("SWF_LS_QPB") ? atoi(getenv("SWF_LS_QPB")) : 0;
             int qpb = 1;
             while (qpb < GEMM_SPLIT && (long long)n * GEMM_SPLIT / (2 * qpb) >= 2LL * b->n_cu) qpb *= 2;
+            // from half a chip of windows on, one block per window: the folded product and the direct-to-S write-out are worth more than the
+            // second round of blocks (measured, 8-iteration cfg3 solves: 256 windows 6.80 -> 5.51 ms, 128 windows 3.92 -> 3.70 ms; 64 windows
+            // would lose, 2.58 -> 3.14 ms)
+            if (2LL * n >= b->n_cu) qpb = GEMM_SPLIT;
             if (force_qpb >= 1 && force_qpb <= GEMM_SPLIT && (force_qpb & (force_qpb - 1)) == 0) qpb = force_qpb;
             b->ls_qpb = qpb;
             b->ls_tpw = (b->max_tiles <= 16 && force < 1) ? 2 : (b->max_tiles <= 40 && force < 2) ? 5 : 10;

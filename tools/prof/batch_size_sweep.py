@@ -1,0 +1,19 @@
+import sys, time, numpy as np
+sys.path.insert(0, '.')
+import bench
+from rtk_visual_inertial_navigation_amd import synth, solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+opt = default_options(max_num_iterations=8)
+allw = bench.make_windows(4, [synth.BASE_SEED + 4 + i for i in range(512)])
+import os
+for B in [int(x) for x in os.environ.get('SWEEP', '512,256,128,64,32,16,8,1').split(',')]:
+    bs = solver.BatchSolver([w.copy() for w in allw[:B]])
+    for _ in range(3):
+        bs.reset_state(); bs.solve_async(opt); bs.sync()
+    t0 = time.perf_counter(); K = 10
+    for _ in range(K):
+        bs.reset_state(); bs.solve_async(opt); bs.sync()
+    dt = (time.perf_counter() - t0) / K
+    its = sum(s.num_iterations for s in bs.summaries())
+    print("windows %4d  %.3f ms per solve  %.1f k it/s  (%.1f us per window-iteration)" % (B, dt * 1e3, its / dt / 1e3, dt * 1e6 / its), flush=True)
+    bs.close()
