@@ -173,6 +173,60 @@ def structure_change_leg(w0, iters, reps=5, n_swap=30):
                 note="wall clock of swf_problem_solve on one cfg3 window through the ceres::Problem-shaped C-ABI")
 
 
+def rtk_topology_leg(iters, n_windows=16, K_vis=10, M=4, F=100, S=10):
+    """Extra configuration: windows in the reference's OWN RTK topology — K_vis visual frames linked only by
+    composite IMU-GNSS factors, each hiding M GNSS epochs whose raw carrier-phase / pseudorange factors were pre-eliminated to a
+    linear prior (GnssPreprocess, R/swf/swf_gnss.cpp:504-532) — built and solved on the device: (1) every GNSS epoch of every
+    window as one batch through swf_batch_marginal_priors, (2) AddMargInfo's bookkeeping on the host (swf_composite_assemble),
+    (3) the composite windows as one batch through the solver.  Synthetic data (tests/rtk_topology_gen.py, a generator only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rtk_topology_gen as rt
+    from rtk_visual_inertial_navigation_amd import solver
+    from rtk_visual_inertial_navigation_amd.flat import default_options
+    t0 = time.perf_counter()
+    wxs = [rt.explicit_window(K_vis=K_vis, M=M, F=F, S=S, seed=900 + i)[0] for i in range(n_windows)]
+    ek = [rt.epoch_windows(wx) for wx in wxs]
+    t_gen = time.perf_counter() - t0
+    ews = [e for (es, _) in ek for e in es]
+    solver.marginal_priors(ews[:8], 1e-8, solver.BatchSolver.PRIOR_EIGEN)           # warm-up (library load, first launches)
+    tm = {}
+    t0 = time.perf_counter()
+    pri = solver.marginal_priors(ews, 1e-8, solver.BatchSolver.PRIOR_EIGEN, timing=tm)
+    t_wrap = time.perf_counter() - t0
+    t_pri = tm["c_abi_call_s"]
+    t0 = time.perf_counter()
+    wins, o = [], 0
+    for wx, (es, kept) in zip(wxs, ek):
+        chains = []
+        for g in range(K_vis - 1):
+            blocks = {}
+            eps = []
+            for e in range(g * M, (g + 1) * M):
+                eps.append(dict(kept=[(sz, blocks.setdefault(k, np.zeros(1)) if sz == 1 else None) for (sz, k) in kept[e]], A=pri[o + e]["A"], b=pri[o + e]["b"]))
+            c = solver.composite_assemble(eps)
+            inv = {id(v): k for k, v in blocks.items()}
+            c["ids"] = [inv[id(b)] for b in c["keys"]]
+            chains.append(c)
+        o += len(es)
+        wins.append(rt.composite_window(wx, chains))
+    t_asm = time.perf_counter() - t0
+    opt = default_options(max_num_iterations=iters)
+    bs = solver.BatchSolver(wins)
+    for _ in range(2):
+        bs.reset_state(); bs.solve_async(opt); bs.sync()
+    lat = []
+    for _ in range(10):
+        bs.reset_state(); t0 = time.perf_counter(); bs.solve_async(opt); bs.sync(); lat.append(time.perf_counter() - t0)
+    sms = bs.summaries()
+    bs.close()
+    its = sum(s.num_iterations for s in sms); dt = float(np.median(lat))
+    return dict(windows=n_windows, visual_frames=K_vis, gnss_epochs_per_gap=M, features=F, satellites=S, gnss_epochs=len(ews),
+                epoch_priors_ms=1e3 * t_pri, epoch_priors_per_s=len(ews) / t_pri, epoch_priors_with_python_marshalling_ms=1e3 * t_wrap, host_assemble_ms=1e3 * t_asm, batch_solve_ms=1e3 * dt,
+                iterations=int(its), iterations_per_s=its / dt, converged=int(sum(s.termination in (1, 2, 3) for s in sms)),
+                mean_cost_reduction=float(np.mean([s.final_cost / s.initial_cost for s in sms])), generate_s=t_gen,
+                note="reference-topology RTK windows: per-epoch GNSS pre-elimination batched on the device, composite IMU-GNSS factors in the solve loop")
+
+
 def relaunch_under_torchrun(n):
     """python bench.py --gpus N (N > 1) without a launcher: become `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`."""
@@ -197,6 +251,7 @@ def main():
     ap.add_argument("--iters", type=int, default=8, help="max_num_iterations (yaml MAX_NUM_ITERATIONS = 8)")
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rtk-topology", action="store_true", help="skip the reference-topology extra configuration")
     ap.add_argument("--no-single-window", action="store_true",
                     help="skip the single-window latency leg (its launches share kernel names with the batch and would dilute rocprofv3 per-kernel averages)")
     a = ap.parse_args()
@@ -365,6 +420,11 @@ def main():
         }
         if not a.no_single_window:
             out["problem_surface"] = structure_change_leg(windows[0].copy(), a.iters)
+        if not a.no_rtk_topology and not a.no_single_window and world == 1:
+            try:
+                out["rtk_topology"] = rtk_topology_leg(a.iters)
+            except Exception as e:                      # an extra: never take the headline line down with it
+                out["rtk_topology"] = dict(error=repr(e))
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(windows, a.iters)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

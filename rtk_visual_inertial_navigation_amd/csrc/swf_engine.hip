@@ -188,6 +188,9 @@ struct swf_batch {
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
     int* mg_tail = nullptr; double* mg_A = nullptr; double* mg_b = nullptr; double* mg_J = nullptr; double* mg_r0 = nullptr; double* mg_w = nullptr; int* mg_rank = nullptr; double* mg_M = nullptr;
     bool mg_valid = false; int mg_ld = 0;
+    // host mirror of the consumer's outputs, filled by the first swf_batch_get_prior after a swf_batch_marginalize of a many-window batch
+    // (one copy per array instead of six small ones per window: 576 GNSS-epoch priors took 46 ms of hipMemcpy latency)
+    bool mg_host = false; std::vector<double> h_mgA, h_mgJ, h_mgb, h_mgr0, h_mgw; std::vector<int> h_mgrank;
     double* mg_resM = nullptr; double* mg_resb = nullptr; int* mg_resok = nullptr;      // k_marg_rescue outputs (rank-deficient tails)
     // ambiguity covariance hand-off outputs (allocated at the first swf_batch_tail_covariance)
     int* tc_tail = nullptr; double* tc_A = nullptr; double* tc_Q = nullptr; double* tc_X = nullptr; int* tc_rank = nullptr; bool tc_valid = false; int tc_ld = 0;
@@ -1397,7 +1400,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                            b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M,
                            (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force);
     HIPCHK(hipGetLastError());
-    b->mg_valid = true;
+    b->mg_valid = true; b->mg_host = false;
     return SWF_OK;
 }
 
@@ -1445,6 +1448,26 @@ extern "C" int swf_batch_get_prior(swf_batch* b, int32_t w, double* A, double* b
     HIPCHK(hipStreamSynchronize(b->stream));
     size_t n = (size_t)b->hw[w].tail_dim, o2 = (size_t)w * b->mg_ld * b->mg_ld, o1 = (size_t)w * b->mg_ld;
     if (n_out) *n_out = (int32_t)n;
+    const size_t nw = b->win.size(), tot2 = nw * b->mg_ld * b->mg_ld, tot1 = nw * b->mg_ld;
+    if (nw >= 8 && tot2 <= ((size_t)1 << 23)) {
+        if (!b->mg_host) {
+            b->h_mgA.resize(tot2); b->h_mgJ.resize(tot2); b->h_mgb.resize(tot1); b->h_mgr0.resize(tot1); b->h_mgw.resize(tot1); b->h_mgrank.resize(nw);
+            HIPCHK(hipMemcpy(b->h_mgA.data(), b->mg_A, tot2 * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(b->h_mgJ.data(), b->mg_J, tot2 * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(b->h_mgb.data(), b->mg_b, tot1 * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(b->h_mgr0.data(), b->mg_r0, tot1 * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(b->h_mgw.data(), b->mg_w, tot1 * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(b->h_mgrank.data(), b->mg_rank, nw * sizeof(int), hipMemcpyDeviceToHost));
+            b->mg_host = true;
+        }
+        if (A) memcpy(A, b->h_mgA.data() + o2, n * n * sizeof(double));
+        if (J) memcpy(J, b->h_mgJ.data() + o2, n * n * sizeof(double));
+        if (bv) memcpy(bv, b->h_mgb.data() + o1, n * sizeof(double));
+        if (r0) memcpy(r0, b->h_mgr0.data() + o1, n * sizeof(double));
+        if (eig) memcpy(eig, b->h_mgw.data() + o1, n * sizeof(double));
+        if (rank) *rank = b->h_mgrank[(size_t)w];
+        return SWF_OK;
+    }
     if (A) HIPCHK(hipMemcpy(A, b->mg_A + o2, n * n * sizeof(double), hipMemcpyDeviceToHost));
     if (J) HIPCHK(hipMemcpy(J, b->mg_J + o2, n * n * sizeof(double), hipMemcpyDeviceToHost));
     if (bv) HIPCHK(hipMemcpy(bv, b->mg_b + o1, n * sizeof(double), hipMemcpyDeviceToHost));

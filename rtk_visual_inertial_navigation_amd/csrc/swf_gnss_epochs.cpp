@@ -26,6 +26,22 @@ extern "C" {
 int swf_batch_marginal_priors(const swf_flat_window* const* windows, int32_t n, double eps, int32_t form,
                               int32_t* dims, int32_t* ranks, double* A, double* b, double* J, double* r0, void* stream) {
     if (!windows || n <= 0 || !dims) return efail(SWF_E_INVALID, "swf_batch_marginal_priors: bad arguments");
+    if (!A && !b && !J && !r0 && !ranks) {
+        // sizing call: the dimension of a prior is the sum of the local sizes of its window's variable tail blocks — no device work
+        for (int i = 0; i < n; i++) {
+            const swf_flat_window* w = windows[i];
+            if (!w || w->n_tail < 0 || w->n_tail > w->n_order) return efail(SWF_E_INVALID, "swf_batch_marginal_priors: bad window");
+            int d = 0;
+            for (int k = w->n_order - w->n_tail; k < w->n_order; k++) {
+                const int g = w->order_block[k];
+                if (g < 0 || g >= w->n_pose + w->n_sb + w->n_lm + w->n_sc) return efail(SWF_E_INVALID, "swf_batch_marginal_priors: block id out of range");
+                if (w->is_const && w->is_const[g]) continue;
+                d += g < w->n_pose ? 6 : g < w->n_pose + w->n_sb ? 9 : g < w->n_pose + w->n_sb + w->n_lm ? 3 : 1;
+            }
+            dims[i] = d;
+        }
+        return SWF_OK;
+    }
     swf_batch* bt = nullptr;
     int rc = swf_batch_create(windows, n, stream, &bt);
     if (rc != SWF_OK) return rc;

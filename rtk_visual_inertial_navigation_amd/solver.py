@@ -490,7 +490,7 @@ class CompositeBatch:
             pass
 
 
-def marginal_priors(windows, eps=1e-8, form=0):
+def marginal_priors(windows, eps=1e-8, form=0, timing=None):
     """swf_batch_marginal_priors: the linear prior over each window's parameter_head tail with everything else eliminated
     (GnssPreprocess's per-epoch marginalize, R/swf/swf_gnss.cpp:504-532), for all windows in one batch on the device.
     Returns a list of dict(n, rank, A, b, J, r0)."""
@@ -503,8 +503,12 @@ def marginal_priors(windows, eps=1e-8, form=0):
          "swf_batch_marginal_priors")
     n2, n1 = int((dims.astype(np.int64) ** 2).sum()), int(dims.sum())
     A, J, b, r0, ranks = np.zeros(max(n2, 1)), np.zeros(max(n2, 1)), np.zeros(max(n1, 1)), np.zeros(max(n1, 1)), np.zeros(n, np.int32)
+    import time as _time
+    t0 = _time.perf_counter()
     _chk(lib().swf_batch_marginal_priors(arr, C.c_int32(n), C.c_double(eps), C.c_int32(form), dims.ctypes.data_as(pi), ranks.ctypes.data_as(pi),
                                          A.ctypes.data_as(_pd), b.ctypes.data_as(_pd), J.ctypes.data_as(_pd), r0.ctypes.data_as(_pd), None), "swf_batch_marginal_priors")
+    if timing is not None:
+        timing["c_abi_call_s"] = _time.perf_counter() - t0          # the C-ABI call alone (structure upload, solve, consumer, download), without this wrapper's marshalling
     out, o2, o1 = [], 0, 0
     for i in range(n):
         d = int(dims[i])
