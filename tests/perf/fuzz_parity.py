@@ -30,8 +30,13 @@ for t in range(N):
     if S and rng.random() < 0.4:
         w = synth.with_spp_and_fixed(w, seed=int(rng.integers(1, 1000)), n_fix=int(rng.integers(0, 4)))
     idp = False
-    if not os.environ.get("FUZZ_LARGE") and rng.random() < 0.35:         # short tracks as inverse-depth landmarks (row a2)
-        w = ig.convert_short_tracks(w, max_track=int(rng.integers(2, 8))); idp = w.counts()["n_idp"] > 0
+    if not os.environ.get("FUZZ_LARGE") and rng.random() < 0.35:         # tracks as inverse-depth landmarks (row a2); long ones take k_clique_big
+        w = ig.convert_short_tracks(w, max_track=int(rng.integers(2, K + 1))); idp = w.counts()["n_idp"] > 0
+    vex = (not idp) and rng.random() < 0.2                                  # variable camera extrinsic: the generic projection path
+    if vex:
+        w = synth.with_variable_extrinsic(w, head=bool(rng.random() < 0.3))
+    strat = 1 if rng.random() < 0.3 else 0                                  # Levenberg-Marquardt / dogleg
+    opts = lambda **k: default_options(strategy=strat, **k)
     msg = []
     try:
         so, eo = ob.solve(w.copy(), default_options(step_mode=1))
@@ -42,8 +47,8 @@ for t in range(N):
         condS = np.linalg.cond(eo["S"])
         bs.close()
         wo, wg = w.copy(), w.copy()
-        so, _ = ob.solve(wo, default_options(), export=False)
-        bs = solver.BatchSolver([wg]); sg = bs.solve(default_options())[0]
+        so, _ = ob.solve(wo, opts(), export=False)
+        bs = solver.BatchSolver([wg]); sg = bs.solve(opts())[0]
         ro, rg_ = so.rows(), sg.rows()
         if sg.termination != so.termination or len(ro) != len(rg_): msg.append("termination %d vs %d" % (sg.termination, so.termination))
         else:
@@ -51,12 +56,14 @@ for t in range(N):
             for a, b in zip(rg_, ro):
                 # a Gauss-Newton step carries eps * cond(S) relative error; the cost sequences of two correct solvers drift apart by that
                 if abs(a["cost"] - b["cost"]) > (5e-7 + 1e-17 * condS) * abs(b["cost"]) + 5e-5: msg.append("cost %.12e vs %.12e (rel %.2e) at iteration %d of %d, cond(S) %.2e" % (a["cost"], b["cost"], abs(a["cost"] - b["cost"]) / abs(b["cost"]), rg_.index(a), len(rg_), condS)); break
-            if np.abs(wg.a["pose"] - wo.a["pose"]).max() > 1e-6: msg.append("pose")
-        wins.append((w, wg, [r["cost"] for r in rg_]))
+            # final states: 1e-6, widened with the conditioning (a variable extrinsic leaves a nearly free direction: cond(S) 1e14..1e16, the two
+            # solvers — and the oracle with itself under another block order — then end ~1e-6 apart in the extrinsic at equal cost)
+            if np.abs(wg.a["pose"] - wo.a["pose"]).max() > 1e-6 * max(1.0, condS / 1e12): msg.append("pose")
+        if strat == 0: wins.append((w, wg, [r["cost"] for r in rg_]))
         bs.close()
     except Exception as e:
         msg.append("exception " + repr(e)[:200])
-    print(t, kw, "spp" if w.a["spr_idx"].size else "", "idepth" if idp else "", "OK" if not msg else "FAIL " + "; ".join(msg), flush=True)
+    print(t, kw, "spp" if w.a["spr_idx"].size else "", "idepth" if idp else "", "var-extrinsic" if vex else "", "LM" if strat else "", "OK" if not msg else "FAIL " + "; ".join(msg), flush=True)
     bad += bool(msg)
 # the whole set as one heterogeneous batch == the singles, bit for bit
 if wins:
