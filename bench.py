@@ -173,6 +173,52 @@ def structure_change_leg(w0, iters, reps=5, n_swap=30):
                 note="wall clock of swf_problem_solve on one cfg3 window through the ceres::Problem-shaped C-ABI")
 
 
+def live_pmc_traffic(kernel_prefix, n_windows, timeout_s=150):
+    """HBM traffic of one kernel, measured NOW on this box: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; TCC counters do not
+    share a pass, and a counter pass is never combined with tracing) over tools/prof/gpu_batch_prof.py — the same windows, batch only, one
+    8-iteration solve — as a child process.  Returns (bytes per launch, per-kernel table) with the guide's gfx950 correction
+    (FETCH_SIZE x 2 for wide coalesced reads), or None when rocprofv3 is unavailable / fails / times out (the caller then falls back to the
+    committed profile and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="swfpmc", dir="/tmp")
+    env = dict(os.environ); env["TMPDIR"] = "/tmp"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = {}
+    try:
+        for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, cn)
+            cmd = [exe, "--pmc", cn, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "prof", "gpu_batch_prof.py"), str(n_windows), "1"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            f = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not f:
+                return None
+            acc = {}
+            for r in csv.DictReader(open(f[0])):
+                if r.get("Counter_Name") != cn:
+                    continue
+                a_ = acc.setdefault(r["Kernel_Name"], [0, 0.0]); a_[0] += 1; a_[1] += float(r["Counter_Value"])
+            res[cn] = {k: v[1] / max(1, v[0]) * 1024.0 for k, v in acc.items()}          # counter unit = KB
+        ks = [k for k in res["FETCH_SIZE"] if kernel_prefix in k]
+        if not ks:
+            return None
+        k0 = ks[0]
+        per_kernel = {k[:64]: 2.0 * res["FETCH_SIZE"][k] + res["WRITE_SIZE"].get(k, 0.0) for k in res["FETCH_SIZE"]}
+        return 2.0 * res["FETCH_SIZE"][k0] + res["WRITE_SIZE"].get(k0, 0.0), per_kernel
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def rtk_topology_leg(iters, n_windows=16, K_vis=10, M=4, F=100, S=10):
     """Extra configuration: windows in the reference's OWN RTK topology — K_vis visual frames linked only by
     composite IMU-GNSS factors, each hiding M GNSS epochs whose raw carrier-phase / pseudorange factors were pre-eliminated to a
@@ -251,6 +297,7 @@ def main():
     ap.add_argument("--iters", type=int, default=8, help="max_num_iterations (yaml MAX_NUM_ITERATIONS = 8)")
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic live")
     ap.add_argument("--no-rtk-topology", action="store_true", help="skip the reference-topology extra configuration")
     ap.add_argument("--no-single-window", action="store_true",
                     help="skip the single-window latency leg (its launches share kernel names with the batch and would dilute rocprofv3 per-kernel averages)")
@@ -354,13 +401,25 @@ def main():
         # HBM traffic from the committed PMC passes of the same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate passes; gfx950: FETCH_SIZE counts half of wide coalesced reads -> x2), if available
         traffic = None
+        traffic_source = None
+        traffic_all = None
+        if world == 1 and not a.no_live_traffic and not os.environ.get("SWF_BENCH_SHARE_GPU"):
+            lt = live_pmc_traffic(knames.get(dom, "k_" + dom).split("<")[0], B)
+            if lt is not None:
+                traffic, traffic_all = lt
+                traffic_source = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation (2 x FETCH + WRITE, per launch)"
         try:
+            if traffic is not None:
+                raise StopIteration
             rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "batch512_pmc_fetch_write.json")))
             pmc = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "batch512_pmc_fetch_write.json")))
             kn = knames.get(dom, "k_" + dom)
             fk = [k for k in pmc["FETCH_SIZE"] if kn.split("<")[0] in k]
             if fk and B == 512:
                 traffic = (2 * pmc["FETCH_SIZE"][fk[0]]["avg_kb_per_launch"] + pmc["WRITE_SIZE"][fk[0]]["avg_kb_per_launch"]) * 1024.0
+                traffic_source = "committed profile profiles/%s/batch512_pmc_fetch_write.json (same workload; live collection unavailable or disabled)" % rounds[-1]
+        except StopIteration:
+            pass
         except Exception:
             traffic = None
         if bound == "mfma":
@@ -379,6 +438,9 @@ def main():
             roof = dict(kernel=knames.get(dom, "k_" + dom), bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, algorithmic=what, algorithmic_bytes_per_launch=units,
                         avg_launch_ms=avg_ms(dom))
+        roof["traffic_source"] = traffic_source
+        if traffic_all:
+            roof["traffic_all_kernels_per_launch"] = {k: v for k, v in sorted(traffic_all.items(), key=lambda kv: -kv[1])[:14]}
         jac = dict(kernel="k_eval_ps<true>", bound="hbm",
                    achieved=calib["proj_bytes"] / (avg_ms("eval_ps") * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                    algorithmic_bytes_per_launch=calib["proj_bytes"], avg_launch_ms=avg_ms("eval_ps"))
