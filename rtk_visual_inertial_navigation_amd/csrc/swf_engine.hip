@@ -776,7 +776,10 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->stream = (hipStream_t)stream;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
-    if ((n * 16 <= b->n_cu || getenv("SWF_AUX_STREAM_ALWAYS")) && !getenv("SWF_NO_AUX_STREAM")) {            // latency path: fork / join inside a linearisation
+    // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
+    // fills what one-block-per-window kernels leave idle (measured: 256 windows 5.52 -> 5.22 ms, 128 windows 3.73 -> 3.49 ms per solve; 64 and
+    // 512 windows: no gain)
+    if ((n * 16 <= b->n_cu || (2 * n >= b->n_cu && n <= b->n_cu) || getenv("SWF_AUX_STREAM_ALWAYS")) && !getenv("SWF_NO_AUX_STREAM")) {            // latency path: fork / join inside a linearisation
         bool ok = (b->aux = handle_cache().stream()) != nullptr;
         for (int i = 0; i < 3 && ok; i++) ok = (b->ev_fork[i] = handle_cache().event(false)) != nullptr;
         if (!ok) { handle_cache().give(b->aux); b->aux = nullptr; }
