@@ -17,7 +17,7 @@ cp "$(find /tmp/swfprof/batch -name '*kernel_stats.csv' | head -1)" "$OUT/batch5
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/single -o s -- python "$ROOT/tools/prof/gpu_single_prof.py" 20 > /tmp/swfprof/single.log 2>&1
 cp "$(find /tmp/swfprof/single -name '*kernel_stats.csv' | head -1)" "$OUT/single_window_kernel_stats.csv"
 # 2b. the bench command itself, without the single-window / CPU legs (same kernel names would dilute the averages)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/bench -o n -- python "$ROOT/bench.py" --no-single-window --no-cpu-baseline > "$OUT/bench_nosingle.json" 2> /tmp/swfprof/bench.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/swfprof/bench -o n -- python "$ROOT/bench.py" --no-single-window --no-cpu-baseline --no-live-traffic > "$OUT/bench_nosingle.json" 2> /tmp/swfprof/bench.log
 cp "$(find /tmp/swfprof/bench -name '*kernel_stats.csv' | head -1)" "$OUT/bench_nosingle_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/swfprof/pmc_$C -o p -- python "$ROOT/tools/prof/gpu_batch_prof.py" 512 2 > /tmp/swfprof/pmc_$C.log 2>&1
