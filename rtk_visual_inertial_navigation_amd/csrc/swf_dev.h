@@ -114,6 +114,7 @@ struct DevBatch {
     const int* lm_win; const int* lm_obs0; const int* lm_loc; const int* lm_col;
     double* lm_Einv; double* lm_g;             // SoA stride n_lm: 6 / 3
     double* P;                                 // landmark Schur product, GEMM_SPLIT partials per window
+    const int* lmb_rec; int n_lmb;             // landmark back-substitution blocks: {first observation, observations (<= 256), first landmark, landmarks}, whole landmarks of one window
     const int* sch_c0; const int* sch_rec;     // k_lm_schur chunk table: chunks of block (window, split); 8-int record per (chunk, group)
     const unsigned long long* lm_fmask;        // frames (slots < 64) each landmark is observed in
     // frames

@@ -805,6 +805,23 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     B.lm_obs0.push_back(D.n_proj);
     PUT(lm_win, B.lm_win); PUT(lm_obs0, B.lm_obs0); PUT(lm_loc, B.lm_loc); PUT(lm_col, B.lm_col); PUT(lm_fmask, B.lm_fmask);
     {
+        // landmark back-substitution blocks: consecutive landmarks of one window with at most 256 observations together
+        std::vector<int> lr;
+        for (const WinRec& Wr : B.win) {
+            int l = Wr.lm0;
+            while (l < Wr.lm1) {
+                const int o0 = B.lm_obs0[(size_t)l]; int l1 = l, cnt = 0;
+                while (l1 < Wr.lm1 && l1 - l < 256 && cnt + (B.lm_obs0[(size_t)l1 + 1] - B.lm_obs0[(size_t)l1]) <= 256) { cnt += B.lm_obs0[(size_t)l1 + 1] - B.lm_obs0[(size_t)l1]; l1++; }
+                if (l1 == l) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "landmark with more than 256 observations"); }
+                lr.push_back(o0); lr.push_back(cnt); lr.push_back(l); lr.push_back(l1 - l);
+                l = l1;
+            }
+        }
+        D.n_lmb = (int)(lr.size() / 4);
+        if (lr.empty()) lr.resize(4, 0);
+        PUT(lmb_rec, lr);
+    }
+    {
         // k_lm_schur chunk table: every (window, split) block walks its landmark range in chunks of LS_LPC 16-lane
         // groups and at most LS_CAP observation cells (one LDS buffer).  A landmark takes 1 / 2 / 4 adjacent, aligned
         // groups (<= 16 / 32 / 64 observations).  Record of (chunk, group): L (-1 = empty), loc, first / end observation
@@ -1202,7 +1219,7 @@ struct Launcher {
         {
             Bracket t(*this, SWF_K_POST_CHOL);
             Segs S{};
-            S.e[0] = nb((size_t)D.n_lm * 16, 256); S.e[1] = S.e[0] + nb((size_t)D.n_cle * 16, 256);
+            S.e[0] = D.n_lmb; S.e[1] = S.e[0] + nb((size_t)D.n_cle * 16, 256);
             S.e[2] = S.e[1]; S.e[3] = S.e[2] + nb(D.n_sc, 256);                                 // (J D^-2 g of the projections rides in segment 0)
             S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + nb((size_t)D.n_prior * 64, 256);
             if (D.n_win < b->n_cu) { if (S.e[5]) hipLaunchKernelGGL(k_post_chol<0>, dim3(S.e[5]), dim3(256), 0, st, D, O, S); }

@@ -984,27 +984,24 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
 // =========================================================================================
 // Back-substitution of the eliminated blocks: y_e = Einv (g_e - H_ef y_f)
 // =========================================================================================
-__device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O, int bid) {
-    // 16 lanes per landmark, one observation per lane and round.  Two things share the observation's Jacobians here:
+__device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O, int bid, double (*sc)[256]) {
+    // One lane per observation (a block = up to 256 consecutive observations = whole landmarks of one window, host-built table), so every
+    // lane of the Jacobian loads is live — 16 lanes per landmark left 6 of them idle at the mean track length of 10.  Two things share the
+    // observation's Jacobians here:
     //   back-substitution  t = g_l - sum_o W_o^T y_pose(o),  W_o^T y = Jl_o^T (Jp_o y)   (W is not stored)
     //   Cauchy point       aux_o = |Jp_o v_pose + Jl_o v_l|^2,  v = D^-2 g            (the projection part of |J D^-2 g|^2)
-    int gid = bid * blockDim.x + threadIdx.x;
-    int L = gid >> 4, sub = threadIdx.x & 15;
-    bool valid = L < B.n_lm;
-    int Lc = valid ? L : B.n_lm - 1;
-    int w = B.lm_win[Lc];
-    const WinState& s = B.ws[w];
-    int loc = B.lm_loc[Lc];
-    bool lin = valid && s.need_lin;
-    bool act = lin && !s.lin_fail && loc >= 0;
-    int nl = B.n_lm, n = B.n_proj;
-    double vl0 = 0, vl1 = 0, vl2 = 0;
-    if (lin && loc >= 0) { vl0 = vec_at<0>(B, O, loc); vl1 = vec_at<0>(B, O, loc + 1); vl2 = vec_at<0>(B, O, loc + 2); }
-    // g_l and Einv of the landmark are fetched up front by lanes 0..8 of the group (one load, off the dependent chain)
-    double pre = 0;
-    if (act && sub < 9) pre = sub < 3 ? B.lm_g[sub * nl + L] : B.lm_Einv[(sub - 3) * nl + L];
-    double t0 = 0, t1 = 0, t2 = 0;
-    if (lin) for (int o = B.lm_obs0[Lc] + sub; o < B.lm_obs0[Lc + 1]; o += 16) {
+    // The per-observation terms of t are staged in LDS and one lane per landmark adds its track in observation order.
+    const int4 rec = ((const int4*)B.lmb_rec)[bid];
+    const int o0 = rec.x, cnt = rec.y, L0 = rec.z, nlm = rec.w, tid = threadIdx.x;
+    const WinState& s = B.ws[B.lm_win[L0]];
+    if (!s.need_lin) return;                                   // uniform: the block belongs to one window
+    const int nl = B.n_lm, n = B.n_proj;
+    double c0 = 0, c1 = 0, c2 = 0;
+    if (tid < cnt) {
+        const int o = o0 + tid;
+        const int loc = B.lm_loc[B.p_lm[o]];
+        double vl0 = 0, vl1 = 0, vl2 = 0;
+        if (loc >= 0) { vl0 = vec_at<0>(B, O, loc); vl1 = vec_at<0>(B, O, loc + 1); vl2 = vec_at<0>(B, O, loc + 2); }
         int lp = B.p_lpose[o];
         double jl0 = B.p_Jl[0 * n + o], jl1 = B.p_Jl[1 * n + o], jl2 = B.p_Jl[2 * n + o];
         double jl3 = B.p_Jl[3 * n + o], jl4 = B.p_Jl[4 * n + o], jl5 = B.p_Jl[5 * n + o];
@@ -1020,16 +1017,19 @@ __device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O,
             }
         }
         B.p_aux[o] = a0 * a0 + a1 * a1;
-        if (B.p_fr[o] >= 0) { t0 -= jl0 * u0 + jl3 * u1; t1 -= jl1 * u0 + jl4 * u1; t2 -= jl2 * u0 + jl5 * u1; }
+        if (B.p_fr[o] >= 0) { c0 = -(jl0 * u0 + jl3 * u1); c1 = -(jl1 * u0 + jl4 * u1); c2 = -(jl2 * u0 + jl5 * u1); }
     }
-    t0 = grp16_sum(t0); t1 = grp16_sum(t1); t2 = grp16_sum(t2);
-    int g0 = (threadIdx.x & 63) & ~15;
-    double pv[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) pv[k] = __shfl(pre, g0 + k, 64);
-    if (!act || sub != 0) return;
-    t0 += pv[0]; t1 += pv[1]; t2 += pv[2];
-    double e00 = pv[3], e10 = pv[4], e20 = pv[5], e11 = pv[6], e21 = pv[7], e22 = pv[8];
+    sc[0][tid] = c0; sc[1][tid] = c1; sc[2][tid] = c2;
+    __syncthreads();
+    if (tid >= nlm || s.lin_fail) return;
+    const int L = L0 + tid, loc = B.lm_loc[L];
+    if (loc < 0) return;
+    double g0 = B.lm_g[0 * nl + L], g1 = B.lm_g[1 * nl + L], g2 = B.lm_g[2 * nl + L];
+    double e00 = B.lm_Einv[0 * nl + L], e10 = B.lm_Einv[1 * nl + L], e20 = B.lm_Einv[2 * nl + L];
+    double e11 = B.lm_Einv[3 * nl + L], e21 = B.lm_Einv[4 * nl + L], e22 = B.lm_Einv[5 * nl + L];
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int q = B.lm_obs0[L] - o0, qe = B.lm_obs0[L + 1] - o0; q < qe; q++) { t0 += sc[0][q]; t1 += sc[1][q]; t2 += sc[2][q]; }
+    t0 += g0; t1 += g1; t2 += g2;
     B.y[loc] = e00 * t0 + e10 * t1 + e20 * t2;
     B.y[loc + 1] = e10 * t0 + e11 * t1 + e21 * t2;
     B.y[loc + 2] = e20 * t0 + e21 * t1 + e22 * t2;
@@ -1114,7 +1114,8 @@ __global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
 template <int PART>
 __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S) {
     int bid = blockIdx.x + (PART == 2 ? S.e[0] : 0);
-    if (PART != 2 && bid < S.e[0]) { d_backsub_lm(B, O, bid); return; }   // also the projection part of |J D^-2 g|^2
+    __shared__ double sm_bs[PART == 2 ? 1 : 3][256];
+    if (PART != 2 && bid < S.e[0]) { d_backsub_lm(B, O, bid, sm_bs); return; }   // also the projection part of |J D^-2 g|^2
     if (PART == 1) return;
     if (bid < S.e[1]) d_backsub_clique(B, bid - S.e[0]);
     else if (bid < S.e[3]) d_jtimes_scalar<0>(B, O, bid - S.e[2]);
