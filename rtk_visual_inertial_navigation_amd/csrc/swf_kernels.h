@@ -1412,8 +1412,9 @@ __global__ void __launch_bounds__(256) k_clique_big(DevBatch B, DevOpt O) {
 // =========================================================================================
 #define FS_BLK 256
 #define FS_VAL 33
+#define FS_HALF 17                            // values staged per pass
 __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
-    __shared__ double V[FS_BLK][FS_VAL];      // 67.6 KB
+    __shared__ double V[FS_BLK][FS_HALF];
     int blk = blockIdx.x;
     if (blk >= B.n_fsb) return;
     int w = B.fsb_win[blk];
@@ -1425,9 +1426,14 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
     __shared__ int foff[168];
     int nF = W.nF;
     for (int e = tid; e <= nF; e += FS_BLK) foff[e] = B.fsb_foff[B.fsb_foff0[blk] + e];
+    // the 33 values are staged in two halves (17 + 16): V = 34.8 KB, four blocks per CU (the full 67.6 KB allowed two)
+    double val[FS_VAL];
+#pragma unroll
+    for (int k = 0; k < FS_VAL; k++) val[k] = 0.0;
+    int rk = 0;
     if (tid < cnt) {
         int o = o_beg + tid;
-        const int rk = B.fsb_perm[o];
+        rk = B.fsb_perm[o];
         double a[6], b[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) { a[i] = B.p_Jp[i * n + o]; b[i] = B.p_Jp[(6 + i) * n + o]; }
@@ -1436,27 +1442,36 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = 0; j <= i; j++) V[rk][k++] = a[i] * a[j] + b[i] * b[j];
+            for (int j = 0; j <= i; j++) val[k++] = a[i] * a[j] + b[i] * b[j];
 #pragma unroll
-        for (int i = 0; i < 6; i++) V[rk][21 + i] = a[i] * r0 + b[i] * r1;
+        for (int i = 0; i < 6; i++) val[21 + i] = a[i] * r0 + b[i] * r1;
         bool lmv = B.lm_loc[B.p_lm[o]] >= 0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) V[rk][27 + i] = lmv ? B.p_yg[i * n + o] : 0.0;
+        for (int i = 0; i < 6; i++) val[27 + i] = lmv ? B.p_yg[i * n + o] : 0.0;
     }
-    __syncthreads();
-    // owner (frame f, value v) adds the block's observations of frame f in permutation order;
-    // loads are issued four at a time, the additions keep their order
     double* out = B.fs_part + (size_t)B.fsb_out0[blk] * FS_VAL;
-    for (int e = tid; e < nF * FS_VAL; e += FS_BLK) {
-        int f = e / FS_VAL, v = e % FS_VAL;
-        double acc = 0;
-        int q = foff[f], q1 = foff[f + 1];
-        for (; q + 4 <= q1; q += 4) {
-            double v0 = V[q][v], v1 = V[q + 1][v], v2 = V[q + 2][v], v3 = V[q + 3][v];
-            acc += v0; acc += v1; acc += v2; acc += v3;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int v0 = half * FS_HALF, nv = half == 0 ? FS_HALF : FS_VAL - FS_HALF;
+        if (half) __syncthreads();                          // the first half's sums are done
+        if (tid < cnt) {
+#pragma unroll
+            for (int k = 0; k < FS_HALF; k++) if (k < nv) V[rk][k] = val[v0 + k];
         }
-        for (; q < q1; q++) acc += V[q][v];
-        out[e] = acc;
+        __syncthreads();
+        // owner (frame f, value v) adds the block's observations of frame f in permutation order;
+        // loads are issued four at a time, the additions keep their order
+        for (int e = tid; e < nF * nv; e += FS_BLK) {
+            int f = e / nv, v = e - f * nv;
+            double acc = 0;
+            int q = foff[f], q1 = foff[f + 1];
+            for (; q + 4 <= q1; q += 4) {
+                double x0 = V[q][v], x1 = V[q + 1][v], x2 = V[q + 2][v], x3 = V[q + 3][v];
+                acc += x0; acc += x1; acc += x2; acc += x3;
+            }
+            for (; q < q1; q++) acc += V[q][v];
+            out[f * FS_VAL + v0 + v] = acc;
+        }
     }
 }
 
