@@ -397,14 +397,14 @@ def main():
             "post_dogleg": ("hbm", (152 + 16) * n_obs, "candidate residuals: 152 B read + 16 B written per observation (the model cost change comes from k_dogleg's vector sums)"),
         }
         bound, units, what = work.get(dom, ("hbm", calib["jacobian_bytes"], "Jacobian bytes of the batch (SURVEY.md 8d formula)"))
-        knames = {"eval_ps": "k_eval_ps<true>", "lm_schur": "k_lm_schur<8, 5>", "assemble": "k_assemble_all", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr2<9>"}
+        knames = {"eval_ps": "k_eval_ps<true>", "lm_schur": "k_lm_schur<8, 5, true>", "assemble": "k_assemble_all", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr2<9>"}
         # HBM traffic from the committed PMC passes of the same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate passes; gfx950: FETCH_SIZE counts half of wide coalesced reads -> x2), if available
         traffic = None
         traffic_source = None
         traffic_all = None
         if world == 1 and not a.no_live_traffic and not os.environ.get("SWF_BENCH_SHARE_GPU"):
-            lt = live_pmc_traffic(knames.get(dom, "k_" + dom).split("<")[0], B)
+            lt = live_pmc_traffic(knames.get(dom, "k_" + dom), B)
             if lt is not None:
                 traffic, traffic_all = lt
                 traffic_source = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation (2 x FETCH + WRITE, per launch)"
@@ -414,7 +414,7 @@ def main():
             rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "batch512_pmc_fetch_write.json")))
             pmc = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "batch512_pmc_fetch_write.json")))
             kn = knames.get(dom, "k_" + dom)
-            fk = [k for k in pmc["FETCH_SIZE"] if kn.split("<")[0] in k]
+            fk = [k for k in pmc["FETCH_SIZE"] if kn in k] or [k for k in pmc["FETCH_SIZE"] if kn.split("<")[0] in k]
             if fk and B == 512:
                 traffic = (2 * pmc["FETCH_SIZE"][fk[0]]["avg_kb_per_launch"] + pmc["WRITE_SIZE"][fk[0]]["avg_kb_per_launch"]) * 1024.0
                 traffic_source = "committed profile profiles/%s/batch512_pmc_fetch_write.json (same workload; live collection unavailable or disabled)" % rounds[-1]

@@ -147,7 +147,7 @@ int swf_batch_get_tail_covariance(swf_batch* b, int32_t w, double* A, double* Qy
  *   CLIQUE_ELIM = the (up to three) size classes of k_clique_elim
  *   ASSEMBLE    = k_assemble_all    diagonal + off-diagonal blocks of the reduced system */
 enum { SWF_K_TOTAL = 0, SWF_K_EVAL_PS = 1, SWF_K_EVAL_IMU = 2, SWF_K_FRAME_SUMS = 3, SWF_K_EVAL_PRIOR = 4,
-       SWF_K_LM_SCHUR = 5, SWF_K_CLIQUE_ELIM = 6, SWF_K_UNUSED7 = 7, SWF_K_ASSEMBLE = 8, SWF_K_CHOL = 9,
+       SWF_K_LM_SCHUR = 5, SWF_K_CLIQUE_ELIM = 6, SWF_K_LM_ELIM = 7, SWF_K_ASSEMBLE = 8, SWF_K_CHOL = 9,
        SWF_K_POST_CHOL = 10, SWF_K_POST_DOGLEG = 11, SWF_K_DOGLEG = 12, SWF_K_CAND_EVAL = 13, SWF_K_DECIDE = 14,
        SWF_K_COUNT = 16 };
 typedef struct swf_timing {

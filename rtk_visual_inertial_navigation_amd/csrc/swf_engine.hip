@@ -1158,17 +1158,23 @@ struct Launcher {
     void lin_elim(int write_S) {
         DevBatch& D = b->D;
         if (D.n_lm) {
-            Bracket t(*this, SWF_K_LM_SCHUR);
+            Bracket t(*this, write_S ? SWF_K_LM_SCHUR : SWF_K_LM_ELIM);
             // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames);
             const int qpb = b->ls_qpb, tpw = b->ls_tpw, sd = b->s_direct ? 1 : 0;       // fixed at creation (swf_batch_create)
             dim3 grid(D.n_win, GEMM_SPLIT / qpb); lm_qpb = qpb;
             lm_folded = b->ls_folded;
-            if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb, 0, sd);
-            else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5>), grid, dim3(LS_NT(8)), 0, st, D, O, write_S, qpb, 0, sd);
+            if (!write_S) {
+                // cost / gradient pass (the solve's final linearisation): the elimination alone — producer waves only, no LDS cells
+                if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2, false>), grid, dim3(LS_NPW * 64), 0, st, D, O, qpb, 0, 0);
+                else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5, false>), grid, dim3(LS_NPW * 64), 0, st, D, O, qpb, 0, 0);
+                else hipLaunchKernelGGL((k_lm_schur<12, 5, false>), grid, dim3(LS_NPW * 64), 0, st, D, O, qpb, 0, 0);
+            }
+            else if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2, true>), grid, dim3(LS_NT(8)), 0, st, D, O, qpb, 0, sd);
+            else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5, true>), grid, dim3(LS_NT(8)), 0, st, D, O, qpb, 0, sd);
             else {
                 // up to 120 tiles: two launches of the 12-consumer-wave, 5-slot variant (tiles 0..59, 60..119)
-                hipLaunchKernelGGL((k_lm_schur<12, 5>), grid, dim3(LS_NT(12)), 0, st, D, O, write_S, qpb, 0, 0);
-                lm_second = write_S && b->max_tiles > 60;       // tiles 60..119: launched below, on the auxiliary stream when there is one
+                hipLaunchKernelGGL((k_lm_schur<12, 5, true>), grid, dim3(LS_NT(12)), 0, st, D, O, qpb, 0, 0);
+                lm_second = b->max_tiles > 60;       // tiles 60..119: launched below, on the auxiliary stream when there is one
             }
         }
         {
@@ -1185,7 +1191,7 @@ struct Launcher {
                 // IMU / clique branch, next to the first range
                 int qpb2 = lm_qpb; dim3 grid2(D.n_win, GEMM_SPLIT / qpb2);
                 Bracket t(*this, SWF_K_LM_SCHUR, sa);
-                hipLaunchKernelGGL((k_lm_schur<12, 5>), grid2, dim3(LS_NT(12)), 0, sa, D, O, write_S, qpb2, 60, 0);
+                hipLaunchKernelGGL((k_lm_schur<12, 5, true>), grid2, dim3(LS_NT(12)), 0, sa, D, O, qpb2, 60, 0);
                 lm_second = false;
             }
             if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);

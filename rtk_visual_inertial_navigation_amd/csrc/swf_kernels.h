@@ -782,11 +782,13 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 // NCW consumer waves with TPW tile slots each, tiles tile_base + [0, NCW * TPW): <8,2> (<= 16 tiles), <8,5> (<= 40),
 // <12,5> twice (<= 120: tile_base 0 and 60; a single 10-slot variant spills under the 128-VGPR cap of 1024 threads —
 // both launches redo the cheap producer work instead)
-template <int NCW, int TPW>
-__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int do_gemm, int qpb, int tile_base, int s_direct) {
+// GEMM = false: the elimination alone (g_l, diag, Einv for a cost / gradient pass: the solve's last linearisation, whose system is never
+// solved): launched with the four producer waves only and no cell storage, under its own kernel name.
+template <int NCW, int TPW, bool GEMM>
+__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int qpb, int tile_base, int s_direct) {
     constexpr int NPW = LS_NPW;
-    __shared__ double cells[2][(LS_CAP + 1) * LS_CS];      // + one all-zero cell per buffer
-    __shared__ int tbl[2][LS_LPC][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
+    __shared__ double cells[2][GEMM ? (LS_CAP + 1) * LS_CS : 1];      // + one all-zero cell per buffer
+    __shared__ int tbl[2][GEMM ? LS_LPC : 1][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
     __shared__ unsigned long long Ms[2][LS_LPC];           // frame mask of the chunk's landmarks (0 = none / constant landmark)
     __shared__ int freds[LS_MAXF];                         // first reduced row of every frame's pose (s_direct write-out)
     constexpr int ZOFF = LS_CAP * LS_CS;
@@ -801,7 +803,7 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
     int nF = W.nF, m = 6 * nF, nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2;
     int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    bool gemm = do_gemm && m > 0;
+    const bool gemm = GEMM && m > 0;
     int blk = w * GEMM_SPLIT + sp0;
     int c0 = B.sch_c0[blk], c1 = B.sch_c0[blk + qpb];
     if (wv >= NPW) {

@@ -19,7 +19,7 @@ class SwfError(RuntimeError):
     pass
 
 
-K_NAMES = ["total", "eval_ps", "eval_imu", "frame_sums", "eval_prior", "lm_schur", "clique_elim", "unused7",
+K_NAMES = ["total", "eval_ps", "eval_imu", "frame_sums", "eval_prior", "lm_schur", "clique_elim", "lm_elim",
            "assemble", "chol_solve", "post_chol", "post_dogleg", "dogleg", "cand_eval", "decide", "unused"]
 
 
