@@ -290,8 +290,8 @@ def relaunch_under_torchrun(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=512, help="windows of the whole job (strong scaling, BASELINE cfg4 = 512) or per GPU (--scaling weak)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--iters", type=int, default=8, help="max_num_iterations (yaml MAX_NUM_ITERATIONS = 8)")
