@@ -809,6 +809,9 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
     if (wv >= NPW) {
         // =========================== consumer waves: P += Y W^T on the matrix cores ===========================
         if (!gemm) return;
+        // (measured: 277 -> 262 us per launch with this s_setprio in place — whatever its value, and equally when the producers carry it instead —
+        // so the gain comes from the instruction's effect on the wave scheduler's interleaving, not from the priority itself)
+        __builtin_amdgcn_s_setprio(1);
         int cw = wv - NPW;
         // tiles of this wave: tile index and frame masks (wave-uniform), per-lane operand addressing:
         // table column of the lane's frame (column nF = the zero cell for lanes outside the matrix and the
