@@ -281,7 +281,8 @@ struct Solver {
         TrustRegionStrategyType trust_region_strategy_type = LEVENBERG_MARQUARDT;      // ceres' default; the window solves set DOGLEG
         int max_num_iterations = 50;         // ceres' default; R/swf/swf.cpp:25 sets MAX_NUM_ITERATIONS
         int num_threads = 1;                 // accepted, unused: the device decides its own parallelism
-        bool jacobi_scaling = false;         // the reference sets 0 everywhere it matters (R/swf/swf.cpp:27); true is refused
+        bool jacobi_scaling = true;          // ceres' default, in force for the reference's default-options solves (R/swf/swf_gnss.cpp:205-214, 562-572:
+                                             // Levenberg-Marquardt, where it is supported); every Options block that selects DOGLEG sets it to 0 (R/swf/swf.cpp:26-27)
         double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16;
         std::shared_ptr<ParameterBlockOrdering> linear_solver_ordering;      // null: automatic ordering (swf_set_ordering, n = 0)
     };
@@ -312,7 +313,7 @@ inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* s) {
     std::memset(&s->raw, 0, sizeof(s->raw));
     s->message.clear();
     int rc = SWF_OK;
-    if (o.jacobi_scaling) { rc = SWF_E_UNSUPPORTED; s->message = "jacobi_scaling = true is not implemented (the reference sets it to false)"; }
+    opt.jacobi_scaling = o.jacobi_scaling ? 1 : 0;       // (with DOGLEG the engine refuses it: SWF_E_UNSUPPORTED, reported below like any failure)
     if (rc == SWF_OK) rc = p->SyncIsUse();
     if (rc == SWF_OK) {
         const ParameterBlockOrdering* ord = o.linear_solver_ordering.get();

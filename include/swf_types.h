@@ -188,6 +188,12 @@ typedef struct swf_options {
     int32_t num_threads;                 /* CPU oracle only */
     int32_t trust_region_strategy;       /* SWF_DOGLEG (what R/swf/swf.cpp:26 sets) / SWF_LEVENBERG_MARQUARDT (the ceres default the
                                             Solver::Options of R/swf/swf_gnss.cpp:200-216, 562-572 run with) */
+    int32_t jacobi_scaling;              /* Solver::Options::jacobi_scaling.  0: what every Options block of the reference that sets it sets
+                                            (R/swf/swf.cpp:27, swf_core.cpp:402,422,449, swf_gnss.cpp:138,152, swf_image.cpp:402,412).  1: ceres'
+                                            default, in force for the default-options solves (R/swf/swf_gnss.cpp:205-214, 562-572): columns
+                                            scaled by 1 / (1 + sqrt(diag(J^T J))) of the FIRST linearisation; supported with
+                                            SWF_LEVENBERG_MARQUARDT (those solves' strategy), refused with SWF_DOGLEG */
+    int32_t reserved;
     double initial_trust_region_radius;  /* 1e4 */
     double max_trust_region_radius;      /* 1e16 */
     double min_trust_region_radius;      /* 1e-32 */
@@ -249,6 +255,8 @@ static inline void swf_options_default(swf_options* o) {
     o->step_mode = SWF_OPTIMIZE;
     o->num_threads = 1;
     o->trust_region_strategy = SWF_DOGLEG;
+    o->jacobi_scaling = 0;
+    o->reserved = 0;
     o->initial_trust_region_radius = 1e4;
     o->max_trust_region_radius = 1e16;
     o->min_trust_region_radius = 1e-32;

@@ -1448,6 +1448,7 @@ int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* 
         sum->tail_dim = td;
     }
     double* dclamp = (double*)malloc(sizeof(double) * (n + 1));
+    double* jq = (double*)malloc(sizeof(double) * (n + 1));          /* Jacobi scaling, see below */
     double* dsqrt = (double*)malloc(sizeof(double) * (n + 1));
     double* tmp = (double*)malloc(sizeof(double) * (n + 1));
     double* xt = (double*)malloc(sizeof(double) * (c->n_x + 1));
@@ -1477,6 +1478,12 @@ int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* 
 
     double radius = opt->initial_trust_region_radius, mu = opt->min_mu;
     const int lm = opt->trust_region_strategy == SWF_LEVENBERG_MARQUARDT;
+    /* Solver::Options::jacobi_scaling (ceres default true; LM only here): TrustRegionMinimizer::IterationZero fixes
+     * scale_i = 1 / (1 + sqrt(diag(J^T J)_i)) at the first linearisation, every later Jacobian is column-scaled by it, the strategy damps the
+     * SCALED system with clamp(diag(J'^T J')) and the step is un-scaled.  In the original coordinates: (J^T J + D_eff / radius) d = -g with
+     * D_eff_i = clamp(diag_i scale_i^2) / scale_i^2.  jq[i] = 1 / scale_i^2. */
+    const int jacobi = lm && opt->jacobi_scaling;
+    if (jacobi) for (int i = 0; i < n; i++) { double r_ = 1.0 + sqrt(c->diag[i] > 0 ? c->diag[i] : 0.0); jq[i] = r_ * r_; }
     double lm_decrease = 2.0;        /* LevenbergMarquardtStrategy::decrease_factor_ */
     int reuse = 0, invalid_run = 0;
     double alpha = 0, dogleg_step_norm = 0;
@@ -1498,9 +1505,9 @@ int oracle_solve(const swf_flat_window* w, const swf_options* opt, swf_summary* 
              * step minimises |J d + r|^2 + |lm_diagonal d|^2, i.e. (J^T J + D^2 / radius) d = -g.  A failed factorisation is an
              * invalid step: StepIsInvalid = StepRejected(0). */
             for (int i = 0; i < n; i++) {
-                double d = c->diag[i];
+                double d = jacobi ? c->diag[i] / jq[i] : c->diag[i];
                 d = d < opt->min_diagonal ? opt->min_diagonal : d; d = d > opt->max_diagonal ? opt->max_diagonal : d;
-                dclamp[i] = d;
+                dclamp[i] = jacobi ? d * jq[i] : d;
             }
             if (linear_solve(c, dclamp, 1.0 / radius, c->gn) != 0) {
                 rec->step_is_valid = 0; rec->cost = x_cost;
@@ -1633,7 +1640,7 @@ done:
         if (ex->loc_off) for (int b = 0; b < c->n_blocks; b++) ex->loc_off[b] = c->loc_off[b];
     }
     ctx_store_state(c);
-    free(dclamp); free(dsqrt); free(tmp); free(xt);
+    free(dclamp); free(jq); free(dsqrt); free(tmp); free(xt);
     ctx_free(c);
     sum->minimizer_time_in_seconds = now_sec() - t0;
     return rc;

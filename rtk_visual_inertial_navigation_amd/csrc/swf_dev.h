@@ -109,6 +109,7 @@ struct DevBatch {
     // two-level per-frame sums: blocks of <= 256 observations of one window
     int n_fsb; const int* fsb_win; const int* fsb_obs0; const int* fsb_perm; const int* fsb_foff; const int* fsb_foff0; const int* fsb_out0;
     double* fs_part;
+    double* jsc;                 // [n_loc_total] Jacobi scaling of the solve's first linearisation, (1 + sqrt(diag))^2 (Solver::Options::jacobi_scaling)
     // landmarks
     int n_lm;
     const int* lm_win; const int* lm_obs0; const int* lm_loc; const int* lm_col;

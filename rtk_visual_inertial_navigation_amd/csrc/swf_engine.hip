@@ -864,6 +864,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     B.fsb_obs0.push_back(D.n_proj); B.fsb_perm.resize((size_t)D.n_proj + 1, 0);
     PUT(fsb_win, B.fsb_win); PUT(fsb_obs0, B.fsb_obs0); PUT(fsb_perm, B.fsb_perm); PUT(fsb_foff, B.fsb_foff); PUT(fsb_foff0, B.fsb_foff0); PUT(fsb_out0, B.fsb_out0);
     rc |= P.zeros((size_t)B.fs_tot * FS_VAL, &D.fs_part);
+    rc |= P.zeros((size_t)std::max<long long>(B.n_loc, 1), &D.jsc);
     D.n_gf = (int)B.gf.size();
     PUT(gf, B.gf);
     PUT(s_x, B.s_x); PUT(s_loc, B.s_loc); PUT(s_ls, B.s_ls); PUT(s_joff, B.s_joff); PUT(s_ccol, B.s_ccol);
@@ -1096,7 +1097,7 @@ extern "C" int swf_batch_reset_state(swf_batch* b) {
 
 static DevOpt to_devopt(const swf_options* o) {
     DevOpt d{};
-    d.max_iter = o->max_num_iterations; d.step_mode = o->step_mode; d.strategy = o->trust_region_strategy;
+    d.max_iter = o->max_num_iterations; d.step_mode = o->step_mode; d.strategy = o->trust_region_strategy; d.jacobi = o->jacobi_scaling ? 1 : 0;
     d.r0 = o->initial_trust_region_radius; d.max_r = o->max_trust_region_radius; d.min_r = o->min_trust_region_radius;
     d.min_rel_dec = o->min_relative_decrease; d.ftol = o->function_tolerance; d.gtol = o->gradient_tolerance;
     d.ptol = o->parameter_tolerance; d.min_mu = o->min_mu; d.max_mu = o->max_mu; d.mu_inc = o->mu_increase_factor;
@@ -1268,6 +1269,8 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
     if (!b || !opt) return fail(SWF_E_INVALID, "swf_batch_solve: bad arguments");
     if (opt->max_num_iterations < 0 || opt->max_num_iterations >= SWF_MAX_TRACE) return fail(SWF_E_INVALID, "max_num_iterations out of range");
     if (opt->trust_region_strategy != SWF_DOGLEG && opt->trust_region_strategy != SWF_LEVENBERG_MARQUARDT) return fail(SWF_E_INVALID, "unknown trust_region_strategy");
+    if (opt->jacobi_scaling && opt->trust_region_strategy == SWF_DOGLEG && opt->step_mode == SWF_OPTIMIZE)
+        return fail(SWF_E_UNSUPPORTED, "jacobi_scaling with the dogleg strategy (the reference sets jacobi_scaling = 0 wherever it selects DOGLEG: R/swf/swf.cpp:26-27)");
     DevBatch& D = b->D;
     Launcher L{ b, to_devopt(opt), b->stream };
     hipStream_t st = b->stream;

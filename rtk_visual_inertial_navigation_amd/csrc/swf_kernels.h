@@ -20,11 +20,24 @@
 #include "swf_dev.h"
 
 struct DevOpt {
-    int max_iter, step_mode, strategy, pad;      // strategy: SWF_DOGLEG / SWF_LEVENBERG_MARQUARDT
+    int max_iter, step_mode, strategy, jacobi;   // strategy: SWF_DOGLEG / SWF_LEVENBERG_MARQUARDT; jacobi: Solver::Options::jacobi_scaling (LM only)
     double r0, max_r, min_r, min_rel_dec, ftol, gtol, ptol, min_mu, max_mu, mu_inc, min_diag, max_diag;
 };
 
 
+
+// The diagonal the trust-region damping multiplies.  Without Jacobi scaling: clamp(diag(J^T J)) (LevenbergMarquardtStrategy / DoglegStrategy,
+// min_diagonal .. max_diagonal).  With it (ceres default, LM): ceres scales column i of J by s_i = 1 / (1 + sqrt(diag_i)) of the FIRST
+// linearisation (TrustRegionMinimizer::IterationZero), damps the scaled system with clamp(diag(J'^T J')) and un-scales the step; in the
+// original coordinates that is (J^T J + mu D_eff) d = -g with D_eff_i = clamp(diag_i s_i^2) / s_i^2.  jsc keeps 1 / s_i^2 = (1 + sqrt(diag0_i))^2
+// per local dimension; `first` = this is the solve's first linearisation (the slot is written, by every lane that computes it, identically).
+__device__ __forceinline__ double damp_diag(const DevOpt& O, double d, double* jsc_slot, bool first) {
+    if (!O.jacobi) return clampd(d, O.min_diag, O.max_diag);
+    double q;
+    if (first) { double r = 1.0 + sqrt(d > 0.0 ? d : 0.0); q = r * r; *jsc_slot = q; }
+    else q = *jsc_slot;
+    return clampd(d / q, O.min_diag, O.max_diag) * q;
+}
 
 #define CLIGHT_D 299792458.0
 #define OMGE_D 7.2921151467E-5
@@ -1028,9 +1041,12 @@ __global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, i
                 B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
                 B.vc[loc] = g0 / clampd(h00, O.min_diag, O.max_diag); B.vc[loc + 1] = g1 / clampd(h11, O.min_diag, O.max_diag); B.vc[loc + 2] = g2 / clampd(h22, O.min_diag, O.max_diag);
             }
-            h00 = __builtin_fma(mu, clampd(h00, O.min_diag, O.max_diag), h00);
-            h11 = __builtin_fma(mu, clampd(h11, O.min_diag, O.max_diag), h11);
-            h22 = __builtin_fma(mu, clampd(h22, O.min_diag, O.max_diag), h22);
+            {
+                const bool jfirst = s.iter == 0;
+                h00 = __builtin_fma(mu, damp_diag(O, h00, B.jsc + loc, jfirst), h00);
+                h11 = __builtin_fma(mu, damp_diag(O, h11, B.jsc + loc + 1, jfirst), h11);
+                h22 = __builtin_fma(mu, damp_diag(O, h22, B.jsc + loc + 2, jfirst), h22);
+            }
             // Cholesky inverse of the 3x3 (ceres InvertPSDMatrix), division-free: the reciprocal pivots
             // come from v_rsq_f64 + Newton steps (the IEEE fp64 sqrt/div expansions are instruction-bound)
             double i00 = rsqrt_nr(h00);
@@ -1180,7 +1196,7 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
 #pragma unroll
         for (int j = 0; j < MAXE; j++) {
             double v = (lane < de && j < de) ? Me[lane][j] : 0.0;
-            if (j == lane) v += s.mu * clampd(v, O.min_diag, O.max_diag);
+            if (j == lane) v += s.mu * (lane < de ? damp_diag(O, v, B.jsc + C.e_loc + lane, s.iter == 0) : clampd(v, O.min_diag, O.max_diag));
             row[j] = v; row[MAXE + j] = (j == lane) ? 1.0 : 0.0;
         }
         bool bad = false;
@@ -1357,7 +1373,7 @@ __global__ void __launch_bounds__(256) k_clique_big(DevBatch B, DevOpt O) {
         if (tid == 0) {
             double A[9][18];
             for (int i = 0; i < de; i++) for (int j = 0; j < de; j++) { A[i][j] = Me[i][j]; A[i][9 + j] = i == j ? 1.0 : 0.0; }
-            for (int i = 0; i < de; i++) A[i][i] += s.mu * clampd(A[i][i], O.min_diag, O.max_diag);
+            for (int i = 0; i < de; i++) A[i][i] += s.mu * damp_diag(O, A[i][i], B.jsc + C.e_loc + i, s.iter == 0);
             bool bad = false;
             for (int k = 0; k < de; k++) {
                 double piv = A[k][k];
@@ -1613,7 +1629,7 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
             }
             if (obs) v += hsum[r];
         }
-        if (DIAG && i == j) v += s.mu * clampd(e < 64 ? dgs0 : dgs1, O.min_diag, O.max_diag);
+        if (DIAG && i == j) v += s.mu * damp_diag(O, e < 64 ? dgs0 : dgs1, B.jsc + Pr.loc_a + i, s.iter == 0);
         S[(size_t)(Pr.ra + i) * n + Pr.rb + j] = v;      // lower triangle only; exports mirror on the host
     }
 }

@@ -1264,7 +1264,7 @@ __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
     }
 #pragma unroll 4
     for (int i = tid; i < n; i += blockDim.x) {
-        double dc = clampd(dg[i], O.min_diag, O.max_diag);
+        double dc = damp_diag(O, dg[i], B.jsc + W.loc_base + i, false);      // (the damping diagonal: with Jacobi scaling, LM's effective one)
         double ir = rsqrt_nr(dc);                     // 1 / sqrt(d): no IEEE sqrt / division expansions in these loops
         double gs = g[i] * ir;
         v[2] += gs * gs; v[3] += dc * y[i] * y[i]; v[4] += -g[i] * y[i];

@@ -277,7 +277,7 @@ def backward_error(A, y, b):
 # ---------------------------------------------------------------------------------- trust-region loop
 def trust_region(w, linearize, cost, strategy="dogleg", damped_solver=None, max_num_iterations=8, initial_radius=1e4, max_radius=1e16, min_radius=1e-32,
                  min_relative_decrease=1e-3, function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8,
-                 min_mu=1e-8, max_mu=1.0, mu_increase_factor=10.0, min_diag=1e-6, max_diag=1e32):
+                 min_mu=1e-8, max_mu=1.0, mu_increase_factor=10.0, min_diag=1e-6, max_diag=1e32, jacobi_scaling=False):
     """ceres::internal::TrustRegionMinimizer::Minimize with a dense linear solver, on the window `w` (state updated in place).
     linearize(w) -> (r, J) at the window's current state; cost(w) -> objective value.
     damped_solver(it, A, g, D2) -> y or None: the solution of A y = g (A = J^T J + mu D2, or + D2 / radius) used in iteration `it`;
@@ -295,9 +295,13 @@ def trust_region(w, linearize, cost, strategy="dogleg", damped_solver=None, max_
         return m
 
     lm = strategy == "lm"
+    assert lm or not jacobi_scaling
     if damped_solver is None:
         damped_solver = lambda it_, A, g_, D2_: refined_solve(A, g_)
     r, J = linearize(w)
+    # Solver::Options::jacobi_scaling, literally: scale = 1 / (1 + sqrt(squared column norms)) of the FIRST Jacobian
+    # (TrustRegionMinimizer::IterationZero); every Jacobian is then column-scaled by it before the strategy sees it
+    scale = 1.0 / (1.0 + np.sqrt(np.einsum("ij,ij->j", J, J))) if jacobi_scaling else None
     x_cost = cost(w)
     g = J.T @ r
     gmax = grad_max_norm(g)
@@ -330,7 +334,18 @@ def trust_region(w, linearize, cost, strategy="dogleg", damped_solver=None, max_
         D2 = np.clip(np.einsum("ij,ij->j", J, J), min_diag, max_diag)
         D = np.sqrt(D2)
         step = None
-        if lm:
+        if lm and jacobi_scaling:
+            # the strategy works on J' = J S: damping diagonal clamp(diag(J'^T J')), step d' of the scaled problem, d = S d'.  Handed to the
+            # solver as the equivalent system in the original coordinates, S^-1 (J'^T J' + D2' / radius) S^-1 d = g (formed from the scaled
+            # quantities), so that an implementation's un-scaled solution can be replayed
+            Js = J * scale
+            Hs = Js.T @ Js
+            D2s = np.clip(np.einsum("ij,ij->j", Js, Js), min_diag, max_diag)
+            A = (Hs + np.diag(D2s) / radius) / np.outer(scale, scale)
+            D2 = D2s / scale ** 2
+            y = damped_solver(it, A, g, D2)
+            step = None if y is None else -y
+        elif lm:
             # LevenbergMarquardtStrategy::ComputeStep: min |J d + r|^2 + |sqrt(D2 / radius) d|^2
             y = damped_solver(it, H + np.diag(D2) / radius, g, D2)
             step = None if y is None else -y

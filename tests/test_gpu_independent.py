@@ -94,14 +94,16 @@ def test_device_reduced_system_and_solution_vs_numpy_dense_normal_equations(name
     assert nd.backward_error(Sd, yf, d["rhs"]) <= 1e-12
 
 
-@pytest.mark.parametrize("strategy", ["dogleg", "lm"])
+@pytest.mark.parametrize("strategy", ["dogleg", "lm", "lm_jacobi"])
 @pytest.mark.parametrize("ci", range(len(TR_CASES)))
 def test_device_trust_region_loop_replayed_by_numpy(ci, strategy):
     cs = TR_CASES[ci]
     w0 = tr_case_window(cs)
+    jac = strategy == "lm_jacobi"            # Solver::Options::jacobi_scaling = true: numpy scales the Jacobian literally
+    strategy = "lm" if jac else strategy
 
     def run(w, k):
-        opt = default_options(max_num_iterations=k, strategy=1 if strategy == "lm" else 0)
+        opt = default_options(max_num_iterations=k, strategy=1 if strategy == "lm" else 0, jacobi_scaling=1 if jac else 0)
         opt.initial_trust_region_radius = cs["r0"]
         bs = solver.BatchSolver([w])
         sm = bs.solve(opt)[0]
@@ -110,20 +112,21 @@ def test_device_trust_region_loop_replayed_by_numpy(ci, strategy):
         run.final = w
         return sm.rows(), ("raw", y)
 
-    rows, impl_rows, berr, wn = nd.replay(w0, run, device_linearize, strategy=strategy, initial_radius=cs["r0"])
+    rows, impl_rows, berr, wn = nd.replay(w0, run, device_linearize, strategy=strategy, initial_radius=cs["r0"], jacobi_scaling=jac)
     hard = bool(cs.get("hard"))
     check_replay(rows, impl_rows, berr, noise=nd.gnss_residual_noise(w0), berr_tol=1e-9 if hard else 1e-12, gtol=1e-6 if hard else 1e-8,
                  rtol_radius=1e-6 if strategy == "lm" else 1e-9)
     assert np.abs(run.final.a["pose"] - wn.a["pose"]).max() <= (1e-9 if hard else 1e-11)
 
 
+@pytest.mark.parametrize("jac", [0, 1])
 @pytest.mark.parametrize("ci", range(len(TR_CASES)))
-def test_device_levenberg_marquardt_sequence_matches_oracle(ci):
+def test_device_levenberg_marquardt_sequence_matches_oracle(ci, jac):
     """The LEVENBERG_MARQUARDT strategy of the device loop against the oracle's: same accept / reject sequence, conditioning-limited
-    costs (see test_gpu_parity.py's header for the bound)."""
+    costs (see test_gpu_parity.py's header for the bound); jac = 1: with ceres' default Jacobi scaling."""
     cs = TR_CASES[ci]
     w0 = tr_case_window(cs)
-    opt = default_options(max_num_iterations=8, strategy=1)
+    opt = default_options(max_num_iterations=8, strategy=1, jacobi_scaling=jac)
     opt.initial_trust_region_radius = cs["r0"]
     wo, wg = w0.copy(), w0.copy()
     so, _ = ob.solve(wo, opt, export=False)

@@ -374,7 +374,7 @@ def test_numpy_window_cost_equals_oracle_cost(win3):
 from np_dense import TR_CASES, tr_case_window, check_replay      # shared with the GPU replay test
 
 
-@pytest.mark.parametrize("strategy", ["dogleg", "lm"])
+@pytest.mark.parametrize("strategy", ["dogleg", "lm", "lm_jacobi"])
 def test_oracle_trust_region_loop_equals_numpy_restatement(strategy):
     """Row a15: oracle_solve against a numpy restatement of ceres' TrustRegionMinimizer + DoglegStrategy /
     LevenbergMarquardtStrategy on the DENSE normal equations (no Schur, no block structure), candidate costs from
@@ -385,22 +385,28 @@ def test_oracle_trust_region_loop_equals_numpy_restatement(strategy):
     reject, radius — at rounding level.  The cases include rejected steps and interpolated dogleg steps."""
     import np_dense as nd
     seen_reject = False
+    # "lm_jacobi": Solver::Options::jacobi_scaling = true (ceres' default, in force for the reference's default-options solves): numpy scales the
+    # Jacobian literally, the oracle damps with the equivalent diagonal in the original coordinates
+    jac = strategy == "lm_jacobi"
+    strategy = "lm" if jac else strategy
     for cs in TR_CASES:
         w0 = tr_case_window(cs)
 
         def run(w, k):
-            opt = default_options(max_num_iterations=k, strategy=1 if strategy == "lm" else 0)
+            opt = default_options(max_num_iterations=k, strategy=1 if strategy == "lm" else 0, jacobi_scaling=1 if jac else 0)
             opt.initial_trust_region_radius = cs["r0"]
             sm, ex = ob.solve(w, opt)
             run.final = w
             return sm.rows(), (("raw" if strategy == "lm" else "scaled"), ex["gn_step"])
 
-        rows, impl_rows, berr, wn = nd.replay(w0, run, ob.export_jacobian, strategy=strategy, initial_radius=cs["r0"])
+        rows, impl_rows, berr, wn = nd.replay(w0, run, ob.export_jacobian, strategy=strategy, initial_radius=cs["r0"], jacobi_scaling=jac)
         check_replay(rows, impl_rows, berr, noise=nd.gnss_residual_noise(w0), berr_tol=1e-9 if cs.get("hard") else 1e-12, gtol=1e-6 if cs.get("hard") else 1e-8,
                      rtol_radius=1e-6 if strategy == "lm" else 1e-9)
         seen_reject |= any(k and r["valid"] and not r["accepted"] for k, r in enumerate(rows))
         assert np.abs(run.final.a["pose"] - wn.a["pose"]).max() <= (1e-9 if cs.get("hard") else 1e-11)
     assert seen_reject, "no case exercised a rejected step"
+    # (Levenberg-Marquardt with the Marquardt diagonal is invariant under column scaling: Jacobi scaling changes the iterates only where the
+    # clamp of the damping diagonal to [min_diagonal, max_diagonal] bites — columns with squared norm below ~1e-6 — and in rounding)
 
 
 def test_linear_solve_forward_error_is_eps_times_condition_number(win3):
