@@ -174,3 +174,35 @@ def test_cfg4_full_size_batch_equals_single_windows_and_the_oracle():
         for a, b in zip(rb, ro):
             assert abs(a["cost"] - b["cost"]) <= 5e-7 * abs(b["cost"]) + 5e-5
         assert np.abs(wo.a["pose"] - batch[i].a["pose"]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_levenberg_marquardt_on_composite_inverse_depth_and_variable_extrinsic_windows():
+    """LEVENBERG_MARQUARDT (with and without Jacobi scaling) on the window kinds the TR_CASES do not hold — composite IMU-GNSS factors in the
+    loop (one window with middle-marginalisation links, whose solve has a rejected step: the re-solve must leave the hidden epochs alone),
+    inverse-depth landmarks, a variable camera extrinsic — against the oracle's LM: same accept / reject sequence, costs and final states at
+    the accuracy LM's well-conditioned steps allow (mu = 1 / radius, not the dogleg's 1e-8)."""
+    import composite_gen as cg
+    import idepth_gen as ig
+    rng = np.random.default_rng(5)
+    wins = {"composite": cg.make_window(rng, 5, 3, 6, F=30), "composite_mid": cg.make_window(rng, 4, 5, 6, F=0, mid=True),
+            "idepth": ig.convert_short_tracks(synth.make_window(2, K=8, F=40, S=0, seed=3), max_track=8),
+            "var_ex": synth.with_variable_extrinsic(synth.make_window(3, K=6, F=30, S=5, seed=8))}
+    rejected = 0
+    for name, w in wins.items():
+        for jac in (0, 1):
+            opt = default_options(max_num_iterations=12, strategy=1, jacobi_scaling=jac)
+            opt.initial_trust_region_radius = 30.0
+            wo, wg = w.copy(), w.copy()
+            so, _ = ob.solve(wo, opt, export=False)
+            bs = solver.BatchSolver([wg]); sg = bs.solve(opt)[0]; bs.close()
+            ro, rg = so.rows(), sg.rows()
+            assert sg.termination == so.termination and len(ro) == len(rg), name
+            assert [r["step_is_successful"] for r in ro] == [r["step_is_successful"] for r in rg], name
+            rejected += sum(1 for r in ro if not r["step_is_successful"])
+            tol = 1e-8 if name == "var_ex" else 1e-10
+            assert max(abs(a["cost"] - b["cost"]) / abs(a["cost"]) for a, b in zip(ro, rg)) <= tol, name
+            assert np.abs(wo.a["pose"] - wg.a["pose"]).max() <= (1e-6 if name == "var_ex" else 1e-9), name
+            if "comp_pose" in w.a and w.a["comp_pose"].size:
+                assert np.abs(wo.a["comp_pose"] - wg.a["comp_pose"]).max() <= 1e-9, name
+    assert rejected > 0
