@@ -722,6 +722,81 @@ def test_problem_api_structure_changes():
     P.close()
 
 
+def test_problem_surface_random_structure_edits_equal_fresh_flat_windows():
+    """A long-lived Problem edited the way the estimator edits its window — landmarks removed with their observations, new ones added,
+    poses frozen and released, the ordering re-issued — and solved after every edit, against a FRESH flat window holding the same content,
+    built from scratch each round: bit-identical costs and states.  Exercises the incremental rebuild of round 2 (slab arena, cached
+    slabs / streams / events handed from one batch to the next, dirty tracking) over a dozen rebuilds of changing sizes."""
+    rng = np.random.default_rng(2024)
+    w = synth.make_window(3, K=6, F=30, S=5, seed=17)
+    P, blocks = solver.problem_from_window(w)
+    saved = [b.copy() for b in blocks]
+    pi, uv = w.a["proj_idx"].reshape(-1, 3), w.a["proj_uv"].reshape(-1, 2)
+    ex_id = int(pi[0, 1])
+    # model: landmark key -> (block, value, observations); the order of keys = the order inside elimination group 0
+    model = {}
+    for l in range(w.n_lm):
+        sel = pi[:, 2] == l
+        model[l] = dict(block=blocks[w.bid_lm(l)], value=saved[w.bid_lm(l)].copy(), obs=[(int(p_), u.copy()) for (p_, _, _), u in zip(pi[sel], uv[sel])])
+    lm_ids = set(w.bid_lm(l) for l in range(w.n_lm))
+    ob0, og0 = list(w.a["order_block"]), list(w.a["order_group"])
+    head = [(b, g) for b, g in zip(ob0, og0) if b not in lm_ids and g == 0]           # group-0 blocks that are not landmarks (clocks, dummy, speed-biases)
+    rest = [(b, g) for b, g in zip(ob0, og0) if g != 0]
+    lm_order = [l for l in range(w.n_lm)]
+    const_pose = set()
+    next_key = w.n_lm
+    for rnd in range(12):
+        # ---- edit
+        for _ in range(int(rng.integers(1, 5))):
+            if lm_order and rng.random() < 0.55:
+                l = lm_order.pop(int(rng.integers(0, len(lm_order))))
+                P.RemoveParameterBlock(model[l]["block"]); model[l]["block"] = None
+            else:
+                src = model[int(rng.integers(0, w.n_lm))]                               # a new landmark near an old one, seen from a random run of frames
+                val = src["value"] + rng.normal(0, 0.05, 3)
+                blk = val.copy()
+                obs = [(p_, u + rng.normal(0, 1e-3, 2)) for (p_, u) in src["obs"]]
+                for (p_, u) in obs:
+                    P.AddProjection(blocks[w.bid_pose(p_)], blocks[w.bid_pose(ex_id)], blk, u, w.proj_sqrt_info, w.proj_loss_a)
+                model[next_key] = dict(block=blk, value=val, obs=obs); lm_order.append(next_key); next_key += 1
+        k = int(rng.integers(1, w.meta["K"]))
+        if k in const_pose: const_pose.discard(k); P.SetParameterBlockVariable(blocks[w.bid_pose(k)])
+        elif rng.random() < 0.5: const_pose.add(k); P.SetParameterBlockConstant(blocks[w.bid_pose(k)])
+        # ---- same start for both
+        for b, s_ in zip(blocks, saved): b[...] = s_
+        for l in lm_order: model[l]["block"][...] = model[l]["value"]
+        order_blocks = [model[l]["block"] for l in lm_order] + [blocks[b] for b, _ in head] + [blocks[b] for b, _ in rest]
+        order_groups = [0] * (len(lm_order) + len(head)) + [g for _, g in rest]
+        P.SetOrdering(order_blocks, order_groups)
+        sm = P.Solve(default_options())
+        # ---- the fresh flat window with the same content
+        w2 = w.copy()
+        n_lm2 = len(lm_order)
+        w2.a["lm"] = np.ascontiguousarray(np.concatenate([model[l]["value"] for l in lm_order])) if n_lm2 else np.zeros(0)
+        pidx, puv = [], []
+        for j, l in enumerate(lm_order):
+            for (p_, u) in model[l]["obs"]:
+                pidx.append([p_, ex_id, j]); puv.append(u)
+        w2.a["proj_idx"] = np.ascontiguousarray(np.array(pidx, np.int32).reshape(-1, 3)); w2.a["proj_uv"] = np.ascontiguousarray(np.array(puv).reshape(-1, 2))
+        shift = n_lm2 - w.n_lm                                                        # scalar-pool block ids move with the landmark count
+        remap = lambda b: b if b < w.bid_lm(0) else b + shift
+        ic_old = w.a["is_const"]
+        ic = np.concatenate([ic_old[:w.bid_lm(0)], np.zeros(n_lm2, np.uint8), ic_old[w.bid_lm(0) + w.n_lm:]]).astype(np.uint8)
+        for k_ in const_pose: ic[w.bid_pose(k_)] = 1
+        w2.a["is_const"] = np.ascontiguousarray(ic)
+        ob2 = [w.bid_lm(0) + j for j in range(n_lm2)] + [remap(b) for b, _ in head] + [remap(b) for b, _ in rest]
+        keep = [q for q, b in enumerate(ob2) if not ic[b]]                              # the flat format lists variable blocks only (ceres ignores constant ones)
+        gs = sorted(set(order_groups[q] for q in keep)); rank = {g: r for r, g in enumerate(gs)}
+        w2.a["order_block"] = np.array([ob2[q] for q in keep], np.int32)
+        w2.a["order_group"] = np.array([rank[order_groups[q]] for q in keep], np.int32)
+        if w2.a["prior_blk"].size: w2.a["prior_blk"] = np.array([remap(int(b)) for b in w2.a["prior_blk"]], np.int32)
+        bs = solver.BatchSolver([w2]); s2 = bs.solve(default_options())[0]; bs.close()
+        assert [r["cost"] for r in sm.rows()] == [r["cost"] for r in s2.rows()], rnd
+        assert np.array_equal(np.concatenate(blocks[:w.n_pose]), w2.a["pose"].ravel()) and np.array_equal(np.concatenate(blocks[w.n_pose:w.n_pose + w.n_sb]), w2.a["sb"].ravel()), rnd
+        if n_lm2: assert np.array_equal(np.concatenate([model[l]["block"] for l in lm_order]), w2.a["lm"].ravel()), rnd
+    P.close()
+
+
 def _imu_samples(rng, n, dt=0.0025, jitter=True):
     """A plausible IMU stream: gravity-ish specific force, slow rotation, per-sample dt jitter."""
     t = np.cumsum(np.full(n, dt))
