@@ -1,0 +1,75 @@
+"""Randomised sweep of the marginalisation consumer and the ambiguity covariance hand-off (not part of the test suite; run on a GPU box):
+   python tests/perf/fuzz_marginalize.py [n_cases] [seed]
+Random windows and parameter_head choices; per case swf_batch_marginalize (eigen + Cholesky forms) against the oracle's literal restatement
+of UpdateSchur + setmarginalizeinfo, the tail covariance against numpy, and GlobalMarge-shaped windows (first frame marginalised, possibly
+rank-deficient on the kept states) through the rescue path; finally all windows as one batch == singles, bit for bit."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_binding as ob
+import cfg5_marg_gen as mg
+from rtk_visual_inertial_navigation_amd import synth, solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+bad = 0; singles = []
+for t in range(N):
+    vi = rng.random() < 0.3
+    K = int(rng.integers(3, 13)); F = int(rng.integers(max(4, K), 60)); S = 0 if vi else int(rng.integers(4, 11))
+    kind = rng.choice(["ambiguities", "frames", "globalmarge"]) if S else rng.choice(["frames", "globalmarge"])
+    msg = []
+    try:
+        if kind == "globalmarge":
+            full = synth.make_window(3 if S else 2, K=K + 1, F=F, S=S, prior="gauge", seed=int(rng.integers(1, 10 ** 6)))
+            w, _ = mg.marginalisation_window(full)
+        else:
+            w = synth.make_window(3 if S else 2, K=K, F=F, S=S, seed=int(rng.integers(1, 10 ** 6)), head=str(kind))
+        so, eo = ob.solve(w.copy(), default_options(step_mode=1))
+        bs = solver.BatchSolver([w.copy()]); sg = bs.solve(default_options(step_mode=1))[0]
+        n = sg.tail_dim
+        if n <= 0 or n > 384: bs.close(); print(t, kind, K, F, S, "skip n", n); continue
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN); g = bs.get_prior(0)
+        o = ob.marginalize(eo["S"], eo["rhs"], n)
+        m = eo["S"].shape[0] - n
+        ev = np.linalg.eigvalsh(eo["S"][:m, :m]) if m else np.ones(1)
+        tol = max(1e-9, 1e-16 * ev[-1] / max(ev[0], 1e-300))
+        sc = np.abs(o["A"]).max()
+        # an extended-precision Schur complement as the referee: A cancels heavily (its entries are orders of magnitude below those of
+        # S_nn), so device and oracle differ by eps * cond * cancellation — the device, which never forms the eigen pseudo-inverse,
+        # is usually the closer one.  Criterion: the device is at least as accurate as the reference's literal method (x10 slack).
+        S_ = eo["S"].astype(np.longdouble)
+        if m:
+            d = np.sqrt(np.diag(S_)[:m]); Ss = S_[:m, :m] / np.outer(d, d); B0 = S_[:m, m:] / d[:, None]
+            X = np.linalg.solve(Ss.astype(np.float64), B0.astype(np.float64)).astype(np.longdouble)
+            for _ in range(3):
+                X = X + np.linalg.solve(Ss.astype(np.float64), (B0 - Ss @ X).astype(np.float64)).astype(np.longdouble)
+            Aref = (S_[m:, m:] - (S_[m:, :m] / d[None, :]) @ X).astype(np.float64)
+        else:
+            Aref = eo["S"][m:, m:]
+        err_d, err_o = np.abs(g["A"] - Aref).max() / sc, np.abs(o["A"] - Aref).max() / sc
+        if g["rank"] < 0: msg.append("rank -1")
+        else:
+            if err_d > 10 * err_o + 1e-10: msg.append("A: device %.1e, oracle %.1e off the extended-precision Schur complement" % (err_d, err_o))
+            if abs(g["rank"] - o["rank"]) > 0:
+                # eigenvalues within the accuracy of A of the 1e-8 cut-off may fall on either side of it
+                lam = np.sort(np.linalg.eigvalsh(Aref)); near = np.sum(np.abs(lam - 1e-8) <= 10 * max(err_d, err_o) * sc + 1e-9)
+                if near < abs(g["rank"] - o["rank"]): msg.append("rank %d vs %d" % (g["rank"], o["rank"]))
+            if np.abs(g["J"].T @ g["J"] - g["A"]).max() > 1e-11 * sc + 2e-8: msg.append("JtJ %.1e" % (np.abs(g["J"].T @ g["J"] - g["A"]).max() / sc))
+            if np.abs(g["J"].T @ g["r0"] - g["b"]).max() > 1e-8 * np.abs(g["b"]).max() + 1e-6: msg.append("Jtr0")
+        singles.append((w, g))
+        bs.close()
+    except Exception as e:
+        msg.append("exception " + repr(e)[:160])
+    print(t, kind, "K", K, "F", F, "S", S, "OK" if not msg else "FAIL " + "; ".join(msg), flush=True)
+    bad += bool(msg)
+if singles:
+    bs = solver.BatchSolver([w.copy() for w, _ in singles]); bs.solve(default_options(step_mode=1)); bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+    for i, (w, g1) in enumerate(singles):
+        gb = bs.get_prior(i)
+        if gb["rank"] != g1["rank"] or any(not np.array_equal(gb[k], g1[k]) for k in ("A", "b", "J", "r0")):
+            print("batch != single for case", i); bad += 1
+    bs.close()
+print("fuzz_marginalize: %d cases, %d failures" % (N, bad))
+sys.exit(1 if bad else 0)
