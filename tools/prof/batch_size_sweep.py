@@ -14,6 +14,7 @@ for B in [int(x) for x in os.environ.get('SWEEP', '512,256,128,64,32,16,8,1').sp
     for _ in range(K):
         bs.reset_state(); bs.solve_async(opt); bs.sync()
     dt = (time.perf_counter() - t0) / K
+    assert all(s.termination in (1, 2, 3, 4) for s in bs.summaries()), "a solve failed: the timing would be meaningless"
     its = sum(s.num_iterations for s in bs.summaries())
     print("windows %4d  %.3f ms per solve  %.1f k it/s  (%.1f us per window-iteration)" % (B, dt * 1e3, its / dt / 1e3, dt * 1e6 / its), flush=True)
     bs.close()
