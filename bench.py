@@ -474,6 +474,8 @@ def main():
             "with_state_upload": {"ms_per_step": 1e3 * dt_up / a.steps, "value": its_total * a.steps / dt_up,
                                   "note": "parameter blocks re-uploaded from pageable host memory before every solve (PCIe-inclusive)"},
             "job_final_cost_mean": float(job[:, 0].mean()), "job_windows": int(job.shape[0]),
+            # terminations 1..4 = converged / iteration limit; anything else (linear solver failure, ...) would make the rate meaningless
+            "job_failed_windows": int(np.sum(~np.isin(job[:, 2].astype(int), (1, 2, 3, 4)))),
             "roofline": roof,
             "roofline_jacobian": jac,
             "kernel_ms_per_solve_calibration": {k: v["ms"] for k, v in calib["kernels"].items()},
