@@ -57,7 +57,16 @@ def gather_summaries(local, device="cpu"):
     if d is None:
         return local
     import torch
-    t = torch.from_numpy(local).to(device)
-    out = [torch.empty_like(t) for _ in range(d.get_world_size())]
+    # ranks may own different numbers of windows (strong partition of a job that does not divide evenly): gather the counts, pad to the
+    # largest, trim after the gather
+    world = d.get_world_size()
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    d.all_gather(cnts, cnt)
+    counts = [int(c.item()) for c in cnts]
+    width = local.shape[1] if local.ndim == 2 else 3
+    pad = np.zeros((max(counts), width)); pad[:local.shape[0]] = local.reshape(-1, width)
+    t = torch.from_numpy(pad).to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
     d.all_gather(out, t)
-    return np.concatenate([o.cpu().numpy() for o in out], axis=0)
+    return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(out, counts)], axis=0)

@@ -119,3 +119,28 @@ def test_bench_two_ranks_sharing_one_gpu_reports_the_whole_job():
     out1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
     assert out1["n_gpus"] == 1 and out1["job_windows"] == 16
     assert out1["job_final_cost_mean"] == out["job_final_cost_mean"]
+
+
+def _uneven_worker(rank, world, port, total, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from rtk_visual_inertial_navigation_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = shard.partition(total, world, rank)
+    recs = np.array([[100.0 + first + i, first + i, 4.0] for i in range(count)]).reshape(-1, 3)
+    np.save(os.path.join(out_dir, "u%d.npy" % rank), shard.gather_summaries(recs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_of_an_uneven_strong_partition(tmp_path):
+    """A job that does not divide evenly over the ranks (5 windows on 2 ranks: 3 + 2): the gathered records are the job's windows in order."""
+    import torch.multiprocessing as mp
+    world, total = 2, 5
+    mp.spawn(_uneven_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = (np.load(os.path.join(str(tmp_path), "u%d.npy" % r)) for r in range(world))
+    assert g0.shape == (total, 3) and np.array_equal(g0, g1)
+    assert np.array_equal(g0[:, 1], np.arange(total)) and np.array_equal(g0[:, 0], 100.0 + np.arange(total))
