@@ -1228,7 +1228,7 @@ struct Launcher {
             Segs S{};
             S.e[0] = D.n_lmb; S.e[1] = S.e[0] + nb((size_t)D.n_cle * 16, 256);
             S.e[2] = S.e[1]; S.e[3] = S.e[2] + nb(D.n_sc, 256);                                 // (J D^-2 g of the projections rides in segment 0)
-            S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + nb((size_t)D.n_prior * 64, 256);
+            S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + D.n_prior;      // one workgroup per prior
             if (D.n_win < b->n_cu) { if (S.e[5]) hipLaunchKernelGGL(k_post_chol<0>, dim3(S.e[5]), dim3(256), 0, st, D, O, S); }
             else {
                 if (S.e[0]) hipLaunchKernelGGL(k_post_chol<1>, dim3(S.e[0]), dim3(256), 0, st, D, O, S);

@@ -738,19 +738,47 @@ __device__ __forceinline__ void d_jtimes_imu(const DevBatch& B, const DevOpt& O,
     part = grp16_sum(part);
     if (act && sub == 0) B.g_aux[f] = part;
 }
-// priors: one wavefront per prior, lanes over residual rows
+// priors: one 256-thread workgroup per prior, threads over residual rows.  The vector entries at the prior's columns (the same for every
+// row) are staged in LDS once together with the column -> local index map, so a row's dot product is n coalesced loads of the transposed
+// record and LDS broadcasts: the stress window's 263-dimension prior took 100 us as one wavefront whose lanes each gathered v per column.
+// Sums: columns in order inside a row (constant columns skipped), rows by wave butterfly, waves in order — for priors of up to 64 rows
+// (every configuration but the stress window) bit-identical to the one-wavefront form.
+#define PRB_MAX 512
 template <int MODE>
-__device__ __forceinline__ void d_jtimes_prior(const DevBatch& B, const DevOpt& O, int bid) {
-    int q = (bid * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ void d_jtimes_prior(const DevBatch& B, const DevOpt& O, int q, double* sv, int* sl, double* sw) {
+    const int tid = threadIdx.x;
     if (q >= B.n_prior) return;
     int f = B.prior_gf[q];
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
-    if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;
+    if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;        // uniform per block
+    const int n = G.nres;
+    const bool staged = n <= PRB_MAX;
+    const int* cl = B.prior_colloc + B.prior_roff[G.data];
+    if (staged) for (int c = tid; c < n; c += 256) { int lo = cl[c]; sl[c] = lo; sv[c] = lo >= 0 ? vec_at<MODE>(B, O, lo) : 0.0; }
+    __syncthreads();
     double part = 0;
-    for (int k = lane; k < G.nres; k += 64) part += gf_row_term<MODE>(B, G, k, gf_row_dot<MODE>(B, O, G, k));
+    for (int k = tid; k < n; k += 256) {
+        double a;
+        if (staged) {
+            const double* ck = B.prior_Jt + B.prior_Joff[G.data] + k;
+            a = 0;
+            int c = 0;
+            for (; c + 8 <= n; c += 8) {
+                double cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) cv[u] = ck[(size_t)(c + u) * n];
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (sl[c + u] >= 0) a += cv[u] * sv[c + u];
+            }
+            for (; c < n; c++) if (sl[c] >= 0) a += ck[(size_t)c * n] * sv[c];
+        } else a = gf_row_dot<MODE>(B, O, G, k);
+        part += gf_row_term<MODE>(B, G, k, a);
+    }
     part = wave_sum(part);
-    if (lane == 0) B.g_aux[f] = part;
+    if ((tid & 63) == 0) sw[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) B.g_aux[f] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
 }
 
 // =========================================================================================

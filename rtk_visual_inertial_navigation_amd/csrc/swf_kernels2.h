@@ -1115,12 +1115,13 @@ template <int PART>
 __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S) {
     int bid = blockIdx.x + (PART == 2 ? S.e[0] : 0);
     __shared__ double sm_bs[PART == 2 ? 1 : 3][256];
+    __shared__ double sm_pv[PART == 1 ? 1 : PRB_MAX]; __shared__ int sm_pl[PART == 1 ? 1 : PRB_MAX]; __shared__ double sm_pw[4];
     if (PART != 2 && bid < S.e[0]) { d_backsub_lm(B, O, bid, sm_bs); return; }   // also the projection part of |J D^-2 g|^2
     if (PART == 1) return;
     if (bid < S.e[1]) d_backsub_clique(B, bid - S.e[0]);
     else if (bid < S.e[3]) d_jtimes_scalar<0>(B, O, bid - S.e[2]);
     else if (bid < S.e[4]) d_jtimes_imu<0>(B, O, bid - S.e[3]);
-    else d_jtimes_prior<0>(B, O, bid - S.e[4]);
+    else d_jtimes_prior<0>(B, O, bid - S.e[4], sm_pv, sm_pl, sm_pw);
 }
 // after the dogleg step: the candidate residuals (costs) of every factor family.  The model cost change needs no pass over the
 // Jacobians any more: k_dogleg gets it from vectors alone (see there).
