@@ -128,12 +128,17 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         // Cholesky square root, straight from the L buffer (no LDS residency, any tail up to ldn):
         //   A = L_nn L_nn^T, b = A y_n = L_nn (L_nn^T y_n), J = L_nn^T, r0 = L_nn^T y_n;  J^T J = A, J^T r0 = b
         const double* Ln = L + (size_t)m * nr + m;     // L_nn[i][r] = Ln[i * nr + r]
+        // J = L_nn^T first; A is then formed from J's rows, J[r][i] J[r][j] with the lanes over j: coalesced, where the same products read
+        // from the L buffer stride by n_red (the 263-dimension tail of the stress window: 2.7 ms that way).  Same terms in the same order.
+        double* Jw = outJ + o2;
+        for (int e = tid; e < n * n; e += MG_NT) { int i = e / n, j = e - i * n; Jw[e] = (j >= i) ? Ln[(size_t)j * nr + i] : 0.0; }
+        __threadfence_block();
+        __syncthreads();
         for (int e = tid; e < n * n; e += MG_NT) {
             int i = e / n, j = e - i * n, k = i < j ? i : j;
             double a = 0;
-            for (int r = 0; r <= k; r++) a += Ln[(size_t)i * nr + r] * Ln[(size_t)j * nr + r];
+            for (int r = 0; r <= k; r++) a += Jw[(size_t)r * n + i] * Jw[(size_t)r * n + j];
             outA[o2 + e] = a;
-            outJ[o2 + e] = (j >= i) ? Ln[(size_t)j * nr + i] : 0.0;
         }
         for (int r = tid; r < n; r += MG_NT) {
             double a = 0;
