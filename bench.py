@@ -403,7 +403,9 @@ def main():
         traffic = None
         traffic_source = None
         traffic_all = None
-        if world == 1 and not a.no_live_traffic and not os.environ.get("SWF_BENCH_SHARE_GPU"):
+        # (not when this process is itself running under a profiler: a nested rocprofv3 is asking for trouble)
+        profiled = any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) or k == "HSA_TOOLS_LIB" for k in os.environ)
+        if world == 1 and not a.no_live_traffic and not profiled and not os.environ.get("SWF_BENCH_SHARE_GPU"):
             lt = live_pmc_traffic(knames.get(dom, "k_" + dom), B)
             if lt is not None:
                 traffic, traffic_all = lt
