@@ -82,6 +82,7 @@ struct Pair {
     int fsb0, fsb1;              // the window's frame-sum blocks (diagonal pairs of observing poses)
     int n, m;                    // the window's n_red and 6 * nF, and its S / P slabs: the record is self-contained,
     long long S_base, P_base;    // no load of the pair's data depends on a second record
+    long long q_base;            // the window's landmark rhs partials in DevBatch::lmq (GEMM_SPLIT vectors of m doubles)
 };
 
 struct DevBatch {
@@ -105,7 +106,7 @@ struct DevBatch {
     const int* p_win; const int* p_xpose; const int* p_xex; const int* p_xlm;
     const int* p_lpose; const int* p_llm; const int* p_fr; const int* p_lm;
     const double* p_uv;
-    double* p_r; double* p_Jp; double* p_Jl; double* p_yg; double* p_cost; double* p_aux;
+    double* p_r; double* p_Jp; double* p_Jl; double* p_cost; double* p_aux;
     // two-level per-frame sums: blocks of <= 256 observations of one window
     int n_fsb; const int* fsb_win; const int* fsb_obs0; const int* fsb_perm; const int* fsb_foff; const int* fsb_foff0; const int* fsb_out0;
     double* fs_part;
@@ -115,8 +116,10 @@ struct DevBatch {
     const int* lm_win; const int* lm_obs0; const int* lm_loc; const int* lm_col;
     double* lm_Einv; double* lm_g;             // SoA stride n_lm: 6 / 3
     double* P;                                 // landmark Schur product, GEMM_SPLIT partials per window
+    double* lmq;                               // landmark part of the reduced rhs, sum_l Y_l g_l per pose row: GEMM_SPLIT partial vectors of 6 nF per window (at 6 fr_base GEMM_SPLIT)
     const int* lmb_rec; int n_lmb;             // landmark back-substitution blocks: {first observation, observations (<= 256), first landmark, landmarks}, whole landmarks of one window
     const int* sch_c0; const int* sch_rec;     // k_lm_schur chunk table: chunks of block (window, split); 8-int record per (chunk, group)
+    const int* sch_km;                         // k_lm_schur tile masks: word (chunk, launch, consumer wave) = 4 bits per tile slot of the wave, bit g = column group g is needed
     const unsigned long long* lm_fmask;        // frames (slots < 64) each landmark is observed in
     // frames
     int n_fr;

@@ -202,7 +202,7 @@ struct swf_batch {
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
-    int ls_qpb = 1, ls_tpw = 2; bool ls_folded = false, s_direct = false;     // k_lm_schur launch shape, fixed at creation (the pair lists depend on it)
+    int ls_qpb = 1, ls_var = 0, ls_kms = 8; bool ls_folded = false, s_direct = false;     // k_lm_schur launch shape, fixed at creation (the pair lists depend on it)
     int timing = 0;                       // bitmask of SWF_K_* brackets
     swf_timing last{};
     std::vector<hipEvent_t> ev;           // event pool (pairs)
@@ -311,11 +311,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     std::vector<int> ord;
     for (int i = 0; i < w->n_proj; i++) if (!lm_generic[w->proj_idx[i * 3 + 2]]) ord.push_back(i);
     const int n_fast = (int)ord.size();
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
-        int la = w->proj_idx[a * 3 + 2], lb = w->proj_idx[b * 3 + 2];
-        if (la != lb) return la < lb;
-        return w->proj_idx[a * 3] < w->proj_idx[b * 3];
-    });
+    // (sorted below, once the landmark records have their order)
     // frames: variable, non-eliminated poses that carry observations, in pose order
     std::vector<int> frame_of(nP, -1);
     {
@@ -329,6 +325,27 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         }
         R.nF = nf; R.fr_base = B.n_fr;
     }
+    // Landmark records — and with them the observations — are laid out in the order k_lm_schur packs them into wave tasks: by the
+    // footprint of the track in the 16-row tiles of the reduced camera matrix (last tile, first tile), ties in the caller's order.
+    // A wave task's four landmarks then read four adjacent runs of every Jacobian array.  (Internal order only: the elimination
+    // order is that of the blocks, and hw.p_orig maps the observations back to the caller's factors.)
+    std::vector<int> lm_rank(nL), lm_perm(nL);
+    {
+        std::vector<unsigned> trs(nL, 0u);
+        for (int i : ord) {
+            int f = frame_of[w->proj_idx[i * 3]];
+            if (f >= 0 && f < 64) { trs[w->proj_idx[i * 3 + 2]] |= 1u << ((6 * f) / 16); trs[w->proj_idx[i * 3 + 2]] |= 1u << ((6 * f + 5) / 16); }
+        }
+        auto key = [&](int l) { unsigned t = trs[l]; return t ? (31 - __builtin_clz(t)) * 64 + __builtin_ctz(t) : (lm_generic[l] ? 1 << 20 : 0); };
+        for (int l = 0; l < nL; l++) lm_perm[l] = l;
+        std::stable_sort(lm_perm.begin(), lm_perm.end(), [&](int a, int b) { return key(a) < key(b); });
+        for (int r = 0; r < nL; r++) lm_rank[lm_perm[r]] = r;
+    }
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+        int la = lm_rank[w->proj_idx[a * 3 + 2]], lb = lm_rank[w->proj_idx[b * 3 + 2]];
+        if (la != lb) return la < lb;
+        return w->proj_idx[a * 3] < w->proj_idx[b * 3];
+    });
     R.proj0 = (int)B.p_win.size();
     R.lm0 = (int)B.lm_win.size();
     hw.p_orig = ord;
@@ -344,16 +361,17 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
             B.p_win.push_back(wi);
             B.p_xpose.push_back(gx(bidP(p))); B.p_xex.push_back(gx(bidP(ex))); B.p_xlm.push_back(gx(bidL(l)));
             B.p_lpose.push_back(gloc(bidP(p))); B.p_llm.push_back(gloc(bidL(l)));
-            B.p_fr.push_back(frame_of[p]); B.p_lm.push_back(R.lm0 + l);
+            B.p_fr.push_back(frame_of[p]); B.p_lm.push_back(R.lm0 + lm_rank[l]);
             B.p_uv.push_back(w->proj_uv[i * 2]); B.p_uv.push_back(w->proj_uv[i * 2 + 1]);
             if (frame_of[p] >= 0) fobs[frame_of[p]].push_back(gi);
-            lm_first[l + 1]++;
+            lm_first[lm_rank[l] + 1]++;
         }
         for (int l = 0; l < nL; l++) lm_first[l + 1] += lm_first[l];
-        for (int l = 0; l < nL; l++) {
+        for (int rk = 0; rk < nL; rk++) {
+            const int l = lm_perm[rk];
             int b = bidL(l);
             B.lm_win.push_back(wi);
-            B.lm_obs0.push_back(R.proj0 + lm_first[l]);
+            B.lm_obs0.push_back(R.proj0 + lm_first[rk]);
             B.lm_loc.push_back(lm_generic[l] ? -1 : gloc(b));        // a generic-path landmark has no observations here: an inactive record
             B.lm_col.push_back(3 * l);
             B.lm_fmask.push_back(0ULL);
@@ -395,7 +413,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     {
         int m = 6 * R.nF, nt = (m + 15) / 16;
         B.max_tiles = std::max(B.max_tiles, nt * (nt + 1) / 2);
-        if (nt * (nt + 1) / 2 > 120) return fail(SWF_E_UNSUPPORTED, "more than 40 observing frames in one window");
+        if (R.nF > LS_MAXF) return fail(SWF_E_UNSUPPORTED, "more than 64 observing frames in one window");
     }
 
     // ---- generic factors
@@ -822,40 +840,101 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         PUT(lmb_rec, lr);
     }
     {
-        // k_lm_schur chunk table: every (window, split) block walks its landmark range in chunks of LS_LPC 16-lane
-        // groups and at most LS_CAP observation cells (one LDS buffer).  A landmark takes 1 / 2 / 4 adjacent, aligned
-        // groups (<= 16 / 32 / 64 observations).  Record of (chunk, group): L (-1 = empty), loc, first / end observation
-        // of this group, frame mask lo / hi, table row | G << 8 | first << 16, first LDS cell.
-        std::vector<int> c0, rec;
-        auto new_chunk = [&]() { size_t at = rec.size(); rec.resize(at + (size_t)LS_LPC * 8, 0); for (int g = 0; g < LS_LPC; g++) rec[at + g * 8] = -1; return at; };
+        // k_lm_schur's launch shape: the row class of the panel by the batch's largest window (<= 10 / 21 / 42 / 64 observing frames) and
+        // the landmark parts per block — as many as still leave >= 2 blocks per CU.  SWF_LS_VARIANT / SWF_LS_QPB: test / debugging aids.
+        // A block that covers all parts folds them in registers (ls_folded) and, in that case, writes -P straight into S (s_direct); the
+        // off-diagonal frame pairs without any other contribution then leave the assembly's list.
+        const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;
+        const int force_qpb = getenv("SWF_LS_QPB") ? atoi(getenv("SWF_LS_QPB")) : 0;
+        int qpb = 1;
+        while (qpb < GEMM_SPLIT && (long long)n * GEMM_SPLIT / (2 * qpb) >= 2LL * b->n_cu) qpb *= 2;
+        // from half a chip of windows on, one block per window: the folded product and the direct-to-S write-out are worth more than the
+        // second round of blocks
+        if (2LL * n >= b->n_cu) qpb = GEMM_SPLIT;
+        if (force_qpb >= 1 && force_qpb <= GEMM_SPLIT && (force_qpb & (force_qpb - 1)) == 0) qpb = force_qpb;
+        b->ls_qpb = qpb;
+        b->ls_var = (b->max_tiles <= 10 && force < 1) ? 0 : (b->max_tiles <= 36 && force < 2) ? 1 : (b->max_tiles <= 136 && force < 3) ? 2 : 3;
+        b->ls_folded = qpb == GEMM_SPLIT && b->ls_var <= 1;          // must mirror CAN_FOLD in k_lm_schur
+        b->s_direct = b->ls_folded && !getenv("SWF_NO_S_DIRECT");
+    }
+    {
+        // k_lm_schur task table.  A wave task = the four 16-lane groups of one producer wave: a landmark takes 1 / 2 / 4 adjacent, aligned
+        // groups (<= 16 / 32 / 64 observations) and three of the task's twelve panel columns.  Record of (task, group): L (-1 = empty), loc,
+        // first / end observation of this group, first column within the task (0, 3, 6, 9), 0, G << 8 | first << 16, 0.  The window's landmarks
+        // enter in the order of their tile footprint (last, first 16-row tile of the reduced camera matrix they touch), so the landmarks of a
+        // task mostly share theirs; bit g of the tile mask of (chunk, tile) — some landmark of the chunk's wave task g is seen from the tile's
+        // row frames and from its column frames — is what the consumer waves walk (a chunk = TW tasks, by size class; the packing into tasks
+        // and the parts, which end on even task numbers, are the same in every class: so is every sum).  Tile list of a window: the nt
+        // diagonal tiles, then (tr > tc) row by row.
+        const int TW = b->ls_var <= 1 ? 2 : 1;
+        const int NCW = b->ls_var <= 1 ? 8 : 12, TPW = b->ls_var == 0 ? 2 : b->ls_var == 1 ? 5 : 6;
+        const int n_launch = std::max(1, (b->max_tiles + NCW * TPW - 1) / (NCW * TPW));
+        b->ls_kms = n_launch * NCW;                                  // mask words per chunk
+        std::vector<int> c0, rec, km;
+        std::vector<std::vector<unsigned>> task_tiles;               // per task of the current window: tile-list entries it touches
         for (auto& W : B.win) {
-            // the window's chunks first (greedy: every chunk but the last is full), then consecutive chunks are dealt to the
-            // GEMM_SPLIT parts in equal shares — a part never ends in a nearly empty chunk; trailing parts may be empty
-            int first_chunk = (int)(rec.size() / (LS_LPC * 8));
-            size_t at = 0; int g = LS_LPC, cells = 0;              // force a new chunk at the first landmark
+            const int m = 6 * W.nF, nt = (m + 15) / 16, ntl = nt * (nt + 1) / 2;
+            auto tile_rows = [&](unsigned long long fm) {          // 16-row tiles the frames of fm touch
+                unsigned t = 0;
+                for (int f = 0; f < W.nF && f < 64; f++) if ((fm >> f) & 1ULL) { t |= 1u << ((6 * f) / 16); t |= 1u << ((6 * f + 5) / 16); }
+                return t;
+            };
+            std::vector<int> ord; std::vector<unsigned> trs((size_t)(W.lm1 - W.lm0), 0u);
             for (int l = W.lm0; l < W.lm1; l++) {
-                int o0 = B.lm_obs0[l], k = B.lm_obs0[l + 1] - o0;
+                if (B.lm_loc[l] < 0) continue;                     // constant landmark: nothing to eliminate
+                int k = B.lm_obs0[l + 1] - B.lm_obs0[l];
                 if (k > 64) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "landmark with more than 64 observations"); }
+                trs[(size_t)(l - W.lm0)] = tile_rows(B.lm_fmask[l]);
+                ord.push_back(l);
+            }
+            auto key = [&](int l) { unsigned t = trs[(size_t)(l - W.lm0)]; int lo = t ? __builtin_ctz(t) : 0, hi = t ? 31 - __builtin_clz(t) : 0; return hi * 64 + lo; };
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return key(x) < key(y); });
+            const int first_task = (int)(rec.size() / 32);
+            task_tiles.clear();
+            size_t at = 0; int gw = 4, lw = 4;                     // force a new task at the first landmark
+            auto new_task = [&]() { at = rec.size(); rec.resize(at + 32, 0); for (int g = 0; g < 4; g++) rec[at + g * 8] = -1; task_tiles.emplace_back((size_t)ntl, 0u); gw = 0; lw = 0; };
+            for (int l : ord) {
+                int o0 = B.lm_obs0[l], k = B.lm_obs0[l + 1] - o0;
                 int G = k <= 16 ? 1 : k <= 32 ? 2 : 4;
-                int ga = (g + G - 1) / G * G;
-                if (ga + G > LS_LPC || cells + k > LS_CAP) { at = new_chunk(); ga = 0; cells = 0; }
+                int ga = (gw + G - 1) / G * G;
+                if (ga + G > 4 || lw >= 4) { new_task(); ga = 0; }
                 for (int h = 0; h < G; h++) {
                     int* r = &rec[at + (size_t)(ga + h) * 8];
                     r[0] = l; r[1] = B.lm_loc[l]; r[2] = o0 + 16 * h; r[3] = std::min(o0 + 16 * h + 16, o0 + k);
-                    r[4] = (int)(unsigned)(B.lm_fmask[l] & 0xffffffffULL); r[5] = (int)(unsigned)(B.lm_fmask[l] >> 32);
-                    r[6] = ga | (G << 8) | ((h == 0 ? 1 : 0) << 16); r[7] = cells + 16 * h;
+                    r[4] = 3 * lw; r[5] = 0; r[6] = (G << 8) | ((h == 0 ? 1 : 0) << 16); r[7] = 0;
                 }
-                g = ga + G; cells += k;
+                // tile-list entries this landmark touches
+                unsigned t = trs[(size_t)(l - W.lm0)];
+                std::vector<unsigned>& tt = task_tiles.back();
+                for (int tr = 0; tr < nt; tr++) {
+                    if (!((t >> tr) & 1u)) continue;
+                    tt[(size_t)tr] = 1u;
+                    for (int tc = 0; tc < tr; tc++) if ((t >> tc) & 1u) tt[(size_t)(nt + tr * (tr - 1) / 2 + tc)] = 1u;
+                }
+                gw = ga + G; lw++;
             }
-            // part sp = chunks [sp nch / 16, (sp + 1) nch / 16): the parts differ by at most one chunk, so any grouping of consecutive parts
-            // into workgroups (qpb = 1 .. 16, by batch size) is balanced (dealing ceil(nch / 16) chunks to the leading parts left 16 + 3 chunks
-            // on the two workgroups of a cfg3 window at 256 windows)
-            int nch = (int)(rec.size() / (LS_LPC * 8)) - first_chunk;
-            for (int sp = 0; sp < GEMM_SPLIT; sp++) c0.push_back(first_chunk + (int)((long long)sp * nch / GEMM_SPLIT));
+            if (task_tiles.size() & 1) new_task();                 // an even number of tasks per window
+            const int ntask = (int)task_tiles.size();
+            // masks: chunk c of this window = tasks [c TW, (c + 1) TW)
+            for (int c = 0; c < ntask / TW; c++) {
+                size_t kw = km.size(); km.resize(kw + (size_t)b->ls_kms, 0);
+                for (int g = 0; g < TW; g++) {
+                    const std::vector<unsigned>& tt = task_tiles[(size_t)(c * TW + g)];
+                    for (int e = 0; e < ntl; e++) if (tt[(size_t)e]) {
+                        int lp = e / (NCW * TPW), r = e % (NCW * TPW), sl = r / NCW, cw = r % NCW;
+                        km[kw + (size_t)(lp * NCW + cw)] |= (1 << g) << (4 * sl);
+                    }
+                }
+            }
+            // part sp = task pairs [sp np / 16, (sp + 1) np / 16): the parts differ by at most one pair, so any grouping of consecutive parts
+            // into workgroups (qpb = 1 .. 16, by batch size) is balanced
+            const int np = ntask / 2;
+            for (int sp = 0; sp < GEMM_SPLIT; sp++) c0.push_back(first_task + 2 * (int)((long long)sp * np / GEMM_SPLIT));
         }
-        c0.push_back((int)(rec.size() / (LS_LPC * 8)));
-        rec.resize(rec.size() + (size_t)LS_LPC * 8 * 2, 0);         // pad: the pipeline never reads past the table, but keep slack
-        PUT(sch_c0, c0); PUT(sch_rec, rec);
+        c0.push_back((int)(rec.size() / 32));
+        rec.resize(rec.size() + (size_t)32 * 4 * LS_NB, 0);           // slack behind the table
+        km.resize(km.size() + (size_t)b->ls_kms * 2, 0);
+        PUT(sch_c0, c0); PUT(sch_rec, rec); PUT(sch_km, km);
     }
     D.n_fr = B.n_fr;
     B.fr_obs0.push_back((int)B.fr_obs.size());
@@ -903,28 +982,9 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
     {
         std::vector<int> pd, po, clc[4], cle;
-        {
-            // k_lm_schur's launch shape: size-specialised variants (<= 16 tiles / <= 10 frames, <= 40 tiles / <= 21 frames, <= 120 tiles /
-            // <= 40 frames) and the landmark parts per block — as many as still leave >= 2 blocks per CU.  SWF_LS_VARIANT / SWF_LS_QPB:
-            // test / debugging aids.  A block that covers all parts folds them in registers (ls_folded) and, in that case, writes -P
-            // straight into S (s_direct); the off-diagonal frame pairs without any other contribution then leave the assembly's list.
-            const int force = getenv("SWF_LS_VARIANT") ? atoi(getenv("SWF_LS_VARIANT")) : 0;
-            const int force_qpb = getenv("SWF_LS_QPB") ? atoi(getenv("SWF_LS_QPB")) : 0;
-            int qpb = 1;
-            while (qpb < GEMM_SPLIT && (long long)n * GEMM_SPLIT / (2 * qpb) >= 2LL * b->n_cu) qpb *= 2;
-            // from half a chip of windows on, one block per window: the folded product and the direct-to-S write-out are worth more than the
-            // second round of blocks (measured, 8-iteration cfg3 solves: 256 windows 6.80 -> 5.51 ms, 128 windows 3.92 -> 3.70 ms; 64 windows
-            // would lose, 2.58 -> 3.14 ms)
-            if (2LL * n >= b->n_cu) qpb = GEMM_SPLIT;
-            if (force_qpb >= 1 && force_qpb <= GEMM_SPLIT && (force_qpb & (force_qpb - 1)) == 0) qpb = force_qpb;
-            b->ls_qpb = qpb;
-            b->ls_tpw = (b->max_tiles <= 16 && force < 1) ? 2 : (b->max_tiles <= 40 && force < 2) ? 5 : 10;
-            b->ls_folded = qpb == GEMM_SPLIT && b->ls_tpw <= 5;          // must mirror CAN_FOLD in k_lm_schur (tpw 10 = the 1024-thread variant: no fold)
-            b->s_direct = b->ls_folded && !getenv("SWF_NO_S_DIRECT");
-        }
         for (size_t i = 0; i < B.pair.size(); i++) {
             Pair& Pq = B.pair[i]; const WinRec& Rw = B.win[Pq.win];      // self-contained records (see Pair)
-            Pq.fsb0 = Rw.fsb0; Pq.fsb1 = Rw.fsb1; Pq.n = Rw.n_red; Pq.m = 6 * Rw.nF; Pq.S_base = Rw.S_base; Pq.P_base = Rw.P_base;
+            Pq.fsb0 = Rw.fsb0; Pq.fsb1 = Rw.fsb1; Pq.n = Rw.n_red; Pq.m = 6 * Rw.nF; Pq.S_base = Rw.S_base; Pq.P_base = Rw.P_base; Pq.q_base = (long long)6 * Rw.fr_base * GEMM_SPLIT;
             if (b->s_direct && !Pq.is_diag && Pq.fa >= 0 && Pq.fb >= 0 && Pq.c0 == Pq.c1) continue;       // -P is already in S, nothing to add
             (Pq.is_diag ? pd : po).push_back((int)i);
         }
@@ -971,10 +1031,11 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     if (b->max_red > 240 && b->max_red <= 512 && n * 4 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);      // >= 4 workgroups per window
     rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
     size_t np = (size_t)D.n_proj;
-    rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl); rc |= P.zeros(6 * np, &D.p_yg);
+    rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl);
     rc |= P.zeros(np, &D.p_cost); rc |= P.zeros(np, &D.p_aux);
     rc |= P.zeros(6 * (size_t)D.n_lm, &D.lm_Einv); rc |= P.zeros(3 * (size_t)D.n_lm, &D.lm_g);
     rc |= P.zeros(B.P_tot * GEMM_SPLIT, &D.P);
+    rc |= P.zeros((size_t)std::max(1, 6 * B.n_fr) * GEMM_SPLIT, &D.lmq);
     rc |= P.zeros((size_t)B.r_tot, &D.g_r); rc |= P.zeros((size_t)B.j_tot, &D.g_J);
     rc |= P.zeros((size_t)D.n_gf, &D.g_cost); rc |= P.zeros((size_t)D.n_gf, &D.g_aux);
     {
@@ -1110,7 +1171,20 @@ namespace {
 struct Launcher {
     swf_batch* b; DevOpt O; hipStream_t st;
     bool lm_folded = false;     // k_lm_schur of the current linearisation wrote ONE folded product (else GEMM_SPLIT partials)
-    bool lm_second = false; int lm_qpb = 1;      // a second tile range of k_lm_schur<12, 5> is pending (launched with the clique kernels)
+    int lm_next = 0, lm_qpb = 1;                 // first tile of the ranges of k_lm_schur still to launch (with the clique kernels)
+    int ls_tiles_per_launch() const { return b->ls_var == 0 ? 16 : b->ls_var == 1 ? 40 : 72; }
+    // one launch of the landmark Schur kernel over the tile-list entries [tile_base, tile_base + tiles per launch), by row class
+    void lm_launch(int tile_base, hipStream_t on) {
+        DevBatch& D = b->D;
+        dim3 grid(D.n_win, GEMM_SPLIT / b->ls_qpb);
+        const int qpb = b->ls_qpb, sd = b->s_direct ? 1 : 0, lp = tile_base / ls_tiles_per_launch(), kms = b->ls_kms;
+        switch (b->ls_var) {
+        case 0: hipLaunchKernelGGL((k_lm_schur<8, 2, 2, 80, true>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd); break;
+        case 1: hipLaunchKernelGGL((k_lm_schur<8, 5, 2, 144, true>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd); break;
+        case 2: hipLaunchKernelGGL((k_lm_schur<12, 6, 1, 272, true>), grid, dim3(LS_NT(12, 1)), 0, on, D, O, qpb, lp, kms, 0); break;
+        default: hipLaunchKernelGGL((k_lm_schur<12, 6, 1, 400, true>), grid, dim3(LS_NT(12, 1)), 0, on, D, O, qpb, lp, kms, 0); break;
+        }
+    }
     // optional event pair around one launch
     struct Bracket {
         Launcher& L; int slot; hipStream_t bst;
@@ -1160,22 +1234,14 @@ struct Launcher {
         DevBatch& D = b->D;
         if (D.n_lm) {
             Bracket t(*this, write_S ? SWF_K_LM_SCHUR : SWF_K_LM_ELIM);
-            // size-specialised variants: <= 16 tiles (<= 10 frames), <= 40 tiles (<= 21 frames), <= 120 tiles (<= 40 frames);
-            const int qpb = b->ls_qpb, tpw = b->ls_tpw, sd = b->s_direct ? 1 : 0;       // fixed at creation (swf_batch_create)
-            dim3 grid(D.n_win, GEMM_SPLIT / qpb); lm_qpb = qpb;
-            lm_folded = b->ls_folded;
+            lm_qpb = b->ls_qpb; lm_folded = b->ls_folded;
             if (!write_S) {
-                // cost / gradient pass (the solve's final linearisation): the elimination alone — producer waves only, no LDS cells
-                if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2, false>), grid, dim3(LS_NPW * 64), 0, st, D, O, qpb, 0, 0);
-                else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5, false>), grid, dim3(LS_NPW * 64), 0, st, D, O, qpb, 0, 0);
-                else hipLaunchKernelGGL((k_lm_schur<12, 5, false>), grid, dim3(LS_NPW * 64), 0, st, D, O, qpb, 0, 0);
-            }
-            else if (tpw == 2) hipLaunchKernelGGL((k_lm_schur<8, 2, true>), grid, dim3(LS_NT(8)), 0, st, D, O, qpb, 0, sd);
-            else if (tpw == 5) hipLaunchKernelGGL((k_lm_schur<8, 5, true>), grid, dim3(LS_NT(8)), 0, st, D, O, qpb, 0, sd);
-            else {
-                // up to 120 tiles: two launches of the 12-consumer-wave, 5-slot variant (tiles 0..59, 60..119)
-                hipLaunchKernelGGL((k_lm_schur<12, 5, true>), grid, dim3(LS_NT(12)), 0, st, D, O, qpb, 0, 0);
-                lm_second = b->max_tiles > 60;       // tiles 60..119: launched below, on the auxiliary stream when there is one
+                // cost / gradient pass (the solve's final linearisation): the elimination alone — producer waves only, no panel
+                dim3 grid(D.n_win, GEMM_SPLIT / lm_qpb);
+                hipLaunchKernelGGL((k_lm_schur<8, 2, 2, 80, false>), grid, dim3(256), 0, st, D, O, lm_qpb, 0, 0, 0);
+            } else {
+                lm_launch(0, st);
+                lm_next = ls_tiles_per_launch();        // further tile ranges: launched below, on the auxiliary stream when there is one
             }
         }
         {
@@ -1187,13 +1253,10 @@ struct Launcher {
             if (D.n_clc[0]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(0)); hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, cstream(0), D, O); }
             if (D.n_clc[2]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(2)); hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, cstream(2), D, O); }
             if (D.n_clc[3]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(3)); hipLaunchKernelGGL(k_clique_big, dim3(D.n_clc[3]), dim3(256), 0, cstream(3), D, O); }
-            if (lm_second) {
-                // the second tile range writes nothing but its tiles of P (k_lm_schur: outs), so on the latency path it runs behind the
+            if (write_S && D.n_lm) {
+                // further tile ranges write nothing but their tiles of P (k_lm_schur: outs), so on the latency path they run behind the
                 // IMU / clique branch, next to the first range
-                int qpb2 = lm_qpb; dim3 grid2(D.n_win, GEMM_SPLIT / qpb2);
-                Bracket t(*this, SWF_K_LM_SCHUR, sa);
-                hipLaunchKernelGGL((k_lm_schur<12, 5, true>), grid2, dim3(LS_NT(12)), 0, sa, D, O, qpb2, 60, 0);
-                lm_second = false;
+                for (; lm_next < b->max_tiles; lm_next += ls_tiles_per_launch()) { Bracket t(*this, SWF_K_LM_SCHUR, sa); lm_launch(lm_next, sa); }
             }
             if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);
         }
@@ -1202,7 +1265,7 @@ struct Launcher {
         if (D.n_pd) {
             Bracket t(*this, SWF_K_ASSEMBLE);
             Segs S{}; S.e[0] = nb((size_t)D.n_pd * 64, 256); S.e[1] = S.e[0] + (write_S ? nb((size_t)D.n_po * 16, 256) : 0);
-            hipLaunchKernelGGL(k_assemble_all, dim3(S.e[1]), dim3(256), 0, st, D, O, write_S, S, b->s_direct ? 0 : lm_folded ? 1 : GEMM_SPLIT);
+            hipLaunchKernelGGL(k_assemble_all, dim3(S.e[1]), dim3(256), 0, st, D, O, write_S, S, b->s_direct ? 0 : lm_folded ? 1 : GEMM_SPLIT, lm_folded ? 1 : GEMM_SPLIT);
         }
     }
     void reduced() {

@@ -781,350 +781,7 @@ __device__ __forceinline__ void d_jtimes_prior(const DevBatch& B, const DevOpt& 
     if (tid == 0) B.g_aux[f] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
 }
 
-// =========================================================================================
-// Landmark Schur elimination (the bulk of group 0), one fused kernel per linearisation:
-//   H_ll = sum Jl^T Jl + mu*clamp(diag),  Einv = H_ll^-1,  W_o = Jp^T Jl,  Y_o = W_o Einv,
-//   P = sum_l Y_l W_l^T   (the landmark part of the reduced camera matrix, fp64 matrix cores).
-// One workgroup per (window, landmark split).  It walks its landmarks in chunks of NT/16:
-//   phase A  16 lanes per landmark (one observation per lane and round, 16-lane butterflies for
-//            H_ll / g_l, division-free 3x3 inverse) build the [Y(3x6) | W(3x6)] cell of every
-//            observation IN LDS, plus a (landmark, frame) -> cell table; g_l, Einv, diag and Y g_l
-//            go to HBM (coalesced SoA) for the assembly and the back-substitution;
-//   phase B  every wave owns a fixed set of 16x16 tiles of the lower triangle of P and issues one
-//            v_mfma_f64_16x16x4_f64 per (tile, landmark): the 4 k-slots are the landmark's three
-//            coordinates (+ one zero).  Tiles whose frame range the landmark does not observe are
-//            skipped (wave-uniform test on the landmark's frame bit-mask).
-// The cells never touch HBM: per observation the kernel reads 160 B (Jp, Jl, r) and writes 48 B.
-// In-tree analogue of this arithmetic: MarginalizationInfo::marginalize,
-// R/factor/marginalization_factor.cpp:260-377; in Ceres it is SchurEliminator::Eliminate.
-// f64 MFMA layouts: A[i][k]: lane = i + 16k; B[k][j]: lane = j + 16k; D: lane l, reg q -> row (l>>4)+4q, col l&15.
-// =========================================================================================
-typedef double double4_t __attribute__((ext_vector_type(4)));
-#define GEMM_SPLIT 16                         // fixed landmark split: partial products P_0..P_15, summed in order (by k_lm_schur
-                                              // itself when one block covers them all, else by k_assemble)
-#ifdef SWF_PROFILE_GEMM
-__device__ unsigned long long g_gemm_stamps[16];
-#define GSTAMP_ACC(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_gemm_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
-#define GNOW() __builtin_amdgcn_s_memtime()
-#else
-#define GSTAMP_ACC(i, t0)
-#define GNOW() 0ULL
-#endif
-__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
-    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l);
-    return ((unsigned long long)hi << 32) | lo;
-}
-#define LS_CS 37                              // LDS cell stride in doubles (36 + 1: conflict-free 16-lane cell writes)
-#define LS_NPW 4                              // producer waves (one per SIMD); NCW consumer waves follow
-#define LS_NT(NCW) ((LS_NPW + (NCW)) * 64)
-#define LS_LPC 16                             // landmarks per chunk = 16-lane groups of the producer waves
-#define LS_CAP 192                            // observation cells per chunk and buffer (host chunk table honours both)
-#define LS_MAXF 40
-// NCW consumer waves with TPW tile slots each, tiles tile_base + [0, NCW * TPW): <8,2> (<= 16 tiles), <8,5> (<= 40),
-// <12,5> twice (<= 120: tile_base 0 and 60; a single 10-slot variant spills under the 128-VGPR cap of 1024 threads —
-// both launches redo the cheap producer work instead)
-// GEMM = false: the elimination alone (g_l, diag, Einv for a cost / gradient pass: the solve's last linearisation, whose system is never
-// solved): launched with the four producer waves only and no cell storage, under its own kernel name.
-template <int NCW, int TPW, bool GEMM>
-__global__ void __launch_bounds__(LS_NT(NCW)) k_lm_schur(DevBatch B, DevOpt O, int qpb, int tile_base, int s_direct) {
-    constexpr int NPW = LS_NPW;
-    __shared__ double cells[2][GEMM ? (LS_CAP + 1) * LS_CS : 1];      // + one all-zero cell per buffer
-    __shared__ int tbl[2][GEMM ? LS_LPC : 1][LS_MAXF + 1];            // cell offset of (landmark, frame); unobserved -> the zero cell
-    __shared__ unsigned long long Ms[2][LS_LPC];           // frame mask of the chunk's landmarks (0 = none / constant landmark)
-    __shared__ int freds[LS_MAXF];                         // first reduced row of every frame's pose (s_direct write-out)
-    constexpr int ZOFF = LS_CAP * LS_CS;
-    // a block covers qpb consecutive landmark parts of its window (qpb = 1, 2, 4, 8 or 16; a single window spreads over 16
-    // workgroups, large batches use 16 so the producer / consumer pipeline fills once per block).  Every part still gets
-    // its own partial product, so the result does not depend on qpb.
-    int w = blockIdx.x, sp0 = blockIdx.y * qpb;
-    const bool outs = tile_base == 0;                  // the launch of the second tile range only adds its tiles of P: it may run next to the first
-    WinState& s = B.ws[w];
-    if (!s.need_lin) return;
-    const WinRec& W = B.win[w];
-    int nF = W.nF, m = 6 * nF, nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2;
-    int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool gemm = GEMM && m > 0;
-    int blk = w * GEMM_SPLIT + sp0;
-    int c0 = B.sch_c0[blk], c1 = B.sch_c0[blk + qpb];
-    if (wv >= NPW) {
-        // =========================== consumer waves: P += Y W^T on the matrix cores ===========================
-        if (!gemm) return;
-        // (measured: 277 -> 262 us per launch with this s_setprio in place — whatever its value, and equally when the producers carry it instead —
-        // so the gain comes from the instruction's effect on the wave scheduler's interleaving, not from the priority itself)
-        __builtin_amdgcn_s_setprio(1);
-        int cw = wv - NPW;
-        // tiles of this wave: tile index and frame masks (wave-uniform), per-lane operand addressing:
-        // table column of the lane's frame (column nF = the zero cell for lanes outside the matrix and the
-        // fourth k-slot) and offset inside the cell
-        int pk[TPW];                                       // pk = fA | fB << 8 | subA << 16 | subB << 24 (one VGPR per slot)
-        auto tile_rc = [&](int t, int& tr, int& tc) {      // (row, column) of lower-triangle tile t; recomputed at write-out: a register pair per slot spilled
-            tr = 0;
-            while ((tr + 1) * (tr + 2) / 2 <= t) tr++;
-            tc = t - tr * (tr + 1) / 2;
-        };
-        unsigned long long mA[TPW], mB[TPW];
-        constexpr bool CAN_FOLD = TPW <= 5 && NCW == 8;     // 768-thread blocks have the registers for the folded product
-        double4_t acc[TPW], tot[CAN_FOLD ? TPW : 1];
-#pragma unroll
-        for (int sl = 0; sl < TPW; sl++) {
-            if (CAN_FOLD) tot[sl] = double4_t{ 0, 0, 0, 0 };
-            int t = tile_base + cw + sl * NCW;
-            int tr = 0, tc = 0;
-            if (t < ntiles) tile_rc(t, tr, tc);
-            int ra = tr * 16 + li, cb = tc * 16 + li;
-            bool okA = ra < m && lk < 3 && t < ntiles, okB = cb < m && lk < 3 && t < ntiles;
-            int fA_ = okA ? ra / 6 : nF, subA_ = okA ? lk * 6 + ra % 6 : 0;
-            int fB_ = okB ? cb / 6 : nF, subB_ = okB ? 18 + lk * 6 + cb % 6 : 0;
-            pk[sl] = fA_ | (fB_ << 8) | (subA_ << 16) | (subB_ << 24);
-            int f0 = (tr * 16) / 6, f1 = (tr * 16 + 15) / 6; if (f1 > 63) f1 = 63;
-            int g0 = (tc * 16) / 6, g1 = (tc * 16 + 15) / 6; if (g1 > 63) g1 = 63;
-            mA[sl] = (t < ntiles && f0 < 64) ? ((~0ULL >> (63 - f1)) & (~0ULL << f0)) : 0ULL;
-            mB[sl] = (t < ntiles && g0 < 64) ? ((~0ULL >> (63 - g1)) & (~0ULL << g0)) : 0ULL;
-            acc[sl] = double4_t{ 0, 0, 0, 0 };
-        }
-        unsigned long long tg = GNOW(); (void)tg;
-        if (s_direct) { int e = tid - NPW * 64; if (e < nF) freds[e] = B.fr_red[W.fr_base + e]; }
-        __syncthreads();                                    // chunk c0 produced
-        if (cw == 0) GSTAMP_ACC(8, tg);
-        for (int sq = 0; sq < qpb; sq++) {
-        int cq1 = B.sch_c0[blk + sq + 1];
-        for (int c = (sq == 0 ? c0 : B.sch_c0[blk + sq]); c < cq1; c++) {
-            int buf = (c - c0) & 1;
-            tg = GNOW();
-            // lane j tests row j's frame mask against each tile slot; the ballot is the slot's hit list over the
-            // chunk's rows (wave-uniform).  Each slot then walks only its hits, in row order; the table reads of the
-            // next hit are issued before the MFMA of the current one.  (Measured: the loop is instruction-issue
-            // bound at ~25 instructions per hit; deeper software pipelines and a lockstep multi-slot form were slower.)
-            unsigned long long fm_r = Ms[buf][lane & (LS_LPC - 1)];
-            const double* cb = cells[buf];
-            const int* tb = &tbl[buf][0][0];
-#pragma unroll
-            for (int sl = 0; sl < TPW; sl++) {
-                unsigned hits = (unsigned)__ballot((fm_r & mA[sl]) && (fm_r & mB[sl])) & ((1u << LS_LPC) - 1u);
-                if (!hits) continue;
-                int l = __builtin_ctz(hits); hits &= hits - 1;
-                const int fA = pk[sl] & 255, fB = (pk[sl] >> 8) & 255, subA = (pk[sl] >> 16) & 255, subB = (pk[sl] >> 24) & 255;
-                int ia = tb[l * (LS_MAXF + 1) + fA], ib = tb[l * (LS_MAXF + 1) + fB];
-                double4_t c_ = acc[sl];
-                while (true) {
-                    double av = cb[ia + subA], bv = cb[ib + subB];
-                    bool more = hits != 0;
-                    if (more) {
-                        l = __builtin_ctz(hits); hits &= hits - 1;
-                        ia = tb[l * (LS_MAXF + 1) + fA]; ib = tb[l * (LS_MAXF + 1) + fB];
-                    }
-                    c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c_, 0, 0, 0);
-                    if (!more) break;
-                }
-                acc[sl] = c_;
-            }
-            if (cw == 0) GSTAMP_ACC(9, tg);
-            tg = GNOW();
-            __syncthreads();                                // chunk c consumed, chunk c+1 produced
-            if (cw == 0) GSTAMP_ACC(10, tg);
-        }
-        // end of a part.  A block that covers all GEMM_SPLIT parts folds them in registers in exactly the order
-        // k_assemble adds partials, ((P0 + P1) + P2) + ... with every Pq summed from zero, and writes ONE product
-        // (slot 0; k_assemble is told to read one partial): same bits, 1/GEMM_SPLIT of the P traffic.  Otherwise
-        // each part's partial product is flushed to its own slot.
-        bool fold = CAN_FOLD && qpb == GEMM_SPLIT;
-        tg = GNOW();
-        if (fold) {
-#pragma unroll
-            for (int sl = 0; sl < TPW; sl++) { tot[CAN_FOLD ? sl : 0] = sq == 0 ? acc[sl] : tot[CAN_FOLD ? sl : 0] + acc[sl]; acc[sl] = double4_t{ 0, 0, 0, 0 }; }
-            if (sq + 1 < qpb) continue;
-        }
-        double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)(fold ? 0 : sp0 + sq) * m * m;
-        if (fold && s_direct) {
-            // large batches: the folded product goes straight to where it ends up, S_pp = -P in the reduced system's own order
-            // (k_assemble_all then adds the few other contributions on top and never touches a frame pair that has none — 171 of the
-            // 190 pose pairs of a cfg3 window).  -P + c == c - P bit for bit, so the result is that of the P route.
-            double* Sw = B.S + W.S_base; const int nr = W.n_red; const int* fred = freds;
-#pragma unroll
-            for (int sl = 0; sl < TPW; sl++) {
-                int t = tile_base + cw + sl * NCW;
-                if (t < ntiles) {
-                    int tr, tc; tile_rc(t, tr, tc);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        int r = tr * 16 + lk + 4 * q, c = tc * 16 + li;
-                        if (r < m && c < m && r >= c) {
-                            int fa = r / 6, fb = c / 6;
-                            int row = fred[fa] + (r - 6 * fa), col = fred[fb] + (c - 6 * fb);
-                            if (row < col) { int tt = row; row = col; col = tt; }
-                            Sw[(size_t)row * nr + col] = -tot[CAN_FOLD ? sl : 0][q];
-                        }
-                    }
-                }
-                acc[sl] = double4_t{ 0, 0, 0, 0 };
-            }
-            if (cw == 0) GSTAMP_ACC(11, tg);
-            continue;
-        }
-#pragma unroll
-        for (int sl = 0; sl < TPW; sl++) {
-            int t = tile_base + cw + sl * NCW;
-            if (t < ntiles) {
-                int tr, tc; tile_rc(t, tr, tc);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    int r = tr * 16 + lk + 4 * q, c = tc * 16 + li;
-                    if (r < m && c < m) P[(size_t)r * m + c] = fold ? tot[CAN_FOLD ? sl : 0][q] : acc[sl][q];
-                }
-            }
-            acc[sl] = double4_t{ 0, 0, 0, 0 };
-        }
-        }
-        return;
-    }
-    // =========================== producer waves: eliminate the landmarks, chunk by chunk ===========================
-    // One 16-lane group per landmark (tracks of 17..32 / 33..64 observations take 2 / 4 adjacent groups and
-    // merge their sums with one / two more butterfly steps).  The host-built record of (chunk, group) makes
-    // the addressing one level deep, and the loads run as a 3-stage software pipeline: records two chunks
-    // ahead, Jl / r / frame one chunk ahead, Jp at the start of the chunk (it lands during sums + inverse).
-    {
-    // The arithmetic below is written with explicit fma() under contract(off): the kernel is instantiated per TPW,
-    // and a window must get bit-identical cells whichever instantiation its batch selects.
-#pragma clang fp contract(off)
-    int grp = tid >> 4, sub = tid & 15;
-    int n = B.n_proj, nl = B.n_lm;
-    double mu = s.mu;
-#ifdef SWF_PROFILE_GEMM
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) for (int i = 0; i < 16; i++) g_gemm_stamps[i] = 0;
-#endif
-    unsigned long long tg = GNOW(), tall = tg; (void)tg; (void)tall;
-    if (gemm) for (int e = tid; e < 2 * LS_CS; e += NPW * 64) cells[e / LS_CS][ZOFF + e % LS_CS] = 0.0;
-    struct Rec { int L, loc, o0, o1; unsigned fm_lo, fm_hi; int info, cell0; };   // info = row | G << 8 | first << 16
-    auto load_rec = [&](int c) {
-        Rec r; r.L = -1; r.loc = -1; r.o0 = r.o1 = 0; r.fm_lo = r.fm_hi = 0; r.info = 0; r.cell0 = 0;
-        if (c < c1) {
-            const int4* q = (const int4*)(B.sch_rec + ((size_t)c * LS_LPC + grp) * 8);
-            int4 a = q[0], b = q[1];
-            r.L = a.x; r.loc = a.y; r.o0 = a.z; r.o1 = a.w; r.fm_lo = (unsigned)b.x; r.fm_hi = (unsigned)b.y; r.info = b.z; r.cell0 = b.w;
-        }
-        return r;
-    };
-    struct Pre { double jl[6], rr[2]; int f; };
-    auto load_pre = [&](const Rec& r) {
-        Pre p;
-#pragma unroll
-        for (int k = 0; k < 6; k++) p.jl[k] = 0.0;
-        p.rr[0] = p.rr[1] = 0.0; p.f = -1;
-        int o = r.o0 + sub;
-        if (r.L >= 0 && r.loc >= 0 && o < r.o1) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) p.jl[k] = B.p_Jl[k * n + o];
-            p.rr[0] = B.p_r[o]; p.rr[1] = B.p_r[n + o];
-            p.f = B.p_fr[o];
-        }
-        return p;
-    };
-    Rec rc = load_rec(c0);
-    Pre pc = load_pre(rc);
-    Rec rn = load_rec(c0 + 1);
-    for (int c = c0; c < c1; c++) {
-        int buf = (c - c0) & 1;
-        tg = GNOW();
-        int L = rc.L, loc = rc.loc, o = rc.o0 + sub;
-        bool act = L >= 0 && loc >= 0, has = act && o < rc.o1;
-        int G = (rc.info >> 8) & 255, row = rc.info & 255;
-        bool first = (rc.info >> 16) & 1;
-        double jp[12];
-        if (has) {
-#pragma unroll
-            for (int k = 0; k < 12; k++) jp[k] = B.p_Jp[k * n + o];
-        }
-        Pre pn = load_pre(rn);
-        Rec rnn = load_rec(c + 2);
-        const double* a = pc.jl;
-#define FMA2(x0, y0, x1, y1) __builtin_fma(x0, y0, (x1) * (y1))
-#define FMA3(x0, y0, x1, y1, x2, y2) __builtin_fma(x0, y0, __builtin_fma(x1, y1, (x2) * (y2)))
-        double h00 = FMA2(a[0], a[0], a[3], a[3]), h10 = FMA2(a[1], a[0], a[4], a[3]), h20 = FMA2(a[2], a[0], a[5], a[3]);
-        double h11 = FMA2(a[1], a[1], a[4], a[4]), h21 = FMA2(a[2], a[1], a[5], a[4]), h22 = FMA2(a[2], a[2], a[5], a[5]);
-        double g0 = FMA2(a[0], pc.rr[0], a[3], pc.rr[1]), g1 = FMA2(a[1], pc.rr[0], a[4], pc.rr[1]), g2 = FMA2(a[2], pc.rr[0], a[5], pc.rr[1]);
-        bool wide = __any(G >= 2);                          // some track of this wave spans several groups (rare)
-        auto red = [&](double v) {
-            v = grp16_sum(v);
-            if (wide) {
-                double v2 = v + __shfl_xor(v, 16, 64);
-                v = G >= 2 ? v2 : v;
-                double v4 = v + __shfl_xor(v, 32, 64);
-                v = G >= 4 ? v4 : v;
-            }
-            return v;
-        };
-        h00 = red(h00); h10 = red(h10); h20 = red(h20); h11 = red(h11); h21 = red(h21); h22 = red(h22);
-        g0 = red(g0); g1 = red(g1); g2 = red(g2);
-        if (wv == 0) GSTAMP_ACC(0, tg);
-        tg = GNOW();
-        if (gemm) {
-            if (first || !act) for (int f = sub; f <= nF; f += 16) tbl[buf][grp][f] = ZOFF;
-            if (sub == 0) Ms[buf][grp] = (act && first) ? (((unsigned long long)rc.fm_hi << 32) | rc.fm_lo) : 0ULL;
-        }
-        if (act) {
-            bool lead = first && sub == 0;
-            if (lead && outs) {
-                B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
-                B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
-                B.vc[loc] = g0 / clampd(h00, O.min_diag, O.max_diag); B.vc[loc + 1] = g1 / clampd(h11, O.min_diag, O.max_diag); B.vc[loc + 2] = g2 / clampd(h22, O.min_diag, O.max_diag);
-            }
-            {
-                const bool jfirst = s.iter == 0;
-                h00 = __builtin_fma(mu, damp_diag(O, h00, B.jsc + loc, jfirst), h00);
-                h11 = __builtin_fma(mu, damp_diag(O, h11, B.jsc + loc + 1, jfirst), h11);
-                h22 = __builtin_fma(mu, damp_diag(O, h22, B.jsc + loc + 2, jfirst), h22);
-            }
-            // Cholesky inverse of the 3x3 (ceres InvertPSDMatrix), division-free: the reciprocal pivots
-            // come from v_rsq_f64 + Newton steps (the IEEE fp64 sqrt/div expansions are instruction-bound)
-            double i00 = rsqrt_nr(h00);
-            double l10 = h10 * i00, l20 = h20 * i00;
-            double d11 = __builtin_fma(-l10, l10, h11);
-            double i11 = rsqrt_nr(d11);
-            double l21 = __builtin_fma(-l20, l10, h21) * i11;
-            double d22 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, h22));
-            double i22 = rsqrt_nr(d22);
-            bool bad = !(h00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0);
-            if (bad) { if (lead && outs) s.lin_fail = 1; i00 = i11 = i22 = 0.0; }
-            double i10 = -l10 * i00 * i11;
-            double i21 = -l21 * i11 * i22;
-            double i20 = -FMA2(l20, i00, l21, i10) * i22;
-            double e00 = FMA3(i00, i00, i10, i10, i20, i20), e10 = FMA2(i10, i11, i20, i21), e20 = i20 * i22;
-            double e11 = FMA2(i11, i11, i21, i21), e21 = i21 * i22, e22 = i22 * i22;
-            if (lead && outs) {
-                B.lm_Einv[0 * nl + L] = e00; B.lm_Einv[1 * nl + L] = e10; B.lm_Einv[2 * nl + L] = e20;
-                B.lm_Einv[3 * nl + L] = e11; B.lm_Einv[4 * nl + L] = e21; B.lm_Einv[5 * nl + L] = e22;
-                B.lm_g[0 * nl + L] = g0; B.lm_g[1 * nl + L] = g1; B.lm_g[2 * nl + L] = g2;
-            }
-            // per observation: W = Jp^T Jl, Y = W Einv as one [Y(3x6) | W(3x6)] LDS cell; Y g_l for the reduced rhs
-            if (has && pc.f >= 0) {
-                int ci = (rc.cell0 + sub) * LS_CS;
-                double* cell = cells[buf] + ci;
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    double w0 = FMA2(jp[i], a[0], jp[6 + i], a[3]), w1 = FMA2(jp[i], a[1], jp[6 + i], a[4]), w2 = FMA2(jp[i], a[2], jp[6 + i], a[5]);
-                    double y0 = FMA3(w0, e00, w1, e10, w2, e20), y1 = FMA3(w0, e10, w1, e11, w2, e21), y2 = FMA3(w0, e20, w1, e21, w2, e22);
-                    if (outs) B.p_yg[i * n + o] = FMA3(y0, g0, y1, g1, y2, g2);
-                    if (gemm) {
-                        cell[i] = y0; cell[6 + i] = y1; cell[12 + i] = y2;
-                        cell[18 + i] = w0; cell[24 + i] = w1; cell[30 + i] = w2;
-                    }
-                }
-                if (gemm) tbl[buf][row][pc.f] = ci;
-            }
-        }
-        if (wv == 0) GSTAMP_ACC(1, tg);
-        tg = GNOW();
-        if (gemm) __syncthreads();                          // chunk c produced (and chunk c-1 consumed)
-        if (wv == 0) GSTAMP_ACC(2, tg);
-        rc = rn; pc = pn; rn = rnn;
-    }
-    if (gemm) __syncthreads();                              // pairs with the consumers' last barrier
-    if (wv == 0) GSTAMP_ACC(6, tall);
-#undef FMA2
-#undef FMA3
-    }
-}
+#include "swf_lmschur.h"
 
 // =========================================================================================
 // Clique elimination: every group-0 block that is not a landmark (alternate speed-biases,
@@ -1457,11 +1114,12 @@ __global__ void __launch_bounds__(256) k_clique_big(DevBatch B, DevOpt O) {
 // instead of gathering them (one 64-byte line per 8-byte value, PMC-measured 8x amplification),
 // every block of 256 consecutive observations is read coalesced, staged in LDS, and reduced per
 // frame through a host-built frame-sorted permutation of the block.  Output per (block, frame):
-//   33 doubles = lower(Jp^T Jp)(21) | Jp^T r (6) | Y g_l (6);   k_assemble<true> adds the blocks in order.
+//   27 doubles = lower(Jp^T Jp)(21) | Jp^T r (6);   k_assemble<true> adds the blocks in order.  (The landmark part of the
+//   reduced right-hand side, sum Y g_l per frame, comes out of k_lm_schur's matrix-core pass: DevBatch::lmq.)
 // =========================================================================================
 #define FS_BLK 256
-#define FS_VAL 33
-#define FS_HALF 17                            // values staged per pass
+#define FS_VAL 27
+#define FS_HALF 14                            // values staged per pass
 __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
     __shared__ double V[FS_BLK][FS_HALF];
     int blk = blockIdx.x;
@@ -1475,7 +1133,7 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
     __shared__ int foff[168];
     int nF = W.nF;
     for (int e = tid; e <= nF; e += FS_BLK) foff[e] = B.fsb_foff[B.fsb_foff0[blk] + e];
-    // the 33 values are staged in two halves (17 + 16): V = 34.8 KB, four blocks per CU (the full 67.6 KB allowed two)
+    // the 27 values are staged in two halves (14 + 13): V = 28.7 KB, five blocks per CU
     double val[FS_VAL];
 #pragma unroll
     for (int k = 0; k < FS_VAL; k++) val[k] = 0.0;
@@ -1494,9 +1152,6 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
             for (int j = 0; j <= i; j++) val[k++] = a[i] * a[j] + b[i] * b[j];
 #pragma unroll
         for (int i = 0; i < 6; i++) val[21 + i] = a[i] * r0 + b[i] * r1;
-        bool lmv = B.lm_loc[B.p_lm[o]] >= 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) val[27 + i] = lmv ? B.p_yg[i * n + o] : 0.0;
     }
     double* out = B.fs_part + (size_t)B.fsb_out0[blk] * FS_VAL;
 #pragma unroll
@@ -1534,7 +1189,7 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
 // DIAG = true : one wavefront per diagonal pair (needs wave reductions over the frame's observations)
 // DIAG = false: 16 lanes per off-diagonal pair (four pairs per wavefront; no cross-lane traffic)
 template <bool DIAG>
-__device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, int write_S, int bid, int n_part) {
+__device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, int write_S, int bid, int n_part, int n_qpart) {
     constexpr int G = DIAG ? 64 : 16;
     int gidx = (bid * blockDim.x + threadIdx.x) / G, lane = threadIdx.x % G;
     if (gidx >= (DIAG ? B.n_pd : B.n_po)) return;
@@ -1544,7 +1199,7 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
     int la = Pr.la, lb = Pr.lb, n = Pr.n, m = Pr.m;
     double* S = B.S + Pr.S_base;
     const double* P = B.P + Pr.P_base * GEMM_SPLIT;
-    double acc = 0;                                   // lane k of a diagonal pair's wave: frame sum k (H 0..20 | g 21..26 | q 27..32)
+    double acc = 0;                                   // lane k of a diagonal pair's wave: frame sum k (H 0..20 | g 21..26), q = sum Y g_l in lanes 27..32
     bool obs = DIAG && Pr.fa >= 0;
     if (obs) {
         // level 2: lanes v < 33 add this frame's block partials in block order
@@ -1558,6 +1213,12 @@ __device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, i
                 double v = B.fs_part[((size_t)off + Pr.fa) * FS_VAL + (lane < FS_VAL ? lane : 0)];
                 acc += lane < FS_VAL ? v : 0.0;
             }
+        }
+        // q: the window's landmark parts as k_lm_schur left them (one folded vector, or GEMM_SPLIT partials added in order)
+        if (lane >= FS_VAL && lane < FS_VAL + 6) {
+            const double* Q = B.lmq + Pr.q_base + 6 * Pr.fa + (lane - FS_VAL);
+#pragma unroll
+            for (int q = 0; q < GEMM_SPLIT; q++) if (q < n_qpart) acc += Q[(size_t)q * m];
         }
     }
     // contribution descriptors: lane c of the group keeps descriptor c0 + c (+ G per round) in

@@ -1139,10 +1139,10 @@ __global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs 
     else if (WITH_IMU) d_eval_imu<false>(B, bid - S.e[2]);    // candidate IMU residuals (8 factors per workgroup), small batches only
 }
 // diagonal + off-diagonal block assembly of the reduced system
-__global__ void __launch_bounds__(256) k_assemble_all(DevBatch B, DevOpt O, int write_S, Segs S, int n_part) {
+__global__ void __launch_bounds__(256) k_assemble_all(DevBatch B, DevOpt O, int write_S, Segs S, int n_part, int n_qpart) {
     int bid = blockIdx.x;
-    if (bid < S.e[0]) d_assemble<true>(B, O, write_S, bid, n_part);
-    else d_assemble<false>(B, O, write_S, bid - S.e[0], n_part);
+    if (bid < S.e[0]) d_assemble<true>(B, O, write_S, bid, n_part, n_qpart);
+    else d_assemble<false>(B, O, write_S, bid - S.e[0], n_part, n_qpart);
 }
 
 // =========================================================================================

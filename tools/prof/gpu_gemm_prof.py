@@ -12,4 +12,5 @@ for _ in range(3):
 out = (C.c_ulonglong * 16)()
 solver.lib().swf_debug_gemm_stamps(out)
 s = list(out)
-print("windows", B, "| producer: loads+sums", s[0], "inverse+cells", s[1], "barrier wait", s[2], "total", s[6], "| consumer wave 0: first wait", s[8], "mfma loops", s[9], "barrier wait", s[10], "S-direct tail", s[11], "(core clock cycles, block 0)")
+print("windows", B, "| producer wave 0: land + sums", s[0], "inverse", s[1], "wait for the buffer", s[2], "Z + write", s[3], "total", s[6],
+      "| consumer wave 0: wait for chunks", s[10], "mfma", s[9], "S-direct tail", s[11], "(core clock cycles, block 0)")
