@@ -39,7 +39,9 @@ enum {
 /* library / device info */
 int swf_version(void);
 int swf_device_count(int32_t* n);                 /* hipGetDeviceCount */
-int swf_set_device(int32_t device);               /* hipSetDevice; one device per process */
+int swf_set_device(int32_t device);               /* hipSetDevice: the device of the batches / problems created next on this thread */
+void swf_default_options(swf_options* opt);       /* Solver::Options as the reference sets them for the window solves (R/swf/swf.cpp:25-30: DENSE_SCHUR, DOGLEG,
+                                                      8 iterations, jacobi_scaling = false) + the public Ceres 2.x defaults of SURVEY.md App. C */
 const char* swf_last_error(void);                 /* thread-local message for the last failure */
 
 /* =====================================================================================
@@ -52,6 +54,25 @@ typedef struct swf_batch swf_batch;
  * pointers are remembered for swf_batch_download_state().  `stream` is a hipStream_t (or
  * NULL for the default stream) on which every later operation of this batch is enqueued. */
 int swf_batch_create(const swf_flat_window* const* windows, int32_t n, void* stream, swf_batch** out);
+
+/* ---- several GPUs of one node from ONE process (SURVEY.md 8b "batch API swf_solve_batch(handles[], n, device_mask)", 8e "one host
+ * thread + one HIP stream per GPU").  Windows are independent units: they are dealt to the devices in contiguous blocks, there is no
+ * data-path collective, and because swf_batch_solve only enqueues, one host thread drives every device.  A batch remembers its device;
+ * every swf_batch_* call switches to it for its duration (and back), so batches of different devices may be used from the same thread.
+ *   swf_batch_create_on       swf_batch_create on the given device (the caller's current device is left as it was).
+ *   swf_batch_create_sharded  windows [0, n) in near-equal contiguous blocks over the devices of device_mask (bit d = device d, 0 = all
+ *                             visible devices); out_batches / out_first / out_count need room for one entry per selected device.
+ *   swf_solve_batches         swf_batch_solve on every batch, then swf_batch_sync on every batch: the node-level Solve.
+ *   swf_batch_device          the device a batch lives on.
+ *   swf_shard_partition       the block partition swf_batch_create_sharded applies (and the multi-process harness, shard.py).
+ * This replaces the reference's single CPU solve loop (R/swf/swf_image.cpp:198-251) only for the batch-throughput path; the single-window
+ * latency path stays on one GPU. */
+int swf_batch_create_on(int32_t device, const swf_flat_window* const* windows, int32_t n, void* stream, swf_batch** out);
+int swf_batch_create_sharded(const swf_flat_window* const* windows, int32_t n, uint32_t device_mask,
+                             swf_batch** out_batches, int32_t* out_first, int32_t* out_count, int32_t* n_batches);
+int swf_solve_batches(swf_batch* const* batches, int32_t n, const swf_options* opt);
+int swf_batch_device(swf_batch* b, int32_t* device);
+int swf_shard_partition(int32_t n, int32_t G, int32_t k, int32_t* first, int32_t* count);   /* shard k of G: the first n % G shards take one more (host only) */
 int swf_batch_destroy(swf_batch* b);
 
 /* Re-upload the parameter blocks from the windows' host arrays (new epoch, same structure):
@@ -160,6 +181,8 @@ typedef struct swf_timing {
     int64_t n_obs;           /* projection observations in the batch */
     int32_t n_linearizations;/* Jacobian evaluations enqueued per window in the last solve */
     int32_t reserved;
+    int64_t lm_schur_flops_sym;  /* the same product counted over the lower triangle only: sum over landmarks of 108 k (k - 1) + 162 k flops */
+    int64_t lm_schur_mfma;       /* v_mfma_f64_16x16x4_f64 instructions one product launch executes over the batch (2048 flops each) */
 } swf_timing;
 int swf_batch_enable_timing(swf_batch* b, int32_t mask);
 int swf_batch_timing(swf_batch* b, swf_timing* out);

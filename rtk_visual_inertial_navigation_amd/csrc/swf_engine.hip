@@ -35,6 +35,14 @@ extern "C" int swf_device_count(int32_t* n) {
     return SWF_OK;
 }
 extern "C" int swf_set_device(int32_t d) { HIPCHK(hipSetDevice(d)); return SWF_OK; }
+extern "C" void swf_default_options(swf_options* o) {
+    if (!o) return;
+    *o = swf_options{};
+    o->max_num_iterations = 8; o->step_mode = SWF_OPTIMIZE; o->num_threads = 1; o->trust_region_strategy = SWF_DOGLEG; o->jacobi_scaling = 0;
+    o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+    o->min_mu = 1e-8; o->max_mu = 1.0; o->mu_increase_factor = 10.0; o->min_diagonal = 1e-6; o->max_diagonal = 1e32;
+}
 
 // ------------------------------------------------------------------ device buffer helper
 // Every buffer of a batch is carved out of a few slabs (bump allocation, 256-byte aligned): buffers with initial data share
@@ -72,8 +80,12 @@ struct SlabCache {
         while (held > keep && !free_.empty()) { held -= free_.back().second; (void)hipFree(free_.back().first); free_.pop_back(); }
     }
 };
-// never destroyed: a ceres::Problem with static storage duration may release its batch after this file's statics are gone
-SlabCache& slab_cache() { static SlabCache* c = new SlabCache(); return *c; }
+// never destroyed: a ceres::Problem with static storage duration may release its batch after this file's statics are gone.
+// One cache per device (a slab, a stream or an event belongs to the device it was created on): the CURRENT device's; every
+// swf_batch_* entry point runs under the batch's device (DeviceGuard).
+constexpr int SWF_MAX_DEVICES = 32;
+int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= SWF_MAX_DEVICES) d = 0; return d; }
+SlabCache& slab_cache() { static SlabCache* c = new SlabCache[SWF_MAX_DEVICES]; return c[current_device()]; }
 }  // namespace
 
 // streams and events are as expensive to create and destroy as device memory (milliseconds for a non-blocking stream): the
@@ -104,7 +116,17 @@ struct HandleCache {
         if (v.size() < 4096) v.push_back(e); else (void)hipEventDestroy(e);
     }
 };
-HandleCache& handle_cache() { static HandleCache* c = new HandleCache(); return *c; }
+HandleCache& handle_cache() { static HandleCache* c = new HandleCache[SWF_MAX_DEVICES]; return c[current_device()]; }
+// makes a batch's device the current one for the duration of an entry point (several batches on several GPUs may be driven from
+// one host thread: swf_solve_batches)
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 }  // namespace
 
 struct DevPool {
@@ -174,6 +196,7 @@ struct HostWin {       // what the host keeps per window for state transfer / ex
 };
 
 struct swf_batch {
+    int device = 0;                    // the HIP device the batch lives on (current at swf_batch_create)
     DevBatch D{};
     DevPool pool;
     hipStream_t stream = nullptr;
@@ -182,7 +205,7 @@ struct swf_batch {
     int max_tiles = 0, max_prior_dim = 0, max_red = 0, min_red = 1 << 30, n_cu = 256;
     bool clc_imu[4] = { false, false, false, false };
     // composite IMU-GNSS factors of the batch (swf_kernels4.h): operator arguments, solver-side bookkeeping, initial hidden epochs
-    CompArgs CA{}; CompMeta CM{}; int n_comp = 0; long long comp_ne = 0;
+    CompArgs CA{}; CompMeta CM{}; int n_comp = 0, comp_nmax = 0; long long comp_ne = 0;
     bool comp_eigen_root = false;                      // SWF_COMP_EIGEN_ROOT=1 at create: the composite factors expose the reference's eigen square root
     double* co_pose0 = nullptr; double* co_sb0 = nullptr;    // clique class holds IMU factors (its elimination must follow k_eval_imu)
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
@@ -208,7 +231,7 @@ struct swf_batch {
     std::vector<hipEvent_t> ev;           // event pool (pairs)
     std::vector<int> ev_kind;             // kernel id per recorded pair
     int ev_used = 0;
-    int64_t jac_bytes = 0, proj_bytes = 0, chol_flops = 0, lm_schur_flops = 0;
+    int64_t jac_bytes = 0, proj_bytes = 0, chol_flops = 0, lm_schur_flops = 0, lm_schur_flops_sym = 0, lm_schur_mfma = 0;
     int last_mode = -1;
 };
 
@@ -549,7 +572,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         for (int k = 0; k < w->n_comp; k++) {
             const int M = w->comp_M[k], N = w->comp_N[k], G = 30 + N;
             if (M < 1) return fail(SWF_E_INVALID, "composite factor without hidden epochs");
-            if (N < 0 || N > CO_MAXN) return fail(SWF_E_UNSUPPORTED, "composite factor with more than 24 ambiguities");
+            if (N < 0 || N > CO_MAXN) return fail(SWF_E_UNSUPPORTED, "composite factor with more than 64 ambiguities");
             const int* ix = w->comp_idx + io;
             CHK(ix[0], nP, "composite") CHK(ix[1], nS, "composite") CHK(ix[2], nP, "composite") CHK(ix[3], nS, "composite")
             std::vector<int> blks = { bidP(ix[0]), bidS(ix[1]), bidP(ix[2]), bidS(ix[3]) };
@@ -791,6 +814,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     const double tc1 = now();
     if (B.n_x > 0x7fffffffLL || B.n_loc > 0x7fffffffLL) return fail(SWF_E_UNSUPPORTED, "batch too large for 32-bit offsets");
     swf_batch* b = new swf_batch();
+    b->device = current_device();
     b->stream = (hipStream_t)stream;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
@@ -807,6 +831,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     for (size_t l = 0; l + 1 < B.lm_obs0.size() + 1 && l < B.lm_win.size(); l++) {
         int64_t k = (l + 1 < B.lm_obs0.size() ? B.lm_obs0[l + 1] : (int)B.p_win.size()) - B.lm_obs0[l];
         b->lm_schur_flops += 216 * k * k + 108 * k;
+        b->lm_schur_flops_sym += 108 * k * (k - 1) + 162 * k;
     }
     for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); b->min_red = std::min(b->min_red, W.n_red); }
     DevBatch& D = b->D;
@@ -921,6 +946,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
                 for (int g = 0; g < TW; g++) {
                     const std::vector<unsigned>& tt = task_tiles[(size_t)(c * TW + g)];
                     for (int e = 0; e < ntl; e++) if (tt[(size_t)e]) {
+                        b->lm_schur_mfma += 3;
                         int lp = e / (NCW * TPW), r = e % (NCW * TPW), sl = r / NCW, cw = r % NCW;
                         km[kw + (size_t)(lp * NCW + cw)] |= (1 << g) << (4 * sl);
                     }
@@ -1026,9 +1052,9 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     rc |= P.zeros(B.n_loc, &D.g); rc |= P.zeros(B.n_loc, &D.diag); rc |= P.zeros(B.n_loc, &D.rhs); rc |= P.zeros(B.n_loc, &D.vc);
     rc |= P.zeros(B.n_loc, &D.y); rc |= P.zeros(B.n_loc, &D.step);
     rc |= P.zeros(B.S_tot, &D.S); rc |= P.zeros(B.Lt_tot, &D.L);
-    if (b->max_red > 240 && b->max_red <= 512) rc |= P.zeros((size_t)n * (CB_MAXT - 1) * 256, &D.Linv);
+    if (b->max_red > 240 && b->max_red <= CB_NMAX) rc |= P.zeros((size_t)n * (CB_MAXT - 1) * 256, &D.Linv);
     // few windows, one of them on the streamed Cholesky: the factorisation is spread over the chip, two tile columns per launch (k_chol_col)
-    if (b->max_red > 240 && b->max_red <= 512 && n * 4 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);      // >= 4 workgroups per window
+    if (b->max_red > 240 && b->max_red <= CC_NMAX && n * 4 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);      // >= 4 workgroups per window
     rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
     size_t np = (size_t)D.n_proj;
     rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl);
@@ -1054,6 +1080,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         std::vector<long long> pno(nc + 1, 0), nno(nc + 1, 0), go(nc + 1, 0), g2o(nc + 1, 0), Joff(nc), Coff(nc);
         for (int f = 0; f < nc; f++) {
             const int M = B.co_M[f], N = B.co_N[f], G = 30 + N;
+            b->comp_nmax = std::max(b->comp_nmax, N);
             eo[f + 1] = eo[f] + M; no[f + 1] = no[f] + N; pno[f + 1] = pno[f] + 15LL * M * N; nno[f + 1] = nno[f] + (long long)N * N;
             go[f + 1] = go[f] + G; g2o[f + 1] = g2o[f] + (long long)G * G;
             const GFac& Gf = B.gf[B.co_gf[f]];
@@ -1102,9 +1129,59 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     return SWF_OK;
 }
 
+// the static block partition of SURVEY.md 8e (512 windows, 64 per GPU at 8): shard k of G takes `count` consecutive windows from `first`,
+// the first n % G shards one more — the same rule as the harness's shard.partition (no device needed)
+extern "C" int swf_shard_partition(int32_t n, int32_t G, int32_t k, int32_t* first, int32_t* count) {
+    if (n < 0 || G <= 0 || k < 0 || k >= G || !first || !count) return fail(SWF_E_INVALID, "swf_shard_partition: bad arguments");
+    const int q = n / G, r = n % G;
+    *first = k * q + std::min(k, r); *count = q + (k < r ? 1 : 0);
+    return SWF_OK;
+}
+
+// ---- several GPUs of one node from one process (windows are independent units, "one host thread + one HIP stream per
+// GPU", no data-path collective).  swf_batch_solve only ENQUEUES work on its batch's stream, so a single host thread keeps all devices busy.
+extern "C" int swf_batch_create_on(int32_t device, const swf_flat_window* const* windows, int32_t n, void* stream, swf_batch** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SWF_E_NODEVICE, "no HIP device: this library has no CPU fallback");
+    if (device < 0 || device >= ndev || device >= SWF_MAX_DEVICES) return fail(SWF_E_INVALID, "swf_batch_create_on: no such device");
+    DeviceGuard dg_(device);
+    return swf_batch_create(windows, n, stream, out);
+}
+
+// windows [0, n) dealt in contiguous, near-equal blocks to the devices of device_mask (bit d = use device d; 0 = every visible device):
+// one batch per device that receives windows, out_batches[k] / out_first[k] / out_count[k] for k < *n_batches (capacity: the device count)
+extern "C" int swf_batch_create_sharded(const swf_flat_window* const* windows, int32_t n, uint32_t device_mask,
+                                        swf_batch** out_batches, int32_t* out_first, int32_t* out_count, int32_t* n_batches) {
+    if (!windows || n <= 0 || !out_batches || !n_batches) return fail(SWF_E_INVALID, "swf_batch_create_sharded: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SWF_E_NODEVICE, "no HIP device: this library has no CPU fallback");
+    std::vector<int> devs;
+    for (int d = 0; d < ndev && d < SWF_MAX_DEVICES; d++) if (device_mask == 0 || ((device_mask >> d) & 1u)) devs.push_back(d);
+    if (devs.empty()) return fail(SWF_E_INVALID, "swf_batch_create_sharded: device_mask selects no visible device");
+    const int G = (int)std::min<size_t>(devs.size(), (size_t)n);
+    *n_batches = 0;
+    for (int k = 0; k < G; k++) {
+        int32_t lo = 0, cnt = 0;
+        swf_shard_partition(n, G, k, &lo, &cnt);
+        const int hi = lo + cnt;
+        swf_batch* bk = nullptr;
+        int rc = swf_batch_create_on(devs[k], windows + lo, hi - lo, nullptr, &bk);
+        if (rc != SWF_OK) { for (int q = 0; q < *n_batches; q++) swf_batch_destroy(out_batches[q]); *n_batches = 0; return rc; }
+        out_batches[k] = bk;
+        if (out_first) out_first[k] = lo;
+        if (out_count) out_count[k] = hi - lo;
+        *n_batches = k + 1;
+    }
+    return SWF_OK;
+}
+
+extern "C" int swf_batch_device(swf_batch* b, int32_t* device) { if (!b || !device) return fail(SWF_E_INVALID, "bad arguments"); *device = b->device; return SWF_OK; }
+
 extern "C" int swf_batch_destroy(swf_batch* b) {
     if (!b) return SWF_OK;
+    DeviceGuard dg_(b->device);
     (void)hipStreamSynchronize(b->stream);
+    if (b->aux) (void)hipStreamSynchronize(b->aux);     // nothing of this batch may still run when its slabs go back to the cache
     for (auto& e : b->ev) handle_cache().give(e, true);
     b->pool.release();
     delete b;
@@ -1112,6 +1189,7 @@ extern "C" int swf_batch_destroy(swf_batch* b) {
 }
 
 extern "C" int swf_batch_upload_state(swf_batch* b) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b) return fail(SWF_E_INVALID, "null batch");
     std::vector<double> x((size_t)b->D.n_x);
     for (size_t i = 0; i < b->win.size(); i++) {
@@ -1144,6 +1222,7 @@ extern "C" int swf_batch_upload_state(swf_batch* b) {
 }
 
 extern "C" int swf_batch_reset_state(swf_batch* b) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b) return fail(SWF_E_INVALID, "null batch");
     int n = b->D.n_x;
     hipLaunchKernelGGL(k_copy, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->D.x, (const double*)b->D.x0, n);
@@ -1194,7 +1273,12 @@ struct Launcher {
             if ((size_t)(b->ev_used + 1) * 2 > b->ev.size()) {
                 size_t old = b->ev.size();
                 b->ev.resize(old + 64);
-                for (size_t i = old; i < b->ev.size(); i++) b->ev[i] = handle_cache().event(true);
+                bool ok = true;
+                for (size_t i = old; i < b->ev.size(); i++) { b->ev[i] = handle_cache().event(true); ok = ok && b->ev[i] != nullptr; }
+                if (!ok) {                                 // no events to be had: this launch goes untimed
+                    for (size_t i = old; i < b->ev.size(); i++) handle_cache().give(b->ev[i], true);
+                    b->ev.resize(old); return;
+                }
             }
             slot = b->ev_used++;
             b->ev_kind.push_back(kind);
@@ -1210,11 +1294,15 @@ struct Launcher {
         DevBatch& D = b->D;
         if (b->n_comp) {
             // composite IMU-GNSS factors of the windows that re-linearise: hidden epochs move, re-elimination, prior records rewritten
-            hipLaunchKernelGGL(k_comp_gather, dim3(b->n_comp), dim3(64), 0, st, D, b->CA, b->CM);
+            hipLaunchKernelGGL(k_comp_gather, dim3(b->n_comp), dim3(128), 0, st, D, b->CA, b->CM);
             hipLaunchKernelGGL(k_comp_prep, dim3(b->n_comp), dim3(256), 0, st, b->CA);
             hipLaunchKernelGGL(k_comp_imu, dim3((b->CA.n_iq + 7) / 8), dim3(256), 0, st, b->CA);
-            hipLaunchKernelGGL(k_comp_elim, dim3(b->n_comp), dim3(256), 0, st, b->CA);
-            if (b->comp_eigen_root) hipLaunchKernelGGL(k_comp_eigroot, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            if (b->comp_nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_elim<CO_SMALLN>, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            else hipLaunchKernelGGL(k_comp_elim<CO_MAXN>, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            if (b->comp_eigen_root) {
+                if (b->comp_nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_eigroot<CO_SMALLN>, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+                else hipLaunchKernelGGL(k_comp_eigroot<CO_MAXN>, dim3(b->n_comp), dim3(512), 0, st, b->CA);
+            }
             hipLaunchKernelGGL(k_comp_scatter, dim3(b->n_comp), dim3(256), 0, st, D, b->CA, b->CM);
         }
         hipStream_t sa = b->aux ? b->aux : st;
@@ -1271,7 +1359,7 @@ struct Launcher {
     void reduced() {
         DevBatch& D = b->D;
         Bracket t(*this, SWF_K_CHOL);
-        if (b->max_red <= 512 && !b->force_chol_v1) {
+        if (b->max_red <= CB_NMAX && !b->force_chol_v1) {
             // per-window choice (each kernel skips the other's windows): register-resident tiles up to 240 dimensions, streamed above
             if (b->min_red <= 240) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
             if (b->max_red > 240 && D.Wk) {
@@ -1298,7 +1386,7 @@ struct Launcher {
                 if (S.e[5] > S.e[0]) hipLaunchKernelGGL(k_post_chol<2>, dim3(S.e[5] - S.e[0]), dim3(256), 0, st, D, O, S);
             }
         }
-        { Bracket t(*this, SWF_K_DOGLEG); hipLaunchKernelGGL(k_dogleg, dim3(D.n_win), dim3(256), 0, st, D, O); }
+        { Bracket t(*this, SWF_K_DOGLEG); hipLaunchKernelGGL(k_dogleg, dim3(D.n_win), dim3(CTL_NT), 0, st, D, O); }
     }
     void cand_eval() {
         DevBatch& D = b->D;
@@ -1323,12 +1411,13 @@ struct Launcher {
             Bracket t(*this, SWF_K_CAND_EVAL);
             if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
         }
-        { Bracket t(*this, SWF_K_DECIDE); hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(256), 0, st, D, O); }
+        { Bracket t(*this, SWF_K_DECIDE); hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(CTL_NT), 0, st, D, O); }
     }
 };
 }  // namespace
 
 extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b || !opt) return fail(SWF_E_INVALID, "swf_batch_solve: bad arguments");
     if (opt->max_num_iterations < 0 || opt->max_num_iterations >= SWF_MAX_TRACE) return fail(SWF_E_INVALID, "max_num_iterations out of range");
     if (opt->trust_region_strategy != SWF_DOGLEG && opt->trust_region_strategy != SWF_LEVENBERG_MARQUARDT) return fail(SWF_E_INVALID, "unknown trust_region_strategy");
@@ -1360,12 +1449,14 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
     b->last = swf_timing{};
     b->last.jacobian_bytes = b->jac_bytes; b->last.proj_bytes = b->proj_bytes; b->last.chol_flops = b->chol_flops;
     b->last.lm_schur_flops = b->lm_schur_flops; b->last.n_obs = b->D.n_proj;
+    b->last.lm_schur_flops_sym = b->lm_schur_flops_sym; b->last.lm_schur_mfma = b->lm_schur_mfma;
     b->last.n_linearizations = nlin;
     b->last_mode = opt->step_mode; b->mg_valid = false; b->tc_valid = false;      // consumer outputs belong to the previous solve
     return SWF_OK;
 }
 
 extern "C" int swf_batch_sync(swf_batch* b) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b) return fail(SWF_E_INVALID, "null batch");
     HIPCHK(hipStreamSynchronize(b->stream));
     for (int i = 0; i < b->ev_used; i++) {
@@ -1379,10 +1470,20 @@ extern "C" int swf_batch_sync(swf_batch* b) {
     return SWF_OK;
 }
 
+// one call for the whole node: every batch's solve is enqueued on its own device first, then all are awaited
+extern "C" int swf_solve_batches(swf_batch* const* batches, int32_t n, const swf_options* opt) {
+    if (!batches || n <= 0 || !opt) return fail(SWF_E_INVALID, "swf_solve_batches: bad arguments");
+    for (int i = 0; i < n; i++) { int rc = swf_batch_solve(batches[i], opt); if (rc != SWF_OK) return rc; }
+    int rc_all = SWF_OK;
+    for (int i = 0; i < n; i++) { int rc = swf_batch_sync(batches[i]); if (rc != SWF_OK) rc_all = rc; }
+    return rc_all;
+}
+
 extern "C" int swf_batch_enable_timing(swf_batch* b, int32_t mask) { if (!b) return fail(SWF_E_INVALID, "null batch"); b->timing = mask; return SWF_OK; }
 extern "C" int swf_batch_timing(swf_batch* b, swf_timing* out) { if (!b || !out) return fail(SWF_E_INVALID, "bad arguments"); *out = b->last; return SWF_OK; }
 
 extern "C" int swf_batch_download_state(swf_batch* b) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b) return fail(SWF_E_INVALID, "null batch");
     std::vector<double> x((size_t)b->D.n_x);
     HIPCHK(hipMemcpyAsync(x.data(), b->D.x, x.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
@@ -1410,6 +1511,7 @@ extern "C" int swf_batch_download_state(swf_batch* b) {
 }
 
 extern "C" int swf_batch_summaries(swf_batch* b, swf_summary* out) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b || !out) return fail(SWF_E_INVALID, "bad arguments");
     size_t n = b->win.size();
     std::vector<WinState> ws(n);
@@ -1437,6 +1539,7 @@ extern "C" int swf_batch_dims(swf_batch* b, int32_t w, int32_t* n_loc, int32_t* 
 }
 
 extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, double* rhs, double* L) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
     if (b->last_mode < 0) return fail(SWF_E_STATE, "export before any solve");
     const WinRec& W = b->win[w];
@@ -1450,7 +1553,7 @@ extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, doub
     if (L) {
         std::vector<double> Lt((n + 1) * (n + 1));
         HIPCHK(hipMemcpy(Lt.data(), b->D.L + W.Lt_base, Lt.size() * sizeof(double), hipMemcpyDeviceToHost));
-        bool rr = b->max_red <= 512 && !b->force_chol_v1;      // k_chol_rr2 / k_chol_big write row-major lower, ld = n
+        bool rr = b->max_red <= CB_NMAX && !b->force_chol_v1;      // k_chol_rr2 / k_chol_big write row-major lower, ld = n
         for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++)
             L[r * n + c] = (c <= r) ? (rr ? Lt[r * n + c] : Lt[c * (n + 1) + r]) : 0.0;
     }
@@ -1458,12 +1561,13 @@ extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, doub
 }
 
 extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b || (form != SWF_PRIOR_EIGEN && form != SWF_PRIOR_CHOLESKY) || !(eps >= 0.0)) return fail(SWF_E_INVALID, "swf_batch_marginalize: bad arguments");
     if (b->last_mode != SWF_ASSEMBLE_ELIMINATE_ONLY) return fail(SWF_E_STATE, "swf_batch_marginalize needs a preceding solve with step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY");
-    if (b->max_red > 512 || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "marginalisation needs the row-major Cholesky factor (n_red <= 512)");
+    if (b->max_red > CB_NMAX || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "marginalisation needs the row-major Cholesky factor (n_red <= 640)");
     int nw = (int)b->win.size(), ldn = 1;
     for (int w = 0; w < nw; w++) ldn = std::max(ldn, b->hw[w].tail_dim);
-    if (form == SWF_PRIOR_EIGEN && ldn > MG_BIGN) return fail(SWF_E_UNSUPPORTED, "eigen square root: parameter_head tail larger than 384 dimensions (use SWF_PRIOR_CHOLESKY)");
+    if (form == SWF_PRIOR_EIGEN && ldn > MG_BIGN) return fail(SWF_E_UNSUPPORTED, "eigen square root: parameter_head tail larger than 640 dimensions (use SWF_PRIOR_CHOLESKY)");
     b->mg_ld = ldn;
     if (!b->mg_A) {
         std::vector<int> td(nw);
@@ -1483,7 +1587,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
     // rank-revealing factor of A; every other window leaves this kernel at once
     const int force = getenv("SWF_FORCE_MARG_RESCUE") ? 1 : 0;      // testing aid: healthy windows through the rank-deficient path too
     if (form == SWF_PRIOR_EIGEN)
-        hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), 0, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok, force);
+        hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), 0, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok, force, eps);
     hipLaunchKernelGGL(k_marginalize<false>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
                        b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, (double*)nullptr,
                        (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force);
@@ -1498,9 +1602,10 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
 
 // ambiguity covariance hand-off: information and covariance of the parameter_head tail from the factor of the last linear solve
 extern "C" int swf_batch_tail_covariance(swf_batch* b) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b) return fail(SWF_E_INVALID, "swf_batch_tail_covariance: null batch");
     if (b->last_mode < 0) return fail(SWF_E_STATE, "swf_batch_tail_covariance needs a preceding solve");
-    if (b->max_red > 512 || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "the tail covariance needs the row-major Cholesky factor (n_red <= 512)");
+    if (b->max_red > CB_NMAX || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "the tail covariance needs the row-major Cholesky factor (n_red <= 640)");
     int nw = (int)b->win.size(), ldn = 1;
     for (int w = 0; w < nw; w++) ldn = std::max(ldn, b->hw[w].tail_dim);
     if (!b->tc_A) {
@@ -1521,6 +1626,7 @@ extern "C" int swf_batch_tail_covariance(swf_batch* b) {
 }
 
 extern "C" int swf_batch_get_tail_covariance(swf_batch* b, int32_t w, double* A, double* Qy, int32_t* n_out) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
     if (!b->tc_valid) return fail(SWF_E_STATE, "swf_batch_get_tail_covariance before swf_batch_tail_covariance");
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1535,6 +1641,7 @@ extern "C" int swf_batch_get_tail_covariance(swf_batch* b, int32_t w, double* A,
 }
 
 extern "C" int swf_batch_get_prior(swf_batch* b, int32_t w, double* A, double* bv, double* J, double* r0, double* eig, int32_t* n_out, int32_t* rank) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
     if (!b->mg_valid) return fail(SWF_E_STATE, "swf_batch_get_prior before swf_batch_marginalize");
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1570,6 +1677,7 @@ extern "C" int swf_batch_get_prior(swf_batch* b, int32_t w, double* A, double* b
 }
 
 extern "C" int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, double* diag, double* y) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
     const WinRec& W = b->win[w];
     size_t n = (size_t)W.n_loc;
@@ -1583,6 +1691,7 @@ extern "C" int swf_batch_export_vectors(swf_batch* b, int32_t w, double* grad, d
 // Debug / parity export: residual vector and dense Jacobian of window w as the device holds them after its last
 // linearisation (see include/swf_solver.h).  Host-side gather of the device buffers; nothing here is on the solve path.
 extern "C" int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, double* J, int32_t* n_res_out, int32_t* n_loc_out) {
+    DeviceGuard dg_(b ? b->device : -1);
     if (!b || w < 0 || w >= (int)b->win.size()) return fail(SWF_E_INVALID, "bad window index");
     const WinRec& W = b->win[w];
     const DevBatch& D = b->D;
@@ -1693,7 +1802,7 @@ extern "C" int swf_debug_gemm_stamps(unsigned long long* out) {
 struct swf_composite {
     CompArgs A{};
     std::vector<void*> bufs;
-    int n = 0; long long sumM = 0, sumN = 0, sumG = 0, sumG2 = 0;
+    int n = 0, nmax = 0; long long sumM = 0, sumN = 0, sumG = 0, sumG2 = 0;
     std::vector<int> M;
     bool eigen_root = false;
     hipStream_t stream = nullptr;
@@ -1710,15 +1819,17 @@ extern "C" int swf_composite_create(int32_t n, const int32_t* M, const int32_t* 
         return fail(SWF_E_INVALID, "swf_composite_create: null argument");
     std::vector<int> eo(n + 1, 0), no(n + 1, 0);
     std::vector<long long> pno(n + 1, 0), nno(n + 1, 0), go(n + 1, 0), g2o(n + 1, 0);
+    int nmax_ = 0;
     for (int f = 0; f < n; f++) {
         if (M[f] < 1) return fail(SWF_E_INVALID, "composite factor without hidden epochs");
-        if (N[f] < 0 || N[f] > CO_MAXN) return fail(SWF_E_UNSUPPORTED, "composite factor with more than 24 ambiguities");
+        if (N[f] < 0 || N[f] > CO_MAXN) return fail(SWF_E_UNSUPPORTED, "composite factor with more than 64 ambiguities");
+        nmax_ = std::max(nmax_, (int)N[f]);
         eo[f + 1] = eo[f] + M[f]; no[f + 1] = no[f] + N[f];
         pno[f + 1] = pno[f] + 15LL * M[f] * N[f]; nno[f + 1] = nno[f] + (long long)N[f] * N[f];
         go[f + 1] = go[f] + 30 + N[f]; g2o[f + 1] = g2o[f] + (long long)(30 + N[f]) * (30 + N[f]);
     }
     std::unique_ptr<swf_composite> c(new swf_composite());
-    c->n = n; c->sumM = eo[n]; c->sumN = no[n]; c->sumG = go[n]; c->sumG2 = g2o[n]; c->stream = (hipStream_t)stream;
+    c->n = n; c->nmax = nmax_; c->sumM = eo[n]; c->sumN = no[n]; c->sumG = go[n]; c->sumG2 = g2o[n]; c->stream = (hipStream_t)stream;
     bool bad = false;
     auto up = [&](const void* src, size_t bytes) -> void* {
         void* d = nullptr;
@@ -1778,8 +1889,12 @@ extern "C" int swf_composite_evaluate(swf_composite* c, const double* outer, con
     A.want_jac = want_jac ? 1 : 0;
     hipLaunchKernelGGL(k_comp_prep, dim3(c->n), dim3(256), 0, st, A);
     hipLaunchKernelGGL(k_comp_imu, dim3((A.n_iq + 7) / 8), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(k_comp_elim, dim3(c->n), dim3(256), 0, st, A);
-    if (c->eigen_root) hipLaunchKernelGGL(k_comp_eigroot, dim3(c->n), dim3(256), 0, st, A);
+    if (c->nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_elim<CO_SMALLN>, dim3(c->n), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(k_comp_elim<CO_MAXN>, dim3(c->n), dim3(256), 0, st, A);
+    if (c->eigen_root) {
+        if (c->nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_eigroot<CO_SMALLN>, dim3(c->n), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(k_comp_eigroot<CO_MAXN>, dim3(c->n), dim3(512), 0, st, A);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(residual, c->A.res_out, c->sumG * sizeof(double), hipMemcpyDeviceToHost, st));
     if (jac && want_jac) HIPCHK(hipMemcpyAsync(jac, c->A.jac_out, c->sumG2 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 }
 
 // =========================================================================================
-// k_chol_big — the same pivot / panel / look-ahead pipeline as k_chol_rr2 for 240 < n_red <= 512, where the factor
+// k_chol_big — the same pivot / panel / look-ahead pipeline as k_chol_rr2 for 240 < n_red <= 640, where the factor
 // (n^2/2 doubles, up to 1 MB) no longer fits the register file.  The tiles live in HBM/L2 in the window's L buffer
 // (row-major, ld = n, the reduced rhs as row n) and are streamed through registers step by step:
 //   wave 0        pivot wave: chol_pivot_tile on the published diagonal tile, Linv_jj kept in LDS for the panel and
@@ -545,15 +545,18 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 //          4 MFMAs with the panel operands from LDS, store; the next tile's loads are issued before the MFMAs].
 // Step 0 reads S (lower; diagonal tiles mirrored), later steps read the L buffer.  Right-looking backward pass.
 // =========================================================================================
-#define CB_MAXT 33                      // tile rows: 32 of the matrix (n <= 512) + the rhs row
+#define CB_NMAX 640                     // largest reduced system of the tiled kernels (hs_row reaches ~620 in a live window)
+#define CB_MAXT (CB_NMAX / 16 + 1)      // tile rows: 40 of the matrix + the rhs row
+#define CC_NMAX 512                     // k_chol_col keeps two panels in LDS: up to 512 dimensions
+#define CC_MAXT (CC_NMAX / 16 + 1)
 template <bool BACK_ONLY>
 __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
-    __shared__ double Pn[CB_MAXT][16][17];     // panel of the current column, tile row I -> L_Ij (72 KB)
+    __shared__ double Pn[CB_MAXT][16][17];     // panel of the current column, tile row I -> L_Ij (89 KB)
     __shared__ double Lic[16][17];             // Linv_jj of the current column
     __shared__ double ipiv[16];                // 1/sqrt(pivot) of the tile being factored (chol_pivot_tile scratch)
     __shared__ double Dt[2][16][17];           // published diagonal tiles, double-buffered
-    __shared__ double zs[528];
-    __shared__ double yv[528];
+    __shared__ double zs[CB_NMAX + 16];
+    __shared__ double yv[CB_NMAX + 16];
     __shared__ int fail;
     int w = blockIdx.x;
     WinState& st = B.ws[w];
@@ -568,7 +571,7 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     double* Lw = B.L + W.Lt_base;
     double* LinvG = B.Linv + (size_t)w * (CB_MAXT - 1) * 256;
     if (tid == 0) fail = 0;
-    for (int e = tid; e < 528; e += 1024) yv[e] = 0.0;     // padded entries must be exact zeros (they meet identity rows of Linv)
+    for (int e = tid; e < CB_NMAX + 16; e += 1024) yv[e] = 0.0;     // padded entries must be exact zeros (they meet identity rows of Linv)
     // tile I/O in the C-layout.  first = true: from S (lower, mirrored inside diagonal tiles, rhs = row n of S)
     // interior tiles (all 16 rows inside the matrix, not a mirrored first read): scalar tile base + per-lane offset
     const int lane_off = lk * n + li;
@@ -748,7 +751,7 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     // z = L^-1 rhs sits in row n of the L buffer: this wave's tiles of the rhs row -> yv
     for (int J = 0; J < Tc; J++)
         if ((Tc + J) % 15 == kq && lk == 0 && 16 * J + li < n) yv[16 * J + li] = Lw[(size_t)n * n + 16 * J + li];
-    for (int e = tid - 64; e < 528; e += 960) zs[e] = 0.0;
+    for (int e = tid - 64; e < CB_NMAX + 16; e += 960) zs[e] = 0.0;
     __syncthreads();                                       // E
     // tiles (J, J') of row J, J' < J, owned by this wave: J' = (kq - J) mod 15, + 15, + 30.  The tiles of row J - 1 are
     // requested before row J is applied (L is final: the loads do not depend on y), so no step waits for its loads
@@ -795,8 +798,8 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
 #define CC_NB 32                        // workgroups per window, at most (the engine divides the chip by the window count)
 #define CC_NT 512
 __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
-    __shared__ double Pn[CB_MAXT][16][17];      // panel of column j
-    __shared__ double Pn2[CB_MAXT][16][17];     // panel of column j + 1 (2 x 72 KB)
+    __shared__ double Pn[CC_MAXT][16][17];      // panel of column j
+    __shared__ double Pn2[CC_MAXT][16][17];     // panel of column j + 1 (2 x 72 KB)
     __shared__ double Lic[16][17];
     __shared__ double ipiv[16];
     __shared__ double Dt[16][17];
@@ -857,7 +860,7 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
     // ---- the loads that do not depend on the pivots go out first: this wave's tiles of columns j and j + 1 and its first
     //      trailing tiles
     constexpr int NW = CC_NT / 64;                         // waves per workgroup
-    constexpr int PPW = (CB_MAXT - 1 + NW - 1) / NW;        // column tiles per wave, at most
+    constexpr int PPW = (CC_MAXT - 1 + NW - 1) / NW;        // column tiles per wave, at most
     const bool two = j + 1 < Tc;                           // this launch also finishes column j + 1
     const int jt = two ? j + 2 : j + 1;                    // first trailing column
     double4_t pv[PPW], pw[PPW];
@@ -1236,7 +1239,11 @@ __device__ unsigned long long g_dog_stamps[16];
 #else
 #define DST(i)
 #endif
-__global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
+// threads of the per-window control kernels k_dogleg / k_decide: their loops over the window's dimensions and cost terms are chains of
+// dependent loads, so a window's latency falls with the thread count (one window: k_dogleg 20.7 -> ? us); the same count for every
+// batch size, because the order of the strided partial sums depends on it
+#define CTL_NT 256
+__global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     __shared__ double red[16 * 6];
     __shared__ int go;
 #ifdef SWF_PROFILE_DOG
@@ -1380,7 +1387,7 @@ __global__ void __launch_bounds__(256) k_dogleg(DevBatch B, DevOpt O) {
 
 // acceptance test + trust-region update (TrustRegionMinimizer::Minimize loop body,
 // DoglegStrategy::StepAccepted / StepRejected / StepIsInvalid)
-__global__ void __launch_bounds__(256) k_decide(DevBatch B, DevOpt O) {
+__global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
     __shared__ double red[16 * 2];
     __shared__ int accept;
     int w = blockIdx.x, tid = threadIdx.x;

@@ -13,7 +13,7 @@
 #include "swf_dev.h"
 
 #define MG_MAXN 140                       // largest tail whose M is LDS-resident (153 KB)
-#define MG_BIGN 384                       // largest tail of the eigen form: above MG_MAXN, M lives in a per-window HBM / L2 scratch
+#define MG_BIGN 640                       // largest tail of the eigen form (= the largest reduced system, CB_NMAX): above MG_MAXN, M lives in a per-window HBM / L2 scratch
 #define MG_NT 1024                        // 64 sixteen-lane groups = 64 column pairs per step
 #define MG_LDS_DOUBLES 19600              // 153 KB: M for n <= 140, M and V together for n <= 98
 #define Mc(c, r) Mm[(c) * n + (r)]
@@ -29,10 +29,17 @@
 // first m columns only, in the window's (now free) L buffer, leaves the Schur complement A and the reduced right-hand side b
 // in the trailing block; a diagonally pivoted outer-product Cholesky of A then yields rows v_r with sum_r v_r v_r^T = A up to
 // the pivots it drops (rank-revealing: it stops at pivots below 1e-14 of the largest).  k_marginalize takes M = [v_r] and b
-// from here instead of L_nn / y_n.  A non-positive pivot among the first m columns is a real failure (rank -1).
+// from here instead of L_nn / y_n.
+// A singular S_mm — a marginalised state nothing constrains, or a direction of the marginalised block only a combination of
+// which is observed — is business as usual in the reference too: UpdateSchur PSEUDO-inverts S_mm (eigenvalues <= 1e-8 dropped,
+// R/swf/swf_gnss.cpp:44-51; the same in MarginalizationInfo::marginalize, R/factor/marginalization_factor.cpp:260-377).  For a
+// positive semi-definite S the generalised Schur complement does not depend on which generalised inverse is taken, and a
+// Cholesky that SKIPS a numerically null pivot (the column below it is null as well) computes it: a pivot <= max(eps, 1e-13 of
+// the block's largest diagonal entry) among the first m columns drops its column; a pivot below minus a thousand times that
+// (an indefinite matrix, or a NaN) is a real failure (rank -1).
 // One 1024-thread workgroup per window; this is the slow, rare path.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tail_dim, int ldn, double* resM, double* resb, int* res_ok, int force) {
+__global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tail_dim, int ldn, double* resM, double* resb, int* res_ok, int force, double eps) {
     __shared__ double red_v[16]; __shared__ int red_i[16];
     __shared__ double piv_s; __shared__ int piv_i, stop_s;
     int w = blockIdx.x, tid = threadIdx.x;
@@ -45,10 +52,24 @@ __global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tai
     double* Wk = B.L + W.Lt_base;                       // (nr + 1) rows x nr columns, row-major; row nr carries the right-hand side
     const double* S = B.S + W.S_base;
     for (size_t e = tid; e < (size_t)(nr + 1) * nr; e += 1024) Wk[e] = S[e];
+    // scale of the marginalised block: its largest diagonal entry
+    {
+        double dm = 0.0;
+        for (int j = tid; j < m; j += 1024) dm = fmax(dm, S[(size_t)j * nr + j]);
+        dm = wave_max(dm);
+        if ((tid & 63) == 0) red_v[tid >> 6] = dm;
+        __syncthreads();
+        if (tid == 0) { double v = red_v[0]; for (int q = 1; q < 16; q++) v = fmax(v, red_v[q]); piv_s = v; }
+    }
+    __syncthreads();
+    const double tol = fmax(eps, 1e-13 * piv_s);
     __syncthreads();
     for (int j = 0; j < m; j++) {
-        double piv = Wk[(size_t)j * nr + j];
-        if (!(piv > 0.0)) return;                        // uniform: every thread reads the same value
+        double piv = Wk[(size_t)j * nr + j];             // uniform: every thread reads the same value
+        if (!(piv > tol)) {
+            if (!(piv >= -1e3 * tol)) return;            // indefinite (or NaN): a real failure
+            continue;                                    // a null direction of S_mm: the pseudo-inverse drops it (the column is never read again)
+        }
         double id = 1.0 / sqrt(piv);
         __syncthreads();
         for (int i = j + tid; i <= nr; i += 1024) Wk[(size_t)i * nr + j] = i == j ? sqrt(piv) : Wk[(size_t)i * nr + j] * id;
@@ -110,8 +131,8 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
                                                         double* outw, int* outrank, double* Mscr,
                                                         const double* resM, const double* resb, const int* res_ok, int force) {
     __shared__ double lds[GM ? 16 : MG_LDS_DOUBLES];  // M (n x n, column c contiguous: row c of L_nn) | V (n x n) if both fit
-    __shared__ double lam[MG_BIGN];
-    __shared__ double bv[MG_BIGN];
+    __shared__ double lam[GM ? MG_BIGN : MG_MAXN + 4];
+    __shared__ double bv[GM ? MG_BIGN : MG_MAXN + 4];
     __shared__ int nrot;
     int w = blockIdx.x, tid = threadIdx.x;
     const WinRec& W = B.win[w];

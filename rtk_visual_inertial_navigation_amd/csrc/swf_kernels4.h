@@ -15,7 +15,9 @@
 #pragma once
 #include "swf_kernels.h"
 
-#define CO_MAXN 24                         // ambiguities per composite factor
+#define CO_MAXN 64                         // ambiguities per composite factor (the reference's data model: 3 constellations x NFREQ 2 on up to MAXOBS 64
+                                           // satellites, R/gnss/include/common_function.h:24-37; 30..48 per gap is a normal open-sky epoch)
+#define CO_SMALLN 24                       // k_comp_elim / k_comp_eigroot are instantiated for <= 24 (36 KB of LDS, four workgroups per CU) and <= 64 ambiguities
 #define CO_MAXG (30 + CO_MAXN)
 
 struct CompArgs {
@@ -177,21 +179,23 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
 }
 
 // phase 3: re-elimination of the hidden epochs from the whitened IMU Jacobians of phase 2, remainder, square root
-__global__ void __launch_bounds__(256, 4) k_comp_elim(CompArgs A) {
+template <int NMAX>
+__global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(CompArgs A) {
     const int f = blockIdx.x, t = threadIdx.x;
     if (f >= A.n || !A.todo[f]) return;
     const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
     const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
-    __shared__ double pool[6 * 225 + 3 * 15 * CO_MAXN + CO_MAXN * CO_MAXN];            // ten elimination blocks, later the dense remainder + rhs row
+    constexpr int POOL_A = 6 * 225 + 3 * 15 * NMAX + NMAX * NMAX, POOL_B = (30 + NMAX) * (31 + NMAX);
+    __shared__ double pool[POOL_A > POOL_B ? POOL_A : POOL_B];                         // ten elimination blocks, later the dense remainder + rhs row
     double* const H00 = pool; double* const H01 = pool + 225; double* const H03 = pool + 450; double* const H11 = pool + 675;
-    double* const H13 = pool + 900; double* const H33 = pool + 1125; double* const H0N = pool + 1350; double* const H1N = H0N + 15 * CO_MAXN;
-    double* const HN3 = H1N + 15 * CO_MAXN; double* const HNN = HN3 + 15 * CO_MAXN;
+    double* const H13 = pool + 900; double* const H33 = pool + 1125; double* const H0N = pool + 1350; double* const H1N = H0N + 15 * NMAX;
+    double* const HN3 = H1N + 15 * NMAX; double* const HNN = HN3 + 15 * NMAX;
     double* const sD = pool;
-    __shared__ double r0b[15], r1b[15], rNb[CO_MAXN], r3b[15];
-    __shared__ double scratch[1260];                                       // sJ ; then Ainv | L | T2 | T0 | TN
+    __shared__ double r0b[15], r1b[15], rNb[NMAX], r3b[15];
+    __shared__ double scratch[900 + 15 * NMAX];                            // sJ ; then Ainv | L | T2 | T0 | TN (15 x N)
     double* const sJ = scratch + 450;
     double* const sAinv = scratch; double* const sL = scratch + 225; double* const T2 = scratch + 450; double* const T0 = scratch + 675; double* const TN = scratch + 900;
-    __shared__ double sRes[16], sdinv[CO_MAXG], sOut[32], sNv[CO_MAXN], sDx[16], sDx2[16];
+    __shared__ double sRes[16], sdinv[30 + NMAX], sOut[32], sNv[NMAX], sDx[16], sDx2[16];
     __shared__ int sBad;
     const int midk = A.mid[f]; const double* H12 = A.H12 + (size_t)f * 225;
     if (t < 32) sOut[t] = A.outer[(size_t)f * 32 + t];
@@ -413,15 +417,18 @@ __global__ void __launch_bounds__(256, 4) k_comp_elim(CompArgs A) {
 // singular vectors of R: a one-sided (Hestenes) Jacobi on the columns of R — G columns of length rank, 8 lanes per column pair,
 // round-robin pairing, V accumulated — never forms H again and keeps small eigenvalues to high relative accuracy.  One 256-thread
 // workgroup per factor; off by default (swf_composite_set_root / SWF_COMP_EIGEN_ROOT): it costs a few sweeps of G - 1 barrier steps.
-__global__ void __launch_bounds__(256) k_comp_eigroot(CompArgs A) {
+template <int NMAX>
+__global__ void __launch_bounds__(NMAX <= CO_SMALLN ? 256 : 512) k_comp_eigroot(CompArgs A) {
+    constexpr int NT = NMAX <= CO_SMALLN ? 256 : 512;          // 8 lanes per column pair: 32 / 64 pairs per step (G <= 54 / 94 columns)
     const int f = blockIdx.x, t = threadIdx.x;
     if (f >= A.n || !A.todo[f]) return;
     const int N = A.N[f], G = 30 + N;
     const long long g0 = A.g_off[f], g20 = A.g2_off[f];
-    __shared__ double Rm[CO_MAXG * CO_MAXG], Vm[CO_MAXG * CO_MAXG];      // column-major: column c at [c * G, c * G + G)
-    __shared__ double lam[CO_MAXG], rho[CO_MAXG], srd[CO_MAXG];
-    __shared__ int srank[CO_MAXG];
-    for (int e = t; e < G * G; e += 256) { Rm[e] = A.Ld[g20 + e]; int c = e / G, r = e - c * G; Vm[e] = c == r ? 1.0 : 0.0; }   // Ld[a * G + r] = component a of row r
+    constexpr int GM_ = 30 + NMAX;
+    __shared__ double Rm[GM_ * GM_], Vm[GM_ * GM_];      // column-major: column c at [c * G, c * G + G)
+    __shared__ double lam[GM_], rho[GM_], srd[GM_];
+    __shared__ int srank[GM_];
+    for (int e = t; e < G * G; e += NT) { Rm[e] = A.Ld[g20 + e]; int c = e / G, r = e - c * G; Vm[e] = c == r ? 1.0 : 0.0; }   // Ld[a * G + r] = component a of row r
     if (t < G) srd[t] = A.rd[g0 + t];
     __syncthreads();
     const int Ge = (G + 1) & ~1, np = Ge / 2;            // round-robin over an even number of players (a bye when G is odd)
@@ -462,7 +469,7 @@ __global__ void __launch_bounds__(256) k_comp_eigroot(CompArgs A) {
     __syncthreads();
     if (t < G) { int rk = 0; for (int j = 0; j < G; j++) if (lam[j] < lam[t] || (lam[j] == lam[t] && j < t)) rk++; srank[t] = rk; }
     __syncthreads();
-    for (int e = t; e < G * G; e += 256) {
+    for (int e = t; e < G * G; e += NT) {
         int k = e / G, a = e - k * G, row = srank[k];
         double v = lam[k] > 1e-8 ? sqrt(lam[k]) * Vm[k * G + a] : 0.0;
         A.Ld[g20 + (size_t)a * G + row] = v;
@@ -490,7 +497,7 @@ struct CompMeta {
     double* outer; double* Nv;      // = CompArgs.outer / .Nv
 };
 
-__global__ void __launch_bounds__(64) k_comp_gather(DevBatch B, CompArgs A, CompMeta Mt) {
+__global__ void __launch_bounds__(128) k_comp_gather(DevBatch B, CompArgs A, CompMeta Mt) {
     int f = blockIdx.x, t = threadIdx.x;
     if (f >= A.n) return;
     const WinState& s = B.ws[Mt.win[f]];

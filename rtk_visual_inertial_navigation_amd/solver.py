@@ -26,7 +26,8 @@ K_NAMES = ["total", "eval_ps", "eval_imu", "frame_sums", "eval_prior", "lm_schur
 class TimingC(C.Structure):
     _fields_ = [("ms", C.c_double * 16), ("calls", C.c_int32 * 16), ("jacobian_bytes", C.c_int64),
                 ("proj_bytes", C.c_int64), ("chol_flops", C.c_int64), ("lm_schur_flops", C.c_int64), ("n_obs", C.c_int64),
-                ("n_linearizations", C.c_int32), ("reserved", C.c_int32)]
+                ("n_linearizations", C.c_int32), ("reserved", C.c_int32),
+                ("lm_schur_flops_sym", C.c_int64), ("lm_schur_mfma", C.c_int64)]
 
 
 EXPORTED = [
@@ -52,6 +53,7 @@ EXPORTED = [
     "swf_get_parameter_blocks", "swf_get_parameter_blocks_for_residual_block", "swf_batch_export_jacobian",
     "swf_batch_marginal_priors", "swf_composite_assemble",
     "swf_composite_set_mid_links", "swf_composite_add_mid_prior", "swf_set_imu_gnss_mid_link", "swf_composite_set_root",
+    "swf_batch_create_on", "swf_batch_create_sharded", "swf_solve_batches", "swf_batch_device", "swf_default_options", "swf_shard_partition",
 ]
 
 
@@ -83,16 +85,28 @@ def set_device(d):
 
 
 class BatchSolver:
-    """A batch of flat windows resident on the current HIP device (swf_batch_*)."""
+    """A batch of flat windows resident on the current HIP device (swf_batch_*), or on `device` (swf_batch_create_on)."""
 
-    def __init__(self, windows, stream=None):
+    def __init__(self, windows, stream=None, device=None, _handle=None):
         self.windows = list(windows)
+        self.n = len(self.windows)
+        if _handle is not None:                      # adopted from swf_batch_create_sharded
+            self._structs = None
+            self._h = _handle
+            return
         self._structs = [w.c_struct() for w in self.windows]
         arr = (C.POINTER(FlatWindowC) * len(self._structs))(*[C.pointer(s) for s in self._structs])
         self._h = C.c_void_p()
-        _chk(lib().swf_batch_create(arr, C.c_int32(len(self._structs)), C.c_void_p(stream or 0), C.byref(self._h)),
-             "swf_batch_create")
-        self.n = len(self.windows)
+        if device is None:
+            _chk(lib().swf_batch_create(arr, C.c_int32(len(self._structs)), C.c_void_p(stream or 0), C.byref(self._h)), "swf_batch_create")
+        else:
+            _chk(lib().swf_batch_create_on(C.c_int32(device), arr, C.c_int32(len(self._structs)), C.c_void_p(stream or 0), C.byref(self._h)),
+                 "swf_batch_create_on")
+
+    def device(self):
+        d = C.c_int32(-1)
+        _chk(lib().swf_batch_device(self._h, C.byref(d)), "swf_batch_device")
+        return d.value
 
     def close(self):
         if self._h:
@@ -204,10 +218,42 @@ class BatchSolver:
         t = TimingC()
         _chk(lib().swf_batch_timing(self._h, C.byref(t)), "swf_batch_timing")
         d = dict(jacobian_bytes=t.jacobian_bytes, proj_bytes=t.proj_bytes, chol_flops=t.chol_flops,
-                 lm_schur_flops=t.lm_schur_flops, n_obs=t.n_obs,
+                 lm_schur_flops=t.lm_schur_flops, lm_schur_flops_sym=t.lm_schur_flops_sym, lm_schur_mfma=t.lm_schur_mfma, n_obs=t.n_obs,
                  n_linearizations=t.n_linearizations, total_ms=t.ms[0])
         d["kernels"] = {K_NAMES[k]: dict(ms=t.ms[k], calls=t.calls[k]) for k in range(16) if t.calls[k]}
         return d
+
+
+class ShardedBatchSolver:
+    """Windows sharded over the GPUs of one node from ONE process (swf_batch_create_sharded + swf_solve_batches): contiguous, near-equal
+    blocks per device of `device_mask` (0 = every visible device), no data-path collective, one host thread driving every device."""
+
+    def __init__(self, windows, device_mask=0):
+        self.windows = list(windows)
+        self._structs = [w.c_struct() for w in self.windows]
+        n = len(self._structs)
+        arr = (C.POINTER(FlatWindowC) * n)(*[C.pointer(s) for s in self._structs])
+        cap = max(1, device_count())
+        hs = (C.c_void_p * cap)(); first = (C.c_int32 * cap)(); count = (C.c_int32 * cap)(); nb = C.c_int32(0)
+        _chk(lib().swf_batch_create_sharded(arr, C.c_int32(n), C.c_uint32(device_mask), hs, first, count, C.byref(nb)), "swf_batch_create_sharded")
+        self.parts = [(first[k], count[k]) for k in range(nb.value)]
+        self.batches = [BatchSolver(self.windows[first[k]:first[k] + count[k]], _handle=C.c_void_p(hs[k])) for k in range(nb.value)]
+
+    def solve(self, opt=None, download=True):
+        self._opt = opt if opt is not None else default_options()
+        hs = (C.c_void_p * len(self.batches))(*[b._h for b in self.batches])
+        _chk(lib().swf_solve_batches(hs, C.c_int32(len(self.batches)), C.byref(self._opt)), "swf_solve_batches")
+        out = []
+        for b in self.batches:
+            if download:
+                b.download_state()
+            out += b.summaries()
+        return out
+
+    def close(self):
+        for b in self.batches:
+            b.close()
+        self.batches = []
 
 
 class Problem:

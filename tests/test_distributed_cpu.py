@@ -77,6 +77,13 @@ def test_strong_scaling_partition_covers_the_job_exactly():
         for (f0, c0), (f1, _) in zip(parts, parts[1:]):
             assert f1 == f0 + c0
         assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+        # the C-ABI's in-process sharding (swf_batch_create_sharded) deals the windows by the same rule
+        import ctypes
+        from rtk_visual_inertial_navigation_amd import solver
+        for r in range(world):
+            f_, c_ = ctypes.c_int32(-1), ctypes.c_int32(-1)
+            assert solver.lib().swf_shard_partition(ctypes.c_int32(n), ctypes.c_int32(world), ctypes.c_int32(r), ctypes.byref(f_), ctypes.byref(c_)) == 0
+            assert (f_.value, c_.value) == parts[r]
         seeds = sum((shard.window_seeds(synth.BASE_SEED, 4, c, first=f) for f, c in parts), [])
         assert seeds == [synth.BASE_SEED + 4 + i for i in range(n)]
     assert shard.partition(512, 8, 7) == (448, 64)

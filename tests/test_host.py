@@ -7,6 +7,7 @@ import re
 
 import numpy as np
 import pytest
+from rtk_visual_inertial_navigation_amd.flat import default_options
 
 from rtk_visual_inertial_navigation_amd import synth, solver, build
 from rtk_visual_inertial_navigation_amd.ordering import my_ordering
@@ -128,6 +129,63 @@ def test_ceres_shaped_cpp_example_runs_on_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Iterations:" in r.stdout
+
+
+def test_multi_gpu_example_compiles_and_the_c_defaults_match_the_python_ones(tmp_path):
+    """The in-process multi-device entry (swf_batch_create_sharded + swf_solve_batches) compiles from plain C++ against
+    include/swf_solver.h; swf_default_options fills the struct flat.default_options() fills.  Without a GPU the example reports it."""
+    import subprocess
+    exe = _compile_shim_example(tmp_path, "shim_multi_gpu")
+    from rtk_visual_inertial_navigation_amd.flat import OptionsC, default_options
+    o = OptionsC()
+    solver.lib().swf_default_options.restype = None
+    solver.lib().swf_default_options(ctypes.byref(o))
+    d = default_options()
+    for f, _ in OptionsC._fields_:
+        assert getattr(o, f) == getattr(d, f), f
+    if solver.device_count() == 0:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device" in r.stdout
+        w = synth.make_window(2, K=3, F=5, S=0, seed=3)
+        with pytest.raises(solver.SwfError):
+            solver.ShardedBatchSolver([w])
+
+
+@pytest.mark.gpu
+def test_multi_gpu_example_runs_on_gpu(tmp_path):
+    import subprocess
+    exe = _compile_shim_example(tmp_path, "shim_multi_gpu")
+    for mask in ("0", "1"):
+        r = subprocess.run([exe, mask], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "37 of 37 windows solved" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_batches_from_one_process_equal_one_batch_bitwise():
+    """swf_batch_create_sharded / swf_solve_batches: the windows dealt to the visible devices (here possibly one) and, separately, to two
+    batches created on the same device with swf_batch_create_on and solved through ONE swf_solve_batches call, give what one batch
+    gives, bit for bit (windows are independent units; a window's arithmetic does not depend on its batch)."""
+    ws = [synth.make_window(3, K=5 + (i % 3), F=20 + 3 * i, S=5, seed=70 + i) for i in range(7)]
+    ref = [w.copy() for w in ws]
+    bs = solver.BatchSolver(ref); sm_ref = bs.solve(default_options()); bs.close()
+    sh = [w.copy() for w in ws]
+    S = solver.ShardedBatchSolver(sh, device_mask=0)
+    assert sum(c for _, c in S.parts) == len(ws) and [f for f, _ in S.parts] == sorted(f for f, _ in S.parts)
+    assert all(b.device() in range(solver.device_count()) for b in S.batches)
+    sm = S.solve(default_options()); S.close()
+    two = [w.copy() for w in ws]
+    b0, b1 = solver.BatchSolver(two[:3], device=0), solver.BatchSolver(two[3:], device=solver.device_count() - 1)
+    hs = (ctypes.c_void_p * 2)(b0._h, b1._h)
+    opt = default_options()
+    assert solver.lib().swf_solve_batches(hs, ctypes.c_int32(2), ctypes.byref(opt)) == 0
+    b0.download_state(); b1.download_state()
+    sm2 = b0.summaries() + b1.summaries()
+    b0.close(); b1.close()
+    for a, b_, c, s0, s1, s2 in zip(ref, sh, two, sm_ref, sm, sm2):
+        assert s0.final_cost == s1.final_cost == s2.final_cost and s0.num_iterations == s1.num_iterations == s2.num_iterations
+        for k in ("pose", "sb", "lm", "sc"):
+            assert np.array_equal(a.a[k], b_.a[k]) and np.array_equal(a.a[k], c.a[k])
 
 
 def test_problem_bookkeeping_without_gpu():
