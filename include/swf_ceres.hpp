@@ -179,12 +179,12 @@ class Problem {
     void GetResidualBlocks(std::vector<ResidualBlockId>* out) const {
         int32_t n = 0; chk(swf_get_residual_blocks(h_, nullptr, 0, &n), "GetResidualBlocks");
         std::vector<swf_factor_id> ids((size_t)n); chk(swf_get_residual_blocks(h_, ids.data(), n, &n), "GetResidualBlocks");
-        out->clear(); for (swf_factor_id i : ids) out->push_back(rb_[(size_t)i].get());
+        out->clear(); for (swf_factor_id i : ids) out->push_back(handle_of(i));
     }
     void GetResidualBlocksForParameterBlock(const double* p, std::vector<ResidualBlockId>* out) const {
         int32_t n = 0; chk(swf_get_residual_blocks_for_parameter_block(h_, p, nullptr, 0, &n), "GetResidualBlocksForParameterBlock");
         std::vector<swf_factor_id> ids((size_t)n); chk(swf_get_residual_blocks_for_parameter_block(h_, p, ids.data(), n, &n), "GetResidualBlocksForParameterBlock");
-        out->clear(); for (swf_factor_id i : ids) out->push_back(rb_[(size_t)i].get());
+        out->clear(); for (swf_factor_id i : ids) out->push_back(handle_of(i));
     }
     void GetParameterBlocks(std::vector<double*>* out) const {
         int32_t n = 0; chk(swf_get_parameter_blocks(h_, nullptr, 0, &n), "GetParameterBlocks");
@@ -200,7 +200,7 @@ class Problem {
         if (rc != SWF_OK) return rc;
         std::vector<swf_factor_id> ids((size_t)n);
         if ((rc = swf_get_residual_blocks(h_, ids.data(), n, &n)) != SWF_OK) return rc;
-        for (swf_factor_id i : ids) if ((rc = swf_factor_set_enabled(h_, i, rb_[(size_t)i]->is_use ? 1 : 0)) != SWF_OK) return rc;
+        for (swf_factor_id i : ids) if ((rc = swf_factor_set_enabled(h_, i, handle_of(i)->is_use ? 1 : 0)) != SWF_OK) return rc;
         return SWF_OK;
     }
     void SetConstants(const double* pbg, const double* gw, const double* base) { chk(swf_set_constants(h_, pbg, gw, base), "SetConstants"); }
@@ -271,8 +271,16 @@ class Problem {
         rb_[(size_t)id]->id = id;
         return rb_[(size_t)id].get();
     }
+    // the handle of a live factor id; created on demand for factors that were added through handle() and the C API
+    // (is_use = true, like a freshly added block)
+    ResidualBlockId handle_of(swf_factor_id id) const {
+        if (id < 0) throw std::runtime_error("residual block id out of range");
+        if (rb_.size() <= (size_t)id) rb_.resize((size_t)id + 1);
+        if (!rb_[(size_t)id]) { rb_[(size_t)id].reset(new internal::ResidualBlock()); rb_[(size_t)id]->id = id; }
+        return rb_[(size_t)id].get();
+    }
     swf_problem* h_ = nullptr;
-    std::vector<std::unique_ptr<internal::ResidualBlock>> rb_;
+    mutable std::vector<std::unique_ptr<internal::ResidualBlock>> rb_;
 };
 
 struct Solver {
@@ -346,7 +354,7 @@ struct MarginalPrior {
     const double* A = nullptr; const double* b = nullptr;
     int n = 0, rank = 0;
 };
-// eigen = true: the reference's eigen square root (n <= 140); false: the Cholesky square root (same quadratic, cheaper)
+// eigen = true: the reference's eigen square root (tails up to 640 dimensions); false: the Cholesky square root (same quadratic, cheaper)
 inline bool UpdateSchurAndSetMarginalizeInfo(Problem* p, MarginalPrior* out, bool eigen = true, double eps = 1e-8) {
     int32_t n = 0, rank = 0;
     int rc = swf_problem_marginalize(p->handle(), eps, eigen ? SWF_PRIOR_EIGEN : SWF_PRIOR_CHOLESKY, &out->linearized_jacobians,

@@ -288,10 +288,13 @@ int swf_composite_destroy(swf_composite* c);
  * swf_composite_assemble: IMUGNSSBase::AddMargInfo (R/factor/gnss_imu_factor.cpp:245-352) for a chain of M epochs — pure host
  * bookkeeping.  Epoch e keeps n_kept[e] blocks; kept_size (7 / 9 / 1) and kept_key (the block's address; only the scalars' are
  * looked at) are concatenated over the epochs in prior order, as are A (dim_e^2) and b (dim_e).  The scalar blocks become the
- * factor's ambiguities in first-seen order: *N_out of them, their keys in N_keys.  Hpp [M][225], HpN [M][15][N], rhs_p [M][15],
- * HNN [N][N], rhsN [N] receive what swf_add_imu_gnss / swf_flat_window::comp_* expect (pose rows 0..5, speed-bias rows 6..14 of
- * an epoch's 15-block; the N x N block and its right-hand side accumulate over the epochs).  Passing Hpp = NULL only counts
- * (*N_out).  N_cap = the N the caller sized HpN / HNN / rhsN / N_keys for.
+ * factor's ambiguities in first-seen order: *N_out of them, their keys in N_keys.  Hpp [M][225], HpN [M][15][N_cap], rhs_p [M][15],
+ * HNN [N_cap][N_cap], rhsN [N_cap] receive what swf_add_imu_gnss / swf_flat_window::comp_* expect (pose rows 0..5, speed-bias rows
+ * 6..14 of an epoch's 15-block; the N x N block and its right-hand side accumulate over the epochs).  Passing Hpp = NULL only counts
+ * (*N_out).  N_cap = the N the caller sized HpN / HNN / rhsN / N_keys for — and the STRIDE of their ambiguity dimension, here and in
+ * swf_composite_add_mid_prior alike (so the two calls chain on the same buffers; compact to *N_out / *N_io before handing the arrays
+ * to swf_add_imu_gnss if N_cap was larger).  swf_batch_marginal_priors reports a window whose marginal could not be formed with
+ * ranks[i] = -1 (and zeros in its slots): check the ranks before filing the priors into a composite factor.
  * ===================================================================================== */
 int swf_batch_marginal_priors(const swf_flat_window* const* windows, int32_t n, double eps, int32_t form,
                               int32_t* dims, int32_t* ranks, double* A, double* b, double* J, double* r0, void* stream);

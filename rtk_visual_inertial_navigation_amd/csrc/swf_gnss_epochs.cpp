@@ -89,8 +89,12 @@ int swf_composite_assemble(int32_t M, const int32_t* n_kept, const int32_t* kept
     if (!Hpp || !HpN || !rhs_p || !HNN || !rhsN) return SWF_OK;          // sizing call
     if (N > N_cap) return efail(SWF_E_INVALID, "swf_composite_assemble: more ambiguity blocks than the caller's buffers hold");
     if (N_keys) for (int i = 0; i < N; i++) N_keys[i] = keys[(size_t)i];
-    memset(Hpp, 0, sizeof(double) * (size_t)M * 225); memset(HpN, 0, sizeof(double) * (size_t)M * 15 * N); memset(rhs_p, 0, sizeof(double) * (size_t)M * 15);
-    memset(HNN, 0, sizeof(double) * (size_t)N * N); memset(rhsN, 0, sizeof(double) * (size_t)N);
+    // one stride convention for both bookkeeping calls: the ambiguity dimension of HpN / HNN / rhsN is laid out for N_cap columns (what
+    // the caller sized them for), here and in swf_composite_add_mid_prior — a caller that leaves room for ambiguities a later middle
+    // marginalisation introduces chains the two calls on the same buffers
+    const size_t ldN = (size_t)N_cap;
+    memset(Hpp, 0, sizeof(double) * (size_t)M * 225); memset(HpN, 0, sizeof(double) * (size_t)M * 15 * ldN); memset(rhs_p, 0, sizeof(double) * (size_t)M * 15);
+    memset(HNN, 0, sizeof(double) * ldN * ldN); memset(rhsN, 0, sizeof(double) * ldN);
     // pass 2: scatter every epoch's prior (A_e over its kept blocks' local coordinates, b_e) — :299-347
     size_t q0 = 0, oA = 0, ob = 0;
     for (int e = 0; e < M; e++) {
@@ -108,7 +112,7 @@ int swf_composite_assemble(int32_t M, const int32_t* n_kept, const int32_t* kept
         }
         if (n_pose > 1 || n_sb > 1) return efail(SWF_E_INVALID, "swf_composite_assemble: an epoch's prior keeps more than one pose or speed-bias");
         const double* Ae = A + oA; const double* be = b + ob;
-        double* Hp = Hpp + (size_t)e * 225; double* HN = HpN + (size_t)e * 15 * N; double* rp = rhs_p + (size_t)e * 15;
+        double* Hp = Hpp + (size_t)e * 225; double* HN = HpN + (size_t)e * 15 * ldN; double* rp = rhs_p + (size_t)e * 15;
         for (int k1 = 0; k1 < nk; k1++) {
             const int d1 = dst[(size_t)k1], s1 = d1 == -1 ? 0 : 6;            // row shift inside the 15-block
             for (int i = 0; i < len[(size_t)k1]; i++) {
@@ -118,9 +122,9 @@ int swf_composite_assemble(int32_t M, const int32_t* n_kept, const int32_t* kept
                     const int d2 = dst[(size_t)k2], s2 = d2 == -1 ? 0 : 6;
                     for (int j = 0; j < len[(size_t)k2]; j++) {
                         const double v = Ae[(size_t)r * dim + off[(size_t)k2] + j];
-                        if (d1 >= 0 && d2 >= 0) HNN[(size_t)d1 * N + d2] += v;
+                        if (d1 >= 0 && d2 >= 0) HNN[(size_t)d1 * ldN + d2] += v;
                         else if (d1 < 0 && d2 < 0) Hp[(s1 + i) * 15 + s2 + j] += v;
-                        else if (d1 < 0 && d2 >= 0) HN[(size_t)(s1 + i) * N + d2] += v;
+                        else if (d1 < 0 && d2 >= 0) HN[(size_t)(s1 + i) * ldN + d2] += v;
                         // (d1 >= 0, d2 < 0) is the transpose of the case above: the factor stores H_pN only
                     }
                 }

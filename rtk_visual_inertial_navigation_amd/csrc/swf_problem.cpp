@@ -504,6 +504,7 @@ static void scatter_values(swf_problem* p) {     // Double2Vector direction; con
 int swf_problem_solve(swf_problem* p, const swf_options* opt, swf_summary* summary) {
     if (!p || !opt || !summary) return SWF_E_INVALID;
     int rc;
+    p->solved = false;                             // consumers (marginalize, tail covariance, get_reduced) answer only for a solve that went through
     const bool trace = getenv("SWF_TRACE_REBUILD") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();

@@ -536,10 +536,11 @@ class CompositeBatch:
             pass
 
 
-def marginal_priors(windows, eps=1e-8, form=0, timing=None):
+def marginal_priors(windows, eps=1e-8, form=0, timing=None, allow_failed=False):
     """swf_batch_marginal_priors: the linear prior over each window's parameter_head tail with everything else eliminated
     (GnssPreprocess's per-epoch marginalize, R/swf/swf_gnss.cpp:504-532), for all windows in one batch on the device.
-    Returns a list of dict(n, rank, A, b, J, r0)."""
+    Returns a list of dict(n, rank, A, b, J, r0).  A window whose marginal could not be formed comes back with rank -1 and zeros:
+    that raises here unless allow_failed (such a prior must not be filed into a composite factor)."""
     structs = [w.c_struct() for w in windows]
     arr = (C.POINTER(FlatWindowC) * len(structs))(*[C.pointer(s) for s in structs])
     n = len(structs)
@@ -555,6 +556,8 @@ def marginal_priors(windows, eps=1e-8, form=0, timing=None):
                                          A.ctypes.data_as(_pd), b.ctypes.data_as(_pd), J.ctypes.data_as(_pd), r0.ctypes.data_as(_pd), None), "swf_batch_marginal_priors")
     if timing is not None:
         timing["c_abi_call_s"] = _time.perf_counter() - t0          # the C-ABI call alone (structure upload, solve, consumer, download), without this wrapper's marshalling
+    if not allow_failed and (ranks < 0).any():
+        raise SwfError("swf_batch_marginal_priors: no marginal for window(s) %s (rank -1: failed elimination)" % np.nonzero(ranks < 0)[0].tolist())
     out, o2, o1 = [], 0, 0
     for i in range(n):
         d = int(dims[i])

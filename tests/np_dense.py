@@ -45,7 +45,6 @@ def factor_list(w):
     idp, prior), as dict(kind, nres, blocks = global block ids, fun(*block values) -> RAW residual (no loss), loss_a,
     fd = finite-difference step per block, quirk = what the reference's analytic Jacobian leaves out (asserted, not fixed))."""
     a = w.a
-    assert a["comp_M"].size == 0, "composite factors have no numpy restatement here"
     si, pbg, gw, base = w.proj_sqrt_info, w.pbg, w.gw, w.base
     out = []
     add = lambda **k: out.append(k)
@@ -96,7 +95,67 @@ def factor_list(w):
         add(kind="prior", nres=int(dim), blocks=ids, loss_a=0.0, fd=[1e-6] * len(ids),
             fun=lambda *v, J=J, r0=r0, x0s=x0s: r0 + J @ np.concatenate([prior_dx(x, x0) for x, x0 in zip(v, x0s)]))
         bo += nb; jo += dim * dim; ro += dim
+    # composite IMU-GNSS factors (IMUGNSSBase, R/factor/gnss_imu_factor.cpp): no per-row restatement — the exposed rows are a square
+    # root, unique only up to an orthogonal factor — but what they must reproduce is defined by plain elimination: J^T J and J^T r are
+    # the Schur complement / reduced gradient of the dense Gauss-Newton system over [outer blocks | hidden GNSS epochs] (composite_dense
+    # below: numpy IMU residuals + central differences, the per-epoch priors and the middle-marginalisation cross term as plain algebra)
+    e0 = io = pn0 = nn0 = n0 = 0
+    for k, (M, N) in enumerate(zip(a["comp_M"], a["comp_N"])):
+        M, N = int(M), int(N)
+        ix = a["comp_idx"][io:io + 4 + N]
+        blocks = [w.bid_pose(ix[0]), w.bid_sb(ix[1]), w.bid_pose(ix[2]), w.bid_sb(ix[3])] + [w.bid_sc(q) for q in ix[4:]]
+        c = dict(M=M, N=N, pose=a["comp_pose"].reshape(-1, 7)[e0:e0 + M], sb=a["comp_sb"].reshape(-1, 9)[e0:e0 + M],
+                 pose_lin=a["comp_pose_lin"].reshape(-1, 7)[e0:e0 + M], sb_lin=a["comp_sb_lin"].reshape(-1, 9)[e0:e0 + M],
+                 Hpp=a["comp_Hpp"].reshape(-1, 15, 15)[e0:e0 + M], HpN=a["comp_HpN"][pn0:pn0 + 15 * M * N].reshape(M, 15, N),
+                 rhs_p=a["comp_rhs_p"].reshape(-1, 15)[e0:e0 + M], HNN=a["comp_HNN"][nn0:nn0 + N * N].reshape(N, N), rhsN=a["comp_rhsN"][n0:n0 + N],
+                 pre=a["comp_pre"].reshape(-1, PRE)[e0 + k:e0 + k + M + 1], mid=int(a["comp_mid"][k]) if a["comp_mid"].size else 0,
+                 H12=a["comp_H12"].reshape(-1, 15, 15)[k] if a["comp_H12"].size else np.zeros((15, 15)), pbg=pbg, gw=gw)
+        add(kind="comp", nres=30 + N, blocks=blocks, loss_a=0.0, fd=[None] * len(blocks), comp=c,
+            fun=lambda *v: (_ for _ in ()).throw(NotImplementedError("a composite factor's rows are a square root: compare J^T J, J^T r (composite_dense)")))
+        e0 += M; io += 4 + N; pn0 += 15 * M * N; nn0 += N * N; n0 += N
     return out
+
+
+def _inc15(P, B, P0, B0):
+    """x (-) x0 = [p - p0, +-2 vec(q0^-1 q), sb - sb0] (GetInc, R/factor/gnss_imu_factor.cpp:654-670)."""
+    return np.concatenate([prior_dx(P, P0), B - B0])
+
+
+def composite_dense(c, Pi, Bi, Pj, Bj, Nv):
+    """(S, g) the composite factor must expose at the given outer states: Schur complement and reduced gradient, onto
+    z_o = [pose_i sb_i | pose_j sb_j | N ambiguities] (local coordinates), of the dense Gauss-Newton system of everything the factor
+    hides — the M + 1 IMU factors of the chain frame_i -> e_0 -> ... -> e_M-1 -> frame_j (numpy residuals, central differences on the
+    manifold), each hidden epoch's linearised GNSS prior 1/2 dx^T Hpp dx + dx^T (HpN N + rhs_p) (dx = e (-) e_lin), the ambiguity block
+    1/2 N^T HNN N + N^T rhsN, and the cross term dx_{k-1}^T H12 dx_k of a middle marginalisation on link k.  Nothing here is shared with
+    the oracle or the kernels."""
+    M, N = c["M"], c["N"]
+    G = 30 + N; n = G + 15 * M
+    H, g = np.zeros((n, n)), np.zeros(n)
+    off = lambda k: G + 15 * k
+    chain = [(Pi, Bi, 0)] + [(c["pose"][k], c["sb"][k], off(k)) for k in range(M)] + [(Pj, Bj, 15)]
+    for k in range(M + 1):
+        (pa, ba, oa), (pb, bb, obf) = chain[k], chain[k + 1]
+        if c["mid"] and k == c["mid"]:
+            d1 = _inc15(pa, ba, c["pose_lin"][k - 1], c["sb_lin"][k - 1]); d2 = _inc15(pb, bb, c["pose_lin"][k], c["sb_lin"][k])
+            H[oa:oa + 15, obf:obf + 15] += c["H12"]; H[obf:obf + 15, oa:oa + 15] += c["H12"].T
+            g[oa:oa + 15] += c["H12"] @ d2; g[obf:obf + 15] += c["H12"].T @ d1
+            continue
+        fun = lambda A, B, Cc, D, pre=c["pre"][k]: nf.imu_residual(A, B, Cc, D, pre, c["pbg"], c["gw"])
+        vals = [pa, ba, pb, bb]
+        r = fun(*vals)
+        J = np.zeros((15, n))
+        J[:, oa:oa + 6] = nf.fd_jac(fun, vals, 0, 1e-6); J[:, oa + 6:oa + 15] = nf.fd_jac(fun, vals, 1, 1e-6)
+        J[:, obf:obf + 6] = nf.fd_jac(fun, vals, 2, 1e-6); J[:, obf + 6:obf + 15] = nf.fd_jac(fun, vals, 3, 1e-6)
+        H += J.T @ J; g += J.T @ r
+    for k in range(M):
+        dx = _inc15(c["pose"][k], c["sb"][k], c["pose_lin"][k], c["sb_lin"][k])
+        o = off(k)
+        H[o:o + 15, o:o + 15] += c["Hpp"][k]; H[o:o + 15, 30:G] += c["HpN"][k]; H[30:G, o:o + 15] += c["HpN"][k].T
+        g[o:o + 15] += c["rhs_p"][k] + c["Hpp"][k] @ dx + c["HpN"][k] @ Nv
+        g[30:G] += c["HpN"][k].T @ dx
+    H[30:G, 30:G] += c["HNN"]; g[30:G] += c["rhsN"] + c["HNN"] @ Nv
+    Hoo, Hoh, Hhh = H[:G, :G], H[:G, G:], H[G:, G:]
+    return Hoo - Hoh @ np.linalg.solve(Hhh, Hoh.T), g[:G] - Hoh @ np.linalg.solve(Hhh, g[G:])
 
 
 def window_cost(w):
@@ -104,6 +163,10 @@ def window_cost(w):
     blks = blocks_of(w)
     c = 0.0
     for f in factor_list(w):
+        if f["kind"] == "comp":             # r^T r of a composite factor is g^T S^+ g of its remaining system
+            S_, g_ = composite_dense(f["comp"], *[blks[b] for b in f["blocks"][:4]], np.array([blks[b][0] for b in f["blocks"][4:]]))
+            c += 0.5 * float(g_ @ np.linalg.lstsq(S_, g_, rcond=1e-13)[0])
+            continue
         r = np.atleast_1d(f["fun"](*[blks[b] for b in f["blocks"]]))
         c += 0.5 * _rho(r @ r, f["loss_a"])
     return c
@@ -124,6 +187,22 @@ def check_linearization(w, r_exp, J_exp, label=""):
     n_checked = 0
     for fi, f in enumerate(factor_list(w)):
         vals = [blks[b] for b in f["blocks"]]
+        if f["kind"] == "comp":
+            # the exposed rows against plain elimination: J^T J = S, J^T r = g_red over the factor's own columns (block order of the factor);
+            # tolerance = that of the central-difference IMU Jacobians inside S (5e-5, as for the plain IMU factor below)
+            G = f["nres"]
+            S_np, g_np = composite_dense(f["comp"], vals[0], vals[1], vals[2], vals[3], np.array([v[0] for v in vals[4:]]))
+            cols = np.concatenate([np.arange(loc[b], loc[b] + l[b]) if loc[b] >= 0 else np.full(l[b], -1) for b in f["blocks"]])
+            assert (cols >= 0).all(), "composite factor on a constant block"
+            Je = J_exp[row:row + G][:, cols]; re = r_exp[row:row + G]
+            sc = np.abs(S_np).max()
+            assert np.abs(Je.T @ Je - S_np).max() <= 2e-4 * sc, (label, "comp", fi, np.abs(Je.T @ Je - S_np).max() / sc)
+            assert np.abs(Je.T @ re - g_np).max() <= 2e-4 * (np.abs(g_np).max() + 1e-3 * sc), (label, "comp", fi)
+            touched = np.zeros(n_loc, bool); touched[cols] = True
+            assert not J_exp[row:row + G, ~touched].any(), (label, "comp", fi)
+            n_checked += len(f["blocks"])
+            row += G
+            continue
         r = np.atleast_1d(f["fun"](*vals))
         sr = 1.0
         if f["loss_a"] > 0:

@@ -632,9 +632,19 @@ def test_cfg5_prior_obtained_by_marginalising_a_41st_frame():
     assert info["rank"] == info["prior_dim"] and info["prior_dim"] >= 6 + 9 + 20 + 6 * 8
     c = w5.counts()
     assert c["n_pose"] == 41 and c["n_lm"] > 900 and c["n_cp"] == 800
+    w5o = w5.copy()
     bs, s5 = gpu_solve(w5, default_options())
     bs.close()
     assert s5.termination in (1, 2, 3, 4) and s5.final_cost < 1e-3 * s5.initial_cost
+    # ... and, once, the full-size window with its 263-dimension marginalised prior against the oracle's own solve: same accept / reject
+    # sequence, costs and final states (until now only properties were checked at this size)
+    s5o, _ = ob.solve(w5o, default_options(), export=False)
+    assert s5o.termination == s5.termination and s5o.num_iterations == s5.num_iterations
+    assert [r["step_is_successful"] for r in s5.rows()] == [r["step_is_successful"] for r in s5o.rows()]
+    assert abs(s5.rows()[0]["cost"] - s5o.rows()[0]["cost"]) <= 1e-11 * s5o.rows()[0]["cost"]
+    for a, b in zip(s5.rows(), s5o.rows()):
+        assert abs(a["cost"] - b["cost"]) <= 2e-6 * abs(b["cost"]) + 5e-5
+    assert np.abs(w5.a["pose"] - w5o.a["pose"]).max() < 1e-6 and np.abs(w5.a["sb"] - w5o.a["sb"]).max() < 1e-5
 
 
 def test_full_size_properties_cfg5_and_batch():

@@ -277,6 +277,17 @@ def test_composite_imu_gnss_factor_equals_dense_elimination_of_its_hidden_states
         F.close()
 
 
+def test_oracle_composite_rows_vs_independent_numpy_elimination():
+    """The same independent check the device gets (tests/test_gpu_independent.py), on the oracle's exported rows: a window in the reference's
+    RTK topology; every composite factor's J^T J / J^T r against tests/np_dense.py::composite_dense."""
+    import composite_gen as cg
+    import np_dense as nd
+    rng = np.random.default_rng(91)
+    for w in (cg.make_window(rng, 4, 3, 6), cg.make_window(rng, 4, 5, 6, mid=True)):
+        r, J = ob.export_jacobian(w.copy())
+        assert nd.check_linearization(w, r, J, "oracle:composite") >= 4 * len(w.a["comp_M"])
+
+
 def test_oracle_solver_invariants(win3):
     w = win3.copy()
     sm, ex = ob.solve(w, default_options(max_num_iterations=8))

@@ -1,0 +1,26 @@
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+import numpy as np
+import test_rtk_topology as T
+from rtk_visual_inertial_navigation_amd import solver
+from rtk_visual_inertial_navigation_amd.flat import default_options
+import oracle_binding as ob
+rt = T.rt
+for kw in T.CASES:
+    wx, vis, hid = rt.explicit_window(**kw)
+    ews, kept = rt.epoch_windows(wx)
+    po = T.oracle_epoch_priors(ews)
+    wo = rt.composite_window(wx, T.build_chains(wx, kept, po, rt.assemble_np))
+    w_or = wo.copy()
+    so, _ = ob.solve(w_or, default_options(max_num_iterations=30), export=False)
+    for root in ("pivoted", "eigen"):
+        if root == "eigen": os.environ["SWF_COMP_EIGEN_ROOT"] = "1"
+        else: os.environ.pop("SWF_COMP_EIGEN_ROOT", None)
+        wd = wo.copy()
+        bs = solver.BatchSolver([wd]); sd = bs.solve(default_options(max_num_iterations=30))[0]; bs.close()
+        ro, rd = so.rows(), sd.rows()
+        same = [r["step_is_successful"] for r in rd] == [r["step_is_successful"] for r in ro]
+        dc = [abs(a["cost"] - b["cost"]) / (abs(b["cost"]) + 1e-3) for a, b in zip(rd, ro)]
+        print(root, "iters", len(rd), len(ro), "same accept seq", same, "max dcost %.2e" % max(dc), "first3 %s" % ["%.1e" % x for x in dc[:4]],
+              "dpose %.2e" % np.abs(wd.a["pose"] - w_or.a["pose"]).max(), "dhidden %.2e" % np.abs(wd.a["comp_pose"] - w_or.a["comp_pose"]).max(),
+              "final cost %.6e vs %.6e" % (sd.final_cost, so.final_cost))
