@@ -85,6 +85,25 @@ struct Pair {
     long long q_base;            // the window's landmark rhs partials in DevBatch::lmq (GEMM_SPLIT vectors of m doubles)
 };
 
+// ---- assembly program of a window (k_assemble_flat): one thread per entry of the reduced system that receives anything, one
+// per reduced dimension for the vectors.  The tables hold window-RELATIVE offsets, so windows of identical structure (a batch
+// of one configuration) share one copy, which then lives in L2.
+struct AsmWin {
+    int se0, ne;                 // S-entry range in the shared tables
+    int ve0, nv;                 // vector-entry range
+    int n_red, m;                // reduced dimension; 6 nF
+    int loc_base;                // first local dimension of the window's REDUCED part (g / diag / vc / rhs / jsc)
+    int fs_base;                 // first frame-sum row of the window (fs_part rows of 27 doubles)
+    int v_base;                  // first clique-vector slot of the window (cv_graw / cv_dgraw / cv_cs)
+    int win;
+    long long C_base, S_base, P_base, q_base;
+};
+#define AS_NC(c) ((c) & 4095u)
+#define AS_NP(c) (((c) >> 12) & 31u)
+#define AS_NH(c) (((c) >> 17) & 4095u)
+#define AS_DIAG(c) (((c) >> 29) & 1u)
+#define AS_SOLD(c) (((c) >> 30) & 1u)
+
 struct DevBatch {
     int n_win;
     int n_x, n_loc_total;
@@ -155,6 +174,10 @@ struct DevBatch {
     int n_pair;
     const long long* pc_coff; const int* pc_cld; const int* pc_voff;
     int n_pd, n_po; const Pair* pair_d; const Pair* pair_o;   // diagonal / off-diagonal pair records (the latter sorted by size)
+    // assembly programs (k_assemble_flat)
+    const AsmWin* asw; int as_max_ne, as_max_nv;
+    const int* as_dst; const unsigned* as_cnt; const int* as_src0; const int* as_aux; const int* as_src;
+    const int* av_loc; const int* av_red; const unsigned* av_cnt; const int* av_src0; const int* av_i; const int* av_src;
 };
 
 // ------------------------------------------------------------------ device math

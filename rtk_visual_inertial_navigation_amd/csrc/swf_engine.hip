@@ -225,6 +225,9 @@ struct swf_batch {
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
+    bool fs_fused = true;                 // per-frame sums inside k_eval_ps (SWF_FS_SEPARATE=1: k_frame_sums as its own launch; A/B testing)
+    bool asm_old = false;                 // SWF_ASM_OLD=1: the pair-walking assembly kernel instead of the flat program (A/B testing)
+    int asm_programs = 0;                 // distinct assembly programs of the batch (windows of identical structure share one)
     int ls_qpb = 1, ls_var = 0, ls_kms = 8; bool ls_folded = false, s_direct = false;     // k_lm_schur launch shape, fixed at creation (the pair lists depend on it)
     int timing = 0;                       // bitmask of SWF_K_* brackets
     swf_timing last{};
@@ -818,6 +821,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->stream = (hipStream_t)stream;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
+    b->asm_old = getenv("SWF_ASM_OLD") != nullptr;
+    b->fs_fused = getenv("SWF_FS_SEPARATE") == nullptr;
     // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
     // fills what one-block-per-window kernels leave idle (measured: 256 windows 5.52 -> 5.22 ms, 128 windows 3.73 -> 3.49 ms per solve; 64 and
     // 512 windows: no gain)
@@ -1029,6 +1034,99 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             for (int q = c.fac0; q < c.fac1; q++) if (B.gf[B.cl_fac[q]].type == GF_IMU) b->clc_imu[cls] = true;
         }
         D.n_pd = (int)pd.size(); D.n_po = (int)po.size(); D.n_cle = (int)cle.size();
+        {
+            // ---- assembly programs (k_assemble_flat): every pair of the two lists above, flattened into per-entry source lists with
+            // window-relative offsets; windows whose programs come out identical share one copy.  Entry order inside a window: the
+            // window's pairs in pair order, (i, j) row-major — any order would do, every entry is written by exactly one thread.
+            const int n_part = b->s_direct ? 0 : b->ls_folded ? 1 : GEMM_SPLIT, n_qpart = b->ls_folded ? 1 : GEMM_SPLIT;
+            struct Prog { std::vector<int> dst, src0, aux, src, vloc, vred, vsrc0, vi, vsrc; std::vector<unsigned> cnt, vcnt; };
+            std::vector<AsmWin> asw((size_t)n);
+            std::vector<int> t_dst, t_src0, t_aux, t_src, tv_loc, tv_red, tv_src0, tv_i, tv_src; std::vector<unsigned> t_cnt, tv_cnt;
+            std::map<std::vector<int>, std::array<int, 4>> seen;           // serialised program -> (se0, ne, ve0, nv)
+            std::vector<std::vector<int>> wpairs((size_t)n);
+            for (int i : pd) wpairs[(size_t)B.pair[i].win].push_back(i);
+            for (int i : po) wpairs[(size_t)B.pair[i].win].push_back(i);
+            bool overflow = false;
+            for (int w = 0; w < n; w++) {
+                const WinRec& Rw = B.win[w];
+                AsmWin& A = asw[(size_t)w];
+                A.win = w; A.n_red = Rw.n_red; A.m = 6 * Rw.nF; A.loc_base = Rw.loc_base; A.S_base = Rw.S_base;
+                A.P_base = Rw.P_base * GEMM_SPLIT; A.q_base = (long long)6 * Rw.fr_base * GEMM_SPLIT;
+                A.fs_base = Rw.fsb1 > Rw.fsb0 ? B.fsb_out0[(size_t)Rw.fsb0] : 0;
+                long long Cb = -1; int vb = -1;
+                for (int c = Rw.cl0; c < Rw.cl1; c++) { if (Cb < 0 || B.cl[c].C_off < Cb) Cb = B.cl[c].C_off; if (vb < 0 || B.cl[c].v_off < vb) vb = B.cl[c].v_off; }
+                A.C_base = Cb < 0 ? 0 : Cb; A.v_base = vb < 0 ? 0 : vb;
+                Prog Pg;
+                const int nfsb = Rw.fsb1 - Rw.fsb0, mm = A.m;
+                for (int pi_ : wpairs[(size_t)w]) {
+                    const Pair& Pq = B.pair[(size_t)pi_];
+                    const bool frame_pair = Pq.fa >= 0 && Pq.fb >= 0, obs = Pq.is_diag && Pq.fa >= 0;
+                    const int ncon = Pq.c1 - Pq.c0;
+                    for (int i = 0; i < Pq.la; i++) for (int j = 0; j < Pq.lb; j++) {
+                        if (Pq.is_diag && j > i) continue;                  // lower half only; the mirror is the host's job at export
+                        const bool dg = Pq.is_diag && i == j;
+                        const int nP = frame_pair ? n_part : 0, nH = obs ? nfsb : 0;
+                        if (ncon > 4095 || nH > 4095) overflow = true;
+                        Pg.dst.push_back((Pq.ra + i) * Pq.n + Pq.rb + j);
+                        Pg.cnt.push_back((unsigned)ncon | ((unsigned)nP << 12) | ((unsigned)nH << 17) | ((dg ? 1u : 0u) << 29) | ((frame_pair && b->s_direct ? 1u : 0u) << 30));
+                        Pg.src0.push_back((int)Pg.src.size());
+                        Pg.aux.push_back(dg ? (Pq.loc_a - Rw.loc_base) + i : 0);
+                        for (int c = Pq.c0; c < Pq.c1; c++) Pg.src.push_back((int)(B.pc_coff[(size_t)c] + (long long)i * B.pc_cld[(size_t)c] + j - A.C_base));
+                        if (nP) {
+                            const int pr = 6 * Pq.fa + i, pc = 6 * Pq.fb + j;
+                            const long long pel = pr >= pc ? (long long)pr * mm + pc : (long long)pc * mm + pr;
+                            for (int q = 0; q < nP; q++) Pg.src.push_back((int)((long long)q * mm * mm + pel));
+                        }
+                        if (nH) {
+                            const int hi = i > j ? i : j, lo = i > j ? j : i;
+                            for (int k2 = Rw.fsb0; k2 < Rw.fsb1; k2++) Pg.src.push_back((B.fsb_out0[(size_t)k2] - A.fs_base + Pq.fa) * FS_VAL + hi * (hi + 1) / 2 + lo);
+                        }
+                        if (dg) for (int c = Pq.c0; c < Pq.c1; c++) Pg.src.push_back(B.pc_voff[(size_t)c] + i - A.v_base);
+                    }
+                    if (!Pq.is_diag) continue;
+                    for (int i = 0; i < Pq.la; i++) {
+                        const int nH = obs ? nfsb : 0, nQ = obs ? n_qpart : 0;
+                        Pg.vloc.push_back(Pq.loc_a - Rw.loc_base + i); Pg.vred.push_back(Pq.ra + i); Pg.vi.push_back(obs ? i : 0);
+                        Pg.vcnt.push_back((unsigned)ncon | ((unsigned)nQ << 12) | ((unsigned)nH << 17));
+                        Pg.vsrc0.push_back((int)Pg.vsrc.size());
+                        if (nH) for (int k2 = Rw.fsb0; k2 < Rw.fsb1; k2++) Pg.vsrc.push_back((B.fsb_out0[(size_t)k2] - A.fs_base + Pq.fa) * FS_VAL);
+                        for (int c = Pq.c0; c < Pq.c1; c++) Pg.vsrc.push_back(B.pc_voff[(size_t)c] + i - A.v_base);
+                        for (int q = 0; q < nQ; q++) Pg.vsrc.push_back(q * mm + 6 * Pq.fa + i);
+                    }
+                }
+                // serialise and look up
+                std::vector<int> key;
+                key.reserve(Pg.dst.size() * 4 + Pg.src.size() + Pg.vloc.size() * 5 + Pg.vsrc.size() + 8);
+                key.push_back((int)Pg.dst.size()); key.push_back((int)Pg.vloc.size());
+                key.insert(key.end(), Pg.dst.begin(), Pg.dst.end()); for (unsigned c : Pg.cnt) key.push_back((int)c);
+                key.insert(key.end(), Pg.src0.begin(), Pg.src0.end()); key.insert(key.end(), Pg.aux.begin(), Pg.aux.end()); key.insert(key.end(), Pg.src.begin(), Pg.src.end());
+                key.insert(key.end(), Pg.vloc.begin(), Pg.vloc.end()); key.insert(key.end(), Pg.vred.begin(), Pg.vred.end()); for (unsigned c : Pg.vcnt) key.push_back((int)c);
+                key.insert(key.end(), Pg.vsrc0.begin(), Pg.vsrc0.end()); key.insert(key.end(), Pg.vi.begin(), Pg.vi.end()); key.insert(key.end(), Pg.vsrc.begin(), Pg.vsrc.end());
+                auto it = seen.find(key);
+                if (it == seen.end()) {
+                    const int se0 = (int)t_dst.size(), ve0 = (int)tv_loc.size(), so = (int)t_src.size(), vo = (int)tv_src.size();
+                    t_dst.insert(t_dst.end(), Pg.dst.begin(), Pg.dst.end()); t_cnt.insert(t_cnt.end(), Pg.cnt.begin(), Pg.cnt.end()); t_aux.insert(t_aux.end(), Pg.aux.begin(), Pg.aux.end());
+                    for (int x : Pg.src0) t_src0.push_back(x + so);
+                    t_src.insert(t_src.end(), Pg.src.begin(), Pg.src.end());
+                    tv_loc.insert(tv_loc.end(), Pg.vloc.begin(), Pg.vloc.end()); tv_red.insert(tv_red.end(), Pg.vred.begin(), Pg.vred.end()); tv_cnt.insert(tv_cnt.end(), Pg.vcnt.begin(), Pg.vcnt.end());
+                    tv_i.insert(tv_i.end(), Pg.vi.begin(), Pg.vi.end());
+                    for (int x : Pg.vsrc0) tv_src0.push_back(x + vo);
+                    tv_src.insert(tv_src.end(), Pg.vsrc.begin(), Pg.vsrc.end());
+                    it = seen.emplace(std::move(key), std::array<int, 4>{ se0, (int)Pg.dst.size(), ve0, (int)Pg.vloc.size() }).first;
+                }
+                A.se0 = it->second[0]; A.ne = it->second[1]; A.ve0 = it->second[2]; A.nv = it->second[3];
+                D.as_max_ne = std::max(D.as_max_ne, A.ne); D.as_max_nv = std::max(D.as_max_nv, A.nv);
+            }
+            if (overflow) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "assembly program: more than 4095 contributions to one entry of the reduced system"); }
+            b->asm_programs = (int)seen.size();
+            auto nonempty_i = [](std::vector<int>& v) { if (v.empty()) v.push_back(0); };
+            auto nonempty_u = [](std::vector<unsigned>& v) { if (v.empty()) v.push_back(0u); };
+            nonempty_i(t_dst); nonempty_u(t_cnt); nonempty_i(t_src0); nonempty_i(t_aux); nonempty_i(t_src);
+            nonempty_i(tv_loc); nonempty_i(tv_red); nonempty_u(tv_cnt); nonempty_i(tv_src0); nonempty_i(tv_i); nonempty_i(tv_src);
+            PUT(asw, asw);
+            PUT(as_dst, t_dst); PUT(as_cnt, t_cnt); PUT(as_src0, t_src0); PUT(as_aux, t_aux); PUT(as_src, t_src);
+            PUT(av_loc, tv_loc); PUT(av_red, tv_red); PUT(av_cnt, tv_cnt); PUT(av_src0, tv_src0); PUT(av_i, tv_i); PUT(av_src, tv_src);
+        }
         {
             std::vector<Pair> vd, vo;
             for (int i : pd) vd.push_back(B.pair[i]);
@@ -1310,8 +1408,10 @@ struct Launcher {
         if (D.n_proj + D.n_sc + D.n_prior) {
             Bracket t(*this, SWF_K_EVAL_PS);
             bool pf = b->max_prior_dim <= PRIOR_LDS_DIM;          // priors fused as a segment
-            Segs S{}; S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
-            hipLaunchKernelGGL(k_eval_ps<true>, dim3(S.e[2]), dim3(256), 0, st, D, S);
+            // (the projection segment: one workgroup per frame-sum block, the per-frame sums fused in; SWF_FS_SEPARATE=1: k_frame_sums as its own launch)
+            Segs S{}; S.e[0] = b->fs_fused ? D.n_fsb : nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
+            if (b->fs_fused) hipLaunchKernelGGL((k_eval_ps<true, true>), dim3(S.e[2]), dim3(256), 0, st, D, S);
+            else hipLaunchKernelGGL((k_eval_ps<true, false>), dim3(S.e[2]), dim3(256), 0, st, D, S);
         }
         if (D.n_idp) hipLaunchKernelGGL(k_eval_idp<true>, GRID(D.n_idp, 128), dim3(128), 0, st, D);
         if (b->aux) (void)hipEventRecord(b->ev_fork[1], st);
@@ -1348,9 +1448,13 @@ struct Launcher {
             }
             if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);
         }
-        if (D.n_fsb) { Bracket t(*this, SWF_K_FRAME_SUMS); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
+        if (D.n_fsb && !b->fs_fused) { Bracket t(*this, SWF_K_FRAME_SUMS); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
         if (b->aux) (void)hipStreamWaitEvent(st, b->ev_fork[2], 0);                  // join before the assembly
-        if (D.n_pd) {
+        if (D.n_pd && !b->asm_old) {
+            Bracket t(*this, SWF_K_ASSEMBLE);
+            const int nbS = write_S ? nb((size_t)D.as_max_ne, 256) : 0, nbV = nb((size_t)D.as_max_nv, 256);
+            hipLaunchKernelGGL(k_assemble_flat, dim3(nbS + nbV, D.n_win), dim3(256), 0, st, D, O, write_S, nbS);
+        } else if (D.n_pd) {
             Bracket t(*this, SWF_K_ASSEMBLE);
             Segs S{}; S.e[0] = nb((size_t)D.n_pd * 64, 256); S.e[1] = S.e[0] + (write_S ? nb((size_t)D.n_po * 16, 256) : 0);
             hipLaunchKernelGGL(k_assemble_all, dim3(S.e[1]), dim3(256), 0, st, D, O, write_S, S, b->s_direct ? 0 : lm_folded ? 1 : GEMM_SPLIT, lm_folded ? 1 : GEMM_SPLIT);

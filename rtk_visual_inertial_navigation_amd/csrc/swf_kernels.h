@@ -47,10 +47,10 @@ __device__ __forceinline__ double damp_diag(const DevOpt& O, double d, double* j
 // (R/factor/marginalization_factor.cpp:23-45).  One lane per observation; SoA outputs so
 // that every store instruction of a wave is one contiguous 512-byte run.
 // =========================================================================================
+// keep != nullptr (Jacobian evaluations only): the whitened residual and the pose Jacobian rows also stay in registers,
+// keep[0..5] = row 0, keep[6..11] = row 1 of Jp, keep[12..13] = r, for the per-frame sums of the fused kernel (zero where nothing is stored)
 template <bool JAC>
-__device__ __forceinline__ void d_eval_proj(const DevBatch& B, int bid) {
-    int i = bid * blockDim.x + threadIdx.x;
-    if (i >= B.n_proj) return;
+__device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double* keep) {
     int w = B.p_win[i];
     const WinState& s = B.ws[w];
     if (JAC ? !s.need_lin : !s.eval_cand) return;
@@ -86,6 +86,7 @@ __device__ __forceinline__ void d_eval_proj(const DevBatch& B, int bid) {
     if (!JAC) return;
     int n = B.n_proj;
     B.p_r[i] = r0 * sr; B.p_r[n + i] = r1 * sr;
+    if (keep) { keep[12] = r0 * sr; keep[13] = r1 * sr; }
     bool jp = B.p_lpose[i] >= 0, jl = B.p_llm[i] >= 0;
     if (!jp && !jl) return;
     double Rj[9], ric[9], ricT[9], RjT[9], A[9];
@@ -106,6 +107,7 @@ __device__ __forceinline__ void d_eval_proj(const DevBatch& B, int bid) {
                 for (int k = 0; k < 3; k++) { u += red[a * 3 + k] * -A[k * 3 + j]; v += red[a * 3 + k] * Bm[k * 3 + j]; }
                 B.p_Jp[(a * 6 + j) * n + i] = u * sr;
                 B.p_Jp[(a * 6 + 3 + j) * n + i] = v * sr;
+                if (keep) { keep[a * 6 + j] = u * sr; keep[a * 6 + 3 + j] = v * sr; }
             }
     }
     if (jl) {
@@ -119,6 +121,13 @@ __device__ __forceinline__ void d_eval_proj(const DevBatch& B, int bid) {
                 B.p_Jl[(a * 3 + j) * n + i] = u * sr;
             }
     }
+}
+
+template <bool JAC>
+__device__ __forceinline__ void d_eval_proj(const DevBatch& B, int bid) {
+    int i = bid * blockDim.x + threadIdx.x;
+    if (i >= B.n_proj) return;
+    d_eval_proj_at<JAC>(B, i, nullptr);
 }
 
 // =========================================================================================
@@ -1120,6 +1129,55 @@ __global__ void __launch_bounds__(256) k_clique_big(DevBatch B, DevOpt O) {
 #define FS_BLK 256
 #define FS_VAL 27
 #define FS_HALF 14                            // values staged per pass
+// The same, fused into the Jacobian evaluation (k_eval_ps<true>, one workgroup per frame-sum block): thread t evaluates observation t of
+// the block and the 27 products never leave the chip — Jp and r are not read back (112 B per observation and one launch less).
+// Same products, same staging, same owner loop as k_frame_sums below: bit-identical partial sums.
+__device__ __forceinline__ void d_eval_proj_fs(const DevBatch& B, int blk, double (*V)[FS_HALF], int* foff) {
+    int w = B.fsb_win[blk];
+    if (!B.ws[w].need_lin) return;                           // uniform per block (a block holds observations of one window)
+    const WinRec& W = B.win[w];
+    int o_beg = B.fsb_obs0[blk], cnt = B.fsb_obs0[blk + 1] - o_beg, tid = threadIdx.x;
+    int nF = W.nF;
+    for (int e = tid; e <= nF; e += FS_BLK) foff[e] = B.fsb_foff[B.fsb_foff0[blk] + e];
+    double keep[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) keep[k] = 0.0;
+    int rk = 0;
+    if (tid < cnt) { rk = B.fsb_perm[o_beg + tid]; d_eval_proj_at<true>(B, o_beg + tid, keep); }
+    double val[FS_VAL];
+    {
+        const double* a = keep; const double* b = keep + 6;
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) val[k++] = a[i] * a[j] + b[i] * b[j];
+#pragma unroll
+        for (int i = 0; i < 6; i++) val[21 + i] = a[i] * keep[12] + b[i] * keep[13];
+    }
+    double* out = B.fs_part + (size_t)B.fsb_out0[blk] * FS_VAL;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int v0 = half * FS_HALF, nv = half == 0 ? FS_HALF : FS_VAL - FS_HALF;
+        if (half) __syncthreads();                          // the first half's sums are done
+        if (tid < cnt) {
+#pragma unroll
+            for (int k = 0; k < FS_HALF; k++) if (k < nv) V[rk][k] = val[v0 + k];
+        }
+        __syncthreads();
+        for (int e = tid; e < nF * nv; e += FS_BLK) {
+            int f = e / nv, v = e - f * nv;
+            double acc = 0;
+            int q = foff[f], q1 = foff[f + 1];
+            for (; q + 4 <= q1; q += 4) {
+                double x0 = V[q][v], x1 = V[q + 1][v], x2 = V[q + 2][v], x3 = V[q + 3][v];
+                acc += x0; acc += x1; acc += x2; acc += x3;
+            }
+            for (; q < q1; q++) acc += V[q][v];
+            out[f * FS_VAL + v0 + v] = acc;
+        }
+    }
+}
 __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
     __shared__ double V[FS_BLK][FS_HALF];
     int blk = blockIdx.x;
@@ -1177,6 +1235,95 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
             out[f * FS_VAL + v0 + v] = acc;
         }
     }
+}
+
+// =========================================================================================
+// Assembly of the reduced system as a static PROGRAM (round 3).  What every entry of S, and every reduced dimension of g / diag /
+// rhs, receives is known at build time: the host flattens it into per-entry lists (window-relative offsets into the clique blocks C,
+// the landmark product P or the -P k_lm_schur left in S, the frame-sum partials, the clique vectors, the landmark rhs partials) and
+// one thread per entry adds its list in order.  Same sums, same order as the pair-walking kernel it replaces (k_assemble_all: one
+// wavefront per block pair, descriptor -> value load chains, 142 us per launch over 512 cfg3 windows):
+//   S_ab[i][j] = sum_cliques C_k[i][j]  ( + (-P) already in place  |  - sum_parts P_q )  + [a == b observing pose] sum_blocks H
+//                + [i == j] mu damp(diag_i)
+//   g_i = sum_blocks (Jp^T r)_i + sum_cliques graw,  diag_i = sum_blocks H_ii + sum_cliques dgraw,  rhs_i = g_i + sum_cliques cs - sum_parts q
+// grid = (blocks of 256 entries, windows); blocks [0, nbS) walk S entries (write_S only), the rest vector entries.
+// =========================================================================================
+// sum of base[src[0 .. n)] in list order; indices and values are fetched four at a time (the additions keep their order)
+__device__ __forceinline__ double as_sum(const double* base, const int* src, int n, int add = 0) {
+    double v = 0;
+    int c = 0;
+    for (; c + 4 <= n; c += 4) {
+        const int i0 = src[c], i1 = src[c + 1], i2 = src[c + 2], i3 = src[c + 3];
+        const double x0 = base[i0 + add], x1 = base[i1 + add], x2 = base[i2 + add], x3 = base[i3 + add];
+        v += x0; v += x1; v += x2; v += x3;
+    }
+    for (; c < n; c++) v += base[src[c] + add];
+    return v;
+}
+__global__ void __launch_bounds__(256) k_assemble_flat(DevBatch B, DevOpt O, int write_S, int nbS) {
+    const AsmWin& A = B.asw[blockIdx.y];
+    const WinState& s = B.ws[A.win];
+    if (!s.need_lin) return;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < nbS) {
+        if (!write_S) return;
+        const int e = blockIdx.x * 256 + tid;
+        if (e >= A.ne) return;
+        const int k = A.se0 + e;
+        const unsigned cnt = B.as_cnt[k];
+        const int nC = AS_NC(cnt), nP = AS_NP(cnt), nH = AS_NH(cnt);
+        const int* src = B.as_src + B.as_src0[k];
+        const int dst = B.as_dst[k];
+        double* S = B.S + A.S_base;
+        const double* C = B.C + A.C_base;
+        const double sold = AS_SOLD(cnt) ? S[dst] : 0.0;    // (requested up front: it does not depend on the lists)
+        double v = as_sum(C, src, nC);
+        if (AS_SOLD(cnt)) v = sold + v;                    // k_lm_schur left -P in place: -P + c == c - P
+        else if (nP) v -= as_sum(B.P + A.P_base, src + nC, nP);
+        double hs = 0;
+        if (nH) { hs = as_sum(B.fs_part + (size_t)A.fs_base * FS_VAL, src + nC + nP, nH); v += hs; }
+        if (AS_DIAG(cnt)) {
+            // dg = hs + the cliques' raw diagonals, in contribution order
+            const double* dgr = B.cv_dgraw + A.v_base;
+            const int* sd = src + nC + nP + nH;
+            double dg = hs;
+            int c = 0;
+            for (; c + 4 <= nC; c += 4) { const double x0 = dgr[sd[c]], x1 = dgr[sd[c + 1]], x2 = dgr[sd[c + 2]], x3 = dgr[sd[c + 3]]; dg += x0; dg += x1; dg += x2; dg += x3; }
+            for (; c < nC; c++) dg += dgr[sd[c]];
+            v += s.mu * damp_diag(O, dg, B.jsc + A.loc_base + B.as_aux[k], s.iter == 0);
+        }
+        S[dst] = v;
+        return;
+    }
+    const int e = (blockIdx.x - nbS) * 256 + tid;
+    if (e >= A.nv) return;
+    const int k = A.ve0 + e;
+    const unsigned cnt = B.av_cnt[k];
+    const int nC = AS_NC(cnt), nQ = AS_NP(cnt), nH = AS_NH(cnt);
+    const int* src = B.av_src + B.av_src0[k];
+    double gi = 0, dg = 0, cs = 0;
+    if (nH) {
+        const double* fs = B.fs_part + (size_t)A.fs_base * FS_VAL;
+        const int i = B.av_i[k];
+        const double g0 = as_sum(fs, src, nH, 21 + i), h0 = as_sum(fs, src, nH, i * (i + 1) / 2 + i);
+        const double q0 = as_sum(B.lmq + A.q_base, src + nH + nC, nQ);
+        gi = g0; dg = h0; cs = -q0;
+    }
+    {
+        const double* gr = B.cv_graw + A.v_base; const double* dgr = B.cv_dgraw + A.v_base; const double* csr = B.cv_cs + A.v_base;
+        int c = 0;
+        for (; c + 2 <= nC; c += 2) {
+            const int v0 = src[nH + c], v1 = src[nH + c + 1];
+            const double a0 = gr[v0], b0 = dgr[v0], c0_ = csr[v0], a1 = gr[v1], b1 = dgr[v1], c1_ = csr[v1];
+            gi += a0; dg += b0; cs += c0_; gi += a1; dg += b1; cs += c1_;
+        }
+        for (; c < nC; c++) { const int vo = src[nH + c]; gi += gr[vo]; dg += dgr[vo]; cs += csr[vo]; }
+    }
+    const int loc = A.loc_base + B.av_loc[k];
+    B.g[loc] = gi; B.diag[loc] = dg; B.vc[loc] = gi / clampd(dg, O.min_diag, O.max_diag);
+    // the reduced rhs is kept twice: in the local-space vector, and as row n of the window's S storage
+    // (the Cholesky carries it as one more tile row with the same addressing as every other tile)
+    if (write_S) { B.rhs[loc] = gi + cs; B.S[A.S_base + (size_t)A.n_red * A.n_red + B.av_red[k]] = gi + cs; }
 }
 
 // =========================================================================================

@@ -1103,11 +1103,15 @@ __device__ __forceinline__ void d_backsub_clique(const DevBatch& B, int bid) {
 struct Segs { int e[8]; };     // exclusive end block of segment k (cumulative)
 
 // Jacobian/residual evaluation of the one-lane-per-factor families: projection + scalar GNSS/prior factors
-template <bool JAC>
+// FS (Jacobian evaluations): the projection segment runs one workgroup per frame-sum block and leaves the per-frame partial sums of
+// Jp^T Jp | Jp^T r next to the Jacobians (d_eval_proj_fs); k_frame_sums is then not launched.
+template <bool JAC, bool FS = false>
 __global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
     __shared__ double sm_prior[2 * PRIOR_LDS_DIM + 16];
+    __shared__ double sm_V[FS ? FS_BLK : 1][FS_HALF];
+    __shared__ int sm_foff[FS ? 168 : 1];
     int bid = blockIdx.x;
-    if (bid < S.e[0]) d_eval_proj<JAC>(B, bid);
+    if (bid < S.e[0]) { if (FS) d_eval_proj_fs(B, bid, sm_V, sm_foff); else d_eval_proj<JAC>(B, bid); }
     else if (bid < S.e[1]) d_eval_scalar<JAC>(B, bid - S.e[0]);
     else d_eval_prior<JAC>(B, bid - S.e[1], sm_prior);        // one workgroup per prior (segment empty for large priors)
 }
