@@ -389,7 +389,7 @@ def main():
         # algorithmic work of ONE launch over this GPU's batch (DESIGN.md §3 states the per-unit figures)
         n_obs = calib["n_obs"]
         work = {
-            "eval_ps": ("hbm", calib["proj_bytes"], "312 B per observation (152 read + 160 written)"),
+            "eval_ps": ("hbm", calib["proj_bytes"], "312 B per observation (152 read + 160 written); the per-frame sums of Jp^T Jp | Jp^T r are formed in the same kernel"),
             "lm_schur": ("mfma", calib["lm_schur_flops"], "sum over landmarks of 216 k^2 + 108 k flops (SURVEY.md 8d landmark Schur, both triangles of the symmetric product); "
                          "HBM side: 160 B per observation (Jp, Jl, r read) + S_pp written once"),
             "chol_solve": ("mfma", calib["chol_flops"], "sum_w n_red^3 / 3 flops (n_red^3 / 6 multiply-adds)"),
@@ -398,7 +398,7 @@ def main():
             "post_dogleg": ("hbm", (152 + 16) * n_obs, "candidate residuals: 152 B read + 16 B written per observation (the model cost change comes from k_dogleg's vector sums)"),
         }
         bound, units, what = work.get(dom, ("hbm", calib["jacobian_bytes"], "Jacobian bytes of the batch (SURVEY.md 8d formula)"))
-        knames = {"eval_ps": "k_eval_ps<true>", "lm_schur": "k_lm_schur<8, 5, 2, 144, true>", "assemble": "k_assemble_all", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr2<9>"}
+        knames = {"eval_ps": "k_eval_ps<true, true>", "lm_schur": "k_lm_schur<8, 5, 2, 144, true>", "assemble": "k_assemble_flat", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr2<9>"}
         # HBM traffic from the committed PMC passes of the same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate passes; gfx950: FETCH_SIZE counts half of wide coalesced reads -> x2), if available
         traffic = None
@@ -454,7 +454,7 @@ def main():
         roof["traffic_source"] = traffic_source
         if traffic_all:
             roof["traffic_all_kernels_per_launch"] = {k: v for k, v in sorted(traffic_all.items(), key=lambda kv: -kv[1])[:14]}
-        jac = dict(kernel="k_eval_ps<true>", bound="hbm",
+        jac = dict(kernel="k_eval_ps<true, true>", bound="hbm",
                    achieved=calib["proj_bytes"] / (avg_ms("eval_ps") * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                    algorithmic_bytes_per_launch=calib["proj_bytes"], avg_launch_ms=avg_ms("eval_ps"))
         jac["frac"] = jac["achieved"] / HBM_PEAK_GBS

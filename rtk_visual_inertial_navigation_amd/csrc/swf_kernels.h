@@ -47,9 +47,11 @@ __device__ __forceinline__ double damp_diag(const DevOpt& O, double d, double* j
 // (R/factor/marginalization_factor.cpp:23-45).  One lane per observation; SoA outputs so
 // that every store instruction of a wave is one contiguous 512-byte run.
 // =========================================================================================
-// keep != nullptr (Jacobian evaluations only): the whitened residual and the pose Jacobian rows also stay in registers,
-// keep[0..5] = row 0, keep[6..11] = row 1 of Jp, keep[12..13] = r, for the per-frame sums of the fused kernel (zero where nothing is stored)
-template <bool JAC>
+// keep != nullptr (Jacobian evaluations only): the whitened residual and the Jacobian rows also stay in registers,
+// keep[0..5] = row 0, keep[6..11] = row 1 of Jp, keep[12..13] = r, keep[14..16] = row 0, keep[17..19] = row 1 of Jl (zero where the
+// block is constant) — for the per-frame sums of the fused evaluation kernel, and, with STORE = false (nothing written), for the
+// back-substitution pass, which re-derives an observation's Jacobian from its 56 B of inputs instead of re-reading 144 B
+template <bool JAC, bool STORE = true>
 __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double* keep) {
     int w = B.p_win[i];
     const WinState& s = B.ws[w];
@@ -82,10 +84,10 @@ __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double*
         cost = 0.5 * b * log(sum);
         sr = sqrt(inv > 2.2250738585072014e-308 ? inv : 2.2250738585072014e-308);
     } else cost = 0.5 * sq;
-    B.p_cost[i] = cost;
+    if (STORE) B.p_cost[i] = cost;
     if (!JAC) return;
     int n = B.n_proj;
-    B.p_r[i] = r0 * sr; B.p_r[n + i] = r1 * sr;
+    if (STORE) { B.p_r[i] = r0 * sr; B.p_r[n + i] = r1 * sr; }
     if (keep) { keep[12] = r0 * sr; keep[13] = r1 * sr; }
     bool jp = B.p_lpose[i] >= 0, jl = B.p_llm[i] >= 0;
     if (!jp && !jl) return;
@@ -105,8 +107,7 @@ __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double*
                 double u = 0, v = 0;
 #pragma unroll
                 for (int k = 0; k < 3; k++) { u += red[a * 3 + k] * -A[k * 3 + j]; v += red[a * 3 + k] * Bm[k * 3 + j]; }
-                B.p_Jp[(a * 6 + j) * n + i] = u * sr;
-                B.p_Jp[(a * 6 + 3 + j) * n + i] = v * sr;
+                if (STORE) { B.p_Jp[(a * 6 + j) * n + i] = u * sr; B.p_Jp[(a * 6 + 3 + j) * n + i] = v * sr; }
                 if (keep) { keep[a * 6 + j] = u * sr; keep[a * 6 + 3 + j] = v * sr; }
             }
     }
@@ -118,7 +119,8 @@ __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double*
                 double u = 0;
 #pragma unroll
                 for (int k = 0; k < 3; k++) u += red[a * 3 + k] * A[k * 3 + j];
-                B.p_Jl[(a * 3 + j) * n + i] = u * sr;
+                if (STORE) B.p_Jl[(a * 3 + j) * n + i] = u * sr;
+                if (keep) keep[14 + a * 3 + j] = u * sr;
             }
     }
 }
@@ -1139,9 +1141,9 @@ __device__ __forceinline__ void d_eval_proj_fs(const DevBatch& B, int blk, doubl
     int o_beg = B.fsb_obs0[blk], cnt = B.fsb_obs0[blk + 1] - o_beg, tid = threadIdx.x;
     int nF = W.nF;
     for (int e = tid; e <= nF; e += FS_BLK) foff[e] = B.fsb_foff[B.fsb_foff0[blk] + e];
-    double keep[14];
+    double keep[20];
 #pragma unroll
-    for (int k = 0; k < 14; k++) keep[k] = 0.0;
+    for (int k = 0; k < 20; k++) keep[k] = 0.0;
     int rk = 0;
     if (tid < cnt) { rk = B.fsb_perm[o_beg + tid]; d_eval_proj_at<true>(B, o_beg + tid, keep); }
     double val[FS_VAL];

@@ -1006,14 +1006,19 @@ __device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O,
         double vl0 = 0, vl1 = 0, vl2 = 0;
         if (loc >= 0) { vl0 = vec_at<0>(B, O, loc); vl1 = vec_at<0>(B, O, loc + 1); vl2 = vec_at<0>(B, O, loc + 2); }
         int lp = B.p_lpose[o];
-        double jl0 = B.p_Jl[0 * n + o], jl1 = B.p_Jl[1 * n + o], jl2 = B.p_Jl[2 * n + o];
-        double jl3 = B.p_Jl[3 * n + o], jl4 = B.p_Jl[4 * n + o], jl5 = B.p_Jl[5 * n + o];
+        // the observation's Jacobian, re-derived at the linearisation point from its inputs (pose, extrinsic and landmark sit in cache
+        // for the whole track; 16 B of image coordinates per observation) rather than read back: 144 B per observation less traffic
+        double kj[20];
+#pragma unroll
+        for (int k = 0; k < 20; k++) kj[k] = 0.0;
+        d_eval_proj_at<true, false>(B, o, kj);
+        double jl0 = kj[14], jl1 = kj[15], jl2 = kj[16], jl3 = kj[17], jl4 = kj[18], jl5 = kj[19];
         double u0 = 0, u1 = 0;                                     // Jp y
         double a0 = jl0 * vl0 + jl1 * vl1 + jl2 * vl2, a1 = jl3 * vl0 + jl4 * vl1 + jl5 * vl2;   // J v
         if (lp >= 0) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                double ja = B.p_Jp[i * n + o], jb = B.p_Jp[(6 + i) * n + o];
+                double ja = kj[i], jb = kj[6 + i];
                 double yv = B.y[lp + i], vv = vec_at<0>(B, O, lp + i);
                 u0 += ja * yv; u1 += jb * yv;
                 a0 += ja * vv; a1 += jb * vv;
@@ -1107,13 +1112,13 @@ struct Segs { int e[8]; };     // exclusive end block of segment k (cumulative)
 // Jp^T Jp | Jp^T r next to the Jacobians (d_eval_proj_fs); k_frame_sums is then not launched.
 template <bool JAC, bool FS = false>
 __global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
-    __shared__ double sm_prior[2 * PRIOR_LDS_DIM + 16];
-    __shared__ double sm_V[FS ? FS_BLK : 1][FS_HALF];
-    __shared__ int sm_foff[FS ? 168 : 1];
+    // one LDS buffer for whichever segment the block runs: the prior's staging vectors, or the frame sums' staging tile (+ its frame offsets)
+    constexpr int SM_PRIOR = 2 * PRIOR_LDS_DIM + 16, SM_FS = FS ? FS_BLK * FS_HALF + 168 / 2 + 1 : 1;
+    __shared__ double sm[SM_PRIOR > SM_FS ? SM_PRIOR : SM_FS];
     int bid = blockIdx.x;
-    if (bid < S.e[0]) { if (FS) d_eval_proj_fs(B, bid, sm_V, sm_foff); else d_eval_proj<JAC>(B, bid); }
+    if (bid < S.e[0]) { if (FS) d_eval_proj_fs(B, bid, (double (*)[FS_HALF])sm, (int*)(sm + FS_BLK * FS_HALF)); else d_eval_proj<JAC>(B, bid); }
     else if (bid < S.e[1]) d_eval_scalar<JAC>(B, bid - S.e[0]);
-    else d_eval_prior<JAC>(B, bid - S.e[1], sm_prior);        // one workgroup per prior (segment empty for large priors)
+    else d_eval_prior<JAC>(B, bid - S.e[1], sm);              // one workgroup per prior (segment empty for large priors)
 }
 // after the reduced solve: back-substitution of the eliminated blocks, and |J D^-2 g|^2 for the Cauchy point.
 // PART 0: every segment in one grid (latency path).  Large batches launch the landmark segment (PART 1, the
