@@ -888,9 +888,9 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         b->s_direct = b->ls_folded && !getenv("SWF_NO_S_DIRECT");
     }
     {
-        // k_lm_schur task table.  A wave task = the four 16-lane groups of one producer wave: a landmark takes 1 / 2 / 4 adjacent, aligned
-        // groups (<= 16 / 32 / 64 observations) and three of the task's twelve panel columns.  Record of (task, group): L (-1 = empty), loc,
-        // first / end observation of this group, first column within the task (0, 3, 6, 9), 0, G << 8 | first << 16, 0.  The window's landmarks
+        // k_lm_schur task table.  A wave task = the four 16-lane groups of one producer wave = four landmarks, one group and three of the
+        // task's twelve panel columns each (a track of more than 16 observations takes further rounds of its group's lanes).  Record of
+        // (task, group): L (-1 = empty), loc, first / end observation of the landmark, first column within the task (0, 3, 6, 9).  The window's landmarks
         // enter in the order of their tile footprint (last, first 16-row tile of the reduced camera matrix they touch), so the landmarks of a
         // task mostly share theirs; bit g of the tile mask of (chunk, tile) — some landmark of the chunk's wave task g is seen from the tile's
         // row frames and from its column frames — is what the consumer waves walk (a chunk = TW tasks, by size class; the packing into tasks
@@ -921,18 +921,13 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return key(x) < key(y); });
             const int first_task = (int)(rec.size() / 32);
             task_tiles.clear();
-            size_t at = 0; int gw = 4, lw = 4;                     // force a new task at the first landmark
-            auto new_task = [&]() { at = rec.size(); rec.resize(at + 32, 0); for (int g = 0; g < 4; g++) rec[at + g * 8] = -1; task_tiles.emplace_back((size_t)ntl, 0u); gw = 0; lw = 0; };
+            size_t at = 0; int lw = 4;                             // force a new task at the first landmark
+            auto new_task = [&]() { at = rec.size(); rec.resize(at + 32, 0); for (int g = 0; g < 4; g++) rec[at + g * 8] = -1; task_tiles.emplace_back((size_t)ntl, 0u); lw = 0; };
             for (int l : ord) {
                 int o0 = B.lm_obs0[l], k = B.lm_obs0[l + 1] - o0;
-                int G = k <= 16 ? 1 : k <= 32 ? 2 : 4;
-                int ga = (gw + G - 1) / G * G;
-                if (ga + G > 4 || lw >= 4) { new_task(); ga = 0; }
-                for (int h = 0; h < G; h++) {
-                    int* r = &rec[at + (size_t)(ga + h) * 8];
-                    r[0] = l; r[1] = B.lm_loc[l]; r[2] = o0 + 16 * h; r[3] = std::min(o0 + 16 * h + 16, o0 + k);
-                    r[4] = 3 * lw; r[5] = 0; r[6] = (G << 8) | ((h == 0 ? 1 : 0) << 16); r[7] = 0;
-                }
+                if (lw >= 4) new_task();
+                int* r = &rec[at + (size_t)lw * 8];                 // group lw of the task = this landmark, whatever its track length
+                r[0] = l; r[1] = B.lm_loc[l]; r[2] = o0; r[3] = o0 + k; r[4] = 3 * lw; r[5] = 0; r[6] = 0; r[7] = 0;
                 // tile-list entries this landmark touches
                 unsigned t = trs[(size_t)(l - W.lm0)];
                 std::vector<unsigned>& tt = task_tiles.back();
@@ -941,7 +936,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
                     tt[(size_t)tr] = 1u;
                     for (int tc = 0; tc < tr; tc++) if ((t >> tc) & 1u) tt[(size_t)(nt + tr * (tr - 1) / 2 + tc)] = 1u;
                 }
-                gw = ga + G; lw++;
+                lw++;
             }
             if (task_tiles.size() & 1) new_task();                 // an even number of tasks per window
             const int ntask = (int)task_tiles.size();

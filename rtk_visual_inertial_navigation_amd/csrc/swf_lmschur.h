@@ -8,8 +8,9 @@
 // In-tree analogue of this arithmetic: MarginalizationInfo::marginalize, R/factor/marginalization_factor.cpp:260-377;
 // in Ceres it is SchurEliminator::Eliminate (E^T E inverted by InvertPSDMatrix = Cholesky, F^T E (E^T E)^-1 E^T F).
 //
-// Unit of work: the WAVE TASK = one producer wavefront's four 16-lane groups = up to four landmarks (a track of 17..32 / 33..64
-// observations takes 2 / 4 adjacent groups) = 12 columns = three k-steps of the K-packed panel
+// Unit of work: the WAVE TASK = one producer wavefront's four 16-lane groups = four landmarks (one group each, whatever the track
+// length: lane j takes observations j, j + 16, j + 32, j + 48 in as many rounds as the task's longest track needs) = 12 columns =
+// three k-steps of the K-packed panel
 //   Zp[column][row],  column = 3 * (landmark slot) + coordinate,  row = 6 * frame + i     (k-major, LDR doubles per column)
 // which is zero where a landmark does not see a frame.  One workgroup per (window, 1..16 of the window's 16 landmark parts)
 // runs a RING of four panel buffers in LDS between two kinds of wavefronts that never meet at a barrier:
@@ -53,7 +54,7 @@ __device__ unsigned long long g_gemm_stamps[16];
 //   <12, 6, 1, 272>  <= 42 frames  (<= 136 tiles, 2 launches of 72)    <12, 6, 1, 400>  <= 64 frames (<= 300 tiles, 5 launches)
 // GEMM = false: the elimination alone (g_l, diag, Einv for a cost / gradient pass: the solve's last linearisation, whose system
 // is never solved): producer waves only, no panel, under its own kernel name.
-struct LsRec { int L, loc, o0, o1, col, info; };            // info = G << 8 | first << 16; col = first column of the landmark within its wave's twelve (0, 3, 6, 9)
+struct LsRec { int L, loc, o0, o1, col, info; };            // o0 .. o1: the landmark's observations (<= 64); col = first column of the landmark within its wave's twelve (0, 3, 6, 9)
 struct LsDat { double jl[6], rr[2]; int f; };
 __device__ __forceinline__ void ls_wait(const unsigned* flag, unsigned target, WinState& s) {
     asm volatile("" ::: "memory");
@@ -76,6 +77,7 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
     constexpr int NCOL = 12 * TW, NG = TW;                             // columns / wave tasks per chunk
     constexpr int PANEL = NCOL * LDR;                                  // doubles per buffer
     constexpr int KSB = 4 * LDR * 8;                                   // bytes per k-step
+    static_assert(!GEMM || LS_NB * PANEL < 0xffff, "panel offsets are kept in 16 bits");
     __shared__ double Zp[GEMM ? LS_NB * PANEL + LS_NB * NCOL : 1];     // four panels | h_l at the landmark's columns, per buffer
     __shared__ unsigned flg[2 * LS_NB];                                // ready[4] | done[4]
     __shared__ int freds[LS_MAXF];                                     // first reduced row of every frame's pose (s_direct write-out)
@@ -292,11 +294,13 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
         }
         return r;
     };
-    auto load_dat = [&](const LsRec& r, LsDat& d) {
+    // round rd of a track: lane `sub` takes observation o0 + 16 rd + sub (a landmark is ONE 16-lane group whatever its track length;
+    // tracks beyond 16 observations take further rounds of the same lanes: tile-footprint order puts them into the same tasks)
+    auto load_dat = [&](const LsRec& r, LsDat& d, int rd) {
 #pragma unroll
         for (int k = 0; k < 6; k++) d.jl[k] = 0.0;
         d.rr[0] = d.rr[1] = 0.0; d.f = -1;
-        int o = r.o0 + sub;
+        int o = r.o0 + 16 * rd + sub;
         if (r.L >= 0 && r.loc >= 0 && o < r.o1) {
             const double* pl = B.p_Jl + o;
 #pragma unroll
@@ -305,26 +309,27 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
             d.f = B.p_fr[o];
         }
     };
-    int oldp = -1;                                          // where this lane wrote its Z block in the team's buffer last time (doubles), -1 = nowhere
+    unsigned oldp01 = 0xffffffffu, oldp23 = 0xffffffffu;    // where this lane wrote its Z blocks (one per round) last time: four 16-bit offsets in doubles (0xffff = nowhere)
+    int nold = 0;                                           // rounds the wave wrote last time (uniform)
     int use = 0;
-    // one wave task: `cur` (Jl, r, frame) was requested a task ago; the next task's and the record after that are requested first thing,
-    // then this task's Jp (it lands during the sums and the inverse)
+    // one wave task: `cur` (Jl, r, frame of round 0) was requested a task ago; the next task's and the record after that are requested
+    // first thing, then this task's Jp (it lands during the sums and the inverse)
     auto run_task = [&](const LsRec& rc, LsDat& cur, const LsRec& rn, LsDat& nxt, LsRec& rnn) {
         tg = GNOW();
         // land this task's data here (everything requested a task ago), then send the next requests on their way
 #pragma unroll
         for (int k = 0; k < 6; k++) asm volatile("" : "+v"(cur.jl[k]));
         asm volatile("" : "+v"(cur.rr[0]), "+v"(cur.rr[1]), "+v"(cur.f));
-        load_dat(rn, nxt);
+        load_dat(rn, nxt, 0);
         rnn = load_rec(task + 2 * tstep);
-        const int L = rc.L, loc = rc.loc, o = rc.o0 + sub;
+        const int L = rc.L, loc = rc.loc, o = rc.o0 + sub, kobs = rc.o1 - rc.o0;
 #ifdef SWF_LS_NOPROD
         const bool act = false, has = false;               // experiment: producers idle
 #else
         const bool act = L >= 0 && loc >= 0, has = act && o < rc.o1;
 #endif
-        const int G = (rc.info >> 8) & 255;
-        const bool first = (rc.info >> 16) & 1;
+        // rounds of this wave (uniform): 1 unless some track of the task has more than 16 observations
+        const int nrd = !__any(act && kobs > 16) ? 1 : !__any(act && kobs > 32) ? 2 : !__any(act && kobs > 48) ? 3 : 4;
         const double* a = cur.jl;
         double jp[12];
 #pragma unroll
@@ -339,22 +344,19 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
         double h00 = FMA2(a[0], a[0], a[3], a[3]), h10 = FMA2(a[1], a[0], a[4], a[3]), h20 = FMA2(a[2], a[0], a[5], a[3]);
         double h11 = FMA2(a[1], a[1], a[4], a[4]), h21 = FMA2(a[2], a[1], a[5], a[4]), h22 = FMA2(a[2], a[2], a[5], a[5]);
         double g0 = FMA2(a[0], cur.rr[0], a[3], cur.rr[1]), g1 = FMA2(a[1], cur.rr[0], a[4], cur.rr[1]), g2 = FMA2(a[2], cur.rr[0], a[5], cur.rr[1]);
-        bool wide = __any(G >= 2);                          // some track of this wave spans several groups (rare)
-        auto red = [&](double v) {
-            v = grp16_sum(v);
-            if (wide) {
-                double v2 = v + __shfl_xor(v, 16, 64);
-                v = G >= 2 ? v2 : v;
-                double v4 = v + __shfl_xor(v, 32, 64);
-                v = G >= 4 ? v4 : v;
-            }
-            return v;
-        };
-        h00 = red(h00); h10 = red(h10); h20 = red(h20); h11 = red(h11); h21 = red(h21); h22 = red(h22);
-        g0 = red(g0); g1 = red(g1); g2 = red(g2);
+        for (int rd = 1; rd < nrd; rd++) {                  // further rounds: each lane adds its later observations to its own sums, in round order
+            LsDat d2;
+            load_dat(rc, d2, rd);
+            const double* b = d2.jl;
+            h00 += FMA2(b[0], b[0], b[3], b[3]); h10 += FMA2(b[1], b[0], b[4], b[3]); h20 += FMA2(b[2], b[0], b[5], b[3]);
+            h11 += FMA2(b[1], b[1], b[4], b[4]); h21 += FMA2(b[2], b[1], b[5], b[4]); h22 += FMA2(b[2], b[2], b[5], b[5]);
+            g0 += FMA2(b[0], d2.rr[0], b[3], d2.rr[1]); g1 += FMA2(b[1], d2.rr[0], b[4], d2.rr[1]); g2 += FMA2(b[2], d2.rr[0], b[5], d2.rr[1]);
+        }
+        h00 = grp16_sum(h00); h10 = grp16_sum(h10); h20 = grp16_sum(h20); h11 = grp16_sum(h11); h21 = grp16_sum(h21); h22 = grp16_sum(h22);
+        g0 = grp16_sum(g0); g1 = grp16_sum(g1); g2 = grp16_sum(g2);
         if (wv == 0) GSTAMP_ACC(0, tg);
         tg = GNOW();
-        const bool lead = act && first && sub == 0;
+        const bool lead = act && sub == 0;
         if (lead && outs) {
             B.g[loc] = g0; B.g[loc + 1] = g1; B.g[loc + 2] = g2;
             B.diag[loc] = h00; B.diag[loc + 1] = h11; B.diag[loc + 2] = h22;
@@ -391,41 +393,63 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
             }
         }
         if (gemm) {
-            const bool wr = has && cur.f >= 0;
             if (wv == 0) GSTAMP_ACC(1, tg);
             tg = GNOW();
             ls_wait(&flg[LS_NB + team], (unsigned)(NCW * use), s);               // every consumer wave is through with the buffer's previous chunk
             if (wv == 0) GSTAMP_ACC(2, tg);
             tg = GNOW();
             // the panel stays zero outside the live Z blocks: clear what this lane wrote here last time, then write
-            if (oldp >= 0) {
-                double* zo = Zp + oldp;
+            for (int rd = 0; rd < nold; rd++) {
+                const unsigned op = ((rd < 2 ? oldp01 : oldp23) >> (16 * (rd & 1))) & 0xffffu;
+                if (op != 0xffffu) {
+                    double* zo = Zp + op;
 #pragma unroll
-                for (int cc = 0; cc < 3; cc++)
+                    for (int cc = 0; cc < 3; cc++)
 #pragma unroll
-                    for (int i = 0; i < 6; i++) zo[cc * LDR + i] = 0.0;
-            }
-            oldp = -1;
-            if (wr) {
-                // per observation: Z = Jp^T (Jl C), column by column straight into the panel
-                oldp = team * PANEL + (12 * mi + rc.col) * LDR + 6 * cur.f;
-                double* zn = Zp + oldp;
-                {
-                    const double q0 = a[0] * i00, q1 = a[3] * i00;
-#pragma unroll
-                    for (int i = 0; i < 6; i++) zn[i] = FMA2(jp[i], q0, jp[6 + i], q1);
-                }
-                {
-                    const double q0 = FMA2(a[0], i10, a[1], i11), q1 = FMA2(a[3], i10, a[4], i11);
-#pragma unroll
-                    for (int i = 0; i < 6; i++) zn[LDR + i] = FMA2(jp[i], q0, jp[6 + i], q1);
-                }
-                {
-                    const double q0 = FMA3(a[0], i20, a[1], i21, a[2], i22), q1 = FMA3(a[3], i20, a[4], i21, a[5], i22);
-#pragma unroll
-                    for (int i = 0; i < 6; i++) zn[2 * LDR + i] = FMA2(jp[i], q0, jp[6 + i], q1);
+                        for (int i = 0; i < 6; i++) zo[cc * LDR + i] = 0.0;
                 }
             }
+            oldp01 = oldp23 = 0xffffffffu;
+            // per observation: Z = Jp^T (Jl C), column by column straight into the panel
+            auto write_z = [&](const double* jl_, const double* jp_, int f_) {
+                const int np = team * PANEL + (12 * mi + rc.col) * LDR + 6 * f_;
+                double* zn = Zp + np;
+                {
+                    const double q0 = jl_[0] * i00, q1 = jl_[3] * i00;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) zn[i] = FMA2(jp_[i], q0, jp_[6 + i], q1);
+                }
+                {
+                    const double q0 = FMA2(jl_[0], i10, jl_[1], i11), q1 = FMA2(jl_[3], i10, jl_[4], i11);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) zn[LDR + i] = FMA2(jp_[i], q0, jp_[6 + i], q1);
+                }
+                {
+                    const double q0 = FMA3(jl_[0], i20, jl_[1], i21, jl_[2], i22), q1 = FMA3(jl_[3], i20, jl_[4], i21, jl_[5], i22);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) zn[2 * LDR + i] = FMA2(jp_[i], q0, jp_[6 + i], q1);
+                }
+                return np;
+            };
+            if (has && cur.f >= 0) oldp01 = (oldp01 & 0xffff0000u) | (unsigned)write_z(a, jp, cur.f);
+            for (int rd = 1; rd < nrd; rd++) {              // later rounds: Jl, frame and Jp of the lane's next observation come from L2 again
+                LsDat d2;
+                load_dat(rc, d2, rd);
+                const int o2 = rc.o0 + 16 * rd + sub;
+                double jq[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) jq[k] = 0.0;
+                const bool has2 = act && o2 < rc.o1;
+                if (has2) {
+                    const double* pj = B.p_Jp + o2;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) jq[k] = pj[(size_t)k * n];
+                }
+                unsigned np = 0xffffu;
+                if (has2 && d2.f >= 0) np = (unsigned)write_z(d2.jl, jq, d2.f);
+                if (rd == 1) oldp01 = (oldp01 & 0xffffu) | (np << 16); else if (rd == 2) oldp23 = (oldp23 & 0xffff0000u) | np; else oldp23 = (oldp23 & 0xffffu) | (np << 16);
+            }
+            nold = nrd;
             if (lead) {
                 // h = C^T g_l = L^-1 g_l
                 double* hq = hb + team * NCOL + 12 * mi + rc.col;
@@ -442,7 +466,7 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
     if (!GEMM || gemm) {
         LsRec rc = load_rec(task), rn = load_rec(task + tstep), rnn;
         LsDat da, db;
-        load_dat(rc, da);
+        load_dat(rc, da, 0);
         // two tasks per round, the data sets swapping roles (no register moves of loads in flight)
         while (task < t1) {
             run_task(rc, da, rn, db, rnn);
