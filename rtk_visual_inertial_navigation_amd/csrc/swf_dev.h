@@ -28,6 +28,7 @@ struct WinRec {
     int cl0, cl1;                // cliques
     int pair0, pair1;            // reduced block pairs
     int fsb0, fsb1;              // frame-sum blocks of this window
+    int tail_dim;                // dimensions of the parameter_head tail (last rows of the reduced system): the block of L its consumers read
     double proj_sqrt_info, proj_loss_a;
     double pbg[3], gw[3], base[3];
 };

@@ -225,6 +225,9 @@ struct swf_batch {
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
+    bool chol_rr2 = false;                // SWF_CHOL_RR2=1: the previous register-resident kernel (A/B testing)
+    bool export_L_always = false;         // SWF_EXPORT_L=1: k_chol_rr3 writes the whole factor on every solve path
+    bool L_full = false;                  // the L buffer holds the whole factor of the last linear solve
     bool fs_fused = true;                 // per-frame sums inside k_eval_ps (SWF_FS_SEPARATE=1: k_frame_sums as its own launch; A/B testing)
     bool asm_old = false;                 // SWF_ASM_OLD=1: the pair-walking assembly kernel instead of the flat program (A/B testing)
     int asm_programs = 0;                 // distinct assembly programs of the batch (windows of identical structure share one)
@@ -308,7 +311,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
     {
         int td = 0;
         for (int i = w->n_order - w->n_tail; i < w->n_order; i++) if (i >= 0) td += ls[w->order_block[i]];
-        hw.tail_dim = td;
+        hw.tail_dim = td; R.tail_dim = td;
     }
     for (int b = 0; b < nb; b++) {
         B.blk_xoff.push_back(R.x_base + xo[b]);
@@ -821,6 +824,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->stream = (hipStream_t)stream;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
+    b->chol_rr2 = getenv("SWF_CHOL_RR2") != nullptr;
+    b->export_L_always = getenv("SWF_EXPORT_L") != nullptr;
     b->asm_old = getenv("SWF_ASM_OLD") != nullptr;
     b->fs_fused = getenv("SWF_FS_SEPARATE") == nullptr;
     // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
@@ -1343,6 +1348,7 @@ namespace {
 struct Launcher {
     swf_batch* b; DevOpt O; hipStream_t st;
     bool lm_folded = false;     // k_lm_schur of the current linearisation wrote ONE folded product (else GEMM_SPLIT partials)
+    bool export_full = false;   // k_chol_rr3 writes the whole factor (ASSEMBLE_ELIMINATE_ONLY: marginalisation, swf_batch_export_reduced), else the tail block only
     int lm_next = 0, lm_qpb = 1;                 // first tile of the ranges of k_lm_schur still to launch (with the clique kernels)
     int ls_tiles_per_launch() const { return b->ls_var == 0 ? 16 : b->ls_var == 1 ? 40 : 72; }
     // one launch of the landmark Schur kernel over the tile-list entries [tile_base, tile_base + tiles per launch), by row class
@@ -1460,7 +1466,10 @@ struct Launcher {
         Bracket t(*this, SWF_K_CHOL);
         if (b->max_red <= CB_NMAX && !b->force_chol_v1) {
             // per-window choice (each kernel skips the other's windows): register-resident tiles up to 240 dimensions, streamed above
-            if (b->min_red <= 240) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
+            if (b->min_red <= 240) {
+                if (b->chol_rr2) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
+                else hipLaunchKernelGGL(k_chol_rr3, dim3(D.n_win), dim3(1024), 0, st, D, export_full ? 1 : 0);
+            }
             if (b->max_red > 240 && D.Wk) {
                 const int Tc = (b->max_red + 15) / 16;
                 const int nbw = std::max(1, std::min(CC_NB, b->n_cu / D.n_win));       // the chip divided by the windows
@@ -1524,6 +1533,8 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
         return fail(SWF_E_UNSUPPORTED, "jacobi_scaling with the dogleg strategy (the reference sets jacobi_scaling = 0 wherever it selects DOGLEG: R/swf/swf.cpp:26-27)");
     DevBatch& D = b->D;
     Launcher L{ b, to_devopt(opt), b->stream };
+    L.export_full = opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY || b->export_L_always;
+    b->L_full = L.export_full || b->chol_rr2 || b->min_red > 240 || b->force_chol_v1 || b->max_red > CB_NMAX;
     hipStream_t st = b->stream;
     b->ev_used = 0; b->ev_kind.clear();
     int nlin = 0;
@@ -1652,9 +1663,13 @@ extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, doub
     if (L) {
         std::vector<double> Lt((n + 1) * (n + 1));
         HIPCHK(hipMemcpy(Lt.data(), b->D.L + W.Lt_base, Lt.size() * sizeof(double), hipMemcpyDeviceToHost));
-        bool rr = b->max_red <= CB_NMAX && !b->force_chol_v1;      // k_chol_rr2 / k_chol_big write row-major lower, ld = n
+        bool rr = b->max_red <= CB_NMAX && !b->force_chol_v1;      // k_chol_rr3 / k_chol_big write row-major lower, ld = n
+        // k_chol_rr3 on a solve path keeps the factor in registers and writes only the block its readers use: the parameter_head
+        // tail (from the 16-aligned row / column at or before its start).  Everything else is returned as zero.
+        size_t first = 0;
+        if (!b->L_full && n <= 240) { const size_t td = (size_t)b->hw[w].tail_dim; first = td ? ((n - td) >> 4) << 4 : n; }
         for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++)
-            L[r * n + c] = (c <= r) ? (rr ? Lt[r * n + c] : Lt[c * (n + 1) + r]) : 0.0;
+            L[r * n + c] = (c <= r && c >= first) ? (rr ? Lt[r * n + c] : Lt[c * (n + 1) + r]) : 0.0;
     }
     return SWF_OK;
 }

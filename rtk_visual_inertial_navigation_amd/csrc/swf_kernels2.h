@@ -51,9 +51,11 @@ __device__ __forceinline__ double bperm_d(double v, int idx_bytes) {
 __device__ unsigned long long g_chol_stamps[64];
 #define CHSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define CHACC(i, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define CHSTAMP2(i) do { if (blockIdx.x == 0 && threadIdx.x == 128) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CHSTAMP(i)
 #define CHACC(i, t0)
+#define CHSTAMP2(i)
 #endif
 template <int NT>
 __global__ void __launch_bounds__(NT, NT == 256 ? CH_OCC : 4) k_chol_solve(DevBatch B) {
@@ -350,8 +352,14 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
     unsigned long long tq = 0;
 #endif
     CHSTAMP(0);
+#ifdef SWF_PROFILE_CHOL
+    if (blockIdx.x == 0 && lane == 0) g_chol_stamps[32 + wv] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);   // HW_ID
+#endif
     if (wv == 0) {
         // =============================== pivot wave ===============================
+#ifdef SWF_CHOL_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         __syncthreads();                                   // tables / fail initialised
         __syncthreads();                                   // A_0: tile (0,0) published
         CHSTAMP(3);
@@ -531,6 +539,8 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
     double* y = B.y + W.loc_base + W.n_e;
     for (int e = tid - 64; e < n; e += 960) y[e] = zs[e];
 }
+
+#include "swf_chol_rr.h"
 
 // =========================================================================================
 // k_chol_big — the same pivot / panel / look-ahead pipeline as k_chol_rr2 for 240 < n_red <= 640, where the factor

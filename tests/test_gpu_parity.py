@@ -184,7 +184,10 @@ def test_golden_fixtures():
         bs.close()
         bs, sm = gpu_solve(w, default_options(max_num_iterations=int(gold["iters"])))
         costs = np.array([r["cost"] for r in sm.rows()])
-        assert np.abs(costs - gold["costs"]).max() <= 5e-7 * np.abs(gold["costs"]).min() + 1e-7 * 0 or rel(costs / gold["costs"], np.ones_like(costs)) < 5e-7
+        # the trajectory follows the oracle's to what eps cond(S) leaves of it: 5e-7 relative, or 3e-19 cond(S0) where that is larger (the RTK
+        # fixture: cond 6e12, two backward-stable factorisations — k_chol_rr2 and k_chol_rr3 — sit at 4.5e-7 and 6.2e-7 from the oracle)
+        tol = max(5e-7, 3e-19 * np.linalg.cond(gold["S0"]))
+        assert np.abs(costs - gold["costs"]).max() <= 5e-7 * np.abs(gold["costs"]).min() or rel(costs / gold["costs"], np.ones_like(costs)) < tol
         assert np.array_equal(np.array([r["step_is_successful"] for r in sm.rows()]), gold["ok"])
         assert np.abs(w.a["pose"] - gold["pose"]).max() < 1e-6
         if "comp_pose" in gold and gold["comp_pose"].size:
@@ -997,9 +1000,11 @@ def test_ambiguity_covariance_hand_off():
     cond = np.linalg.cond(t["A"])
     assert np.abs(t["A"] @ t["Qy"] - np.eye(n)).max() <= 1e-14 * cond
     assert np.abs(t["Qy"] - t["Qy"].T).max() <= 1e-14 * np.abs(t["Qy"]).max() * np.sqrt(cond)
-    # it is the marginal covariance of the tail: the trailing block of the inverse of the factorised matrix L L^T
-    full = np.linalg.inv(L @ L.T)[m:, m:]
-    assert np.abs(t["Qy"] - full).max() <= 1e-15 * np.linalg.cond(L @ L.T) * np.abs(full).max() + 1e-12 * np.abs(full).max()
+    # it is the marginal covariance of the tail: the trailing block of the inverse of the factorised matrix S = L L^T
+    # (after an optimising solve the export carries the tail block of L only — include/swf_solver.h — so S itself is inverted here)
+    assert np.all(L[:m - 16, :] == 0.0) and np.all(L[:, :max(0, m - 16)] == 0.0)
+    full = np.linalg.inv(S)[m:, m:]
+    assert np.abs(t["Qy"] - full).max() <= 1e-15 * np.linalg.cond(S) * np.abs(full).max() + 1e-12 * np.abs(full).max()
     bs.close()
     P, blocks = solver.problem_from_window(w0.copy())
     P.Solve(default_options())

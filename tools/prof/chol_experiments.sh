@@ -1,4 +1,4 @@
-# k_chol_rr2 on one box: kernel stats (batch 512, single window), per-phase stamps
+# the register-resident Cholesky on one box: kernel stats (batch 512, single window), per-phase stamps
 cd $GRAFT_REPO_ROOT
 bash tools/prof/kstats.sh 512 2 2>&1 | grep "chol\|lm_schur"
 cd /tmp && export TMPDIR=/tmp
@@ -6,9 +6,8 @@ rm -rf /tmp/ks1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/
 python - <<'PY'
 import csv,glob
 f=glob.glob('/tmp/ks1/**/*kernel_stats.csv', recursive=True)[0]
-tot=0
 rows=list(csv.DictReader(open(f)))
-for r in rows[:16]:
+for r in rows[:8]:
     print('1win %-58s calls %4s avg %8.1f us %5s%%'%(r['Name'][:58], r['Calls'], float(r['AverageNs'])/1e3, r['Percentage']))
 PY
 cd $GRAFT_REPO_ROOT

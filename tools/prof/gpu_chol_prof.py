@@ -15,3 +15,5 @@ print("factor total ticks", s[1] - s[0], "backward", s[2] - s[1], "(s_memtime ti
 print("v1: mfma+init / rr: publish+sync", s[8], "| v1: transpose / rr: diag factor+inverse", s[9], "| v1: diag / rr: panel", s[10], "| v1: trsm / rr: trailing", s[11])
 print("rr2: start->A0 (load)", s[3] - s[0], "| factor loop", s[1] - s[3], "| export wait", s[4] - s[1], "| backward", s[2] - s[4])
 print("rr2 sums: pivot factor+inverse", s[9], "| wait B (trailing of others)", s[8], "| B->C (panel)", s[10], "| C->A (lookahead diag)", s[11])
+print("rr3 tile wave 2 (ticks from kernel start): tile list", s[16]-s[0], "| loads issued + diag tiles", s[17]-s[0], "| transposed", s[18]-s[0], "| A_0", s[19]-s[0], "| loop end", s[20]-s[0], "| exported", s[21]-s[0])
+print("rr3 arrival at A_0 per wave (ticks from kernel start):", [x - s[0] if x else 0 for x in s[32:48]])
