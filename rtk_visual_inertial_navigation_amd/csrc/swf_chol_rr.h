@@ -7,16 +7,17 @@
 //     A_JI -= U_jJ^T U_jI, so the panel needs no LDS round trip before its MFMAs and publishes its registers as they are;
 //   * the wave that owns panel tile (j+1, j) also owns diagonal tile (j+1, j+1): it updates and publishes it straight from its own
 //     registers, inside the panel phase — two workgroup barriers per step instead of three;
-//   * the pivot is two waves: wave 0 factors the diagonal tile (the 16-step rsqrt chain and nothing else), wave 1 runs the
-//     forward substitution L X = I one column behind it, fed through LDS (the row of A and 1/sqrt(pivot) per column, a progress
-//     counter), so the inverse costs the chain only its lag;
+//   * the pivot is two waves on a SIMD of their own: wave 0 factors the diagonal tile (the 16-step rsqrt chain and nothing else),
+//     the first other wave of its SIMD runs the forward substitution L X = I one column behind it, fed through LDS (the row of A
+//     and 1/sqrt(pivot) per column; the latter doubles as the "column ready" flag); the SIMD's remaining waves own no tiles,
+//     because fp64 MFMAs and fp64 VALU work of one SIMD do not overlap (tests/microbench/pivot_chain.hip);
 //   * the factor is written to HBM only where somebody reads it: the parameter_head tail block (marginalisation / covariance
 //     hand-off) on solve paths, everything in ASSEMBLE_ELIMINATE_ONLY mode (swf_batch_export_reduced).
 // Plain dense Cholesky of S in the predefined elimination order, only tiled; same MFMA term order as k_chol_rr2.
 #pragma once
 
-#define RR3_NS 9         // off-diagonal tiles per tile wave (120 of a 240-dimension system, rhs row included, over 14 waves)
-#define RR3_NTW 14       // tile waves (waves 2..15)
+#define RR3_NS 10        // off-diagonal tiles per tile wave (120 of a 240-dimension system, rhs row included, over 12 or more waves)
+#define RR3_MINTW 12     // tile waves the roles guarantee
 
 // transpose a 16x16 tile held in the accumulator layout through a wave-private [16][17] LDS scratch.  No s_waitcnt between the
 // writes and the reads: the LDS executes one wave's instructions in order, so only the compiler has to keep them in place.
@@ -32,14 +33,18 @@ __device__ __forceinline__ void rr3_transpose(double4_t& a, double* X, int li, i
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void rr3_wait_prog(unsigned* prog, unsigned target) {
+// wave 1 waits for column c of the pivot wave: 1/sqrt(pivot) is written last (the LDS keeps a wave's operations in order) into a slot
+// that is zero between tiles; any non-zero bit pattern (NaN of a broken pivot included) releases the wait
+__device__ __forceinline__ double rr3_wait_ip(const double* slot) {
     asm volatile("" ::: "memory");
+    double v = 0.0;
     for (int spin = 0; spin < (1 << 22); spin++) {
-        unsigned v = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+        v = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (__builtin_amdgcn_readfirstlane(__double2hiint(v)) != 0) break;
         __builtin_amdgcn_s_sleep(0);
     }
     asm volatile("" ::: "memory");
+    return v;
 }
 
 // wave 0: right-looking Cholesky of the published diagonal tile D (full symmetric), lane (li, lk), register q <-> A[lk+4q][li].
@@ -52,7 +57,7 @@ __device__ __forceinline__ void rr3_wait_prog(unsigned* prog, unsigned target) {
 //   * 1/sqrt is v_rsq_f64 + two Newton steps (rsqrt_nr) opened up: the scaled row sA = A[c][:] / A_cc leaves two operations
 //     after the last Newton factor f, sA = (row y1 f) (y1 f), instead of four (ip, ip^2, row ip^2, mask).
 // Column scalings are deferred (as in chol_pivot_tile).
-__device__ __forceinline__ bool rr3_pivot_factor(double (*D)[17], double* colb, double* ipb, unsigned* prog, double (*Dl)[17], bool want_L, int li, int lk) {
+__device__ __forceinline__ bool rr3_pivot_factor(double (*D)[17], double* colb, double* ipb, double (*Dl)[17], bool want_L, int li, int lk) {
 #pragma clang fp contract(off)
     double A_[4];
 #pragma unroll
@@ -74,10 +79,10 @@ __device__ __forceinline__ bool rr3_pivot_factor(double (*D)[17], double* colb, 
         const double ip = y * f;
         const double row0 = (li > c) ? rowA : 0.0;        // columns <= c of A are final (L) already
         const double sA = ((row0 * y) * f) * ip;
-        colb[c * 16 + pidx] = rowA;                       // (the four rows of lanes write the same values)
-        ipb[c] = ip;
         asm volatile("" ::: "memory");
-        __hip_atomic_store(prog, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // LDS keeps a wave's operations in order
+        colb[c * 16 + pidx] = rowA;                       // (the four rows of lanes write the same values)
+        asm volatile("" ::: "memory");
+        __hip_atomic_store((unsigned long long*)(ipb + c), (unsigned long long)__double_as_longlong(ip), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // ... and this releases wave 1 (the LDS keeps a wave's operations in order)
         asm volatile("" ::: "memory");
         if (c == 15) break;
         const int c1 = c + 1;
@@ -104,38 +109,55 @@ __device__ __forceinline__ bool rr3_pivot_factor(double (*D)[17], double* colb, 
 }
 
 // wave 1: X = L^-1 by forward substitution, column by column behind wave 0:  R[r][:] -= A[r][c] R[c][:] / A_cc for r > c.
-__device__ __forceinline__ void rr3_pivot_inverse(double (*LiJ)[17], const double* colb, const double* ipb, unsigned* prog, int li, int lk) {
+// One LDS round trip per column: the poll of 1/sqrt(pivot) and the reads of the column go out together (the column was written
+// first, so a released poll means the reads behind it saw it); row c+1 of R is fetched across the lanes a column ahead and
+// brought up to date by the FMA its register copy gets too, as in the pivot wave.
+__device__ __forceinline__ void rr3_pivot_inverse(double (*LiJ)[17], const double* colb, double* ipb, int li, int lk) {
+#pragma clang fp contract(off)
     double R_[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) R_[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
     int bidx[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
+    double rowR = li == 0 ? 1.0 : 0.0;                    // R[0][li]
+    double rowPre = li == 1 ? 1.0 : 0.0;                  // row 1, before step 0
 #pragma unroll
     for (int c = 0; c < 15; c++) {
-        const int cq = c >> 2, cr = c & 3;
-        rr3_wait_prog(prog, (unsigned)(c + 1));
-        double colv[4];
+        double ip, colv[4];
+        asm volatile("" ::: "memory");
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            asm volatile("" ::: "memory");
+            ip = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)(ipb + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 #pragma unroll
-        for (int q = 0; q < 4; q++) colv[q] = colb[c * 16 + lk * 4 + q];      // A[lk+4q][c]
-        double ip = ipb[c];
-        double ip2 = ip * ip;
-        double rowR = bperm_d(R_[cq], bidx[cr]);          // R[c][li]
-        double sR = rowR * ip2;
+            for (int q = 0; q < 4; q++) colv[q] = colb[c * 16 + lk * 4 + q];      // A[lk+4q][c]
+            asm volatile("" ::: "memory");
+            if (__builtin_amdgcn_readfirstlane(__double2hiint(ip)) != 0) break;
+            __builtin_amdgcn_s_sleep(0);
+        }
+        asm volatile("" ::: "memory");
+        const double ip2 = ip * ip;
+        const double sR = rowR * ip2;
+        const int c1 = c + 1;
+        const double x = readlane_d(colv[c1 >> 2], (c1 & 3) * 16);            // A[c+1][c]
+        const double rowNext = __builtin_fma(-x, sR, rowPre);                // row c+1 of R after step c
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (4 * q + 3 <= c) continue;
             if (lk + 4 * q > c) R_[q] = __builtin_fma(-colv[q], sR, R_[q]);
         }
+        if (c + 2 < 16) rowPre = bperm_d(R_[(c + 2) >> 2], bidx[(c + 2) & 3]);      // row c+2 after step c
+        rowR = rowNext;
     }
-    rr3_wait_prog(prog, 16u);
+    (void)rr3_wait_ip(ipb + 15);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         int r = lk + 4 * q;
         LiJ[r][li] = (li <= r) ? R_[q] * ipb[r] : 0.0;    // row r of X = L^-1
     }
     asm volatile("" ::: "memory");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(prog, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // wave 0 starts the next tile two barriers from here
+    __builtin_amdgcn_wave_barrier();
+    if ((threadIdx.x & 63) < 16) __hip_atomic_store((unsigned long long*)(ipb + (threadIdx.x & 63)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // slots back to "not yet" (wave 0 starts the next tile two barriers from here)
     asm volatile("" ::: "memory");
 }
 
@@ -149,7 +171,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
     __shared__ double dinv[16];                //             1/sqrt(pivot), per column
     __shared__ double zs[256];
     __shared__ double yv[256];
-    __shared__ unsigned prog;
+    __shared__ int wsimd[16];
     __shared__ int fail;
     int w = blockIdx.x;
     WinState& st = B.ws[w];
@@ -167,9 +189,28 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
     unsigned long long tq = 0;
 #endif
     CHSTAMP(0);
-    if (tid == 0) { fail = 0; prog = 0u; }
+    if (tid == 0) fail = 0;
+    if (tid < 16) dinv[tid] = 0.0;
     for (int e = tid; e < 256; e += 1024) zs[e] = 0.0;
-    if (wv == 0) {
+    // Roles by SIMD.  fp64 MFMAs and fp64 VALU instructions of one SIMD do not overlap, so every trailing-update MFMA issued on the
+    // pivot wave's SIMD lengthens the one dependency chain the whole factorisation waits for (tests/microbench/pivot_chain.hip: 211
+    // cycles per column alone, ~350 next to three tile waves).  Wave 0 is the pivot wave; the first other wave on its SIMD takes
+    // the inverse (light VALU work); the SIMD's remaining waves leave at once unless fewer than 12 waves sit on the other SIMDs.
+    if (lane == 0) wsimd[wv] = (int)__builtin_amdgcn_s_getreg(2308);       // HW_REG_HW_ID, SIMD_ID (bits 5:4)
+    __syncthreads();                                       // R
+    int role, tw, ntw;                                     // role 0 pivot factor, 1 pivot inverse, 2 tile wave (tw of ntw)
+    {
+        const int ps = wsimd[0];
+        const unsigned onp = (unsigned)__ballot(lane >= 1 && lane < 16 && wsimd[lane & 15] == ps) & 0xfffeu;      // other waves on the pivot's SIMD
+        const unsigned rbit = onp ? (onp & (0u - onp)) : 2u;                                                     // the inverse wave
+        unsigned rest = onp & ~rbit, tiles = 0xfffeu & ~onp & ~rbit;
+        for (int need = RR3_MINTW - __popc(tiles); need > 0 && rest; need--) { unsigned b = rest & (0u - rest); tiles |= b; rest &= ~b; }
+        const unsigned me = 1u << wv;
+        role = wv == 0 ? 0 : (rbit & me) ? 1 : (tiles & me) ? 2 : 3;
+        tw = __popc(tiles & (me - 1u)); ntw = __popc(tiles);
+    }
+    if (role == 3) return;
+    if (role == 0) {
         // =============================== pivot wave: the factor of the diagonal tiles ===============================
         __syncthreads();                                   // A_0: tile (0,0) published
         CHSTAMP(3);
@@ -177,9 +218,12 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
-            bool bad = rr3_pivot_factor(Dt[j & 1], colb, dinv, &prog, Dl, j >= ef, li, lk);
+            bool bad = rr3_pivot_factor(Dt[j & 1], colb, dinv, Dl, j >= ef, li, lk);
             if (bad && lane == 0) fail = 1;
             CHACC(9, tq);
+#ifdef SWF_PROFILE_CHOL
+            if (blockIdx.x == 0 && lane == 0 && j == SWF_PROFILE_CHOL_STEP) { g_chol_stamps[48] = tq; g_chol_stamps[32] = __builtin_amdgcn_s_memtime(); }
+#endif
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
@@ -210,11 +254,14 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
         CHSTAMP(2);
         return;
     }
-    if (wv == 1) {
+    if (role == 1) {
         // =============================== pivot wave: the inverse of the diagonal tiles ===============================
         __syncthreads();                                   // A_0
         for (int j = 0; j < Tc; j++) {
-            rr3_pivot_inverse(Li[j], colb, dinv, &prog, li, lk);
+            rr3_pivot_inverse(Li[j], colb, dinv, li, lk);
+#ifdef SWF_PROFILE_CHOL
+            if (blockIdx.x == 0 && lane == 0 && j == SWF_PROFILE_CHOL_STEP) g_chol_stamps[32 + wv] = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();                               // B_j
             if (fail) return;
             if (j >= ef) {
@@ -233,15 +280,14 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
     }
     // =============================== tile waves ===============================
     const double* S = B.S + W.S_base;
-    const int tw = wv - 2;
-    double* Xs = &Pn[0][0][0] + tw * 272;                  // wave-private transposition scratch (14 x 272 doubles of the panel buffer)
-    // this wave's off-diagonal tiles (the rhs tile row Tc included): tile e of the column-order list belongs to wave e mod 14, slot e / 14,
+    double* Xs = &Pn[0][0][0] + tw * 272;                  // wave-private transposition scratch (up to 14 x 272 doubles of the panel buffer)
+    // this wave's off-diagonal tiles (the rhs tile row Tc included): tile e of the column-order list belongs to tile wave e mod ntw, slot e / ntw,
     // so the panel tiles of a column and the trailing tiles of every step spread evenly over the waves
     int sI[RR3_NS], sJ[RR3_NS];
     {
         int mI = -1, mJ = -1;                               // lane s works out slot s
         if (lane < RR3_NS) {
-            int e = lane * RR3_NTW + tw, J = 0;
+            int e = lane * ntw + tw, J = 0;
             while (J < Tc && (J + 1) * (Tr - 1) - (J + 1) * J / 2 <= e) J++;
             if (J < Tc) { mI = J + 1 + e - (J * (Tr - 1) - J * (J - 1) / 2); mJ = J; }
         }
@@ -263,7 +309,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
             // tile fully inside the matrix (its columns end before its rows begin): one add per element
             const double* St = S + (16 * I * n + 16 * J);
 #pragma unroll
-            for (int q = 0; q < 4; q++) acc[s][q] = -St[lpart[q]];
+            for (int q = 0; q < 4; q++) acc[s][q] = St[lpart[q]];
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -274,12 +320,13 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
                 int rc = rr < n ? rr : (rhs_el ? n : n - 1), cc = c < n ? c : n - 1;
                 if (I < 0) { rc = 0; cc = 0; }
                 double v = S[rc * n + cc];                                // 32-bit element offset from the one S base (rc >= cc: I > J)
-                acc[s][q] = inside ? -v : 0.0;
+                acc[s][q] = inside ? v : 0.0;
             }
         }
     }
-    // the diagonal tiles go to LDS, fully symmetric (the pivot needs both triangles), identity on the padding; tile J by wave J mod 14
-    for (int J = tw; J < Tc; J += RR3_NTW) {
+    asm volatile("" ::: "memory");                          // (every load above is on its way before the first value is touched)
+    // the diagonal tiles go to LDS, fully symmetric (the pivot needs both triangles), identity on the padding; tile J by tile wave J mod ntw
+    for (int J = tw; J < Tc; J += ntw) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             int r = 16 * J + lk + 4 * q, c = 16 * J + li;
@@ -291,14 +338,15 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
         }
     }
     CHSTAMP2(17);
-    // into the transposed layout
+    // negated, into the transposed layout
 #pragma unroll
     for (int s = 0; s < RR3_NS; s++)
-        if (sI[s] >= 0) rr3_transpose(acc[s], Xs, li, lk);
+        if (sI[s] >= 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[s][q] = -acc[s][q];
+            rr3_transpose(acc[s], Xs, li, lk);
+        }
     CHSTAMP2(18);
-#ifdef SWF_PROFILE_CHOL
-    if (blockIdx.x == 0 && lane == 0) g_chol_stamps[32 + wv] = __builtin_amdgcn_s_memtime();
-#endif
     __syncthreads();                                       // A_0
     CHSTAMP2(19);
     for (int j = 0; j < Tc; j++) {
@@ -311,6 +359,9 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
 #pragma unroll
             for (int q = 0; q < 4; q++) dn[q] = Dg[j + 1][q][lane];
         }
+#ifdef SWF_PROFILE_CHOL
+        if (blockIdx.x == 0 && lane == 0 && j == SWF_PROFILE_CHOL_STEP) g_chol_stamps[32 + wv] = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();                                   // B_j: Linv_jj ready; trailing updates of step j-1 done
         if (fail) return;
         // panel row j of U: U_jI = Linv_jj A_jI.  Tile (j+1, j) first, with the diagonal tile j+1 right behind it (published for the pivot).
@@ -325,7 +376,8 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
 #pragma unroll
         for (int s = 0; s < RR3_NS; s++) {
             if (sJ[s] != j) continue;
-            const int I = sI[s];
+            int I = sI[s];
+            asm volatile("" : "+s"(I));                    // (addresses from the scalar tile index at the point of use: no per-slot address registers across the loop)
             double4_t X = { 0, 0, 0, 0 };
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(linv[kk], acc[s][kk], X, 0, 0, 0);
@@ -355,8 +407,9 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
 #pragma unroll
         for (int s = 0; s < RR3_NS; s++) {
             if (sJ[s] != j) continue;
-            const int I = sI[s];
+            int I = sI[s];
             if (I <= j + 2 || I >= Tc) continue;
+            asm volatile("" : "+s"(I));
             double4_t d;
 #pragma unroll
             for (int q = 0; q < 4; q++) d[q] = Dg[I][q][lane];
@@ -408,5 +461,5 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
         __syncthreads();                                   // Y_J
     }
     double* y = B.y + W.loc_base + W.n_e;
-    for (int e = tid - 128; e < n; e += 896) y[e] = zs[e];
+    for (int e = tw * 64 + lane; e < n; e += ntw * 64) y[e] = zs[e];
 }

@@ -48,6 +48,9 @@ __device__ __forceinline__ double bperm_d(double v, int idx_bytes) {
     return __hiloint2double(hi, lo);
 }
 #ifdef SWF_PROFILE_CHOL
+#ifndef SWF_PROFILE_CHOL_STEP
+#define SWF_PROFILE_CHOL_STEP 2
+#endif
 __device__ unsigned long long g_chol_stamps[64];
 #define CHSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define CHACC(i, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
