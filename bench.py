@@ -400,7 +400,7 @@ def main():
             "post_dogleg": ("hbm", (152 + 16) * n_obs, "candidate residuals: 152 B read + 16 B written per observation (the model cost change comes from k_dogleg's vector sums)"),
         }
         bound, units, what = work.get(dom, ("hbm", calib["jacobian_bytes"], "Jacobian bytes of the batch (SURVEY.md 8d formula)"))
-        knames = {"eval_ps": "k_eval_ps<true, true>", "lm_schur": "k_lm_schur<8, 5, 2, 144, true>", "assemble": "k_assemble_flat", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr2<9>"}
+        knames = {"eval_ps": "k_eval_ps<true, true>", "lm_schur": "k_lm_schur<8, 5, 2, 144, true>", "assemble": "k_assemble_flat", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr3"}
         # HBM traffic from the committed PMC passes of the same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate passes; gfx950: FETCH_SIZE counts half of wide coalesced reads -> x2), if available
         traffic = None

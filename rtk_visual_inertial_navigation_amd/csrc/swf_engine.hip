@@ -215,6 +215,7 @@ struct swf_batch {
     // (one copy per array instead of six small ones per window: 576 GNSS-epoch priors took 46 ms of hipMemcpy latency)
     bool mg_host = false; std::vector<double> h_mgA, h_mgJ, h_mgb, h_mgr0, h_mgw; std::vector<int> h_mgrank;
     double* mg_resM = nullptr; double* mg_resb = nullptr; int* mg_resok = nullptr;      // k_marg_rescue outputs (rank-deficient tails)
+    int* mg_rot = nullptr; int* mg_bjok = nullptr;                                       // k_marg_bj: rotations per sweep, windows taking part
     // ambiguity covariance hand-off outputs (allocated at the first swf_batch_tail_covariance)
     int* tc_tail = nullptr; double* tc_A = nullptr; double* tc_Q = nullptr; double* tc_X = nullptr; int* tc_rank = nullptr; bool tc_valid = false; int tc_ld = 0;
     // latency path (small batches): an auxiliary stream runs the IMU / clique branch of a linearisation next to the
@@ -1704,11 +1705,47 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
         hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), 0, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok, force, eps);
     hipLaunchKernelGGL(k_marginalize<false>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
                        b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, (double*)nullptr,
-                       (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force);
-    if (big)
-        hipLaunchKernelGGL(k_marginalize<true>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
-                           b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M,
-                           (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force);
+                       (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force, 0, (int*)nullptr);
+    if (big) {
+        // large tails: set-up, the block-Jacobi sweeps over many workgroups (fixed launch schedule; converged windows return at once), write-out
+        if (!b->mg_rot && (b->pool.zeros((size_t)nw * MG_SWEEPS, &b->mg_rot) || b->pool.zeros((size_t)nw, &b->mg_bjok))) return fail(SWF_E_NODEVICE, "device allocation failed");
+        HIPCHK(hipMemsetAsync(b->mg_rot, 0, (size_t)nw * MG_SWEEPS * sizeof(int), b->stream));
+        auto phase = [&](int ph) {
+            hipLaunchKernelGGL(k_marginalize<true>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
+                               b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M,
+                               (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force, ph, b->mg_bjok);
+        };
+        if (getenv("SWF_MARG_ONE_WG")) phase(0);              // A/B: the single-workgroup sweeps
+        else {
+            phase(1);
+            hipLaunchKernelGGL(k_marg_gram, dim3((ldn * ldn + 255) / 256, nw), dim3(256), 0, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_M, b->mg_A, (const int*)b->mg_bjok);
+            // block size: 8 columns (17 workgroups per launch at 263 dimensions, 8 inner steps each; 16-column blocks halve the launches
+            // but leave a step to 9 workgroups whose 16 waves share 4 SIMDs: 49 us per launch against 15)
+            const int bs = getenv("SWF_MARG_BS16") && ldn <= 288 ? 16 : ldn <= 576 ? 8 : 4, nb = (ldn + bs - 1) / bs, nbe = (nb + 1) & ~1;
+            std::vector<int> hrot((size_t)nw * MG_SWEEPS);
+            for (int sweep = 0; sweep < MG_SWEEPS; sweep++) {
+                if (sweep >= 8 && (sweep & 3) == 0) {
+                    // every four sweeps: has every window reported a sweep without rotations?  (the launches of a converged window return
+                    // at once, but a 263-dimension sweep is still 34 launches)
+                    HIPCHK(hipMemcpyAsync(hrot.data(), b->mg_rot, hrot.size() * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+                    HIPCHK(hipStreamSynchronize(b->stream));
+                    bool all = true;
+                    for (int w = 0; w < nw && all; w++) { bool done = false; for (int k = 0; k < sweep; k++) done = done || hrot[(size_t)w * MG_SWEEPS + k] == 0; all = done; }
+                    if (all) break;
+                }
+                for (int st = -1; st < nbe - 1; st++) {
+                    dim3 grid(nbe / 2, nw);
+#define BJ_LAUNCH(BS_, LDM_, NR_) hipLaunchKernelGGL((k_marg_bj<BS_, LDM_, NR_>), grid, dim3(1024), 0, b->stream, (const int*)b->mg_tail, ldn, b->mg_M, b->mg_J, b->mg_rot, (const int*)b->mg_bjok, sweep, st)
+                    if (bs == 16) BJ_LAUNCH(16, 288, 5);
+                    else if (bs == 8 && ldn <= 320) BJ_LAUNCH(8, 576, 5);
+                    else if (bs == 8) BJ_LAUNCH(8, 576, 9);
+                    else BJ_LAUNCH(4, 640, 10);
+#undef BJ_LAUNCH
+                }
+            }
+            phase(2);
+        }
+    }
     HIPCHK(hipGetLastError());
     b->mg_valid = true; b->mg_host = false;
     return SWF_OK;

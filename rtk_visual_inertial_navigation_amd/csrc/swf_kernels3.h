@@ -129,7 +129,10 @@ template <bool GM>
 __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* tail_dim, double eps, int form, int ldn,
                                                         double* outA, double* outb, double* outJ, double* outr0,
                                                         double* outw, int* outrank, double* Mscr,
-                                                        const double* resM, const double* resb, const int* res_ok, int force) {
+                                                        const double* resM, const double* resb, const int* res_ok, int force,
+                                                        int phase, int* bj_ok) {
+    // phase 0: everything (GM = false).  GM = true runs as phase 1 (set-up: M, A, b, V = I), the block-Jacobi sweeps of k_marg_bj
+    // over many workgroups, then phase 2 (eigenvalues, square root, sorted write-out).
     __shared__ double lds[GM ? 16 : MG_LDS_DOUBLES];  // M (n x n, column c contiguous: row c of L_nn) | V (n x n) if both fit
     __shared__ double lam[GM ? MG_BIGN : MG_MAXN + 4];
     __shared__ double bv[GM ? MG_BIGN : MG_MAXN + 4];
@@ -141,6 +144,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     size_t o2 = (size_t)w * ldn * ldn, o1 = (size_t)w * ldn;
     if (GM != (form == 0 && n > MG_MAXN)) return;     // the other instantiation's window
     const bool rescued = ((s.lin_fail && s.chol_fail) || (force && !s.lin_fail)) && form == 0 && res_ok[w];       // k_marg_rescue supplied M (M^T M = A) and b
+    if (GM && phase == 1 && tid == 0) bj_ok[w] = 0;
     if (n <= 0 || n > ldn || m < 0 || (s.lin_fail && !rescued) || (form == 0 && n > MG_BIGN)) { if (tid == 0) outrank[w] = -1; return; }
     double* Mm = GM ? Mscr + o2 : lds;
     const double* L = B.L + W.Lt_base;                // row-major lower, ld = n_red (k_chol_rr2 / k_chol_big)
@@ -175,11 +179,15 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         if (tid == 0) outrank[w] = n;
         return;
     }
-    if (rescued) {
+    if (phase == 2) {
+        for (int i = tid; i < n; i += MG_NT) bv[i] = outb[o1 + i];
+        __syncthreads();
+    } else if (rescued) {
         // the rank-revealing factor of A from k_marg_rescue: row r of resM is v_r (sum_r v_r v_r^T = A), b comes with it
         const double* Rm = resM + o2;
         for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Mc(c, r) = Rm[(size_t)r * n + c]; }
         __syncthreads();
+        if (!(GM && phase == 1))                          // (large tails: k_marg_gram, over the chip)
         for (int e = tid; e < n * n; e += MG_NT) {
             int i = e / n, j = e - i * n;
             double a = 0;
@@ -192,6 +200,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Mc(c, r) = (r <= c) ? L[(size_t)(m + c) * nr + m + r] : 0.0; }
     __syncthreads();
     // A = M^T M (= L_nn L_nn^T, the marginal information of the tail), b = A y_n
+    if (!(GM && phase == 1))                              // (large tails: k_marg_gram, over the chip)
     for (int e = tid; e < n * n; e += MG_NT) {
         int i = e / n, j = e - i * n, k = i < j ? i : j;
         double a = 0;
@@ -214,12 +223,15 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     // U = M V / sigma loses orthogonality like eps * sqrt(cond) — measured 1.5e-9 in J^T r0 - b.  V lives in the
     // window's J buffer (column c contiguous, L2-resident working set) until the final permuted write-out.
     double* Vg = (!GM && 2 * n * n <= MG_LDS_DOUBLES) ? lds + n * n : outJ + o2;      // LDS-resident V when it fits (n <= 98)
-    for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Vg[e] = (r == c) ? 1.0 : 0.0; }
-    __syncthreads();
+    if (phase != 2) {
+        for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Vg[e] = (r == c) ? 1.0 : 0.0; }
+        __syncthreads();
+    }
+    if (phase == 1) { if (tid == 0) bj_ok[w] = 1; return; }      // the sweeps of this window run in k_marg_bj
     int grp = tid >> 4, sub = tid & 15;
     int ne = (n + 1) & ~1;                            // even number of players in the round-robin (a bye if n is odd)
     int sweeps_done = 0;
-    for (int sweep = 0; sweep < 40; sweep++) {
+    for (int sweep = 0; sweep < (phase == 2 ? 0 : 40); sweep++) {
         sweeps_done = sweep + 1;
         if (tid == 0) nrot = 0;
         __syncthreads();
@@ -290,6 +302,151 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         for (int k = 0; k < n; k++) pos += (lam[k] < lc) || (lam[k] == lc && k < c);
         for (int j = sub; j < n; j += 16) outJ[o2 + (size_t)pos * n + j] = Mc(c, j);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_marg_bj — the Jacobi sweeps of the large tails (MG_MAXN < n <= MG_BIGN) as a BLOCK one-sided Jacobi over many workgroups.
+// The single-workgroup loop above streams M and V (2 n^2 doubles) through one CU's L2 port at every one of its n - 1 steps per sweep:
+// 184 ms for the 263-dimension prior of the cfg5 window.  Here the columns are cut into blocks of BS; a launch is one BLOCK step:
+// workgroup g loads the columns of two blocks (M and V, 2 BS columns each) into LDS, orthogonalises every pair (p in the first block,
+// q in the second) in BS inner steps of BS disjoint pairs (one wavefront per pair), and writes the columns back.  The block pairs of
+// a step are disjoint (circle method), so a sweep is nb - 1 cross launches plus one launch for the pairs inside the blocks; every
+// column pair meets exactly once per sweep, as in the cyclic order.  Sweeps end when one reports no rotation (rot[sweep] == 0):
+// the remaining launches of the fixed schedule return at once.  Same rotation formulas and thresholds as k_marginalize.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MG_SWEEPS 32
+// A = M^T M of the large tails, one thread per entry over as many workgroups as it takes (the single workgroup of the set-up phase
+// spent 2.6 ms on the 263-dimension tail here).  Full-length sums: the zeros of a triangular M add exact zeros, so the entries are
+// those of the triangular loops above, bit for bit.
+__global__ void __launch_bounds__(256) k_marg_gram(const int* tail_dim, int ldn, const double* Mscr, double* outA, const int* bj_ok) {
+    const int w = blockIdx.y;
+    if (!bj_ok[w]) return;
+    const int n = tail_dim[w], e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * n) return;
+    const size_t o2 = (size_t)w * ldn * ldn;
+    const double* Mm = Mscr + o2;
+    const int i = e / n, j = e - i * n;
+    double a = 0;
+    for (int r = 0; r < n; r++) a += Mc(i, r) * Mc(j, r);
+    outA[o2 + e] = a;
+}
+template <int BS, int LDM, int NR>       // NR = rows per lane the launch's largest tail needs (n <= 64 NR <= LDM)
+__global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, double* Mscr, double* Vout, int* rot, const int* bj_ok, int sweep, int bstep) {
+    __shared__ double Ml[2 * BS][LDM];
+    __shared__ double Vl[2 * BS][LDM];
+    __shared__ int nrot;
+    const int w = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    if (!bj_ok[w]) return;
+    const int n = tail_dim[w];
+    if (n > LDM || n > 64 * NR) return;
+    int* rw = rot + (size_t)w * MG_SWEEPS;
+    if (sweep > 0 && rw[sweep - 1] == 0) return;         // converged
+    const int nb = (n + BS - 1) / BS, nbe = (nb + 1) & ~1;
+    int P, Q;
+    if (bstep < 0) { P = 2 * g; Q = 2 * g + 1; }          // the pairs inside blocks 2g and 2g + 1
+    else {
+        // circle method over the blocks: block nbe - 1 is fixed, the others rotate
+        if (g == 0) { P = nbe - 1; Q = bstep; }
+        else { P = bstep + g; if (P >= nbe - 1) P -= nbe - 1; Q = bstep - g; if (Q < 0) Q += nbe - 1; }
+        if (P > Q) { int t = P; P = Q; Q = t; }
+        if (Q >= nb) return;                              // the bye (odd number of blocks)
+    }
+    if (P >= nb) return;
+    const size_t o2 = (size_t)w * ldn * ldn;
+    double* Mm = Mscr + o2; double* Vg = Vout + o2;
+    auto gcol = [&](int lc) { int c = lc < BS ? P * BS + lc : Q * BS + (lc - BS); return (lc >= BS && Q >= nb) ? n : c; };
+#ifdef SWF_PROFILE_CHOL
+#define MGACC(i) do { if (blockIdx.x == 1 && blockIdx.y == 0 && tid == 0 && sweep == 1 && bstep == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_chol_stamps[i] += t_ - tacc; tacc = t_; } } while (0)
+#define MGSTAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 0 && tid == 0 && sweep == 1 && bstep == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MGSTAMP(i)
+#define MGACC(i)
+#endif
+    unsigned long long tacc = 0; (void)tacc;
+    MGSTAMP(50);
+    for (int lc = wv; lc < 2 * BS; lc += 16) {
+        const int c = gcol(lc);
+        if (c < n) {
+            // every request of the column on its way before the first value is stored (a launch is a few microseconds of work: one
+            // round trip to the other workgroups' columns per loop iteration was half of it)
+            double tm[NR], tv[NR];
+#pragma unroll
+            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k, rc = r < n ? r : 0; tm[k] = Mm[(size_t)c * n + rc]; tv[k] = Vg[(size_t)c * n + rc]; }
+#pragma unroll
+            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; if (r < n) { Ml[lc][r] = tm[k]; Vl[lc][r] = tv[k]; } }
+        }
+    }
+    if (tid == 0) nrot = 0;
+    __syncthreads();
+    MGSTAMP(51);
+#ifdef SWF_PROFILE_CHOL
+    if (blockIdx.x == 1 && blockIdx.y == 0 && tid == 0 && sweep == 1 && bstep == 0) { for (int i = 54; i < 60; i++) g_chol_stamps[i] = 0; }
+    tacc = __builtin_amdgcn_s_memtime();
+#endif
+    // one inner step = BS disjoint pairs, one wavefront each.  A step is bound by the latency of one wave's dependent work, not by issue
+    // (two half-wave pairs per wavefront were slower), so: the rows of the four columns are read ONCE, all requests before the first
+    // use (the loop over the rows is unrolled to the class's LDM / 64), and the rotation angle comes from the raw v_rcp / v_rsq
+    // estimates — a rotation by a slightly inexact angle is still exactly a rotation as long as c^2 + s^2 = 1, which the one
+    // Newton-refined rsqrt for c (s = c t) keeps to rounding; the angle only has to shrink the off-diagonal term.
+    const int nst = bstep < 0 ? BS - 1 : BS;
+    for (int st = 0; st < nst; st++) {
+        if (wv < BS) {
+            int p, q;
+            if (bstep < 0) {
+                // two independent round-robins of BS players (blocks P and Q): waves 0..BS/2-1 play in P, the others in Q
+                const int blk = wv >= BS / 2, pr = wv - blk * (BS / 2);
+                if (pr == 0) { p = BS - 1; q = st; }
+                else { p = st + pr; if (p >= BS - 1) p -= BS - 1; q = st - pr; if (q < 0) q += BS - 1; }
+                p += blk * BS; q += blk * BS;
+            } else { p = wv; q = BS + ((wv + st) % BS); }
+            if (p > q) { int t = p; p = q; q = t; }
+            if (gcol(p) < n && gcol(q) < n) {
+                double ma[NR], mb[NR], va[NR], vb[NR];
+#pragma unroll
+                for (int k = 0; k < NR; k++) {
+                    const int r = lane + 64 * k, rc = r < n ? r : n - 1;      // (unconditional reads, selected afterwards: no branch per row)
+                    const double x0 = Ml[p][rc], x1 = Ml[q][rc], x2 = Vl[p][rc], x3 = Vl[q][rc];
+                    const bool in = r < n;
+                    ma[k] = in ? x0 : 0.0; mb[k] = in ? x1 : 0.0; va[k] = in ? x2 : 0.0; vb[k] = in ? x3 : 0.0;
+                }
+                MGACC(54);
+                double al = 0, be = 0, ga = 0;
+#pragma unroll
+                for (int k = 0; k < NR; k++) { al += ma[k] * ma[k]; be += mb[k] * mb[k]; ga += ma[k] * mb[k]; }
+                // wave_sum of the three, stage by stage (two LDS round trips instead of six)
+                { const double x = __shfl_xor(al, 32, 64), y = __shfl_xor(be, 32, 64), z = __shfl_xor(ga, 32, 64); al += x; be += y; ga += z; }
+                { const double x = __shfl_xor(al, 16, 64), y = __shfl_xor(be, 16, 64), z = __shfl_xor(ga, 16, 64); al += x; be += y; ga += z; }
+                al = grp16_sum(al); be = grp16_sum(be); ga = grp16_sum(ga);
+                MGACC(55);
+                if (ga * ga > 1e-30 * (al * be) && fabs(ga) > 1e-140 * (al + be)) {
+                    const double zeta = (be - al) * (0.5 * __builtin_amdgcn_rcp(ga));
+                    const double hz = 1.0 + zeta * zeta;
+                    const double t = (zeta >= 0 ? 1.0 : -1.0) * __builtin_amdgcn_rcp(fabs(zeta) + hz * __builtin_amdgcn_rsq(hz));
+                    const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
+                    MGACC(56);
+#pragma unroll
+                    for (int k = 0; k < NR; k++) {
+                        const int r = lane + 64 * k;
+                        if (64 * NR <= LDM || r < n) {            // (rows past n of a column are scratch when the row has room for them: no branch)
+                            Ml[p][r] = c * ma[k] - sn * mb[k]; Ml[q][r] = sn * ma[k] + c * mb[k];
+                            Vl[p][r] = c * va[k] - sn * vb[k]; Vl[q][r] = sn * va[k] + c * vb[k];
+                        }
+                    }
+                    if (lane == 0) atomicAdd(&nrot, 1);
+                    MGACC(57);
+                }
+            }
+        }
+        __syncthreads();
+        MGACC(58);
+    }
+    MGSTAMP(52);
+    for (int lc = wv; lc < 2 * BS; lc += 16) {
+        const int c = gcol(lc);
+        if (c < n) for (int r = lane; r < n; r += 64) { Mm[(size_t)c * n + r] = Ml[lc][r]; Vg[(size_t)c * n + r] = Vl[lc][r]; }
+    }
+    if (tid == 0 && nrot) atomicAdd(&rw[sweep], nrot);
+    MGSTAMP(53);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
