@@ -245,9 +245,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
             double p = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) p += Li[J][lk + 4 * q][li] * yv[16 * J + lk + 4 * q];
-            p += __shfl_xor(p, 16, 64);
-            p += __shfl_xor(p, 32, 64);
-            if (lk == 0) zs[16 * J + li] = p;
+            atomicAdd(&zs[16 * J + li], p);                // ds_add_f64: the four row groups of lanes add into the (zeroed) slot, no cross-lane round trips
             __syncthreads();                               // X_J: y_J published
             __syncthreads();                               // Y_J: row J applied to the pending blocks
         }
@@ -454,9 +452,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
             double p = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) p += acc[s][q] * zs[16 * J + lk + 4 * q];
-            p += __shfl_xor(p, 16, 64);
-            p += __shfl_xor(p, 32, 64);
-            if (lk == 0) yv[16 * sJ[s] + li] -= p;
+            atomicAdd(&yv[16 * sJ[s] + li], -p);           // ds_add_f64 (the tiles of row J update distinct blocks J')
         }
         __syncthreads();                                   // Y_J
     }
