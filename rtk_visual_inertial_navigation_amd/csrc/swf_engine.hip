@@ -1719,9 +1719,12 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
         else {
             phase(1);
             hipLaunchKernelGGL(k_marg_gram, dim3((ldn * ldn + 255) / 256, nw), dim3(256), 0, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_M, b->mg_A, (const int*)b->mg_bjok);
-            // block size: 8 columns (17 workgroups per launch at 263 dimensions, 8 inner steps each; 16-column blocks halve the launches
-            // but leave a step to 9 workgroups whose 16 waves share 4 SIMDs: 49 us per launch against 15)
-            const int bs = getenv("SWF_MARG_BS16") && ldn <= 288 ? 16 : ldn <= 576 ? 8 : 4, nb = (ldn + bs - 1) / bs, nbe = (nb + 1) & ~1;
+            // block size by window: 8 columns up to 576 dimensions (17 workgroups per launch at 263 dimensions, 8 inner steps each; 16-column
+            // blocks halve the launches but leave a step to 9 workgroups whose 16 waves share 4 SIMDs: 49 us per launch against 16), 4 above.
+            // One launch schedule per class, sized by the class's largest tail; every window follows its own round-robin inside it.
+            int ldA = 0, ldB = 0;
+            for (int w = 0; w < nw; w++) { const int t = b->hw[w].tail_dim; if (t > MG_MAXN && t <= 576) ldA = std::max(ldA, t); else if (t > 576) ldB = std::max(ldB, t); }
+            const bool bs16 = getenv("SWF_MARG_BS16") && ldn <= 288;        // A/B only
             std::vector<int> hrot((size_t)nw * MG_SWEEPS);
             for (int sweep = 0; sweep < MG_SWEEPS; sweep++) {
                 if (sweep >= 8 && (sweep & 3) == 0) {
@@ -1733,15 +1736,21 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                     for (int w = 0; w < nw && all; w++) { bool done = false; for (int k = 0; k < sweep; k++) done = done || hrot[(size_t)w * MG_SWEEPS + k] == 0; all = done; }
                     if (all) break;
                 }
-                for (int st = -1; st < nbe - 1; st++) {
-                    dim3 grid(nbe / 2, nw);
 #define BJ_LAUNCH(BS_, LDM_, NR_) hipLaunchKernelGGL((k_marg_bj<BS_, LDM_, NR_>), grid, dim3(1024), 0, b->stream, (const int*)b->mg_tail, ldn, b->mg_M, b->mg_J, b->mg_rot, (const int*)b->mg_bjok, sweep, st)
-                    if (bs == 16) BJ_LAUNCH(16, 288, 5);
-                    else if (bs == 8 && ldn <= 320) BJ_LAUNCH(8, 576, 5);
-                    else if (bs == 8) BJ_LAUNCH(8, 576, 9);
-                    else BJ_LAUNCH(4, 640, 10);
-#undef BJ_LAUNCH
+                if (ldA) {
+                    const int bs = bs16 ? 16 : 8, nbe = ((ldA + bs - 1) / bs + 1) & ~1;
+                    for (int st = -1; st < nbe - 1; st++) {
+                        dim3 grid(nbe / 2, nw);
+                        if (bs16) BJ_LAUNCH(16, 288, 5);
+                        else if (ldA <= 320) BJ_LAUNCH(8, 576, 5);
+                        else BJ_LAUNCH(8, 576, 9);
+                    }
                 }
+                if (ldB) {
+                    const int nbe = ((ldB + 3) / 4 + 1) & ~1;
+                    for (int st = -1; st < nbe - 1; st++) { dim3 grid(nbe / 2, nw); BJ_LAUNCH(4, 640, 10); }
+                }
+#undef BJ_LAUNCH
             }
             phase(2);
         }

@@ -339,6 +339,7 @@ __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, 
     if (!bj_ok[w]) return;
     const int n = tail_dim[w];
     if (n > LDM || n > 64 * NR) return;
+    if ((BS == 4) != (n > 576)) return;                    // the block size is a property of the WINDOW (8 columns up to 576 dimensions, 4 above): a batch launches both classes, and a window's rotation sequence does not depend on its neighbours
     int* rw = rot + (size_t)w * MG_SWEEPS;
     if (sweep > 0 && rw[sweep - 1] == 0) return;         // converged
     const int nb = (n + BS - 1) / BS, nbe = (nb + 1) & ~1;
@@ -346,6 +347,7 @@ __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, 
     if (bstep < 0) { P = 2 * g; Q = 2 * g + 1; }          // the pairs inside blocks 2g and 2g + 1
     else {
         // circle method over the blocks: block nbe - 1 is fixed, the others rotate
+        if (bstep >= nbe - 1 || g >= nbe / 2) return;     // (the schedule and the grid are the batch's largest window's: this one's sweep is over / has fewer block pairs)
         if (g == 0) { P = nbe - 1; Q = bstep; }
         else { P = bstep + g; if (P >= nbe - 1) P -= nbe - 1; Q = bstep - g; if (Q < 0) Q += nbe - 1; }
         if (P > Q) { int t = P; P = Q; Q = t; }
