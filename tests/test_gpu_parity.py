@@ -984,6 +984,39 @@ def test_batched_triangulation_matches_oracle():
     assert np.array_equal(dg[5:10] == 5.0, do[5:10] == 5.0)
 
 
+def test_large_tail_eigen_priors_are_the_same_bits_alone_and_in_a_batch():
+    """Tails above 140 dimensions take the block Jacobi over many workgroups (k_marg_bj): one launch schedule per batch, sized by
+    its largest tail.  A window's blocks, round-robin and therefore its prior must not depend on its neighbours: three windows
+    with 150 / 210 / 225-dimension tails (19 / 27 / 29 blocks) alone and as one batch, bit for bit; and the prior is the square
+    root of the device's own A, b with numpy's eigenvalues."""
+    ws = [synth.make_window(config_id=3, K=11, F=40, S=6, seed=61, head="frames"),
+          synth.make_window(config_id=3, K=15, F=50, S=8, seed=62, head="frames"),
+          synth.make_window(config_id=2, K=16, F=60, S=0, seed=63, head="frames")]
+    singles = []
+    for w in ws:
+        bs, sg = gpu_solve(w.copy(), default_options(step_mode=1))
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+        g = bs.get_prior(0)
+        bs.close()
+        assert g["n"] > 140 and g["rank"] > 0
+        sc = np.abs(g["A"]).max()
+        assert np.abs(g["J"].T @ g["J"] - g["A"]).max() <= 1e-11 * sc
+        assert np.abs(g["J"].T @ g["r0"] - g["b"]).max() <= 1e-9 * np.abs(g["b"]).max()
+        lam = np.linalg.eigvalsh(g["A"])
+        assert np.abs(np.sort(g["eig"]) - lam).max() <= 1e-11 * lam.max()
+        singles.append(g)
+    assert len({g["n"] for g in singles}) == 3
+    bs = solver.BatchSolver([w.copy() for w in ws])
+    bs.solve(default_options(step_mode=1))
+    bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+    for i, g1 in enumerate(singles):
+        gb = bs.get_prior(i)
+        assert gb["rank"] == g1["rank"]
+        for k in ("A", "b", "J", "r0", "eig"):
+            assert np.array_equal(gb[k], g1[k]), (i, k)
+    bs.close()
+
+
 def test_ambiguity_covariance_hand_off():
     """after an optimising solve with the RTK ambiguities as parameter_head, the information A = L_nn L_nn^T
     (UpdateSchurHessianOnly, R/swf/swf_gnss.cpp:65-94) and the covariance Qy = A^-1 (LambdaSearch, swf_lambda.cpp:94-99) of the
