@@ -1883,7 +1883,8 @@ extern "C" int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, dou
             for (int a = 0; a < 2; a++) {
                 if (r) r[row + a] = pr[(size_t)a * nobs + q];
                 if (!J) continue;
-                if (lp[q] >= 0) for (int c = 0; c < 6; c++) J[(row + a) * nl + (lp[q] - W.loc_base) + c] = Jp[(size_t)(a * 6 + c) * nobs + q];
+                // (the translation half of Jp is not stored next to a variable landmark: it is -Jl)
+                if (lp[q] >= 0) for (int c = 0; c < 6; c++) J[(row + a) * nl + (lp[q] - W.loc_base) + c] = (c < 3 && ll[q] >= 0) ? -Jl[(size_t)(a * 3 + c) * nobs + q] : Jp[(size_t)(a * 6 + c) * nobs + q];
                 if (ll[q] >= 0) for (int c = 0; c < 3; c++) J[(row + a) * nl + (ll[q] - W.loc_base) + c] = Jl[(size_t)(a * 3 + c) * nobs + q];
             }
         }

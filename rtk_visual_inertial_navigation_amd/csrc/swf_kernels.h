@@ -107,7 +107,8 @@ __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double*
                 double u = 0, v = 0;
 #pragma unroll
                 for (int k = 0; k < 3; k++) { u += red[a * 3 + k] * -A[k * 3 + j]; v += red[a * 3 + k] * Bm[k * 3 + j]; }
-                if (STORE) { B.p_Jp[(a * 6 + j) * n + i] = u * sr; B.p_Jp[(a * 6 + 3 + j) * n + i] = v * sr; }
+                // the translation half of Jp is -Jl, bit for bit (same products, negated): it is stored only where Jl is not (constant landmark)
+                if (STORE) { if (!jl) B.p_Jp[(a * 6 + j) * n + i] = u * sr; B.p_Jp[(a * 6 + 3 + j) * n + i] = v * sr; }
                 if (keep) { keep[a * 6 + j] = u * sr; keep[a * 6 + 3 + j] = v * sr; }
             }
     }
@@ -675,7 +676,11 @@ __device__ __forceinline__ void d_jtimes_proj(const DevBatch& B, const DevOpt& O
     if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;
     int n = B.n_proj, lp = B.p_lpose[i], ll = B.p_llm[i];
     double a0 = 0, a1 = 0;
-    if (lp >= 0) for (int j = 0; j < 6; j++) { double v = vec_at<MODE>(B, O, lp + j); a0 += B.p_Jp[j * n + i] * v; a1 += B.p_Jp[(6 + j) * n + i] * v; }
+    if (lp >= 0) for (int j = 0; j < 6; j++) {
+        double v = vec_at<MODE>(B, O, lp + j);
+        const bool tl = j < 3 && ll >= 0;                 // translation half of Jp = -Jl (not stored next to a variable landmark)
+        a0 += (tl ? -B.p_Jl[j * n + i] : B.p_Jp[j * n + i]) * v; a1 += (tl ? -B.p_Jl[(3 + j) * n + i] : B.p_Jp[(6 + j) * n + i]) * v;
+    }
     if (ll >= 0) for (int j = 0; j < 3; j++) { double v = vec_at<MODE>(B, O, ll + j); a0 += B.p_Jl[j * n + i] * v; a1 += B.p_Jl[(3 + j) * n + i] * v; }
     if (MODE == 0) B.p_aux[i] = a0 * a0 + a1 * a1;
     else B.p_aux[i] = a0 * (B.p_r[i] + a0 / 2.0) + a1 * (B.p_r[n + i] + a1 / 2.0);
@@ -1202,8 +1207,12 @@ __global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
         int o = o_beg + tid;
         rk = B.fsb_perm[o];
         double a[6], b[6];
+        const bool lv = B.p_llm[o] >= 0;                 // translation half of Jp = -Jl (not stored next to a variable landmark)
 #pragma unroll
-        for (int i = 0; i < 6; i++) { a[i] = B.p_Jp[i * n + o]; b[i] = B.p_Jp[(6 + i) * n + o]; }
+        for (int i = 0; i < 6; i++) {
+            const bool tl = i < 3 && lv;
+            a[i] = tl ? -B.p_Jl[i * n + o] : B.p_Jp[i * n + o]; b[i] = tl ? -B.p_Jl[(3 + i) * n + o] : B.p_Jp[(6 + i) * n + o];
+        }
         double r0 = B.p_r[o], r1 = B.p_r[n + o];
         int k = 0;
 #pragma unroll

@@ -335,9 +335,10 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
 #pragma unroll
         for (int k = 0; k < 12; k++) jp[k] = 0.0;
         if (GEMM && has) {
+            // the translation half of Jp is -Jl bit for bit (k_eval_ps does not store it next to a variable landmark): six loads, not twelve
             const double* pj = B.p_Jp + o;
 #pragma unroll
-            for (int k = 0; k < 12; k++) jp[k] = pj[(size_t)k * n];
+            for (int k = 0; k < 3; k++) { jp[k] = -a[k]; jp[6 + k] = -a[3 + k]; jp[3 + k] = pj[(size_t)(3 + k) * n]; jp[9 + k] = pj[(size_t)(9 + k) * n]; }
         }
 #define FMA2(x0, y0, x1, y1) __builtin_fma(x0, y0, (x1) * (y1))
 #define FMA3(x0, y0, x1, y1, x2, y2) __builtin_fma(x0, y0, __builtin_fma(x1, y1, (x2) * (y2)))
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
                 if (has2) {
                     const double* pj = B.p_Jp + o2;
 #pragma unroll
-                    for (int k = 0; k < 12; k++) jq[k] = pj[(size_t)k * n];
+                    for (int k = 0; k < 3; k++) { jq[k] = -d2.jl[k]; jq[6 + k] = -d2.jl[3 + k]; jq[3 + k] = pj[(size_t)(3 + k) * n]; jq[9 + k] = pj[(size_t)(9 + k) * n]; }
                 }
                 unsigned np = 0xffffu;
                 if (has2 && d2.f >= 0) np = (unsigned)write_z(d2.jl, jq, d2.f);
