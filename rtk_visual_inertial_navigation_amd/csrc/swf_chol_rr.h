@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
     __shared__ double zs[256];
     __shared__ double yv[256];
     __shared__ int wsimd[16];
+    __shared__ unsigned nzm[2];                // bit I: panel tile (I, j) of the step is not all zero (double-buffered by step parity)
     __shared__ int fail;
     int w = blockIdx.x;
     WinState& st = B.ws[w];
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
     unsigned long long tq = 0;
 #endif
     CHSTAMP(0);
-    if (tid == 0) fail = 0;
+    if (tid == 0) { fail = 0; nzm[0] = 0u; nzm[1] = 0u; }
     if (tid < 16) dinv[tid] = 0.0;
     for (int e = tid; e < 256; e += 1024) zs[e] = 0.0;
     // Roles by SIMD.  fp64 MFMAs and fp64 VALU instructions of one SIMD do not overlap, so every trailing-update MFMA issued on the
@@ -233,6 +234,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
             tq = __builtin_amdgcn_s_memtime();
 #endif
             if (fail) { if (tid == 0) { st.lin_fail = 1; st.chol_fail = 1; } return; }
+            if (lane == 0) nzm[(j + 1) & 1] = 0u;          // the next step's mask (its last readers left before B_j)
             __syncthreads();                               // C_j
             CHACC(10, tq);
         }
@@ -363,22 +365,27 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
         __syncthreads();                                   // B_j: Linv_jj ready; trailing updates of step j-1 done
         if (fail) return;
         // panel row j of U: U_jI = Linv_jj A_jI.  Tile (j+1, j) first, with the diagonal tile j+1 right behind it (published for the pivot).
-        double linv[4] = { 0.0, 0.0, 0.0, 0.0 };
-        bool any = false;
-#pragma unroll
-        for (int s = 0; s < RR3_NS; s++) any = any || sJ[s] == j;
-        if (any) {
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) linv[kk] = -Li[j][li][lk + 4 * kk];       // U_jI = Linv (A_jI) = (-Linv) (-A_jI)
-        }
 #pragma unroll
         for (int s = 0; s < RR3_NS; s++) {
             if (sJ[s] != j) continue;
             int I = sI[s];
             asm volatile("" : "+s"(I));                    // (addresses from the scalar tile index at the point of use: no per-slot address registers across the loop)
+            // A tile of S that is still exactly zero (no coupling, no fill yet: the banded speed-bias part of a cfg3 window leaves 14 of
+            // its 105 tiles like that) stays zero through the panel product and contributes nothing below: it is neither multiplied
+            // nor published, and the trailing updates skip every product one of whose operands is such a tile (the step's mask, nzm) —
+            // 455 -> 314 tile updates for a cfg3 window, most of them in the first steps, where the updates and not the pivot set the pace.
+            const bool tnz = __ballot((acc[s][0] != 0.0) | (acc[s][1] != 0.0) | (acc[s][2] != 0.0) | (acc[s][3] != 0.0)) != 0ull;
+            if (!tnz) {
+                if (I == j + 1 && j + 1 < Tc) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) Dt[(j + 1) & 1][lk + 4 * q][li] = -dn[q];       // diagonal tile j+1 takes nothing from this step
+                }
+                continue;
+            }
+            if (lane == 0) atomicOr(&nzm[j & 1], 1u << I);
             double4_t X = { 0, 0, 0, 0 };
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(linv[kk], acc[s][kk], X, 0, 0, 0);
+            for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(-Li[j][li][lk + 4 * kk], acc[s][kk], X, 0, 0, 0);       // U_jI = Linv (A_jI) = (-Linv) (-A_jI)
             acc[s] = X;
             if (I == j + 1 && j + 1 < Tc) {
 #pragma unroll
@@ -390,23 +397,26 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
             for (int kk = 0; kk < 4; kk++) Pn[I][kk][lane] = X[kk];
             if (I == j + 2 && I < Tc) {
                 // diagonal tile j+2 takes its term here, ahead of the barrier: the next step's (j+2, j+1) owner fetches it before B_j+1
+                int I2 = j + 2;
+                asm volatile("" : "+s"(I2));
                 double4_t d;
 #pragma unroll
-                for (int q = 0; q < 4; q++) d[q] = Dg[I][q][lane];
+                for (int q = 0; q < 4; q++) d[q] = Dg[I2][q][lane];
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(X[kk], X[kk], d, 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 4; q++) Dg[I][q][lane] = d[q];
+                for (int q = 0; q < 4; q++) Dg[I2][q][lane] = d[q];
             }
         }
         __syncthreads();                                   // C_j: panel and diagonal tile j+1 published
         // trailing updates (overlap with the pivot pair's work on tile j+1): the later diagonal tiles take their term of this step
         // from the wave that holds it in registers, -A_II += U_jI^T U_jI; the off-diagonal tiles -A_JI += U_jJ^T U_jI from the panel
+        const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)nzm[j & 1]);
 #pragma unroll
         for (int s = 0; s < RR3_NS; s++) {
             if (sJ[s] != j) continue;
             int I = sI[s];
-            if (I <= j + 2 || I >= Tc) continue;
+            if (I <= j + 2 || I >= Tc || !((m >> I) & 1u)) continue;
             asm volatile("" : "+s"(I));
             double4_t d;
 #pragma unroll
@@ -419,7 +429,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
 #pragma unroll
         for (int s = 0; s < RR3_NS; s++) {
             int J = sJ[s], I = sI[s];
-            if (J <= j || I < 0) continue;
+            if (J <= j || I < 0 || !((m >> I) & (m >> J) & 1u)) continue;
             asm volatile("" : "+s"(I), "+s"(J));           // (the panel addresses are one scalar add away: not worth a register pair per slot across the loop)
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[J][kk][lane], Pn[I][kk][lane], acc[s], 0, 0, 0);
