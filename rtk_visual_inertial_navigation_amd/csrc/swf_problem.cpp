@@ -39,6 +39,7 @@ struct swf_problem {
     std::unordered_map<double*, PBlock> blocks;
     long seq = 0;
     std::vector<PFactor> factors;
+    std::vector<swf_factor_id> free_ids;   // slots of removed factors, reused by the next additions: a long-lived problem (landmarks come and go every frame) stays bounded
     std::vector<double*> order_keys; std::vector<int> order_groups;
     std::vector<double*> tail_keys;
     double pbg[3] = {0, 0, 0}, gw[3] = {0, 0, 9.8}, base[3] = {0, 0, 0};
@@ -93,12 +94,19 @@ int swf_add_parameter_block(swf_problem* p, double* key, int32_t size, int32_t m
     p->dirty = true;
     return SWF_OK;
 }
+// a removed factor gives its slot (and its memory) back; the id is handed out again by a later swf_add_* (as ceres reuses the slots of removed
+// residual blocks: a ResidualBlockId is dead after RemoveResidualBlock)
+static void kill_factor(swf_problem* p, swf_factor_id id) {
+    PFactor dead; dead.type = p->factors[id].type; dead.alive = false; dead.enabled = false;
+    p->factors[id] = std::move(dead);
+    p->free_ids.push_back(id);
+}
 int swf_has_parameter_block(swf_problem* p, const double* key) { return p && p->blocks.count((double*)key) ? 1 : 0; }
 int swf_remove_parameter_block(swf_problem* p, double* key) {
     if (!p) return SWF_E_INVALID;
     auto it = p->blocks.find(key);
     if (it == p->blocks.end()) return SWF_E_NOTFOUND;
-    for (auto& f : p->factors) if (f.alive && std::find(f.keys.begin(), f.keys.end(), key) != f.keys.end()) f.alive = false;
+    for (size_t i = 0; i < p->factors.size(); i++) { PFactor& f = p->factors[i]; if (f.alive && std::find(f.keys.begin(), f.keys.end(), key) != f.keys.end()) kill_factor(p, (swf_factor_id)i); }
     p->blocks.erase(it);
     p->dirty = true;
     return SWF_OK;
@@ -143,8 +151,9 @@ static swf_factor_id add_factor(swf_problem* p, FType t, std::vector<double*> ke
     }
     PFactor f; f.type = t; f.alive = true; f.enabled = true; f.keys = std::move(keys);
     if (data && ndata) f.data.assign(data, data + ndata);
-    p->factors.push_back(std::move(f));
     p->dirty = true;
+    if (!p->free_ids.empty()) { const swf_factor_id id = p->free_ids.back(); p->free_ids.pop_back(); p->factors[id] = std::move(f); return id; }
+    p->factors.push_back(std::move(f));
     return (swf_factor_id)p->factors.size() - 1;
 }
 
@@ -240,7 +249,7 @@ swf_factor_id swf_add_linear_prior(swf_problem* p, double* const* keys, int32_t 
 }
 int swf_remove_factor(swf_problem* p, swf_factor_id id) {
     if (!p || id < 0 || id >= (int)p->factors.size() || !p->factors[id].alive) return SWF_E_NOTFOUND;
-    p->factors[id].alive = false; p->dirty = true;
+    kill_factor(p, id); p->dirty = true;
     return SWF_OK;
 }
 int swf_factor_set_enabled(swf_problem* p, swf_factor_id id, int32_t on) {

@@ -241,4 +241,14 @@ def test_problem_query_surface_without_gpu():
     assert not any(q is lm0 for q in P.GetParameterBlocks())
     with pytest.raises(solver.SwfError):
         P.GetResidualBlocksForParameterBlock(lm0)
+    # a long-lived problem stays bounded: the slots of removed residual blocks are handed out again (the estimator adds and removes
+    # landmarks every frame); the ids of live blocks do not move
+    freed = set(f_lm0)
+    n_before, live_before = P.NumResidualBlocks(), set(P.GetResidualBlocks())
+    assert not (freed & live_before)
+    lm1 = blocks[w.bid_lm(1)]
+    new = [P.AddProjection(blocks[w.bid_pose(0)], blocks[w.bid_pose(4)], lm1, [0.01 * k, 0.0]) for k in range(len(freed) + 2)]
+    assert set(new[:len(freed)]) == freed and all(f > max(live_before | freed) for f in new[len(freed):])
+    assert P.NumResidualBlocks() == n_before + len(new) and set(P.GetResidualBlocks()) == live_before | set(new)
+    assert all(any(q is lm1 for q in P.GetParameterBlocksForResidualBlock(f)) for f in new)
     P.close()
