@@ -296,6 +296,10 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
     }
     CHSTAMP2(16);
     double4_t acc[RR3_NS];
+#ifdef SWF_PROFILE_CHOL
+    unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && tid == 128) for (int i = 22; i < 30; i++) g_chol_stamps[i] = 0;
+#endif
     // all loads of the wave's tiles are issued branch-free (clamped addresses, values selected afterwards): S is stored lower;
     // the extra tile row Tc carries the right-hand side in its first row
     // (the tile waves keep -A: every update is then a plain accumulate)
@@ -362,7 +366,9 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
 #ifdef SWF_PROFILE_CHOL
         if (blockIdx.x == 0 && lane == 0 && j == SWF_PROFILE_CHOL_STEP) g_chol_stamps[32 + wv] = __builtin_amdgcn_s_memtime();
 #endif
+        CHACC2(28, tq2);
         __syncthreads();                                   // B_j: Linv_jj ready; trailing updates of step j-1 done
+        CHACC2(26, tq2);
         if (fail) return;
         // panel row j of U: U_jI = Linv_jj A_jI.  Tile (j+1, j) first, with the diagonal tile j+1 right behind it (published for the pivot).
 #pragma unroll
@@ -408,10 +414,13 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
                 for (int q = 0; q < 4; q++) Dg[I2][q][lane] = d[q];
             }
         }
+        CHACC2(27, tq2);
         __syncthreads();                                   // C_j: panel and diagonal tile j+1 published
         // trailing updates (overlap with the pivot pair's work on tile j+1): the later diagonal tiles take their term of this step
         // from the wave that holds it in registers, -A_II += U_jI^T U_jI; the off-diagonal tiles -A_JI += U_jJ^T U_jI from the panel
+        CHACC2(22, tq2);
         const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)nzm[j & 1]);
+        CHACC2(23, tq2);
 #pragma unroll
         for (int s = 0; s < RR3_NS; s++) {
             if (sJ[s] != j) continue;
@@ -426,6 +435,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
 #pragma unroll
             for (int q = 0; q < 4; q++) Dg[I][q][lane] = d[q];
         }
+        CHACC2(24, tq2);
 #pragma unroll
         for (int s = 0; s < RR3_NS; s++) {
             int J = sJ[s], I = sI[s];
@@ -434,6 +444,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[J][kk][lane], Pn[I][kk][lane], acc[s], 0, 0, 0);
         }
+        CHACC2(25, tq2);
     }
     CHSTAMP2(20);
     // back to the row layout (lane (li, lk), register q <-> L[lk+4q][li]); export L where it is read, y = L^-1 rhs from the rhs tile row

@@ -55,10 +55,12 @@ __device__ unsigned long long g_chol_stamps[64];
 #define CHSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define CHACC(i, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #define CHSTAMP2(i) do { if (blockIdx.x == 0 && threadIdx.x == 128) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CHACC2(i, t0) do { if (blockIdx.x == 0 && threadIdx.x == 128) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_chol_stamps[i] += t_ - (t0); (t0) = t_; } } while (0)
 #else
 #define CHSTAMP(i)
 #define CHACC(i, t0)
 #define CHSTAMP2(i)
+#define CHACC2(i, t0)
 #endif
 template <int NT>
 __global__ void __launch_bounds__(NT, NT == 256 ? CH_OCC : 4) k_chol_solve(DevBatch B) {
