@@ -78,6 +78,7 @@ def cpu_baseline(windows, iters, budget_s=24.0):
     import oracle_binding as ob
     from concurrent.futures import ThreadPoolExecutor
     from rtk_visual_inertial_navigation_amd.flat import default_options
+    isa = ob.use_native() or "-O3 -march=x86-64-v3 (prebuilt; the -march=native rebuild on this host failed)"
     ob.lib()
     cores, model = _physical_cores()
     rows = {}
@@ -118,6 +119,7 @@ def cpu_baseline(windows, iters, budget_s=24.0):
     return dict(value=r4["iterations_per_s"], unit="gauss_newton_iterations/s", cores=4, kind="port",
                 sample="%d warm solves of the benchmark's cfg3 windows (%d dogleg iterations each) with 4 OpenMP threads inside one solve; "
                        "unvectorised plain-C port of the reference's algorithm (the reference itself is unbuildable here)" % (r4["solves"], iters),
+                build="gcc " + isa + ", built on the host it is timed on",
                 rows=rows, single_thread_us_per_iteration=rows["threads_1"]["us_per_iteration_median"],
                 host_physical_cores=cores, host_logical_cpus=os.cpu_count(), host_cpu_model=model)
 

@@ -37,7 +37,13 @@ enum {
 };
 
 /* library / device info */
+/* 100 + the number of ABI revisions.  104 (round 4): swf_timing grew by lm_schur_flops_sym / lm_schur_mfma (swf_batch_timing writes
+ * sizeof(swf_timing) bytes: a caller compiled against an older header must be rebuilt); swf_composite_assemble / _add_mid_prior stride
+ * HpN / HNN by N_cap; after an optimising solve swf_get_reduced / swf_batch_export_reduced return L zero outside the parameter_head tail
+ * block (the whole factor only after step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY); swf_prior_reset_linearization_point added.
+ * swf_abi_sizes reports sizeof(swf_options), sizeof(swf_summary), sizeof(swf_timing), sizeof(swf_flat_window), sizeof(swf_iteration) so a binding can check its own. */
 int swf_version(void);
+int swf_abi_sizes(int32_t out[5]);
 int swf_device_count(int32_t* n);                 /* hipGetDeviceCount */
 int swf_set_device(int32_t device);               /* hipSetDevice: the device of the batches / problems created next on this thread */
 void swf_default_options(swf_options* opt);       /* Solver::Options as the reference sets them for the window solves (R/swf/swf.cpp:25-30: DENSE_SCHUR, DOGLEG,
@@ -141,7 +147,9 @@ int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, double* J, int
  * SWF_LINEAR_SOLVER_FAILURE): SWF_PRIOR_EIGEN then re-factors the first m columns only and takes a rank-revealing factor of
  * A (rank < n is reported, the prior is valid); SWF_PRIOR_CHOLESKY has no such variant and reports rank -1.  A breakdown
  * inside S_mm itself is a failure in both forms (rank -1, no silent fallback).  SWF_PRIOR_EIGEN: n <= 384 (the Jacobi iteration keeps M in LDS up to n = 140, in an HBM scratch above);
- * SWF_PRIOR_CHOLESKY: n <= 512.  Asynchronous on the batch stream. */
+ * SWF_PRIOR_CHOLESKY: n <= 512.  Asynchronous on the batch stream up to tails of 140 dimensions; SWF_PRIOR_EIGEN above that (the block-Jacobi
+ * schedule over many workgroups) is SYNCHRONOUS: the host reads the rotation counters back every few sweeps to stop enqueueing, so the
+ * call blocks the calling thread until the priors exist. */
 enum { SWF_PRIOR_EIGEN = 0, SWF_PRIOR_CHOLESKY = 1 };
 int swf_batch_marginalize(swf_batch* b, double eps, int32_t form);
 /* Results of the last swf_batch_marginalize for window w (synchronises).  Any pointer may be NULL; eig receives the n
@@ -306,6 +314,14 @@ int swf_batch_marginal_priors(const swf_flat_window* const* windows, int32_t n, 
 int swf_composite_assemble(int32_t M, const int32_t* n_kept, const int32_t* kept_size, double* const* kept_key,
                            const double* A, const double* b, int32_t N_cap, double** N_keys, int32_t* N_out,
                            double* Hpp, double* HpN, double* rhs_p, double* HNN, double* rhsN);
+/* swf_prior_reset_linearization_point: MarginalizationInfo::ResetLinearizationPoint (R/factor/marginalization_factor.cpp:232-258;
+ * called on the two priors bounding a middle marginalisation, R/swf/swf_core.cpp:636-637) — host bookkeeping on the prior's own arrays.
+ * kept_size[n_kept] = global sizes of the kept blocks in kept order (7 = pose), x_new[k] = the block's current values, dim = sum of the
+ * local sizes.  dx_k = x_new - x0 (pose: [p - p0 ; +-2 vec(q0^-1 q)], sign of the scalar part, as MarginalizationFactor::Evaluate);
+ * r0 += J dx (linearized_residuals, J dim x dim row-major), b += A dx (either pair may be NULL), x0 (concatenated global sizes) <- x_new.
+ * (The reference asserts that scalar blocks hold 0 at the call — PhaseBiasSaveAndReset zeroes them first; not enforced here.) */
+int swf_prior_reset_linearization_point(int32_t n_kept, const int32_t* kept_size, const double* const* x_new, int32_t dim,
+                                        const double* J, const double* A, double* r0, double* b, double* x0);
 /* swf_composite_add_mid_prior: IMUGNSSBase::AddMidMargInfo (R/factor/gnss_imu_factor.cpp:121-240) — host bookkeeping.  The prior
  * (A, b) of a marginalised stretch of GNSS epochs (MargGNSSFrames, R/swf/swf_core.cpp:570-641) keeps n_kept blocks: the pose (7) and
  * speed-bias (9) of the two epochs either side of the stretch — kept_epoch[q] = k-1 or k for those blocks (ignored for scalars) — and
@@ -325,6 +341,11 @@ int swf_composite_add_mid_prior(int32_t M, int32_t k, int32_t n_kept, const int3
  * pointer at swf_problem_solve() and written back before it returns.
  * ===================================================================================== */
 typedef struct swf_problem swf_problem;
+/* Factor ids are SLOT numbers: stable while the factor lives; the slot of a removed factor is handed out again (LIFO) to a later
+ * swf_add_*, so an id held across its own swf_remove_factor / a cascading swf_remove_parameter_block may name a DIFFERENT live factor
+ * afterwards (it does not become SWF_E_NOTFOUND) — drop ids when you remove, as with ceres::ResidualBlockId.  The flat window is built
+ * in slot order, so a long-lived problem and a freshly built one with the same factors may sum in a different factor order (results
+ * agree to rounding, not bit for bit). */
 typedef int32_t swf_factor_id;
 
 enum { SWF_MANIFOLD_NONE = 0, SWF_MANIFOLD_POSE = 1 };   /* PoseLocalParameterization, 7 -> 6 */

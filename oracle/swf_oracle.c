@@ -470,6 +470,28 @@ static void prior_block_dx(const double* x, const double* x0, int gsize, double*
     dx[3] = s * dq[0]; dx[4] = s * dq[1]; dx[5] = s * dq[2];
 }
 
+/* MarginalizationInfo::ResetLinearizationPoint, R/factor/marginalization_factor.cpp:232-258:
+ * dx over the kept blocks between the given parameters and keep_block_data (the dx of Evaluate),
+ * linearized_residuals += linearized_jacobians * dx;  b += A * dx;  keep_block_data <- parameters.
+ * x_new / x0: the kept blocks' values concatenated (global sizes); J, A: n x n row-major. */
+void oracle_prior_reset_lin_point(int n_kept, const int* sizes, const double* x_new, int n,
+                                  const double* J, const double* A, double* r0, double* b, double* x0) {
+    double* dx = (double*)calloc((size_t)n, sizeof(double));
+    int idx = 0, g = 0;
+    for (int i = 0; i < n_kept; i++) {
+        int size = sizes[i];
+        prior_block_dx(x_new + g, x0 + g, size, dx + idx);
+        for (int k = 0; k < size; k++) x0[g + k] = x_new[g + k];
+        idx += (size == 7) ? 6 : size; g += size;
+    }
+    for (int r = 0; r < n; r++) {
+        double a = 0, c = 0;
+        for (int k = 0; k < n; k++) { a += J[r * n + k] * dx[k]; c += A[r * n + k] * dx[k]; }
+        r0[r] += a; b[r] += c;
+    }
+    free(dx);
+}
+
 /* Cauchy loss + Ceres corrector as restated at R/factor/marginalization_factor.cpp:23-45.
  * rho'' < 0 always for Cauchy => residual and Jacobian are scaled by sqrt(rho').
  * Returns the block's cost 0.5*rho(s) (ceres::ResidualBlock::Evaluate). */

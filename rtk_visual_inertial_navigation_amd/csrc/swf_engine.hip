@@ -14,6 +14,7 @@
 #include <map>
 #include <string>
 #include <memory>
+#include <thread>
 #include <vector>
 #include "../../include/swf_solver.h"
 #include "swf_kernels2.h"
@@ -26,7 +27,13 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 extern "C" const char* swf_last_error(void) { return g_err.c_str(); }
 void swf_internal_set_error(const std::string& m) { g_err = m; }
-extern "C" int swf_version(void) { return 100; }
+extern "C" int swf_version(void) { return 104; }
+extern "C" int swf_abi_sizes(int32_t out[5]) {
+    if (!out) return fail(SWF_E_INVALID, "swf_abi_sizes: null");
+    out[0] = (int32_t)sizeof(swf_options); out[1] = (int32_t)sizeof(swf_summary); out[2] = (int32_t)sizeof(swf_timing);
+    out[3] = (int32_t)sizeof(swf_flat_window); out[4] = (int32_t)sizeof(swf_iteration);
+    return SWF_OK;
+}
 extern "C" int swf_device_count(int32_t* n) {
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
@@ -1584,9 +1591,37 @@ extern "C" int swf_batch_sync(swf_batch* b) {
 // one call for the whole node: every batch's solve is enqueued on its own device first, then all are awaited
 extern "C" int swf_solve_batches(swf_batch* const* batches, int32_t n, const swf_options* opt) {
     if (!batches || n <= 0 || !opt) return fail(SWF_E_INVALID, "swf_solve_batches: bad arguments");
-    for (int i = 0; i < n; i++) { int rc = swf_batch_solve(batches[i], opt); if (rc != SWF_OK) return rc; }
-    int rc_all = SWF_OK;
-    for (int i = 0; i < n; i++) { int rc = swf_batch_sync(batches[i]); if (rc != SWF_OK) rc_all = rc; }
+    for (int i = 0; i < n; i++) if (!batches[i]) return fail(SWF_E_INVALID, "swf_solve_batches: null batch");
+    // Enqueue: one host thread per DEVICE (a solve is ~90 launches; at 64 windows per GPU one thread enqueueing eight devices in turn
+    // would put that host time on the critical path).  Batches that share a device are enqueued by that device's thread, in order.
+    std::vector<int> rcs((size_t)n, SWF_OK);
+    std::vector<std::string> msgs((size_t)n);
+    std::vector<int> devs;
+    for (int i = 0; i < n; i++) if (std::find(devs.begin(), devs.end(), batches[i]->device) == devs.end()) devs.push_back(batches[i]->device);
+    auto enqueue_device = [&](int dev) {
+        for (int i = 0; i < n; i++) {
+            if (batches[i]->device != dev) continue;
+            rcs[(size_t)i] = swf_batch_solve(batches[i], opt);
+            if (rcs[(size_t)i] != SWF_OK) msgs[(size_t)i] = g_err;          // (g_err is thread-local: carried back to the caller below)
+        }
+    };
+    if (devs.size() <= 1) enqueue_device(devs.empty() ? 0 : devs[0]);
+    else {
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < devs.size(); d++) th.emplace_back(enqueue_device, devs[d]);
+        enqueue_device(devs[0]);
+        for (auto& t : th) t.join();
+    }
+    // Await EVERY batch that was enqueued, whatever happened to the others: a caller that reads states or destroys windows after an
+    // error return must not race work still in flight.  The first error is the one reported.
+    int rc_all = SWF_OK; std::string msg;
+    for (int i = 0; i < n; i++) if (rcs[(size_t)i] != SWF_OK && rc_all == SWF_OK) { rc_all = rcs[(size_t)i]; msg = msgs[(size_t)i]; }
+    for (int i = 0; i < n; i++) {
+        if (rcs[(size_t)i] != SWF_OK) continue;
+        int rc = swf_batch_sync(batches[i]);
+        if (rc != SWF_OK && rc_all == SWF_OK) { rc_all = rc; msg = g_err; }
+    }
+    if (rc_all != SWF_OK) g_err = msg;
     return rc_all;
 }
 

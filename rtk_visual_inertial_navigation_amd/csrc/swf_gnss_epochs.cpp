@@ -183,4 +183,44 @@ int swf_composite_add_mid_prior(int32_t M, int32_t k, int32_t n_kept, const int3
     return SWF_OK;
 }
 
+// MarginalizationInfo::ResetLinearizationPoint (R/factor/marginalization_factor.cpp:232-258; call site: the middle-marginalisation
+// path, R/swf/swf_core.cpp:636-637).  Host bookkeeping on a prior's own small arrays, as in the reference: dx between the new values
+// and the stored linearisation point per kept block (vector blocks x - x0; pose blocks [p - p0 ; +-2 vec(q0^-1 q)], the sign that
+// makes the scalar part non-negative — the same dx MarginalizationFactor::Evaluate forms, :416-431), then
+// linearized_residuals += linearized_jacobians dx,  b += A dx,  keep_block_data <- parameters.
+int swf_prior_reset_linearization_point(int32_t n_kept, const int32_t* kept_size, const double* const* x_new, int32_t dim,
+                                        const double* J, const double* A, double* r0, double* b, double* x0) {
+    if (n_kept < 1 || !kept_size || !x_new || dim < 1 || !x0 || (J && !r0) || (A && !b))
+        return efail(SWF_E_INVALID, "swf_prior_reset_linearization_point: bad arguments");
+    std::vector<double> dx((size_t)dim);
+    int d = 0; size_t g = 0;
+    for (int k = 0; k < n_kept; k++) {
+        const int sz = kept_size[k], loc = sz == 7 ? 6 : sz;
+        if (sz < 1 || !x_new[k]) return efail(SWF_E_INVALID, "swf_prior_reset_linearization_point: bad kept block");
+        if (d + loc > dim) return efail(SWF_E_INVALID, "swf_prior_reset_linearization_point: the kept blocks' local sizes exceed dim");
+        const double* x = x_new[k]; const double* y = x0 + g;
+        if (sz != 7) for (int i = 0; i < sz; i++) dx[(size_t)(d + i)] = x[i] - y[i];
+        else {
+            for (int i = 0; i < 3; i++) dx[(size_t)(d + i)] = x[i] - y[i];
+            // q0^-1 (conjugate over the squared norm, Eigen's inverse()) times q, storage (x, y, z, w)
+            const double n2 = y[3] * y[3] + y[4] * y[4] + y[5] * y[5] + y[6] * y[6];
+            const double ax = -y[3] / n2, ay = -y[4] / n2, az = -y[5] / n2, aw = y[6] / n2;
+            const double bx = x[3], by = x[4], bz = x[5], bw = x[6];
+            const double qx = aw * bx + ax * bw + ay * bz - az * by;
+            const double qy = aw * by - ax * bz + ay * bw + az * bx;
+            const double qz = aw * bz + ax * by - ay * bx + az * bw;
+            const double qw = aw * bw - ax * bx - ay * by - az * bz;
+            const double sg = (qw >= 0) ? 2.0 : -2.0;
+            dx[(size_t)(d + 3)] = sg * qx; dx[(size_t)(d + 4)] = sg * qy; dx[(size_t)(d + 5)] = sg * qz;
+        }
+        d += loc; g += (size_t)sz;
+    }
+    if (d != dim) return efail(SWF_E_INVALID, "swf_prior_reset_linearization_point: the kept blocks' local sizes do not add up to dim");
+    if (J) for (int r = 0; r < dim; r++) { double a = 0; for (int c = 0; c < dim; c++) a += J[(size_t)r * dim + c] * dx[(size_t)c]; r0[r] += a; }
+    if (A) for (int r = 0; r < dim; r++) { double a = 0; for (int c = 0; c < dim; c++) a += A[(size_t)r * dim + c] * dx[(size_t)c]; b[r] += a; }
+    g = 0;
+    for (int k = 0; k < n_kept; k++) { memcpy(x0 + g, x_new[k], sizeof(double) * (size_t)kept_size[k]); g += (size_t)kept_size[k]; }
+    return SWF_OK;
+}
+
 }  // extern "C"

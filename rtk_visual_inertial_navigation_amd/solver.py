@@ -54,6 +54,7 @@ EXPORTED = [
     "swf_batch_marginal_priors", "swf_composite_assemble",
     "swf_composite_set_mid_links", "swf_composite_add_mid_prior", "swf_set_imu_gnss_mid_link", "swf_composite_set_root",
     "swf_batch_create_on", "swf_batch_create_sharded", "swf_solve_batches", "swf_batch_device", "swf_default_options", "swf_shard_partition",
+    "swf_prior_reset_linearization_point",
 ]
 
 
@@ -205,7 +206,7 @@ class BatchSolver:
             _chk(lib().swf_batch_get_tail_covariance(self._h, C.c_int32(i), A.ctypes.data_as(_pd), Q.ctypes.data_as(_pd), C.byref(n)),
                  "swf_batch_get_tail_covariance")
             return dict(A=A, Qy=Q, n=k)
-        return [one(i) for i in range(len(self._structs))] if w is None else one(w)
+        return [one(i) for i in range(self.n)] if w is None else one(w)
 
     def enable_timing(self, mask=1):
         """mask: bit k brackets kernel K_NAMES[k] with a HIP event pair per launch (bit 0 = whole solve);
@@ -600,6 +601,23 @@ def composite_assemble(epochs):
     HpN = HpN_buf[:M * 15 * n].reshape(M, 15, n) if n else np.zeros((M, 15, 0))
     return dict(N=n, keys=[keep_alive[C.cast(nk[i], C.c_void_p).value] for i in range(n)], Hpp=Hpp, HpN=HpN, rhs_p=rhs_p,
                 HNN=HNN[:n, :n].copy(), rhsN=rhsN[:n].copy())
+
+
+def prior_reset_linearization_point(blocks, sizes, J, A, r0, b, x0):
+    """swf_prior_reset_linearization_point: MarginalizationInfo::ResetLinearizationPoint (R/factor/marginalization_factor.cpp:232-258).
+    blocks = the kept blocks' current values (numpy arrays, kept order), sizes = their global sizes; J / A dim x dim or None.
+    Returns the shifted (r0, b, x0) as new arrays (None where the pair was not given)."""
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    arrs = [np.ascontiguousarray(np.asarray(x, np.float64).ravel()) for x in blocks]
+    ptrs = (_pd * max(1, len(arrs)))(*[a.ctypes.data_as(_pd) for a in arrs])
+    dim = int(sum(6 if sz == 7 else sz for sz in sizes))
+    Jc = None if J is None else np.ascontiguousarray(J, np.float64); Ac = None if A is None else np.ascontiguousarray(A, np.float64)
+    r = None if r0 is None else np.array(r0, np.float64); bb = None if b is None else np.array(b, np.float64)
+    x = np.array(x0, np.float64)
+    pn = lambda a: a.ctypes.data_as(_pd) if a is not None else None
+    _chk(lib().swf_prior_reset_linearization_point(C.c_int32(len(arrs)), sizes.ctypes.data_as(C.POINTER(C.c_int32)), ptrs, C.c_int32(dim),
+                                                   pn(Jc), pn(Ac), pn(r), pn(bb), pn(x)), "swf_prior_reset_linearization_point")
+    return r, bb, x
 
 
 def composite_add_mid_prior(fac, k, kept, A, b):

@@ -32,6 +32,32 @@ def build_oracle(force=False):
     return so
 
 
+def _bind(l):
+    l.oracle_solve.restype = C.c_int
+    l.oracle_dims.restype = C.c_int
+    l.oracle_evaluate.restype = C.c_int
+    l.oracle_cauchy_correct.restype = C.c_double
+    return l
+
+
+def use_native():
+    """bench.py's cpu_baseline leg: rebuild the same source with -march=native ON THE HOST IT IS TIMED ON (oracle/Makefile `native`) and
+    switch the binding to it.  Returns the ISA string gcc resolved `native` to, or None (the portable x86-64-v3 build stays in use)."""
+    global _lib
+    try:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "native"], timeout=300)
+        l = _bind(C.CDLL(os.path.join(ORACLE_DIR, "libswf_oracle_native.so")))
+    except Exception:
+        return None
+    _lib = l
+    try:
+        q = subprocess.run(["gcc", "-march=native", "-Q", "--help=target"], capture_output=True, text=True, timeout=30).stdout
+        arch = [ln.split()[-1] for ln in q.splitlines() if ln.strip().startswith("-march=")]
+        return "-O3 -march=native (gcc resolves it to %s)" % (arch[0] if arch else "?")
+    except Exception:
+        return "-O3 -march=native"
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -265,3 +291,15 @@ def marginalize(S, rhs, n_tail, eps_mm=1e-8, eps=1e-8):
     if rc != 0:
         raise RuntimeError("oracle_marginalize failed")
     return dict(A=A, b=b, J=J, r0=r0, rank=int(rank.value))
+
+
+def prior_reset_lin_point(sizes, x_new, J, A, r0, b, x0):
+    """oracle_prior_reset_lin_point: MarginalizationInfo::ResetLinearizationPoint.  x_new / x0 concatenated over the kept blocks."""
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    xn = np.ascontiguousarray(np.asarray(x_new, np.float64).ravel()); n = int(sum(6 if s == 7 else s for s in sizes))
+    Jc = np.ascontiguousarray(J, np.float64); Ac = np.ascontiguousarray(A, np.float64)
+    r, bb, x = np.array(r0, np.float64), np.array(b, np.float64), np.array(x0, np.float64)
+    f = lib().oracle_prior_reset_lin_point
+    f.restype = None
+    f(C.c_int(len(sizes)), sizes.ctypes.data_as(_pi), _p(xn), C.c_int(n), _p(Jc), _p(Ac), _p(r), _p(bb), _p(x))
+    return r, bb, x

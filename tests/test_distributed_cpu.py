@@ -128,6 +128,26 @@ def test_bench_two_ranks_sharing_one_gpu_reports_the_whole_job():
     assert out1["job_final_cost_mean"] == out["job_final_cost_mean"]
 
 
+@pytest.mark.gpu
+def test_bench_eight_ranks_sharing_one_gpu_reports_the_whole_job():
+    """The 8-GPU launch shape the driver uses (`--gpus 8`: eight ranks, harness collectives, an UNEVEN strong partition — 20 windows as
+    3+3+3+3+2+2+2+2) exercised end to end on a 1-GPU box in share mode: one line, n_gpus = 8, every window of the job gathered, and the
+    same per-window results as the one-rank job."""
+    import json
+    args = ["--steps", "2", "--warmup", "1", "--windows", "20", "--no-cpu-baseline", "--no-single-window"]
+    r = _run_bench(["--gpus", "8"] + args, {"SWF_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["windows"] == 20 and out["config"]["windows_rank0"] == 3
+    assert out["job_windows"] == 20 and out["job_failed_windows"] == 0 and out["value"] > 0
+    r1 = _run_bench(["--gpus", "1"] + args, {})
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    out1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert out1["job_windows"] == 20 and out1["job_final_cost_mean"] == out["job_final_cost_mean"]
+
+
 def _uneven_worker(rank, world, port, total, out_dir):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -141,6 +161,19 @@ def _uneven_worker(rank, world, port, total, out_dir):
     np.save(os.path.join(out_dir, "u%d.npy" % rank), shard.gather_summaries(recs))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_gather_of_an_uneven_strong_partition_over_eight_ranks(tmp_path):
+    """The 8-way partition of a job that does not divide (21 windows: 3+3+3+3+3+2+2+2): every rank gathers the job's windows in order."""
+    import torch.multiprocessing as mp
+    from rtk_visual_inertial_navigation_amd import shard
+    world, total = 8, 21
+    mp.spawn(_uneven_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    g = [np.load(os.path.join(str(tmp_path), "u%d.npy" % r)) for r in range(world)]
+    assert all(np.array_equal(g[0], x) for x in g[1:])
+    assert g[0].shape == (total, 3) and np.array_equal(g[0][:, 1], np.arange(total))
+    counts = [shard.partition(total, world, r)[1] for r in range(world)]
+    assert counts == [3, 3, 3, 3, 3, 2, 2, 2] and sum(counts) == total
 
 
 def test_gather_of_an_uneven_strong_partition(tmp_path):

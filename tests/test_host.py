@@ -71,7 +71,12 @@ def test_c_abi_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
     assert set(solver.EXPORTED) <= declared
-    assert lib.swf_version() >= 100
+    assert lib.swf_version() >= 104
+    # the ctypes mirrors of the ABI structs have the library's sizes (swf_abi_sizes: options, summary, timing, flat window, iteration)
+    from rtk_visual_inertial_navigation_amd.flat import FlatWindowC, OptionsC, SummaryC
+    sz = (ctypes.c_int32 * 5)()
+    assert lib.swf_abi_sizes(sz) == 0
+    assert (sz[0], sz[1], sz[2], sz[3]) == (ctypes.sizeof(OptionsC), ctypes.sizeof(SummaryC), ctypes.sizeof(solver.TimingC), ctypes.sizeof(FlatWindowC))
 
 
 def test_no_cpu_fallback_without_gpu():
