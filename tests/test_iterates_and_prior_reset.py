@@ -95,6 +95,12 @@ def test_prior_relinearised_at_the_current_state_is_the_same_factor_there():
     for kw in (dict(config_id=5, K=14, F=40, S=4, seed=10), dict(config_id=3, K=6, F=30, S=5, seed=21)):
         w = synth.make_window(**kw)
         a = w.a
+        # move the state away from the prior's linearisation point (the generator linearises the prior at the window's own state)
+        rng = np.random.default_rng(3)
+        P = a["pose"].reshape(-1, 7); P[:, :3] += 0.05 * rng.standard_normal((P.shape[0], 3))
+        P[:, 3:] += 0.01 * rng.standard_normal((P.shape[0], 4)); P[:, 3:] /= np.linalg.norm(P[:, 3:], axis=1)[:, None]
+        a["sb"] += 0.01 * rng.standard_normal(a["sb"].shape)
+        if a["sc"].size: a["sc"] += 0.1 * rng.standard_normal(a["sc"].shape)
         blk = [int(g) for g in a["prior_blk"]]
         vals = [_block_values(w, g) for g in blk]
         sizes = [s for _, s in vals]
