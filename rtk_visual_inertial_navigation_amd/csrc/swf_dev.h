@@ -29,6 +29,7 @@ struct WinRec {
     int pair0, pair1;            // reduced block pairs
     int fsb0, fsb1;              // frame-sum blocks of this window
     int tail_dim;                // dimensions of the parameter_head tail (last rows of the reduced system): the block of L its consumers read
+    int n_pose_blk;              // the window's first n_pose_blk blocks are its pose blocks (7 -> 6, PoseLocalParameterization)
     double proj_sqrt_info, proj_loss_a;
     double pbg[3], gw[3], base[3];
 };
@@ -121,6 +122,8 @@ struct DevBatch {
     // tables
     const WinRec* win; WinState* ws; swf_iteration* trace;
     const int* blk_xoff; const int* blk_loc; const int* blk_gs;
+    const int* loc2x;                          // per local dimension: its ambient coordinate (absolute), -1 for the dimensions of a pose block
+    const unsigned char* x_var;                // per ambient coordinate: 1 if its block is variable
     // projection observations (SoA outputs, stride n_proj)
     int n_proj;
     const int* p_win; const int* p_xpose; const int* p_xex; const int* p_xlm;

@@ -232,6 +232,7 @@ struct swf_batch {
         if (aux) { (void)hipStreamSynchronize(aux); handle_cache().give(aux); }
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
+    bool lat_fuse = false;                // latency path: fused grids on one stream (see swf_batch_create)
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
     bool chol_rr2 = false;                // SWF_CHOL_RR2=1: the previous register-resident kernel (A/B testing)
     bool export_L_always = false;         // SWF_EXPORT_L=1: k_chol_rr3 writes the whole factor on every solve path
@@ -254,7 +255,8 @@ namespace {
 struct Build {
     // concatenated host arrays
     std::vector<WinRec> win;
-    std::vector<int> blk_xoff, blk_loc, blk_gs;
+    std::vector<int> blk_xoff, blk_loc, blk_gs, loc2x;
+    std::vector<unsigned char> x_var;
     std::vector<int> p_win, p_xpose, p_xex, p_xlm, p_lpose, p_llm, p_fr, p_lm;
     std::vector<double> p_uv;
     std::vector<int> lm_win, lm_obs0, lm_loc, lm_col;
@@ -321,10 +323,16 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         for (int i = w->n_order - w->n_tail; i < w->n_order; i++) if (i >= 0) td += ls[w->order_block[i]];
         hw.tail_dim = td; R.tail_dim = td;
     }
+    if (nP > CTL_NT) return fail(SWF_E_UNSUPPORTED, "more than 256 pose blocks in a window");      // k_dogleg: a thread per pose block
+    R.n_pose_blk = nP;
+    B.loc2x.resize((size_t)R.loc_base + (size_t)R.n_loc, -1); B.x_var.resize((size_t)R.x_base + (size_t)R.x_n, 0);
     for (int b = 0; b < nb; b++) {
         B.blk_xoff.push_back(R.x_base + xo[b]);
         B.blk_loc.push_back(loc[b] >= 0 ? R.loc_base + loc[b] : -1);
         B.blk_gs.push_back(gs[b]);
+        if (loc[b] < 0) continue;
+        for (int k = 0; k < gs[b]; k++) B.x_var[(size_t)R.x_base + xo[b] + k] = 1;
+        if (gs[b] != 7) for (int k = 0; k < gs[b]; k++) B.loc2x[(size_t)R.loc_base + loc[b] + k] = R.x_base + xo[b] + k;
     }
     auto bidP = [&](int i) { return i; };
     auto bidS = [&](int i) { return nP + i; };
@@ -839,7 +847,12 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
     // fills what one-block-per-window kernels leave idle (measured: 256 windows 5.52 -> 5.22 ms, 128 windows 3.73 -> 3.49 ms per solve; 64 and
     // 512 windows: no gain)
-    if ((n * 16 <= b->n_cu || (2 * n >= b->n_cu && n <= b->n_cu) || getenv("SWF_AUX_STREAM_ALWAYS")) && !getenv("SWF_NO_AUX_STREAM")) {            // latency path: fork / join inside a linearisation
+    // latency path (up to n_CU / 8 windows): independent kernels of an iteration ride in ONE grid (the IMU factors with the projection /
+    // scalar factors, every clique size class in one launch) on ONE stream.  Round 3 ran the IMU / clique branch of such batches on the
+    // auxiliary stream instead; the kernel trace shows what that buys: every cross-queue edge (event record -> stream wait) costs 6-13 us
+    // of dependency resolution, as much as the overlap saves (one window: 1.432 ms with the auxiliary stream, 1.443 without).
+    b->lat_fuse = n * 8 <= b->n_cu && !getenv("SWF_NO_LAT_FUSE");
+    if ((((n * 16 <= b->n_cu && !b->lat_fuse) || (2 * n >= b->n_cu && n <= b->n_cu)) || getenv("SWF_AUX_STREAM_ALWAYS")) && !getenv("SWF_NO_AUX_STREAM")) {            // fork / join inside a linearisation
         bool ok = (b->aux = handle_cache().stream()) != nullptr;
         for (int i = 0; i < 3 && ok; i++) ok = (b->ev_fork[i] = handle_cache().event(false)) != nullptr;
         if (!ok) { handle_cache().give(b->aux); b->aux = nullptr; }
@@ -859,6 +872,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
 #define PUT(field, vec) rc |= P.put(vec, &D.field)
     PUT(win, B.win);
     PUT(blk_xoff, B.blk_xoff); PUT(blk_loc, B.blk_loc); PUT(blk_gs, B.blk_gs);
+    if (B.loc2x.empty()) B.loc2x.push_back(-1);
+    PUT(loc2x, B.loc2x); PUT(x_var, B.x_var);
     D.n_proj = (int)B.p_win.size();
     PUT(p_win, B.p_win); PUT(p_xpose, B.p_xpose); PUT(p_xex, B.p_xex); PUT(p_xlm, B.p_xlm);
     PUT(p_lpose, B.p_lpose); PUT(p_llm, B.p_llm); PUT(p_fr, B.p_fr); PUT(p_lm, B.p_lm); PUT(p_uv, B.p_uv);
@@ -1038,6 +1053,9 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             int d = c.d_e + c.d_f;
             // one wavefront per clique up to 64 x 64 (three size classes); anything larger takes the workgroup kernel (class 3)
             int cls = (c.d_e <= 1 && d <= 32 && c.n_rows <= 48) ? 0 : (c.n_rows <= 32 && d <= 48) ? 1 : (c.n_rows <= CLQ_MAXR && d <= CLQ_MAXD) ? 2 : 3;
+            // latency path: every one-wavefront clique in ONE launch (the 64 x 64 instantiation; the classes differ in loop bounds and zero
+            // padding only, the sums and their order are the same: bit-identical results)
+            if (b->lat_fuse && cls < 2) cls = 2;
             clc[cls].push_back((int)i);
             for (int q = c.fac0; q < c.fac1; q++) if (B.gf[B.cl_fac[q]].type == GF_IMU) b->clc_imu[cls] = true;
         }
@@ -1308,6 +1326,7 @@ extern "C" int swf_batch_upload_state(swf_batch* b) {
     }
     HIPCHK(hipMemcpyAsync(b->D.x, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->D.x0, b->D.x, x.size() * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->D.xc, b->D.x, x.size() * sizeof(double), hipMemcpyDeviceToDevice, b->stream));      // (the candidate's constant blocks: k_dogleg writes the variable ones only)
     std::vector<double> hp, hs;
     if (b->n_comp) {
         hp.resize((size_t)b->comp_ne * 7); hs.resize((size_t)b->comp_ne * 9);
@@ -1414,17 +1433,21 @@ struct Launcher {
         }
         hipStream_t sa = b->aux ? b->aux : st;
         if (b->aux) { (void)hipEventRecord(b->ev_fork[0], st); (void)hipStreamWaitEvent(b->aux, b->ev_fork[0], 0); }
+        bool imu_fused = false;
         if (D.n_proj + D.n_sc + D.n_prior) {
             Bracket t(*this, SWF_K_EVAL_PS);
             bool pf = b->max_prior_dim <= PRIOR_LDS_DIM;          // priors fused as a segment
             // (the projection segment: one workgroup per frame-sum block, the per-frame sums fused in; SWF_FS_SEPARATE=1: k_frame_sums as its own launch)
             Segs S{}; S.e[0] = b->fs_fused ? D.n_fsb : nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
-            if (b->fs_fused) hipLaunchKernelGGL((k_eval_ps<true, true>), dim3(S.e[2]), dim3(256), 0, st, D, S);
+            imu_fused = b->lat_fuse && b->fs_fused && D.n_imu > 0;          // latency path: the IMU factors as a segment of this grid
+            S.e[3] = S.e[2] + (imu_fused ? nb(D.n_imu, IMU_FPB) : 0);
+            if (imu_fused) hipLaunchKernelGGL((k_eval_ps<true, true, true>), dim3(S.e[3]), dim3(256), 0, st, D, S);
+            else if (b->fs_fused) hipLaunchKernelGGL((k_eval_ps<true, true>), dim3(S.e[2]), dim3(256), 0, st, D, S);
             else hipLaunchKernelGGL((k_eval_ps<true, false>), dim3(S.e[2]), dim3(256), 0, st, D, S);
         }
         if (D.n_idp) hipLaunchKernelGGL(k_eval_idp<true>, GRID(D.n_idp, 128), dim3(128), 0, st, D);
         if (b->aux) (void)hipEventRecord(b->ev_fork[1], st);
-        if (D.n_imu) { Bracket t(*this, SWF_K_EVAL_IMU, sa); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, sa, D); }
+        if (D.n_imu && !imu_fused) { Bracket t(*this, SWF_K_EVAL_IMU, sa); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, sa, D); }
         if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
     }
     void lin_elim(int write_S) {

@@ -1125,7 +1125,11 @@ struct Segs { int e[8]; };     // exclusive end block of segment k (cumulative)
 // Jacobian/residual evaluation of the one-lane-per-factor families: projection + scalar GNSS/prior factors
 // FS (Jacobian evaluations): the projection segment runs one workgroup per frame-sum block and leaves the per-frame partial sums of
 // Jp^T Jp | Jp^T r next to the Jacobians (d_eval_proj_fs); k_frame_sums is then not launched.
-template <bool JAC, bool FS = false>
+// IMU (latency path, few windows): the IMU factors ride along as a fourth segment (8 factors per workgroup) instead of their own launch
+// behind this one — the two evaluations are independent, and on the latency path a launch costs its whole dependent-load chain
+// (one window: 7.6 + 11.8 us as two kernels).  Large batches keep k_eval_imu apart: its LDS and registers would cost the HBM-bound
+// segments their occupancy.  Same device functions, same results.
+template <bool JAC, bool FS = false, bool IMU = false>
 __global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
     // one LDS buffer for whichever segment the block runs: the prior's staging vectors, or the frame sums' staging tile (+ its frame offsets)
     constexpr int SM_PRIOR = 2 * PRIOR_LDS_DIM + 16, SM_FS = FS ? FS_BLK * FS_HALF + 168 / 2 + 1 : 1;
@@ -1133,7 +1137,8 @@ __global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
     int bid = blockIdx.x;
     if (bid < S.e[0]) { if (FS) d_eval_proj_fs(B, bid, (double (*)[FS_HALF])sm, (int*)(sm + FS_BLK * FS_HALF)); else d_eval_proj<JAC>(B, bid); }
     else if (bid < S.e[1]) d_eval_scalar<JAC>(B, bid - S.e[0]);
-    else d_eval_prior<JAC>(B, bid - S.e[1], sm);              // one workgroup per prior (segment empty for large priors)
+    else if (!IMU || bid < S.e[2]) d_eval_prior<JAC>(B, bid - S.e[1], sm);              // one workgroup per prior (segment empty for large priors)
+    else d_eval_imu<JAC>(B, bid - S.e[2]);
 }
 // after the reduced solve: back-substitution of the eliminated blocks, and |J D^-2 g|^2 for the Cauchy point.
 // PART 0: every segment in one grid (latency path).  Large batches launch the landmark segment (PART 1, the
@@ -1241,7 +1246,9 @@ __global__ void __launch_bounds__(256) k_init(DevBatch B, DevOpt O) {
     __shared__ double red[16];
     int w = blockIdx.x;
     const WinRec& W = B.win[w];
-    double xn = win_x_norm(B, W, B.x, red);
+    double xa = 0;
+    for (int i = W.x_base + threadIdx.x; i < W.x_base + W.x_n; i += blockDim.x) { const double xv = B.x[i]; if (B.x_var[i]) xa += xv * xv; }
+    double xn = sqrt(block_sum(xa, red));
     for (int k = threadIdx.x; k < B.max_iter_trace * (int)(sizeof(swf_iteration) / 8); k += blockDim.x)
         ((double*)(B.trace + (size_t)w * B.max_iter_trace))[k] = 0.0;
     if (threadIdx.x == 0) {
@@ -1267,6 +1274,11 @@ __device__ unsigned long long g_dog_stamps[16];
 // dependent loads, so a window's latency falls with the thread count (one window: k_dogleg 20.7 -> ? us); the same count for every
 // batch size, because the order of the strided partial sums depends on it
 #define CTL_NT 256
+// Latency notes (one window: 46 k cycles in round 3, most of them chains of dependent loads — block table -> offsets -> values, three
+// blocks per thread one after the other, twice): the passes below run over FLAT host-built tables instead.  loc2x[i] = ambient
+// coordinate of local dimension i (-1 for the six dimensions of a pose block, which a thread per pose block handles with Plus);
+// every load of a pass depends on nothing but the window record, so a pass is one round trip.  Constant blocks are never written:
+// xc holds their values since the upload (swf_batch_upload_state / _reset_state copy x to xc).
 __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     __shared__ double red[16 * 6];
     __shared__ int go;
@@ -1282,24 +1294,42 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     int fresh = s.need_lin;
     double x_cost = s.x_cost, gmax = s.gmax, jg_sq = s.jg_sq;
     const double* g = B.g + W.loc_base; const double* dg = B.diag + W.loc_base; const double* y = B.y + W.loc_base;
+    const int* l2x = B.loc2x + W.loc_base;
     double* step = B.step + W.loc_base;
     int n = W.n_loc;
+    const bool want_gmax = fresh && !s.lin_fail;
     // one pass, one barrier pair: cost, |J D^-2 g|^2, gradient max-norm (fresh linearisation only) and the scalars of the
     // scaled problem |g/d|^2, |d y|^2, (g/d).(-d y)
     double v[6] = { 0, 0, 0, 0, 0, 0 };
     DST(0);
-    if (fresh) {
-        win_cost_aux_part(B, W, v[0], v[1]);
-        DST(1);
-        if (!s.lin_fail) v[5] = win_gmax_part(B, W);
-        DST(2);
+    // the pose blocks (the window's first blocks; constant ones have no local dimensions): a thread each, its loads issued ahead of the flat passes
+    int p_lo = -1, p_xo = 0;
+    if (tid < W.n_pose_blk) { p_lo = B.blk_loc[W.blk_base + tid]; p_xo = B.blk_xoff[W.blk_base + tid]; }
+    if (fresh) win_cost_aux_part(B, W, v[0], v[1]);
+    DST(1);
+    double xp[7] = { 0, 0, 0, 0, 0, 0, 1 };
+    if (p_lo >= 0) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) xp[k] = B.x[p_xo + k];
+        if (want_gmax) {
+            // gradient_max_norm = || x - Plus(x, -g) ||_inf (TrustRegionMinimizer::EvaluateGradientAndJacobian)
+            double d[6], o[7];
+#pragma unroll
+            for (int k = 0; k < 6; k++) d[k] = -B.g[p_lo + k];
+            pose_plus(xp, d, o);
+#pragma unroll
+            for (int k = 0; k < 7; k++) { double q = fabs(xp[k] - o[k]); v[5] = q > v[5] ? q : v[5]; }
+        }
     }
+    DST(2);
 #pragma unroll 4
     for (int i = tid; i < n; i += blockDim.x) {
+        double gi = g[i], yi = y[i];
         double dc = damp_diag(O, dg[i], B.jsc + W.loc_base + i, false);      // (the damping diagonal: with Jacobi scaling, LM's effective one)
         double ir = rsqrt_nr(dc);                     // 1 / sqrt(d): no IEEE sqrt / division expansions in these loops
-        double gs = g[i] * ir;
-        v[2] += gs * gs; v[3] += dc * y[i] * y[i]; v[4] += -g[i] * y[i];
+        double gs = gi * ir;
+        v[2] += gs * gs; v[3] += dc * yi * yi; v[4] += -gi * yi;
+        if (want_gmax && l2x[i] >= 0) { double q = fabs(gi); v[5] = q > v[5] ? q : v[5]; }       // (Plus of a vector block is x + delta)
     }
     DST(3);
     block_reduce<5, 1>(v, red);
@@ -1374,31 +1404,34 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
         const double sHs = c1 * c1 * jg_sq + 2.0 * c1 * c2 * (gsq - mu * gy) + c2 * c2 * (gy - mu * ynn);
         s.model_cost_change = -(c1 * gsq + c2 * gy + 0.5 * sHs);
     }
-    double a_s = 0;
+    // the step and the candidate = Plus(x, step) in one pass over the local dimensions; the pose threads form their six step entries from the
+    // same operands (the same bits as step[]) and apply PoseLocalParameterization::Plus
+    double a_s = 0, a_n = 0;
 #pragma unroll 4
     for (int i = tid; i < n; i += blockDim.x) {
+        const int a = l2x[i];
         double dc = clampd(dg[i], O.min_diag, O.max_diag);
         double ir = rsqrt_nr(dc);
         // scaled step c1 g / sqrt(d) + c2 sqrt(d) y, then un-scaled (/ sqrt(d))
         double sc = c1 * (g[i] * ir) + c2 * (dc * ir * y[i]);
         a_s += sc * sc;
-        step[i] = sc * ir;
+        const double st = sc * ir;
+        step[i] = st;
+        if (a >= 0) { const double x0 = B.x[a], xv = x0 + st; B.xc[a] = xv; const double dv = x0 - xv; a_n += dv * dv; }
     }
     DST(6);
-    __syncthreads();                                   // step visible to the block-wise Plus below
-    // candidate = Plus(x, step); constant blocks are copied
-    double a_n = 0;
-    for (int b = W.blk_base + tid; b < W.blk_base + W.n_blk; b += blockDim.x) {
-        int lo = B.blk_loc[b];
-        int xo = B.blk_xoff[b], gs = B.blk_gs[b];
-        if (lo < 0) { for (int k = 0; k < gs; k++) B.xc[xo + k] = B.x[xo + k]; continue; }
-        if (gs == 7) {
-            double o[7];
-            pose_plus(B.x + xo, B.step + lo, o);
-            for (int k = 0; k < 7; k++) { B.xc[xo + k] = o[k]; double dv = B.x[xo + k] - o[k]; a_n += dv * dv; }
-        } else {
-            for (int k = 0; k < gs; k++) { double xv = B.x[xo + k] + B.step[lo + k]; B.xc[xo + k] = xv; double dv = B.x[xo + k] - xv; a_n += dv * dv; }
+    if (p_lo >= 0) {
+        double d[6], o[7];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            double dc = clampd(B.diag[p_lo + k], O.min_diag, O.max_diag);
+            double ir = rsqrt_nr(dc);
+            double sc = c1 * (B.g[p_lo + k] * ir) + c2 * (dc * ir * B.y[p_lo + k]);
+            d[k] = sc * ir;
         }
+        pose_plus(xp, d, o);
+#pragma unroll
+        for (int k = 0; k < 7; k++) { B.xc[p_xo + k] = o[k]; const double dv = xp[k] - o[k]; a_n += dv * dv; }
     }
     DST(7);
     double r2[2] = { a_s, a_n };
@@ -1493,9 +1526,10 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
     }
     __syncthreads();
     if (accept) {
-        for (int i = W.x_base + tid; i < W.x_base + W.x_n; i += blockDim.x) B.x[i] = B.xc[i];
-        __syncthreads();
-        double xn = win_x_norm(B, W, B.x, red);
+        // x <- candidate and || x || over the variable blocks in one pass (x_var: host-built flag per ambient coordinate)
+        double a = 0;
+        for (int i = W.x_base + tid; i < W.x_base + W.x_n; i += blockDim.x) { const double xv = B.xc[i]; B.x[i] = xv; if (B.x_var[i]) a += xv * xv; }
+        const double xn = sqrt(block_sum(a, red));
         if (tid == 0) s.x_norm = xn;
     }
 }
