@@ -1379,10 +1379,20 @@ struct Launcher {
     int lm_next = 0, lm_qpb = 1;                 // first tile of the ranges of k_lm_schur still to launch (with the clique kernels)
     int ls_tiles_per_launch() const { return b->ls_var == 0 ? 16 : b->ls_var == 1 ? 40 : 72; }
     // one launch of the landmark Schur kernel over the tile-list entries [tile_base, tile_base + tiles per launch), by row class
-    void lm_launch(int tile_base, hipStream_t on) {
+    void lm_launch(int tile_base, hipStream_t on, int clique_rows = 0) {
         DevBatch& D = b->D;
         dim3 grid(D.n_win, GEMM_SPLIT / b->ls_qpb);
         const int qpb = b->ls_qpb, sd = b->s_direct ? 1 : 0, lp = tile_base / ls_tiles_per_launch(), kms = b->ls_kms;
+        if (clique_rows > 0) {
+            const int np = (int)grid.y;
+            grid.y += clique_rows;
+            switch (b->ls_var) {
+            case 0: hipLaunchKernelGGL((k_lm_clique<8, 2, 2, 80>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd, np); break;
+            case 1: hipLaunchKernelGGL((k_lm_clique<8, 5, 2, 144>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd, np); break;
+            default: hipLaunchKernelGGL((k_lm_clique<12, 6, 1, 272>), grid, dim3(LS_NT(12, 1)), 0, on, D, O, qpb, lp, kms, 0, np); break;
+            }
+            return;
+        }
         switch (b->ls_var) {
         case 0: hipLaunchKernelGGL((k_lm_schur<8, 2, 2, 80, true>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd); break;
         case 1: hipLaunchKernelGGL((k_lm_schur<8, 5, 2, 144, true>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd); break;
@@ -1452,6 +1462,7 @@ struct Launcher {
     }
     void lin_elim(int write_S) {
         DevBatch& D = b->D;
+        bool clq_fused = false;
         if (D.n_lm) {
             Bracket t(*this, write_S ? SWF_K_LM_SCHUR : SWF_K_LM_ELIM);
             lm_qpb = b->ls_qpb; lm_folded = b->ls_folded;
@@ -1460,7 +1471,12 @@ struct Launcher {
                 dim3 grid(D.n_win, GEMM_SPLIT / lm_qpb);
                 hipLaunchKernelGGL((k_lm_schur<8, 2, 2, 80, false>), grid, dim3(256), 0, st, D, O, lm_qpb, 0, 0, 0);
             } else {
-                lm_launch(0, st);
+                // latency path: the one-wavefront cliques ride in the same grid (k_lm_clique); the 64-frame class has no LDS to spare for them
+                // (a workgroup of that grid fills a CU: only while all of them — landmark parts and cliques — are resident at once)
+                const int crow = D.n_win > 0 ? (D.n_clc[2] + D.n_win - 1) / D.n_win : 0;
+                clq_fused = b->lat_fuse && b->ls_var <= 2 && D.n_clc[2] > 0 && !D.n_clc[0] && !D.n_clc[1] && !getenv("SWF_NO_LM_CLIQUE")
+                            && (long long)D.n_win * (GEMM_SPLIT / b->ls_qpb + crow) <= b->n_cu;
+                lm_launch(0, st, clq_fused ? crow : 0);
                 lm_next = ls_tiles_per_launch();        // further tile ranges: launched below, on the auxiliary stream when there is one
             }
         }
@@ -1471,7 +1487,11 @@ struct Launcher {
             auto cstream = [&](int cls) { return (b->aux && !b->clc_imu[cls]) ? st : sa; };
             if (D.n_clc[1]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(1)); hipLaunchKernelGGL((k_clique_elim<32, 48, 9, 1>), dim3(D.n_clc[1]), dim3(64), 0, cstream(1), D, O); }
             if (D.n_clc[0]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(0)); hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, cstream(0), D, O); }
-            if (D.n_clc[2]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(2)); hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, cstream(2), D, O); }
+            if (D.n_clc[2] && !clq_fused) {
+                Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(2));
+                if (b->lat_fuse) hipLaunchKernelGGL(k_clique_elim4, dim3(D.n_clc[2]), dim3(256), 0, cstream(2), D, O);      // latency form: four waves per clique, same bits
+                else hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, cstream(2), D, O);
+            }
             if (D.n_clc[3]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(3)); hipLaunchKernelGGL(k_clique_big, dim3(D.n_clc[3]), dim3(256), 0, cstream(3), D, O); }
             if (write_S && D.n_lm) {
                 // further tile ranges write nothing but their tiles of P (k_lm_schur: outs), so on the latency path they run behind the

@@ -811,7 +811,10 @@ __device__ __forceinline__ void d_jtimes_prior(const DevBatch& B, const DevOpt& 
 #define CLQ_MAXR 64
 #ifdef SWF_PROFILE_CLQ
 __device__ unsigned long long g_clq_stamps[16];
-#define QST(i) do { if (CLS == 1 && blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_clq_stamps[i] += t_ - tq_; tq_ = t_; } } while (0)
+#ifndef SWF_PROFILE_CLQ_IDX
+#define SWF_PROFILE_CLQ_IDX 0
+#endif
+#define QST(i) do { if (cidx_ == SWF_PROFILE_CLQ_IDX && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_clq_stamps[i] += t_ - tq_; tq_ = t_; } } while (0)
 #else
 #define QST(i)
 #endif
@@ -824,24 +827,33 @@ __device__ unsigned long long g_clq_stamps[16];
 //   lanes < d_e: one row of [M_ee + mu D | I] each, Gauss-Jordan through v_readlane broadcasts of the pivot row
 //   lane j:      column j of T = Einv M_ef
 //   2x2 blocks:  C = M_ff - M_fe T  written straight to HBM
-template <int MAXR, int MAXD, int MAXE, int CLS>
-__global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
-    constexpr int LD = MAXD + 1;
+// PF: values per lane and round of the Jacobian gather (24 in the stand-alone kernel; the fused grid k_lm_clique lives under the 128
+// registers of a 1024-thread workgroup and takes fewer).
+// NW: wavefronts per clique.  1 = the throughput form (a CU keeps many cliques in flight).  4 = the latency form (few windows): the
+// phases whose work is a set of independent output elements — the gather, the rows of M_e*, the 2x2 blocks of C — are dealt over
+// 4 waves; the Gauss-Jordan inverse and the columns of T stay on wave 0.  Every output element is still formed by ONE lane with the
+// same operands in the same order, so the two forms give the same bits (tested: a window alone vs inside a large batch).
+template <int MAXR, int MAXD, int MAXE, int CLS, int PF = 24, int NW = 1>
+__device__ __forceinline__ void d_clique_elim(const DevBatch& B, const DevOpt& O, const int cidx_) {
+    constexpr int LD = MAXD + 1, NT = 64 * NW;
     __shared__ double Jc[MAXR][LD];                 // dense clique Jacobian: rows = residual rows, cols = [e | members]
     __shared__ double Me[MAXE][LD];                 // M_e* = J_e^T J (rows of M that belong to e)
     __shared__ double T[MAXE][LD];                  // Einv M_ef
     __shared__ double Ei[MAXE][MAXE + 1];           // Einv
     __shared__ double rv[MAXR];
     __shared__ double Eg[MAXE];
+    __shared__ double gcs[NW > 1 ? MAXD : 1];       // (NW > 1) g_c of every column, for the waves that do not hold it in registers
+    __shared__ int bad_sh;
 #ifdef SWF_PROFILE_CLQ
     unsigned long long tq_ = __builtin_amdgcn_s_memtime();
-    if (CLS == 1 && blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < 16; i++) g_clq_stamps[i] = 0;
+    if (cidx_ == SWF_PROFILE_CLQ_IDX && threadIdx.x == 0) for (int i = 0; i < 16; i++) g_clq_stamps[i] = 0;
 #endif
-    if ((int)blockIdx.x >= B.n_clc[CLS]) return;
-    const Clique& C = B.clc_rec[CLS][blockIdx.x];
+    if (cidx_ >= B.n_clc[CLS]) return;
+    const Clique& C = B.clc_rec[CLS][cidx_];
     WinState& s = B.ws[C.win];
     if (!s.need_lin) return;
-    int de = C.d_e, df = C.d_f, d = de + df, lane = threadIdx.x, nrow = C.n_rows;
+    const int tid = threadIdx.x, lane = tid & 63, wq = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+    int de = C.d_e, df = C.d_f, d = de + df, nrow = C.n_rows;
     QST(0);
     // the clique's Jacobian is dense and column-major in HBM (the factor kernels write their blocks at their (row, column)
     // position; the structural zeros are static): no gather lists, no indirection
@@ -849,16 +861,17 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
         const double* gJ = B.g_J + C.j_off;
         int tot = nrow * d;
         float rd = 1.0f / (float)nrow;
-        if (lane < nrow) rv[lane] = B.g_r[C.r_off + lane];
-        for (int k = lane; k < nrow; k += 64) Jc[k][d] = 0.0;                      // zero pad column (odd d, 2x2 blocks)
-        // flat, fully coalesced loads, all issued before the first use (one exposed round trip per 24 values)
-        for (int base = 0; base < tot; base += 24 * 64) {
-            double v[24];
+        if (tid < nrow) rv[tid] = B.g_r[C.r_off + tid];
+        for (int k = tid; k < nrow; k += NT) Jc[k][d] = 0.0;                      // zero pad column (odd d, 2x2 blocks)
+        if (NW > 1 && tid == 0) bad_sh = 0;
+        // flat, fully coalesced loads, all issued before the first use (one exposed round trip per PF values)
+        for (int base = 0; base < tot; base += PF * NT) {
+            double v[PF];
 #pragma unroll
-            for (int u = 0; u < 24; u++) { int e = base + u * 64 + lane; v[u] = e < tot ? gJ[e] : 0.0; }
+            for (int u = 0; u < PF; u++) { int e = base + u * NT + tid; v[u] = e < tot ? gJ[e] : 0.0; }
 #pragma unroll
-            for (int u = 0; u < 24; u++) {
-                int e = base + u * 64 + lane;
+            for (int u = 0; u < PF; u++) {
+                int e = base + u * NT + tid;
                 int col = (int)((e + 0.5f) * rd);                                    // exact floor(e / nrow) for e < 4096, nrow <= 64
                 col += (e - col * nrow >= nrow) ? 1 : 0; col -= (e - col * nrow < 0) ? 1 : 0;   // (belt and braces)
                 if (e < tot) Jc[e - col * nrow][col] = v[u];
@@ -867,66 +880,91 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
     }
     __syncthreads();
     QST(1);
-    // lane c < d: column c of M_e* (k-ascending dot products), gradient entry g_c, and the diagonal M_cc
+    // lane c < d: column c of M_e* (k-ascending dot products), gradient entry g_c, and the diagonal M_cc.  NW > 1: wave q forms the rows
+    // a2 = q, q + NW, ... of M_e*; g_c and M_cc are wave 0's.
     double me[MAXE], gc = 0, mcc = 0;
 #pragma unroll
     for (int a2 = 0; a2 < MAXE; a2++) me[a2] = 0;
     {
         int c = lane < d ? lane : 0;
+        if (NW == 1) {
 #pragma unroll 4
-        for (int k = 0; k < nrow; k++) {
-            double x = Jc[k][c];
-            gc += x * rv[k]; mcc += x * x;
+            for (int k = 0; k < nrow; k++) {
+                double x = Jc[k][c];
+                gc += x * rv[k]; mcc += x * x;
 #pragma unroll
-            for (int a2 = 0; a2 < MAXE; a2++) me[a2] += Jc[k][a2] * x;      // (rows a2 >= d_e are computed and dropped)
+                for (int a2 = 0; a2 < MAXE; a2++) me[a2] += Jc[k][a2] * x;      // (rows a2 >= d_e are computed and dropped)
+            }
+        } else {
+            constexpr int RPW = (MAXE + NW - 1) / NW;                          // rows of M_e* per wave
+#pragma unroll 4
+            for (int k = 0; k < nrow; k++) {
+                double x = Jc[k][c];
+                if (wq == 0) { gc += x * rv[k]; mcc += x * x; }
+#pragma unroll
+                for (int u = 0; u < RPW; u++) { int a2 = wq + u * NW; if (a2 < MAXE) me[u] += Jc[k][a2] * x; }
+            }
         }
     }
     if (lane < d) {
         // rows >= d_e of Me / Ei / T are kept at zero so the inner loops below need no d_e guards
+        if (NW == 1) {
 #pragma unroll
-        for (int a2 = 0; a2 < MAXE; a2++) Me[a2][lane] = a2 < de ? me[a2] : 0.0;
-        if (lane < de) { B.g[C.e_loc + lane] = gc; B.diag[C.e_loc + lane] = mcc; B.vc[C.e_loc + lane] = gc / clampd(mcc, O.min_diag, O.max_diag); }
-        else { B.cv_graw[C.v_off + lane - de] = gc; B.cv_dgraw[C.v_off + lane - de] = mcc; }
+            for (int a2 = 0; a2 < MAXE; a2++) Me[a2][lane] = a2 < de ? me[a2] : 0.0;
+        } else {
+            constexpr int RPW = (MAXE + NW - 1) / NW;
+#pragma unroll
+            for (int u = 0; u < RPW; u++) { int a2 = wq + u * NW; if (a2 < MAXE) Me[a2][lane] = a2 < de ? me[u] : 0.0; }
+        }
+        if (wq == 0) {
+            if (NW > 1) gcs[lane] = gc;
+            if (lane < de) { B.g[C.e_loc + lane] = gc; B.diag[C.e_loc + lane] = mcc; B.vc[C.e_loc + lane] = gc / clampd(mcc, O.min_diag, O.max_diag); }
+            else { B.cv_graw[C.v_off + lane - de] = gc; B.cv_dgraw[C.v_off + lane - de] = mcc; }
+        }
     }
     __syncthreads();
     QST(2);
     if (de > 0) {
-        // [M_ee + mu D | I] -> [I | Einv] by Gauss-Jordan (SPD: no pivoting).  Lane r < d_e keeps row r in registers;
-        // step k broadcasts the pivot row through SGPRs (v_readlane), so there is no LDS traffic and no barrier.
-        double row[2 * MAXE];
+        if (wq == 0) {
+            // [M_ee + mu D | I] -> [I | Einv] by Gauss-Jordan (SPD: no pivoting).  Lane r < d_e keeps row r in registers;
+            // step k broadcasts the pivot row through SGPRs (v_readlane), so there is no LDS traffic and no barrier.
+            double row[2 * MAXE];
 #pragma unroll
-        for (int j = 0; j < MAXE; j++) {
-            double v = (lane < de && j < de) ? Me[lane][j] : 0.0;
-            if (j == lane) v += s.mu * (lane < de ? damp_diag(O, v, B.jsc + C.e_loc + lane, s.iter == 0) : clampd(v, O.min_diag, O.max_diag));
-            row[j] = v; row[MAXE + j] = (j == lane) ? 1.0 : 0.0;
-        }
-        bool bad = false;
+            for (int j = 0; j < MAXE; j++) {
+                double v = (lane < de && j < de) ? Me[lane][j] : 0.0;
+                if (j == lane) v += s.mu * (lane < de ? damp_diag(O, v, B.jsc + C.e_loc + lane, s.iter == 0) : clampd(v, O.min_diag, O.max_diag));
+                row[j] = v; row[MAXE + j] = (j == lane) ? 1.0 : 0.0;
+            }
+            bool bad = false;
 #pragma unroll
-        for (int k = 0; k < MAXE; k++) {
-            if (k < de) {
-                double piv = readlane_d(row[k], k);
-                if (!(piv > 0.0)) bad = true;
-                // reciprocal by v_rcp_f64 + 2 Newton steps instead of the IEEE division expansion
-                double ip = __builtin_amdgcn_rcp(piv);
-                ip = ip * (2.0 - piv * ip); ip = ip * (2.0 - piv * ip);
-                double aik = row[k];
+            for (int k = 0; k < MAXE; k++) {
+                if (k < de) {
+                    double piv = readlane_d(row[k], k);
+                    if (!(piv > 0.0)) bad = true;
+                    // reciprocal by v_rcp_f64 + 2 Newton steps instead of the IEEE division expansion
+                    double ip = __builtin_amdgcn_rcp(piv);
+                    ip = ip * (2.0 - piv * ip); ip = ip * (2.0 - piv * ip);
+                    double aik = row[k];
 #pragma unroll
-                for (int j = 0; j < 2 * MAXE; j++) {
-                    double akj = readlane_d(row[j], k) * ip;
-                    row[j] = (lane == k) ? akj : row[j] - aik * akj;
+                    for (int j = 0; j < 2 * MAXE; j++) {
+                        double akj = readlane_d(row[j], k) * ip;
+                        row[j] = (lane == k) ? akj : row[j] - aik * akj;
+                    }
                 }
             }
-        }
-        if (bad) { if (lane == 0) s.lin_fail = 1; return; }
-        if (lane < MAXE) {
+            if (NW == 1) { if (bad) { if (lane == 0) s.lin_fail = 1; return; } }
+            else if (bad && lane == 0) { s.lin_fail = 1; bad_sh = 1; }
+            if (lane < MAXE) {
 #pragma unroll
-            for (int j = 0; j < MAXE; j++) Ei[lane][j] = (lane < de && j < de) ? row[MAXE + j] : 0.0;
+                for (int j = 0; j < MAXE; j++) Ei[lane][j] = (lane < de && j < de) ? row[MAXE + j] : 0.0;
+            }
         }
         __syncthreads();
+        if (NW > 1 && bad_sh) return;
         QST(3);
         // lane j < d_f: column j of T = Einv M_ef; lanes < d_e: Eg = Einv g_e
-        double gE = 0;
-        {
+        if (wq == 0) {
+            double gE = 0;
             // g_e entries sit in lanes < d_e (gc): broadcast them
             double tcol[MAXE];
             int j = lane < df ? lane : 0;
@@ -947,36 +985,41 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
         __syncthreads();
         QST(4);
         double* E = B.cE + C.e_off;
-        for (int e = lane; e < de * de; e += 64) E[e] = Ei[e / de][e % de];
-        if (lane < df) {
+        if (NW == 1 || wq == 1) {
+            // (NW > 1: the back-substitution record is wave 1's, while wave 0 starts on its blocks of C)
+            for (int e = lane; e < de * de; e += 64) E[e] = Ei[e / de][e % de];
+            if (lane < df) {
 #pragma unroll
-            for (int a2 = 0; a2 < MAXE; a2++) if (a2 < de) E[de * de + a2 * df + lane] = Me[a2][de + lane];
-        }
-        if (lane < de) E[de * de + de * df + lane] = gc;
-        // cs_j = -(M_fe Eg)_j
-        if (lane < df) {
-            double v = 0;
+                for (int a2 = 0; a2 < MAXE; a2++) if (a2 < de) E[de * de + a2 * df + lane] = Me[a2][de + lane];
+            }
+            if (lane < de) E[de * de + de * df + lane] = NW == 1 ? gc : gcs[lane];
+            // cs_j = -(M_fe Eg)_j
+            if (lane < df) {
+                double v = 0;
 #pragma unroll
-            for (int a2 = 0; a2 < MAXE; a2++) v -= Me[a2][de + lane] * (a2 < de ? Eg[a2] : 0.0);
-            B.cv_cs[C.v_off + lane] = v;
+                for (int a2 = 0; a2 < MAXE; a2++) v -= Me[a2][de + lane] * (a2 < de ? Eg[a2] : 0.0);
+                B.cv_cs[C.v_off + lane] = v;
+            }
         }
     } else {
-        if (lane < df) B.cv_cs[C.v_off + lane] = 0.0;
+        if (wq == 0) {
+            if (lane < df) B.cv_cs[C.v_off + lane] = 0.0;
 #pragma unroll
-        for (int a2 = 0; a2 < MAXE; a2++) T[a2][lane < LD ? lane : 0] = 0.0;
+            for (int a2 = 0; a2 < MAXE; a2++) T[a2][lane < LD ? lane : 0] = 0.0;
+        }
         __syncthreads();
     }
     // C = M_ff - M_fe T in 2x2 blocks of the lower triangle: M_ff block from Jc (k-ascending sums), correction from Me / T
     double* Cm = B.C + C.C_off;
     {
-        // two blocks per lane and pass (eight independent accumulators keep the LDS pipe busy)
+        // two blocks per lane and pass (eight independent accumulators keep the LDS pipe busy); NW > 1: the blocks dealt over all the waves
         int nb = (df + 1) >> 1, nblk = nb * (nb + 1) / 2;
-        for (int t0 = lane; t0 < nblk; t0 += 128) {
+        for (int t0 = tid; t0 < nblk; t0 += 2 * NT) {
             int i0[2], j0[2];
             bool diag[2], on[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                int t = t0 + 64 * u;
+                int t = t0 + NT * u;
                 on[u] = t < nblk;
                 if (!on[u]) t = 0;
                 int ba = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
@@ -1015,6 +1058,23 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) {
         }
     }
     QST(5);
+}
+template <int MAXR, int MAXD, int MAXE, int CLS>
+__global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) { d_clique_elim<MAXR, MAXD, MAXE, CLS>(B, O, (int)blockIdx.x); }
+// the latency form as a kernel of its own: four waves per clique (batches too large for the fused grid below, but still on the latency path)
+__global__ void __launch_bounds__(256) k_clique_elim4(DevBatch B, DevOpt O) { d_clique_elim<64, 64, 9, 2, 8, 4>(B, O, (int)blockIdx.x); }
+
+// Latency path: the landmark Schur complement and the clique eliminations are independent of each other (both follow the factor
+// evaluation, both feed the assembly) — ONE grid of 1024-thread workgroups runs both: rows [0, n_parts) of the grid are k_lm_schur's
+// workgroups, the rows behind them take one clique each on their first four wavefronts (the other waves leave at once).  One window: 13.5 +
+// 15.4 us as two dependent launches, the longer of the two as one.  Same device functions: bit-identical results.
+template <int NCW, int TPW, int TW, int LDR>
+__global__ void __launch_bounds__(LS_NT(NCW, TW)) k_lm_clique(DevBatch B, DevOpt O, int qpb, int lp, int kms, int s_direct, int n_parts) {
+    if ((int)blockIdx.y < n_parts) d_lm_schur<NCW, TPW, TW, LDR, true>(B, O, qpb, lp, kms, s_direct, (int)blockIdx.x, (int)blockIdx.y);
+    else {
+        if (threadIdx.x >= 256) return;
+        d_clique_elim<64, 64, 9, 2, 8, 4>(B, O, ((int)blockIdx.y - n_parts) * (int)gridDim.x + (int)blockIdx.x);
+    }
 }
 
 // =========================================================================================

@@ -39,7 +39,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
                                               // itself when one block covers them all, else by k_assemble)
 #ifdef SWF_PROFILE_GEMM
 __device__ unsigned long long g_gemm_stamps[16];
-#define GSTAMP_ACC(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_gemm_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define GSTAMP_ACC(i, t0) do { if (bx_ == 0 && by_ == 0 && (threadIdx.x & 63) == 0) g_gemm_stamps[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #define GNOW() __builtin_amdgcn_s_memtime()
 #else
 #define GSTAMP_ACC(i, t0)
@@ -71,8 +71,10 @@ __device__ __forceinline__ void ls_signal(unsigned* flag) {
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
 }
+// (the kernel's body as a device function of the block coordinates: k_lm_schur below, and — latency path — the landmark workgroups of the
+// fused elimination grid k_lm_clique in swf_kernels.h)
 template <int NCW, int TPW, int TW, int LDR, bool GEMM>
-__global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBatch B, DevOpt O, int qpb, int lp, int kms, int s_direct) {
+__device__ __forceinline__ void d_lm_schur(const DevBatch& B, const DevOpt& O, int qpb, int lp, int kms, int s_direct, const int bx_, const int by_) {
     constexpr int NPW = GEMM ? LS_NB * TW : 4;                         // producer waves
     constexpr int NCOL = 12 * TW, NG = TW;                             // columns / wave tasks per chunk
     constexpr int PANEL = NCOL * LDR;                                  // doubles per buffer
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
     // a block covers qpb consecutive landmark parts of its window (qpb = 1, 2, 4, 8 or 16; a single window spreads over 16
     // workgroups, large batches use 16 so the ring fills once per block).  Every part still gets its own partial product,
     // so the result does not depend on qpb.
-    int w = blockIdx.x, sp0 = blockIdx.y * qpb;
+    int w = bx_, sp0 = by_ * qpb;
     const bool outs = tile_base == 0;                  // launches of further tile ranges only add their tiles of P: they may run next to the first
     WinState& s = B.ws[w];
     if (!s.need_lin) return;
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
     const int n = B.n_proj, nl = B.n_lm;
     const double mu = s.mu;
 #ifdef SWF_PROFILE_GEMM
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) for (int i = 0; i < 16; i++) g_gemm_stamps[i] = 0;
+    if (bx_ == 0 && by_ == 0 && tid == 0) for (int i = 0; i < 16; i++) g_gemm_stamps[i] = 0;
 #endif
     unsigned long long tg = GNOW(), tall = tg; (void)tg; (void)tall;
     const int team = GEMM ? wv / TW : 0, mi = GEMM ? wv % TW : 0;
@@ -479,4 +481,8 @@ __global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBat
     }
     if (wv == 0) GSTAMP_ACC(6, tall);
     }
+}
+template <int NCW, int TPW, int TW, int LDR, bool GEMM>
+__global__ void __launch_bounds__(GEMM ? LS_NT(NCW, TW) : 256) k_lm_schur(DevBatch B, DevOpt O, int qpb, int lp, int kms, int s_direct) {
+    d_lm_schur<NCW, TPW, TW, LDR, GEMM>(B, O, qpb, lp, kms, s_direct, (int)blockIdx.x, (int)blockIdx.y);
 }
