@@ -232,6 +232,7 @@ struct swf_batch {
         if (aux) { (void)hipStreamSynchronize(aux); handle_cache().give(aux); }
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
+    bool post_split = false;              // SWF_POST_SPLIT=1: the landmark segment of k_post_chol apart from the others whatever the batch size (A/B timing)
     bool lat_fuse = false;                // latency path: fused grids on one stream (see swf_batch_create)
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
     bool chol_rr2 = false;                // SWF_CHOL_RR2=1: the previous register-resident kernel (A/B testing)
@@ -843,6 +844,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->chol_rr2 = getenv("SWF_CHOL_RR2") != nullptr;
     b->export_L_always = getenv("SWF_EXPORT_L") != nullptr;
     b->asm_old = getenv("SWF_ASM_OLD") != nullptr;
+    b->post_split = getenv("SWF_POST_SPLIT") != nullptr;
     b->fs_fused = getenv("SWF_FS_SEPARATE") == nullptr;
     // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
     // fills what one-block-per-window kernels leave idle (measured: 256 windows 5.52 -> 5.22 ms, 128 windows 3.73 -> 3.49 ms per solve; 64 and
@@ -1032,6 +1034,13 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     PUT(prior_J, B.prior_J); PUT(prior_r0, B.prior_r0); PUT(prior_x0, B.prior_x0);
     D.n_cl = (int)B.cl.size();
     PUT(cl, B.cl); PUT(cl_fac, B.cl_fac); PUT(cl_frow, B.cl_frow); PUT(cm_loc, B.cm_loc); PUT(cm_ls, B.cm_ls); PUT(cm_col, B.cm_col);
+    {
+        std::vector<int> cvl((size_t)std::max(B.v_tot, 1), 0);
+        for (const Clique& c : B.cl)
+            for (int m = c.mem0; m < c.mem1; m++)
+                for (int q = 0; q < B.cm_ls[(size_t)m]; q++) cvl[(size_t)c.v_off + (size_t)B.cm_col[(size_t)m] + (size_t)q] = B.cm_loc[(size_t)m] + q;
+        PUT(cv_loc, cvl);
+    }
     D.n_pair = (int)B.pair.size();
     PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
     {
@@ -1539,7 +1548,7 @@ struct Launcher {
             S.e[0] = D.n_lmb; S.e[1] = S.e[0] + nb((size_t)D.n_cle * 16, 256);
             S.e[2] = S.e[1]; S.e[3] = S.e[2] + nb(D.n_sc, 256);                                 // (J D^-2 g of the projections rides in segment 0)
             S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + D.n_prior;      // one workgroup per prior
-            if (D.n_win < b->n_cu) { if (S.e[5]) hipLaunchKernelGGL(k_post_chol<0>, dim3(S.e[5]), dim3(256), 0, st, D, O, S); }
+            if (D.n_win < b->n_cu && !b->post_split) { if (S.e[5]) hipLaunchKernelGGL(k_post_chol<0>, dim3(S.e[5]), dim3(256), 0, st, D, O, S); }
             else {
                 if (S.e[0]) hipLaunchKernelGGL(k_post_chol<1>, dim3(S.e[0]), dim3(256), 0, st, D, O, S);
                 if (S.e[5] > S.e[0]) hipLaunchKernelGGL(k_post_chol<2>, dim3(S.e[5] - S.e[0]), dim3(256), 0, st, D, O, S);

@@ -51,6 +51,12 @@ __device__ __forceinline__ double damp_diag(const DevOpt& O, double d, double* j
 // keep[0..5] = row 0, keep[6..11] = row 1 of Jp, keep[12..13] = r, keep[14..16] = row 0, keep[17..19] = row 1 of Jl (zero where the
 // block is constant) — for the per-frame sums of the fused evaluation kernel, and, with STORE = false (nothing written), for the
 // back-substitution pass, which re-derives an observation's Jacobian from its 56 B of inputs instead of re-reading 144 B
+// the arithmetic of one observation from its inputs in registers (P pose, E extrinsic, X landmark, (u0, u1) image point; jp / jl: the pose /
+// the landmark is variable) — d_eval_proj_at below loads them one dependent level after another; the back-substitution pass fetches
+// them together with everything else it needs
+template <bool JAC, bool STORE>
+__device__ __forceinline__ void proj_core(const DevBatch& B, int i, const WinRec& W, const double* P, const double* E, const double* X,
+                                          double u0, double u1, bool jp, bool jl, double* keep);
 template <bool JAC, bool STORE = true>
 __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double* keep) {
     int w = B.p_win[i];
@@ -65,6 +71,11 @@ __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double*
 #pragma unroll
     for (int k = 0; k < 7; k++) { P[k] = pose[k]; E[k] = ex[k]; }
     X[0] = lm[0]; X[1] = lm[1]; X[2] = lm[2];
+    proj_core<JAC, STORE>(B, i, W, P, E, X, B.p_uv[2 * i], B.p_uv[2 * i + 1], JAC && B.p_lpose[i] >= 0, JAC && B.p_llm[i] >= 0, keep);
+}
+template <bool JAC, bool STORE>
+__device__ __forceinline__ void proj_core(const DevBatch& B, int i, const WinRec& W, const double* P, const double* E, const double* X,
+                                          double u0, double u1, bool jp, bool jl, double* keep) {
     double Qj_inv[4], qic_inv[4], d[3], pts_imu[3], t[3], pc[3];
     qinv(P + 3, Qj_inv);
     qinv(E + 3, qic_inv);
@@ -73,8 +84,8 @@ __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double*
     t[0] = pts_imu[0] + W.pbg[0] - E[0]; t[1] = pts_imu[1] + W.pbg[1] - E[1]; t[2] = pts_imu[2] + W.pbg[2] - E[2];
     qrot(qic_inv, t, pc);
     double dep = pc[2], si = W.proj_sqrt_info;
-    double r0 = si * (pc[0] / dep - B.p_uv[2 * i]);
-    double r1 = si * (pc[1] / dep - B.p_uv[2 * i + 1]);
+    double r0 = si * (pc[0] / dep - u0);
+    double r1 = si * (pc[1] / dep - u1);
     // Cauchy: rho'' < 0 always => scale r and J by sqrt(rho'); block cost = 0.5 rho(s)
     double sr = 1.0, cost;
     double sq = r0 * r0 + r1 * r1;
@@ -89,7 +100,6 @@ __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double*
     int n = B.n_proj;
     if (STORE) { B.p_r[i] = r0 * sr; B.p_r[n + i] = r1 * sr; }
     if (keep) { keep[12] = r0 * sr; keep[13] = r1 * sr; }
-    bool jp = B.p_lpose[i] >= 0, jl = B.p_llm[i] >= 0;
     if (!jp && !jl) return;
     double Rj[9], ric[9], ricT[9], RjT[9], A[9];
     q2R(P + 3, Rj); q2R(E + 3, ric);

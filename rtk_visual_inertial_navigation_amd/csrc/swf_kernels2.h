@@ -1009,53 +1009,69 @@ __device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O,
     //   back-substitution  t = g_l - sum_o W_o^T y_pose(o),  W_o^T y = Jl_o^T (Jp_o y)   (W is not stored)
     //   Cauchy point       aux_o = |Jp_o v_pose + Jl_o v_l|^2,  v = D^-2 g            (the projection part of |J D^-2 g|^2)
     // The per-observation terms of t are staged in LDS and one lane per landmark adds its track in observation order.
+    // Loads by dependency level, each level issued as a whole (round 3 walked them one after the other — record -> window -> flags ->
+    // landmark -> offsets -> values, ~8 exposed round trips of ~1.2 us on the latency path): (1) the block record; (2) every index and
+    // constant that hangs off it (clamped addresses: unconditional loads); (3) the window's flags, the state values, y and D^-2 g at
+    // the pose; (4) D^-2 g at the landmark.
     const int4 rec = ((const int4*)B.lmb_rec)[bid];
     const int o0 = rec.x, cnt = rec.y, L0 = rec.z, nlm = rec.w, tid = threadIdx.x;
-    const WinState& s = B.ws[B.lm_win[L0]];
-    if (!s.need_lin) return;                                   // uniform: the block belongs to one window
     const int nl = B.n_lm, n = B.n_proj;
+    const int win = B.lm_win[L0];
+    const bool ho = tid < cnt, hl = tid < nlm;
+    const int o = ho ? o0 + tid : o0, L = hl ? L0 + tid : L0;
+    const int plm = B.p_lm[o], lp = B.p_lpose[o], xpo = B.p_xpose[o], xex = B.p_xex[o], xlm = B.p_xlm[o], pfr = B.p_fr[o], pll = B.p_llm[o];
+    const double u0 = B.p_uv[2 * o], u1 = B.p_uv[2 * o + 1];
+    const int lloc = B.lm_loc[L], lob = B.lm_obs0[L], loe = B.lm_obs0[L + 1];
+    const double g0 = B.lm_g[0 * nl + L], g1 = B.lm_g[1 * nl + L], g2 = B.lm_g[2 * nl + L];
+    const double e00 = B.lm_Einv[0 * nl + L], e10 = B.lm_Einv[1 * nl + L], e20 = B.lm_Einv[2 * nl + L];
+    const double e11 = B.lm_Einv[3 * nl + L], e21 = B.lm_Einv[4 * nl + L], e22 = B.lm_Einv[5 * nl + L];
+    const WinState& s = B.ws[win];
+    const WinRec& W = B.win[win];
+    const int need = s.need_lin, failed = s.lin_fail;
+    const int loc = B.lm_loc[plm];
+    double P[7], E[7], X[3], yp[6], vp[6];
+#pragma unroll
+    for (int k = 0; k < 7; k++) { P[k] = B.x[xpo + k]; E[k] = B.x[xex + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) X[k] = B.x[xlm + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { const int q = lp >= 0 ? lp + k : 0; yp[k] = B.y[q]; vp[k] = B.vc[q]; }
+    double vl0 = 0, vl1 = 0, vl2 = 0;
+    { const int q = loc >= 0 ? loc : 0; vl0 = B.vc[q]; vl1 = B.vc[q + 1]; vl2 = B.vc[q + 2]; }
+    if (loc < 0) { vl0 = 0; vl1 = 0; vl2 = 0; }
+    if (!need) return;                                         // uniform: the block belongs to one window
     double c0 = 0, c1 = 0, c2 = 0;
-    if (tid < cnt) {
-        const int o = o0 + tid;
-        const int loc = B.lm_loc[B.p_lm[o]];
-        double vl0 = 0, vl1 = 0, vl2 = 0;
-        if (loc >= 0) { vl0 = vec_at<0>(B, O, loc); vl1 = vec_at<0>(B, O, loc + 1); vl2 = vec_at<0>(B, O, loc + 2); }
-        int lp = B.p_lpose[o];
+    if (ho) {
         // the observation's Jacobian, re-derived at the linearisation point from its inputs (pose, extrinsic and landmark sit in cache
         // for the whole track; 16 B of image coordinates per observation) rather than read back: 144 B per observation less traffic
         double kj[20];
 #pragma unroll
         for (int k = 0; k < 20; k++) kj[k] = 0.0;
-        d_eval_proj_at<true, false>(B, o, kj);
+        proj_core<true, false>(B, o, W, P, E, X, u0, u1, lp >= 0, pll >= 0, kj);
         double jl0 = kj[14], jl1 = kj[15], jl2 = kj[16], jl3 = kj[17], jl4 = kj[18], jl5 = kj[19];
-        double u0 = 0, u1 = 0;                                     // Jp y
+        double w0 = 0, w1 = 0;                                     // Jp y
         double a0 = jl0 * vl0 + jl1 * vl1 + jl2 * vl2, a1 = jl3 * vl0 + jl4 * vl1 + jl5 * vl2;   // J v
         if (lp >= 0) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 double ja = kj[i], jb = kj[6 + i];
-                double yv = B.y[lp + i], vv = vec_at<0>(B, O, lp + i);
-                u0 += ja * yv; u1 += jb * yv;
-                a0 += ja * vv; a1 += jb * vv;
+                w0 += ja * yp[i]; w1 += jb * yp[i];
+                a0 += ja * vp[i]; a1 += jb * vp[i];
             }
         }
         B.p_aux[o] = a0 * a0 + a1 * a1;
-        if (B.p_fr[o] >= 0) { c0 = -(jl0 * u0 + jl3 * u1); c1 = -(jl1 * u0 + jl4 * u1); c2 = -(jl2 * u0 + jl5 * u1); }
+        if (pfr >= 0) { c0 = -(jl0 * w0 + jl3 * w1); c1 = -(jl1 * w0 + jl4 * w1); c2 = -(jl2 * w0 + jl5 * w1); }
     }
+    (void)n;
     sc[0][tid] = c0; sc[1][tid] = c1; sc[2][tid] = c2;
     __syncthreads();
-    if (tid >= nlm || s.lin_fail) return;
-    const int L = L0 + tid, loc = B.lm_loc[L];
-    if (loc < 0) return;
-    double g0 = B.lm_g[0 * nl + L], g1 = B.lm_g[1 * nl + L], g2 = B.lm_g[2 * nl + L];
-    double e00 = B.lm_Einv[0 * nl + L], e10 = B.lm_Einv[1 * nl + L], e20 = B.lm_Einv[2 * nl + L];
-    double e11 = B.lm_Einv[3 * nl + L], e21 = B.lm_Einv[4 * nl + L], e22 = B.lm_Einv[5 * nl + L];
+    if (!hl || failed || lloc < 0) return;
     double t0 = 0, t1 = 0, t2 = 0;
-    for (int q = B.lm_obs0[L] - o0, qe = B.lm_obs0[L + 1] - o0; q < qe; q++) { t0 += sc[0][q]; t1 += sc[1][q]; t2 += sc[2][q]; }
+    for (int q = lob - o0, qe = loe - o0; q < qe; q++) { t0 += sc[0][q]; t1 += sc[1][q]; t2 += sc[2][q]; }
     t0 += g0; t1 += g1; t2 += g2;
-    B.y[loc] = e00 * t0 + e10 * t1 + e20 * t2;
-    B.y[loc + 1] = e10 * t0 + e11 * t1 + e21 * t2;
-    B.y[loc + 2] = e20 * t0 + e21 * t1 + e22 * t2;
+    B.y[lloc] = e00 * t0 + e10 * t1 + e20 * t2;
+    B.y[lloc + 1] = e10 * t0 + e11 * t1 + e21 * t2;
+    B.y[lloc + 2] = e20 * t0 + e21 * t1 + e22 * t2;
 }
 __device__ __forceinline__ void d_backsub_clique(const DevBatch& B, int bid) {
     // 16 lanes per clique with an eliminated block (d_e <= 9).  The strip product M_ef y_f is split by column over the
@@ -1073,32 +1089,14 @@ __device__ __forceinline__ void d_backsub_clique(const DevBatch& B, int bid) {
     double part[9];
 #pragma unroll
     for (int a = 0; a < 9; a++) part[a] = 0;
-    // member records are fetched lane-parallel (16 per round) and searched with shuffles: a lane's column -> reduced
-    // index lookup costs one load level whatever the member count.  Uniform control flow (all 64 lanes shuffle).
-    const int nm = act ? C.mem1 - C.mem0 : 0, g0 = lane & ~15;
-    int nmx = nm;                                            // the wave iterates to its largest member / column count
+    // column c of the strip -> local index of its variable: host-built table at the clique's vector slot (cv_loc[v_off + c]; round 3
+    // searched the member records with 16-wide shuffles per column chunk — 12 us of the latency path's back-substitution launch were this
+    // loop).  Same products in the same order (a lane's columns ascending).
+    const int* cl = B.cv_loc + C.v_off;
+    for (int c = sub; c < (act ? df : 0); c += 16) {
+        const double yv = B.y[cl[c]];
 #pragma unroll
-    for (int o = 16; o < 64; o <<= 1) { int t = __shfl_xor(nmx, o, 64); nmx = t > nmx ? t : nmx; }
-    int dfx = act ? df : 0;
-#pragma unroll
-    for (int o = 16; o < 64; o <<= 1) { int t = __shfl_xor(dfx, o, 64); dfx = t > dfx ? t : dfx; }
-    for (int c0 = 0; c0 < dfx; c0 += 16) {
-        const int c = c0 + sub;
-        int cc = 0, lo = 0;                                  // member holding column c: the last one with cm_col <= c
-        for (int m0 = 0; m0 < nmx; m0 += 16) {
-            bool have = m0 + sub < nm;
-            int mc = have ? B.cm_col[C.mem0 + m0 + sub] : 0x7fffffff, ml = have ? B.cm_loc[C.mem0 + m0 + sub] : 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                int kc = __shfl(mc, g0 + k, 64), kl = __shfl(ml, g0 + k, 64);
-                if (kc <= c) { cc = kc; lo = kl; }
-            }
-        }
-        if (act && c < df) {
-            double yv = B.y[lo + c - cc];
-#pragma unroll
-            for (int a = 0; a < 9; a++) if (a < de) part[a] += M[a * df + c] * yv;
-        }
+        for (int a = 0; a < 9; a++) if (a < de) part[a] += M[a * df + c] * yv;
     }
     double t = 0;
 #pragma unroll
@@ -1150,6 +1148,9 @@ __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S)
     __shared__ double sm_pv[PART == 1 ? 1 : PRB_MAX]; __shared__ int sm_pl[PART == 1 ? 1 : PRB_MAX]; __shared__ double sm_pw[4];
     if (PART != 2 && bid < S.e[0]) { d_backsub_lm(B, O, bid, sm_bs); return; }   // also the projection part of |J D^-2 g|^2
     if (PART == 1) return;
+#ifdef SWF_DEBUG_POST_SKIP        // timing experiments only (tools/prof/post_segments.sh): leave segments out to see which one a launch waits for
+    { const int sg = bid < S.e[1] ? 1 : bid < S.e[3] ? 2 : bid < S.e[4] ? 4 : 8; if (SWF_DEBUG_POST_SKIP & sg) return; }
+#endif
     if (bid < S.e[1]) d_backsub_clique(B, bid - S.e[0]);
     else if (bid < S.e[3]) d_jtimes_scalar<0>(B, O, bid - S.e[2]);
     else if (bid < S.e[4]) d_jtimes_imu<0>(B, O, bid - S.e[3]);
@@ -1299,37 +1300,84 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     int n = W.n_loc;
     const bool want_gmax = fresh && !s.lin_fail;
     // one pass, one barrier pair: cost, |J D^-2 g|^2, gradient max-norm (fresh linearisation only) and the scalars of the
-    // scaled problem |g/d|^2, |d y|^2, (g/d).(-d y)
+    // scaled problem |g/d|^2, |d y|^2, (g/d).(-d y).
+    // EVERY load of the kernel is issued here, before the first value is used: the first PU / GU / DU strided elements per thread of the
+    // cost arrays and of g, diag, y, loc2x stay in registers (a cfg3 window: all of them) and serve the step pass below as well, which
+    // then touches no memory but its stores.  Two exposed round trips (the tables, then x through loc2x) instead of eight.
     double v[6] = { 0, 0, 0, 0, 0, 0 };
+    constexpr int PU = 12, GU = 4, DU = 16;
     DST(0);
-    // the pose blocks (the window's first blocks; constant ones have no local dimensions): a thread each, its loads issued ahead of the flat passes
+    // the pose blocks (the window's first blocks; constant ones have no local dimensions): a thread each
     int p_lo = -1, p_xo = 0;
     if (tid < W.n_pose_blk) { p_lo = B.blk_loc[W.blk_base + tid]; p_xo = B.blk_xoff[W.blk_base + tid]; }
-    if (fresh) win_cost_aux_part(B, W, v[0], v[1]);
-    DST(1);
-    double xp[7] = { 0, 0, 0, 0, 0, 0, 1 };
+    double cvp[PU], avp[PU], cvg[GU], avg[GU], gv[DU], yv[DU], dgv[DU], xv[DU];
+    int lxv[DU];
+#pragma unroll
+    for (int u = 0; u < PU; u++) { int i = W.proj0 + tid + u * CTL_NT; bool ok = fresh && i < W.proj1; cvp[u] = ok ? B.p_cost[i] : 0.0; avp[u] = ok ? B.p_aux[i] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < GU; u++) { int i = W.gf0 + tid + u * CTL_NT; bool ok = fresh && i < W.gf1; cvg[u] = ok ? B.g_cost[i] : 0.0; avg[u] = ok ? B.g_aux[i] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < DU; u++) { int i = tid + u * CTL_NT; bool ok = i < n; gv[u] = ok ? g[i] : 0.0; yv[u] = ok ? y[i] : 0.0; dgv[u] = ok ? dg[i] : 1.0; lxv[u] = ok ? l2x[i] : -1; }
+    double xp[7] = { 0, 0, 0, 0, 0, 0, 1 }, pg[6] = { 0, 0, 0, 0, 0, 0 }, pd[6] = { 1, 1, 1, 1, 1, 1 }, py[6] = { 0, 0, 0, 0, 0, 0 };
     if (p_lo >= 0) {
 #pragma unroll
         for (int k = 0; k < 7; k++) xp[k] = B.x[p_xo + k];
-        if (want_gmax) {
-            // gradient_max_norm = || x - Plus(x, -g) ||_inf (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-            double d[6], o[7];
 #pragma unroll
-            for (int k = 0; k < 6; k++) d[k] = -B.g[p_lo + k];
-            pose_plus(xp, d, o);
+        for (int k = 0; k < 6; k++) { pg[k] = B.g[p_lo + k]; pd[k] = B.diag[p_lo + k]; py[k] = B.y[p_lo + k]; }
+    }
 #pragma unroll
-            for (int k = 0; k < 7; k++) { double q = fabs(xp[k] - o[k]); v[5] = q > v[5] ? q : v[5]; }
+    for (int u = 0; u < DU; u++) xv[u] = lxv[u] >= 0 ? B.x[lxv[u]] : 0.0;
+    if (fresh) {
+        // (the sums in the order of win_cost_aux_part: index order per thread, projection factors first)
+#pragma unroll
+        for (int u = 0; u < PU; u++) { v[0] += cvp[u]; v[1] += avp[u]; }
+        for (int base = W.proj0 + tid + PU * CTL_NT; base < W.proj1; base += PU * CTL_NT) {
+            double cv[PU], av[PU];
+#pragma unroll
+            for (int u = 0; u < PU; u++) { int i = base + u * CTL_NT; bool ok = i < W.proj1; cv[u] = ok ? B.p_cost[i] : 0.0; av[u] = ok ? B.p_aux[i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < PU; u++) { v[0] += cv[u]; v[1] += av[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; u++) { v[0] += cvg[u]; v[1] += avg[u]; }
+        for (int base = W.gf0 + tid + GU * CTL_NT; base < W.gf1; base += GU * CTL_NT) {
+            double cv[GU], av[GU];
+#pragma unroll
+            for (int u = 0; u < GU; u++) { int i = base + u * CTL_NT; bool ok = i < W.gf1; cv[u] = ok ? B.g_cost[i] : 0.0; av[u] = ok ? B.g_aux[i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < GU; u++) { v[0] += cv[u]; v[1] += av[u]; }
         }
     }
+    DST(1);
+    if (p_lo >= 0 && want_gmax) {
+        // gradient_max_norm = || x - Plus(x, -g) ||_inf (TrustRegionMinimizer::EvaluateGradientAndJacobian)
+        double d[6], o[7];
+#pragma unroll
+        for (int k = 0; k < 6; k++) d[k] = -pg[k];
+        pose_plus(xp, d, o);
+#pragma unroll
+        for (int k = 0; k < 7; k++) { double q = fabs(xp[k] - o[k]); v[5] = q > v[5] ? q : v[5]; }
+    }
     DST(2);
-#pragma unroll 4
-    for (int i = tid; i < n; i += blockDim.x) {
+#pragma unroll
+    for (int u = 0; u < DU; u++) {
+        const int i = tid + u * CTL_NT;
+        if (i < n) {
+            double gi = gv[u], yi = yv[u];
+            double dc = damp_diag(O, dgv[u], B.jsc + W.loc_base + i, false);      // (the damping diagonal: with Jacobi scaling, LM's effective one)
+            double ir = rsqrt_nr(dc);                     // 1 / sqrt(d): no IEEE sqrt / division expansions in these loops
+            double gs = gi * ir;
+            v[2] += gs * gs; v[3] += dc * yi * yi; v[4] += -gi * yi;
+            if (want_gmax && lxv[u] >= 0) { double q = fabs(gi); v[5] = q > v[5] ? q : v[5]; }       // (Plus of a vector block is x + delta)
+        }
+    }
+    for (int i = tid + DU * CTL_NT; i < n; i += CTL_NT) {       // windows of more than DU * 256 local dimensions
         double gi = g[i], yi = y[i];
-        double dc = damp_diag(O, dg[i], B.jsc + W.loc_base + i, false);      // (the damping diagonal: with Jacobi scaling, LM's effective one)
-        double ir = rsqrt_nr(dc);                     // 1 / sqrt(d): no IEEE sqrt / division expansions in these loops
+        double dc = damp_diag(O, dg[i], B.jsc + W.loc_base + i, false);
+        double ir = rsqrt_nr(dc);
         double gs = gi * ir;
         v[2] += gs * gs; v[3] += dc * yi * yi; v[4] += -gi * yi;
-        if (want_gmax && l2x[i] >= 0) { double q = fabs(gi); v[5] = q > v[5] ? q : v[5]; }       // (Plus of a vector block is x + delta)
+        if (want_gmax && l2x[i] >= 0) { double q = fabs(gi); v[5] = q > v[5] ? q : v[5]; }
     }
     DST(3);
     block_reduce<5, 1>(v, red);
@@ -1404,29 +1452,41 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
         const double sHs = c1 * c1 * jg_sq + 2.0 * c1 * c2 * (gsq - mu * gy) + c2 * c2 * (gy - mu * ynn);
         s.model_cost_change = -(c1 * gsq + c2 * gy + 0.5 * sHs);
     }
-    // the step and the candidate = Plus(x, step) in one pass over the local dimensions; the pose threads form their six step entries from the
-    // same operands (the same bits as step[]) and apply PoseLocalParameterization::Plus
+    // the step and the candidate = Plus(x, step) in one pass over the local dimensions, from the registers of the pass above; the pose
+    // threads form their six step entries from the same operands (the same bits as step[]) and apply PoseLocalParameterization::Plus
     double a_s = 0, a_n = 0;
-#pragma unroll 4
-    for (int i = tid; i < n; i += blockDim.x) {
+#pragma unroll
+    for (int u = 0; u < DU; u++) {
+        const int i = tid + u * CTL_NT;
+        if (i < n) {
+            double dc = clampd(dgv[u], O.min_diag, O.max_diag);
+            double ir = rsqrt_nr(dc);
+            // scaled step c1 g / sqrt(d) + c2 sqrt(d) y, then un-scaled (/ sqrt(d))
+            double sc = c1 * (gv[u] * ir) + c2 * (dc * ir * yv[u]);
+            a_s += sc * sc;
+            const double st = sc * ir;
+            step[i] = st;
+            if (lxv[u] >= 0) { const double x0 = xv[u], xn = x0 + st; B.xc[lxv[u]] = xn; const double dv = x0 - xn; a_n += dv * dv; }
+        }
+    }
+    for (int i = tid + DU * CTL_NT; i < n; i += CTL_NT) {
         const int a = l2x[i];
         double dc = clampd(dg[i], O.min_diag, O.max_diag);
         double ir = rsqrt_nr(dc);
-        // scaled step c1 g / sqrt(d) + c2 sqrt(d) y, then un-scaled (/ sqrt(d))
         double sc = c1 * (g[i] * ir) + c2 * (dc * ir * y[i]);
         a_s += sc * sc;
         const double st = sc * ir;
         step[i] = st;
-        if (a >= 0) { const double x0 = B.x[a], xv = x0 + st; B.xc[a] = xv; const double dv = x0 - xv; a_n += dv * dv; }
+        if (a >= 0) { const double x0 = B.x[a], xn = x0 + st; B.xc[a] = xn; const double dv = x0 - xn; a_n += dv * dv; }
     }
     DST(6);
     if (p_lo >= 0) {
         double d[6], o[7];
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            double dc = clampd(B.diag[p_lo + k], O.min_diag, O.max_diag);
+            double dc = clampd(pd[k], O.min_diag, O.max_diag);
             double ir = rsqrt_nr(dc);
-            double sc = c1 * (B.g[p_lo + k] * ir) + c2 * (dc * ir * B.y[p_lo + k]);
+            double sc = c1 * (pg[k] * ir) + c2 * (dc * ir * py[k]);
             d[k] = sc * ir;
         }
         pose_plus(xp, d, o);
@@ -1452,20 +1512,34 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
     if (s.status != SWF_RUNNING || !s.eval_cand) return;
     const WinRec& W = B.win[w];
     double ca[2] = { 0.0, 0.0 };
+    // every load up front, as in k_dogleg: the candidate costs, and — speculatively — the candidate itself with the flags of its
+    // coordinates (the first XU strided coordinates per thread: a cfg3 window's 1447 are all of them), so that an accepted step is stored
+    // from registers
+    constexpr int U = 12, XU = 8;
+    double cvp[U], cvg[4], xcv[XU]; unsigned char xfl[XU];
+#pragma unroll
+    for (int u = 0; u < U; u++) { int i = W.proj0 + tid + u * CTL_NT; cvp[u] = i < W.proj1 ? B.p_cost[i] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { int i = W.gf0 + tid + u * CTL_NT; cvg[u] = i < W.gf1 ? B.g_cost[i] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < XU; u++) { int i = W.x_base + tid + u * CTL_NT; bool ok = i < W.x_base + W.x_n; xcv[u] = ok ? B.xc[i] : 0.0; xfl[u] = ok ? B.x_var[i] : (unsigned char)0; }
     {
         // candidate cost: the same guarded load groups and index-ordered additions as win_cost_aux_part, costs only
-        constexpr int U = 12;
-        for (int base = W.proj0 + threadIdx.x; base < W.proj1; base += U * blockDim.x) {
+#pragma unroll
+        for (int u = 0; u < U; u++) ca[0] += cvp[u];
+        for (int base = W.proj0 + tid + U * CTL_NT; base < W.proj1; base += U * CTL_NT) {
             double cv[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) { int i = base + u * blockDim.x; cv[u] = i < W.proj1 ? B.p_cost[i] : 0.0; }
+            for (int u = 0; u < U; u++) { int i = base + u * CTL_NT; cv[u] = i < W.proj1 ? B.p_cost[i] : 0.0; }
 #pragma unroll
             for (int u = 0; u < U; u++) ca[0] += cv[u];
         }
-        for (int base = W.gf0 + threadIdx.x; base < W.gf1; base += 4 * blockDim.x) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) ca[0] += cvg[u];
+        for (int base = W.gf0 + tid + 4 * CTL_NT; base < W.gf1; base += 4 * CTL_NT) {
             double cv[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { int i = base + u * blockDim.x; cv[u] = i < W.gf1 ? B.g_cost[i] : 0.0; }
+            for (int u = 0; u < 4; u++) { int i = base + u * CTL_NT; cv[u] = i < W.gf1 ? B.g_cost[i] : 0.0; }
 #pragma unroll
             for (int u = 0; u < 4; u++) ca[0] += cv[u];
         }
@@ -1528,7 +1602,9 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
     if (accept) {
         // x <- candidate and || x || over the variable blocks in one pass (x_var: host-built flag per ambient coordinate)
         double a = 0;
-        for (int i = W.x_base + tid; i < W.x_base + W.x_n; i += blockDim.x) { const double xv = B.xc[i]; B.x[i] = xv; if (B.x_var[i]) a += xv * xv; }
+#pragma unroll
+        for (int u = 0; u < XU; u++) { int i = W.x_base + tid + u * CTL_NT; if (i < W.x_base + W.x_n) { B.x[i] = xcv[u]; if (xfl[u]) a += xcv[u] * xcv[u]; } }
+        for (int i = W.x_base + tid + XU * CTL_NT; i < W.x_base + W.x_n; i += CTL_NT) { const double xv = B.xc[i]; B.x[i] = xv; if (B.x_var[i]) a += xv * xv; }
         const double xn = sqrt(block_sum(a, red));
         if (tid == 0) s.x_norm = xn;
     }
