@@ -142,7 +142,7 @@ struct DevBatch {
     double* lmq;                               // landmark part of the reduced rhs, sum_l Y_l g_l per pose row: GEMM_SPLIT partial vectors of 6 nF per window (at 6 fr_base GEMM_SPLIT)
     const int* lmb_rec; int n_lmb;             // landmark back-substitution blocks: {first observation, observations (<= 256), first landmark, landmarks}, whole landmarks of one window
     const int* sch_c0; const int* sch_rec;     // k_lm_schur chunk table: chunks of block (window, split); 8-int record per (chunk, group)
-    const int* sch_km;                         // k_lm_schur tile masks: word (chunk, launch, consumer wave) = 4 bits per tile slot of the wave, bit g = column group g is needed
+    const int* sch_km;                         // k_lm_schur tile masks: word (chunk, launch, consumer wave) = 3 TW bits per tile slot of the wave, bit 3 g + j = k-step j of wave task g is needed
     const unsigned long long* lm_fmask;        // frames (slots < 64) each landmark is observed in
     // frames
     int n_fr;

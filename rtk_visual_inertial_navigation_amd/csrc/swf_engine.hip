@@ -232,6 +232,7 @@ struct swf_batch {
         if (aux) { (void)hipStreamSynchronize(aux); handle_cache().give(aux); }
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
+    bool post_fuse = false;               // SWF_POST_FUSE=1: the one-grid forms of k_post_chol / k_post_dogleg at every batch size (A/B timing)
     bool post_split = false;              // SWF_POST_SPLIT=1: the landmark segment of k_post_chol apart from the others whatever the batch size (A/B timing)
     bool lat_fuse = false;                // latency path: fused grids on one stream (see swf_batch_create)
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
@@ -845,6 +846,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->export_L_always = getenv("SWF_EXPORT_L") != nullptr;
     b->asm_old = getenv("SWF_ASM_OLD") != nullptr;
     b->post_split = getenv("SWF_POST_SPLIT") != nullptr;
+    b->post_fuse = getenv("SWF_POST_FUSE") != nullptr;
     b->fs_fused = getenv("SWF_FS_SEPARATE") == nullptr;
     // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
     // fills what one-block-per-window kernels leave idle (measured: 256 windows 5.52 -> 5.22 ms, 128 windows 3.73 -> 3.49 ms per solve; 64 and
@@ -853,7 +855,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     // scalar factors, every clique size class in one launch) on ONE stream.  Round 3 ran the IMU / clique branch of such batches on the
     // auxiliary stream instead; the kernel trace shows what that buys: every cross-queue edge (event record -> stream wait) costs 6-13 us
     // of dependency resolution, as much as the overlap saves (one window: 1.432 ms with the auxiliary stream, 1.443 without).
-    b->lat_fuse = n * 8 <= b->n_cu && !getenv("SWF_NO_LAT_FUSE");
+    { const char* lm = getenv("SWF_LAT_FUSE_MAX"); b->lat_fuse = (lm ? n <= atoi(lm) : n * 8 <= b->n_cu) && !getenv("SWF_NO_LAT_FUSE"); }
     if ((((n * 16 <= b->n_cu && !b->lat_fuse) || (2 * n >= b->n_cu && n <= b->n_cu)) || getenv("SWF_AUX_STREAM_ALWAYS")) && !getenv("SWF_NO_AUX_STREAM")) {            // fork / join inside a linearisation
         bool ok = (b->aux = handle_cache().stream()) != nullptr;
         for (int i = 0; i < 3 && ok; i++) ok = (b->ev_fork[i] = handle_cache().event(false)) != nullptr;
@@ -923,7 +925,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         // (task, group): L (-1 = empty), loc, first / end observation of the landmark, first column within the task (0, 3, 6, 9).  The window's landmarks
         // enter in the order of their tile footprint (last, first 16-row tile of the reduced camera matrix they touch), so the landmarks of a
         // task mostly share theirs; bit g of the tile mask of (chunk, tile) — some landmark of the chunk's wave task g is seen from the tile's
-        // row frames and from its column frames — is what the consumer waves walk (a chunk = TW tasks, by size class; the packing into tasks
+        // row frames and from its column frames, per k-step of the task since round 4 (three bits per task: a tile skips the k-steps none of
+        // whose landmarks touch it) — is what the consumer waves walk (a chunk = TW tasks, by size class; the packing into tasks
         // and the parts, which end on even task numbers, are the same in every class: so is every sum).  Tile list of a window: the nt
         // diagonal tiles, then (tr > tc) row by row.
         const int TW = b->ls_var <= 1 ? 2 : 1;
@@ -958,13 +961,15 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
                 if (lw >= 4) new_task();
                 int* r = &rec[at + (size_t)lw * 8];                 // group lw of the task = this landmark, whatever its track length
                 r[0] = l; r[1] = B.lm_loc[l]; r[2] = o0; r[3] = o0 + k; r[4] = 3 * lw; r[5] = 0; r[6] = 0; r[7] = 0;
-                // tile-list entries this landmark touches
+                // tile-list entries this landmark touches, as the k-steps of the task that carry its three columns (columns 3 lw .. 3 lw + 2 of
+                // the task's twelve; a k-step = four columns): group 0 -> k-step 0, group 1 -> 0 and 1, group 2 -> 1 and 2, group 3 -> 2
                 unsigned t = trs[(size_t)(l - W.lm0)];
+                const unsigned ks = lw == 0 ? 1u : lw == 1 ? 3u : lw == 2 ? 6u : 4u;
                 std::vector<unsigned>& tt = task_tiles.back();
                 for (int tr = 0; tr < nt; tr++) {
                     if (!((t >> tr) & 1u)) continue;
-                    tt[(size_t)tr] = 1u;
-                    for (int tc = 0; tc < tr; tc++) if ((t >> tc) & 1u) tt[(size_t)(nt + tr * (tr - 1) / 2 + tc)] = 1u;
+                    tt[(size_t)tr] |= ks;
+                    for (int tc = 0; tc < tr; tc++) if ((t >> tc) & 1u) tt[(size_t)(nt + tr * (tr - 1) / 2 + tc)] |= ks;
                 }
                 lw++;
             }
@@ -976,9 +981,9 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
                 for (int g = 0; g < TW; g++) {
                     const std::vector<unsigned>& tt = task_tiles[(size_t)(c * TW + g)];
                     for (int e = 0; e < ntl; e++) if (tt[(size_t)e]) {
-                        b->lm_schur_mfma += 3;
+                        b->lm_schur_mfma += __builtin_popcount(tt[(size_t)e]);
                         int lp = e / (NCW * TPW), r = e % (NCW * TPW), sl = r / NCW, cw = r % NCW;
-                        km[kw + (size_t)(lp * NCW + cw)] |= (1 << g) << (4 * sl);
+                        km[kw + (size_t)(lp * NCW + cw)] |= (tt[(size_t)e] << (3 * g)) << (3 * TW * sl);
                     }
                 }
             }
@@ -1548,7 +1553,7 @@ struct Launcher {
             S.e[0] = D.n_lmb; S.e[1] = S.e[0] + nb((size_t)D.n_cle * 16, 256);
             S.e[2] = S.e[1]; S.e[3] = S.e[2] + nb(D.n_sc, 256);                                 // (J D^-2 g of the projections rides in segment 0)
             S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + D.n_prior;      // one workgroup per prior
-            if (D.n_win < b->n_cu && !b->post_split) { if (S.e[5]) hipLaunchKernelGGL(k_post_chol<0>, dim3(S.e[5]), dim3(256), 0, st, D, O, S); }
+            if ((D.n_win < b->n_cu || b->post_fuse) && !b->post_split) { if (S.e[5]) hipLaunchKernelGGL(k_post_chol<0>, dim3(S.e[5]), dim3(256), 0, st, D, O, S); }
             else {
                 if (S.e[0]) hipLaunchKernelGGL(k_post_chol<1>, dim3(S.e[0]), dim3(256), 0, st, D, O, S);
                 if (S.e[5] > S.e[0]) hipLaunchKernelGGL(k_post_chol<2>, dim3(S.e[5] - S.e[0]), dim3(256), 0, st, D, O, S);
@@ -1565,7 +1570,7 @@ struct Launcher {
             S.e[2] = S.e[1] + (b->max_prior_dim <= PRIOR_LDS_DIM ? D.n_prior : 0);
             // small batches (latency path): the candidate IMU residuals ride along as a segment; large batches keep them in
             // their own launch (the segment's LDS would cost the memory-bound segments occupancy).  Same results either way.
-            bool fuse_imu = D.n_win < b->n_cu;
+            bool fuse_imu = D.n_win < b->n_cu || b->post_fuse;
             S.e[3] = S.e[2] + (fuse_imu ? nb(D.n_imu, IMU_FPB) : 0);
             if (S.e[3] && fuse_imu) hipLaunchKernelGGL((k_post_dogleg<true, 0>), dim3(S.e[3]), dim3(256), 0, st, D, O, S);
             else if (S.e[3]) {

@@ -164,7 +164,9 @@ __device__ __forceinline__ void d_lm_schur(const DevBatch& B, const DevOpt& O, i
             const unsigned hbo = hoff + (unsigned)buf * (unsigned)(NCOL * 8);
 #pragma unroll
             for (int sl = 0; sl < TPW; sl++) {
-                const unsigned mg = (wm >> (4 * sl)) & 15u;
+                // 3 NG bits per slot: bit 3 g + j = k-step j of wave task g carries a landmark this tile needs (round 3 kept one bit per
+                // task; a k-step whose landmarks do not touch the tile multiplies zeros)
+                const unsigned mg = (wm >> (3 * NG * sl)) & ((1u << (3 * NG)) - 1u);
                 if (!mg) continue;
                 const bool dg = sl < NDS && tile_base + cw + sl * NCW < nt;   // diagonal tile: B operand = A operand, and the q side product
                 const unsigned ao = aoff[sl] + pb, bo = boff[sl] + pb;
@@ -173,28 +175,29 @@ __device__ __forceinline__ void d_lm_schur(const DevBatch& B, const DevOpt& O, i
                     double q_ = qa[sl < NDS ? sl : 0];
 #pragma unroll
                     for (int g = 0; g < NG; g++) {
-                        if (!(mg & (1u << g))) continue;
+                        if (!(mg & (7u << (3 * g)))) continue;
+                        // (the task's operands are requested together; the mask decides which k-steps are multiplied)
                         double a0 = *(const double*)(lds + ao + (unsigned)((3 * g + 0) * KSB)), a1 = *(const double*)(lds + ao + (unsigned)((3 * g + 1) * KSB)),
                                a2 = *(const double*)(lds + ao + (unsigned)((3 * g + 2) * KSB));
                         double h0 = *(const double*)(lds + hbo + (unsigned)((3 * g + 0) * 32)), h1 = *(const double*)(lds + hbo + (unsigned)((3 * g + 1) * 32)),
                                h2 = *(const double*)(lds + hbo + (unsigned)((3 * g + 2) * 32));
-                        c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, c_, 0, 0, 0);
-                        q_ = __builtin_fma(a0, h0, q_); q_ = __builtin_fma(a1, h1, q_); q_ = __builtin_fma(a2, h2, q_);
+                        if (mg & (1u << (3 * g + 0))) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, c_, 0, 0, 0);
+                        if (mg & (1u << (3 * g + 1))) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, c_, 0, 0, 0);
+                        if (mg & (1u << (3 * g + 2))) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, c_, 0, 0, 0);
+                        q_ = __builtin_fma(a0, h0, q_); q_ = __builtin_fma(a1, h1, q_); q_ = __builtin_fma(a2, h2, q_);      // (a skipped k-step's rows are zero)
                     }
                     qa[sl < NDS ? sl : 0] = q_;
                 } else {
 #pragma unroll
                     for (int g = 0; g < NG; g++) {
-                        if (!(mg & (1u << g))) continue;
+                        if (!(mg & (7u << (3 * g)))) continue;
                         double a0 = *(const double*)(lds + ao + (unsigned)((3 * g + 0) * KSB)), a1 = *(const double*)(lds + ao + (unsigned)((3 * g + 1) * KSB)),
                                a2 = *(const double*)(lds + ao + (unsigned)((3 * g + 2) * KSB));
                         double b0 = *(const double*)(lds + bo + (unsigned)((3 * g + 0) * KSB)), b1 = *(const double*)(lds + bo + (unsigned)((3 * g + 1) * KSB)),
                                b2 = *(const double*)(lds + bo + (unsigned)((3 * g + 2) * KSB));
-                        c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c_, 0, 0, 0);
+                        if (mg & (1u << (3 * g + 0))) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c_, 0, 0, 0);
+                        if (mg & (1u << (3 * g + 1))) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c_, 0, 0, 0);
+                        if (mg & (1u << (3 * g + 2))) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c_, 0, 0, 0);
                     }
                 }
                 acc[sl] = c_;
