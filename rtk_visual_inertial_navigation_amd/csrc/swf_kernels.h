@@ -843,7 +843,7 @@ __device__ unsigned long long g_clq_stamps[16];
 // phases whose work is a set of independent output elements — the gather, the rows of M_e*, the 2x2 blocks of C — are dealt over
 // 4 waves; the Gauss-Jordan inverse and the columns of T stay on wave 0.  Every output element is still formed by ONE lane with the
 // same operands in the same order, so the two forms give the same bits (tested: a window alone vs inside a large batch).
-template <int MAXR, int MAXD, int MAXE, int CLS, int PF = 24, int NW = 1>
+template <int MAXR, int MAXD, int MAXE, int CLS, int PF = 24, int NW = 1, int UK = 4>      // UK: unrolling of the k loops (register budget)
 __device__ __forceinline__ void d_clique_elim(const DevBatch& B, const DevOpt& O, const int cidx_) {
     constexpr int LD = MAXD + 1, NT = 64 * NW;
     __shared__ double Jc[MAXR][LD];                 // dense clique Jacobian: rows = residual rows, cols = [e | members]
@@ -898,7 +898,7 @@ __device__ __forceinline__ void d_clique_elim(const DevBatch& B, const DevOpt& O
     {
         int c = lane < d ? lane : 0;
         if (NW == 1) {
-#pragma unroll 4
+#pragma unroll UK
             for (int k = 0; k < nrow; k++) {
                 double x = Jc[k][c];
                 gc += x * rv[k]; mcc += x * x;
@@ -907,7 +907,7 @@ __device__ __forceinline__ void d_clique_elim(const DevBatch& B, const DevOpt& O
             }
         } else {
             constexpr int RPW = (MAXE + NW - 1) / NW;                          // rows of M_e* per wave
-#pragma unroll 4
+#pragma unroll UK
             for (int k = 0; k < nrow; k++) {
                 double x = Jc[k][c];
                 if (wq == 0) { gc += x * rv[k]; mcc += x * x; }
@@ -976,19 +976,35 @@ __device__ __forceinline__ void d_clique_elim(const DevBatch& B, const DevOpt& O
         if (wq == 0) {
             double gE = 0;
             // g_e entries sit in lanes < d_e (gc): broadcast them
-            double tcol[MAXE];
             int j = lane < df ? lane : 0;
+            if (NW == 1) {
+                double tcol[MAXE];
 #pragma unroll
-            for (int a2 = 0; a2 < MAXE; a2++) {
-                double sv = 0, sg = 0;
+                for (int a2 = 0; a2 < MAXE; a2++) {
+                    double sv = 0, sg = 0;
 #pragma unroll
-                for (int b2 = 0; b2 < MAXE; b2++) { double ev = Ei[a2][b2]; sv += ev * Me[b2][de + j]; sg += ev * readlane_d(gc, b2); }
-                tcol[a2] = sv;
-                if (lane == a2) gE = sg;
-            }
-            if (lane < df) {
+                    for (int b2 = 0; b2 < MAXE; b2++) { double ev = Ei[a2][b2]; sv += ev * Me[b2][de + j]; sg += ev * readlane_d(gc, b2); }
+                    tcol[a2] = sv;
+                    if (lane == a2) gE = sg;
+                }
+                if (lane < df) {
 #pragma unroll
-                for (int a2 = 0; a2 < MAXE; a2++) T[a2][lane] = tcol[a2];
+                    for (int a2 = 0; a2 < MAXE; a2++) T[a2][lane] = tcol[a2];
+                }
+            } else {
+                // (latency form, 128-register cap: the column of M_ef and g_e once in registers, a row of Einv at a time — the same sums
+                // in the same order; the fully unrolled form above keeps all 81 entries of Einv in flight)
+                double mcol[MAXE], gb[MAXE];
+#pragma unroll
+                for (int b2 = 0; b2 < MAXE; b2++) { mcol[b2] = Me[b2][de + j]; gb[b2] = readlane_d(gc, b2); }
+#pragma unroll 1
+                for (int a2 = 0; a2 < MAXE; a2++) {
+                    double sv = 0, sg = 0;
+#pragma unroll
+                    for (int b2 = 0; b2 < MAXE; b2++) { double ev = Ei[a2][b2]; sv += ev * mcol[b2]; sg += ev * gb[b2]; }
+                    if (lane < df) T[a2][lane] = sv;
+                    if (lane == a2) gE = sg;
+                }
             }
             if (lane < de) Eg[lane] = gE;
         }
@@ -1039,7 +1055,7 @@ __device__ __forceinline__ void d_clique_elim(const DevBatch& B, const DevOpt& O
                 i0[u] = 2 * ba; j0[u] = 2 * bb; diag[u] = ba == bb;
             }
             double m[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-#pragma unroll 4
+#pragma unroll UK
             for (int k = 0; k < nrow; k++) {
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
@@ -1047,8 +1063,10 @@ __device__ __forceinline__ void d_clique_elim(const DevBatch& B, const DevOpt& O
                     m[u][0] += xa0 * xb0; m[u][1] += xa0 * xb1; m[u][2] += xa1 * xb0; m[u][3] += xa1 * xb1;
                 }
             }
-#pragma unroll
-            for (int a2 = 0; a2 < MAXE; a2++) {
+            // (the latency form lives under a 128-register cap inside k_lm_clique: its correction loop runs over the d_e live rows without
+            // unrolling — the rows beyond are zero, the terms they would add are exact zeros — instead of 72 operand loads in flight)
+#pragma unroll(NW > 1 ? 1 : MAXE)
+            for (int a2 = 0; a2 < (NW > 1 ? de : MAXE); a2++) {
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     double f0 = Me[a2][de + i0[u]], f1 = Me[a2][de + i0[u] + 1], t0_ = T[a2][j0[u]], t1_ = T[a2][j0[u] + 1];
@@ -1083,7 +1101,7 @@ __global__ void __launch_bounds__(LS_NT(NCW, TW)) k_lm_clique(DevBatch B, DevOpt
     if ((int)blockIdx.y < n_parts) d_lm_schur<NCW, TPW, TW, LDR, true>(B, O, qpb, lp, kms, s_direct, (int)blockIdx.x, (int)blockIdx.y);
     else {
         if (threadIdx.x >= 256) return;
-        d_clique_elim<64, 64, 9, 2, 8, 4>(B, O, ((int)blockIdx.y - n_parts) * (int)gridDim.x + (int)blockIdx.x);
+        d_clique_elim<64, 64, 9, 2, 8, 4, 4>(B, O, ((int)blockIdx.y - n_parts) * (int)gridDim.x + (int)blockIdx.x);
     }
 }
 
