@@ -364,6 +364,14 @@ inline bool UpdateSchurAndSetMarginalizeInfo(Problem* p, MarginalPrior* out, boo
     return rc == SWF_OK && rank >= 0;
 }
 
+// MarginalizationInfo::ResetLinearizationPoint (R/factor/marginalization_factor.cpp:232-258; R/swf/swf_core.cpp:636-637): shift the prior
+// (linearized_jacobians J, linearized_residuals r0, optionally the marginal system A, b) to the kept blocks' current values.  sizes = the
+// kept blocks' global sizes (7 = pose) in kept order, parameters[i] = block i's current values, x0 = keep_block_data concatenated.
+inline bool ResetLinearizationPoint(const std::vector<int32_t>& sizes, const std::vector<const double*>& parameters, int n,
+                                    const double* J, const double* A, double* r0, double* b, double* x0) {
+    return swf_prior_reset_linearization_point((int32_t)sizes.size(), sizes.data(), parameters.data(), n, J, A, r0, b, x0) == SWF_OK;
+}
+
 // SWFOptimization::UpdateSchurHessianOnly (R/swf/swf_gnss.cpp:65-94) after an optimising Solve: A = A3 A3^T over the
 // parameter_head states, plus the covariance Qy = A^-1 LambdaSearch computes from it (R/swf/swf_lambda.cpp:94-99).
 struct TailCovariance { const double* A = nullptr; const double* Qy = nullptr; int n = 0; };
