@@ -151,7 +151,7 @@ __device__ __forceinline__ void d_eval_proj(const DevBatch& B, int bid) {
 // =========================================================================================
 // part 0: residual + d/d pose_i;  1: d/d sb_i;  2: d/d pose_j;  3: d/d sb_j.  The parts run on different waves of the
 // block (they share only cheap prefixes), which cuts the lane-serial critical path of the kernel.
-__device__ void imu_unwhitened(const double* pi, const double* sbi, const double* pj, const double* sbj,
+__device__ __forceinline__ void imu_unwhitened(const double* pi, const double* sbi, const double* pj, const double* sbj,
                                const double* pre, const double* pbg, const double* gw,
                                double* raw, double* U, bool jac, int part) {
     const double* Pi = pi; const double* Qi = pi + 3;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void d_eval_imu(const DevBatch& B, int bid) {
 }
 
 template <bool JAC>
-__global__ void __launch_bounds__(IMU_FPB * IMU_LPF) k_eval_imu(DevBatch B) { d_eval_imu<JAC>(B, blockIdx.x); }
+__global__ void __launch_bounds__(IMU_FPB * IMU_LPF) __attribute__((amdgpu_waves_per_eu(4, 4))) k_eval_imu(DevBatch B) { d_eval_imu<JAC>(B, blockIdx.x); }
 
 // =========================================================================================
 // scalar factors, one lane each:
