@@ -1559,7 +1559,11 @@ struct Launcher {
                 if (S.e[5] > S.e[0]) hipLaunchKernelGGL(k_post_chol<2>, dim3(S.e[5] - S.e[0]), dim3(256), 0, st, D, O, S);
             }
         }
-        { Bracket t(*this, SWF_K_DOGLEG); hipLaunchKernelGGL(k_dogleg, dim3(D.n_win), dim3(CTL_NT), 0, st, D, O); }
+        {
+            Bracket t(*this, SWF_K_DOGLEG);
+            if (b->lat_fuse) hipLaunchKernelGGL((k_dogleg<16, 12, 4>), dim3(D.n_win), dim3(CTL_NT), 0, st, D, O);
+            else hipLaunchKernelGGL((k_dogleg<4, 4, 2>), dim3(D.n_win), dim3(CTL_NT), 0, st, D, O);
+        }
     }
     void cand_eval() {
         DevBatch& D = b->D;

@@ -847,9 +847,11 @@ template <int MAXR, int MAXD, int MAXE, int CLS, int PF = 24, int NW = 1, int UK
 __device__ __forceinline__ void d_clique_elim(const DevBatch& B, const DevOpt& O, const int cidx_) {
     constexpr int LD = MAXD + 1, NT = 64 * NW;
     __shared__ double Jc[MAXR][LD];                 // dense clique Jacobian: rows = residual rows, cols = [e | members]
-    __shared__ double Me[MAXE][LD];                 // M_e* = J_e^T J (rows of M that belong to e)
-    __shared__ double T[MAXE][LD];                  // Einv M_ef
-    __shared__ double Ei[MAXE][MAXE + 1];           // Einv
+    // (Me / T are walked along their rows by the lanes, Ei is read as broadcasts: no padding column — the 216 bytes put the speed-bias
+    // class at 20 448 B, eight cliques per CU instead of seven)
+    __shared__ double Me[MAXE][MAXD];               // M_e* = J_e^T J (rows of M that belong to e)
+    __shared__ double T[MAXE][MAXD];                // Einv M_ef
+    __shared__ double Ei[MAXE][MAXE];               // Einv
     __shared__ double rv[MAXR];
     __shared__ double Eg[MAXE];
     __shared__ double gcs[NW > 1 ? MAXD : 1];       // (NW > 1) g_c of every column, for the waves that do not hold it in registers
@@ -1031,7 +1033,7 @@ __device__ __forceinline__ void d_clique_elim(const DevBatch& B, const DevOpt& O
         if (wq == 0) {
             if (lane < df) B.cv_cs[C.v_off + lane] = 0.0;
 #pragma unroll
-            for (int a2 = 0; a2 < MAXE; a2++) T[a2][lane < LD ? lane : 0] = 0.0;
+            for (int a2 = 0; a2 < MAXE; a2++) T[a2][lane < MAXD ? lane : 0] = 0.0;
         }
         __syncthreads();
     }

@@ -1280,6 +1280,10 @@ __device__ unsigned long long g_dog_stamps[16];
 // coordinate of local dimension i (-1 for the six dimensions of a pose block, which a thread per pose block handles with Plus);
 // every load of a pass depends on nothing but the window record, so a pass is one round trip.  Constant blocks are never written:
 // xc holds their values since the upload (swf_batch_upload_state / _reset_state copy x to xc).
+// DU / PU / GU: strided elements per thread whose loads are issued up front and kept in registers (the latency path takes a cfg3 window
+// whole: 256 registers, one workgroup per CU; batches take a quarter and walk the rest in the loops behind — two workgroups per CU and
+// more: 512 windows 33.5 -> ? us).  The sums run in index order either way: same bits.
+template <int DU, int PU, int GU>
 __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     __shared__ double red[16 * 6];
     __shared__ int go;
@@ -1305,7 +1309,6 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     // cost arrays and of g, diag, y, loc2x stay in registers (a cfg3 window: all of them) and serve the step pass below as well, which
     // then touches no memory but its stores.  Two exposed round trips (the tables, then x through loc2x) instead of eight.
     double v[6] = { 0, 0, 0, 0, 0, 0 };
-    constexpr int PU = 12, GU = 4, DU = 16;
     DST(0);
     // the pose blocks (the window's first blocks; constant ones have no local dimensions): a thread each
     int p_lo = -1, p_xo = 0;
