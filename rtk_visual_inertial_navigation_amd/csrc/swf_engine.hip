@@ -1798,7 +1798,13 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
     // rank-revealing factor of A; every other window leaves this kernel at once
     const int force = getenv("SWF_FORCE_MARG_RESCUE") ? 1 : 0;      // testing aid: healthy windows through the rank-deficient path too
     if (form == SWF_PRIOR_EIGEN)
-        hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), 0, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok, force, eps);
+        {
+            // dynamic LDS: the 16-column panel over (n_red + 1) rows, later 16 rows of the tail + its diagonal + flags
+            const size_t l1 = (size_t)(b->max_red + 1) * (RS_NB + 1), l2 = (size_t)(RS_NB + 2) * (size_t)ldn;
+            const size_t lds = sizeof(double) * std::max(l1, l2);
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_marg_rescue, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      // (up to 92 KB at 640 dimensions)
+            hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), lds, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok, force, eps);
+        }
     hipLaunchKernelGGL(k_marginalize<false>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
                        b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, (double*)nullptr,
                        (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force, 0, (int*)nullptr);

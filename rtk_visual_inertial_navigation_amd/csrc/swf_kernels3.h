@@ -37,11 +37,21 @@
 // Cholesky that SKIPS a numerically null pivot (the column below it is null as well) computes it: a pivot <= max(eps, 1e-13 of
 // the block's largest diagonal entry) among the first m columns drops its column; a pivot below minus a thousand times that
 // (an indefinite matrix, or a NaN) is a real failure (rank -1).
-// One 1024-thread workgroup per window; this is the slow, rare path.
+// One 1024-thread workgroup per window.  Round 4: both halves are BLOCKED (16 columns / pivots at a time) — round 3 applied every
+// column and every pivot as a rank-one update of the whole trailing matrix in global memory (one CU streaming 1.5 MB 177 times, then
+// 0.55 MB 263 times: 9.1 ms at cfg5 size; the path is not rare there: 6 of 128 marginalisation windows took it):
+//   * the first m columns: the panel (rows below the block, 16 columns) is factored in LDS, null pivots dropping their columns as before,
+//     and applied to the trailing matrix once, as a rank-16 update;
+//   * the pivoted Cholesky of A is LAZY inside a block (LAPACK's dpstrf): the diagonal is kept up to date pivot by pivot (that is all the
+//     pivot choice needs), the row of a chosen pivot is formed from the untouched trailing matrix minus the block's earlier rows (in
+//     LDS), and the trailing matrix takes the block's 16 rows at once.
+// Same pivots, same drops, same stopping rule; the sums run in a different order (tolerances of the parity tests unchanged).
 // ---------------------------------------------------------------------------------------------------------------------
+#define RS_NB 16
 __global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tail_dim, int ldn, double* resM, double* resb, int* res_ok, int force, double eps) {
+    extern __shared__ double rs_lds[];                  // panel: (nr + 1) x 16 | later: block rows 16 x n, diagonal n, flags n
     __shared__ double red_v[16]; __shared__ int red_i[16];
-    __shared__ double piv_s; __shared__ int piv_i, stop_s;
+    __shared__ double piv_s, d0_s; __shared__ int piv_i, stop_s, bad_s;
     int w = blockIdx.x, tid = threadIdx.x;
     const WinRec& W = B.win[w];
     const WinState& s = B.ws[w];
@@ -58,29 +68,71 @@ __global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tai
         for (int j = tid; j < m; j += 1024) dm = fmax(dm, S[(size_t)j * nr + j]);
         dm = wave_max(dm);
         if ((tid & 63) == 0) red_v[tid >> 6] = dm;
+        if (tid == 0) bad_s = 0;
         __syncthreads();
         if (tid == 0) { double v = red_v[0]; for (int q = 1; q < 16; q++) v = fmax(v, red_v[q]); piv_s = v; }
     }
     __syncthreads();
     const double tol = fmax(eps, 1e-13 * piv_s);
     __syncthreads();
-    for (int j = 0; j < m; j++) {
-        double piv = Wk[(size_t)j * nr + j];             // uniform: every thread reads the same value
-        if (!(piv > tol)) {
-            if (!(piv >= -1e3 * tol)) return;            // indefinite (or NaN): a real failure
-            continue;                                    // a null direction of S_mm: the pseudo-inverse drops it (the column is never read again)
+    // ---- the first m columns, 16 at a time.  Panel P[r][c] = Wk[jb + r][jb + c], r = 0 .. nr - jb (the right-hand-side row included)
+    double (*P)[RS_NB + 1] = (double (*)[RS_NB + 1])rs_lds;
+    for (int jb = 0; jb < m; jb += RS_NB) {
+        const int wd = min(RS_NB, m - jb), rows = nr + 1 - jb;
+        // (columns beyond a short last block are zero: the rank-16 update below runs over all sixteen)
+        for (int e = tid; e < rows * RS_NB; e += 1024) { int r = e / RS_NB, c = e - r * RS_NB; P[r][c] = (c < wd && (r >= c || jb + r == nr)) ? Wk[(size_t)(jb + r) * nr + jb + c] : 0.0; }
+        __syncthreads();
+        for (int c = 0; c < wd; c++) {
+            const double piv = P[c][c];                    // uniform
+            if (!(piv > tol)) {
+                if (!(piv >= -1e3 * tol)) { if (tid == 0) bad_s = 1; }      // indefinite (or NaN): a real failure
+                // a null direction of S_mm: the pseudo-inverse drops it (its column takes no part in any update)
+                __syncthreads();
+                for (int r = tid; r < rows; r += 1024) P[r][c] = 0.0;
+                __syncthreads();
+                continue;
+            }
+            const double id = 1.0 / sqrt(piv);
+            __syncthreads();
+            for (int r = c + tid; r < rows; r += 1024) P[r][c] = r == c ? sqrt(piv) : P[r][c] * id;
+            __syncthreads();
+            // the rest of the panel: columns c' in (c, wd), rows r >= c'
+            const int rem = wd - 1 - c;
+            for (int e = tid; e < rem * rows; e += 1024) {
+                int cc = c + 1 + e / rows, r = e - (e / rows) * rows;
+                if (r >= cc) P[r][cc] -= P[r][c] * P[cc][c];
+            }
+            __syncthreads();
         }
-        double id = 1.0 / sqrt(piv);
-        __syncthreads();
-        for (int i = j + tid; i <= nr; i += 1024) Wk[(size_t)i * nr + j] = i == j ? sqrt(piv) : Wk[(size_t)i * nr + j] * id;
-        __syncthreads();
-        // trailing update of the lower triangle (and of the right-hand-side row): rows i in (j, nr], columns k in (j, min(i, nr - 1)]
-        const int rem = nr - j;                          // rows j+1 .. nr  ->  rem rows
-        for (long long t = tid; t < (long long)rem * (rem - 1 + 1); t += 1024) {
-            int ii = (int)(t / rem), kk = (int)(t - (long long)ii * rem);   // ii: 0..rem-1 -> row j+1+ii ; kk: 0..rem-1 -> column j+1+kk
-            int i = j + 1 + ii, k = j + 1 + kk;
-            if (k > i || k >= nr) continue;
-            Wk[(size_t)i * nr + k] -= Wk[(size_t)i * nr + j] * Wk[(size_t)k * nr + j];
+        if (bad_s) return;
+        // trailing update (lower triangle and the right-hand-side row): Wk[i][k] -= sum_c P[i][c] P[k][c], i in [jb + wd, nr], k in [jb + wd, min(i, nr - 1)]
+        {
+            const int t0 = jb + wd, nt = nr - t0;          // trailing columns t0 .. nr - 1 (nt of them), rows t0 .. nr
+            // a thread takes one row and every 32nd group of four columns: its row of the panel stays in registers
+            const int kg = (nt + 3) >> 2;                   // groups of four columns
+            for (int i = t0 + (tid >> 5); i <= nr; i += 32) {
+                double pi[RS_NB];
+#pragma unroll
+                for (int c = 0; c < RS_NB; c++) pi[c] = c < wd ? P[i - jb][c] : 0.0;
+                for (int g = tid & 31; g < kg; g += 32) {
+                    const int k0 = t0 + 4 * g;
+                    if (k0 > i) break;
+                    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+                    for (int c = 0; c < RS_NB; c++) {
+                        const double x = pi[c];
+                        a0 += x * P[k0 - jb][c];
+                        a1 += x * P[min(k0 + 1, nr) - jb][c];
+                        a2 += x * P[min(k0 + 2, nr) - jb][c];
+                        a3 += x * P[min(k0 + 3, nr) - jb][c];
+                    }
+                    double* row = Wk + (size_t)i * nr;
+                    if (k0 <= i && k0 < nr) row[k0] -= a0;
+                    if (k0 + 1 <= i && k0 + 1 < nr) row[k0 + 1] -= a1;
+                    if (k0 + 2 <= i && k0 + 2 < nr) row[k0 + 2] -= a2;
+                    if (k0 + 3 <= i && k0 + 3 < nr) row[k0 + 3] -= a3;
+                }
+            }
         }
         __syncthreads();
     }
@@ -89,35 +141,61 @@ __global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tai
     for (int e = tid; e < n * n; e += 1024) { int i = e / n, k = e - i * n; M[e] = i >= k ? Wk[(size_t)(m + i) * nr + m + k] : Wk[(size_t)(m + k) * nr + m + i]; }
     for (int i = tid; i < n; i += 1024) resb[(size_t)w * ldn + i] = Wk[(size_t)nr * nr + m + i];
     __syncthreads();
-    // pivoted outer-product Cholesky on M (full symmetric n x n); row r of the result goes to V = Wk (n x n, ld = n; Wk has
-    // (nr + 1) * nr >= n * n doubles since nr >= n)
+    // ---- pivoted Cholesky of A, 16 pivots at a time.  V = Wk (n x n, ld = n; Wk has (nr + 1) * nr >= n * n doubles): row r of the result.
+    // LDS: Vb[16][n] the block's rows | dg[n] the running diagonal | el[n] 1.0 for an eliminated index
     double* V = Wk;
+    double* Vb = rs_lds; double* dg = rs_lds + (size_t)RS_NB * n; double* el = dg + n;
     __syncthreads();
     for (int e = tid; e < n * n; e += 1024) V[e] = 0.0;
+    for (int i = tid; i < n; i += 1024) { dg[i] = M[(size_t)i * n + i]; el[i] = 0.0; }
     if (tid == 0) stop_s = 0;
     __syncthreads();
-    double d0 = 0;
-    for (int r = 0; r < n; r++) {
-        // arg max of the remaining diagonal (first index wins ties: deterministic)
-        double bv = -1.0; int bi = -1;
-        for (int i = tid; i < n; i += 1024) { double v = M[(size_t)i * n + i]; if (v > bv) { bv = v; bi = i; } }
-        for (int o = 32; o > 0; o >>= 1) { double ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64); if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; } }
-        if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            double v = red_v[0]; int ix = red_i[0];
-            for (int q = 1; q < 16; q++) if (red_v[q] > v || (red_v[q] == v && red_i[q] >= 0 && (ix < 0 || red_i[q] < ix))) { v = red_v[q]; ix = red_i[q]; }
-            piv_s = v; piv_i = ix;
+    int r = 0;
+    for (int rb = 0; rb < n && !stop_s; rb += RS_NB) {
+        int nbk = 0;                                        // pivots taken in this block
+        for (int sblk = 0; sblk < RS_NB && rb + sblk < n; sblk++) {
+            // arg max of the remaining diagonal (first index wins ties: deterministic)
+            double bv = -1.0; int bi = -1;
+            for (int i = tid; i < n; i += 1024) { double v = el[i] != 0.0 ? -1.0 : dg[i]; if (v > bv) { bv = v; bi = i; } }
+            for (int o = 32; o > 0; o >>= 1) { double ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64); if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; } }
+            if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                double v = red_v[0]; int ix = red_i[0];
+                for (int q = 1; q < 16; q++) if (red_v[q] > v || (red_v[q] == v && red_i[q] >= 0 && (ix < 0 || red_i[q] < ix))) { v = red_v[q]; ix = red_i[q]; }
+                piv_s = v; piv_i = ix;
+                if (r == 0) d0_s = v;
+                if (!(v > 1e-14 * d0_s) || !(v > 0.0) || ix < 0) stop_s = 1;      // numerically zero remainder: rank r
+            }
+            __syncthreads();
+            if (stop_s) break;
+            const int p = piv_i; const double isq = 1.0 / sqrt(piv_s);
+            // row of the pivot: the untouched trailing matrix's column p minus the block's earlier rows; zero at eliminated indices
+            for (int i = tid; i < n; i += 1024) {
+                double v = M[(size_t)p * n + i];                 // (M is kept fully symmetric: row p = column p, read along the row)
+                for (int t = 0; t < sblk; t++) v -= Vb[(size_t)t * n + i] * Vb[(size_t)t * n + p];
+                v = (el[i] != 0.0) ? 0.0 : v * isq;
+                Vb[(size_t)sblk * n + i] = v;
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) { const double v = Vb[(size_t)sblk * n + i]; dg[i] -= v * v; }
+            if (tid == 0) el[p] = 1.0;
+            __syncthreads();
+            nbk = sblk + 1; r++;
         }
-        __syncthreads();
-        if (r == 0) d0 = piv_s;
-        if (!(piv_s > 1e-14 * d0) || !(piv_s > 0.0)) break;          // numerically zero remainder: rank r
-        const int p = piv_i; const double isq = 1.0 / sqrt(piv_s);
-        for (int i = tid; i < n; i += 1024) V[(size_t)r * n + i] = M[(size_t)i * n + p] * isq;
-        __syncthreads();
-        for (int e = tid; e < n * n; e += 1024) { int i = e / n, k = e - i * n; M[e] -= V[(size_t)r * n + i] * V[(size_t)r * n + k]; }
-        __syncthreads();
-        for (int i = tid; i < n; i += 1024) { M[(size_t)i * n + p] = 0.0; M[(size_t)p * n + i] = 0.0; }      // the eliminated index is exactly done
+        // the block's rows to V, and the trailing matrix takes them at once (eliminated rows / columns are never read again)
+        for (int e = tid; e < nbk * n; e += 1024) V[(size_t)(rb) * n + e] = Vb[e];
+        if (!stop_s && rb + RS_NB < n) {
+            // (the lower triangle is formed, the mirror image copied: M stays fully symmetric for the row reads above)
+            for (int e = tid; e < n * n; e += 1024) {
+                const int i = e / n, k = e - i * n;
+                if (k > i || el[i] != 0.0 || el[k] != 0.0) continue;
+                double a = 0;
+                for (int t = 0; t < nbk; t++) a += Vb[(size_t)t * n + i] * Vb[(size_t)t * n + k];
+                const double v = M[e] - a;
+                M[e] = v; M[(size_t)k * n + i] = v;
+            }
+        }
         __syncthreads();
     }
     __syncthreads();
