@@ -311,6 +311,16 @@ __device__ __forceinline__ double grp16_sum(double v) {
     v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
     return v;
 }
+// sum over the four 16-lane rows of a value that is already uniform inside each row (after grp16_sum): v_readlane of lanes 0, 16, 32
+// and 48, no LDS crossbar; the result is wave-uniform.  ((row 0 + row 1) + (row 2 + row 3))
+__device__ __forceinline__ double rows4_sum(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double a0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double a1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double a2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double a3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (a0 + a1) + (a2 + a3);
+}
 // wave-level all-reduce (butterfly 32, 16, 8, 4, 2, 1: every lane ends with the total)
 __device__ __forceinline__ double wave_sum(double v) {
     v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64);

@@ -1820,7 +1820,13 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
         if (getenv("SWF_MARG_ONE_WG")) phase(0);              // A/B: the single-workgroup sweeps
         else {
             phase(1);
-            hipLaunchKernelGGL(k_marg_gram, dim3((ldn * ldn + 255) / 256, nw), dim3(256), 0, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_M, b->mg_A, (const int*)b->mg_bjok);
+            hipLaunchKernelGGL(k_marg_gram, dim3((ldn * ldn + 255) / 256, nw), dim3(256), 0, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_M, b->mg_A, b->mg_resM, (const int*)b->mg_bjok);
+            if (!getenv("SWF_MARG_NO_PCHOL")) {
+                // the Jacobi preconditioner: pivoted Cholesky of A into the G slab (9 sweeps instead of 16 at the 263-dimension tail)
+                const size_t lds = sizeof(double) * (size_t)(RS_NB + 2) * (size_t)ldn;
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_marg_pchol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(k_marg_pchol, dim3(nw), dim3(1024), lds, b->stream, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_M, (const int*)b->mg_bjok);
+            }
             // block size by window: 8 columns up to 576 dimensions (17 workgroups per launch at 263 dimensions, 8 inner steps each; 16-column
             // blocks halve the launches but leave a step to 9 workgroups whose 16 waves share 4 SIMDs: 49 us per launch against 16), 4 above.
             // One launch schedule per class, sized by the class's largest tail; every window follows its own round-robin inside it.
@@ -1828,17 +1834,21 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
             for (int w = 0; w < nw; w++) { const int t = b->hw[w].tail_dim; if (t > MG_MAXN && t <= 576) ldA = std::max(ldA, t); else if (t > 576) ldB = std::max(ldB, t); }
             const bool bs16 = getenv("SWF_MARG_BS16") && ldn <= 288;        // A/B only
             std::vector<int> hrot((size_t)nw * MG_SWEEPS);
+            // from the sixth sweep on, one look at the rotation counts per sweep: 30 us of synchronisation against the 34 launches of a
+            // 263-dimension sweep (0.55 ms) that a check every fourth sweep ran up to three times too often
+            const int mg_first_check = getenv("SWF_MARG_FIRST_CHECK") ? atoi(getenv("SWF_MARG_FIRST_CHECK")) : 6;
             for (int sweep = 0; sweep < MG_SWEEPS; sweep++) {
-                if (sweep >= 8 && (sweep & 3) == 0) {
+                if (sweep >= mg_first_check) {
                     // every four sweeps: has every window reported a sweep without rotations?  (the launches of a converged window return
                     // at once, but a 263-dimension sweep is still 34 launches)
                     HIPCHK(hipMemcpyAsync(hrot.data(), b->mg_rot, hrot.size() * sizeof(int), hipMemcpyDeviceToHost, b->stream));
                     HIPCHK(hipStreamSynchronize(b->stream));
                     bool all = true;
                     for (int w = 0; w < nw && all; w++) { bool done = false; for (int k = 0; k < sweep; k++) done = done || hrot[(size_t)w * MG_SWEEPS + k] == 0; all = done; }
+                    if (getenv("SWF_MARG_TRACE")) { fprintf(stderr, "marg sweep %d rotations (window 0):", sweep); for (int k = 0; k < sweep; k++) fprintf(stderr, " %d", hrot[k]); fprintf(stderr, "\n"); }
                     if (all) break;
                 }
-#define BJ_LAUNCH(BS_, LDM_, NR_) hipLaunchKernelGGL((k_marg_bj<BS_, LDM_, NR_>), grid, dim3(1024), 0, b->stream, (const int*)b->mg_tail, ldn, b->mg_M, b->mg_J, b->mg_rot, (const int*)b->mg_bjok, sweep, st)
+#define BJ_LAUNCH(BS_, LDM_, NR_) hipLaunchKernelGGL((k_marg_bj<BS_, LDM_, NR_>), grid, dim3(1024), 0, b->stream, (const int*)b->mg_tail, ldn, b->mg_M, b->mg_rot, (const int*)b->mg_bjok, sweep, st)
                 if (ldA) {
                     const int bs = bs16 ? 16 : 8, nbe = ((ldA + bs - 1) / bs + 1) & ~1;
                     for (int st = -1; st < nbe - 1; st++) {

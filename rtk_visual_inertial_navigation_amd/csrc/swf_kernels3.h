@@ -7,8 +7,9 @@
 // last), the Schur complement onto the trailing n states IS L_nn L_nn^T, and b = A y_n with y = S^-1 rhs — no m x m
 // eigen-decomposition (the reference's pseudo-inverse equals the inverse whenever S_mm is positive definite, which
 // the successful Cholesky certifies; a failed factorisation is reported, not papered over).  The eigen square root of
-// A = M^T M, M = L_nn^T, comes from a ONE-SIDED (Hestenes) Jacobi on the columns of M held in LDS: it never forms A
-// for the iteration, works to high relative accuracy, and parallelises as n/2 independent column pairs per step.
+// A = G G^T, G = L_nn, comes from a ONE-SIDED (Hestenes) Jacobi on the columns of G held in LDS: it never forms A
+// for the iteration, works to high relative accuracy, and parallelises as n/2 independent column pairs per step;
+// the orthogonalised columns are the rows of J (G W = U Sigma), no eigenvector matrix is carried along.
 #pragma once
 #include "swf_dev.h"
 
@@ -48,10 +49,81 @@
 // Same pivots, same drops, same stopping rule; the sums run in a different order (tolerances of the parity tests unchanged).
 // ---------------------------------------------------------------------------------------------------------------------
 #define RS_NB 16
+// Diagonally pivoted outer-product Cholesky of the n x n matrix M (full symmetric, ld = n; destroyed), 16 pivots at a time, by one
+// 1024-thread workgroup: rows v_r of V (ld = n) with sum_r v_r v_r^T = M up to the pivots it drops (it stops at pivots below 1e-14 of
+// the largest; the remaining rows are zero).  LAZY inside a block (LAPACK's dpstrf): the diagonal is kept up to date pivot by pivot
+// (all the pivot choice needs), the row of a chosen pivot is formed from the untouched trailing matrix minus the block's earlier rows,
+// and the trailing matrix takes the block's rows at once.  Vb = 16 x n staging for the block's rows (LDS), or nullptr when V itself is
+// fast memory (the rows are then built in place); dg, el = n doubles each (running diagonal, 1.0 for an eliminated index).
+// Two callers: the rank-deficient tails (k_marg_rescue), and the PRECONDITIONER of the Jacobi sweeps (k_marg_pchol, k_marginalize):
+// the one-sided Jacobi on the columns of a pivoted Cholesky factor (Veselic / Hari) converges in about half the sweeps the columns of
+// the unpivoted L_nn need (cfg5's 263-dimension prior: 9 against 16).
+template <bool INPLACE>
+__device__ __forceinline__ void d_pivoted_chol(double* M, double* V, double* Vb_, double* dg, double* el, const int n) {
+    __shared__ double red_v[16]; __shared__ int red_i[16];
+    __shared__ double piv_s, d0_s; __shared__ int piv_i, stop_s;
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 1024) V[e] = 0.0;
+    for (int i = tid; i < n; i += 1024) { dg[i] = M[(size_t)i * n + i]; el[i] = 0.0; }
+    if (tid == 0) stop_s = 0;
+    __syncthreads();
+    int r = 0;
+    for (int rb = 0; rb < n && !stop_s; rb += RS_NB) {
+        double* Vb = INPLACE ? V + (size_t)rb * n : Vb_;          // (a compile-time choice: the pointer keeps its address space, LDS either way)
+        int nbk = 0;                                        // pivots taken in this block
+        for (int sblk = 0; sblk < RS_NB && rb + sblk < n; sblk++) {
+            // arg max of the remaining diagonal (first index wins ties: deterministic)
+            double bv = -1.0; int bi = -1;
+            for (int i = tid; i < n; i += 1024) { double v = el[i] != 0.0 ? -1.0 : dg[i]; if (v > bv) { bv = v; bi = i; } }
+            for (int o = 32; o > 0; o >>= 1) { double ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64); if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; } }
+            if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                double v = red_v[0]; int ix = red_i[0];
+                for (int q = 1; q < 16; q++) if (red_v[q] > v || (red_v[q] == v && red_i[q] >= 0 && (ix < 0 || red_i[q] < ix))) { v = red_v[q]; ix = red_i[q]; }
+                piv_s = v; piv_i = ix;
+                if (r == 0) d0_s = v;
+                if (!(v > 1e-14 * d0_s) || !(v > 0.0) || ix < 0) stop_s = 1;      // numerically zero remainder: rank r
+            }
+            __syncthreads();
+            if (stop_s) break;
+            const int p = piv_i; const double isq = 1.0 / sqrt(piv_s);
+            // row of the pivot: the untouched trailing matrix's column p minus the block's earlier rows; zero at eliminated indices
+            for (int i = tid; i < n; i += 1024) {
+                double v = M[(size_t)p * n + i];                 // (M is kept fully symmetric: row p = column p, read along the row)
+                for (int t = 0; t < sblk; t++) v -= Vb[(size_t)t * n + i] * Vb[(size_t)t * n + p];
+                v = (el[i] != 0.0) ? 0.0 : v * isq;
+                Vb[(size_t)sblk * n + i] = v;
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) { const double v = Vb[(size_t)sblk * n + i]; dg[i] -= v * v; }
+            if (tid == 0) el[p] = 1.0;
+            __syncthreads();
+            nbk = sblk + 1; r++;
+        }
+        // the block's rows to V, and the trailing matrix takes them at once (eliminated rows / columns are never read again)
+        if (!INPLACE) for (int e = tid; e < nbk * n; e += 1024) V[(size_t)(rb) * n + e] = Vb[e];
+        if (!stop_s && rb + RS_NB < n) {
+            // (the lower triangle is formed, the mirror image copied: M stays fully symmetric for the row reads above)
+            for (int e = tid; e < n * n; e += 1024) {
+                const int i = e / n, k = e - i * n;
+                if (k > i || el[i] != 0.0 || el[k] != 0.0) continue;
+                double a = 0;
+                for (int t = 0; t < nbk; t++) a += Vb[(size_t)t * n + i] * Vb[(size_t)t * n + k];
+                const double v = M[e] - a;
+                M[e] = v; M[(size_t)k * n + i] = v;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tail_dim, int ldn, double* resM, double* resb, int* res_ok, int force, double eps) {
     extern __shared__ double rs_lds[];                  // panel: (nr + 1) x 16 | later: block rows 16 x n, diagonal n, flags n
-    __shared__ double red_v[16]; __shared__ int red_i[16];
-    __shared__ double piv_s, d0_s; __shared__ int piv_i, stop_s, bad_s;
+    __shared__ double red_v[16];
+    __shared__ double piv_s; __shared__ int bad_s;
     int w = blockIdx.x, tid = threadIdx.x;
     const WinRec& W = B.win[w];
     const WinState& s = B.ws[w];
@@ -144,60 +216,7 @@ __global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tai
     // ---- pivoted Cholesky of A, 16 pivots at a time.  V = Wk (n x n, ld = n; Wk has (nr + 1) * nr >= n * n doubles): row r of the result.
     // LDS: Vb[16][n] the block's rows | dg[n] the running diagonal | el[n] 1.0 for an eliminated index
     double* V = Wk;
-    double* Vb = rs_lds; double* dg = rs_lds + (size_t)RS_NB * n; double* el = dg + n;
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 1024) V[e] = 0.0;
-    for (int i = tid; i < n; i += 1024) { dg[i] = M[(size_t)i * n + i]; el[i] = 0.0; }
-    if (tid == 0) stop_s = 0;
-    __syncthreads();
-    int r = 0;
-    for (int rb = 0; rb < n && !stop_s; rb += RS_NB) {
-        int nbk = 0;                                        // pivots taken in this block
-        for (int sblk = 0; sblk < RS_NB && rb + sblk < n; sblk++) {
-            // arg max of the remaining diagonal (first index wins ties: deterministic)
-            double bv = -1.0; int bi = -1;
-            for (int i = tid; i < n; i += 1024) { double v = el[i] != 0.0 ? -1.0 : dg[i]; if (v > bv) { bv = v; bi = i; } }
-            for (int o = 32; o > 0; o >>= 1) { double ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64); if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; } }
-            if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
-            __syncthreads();
-            if (tid == 0) {
-                double v = red_v[0]; int ix = red_i[0];
-                for (int q = 1; q < 16; q++) if (red_v[q] > v || (red_v[q] == v && red_i[q] >= 0 && (ix < 0 || red_i[q] < ix))) { v = red_v[q]; ix = red_i[q]; }
-                piv_s = v; piv_i = ix;
-                if (r == 0) d0_s = v;
-                if (!(v > 1e-14 * d0_s) || !(v > 0.0) || ix < 0) stop_s = 1;      // numerically zero remainder: rank r
-            }
-            __syncthreads();
-            if (stop_s) break;
-            const int p = piv_i; const double isq = 1.0 / sqrt(piv_s);
-            // row of the pivot: the untouched trailing matrix's column p minus the block's earlier rows; zero at eliminated indices
-            for (int i = tid; i < n; i += 1024) {
-                double v = M[(size_t)p * n + i];                 // (M is kept fully symmetric: row p = column p, read along the row)
-                for (int t = 0; t < sblk; t++) v -= Vb[(size_t)t * n + i] * Vb[(size_t)t * n + p];
-                v = (el[i] != 0.0) ? 0.0 : v * isq;
-                Vb[(size_t)sblk * n + i] = v;
-            }
-            __syncthreads();
-            for (int i = tid; i < n; i += 1024) { const double v = Vb[(size_t)sblk * n + i]; dg[i] -= v * v; }
-            if (tid == 0) el[p] = 1.0;
-            __syncthreads();
-            nbk = sblk + 1; r++;
-        }
-        // the block's rows to V, and the trailing matrix takes them at once (eliminated rows / columns are never read again)
-        for (int e = tid; e < nbk * n; e += 1024) V[(size_t)(rb) * n + e] = Vb[e];
-        if (!stop_s && rb + RS_NB < n) {
-            // (the lower triangle is formed, the mirror image copied: M stays fully symmetric for the row reads above)
-            for (int e = tid; e < n * n; e += 1024) {
-                const int i = e / n, k = e - i * n;
-                if (k > i || el[i] != 0.0 || el[k] != 0.0) continue;
-                double a = 0;
-                for (int t = 0; t < nbk; t++) a += Vb[(size_t)t * n + i] * Vb[(size_t)t * n + k];
-                const double v = M[e] - a;
-                M[e] = v; M[(size_t)k * n + i] = v;
-            }
-        }
-        __syncthreads();
-    }
+    d_pivoted_chol<false>(M, V, rs_lds, rs_lds + (size_t)RS_NB * n, rs_lds + (size_t)(RS_NB + 1) * n, n);
     __syncthreads();
     for (int e = tid; e < n * n; e += 1024) M[e] = V[e];
     if (tid == 0) res_ok[w] = 1;
@@ -214,6 +233,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     __shared__ double lds[GM ? 16 : MG_LDS_DOUBLES];  // M (n x n, column c contiguous: row c of L_nn) | V (n x n) if both fit
     __shared__ double lam[GM ? MG_BIGN : MG_MAXN + 4];
     __shared__ double bv[GM ? MG_BIGN : MG_MAXN + 4];
+    __shared__ double pc_dg[GM ? 1 : MG_MAXN + 4], pc_el[GM ? 1 : MG_MAXN + 4];      // d_pivoted_chol's running diagonal and flags
     __shared__ int nrot;
     int w = blockIdx.x, tid = threadIdx.x;
     const WinRec& W = B.win[w];
@@ -260,52 +280,50 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     if (phase == 2) {
         for (int i = tid; i < n; i += MG_NT) bv[i] = outb[o1 + i];
         __syncthreads();
-    } else if (rescued) {
-        // the rank-revealing factor of A from k_marg_rescue: row r of resM is v_r (sum_r v_r v_r^T = A), b comes with it
-        const double* Rm = resM + o2;
-        for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Mc(c, r) = Rm[(size_t)r * n + c]; }
-        __syncthreads();
-        if (!(GM && phase == 1))                          // (large tails: k_marg_gram, over the chip)
-        for (int e = tid; e < n * n; e += MG_NT) {
-            int i = e / n, j = e - i * n;
-            double a = 0;
-            for (int r = 0; r < n; r++) a += Mc(i, r) * Mc(j, r);
-            outA[o2 + e] = a;
-        }
-        for (int i = tid; i < n; i += MG_NT) { double a = resb[o1 + i]; bv[i] = a; outb[o1 + i] = a; }
-        __syncthreads();
     } else {
-    for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Mc(c, r) = (r <= c) ? L[(size_t)(m + c) * nr + m + r] : 0.0; }
+    // G (column c contiguous) with G G^T = A: the columns of L_nn, or of the transposed rank-revealing factor of k_marg_rescue
+    // (row r of resM is v_r, sum_r v_r v_r^T = A).  The loads run along the rows of the source (coalesced).
+    if (rescued) {
+        const double* Rm = resM + o2;
+        for (int e = tid; e < n * n; e += MG_NT) Mm[e] = Rm[e];
+    } else
+        for (int e = tid; e < n * n; e += MG_NT) { int r = e / n, c = e - r * n; Mc(c, r) = (c <= r) ? L[(size_t)(m + r) * nr + m + c] : 0.0; }
     __syncthreads();
-    // A = M^T M (= L_nn L_nn^T, the marginal information of the tail), b = A y_n
+    // A = G G^T (= L_nn L_nn^T, the marginal information of the tail)
     if (!(GM && phase == 1))                              // (large tails: k_marg_gram, over the chip)
     for (int e = tid; e < n * n; e += MG_NT) {
-        int i = e / n, j = e - i * n, k = i < j ? i : j;
+        int i = e / n, j = e - i * n, k = rescued ? n - 1 : (i < j ? i : j);
         double a = 0;
-        for (int r = 0; r <= k; r++) a += Mc(i, r) * Mc(j, r);
+        for (int r = 0; r <= k; r++) a += Mc(r, i) * Mc(r, j);
         outA[o2 + e] = a;
+        if (!GM && !rescued) outJ[o2 + e] = a;            // the copy the preconditioner factors (the J slab is written last)
     }
-    __syncthreads();
-    // b = A y_n evaluated as L_nn (L_nn^T y_n), the same two triangular products as the Cholesky form (bit-identical b)
-    for (int r = tid; r < n; r += MG_NT) { double a = 0; for (int c = r; c < n; c++) a += Mc(c, r) * y[c]; lam[r] = a; }
-    __syncthreads();
-    for (int i = tid; i < n; i += MG_NT) {
-        double a = 0;
-        for (int r = 0; r <= i; r++) a += Mc(i, r) * lam[r];
-        bv[i] = a; outb[o1 + i] = a;
-    }
-    __syncthreads();
-    }
-    // ---- one-sided Jacobi: rotate column pairs of M until all columns are mutually orthogonal (M V = U Sigma).
-    // V is accumulated explicitly (same rotations applied to I): it stays orthogonal to machine precision, whereas
-    // U = M V / sigma loses orthogonality like eps * sqrt(cond) — measured 1.5e-9 in J^T r0 - b.  V lives in the
-    // window's J buffer (column c contiguous, L2-resident working set) until the final permuted write-out.
-    double* Vg = (!GM && 2 * n * n <= MG_LDS_DOUBLES) ? lds + n * n : outJ + o2;      // LDS-resident V when it fits (n <= 98)
-    if (phase != 2) {
-        for (int e = tid; e < n * n; e += MG_NT) { int c = e / n, r = e - c * n; Vg[e] = (r == c) ? 1.0 : 0.0; }
+    if (rescued) {
+        for (int i = tid; i < n; i += MG_NT) { double a = resb[o1 + i]; bv[i] = a; outb[o1 + i] = a; }
+    } else {
+        // b = A y_n evaluated as L_nn (L_nn^T y_n), the same two triangular products as the Cholesky form (bit-identical b)
+        for (int r = tid; r < n; r += MG_NT) { double a = 0; for (int c = r; c < n; c++) a += Mc(r, c) * y[c]; lam[r] = a; }
         __syncthreads();
+        for (int i = tid; i < n; i += MG_NT) {
+            double a = 0;
+            for (int r = 0; r <= i; r++) a += Mc(r, i) * lam[r];
+            bv[i] = a; outb[o1 + i] = a;
+        }
     }
-    if (phase == 1) { if (tid == 0) bj_ok[w] = 1; return; }      // the sweeps of this window run in k_marg_bj
+    __syncthreads();
+    }
+    // ---- one-sided Jacobi on the columns of G (Veselic / Hari: the Cholesky factor, not A, is what gets rotated).  Plane rotations
+    // from the right, G <- G W, until all columns are mutually orthogonal: G W = U Sigma, so A = G G^T = (U Sigma)(U Sigma)^T and the
+    // rows of J = Sigma U^T are the final columns themselves — no eigenvector matrix to accumulate, nothing divided by a small sigma,
+    // and J^T J = A holds as long as every rotation is a rotation.  The implicit Gram matrix G^T G = L^T L is one LR step closer to
+    // diagonal than A (round 3 rotated the columns of L^T, Gram matrix A, and carried V: 16 sweeps at the 263-dimension tail of cfg5
+    // against the sweeps this order needs, at twice the traffic per rotation).
+    if (!GM && !rescued && phase != 2) {
+        // preconditioner: G <- the pivoted Cholesky factor of A (d_pivoted_chol; the rows are built in place, G lives in LDS)
+        __threadfence_block();
+        d_pivoted_chol<true>(outJ + o2, lds, nullptr, pc_dg, pc_el, n);
+    }
+    if (phase == 1) { if (tid == 0) bj_ok[w] = rescued ? 2 : 1; return; }      // k_marg_gram, k_marg_pchol (1 only) and the sweeps of k_marg_bj follow
     int grp = tid >> 4, sub = tid & 15;
     int ne = (n + 1) & ~1;                            // even number of players in the round-robin (a bye if n is odd)
     int sweeps_done = 0;
@@ -331,11 +349,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
                     double hz = 1.0 + zeta * zeta;
                     double t = (zeta >= 0 ? 1.0 : -1.0) * rcp_nr(fabs(zeta) + hz * rsqrt_nr(hz));
                     double c = rsqrt_nr(1.0 + t * t), sn = c * t;
-                    double* vp = Vg + (size_t)p * n; double* vq = Vg + (size_t)q * n;
-                    for (int r = sub; r < n; r += 16) {
-                        double a = Mc(p, r), b2 = Mc(q, r); Mc(p, r) = c * a - sn * b2; Mc(q, r) = sn * a + c * b2;
-                        double va = vp[r], vb = vq[r]; vp[r] = c * va - sn * vb; vq[r] = sn * va + c * vb;
-                    }
+                    for (int r = sub; r < n; r += 16) { double a = Mc(p, r), b2 = Mc(q, r); Mc(p, r) = c * a - sn * b2; Mc(q, r) = sn * a + c * b2; }
                     if (sub == 0) atomicAdd(&nrot, 1);
                 }
             }
@@ -345,9 +359,8 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         __syncthreads();
         if (done) break;
     }
-    // eigenvalues = squared column norms of M V; J = Sigma V^T (row c = sigma_c v_c^T), r0 = Sigma^-1 V^T b; rows ordered
-    // by ascending eigenvalue as Eigen returns them.  The scaled columns are staged through LDS (M is done) because
-    // the sorted write-out permutes the buffer V sits in.
+    // eigenvalues = squared column norms; J = the columns as rows (row k = sigma_k u_k^T), r0 = Sigma^-1 U^T b = (column . b) / lambda;
+    // rows ordered by ascending eigenvalue as Eigen returns them; eigenvalues <= eps dropped (null row, null r0) as the reference does.
     for (int c = grp; c < n; c += MG_NT / 16) {
         double a = 0;
         for (int r = sub; r < n; r += 16) a += Mc(c, r) * Mc(c, r);
@@ -363,22 +376,14 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     if (tid == 0) outrank[w] = rank;
 #endif
     for (int c = grp; c < n; c += MG_NT / 16) {
-        double lc = lam[c];
-        bool keep = lc > eps;
-        double sg = keep ? sqrt(lc) : 0.0;
+        const double lc = lam[c];
+        const bool keep = lc > eps;
+        int pos = 0;
+        for (int k = 0; k < n; k++) pos += (lam[k] < lc) || (lam[k] == lc && k < c);
         double dotb = 0;
-        for (int j = sub; j < n; j += 16) { double v = Vg[(size_t)c * n + j]; Mc(c, j) = sg * v; dotb += v * bv[j]; }
+        for (int j = sub; j < n; j += 16) { const double v = Mc(c, j); outJ[o2 + (size_t)pos * n + j] = keep ? v : 0.0; dotb += v * bv[j]; }
         dotb = grp16_sum(dotb);
-        int pos = 0;
-        for (int k = 0; k < n; k++) pos += (lam[k] < lc) || (lam[k] == lc && k < c);
-        if (sub == 0) { outr0[o1 + pos] = keep ? dotb / sg : 0.0; outw[o1 + pos] = lc; }
-    }
-    __syncthreads();
-    for (int c = grp; c < n; c += MG_NT / 16) {
-        double lc = lam[c];
-        int pos = 0;
-        for (int k = 0; k < n; k++) pos += (lam[k] < lc) || (lam[k] == lc && k < c);
-        for (int j = sub; j < n; j += 16) outJ[o2 + (size_t)pos * n + j] = Mc(c, j);
+        if (sub == 0) { outr0[o1 + pos] = keep ? dotb / lc : 0.0; outw[o1 + pos] = lc; }
     }
 }
 
@@ -396,7 +401,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
 // A = M^T M of the large tails, one thread per entry over as many workgroups as it takes (the single workgroup of the set-up phase
 // spent 2.6 ms on the 263-dimension tail here).  Full-length sums: the zeros of a triangular M add exact zeros, so the entries are
 // those of the triangular loops above, bit for bit.
-__global__ void __launch_bounds__(256) k_marg_gram(const int* tail_dim, int ldn, const double* Mscr, double* outA, const int* bj_ok) {
+__global__ void __launch_bounds__(256) k_marg_gram(const int* tail_dim, int ldn, const double* Mscr, double* outA, double* work, const int* bj_ok) {
     const int w = blockIdx.y;
     if (!bj_ok[w]) return;
     const int n = tail_dim[w], e = blockIdx.x * 256 + threadIdx.x;
@@ -405,13 +410,24 @@ __global__ void __launch_bounds__(256) k_marg_gram(const int* tail_dim, int ldn,
     const double* Mm = Mscr + o2;
     const int i = e / n, j = e - i * n;
     double a = 0;
-    for (int r = 0; r < n; r++) a += Mc(i, r) * Mc(j, r);
+    for (int r = 0; r < n; r++) a += Mc(r, i) * Mc(r, j);
     outA[o2 + e] = a;
+    if (bj_ok[w] == 1) work[o2 + e] = a;                  // the copy k_marg_pchol factors (ld = n)
+}
+// The Jacobi preconditioner of the large tails: G <- the pivoted Cholesky factor of A = G G^T (columns v_r, original row order), one
+// workgroup per window, in the window's Mscr slab (ld = n; k_marg_gram is done with the old G).  Windows whose G already is one
+// (bj_ok == 2: k_marg_rescue supplied it) pass.
+__global__ void __launch_bounds__(1024) k_marg_pchol(const int* tail_dim, int ldn, double* work, double* Mscr, const int* bj_ok) {
+    extern __shared__ double rs_lds[];                  // block rows 16 x n, diagonal n, flags n
+    const int w = blockIdx.x;
+    if (bj_ok[w] != 1) return;
+    const int n = tail_dim[w];
+    const size_t o2 = (size_t)w * ldn * ldn;
+    d_pivoted_chol<false>(work + o2, Mscr + o2, rs_lds, rs_lds + (size_t)RS_NB * n, rs_lds + (size_t)(RS_NB + 1) * n, n);
 }
 template <int BS, int LDM, int NR>       // NR = rows per lane the launch's largest tail needs (n <= 64 NR <= LDM)
-__global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, double* Mscr, double* Vout, int* rot, const int* bj_ok, int sweep, int bstep) {
+__global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, double* Mscr, int* rot, const int* bj_ok, int sweep, int bstep) {
     __shared__ double Ml[2 * BS][LDM];
-    __shared__ double Vl[2 * BS][LDM];
     __shared__ int nrot;
     const int w = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (!bj_ok[w]) return;
@@ -433,7 +449,7 @@ __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, 
     }
     if (P >= nb) return;
     const size_t o2 = (size_t)w * ldn * ldn;
-    double* Mm = Mscr + o2; double* Vg = Vout + o2;
+    double* Mm = Mscr + o2;
     auto gcol = [&](int lc) { int c = lc < BS ? P * BS + lc : Q * BS + (lc - BS); return (lc >= BS && Q >= nb) ? n : c; };
 #ifdef SWF_PROFILE_CHOL
 #define MGACC(i) do { if (blockIdx.x == 1 && blockIdx.y == 0 && tid == 0 && sweep == 1 && bstep == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_chol_stamps[i] += t_ - tacc; tacc = t_; } } while (0)
@@ -449,11 +465,11 @@ __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, 
         if (c < n) {
             // every request of the column on its way before the first value is stored (a launch is a few microseconds of work: one
             // round trip to the other workgroups' columns per loop iteration was half of it)
-            double tm[NR], tv[NR];
+            double tm[NR];
 #pragma unroll
-            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k, rc = r < n ? r : 0; tm[k] = Mm[(size_t)c * n + rc]; tv[k] = Vg[(size_t)c * n + rc]; }
+            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k, rc = r < n ? r : 0; tm[k] = Mm[(size_t)c * n + rc]; }
 #pragma unroll
-            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; if (r < n) { Ml[lc][r] = tm[k]; Vl[lc][r] = tv[k]; } }
+            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; if (r < n) Ml[lc][r] = tm[k]; }
         }
     }
     if (tid == 0) nrot = 0;
@@ -469,6 +485,55 @@ __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, 
     // estimates — a rotation by a slightly inexact angle is still exactly a rotation as long as c^2 + s^2 = 1, which the one
     // Newton-refined rsqrt for c (s = c t) keeps to rounding; the angle only has to shrink the off-diagonal term.
     const int nst = bstep < 0 ? BS - 1 : BS;
+    if (bstep >= 0) {
+        // cross launches (all but one of a sweep): wave wv plays column p = wv of block P against every column of block Q in turn, so
+        // its p stays in REGISTERS for the BS steps and only the q columns travel through LDS (half the LDS reads and writes of a step);
+        // the three sums leave the 16-lane rows through v_readlane (uniform from there on) instead of two ds_bpermute round trips.
+        const bool act = wv < BS && gcol(wv) < n;
+        double mp[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; mp[k] = (act && r < n) ? Ml[wv < BS ? wv : 0][r < n ? r : 0] : 0.0; }
+        int myrot = 0;
+        for (int st = 0; st < BS; st++) {
+            const int q = BS + ((wv + st) % BS);
+            if (act && gcol(q) < n) {
+                double mb[NR];
+#pragma unroll
+                for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; const double x1 = Ml[q][r < n ? r : n - 1]; mb[k] = r < n ? x1 : 0.0; }
+                MGACC(54);
+                double al = 0, be = 0, ga = 0;
+#pragma unroll
+                for (int k = 0; k < NR; k++) { al += mp[k] * mp[k]; be += mb[k] * mb[k]; ga += mp[k] * mb[k]; }
+                al = grp16_sum(al); be = grp16_sum(be); ga = grp16_sum(ga);
+                al = rows4_sum(al); be = rows4_sum(be); ga = rows4_sum(ga);
+                MGACC(55);
+                if (ga * ga > 1e-30 * (al * be) && fabs(ga) > 1e-140 * (al + be)) {
+                    const double zeta = (be - al) * (0.5 * __builtin_amdgcn_rcp(ga));
+                    const double hz = 1.0 + zeta * zeta;
+                    const double t = (zeta >= 0 ? 1.0 : -1.0) * __builtin_amdgcn_rcp(fabs(zeta) + hz * __builtin_amdgcn_rsq(hz));
+                    const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
+                    MGACC(56);
+#pragma unroll
+                    for (int k = 0; k < NR; k++) {
+                        const int r = lane + 64 * k;
+                        const double a = mp[k], b2 = mb[k];
+                        mp[k] = c * a - sn * b2;
+                        if (64 * NR <= LDM || r < n) Ml[q][r] = sn * a + c * b2;
+                    }
+                    myrot++;
+                    MGACC(57);
+                }
+            }
+            __syncthreads();
+            MGACC(58);
+        }
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; if (r < n) Ml[wv][r] = mp[k]; }
+            if (lane == 0 && myrot) atomicAdd(&nrot, myrot);
+        }
+        __syncthreads();
+    } else
     for (int st = 0; st < nst; st++) {
         if (wv < BS) {
             int p, q;
@@ -481,13 +546,13 @@ __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, 
             } else { p = wv; q = BS + ((wv + st) % BS); }
             if (p > q) { int t = p; p = q; q = t; }
             if (gcol(p) < n && gcol(q) < n) {
-                double ma[NR], mb[NR], va[NR], vb[NR];
+                double ma[NR], mb[NR];
 #pragma unroll
                 for (int k = 0; k < NR; k++) {
                     const int r = lane + 64 * k, rc = r < n ? r : n - 1;      // (unconditional reads, selected afterwards: no branch per row)
-                    const double x0 = Ml[p][rc], x1 = Ml[q][rc], x2 = Vl[p][rc], x3 = Vl[q][rc];
+                    const double x0 = Ml[p][rc], x1 = Ml[q][rc];
                     const bool in = r < n;
-                    ma[k] = in ? x0 : 0.0; mb[k] = in ? x1 : 0.0; va[k] = in ? x2 : 0.0; vb[k] = in ? x3 : 0.0;
+                    ma[k] = in ? x0 : 0.0; mb[k] = in ? x1 : 0.0;
                 }
                 MGACC(54);
                 double al = 0, be = 0, ga = 0;
@@ -509,7 +574,6 @@ __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, 
                         const int r = lane + 64 * k;
                         if (64 * NR <= LDM || r < n) {            // (rows past n of a column are scratch when the row has room for them: no branch)
                             Ml[p][r] = c * ma[k] - sn * mb[k]; Ml[q][r] = sn * ma[k] + c * mb[k];
-                            Vl[p][r] = c * va[k] - sn * vb[k]; Vl[q][r] = sn * va[k] + c * vb[k];
                         }
                     }
                     if (lane == 0) atomicAdd(&nrot, 1);
@@ -523,7 +587,7 @@ __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, 
     MGSTAMP(52);
     for (int lc = wv; lc < 2 * BS; lc += 16) {
         const int c = gcol(lc);
-        if (c < n) for (int r = lane; r < n; r += 64) { Mm[(size_t)c * n + r] = Ml[lc][r]; Vg[(size_t)c * n + r] = Vl[lc][r]; }
+        if (c < n) for (int r = lane; r < n; r += 64) Mm[(size_t)c * n + r] = Ml[lc][r];
     }
     if (tid == 0 && nrot) atomicAdd(&rw[sweep], nrot);
     MGSTAMP(53);
