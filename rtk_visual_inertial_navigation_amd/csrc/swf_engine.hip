@@ -222,7 +222,7 @@ struct swf_batch {
     // (one copy per array instead of six small ones per window: 576 GNSS-epoch priors took 46 ms of hipMemcpy latency)
     bool mg_host = false; std::vector<double> h_mgA, h_mgJ, h_mgb, h_mgr0, h_mgw; std::vector<int> h_mgrank;
     double* mg_resM = nullptr; double* mg_resb = nullptr; int* mg_resok = nullptr;      // k_marg_rescue outputs (rank-deficient tails)
-    int* mg_rot = nullptr; int* mg_bjok = nullptr;                                       // k_marg_bj: rotations per sweep, windows taking part
+    int* mg_rot = nullptr; int* mg_bjok = nullptr; unsigned long long* mg_crit = nullptr;                                       // k_marg_bj: rotations per sweep, windows taking part
     // ambiguity covariance hand-off outputs (allocated at the first swf_batch_tail_covariance)
     int* tc_tail = nullptr; double* tc_A = nullptr; double* tc_Q = nullptr; double* tc_X = nullptr; int* tc_rank = nullptr; bool tc_valid = false; int tc_ld = 0;
     // latency path (small batches): an auxiliary stream runs the IMU / clique branch of a linearisation next to the
@@ -1810,8 +1810,9 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                        (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force, 0, (int*)nullptr);
     if (big) {
         // large tails: set-up, the block-Jacobi sweeps over many workgroups (fixed launch schedule; converged windows return at once), write-out
-        if (!b->mg_rot && (b->pool.zeros((size_t)nw * MG_SWEEPS, &b->mg_rot) || b->pool.zeros((size_t)nw, &b->mg_bjok))) return fail(SWF_E_NODEVICE, "device allocation failed");
+        if (!b->mg_rot && (b->pool.zeros((size_t)nw * MG_SWEEPS, &b->mg_rot) || b->pool.zeros((size_t)nw, &b->mg_bjok) || b->pool.zeros((size_t)nw * 2, &b->mg_crit))) return fail(SWF_E_NODEVICE, "device allocation failed");
         HIPCHK(hipMemsetAsync(b->mg_rot, 0, (size_t)nw * MG_SWEEPS * sizeof(int), b->stream));
+        HIPCHK(hipMemsetAsync(b->mg_crit, 0, (size_t)nw * 2 * sizeof(unsigned long long), b->stream));
         auto phase = [&](int ph) {
             hipLaunchKernelGGL(k_marginalize<true>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
                                b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M,
@@ -1832,7 +1833,6 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
             // One launch schedule per class, sized by the class's largest tail; every window follows its own round-robin inside it.
             int ldA = 0, ldB = 0;
             for (int w = 0; w < nw; w++) { const int t = b->hw[w].tail_dim; if (t > MG_MAXN && t <= 576) ldA = std::max(ldA, t); else if (t > 576) ldB = std::max(ldB, t); }
-            const bool bs16 = getenv("SWF_MARG_BS16") && ldn <= 288;        // A/B only
             std::vector<int> hrot((size_t)nw * MG_SWEEPS);
             // from the sixth sweep on, one look at the rotation counts per sweep: 30 us of synchronisation against the 34 launches of a
             // 263-dimension sweep (0.55 ms) that a check every fourth sweep ran up to three times too often
@@ -1848,13 +1848,12 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                     if (getenv("SWF_MARG_TRACE")) { fprintf(stderr, "marg sweep %d rotations (window 0):", sweep); for (int k = 0; k < sweep; k++) fprintf(stderr, " %d", hrot[k]); fprintf(stderr, "\n"); }
                     if (all) break;
                 }
-#define BJ_LAUNCH(BS_, LDM_, NR_) hipLaunchKernelGGL((k_marg_bj<BS_, LDM_, NR_>), grid, dim3(1024), 0, b->stream, (const int*)b->mg_tail, ldn, b->mg_M, b->mg_rot, (const int*)b->mg_bjok, sweep, st)
+#define BJ_LAUNCH(BS_, LDM_, NR_) hipLaunchKernelGGL((k_marg_bj<BS_, LDM_, NR_>), grid, dim3(1024), 0, b->stream, (const int*)b->mg_tail, ldn, b->mg_M, b->mg_rot, b->mg_crit, (const int*)b->mg_bjok, sweep, st)
                 if (ldA) {
-                    const int bs = bs16 ? 16 : 8, nbe = ((ldA + bs - 1) / bs + 1) & ~1;
+                    const int bs = 8, nbe = ((ldA + bs - 1) / bs + 1) & ~1;
                     for (int st = -1; st < nbe - 1; st++) {
                         dim3 grid(nbe / 2, nw);
-                        if (bs16) BJ_LAUNCH(16, 288, 5);
-                        else if (ldA <= 320) BJ_LAUNCH(8, 576, 5);
+                        if (ldA <= 320) BJ_LAUNCH(8, 576, 5);
                         else BJ_LAUNCH(8, 576, 9);
                     }
                 }
@@ -1863,6 +1862,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                     for (int st = -1; st < nbe - 1; st++) { dim3 grid(nbe / 2, nw); BJ_LAUNCH(4, 640, 10); }
                 }
 #undef BJ_LAUNCH
+                if (!getenv("SWF_MARG_NO_CRIT")) hipLaunchKernelGGL(k_marg_bj_crit, dim3((nw + 63) / 64), dim3(64), 0, b->stream, (const int*)b->mg_tail, nw, b->mg_rot, b->mg_crit, (const int*)b->mg_bjok, sweep);
             }
             phase(2);
         }

@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     __shared__ double bv[GM ? MG_BIGN : MG_MAXN + 4];
     __shared__ double pc_dg[GM ? 1 : MG_MAXN + 4], pc_el[GM ? 1 : MG_MAXN + 4];      // d_pivoted_chol's running diagonal and flags
     __shared__ int nrot;
+    __shared__ unsigned long long crit_sh[2];
     int w = blockIdx.x, tid = threadIdx.x;
     const WinRec& W = B.win[w];
     const WinState& s = B.ws[w];
@@ -329,7 +330,8 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     int sweeps_done = 0;
     for (int sweep = 0; sweep < (phase == 2 ? 0 : 40); sweep++) {
         sweeps_done = sweep + 1;
-        if (tid == 0) nrot = 0;
+        if (tid == 0) { nrot = 0; crit_sh[0] = 0; crit_sh[1] = 0; }
+        double mc2 = 0.0, ms2 = 0.0;
         __syncthreads();
         for (int st = 0; st < ne - 1; st++) {
             // circle method: player ne-1 is fixed, the others rotate; group k plays pair k (and k + 64) of this step
@@ -349,13 +351,17 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
                     double hz = 1.0 + zeta * zeta;
                     double t = (zeta >= 0 ? 1.0 : -1.0) * rcp_nr(fabs(zeta) + hz * rsqrt_nr(hz));
                     double c = rsqrt_nr(1.0 + t * t), sn = c * t;
+                    mc2 = fmax(mc2, ga * ga * __builtin_amdgcn_rcp(al * be)); ms2 = fmax(ms2, sn * sn);
                     for (int r = sub; r < n; r += 16) { double a = Mc(p, r), b2 = Mc(q, r); Mc(p, r) = c * a - sn * b2; Mc(q, r) = sn * a + c * b2; }
                     if (sub == 0) atomicAdd(&nrot, 1);
                 }
             }
             __syncthreads();
         }
-        int done = nrot == 0;
+        // (a sweep of tiny rotations leaves nothing for the next one to rotate: see k_marg_bj_crit)
+        if (sub == 0 && ms2 > 0.0) { atomicMax(&crit_sh[0], (unsigned long long)__double_as_longlong(mc2)); atomicMax(&crit_sh[1], (unsigned long long)__double_as_longlong(ms2)); }
+        __syncthreads();
+        int done = nrot == 0 || (double)n * (double)n * __longlong_as_double((long long)crit_sh[0]) * __longlong_as_double((long long)crit_sh[1]) <= 1e-30;
         __syncthreads();
         if (done) break;
     }
@@ -426,9 +432,12 @@ __global__ void __launch_bounds__(1024) k_marg_pchol(const int* tail_dim, int ld
     d_pivoted_chol<false>(work + o2, Mscr + o2, rs_lds, rs_lds + (size_t)RS_NB * n, rs_lds + (size_t)(RS_NB + 1) * n, n);
 }
 template <int BS, int LDM, int NR>       // NR = rows per lane the launch's largest tail needs (n <= 64 NR <= LDM)
-__global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, double* Mscr, int* rot, const int* bj_ok, int sweep, int bstep) {
+__global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, double* Mscr, int* rot, unsigned long long* crit, const int* bj_ok, int sweep, int bstep) {
+    static_assert(64 * NR <= LDM && 2 * BS <= 16, "a column's LDS row holds all 64 NR lanes' rows (zero past n); one wave per column");
     __shared__ double Ml[2 * BS][LDM];
+    __shared__ double nrm[2 * BS];                        // squared norms of the columns, kept up to date rotation by rotation
     __shared__ int nrot;
+    __shared__ unsigned long long crit_s[2];              // largest cos^2 between two rotated columns, largest sin^2 of a rotation (bit patterns)
     const int w = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (!bj_ok[w]) return;
     const int n = tail_dim[w];
@@ -460,137 +469,148 @@ __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, 
 #endif
     unsigned long long tacc = 0; (void)tacc;
     MGSTAMP(50);
-    for (int lc = wv; lc < 2 * BS; lc += 16) {
-        const int c = gcol(lc);
-        if (c < n) {
-            // every request of the column on its way before the first value is stored (a launch is a few microseconds of work: one
-            // round trip to the other workgroups' columns per loop iteration was half of it)
-            double tm[NR];
+    // wave lc loads column lc: every request on its way before the first value is used (a launch is a few microseconds of work), zeros
+    // past row n (the steps then need no row masks), and the column's squared norm — the only full-length sums of the launch besides
+    // the one inner product per pair: a plane rotation by tan t moves t * <p, q> from one squared norm to the other.
+    const bool mine = wv < 2 * BS && gcol(wv) < n;        // this wave's column exists
+    double mp[NR];
+    double al = 0.0;
 #pragma unroll
-            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k, rc = r < n ? r : 0; tm[k] = Mm[(size_t)c * n + rc]; }
+    for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; mp[k] = (mine && r < n) ? Mm[(size_t)gcol(wv) * n + r] : 0.0; }
+    if (wv < 2 * BS) {
 #pragma unroll
-            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; if (r < n) Ml[lc][r] = tm[k]; }
-        }
+        for (int k = 0; k < NR; k++) { Ml[wv][lane + 64 * k] = mp[k]; al += mp[k] * mp[k]; }
+        al = rows4_sum(grp16_sum(al));
+        if (lane == 0) nrm[wv] = al;
     }
-    if (tid == 0) nrot = 0;
+    if (tid == 0) { nrot = 0; crit_s[0] = 0; crit_s[1] = 0; }
+    double mc2 = 0.0, ms2 = 0.0;
+    int myrot = 0;
     __syncthreads();
     MGSTAMP(51);
 #ifdef SWF_PROFILE_CHOL
     if (blockIdx.x == 1 && blockIdx.y == 0 && tid == 0 && sweep == 1 && bstep == 0) { for (int i = 54; i < 60; i++) g_chol_stamps[i] = 0; }
     tacc = __builtin_amdgcn_s_memtime();
 #endif
-    // one inner step = BS disjoint pairs, one wavefront each.  A step is bound by the latency of one wave's dependent work, not by issue
-    // (two half-wave pairs per wavefront were slower), so: the rows of the four columns are read ONCE, all requests before the first
-    // use (the loop over the rows is unrolled to the class's LDM / 64), and the rotation angle comes from the raw v_rcp / v_rsq
-    // estimates — a rotation by a slightly inexact angle is still exactly a rotation as long as c^2 + s^2 = 1, which the one
-    // Newton-refined rsqrt for c (s = c t) keeps to rounding; the angle only has to shrink the off-diagonal term.
-    const int nst = bstep < 0 ? BS - 1 : BS;
+    // one inner step = BS disjoint pairs, one wavefront each (8 of the 16 waves: two per SIMD).  A step is bound by the INSTRUCTIONS the
+    // two waves of a SIMD issue, not by their latency (two half-wave pairs per wavefront were slower; so were three full-length sums per
+    // pair), so the step is kept short: one inner product, the norms carried along, no row masks, and the rotation angle from the raw
+    // v_rcp / v_rsq estimates — a rotation by a slightly inexact angle is still exactly a rotation as long as c^2 + s^2 = 1, which the
+    // one Newton-refined rsqrt for c (s = c t) keeps to rounding; the angle only has to shrink the off-diagonal term.
     if (bstep >= 0) {
         // cross launches (all but one of a sweep): wave wv plays column p = wv of block P against every column of block Q in turn, so
-        // its p stays in REGISTERS for the BS steps and only the q columns travel through LDS (half the LDS reads and writes of a step);
-        // the three sums leave the 16-lane rows through v_readlane (uniform from there on) instead of two ds_bpermute round trips.
-        const bool act = wv < BS && gcol(wv) < n;
-        double mp[NR];
-#pragma unroll
-        for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; mp[k] = (act && r < n) ? Ml[wv < BS ? wv : 0][r < n ? r : 0] : 0.0; }
-        int myrot = 0;
+        // its p stays in REGISTERS for the BS steps (it is the column the wave loaded) and only the q columns travel through LDS.
+        const bool act = wv < BS && mine;
         for (int st = 0; st < BS; st++) {
             const int q = BS + ((wv + st) % BS);
             if (act && gcol(q) < n) {
                 double mb[NR];
 #pragma unroll
-                for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; const double x1 = Ml[q][r < n ? r : n - 1]; mb[k] = r < n ? x1 : 0.0; }
+                for (int k = 0; k < NR; k++) mb[k] = Ml[q][lane + 64 * k];
+                const double be = nrm[q];
                 MGACC(54);
-                double al = 0, be = 0, ga = 0;
+                double ga = 0;
 #pragma unroll
-                for (int k = 0; k < NR; k++) { al += mp[k] * mp[k]; be += mb[k] * mb[k]; ga += mp[k] * mb[k]; }
-                al = grp16_sum(al); be = grp16_sum(be); ga = grp16_sum(ga);
-                al = rows4_sum(al); be = rows4_sum(be); ga = rows4_sum(ga);
+                for (int k = 0; k < NR; k++) ga += mp[k] * mb[k];
+                ga = rows4_sum(grp16_sum(ga));
                 MGACC(55);
-                if (ga * ga > 1e-30 * (al * be) && fabs(ga) > 1e-140 * (al + be)) {
-                    const double zeta = (be - al) * (0.5 * __builtin_amdgcn_rcp(ga));
-                    const double hz = 1.0 + zeta * zeta;
-                    const double t = (zeta >= 0 ? 1.0 : -1.0) * __builtin_amdgcn_rcp(fabs(zeta) + hz * __builtin_amdgcn_rsq(hz));
-                    const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
-                    MGACC(56);
+                // (no rotation: c = 1, s = t = 0 through the same instructions — the waves of a step stay in step)
+                const bool go = ga * ga > 1e-30 * (al * be) && fabs(ga) > 1e-140 * (al + be);
+                const double zeta = (be - al) * (0.5 * __builtin_amdgcn_rcp(ga));
+                const double hz = 1.0 + zeta * zeta;
+                const double t = go ? (zeta >= 0 ? 1.0 : -1.0) * __builtin_amdgcn_rcp(fabs(zeta) + hz * __builtin_amdgcn_rsq(hz)) : 0.0;
+                const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
+                if (go) { mc2 = fmax(mc2, ga * ga * __builtin_amdgcn_rcp(al * be)); ms2 = fmax(ms2, sn * sn); myrot++; }
+                MGACC(56);
 #pragma unroll
-                    for (int k = 0; k < NR; k++) {
-                        const int r = lane + 64 * k;
-                        const double a = mp[k], b2 = mb[k];
-                        mp[k] = c * a - sn * b2;
-                        if (64 * NR <= LDM || r < n) Ml[q][r] = sn * a + c * b2;
-                    }
-                    myrot++;
-                    MGACC(57);
+                for (int k = 0; k < NR; k++) {
+                    const double a = mp[k], b2 = mb[k];
+                    mp[k] = c * a - sn * b2;
+                    Ml[q][lane + 64 * k] = sn * a + c * b2;
                 }
+                const double tg = t * ga;
+                al -= tg;
+                if (lane == 0) nrm[q] = be + tg;
+                MGACC(57);
             }
             __syncthreads();
             MGACC(58);
         }
-        if (act) {
+        if (lane == 0 && myrot) atomicAdd(&nrot, myrot);
+    } else {
+        // the launch of the pairs inside the blocks: two independent round-robins of BS players (blocks P and Q), waves 0 .. BS/2 - 1 play
+        // in P, the others in Q; both columns of a pair change hands every step, so both travel through LDS.
+        if (wv < 2 * BS) {
 #pragma unroll
-            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; if (r < n) Ml[wv][r] = mp[k]; }
-            if (lane == 0 && myrot) atomicAdd(&nrot, myrot);
+            for (int k = 0; k < NR; k++) mp[k] = 0.0;
         }
-        __syncthreads();
-    } else
-    for (int st = 0; st < nst; st++) {
-        if (wv < BS) {
-            int p, q;
-            if (bstep < 0) {
-                // two independent round-robins of BS players (blocks P and Q): waves 0..BS/2-1 play in P, the others in Q
+        for (int st = 0; st < BS - 1; st++) {
+            if (wv < BS) {
+                int p, q;
                 const int blk = wv >= BS / 2, pr = wv - blk * (BS / 2);
                 if (pr == 0) { p = BS - 1; q = st; }
                 else { p = st + pr; if (p >= BS - 1) p -= BS - 1; q = st - pr; if (q < 0) q += BS - 1; }
                 p += blk * BS; q += blk * BS;
-            } else { p = wv; q = BS + ((wv + st) % BS); }
-            if (p > q) { int t = p; p = q; q = t; }
-            if (gcol(p) < n && gcol(q) < n) {
-                double ma[NR], mb[NR];
+                if (p > q) { int t = p; p = q; q = t; }
+                if (gcol(p) < n && gcol(q) < n) {
+                    double ma[NR], mb[NR];
 #pragma unroll
-                for (int k = 0; k < NR; k++) {
-                    const int r = lane + 64 * k, rc = r < n ? r : n - 1;      // (unconditional reads, selected afterwards: no branch per row)
-                    const double x0 = Ml[p][rc], x1 = Ml[q][rc];
-                    const bool in = r < n;
-                    ma[k] = in ? x0 : 0.0; mb[k] = in ? x1 : 0.0;
-                }
-                MGACC(54);
-                double al = 0, be = 0, ga = 0;
+                    for (int k = 0; k < NR; k++) { ma[k] = Ml[p][lane + 64 * k]; mb[k] = Ml[q][lane + 64 * k]; }
+                    const double ap = nrm[p], be = nrm[q];
+                    double ga = 0;
 #pragma unroll
-                for (int k = 0; k < NR; k++) { al += ma[k] * ma[k]; be += mb[k] * mb[k]; ga += ma[k] * mb[k]; }
-                // wave_sum of the three, stage by stage (two LDS round trips instead of six)
-                { const double x = __shfl_xor(al, 32, 64), y = __shfl_xor(be, 32, 64), z = __shfl_xor(ga, 32, 64); al += x; be += y; ga += z; }
-                { const double x = __shfl_xor(al, 16, 64), y = __shfl_xor(be, 16, 64), z = __shfl_xor(ga, 16, 64); al += x; be += y; ga += z; }
-                al = grp16_sum(al); be = grp16_sum(be); ga = grp16_sum(ga);
-                MGACC(55);
-                if (ga * ga > 1e-30 * (al * be) && fabs(ga) > 1e-140 * (al + be)) {
-                    const double zeta = (be - al) * (0.5 * __builtin_amdgcn_rcp(ga));
-                    const double hz = 1.0 + zeta * zeta;
-                    const double t = (zeta >= 0 ? 1.0 : -1.0) * __builtin_amdgcn_rcp(fabs(zeta) + hz * __builtin_amdgcn_rsq(hz));
-                    const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
-                    MGACC(56);
+                    for (int k = 0; k < NR; k++) ga += ma[k] * mb[k];
+                    ga = rows4_sum(grp16_sum(ga));
+                    if (ga * ga > 1e-30 * (ap * be) && fabs(ga) > 1e-140 * (ap + be)) {
+                        const double zeta = (be - ap) * (0.5 * __builtin_amdgcn_rcp(ga));
+                        const double hz = 1.0 + zeta * zeta;
+                        const double t = (zeta >= 0 ? 1.0 : -1.0) * __builtin_amdgcn_rcp(fabs(zeta) + hz * __builtin_amdgcn_rsq(hz));
+                        const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
+                        mc2 = fmax(mc2, ga * ga * __builtin_amdgcn_rcp(ap * be)); ms2 = fmax(ms2, sn * sn);
 #pragma unroll
-                    for (int k = 0; k < NR; k++) {
-                        const int r = lane + 64 * k;
-                        if (64 * NR <= LDM || r < n) {            // (rows past n of a column are scratch when the row has room for them: no branch)
-                            Ml[p][r] = c * ma[k] - sn * mb[k]; Ml[q][r] = sn * ma[k] + c * mb[k];
+                        for (int k = 0; k < NR; k++) {
+                            Ml[p][lane + 64 * k] = c * ma[k] - sn * mb[k]; Ml[q][lane + 64 * k] = sn * ma[k] + c * mb[k];
                         }
+                        if (lane == 0) { nrm[p] = ap - t * ga; nrm[q] = be + t * ga; }
+                        myrot++;
                     }
-                    if (lane == 0) atomicAdd(&nrot, 1);
-                    MGACC(57);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        MGACC(58);
+        if (lane == 0 && myrot) atomicAdd(&nrot, myrot);
     }
+    if (lane == 0 && ms2 > 0.0) { atomicMax(&crit_s[0], (unsigned long long)__double_as_longlong(mc2)); atomicMax(&crit_s[1], (unsigned long long)__double_as_longlong(ms2)); }
+    __syncthreads();
     MGSTAMP(52);
-    for (int lc = wv; lc < 2 * BS; lc += 16) {
-        const int c = gcol(lc);
-        if (c < n) for (int r = lane; r < n; r += 64) Mm[(size_t)c * n + r] = Ml[lc][r];
+    // write-back: a cross launch's p columns straight from the registers, everything else from LDS; nothing if nothing rotated
+    if (nrot && mine) {
+        double* col = Mm + (size_t)gcol(wv) * n;
+        if (bstep >= 0 && wv < BS) {
+#pragma unroll
+            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; if (r < n) col[r] = mp[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NR; k++) { const int r = lane + 64 * k; if (r < n) col[r] = Ml[wv][r]; }
+        }
     }
-    if (tid == 0 && nrot) atomicAdd(&rw[sweep], nrot);
+    if (tid == 0 && nrot) { atomicAdd(&rw[sweep], nrot); atomicMax(&crit[2 * w], crit_s[0]); atomicMax(&crit[2 * w + 1], crit_s[1]); }
     MGSTAMP(53);
+}
+
+// End of a sweep: the sweep after one whose rotations were all tiny finds nothing to rotate, and need not be run to know it.  A rotation
+// by an angle of sine s changes the inner product of either of its columns with a third column r by at most |s| times the cosine that
+// r makes with the other one; with every cosine met in the sweep <= c_max and every sine <= s_max, the cosines the sweep leaves behind
+// are below n s_max c_max.  Below the rotation threshold (1e-15) the sweep is recorded as the converged one (rot = 0): the launches
+// of the next sweep would all return at once.  At cfg5's 263-dimension tail this is the ninth sweep (of 34 launches) not run.
+__global__ void k_marg_bj_crit(const int* tail_dim, int nw, int* rot, unsigned long long* crit, const int* bj_ok, int sweep) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw || !bj_ok[w]) return;
+    const double c2 = __longlong_as_double((long long)crit[2 * w]), s2 = __longlong_as_double((long long)crit[2 * w + 1]);
+    const double n = (double)tail_dim[w];
+    int* rw = rot + (size_t)w * MG_SWEEPS;
+    if (rw[sweep] != 0 && n * n * c2 * s2 <= 1e-30) rw[sweep] = 0;
+    crit[2 * w] = 0; crit[2 * w + 1] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

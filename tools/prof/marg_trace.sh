@@ -1,19 +1,29 @@
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/mg1 && rocprofv3 --kernel-trace --output-format csv -d /tmp/mg1 -o s -- python $GRAFT_REPO_ROOT/tools/prof/marg_eigen_time.py > /tmp/mg1.log 2>&1
-python - <<'PY'
-import csv,glob
-f=glob.glob('/tmp/mg1/**/*kernel_trace.csv', recursive=True)[0]
-rows=[r for r in csv.DictReader(open(f)) if 'k_marg_bj' in r['Kernel_Name']]
-d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in rows]
-print(len(d), 'k_marg_bj launches in 4 calls')
-per=len(d)//4
-one=d[per:2*per]
-import os
-W=int(os.environ.get('LPS','34'))
-print('second call: mean duration (us) of the launches of each sweep (%d launches per sweep):'%W)
-print(' '.join('%5.1f'%(sum(one[s:s+W])/max(1,len(one[s:s+W]))) for s in range(0,len(one),W)))
-st=[int(r['Start_Timestamp']) for r in rows][per:2*per]; en=[int(r['End_Timestamp']) for r in rows][per:2*per]
-print('span of the k_marg_bj launches of one call: %.2f ms; sum of durations %.2f ms'%((en[-1]-st[0])/1e6, sum(one)/1e3))
-rows=[r for r in csv.DictReader(open(f)) if 'k_marginalize' in r['Kernel_Name']]
-print('k_marginalize launches:', [(r['Kernel_Name'][:30], (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3) for r in rows[:6]])
+#!/bin/bash
+# kernel-level account of ONE eigen marginalisation call of the cfg5 window (263-dimension tail): rocprofv3 kernel trace of
+# tools/prof/marg_eigen_time.py, the launches between the last two k_marg_rescue launches of the eigen form summed by kernel
+# usage (on the GPU box): bash tools/prof/marg_trace.sh
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/mgtr
+rocprofv3 --kernel-trace --output-format csv -d /tmp/mgtr -o r -- python $GRAFT_REPO_ROOT/tools/prof/marg_eigen_time.py > /tmp/mgtr.log 2>&1
+sed -n 2,2p /tmp/mgtr.log
+python - <<PY
+import csv, glob, collections
+f = glob.glob("/tmp/mgtr/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_marg_pchol")]
+i0 = idx[-1]
+j = i0
+while not rows[j]["Kernel_Name"].startswith("k_marg_rescue"): j -= 1
+t0 = int(rows[j]["Start_Timestamp"])
+acc = collections.OrderedDict()
+k = j
+while k < len(rows):
+    nm = rows[k]["Kernel_Name"].split("(")[0][:40]
+    if k > i0 and nm.startswith("k_marg_rescue"): break
+    d = (int(rows[k]["End_Timestamp"]) - int(rows[k]["Start_Timestamp"])) / 1e3
+    a = acc.setdefault(nm, [0, 0.0]); a[0] += 1; a[1] += d
+    last = int(rows[k]["End_Timestamp"])
+    k += 1
+for nm, (c, t) in acc.items(): print("%-42s n %4d total %8.1f us  avg %6.1f" % (nm, c, t, t / c))
+print("first launch to last end: %.1f us" % ((last - t0) / 1e3))
 PY
