@@ -311,6 +311,15 @@ __device__ __forceinline__ double grp16_sum(double v) {
     v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
     return v;
 }
+// maximum over the 16-lane row, every lane of the row ends with it (DPP row rotations)
+__device__ __forceinline__ double grp16_max(double v) {
+    v = fmax(v, row_ror<8>(v)); v = fmax(v, row_ror<4>(v)); v = fmax(v, row_ror<2>(v)); v = fmax(v, row_ror<1>(v));
+    return v;
+}
+// the value lane L holds, as a wave-uniform number (v_readlane)
+__device__ __forceinline__ double rows_lane(double v, int L) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), L), __builtin_amdgcn_readlane(__double2loint(v), L));
+}
 // sum over the four 16-lane rows of a value that is already uniform inside each row (after grp16_sum): v_readlane of lanes 0, 16, 32
 // and 48, no LDS crossbar; the result is wave-uniform.  ((row 0 + row 1) + (row 2 + row 3))
 __device__ __forceinline__ double rows4_sum(double v) {

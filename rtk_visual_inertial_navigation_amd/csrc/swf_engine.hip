@@ -1796,14 +1796,17 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
     if (big && !b->mg_M && b->pool.zeros((size_t)nw * ldn * ldn, &b->mg_M)) return fail(SWF_E_NODEVICE, "device allocation failed");
     // windows whose factorisation broke down in the tail (a marginal that is singular on the kept states): partial factorisation +
     // rank-revealing factor of A; every other window leaves this kernel at once
+    // rows of V the pivoted Cholesky (d_pivoted_chol) takes per pass over its pool: what 150 KB of LDS leave next to 25 rows of the tail
+    const int mg_rc = std::max(16, std::min(ldn, (int)((150 * 1024 / 8 - (RS_POOL + 1) * (long)ldn) / RS_POOL)));
     const int force = getenv("SWF_FORCE_MARG_RESCUE") ? 1 : 0;      // testing aid: healthy windows through the rank-deficient path too
     if (form == SWF_PRIOR_EIGEN)
         {
-            // dynamic LDS: the 16-column panel over (n_red + 1) rows, later 16 rows of the tail + its diagonal + flags
-            const size_t l1 = (size_t)(b->max_red + 1) * (RS_NB + 1), l2 = (size_t)(RS_NB + 2) * (size_t)ldn;
+            // dynamic LDS: the 16-column panel over (n_red + 1) rows, later the pivoted Cholesky's pool (24 rows of the tail), its diagonal
+            // and the staging of 24 x rc entries of V^T (rc = rows of V per pass: all of them up to 400 dimensions)
+            const size_t l1 = (size_t)(b->max_red + 1) * (RS_NB + 1), l2 = (size_t)(RS_POOL + 1) * (size_t)ldn + (size_t)RS_POOL * (size_t)mg_rc;
             const size_t lds = sizeof(double) * std::max(l1, l2);
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_marg_rescue, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      // (up to 92 KB at 640 dimensions)
-            hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), lds, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok, force, eps);
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_marg_rescue, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      // (up to 150 KB at 640 dimensions)
+            hipLaunchKernelGGL(k_marg_rescue, dim3(nw), dim3(1024), lds, b->stream, b->D, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_resb, b->mg_resok, force, eps, b->mg_J, mg_rc);
         }
     hipLaunchKernelGGL(k_marginalize<false>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
                        b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, (double*)nullptr,
@@ -1821,12 +1824,12 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
         if (getenv("SWF_MARG_ONE_WG")) phase(0);              // A/B: the single-workgroup sweeps
         else {
             phase(1);
-            hipLaunchKernelGGL(k_marg_gram, dim3((ldn * ldn + 255) / 256, nw), dim3(256), 0, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_M, b->mg_A, b->mg_resM, (const int*)b->mg_bjok);
+            hipLaunchKernelGGL(k_marg_gram, dim3((ldn * ldn + 255) / 256, nw), dim3(256), 0, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_M, b->mg_A, (const int*)b->mg_bjok);
             if (!getenv("SWF_MARG_NO_PCHOL")) {
                 // the Jacobi preconditioner: pivoted Cholesky of A into the G slab (9 sweeps instead of 16 at the 263-dimension tail)
-                const size_t lds = sizeof(double) * (size_t)(RS_NB + 2) * (size_t)ldn;
+                const size_t lds = sizeof(double) * ((size_t)(RS_POOL + 1) * (size_t)ldn + (size_t)RS_POOL * (size_t)mg_rc);
                 if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_marg_pchol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(k_marg_pchol, dim3(nw), dim3(1024), lds, b->stream, (const int*)b->mg_tail, ldn, b->mg_resM, b->mg_M, (const int*)b->mg_bjok);
+                hipLaunchKernelGGL(k_marg_pchol, dim3(nw), dim3(1024), lds, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_A, b->mg_resM, b->mg_M, (const int*)b->mg_bjok, mg_rc);
             }
             // block size by window: 8 columns up to 576 dimensions (17 workgroups per launch at 263 dimensions, 8 inner steps each; 16-column
             // blocks halve the launches but leave a step to 9 workgroups whose 16 waves share 4 SIMDs: 49 us per launch against 16), 4 above.

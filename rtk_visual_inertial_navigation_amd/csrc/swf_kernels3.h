@@ -49,78 +49,196 @@
 // Same pivots, same drops, same stopping rule; the sums run in a different order (tolerances of the parity tests unchanged).
 // ---------------------------------------------------------------------------------------------------------------------
 #define RS_NB 16
-// Diagonally pivoted outer-product Cholesky of the n x n matrix M (full symmetric, ld = n; destroyed), 16 pivots at a time, by one
-// 1024-thread workgroup: rows v_r of V (ld = n) with sum_r v_r v_r^T = M up to the pivots it drops (it stops at pivots below 1e-14 of
-// the largest; the remaining rows are zero).  LAZY inside a block (LAPACK's dpstrf): the diagonal is kept up to date pivot by pivot
-// (all the pivot choice needs), the row of a chosen pivot is formed from the untouched trailing matrix minus the block's earlier rows,
-// and the trailing matrix takes the block's rows at once.  Vb = 16 x n staging for the block's rows (LDS), or nullptr when V itself is
-// fast memory (the rows are then built in place); dg, el = n doubles each (running diagonal, 1.0 for an eliminated index).
+// Diagonally pivoted Cholesky of the n x n matrix A (full symmetric, ld = n; read only), 16 pivots at a time, by one 1024-thread
+// workgroup: rows v_r of V (ld = n) with sum_r v_r v_r^T = A up to the pivots it drops (it stops at pivots below 1e-14 of the largest;
+// the remaining rows are zero).  LEFT-LOOKING by blocks: a block starts from a POOL of candidates, the (up to) 24 largest entries of
+// the running diagonal; their rows of the Schur complement, A[p, :] - sum_r v_r[:] v_r[p] over all rows so far, are formed in LDS in one
+// pass over V; the block's (up to) 16 pivots are then taken from the pool in the order the running diagonal dictates (it is kept up to
+// date pivot by pivot: that is all the choice needs), each pivot row = its pool row minus the block's earlier rows — LDS work behind
+// ONE barrier, no trip to L2 per pivot, no trailing matrix to update (round 3: a rank-one update of the trailing matrix per pivot;
+// an earlier form of this round: a lazily updated trailing matrix, one L2 round trip per pivot + 0.5 MB streamed per block).  With 24
+// candidates for 16 places the pivots are those of full diagonal pivoting on the cfg5 prior (same rotation counts in the sweeps).
+//   !INPLACE: V in global memory (rows) with VT its transpose (the pool pass reads v_r[p] for 24 fixed p and all r: contiguous in VT),
+//             Rb = LDS pool rows (24 x n), stg = LDS staging of the pool's VT rows (24 x rc doubles, rc = rows of V per pass)
+//   INPLACE:  V itself is LDS (the small tails): pool rows and pivot rows are built in its rows, everything is read from there
+// dg = n doubles of LDS: the running diagonal, -1e300 for an eliminated (or dropped) index.
 // Two callers: the rank-deficient tails (k_marg_rescue), and the PRECONDITIONER of the Jacobi sweeps (k_marg_pchol, k_marginalize):
 // the one-sided Jacobi on the columns of a pivoted Cholesky factor (Veselic / Hari) converges in about half the sweeps the columns of
-// the unpivoted L_nn need (cfg5's 263-dimension prior: 9 against 16).
+// the unpivoted L_nn need (cfg5's 263-dimension prior: 8 against 16).
+#define RS_POOL 24                        // candidate rows held per block (16 of them at most become pivots)
+#define RS_GONE (-1e300)
 template <bool INPLACE>
-__device__ __forceinline__ void d_pivoted_chol(double* M, double* V, double* Vb_, double* dg, double* el, const int n) {
-    __shared__ double red_v[16]; __shared__ int red_i[16];
-    __shared__ double piv_s, d0_s; __shared__ int piv_i, stop_s;
+__device__ __forceinline__ void d_pivoted_chol(const double* A, double* V, double* VT, double* Rb, double* dg, double* stg, const int rc, const int n) {
+    __shared__ int cid[RS_POOL];                          // the block's candidates (indices)
+    __shared__ double cdg[RS_POOL];                       // their running diagonal entries; -2 once taken, -1 for an empty slot
+    __shared__ int ncand_s;
+    __shared__ double d0_s;
     const int tid = threadIdx.x;
     __syncthreads();
     for (int e = tid; e < n * n; e += 1024) V[e] = 0.0;
-    for (int i = tid; i < n; i += 1024) { dg[i] = M[(size_t)i * n + i]; el[i] = 0.0; }
-    if (tid == 0) stop_s = 0;
+    for (int i = tid; i < n; i += 1024) dg[i] = A[(size_t)i * n + i];
+    if (tid == 0) d0_s = -1.0;
     __syncthreads();
-    int r = 0;
-    for (int rb = 0; rb < n && !stop_s; rb += RS_NB) {
-        double* Vb = INPLACE ? V + (size_t)rb * n : Vb_;          // (a compile-time choice: the pointer keeps its address space, LDS either way)
-        int nbk = 0;                                        // pivots taken in this block
-        for (int sblk = 0; sblk < RS_NB && rb + sblk < n; sblk++) {
-            // arg max of the remaining diagonal (first index wins ties: deterministic)
-            double bv = -1.0; int bi = -1;
-            for (int i = tid; i < n; i += 1024) { double v = el[i] != 0.0 ? -1.0 : dg[i]; if (v > bv) { bv = v; bi = i; } }
-            for (int o = 32; o > 0; o >>= 1) { double ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64); if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; } }
-            if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
-            __syncthreads();
-            if (tid == 0) {
-                double v = red_v[0]; int ix = red_i[0];
-                for (int q = 1; q < 16; q++) if (red_v[q] > v || (red_v[q] == v && red_i[q] >= 0 && (ix < 0 || red_i[q] < ix))) { v = red_v[q]; ix = red_i[q]; }
-                piv_s = v; piv_i = ix;
-                if (r == 0) d0_s = v;
-                if (!(v > 1e-14 * d0_s) || !(v > 0.0) || ix < 0) stop_s = 1;      // numerically zero remainder: rank r
-            }
-            __syncthreads();
-            if (stop_s) break;
-            const int p = piv_i; const double isq = 1.0 / sqrt(piv_s);
-            // row of the pivot: the untouched trailing matrix's column p minus the block's earlier rows; zero at eliminated indices
-            for (int i = tid; i < n; i += 1024) {
-                double v = M[(size_t)p * n + i];                 // (M is kept fully symmetric: row p = column p, read along the row)
-                for (int t = 0; t < sblk; t++) v -= Vb[(size_t)t * n + i] * Vb[(size_t)t * n + p];
-                v = (el[i] != 0.0) ? 0.0 : v * isq;
-                Vb[(size_t)sblk * n + i] = v;
-            }
-            __syncthreads();
-            for (int i = tid; i < n; i += 1024) { const double v = Vb[(size_t)sblk * n + i]; dg[i] -= v * v; }
-            if (tid == 0) el[p] = 1.0;
-            __syncthreads();
-            nbk = sblk + 1; r++;
+    // thread (g, i): group 0 owns index i = tid (n <= 640) through the pivot steps; up to three groups share the passes over j (ranks)
+    // and over the rows of V (pool rows), a third of the rows each, their partial sums added in group order (deterministic)
+    const int ng = min(3, 1024 / n), g = tid / n, i = tid - g * n;
+    const bool act = g == 0, gact = g < ng;
+#ifdef SWF_PROFILE_CHOL
+    unsigned long long pc_t[6] = {0, 0, 0, 0, 0, 0}, pc_l = __builtin_amdgcn_s_memtime();
+#define PCACC(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pc_t[k] += t_ - pc_l; pc_l = t_; } while (0)
+#else
+#define PCACC(k)
+#endif
+    int r0 = 0;                                             // rows of V written
+    bool stop = false;
+    while (r0 < n && !stop) {
+        double* R = INPLACE ? V + (size_t)r0 * n : Rb;        // (a compile-time choice: the pointer keeps its address space, LDS either way)
+        // ---- the block's candidate pool: the largest entries of the running diagonal, by rank (ties: the smaller index first)
+        if (tid < RS_POOL) { cid[tid] = -1; cdg[tid] = -1.0; }
+        if (tid == 0) ncand_s = 0;
+        __syncthreads();
+        int myslot = -1;
+        const int pool = INPLACE ? min(RS_POOL, n - r0) : RS_POOL;
+        int* rk = INPLACE ? (int*)R : (int*)stg;            // n integers of LDS that are free right now
+        if (act) rk[i] = 0;
+        __syncthreads();
+        if (gact && dg[i] > 0.5 * RS_GONE) {
+            const double ki = dg[i];
+            int rank = 0;
+            const int j0 = g * n / ng, j1 = (g + 1) * n / ng;
+#pragma unroll 8
+            for (int j = j0; j < j1; j++) { const double kj = dg[j]; rank += (kj > ki) || (kj == ki && j < i); }
+            atomicAdd(&rk[i], rank);
         }
-        // the block's rows to V, and the trailing matrix takes them at once (eliminated rows / columns are never read again)
-        if (!INPLACE) for (int e = tid; e < nbk * n; e += 1024) V[(size_t)(rb) * n + e] = Vb[e];
-        if (!stop_s && rb + RS_NB < n) {
-            // (the lower triangle is formed, the mirror image copied: M stays fully symmetric for the row reads above)
-            for (int e = tid; e < n * n; e += 1024) {
-                const int i = e / n, k = e - i * n;
-                if (k > i || el[i] != 0.0 || el[k] != 0.0) continue;
-                double a = 0;
-                for (int t = 0; t < nbk; t++) a += Vb[(size_t)t * n + i] * Vb[(size_t)t * n + k];
-                const double v = M[e] - a;
-                M[e] = v; M[(size_t)k * n + i] = v;
+        __syncthreads();
+        if (act && dg[i] > 0.5 * RS_GONE) {
+            const int rank = rk[i];
+            if (rank < pool) { myslot = rank; cid[rank] = i; cdg[rank] = dg[i]; atomicAdd(&ncand_s, 1); }
+        }
+        __syncthreads();
+        if (INPLACE && act && 2 * i < n + 1) R[i] = 0.0;      // (the rank counters sat in a row of V)
+        PCACC(0);
+        const int ncand = ncand_s;                          // (ranks 0 .. ncand - 1 are all present)
+        if (ncand == 0) break;
+        if (d0_s < 0.0) { __syncthreads(); if (tid == 0) d0_s = cdg[0]; __syncthreads(); }
+        const double d0 = d0_s;
+        // ---- the pool's rows of the Schur complement: thread (g, i) forms entry i of all of them over every ng-th row of V
+        {
+            double acc[RS_POOL];
+#pragma unroll
+            for (int c = 0; c < RS_POOL; c++) acc[c] = 0.0;
+            if (INPLACE) {
+                int pc[RS_POOL];
+#pragma unroll
+                for (int c = 0; c < RS_POOL; c++) pc[c] = c < ncand ? cid[c] : 0;
+                if (gact) for (int r = g; r < r0; r += ng) {
+                    const double* row = V + (size_t)r * n;
+                    const double vi = row[i];
+#pragma unroll
+                    for (int c = 0; c < RS_POOL; c++) acc[c] -= vi * row[pc[c]];
+                }
+            } else {
+                for (int rb = 0; rb < r0; rb += rc) {
+                    const int nr_ = min(rc, r0 - rb);
+                    // stg[rr][c] = v_(rb + rr)[cid[c]], read along the rows of VT
+                    __syncthreads();
+                    for (int e = tid; e < RS_POOL * nr_; e += 1024) { const int c = e / nr_, rr = e - c * nr_; stg[rr * RS_POOL + c] = c < ncand ? __hip_atomic_load(VT + (size_t)cid[c] * n + rb + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }      // (past this CU's L1: the lines of a row of VT fill up block by block, written by other waves)
+                    __syncthreads();
+                    if (gact) {
+                        // (eight rows of V on their way at a time: a row is one L2 round trip)
+#pragma unroll 8
+                        for (int rr = g; rr < nr_; rr += ng) {
+                            const double vi = V[(size_t)(rb + rr) * n + i];
+                            const double* sp = stg + rr * RS_POOL;
+#pragma unroll
+                            for (int c = 0; c < RS_POOL; c++) acc[c] -= vi * sp[c];
+                        }
+                    }
+                }
+            }
+            for (int gg = 0; gg < ng; gg++) {
+                if (g == gg) {
+#pragma unroll
+                    for (int c = 0; c < RS_POOL; c++) if (c < ncand) R[(size_t)c * n + i] = (gg == 0 ? A[(size_t)cid[c] * n + i] : R[(size_t)c * n + i]) + acc[c];      // (A is symmetric: row p = column p, read along the row)
+                }
+                if (gg + 1 < ng) __syncthreads();
             }
         }
         __syncthreads();
+        PCACC(1);
+        unsigned long long o_lo = 0, o_hi = 0;              // slot taken at each step, a byte each (uniform)
+        auto slot_of = [&](int t) { return (int)(((t < 8 ? o_lo : o_hi) >> (8 * (t & 7))) & 255ull); };
+        int nbk = 0;
+        for (int sblk = 0; sblk < RS_NB && sblk < ncand; sblk++) {
+            // the largest running diagonal entry among the candidates not taken yet (every thread, redundantly: no broadcast step)
+            // (every wave, redundantly — no broadcast step — but lane-parallel: most of the 16 waves have no index to work on, and what
+            // they issue here competes with the waves that do.  Lane c holds candidate c; the first lane holding the maximum wins.)
+            const int ln = tid & 63;
+            const double cv = ln < RS_POOL ? cdg[ln] : -3.0;
+            const double m16 = grp16_max(cv);
+            const double bv = fmax(rows_lane(m16, 0), rows_lane(m16, 16));
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(cv == bv);
+            int bc = hit ? __builtin_ctzll(hit) : -1;
+            const int ok = (int)(bc >= 0 && bv > 1e-14 * d0 && bv > 0.0);      // uniform
+            if (!ok) { if (sblk == 0) stop = true; break; }      // numerically zero; the largest of all: rank reached
+            const int p = __builtin_amdgcn_readfirstlane(cid[bc]); const double isq = rsqrt_nr(bv);
+            // row of the pivot: its pool row minus the block's earlier rows (all requests before the first use); zero at eliminated indices
+            if (act) {
+                double v = R[(size_t)bc * n + i];
+                double xi[RS_NB], xp[RS_NB];
+#pragma unroll
+                for (int t = 0; t < RS_NB; t++) { const double* row = R + (size_t)(t < sblk ? slot_of(t) : bc) * n; xi[t] = row[i]; xp[t] = row[p]; }
+#pragma unroll
+                for (int t = 0; t < RS_NB; t++) v -= t < sblk ? xi[t] * xp[t] : 0.0;
+                const double di = dg[i];
+                const bool gone = !(di > 0.5 * RS_GONE);
+                v = gone ? 0.0 : v * isq;
+                R[(size_t)bc * n + i] = v;
+                const double d = di - v * v;
+                if (i == p) { dg[i] = RS_GONE; cdg[bc] = -2.0; }
+                else if (!gone) { dg[i] = d; if (myslot >= 0) cdg[myslot] = d; }
+            }
+            if (sblk < 8) o_lo |= (unsigned long long)bc << (8 * sblk); else o_hi |= (unsigned long long)bc << (8 * (sblk - 8));
+            nbk = sblk + 1;
+            __syncthreads();
+        }
+        PCACC(2);
+        // pool members that are numerically null by now (a running diagonal only shrinks) are dropped for good
+        if (act && myslot >= 0) { const double di = dg[i]; if (di > 0.5 * RS_GONE && !(di > 1e-14 * d0)) dg[i] = RS_GONE; }
+        if (INPLACE) {
+            // the block's rows to the front of the pool's slots, in pivot order (row swaps inside LDS: thread i moves column i)
+            for (int t = 0; t < nbk; t++) {
+                const int sl = slot_of(t);                      // uniform
+                if (sl != t) {
+                    if (act) { const double x = R[(size_t)t * n + i]; R[(size_t)t * n + i] = R[(size_t)sl * n + i]; R[(size_t)sl * n + i] = x; }
+                    // whatever pivot row sat in slot t now sits in slot sl
+                    for (int u = t + 1; u < nbk; u++) if (slot_of(u) == t) {
+                        if (u < 8) o_lo = (o_lo & ~(255ull << (8 * u))) | ((unsigned long long)sl << (8 * u));
+                        else o_hi = (o_hi & ~(255ull << (8 * (u - 8)))) | ((unsigned long long)sl << (8 * (u - 8)));
+                    }
+                    if (t < 8) o_lo = (o_lo & ~(255ull << (8 * t))) | ((unsigned long long)t << (8 * t));
+                    else o_hi = (o_hi & ~(255ull << (8 * (t - 8)))) | ((unsigned long long)t << (8 * (t - 8)));
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < (ncand - nbk) * n; e += 1024) R[(size_t)nbk * n + e] = 0.0;      // the other slots back to zero
+        } else if (act) {
+            // the block's rows to V and, transposed, to VT (thread i: 16 consecutive entries of its row of VT)
+            for (int t = 0; t < nbk; t++) { const double v = R[(size_t)slot_of(t) * n + i]; V[(size_t)(r0 + t) * n + i] = v; VT[(size_t)i * n + r0 + t] = v; }
+        }
+        r0 += nbk;
+        if (nbk == 0) stop = true;
+        __threadfence_block();
+        __syncthreads();
+        PCACC(3);
     }
     __syncthreads();
+#ifdef SWF_PROFILE_CHOL
+    if (tid == 0 && blockIdx.x == 0) for (int k = 0; k < 5; k++) g_chol_stamps[40 + k] = pc_t[k];
+#endif
 }
 
-__global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tail_dim, int ldn, double* resM, double* resb, int* res_ok, int force, double eps) {
+__global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tail_dim, int ldn, double* resM, double* resb, int* res_ok, int force, double eps, double* vt_scr, int rc) {
     extern __shared__ double rs_lds[];                  // panel: (nr + 1) x 16 | later: block rows 16 x n, diagonal n, flags n
     __shared__ double red_v[16];
     __shared__ double piv_s; __shared__ int bad_s;
@@ -214,9 +332,9 @@ __global__ void __launch_bounds__(1024) k_marg_rescue(DevBatch B, const int* tai
     for (int i = tid; i < n; i += 1024) resb[(size_t)w * ldn + i] = Wk[(size_t)nr * nr + m + i];
     __syncthreads();
     // ---- pivoted Cholesky of A, 16 pivots at a time.  V = Wk (n x n, ld = n; Wk has (nr + 1) * nr >= n * n doubles): row r of the result.
-    // LDS: Vb[16][n] the block's rows | dg[n] the running diagonal | el[n] 1.0 for an eliminated index
+    // LDS: the pool's rows 24 x n | dg[n] the running diagonal | 24 x rc staging; vt_scr = the window's (still unused) J slab for V^T
     double* V = Wk;
-    d_pivoted_chol<false>(M, V, rs_lds, rs_lds + (size_t)RS_NB * n, rs_lds + (size_t)(RS_NB + 1) * n, n);
+    d_pivoted_chol<false>(M, V, vt_scr + (size_t)w * ldn * ldn, rs_lds, rs_lds + (size_t)RS_POOL * n, rs_lds + (size_t)(RS_POOL + 1) * n, rc, n);
     __syncthreads();
     for (int e = tid; e < n * n; e += 1024) M[e] = V[e];
     if (tid == 0) res_ok[w] = 1;
@@ -233,7 +351,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     __shared__ double lds[GM ? 16 : MG_LDS_DOUBLES];  // M (n x n, column c contiguous: row c of L_nn) | V (n x n) if both fit
     __shared__ double lam[GM ? MG_BIGN : MG_MAXN + 4];
     __shared__ double bv[GM ? MG_BIGN : MG_MAXN + 4];
-    __shared__ double pc_dg[GM ? 1 : MG_MAXN + 4], pc_el[GM ? 1 : MG_MAXN + 4];      // d_pivoted_chol's running diagonal and flags
+    __shared__ double pc_dg[GM ? 1 : MG_MAXN + 4];      // d_pivoted_chol's running diagonal
     __shared__ int nrot;
     __shared__ unsigned long long crit_sh[2];
     int w = blockIdx.x, tid = threadIdx.x;
@@ -297,7 +415,6 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         double a = 0;
         for (int r = 0; r <= k; r++) a += Mc(r, i) * Mc(r, j);
         outA[o2 + e] = a;
-        if (!GM && !rescued) outJ[o2 + e] = a;            // the copy the preconditioner factors (the J slab is written last)
     }
     if (rescued) {
         for (int i = tid; i < n; i += MG_NT) { double a = resb[o1 + i]; bv[i] = a; outb[o1 + i] = a; }
@@ -322,7 +439,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     if (!GM && !rescued && phase != 2) {
         // preconditioner: G <- the pivoted Cholesky factor of A (d_pivoted_chol; the rows are built in place, G lives in LDS)
         __threadfence_block();
-        d_pivoted_chol<true>(outJ + o2, lds, nullptr, pc_dg, pc_el, n);
+        d_pivoted_chol<true>(outA + o2, lds, nullptr, nullptr, pc_dg, nullptr, 0, n);
     }
     if (phase == 1) { if (tid == 0) bj_ok[w] = rescued ? 2 : 1; return; }      // k_marg_gram, k_marg_pchol (1 only) and the sweeps of k_marg_bj follow
     int grp = tid >> 4, sub = tid & 15;
@@ -407,7 +524,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
 // A = M^T M of the large tails, one thread per entry over as many workgroups as it takes (the single workgroup of the set-up phase
 // spent 2.6 ms on the 263-dimension tail here).  Full-length sums: the zeros of a triangular M add exact zeros, so the entries are
 // those of the triangular loops above, bit for bit.
-__global__ void __launch_bounds__(256) k_marg_gram(const int* tail_dim, int ldn, const double* Mscr, double* outA, double* work, const int* bj_ok) {
+__global__ void __launch_bounds__(256) k_marg_gram(const int* tail_dim, int ldn, const double* Mscr, double* outA, const int* bj_ok) {
     const int w = blockIdx.y;
     if (!bj_ok[w]) return;
     const int n = tail_dim[w], e = blockIdx.x * 256 + threadIdx.x;
@@ -418,18 +535,17 @@ __global__ void __launch_bounds__(256) k_marg_gram(const int* tail_dim, int ldn,
     double a = 0;
     for (int r = 0; r < n; r++) a += Mc(r, i) * Mc(r, j);
     outA[o2 + e] = a;
-    if (bj_ok[w] == 1) work[o2 + e] = a;                  // the copy k_marg_pchol factors (ld = n)
 }
 // The Jacobi preconditioner of the large tails: G <- the pivoted Cholesky factor of A = G G^T (columns v_r, original row order), one
 // workgroup per window, in the window's Mscr slab (ld = n; k_marg_gram is done with the old G).  Windows whose G already is one
 // (bj_ok == 2: k_marg_rescue supplied it) pass.
-__global__ void __launch_bounds__(1024) k_marg_pchol(const int* tail_dim, int ldn, double* work, double* Mscr, const int* bj_ok) {
-    extern __shared__ double rs_lds[];                  // block rows 16 x n, diagonal n, flags n
+__global__ void __launch_bounds__(1024) k_marg_pchol(const int* tail_dim, int ldn, const double* outA, double* vt_scr, double* Mscr, const int* bj_ok, int rc) {
+    extern __shared__ double rs_lds[];                  // the pool's rows 24 x n | diagonal n | staging 24 x rc
     const int w = blockIdx.x;
     if (bj_ok[w] != 1) return;
     const int n = tail_dim[w];
     const size_t o2 = (size_t)w * ldn * ldn;
-    d_pivoted_chol<false>(work + o2, Mscr + o2, rs_lds, rs_lds + (size_t)RS_NB * n, rs_lds + (size_t)(RS_NB + 1) * n, n);
+    d_pivoted_chol<false>(outA + o2, Mscr + o2, vt_scr + o2, rs_lds, rs_lds + (size_t)RS_POOL * n, rs_lds + (size_t)(RS_POOL + 1) * n, rc, n);
 }
 template <int BS, int LDM, int NR>       // NR = rows per lane the launch's largest tail needs (n <= 64 NR <= LDM)
 __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, double* Mscr, int* rot, unsigned long long* crit, const int* bj_ok, int sweep, int bstep) {
