@@ -1811,6 +1811,8 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
     hipLaunchKernelGGL(k_marginalize<false>, dim3(nw), dim3(MG_NT), 0, b->stream, b->D, (const int*)b->mg_tail, eps, (int)form, ldn,
                        b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, (double*)nullptr,
                        (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force, 0, (int*)nullptr);
+    if (form == SWF_PRIOR_CHOLESKY)      // A = J^T J, one thread per entry (full-length sums: the zeros of the triangular J add exact zeros)
+        hipLaunchKernelGGL(k_marg_gram, dim3((ldn * ldn + 255) / 256, nw), dim3(256), 0, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_J, b->mg_A, (const int*)nullptr);
     if (big) {
         // large tails: set-up, the block-Jacobi sweeps over many workgroups (fixed launch schedule; converged windows return at once), write-out
         if (!b->mg_rot && (b->pool.zeros((size_t)nw * MG_SWEEPS, &b->mg_rot) || b->pool.zeros((size_t)nw, &b->mg_bjok) || b->pool.zeros((size_t)nw * 2, &b->mg_crit))) return fail(SWF_E_NODEVICE, "device allocation failed");

@@ -372,16 +372,10 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
         const double* Ln = L + (size_t)m * nr + m;     // L_nn[i][r] = Ln[i * nr + r]
         // J = L_nn^T first; A is then formed from J's rows, J[r][i] J[r][j] with the lanes over j: coalesced, where the same products read
         // from the L buffer stride by n_red (the 263-dimension tail of the stress window: 2.7 ms that way).  Same terms in the same order.
+        // (the reads run along the rows of L_nn.  A = J^T J follows in k_marg_gram, over the chip: this workgroup alone spent 1.4 ms on it
+        // at the 263-dimension tail)
         double* Jw = outJ + o2;
-        for (int e = tid; e < n * n; e += MG_NT) { int i = e / n, j = e - i * n; Jw[e] = (j >= i) ? Ln[(size_t)j * nr + i] : 0.0; }
-        __threadfence_block();
-        __syncthreads();
-        for (int e = tid; e < n * n; e += MG_NT) {
-            int i = e / n, j = e - i * n, k = i < j ? i : j;
-            double a = 0;
-            for (int r = 0; r <= k; r++) a += Jw[(size_t)r * n + i] * Jw[(size_t)r * n + j];
-            outA[o2 + e] = a;
-        }
+        for (int e = tid; e < n * n; e += MG_NT) { int j = e / n, i = e - j * n; Jw[(size_t)i * n + j] = (j >= i) ? Ln[(size_t)j * nr + i] : 0.0; }
         for (int r = tid; r < n; r += MG_NT) {
             double a = 0;
             for (int c = r; c < n; c++) a += Ln[(size_t)c * nr + r] * y[c];
@@ -526,7 +520,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
 // those of the triangular loops above, bit for bit.
 __global__ void __launch_bounds__(256) k_marg_gram(const int* tail_dim, int ldn, const double* Mscr, double* outA, const int* bj_ok) {
     const int w = blockIdx.y;
-    if (!bj_ok[w]) return;
+    if (bj_ok && !bj_ok[w]) return;                       // (no flags: the Cholesky form, every window)
     const int n = tail_dim[w], e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n * n) return;
     const size_t o2 = (size_t)w * ldn * ldn;

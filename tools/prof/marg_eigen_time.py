@@ -32,5 +32,5 @@ if os.environ.get("MG_STAMPS"):
     out = (C.c_ulonglong * 64)()
     solver.lib().swf_debug_chol_stamps(out)
     t = list(out)
-    print("d_pivoted_chol (core clock ticks): candidate ranks", t[40], "| candidate rows", t[41], "| pivot steps", t[42], "| compaction + copy", t[43], "| trailing update", t[44])
+    print("d_pivoted_chol (core clock ticks, wave 0): candidate ranks", t[40], "| pool rows", t[41], "| pivot steps", t[42], "| copy-out", t[43])
     print("k_marg_bj workgroup 1 of sweep 1, block step 0 (core clock ticks): load", t[51] - t[50], "| inner steps", t[52] - t[51], "| store", t[53] - t[52], "| inner steps by part: reads", t[54], "sums", t[55], "angle", t[56], "update", t[57], "barrier", t[58])
