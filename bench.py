@@ -348,6 +348,24 @@ def stress_leg(fulls, n_windows, iters):
                marginalise_41st_frame_s=t_marg, single_window=run(ws[:1], 10))
     if len(ws) > 1:
         res["batch"] = run(ws, 5)
+    # SURVEY.md 8f rank 1 at this size: the marginalisation consumer on the window GlobalMarge solves (every factor that touches frame 0,
+    # is_optimize = false), both square-root forms, wall time per call including the download of the prior (A, b, J, r0)
+    try:
+        wm, _head = cg.marginalisation_window(fulls[0])
+        bs = solver.BatchSolver([wm.copy()])
+        sm = bs.solve(default_options(step_mode=1), download=False)[0]
+        mc = dict(window="GlobalMarge's (frame 0, its speed-bias, receiver clock and first-seen landmarks marginalised)", tail_dim=int(sm.tail_dim), n_red=int(sm.reduced_dim))
+        for form, name in ((solver.BatchSolver.PRIOR_EIGEN, "eigen_form"), (solver.BatchSolver.PRIOR_CHOLESKY, "cholesky_form")):
+            ts, g = [], None
+            for _ in range(5):
+                t1 = time.perf_counter(); bs.marginalize(1e-8, form); g = bs.get_prior(0); ts.append(time.perf_counter() - t1)
+            A, J, b_, r0 = g["A"], g["J"], g["b"], g["r0"]
+            mc[name] = dict(ms_per_call=1e3 * float(np.median(ts[1:])), rank=int(g["rank"]),
+                            JtJ_vs_A=float(np.abs(J.T @ J - A).max() / np.abs(A).max()), Jtr0_vs_b=float(np.abs(J.T @ r0 - b_).max() / np.abs(b_).max()))
+        bs.close()
+        res["marginalisation_consumer"] = mc
+    except (solver.SwfError, AssertionError) as e:
+        res["marginalisation_consumer"] = dict(error=str(e))
     return res
 
 
