@@ -575,6 +575,18 @@ def test_marginalisation_consumer_matches_oracle():
     assert np.abs(g["J"].T @ g["r0"] - g["b"]).max() <= 1e-9 * np.abs(g["b"]).max()
     assert np.all(np.diff(g["eig"]) >= 0)
     bs.close()
+    # a 606-dimension tail: the 4-column blocks of k_marg_bj (tails above 576 dimensions), the pivoted Cholesky's pool pass in chunks
+    wz = synth.make_window(3, K=41, F=40, S=6, seed=35, head="frames")
+    bs, _ = gpu_solve(wz.copy(), default_options(step_mode=1))
+    bs.marginalize(1e-8, solver.BatchSolver.PRIOR_CHOLESKY)
+    c = bs.get_prior(0)
+    bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN)
+    g = bs.get_prior(0)
+    assert g["n"] == 606 and g["rank"] == 606 and np.array_equal(g["A"], c["A"]) and np.array_equal(g["b"], c["b"])
+    assert np.abs(g["J"].T @ g["J"] - g["A"]).max() <= 1e-11 * np.abs(g["A"]).max()
+    assert np.abs(g["J"].T @ g["r0"] - g["b"]).max() <= 1e-9 * np.abs(g["b"]).max()
+    assert np.abs(np.sort(g["eig"]) - np.linalg.eigvalsh(g["A"])).max() <= 1e-11 * np.abs(g["A"]).max() and np.all(np.diff(g["eig"]) >= 0)
+    bs.close()
     # a reduced system beyond 512 dimensions (k_chol_big alone; 52 frames): the prior over the ambiguities against the oracle
     wy = synth.make_window(3, K=52, F=48, S=4, seed=16, head="ambiguities")
     so, eo = ob.solve(wy.copy(), default_options(step_mode=1))
