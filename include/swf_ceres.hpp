@@ -12,7 +12,8 @@
 //
 // Mapping (reference file:line -> here):
 //   projection_factor(pts)                      R/factor/projection_factor.h:9-18     -> swf_add_projection
-//   IMUFactor(pre_integration)                  R/factor/imu_factor.h:7-19            -> swf_add_imu (SWF_PRE_DOUBLES record)
+//   IMUFactor(pre_integration)                  R/factor/imu_factor.h:7-19            -> swf_add_imu (SWF_PRE_DOUBLES record; from an
+//                                                                                        IntegrationBase* or from the record itself)
 //   RTKCarrierPhaseFactor(...)                  R/factor/gnss_factor.h:8-40           -> swf_add_rtk_carrier_phase
 //   RTKPseudorangeFactor(...)                   R/factor/gnss_factor.h:43-66          -> swf_add_rtk_pseudorange
 //   SppDopplerFactor(...)                       R/factor/gnss_factor.h:108-131        -> swf_add_doppler
@@ -23,7 +24,8 @@
 //                                               R/factor/projection_factor.h:33-66    -> swf_add_projection_inverse_depth
 //   IMUGNSSFactor(IMUGNSSBase*)                 R/factor/gnss_imu_factor.h:19-151     -> swf_add_imu_gnss (IMUGNSSInfo below)
 //   InitialBlackFactor(istd)                    R/factor/initial_factor.h:42-48       -> swf_add_scalar_prior
-//   MarginalizationFactor(info)                 R/factor/marginalization_factor.h:104-110 -> swf_add_linear_prior
+//   MarginalizationFactor(info)                 R/factor/marginalization_factor.h:104-110 -> swf_add_linear_prior (from a
+//                                                                                        MarginalizationInfo* or from J, r0, x0)
 //   ceres::internal::{parameter_head,is_optimize,lhs_out,rhs_out,lhs_out2,hs_row}
 //                                               R/swf/swf_gnss.cpp:25-94              -> swf_ceres::internal::* below
 #pragma once
@@ -34,6 +36,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 #include "swf_solver.h"
 
@@ -56,6 +59,29 @@ struct projection_factor : CostFunction {
 struct IMUFactor : CostFunction {
     std::vector<double> pre;   // SWF_PRE_DOUBLES record, see include/swf_types.h
     explicit IMUFactor(const double* record) : pre(record, record + SWF_PRE_DOUBLES) {}
+    // The reference's own constructor, IMUFactor(IntegrationBase* _pre_integration) (R/factor/imu_factor.h:11): any type with the
+    // member names of R/factor/integration_base.h:28-47 (Eigen or not: only operator()(i), operator()(i, j) and x() y() z() w() are
+    // used) is copied into the record — delta_p / delta_q / delta_v, the linearisation biases, the five bias blocks of `jacobian`
+    // (O_P = 0, O_R = 3, O_V = 6, O_BA = 9, O_BG = 12, R/factor/integration_base.h and utility.h), sum_dt, gyri / gyrj, and
+    // get_sqrtinfo() (what IMUFactor::Evaluate whitens with, R/factor/imu_factor.cpp:26).  A snapshot: re-propagate -> a new factor,
+    // as the reference does (it deletes and re-adds its IMU factors with every window, R/swf/swf_image.cpp:198-251).
+    template <class IB, class = decltype(std::declval<IB&>().delta_p(0)), class = decltype(std::declval<IB&>().get_sqrtinfo())>
+    explicit IMUFactor(IB* ib) : pre(SWF_PRE_DOUBLES, 0.0) {
+        for (int k = 0; k < 3; k++) {
+            pre[SWF_PRE_DP + k] = ib->delta_p(k); pre[SWF_PRE_DV + k] = ib->delta_v(k);
+            pre[SWF_PRE_LBA + k] = ib->linearized_ba(k); pre[SWF_PRE_LBG + k] = ib->linearized_bg(k);
+            pre[SWF_PRE_GYRI + k] = ib->gyri(k); pre[SWF_PRE_GYRJ + k] = ib->gyrj(k);
+        }
+        pre[SWF_PRE_DQ + 0] = ib->delta_q.x(); pre[SWF_PRE_DQ + 1] = ib->delta_q.y(); pre[SWF_PRE_DQ + 2] = ib->delta_q.z(); pre[SWF_PRE_DQ + 3] = ib->delta_q.w();
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            pre[SWF_PRE_DP_DBA + 3 * i + j] = ib->jacobian(0 + i, 9 + j); pre[SWF_PRE_DP_DBG + 3 * i + j] = ib->jacobian(0 + i, 12 + j);
+            pre[SWF_PRE_DQ_DBG + 3 * i + j] = ib->jacobian(3 + i, 12 + j);
+            pre[SWF_PRE_DV_DBA + 3 * i + j] = ib->jacobian(6 + i, 9 + j); pre[SWF_PRE_DV_DBG + 3 * i + j] = ib->jacobian(6 + i, 12 + j);
+        }
+        pre[SWF_PRE_SUMDT] = ib->sum_dt;
+        const auto si = ib->get_sqrtinfo();
+        for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) pre[SWF_PRE_SQRTINFO + 15 * i + j] = si(i, j);
+    }
 };
 struct RTKCarrierPhaseFactor : CostFunction {
     double dat[SWF_CP_DOUBLES];
@@ -123,6 +149,26 @@ struct MarginalizationFactor : CostFunction {
     std::vector<double> J, r0, x0;
     MarginalizationFactor(const double* J_, const double* r0_, const double* x0_, int dim, int global_sum)
         : J(J_, J_ + (size_t)dim * dim), r0(r0_, r0_ + dim), x0(x0_, x0_ + global_sum) {}
+    // The reference's own constructor, MarginalizationFactor(MarginalizationInfo*) (R/factor/marginalization_factor.h:106,
+    // .cpp:401-408): any type with its members n, m, keep_block_size (global sizes), keep_block_idx (position of the block's local
+    // dimensions among the prior's columns, offset by m), keep_block_data (the linearisation point per block), linearized_jacobians
+    // (n x n) and linearized_residuals (n), as MarginalizationFactor::Evaluate reads them (R/factor/marginalization_factor.cpp:410-446).
+    // The columns are re-filed in the order of the blocks — the order of the parameter blocks handed to AddResidualBlock, which is the
+    // order swf_add_linear_prior expects — so a keep_block_idx that does not ascend with the blocks is handled here.
+    template <class MI, class = decltype(std::declval<MI&>().keep_block_idx), class = decltype(std::declval<MI&>().linearized_jacobians(0, 0))>
+    explicit MarginalizationFactor(MI* mi) {
+        const int n = mi->n, m = mi->m, nb = (int)mi->keep_block_size.size();
+        J.assign((size_t)n * n, 0.0); r0.resize(n);
+        for (int k = 0; k < n; k++) r0[k] = mi->linearized_residuals(k);
+        int col = 0;
+        for (int b = 0; b < nb; b++) {
+            const int gs = mi->keep_block_size[b], ls = gs == 7 ? 6 : gs, idx = mi->keep_block_idx[b] - m;
+            for (int r = 0; r < n; r++) for (int c = 0; c < ls; c++) J[(size_t)r * n + col + c] = mi->linearized_jacobians(r, idx + c);
+            x0.insert(x0.end(), mi->keep_block_data[b], mi->keep_block_data[b] + gs);
+            col += ls;
+        }
+        if (col != n) throw std::invalid_argument("MarginalizationFactor: the kept blocks' local sizes do not add up to n");
+    }
 };
 
 class PoseLocalParameterization : public LocalParameterization {};   // R/factor/pose_local_parameterization.h

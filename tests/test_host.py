@@ -111,6 +111,16 @@ def test_ceres_shaped_cpp_header_compiles_and_fails_loudly_without_gpu(tmp_path)
     assert r.returncode == 1 and "Final cost: 1.000000e+300" in r.stdout
 
 
+def test_reference_constructor_signatures_of_the_adapter(tmp_path):
+    """IMUFactor(IntegrationBase*) (R/factor/imu_factor.h:11) and MarginalizationFactor(MarginalizationInfo*)
+    (R/factor/marginalization_factor.h:106): the adapter takes the reference's own objects (stand-ins with its member names and Eigen's
+    accessors here) and files their contents in the C-ABI's record layouts — the prior's columns re-ordered to the order of its blocks."""
+    import subprocess
+    exe = _compile_shim_example(tmp_path, "shim_reference_ctors")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "reference constructors: ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_globalmarge_sequence_compiles_against_the_adapter(tmp_path):
     """SWFOptimization::GlobalMarge (R/swf/swf_image.cpp:343-433) statement by statement — GetParameterBlocks, GetResidualBlocks,
     ->is_use, GetResidualBlocksForParameterBlock, GetParameterBlocksForResidualBlock, parameter_head, is_optimize — compiles
