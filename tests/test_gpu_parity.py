@@ -1400,3 +1400,27 @@ def test_windows_with_inverse_depth_landmarks_match_oracle_solver():
     sc_blocks = blocks[wins[0].n_pose + wins[0].n_sb + wins[0].n_lm:]
     assert np.array_equal(np.concatenate(sc_blocks), c.a["sc"])
     P.close()
+
+
+@pytest.mark.gpu
+def test_eigen_prior_invariants_over_tail_sizes():
+    """The eigen square root of round 4 (one-sided Jacobi on the columns of a pool-pivoted Cholesky factor) across the sizes at which its
+    blocking changes: tails of 5 .. 40 dimensions (16 pivots per block out of a pool of 24), 51 .. 126 (several blocks, LDS-resident),
+    141 and 156 (k_marg_pchol + k_marg_bj).  J^T J = A, J^T r0 = b, eigenvalues against LAPACK, the rank against the threshold, and A
+    bit-identical to the Cholesky form's."""
+    cases = [dict(K=4, F=12, S=S, head="ambiguities") for S in range(5, 41)] + [dict(K=K, F=20, S=6, head="frames") for K in range(2, 12)]
+    seen = set()
+    for kw in cases:
+        w = synth.make_window(3, seed=77 + kw["K"] + kw["S"], **kw)
+        bs, _ = gpu_solve(w.copy(), default_options(step_mode=1))
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_CHOLESKY); c = bs.get_prior(0)
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN); g = bs.get_prior(0)
+        bs.close()
+        A = g["A"]; sc = np.abs(A).max(); lam = np.linalg.eigvalsh(A)
+        assert np.array_equal(A, c["A"]) and np.array_equal(g["b"], c["b"]), kw
+        assert np.abs(g["J"].T @ g["J"] - A).max() <= 1e-12 * sc, kw
+        assert np.abs(g["J"].T @ g["r0"] - g["b"]).max() <= 1e-10 * np.abs(g["b"]).max(), kw
+        assert np.abs(np.sort(g["eig"]) - lam).max() <= 1e-12 * sc and np.all(np.diff(g["eig"]) >= 0), kw
+        assert g["rank"] == int((lam > 1e-8).sum()), kw
+        seen.add(g["n"])
+    assert set(range(5, 41)) <= seen and {141, 156} <= seen
