@@ -219,7 +219,9 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
 #ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
+            WST(j, 0);
             bool bad = rr3_pivot_factor(Dt[j & 1], colb, dinv, Dl, j >= ef, li, lk);
+            WST(j, 1);
             if (bad && lane == 0) fail = 1;
             CHACC(9, tq);
 #ifdef SWF_PROFILE_CHOL
@@ -231,11 +233,16 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
             __syncthreads();                               // B_j
             CHACC(8, tq);
 #ifdef SWF_PROFILE_CHOL
+            if (blockIdx.x == 0 && lane == 0 && j < 15) g_chol_stamps[49 + j] = __builtin_amdgcn_s_memtime();     // the pivot wave past B_j
+#endif
+#ifdef SWF_PROFILE_CHOL
             tq = __builtin_amdgcn_s_memtime();
 #endif
+            WST(j, 2);
             if (fail) { if (tid == 0) { st.lin_fail = 1; st.chol_fail = 1; } return; }
             if (lane == 0) nzm[(j + 1) & 1] = 0u;          // the next step's mask (its last readers left before B_j)
             __syncthreads();                               // C_j
+            WST(j, 3);
             CHACC(10, tq);
         }
         CHSTAMP(1);
@@ -259,6 +266,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
         __syncthreads();                                   // A_0
         for (int j = 0; j < Tc; j++) {
             rr3_pivot_inverse(Li[j], colb, dinv, li, lk);
+            WST(j, 1);
 #ifdef SWF_PROFILE_CHOL
             if (blockIdx.x == 0 && lane == 0 && j == SWF_PROFILE_CHOL_STEP) g_chol_stamps[32 + wv] = __builtin_amdgcn_s_memtime();
 #endif
@@ -367,7 +375,10 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
         if (blockIdx.x == 0 && lane == 0 && j == SWF_PROFILE_CHOL_STEP) g_chol_stamps[32 + wv] = __builtin_amdgcn_s_memtime();
 #endif
         CHACC2(28, tq2);
+        WST(j - 1, 6);
         __syncthreads();                                   // B_j: Linv_jj ready; trailing updates of step j-1 done
+        WST(j - 1, 7);
+        WST(j, 0);
         CHACC2(26, tq2);
         if (fail) return;
         // panel row j of U: U_jI = Linv_jj A_jI.  Tile (j+1, j) first, with the diagonal tile j+1 right behind it (published for the pivot).
@@ -415,12 +426,15 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
             }
         }
         CHACC2(27, tq2);
+        WST(j, 1);
         __syncthreads();                                   // C_j: panel and diagonal tile j+1 published
+        WST(j, 2);
         // trailing updates (overlap with the pivot pair's work on tile j+1): the later diagonal tiles take their term of this step
         // from the wave that holds it in registers, -A_II += U_jI^T U_jI; the off-diagonal tiles -A_JI += U_jJ^T U_jI from the panel
         CHACC2(22, tq2);
         const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)nzm[j & 1]);
         CHACC2(23, tq2);
+        WST(j, 3);
 #pragma unroll
         for (int s = 0; s < RR3_NS; s++) {
             if (sJ[s] != j) continue;
@@ -436,6 +450,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
             for (int q = 0; q < 4; q++) Dg[I][q][lane] = d[q];
         }
         CHACC2(24, tq2);
+        WST(j, 4);
 #pragma unroll
         for (int s = 0; s < RR3_NS; s++) {
             int J = sJ[s], I = sI[s];
@@ -445,6 +460,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr3(DevBatch B, int export_full) 
             for (int kk = 0; kk < 4; kk++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[J][kk][lane], Pn[I][kk][lane], acc[s], 0, 0, 0);
         }
         CHACC2(25, tq2);
+        WST(j, 5);
     }
     CHSTAMP2(20);
     // back to the row layout (lane (li, lk), register q <-> L[lk+4q][li]); export L where it is read, y = L^-1 rhs from the rhs tile row

@@ -2048,6 +2048,21 @@ extern "C" int swf_debug_chol_stamps(unsigned long long* out) {
 }
 #endif
 
+#ifdef SWF_PROFILE_CHOLW
+extern "C" int swf_debug_chol_wstep(int step) {
+    if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;
+    unsigned long long z[16 * 8] = { 0 };
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_chol_wst), z, sizeof(z)) != hipSuccess) return SWF_E_NODEVICE;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_chol_wstep), &step, sizeof(int)) != hipSuccess) return SWF_E_NODEVICE;
+    return SWF_OK;
+}
+extern "C" int swf_debug_chol_wstamps(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_wst), 16 * 8 * sizeof(unsigned long long)) != hipSuccess) return SWF_E_NODEVICE;
+    return SWF_OK;
+}
+#endif
+
 #ifdef SWF_PROFILE_DOG
 extern "C" int swf_debug_dog_stamps(unsigned long long* out) {
     if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;

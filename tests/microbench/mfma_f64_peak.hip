@@ -37,5 +37,10 @@ int main() {
     run<4>(256, "4 acc, 1 wave/SIMD");
     run<4>(512, "4 acc, 2 waves/SIMD");
     run<8>(1024, "8 acc, 4 waves/SIMD");
+    // one CU alone (the latency path's regime: does the clock / the matrix pipe behave differently when 255 CUs idle?)
+    run<1>(1, "ONE block: 1 acc (dependent)");
+    run<4>(1, "ONE block: 4 acc, 1 wave/SIMD");
+    run<4>(2, "TWO blocks: 4 acc");
+    run<8>(4, "FOUR blocks: 8 acc");
     return 0;
 }

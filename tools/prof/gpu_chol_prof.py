@@ -18,3 +18,5 @@ print("rr2 sums: pivot factor+inverse", s[9], "| wait B (trailing of others)", s
 print("rr3 tile wave 2 (ticks from kernel start): tile list", s[16]-s[0], "| loads issued + diag tiles", s[17]-s[0], "| transposed", s[18]-s[0], "| A_0", s[19]-s[0], "| loop end", s[20]-s[0], "| exported", s[21]-s[0])
 print("rr3 arrival at B_j of the profiled step, per wave, ticks after the pivot wave STARTED tile j (wave 0 = its own end; 0 = idle wave):", [int(x) - int(s[48]) if x else 0 for x in s[32:48]])
 print("rr3 tile wave 2, summed over the steps: top-of-step -> at B", s[28], "| B wait", s[26], "| panel phase", s[27], "| C wait", s[22], "| mask read", s[23], "| diagonal terms", s[24], "| trailing", s[25])
+print("rr3 pivot wave past B_j, ticks after kernel start:", [int(x) - int(s[0]) if x else 0 for x in s[49:64]])
+print("rr3 step lengths B_j -> B_j+1:", [int(s[50 + j]) - int(s[49 + j]) for j in range(14) if s[50 + j] and s[49 + j]])
