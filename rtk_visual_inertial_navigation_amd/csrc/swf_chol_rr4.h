@@ -1,0 +1,490 @@
+// swf_chol_rr4.h — k_chol_rr4 (round 5): the register-resident tiled Cholesky of the reduced system, n_red <= 240, rebuilt around
+// three measurements of this round (tests/microbench/valu_rate.hip, mfma_f64_4x4.hip, pivot_chain_ff.hip; tools/prof/chol_wprof.sh):
+//   * a lone wave issues ONE fp64 VALU instruction per ~8.5 cycles whatever the dependencies: the pivot wave of k_chol_rr3 was bound by
+//     its ~26 instructions per column (v_rsq_f64 + two Newton steps + three scalings are 12 of them), not by a latency chain;
+//   * v_mfma_f64_16x16x4_f64 issues every 64 cycles from one wave, dependent or not (the 105 cycles of rounds 3-4 were accumulator
+//     copies in the micro-benchmark's loop): four panel MFMAs are 256 cycles, and ONE wave saturates a SIMD's matrix pipe;
+//   * per-wave stamps inside k_chol_rr3: the inverse wave finished 1.8 k cycles behind the pivot wave, a tile wave spent 1.3 - 3.2 k
+//     cycles per step between the barriers on ten statically unrolled slots x three phases of mostly skipped code, the read-modify-
+//     write of the pending diagonal tiles in LDS, and three LDS round trips.
+// What changed against k_chol_rr3 (same mathematics, same elimination order, same tile layout U = L^T in the MFMA accumulator layout):
+//   * FRACTION-FREE PIVOT.  The diagonal tile is carried as M^(c) = s_c A^(c) (A^(c) = the Schur complement after c columns):
+//         M^(c+1) = (dp M^(c) - col row^T) 2^-e,   dp = M^(c)_cc = m 2^e, m in [1, 2)        (exponent arithmetic on scalar registers)
+//     so nothing is divided and no square root is taken while the columns are eliminated: 19 instructions per column instead of 26
+//     for the pivot wave, and the inverse wave (same row operations on the identity) keeps up with it.  The Cholesky scaling
+//     rho_c = 1 / sqrt(s_c dp_c) of ALL sixteen columns is one lane-parallel rsqrt at the end of the tile (s_c by a DPP prefix
+//     product); the panel product applies it to its A operand.  L[r][c] = M^(c)[r][c] rho_c, Linv[r][:] = R^(r)[r][:] rho_r.
+//   * ROW OWNERSHIP.  A tile wave owns whole tile rows — rows (t + 1, Tc - 1 - t) for wave t, the right-hand-side row for the last
+//     wave: at most 15 tiles, row A at acc[J], row B at acc[14 - J], every register index static once the step loop is unrolled.
+//     The pending diagonal tile of a row lives in its owner's registers (its terms are the owner's own panel tiles: no LDS
+//     read-modify-write, no hand-off); a trailing update takes one operand from LDS and the other from the owner's registers;
+//     a step is straight-line code: 2 panel products, then (Tc - 1 - j) x 2 guarded updates.
+//   * 12 waves (768 threads, 168 registers): pivot + inverse on one SIMD, eight tile waves on the other three.
+// Determinism: as before, every output element is formed by one lane from the same operands in the same order.
+#pragma once
+#include <utility>
+#include <type_traits>
+
+#define R4_NT 768
+// NS = tiles per tile wave = the most tile columns the instance takes: 14 (n_red <= 224: no register spills under the 168-register
+// budget of twelve waves) or 15 (224 < n_red <= 240).  A launch of each covers a batch; every window belongs to exactly one.
+
+// pivot wave: fraction-free elimination of the published diagonal tile D (full symmetric), lane (li, lk), register q <-> M[lk+4q][li].
+// Column c: row c of M (the chain's copy, brought up to date one column ahead as in rr3_pivot_factor) is published for the
+// inverse wave — its own element c is the pivot — and flagged; rows r > c: M[r][:] <- m M[r][:] - M[r][c] (M[c][:] 2^-e).
+// Finished rows and columns are left to rot: nothing reads them again.  Both triangles stay bit-symmetric (a (b 2^-e) == b (a 2^-e)).
+__device__ __forceinline__ bool rr4_pivot(double (*D)[17], double* colb, unsigned* flagb, int li, int lk) {
+#pragma clang fp contract(off)
+    double A_[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) A_[q] = D[lk + 4 * q][li];
+    int bidx[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
+    const int pidx = (li & 3) * 4 + (li >> 2);            // row r of the tile sits at 4 (r mod 4) + r / 4: the inverse wave's lanes read their four rows as one run
+    double rowA = bperm_d(A_[0], bidx[0]);                // M[0][li]
+    double rowPre = bperm_d(A_[0], bidx[1]);              // row 1, before step 0
+    int bad = 0;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(rowA), c), lo = __builtin_amdgcn_readlane(__double2loint(rowA), c);
+        bad |= (hi < 0x00100000) | (hi >= 0x7fd00000);    // pivot <= 0, subnormal, huge, Inf or NaN
+        asm volatile("" ::: "memory");
+        colb[c * 16 + pidx] = rowA;                       // (the four rows of lanes write the same values)
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(flagb + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // releases the inverse wave (the LDS keeps a wave's operations in order)
+        asm volatile("" ::: "memory");
+        if (c == 15) break;
+        const double sg = __hiloint2double(0x7fe00000 - (hi & 0x7ff00000), 0);               // 2^-e
+        const double dpS = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);             // m
+        const double rowS = rowA * sg;
+        const double x = readlane_d(rowA, c + 1);                                            // M[c][c+1] == M[c+1][c]
+        const double rowNext = __builtin_fma(dpS, rowPre, -(x * rowS));                      // row c+1 after step c (what the register copy becomes below)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (4 * q + 3 <= c) continue;                 // every row of this register is finished
+            const double col = row_newbcast_d(A_[q], c);  // M[lk+4q][c]
+            A_[q] = __builtin_fma(dpS, A_[q], -(col * rowS));
+        }
+        if (c + 2 < 16) rowPre = bperm_d(A_[(c + 2) >> 2], bidx[(c + 2) & 3]);      // row c+2 after step c, for the column after next
+        rowA = rowNext;
+    }
+    return bad != 0;
+}
+
+// inverse wave: the same row operations on the identity, column by column behind the pivot wave:  R[r][:] <- m R[r][:] - M[r][c] (R[c][:] 2^-e)
+// for r > c.  Row r of R is final after column r - 1: Linv[r][:] = R[r][:] rho_r.  At the end of the tile, lane-parallel:
+// rho_c = 1 / sqrt(s_c dp_c), s_c = prod_{k<c} m_k (the scale the eliminations have put on M^(c)).  R goes out UNSCALED with rho
+// beside it (the panel product scales its A operand); L_jj (export only) = published rows x rho.
+__device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* rhoJ, double* colb, unsigned* flagb, double (*Dl)[17], bool want_L, int li, int lk) {
+#pragma clang fp contract(off)
+    double R_[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) R_[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
+    int bidx[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
+    double rowR = li == 0 ? 1.0 : 0.0;                    // R[0][li]
+    double rowPre = li == 1 ? 1.0 : 0.0;                  // row 1, before step 0
+#pragma unroll
+    for (int c = 0; c < 15; c++) {
+        double colv[4], dpv = 0, xv = 0;
+        const int c1 = c + 1;
+        asm volatile("" ::: "memory");
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            asm volatile("" ::: "memory");
+            const unsigned f = __hip_atomic_load(flagb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int q = 0; q < 4; q++) colv[q] = colb[c * 16 + lk * 4 + q];      // M[c][lk+4q] == M[lk+4q][c]
+            dpv = colb[c * 16 + (c & 3) * 4 + (c >> 2)];                          // the pivot (one address: a broadcast read)
+            xv = colb[c * 16 + (c1 & 3) * 4 + (c1 >> 2)];                         // M[c+1][c]
+            asm volatile("" ::: "memory");
+            if (__builtin_amdgcn_readfirstlane((int)f) != 0) break;
+            __builtin_amdgcn_s_sleep(0);
+        }
+        asm volatile("" ::: "memory");
+        const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(dpv)), lo = __builtin_amdgcn_readfirstlane(__double2loint(dpv));
+        const double sg = __hiloint2double(0x7fe00000 - (hi & 0x7ff00000), 0);
+        const double dpS = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
+        const double sR = rowR * sg;
+        const double rowNext = __builtin_fma(dpS, rowPre, -(xv * sR));            // row c+1 of R after step c
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (4 * q + 3 <= c) continue;
+            const double nv = __builtin_fma(dpS, R_[q], -(colv[q] * sR));
+            R_[q] = (4 * q > c || lk + 4 * q > c) ? nv : R_[q];                   // rows <= c are final
+        }
+        if (c + 2 < 16) rowPre = bperm_d(R_[(c + 2) >> 2], bidx[(c + 2) & 3]);   // row c+2 after step c
+        rowR = rowNext;
+    }
+    // column 15: only its pivot is needed
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        const unsigned f = __hip_atomic_load(flagb + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_readfirstlane((int)f) != 0) break;
+        __builtin_amdgcn_s_sleep(0);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = lk + 4 * q;
+        LiJ[r][li] = (li <= r) ? R_[q] : 0.0;
+    }
+    // rho: lane li takes column li.  s_li = prod_{k < li} m_k: inclusive DPP scan of m over the 16-lane row, shifted by one lane
+    const double dpl = colb[li * 16 + (li & 3) * 4 + (li >> 2)];
+    const double ml = __hiloint2double((__double2hiint(dpl) & 0x000fffff) | 0x3ff00000, __double2loint(dpl));
+    double v = ml;
+    v = v * __builtin_amdgcn_update_dpp(1.0, v, 0x111, 0xf, 0xf, false);          // row_shr:1 (lanes without a source keep 1.0)
+    v = v * __builtin_amdgcn_update_dpp(1.0, v, 0x112, 0xf, 0xf, false);
+    v = v * __builtin_amdgcn_update_dpp(1.0, v, 0x114, 0xf, 0xf, false);
+    v = v * __builtin_amdgcn_update_dpp(1.0, v, 0x118, 0xf, 0xf, false);
+    const double sl = __builtin_amdgcn_update_dpp(1.0, v, 0x111, 0xf, 0xf, false);
+    const double rho = rsqrt_nr(sl * dpl);
+    rhoJ[li] = rho;                                       // (the four rows of lanes write the same values)
+    if (want_L) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int r = lk + 4 * q; Dl[r][li] = (li <= r) ? colb[li * 16 + lk * 4 + q] * rho : 0.0; }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if ((threadIdx.x & 63) < 16) __hip_atomic_store(flagb + (threadIdx.x & 63), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // flags back to "not yet" (the pivot wave starts the next tile two barriers from here)
+    asm volatile("" ::: "memory");
+}
+
+// one tile of S into the (row-major) accumulator layout, lane (li, lk), register q <-> S[16 I + lk + 4q][16 J + li]; tile row Tc is the
+// right-hand side (row n of the S storage) in its first row.  Branch-free addressing, values selected afterwards.
+__device__ __forceinline__ double4_t rr4_load_tile(const double* S, int n, int Tc, int I, int J, int li, int lk) {
+    double4_t a;
+    if (16 * I + 16 <= n) {
+        const double* St = S + (16 * I * n + 16 * J);
+#pragma unroll
+        for (int q = 0; q < 4; q++) a[q] = St[(lk + 4 * q) * n + li];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 16 * I + lk + 4 * q, c = 16 * J + li;
+            const bool rhs_el = I == Tc && lk + 4 * q == 0;
+            const int rr = rhs_el ? n : r;
+            const bool inside = c < n && (rhs_el || r < n);
+            const int rc = rr < n ? rr : (rhs_el ? n : n - 1), cc = c < n ? c : n - 1;
+            const double v = S[rc * n + cc];
+            a[q] = inside ? v : 0.0;
+        }
+    }
+    return a;
+}
+// a diagonal tile of S, full symmetric (S is stored lower), identity on the padding, NEGATED (the tile waves keep -A)
+__device__ __forceinline__ double4_t rr4_load_diag(const double* S, int n, int J, int li, int lk) {
+    double4_t a;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = 16 * J + lk + 4 * q, c = 16 * J + li;
+        const int rc = r < n ? r : n - 1, cc = c < n ? c : n - 1;
+        double v = S[(cc > rc) ? cc * n + rc : rc * n + cc];
+        v = (r < n && c < n) ? v : (r == c ? 1.0 : 0.0);
+        a[q] = -v;
+    }
+    return a;
+}
+
+// panel product of one tile of the step: T <- U_jI = Linv_jj A_jI (aop = -Linv rows, scaled; T holds -A_jI), published to Pn[I].
+// The row's pending diagonal tile (Dg[I] in LDS, negated, touched by the row's owner only) takes its term here when it is the NEXT
+// pivot tile and goes to Dt for the pivot wave; the other rows' after the barrier (rr4_diag_term).  Returns false for a tile that is
+// still exactly zero: it stays zero, is not published, and every product with it is skipped (the step's mask nzm).
+__device__ __forceinline__ unsigned rr4_panel(double4_t& T, const double (&aop)[4], int I, int j, int Tc, double (*Pn)[4][64], double (*Dg)[4][64],
+                                          double (*DtN)[17], unsigned* nzmj, int lane, int li, int lk) {
+    const bool crit = I == j + 1 && I < Tc;
+    double4_t d = { 0, 0, 0, 0 };
+    if (crit) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) d[q] = Dg[I][q][lane];
+    }
+    const bool tnz = __ballot((T[0] != 0.0) | (T[1] != 0.0) | (T[2] != 0.0) | (T[3] != 0.0)) != 0ull;
+    if (!tnz) {
+        if (crit) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) DtN[lk + 4 * q][li] = -d[q];          // the next diagonal tile takes nothing from this step
+        }
+        return 0u;
+    }
+    if (lane == 0) atomicOr(nzmj, 1u << I);
+    double4_t X = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], T[kk], X, 0, 0, 0);
+    T = X;
+    if (crit) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(X[kk], X[kk], d, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) DtN[lk + 4 * q][li] = -d[q];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) Pn[I][kk][lane] = X[kk];
+    return 1u;
+}
+// a later diagonal tile takes the step's term from its row's panel tile X (the row's owner is the only wave that touches Dg[I])
+__device__ __forceinline__ void rr4_diag_term(const double4_t& X, int I, double (*Dg)[4][64], int lane) {
+    double4_t d;
+#pragma unroll
+    for (int q = 0; q < 4; q++) d[q] = Dg[I][q][lane];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(X[kk], X[kk], d, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) Dg[I][q][lane] = d[q];
+}
+
+template <class F, int... Js>
+__device__ __forceinline__ void rr4_steps(F& f, std::integer_sequence<int, Js...>) { (void)(f(std::integral_constant<int, Js>{}) && ...); }
+
+template <int R4_NS>
+__global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full) {
+    __shared__ double Pn[16][4][64];           // published panel tiles of the step, registers as they are: Pn[I][kk][lane]; the transposition scratch before / after the loop
+    __shared__ double Dg[16][4][64];           // the rows' pending diagonal tiles, negated, accumulator layout as it is: Dg[I][q][lane] (owner-private)
+    __shared__ double Li[16][16][17];          // R of every step (Linv_jj = diag(rho) R; the backward pass multiplies by them again)
+    __shared__ double rho[16][16];
+    __shared__ double Dt[2][16][17];           // published diagonal tiles, double-buffered
+    __shared__ double Dl[16][17];              // L_jj on its way to HBM (export only)
+    __shared__ double colb[16 * 16];           // pivot pair: row c of the tile being factored, per column
+    __shared__ unsigned flagb[16];             //             "column c is published"
+    __shared__ double zs[256];
+    __shared__ double yv[256];
+    __shared__ int wsimd[16];
+    __shared__ unsigned nzm[2];                // bit I: panel tile (I, j) of the step is not all zero (double-buffered by step parity)
+    __shared__ int fail;
+    const int w = blockIdx.x;
+    WinState& st = B.ws[w];
+    if (!st.need_lin || st.lin_fail) return;
+    const WinRec& W = B.win[w];
+    const int n = W.n_red, tid = threadIdx.x;
+    if (n <= 0 || n > 240) return;                 // larger windows of a mixed batch belong to k_chol_big (launched next to this one)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int Tc = (n + 15) >> 4;
+    if (R4_NS == 14 ? Tc > 14 : Tc != 15) return;  // the other instance's window
+    const int NW = (Tc >> 1) + 1;                  // tile waves: ceil((Tc - 1) / 2) row pairs + the right-hand-side row
+    // first tile row / column whose factor is written out: everything, or the parameter_head tail block, or nothing
+    const int ef = export_full ? 0 : (W.tail_dim > 0 ? (n - W.tail_dim) >> 4 : Tc);
+    double* Lrm = B.L + W.Lt_base;
+    CHSTAMP(0);
+    if (tid == 0) { fail = 0; nzm[0] = 0u; nzm[1] = 0u; }
+    if (tid < 16) flagb[tid] = 0u;
+    for (int e = tid; e < 256; e += R4_NT) zs[e] = 0.0;
+    // Roles by SIMD (HW_ID): wave 0 is the pivot wave, the first other wave on its SIMD the inverse wave; the tile waves come from
+    // the other SIMDs first (fp64 MFMAs and fp64 VALU instructions of one SIMD do not overlap), the rest leave.
+    if (lane == 0) wsimd[wv] = (int)__builtin_amdgcn_s_getreg(2308);       // HW_REG_HW_ID, SIMD_ID (bits 5:4)
+    __syncthreads();                                       // R
+    int role, tw;                                          // role 0 pivot, 1 inverse, 2 tile wave tw, 3 none
+    {
+        const int nwv = R4_NT / 64;
+        const int ps = wsimd[0];
+        const unsigned all = (1u << nwv) - 2u;                                                                   // waves 1 .. nwv-1
+        const unsigned onp = (unsigned)__ballot(lane >= 1 && lane < nwv && wsimd[lane & 15] == ps) & all;        // other waves on the pivot's SIMD
+        const unsigned rbit = onp ? (onp & (0u - onp)) : 2u;                                                     // the inverse wave
+        unsigned rest = onp & ~rbit, tiles = all & ~onp & ~rbit;
+        while (__popc(tiles) > NW) tiles &= ~(1u << (31 - __clz(tiles)));                                        // more than needed: drop the last ones
+        for (int need = NW - __popc(tiles); need > 0 && rest; need--) { unsigned b = rest & (0u - rest); tiles |= b; rest &= ~b; }
+        const unsigned me = 1u << wv;
+        role = wv == 0 ? 0 : (rbit & me) ? 1 : (tiles & me) ? 2 : 3;
+        tw = __popc(tiles & (me - 1u));
+    }
+    if (role == 3) return;
+    if (role == 0) {
+        // =============================== pivot wave ===============================
+        __syncthreads();                                   // A_0: tile (0,0) published
+        CHSTAMP(3);
+        for (int j = 0; j < Tc; j++) {
+            WST(j, 0);
+            const bool bad = rr4_pivot(Dt[j & 1], colb, flagb, li, lk);
+            WST(j, 1);
+            if (bad && lane == 0) fail = 1;
+            __syncthreads();                               // B_j
+#ifdef SWF_PROFILE_CHOL
+            if (blockIdx.x == 0 && lane == 0 && j < 15) g_chol_stamps[49 + j] = __builtin_amdgcn_s_memtime();
+#endif
+            WST(j, 2);
+            if (fail) { if (tid == 0) { st.lin_fail = 1; st.chol_fail = 1; } return; }
+            if (lane == 0) nzm[(j + 1) & 1] = 0u;          // the next step's mask (its last readers left before B_j)
+            __syncthreads();                               // C_j
+            WST(j, 3);
+        }
+        CHSTAMP(1);
+        __syncthreads();                                   // E: L exported, yv ready
+        CHSTAMP(4);
+        // backward solve y = L^-T z, right-looking: yv holds z; once y_J is known the owner of tile row J subtracts
+        // L_{J,J'}^T y_J from the pending blocks J' < J.  Here: y_J = Linv_JJ^T yv_J on all 64 lanes
+        for (int J = Tc - 1; J >= 0; J--) {
+            double p = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) p += Li[J][lk + 4 * q][li] * (rho[J][lk + 4 * q] * yv[16 * J + lk + 4 * q]);
+            atomicAdd(&zs[16 * J + li], p);                // ds_add_f64: the four row groups of lanes add into the (zeroed) slot
+            __syncthreads();                               // X_J: y_J published
+            __syncthreads();                               // Y_J: row J applied to the pending blocks
+        }
+        CHSTAMP(2);
+        return;
+    }
+    if (role == 1) {
+        // =============================== inverse wave ===============================
+        __syncthreads();                                   // A_0
+        for (int j = 0; j < Tc; j++) {
+            rr4_inverse(Li[j], rho[j], colb, flagb, Dl, j >= ef, li, lk);
+            WST(j, 1);
+            __syncthreads();                               // B_j
+            if (fail) return;
+            if (j >= ef) {
+                // L_jj to HBM (nothing overwrites Dl before the next tile's end)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int r = 16 * j + lk + 4 * q, c = 16 * j + li;
+                    if (r < n && c <= r) Lrm[(size_t)r * n + c] = Dl[lk + 4 * q][li];
+                }
+            }
+            __syncthreads();                               // C_j
+        }
+        __syncthreads();                                   // E
+        for (int J = Tc - 1; J >= 0; J--) { __syncthreads(); __syncthreads(); }
+        return;
+    }
+    // =============================== tile waves ===============================
+    const double* S = B.S + W.S_base;
+    double* Xs = &Pn[0][0][0] + tw * 272;                  // wave-private transposition scratch
+    const bool isrhs = tw == NW - 1;
+    const int Ia = isrhs ? Tc : tw + 1;                    // row A: tiles (Ia, J), J < Ia, at acc[J]
+    const int Ib = (!isrhs && Tc - 1 - tw > tw + 1) ? Tc - 1 - tw : 0;      // row B: tiles (Ib, J), J < Ib, at acc[14 - J]
+    const unsigned rmA = (1u << Ia) - 1u, rmB = (1u << Ib) - 1u;      // the columns of rows A and B
+    double4_t acc[R4_NS];
+    CHSTAMP2(16);
+#pragma unroll
+    for (int J = 0; J < R4_NS; J++) {
+        // (rows A and B never share a slot: Ia + Ib <= Tc <= 15)
+        if (J < Ia) acc[J] = rr4_load_tile(S, n, Tc, Ia, J, li, lk);
+        else if (R4_NS - 1 - J < Ib) acc[J] = rr4_load_tile(S, n, Tc, Ib, R4_NS - 1 - J, li, lk);
+        else acc[J] = double4_t{ 0, 0, 0, 0 };
+    }
+    if (!isrhs) {
+        const double4_t d = rr4_load_diag(S, n, Ia, li, lk);
+#pragma unroll
+        for (int q = 0; q < 4; q++) Dg[Ia][q][lane] = d[q];
+    }
+    if (Ib) {
+        const double4_t d = rr4_load_diag(S, n, Ib, li, lk);
+#pragma unroll
+        for (int q = 0; q < 4; q++) Dg[Ib][q][lane] = d[q];
+    }
+    if (isrhs) {
+        const double4_t d0 = rr4_load_diag(S, n, 0, li, lk);
+#pragma unroll
+        for (int q = 0; q < 4; q++) Dt[0][lk + 4 * q][li] = -d0[q];
+    }
+    CHSTAMP2(17);
+    // negated, into the transposed layout
+#pragma unroll
+    for (int J = 0; J < R4_NS; J++)
+        if (J < Ia || R4_NS - 1 - J < Ib) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[J][q] = -acc[J][q];
+            rr3_transpose(acc[J], Xs, li, lk);
+        }
+    CHSTAMP2(18);
+    __syncthreads();                                       // A_0
+    CHSTAMP2(19);
+    // one step, j a compile-time constant (every register index below is static); false ends the factorisation (j == Tc, or a failed pivot)
+    auto step = [&](auto jc) -> bool {
+        constexpr int j = decltype(jc)::value;
+        if (j >= Tc) return false;
+        WST(j - 1, 6);
+        __syncthreads();                                   // B_j: Linv_jj ready; trailing updates of step j-1 done
+        WST(j - 1, 7);
+        WST(j, 0);
+        if (fail) return false;
+        const bool pa = j < Ia, pb = j < Ib;
+        unsigned nza = 0u, nzb = 0u;                       // this step's panel tiles are not zero (wave-uniform)
+        if (pa || pb) {
+            // A operand of the panel products: -Linv_jj = -diag(rho) R
+            double aop[4];
+            const double rl = rho[j][li];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) aop[kk] = -(Li[j][li][lk + 4 * kk] * rl);
+            // the row that holds the next pivot tile first
+            if (pb && Ib == j + 1) {
+                nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, Dg, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, Dg, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+            } else {
+                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, Dg, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+                if (pb) nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, Dg, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+            }
+        }
+        WST(j, 1);
+        __syncthreads();                                   // C_j: panel and diagonal tile j+1 published
+        WST(j, 2);
+        const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)nzm[j & 1]);
+        WST(j, 3);
+        // the rows' pending diagonal tiles take their term of this step (the next pivot tile took its own inside the panel phase)
+        if (nza && !isrhs && Ia > j + 1) rr4_diag_term(acc[j], Ia, Dg, lane);
+        if (nzb && Ib > j + 1) rr4_diag_term(acc[R4_NS - 1 - j], Ib, Dg, lane);
+        WST(j, 4);
+        // trailing updates -A_IJ += U_jJ^T U_jI: U_jJ from the published panel, U_jI from this wave's own registers.
+        // ma / mb: the columns J > j whose tile of row A / row B takes a term (scalar bit masks: one s_bitcmp per test)
+        const unsigned ma = nza ? (m & rmA) : 0u, mb = nzb ? (m & rmB) : 0u, mab = ma | mb;
+#pragma unroll
+        for (int J = j + 1; J < R4_NS; J++) {
+            if (!((mab >> J) & 1u)) continue;
+            double pj[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) pj[kk] = Pn[J][kk][lane];
+            if ((ma >> J) & 1u) {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[kk], acc[j][kk], acc[J], 0, 0, 0);
+            }
+            if ((mb >> J) & 1u) {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc[R4_NS - 1 - J] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[kk], acc[R4_NS - 1 - j][kk], acc[R4_NS - 1 - J], 0, 0, 0);
+            }
+        }
+        WST(j, 5);
+        return true;
+    };
+    rr4_steps(step, std::make_integer_sequence<int, R4_NS>{});
+    if (fail) return;
+    CHSTAMP2(20);
+    // back to the row layout (lane (li, lk), register q <-> L[lk+4q][li]); export L where it is read, y = L^-1 rhs from the rhs tile row
+#pragma unroll
+    for (int J = 0; J < R4_NS; J++) {
+        const bool a = J < Ia, b = R4_NS - 1 - J < Ib;
+        if (!(a || b)) continue;
+        rr3_transpose(acc[J], Xs, li, lk);
+        const int I = a ? Ia : Ib, Jc = a ? J : R4_NS - 1 - J;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 16 * I + lk + 4 * q, c = 16 * Jc + li;
+            if (I < Tc) { if (Jc >= ef && r < n) Lrm[(size_t)r * n + c] = acc[J][q]; }
+            else if (lk + 4 * q == 0) yv[c] = acc[J][q];
+        }
+    }
+    CHSTAMP2(21);
+    __syncthreads();                                       // E
+    for (int J = Tc - 1; J >= 0; J--) {
+        __syncthreads();                                   // X_J: y_J published
+        // tiles (J, J') of row J, J' < J: yv_J' -= L_{J,J'}^T y_J — all of them in the row's owner
+        if (!isrhs && (Ia == J || Ib == J)) {
+            double zq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) zq[q] = zs[16 * J + lk + 4 * q];
+            const bool a = Ia == J;
+#pragma unroll
+            for (int Jp = 0; Jp < R4_NS - 1; Jp++) {
+                if (Jp >= J) continue;
+                double p = 0;
+                if (a) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) p += acc[Jp][q] * zq[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) p += acc[R4_NS - 1 - Jp][q] * zq[q];
+                }
+                atomicAdd(&yv[16 * Jp + li], -p);          // ds_add_f64 (the tiles of row J update distinct blocks J')
+            }
+        }
+        __syncthreads();                                   // Y_J
+    }
+    double* y = B.y + W.loc_base + W.n_e;
+    for (int e = tw * 64 + lane; e < n; e += NW * 64) y[e] = zs[e];
+}

@@ -237,6 +237,8 @@ struct swf_batch {
     bool lat_fuse = false;                // latency path: fused grids on one stream (see swf_batch_create)
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
     bool chol_rr2 = false;                // SWF_CHOL_RR2=1: the previous register-resident kernel (A/B testing)
+    bool chol_rr3 = false;                // SWF_CHOL_RR3=1: round 3's k_chol_rr3 instead of k_chol_rr4 (A/B testing)
+    bool rr4_has15 = false;               // some window has 224 < n_red <= 240: the 15-column instance of k_chol_rr4 is launched as well
     bool export_L_always = false;         // SWF_EXPORT_L=1: k_chol_rr3 writes the whole factor on every solve path
     bool L_full = false;                  // the L buffer holds the whole factor of the last linear solve
     bool fs_fused = true;                 // per-frame sums inside k_eval_ps (SWF_FS_SEPARATE=1: k_frame_sums as its own launch; A/B testing)
@@ -843,6 +845,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
     b->chol_rr2 = getenv("SWF_CHOL_RR2") != nullptr;
+    b->chol_rr3 = getenv("SWF_CHOL_RR3") != nullptr;
     b->export_L_always = getenv("SWF_EXPORT_L") != nullptr;
     b->asm_old = getenv("SWF_ASM_OLD") != nullptr;
     b->post_split = getenv("SWF_POST_SPLIT") != nullptr;
@@ -868,7 +871,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         b->lm_schur_flops += 216 * k * k + 108 * k;
         b->lm_schur_flops_sym += 108 * k * (k - 1) + 162 * k;
     }
-    for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); b->min_red = std::min(b->min_red, W.n_red); }
+    for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); b->min_red = std::min(b->min_red, W.n_red); if (W.n_red > 224 && W.n_red <= 240) b->rr4_has15 = true; }
     DevBatch& D = b->D;
     DevPool& P = b->pool;
     int rc = 0;
@@ -1533,7 +1536,11 @@ struct Launcher {
             // per-window choice (each kernel skips the other's windows): register-resident tiles up to 240 dimensions, streamed above
             if (b->min_red <= 240) {
                 if (b->chol_rr2) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
-                else hipLaunchKernelGGL(k_chol_rr3, dim3(D.n_win), dim3(1024), 0, st, D, export_full ? 1 : 0);
+                else if (b->chol_rr3) hipLaunchKernelGGL(k_chol_rr3, dim3(D.n_win), dim3(1024), 0, st, D, export_full ? 1 : 0);
+                else {
+                    if (b->min_red <= 224) hipLaunchKernelGGL(k_chol_rr4<14>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
+                    if (b->rr4_has15) hipLaunchKernelGGL(k_chol_rr4<15>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
+                }
             }
             if (b->max_red > 240 && D.Wk) {
                 const int Tc = (b->max_red + 15) / 16;

@@ -556,6 +556,7 @@ __global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
 }
 
 #include "swf_chol_rr.h"
+#include "swf_chol_rr4.h"
 
 // =========================================================================================
 // k_chol_big — the same pivot / panel / look-ahead pipeline as k_chol_rr2 for 240 < n_red <= 640, where the factor
