@@ -72,64 +72,12 @@ __device__ __forceinline__ bool rr4_pivot(double (*D)[17], double* colb, unsigne
     return bad != 0;
 }
 
-// inverse wave: the same row operations on the identity, column by column behind the pivot wave:  R[r][:] <- m R[r][:] - M[r][c] (R[c][:] 2^-e)
-// for r > c.  Row r of R is final after column r - 1: Linv[r][:] = R[r][:] rho_r.  At the end of the tile, lane-parallel:
-// rho_c = 1 / sqrt(s_c dp_c), s_c = prod_{k<c} m_k (the scale the eliminations have put on M^(c)).  R goes out UNSCALED with rho
-// beside it (the panel product scales its A operand); L_jj (export only) = published rows x rho.
-__device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* rhoJ, double* colb, unsigned* flagb, double (*Dl)[17], bool want_L, int li, int lk) {
+// the Cholesky scaling of the tile, lane-parallel, by the PIVOT wave once its columns are through (the inverse wave is still catching
+// up then): lane li takes column li.  rho_li = 1 / sqrt(s_li dp_li), s_li = prod_{k < li} m_k (the scale the eliminations have put
+// on M^(li)): an inclusive DPP scan of m over the 16-lane row, shifted by one lane.  L_jj (export only) = published rows x rho.
+__device__ __forceinline__ void rr4_rho(double* rhoJ, const double* colb, double (*Dl)[17], bool want_L, int li, int lk) {
 #pragma clang fp contract(off)
-    double R_[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) R_[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
-    int bidx[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
-    double rowR = li == 0 ? 1.0 : 0.0;                    // R[0][li]
-    double rowPre = li == 1 ? 1.0 : 0.0;                  // row 1, before step 0
-#pragma unroll
-    for (int c = 0; c < 15; c++) {
-        double colv[4], dpv = 0, xv = 0;
-        const int c1 = c + 1;
-        asm volatile("" ::: "memory");
-        for (int spin = 0; spin < (1 << 22); spin++) {
-            asm volatile("" ::: "memory");
-            const unsigned f = __hip_atomic_load(flagb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-            for (int q = 0; q < 4; q++) colv[q] = colb[c * 16 + lk * 4 + q];      // M[c][lk+4q] == M[lk+4q][c]
-            dpv = colb[c * 16 + (c & 3) * 4 + (c >> 2)];                          // the pivot (one address: a broadcast read)
-            xv = colb[c * 16 + (c1 & 3) * 4 + (c1 >> 2)];                         // M[c+1][c]
-            asm volatile("" ::: "memory");
-            if (__builtin_amdgcn_readfirstlane((int)f) != 0) break;
-            __builtin_amdgcn_s_sleep(0);
-        }
-        asm volatile("" ::: "memory");
-        const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(dpv)), lo = __builtin_amdgcn_readfirstlane(__double2loint(dpv));
-        const double sg = __hiloint2double(0x7fe00000 - (hi & 0x7ff00000), 0);
-        const double dpS = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
-        const double sR = rowR * sg;
-        const double rowNext = __builtin_fma(dpS, rowPre, -(xv * sR));            // row c+1 of R after step c
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (4 * q + 3 <= c) continue;
-            const double nv = __builtin_fma(dpS, R_[q], -(colv[q] * sR));
-            R_[q] = (4 * q > c || lk + 4 * q > c) ? nv : R_[q];                   // rows <= c are final
-        }
-        if (c + 2 < 16) rowPre = bperm_d(R_[(c + 2) >> 2], bidx[(c + 2) & 3]);   // row c+2 after step c
-        rowR = rowNext;
-    }
-    // column 15: only its pivot is needed
-    for (int spin = 0; spin < (1 << 22); spin++) {
-        const unsigned f = __hip_atomic_load(flagb + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__builtin_amdgcn_readfirstlane((int)f) != 0) break;
-        __builtin_amdgcn_s_sleep(0);
-    }
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int r = lk + 4 * q;
-        LiJ[r][li] = (li <= r) ? R_[q] : 0.0;
-    }
-    // rho: lane li takes column li.  s_li = prod_{k < li} m_k: inclusive DPP scan of m over the 16-lane row, shifted by one lane
     const double dpl = colb[li * 16 + (li & 3) * 4 + (li >> 2)];
     const double ml = __hiloint2double((__double2hiint(dpl) & 0x000fffff) | 0x3ff00000, __double2loint(dpl));
     double v = ml;
@@ -143,6 +91,74 @@ __device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* rhoJ, dou
     if (want_L) {
 #pragma unroll
         for (int q = 0; q < 4; q++) { const int r = lk + 4 * q; Dl[r][li] = (li <= r) ? colb[li * 16 + lk * 4 + q] * rho : 0.0; }
+    }
+    asm volatile("" ::: "memory");
+}
+
+// inverse wave: the same row operations on the identity, column by column behind the pivot wave:  R[r][:] <- m R[r][:] - M[r][c] (R[c][:] 2^-e)
+// for r > c.  Row r of R is final after column r - 1: Linv[r][:] = R[r][:] rho_r; R goes out UNSCALED (the panel product scales its
+// A operand with the rho the pivot wave leaves beside it).  The LDS reads of column c + 1 are issued before column c is worked on:
+// when the wave runs behind the pivot wave they are there when it gets to them.
+struct rr4_col { unsigned f; double colv[4], dpv, xv; };
+__device__ __forceinline__ void rr4_fetch(rr4_col& o, const double* colb, const unsigned* flagb, int c, int lk) {
+    const int c1 = c + 1;
+    o.f = __hip_atomic_load(flagb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // first: a set flag means the reads behind it see the row
+#pragma unroll
+    for (int q = 0; q < 4; q++) o.colv[q] = colb[c * 16 + lk * 4 + q];        // M[c][lk+4q] == M[lk+4q][c]
+    o.dpv = colb[c * 16 + (c & 3) * 4 + (c >> 2)];                            // the pivot (one address: a broadcast read)
+    o.xv = colb[c * 16 + (c1 & 3) * 4 + (c1 >> 2)];                           // M[c+1][c]
+}
+__device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, unsigned* flagb, int li, int lk) {
+#pragma clang fp contract(off)
+    double R_[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) R_[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
+    int bidx[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
+    double rowR = li == 0 ? 1.0 : 0.0;                    // R[0][li]
+    double rowPre = li == 1 ? 1.0 : 0.0;                  // row 1, before step 0
+    rr4_col cur, nxt;
+    asm volatile("" ::: "memory");
+    rr4_fetch(cur, colb, flagb, 0, lk);
+#pragma unroll
+    for (int c = 0; c < 15; c++) {
+        asm volatile("" ::: "memory");
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            if (__builtin_amdgcn_readfirstlane((int)cur.f) != 0) break;
+            __builtin_amdgcn_s_sleep(0);
+            asm volatile("" ::: "memory");
+            rr4_fetch(cur, colb, flagb, c, lk);
+            asm volatile("" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+        if (c + 1 < 15) rr4_fetch(nxt, colb, flagb, c + 1, lk);
+        asm volatile("" ::: "memory");
+        const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(cur.dpv)), lo = __builtin_amdgcn_readfirstlane(__double2loint(cur.dpv));
+        const double sg = __hiloint2double(0x7fe00000 - (hi & 0x7ff00000), 0);
+        const double dpS = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
+        const double sR = rowR * sg;
+        const double rowNext = __builtin_fma(dpS, rowPre, -(cur.xv * sR));        // row c+1 of R after step c
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (4 * q + 3 <= c) continue;
+            const double nv = __builtin_fma(dpS, R_[q], -(cur.colv[q] * sR));
+            R_[q] = (4 * q > c || lk + 4 * q > c) ? nv : R_[q];                   // rows <= c are final
+        }
+        if (c + 2 < 16) rowPre = bperm_d(R_[(c + 2) >> 2], bidx[(c + 2) & 3]);   // row c+2 after step c
+        rowR = rowNext;
+        if (c + 1 < 15) cur = nxt;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = lk + 4 * q;
+        LiJ[r][li] = (li <= r) ? R_[q] : 0.0;
+    }
+    // column 15 changes nothing here; its flag is awaited so that the reset below cannot overtake it
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        const unsigned f = __hip_atomic_load(flagb + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_readfirstlane((int)f) != 0) break;
+        __builtin_amdgcn_s_sleep(0);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -190,14 +206,9 @@ __device__ __forceinline__ double4_t rr4_load_diag(const double* S, int n, int J
 // The row's pending diagonal tile (Dg[I] in LDS, negated, touched by the row's owner only) takes its term here when it is the NEXT
 // pivot tile and goes to Dt for the pivot wave; the other rows' after the barrier (rr4_diag_term).  Returns false for a tile that is
 // still exactly zero: it stays zero, is not published, and every product with it is skipped (the step's mask nzm).
-__device__ __forceinline__ unsigned rr4_panel(double4_t& T, const double (&aop)[4], int I, int j, int Tc, double (*Pn)[4][64], double (*Dg)[4][64],
+__device__ __forceinline__ unsigned rr4_panel(double4_t& T, const double (&aop)[4], int I, int j, int Tc, double (*Pn)[4][64], double4_t d /* Dg[j+1], fetched ahead of the barrier */,
                                           double (*DtN)[17], unsigned* nzmj, int lane, int li, int lk) {
     const bool crit = I == j + 1 && I < Tc;
-    double4_t d = { 0, 0, 0, 0 };
-    if (crit) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) d[q] = Dg[I][q][lane];
-    }
     const bool tnz = __ballot((T[0] != 0.0) | (T[1] != 0.0) | (T[2] != 0.0) | (T[3] != 0.0)) != 0ull;
     if (!tnz) {
         if (crit) {
@@ -267,8 +278,8 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     if (tid == 0) { fail = 0; nzm[0] = 0u; nzm[1] = 0u; }
     if (tid < 16) flagb[tid] = 0u;
     for (int e = tid; e < 256; e += R4_NT) zs[e] = 0.0;
-    // Roles by SIMD (HW_ID): wave 0 is the pivot wave, the first other wave on its SIMD the inverse wave; the tile waves come from
-    // the other SIMDs first (fp64 MFMAs and fp64 VALU instructions of one SIMD do not overlap), the rest leave.
+    // Roles by SIMD (HW_ID): wave 0 is the pivot wave and keeps its SIMD to itself (fp64 MFMAs and fp64 VALU instructions of one SIMD
+    // do not overlap); the inverse wave and the tile waves come from the other SIMDs, the rest leave.
     if (lane == 0) wsimd[wv] = (int)__builtin_amdgcn_s_getreg(2308);       // HW_REG_HW_ID, SIMD_ID (bits 5:4)
     __syncthreads();                                       // R
     int role, tw;                                          // role 0 pivot, 1 inverse, 2 tile wave tw, 3 none
@@ -277,8 +288,12 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         const int ps = wsimd[0];
         const unsigned all = (1u << nwv) - 2u;                                                                   // waves 1 .. nwv-1
         const unsigned onp = (unsigned)__ballot(lane >= 1 && lane < nwv && wsimd[lane & 15] == ps) & all;        // other waves on the pivot's SIMD
-        const unsigned rbit = onp ? (onp & (0u - onp)) : 2u;                                                     // the inverse wave
-        unsigned rest = onp & ~rbit, tiles = all & ~onp & ~rbit;
+        // The inverse wave sits on ANOTHER SIMD than the pivot wave: both are bound by the instructions they issue (one fp64 instruction per
+        // ~8.5 cycles each alone, ~4.8 per SIMD), and on one SIMD the younger of the two fell 3.5 k cycles behind per tile.  The tile waves
+        // take the remaining waves off the pivot's SIMD; the pivot's SIMD gives some only if the others do not suffice.
+        const unsigned off = all & ~onp;
+        const unsigned rbit = off ? (1u << (31 - __clz(off))) : onp ? (onp & (0u - onp)) : 2u;                       // the inverse wave: the LAST wave off the pivot's SIMD
+        unsigned rest = onp & ~rbit, tiles = off & ~rbit;
         while (__popc(tiles) > NW) tiles &= ~(1u << (31 - __clz(tiles)));                                        // more than needed: drop the last ones
         for (int need = NW - __popc(tiles); need > 0 && rest; need--) { unsigned b = rest & (0u - rest); tiles |= b; rest &= ~b; }
         const unsigned me = 1u << wv;
@@ -294,6 +309,7 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
             WST(j, 0);
             const bool bad = rr4_pivot(Dt[j & 1], colb, flagb, li, lk);
             WST(j, 1);
+            rr4_rho(rho[j], colb, Dl, j >= ef, li, lk);
             if (bad && lane == 0) fail = 1;
             __syncthreads();                               // B_j
 #ifdef SWF_PROFILE_CHOL
@@ -325,7 +341,7 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         // =============================== inverse wave ===============================
         __syncthreads();                                   // A_0
         for (int j = 0; j < Tc; j++) {
-            rr4_inverse(Li[j], rho[j], colb, flagb, Dl, j >= ef, li, lk);
+            rr4_inverse(Li[j], colb, flagb, li, lk);
             WST(j, 1);
             __syncthreads();                               // B_j
             if (fail) return;
@@ -390,6 +406,12 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     auto step = [&](auto jc) -> bool {
         constexpr int j = decltype(jc)::value;
         if (j >= Tc) return false;
+        // the next pivot tile's pending value is final since this wave's own update of step j-1: fetched ahead of the barrier by its row's owner
+        double4_t dn = { 0, 0, 0, 0 };
+        if (j + 1 < Tc && (Ia == j + 1 || Ib == j + 1)) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) dn[q] = Dg[j + 1][q][lane];
+        }
         WST(j - 1, 6);
         __syncthreads();                                   // B_j: Linv_jj ready; trailing updates of step j-1 done
         WST(j - 1, 7);
@@ -405,11 +427,11 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
             for (int kk = 0; kk < 4; kk++) aop[kk] = -(Li[j][li][lk + 4 * kk] * rl);
             // the row that holds the next pivot tile first
             if (pb && Ib == j + 1) {
-                nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, Dg, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
-                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, Dg, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+                nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
             } else {
-                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, Dg, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
-                if (pb) nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, Dg, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+                if (pb) nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
             }
         }
         WST(j, 1);
