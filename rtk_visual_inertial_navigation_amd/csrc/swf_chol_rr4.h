@@ -33,7 +33,7 @@
 // Column c: row c of M (the chain's copy, brought up to date one column ahead as in rr3_pivot_factor) is published for the
 // inverse wave — its own element c is the pivot — and flagged; rows r > c: M[r][:] <- m M[r][:] - M[r][c] (M[c][:] 2^-e).
 // Finished rows and columns are left to rot: nothing reads them again.  Both triangles stay bit-symmetric (a (b 2^-e) == b (a 2^-e)).
-__device__ __forceinline__ bool rr4_pivot(double (*D)[17], double* colb, unsigned* flagb, int li, int lk) {
+__device__ __forceinline__ bool rr4_pivot(double (*D)[17], double* colb, unsigned* flagb, int li, int lk, bool prof = false) {
 #pragma clang fp contract(off)
     double A_[4];
 #pragma unroll
@@ -47,6 +47,7 @@ __device__ __forceinline__ bool rr4_pivot(double (*D)[17], double* colb, unsigne
     int bad = 0;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
+        CST(prof, c);
         const int hi = __builtin_amdgcn_readlane(__double2hiint(rowA), c), lo = __builtin_amdgcn_readlane(__double2loint(rowA), c);
         bad |= (hi < 0x00100000) | (hi >= 0x7fd00000);    // pivot <= 0, subnormal, huge, Inf or NaN
         asm volatile("" ::: "memory");
@@ -59,15 +60,19 @@ __device__ __forceinline__ bool rr4_pivot(double (*D)[17], double* colb, unsigne
         const double dpS = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);             // m
         const double rowS = rowA * sg;
         const double x = readlane_d(rowA, c + 1);                                            // M[c][c+1] == M[c+1][c]
-        const double rowNext = __builtin_fma(dpS, rowPre, -(x * rowS));                      // row c+1 after step c (what the register copy becomes below)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (4 * q + 3 <= c) continue;                 // every row of this register is finished
             const double col = row_newbcast_d(A_[q], c);  // M[lk+4q][c]
             A_[q] = __builtin_fma(dpS, A_[q], -(col * rowS));
         }
-        if (c + 2 < 16) rowPre = bperm_d(A_[(c + 2) >> 2], bidx[(c + 2) & 3]);      // row c+2 after step c, for the column after next
-        rowA = rowNext;
+        // row c+2 after step c goes on its way across the lanes BEFORE the row fetched a column ago is used: the LDS crossbar's
+        // ~130 cycles pass behind this column's arithmetic instead of in front of the next one's
+        double rowPreN = 0;
+        if (c + 2 < 16) rowPreN = bperm_d(A_[(c + 2) >> 2], bidx[(c + 2) & 3]);
+        asm volatile("" ::: "memory");
+        rowA = __builtin_fma(dpS, rowPre, -(x * rowS));                                      // row c+1 after step c (what the register copy has become above)
+        rowPre = rowPreN;
     }
     return bad != 0;
 }
@@ -108,7 +113,7 @@ __device__ __forceinline__ void rr4_fetch(rr4_col& o, const double* colb, const 
     o.dpv = colb[c * 16 + (c & 3) * 4 + (c >> 2)];                            // the pivot (one address: a broadcast read)
     o.xv = colb[c * 16 + (c1 & 3) * 4 + (c1 >> 2)];                           // M[c+1][c]
 }
-__device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, unsigned* flagb, int li, int lk) {
+__device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, unsigned* flagb, int li, int lk, bool prof = false) {
 #pragma clang fp contract(off)
     double R_[4];
 #pragma unroll
@@ -132,21 +137,24 @@ __device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, uns
             asm volatile("" ::: "memory");
         }
         asm volatile("" ::: "memory");
+        CST(prof, 16 + c);
         if (c + 1 < 15) rr4_fetch(nxt, colb, flagb, c + 1, lk);
         asm volatile("" ::: "memory");
         const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(cur.dpv)), lo = __builtin_amdgcn_readfirstlane(__double2loint(cur.dpv));
         const double sg = __hiloint2double(0x7fe00000 - (hi & 0x7ff00000), 0);
         const double dpS = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
         const double sR = rowR * sg;
-        const double rowNext = __builtin_fma(dpS, rowPre, -(cur.xv * sR));        // row c+1 of R after step c
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (4 * q + 3 <= c) continue;
             const double nv = __builtin_fma(dpS, R_[q], -(cur.colv[q] * sR));
             R_[q] = (4 * q > c || lk + 4 * q > c) ? nv : R_[q];                   // rows <= c are final
         }
-        if (c + 2 < 16) rowPre = bperm_d(R_[(c + 2) >> 2], bidx[(c + 2) & 3]);   // row c+2 after step c
-        rowR = rowNext;
+        double rowPreN = 0;
+        if (c + 2 < 16) rowPreN = bperm_d(R_[(c + 2) >> 2], bidx[(c + 2) & 3]);  // row c+2 after step c: on its way before the row fetched a column ago is used
+        asm volatile("" ::: "memory");
+        rowR = __builtin_fma(dpS, rowPre, -(cur.xv * sR));                        // row c+1 of R after step c
+        rowPre = rowPreN;
         if (c + 1 < 15) cur = nxt;
     }
 #pragma unroll
@@ -154,6 +162,7 @@ __device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, uns
         const int r = lk + 4 * q;
         LiJ[r][li] = (li <= r) ? R_[q] : 0.0;
     }
+    CST(prof, 31);
     // column 15 changes nothing here; its flag is awaited so that the reset below cannot overtake it
     for (int spin = 0; spin < (1 << 22); spin++) {
         const unsigned f = __hip_atomic_load(flagb + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -307,7 +316,11 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         CHSTAMP(3);
         for (int j = 0; j < Tc; j++) {
             WST(j, 0);
+#ifdef SWF_PROFILE_CHOLW
+            const bool bad = rr4_pivot(Dt[j & 1], colb, flagb, li, lk, j == g_chol_wstep);
+#else
             const bool bad = rr4_pivot(Dt[j & 1], colb, flagb, li, lk);
+#endif
             WST(j, 1);
             rr4_rho(rho[j], colb, Dl, j >= ef, li, lk);
             if (bad && lane == 0) fail = 1;
@@ -341,7 +354,11 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         // =============================== inverse wave ===============================
         __syncthreads();                                   // A_0
         for (int j = 0; j < Tc; j++) {
+#ifdef SWF_PROFILE_CHOLW
+            rr4_inverse(Li[j], colb, flagb, li, lk, j == g_chol_wstep);
+#else
             rr4_inverse(Li[j], colb, flagb, li, lk);
+#endif
             WST(j, 1);
             __syncthreads();                               // B_j
             if (fail) return;

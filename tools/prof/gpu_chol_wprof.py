@@ -22,6 +22,14 @@ for st in steps:
     print("== step", st)
     print("  wave 0 :", ", ".join("%s %d" % (names0[k], s[k] - t0) for k in range(4) if s[k]))
     print("  wave 1 : inverse end", s[8 + 1] - t0 if s[9] else 0)
+    try:
+        cs = (C.c_ulonglong * 32)()
+        solver.lib().swf_debug_chol_cstamps(cs)
+        cs = [int(x) for x in cs]
+        print("  pivot wave, column starts  :", [c - t0 for c in cs[:16]])
+        print("  inverse wave, column starts:", [c - t0 for c in cs[16:32]], "(the last = rows written)")
+    except AttributeError:
+        pass
     for wv in range(2, 16):
         r = s[wv * 8: wv * 8 + 8]
         if not any(r): continue
