@@ -176,26 +176,38 @@ __device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, uns
 }
 
 // one tile of S into the (row-major) accumulator layout, lane (li, lk), register q <-> S[16 I + lk + 4q][16 J + li]; tile row Tc is the
-// right-hand side (row n of the S storage) in its first row.  Branch-free addressing, values selected afterwards.
-__device__ __forceinline__ double4_t rr4_load_tile(const double* S, int n, int Tc, int I, int J, int li, int lk) {
-    double4_t a;
-    if (16 * I + 16 <= n) {
-        const double* St = S + (16 * I * n + 16 * J);
+// right-hand side (row n of the S storage) in its first row.  The row part of the addressing is worked out once per tile ROW
+// (rr4_rowaddr: element offset of the lane's four rows, 0 and a cleared validity bit for a row outside the matrix), a tile adds its
+// column: ~14 instructions per tile for interior and edge tiles alike (the per-element clamping of k_chol_rr3's edge path cost the
+// owners of the last matrix row and of the right-hand side 5 - 7 k cycles, and everybody else that long at the first barrier).
+struct rr4_rowaddr { int ro[4]; unsigned rv; };
+__device__ __forceinline__ rr4_rowaddr rr4_row(int n, int Tc, int I, int lk) {
+    rr4_rowaddr R; R.rv = 0u;
 #pragma unroll
-        for (int q = 0; q < 4; q++) a[q] = St[(lk + 4 * q) * n + li];
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r = 16 * I + lk + 4 * q, c = 16 * J + li;
-            const bool rhs_el = I == Tc && lk + 4 * q == 0;
-            const int rr = rhs_el ? n : r;
-            const bool inside = c < n && (rhs_el || r < n);
-            const int rc = rr < n ? rr : (rhs_el ? n : n - 1), cc = c < n ? c : n - 1;
-            const double v = S[rc * n + cc];
-            a[q] = inside ? v : 0.0;
-        }
+    for (int q = 0; q < 4; q++) {
+        const int r = 16 * I + lk + 4 * q;
+        const bool rhs_el = I == Tc && lk + 4 * q == 0;
+        const bool valid = rhs_el || (I < Tc && r < n);
+        R.ro[q] = valid ? (rhs_el ? n : r) * n : 0;
+        R.rv |= valid ? 1u << q : 0u;
     }
+    return R;
+}
+// (the loads only: what lies outside the matrix is cleared by rr4_tile_mask when the values are first touched, so that no load of
+// the wave waits behind another tile's select)
+__device__ __forceinline__ double4_t rr4_load_tile(const double* S, int n, const rr4_rowaddr& R, int J, int li) {
+    double4_t a;
+    const int c = 16 * J + li;
+    const int cc = c < n ? c : 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) a[q] = S[R.ro[q] + cc];
     return a;
+}
+// negated, and zero outside the matrix
+__device__ __forceinline__ void rr4_tile_mask(double4_t& a, int n, const rr4_rowaddr& R, int J, int li) {
+    const bool cv = 16 * J + li < n;
+#pragma unroll
+    for (int q = 0; q < 4; q++) a[q] = (cv && ((R.rv >> q) & 1u)) ? -a[q] : 0.0;
 }
 // a diagonal tile of S, full symmetric (S is stored lower), identity on the padding, NEGATED (the tile waves keep -A)
 __device__ __forceinline__ double4_t rr4_load_diag(const double* S, int n, int J, int li, int lk) {
@@ -385,12 +397,23 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     const unsigned rmA = (1u << Ia) - 1u, rmB = (1u << Ib) - 1u;      // the columns of rows A and B
     double4_t acc[R4_NS];
     CHSTAMP2(16);
+    WST(-1, 0);
+    // tiles no block pair of the window reaches are zero in S (and stay out of the load: a third of a cfg3 window's tiles — the
+    // speed-bias columns couple to few poses before the elimination fills them in): one bit per tile from the host's symbolic phase
+    unsigned tzA = ~0u, tzB = ~0u;                         // bit J: tile (Ia, J) / (Ib, J) is loaded
+    if (B.s_tnz) {
+        const unsigned* tm = B.s_tnz + (size_t)w * 4;
+        const unsigned long long m0 = (unsigned long long)tm[0] | ((unsigned long long)tm[1] << 32), m1 = (unsigned long long)tm[2] | ((unsigned long long)tm[3] << 32);
+        if (!isrhs) { const int t0 = Ia * (Ia - 1) / 2; tzA = (unsigned)(t0 < 64 ? (m0 >> t0) | (t0 ? m1 << (64 - t0) : 0ull) : m1 >> (t0 - 64)); }
+        if (Ib) { const int t0 = Ib * (Ib - 1) / 2; tzB = (unsigned)(t0 < 64 ? (m0 >> t0) | (t0 ? m1 << (64 - t0) : 0ull) : m1 >> (t0 - 64)); }
+    }
+    const rr4_rowaddr rwA = rr4_row(n, Tc, Ia, lk), rwB = rr4_row(n, Tc, Ib ? Ib : Ia, lk);
 #pragma unroll
     for (int J = 0; J < R4_NS; J++) {
         // (rows A and B never share a slot: Ia + Ib <= Tc <= 15)
-        if (J < Ia) acc[J] = rr4_load_tile(S, n, Tc, Ia, J, li, lk);
-        else if (R4_NS - 1 - J < Ib) acc[J] = rr4_load_tile(S, n, Tc, Ib, R4_NS - 1 - J, li, lk);
-        else acc[J] = double4_t{ 0, 0, 0, 0 };
+        acc[J] = double4_t{ 0, 0, 0, 0 };
+        if (J < Ia) { if ((tzA >> J) & 1u) acc[J] = rr4_load_tile(S, n, rwA, J, li); }
+        else if (R4_NS - 1 - J < Ib) { if ((tzB >> (R4_NS - 1 - J)) & 1u) acc[J] = rr4_load_tile(S, n, rwB, R4_NS - 1 - J, li); }
     }
     if (!isrhs) {
         const double4_t d = rr4_load_diag(S, n, Ia, li, lk);
@@ -408,16 +431,20 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         for (int q = 0; q < 4; q++) Dt[0][lk + 4 * q][li] = -d0[q];
     }
     CHSTAMP2(17);
+    WST(-1, 1);
     // negated, into the transposed layout
+    // (the LDS port is what bounds this phase: eight waves x 14 tiles x 2 KB written and read back = 3.6 k cycles at 128 B per cycle;
+    // batching several tiles per round trip was measured and is no faster)
 #pragma unroll
     for (int J = 0; J < R4_NS; J++)
-        if (J < Ia || R4_NS - 1 - J < Ib) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc[J][q] = -acc[J][q];
+        if (J < Ia ? ((tzA >> J) & 1u) != 0u : (R4_NS - 1 - J < Ib && ((tzB >> (R4_NS - 1 - J)) & 1u) != 0u)) {
+            if (J < Ia) rr4_tile_mask(acc[J], n, rwA, J, li); else rr4_tile_mask(acc[J], n, rwB, R4_NS - 1 - J, li);
             rr3_transpose(acc[J], Xs, li, lk);
         }
     CHSTAMP2(18);
+    WST(-1, 2);
     __syncthreads();                                       // A_0
+    WST(-1, 3);
     CHSTAMP2(19);
     // one step, j a compile-time constant (every register index below is static); false ends the factorisation (j == Tc, or a failed pivot)
     auto step = [&](auto jc) -> bool {

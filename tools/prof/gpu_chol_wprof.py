@@ -19,6 +19,13 @@ for st in steps:
     solver.lib().swf_debug_chol_wstamps(out)
     s = [int(x) for x in out]
     t0 = s[0]
+    if st < 0:
+        t0 = min(x for x in s if x)
+        print("== load phase (ticks after the first stamp): per tile wave: roles known, loads issued, transposed (at A_0), past A_0")
+        for wv in range(16):
+            r = s[wv * 8: wv * 8 + 4]
+            if any(r): print("  wave %2d:" % wv, [x - t0 if x else 0 for x in r])
+        continue
     print("== step", st)
     print("  wave 0 :", ", ".join("%s %d" % (names0[k], s[k] - t0) for k in range(4) if s[k]))
     print("  wave 1 : inverse end", s[8 + 1] - t0 if s[9] else 0)
