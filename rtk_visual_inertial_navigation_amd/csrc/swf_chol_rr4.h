@@ -53,7 +53,7 @@ __device__ __forceinline__ bool rr4_pivot(double (*D)[17], double* colb, unsigne
         asm volatile("" ::: "memory");
         colb[c * 16 + pidx] = rowA;                       // (the four rows of lanes write the same values)
         asm volatile("" ::: "memory");
-        __hip_atomic_store(flagb + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // releases the inverse wave (the LDS keeps a wave's operations in order)
+        __hip_atomic_store(flagb, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // "c + 1 columns published": releases the inverse wave (the LDS keeps a wave's operations in order)
         asm volatile("" ::: "memory");
         if (c == 15) break;
         const double sg = __hiloint2double(0x7fe00000 - (hi & 0x7ff00000), 0);               // 2^-e
@@ -102,16 +102,21 @@ __device__ __forceinline__ void rr4_rho(double* rhoJ, const double* colb, double
 
 // inverse wave: the same row operations on the identity, column by column behind the pivot wave:  R[r][:] <- m R[r][:] - M[r][c] (R[c][:] 2^-e)
 // for r > c.  Row r of R is final after column r - 1: Linv[r][:] = R[r][:] rho_r; R goes out UNSCALED (the panel product scales its
-// A operand with the rho the pivot wave leaves beside it).  The LDS reads of column c + 1 are issued before column c is worked on:
-// when the wave runs behind the pivot wave they are there when it gets to them.
-struct rr4_col { unsigned f; double colv[4], dpv, xv; };
-__device__ __forceinline__ void rr4_fetch(rr4_col& o, const double* colb, const unsigned* flagb, int c, int lk) {
+// A operand with the rho the pivot wave leaves beside it).
+// Nothing of a column waits for the LDS when the wave runs behind the pivot wave (it does: ~200 against ~160 cycles per column):
+// the pivot wave keeps ONE counter, "columns published"; this wave remembers the last value it saw (avail) and fetches the
+// published row of column c + 2 while it works on column c whenever avail says the row is there; the counter itself is re-read
+// once per column and looked at a column later.  Only a fetch that could not be issued ahead (the wave has caught up) polls.
+struct rr4_col { double colv[4], dpv, xv; };
+__device__ __forceinline__ void rr4_fetch(rr4_col& o, const double* colb, int c, int lk) {
     const int c1 = c + 1;
-    o.f = __hip_atomic_load(flagb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // first: a set flag means the reads behind it see the row
 #pragma unroll
     for (int q = 0; q < 4; q++) o.colv[q] = colb[c * 16 + lk * 4 + q];        // M[c][lk+4q] == M[lk+4q][c]
     o.dpv = colb[c * 16 + (c & 3) * 4 + (c >> 2)];                            // the pivot (one address: a broadcast read)
     o.xv = colb[c * 16 + (c1 & 3) * 4 + (c1 >> 2)];                           // M[c+1][c]
+}
+__device__ __forceinline__ int rr4_progress(const unsigned* flagb) {
+    return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flagb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
 __device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, unsigned* flagb, int li, int lk, bool prof = false) {
 #pragma clang fp contract(off)
@@ -123,22 +128,29 @@ __device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, uns
     for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
     double rowR = li == 0 ? 1.0 : 0.0;                    // R[0][li]
     double rowPre = li == 1 ? 1.0 : 0.0;                  // row 1, before step 0
-    rr4_col cur, nxt;
+    rr4_col buf[3];
+    bool ok[3] = { false, false, false };
+    int avail = 0;                                        // columns known to be published (never more than there are)
+    unsigned pv = 0u;                                     // the counter as read a column ago
     asm volatile("" ::: "memory");
-    rr4_fetch(cur, colb, flagb, 0, lk);
 #pragma unroll
     for (int c = 0; c < 15; c++) {
+        rr4_col& cur = buf[c % 3];
         asm volatile("" ::: "memory");
-        for (int spin = 0; spin < (1 << 22); spin++) {
-            if (__builtin_amdgcn_readfirstlane((int)cur.f) != 0) break;
-            __builtin_amdgcn_s_sleep(0);
+        if (c > 0) { const int a = __builtin_amdgcn_readfirstlane((int)pv); avail = a > avail ? a : avail; }
+        if (!ok[c % 3]) {
+            // not fetched ahead: wait for the column, fetch it now
+            for (int spin = 0; spin < (1 << 22) && avail <= c; spin++) { avail = rr4_progress(flagb); if (avail <= c) __builtin_amdgcn_s_sleep(0); }
             asm volatile("" ::: "memory");
-            rr4_fetch(cur, colb, flagb, c, lk);
+            rr4_fetch(cur, colb, c, lk);
             asm volatile("" ::: "memory");
         }
-        asm volatile("" ::: "memory");
         CST(prof, 16 + c);
-        if (c + 1 < 15) rr4_fetch(nxt, colb, flagb, c + 1, lk);
+        // ahead: the counter for the next column's decisions, the rows of the next two columns if they are there
+        pv = __hip_atomic_load(flagb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        if (c == 0 && c + 1 < 15) { ok[(c + 1) % 3] = avail > c + 1; if (ok[(c + 1) % 3]) rr4_fetch(buf[(c + 1) % 3], colb, c + 1, lk); }
+        if (c + 2 < 15) { ok[(c + 2) % 3] = avail > c + 2; if (ok[(c + 2) % 3]) rr4_fetch(buf[(c + 2) % 3], colb, c + 2, lk); }
         asm volatile("" ::: "memory");
         const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(cur.dpv)), lo = __builtin_amdgcn_readfirstlane(__double2loint(cur.dpv));
         const double sg = __hiloint2double(0x7fe00000 - (hi & 0x7ff00000), 0);
@@ -155,7 +167,6 @@ __device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, uns
         asm volatile("" ::: "memory");
         rowR = __builtin_fma(dpS, rowPre, -(cur.xv * sR));                        // row c+1 of R after step c
         rowPre = rowPreN;
-        if (c + 1 < 15) cur = nxt;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -163,15 +174,11 @@ __device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, uns
         LiJ[r][li] = (li <= r) ? R_[q] : 0.0;
     }
     CST(prof, 31);
-    // column 15 changes nothing here; its flag is awaited so that the reset below cannot overtake it
-    for (int spin = 0; spin < (1 << 22); spin++) {
-        const unsigned f = __hip_atomic_load(flagb + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__builtin_amdgcn_readfirstlane((int)f) != 0) break;
-        __builtin_amdgcn_s_sleep(0);
-    }
+    // column 15 changes nothing here; it is awaited so that the reset below cannot overtake the pivot wave's last count
+    for (int spin = 0; spin < (1 << 22) && avail < 16; spin++) { avail = rr4_progress(flagb); if (avail < 16) __builtin_amdgcn_s_sleep(0); }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if ((threadIdx.x & 63) < 16) __hip_atomic_store(flagb + (threadIdx.x & 63), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // flags back to "not yet" (the pivot wave starts the next tile two barriers from here)
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flagb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // back to "nothing published" (the pivot wave starts the next tile two barriers from here)
     asm volatile("" ::: "memory");
 }
 
@@ -228,8 +235,9 @@ __device__ __forceinline__ double4_t rr4_load_diag(const double* S, int n, int J
 // pivot tile and goes to Dt for the pivot wave; the other rows' after the barrier (rr4_diag_term).  Returns false for a tile that is
 // still exactly zero: it stays zero, is not published, and every product with it is skipped (the step's mask nzm).
 __device__ __forceinline__ unsigned rr4_panel(double4_t& T, const double (&aop)[4], int I, int j, int Tc, double (*Pn)[4][64], double4_t d /* Dg[j+1], fetched ahead of the barrier */,
-                                          double (*DtN)[17], unsigned* nzmj, int lane, int li, int lk) {
+                                          double (*DtN)[17], unsigned* nzmj, int lane, int li, int lk, bool prof = false) {
     const bool crit = I == j + 1 && I < Tc;
+    PST(prof && crit, 2);
     const bool tnz = __ballot((T[0] != 0.0) | (T[1] != 0.0) | (T[2] != 0.0) | (T[3] != 0.0)) != 0ull;
     if (!tnz) {
         if (crit) {
@@ -243,14 +251,17 @@ __device__ __forceinline__ unsigned rr4_panel(double4_t& T, const double (&aop)[
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], T[kk], X, 0, 0, 0);
     T = X;
+    PST(prof && crit, 3);
     if (crit) {
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(X[kk], X[kk], d, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; q++) DtN[lk + 4 * q][li] = -d[q];
     }
+    PST(prof && crit, 4);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) Pn[I][kk][lane] = X[kk];
+    PST(prof && crit, 5);
     return 1u;
 }
 // a later diagonal tile takes the step's term from its row's panel tile X (the row's owner is the only wave that touches Dg[I])
@@ -461,6 +472,12 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         WST(j - 1, 7);
         WST(j, 0);
         if (fail) return false;
+#ifdef SWF_PROFILE_CHOLW
+        const bool prof = j == g_chol_wstep && (Ia == j + 1 || Ib == j + 1);
+#else
+        const bool prof = false;
+#endif
+        PST(prof, 0);
         const bool pa = j < Ia, pb = j < Ib;
         unsigned nza = 0u, nzb = 0u;                       // this step's panel tiles are not zero (wave-uniform)
         if (pa || pb) {
@@ -469,17 +486,20 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
             const double rl = rho[j][li];
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) aop[kk] = -(Li[j][li][lk + 4 * kk] * rl);
+            PST(prof, 1);
             // the row that holds the next pivot tile first
             if (pb && Ib == j + 1) {
-                nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
-                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+                nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
+                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
             } else {
-                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
-                if (pb) nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk);
+                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
+                if (pb) nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
             }
         }
         WST(j, 1);
+        PST(prof, 6);
         __syncthreads();                                   // C_j: panel and diagonal tile j+1 published
+        PST(prof, 7);
         WST(j, 2);
         const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)nzm[j & 1]);
         WST(j, 3);

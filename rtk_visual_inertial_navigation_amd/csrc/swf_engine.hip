@@ -2076,6 +2076,11 @@ extern "C" int swf_debug_chol_wstamps(unsigned long long* out) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_wst), 16 * 8 * sizeof(unsigned long long)) != hipSuccess) return SWF_E_NODEVICE;
     return SWF_OK;
 }
+extern "C" int swf_debug_chol_pstamps(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_pst), 16 * sizeof(unsigned long long)) != hipSuccess) return SWF_E_NODEVICE;
+    return SWF_OK;
+}
 extern "C" int swf_debug_chol_cstamps(unsigned long long* out) {
     if (hipDeviceSynchronize() != hipSuccess) return SWF_E_NODEVICE;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_cst), 32 * sizeof(unsigned long long)) != hipSuccess) return SWF_E_NODEVICE;

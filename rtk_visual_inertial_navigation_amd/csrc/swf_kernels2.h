@@ -66,14 +66,25 @@ __device__ unsigned long long g_chol_stamps[64];
 // (swf_debug_chol_wstep).  slot [wave][k]; wave 0: 0 pivot start, 1 pivot end, 2 past B_j, 3 past C_j; wave 1: 1 inverse end;
 // tile waves: 0 past B_j, 1 panel done, 2 past C_j, 3 mask read, 4 diagonal terms done, 5 trailing done, 6 at B_j+1, 7 past B_j+1
 #ifdef SWF_PROFILE_CHOLW
+__device__ unsigned long long g_chol_pst[16];          // stamps inside the panel phase of the profiled step, by the wave that owns the next pivot tile
+#ifdef SWF_PROFILE_CHOLC
+#define PST(on, k) do { if ((on) && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_chol_pst[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PST(on, k)
+#endif
 __device__ unsigned long long g_chol_cst[2 * 16];      // per-column stamps of the pivot wave [0..15] and the inverse wave [16..31] in the profiled step
+#ifdef SWF_PROFILE_CHOLC      // per-column and in-panel stamps cost ~100 cycles each: only on request
 #define CST(on, k) do { if ((on) && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_chol_cst[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CST(on, k)
+#endif
 __device__ unsigned long long g_chol_wst[16 * 8];
 __device__ int g_chol_wstep;
 #define WST(step, k) do { if (blockIdx.x == 0 && (step) == g_chol_wstep && (threadIdx.x & 63) == 0) g_chol_wst[(threadIdx.x >> 6) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WST(step, k)
 #define CST(on, k)
+#define PST(on, k)
 #endif
 template <int NT>
 __global__ void __launch_bounds__(NT, NT == 256 ? CH_OCC : 4) k_chol_solve(DevBatch B) {

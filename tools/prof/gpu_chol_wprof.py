@@ -37,6 +37,13 @@ for st in steps:
         print("  inverse wave, column starts:", [c - t0 for c in cs[16:32]], "(the last = rows written)")
     except AttributeError:
         pass
+    try:
+        ps = (C.c_ulonglong * 16)()
+        solver.lib().swf_debug_chol_pstamps(ps)
+        ps = [int(x) for x in ps]
+        print("  owner of the next pivot tile: past B, A operand ready, panel entered, X done, diagonal tile published, panel published, at C, past C:", [x - t0 if x else 0 for x in ps[:8]])
+    except AttributeError:
+        pass
     for wv in range(2, 16):
         r = s[wv * 8: wv * 8 + 8]
         if not any(r): continue
