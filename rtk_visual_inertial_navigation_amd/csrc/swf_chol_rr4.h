@@ -302,7 +302,13 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int Tc = (n + 15) >> 4;
     if (R4_NS == 14 ? Tc > 14 : Tc != 15) return;  // the other instance's window
-    const int NW = (Tc >> 1) + 1;                  // tile waves: ceil((Tc - 1) / 2) row pairs + the right-hand-side row
+    // Tile rows -> tile waves (at most nine: three on each SIMD the pivot wave does not use), heaviest first: the right-hand-side row,
+    // the k longest matrix rows one each, the other m = Tc - 1 - k rows in pairs (a, m + 1 - a) (a middle row alone).  The trailing
+    // work of row I is I (I - 1) / 2 tile updates: dealt over the three SIMDs in snake order, the matrix pipes carry 159 / 150 / 146
+    // of a cfg3 window's 455 updates (pairs (t + 1, Tc - 1 - t) in wave order: 150 / 204 / 101, and the steps waited for the 204).
+    int gk = 0;
+    for (int kk = Tc - 1 < 8 ? Tc - 1 : 8; kk >= 0; kk--) if (kk + ((Tc - kk) >> 1) + 1 <= 9) { gk = kk; break; }
+    const int gm = Tc - 1 - gk, NW = 1 + gk + ((gm + 1) >> 1);      // rows left for the pairs; groups = tile waves
     // first tile row / column whose factor is written out: everything, or the parameter_head tail block, or nothing
     const int ef = export_full ? 0 : (W.tail_dim > 0 ? (n - W.tail_dim) >> 4 : Tc);
     double* Lrm = B.L + W.Lt_base;
@@ -310,8 +316,8 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     if (tid == 0) { fail = 0; nzm[0] = 0u; nzm[1] = 0u; }
     if (tid < 16) flagb[tid] = 0u;
     for (int e = tid; e < 256; e += R4_NT) zs[e] = 0.0;
-    // Roles by SIMD (HW_ID): wave 0 is the pivot wave and keeps its SIMD to itself (fp64 MFMAs and fp64 VALU instructions of one SIMD
-    // do not overlap); the inverse wave and the tile waves come from the other SIMDs, the rest leave.
+    // Roles by SIMD (HW_ID): wave 0 is the pivot wave; its SIMD takes the inverse wave and no matrix-core work (fp64 MFMAs and fp64 VALU
+    // instructions of one SIMD do not overlap); the tile waves come from the other SIMDs, the rest leave.
     if (lane == 0) wsimd[wv] = (int)__builtin_amdgcn_s_getreg(2308);       // HW_REG_HW_ID, SIMD_ID (bits 5:4)
     __syncthreads();                                       // R
     int role, tw;                                          // role 0 pivot, 1 inverse, 2 tile wave tw, 3 none
@@ -320,17 +326,28 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         const int ps = wsimd[0];
         const unsigned all = (1u << nwv) - 2u;                                                                   // waves 1 .. nwv-1
         const unsigned onp = (unsigned)__ballot(lane >= 1 && lane < nwv && wsimd[lane & 15] == ps) & all;        // other waves on the pivot's SIMD
-        // The inverse wave sits on ANOTHER SIMD than the pivot wave: both are bound by the instructions they issue (one fp64 instruction per
-        // ~8.5 cycles each alone, ~4.8 per SIMD), and on one SIMD the younger of the two fell 3.5 k cycles behind per tile.  The tile waves
-        // take the remaining waves off the pivot's SIMD; the pivot's SIMD gives some only if the others do not suffice.
         const unsigned off = all & ~onp;
-        const unsigned rbit = off ? (1u << (31 - __clz(off))) : onp ? (onp & (0u - onp)) : 2u;                       // the inverse wave: the LAST wave off the pivot's SIMD
+        // the inverse wave: on the pivot wave's SIMD (no matrix-core work there: next to two tile waves it took 8.5 k cycles per tile
+        // in the update-heavy steps, 4.9 k alone, 5.1 k beside the pivot wave, which as the older wave keeps its own pace)
+        const unsigned rbit = onp ? (onp & (0u - onp)) : off ? (1u << (31 - __clz(off))) : 2u;
         unsigned rest = onp & ~rbit, tiles = off & ~rbit;
-        while (__popc(tiles) > NW) tiles &= ~(1u << (31 - __clz(tiles)));                                        // more than needed: drop the last ones
         for (int need = NW - __popc(tiles); need > 0 && rest; need--) { unsigned b = rest & (0u - rest); tiles |= b; rest &= ~b; }
         const unsigned me = 1u << wv;
-        role = wv == 0 ? 0 : (rbit & me) ? 1 : (tiles & me) ? 2 : 3;
-        tw = __popc(tiles & (me - 1u));
+        // group of this wave: snake order over (slot on the SIMD, SIMD) when the waves sit three to a SIMD, else plain wave order
+        unsigned sm[4], simds = 0u;
+        bool three = __popc(tiles) == 9;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            sm[x] = (unsigned)__ballot(lane < nwv && wsimd[lane & 15] == x) & tiles;
+            if (sm[x]) { simds |= 1u << x; three = three && __popc(sm[x]) == 3; }
+        }
+        int g = __popc(tiles & (me - 1u));
+        if (three && (tiles & me)) {
+            const int mys = wsimd[wv], sr = __popc(simds & ((1u << mys) - 1u)), t = __popc(sm[mys] & (me - 1u));
+            g = t == 0 ? sr : t == 1 ? 5 - sr : 6 + sr;
+        }
+        role = wv == 0 ? 0 : (rbit & me) ? 1 : ((tiles & me) && g < NW) ? 2 : 3;
+        tw = g;
     }
     if (role == 3) return;
     if (role == 0) {
@@ -402,9 +419,11 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     // =============================== tile waves ===============================
     const double* S = B.S + W.S_base;
     double* Xs = &Pn[0][0][0] + tw * 272;                  // wave-private transposition scratch
-    const bool isrhs = tw == NW - 1;
-    const int Ia = isrhs ? Tc : tw + 1;                    // row A: tiles (Ia, J), J < Ia, at acc[J]
-    const int Ib = (!isrhs && Tc - 1 - tw > tw + 1) ? Tc - 1 - tw : 0;      // row B: tiles (Ib, J), J < Ib, at acc[14 - J]
+    const bool isrhs = tw == 0;
+    const int pa_ = tw - gk;                               // pair number (1 ..) behind the right-hand-side row and the gk single rows
+    // row A: tiles (Ia, J), J < Ia, at acc[J]; row B: tiles (Ib, J), J < Ib, at acc[NS - 1 - J]
+    const int Ia = isrhs ? Tc : tw <= gk ? Tc - tw : pa_ <= (gm >> 1) ? pa_ : (gm + 1) >> 1;
+    const int Ib = (!isrhs && tw > gk && pa_ <= (gm >> 1)) ? gm + 1 - pa_ : 0;
     const unsigned rmA = (1u << Ia) - 1u, rmB = (1u << Ib) - 1u;      // the columns of rows A and B
     double4_t acc[R4_NS];
     CHSTAMP2(16);
