@@ -103,10 +103,9 @@ __device__ __forceinline__ void rr4_rho(double* rhoJ, const double* colb, double
 // inverse wave: the same row operations on the identity, column by column behind the pivot wave:  R[r][:] <- m R[r][:] - M[r][c] (R[c][:] 2^-e)
 // for r > c.  Row r of R is final after column r - 1: Linv[r][:] = R[r][:] rho_r; R goes out UNSCALED (the panel product scales its
 // A operand with the rho the pivot wave leaves beside it).
-// Nothing of a column waits for the LDS when the wave runs behind the pivot wave (it does: ~200 against ~160 cycles per column):
-// the pivot wave keeps ONE counter, "columns published"; this wave remembers the last value it saw (avail) and fetches the
-// published row of column c + 2 while it works on column c whenever avail says the row is there; the counter itself is re-read
-// once per column and looked at a column later.  Only a fetch that could not be issued ahead (the wave has caught up) polls.
+// Nothing of a column waits for the LDS when the wave runs behind the pivot wave (it does): the pivot wave keeps ONE counter,
+// "columns published"; this wave fetches the published row of column c + 2 while it works on column c, and looks at the counter
+// only where a fetch could otherwise run ahead of it (see the loop).
 struct rr4_col { double colv[4], dpv, xv; };
 __device__ __forceinline__ void rr4_fetch(rr4_col& o, const double* colb, int c, int lk) {
     const int c1 = c + 1;
@@ -129,28 +128,23 @@ __device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, uns
     double rowR = li == 0 ? 1.0 : 0.0;                    // R[0][li]
     double rowPre = li == 1 ? 1.0 : 0.0;                  // row 1, before step 0
     rr4_col buf[3];
-    bool ok[3] = { false, false, false };
     int avail = 0;                                        // columns known to be published (never more than there are)
-    unsigned pv = 0u;                                     // the counter as read a column ago
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int c = 0; c < 15; c++) {
         rr4_col& cur = buf[c % 3];
-        asm volatile("" ::: "memory");
-        if (c > 0) { const int a = __builtin_amdgcn_readfirstlane((int)pv); avail = a > avail ? a : avail; }
-        if (!ok[c % 3]) {
-            // not fetched ahead: wait for the column, fetch it now
-            for (int spin = 0; spin < (1 << 22) && avail <= c; spin++) { avail = rr4_progress(flagb); if (avail <= c) __builtin_amdgcn_s_sleep(0); }
+        // The counter is looked at every fourth column only, and then until it covers the fetches of the next four columns (two ahead
+        // each): three or four waits per tile instead of a dozen instructions of bookkeeping per column.  The pivot wave publishes a
+        // column every ~160 cycles and this wave needs ~250 for one, so the waits behind the first find the counter where they want it.
+        if ((c & 3) == 0) {
+            const int want = c + 7 < 16 ? c + 7 : 16;
+            for (int spin = 0; spin < (1 << 22) && avail < want; spin++) { avail = rr4_progress(flagb); if (avail < want) __builtin_amdgcn_s_sleep(0); }
             asm volatile("" ::: "memory");
-            rr4_fetch(cur, colb, c, lk);
-            asm volatile("" ::: "memory");
+            if (c == 0) { rr4_fetch(buf[0], colb, 0, lk); rr4_fetch(buf[1], colb, 1, lk); }
         }
         CST(prof, 16 + c);
-        // ahead: the counter for the next column's decisions, the rows of the next two columns if they are there
-        pv = __hip_atomic_load(flagb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
-        if (c == 0 && c + 1 < 15) { ok[(c + 1) % 3] = avail > c + 1; if (ok[(c + 1) % 3]) rr4_fetch(buf[(c + 1) % 3], colb, c + 1, lk); }
-        if (c + 2 < 15) { ok[(c + 2) % 3] = avail > c + 2; if (ok[(c + 2) % 3]) rr4_fetch(buf[(c + 2) % 3], colb, c + 2, lk); }
+        if (c + 2 < 15) rr4_fetch(buf[(c + 2) % 3], colb, c + 2, lk);
         asm volatile("" ::: "memory");
         const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(cur.dpv)), lo = __builtin_amdgcn_readfirstlane(__double2loint(cur.dpv));
         const double sg = __hiloint2double(0x7fe00000 - (hi & 0x7ff00000), 0);
