@@ -77,10 +77,12 @@ __device__ __forceinline__ bool rr4_pivot(double (*D)[17], double* colb, unsigne
     return bad != 0;
 }
 
-// the Cholesky scaling of the tile, lane-parallel, by the PIVOT wave once its columns are through (the inverse wave is still catching
-// up then): lane li takes column li.  rho_li = 1 / sqrt(s_li dp_li), s_li = prod_{k < li} m_k (the scale the eliminations have put
-// on M^(li)): an inclusive DPP scan of m over the 16-lane row, shifted by one lane.  L_jj (export only) = published rows x rho.
-__device__ __forceinline__ void rr4_rho(double* rhoJ, const double* colb, double (*Dl)[17], bool want_L, int li, int lk) {
+// the Cholesky scaling of the tile, lane-parallel, by the PIVOT wave once its columns are through: lane li takes column li.
+// rho_li = 1 / sqrt(s_li dp_li), s_li = prod_{k < li} m_k (the scale the eliminations have put on M^(li)): an inclusive DPP scan of m
+// over the 16-lane row, shifted by one lane.  What the tile waves need is the ROW scaling of the unit-triangular solve,
+// U = D^-1/2 (Ltilde^-1 A):  rsd_li = 1 / sqrt(d_li) = rho_li s_li (d_li = dp_li / s_li), stored at 4 (li mod 4) + li / 4 so that a lane
+// reads its four rows as one run.  L_jj (export only) = published rows x rho.
+__device__ __forceinline__ void rr4_rho(double* rsdJ, const double* colb, double (*Dl)[17], bool want_L, int li, int lk) {
 #pragma clang fp contract(off)
     asm volatile("" ::: "memory");
     const double dpl = colb[li * 16 + (li & 3) * 4 + (li >> 2)];
@@ -92,7 +94,7 @@ __device__ __forceinline__ void rr4_rho(double* rhoJ, const double* colb, double
     v = v * __builtin_amdgcn_update_dpp(1.0, v, 0x118, 0xf, 0xf, false);
     const double sl = __builtin_amdgcn_update_dpp(1.0, v, 0x111, 0xf, 0xf, false);
     const double rho = rsqrt_nr(sl * dpl);
-    rhoJ[li] = rho;                                       // (the four rows of lanes write the same values)
+    rsdJ[(li & 3) * 4 + (li >> 2)] = rho * sl;            // (the four rows of lanes write the same values)
     if (want_L) {
 #pragma unroll
         for (int q = 0; q < 4; q++) { const int r = lk + 4 * q; Dl[r][li] = (li <= r) ? colb[li * 16 + lk * 4 + q] * rho : 0.0; }
@@ -100,79 +102,67 @@ __device__ __forceinline__ void rr4_rho(double* rhoJ, const double* colb, double
     asm volatile("" ::: "memory");
 }
 
-// inverse wave: the same row operations on the identity, column by column behind the pivot wave:  R[r][:] <- m R[r][:] - M[r][c] (R[c][:] 2^-e)
-// for r > c.  Row r of R is final after column r - 1: Linv[r][:] = R[r][:] rho_r; R goes out UNSCALED (the panel product scales its
-// A operand with the rho the pivot wave leaves beside it).
-// Nothing of a column waits for the LDS when the wave runs behind the pivot wave (it does): the pivot wave keeps ONE counter,
-// "columns published"; this wave fetches the published row of column c + 2 while it works on column c, and looks at the counter
-// only where a fetch could otherwise run ahead of it (see the loop).
-struct rr4_col { double colv[4], dpv, xv; };
-__device__ __forceinline__ void rr4_fetch(rr4_col& o, const double* colb, int c, int lk) {
-    const int c1 = c + 1;
-#pragma unroll
-    for (int q = 0; q < 4; q++) o.colv[q] = colb[c * 16 + lk * 4 + q];        // M[c][lk+4q] == M[lk+4q][c]
-    o.dpv = colb[c * 16 + (c & 3) * 4 + (c >> 2)];                            // the pivot (one address: a broadcast read)
-    o.xv = colb[c * 16 + (c1 & 3) * 4 + (c1 >> 2)];                           // M[c+1][c]
-}
+// transform wave (round 5, third form of the "inverse wave"): what the panel product needs of the diagonal tile, without an inverse.
+// A streamed 16 x 16 inverse is a chain of fifteen columns at ~35 instructions each, and the wave finished 2.1 - 3.5 k cycles behind
+// the pivot wave whatever was tried (own SIMD, prefetched columns, one progress counter).  The unit-triangular solve
+// Utilde = Ltilde^-1 A (L_jj = Ltilde D^1/2) of a tile held as four 4-row blocks is four BLOCK GAUSS TRANSFORMS applied in place,
+//     T <- T + G_k T_k,   G_k = [ 0 ; -(Wtilde_k + I) ; -Ltilde_{>k,k} Wtilde_k ]  (16 x 4),   Wtilde_k = inverse of the k-th unit-lower 4 x 4 block
+// — one MFMA each with G_k as the A operand and register k of the tile as the B operand, the same four dependent MFMAs the product
+// with the inverse took.  (T holds -A: row block k becomes +Utilde_k, the blocks below stay negated residuals.)  G_k needs columns
+// 4k .. 4k+3 of the elimination only — the multipliers M[i][c] / dp_c, scale-free — so this wave works a BLOCK behind the pivot
+// wave instead of a chain behind it: ~60 instructions per block, and only the last block's are left when the pivot wave is through.
+// The square roots stay out of it: the tile waves scale the rows of Utilde by rsd (rr4_rho).  It has to be the UNIT-lower factor:
+// Wtilde + I is exact (a 2 on the diagonal), whereas with the Cholesky-scaled blocks W + I rounds W away where 1 / L_cc is small and
+// T_k - (W + I) T_k cancels (tests/perf/block_transform_accuracy.py: 1e-11 against 1e-16 on badly scaled tiles; measured on the
+// device as L L^T = S to 4e-11 instead of 1e-12).
+// Linv_jj, which the backward substitution multiplies by, is the same four transforms applied to -I by a tile wave after the loop.
 __device__ __forceinline__ int rr4_progress(const unsigned* flagb) {
     return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flagb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
-__device__ __forceinline__ void rr4_inverse(double (*LiJ)[17], double* colb, unsigned* flagb, int li, int lk, bool prof = false) {
+__device__ __forceinline__ void rr4_gops(double (*GoJ)[64], const double* colb, unsigned* flagb, int lane, int li, int lk, bool prof = false) {
 #pragma clang fp contract(off)
-    double R_[4];
+    const int pli = (li & 3) * 4 + (li >> 2);             // where row li sits in a published row
+    int avail = 0;
+    const double d0 = lk == 0 ? 1.0 : 0.0, d1 = lk == 1 ? 1.0 : 0.0, d2 = lk == 2 ? 1.0 : 0.0, d3 = lk == 3 ? 1.0 : 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) R_[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
-    int bidx[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) bidx[r] = (r * 16 + li) * 4;
-    double rowR = li == 0 ? 1.0 : 0.0;                    // R[0][li]
-    double rowPre = li == 1 ? 1.0 : 0.0;                  // row 1, before step 0
-    rr4_col buf[3];
-    int avail = 0;                                        // columns known to be published (never more than there are)
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int c = 0; c < 15; c++) {
-        rr4_col& cur = buf[c % 3];
-        // The counter is looked at every fourth column only, and then until it covers the fetches of the next four columns (two ahead
-        // each): three or four waits per tile instead of a dozen instructions of bookkeeping per column.  The pivot wave publishes a
-        // column every ~160 cycles and this wave needs ~250 for one, so the waits behind the first find the counter where they want it.
-        if ((c & 3) == 0) {
-            const int want = c + 7 < 16 ? c + 7 : 16;
-            for (int spin = 0; spin < (1 << 22) && avail < want; spin++) { avail = rr4_progress(flagb); if (avail < want) __builtin_amdgcn_s_sleep(0); }
-            asm volatile("" ::: "memory");
-            if (c == 0) { rr4_fetch(buf[0], colb, 0, lk); rr4_fetch(buf[1], colb, 1, lk); }
-        }
-        CST(prof, 16 + c);
+    for (int k = 0; k < 4; k++) {
+        const int c0 = 4 * k;
+        for (int spin = 0; spin < (1 << 22) && avail < c0 + 4; spin++) { avail = rr4_progress(flagb); if (avail < c0 + 4) __builtin_amdgcn_s_sleep(0); }
         asm volatile("" ::: "memory");
-        if (c + 2 < 15) rr4_fetch(buf[(c + 2) % 3], colb, c + 2, lk);
-        asm volatile("" ::: "memory");
-        const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(cur.dpv)), lo = __builtin_amdgcn_readfirstlane(__double2loint(cur.dpv));
-        const double sg = __hiloint2double(0x7fe00000 - (hi & 0x7ff00000), 0);
-        const double dpS = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
-        const double sR = rowR * sg;
+        CST(prof, 16 + k);
+        // position of row c0 + u in a published row: 4 ((c0 + u) mod 4) + (c0 + u) / 4 = 4 u + k
+        const double dpo = colb[li * 16 + pli];                                   // the pivot of column li (used by lanes c0 <= li < c0 + 4 only)
+        double Mi[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (4 * q + 3 <= c) continue;
-            const double nv = __builtin_fma(dpS, R_[q], -(cur.colv[q] * sR));
-            R_[q] = (4 * q > c || lk + 4 * q > c) ? nv : R_[q];                   // rows <= c are final
-        }
-        double rowPreN = 0;
-        if (c + 2 < 16) rowPreN = bperm_d(R_[(c + 2) >> 2], bidx[(c + 2) & 3]);  // row c+2 after step c: on its way before the row fetched a column ago is used
+        for (int u = 0; u < 4; u++) Mi[u] = colb[(c0 + u) * 16 + pli];           // M[li][c0+u] (by symmetry: element li of published row c0+u)
+        const double m10 = colb[(c0 + 0) * 16 + 4 * 1 + k], m20 = colb[(c0 + 0) * 16 + 4 * 2 + k], m30 = colb[(c0 + 0) * 16 + 4 * 3 + k];
+        const double m21 = colb[(c0 + 1) * 16 + 4 * 2 + k], m31 = colb[(c0 + 1) * 16 + 4 * 3 + k], m32 = colb[(c0 + 2) * 16 + 4 * 3 + k];
         asm volatile("" ::: "memory");
-        rowR = __builtin_fma(dpS, rowPre, -(cur.xv * sR));                        // row c+1 of R after step c
-        rowPre = rowPreN;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int r = lk + 4 * q;
-        LiJ[r][li] = (li <= r) ? R_[q] : 0.0;
+        // 1 / pivot, every lane for its own column; the block's four to every lane (DPP row broadcast)
+        const double idpo = rcp_nr(dpo);
+        const double i0 = row_newbcast_d(idpo, c0), i1 = row_newbcast_d(idpo, c0 + 1), i2 = row_newbcast_d(idpo, c0 + 2), i3 = row_newbcast_d(idpo, c0 + 3);
+        // the unit-lower multipliers inside the block, and column lk of the inverse of the block (forward substitution on e_lk)
+        const double l10 = m10 * i0, l20 = m20 * i0, l30 = m30 * i0, l21 = m21 * i1, l31 = m31 * i1, l32 = m32 * i2;
+        const double x0 = d0;
+        const double x1 = __builtin_fma(-l10, x0, d1);
+        const double x2 = __builtin_fma(-l21, x1, __builtin_fma(-l20, x0, d2));
+        const double x3 = __builtin_fma(-l32, x2, __builtin_fma(-l31, x1, __builtin_fma(-l30, x0, d3)));
+        // rows below the block: -sum_u Ltilde[li][c0+u] x_u
+        double below = (Mi[0] * i0) * x0;
+        below = __builtin_fma(Mi[1] * i1, x1, below);
+        below = __builtin_fma(Mi[2] * i2, x2, below);
+        below = __builtin_fma(Mi[3] * i3, x3, below);
+        // rows of the block: -(Wtilde + I)[li - c0][lk]
+        const int u = li - c0;
+        const double xs = u == 0 ? x0 : u == 1 ? x1 : u == 2 ? x2 : x3;
+        const double blk = xs + (u == lk ? 1.0 : 0.0);
+        const double val = li < c0 ? 0.0 : li < c0 + 4 ? -blk : -below;
+        GoJ[k][lane] = val;
     }
     CST(prof, 31);
-    // column 15 changes nothing here; it is awaited so that the reset below cannot overtake the pivot wave's last count
-    for (int spin = 0; spin < (1 << 22) && avail < 16; spin++) { avail = rr4_progress(flagb); if (avail < 16) __builtin_amdgcn_s_sleep(0); }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flagb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // back to "nothing published" (the pivot wave starts the next tile two barriers from here)
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flagb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // back to "nothing published" (avail == 16 was seen; the pivot wave starts the next tile two barriers from here)
     asm volatile("" ::: "memory");
 }
 
@@ -224,11 +214,18 @@ __device__ __forceinline__ double4_t rr4_load_diag(const double* S, int n, int J
     return a;
 }
 
-// panel product of one tile of the step: T <- U_jI = Linv_jj A_jI (aop = -Linv rows, scaled; T holds -A_jI), published to Pn[I].
-// The row's pending diagonal tile (Dg[I] in LDS, negated, touched by the row's owner only) takes its term here when it is the NEXT
-// pivot tile and goes to Dt for the pivot wave; the other rows' after the barrier (rr4_diag_term).  Returns false for a tile that is
-// still exactly zero: it stays zero, is not published, and every product with it is skipped (the step's mask nzm).
-__device__ __forceinline__ unsigned rr4_panel(double4_t& T, const double (&aop)[4], int I, int j, int Tc, double (*Pn)[4][64], double4_t d /* Dg[j+1], fetched ahead of the barrier */,
+// panel product of one tile of the step: T <- U_jI = D^-1/2 Ltilde_jj^-1 A_jI (T holds -A_jI; g = the four block Gauss transforms of the
+// diagonal tile, rs = the lane's four row scalings), published to Pn[I].  The row's pending diagonal tile (Dg[I] in LDS, negated,
+// touched by the row's owner only) takes its term here when it is the NEXT pivot tile and goes to Dt for the pivot wave; the other
+// rows' after the barrier (rr4_diag_term).  Returns 0 for a tile that is still exactly zero: it stays zero, is not published, and
+// every product with it is skipped (the step's mask nzm).
+__device__ __forceinline__ void rr4_solve(double4_t& T, const double (&g)[4], const double (&rs)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const double b = T[k]; T = __builtin_amdgcn_mfma_f64_16x16x4f64(g[k], b, T, 0, 0, 0); }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) T[kk] *= rs[kk];
+}
+__device__ __forceinline__ unsigned rr4_panel(double4_t& T, const double (&g)[4], const double (&rs)[4], int I, int j, int Tc, double (*Pn)[4][64], double4_t d /* Dg[j+1], fetched ahead of the barrier */,
                                           double (*DtN)[17], unsigned* nzmj, int lane, int li, int lk, bool prof = false) {
     const bool crit = I == j + 1 && I < Tc;
     PST(prof && crit, 2);
@@ -241,20 +238,17 @@ __device__ __forceinline__ unsigned rr4_panel(double4_t& T, const double (&aop)[
         return 0u;
     }
     if (lane == 0) atomicOr(nzmj, 1u << I);
-    double4_t X = { 0, 0, 0, 0 };
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], T[kk], X, 0, 0, 0);
-    T = X;
+    rr4_solve(T, g, rs);
     PST(prof && crit, 3);
     if (crit) {
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(X[kk], X[kk], d, 0, 0, 0);
+        for (int kk = 0; kk < 4; kk++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(T[kk], T[kk], d, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; q++) DtN[lk + 4 * q][li] = -d[q];
     }
     PST(prof && crit, 4);
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) Pn[I][kk][lane] = X[kk];
+    for (int kk = 0; kk < 4; kk++) Pn[I][kk][lane] = T[kk];
     PST(prof && crit, 5);
     return 1u;
 }
@@ -276,8 +270,9 @@ template <int R4_NS>
 __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full) {
     __shared__ double Pn[16][4][64];           // published panel tiles of the step, registers as they are: Pn[I][kk][lane]; the transposition scratch before / after the loop
     __shared__ double Dg[16][4][64];           // the rows' pending diagonal tiles, negated, accumulator layout as it is: Dg[I][q][lane] (owner-private)
-    __shared__ double Li[16][16][17];          // R of every step (Linv_jj = diag(rho) R; the backward pass multiplies by them again)
-    __shared__ double rho[16][16];
+    __shared__ double Li[16][16][17];          // Linv_jj of every step (the transforms applied to -I once the loop is through: the backward pass multiplies by them)
+    __shared__ double Gop[16][4][64];          // the four block Gauss transforms of every diagonal tile, A-operand layout: Gop[j][k][lane]
+    __shared__ double rsd[16][16];             // 1 / sqrt(d) of every column, permuted (rr4_rho)
     __shared__ double Dt[2][16][17];           // published diagonal tiles, double-buffered
     __shared__ double Dl[16][17];              // L_jj on its way to HBM (export only)
     __shared__ double colb[16 * 16];           // pivot pair: row c of the tile being factored, per column
@@ -356,7 +351,7 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
             const bool bad = rr4_pivot(Dt[j & 1], colb, flagb, li, lk);
 #endif
             WST(j, 1);
-            rr4_rho(rho[j], colb, Dl, j >= ef, li, lk);
+            rr4_rho(rsd[j], colb, Dl, j >= ef, li, lk);
             if (bad && lane == 0) fail = 1;
             __syncthreads();                               // B_j
 #ifdef SWF_PROFILE_CHOL
@@ -376,7 +371,7 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         for (int J = Tc - 1; J >= 0; J--) {
             double p = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) p += Li[J][lk + 4 * q][li] * (rho[J][lk + 4 * q] * yv[16 * J + lk + 4 * q]);
+            for (int q = 0; q < 4; q++) p += Li[J][lk + 4 * q][li] * yv[16 * J + lk + 4 * q];
             atomicAdd(&zs[16 * J + li], p);                // ds_add_f64: the four row groups of lanes add into the (zeroed) slot
             __syncthreads();                               // X_J: y_J published
             __syncthreads();                               // Y_J: row J applied to the pending blocks
@@ -389,9 +384,9 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         __syncthreads();                                   // A_0
         for (int j = 0; j < Tc; j++) {
 #ifdef SWF_PROFILE_CHOLW
-            rr4_inverse(Li[j], colb, flagb, li, lk, j == g_chol_wstep);
+            rr4_gops(Gop[j], colb, flagb, lane, li, lk, j == g_chol_wstep);
 #else
-            rr4_inverse(Li[j], colb, flagb, li, lk);
+            rr4_gops(Gop[j], colb, flagb, lane, li, lk);
 #endif
             WST(j, 1);
             __syncthreads();                               // B_j
@@ -494,19 +489,20 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         const bool pa = j < Ia, pb = j < Ib;
         unsigned nza = 0u, nzb = 0u;                       // this step's panel tiles are not zero (wave-uniform)
         if (pa || pb) {
-            // A operand of the panel products: -Linv_jj = -diag(rho) R
-            double aop[4];
-            const double rl = rho[j][li];
+            // the diagonal tile's block Gauss transforms (A operands) and the lane's row scalings
+            double aop[4], rs4[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) aop[kk] = -(Li[j][li][lk + 4 * kk] * rl);
+            for (int k = 0; k < 4; k++) aop[k] = Gop[j][k][lane];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) rs4[kk] = rsd[j][lk * 4 + kk];
             PST(prof, 1);
             // the row that holds the next pivot tile first
             if (pb && Ib == j + 1) {
-                nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
-                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
+                nzb = rr4_panel(acc[R4_NS - 1 - j], aop, rs4, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
+                if (pa) nza = rr4_panel(acc[j], aop, rs4, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
             } else {
-                if (pa) nza = rr4_panel(acc[j], aop, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
-                if (pb) nzb = rr4_panel(acc[R4_NS - 1 - j], aop, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
+                if (pa) nza = rr4_panel(acc[j], aop, rs4, Ia, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
+                if (pb) nzb = rr4_panel(acc[R4_NS - 1 - j], aop, rs4, Ib, j, Tc, Pn, dn, Dt[(j + 1) & 1], &nzm[j & 1], lane, li, lk, prof);
             }
         }
         WST(j, 1);
@@ -544,6 +540,20 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     rr4_steps(step, std::make_integer_sequence<int, R4_NS>{});
     if (fail) return;
     CHSTAMP2(20);
+    // Linv_JJ for the backward substitution: the transforms of tile J applied to -I (accumulator layout = the row layout Li is read in)
+    for (int J = tw; J < Tc; J += NW) {
+        double g[4], rs4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) g[k] = Gop[J][k][lane];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) rs4[kk] = rsd[J][lk * 4 + kk];
+        double4_t T;
+#pragma unroll
+        for (int q = 0; q < 4; q++) T[q] = (lk + 4 * q == li) ? -1.0 : 0.0;
+        rr4_solve(T, g, rs4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) Li[J][lk + 4 * q][li] = T[q];
+    }
     // back to the row layout (lane (li, lk), register q <-> L[lk+4q][li]); export L where it is read, y = L^-1 rhs from the rhs tile row
 #pragma unroll
     for (int J = 0; J < R4_NS; J++) {

@@ -1090,17 +1090,18 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             for (int i : pd) wpairs[(size_t)B.pair[i].win].push_back(i);
             for (int i : po) wpairs[(size_t)B.pair[i].win].push_back(i);
             bool overflow = false;
+            // the 16 x 16 tiles of S some block pair reaches, strictly below the tile diagonal (the diagonal tiles are always loaded): from
+            // EVERY pair of the window — the frame pairs whose only contribution is the -P that k_lm_schur writes straight into S have
+            // left the assembly's lists above, but their tiles are not zero
             std::vector<unsigned> tnz((size_t)n * 4, 0u);
+            for (const Pair& Pq : B.pair) {
+                if (B.win[(size_t)Pq.win].n_red > 240) continue;
+                for (int I = Pq.ra / 16; I <= (Pq.ra + Pq.la - 1) / 16; I++)
+                    for (int J = Pq.rb / 16; J <= (Pq.rb + Pq.lb - 1) / 16 && J < I; J++) { const int t = I * (I - 1) / 2 + J; tnz[(size_t)Pq.win * 4 + (t >> 5)] |= 1u << (t & 31); }
+            }
             for (int w = 0; w < n; w++) {
                 const WinRec& Rw = B.win[w];
                 AsmWin& A = asw[(size_t)w];
-                if (Rw.n_red <= 240)
-                    for (int pi_ : wpairs[(size_t)w]) {
-                        // the 16 x 16 tiles of S this block pair reaches (strictly below the tile diagonal: the diagonal tiles are always loaded)
-                        const Pair& Pq = B.pair[(size_t)pi_];
-                        for (int I = Pq.ra / 16; I <= (Pq.ra + Pq.la - 1) / 16; I++)
-                            for (int J = Pq.rb / 16; J <= (Pq.rb + Pq.lb - 1) / 16 && J < I; J++) { const int t = I * (I - 1) / 2 + J; tnz[(size_t)w * 4 + (t >> 5)] |= 1u << (t & 31); }
-                    }
                 A.win = w; A.n_red = Rw.n_red; A.m = 6 * Rw.nF; A.loc_base = Rw.loc_base; A.S_base = Rw.S_base;
                 A.P_base = Rw.P_base * GEMM_SPLIT; A.q_base = (long long)6 * Rw.fr_base * GEMM_SPLIT;
                 A.fs_base = Rw.fsb1 > Rw.fsb0 ? B.fsb_out0[(size_t)Rw.fsb0] : 0;
@@ -1175,6 +1176,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             nonempty_i(t_dst); nonempty_u(t_cnt); nonempty_i(t_src0); nonempty_i(t_aux); nonempty_i(t_src);
             nonempty_i(tv_loc); nonempty_i(tv_red); nonempty_u(tv_cnt); nonempty_i(tv_src0); nonempty_i(tv_i); nonempty_i(tv_src);
             PUT(asw, asw); PUT(s_tnz, tnz);
+            if (getenv("SWF_NO_TNZ")) D.s_tnz = nullptr;        // A/B: k_chol_rr4 loads every tile
             PUT(as_dst, t_dst); PUT(as_cnt, t_cnt); PUT(as_src0, t_src0); PUT(as_aux, t_aux); PUT(as_src, t_src);
             PUT(av_loc, tv_loc); PUT(av_red, tv_red); PUT(av_cnt, tv_cnt); PUT(av_src0, tv_src0); PUT(av_i, tv_i); PUT(av_src, tv_src);
         }
