@@ -534,7 +534,7 @@ def main():
             "post_dogleg": ("hbm", (152 + 16) * n_obs, "candidate residuals: 152 B read + 16 B written per observation (the model cost change comes from k_dogleg's vector sums)"),
         }
         bound, units, what = work.get(dom, ("hbm", calib["jacobian_bytes"], "Jacobian bytes of the batch (SURVEY.md 8d formula)"))
-        knames = {"eval_ps": "k_eval_ps<true, true>", "lm_schur": "k_lm_schur<8, 5, 2, 144, true>", "assemble": "k_assemble_flat", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr3"}
+        knames = {"eval_ps": "k_eval_ps<true, true>", "lm_schur": "k_lm_schur<8, 5, 2, 144, true>", "assemble": "k_assemble_flat", "post_chol": "k_post_chol", "post_dogleg": "k_post_dogleg", "frame_sums": "k_frame_sums", "chol_solve": "k_chol_rr4"}
         # HBM traffic from the committed PMC passes of the same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate passes; gfx950: FETCH_SIZE counts half of wide coalesced reads -> x2), if available
         traffic = None
@@ -611,6 +611,15 @@ def main():
                    achieved=calib["proj_bytes"] / (avg_ms("eval_ps") * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                    algorithmic_bytes_per_launch=calib["proj_bytes"], avg_launch_ms=avg_ms("eval_ps"))
         jac["frac"] = jac["achieved"] / HBM_PEAK_GBS
+        jac["algorithmic"] = "SURVEY.md 8d: 312 B per projection observation (152 read + 160 written) + the scalar GNSS factors' and the prior's bytes"
+        # ... and on the bytes the counters saw (the kernel no longer stores the translation half of Jp: it moves fewer bytes than 8d charges)
+        if traffic_all:
+            ek = [k for k in traffic_all if k.startswith("void k_eval_ps<true, true") or k.startswith("k_eval_ps<true, true")]
+            if ek:
+                cb_ = float(traffic_all[ek[0]])
+                jac["counter_bytes_per_launch"] = cb_
+                jac["achieved_on_counter_bytes"] = cb_ / (avg_ms("eval_ps") * 1e-3) / 1e9
+                jac["frac_on_counter_bytes"] = jac["achieved_on_counter_bytes"] / HBM_PEAK_GBS
         # single-window latency path (rank 0, extra information)
         single = None
         if not a.no_single_window:
@@ -627,7 +636,10 @@ def main():
             single = dict(us_per_iteration=1e3 * float(np.median(lat)) / max(1, it1), iterations_per_s=max(1, it1) / (1e-3 * float(np.median(lat))),
                           solve_ms_median=float(np.median(lat)), solve_ms_p10=float(np.percentile(lat, 10)), solve_ms_p90=float(np.percentile(lat, 90)))
         out = {
+            # `value`: the timed region starts with the windows' parameter blocks resident in HBM (the bench contract's protocol);
+            # SURVEY.md 8d's host-to-host protocol (upload + solve + download inside the timed region) is `survey_8d_protocol` below
             "metric": "gauss_newton_iterations_per_sec", "value": value, "unit": "iterations/s",
+            "value_protocol": "inputs resident in HBM when the timed region starts; PCIe-inclusive rates: with_state_upload, survey_8d_protocol",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE cfg4: batch of %d independent cfg3 windows (20 keyframes, 300 features, 3000 observations, "

@@ -121,28 +121,80 @@ struct FixedIntegerFactor : CostFunction { double N21, istd; FixedIntegerFactor(
 // fills it from gnss_poses / gnss_speed_bias (the hidden epochs' parameter memory, updated in place by every Solve), their
 // *_lin points, pose_hessians, pose_phase_biases_hessians, pose_rhses, phase_biases_hessians, phase_biases_rhs and the M + 1
 // pre-integrations (imu_factors[k]->pre_integration, last_imu_factor) in SWF_PRE_DOUBLES records.
-struct ProjectionTwoFrameOneCamFactor : CostFunction {
-    static double sqrt_info; double pi[3], pj[3];
+// (the static sqrt_info of each class lives in a class template's static member: one definition across translation units without
+// C++17 inline variables — the reference builds with -std=c++14, rtk_visual_inertial/CMakeLists.txt:5)
+template <class Tag> struct SqrtInfoOf { static double sqrt_info; };
+template <class Tag> double SqrtInfoOf<Tag>::sqrt_info = 0;
+struct ProjectionTwoFrameOneCamFactor : CostFunction, SqrtInfoOf<ProjectionTwoFrameOneCamFactor> {
+    double pi[3], pj[3];
     ProjectionTwoFrameOneCamFactor(const double* pts_i, const double* pts_j) { for (int k = 0; k < 3; k++) { pi[k] = pts_i[k]; pj[k] = pts_j[k]; } }
 };
-inline double ProjectionTwoFrameOneCamFactor::sqrt_info = 0;
-struct ProjectionTwoFrameTwoCamFactor : CostFunction {
-    static double sqrt_info; double pi[3], pj[3];
+struct ProjectionTwoFrameTwoCamFactor : CostFunction, SqrtInfoOf<ProjectionTwoFrameTwoCamFactor> {
+    double pi[3], pj[3];
     ProjectionTwoFrameTwoCamFactor(const double* pts_i, const double* pts_j) { for (int k = 0; k < 3; k++) { pi[k] = pts_i[k]; pj[k] = pts_j[k]; } }
 };
-inline double ProjectionTwoFrameTwoCamFactor::sqrt_info = 0;
-struct ProjectionOneFrameTwoCamFactor : CostFunction {
-    static double sqrt_info; double pi[3], pj[3];
+struct ProjectionOneFrameTwoCamFactor : CostFunction, SqrtInfoOf<ProjectionOneFrameTwoCamFactor> {
+    double pi[3], pj[3];
     ProjectionOneFrameTwoCamFactor(const double* pts_i, const double* pts_j) { for (int k = 0; k < 3; k++) { pi[k] = pts_i[k]; pj[k] = pts_j[k]; } }
 };
-inline double ProjectionOneFrameTwoCamFactor::sqrt_info = 0;
 struct IMUGNSSInfo {
     int M = 0;                                     // hidden GNSS epochs
     double* hidden_pose = nullptr; double* hidden_sb = nullptr;        // [M][7], [M][9]
     std::vector<double> pose_lin, sb_lin, Hpp, HpN, rhs_p, HNN, rhsN, pre;
     int mid = 0; std::vector<double> H12;          // AddMidMargInfo's product (gnss_Index, pose1_pose2_hessians): link mid in 1..M-1, 15 x 15; 0 = none
+    // filled by IMUGNSSFactor(IMUGNSSBase*) only: the reference keeps every hidden epoch in its own allocation (gnss_poses[k],
+    // gnss_speed_bias[k]); the C-ABI wants [M][7] / [M][9], so the adapter owns contiguous copies (hidden_pose / hidden_sb point at
+    // them), Solve() gathers them from the epochs' memory before the solve and scatters the updated values back after it
+    std::vector<double*> pose_ptr, sb_ptr;
+    std::vector<double> pose_buf, sb_buf;
+    void gather() { for (size_t k = 0; k < pose_ptr.size(); k++) { std::memcpy(&pose_buf[7 * k], pose_ptr[k], 7 * sizeof(double)); std::memcpy(&sb_buf[9 * k], sb_ptr[k], 9 * sizeof(double)); } }
+    void scatter() const { for (size_t k = 0; k < pose_ptr.size(); k++) { std::memcpy(pose_ptr[k], &pose_buf[7 * k], 7 * sizeof(double)); std::memcpy(sb_ptr[k], &sb_buf[9 * k], 9 * sizeof(double)); } }
 };
-struct IMUGNSSFactor : CostFunction { IMUGNSSInfo* info; explicit IMUGNSSFactor(IMUGNSSInfo* i) : info(i) {} };
+struct IMUGNSSFactor : CostFunction {
+    IMUGNSSInfo* info; std::unique_ptr<IMUGNSSInfo> owned;
+    explicit IMUGNSSFactor(IMUGNSSInfo* i) : info(i) {}
+    // The reference's own constructor, IMUGNSSFactor(IMUGNSSBase* IMUGNSS_info_) (R/factor/gnss_imu_factor.h:145-151): any type with the
+    // member names of IMUGNSSBase (R/factor/gnss_imu_factor.h:19-140) as SetLastImuFactor leaves them (R/factor/gnss_imu_factor.cpp:99-119):
+    // gnss_poses / gnss_speed_bias (the M hidden epochs' parameter memory) and their *_lin points, pose_hessians[k] (15 x 15),
+    // pose_phase_biases_hessians[k] (15 x N), pose_rhses[k], phase_biases_hessians (N x N), phase_biases_rhs, the M pre-integrations
+    // imu_factors[k]->pre_integration (epoch k-1 -> k; k = 0 starts at para_pose0) and last_imu_factor->pre_integration (epoch M-1 -> the
+    // second visual frame), and — after AddMidMargInfo (:121-240) — gnss_middle_marginfo != 0, gnss_Index, pose1_pose2_hessians.
+    // Only operator()(i), operator()(i, j) and size() of the matrix members are used (Eigen or not).  A snapshot, like the other
+    // factors' constructors: the reference builds a new IMUGNSSFactor whenever it re-adds the residual block (SetLastImuFactor).
+    template <class GB, class = decltype(std::declval<GB&>().gnss_poses), class = decltype(std::declval<GB&>().pose_phase_biases_hessians),
+              class = decltype(std::declval<GB&>().last_imu_factor)>
+    explicit IMUGNSSFactor(GB* b) : info(nullptr), owned(new IMUGNSSInfo()) {
+        IMUGNSSInfo& I = *owned; info = owned.get();
+        const int M = (int)b->gnss_poses.size(), N = (int)b->gnss_phase_biases.size();
+        if (M < 1 || (int)b->gnss_speed_bias.size() != M || (int)b->imu_factors.size() != M || !b->last_imu_factor || (int)b->pose_hessians.size() != M)
+            throw std::invalid_argument("IMUGNSSFactor: IMUGNSSBase holds no complete chain of hidden epochs");
+        I.M = M;
+        I.pose_ptr.assign(b->gnss_poses.begin(), b->gnss_poses.end()); I.sb_ptr.assign(b->gnss_speed_bias.begin(), b->gnss_speed_bias.end());
+        I.pose_buf.resize((size_t)7 * M); I.sb_buf.resize((size_t)9 * M); I.gather();
+        I.hidden_pose = I.pose_buf.data(); I.hidden_sb = I.sb_buf.data();
+        I.pose_lin.resize((size_t)7 * M); I.sb_lin.resize((size_t)9 * M);
+        I.Hpp.resize((size_t)225 * M); I.HpN.assign((size_t)15 * N * M, 0.0); I.rhs_p.resize((size_t)15 * M);
+        I.HNN.resize((size_t)N * N); I.rhsN.resize((size_t)N); I.pre.resize((size_t)SWF_PRE_DOUBLES * (M + 1));
+        for (int k = 0; k < M; k++) {
+            std::memcpy(&I.pose_lin[7 * k], b->gnss_poses_lin[k], 7 * sizeof(double));
+            std::memcpy(&I.sb_lin[9 * k], b->gnss_speed_bias_lin[k], 9 * sizeof(double));
+            for (int i = 0; i < 15; i++) {
+                for (int j = 0; j < 15; j++) I.Hpp[(size_t)225 * k + 15 * i + j] = b->pose_hessians[k](i, j);
+                for (int j = 0; j < N; j++) I.HpN[((size_t)15 * k + i) * N + j] = b->pose_phase_biases_hessians[k](i, j);
+                I.rhs_p[(size_t)15 * k + i] = b->pose_rhses[k](i);
+            }
+            const IMUFactor rec(b->imu_factors[k]->pre_integration);
+            std::memcpy(&I.pre[(size_t)SWF_PRE_DOUBLES * k], rec.pre.data(), SWF_PRE_DOUBLES * sizeof(double));
+        }
+        const IMUFactor last(b->last_imu_factor->pre_integration);
+        std::memcpy(&I.pre[(size_t)SWF_PRE_DOUBLES * M], last.pre.data(), SWF_PRE_DOUBLES * sizeof(double));
+        for (int i = 0; i < N; i++) { I.rhsN[i] = b->phase_biases_rhs(i); for (int j = 0; j < N; j++) I.HNN[(size_t)i * N + j] = b->phase_biases_hessians(i, j); }
+        if (b->gnss_middle_marginfo) {
+            I.mid = b->gnss_Index; I.H12.resize(225);
+            for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) I.H12[15 * i + j] = b->pose1_pose2_hessians(i, j);
+        }
+    }
+};
 struct InitialBlackFactor : CostFunction { double istd; explicit InitialBlackFactor(double w) : istd(w) {} };
 // MarginalizationInfo's product: the linearised prior (J, r0, x0) over its kept blocks
 struct MarginalizationFactor : CostFunction {
@@ -183,14 +235,41 @@ class ParameterBlockOrdering {
 
 class Problem;
 namespace internal {
-// the modified Ceres' private globals, as the reference uses them (R/swf/swf_gnss.cpp:25-94): C++17 inline variables, so the
-// names are ordinary identifiers of this namespace (no macros leak into the including translation unit)
-inline std::vector<double*> parameter_head;
-inline bool is_optimize = true;
-// lhs_out / rhs_out / lhs_out2 / hs_row of the LAST successful Solve; reset by a failed Solve and by the destruction of the
-// Problem they point into
+// the modified Ceres' private globals under their own names, as the reference reads and writes them (R/swf/swf_gnss.cpp:20-94:
+// the bodies of UpdateSchur / UpdateSchurHessianOnly compile unchanged against these): one object per program without C++17
+// inline variables (the reference builds with -std=c++14) — the objects are static members of a class template, the names are
+// namespace-scope references bound to them at static-initialisation time; no macros leak into the including translation unit.
+// lhs_out (hs_row x hs_row, full symmetric, row-major) / rhs_out / lhs_out2 (the lower factor, row-major) /
+// hs_row belong to the LAST successful Solve; a failed Solve and the destruction of the Problem they point into reset them to null.
+// (Non-const pointers because the reference maps them with Eigen::Map<VectorXd> / Map<ceres::Matrix>; the memory is the solver's:
+// read only.)
+template <class = void> struct Globals {
+    static std::vector<double*> parameter_head; static bool is_optimize;
+    static double* lhs_out; static double* rhs_out; static double* lhs_out2; static int hs_row; static const Problem* owner;
+};
+template <class T> std::vector<double*> Globals<T>::parameter_head;
+template <class T> bool Globals<T>::is_optimize = true;
+template <class T> double* Globals<T>::lhs_out = nullptr;
+template <class T> double* Globals<T>::rhs_out = nullptr;
+template <class T> double* Globals<T>::lhs_out2 = nullptr;
+template <class T> int Globals<T>::hs_row = 0;
+template <class T> const Problem* Globals<T>::owner = nullptr;
+#if defined(__GNUC__)
+#define SWF_CERES_UNUSED __attribute__((unused))
+#else
+#define SWF_CERES_UNUSED
+#endif
+static std::vector<double*>& parameter_head SWF_CERES_UNUSED = Globals<>::parameter_head;
+static bool& is_optimize SWF_CERES_UNUSED = Globals<>::is_optimize;
+static double*& lhs_out SWF_CERES_UNUSED = Globals<>::lhs_out;
+static double*& rhs_out SWF_CERES_UNUSED = Globals<>::rhs_out;
+static double*& lhs_out2 SWF_CERES_UNUSED = Globals<>::lhs_out2;
+static int& hs_row SWF_CERES_UNUSED = Globals<>::hs_row;
+#undef SWF_CERES_UNUSED
+inline void reset_exports() { Globals<>::lhs_out = Globals<>::rhs_out = Globals<>::lhs_out2 = nullptr; Globals<>::hs_row = 0; Globals<>::owner = nullptr; }
+// the same four values as one struct (the accessor of rounds 1-4, kept for callers written against it)
 struct Exports { const double* lhs_out = nullptr; const double* rhs_out = nullptr; const double* lhs_out2 = nullptr; int hs_row = 0; const Problem* owner = nullptr; };
-inline Exports& exports() { static Exports e; return e; }
+inline Exports exports() { Exports e; e.lhs_out = Globals<>::lhs_out; e.rhs_out = Globals<>::rhs_out; e.lhs_out2 = Globals<>::lhs_out2; e.hs_row = Globals<>::hs_row; e.owner = Globals<>::owner; return e; }
 // ceres::internal::ResidualBlock as the estimator sees it: a handle whose public is_use flag it flips directly
 // (R/swf/swf_image.cpp:353-365,422; R/swf/swf_gnss.cpp:653).  Solve() carries the flags over to swf_factor_set_enabled.
 struct ResidualBlock { bool is_use = true; swf_factor_id id = -1; };
@@ -202,7 +281,7 @@ class Problem {
   public:
     Problem() { if (swf_problem_create(&h_) != SWF_OK) throw std::runtime_error("swf_problem_create"); }
     ~Problem() {
-        if (internal::exports().owner == this) internal::exports() = internal::Exports();
+        if (internal::Globals<>::owner == this) internal::reset_exports();
         swf_problem_destroy(h_);
     }
     Problem(const Problem&) = delete;
@@ -220,7 +299,7 @@ class Problem {
     int ParameterBlockSize(const double* p) const { return swf_parameter_block_size(h_, p); }
     int NumParameterBlocks() const { return swf_num_parameter_blocks(h_); }
     int NumResidualBlocks() const { return swf_num_residual_blocks(h_); }
-    void RemoveResidualBlock(ResidualBlockId rb) { chk(swf_remove_factor(h_, rb->id), "RemoveResidualBlock"); }
+    void RemoveResidualBlock(ResidualBlockId rb) { chk(swf_remove_factor(h_, rb->id), "RemoveResidualBlock"); hidden_.erase(rb->id); }
     // the query surface GlobalMarge / FeatureManager walk (R/swf/swf_image.cpp:350-367, R/swf/swf.cpp:413-422)
     void GetResidualBlocks(std::vector<ResidualBlockId>* out) const {
         int32_t n = 0; chk(swf_get_residual_blocks(h_, nullptr, 0, &n), "GetResidualBlocks");
@@ -249,6 +328,9 @@ class Problem {
         for (swf_factor_id i : ids) if ((rc = swf_factor_set_enabled(h_, i, handle_of(i)->is_use ? 1 : 0)) != SWF_OK) return rc;
         return SWF_OK;
     }
+    // hidden epochs of composite factors built from an IMUGNSSBase: epochs' own memory <-> the contiguous copies the solver works on
+    void GatherHiddenEpochs() { for (auto& kv : hidden_) kv.second->gather(); }
+    void ScatterHiddenEpochs() const { for (const auto& kv : hidden_) kv.second->scatter(); }
     void SetConstants(const double* pbg, const double* gw, const double* base) { chk(swf_set_constants(h_, pbg, gw, base), "SetConstants"); }
 
     // AddResidualBlock overloads by cost-function type; Problem takes ownership of cost and loss
@@ -296,6 +378,7 @@ class Problem {
         swf_factor_id id = swf_add_imu_gnss(h_, param[0], param[1], param[2], param[3], param.data() + 4, N, I.M, I.hidden_pose, I.hidden_sb,
                                               I.pose_lin.data(), I.sb_lin.data(), I.Hpp.data(), I.HpN.data(), I.rhs_p.data(), I.HNN.data(), I.rhsN.data(), I.pre.data());
         if (id >= 0 && I.mid > 0 && swf_set_imu_gnss_mid_link(h_, id, I.mid, I.H12.data()) != SWF_OK) throw std::runtime_error(swf_last_error());
+        if (id >= 0 && f->owned) hidden_[id] = std::move(f->owned);      // built from an IMUGNSSBase: the Problem keeps the contiguous hidden epochs alive
         delete f; delete loss; return ck(id);
     }
     ResidualBlockId AddResidualBlock(InitialBlackFactor* f, LossFunction* loss, double* scalar) {
@@ -327,6 +410,7 @@ class Problem {
     }
     swf_problem* h_ = nullptr;
     mutable std::vector<std::unique_ptr<internal::ResidualBlock>> rb_;
+    std::map<swf_factor_id, std::unique_ptr<IMUGNSSInfo>> hidden_;
 };
 
 struct Solver {
@@ -374,15 +458,21 @@ inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* s) {
         rc = swf_set_ordering(p->handle(), ord ? ord->keys_.data() : nullptr, ord ? ord->groups_.data() : nullptr, ord ? ord->NumElements() : 0);
     }
     if (rc == SWF_OK) rc = swf_set_export_tail(p->handle(), internal::parameter_head.data(), (int32_t)internal::parameter_head.size());
-    if (rc == SWF_OK) rc = swf_problem_solve(p->handle(), &opt, &s->raw);
-    internal::Exports& e = internal::exports();
     if (rc == SWF_OK) {
-        e = internal::Exports();
-        if (swf_get_reduced(p->handle(), &e.lhs_out, &e.rhs_out, &e.lhs_out2, &e.hs_row) == SWF_OK) e.owner = p; else e = internal::Exports();
+        p->GatherHiddenEpochs();
+        rc = swf_problem_solve(p->handle(), &opt, &s->raw);
+        if (rc == SWF_OK) p->ScatterHiddenEpochs();
+    }
+    internal::reset_exports();
+    if (rc == SWF_OK) {
+        const double *lo = nullptr, *ro = nullptr, *lo2 = nullptr; int32_t hr = 0;
+        if (swf_get_reduced(p->handle(), &lo, &ro, &lo2, &hr) == SWF_OK) {
+            internal::Globals<>::lhs_out = const_cast<double*>(lo); internal::Globals<>::rhs_out = const_cast<double*>(ro);
+            internal::Globals<>::lhs_out2 = const_cast<double*>(lo2); internal::Globals<>::hs_row = hr; internal::Globals<>::owner = p;
+        }
     } else {
         if (s->message.empty()) s->message = swf_last_error();
         std::fprintf(stderr, "swf_ceres::Solve failed (%d): %s\n", rc, s->message.c_str());
-        e = internal::Exports();
     }
     s->initial_cost = s->raw.initial_cost; s->final_cost = rc == SWF_OK ? s->raw.final_cost : 1e300;   // callers test final_cost > 1e10
     s->minimizer_time_in_seconds = s->raw.minimizer_time_in_seconds;

@@ -146,11 +146,15 @@ int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, double* J, int
  * the null directions — while the factorisation of the whole S breaks down in the tail of such a window (the solve reports
  * SWF_LINEAR_SOLVER_FAILURE): SWF_PRIOR_EIGEN then re-factors the first m columns only and takes a rank-revealing factor of
  * A (rank < n is reported, the prior is valid); SWF_PRIOR_CHOLESKY has no such variant and reports rank -1.  A breakdown
- * inside S_mm itself is a failure in both forms (rank -1, no silent fallback).  SWF_PRIOR_EIGEN: n <= 384 (the Jacobi iteration keeps M in LDS up to n = 140, in an HBM scratch above);
- * SWF_PRIOR_CHOLESKY: n <= 512.  Asynchronous on the batch stream up to tails of 140 dimensions; SWF_PRIOR_EIGEN above that (the block-Jacobi
+ * inside S_mm itself is a failure in both forms (rank -1, no silent fallback).  Both forms: n <= SWF_MAX_TAIL_DIM = 640, the limit
+ * of the tiled factorisation of the reduced system itself (SWF_PRIOR_EIGEN: the Jacobi iteration keeps its matrix in LDS up to n = 140; above
+ * that it is a block Jacobi over many workgroups on an HBM scratch, 8-column blocks up to 576 dimensions, 4-column blocks to 640).  A
+ * healthy window's eigen form keeps every direction whose information exceeds eps (the pivoted Cholesky that preconditions the sweeps
+ * runs down to pivots of eps / (16 n), whatever the largest diagonal entry).  Asynchronous on the batch stream up to tails of 140 dimensions; SWF_PRIOR_EIGEN above that (the block-Jacobi
  * schedule over many workgroups) is SYNCHRONOUS: the host reads the rotation counters back every few sweeps to stop enqueueing, so the
  * call blocks the calling thread until the priors exist. */
 enum { SWF_PRIOR_EIGEN = 0, SWF_PRIOR_CHOLESKY = 1 };
+#define SWF_MAX_TAIL_DIM 640
 int swf_batch_marginalize(swf_batch* b, double eps, int32_t form);
 /* Results of the last swf_batch_marginalize for window w (synchronises).  Any pointer may be NULL; eig receives the n
  * eigenvalues (ascending; for SWF_PRIOR_CHOLESKY the squared diagonal of L_nn). */

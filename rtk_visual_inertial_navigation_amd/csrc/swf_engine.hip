@@ -232,6 +232,8 @@ struct swf_batch {
         if (aux) { (void)hipStreamSynchronize(aux); handle_cache().give(aux); }
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
+    bool no_lm_clique = false, marg_one_wg = false, marg_no_pchol = false, marg_trace = false, marg_no_crit = false;      // A/B knobs, read once at creation
+    int marg_first_check = 6;
     bool post_fuse = false;               // SWF_POST_FUSE=1: the one-grid forms of k_post_chol / k_post_dogleg at every batch size (A/B timing)
     bool post_split = false;              // SWF_POST_SPLIT=1: the landmark segment of k_post_chol apart from the others whatever the batch size (A/B timing)
     bool lat_fuse = false;                // latency path: fused grids on one stream (see swf_batch_create)
@@ -851,6 +853,14 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->post_split = getenv("SWF_POST_SPLIT") != nullptr;
     b->post_fuse = getenv("SWF_POST_FUSE") != nullptr;
     b->fs_fused = getenv("SWF_FS_SEPARATE") == nullptr;
+    // (every A/B knob is read once, here: no getenv on the latency path or inside the marginalisation's sweep loop, and none that could
+    // race a setenv from the per-device enqueue threads of swf_solve_batches)
+    b->no_lm_clique = getenv("SWF_NO_LM_CLIQUE") != nullptr;
+    b->marg_one_wg = getenv("SWF_MARG_ONE_WG") != nullptr;
+    b->marg_no_pchol = getenv("SWF_MARG_NO_PCHOL") != nullptr;
+    b->marg_trace = getenv("SWF_MARG_TRACE") != nullptr;
+    b->marg_no_crit = getenv("SWF_MARG_NO_CRIT") != nullptr;
+    b->marg_first_check = getenv("SWF_MARG_FIRST_CHECK") ? atoi(getenv("SWF_MARG_FIRST_CHECK")) : 6;
     // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
     // fills what one-block-per-window kernels leave idle (measured: 256 windows 5.52 -> 5.22 ms, 128 windows 3.73 -> 3.49 ms per solve; 64 and
     // 512 windows: no gain)
@@ -1501,7 +1511,7 @@ struct Launcher {
                 // latency path: the one-wavefront cliques ride in the same grid (k_lm_clique); the 64-frame class has no LDS to spare for them
                 // (a workgroup of that grid fills a CU: only while all of them — landmark parts and cliques — are resident at once)
                 const int crow = D.n_win > 0 ? (D.n_clc[2] + D.n_win - 1) / D.n_win : 0;
-                clq_fused = b->lat_fuse && b->ls_var <= 2 && D.n_clc[2] > 0 && !D.n_clc[0] && !D.n_clc[1] && !getenv("SWF_NO_LM_CLIQUE")
+                clq_fused = b->lat_fuse && b->ls_var <= 2 && D.n_clc[2] > 0 && !D.n_clc[0] && !D.n_clc[1] && !b->no_lm_clique
                             && (long long)D.n_win * (GEMM_SPLIT / b->ls_qpb + crow) <= b->n_cu;
                 lm_launch(0, st, clq_fused ? crow : 0);
                 lm_next = ls_tiles_per_launch();        // further tile ranges: launched below, on the auxiliary stream when there is one
@@ -1695,7 +1705,8 @@ extern "C" int swf_solve_batches(swf_batch* const* batches, int32_t n, const swf
     int rc_all = SWF_OK; std::string msg;
     for (int i = 0; i < n; i++) if (rcs[(size_t)i] != SWF_OK && rc_all == SWF_OK) { rc_all = rcs[(size_t)i]; msg = msgs[(size_t)i]; }
     for (int i = 0; i < n; i++) {
-        if (rcs[(size_t)i] != SWF_OK) continue;
+        // (also a batch whose enqueue FAILED: swf_batch_solve can fail at a launch check with dozens of kernels already on its stream)
+        if (!batches[i]) continue;
         int rc = swf_batch_sync(batches[i]);
         if (rc != SWF_OK && rc_all == SWF_OK) { rc_all = rc; msg = g_err; }
     }
@@ -1815,7 +1826,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
     // rank-revealing factor of A; every other window leaves this kernel at once
     // rows of V the pivoted Cholesky (d_pivoted_chol) takes per pass over its pool: what 150 KB of LDS leave next to 25 rows of the tail
     const int mg_rc = std::max(16, std::min(ldn, (int)((150 * 1024 / 8 - (RS_POOL + 1) * (long)ldn) / RS_POOL)));
-    const int force = getenv("SWF_FORCE_MARG_RESCUE") ? 1 : 0;      // testing aid: healthy windows through the rank-deficient path too
+    const int force = getenv("SWF_FORCE_MARG_RESCUE") ? 1 : 0;      // (read once per call, outside the sweep loop: the tests toggle it between two calls on one batch)      // testing aid: healthy windows through the rank-deficient path too
     if (form == SWF_PRIOR_EIGEN)
         {
             // dynamic LDS: the 16-column panel over (n_red + 1) rows, later the pivoted Cholesky's pool (24 rows of the tail), its diagonal
@@ -1840,15 +1851,15 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                                b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M,
                                (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force, ph, b->mg_bjok);
         };
-        if (getenv("SWF_MARG_ONE_WG")) phase(0);              // A/B: the single-workgroup sweeps
+        if (b->marg_one_wg) phase(0);              // A/B: the single-workgroup sweeps
         else {
             phase(1);
             hipLaunchKernelGGL(k_marg_gram, dim3((ldn * ldn + 255) / 256, nw), dim3(256), 0, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_M, b->mg_A, (const int*)b->mg_bjok);
-            if (!getenv("SWF_MARG_NO_PCHOL")) {
+            if (!b->marg_no_pchol) {
                 // the Jacobi preconditioner: pivoted Cholesky of A into the G slab (9 sweeps instead of 16 at the 263-dimension tail)
                 const size_t lds = sizeof(double) * ((size_t)(RS_POOL + 1) * (size_t)ldn + (size_t)RS_POOL * (size_t)mg_rc);
                 if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_marg_pchol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(k_marg_pchol, dim3(nw), dim3(1024), lds, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_A, b->mg_resM, b->mg_M, (const int*)b->mg_bjok, mg_rc);
+                hipLaunchKernelGGL(k_marg_pchol, dim3(nw), dim3(1024), lds, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_A, b->mg_resM, b->mg_M, (const int*)b->mg_bjok, mg_rc, eps);
             }
             // block size by window: 8 columns up to 576 dimensions (17 workgroups per launch at 263 dimensions, 8 inner steps each; 16-column
             // blocks halve the launches but leave a step to 9 workgroups whose 16 waves share 4 SIMDs: 49 us per launch against 16), 4 above.
@@ -1858,7 +1869,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
             std::vector<int> hrot((size_t)nw * MG_SWEEPS);
             // from the sixth sweep on, one look at the rotation counts per sweep: 30 us of synchronisation against the 34 launches of a
             // 263-dimension sweep (0.55 ms) that a check every fourth sweep ran up to three times too often
-            const int mg_first_check = getenv("SWF_MARG_FIRST_CHECK") ? atoi(getenv("SWF_MARG_FIRST_CHECK")) : 6;
+            const int mg_first_check = b->marg_first_check;
             for (int sweep = 0; sweep < MG_SWEEPS; sweep++) {
                 if (sweep >= mg_first_check) {
                     // every four sweeps: has every window reported a sweep without rotations?  (the launches of a converged window return
@@ -1867,7 +1878,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                     HIPCHK(hipStreamSynchronize(b->stream));
                     bool all = true;
                     for (int w = 0; w < nw && all; w++) { bool done = false; for (int k = 0; k < sweep; k++) done = done || hrot[(size_t)w * MG_SWEEPS + k] == 0; all = done; }
-                    if (getenv("SWF_MARG_TRACE")) { fprintf(stderr, "marg sweep %d rotations (window 0):", sweep); for (int k = 0; k < sweep; k++) fprintf(stderr, " %d", hrot[k]); fprintf(stderr, "\n"); }
+                    if (b->marg_trace) { fprintf(stderr, "marg sweep %d rotations (window 0):", sweep); for (int k = 0; k < sweep; k++) fprintf(stderr, " %d", hrot[k]); fprintf(stderr, "\n"); }
                     if (all) break;
                 }
 #define BJ_LAUNCH(BS_, LDM_, NR_) hipLaunchKernelGGL((k_marg_bj<BS_, LDM_, NR_>), grid, dim3(1024), 0, b->stream, (const int*)b->mg_tail, ldn, b->mg_M, b->mg_rot, b->mg_crit, (const int*)b->mg_bjok, sweep, st)
@@ -1884,7 +1895,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                     for (int st = -1; st < nbe - 1; st++) { dim3 grid(nbe / 2, nw); BJ_LAUNCH(4, 640, 10); }
                 }
 #undef BJ_LAUNCH
-                if (!getenv("SWF_MARG_NO_CRIT")) hipLaunchKernelGGL(k_marg_bj_crit, dim3((nw + 63) / 64), dim3(64), 0, b->stream, (const int*)b->mg_tail, nw, b->mg_rot, b->mg_crit, (const int*)b->mg_bjok, sweep);
+                if (!b->marg_no_crit) hipLaunchKernelGGL(k_marg_bj_crit, dim3((nw + 63) / 64), dim3(64), 0, b->stream, (const int*)b->mg_tail, nw, b->mg_rot, b->mg_crit, (const int*)b->mg_bjok, sweep);
             }
             phase(2);
         }

@@ -1102,8 +1102,14 @@ template <int NCW, int TPW, int TW, int LDR>
 __global__ void __launch_bounds__(LS_NT(NCW, TW)) k_lm_clique(DevBatch B, DevOpt O, int qpb, int lp, int kms, int s_direct, int n_parts) {
     if ((int)blockIdx.y < n_parts) d_lm_schur<NCW, TPW, TW, LDR, true>(B, O, qpb, lp, kms, s_direct, (int)blockIdx.x, (int)blockIdx.y);
     else {
-        if (threadIdx.x >= 256) return;
-        d_clique_elim<64, 64, 9, 2, 8, 4, 4>(B, O, ((int)blockIdx.y - n_parts) * (int)gridDim.x + (int)blockIdx.x);
+        // Waves 4 .. 15 END here, ahead of the __syncthreads() inside d_clique_elim<..., NW = 4>.  That leans on a property of the gfx9
+        // hardware barrier, not of the HIP programming model: s_barrier counts the waves of the workgroup that have NOT terminated (CDNA ISA,
+        // "S_BARRIER": terminated waves are not waited for), so the four surviving waves synchronise among themselves.  Written for
+        // gfx950 only (the file has no other target); the surviving-wave count is tied to the clique function's NW below.
+        constexpr int CLQ_NW = 4;
+        static_assert(CLQ_NW * 64 == 256 && LS_NT(NCW, TW) >= CLQ_NW * 64, "k_lm_clique: the clique rows keep exactly the waves d_clique_elim<..., NW> synchronises");
+        if (threadIdx.x >= CLQ_NW * 64) return;
+        d_clique_elim<64, 64, 9, 2, 8, 4, CLQ_NW>(B, O, ((int)blockIdx.y - n_parts) * (int)gridDim.x + (int)blockIdx.x);
     }
 }
 

@@ -68,7 +68,12 @@
 #define RS_POOL 24                        // candidate rows held per block (16 of them at most become pivots)
 #define RS_GONE (-1e300)
 template <bool INPLACE>
-__device__ __forceinline__ void d_pivoted_chol(const double* A, double* V, double* VT, double* Rb, double* dg, double* stg, const int rc, const int n) {
+// drop_abs: the stopping rule.  The rank-deficient tails pass 0: a pivot below 1e-14 of the largest ends the factorisation (rank-revealing).
+// The preconditioner of a HEALTHY window (its Cholesky went through: A is numerically definite) passes eps / (16 n), eps = the caller's
+// eigenvalue threshold (the reference's 1e-8, R/factor/marginalization_factor.cpp:463-470): there the relative cut alone would drop
+// whole directions the reference keeps — with diag(A) ~ 1e10 it sits at 1e-4, far above eps — whereas a factorisation that ends at a
+// pivot p leaves a remainder of trace <= (n - r) p, i.e. below eps / 16 in every direction: nothing the eps test would have kept is lost.
+__device__ __forceinline__ void d_pivoted_chol(const double* A, double* V, double* VT, double* Rb, double* dg, double* stg, const int rc, const int n, const double drop_abs = 0.0) {
     __shared__ int cid[RS_POOL];                          // the block's candidates (indices)
     __shared__ double cdg[RS_POOL];                       // their running diagonal entries; -2 once taken, -1 for an empty slot
     __shared__ int ncand_s;
@@ -122,6 +127,7 @@ __device__ __forceinline__ void d_pivoted_chol(const double* A, double* V, doubl
         if (ncand == 0) break;
         if (d0_s < 0.0) { __syncthreads(); if (tid == 0) d0_s = cdg[0]; __syncthreads(); }
         const double d0 = d0_s;
+        const double thr = drop_abs > 0.0 ? fmin(1e-14 * d0, drop_abs) : 1e-14 * d0;
         // ---- the pool's rows of the Schur complement: thread (g, i) forms entry i of all of them over every ng-th row of V
         {
             double acc[RS_POOL];
@@ -179,7 +185,7 @@ __device__ __forceinline__ void d_pivoted_chol(const double* A, double* V, doubl
             const double bv = fmax(rows_lane(m16, 0), rows_lane(m16, 16));
             const unsigned long long hit = __builtin_amdgcn_ballot_w64(cv == bv);
             int bc = hit ? __builtin_ctzll(hit) : -1;
-            const int ok = (int)(bc >= 0 && bv > 1e-14 * d0 && bv > 0.0);      // uniform
+            const int ok = (int)(bc >= 0 && bv > thr && bv > 0.0);      // uniform
             if (!ok) { if (sblk == 0) stop = true; break; }      // numerically zero; the largest of all: rank reached
             const int p = __builtin_amdgcn_readfirstlane(cid[bc]); const double isq = rsqrt_nr(bv);
             // row of the pivot: its pool row minus the block's earlier rows (all requests before the first use); zero at eliminated indices
@@ -204,7 +210,7 @@ __device__ __forceinline__ void d_pivoted_chol(const double* A, double* V, doubl
         }
         PCACC(2);
         // pool members that are numerically null by now (a running diagonal only shrinks) are dropped for good
-        if (act && myslot >= 0) { const double di = dg[i]; if (di > 0.5 * RS_GONE && !(di > 1e-14 * d0)) dg[i] = RS_GONE; }
+        if (act && myslot >= 0) { const double di = dg[i]; if (di > 0.5 * RS_GONE && !(di > thr)) dg[i] = RS_GONE; }
         if (INPLACE) {
             // the block's rows to the front of the pool's slots, in pivot order (row swaps inside LDS: thread i moves column i)
             for (int t = 0; t < nbk; t++) {
@@ -433,7 +439,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     if (!GM && !rescued && phase != 2) {
         // preconditioner: G <- the pivoted Cholesky factor of A (d_pivoted_chol; the rows are built in place, G lives in LDS)
         __threadfence_block();
-        d_pivoted_chol<true>(outA + o2, lds, nullptr, nullptr, pc_dg, nullptr, 0, n);
+        d_pivoted_chol<true>(outA + o2, lds, nullptr, nullptr, pc_dg, nullptr, 0, n, eps / (16.0 * n));
     }
     if (phase == 1) { if (tid == 0) bj_ok[w] = rescued ? 2 : 1; return; }      // k_marg_gram, k_marg_pchol (1 only) and the sweeps of k_marg_bj follow
     int grp = tid >> 4, sub = tid & 15;
@@ -533,13 +539,13 @@ __global__ void __launch_bounds__(256) k_marg_gram(const int* tail_dim, int ldn,
 // The Jacobi preconditioner of the large tails: G <- the pivoted Cholesky factor of A = G G^T (columns v_r, original row order), one
 // workgroup per window, in the window's Mscr slab (ld = n; k_marg_gram is done with the old G).  Windows whose G already is one
 // (bj_ok == 2: k_marg_rescue supplied it) pass.
-__global__ void __launch_bounds__(1024) k_marg_pchol(const int* tail_dim, int ldn, const double* outA, double* vt_scr, double* Mscr, const int* bj_ok, int rc) {
+__global__ void __launch_bounds__(1024) k_marg_pchol(const int* tail_dim, int ldn, const double* outA, double* vt_scr, double* Mscr, const int* bj_ok, int rc, double eps) {
     extern __shared__ double rs_lds[];                  // the pool's rows 24 x n | diagonal n | staging 24 x rc
     const int w = blockIdx.x;
     if (bj_ok[w] != 1) return;
     const int n = tail_dim[w];
     const size_t o2 = (size_t)w * ldn * ldn;
-    d_pivoted_chol<false>(outA + o2, Mscr + o2, vt_scr + o2, rs_lds, rs_lds + (size_t)RS_POOL * n, rs_lds + (size_t)(RS_POOL + 1) * n, rc, n);
+    d_pivoted_chol<false>(outA + o2, Mscr + o2, vt_scr + o2, rs_lds, rs_lds + (size_t)RS_POOL * n, rs_lds + (size_t)(RS_POOL + 1) * n, rc, n, eps / (16.0 * n));
 }
 template <int BS, int LDM, int NR>       // NR = rows per lane the launch's largest tail needs (n <= 64 NR <= LDM)
 __global__ void __launch_bounds__(1024) k_marg_bj(const int* tail_dim, int ldn, double* Mscr, int* rot, unsigned long long* crit, const int* bj_ok, int sweep, int bstep) {

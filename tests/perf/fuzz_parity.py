@@ -9,12 +9,23 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_binding as ob
 import idepth_gen as ig
+import referee
 from rtk_visual_inertial_navigation_amd import synth, solver
 from rtk_visual_inertial_navigation_amd.flat import default_options
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+ONLY = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None      # solve this case only (the windows before it are still drawn: same random stream)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 rel = lambda a, b: np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+def device_linearize(w):
+    """(r, J) of the window's current state as the device holds them (ASSEMBLE_ELIMINATE_ONLY leaves the linearisation at the uploaded state)."""
+    b_ = solver.BatchSolver([w.copy()]); b_.solve(default_options(step_mode=1), download=False)
+    rJ = b_.export_jacobian(0); b_.close()
+    return rJ
+
+
 bad = 0
 wins = []
 for t in range(N):
@@ -38,6 +49,7 @@ for t in range(N):
     strat = 1 if rng.random() < 0.3 else 0                                  # Levenberg-Marquardt / dogleg
     opts = lambda **k: default_options(strategy=strat, **k)
     msg = []
+    if ONLY is not None and t != ONLY: continue
     try:
         so, eo = ob.solve(w.copy(), default_options(step_mode=1))
         bs = solver.BatchSolver([w.copy()]); sg = bs.solve(default_options(step_mode=1))[0]
@@ -56,10 +68,17 @@ for t in range(N):
             for a, b in zip(rg_, ro):
                 # a Gauss-Newton step carries eps * cond(S) relative error; the cost sequences of two correct solvers drift apart by that
                 if abs(a["cost"] - b["cost"]) > (5e-7 + 1e-17 * condS) * abs(b["cost"]) + 5e-5: msg.append("cost %.12e vs %.12e (rel %.2e) at iteration %d of %d, cond(S) %.2e" % (a["cost"], b["cost"], abs(a["cost"] - b["cost"]) / abs(b["cost"]), rg_.index(a), len(rg_), condS)); break
-            # final states: 1e-6, widened with the conditioning (a variable extrinsic leaves a nearly free direction: cond(S) 1e14..1e16, the two
-            # solvers — and the oracle with itself under another block order — then end ~1e-6 apart in the extrinsic at equal cost)
-            # (seed 777, case 55: cond(S) 1.8e13, costs equal to 1e-7, poses 2.9e-5 apart along the extrinsic's free direction: 3e-6, not 1e-6, per 1e12)
-            if np.abs(wg.a["pose"] - wo.a["pose"]).max() > 1e-6 * max(1.0, 3.0 * condS / 1e12): msg.append("pose %.2e (cond(S) %.2e, final cost rel %.2e)" % (np.abs(wg.a["pose"] - wo.a["pose"]).max(), condS, abs(rg_[-1]["cost"] - ro[-1]["cost"]) / abs(ro[-1]["cost"])))
+            # final states: 1e-6 where the minimiser is that well determined.  Where it is not (a variable extrinsic leaves a nearly free
+            # direction: cond(S) 1e13 .. 1e16; seed 777 case 55 ended 2.9e-5 apart in the pose at costs equal to 1e-7) the yardstick is
+            # MEASURED, not fitted: tests/referee.py runs the whole trust-region trajectory with every linear solve refined in extended
+            # precision (dense normal equations from the DEVICE's own linearisations), and the device must end no further from that
+            # referee than ten times what the oracle does (the pattern of test_marginalisation_consumer_matches_oracle's referee)
+            dpose = np.abs(wg.a["pose"] - wo.a["pose"]).max()
+            if dpose > 1e-6:
+                wr = referee.trajectory_referee(w, device_linearize, strategy=strat)
+                e_dev, e_or = np.abs(wg.a["pose"] - wr.a["pose"]).max(), np.abs(wo.a["pose"] - wr.a["pose"]).max()
+                print("   referee: device and oracle poses %.2e apart; from the extended-precision trajectory: device %.2e, oracle %.2e (cond(S) %.2e)" % (dpose, e_dev, e_or, condS), flush=True)
+                if e_dev > 10.0 * e_or + 1e-6: msg.append("pose: device %.2e from the referee, oracle %.2e (cond(S) %.2e, final cost rel %.2e)" % (e_dev, e_or, condS, abs(rg_[-1]["cost"] - ro[-1]["cost"]) / abs(ro[-1]["cost"])))
         if strat == 0: wins.append((w, wg, [r["cost"] for r in rg_]))
         bs.close()
     except Exception as e:
@@ -74,5 +93,5 @@ if wins:
         same = [r["cost"] for r in sm.rows()] == costs and all(np.array_equal(wg.a[k], wb.a[k]) for k in ("pose", "sb", "lm", "sc"))
         if not same: print("batch != single for case", i); bad += 1
     bs.close()
-print("fuzz: %d cases, %d failures" % (N, bad))
+print("fuzz: %d cases, %d failures" % (N if ONLY is None else 1, bad))
 sys.exit(1 if bad else 0)

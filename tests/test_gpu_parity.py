@@ -397,6 +397,57 @@ def test_marginalisation_with_a_singular_marginalised_block():
         bs0.close(); bs.close()
 
 
+def _with_weak_and_strong_tail_scalars(w0, weak=(3e-3, 1e-3, 3e-4), strong=1e5):
+    """Extra scalars INSIDE the parameter_head tail, each touched by one scalar prior only (InitialBlackFactor, information w^2):
+    one of information `strong`^2 = 1e10 and some of information 1e-5 .. 1e-7 — states the estimator has barely observed yet (a carrier-phase
+    ambiguity of a satellite that has just risen) next to a very well known one."""
+    from rtk_visual_inertial_navigation_amd.flat import FlatWindow
+    w = w0.copy()
+    n_sc = w.n_sc
+    a = {k: v.copy() for k, v in w.a.items()}
+    ws = [strong] + list(weak)
+    ne = len(ws)
+    a["sc"] = np.concatenate([a["sc"], 0.01 * np.arange(1, ne + 1)])
+    a["is_const"] = np.concatenate([a["is_const"], [0] * ne]).astype(np.uint8)
+    a["sp_idx"] = np.concatenate([a["sp_idx"].ravel(), n_sc + np.arange(ne)]).astype(np.int32)
+    a["sp_w"] = np.concatenate([a["sp_w"].ravel(), ws])
+    nb = w.n_blocks
+    g1 = int(a["order_group"].max()) + 1
+    a["order_block"] = np.concatenate([a["order_block"], nb + np.arange(ne)]).astype(np.int32)
+    a["order_group"] = np.concatenate([a["order_group"], g1 + np.arange(ne)]).astype(np.int32)
+    return FlatWindow(n_tail=w.n_tail + ne, proj_sqrt_info=w.proj_sqrt_info, proj_loss_a=w.proj_loss_a, pbg=w.pbg, gw=w.gw, base=w.base, meta=dict(w.meta), **a)
+
+
+def test_eigen_prior_keeps_weakly_observed_states_next_to_a_large_diagonal():
+    """the pivoted Cholesky that preconditions the Jacobi sweeps stopped at pivots below 1e-14 of the LARGEST diagonal
+    entry and dropped everything behind them; with diag(A) ~ 1e10 that cut sits at 1e-4, while the reference thresholds the eigenvalues at
+    an absolute 1e-8 (R/factor/marginalization_factor.cpp:463-470) — weakly observed states it keeps came out with eigenvalue 0 and a null
+    row of J.  On a healthy window the factorisation now runs down to eps / (16 n).  Tails on both Jacobi paths (LDS-resident, and
+    k_marg_pchol + k_marg_bj above 140 dimensions): the rank counts the weak states, J^T J = A, the eigenvalues are LAPACK's."""
+    weak = (3e-3, 1e-3, 3e-4)                       # informations 9e-6, 1e-6, 9e-8: all above 1e-8, all below 1e-14 * 1e10
+    for kw in (dict(config_id=3, K=4, F=20, S=8, seed=91, head="ambiguities"), dict(config_id=3, K=6, F=30, S=6, seed=92, head="frames"),
+               dict(config_id=3, K=10, F=60, S=6, seed=93, head="frames")):
+        w = _with_weak_and_strong_tail_scalars(synth.make_window(**kw), weak=weak)
+        bs, sg = gpu_solve(w.copy(), default_options(step_mode=1))
+        assert sg.termination == 7                      # SWF_ASSEMBLED_ONLY: a healthy window, its Cholesky went through (6 = LINEAR_SOLVER_FAILURE)
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_CHOLESKY); c = bs.get_prior(0)
+        bs.marginalize(1e-8, solver.BatchSolver.PRIOR_EIGEN); g = bs.get_prior(0)
+        bs.close()
+        A = g["A"]; n = g["n"]; sc = np.abs(A).max(); lam = np.linalg.eigvalsh(A)
+        assert sc >= 1e10 and np.array_equal(A, c["A"])
+        d = np.diag(A)[-len(weak):]
+        assert np.allclose(d, np.square(weak), rtol=1e-12) and np.all(d < 1e-14 * sc) and np.all(d > 1e-8)
+        assert g["rank"] == n == int((lam > 1e-8).sum()), (g["rank"], n, kw)
+        # the weak states' rows: each an eigen-direction of its own (they couple to nothing), eigenvalue = its information
+        ev = np.sort(g["eig"])
+        assert np.abs(ev[:3] - np.sort(np.square(weak))).max() <= 1e-12 * np.square(weak).max(), ev[:4]
+        assert np.abs(ev - lam).max() <= 1e-12 * sc
+        JtJ = g["J"].T @ g["J"]
+        assert np.abs(JtJ - A).max() <= 1e-12 * sc
+        assert np.abs(np.diag(JtJ)[-len(weak):] - d).max() <= 1e-10 * d.max(), (np.diag(JtJ)[-len(weak):], d)
+        assert np.abs(g["J"].T @ g["r0"] - g["b"]).max() <= 1e-10 * np.abs(g["b"]).max()
+
+
 def test_marginalisation_of_a_rank_deficient_tail(monkeypatch):
     """The reference pseudo-inverts only S_mm and lets the eigen square root drop the null directions of A (UpdateSchur +
     setmarginalizeinfo): a marginal that is singular on the kept states is business as usual there.  On the device the Cholesky
