@@ -212,7 +212,7 @@ struct swf_batch {
     int max_tiles = 0, max_prior_dim = 0, max_red = 0, min_red = 1 << 30, n_cu = 256;
     bool clc_imu[4] = { false, false, false, false };
     // composite IMU-GNSS factors of the batch (swf_kernels4.h): operator arguments, solver-side bookkeeping, initial hidden epochs
-    CompArgs CA{}; CompMeta CM{}; int n_comp = 0, comp_nmax = 0; long long comp_ne = 0;
+    CompArgs CA{}; CompMeta CM{}; int n_comp = 0, comp_nmax = 0, comp_nmin = 1 << 30; long long comp_ne = 0;
     bool comp_eigen_root = false;                      // SWF_COMP_EIGEN_ROOT=1 at create: the composite factors expose the reference's eigen square root
     double* co_pose0 = nullptr; double* co_sb0 = nullptr;    // clique class holds IMU factors (its elimination must follow k_eval_imu)
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
@@ -1241,7 +1241,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         std::vector<long long> pno(nc + 1, 0), nno(nc + 1, 0), go(nc + 1, 0), g2o(nc + 1, 0), Joff(nc), Coff(nc);
         for (int f = 0; f < nc; f++) {
             const int M = B.co_M[f], N = B.co_N[f], G = 30 + N;
-            b->comp_nmax = std::max(b->comp_nmax, N);
+            b->comp_nmax = std::max(b->comp_nmax, N); b->comp_nmin = std::min(b->comp_nmin, N);
             eo[f + 1] = eo[f] + M; no[f + 1] = no[f] + N; pno[f + 1] = pno[f] + 15LL * M * N; nno[f + 1] = nno[f] + (long long)N * N;
             go[f + 1] = go[f] + G; g2o[f + 1] = g2o[f] + (long long)G * G;
             const GFac& Gf = B.gf[B.co_gf[f]];
@@ -1470,8 +1470,17 @@ struct Launcher {
             hipLaunchKernelGGL(k_comp_gather, dim3(b->n_comp), dim3(128), 0, st, D, b->CA, b->CM);
             hipLaunchKernelGGL(k_comp_prep, dim3(b->n_comp), dim3(256), 0, st, b->CA);
             hipLaunchKernelGGL(k_comp_imu, dim3((b->CA.n_iq + 7) / 8), dim3(256), 0, st, b->CA);
-            if (b->comp_nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_elim<CO_SMALLN>, dim3(b->n_comp), dim3(256), 0, st, b->CA);
-            else hipLaunchKernelGGL(k_comp_elim<CO_MAXN>, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            // (an instantiation per class of factor, each passing over the other's: a factor's arithmetic does not depend on its batch)
+            // 1024 threads per factor while the chip holds every factor at once (two such workgroups per CU), 256 for larger batches
+            const bool wide = b->n_comp <= 2 * b->n_cu;
+            if (b->comp_nmin <= CO_SMALLN) {
+                if (wide) hipLaunchKernelGGL((k_comp_elim<CO_SMALLN, 1024>), dim3(b->n_comp), dim3(1024), 0, st, b->CA);
+                else hipLaunchKernelGGL((k_comp_elim<CO_SMALLN, 256>), dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            }
+            if (b->comp_nmax > CO_SMALLN) {
+                if (wide) hipLaunchKernelGGL((k_comp_elim<CO_MAXN, 1024>), dim3(b->n_comp), dim3(1024), 0, st, b->CA);
+                else hipLaunchKernelGGL((k_comp_elim<CO_MAXN, 256>), dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            }
             if (b->comp_eigen_root) {
                 if (b->comp_nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_eigroot<CO_SMALLN>, dim3(b->n_comp), dim3(256), 0, st, b->CA);
                 else hipLaunchKernelGGL(k_comp_eigroot<CO_MAXN>, dim3(b->n_comp), dim3(512), 0, st, b->CA);
@@ -2133,7 +2142,7 @@ extern "C" int swf_debug_gemm_stamps(unsigned long long* out) {
 struct swf_composite {
     CompArgs A{};
     std::vector<void*> bufs;
-    int n = 0, nmax = 0; long long sumM = 0, sumN = 0, sumG = 0, sumG2 = 0;
+    int n = 0, nmax = 0, nmin = 0; long long sumM = 0, sumN = 0, sumG = 0, sumG2 = 0;
     std::vector<int> M;
     bool eigen_root = false;
     hipStream_t stream = nullptr;
@@ -2150,17 +2159,17 @@ extern "C" int swf_composite_create(int32_t n, const int32_t* M, const int32_t* 
         return fail(SWF_E_INVALID, "swf_composite_create: null argument");
     std::vector<int> eo(n + 1, 0), no(n + 1, 0);
     std::vector<long long> pno(n + 1, 0), nno(n + 1, 0), go(n + 1, 0), g2o(n + 1, 0);
-    int nmax_ = 0;
+    int nmax_ = 0, nmin_ = 1 << 30;
     for (int f = 0; f < n; f++) {
         if (M[f] < 1) return fail(SWF_E_INVALID, "composite factor without hidden epochs");
         if (N[f] < 0 || N[f] > CO_MAXN) return fail(SWF_E_UNSUPPORTED, "composite factor with more than 64 ambiguities");
-        nmax_ = std::max(nmax_, (int)N[f]);
+        nmax_ = std::max(nmax_, (int)N[f]); nmin_ = std::min(nmin_, (int)N[f]);
         eo[f + 1] = eo[f] + M[f]; no[f + 1] = no[f] + N[f];
         pno[f + 1] = pno[f] + 15LL * M[f] * N[f]; nno[f + 1] = nno[f] + (long long)N[f] * N[f];
         go[f + 1] = go[f] + 30 + N[f]; g2o[f + 1] = g2o[f] + (long long)(30 + N[f]) * (30 + N[f]);
     }
     std::unique_ptr<swf_composite> c(new swf_composite());
-    c->n = n; c->nmax = nmax_; c->sumM = eo[n]; c->sumN = no[n]; c->sumG = go[n]; c->sumG2 = g2o[n]; c->stream = (hipStream_t)stream;
+    c->n = n; c->nmax = nmax_; c->nmin = nmin_; c->sumM = eo[n]; c->sumN = no[n]; c->sumG = go[n]; c->sumG2 = g2o[n]; c->stream = (hipStream_t)stream;
     bool bad = false;
     auto up = [&](const void* src, size_t bytes) -> void* {
         void* d = nullptr;
@@ -2220,8 +2229,8 @@ extern "C" int swf_composite_evaluate(swf_composite* c, const double* outer, con
     A.want_jac = want_jac ? 1 : 0;
     hipLaunchKernelGGL(k_comp_prep, dim3(c->n), dim3(256), 0, st, A);
     hipLaunchKernelGGL(k_comp_imu, dim3((A.n_iq + 7) / 8), dim3(256), 0, st, A);
-    if (c->nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_elim<CO_SMALLN>, dim3(c->n), dim3(256), 0, st, A);
-    else hipLaunchKernelGGL(k_comp_elim<CO_MAXN>, dim3(c->n), dim3(256), 0, st, A);
+    if (c->nmin <= CO_SMALLN) hipLaunchKernelGGL((k_comp_elim<CO_SMALLN, 256>), dim3(c->n), dim3(256), 0, st, A);
+    if (c->nmax > CO_SMALLN) hipLaunchKernelGGL((k_comp_elim<CO_MAXN, 256>), dim3(c->n), dim3(256), 0, st, A);
     if (c->eigen_root) {
         if (c->nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_eigroot<CO_SMALLN>, dim3(c->n), dim3(256), 0, st, A);
         else hipLaunchKernelGGL(k_comp_eigroot<CO_MAXN>, dim3(c->n), dim3(512), 0, st, A);

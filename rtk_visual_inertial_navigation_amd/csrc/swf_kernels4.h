@@ -179,13 +179,21 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
 }
 
 // phase 3: re-elimination of the hidden epochs from the whitened IMU Jacobians of phase 2, remainder, square root
-template <int NMAX>
-__global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(CompArgs A) {
+// NT = threads per factor: 256 for batches (four workgroups per CU), 1024 on the latency path (a window's ~20 factors have the chip to
+// themselves, and with one wave per SIMD every phase below is bound by the instructions that wave issues: 13.6 k cycles for an epoch's
+// T products and Schur update at 256 threads).  Every output element is one thread's, from the same operands in the same order:
+// the thread count does not change a bit.
+template <int NMAX, int NT>
+__global__ void __launch_bounds__(NT, (NT == 256 && NMAX <= CO_SMALLN) ? 4 : 1) k_comp_elim(CompArgs A) {
     const int f = blockIdx.x, t = threadIdx.x;
     if (f >= A.n || !A.todo[f]) return;
+    // the instantiation is the FACTOR's (a launch of each covers a batch with factors of both classes): a factor's arithmetic does not
+    // depend on what else is in its batch (the two instantiations take different square roots since round 5)
+    if ((A.N[f] <= CO_SMALLN) != (NMAX <= CO_SMALLN)) return;
     const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
     const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
-    constexpr int POOL_A = 6 * 225 + 3 * 15 * NMAX + NMAX * NMAX, POOL_B = (30 + NMAX) * (31 + NMAX);
+    CHSTAMP(32);
+    constexpr int POOL_A = 6 * 225 + 3 * 15 * NMAX + NMAX * NMAX, POOL_B = (31 + NMAX) * (31 + NMAX);      // (G + 1 rows of padded length G | 1)
     __shared__ double pool[POOL_A > POOL_B ? POOL_A : POOL_B];                         // ten elimination blocks, later the dense remainder + rhs row
     double* const H00 = pool; double* const H01 = pool + 225; double* const H03 = pool + 450; double* const H11 = pool + 675;
     double* const H13 = pool + 900; double* const H33 = pool + 1125; double* const H0N = pool + 1350; double* const H1N = H0N + 15 * NMAX;
@@ -203,15 +211,16 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
     if (t == 0) sBad = 0;
     __syncthreads();
     // ---- re-elimination at the current outer / hidden states
-    for (int e = t; e < 225; e += 256) { H00[e] = 0; H01[e] = 0; H03[e] = 0; H11[e] = 0; H13[e] = 0; H33[e] = 0; }
-    for (int e = t; e < 15 * N; e += 256) { H0N[e] = 0; H1N[e] = 0; HN3[e] = 0; }
-    for (int e = t; e < N * N; e += 256) HNN[e] = A.HNN[nn0 + e];
+    for (int e = t; e < 225; e += NT) { H00[e] = 0; H01[e] = 0; H03[e] = 0; H11[e] = 0; H13[e] = 0; H33[e] = 0; }
+    for (int e = t; e < 15 * N; e += NT) { H0N[e] = 0; H1N[e] = 0; HN3[e] = 0; }
+    for (int e = t; e < N * N; e += NT) HNN[e] = A.HNN[nn0 + e];
     if (t < 15) { r0b[t] = 0; r1b[t] = 0; r3b[t] = 0; }
     __syncthreads();
     if (t < N) { double s = A.rhsN[n0 + t]; for (int k = 0; k < N; k++) s += HNN[t * N + k] * sNv[k]; rNb[t] = s; }       // UpdateRhsN
     // IMU factor k of the chain links state k-1 -> k (k = 0: frame_i -> e_0, k = M: e_M-1 -> frame_j)
     for (int k = 0; k <= M; k++) {
-        for (int e = t; e < 450; e += 256) sJ[e] = A.Jw[(size_t)(e0 + f + k) * 450 + e];
+        CHSTAMP(33 + k);
+        for (int e = t; e < 450; e += NT) sJ[e] = A.Jw[(size_t)(e0 + f + k) * 450 + e];
         if (t < 15) sRes[t] = A.rw[(size_t)(e0 + f + k) * 16 + t];
         if (k > 0 && t == 255)       // GetInc of the epoch that this factor completes (its GNSS prior is added in the same pass below)
             co_inc15(A.pose + (size_t)(e0 + k - 1) * 7, A.sb + (size_t)(e0 + k - 1) * 9, A.pose_lin + (size_t)(e0 + k - 1) * 7, A.sb_lin + (size_t)(e0 + k - 1) * 9, 1.0, sDx);
@@ -224,7 +233,7 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
         {
             double* Haa = k == 0 ? H33 : H00; double* Hx = k == 0 ? H03 : H01; double* Hbb = k == 0 ? H00 : H11;
             double* ra = k == 0 ? r3b : r0b; double* rb = k == 0 ? r0b : r1b;
-            for (int e = t; e < 675; e += 256) {
+            for (int e = t; e < 675; e += NT) {
                 int blk = e / 225, ee = e - blk * 225, i = ee / 15, j = ee - i * 15;
                 double s = 0;
                 if (blk == 0) { for (int q = 0; q < 15; q++) s += sJ[q * 30 + i] * sJ[q * 30 + j]; Haa[ee] += s; }
@@ -243,6 +252,7 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
             }
         }
         if (k == 0) { __syncthreads(); continue; }
+        if (k == 1) CHSTAMP(40);
         // ---- epoch i = k - 1 is complete: its GNSS prior in the same pass (every element below is touched by the thread that
         // accumulated it above), then eliminate it
         const int i = k - 1;
@@ -254,54 +264,36 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
             r0b[t] += s;
         }
         if (t >= 64 && t - 64 < N) { int a = t - 64; double s = 0; for (int q = 0; q < 15; q++) s += HpN[q * N + a] * sDx[q]; rNb[a] += s; }
-        for (int e = t; e < 225; e += 256) H00[e] += Hpp[e];
-        for (int e = t; e < 15 * N; e += 256) H0N[e] += HpN[e];
+        for (int e = t; e < 225; e += NT) H00[e] += Hpp[e];
+        for (int e = t; e < 15 * N; e += NT) H0N[e] += HpN[e];
         __syncthreads();
-        // MargPose1: Ainv = (H00)^-1 by Cholesky (InvertPSDMatrix<15>, assume_full_rank)
-        for (int e = t; e < 225; e += 256) { int a = e / 15, b = e - a * 15; sL[e] = (b <= a) ? H00[b * 15 + a] : 0.0; }     // lower from the upper triangle
+        if (k == 1) CHSTAMP(41);
+        // MargPose1: Ainv = (H00)^-1 (InvertPSDMatrix<15>, assume_full_rank).  Round 5: in-place Gauss-Jordan without pivoting over a 15 x 15
+        // grid of threads, two barriers per column (read the column and the row of the pivot, write the step): its pivots are the
+        // Cholesky pivots d_j of the same matrix (a non-positive one fails the factor as before), no square root, one reciprocal per column.
+        // (Rounds 1-4: a Cholesky with a barrier per column, then fifteen threads each running a forward and a backward substitution — thirty
+        // dependent IEEE divisions and 210 dependent multiply-adds on one lane: most of an epoch's 40 k cycles.)
+        for (int e = t; e < 225; e += NT) { int a = e / 15, b = e - a * 15; sAinv[e] = (b >= a) ? H00[e] : H00[b * 15 + a]; }     // full symmetric from the upper triangle
         __syncthreads();
-        for (int j = 0; j < 15; j++) {
-            // column j is final but unscaled (L[a][j] sqrt(d_j)); the trailing update needs only it and 1 / d_j: one barrier per column
-            double d = sL[j * 15 + j];
-            if (!(d > 0.0)) { if (t == 0) sBad = 1; d = 1.0; }
-            double inv = 1.0 / d;
-            if (t < 225) { int a = t / 15, b = t - a * 15; if (b > j && a >= b) sL[a * 15 + b] -= sL[a * 15 + j] * sL[b * 15 + j] * inv; }
-            __syncthreads();
-        }
         {
-            double vv = 0, dd = 1; bool low = false;
-            if (t < 225) { int a = t / 15, b = t - a * 15; low = a >= b; if (low) { dd = sL[b * 15 + b]; vv = sL[t]; } }
-            __syncthreads();
-            if (low) { int a = t / 15, b = t - a * 15; dd = dd > 0.0 ? dd : 1.0; sL[t] = (a == b) ? sqrt(dd) : vv / sqrt(dd); }
-            __syncthreads();
-        }
-        if (t < 15) {
-            // column t of the inverse: forward and backward substitution fully unrolled, the column in registers (constant
-            // indices), L read row by row as LDS broadcasts that do not depend on the chain; same operations in the same order
-            // as the in-place LDS solve this replaces
-            double z[15];
-#pragma unroll
-            for (int a = 0; a < 15; a++) {
-                asm volatile("" ::: "memory");              // one row of L in flight at a time (hoisting all 120 reads costs 240 VGPRs)
-                double s = (a == t) ? 1.0 : 0.0;
-#pragma unroll
-                for (int q = 0; q < a; q++) s -= sL[a * 15 + q] * z[q];
-                z[a] = s / sL[a * 15 + a];
+            const int ga = t / 15, gb = t - ga * 15;
+            for (int j = 0; j < 15; j++) {
+                double d = sAinv[j * 15 + j];
+                if (!(d > 0.0)) { if (t == 0) sBad = 1; d = 1.0; }
+                const double ip = rcp_nr(d);
+                double nv = 0.0;
+                if (t < 225) {
+                    const double aij = sAinv[t], aik = sAinv[ga * 15 + j], akj = sAinv[j * 15 + gb];
+                    nv = (ga == j) ? (gb == j ? ip : akj * ip) : (gb == j ? -(aik * ip) : aij - aik * (akj * ip));
+                }
+                __syncthreads();
+                if (t < 225) sAinv[t] = nv;
+                __syncthreads();
             }
-#pragma unroll
-            for (int a = 14; a >= 0; a--) {
-                asm volatile("" ::: "memory");
-                double s = z[a];
-#pragma unroll
-                for (int q = a + 1; q < 15; q++) s -= sL[q * 15 + a] * z[q];
-                z[a] = s / sL[a * 15 + a];
-            }
-#pragma unroll
-            for (int a = 0; a < 15; a++) sAinv[a * 15 + t] = z[a];
         }
-        __syncthreads();
+        if (k == 1) CHSTAMP(42);
         // T_blk = H0blk^T Ainv for blk = Pose2 (15), N, Pose0 (15)
-        for (int e = t; e < 450 + 15 * N; e += 256) {
+        for (int e = t; e < 450 + 15 * N; e += NT) {
             const double* Hs; double* Td; int sn, ee;
             if (e < 225) { Hs = H01; Td = T2; sn = 15; ee = e; } else if (e < 450) { Hs = H03; Td = T0; sn = 15; ee = e - 225; } else { Hs = H0N; Td = TN; sn = N; ee = e - 450; }
             int a = ee / 15, b = ee - a * 15;
@@ -316,7 +308,7 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
         else if (t >= 64 && t - 64 < N) { int a = t - 64; double s = 0; for (int q = 0; q < 15; q++) s += TN[a * 15 + q] * r0b[q]; rNb[a] -= s; }
         {
             const int nA = 225, nB = 15 * N, nC = 225, nD = N * N, nE = 15 * N, nF = 225;     // (2,2) (2,N) (2,0) (N,N) (N,0) (0,0)
-            for (int e = t; e < nA + nB + nC + nD + nE + nF; e += 256) {
+            for (int e = t; e < nA + nB + nC + nD + nE + nF; e += NT) {
                 const double* Tm; const double* Hs; double* Hd_; int sv, ee;
                 if (e < nA) { Tm = T2; Hs = H01; Hd_ = H11; sv = 15; ee = e; }
                 else if (e < nA + nB) { Tm = T2; Hs = H0N; Hd_ = H1N; sv = N; ee = e - nA; }
@@ -331,23 +323,25 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
             }
         }
         __syncthreads();
+        if (k == 1) CHSTAMP(43);
         // MoveHessianData: save what UpdateHiddenState needs, shift Pose2 -> Pose1
         {
             double* s_inv = A.hmn_inv + (size_t)(e0 + i) * 225; double* s_2 = A.hmn_2 + (size_t)(e0 + i) * 225; double* s_0 = A.hmn_0 + (size_t)(e0 + i) * 225;
             double* s_N = A.hmn_N + pn0 + (size_t)i * 15 * N;
-            for (int e = t; e < 225; e += 256) { s_inv[e] = sAinv[e]; s_2[e] = H01[e]; s_0[e] = H03[e]; }
-            for (int e = t; e < 15 * N; e += 256) s_N[e] = H0N[e];
+            for (int e = t; e < 225; e += NT) { s_inv[e] = sAinv[e]; s_2[e] = H01[e]; s_0[e] = H03[e]; }
+            for (int e = t; e < 15 * N; e += NT) s_N[e] = H0N[e];
             if (t < 15) A.rhsmn[(size_t)(e0 + i) * 15 + t] = r0b[t];
         }
         // (same element -> same thread in the save above and the shift below: no barrier between them)
-        for (int e = t; e < 225; e += 256) { H00[e] = H11[e]; H11[e] = 0; H03[e] = H13[e]; H13[e] = 0; H01[e] = 0; }
-        for (int e = t; e < 15 * N; e += 256) { H0N[e] = H1N[e]; H1N[e] = 0; }
+        for (int e = t; e < 225; e += NT) { H00[e] = H11[e]; H11[e] = 0; H03[e] = H13[e]; H13[e] = 0; H01[e] = 0; }
+        for (int e = t; e < 15 * N; e += NT) { H0N[e] = H1N[e]; H1N[e] = 0; }
         if (t < 15) { r0b[t] = r1b[t]; r1b[t] = 0; }
         __syncthreads();
     }
+    CHSTAMP(44);
     // UpdateSchurComponent: dense remainder in the order [Pose0 | Pose1 (= frame j) | N], written to HBM first (it is an output, and
     // the LDS pool it is gathered from is about to be reused for the factorisation)
-    for (int e = t; e < G * G; e += 256) {
+    for (int e = t; e < G * G; e += NT) {
         int a = e / G, b = e - a * G;
         int lo = a < b ? a : b, hi = a < b ? b : a;     // symmetric: take the upper entry (selfadjointView<Upper>)
         int bl = lo < 15 ? 0 : lo < 30 ? 1 : 2, bh = hi < 15 ? 0 : hi < 30 ? 1 : 2;
@@ -363,9 +357,6 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
     }
     if (t < G) { double v = t < 15 ? r3b[t] : t < 30 ? r0b[t - 15] : rNb[t - 30]; A.rd[g0 + t] = v; }
     __syncthreads();
-    for (int e = t; e < G * G; e += 256) sD[e] = A.Hd[g20 + e];
-    if (t < G) sD[G * G + t] = A.rd[g0 + t];                          // the rhs rides along as row G: its factor row is L^-1 rhs
-    __syncthreads();
     // Square root of the remainder.  The remainder of ONE factor is only positive SEMI-definite in general — between two visual
     // frames nothing in the chain pins, say, the heading — which is why the reference takes an eigen square root here
     // (UpdateSchurComponent, R/factor/gnss_imu_factor.cpp:454-488, eigenvalues <= 1e-8 dropped).  A Gauss-Newton solver consumes
@@ -375,9 +366,74 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
     //   H -= v_r v_r^T,  rhs -= v_r rho_r,
     // and stops when the remaining diagonal is below 1e-14 of the first pivot or 1e-8 absolute (the reference's eigenvalue
     // threshold): the rows beyond the rank are zero.  sum_r v_r v_r^T = H and sum_r v_r rho_r = rhs on the retained range.
-    {
+    if constexpr (NMAX <= CO_SMALLN) {
+        // Round 5: LEFT-LOOKING in ONE wavefront, no barrier inside (G + 1 <= 55 lanes: lane i owns row i for good, lane G the right-hand
+        // side, which rides along as row G: its factor row is L^-1 rhs).  Nothing is updated but the running diagonal (a register per
+        // lane); step r forms only the pivot's column, c_i = H[i][p] - sum_{s < r} L[i][s] L[p][s], and stores it as column r.  To
+        // keep column s of L AT position s (every address of the inner product is `row base + s`: contiguous reads along the lane's own
+        // row — rows are padded to an odd length: conflict-free — and LDS broadcasts of the pivot's row) each lane first exchanges, in
+        // its own row, position r with the position that holds H's column p: a column of H is read once, when its index becomes the
+        // pivot; lane q tracks where column q lives (cpos).  Rows never move, so the lane index is the original index, the arg-max is
+        // a ballot, and nothing crosses lanes but the broadcasts.  The factor goes to HBM after the loop, coalesced, by all threads.
+        // G^3 / 6 multiply-adds on one wave instead of G full-matrix updates behind three barriers each, an arg-max through six
+        // ds_bpermute round trips and an IEEE division + square root per step (rounds 1-4: ~180 k of the kernel's 380 k cycles).
+        // What is left is the instructions one wave issues per step (~8 cycles each): 1.1 k cycles a step.
+        __shared__ int sRank;
+        const int LDP = G | 1;
+        for (int e = t; e < G * G; e += NT) { int a = e / G, b = e - a * G; sD[a * LDP + b] = A.Hd[g20 + e]; }
+        if (t < G) sD[G * LDP + t] = A.rd[g0 + t];
+        __syncthreads();
+        CHSTAMP(45);
+        if (t < 64) {
+            const double GONE = -1e300;
+            const int me = t <= G ? t : G;                  // (lanes beyond the right-hand side's shadow it; they store nothing)
+            double* const rowi = sD + me * LDP;
+            double di = t < G ? rowi[t] : GONE;
+            int cpos = t;                                   // where column t of H lives in every row
+            double d0 = 0.0;
+            int r = 0;
+            for (; r < G; r++) {
+                const double m16 = grp16_max(di);
+                const double bv = fmax(fmax(rows_lane(m16, 0), rows_lane(m16, 16)), fmax(rows_lane(m16, 32), rows_lane(m16, 48)));
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(di == bv);
+                const int p = hit ? (int)__builtin_ctzll(hit) : 0;             // (the first index wins ties)
+                if (r == 0) d0 = bv;
+                if (!(bv > 1e-14 * d0) || !(bv > 1e-8)) break;                 // uniform
+                const int P = __builtin_amdgcn_readlane(cpos, p);              // column p of H sits at position P >= r
+                double c = rowi[P];
+                const double hr = rowi[r];
+                asm volatile("" ::: "memory");
+                if (t <= G && P != r) rowi[P] = hr;                            // H's column from position r moves to P (its owner notes it)
+                if (cpos == r) cpos = P;
+                const double* rp = sD + p * LDP;
+#pragma unroll 4
+                for (int s2 = 0; s2 < r; s2++) c -= rowi[s2] * rp[s2];
+                const bool live = t == G || (t < G && di > 0.5 * GONE);
+                const double v = live ? c * rsqrt_nr(bv) : 0.0;                // (a row that was a pivot has nothing right of its own column)
+                asm volatile("" ::: "memory");
+                if (t <= G) rowi[r] = v;
+                asm volatile("" ::: "memory");
+                di = (t == p) ? GONE : (live && t < G ? di - v * v : di);
+            }
+            if (t == 0) sRank = r;
+        }
+        CHSTAMP(46);
+        __syncthreads();
+        // the factor, the rows of the square root and the whitened right-hand side; zero beyond the rank
+        const int rank = sRank;
+        for (int e = t; e < G * G; e += NT) {
+            const int a = e / G, r2 = e - a * G;
+            const double v = r2 < rank ? sD[a * LDP + r2] : 0.0;
+            A.Ld[g20 + e] = v;
+            if (A.jac_out) A.jac_out[g20 + (size_t)r2 * G + a] = v;
+        }
+        if (t < G) { const double v = t < rank ? sD[G * LDP + t] : 0.0; A.r0[g0 + t] = v; A.res_out[g0 + t] = v; }
+    } else {
+        for (int e = t; e < G * G; e += NT) sD[e] = A.Hd[g20 + e];
+        if (t < G) sD[G * G + t] = A.rd[g0 + t];                          // the rhs rides along as row G: its factor row is L^-1 rhs
+        __syncthreads();
         __shared__ int sPiv, sStop; __shared__ double sPv;
-        for (int e = t; e < G * G; e += 256) { A.Ld[g20 + e] = 0.0; if (A.jac_out) A.jac_out[g20 + e] = 0.0; }
+        for (int e = t; e < G * G; e += NT) { A.Ld[g20 + e] = 0.0; if (A.jac_out) A.jac_out[g20 + e] = 0.0; }
         if (t < G) { A.r0[g0 + t] = 0.0; A.res_out[g0 + t] = 0.0; }
         if (t == 0) sStop = 0;
         __syncthreads();
@@ -400,7 +456,7 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
             if (t < G) { vr = sD[t * G + p] * isq; A.Ld[g20 + (size_t)t * G + r] = vr; if (A.jac_out) A.jac_out[g20 + (size_t)r * G + t] = vr; sdinv[t] = vr; }
             if (t == 255) { double rho = sD[G * G + p] * isq; A.r0[g0 + r] = rho; A.res_out[g0 + r] = rho; sRes[0] = rho; }
             __syncthreads();
-            for (int e = t; e < G * G; e += 256) { int a = e / G, b2 = e - a * G; sD[e] = (a == p || b2 == p) ? 0.0 : sD[e] - sdinv[a] * sdinv[b2]; }
+            for (int e = t; e < G * G; e += NT) { int a = e / G, b2 = e - a * G; sD[e] = (a == p || b2 == p) ? 0.0 : sD[e] - sdinv[a] * sdinv[b2]; }
             if (t < G) sD[G * G + t] = t == p ? 0.0 : sD[G * G + t] - sdinv[t] * sRes[0];
             __syncthreads();
         }
@@ -408,6 +464,7 @@ __global__ void __launch_bounds__(256, NMAX <= CO_SMALLN ? 4 : 1) k_comp_elim(Co
     if (t < 32) A.old[(size_t)f * 32 + t] = sOut[t];
     if (t < N) A.N_old[n0 + t] = sNv[t];
     if (t == 0) { A.history[f] = 1; A.status[f] = sBad ? -1 : 0; }
+    CHSTAMP(47);
 }
 
 // Optional phase 4: the reference's square root itself (UpdateSchurComponent, R/factor/gnss_imu_factor.cpp:454-488):

@@ -166,3 +166,51 @@ def composite_window(wx, chains):
                       comp_pose=cat("pose"), comp_sb=cat("sb"), comp_pose_lin=cat("pose"), comp_sb_lin=cat("sb"),
                       comp_Hpp=cat("Hpp"), comp_HpN=cat("HpN"), comp_rhs_p=cat("rhs_p"), comp_HNN=cat("HNN"), comp_rhsN=cat("rhsN"), comp_pre=cat("pre"),
                       pbg=wx.pbg, gw=wx.gw, base=wx.base, meta=dict(K=K, M=M, N=S, F=F)))
+
+
+def _explicit_job(args):
+    kw, seed = args
+    return explicit_window(seed=seed, **kw)[0]
+
+
+def explicit_windows(n, seed0=900, pool=True, **kw):
+    """n explicit windows (seeds seed0 ..), generated in a process pool when asked to — call it BEFORE the process touches HIP."""
+    jobs = [(kw, seed0 + i) for i in range(n)]
+    if pool and n > 2:
+        import multiprocessing as mp, os
+        with mp.get_context("fork").Pool(min(n, max(1, (os.cpu_count() or 2) - 2), 48)) as p:
+            return p.map(_explicit_job, jobs)
+    return [_explicit_job(j) for j in jobs]
+
+
+def composite_batch(solver, wxs, timing=None):
+    """The device-side construction of the reference's topology for a list of explicit windows (what bench.py's rtk_topology /
+    composite legs and tools/prof/gpu_comp_prof.py time): (1) every GNSS epoch of every window as ONE batch through
+    swf_batch_marginal_priors (GnssPreprocess, R/swf/swf_gnss.cpp:504-532), (2) AddMargInfo's bookkeeping on the host
+    (swf_composite_assemble, R/factor/gnss_imu_factor.cpp:245-352), (3) the composite windows.  Needs a GPU (the product has no CPU path)."""
+    import time
+    ek = [epoch_windows(wx) for wx in wxs]
+    ews = [e for (es, _) in ek for e in es]
+    tm = {}
+    t0 = time.perf_counter()
+    pri = solver.marginal_priors(ews, 1e-8, solver.BatchSolver.PRIOR_EIGEN, timing=tm)
+    t_wrap = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    wins, o = [], 0
+    for wx, (es, kept) in zip(wxs, ek):
+        K_vis, M = wx.meta["K_vis"], wx.meta["M"]
+        chains = []
+        for g in range(K_vis - 1):
+            blocks = {}
+            eps = []
+            for e in range(g * M, (g + 1) * M):
+                eps.append(dict(kept=[(sz, blocks.setdefault(k, np.zeros(1)) if sz == 1 else None) for (sz, k) in kept[e]], A=pri[o + e]["A"], b=pri[o + e]["b"]))
+            c = solver.composite_assemble(eps)
+            inv = {id(v): k for k, v in blocks.items()}
+            c["ids"] = [inv[id(b)] for b in c["keys"]]
+            chains.append(c)
+        o += len(es)
+        wins.append(composite_window(wx, chains))
+    if timing is not None:
+        timing.update(gnss_epochs=len(ews), epoch_priors_s=tm.get("c_abi_call_s"), epoch_priors_with_python_marshalling_s=t_wrap, host_assemble_s=time.perf_counter() - t0)
+    return wins
