@@ -173,7 +173,7 @@ struct DevBatch {
     const int* cm_loc; const int* cm_ls; const int* cm_col;
     double* C; double* cv_graw; double* cv_dgraw; double* cv_cs; double* cE;
     const int* cv_loc;                         // per clique vector slot (v_off + c): local index of the variable behind column c of the clique's reduced part
-    int n_clc[4]; const Clique* clc_rec[4];    // non-static cliques by size class (copies of the records: no index indirection); 3 = k_clique_big
+    int n_clc[5]; const Clique* clc_rec[5];    // non-static cliques by size class (copies of the records: no index indirection); 3 = k_clique_big, 4 = k_clique_tall
     int n_cle; const Clique* cle_rec;          // cliques with an eliminated block (back-substitution), likewise
     // pairs
     int n_pair;

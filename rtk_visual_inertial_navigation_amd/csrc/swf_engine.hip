@@ -210,7 +210,7 @@ struct swf_batch {
     std::vector<WinRec> win;
     std::vector<HostWin> hw;
     int max_tiles = 0, max_prior_dim = 0, max_red = 0, min_red = 1 << 30, n_cu = 256;
-    bool clc_imu[4] = { false, false, false, false };
+    bool clc_imu[5] = { false, false, false, false, false };
     // composite IMU-GNSS factors of the batch (swf_kernels4.h): operator arguments, solver-side bookkeeping, initial hidden epochs
     CompArgs CA{}; CompMeta CM{}; int n_comp = 0, comp_nmax = 0, comp_nmin = 1 << 30; long long comp_ne = 0;
     bool comp_eigen_root = false;                      // SWF_COMP_EIGEN_ROOT=1 at create: the composite factors expose the reference's eigen square root
@@ -607,7 +607,6 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
             for (int q = 0; q < N; q++) { CHK(ix[4 + q], nC, "composite") blks.push_back(bidC(ix[4 + q])); }
             for (size_t a = 0; a < blks.size(); a++) {
                 if (loc[blks[a]] < 0) return fail(SWF_E_UNSUPPORTED, "composite factor on a constant parameter block");
-                if (is_e(blks[a])) return fail(SWF_E_UNSUPPORTED, "composite factor on a block of elimination group 0");
                 for (size_t c2 = 0; c2 < a; c2++) if (blks[c2] == blks[a]) return fail(SWF_E_INVALID, "composite factor: repeated parameter block");
             }
             int data = (int)B.prior_dim.size();
@@ -745,6 +744,10 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
                 G.roff = C.r_off + frow; G.jld = nrows;
                 for (int sl = 0; sl < G.nslot; sl++) {
                     int cc = B.s_ccol[G.slot0 + sl];
+                    // a prior-type record inside the clique of a group-0 block (a composite factor on an eliminated speed-bias block, as
+                    // MyOrdering produces them, R/swf/swf_gnss.cpp:683-691): its rows join the clique's dense Jacobian like any factor's —
+                    // the prior evaluation copies the record's columns there at every linearisation
+                    if (G.type == GF_PRIOR && !t.is_static && cc >= 0) B.s_joff[G.slot0 + sl] = 0;
                     if (B.s_joff[G.slot0 + sl] < 0) continue;
                     if (t.is_static || cc < 0) { B.s_joff[G.slot0 + sl] = -1; continue; }
                     B.s_joff[G.slot0 + sl] = C.j_off + cc * nrows + frow;
@@ -1062,7 +1065,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     D.n_pair = (int)B.pair.size();
     PUT(pc_coff, B.pc_coff); PUT(pc_cld, B.pc_cld); PUT(pc_voff, B.pc_voff);
     {
-        std::vector<int> pd, po, clc[4], cle;
+        std::vector<int> pd, po, clc[5], cle;
         for (size_t i = 0; i < B.pair.size(); i++) {
             Pair& Pq = B.pair[i]; const WinRec& Rw = B.win[Pq.win];      // self-contained records (see Pair)
             Pq.fsb0 = Rw.fsb0; Pq.fsb1 = Rw.fsb1; Pq.n = Rw.n_red; Pq.m = 6 * Rw.nF; Pq.S_base = Rw.S_base; Pq.P_base = Rw.P_base; Pq.q_base = (long long)6 * Rw.fr_base * GEMM_SPLIT;
@@ -1079,7 +1082,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             if (c.is_static) continue;
             int d = c.d_e + c.d_f;
             // one wavefront per clique up to 64 x 64 (three size classes); anything larger takes the workgroup kernel (class 3)
-            int cls = (c.d_e <= 1 && d <= 32 && c.n_rows <= 48) ? 0 : (c.n_rows <= 32 && d <= 48) ? 1 : (c.n_rows <= CLQ_MAXR && d <= CLQ_MAXD) ? 2 : 3;
+            int cls = (c.d_e <= 1 && d <= 32 && c.n_rows <= 48) ? 0 : (c.n_rows <= 32 && d <= 48) ? 1 : (c.n_rows <= CLQ_MAXR && d <= CLQ_MAXD) ? 2 : (c.n_rows <= CLQ_TALLR && d <= 64) ? 4 : 3;
             // latency path: every one-wavefront clique in ONE launch (the 64 x 64 instantiation; the classes differ in loop bounds and zero
             // padding only, the sums and their order are the same: bit-identical results)
             if (b->lat_fuse && cls < 2) cls = 2;
@@ -1200,7 +1203,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             std::vector<Clique> v;
             for (int i : cle) v.push_back(B.cl[i]);
             PUT(cle_rec, v);
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 5; k++) {
                 v.clear();
                 for (int i : clc[k]) v.push_back(B.cl[i]);
                 D.n_clc[k] = (int)clc[k].size(); rc |= P.put(v, &D.clc_rec[k]);
@@ -1246,9 +1249,11 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             go[f + 1] = go[f] + G; g2o[f + 1] = g2o[f] + (long long)G * G;
             const GFac& Gf = B.gf[B.co_gf[f]];
             const Clique& Cq = B.cl[Gf.clique];
-            if (!Cq.is_static || Cq.d_f != G || Cq.d_e != 0) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "composite factor: its blocks must all be variable and outside group 0"); }
+            // either its own static clique (every block outside group 0: k_comp_scatter writes C = H and the diagonal there), or a member of
+            // the clique of the ONE group-0 block it touches (its rows reach the elimination through the clique's Jacobian: Coff = -1)
+            if (Cq.is_static ? (Cq.d_f != G || Cq.d_e != 0) : (Cq.d_e <= 0)) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "composite factor: its blocks must all be variable"); }
             Joff[f] = B.prior_Joff[Gf.data]; roff[f] = B.prior_roff[Gf.data]; x0off[f] = B.prior_x0off[Gf.data];
-            Coff[f] = Cq.C_off; voff[f] = Cq.v_off;
+            Coff[f] = Cq.is_static ? Cq.C_off : -1; voff[f] = Cq.is_static ? Cq.v_off : -1;
         }
         b->comp_ne = eo[nc];
         { const char* ev = getenv("SWF_COMP_EIGEN_ROOT"); b->comp_eigen_root = ev && ev[0] == '1'; }
@@ -1539,6 +1544,7 @@ struct Launcher {
                 else hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, cstream(2), D, O);
             }
             if (D.n_clc[3]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(3)); hipLaunchKernelGGL(k_clique_big, dim3(D.n_clc[3]), dim3(256), 0, cstream(3), D, O); }
+            if (D.n_clc[4]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(4)); hipLaunchKernelGGL(k_clique_tall, dim3(D.n_clc[4]), dim3(256), 0, cstream(4), D, O); }
             if (write_S && D.n_lm) {
                 // further tile ranges write nothing but their tiles of P (k_lm_schur: outs), so on the latency path they run behind the
                 // IMU / clique branch, next to the first range

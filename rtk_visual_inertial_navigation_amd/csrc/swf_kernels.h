@@ -650,8 +650,20 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
     double tot = block_sum(part, red);
     if (threadIdx.x == 0) B.g_cost[f] = 0.5 * tot;
     if (!JAC) return;
-    // graw = J^T r into the prior clique's vector slot (members are the kept blocks in order)
     const Clique& C = B.cl[G.clique];
+    if (!C.is_static) {
+        // a prior-type record inside the clique of a group-0 block (a composite factor on an eliminated speed-bias block): its columns
+        // go into the clique's dense column-major Jacobian, next to the other factors' rows; J^T J, J^T r and the elimination are the
+        // clique kernel's
+        for (int sl = 0; sl < G.nslot; sl++) {
+            const int jo = B.s_joff[G.slot0 + sl];
+            if (jo < 0) continue;
+            const int l = B.s_ls[G.slot0 + sl], col = B.s_pcol[G.slot0 + sl];
+            for (int e = threadIdx.x; e < l * n; e += blockDim.x) { const int j = e / n, i = e - j * n; B.g_J[jo + j * G.jld + i] = Jp[(size_t)i * n + col + j]; }
+        }
+        return;
+    }
+    // graw = J^T r into the prior clique's vector slot (members are the kept blocks in order)
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         double a = 0;
         for (int i = 0; i < n; i++) a += Jp[(size_t)i * n + j] * rr[i];
@@ -1093,6 +1105,11 @@ template <int MAXR, int MAXD, int MAXE, int CLS>
 __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) { d_clique_elim<MAXR, MAXD, MAXE, CLS>(B, O, (int)blockIdx.x); }
 // the latency form as a kernel of its own: four waves per clique (batches too large for the fused grid below, but still on the latency path)
 __global__ void __launch_bounds__(256) k_clique_elim4(DevBatch B, DevOpt O) { d_clique_elim<64, 64, 9, 2, 8, 4>(B, O, (int)blockIdx.x); }
+// class 4: up to 96 rows x 64 columns — the clique of a speed-bias block that two composite IMU-GNSS factors touch (the reference's own
+// ordering puts every other speed-bias block into group 0, R/swf/swf_gnss.cpp:683-691: 2 x (30 + N) rows, 9 + 6 + 9 + 6 + 6 + 9 + N
+// columns; N <= 9 ambiguities fit the 64 columns, more take k_clique_big).  The four-wave form of the same function.
+#define CLQ_TALLR 96
+__global__ void __launch_bounds__(256) k_clique_tall(DevBatch B, DevOpt O) { d_clique_elim<CLQ_TALLR, 64, 9, 4, 8, 4>(B, O, (int)blockIdx.x); }
 
 // Latency path: the landmark Schur complement and the clique eliminations are independent of each other (both follow the factor
 // evaluation, both feed the assembly) — ONE grid of 1024-thread workgroups runs both: rows [0, n_parts) of the grid are k_lm_schur's

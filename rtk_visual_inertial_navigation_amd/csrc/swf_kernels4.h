@@ -572,10 +572,14 @@ __global__ void __launch_bounds__(256) k_comp_scatter(DevBatch B, CompArgs A, Co
     if (f >= A.n || !Mt.active[f]) return;
     const int N = A.N[f], G = 30 + N;
     const double* J = A.jac_out + A.g2_off[f]; const double* H = A.Hd + A.g2_off[f]; const double* r = A.res_out + A.g_off[f];
-    double* pJ = Mt.prior_J + Mt.Joff[f]; double* C = B.C + Mt.Coff[f];
+    double* pJ = Mt.prior_J + Mt.Joff[f];
     double* pJt = Mt.prior_Jt + Mt.Joff[f];
-    for (int e = t; e < G * G; e += 256) { double v = J[e]; pJ[e] = v; pJt[(size_t)(e % G) * G + e / G] = v; C[e] = H[e]; }
-    for (int e = t; e < G; e += 256) { Mt.prior_r0[Mt.roff[f] + e] = r[e]; B.cv_dgraw[Mt.voff[f] + e] = H[(size_t)e * G + e]; }
+    // (a factor inside the clique of a group-0 block — Coff < 0 — has no static clique to fill: the prior evaluation copies its rows
+    // into that clique's Jacobian and the clique elimination forms J^T J with the other factors' rows)
+    const bool own = Mt.Coff[f] >= 0;
+    double* C = B.C + (own ? Mt.Coff[f] : 0);
+    for (int e = t; e < G * G; e += 256) { double v = J[e]; pJ[e] = v; pJt[(size_t)(e % G) * G + e / G] = v; if (own) C[e] = H[e]; }
+    for (int e = t; e < G; e += 256) { Mt.prior_r0[Mt.roff[f] + e] = r[e]; if (own) B.cv_dgraw[Mt.voff[f] + e] = H[(size_t)e * G + e]; }
     double* x0 = Mt.prior_x0 + Mt.x0off[f];
     if (t < 32) x0[t] = A.outer[(size_t)f * 32 + t];
     if (t >= 32 && t - 32 < N) x0[t] = A.Nv[A.n_off[f] + t - 32];

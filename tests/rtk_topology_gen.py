@@ -120,9 +120,12 @@ def assemble_np(M, kept, priors):
     return dict(ids=ids, Hpp=Hpp, HpN=HpN, rhs_p=rhs_p, HNN=HNN, rhsN=rhsN)
 
 
-def composite_window(wx, chains):
+def composite_window(wx, chains, reference_ordering=True):
     """The window over the visual frames only: projection factors, the gauge prior, the dummy, and one composite factor per gap
-    built from chains[g] = assemble output (Hpp, HpN, rhs_p, HNN, rhsN over that gap's M epochs, ambiguity ids 0..S-1)."""
+    built from chains[g] = assemble output (Hpp, HpN, rhs_p, HNN, rhsN over that gap's M epochs, ambiguity ids 0..S-1).
+    reference_ordering: SWFOptimization::MyOrdering as it is (R/swf/swf_gnss.cpp:629-783: every other eligible speed-bias block
+    in elimination group 0 — each composite factor then touches exactly one group-0 block); False: every frame block in a group of
+    its own (rounds 1-4, when the engine refused a composite factor on a group-0 block: 90 more reduced dimensions at cfg3 size)."""
     a, m = wx.a, wx.meta
     K, M, S, vis = m["K_vis"], m["M"], m["S"], m["vis"]
     T = m["T"]
@@ -137,13 +140,20 @@ def composite_window(wx, chains):
     n_pose = K + 1
     bid_pose = lambda i: i; bid_sb = lambda i: n_pose + i; bid_lm = lambda i: n_pose + K + i; bid_sc = lambda i: n_pose + K + F + i
     is_const = np.zeros(n_pose + K + F + 1 + S, np.uint8); is_const[K] = 1
-    order_block = [bid_sc(0)] + [bid_lm(f) for f in range(F)]; order_group = [0] * (1 + F)
-    g = 1
-    for k in range(K):
-        for b in (bid_pose(k), bid_sb(k)):
-            order_block.append(b); order_group.append(g); g += 1
-    for s in range(S):
-        order_block.append(bid_sc(1 + s)); order_group.append(g); g += 1
+    if reference_ordering:
+        roles = dict(dummy=bid_sc(0), landmarks=[bid_lm(f) for f in range(F)], speed_bias=[bid_sb(k) for k in range(K)],
+                     poses=[bid_pose(k) for k in range(K)], extrinsics=[bid_pose(K)], rtk_ambiguities=[bid_sc(1 + s) for s in range(S)],
+                     clocks=[], pr_corrections=[], prior_kept=[bid_pose(0), bid_sb(0)], parameter_head=[])
+        ob_, og_, _ = my_ordering(roles, is_const)
+        order_block, order_group = list(ob_), list(og_)
+    else:
+        order_block = [bid_sc(0)] + [bid_lm(f) for f in range(F)]; order_group = [0] * (1 + F)
+        g = 1
+        for k in range(K):
+            for b in (bid_pose(k), bid_sb(k)):
+                order_block.append(b); order_group.append(g); g += 1
+        for s in range(S):
+            order_block.append(bid_sc(1 + s)); order_group.append(g); g += 1
     comp = dict(M=[], N=[], idx=[], pose=[], sb=[], Hpp=[], HpN=[], rhs_p=[], HNN=[], rhsN=[], pre=[])
     pre_all = a["imu_pre"].reshape(-1, PRE_DOUBLES)
     for gi in range(K - 1):
