@@ -57,10 +57,10 @@ __device__ __forceinline__ void co_inc15(const double* P, const double* Bv, cons
 }
 
 // phase 1 of an evaluation: increments, the cost-only answer, or the back-substitution of the hidden epochs
-__global__ void __launch_bounds__(256) k_comp_prep(CompArgs A) {
-    const int f = blockIdx.x, t = threadIdx.x;
-    if (f >= A.n) return;
-    if (A.active && !A.active[f]) { if (t == 0) A.todo[f] = 0; return; }
+__device__ __forceinline__ bool d_comp_prep(const CompArgs& A, const int f) {
+    const int t = threadIdx.x;
+    if (f >= A.n) return false;
+    if (A.active && !A.active[f]) { if (t == 0) A.todo[f] = 0; return false; }
     const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
     const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
     __shared__ double dl2[15], dlN[CO_MAXN], dl0[15];                      // delta5[Pose2], [N], [Pose0]
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_comp_prep(CompArgs A) {
             A.res_out[g0 + k] = A.r0[g0 + k] - s;
         }
         if (t == 0) A.todo[f] = 0;
-        return;
+        return false;
     }
     if (t == 0) A.todo[f] = 1;
     if (hist && update) {
@@ -117,16 +117,19 @@ __global__ void __launch_bounds__(256) k_comp_prep(CompArgs A) {
         }
         __threadfence_block();
     }
+    return true;
 }
+__global__ void __launch_bounds__(256) k_comp_prep(CompArgs A) { (void)d_comp_prep(A, (int)blockIdx.x); }
 
 // phase 2: every IMU factor of every chain that re-eliminates, IMUFactor::Evaluate2 — 8 factors per workgroup, the four un-whitened
 // parts on one lane each (part p on wave p, as in k_eval_imu), then 32 lanes per factor whiten; whitened J (15 x 30) and r to scratch
-__global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
+__device__ __forceinline__ void d_comp_imu(const CompArgs& A, const int qb, const int qend) {
     __shared__ double U[8][450], SIs[8][225], raw[8][16], st[8][32], pr[8][SWF_PRE_SQRTINFO + 6];
-    const int t = threadIdx.x, fl = t >> 5, sub = t & 31;
-    const int q = blockIdx.x * 8 + fl;
-    const bool valid = q < A.n_iq;
-    const int f = A.iq_f[valid ? q : A.n_iq - 1], k = A.iq_k[valid ? q : A.n_iq - 1];
+    const bool on = threadIdx.x < 256;                  // (the fused kernel runs 1024 threads: the others only pass the barriers)
+    const int t = on ? threadIdx.x : 0, fl = t >> 5, sub = t & 31;
+    const int q = qb + fl;
+    const bool valid = on && q < qend;
+    const int f = A.iq_f[valid ? q : qend - 1], k = A.iq_k[valid ? q : qend - 1];
     const int M = A.M[f], e0 = A.e_off[f];
     // the link of a middle marginalisation has no IMU factor (Evaluate :738): its scratch rows stay zero, as allocated
     const bool act = valid && A.todo[f] && !(k > 0 && k == A.mid[f]);
@@ -148,9 +151,9 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
         for (int e = sub; e < 225; e += 32) SIs[fl][e] = pre[SWF_PRE_SQRTINFO + e];
     }
     __syncthreads();
-    if ((t & 63) < 8) {
-        int fq = t & 63, q2 = blockIdx.x * 8 + fq;
-        if (q2 < A.n_iq && A.todo[A.iq_f[q2]] && !(A.iq_k[q2] > 0 && A.iq_k[q2] == A.mid[A.iq_f[q2]]))
+    if (on && (t & 63) < 8) {
+        int fq = t & 63, q2 = qb + fq;
+        if (q2 < qend && A.todo[A.iq_f[q2]] && !(A.iq_k[q2] > 0 && A.iq_k[q2] == A.mid[A.iq_f[q2]]))
             imu_unwhitened(st[fq], st[fq] + 7, st[fq] + 16, st[fq] + 23, pr[fq], pr[fq] + SWF_PRE_SQRTINFO, pr[fq] + SWF_PRE_SQRTINFO + 3, raw[fq], U[fq], true, t >> 6);
     }
     __syncthreads();
@@ -177,6 +180,7 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
         A.rw[(size_t)(e0 + f + k) * 16 + sub] = a;
     }
 }
+__global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) { d_comp_imu(A, (int)blockIdx.x * 8, A.n_iq); }
 
 // phase 3: re-elimination of the hidden epochs from the whitened IMU Jacobians of phase 2, remainder, square root
 // NT = threads per factor: 256 for batches (four workgroups per CU), 1024 on the latency path (a window's ~20 factors have the chip to
@@ -184,8 +188,8 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) {
 // T products and Schur update at 256 threads).  Every output element is one thread's, from the same operands in the same order:
 // the thread count does not change a bit.
 template <int NMAX, int NT>
-__global__ void __launch_bounds__(NT, (NT == 256 && NMAX <= CO_SMALLN) ? 4 : 1) k_comp_elim(CompArgs A) {
-    const int f = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f) {
+    const int t = threadIdx.x;
     if (f >= A.n || !A.todo[f]) return;
     // the instantiation is the FACTOR's (a launch of each covers a batch with factors of both classes): a factor's arithmetic does not
     // depend on what else is in its batch (the two instantiations take different square roots since round 5)
@@ -466,6 +470,8 @@ __global__ void __launch_bounds__(NT, (NT == 256 && NMAX <= CO_SMALLN) ? 4 : 1) 
     if (t == 0) { A.history[f] = 1; A.status[f] = sBad ? -1 : 0; }
     CHSTAMP(47);
 }
+template <int NMAX, int NT>
+__global__ void __launch_bounds__(NT, (NT == 256 && NMAX <= CO_SMALLN) ? 4 : 1) k_comp_elim(CompArgs A) { d_comp_elim<NMAX, NT>(A, (int)blockIdx.x); }
 
 // Optional phase 4: the reference's square root itself (UpdateSchurComponent, R/factor/gnss_imu_factor.cpp:454-488):
 //   H = V diag(lam) V^T,  J = sqrt(lam+) V^T,  r = lam+^-1/2 V^T rhs,  eigenvalues <= 1e-8 dropped, rows in ascending eigenvalue order
@@ -554,8 +560,8 @@ struct CompMeta {
     double* outer; double* Nv;      // = CompArgs.outer / .Nv
 };
 
-__global__ void __launch_bounds__(128) k_comp_gather(DevBatch B, CompArgs A, CompMeta Mt) {
-    int f = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void d_comp_gather(const DevBatch& B, const CompArgs& A, const CompMeta& Mt, const int f) {
+    const int t = threadIdx.x;
     if (f >= A.n) return;
     const WinState& s = B.ws[Mt.win[f]];
     int act = (s.status == SWF_RUNNING && s.need_lin) ? 1 : 0;
@@ -566,9 +572,11 @@ __global__ void __launch_bounds__(128) k_comp_gather(DevBatch B, CompArgs A, Com
     if (t < 32) { int sl = t < 7 ? 0 : t < 16 ? 1 : t < 23 ? 2 : 3, o = t < 7 ? t : t < 16 ? t - 7 : t < 23 ? t - 16 : t - 23; Mt.outer[(size_t)f * 32 + t] = B.x[xo[sl] + o]; }
     if (t >= 32 && t - 32 < N) Mt.Nv[A.n_off[f] + t - 32] = B.x[xo[4 + t - 32]];
 }
+__global__ void __launch_bounds__(128) k_comp_gather(DevBatch B, CompArgs A, CompMeta Mt) { d_comp_gather(B, A, Mt, (int)blockIdx.x); }
 
-__global__ void __launch_bounds__(256) k_comp_scatter(DevBatch B, CompArgs A, CompMeta Mt) {
-    int f = blockIdx.x, t = threadIdx.x;
+template <int NT>
+__device__ __forceinline__ void d_comp_scatter(const DevBatch& B, const CompArgs& A, const CompMeta& Mt, const int f) {
+    const int t = threadIdx.x;
     if (f >= A.n || !Mt.active[f]) return;
     const int N = A.N[f], G = 30 + N;
     const double* J = A.jac_out + A.g2_off[f]; const double* H = A.Hd + A.g2_off[f]; const double* r = A.res_out + A.g_off[f];
@@ -578,10 +586,34 @@ __global__ void __launch_bounds__(256) k_comp_scatter(DevBatch B, CompArgs A, Co
     // into that clique's Jacobian and the clique elimination forms J^T J with the other factors' rows)
     const bool own = Mt.Coff[f] >= 0;
     double* C = B.C + (own ? Mt.Coff[f] : 0);
-    for (int e = t; e < G * G; e += 256) { double v = J[e]; pJ[e] = v; pJt[(size_t)(e % G) * G + e / G] = v; if (own) C[e] = H[e]; }
-    for (int e = t; e < G; e += 256) { Mt.prior_r0[Mt.roff[f] + e] = r[e]; if (own) B.cv_dgraw[Mt.voff[f] + e] = H[(size_t)e * G + e]; }
+    for (int e = t; e < G * G; e += NT) { double v = J[e]; pJ[e] = v; pJt[(size_t)(e % G) * G + e / G] = v; if (own) C[e] = H[e]; }
+    for (int e = t; e < G; e += NT) { Mt.prior_r0[Mt.roff[f] + e] = r[e]; if (own) B.cv_dgraw[Mt.voff[f] + e] = H[(size_t)e * G + e]; }
     double* x0 = Mt.prior_x0 + Mt.x0off[f];
     if (t < 32) x0[t] = A.outer[(size_t)f * 32 + t];
     if (t >= 32 && t - 32 < N) x0[t] = A.Nv[A.n_off[f] + t - 32];
     if (t == 0 && A.status[f] != 0) B.ws[Mt.win[f]].lin_fail = 1;       // a hidden epoch or the remainder was not positive definite
+}
+__global__ void __launch_bounds__(256) k_comp_scatter(DevBatch B, CompArgs A, CompMeta Mt) { d_comp_scatter<256>(B, A, Mt, (int)blockIdx.x); }
+
+// A/B form (round 5, SWF_COMP_FUSED=1; NOT the default): the five phases of a factor's re-linearisation — gather the outer blocks, move
+// the hidden epochs, the chain's IMU factors, the re-elimination with its square root, the prior record — as ONE 1024-thread workgroup
+// per factor, a barrier where a phase reads what the previous one left in memory, instead of five dependent launches.  Same device
+// functions, same thread-to-element maps, same bits.  Measured on a cfg3-size reference-topology window: 298.5 us per iteration against
+// 296.0 with the five launches, a batch of 16 windows 3.83 against 3.48 ms — each phase's exposed memory round trips are the same inside
+// one kernel, the small phases lose the chip-wide parallelism they had as grids of their own, and dependent launches on one stream
+// follow each other without a gap.  Kept as the measurement's record.
+template <int NMAX>
+__global__ void __launch_bounds__(1024, 1) k_comp_lin(DevBatch B, CompArgs A, CompMeta Mt) {
+    const int f = blockIdx.x;
+    if (f >= A.n) return;
+    if ((A.N[f] <= CO_SMALLN) != (NMAX <= CO_SMALLN)) return;          // (the other instantiation's factor)
+    d_comp_gather(B, A, Mt, f);
+    __syncthreads();
+    if (!d_comp_prep(A, f)) return;                                    // (uniform: the window does not re-linearise)
+    __syncthreads();
+    const int q0 = A.e_off[f] + f, q1 = q0 + A.M[f] + 1;               // the chain's IMU factors in the flattened list
+    for (int qb = q0; qb < q1; qb += 8) { d_comp_imu(A, qb, q1); __syncthreads(); }
+    d_comp_elim<NMAX, 1024>(A, f);
+    __syncthreads();
+    d_comp_scatter<1024>(B, A, Mt, f);
 }

@@ -243,3 +243,37 @@ def test_add_mid_marg_info_bookkeeping_equals_numpy_restatement():
         solver.composite_add_mid_prior(fac, k, [(7, k - 2), (9, k)], np.eye(15), np.zeros(15))
     with pytest.raises(solver.SwfError):
         solver.composite_add_mid_prior(fac, M, [(7, M - 1), (9, M - 1)], np.eye(15), np.zeros(15))
+
+
+
+@pytest.mark.gpu
+def test_composite_topology_at_cfg3_size_against_the_oracle():
+    """The reference's own topology at BASELINE cfg3 size: 20 visual frames linked by 19 composite IMU-GNSS factors
+    hiding 4 GNSS epochs each (76 epochs pre-eliminated on the device in one batch), ~280 landmarks / ~2 800 observations, 10 ambiguities,
+    ordered by MyOrdering as it is (R/swf/swf_gnss.cpp:629-783: every other speed-bias block in elimination group 0, so every composite
+    factor touches one group-0 block and the reduced system has cfg3's 220 dimensions).  Same input window for both solvers: the
+    yaml's 8 iterations (same accept / reject decisions, first cost to rounding, end states 1e-5 apart, device cost not above the
+    oracle's) and each to its own termination; and the window alone == inside a batch, bit for bit."""
+    wxs = rt.explicit_windows(3, seed0=900, pool=False, K_vis=20, M=4, F=300, S=10)
+    wins = rt.composite_batch(solver, wxs)
+    w = wins[0]
+    assert w.a["comp_M"].size == 19 and int(w.a["comp_M"].sum()) == 76
+    for iters, tol in ((8, 1e-5), (50, 1e-4)):
+        wo, wd = w.copy(), w.copy()
+        so, _ = ob.solve(wo, default_options(max_num_iterations=iters), export=False)
+        bs = solver.BatchSolver([wd]); sd = bs.solve(default_options(max_num_iterations=iters))[0]
+        assert bs.dims(0)["n_red"] == 220 == ob.dims(w)["n_red"]
+        bs.close()
+        ro, rd = so.rows(), sd.rows()
+        assert sd.termination == so.termination and (iters == 8 or sd.termination in (1, 2, 3)), (sd.termination, so.termination)
+        assert [r["step_is_successful"] for r in rd] == [r["step_is_successful"] for r in ro]
+        assert abs(rd[0]["cost"] - ro[0]["cost"]) <= 1e-10 * ro[0]["cost"]
+        assert sd.final_cost <= so.final_cost * (1 + 1e-6) and sd.final_cost < 1e-3 * sd.initial_cost
+        assert np.abs(wd.a["pose"] - wo.a["pose"]).max() < tol and np.abs(wd.a["comp_pose"] - wo.a["comp_pose"]).max() < tol
+        assert np.abs(wd.a["sc"] - wo.a["sc"]).max() < 10 * tol and np.abs(wd.a["sb"] - wo.a["sb"]).max() < 10 * tol
+        if iters == 8: single = (wd, [r["cost"] for r in rd])
+    batch = [x.copy() for x in wins]
+    bs = solver.BatchSolver(batch); sms = bs.solve(default_options(max_num_iterations=8)); bs.close()
+    assert [r["cost"] for r in sms[0].rows()] == single[1]
+    for k in ("pose", "sb", "lm", "sc", "comp_pose", "comp_sb"):
+        assert np.array_equal(single[0].a[k], batch[0].a[k]), k
