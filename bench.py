@@ -222,62 +222,71 @@ def live_pmc_traffic(kernel_prefix, n_windows, timeout_s=150):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def rtk_topology_leg(iters, n_windows=16, K_vis=10, M=4, F=100, S=10):
-    """Extra configuration: windows in the reference's OWN RTK topology — K_vis visual frames linked only by
-    composite IMU-GNSS factors, each hiding M GNSS epochs whose raw carrier-phase / pseudorange factors were pre-eliminated to a
-    linear prior (GnssPreprocess, R/swf/swf_gnss.cpp:504-532) — built and solved on the device: (1) every GNSS epoch of every
-    window as one batch through swf_batch_marginal_priors, (2) AddMargInfo's bookkeeping on the host (swf_composite_assemble),
-    (3) the composite windows as one batch through the solver.  Synthetic data (tests/rtk_topology_gen.py, a generator only)."""
+def rtk_topology_leg(iters, wxs, cpu=True):
+    """The reference's OWN RTK topology at BASELINE cfg3 size: windows of 20 visual frames
+    linked only by composite IMU-GNSS factors, each hiding 4 GNSS epochs whose raw carrier-phase / pseudorange factors were pre-eliminated
+    to a linear prior (GnssPreprocess, R/swf/swf_gnss.cpp:504-532), ~280 landmarks / ~2 800 observations, 10 ambiguities, ordered by
+    MyOrdering as it is (every other speed-bias block in elimination group 0: n_red = 220 as for the raw-GNSS cfg3 window) — built and
+    solved on the device: (1) every GNSS epoch of every window as one batch through swf_batch_marginal_priors, (2) AddMargInfo's
+    bookkeeping on the host (swf_composite_assemble), (3) the composite windows through the solver: ONE window (latency), the batch of
+    distinct windows, the same batch replicated to 512 windows (throughput), the oracle on the same windows (CPU row), and the
+    warm-start probe that explains the cold windows' iteration counts.  Synthetic data (tests/rtk_topology_gen.py, a generator only;
+    wxs = its explicit windows, generated in a process pool before this process touched HIP)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import rtk_topology_gen as rt
     from rtk_visual_inertial_navigation_amd import solver
     from rtk_visual_inertial_navigation_amd.flat import default_options
-    t0 = time.perf_counter()
-    wxs = [rt.explicit_window(K_vis=K_vis, M=M, F=F, S=S, seed=900 + i)[0] for i in range(n_windows)]
-    ek = [rt.epoch_windows(wx) for wx in wxs]
-    t_gen = time.perf_counter() - t0
-    ews = [e for (es, _) in ek for e in es]
-    solver.marginal_priors(ews[:8], 1e-8, solver.BatchSolver.PRIOR_EIGEN)           # warm-up (library load, first launches)
+    n_windows = len(wxs)
+    ek0 = rt.epoch_windows(wxs[0])[0]
+    solver.marginal_priors(ek0[:8], 1e-8, solver.BatchSolver.PRIOR_EIGEN)           # warm-up (library load, first launches)
     tm = {}
-    t0 = time.perf_counter()
-    pri = solver.marginal_priors(ews, 1e-8, solver.BatchSolver.PRIOR_EIGEN, timing=tm)
-    t_wrap = time.perf_counter() - t0
-    t_pri = tm["c_abi_call_s"]
-    t0 = time.perf_counter()
-    wins, o = [], 0
-    for wx, (es, kept) in zip(wxs, ek):
-        chains = []
-        for g in range(K_vis - 1):
-            blocks = {}
-            eps = []
-            for e in range(g * M, (g + 1) * M):
-                eps.append(dict(kept=[(sz, blocks.setdefault(k, np.zeros(1)) if sz == 1 else None) for (sz, k) in kept[e]], A=pri[o + e]["A"], b=pri[o + e]["b"]))
-            c = solver.composite_assemble(eps)
-            inv = {id(v): k for k, v in blocks.items()}
-            c["ids"] = [inv[id(b)] for b in c["keys"]]
-            chains.append(c)
-        o += len(es)
-        wins.append(rt.composite_window(wx, chains))
-    t_asm = time.perf_counter() - t0
+    wins = rt.composite_batch(solver, wxs, timing=tm)
     opt = default_options(max_num_iterations=iters)
-    bs = solver.BatchSolver(wins)
-    for _ in range(2):
-        bs.reset_state(); bs.solve_async(opt); bs.sync()
-    lat = []
-    for _ in range(10):
-        bs.reset_state(); t0 = time.perf_counter(); bs.solve_async(opt); bs.sync(); lat.append(time.perf_counter() - t0)
-    sms = bs.summaries()
-    # (8 iterations is the yaml's budget per frame, not a convergence criterion: the same windows run to their own termination)
-    bs.reset_state(); bs.solve_async(default_options(max_num_iterations=50)); bs.sync()
-    sms50 = bs.summaries()
-    bs.close()
-    its = sum(s.num_iterations for s in sms); dt = float(np.median(lat))
-    return dict(windows=n_windows, visual_frames=K_vis, gnss_epochs_per_gap=M, features=F, satellites=S, gnss_epochs=len(ews),
-                epoch_priors_ms=1e3 * t_pri, epoch_priors_per_s=len(ews) / t_pri, epoch_priors_with_python_marshalling_ms=1e3 * t_wrap, host_assemble_ms=1e3 * t_asm, batch_solve_ms=1e3 * dt,
-                iterations=int(its), iterations_per_s=its / dt, converged=int(sum(s.termination in (1, 2, 3) for s in sms)),
-                converged_within_50_iterations=int(sum(s.termination in (1, 2, 3) for s in sms50)), mean_iterations_to_termination=float(np.mean([s.num_iterations for s in sms50])),
-                mean_cost_reduction=float(np.mean([s.final_cost / s.initial_cost for s in sms])), generate_s=t_gen,
-                note="reference-topology RTK windows: per-epoch GNSS pre-elimination batched on the device, composite IMU-GNSS factors in the solve loop")
+
+    def timed(ws, reps, warm=2):
+        bs = solver.BatchSolver(ws)
+        for _ in range(warm):
+            bs.reset_state(); bs.solve_async(opt); bs.sync()
+        lat = []
+        for _ in range(reps):
+            bs.reset_state(); t0 = time.perf_counter(); bs.solve_async(opt); bs.sync(); lat.append(time.perf_counter() - t0)
+        sms = bs.summaries()
+        n_red = bs.dims(0)["n_red"]
+        bs.close()
+        return float(np.median(lat)), sms, n_red
+    dt1, sm1, n_red = timed([wins[0].copy()], 20, 3)
+    dtb, smb, _ = timed([w.copy() for w in wins], 10)
+    rep = max(1, 512 // n_windows)
+    dtr, smr, _ = timed([w.copy() for _ in range(rep) for w in wins], 6)
+    its1 = sm1[0].num_iterations; itsb = sum(s.num_iterations for s in smb); itsr = sum(s.num_iterations for s in smr)
+    cw, wi, ci = rt.warm_start_probe(solver, wins[:16], opt, default_options(max_num_iterations=50))
+    out = dict(workload="%d visual frames x %d hidden GNSS epochs per gap, %d landmarks, %d observations, %d ambiguities, %d composite factors per window; n_red %d"
+                        % (wins[0].meta["K"], wins[0].meta["M"], wins[0].n_lm, wins[0].a["proj_idx"].size // 3, wins[0].meta["N"], wins[0].a["comp_M"].size, n_red),
+               single_window=dict(us_per_iteration=1e6 * dt1 / max(1, its1), solve_ms=1e3 * dt1, iterations=int(its1)),
+               batch=dict(windows=n_windows, solve_ms=1e3 * dtb, iterations_per_s=itsb / dtb, us_per_window_iteration=1e6 * dtb / itsb,
+                          failed_windows=int(sum(s.termination not in (1, 2, 3, 4) for s in smb))),
+               batch_replicated=dict(windows=rep * n_windows, solve_ms=1e3 * dtr, iterations_per_s=itsr / dtr, us_per_window_iteration=1e6 * dtr / itsr,
+                                     note="the %d distinct windows x %d (independent windows: throughput only)" % (n_windows, rep)),
+               converged_within_budget_cold=int(sum(s.termination in (1, 2, 3) for s in smb)),
+               cold_mean_iterations_to_termination=ci,
+               warm_start=dict(windows=min(16, n_windows), converged_within_budget=cw, mean_iterations=wi,
+                               note="the windows converged, then ONLY the newest frame moved by an IMU-prediction-sized error (5 cm, 5 cm/s, 2 mrad) — what the "
+                                    "estimator hands the solver at every frame; the cold windows start with EVERY state perturbed (cost 2e7 -> 9e2 in the first "
+                                    "step) and the composite factors' re-linearisation of their hidden epochs (UpdateHiddenState, R/factor/gnss_imu_factor.cpp:601-632) "
+                                    "makes the tail of that descent linear, for the oracle as for the device"),
+               mean_cost_reduction=float(np.mean([s.final_cost / s.initial_cost for s in smb])),
+               construction=dict(gnss_epochs=tm["gnss_epochs"], epoch_priors_ms=1e3 * tm["epoch_priors_s"], epoch_priors_per_s=tm["gnss_epochs"] / tm["epoch_priors_s"],
+                                 epoch_priors_with_python_marshalling_ms=1e3 * tm["epoch_priors_with_python_marshalling_s"], host_assemble_ms=1e3 * tm["host_assemble_s"]),
+               note="reference-topology RTK windows at cfg3 size: per-epoch GNSS pre-elimination batched on the device, composite IMU-GNSS factors in the solve loop, MyOrdering's elimination order")
+    if cpu:
+        import oracle_binding as ob
+        ts, itc = [], 0
+        for w in wins[:4]:
+            wo = w.copy(); t0 = time.perf_counter(); so, _ = ob.solve(wo, opt, export=False); ts.append(time.perf_counter() - t0); itc += so.num_iterations
+        out["cpu_oracle"] = dict(us_per_iteration=1e6 * sum(ts) / max(1, itc), solve_ms=1e3 * float(np.mean(ts)), threads=int(os.environ.get("OMP_NUM_THREADS", "0")) or None,
+                                 sample="the first 4 of the same windows, %d iterations each, plain-C port" % iters)
+        out["single_window"]["speedup_vs_cpu_oracle"] = out["cpu_oracle"]["us_per_iteration"] / out["single_window"]["us_per_iteration"]
+    return out
 
 
 def stress_fulls(n_windows):
@@ -395,6 +404,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic live")
     ap.add_argument("--no-rtk-topology", action="store_true", help="skip the reference-topology extra configuration")
+    ap.add_argument("--topology-windows", type=int, default=64, help="distinct windows of the reference-topology (composite factor) leg")
     ap.add_argument("--stress-windows", type=int, default=128, help="windows of the cfg5 stress block (0 = skip it)")
     ap.add_argument("--no-single-window", action="store_true",
                     help="skip the single-window latency leg (its launches share kernel names with the batch and would dilute rocprofv3 per-kernel averages)")
@@ -418,6 +428,13 @@ def main():
     fulls = None
     if world == 1 and a.stress_windows > 0 and not a.no_single_window and not os.environ.get("SWF_BENCH_SHARE_GPU"):
         fulls = stress_fulls(a.stress_windows)
+    topo_wxs = None
+    if world == 1 and not a.no_rtk_topology and not a.no_single_window and not os.environ.get("SWF_BENCH_SHARE_GPU"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import rtk_topology_gen as rt_gen
+        t0_ = time.perf_counter()
+        topo_wxs = rt_gen.explicit_windows(a.topology_windows, K_vis=20, M=4, F=300, S=10)      # (process pool: before HIP is touched)
+        t_topo_gen = time.perf_counter() - t0_
 
     import torch
     import torch.distributed as dist
@@ -517,6 +534,10 @@ def main():
             sub.close()
             proj["gpus_%d" % g_] = dict(windows_per_gpu=nb_, ms_per_solve=1e3 * float(np.median(ts_)),
                                         projected_efficiency=(dt / a.steps) / (g_ * float(np.median(ts_))))
+        # the natural deployment of independent windows is WEAK scaling (every GPU its own 512 windows; --scaling weak): no data-path collective,
+        # one host thread per device, so the per-GPU step is this run's own and the job's rate is N times it
+        proj["weak_scaling"] = dict(windows_per_gpu=B, ms_per_solve=1e3 * dt / a.steps, projected_efficiency=1.0,
+                                    note="python bench.py --gpus N --scaling weak: B windows per GPU, no collective in the data path (harness all-reduce of the wall time only)")
 
     if rank == 0:
         def avg_ms(k):
@@ -670,9 +691,10 @@ def main():
                 out["stress"] = stress_leg(fulls, a.stress_windows, a.iters)
             except Exception as e:                      # an extra: never take the headline line down with it
                 out["stress"] = dict(error=repr(e))
-        if not a.no_rtk_topology and not a.no_single_window and world == 1:
+        if topo_wxs is not None:
             try:
-                out["rtk_topology"] = rtk_topology_leg(a.iters)
+                out["rtk_topology"] = rtk_topology_leg(a.iters, topo_wxs, cpu=not a.no_cpu_baseline)
+                out["rtk_topology"]["generate_s"] = t_topo_gen
             except Exception as e:                      # an extra: never take the headline line down with it
                 out["rtk_topology"] = dict(error=repr(e))
         if not a.no_cpu_baseline and world == 1:

@@ -272,29 +272,37 @@ __device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f) {
         for (int e = t; e < 15 * N; e += NT) H0N[e] += HpN[e];
         __syncthreads();
         if (k == 1) CHSTAMP(41);
-        // MargPose1: Ainv = (H00)^-1 (InvertPSDMatrix<15>, assume_full_rank).  Round 5: in-place Gauss-Jordan without pivoting over a 15 x 15
-        // grid of threads, two barriers per column (read the column and the row of the pivot, write the step): its pivots are the
-        // Cholesky pivots d_j of the same matrix (a non-positive one fails the factor as before), no square root, one reciprocal per column.
+        // MargPose1: Ainv = (H00)^-1 (InvertPSDMatrix<15>, assume_full_rank).  Round 5: in-place Gauss-Jordan without pivoting (read the column
+        // and the row of the pivot, write the step): its pivots are the Cholesky pivots d_j of the same matrix (a non-positive one
+        // fails the factor as before), no square root, one reciprocal per column.
         // (Rounds 1-4: a Cholesky with a barrier per column, then fifteen threads each running a forward and a backward substitution — thirty
         // dependent IEEE divisions and 210 dependent multiply-adds on one lane: most of an epoch's 40 k cycles.)
         for (int e = t; e < 225; e += NT) { int a = e / 15, b = e - a * 15; sAinv[e] = (b >= a) ? H00[e] : H00[b * 15 + a]; }     // full symmetric from the upper triangle
         __syncthreads();
-        {
-            const int ga = t / 15, gb = t - ga * 15;
+        if (t < 64) {
+            // ONE wavefront, four entries per lane, no barrier inside: a step's reads (the entry, its row's entry in the pivot column, its
+            // column's entry in the pivot row, the pivot) are all issued before its writes, and the LDS executes a wave's operations in
+            // order (two workgroup barriers per column cost 11.9 k cycles per epoch at 1024 threads, 9 k at 256; this form 8 k)
+            int ea[4], eb[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) { const int e = t + 64 * m; ea[m] = e < 225 ? e / 15 : 0; eb[m] = e < 225 ? e - (e / 15) * 15 : 0; }
             for (int j = 0; j < 15; j++) {
                 double d = sAinv[j * 15 + j];
+                double aij[4], aik[4], akj[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) { aij[m] = sAinv[ea[m] * 15 + eb[m]]; aik[m] = sAinv[ea[m] * 15 + j]; akj[m] = sAinv[j * 15 + eb[m]]; }
+                asm volatile("" ::: "memory");
                 if (!(d > 0.0)) { if (t == 0) sBad = 1; d = 1.0; }
                 const double ip = rcp_nr(d);
-                double nv = 0.0;
-                if (t < 225) {
-                    const double aij = sAinv[t], aik = sAinv[ga * 15 + j], akj = sAinv[j * 15 + gb];
-                    nv = (ga == j) ? (gb == j ? ip : akj * ip) : (gb == j ? -(aik * ip) : aij - aik * (akj * ip));
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const double nv = (ea[m] == j) ? (eb[m] == j ? ip : akj[m] * ip) : (eb[m] == j ? -(aik[m] * ip) : aij[m] - aik[m] * (akj[m] * ip));
+                    if (t + 64 * m < 225) sAinv[ea[m] * 15 + eb[m]] = nv;
                 }
-                __syncthreads();
-                if (t < 225) sAinv[t] = nv;
-                __syncthreads();
+                asm volatile("" ::: "memory");
             }
         }
+        __syncthreads();
         if (k == 1) CHSTAMP(42);
         // T_blk = H0blk^T Ainv for blk = Pose2 (15), N, Pose0 (15)
         for (int e = t; e < 450 + 15 * N; e += NT) {

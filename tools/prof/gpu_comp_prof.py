@@ -59,6 +59,8 @@ if mode in ("solve", "batch"):
               % (sum(s.termination in (1, 2, 3) for s in s50), N, float(np.mean([s.num_iterations for s in s50])), sorted(set(int(s.termination) for s in s50))))
     bs.close()
 if mode == "solve":
+    cw, wi, ci = rt.warm_start_probe(solver, wins[:min(N, 16)], opt, default_options(max_num_iterations=50))
+    print("warm start (the windows converged, then only the newest frame moved by an IMU-prediction-sized error): %d of %d converge within %d iterations, mean %.1f iterations (cold: %.1f to termination)" % (cw, min(N, 16), iters, wi, ci))
     print("construction: generate %.1f s; %d GNSS epochs pre-eliminated in %.2f ms (C-ABI call), host bookkeeping %.1f ms" % (t_gen, tm["gnss_epochs"], 1e3 * tm["epoch_priors_s"], 1e3 * tm["host_assemble_s"]))
     import oracle_binding as ob
     ts, its = [], 0
