@@ -44,3 +44,6 @@ json.dump(res, open(out + "/batch512_pmc_fetch_write.json", "w"), indent=1)
 print("pmc kernels:", len(res["FETCH_SIZE"]), len(res["WRITE_SIZE"]))
 PY
 head -16 "$OUT/batch512_kernel_stats.csv" | cut -c1-150
+# 5. (round 5) the per-dispatch timeline of one window's solve, and the batch-size sweep
+bash "$ROOT/tools/prof/timeline.sh" 3 > "$OUT/single_window_timeline.txt" 2>&1
+cd "$ROOT" && python tools/prof/batch_size_sweep.py > "$OUT/batch_size_sweep.txt" 2>&1
