@@ -1107,7 +1107,7 @@ __global__ void __launch_bounds__(64) k_clique_elim(DevBatch B, DevOpt O) { d_cl
 __global__ void __launch_bounds__(256) k_clique_elim4(DevBatch B, DevOpt O) { d_clique_elim<64, 64, 9, 2, 8, 4>(B, O, (int)blockIdx.x); }
 // class 4: up to 96 rows x 64 columns — the clique of a speed-bias block that two composite IMU-GNSS factors touch (the reference's own
 // ordering puts every other speed-bias block into group 0, R/swf/swf_gnss.cpp:683-691: 2 x (30 + N) rows, 9 + 6 + 9 + 6 + 6 + 9 + N
-// columns; N <= 9 ambiguities fit the 64 columns, more take k_clique_big).  The four-wave form of the same function.
+// columns: N <= 18 ambiguities fit 96 rows x 64 columns, more take k_clique_big).  The four-wave form of the same function.
 #define CLQ_TALLR 96
 __global__ void __launch_bounds__(256) k_clique_tall(DevBatch B, DevOpt O) { d_clique_elim<CLQ_TALLR, 64, 9, 4, 8, 4>(B, O, (int)blockIdx.x); }
 
