@@ -719,6 +719,7 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         C.d_f = df;
         if (!t.is_static && C.d_e + df > CB_MAXD) return fail(SWF_E_UNSUPPORTED, "clique with more than 768 columns");
         if (!t.is_static && C.d_e > 9) return fail(SWF_E_UNSUPPORTED, "group-0 block larger than 9 dimensions");
+        if (!t.is_static && (long long)C.d_e * (C.d_e + df) > CB_MAXED) return fail(SWF_E_UNSUPPORTED, "clique: d_e (d_e + d_f) beyond 1536");
         C.C_off = B.C_tot; B.C_tot += (long long)df * df;
         C.v_off = B.v_tot; B.v_tot += df;
         C.e_off = B.e_tot; B.e_tot += C.d_e * C.d_e + C.d_e * df + C.d_e;
@@ -1552,7 +1553,7 @@ struct Launcher {
                 if (b->lat_fuse) hipLaunchKernelGGL(k_clique_elim4, dim3(D.n_clc[2]), dim3(256), 0, cstream(2), D, O);      // latency form: four waves per clique, same bits
                 else hipLaunchKernelGGL((k_clique_elim<64, 64, 9, 2>), dim3(D.n_clc[2]), dim3(64), 0, cstream(2), D, O);
             }
-            if (D.n_clc[3]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(3)); hipLaunchKernelGGL(k_clique_big, dim3(D.n_clc[3]), dim3(256), 0, cstream(3), D, O); }
+            if (D.n_clc[3]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(3)); hipLaunchKernelGGL(k_clique_big, dim3(D.n_clc[3]), dim3(CB_NT), 0, cstream(3), D, O); }
             if (D.n_clc[4]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(4)); hipLaunchKernelGGL(k_clique_tall, dim3(D.n_clc[4]), dim3(256), 0, cstream(4), D, O); }
             if (write_S && D.n_lm) {
                 // further tile ranges write nothing but their tiles of P (k_lm_schur: outs), so on the latency path they run behind the

@@ -1144,97 +1144,145 @@ __global__ void __launch_bounds__(LS_NT(NCW, TW)) k_lm_clique(DevBatch B, DevOpt
 //   thread (i, j):  C_ij = J_i . J_j - M_ei . T_j over the lower triangle
 // =========================================================================================
 #define CB_MAXD 768                           // columns of a big clique (d_e + d_f)
+#define CB_MAXED 1536                         // d_e x (d_e + d_f) of a big clique: the rows of M that belong to e, and T = Einv M_ef, live in LDS
 #define CB_LDS_J 12288                        // doubles of Jacobian staged in LDS (96 KB); larger ones are read through L2
-__global__ void __launch_bounds__(256) k_clique_big(DevBatch B, DevOpt O) {
-    __shared__ double Me[9][CB_MAXD];         // rows of M that belong to e; 54 KB
-    __shared__ double Ei[9][10];
-    __shared__ double Eg[9], ge[9];
-    __shared__ int bad_s;
-    __shared__ double Jl[CB_LDS_J];           // the staged Jacobian [d][nrow], when it fits
+#define CB_NT 1024
+// Round 5: rewritten for the cliques the reference's RTK topology produces with more than 18 ambiguities (two composite factors on an
+// eliminated speed-bias block: 2 (30 + N) rows x 45 + N columns; N = 24: 307 us per launch, half of that window's iteration).  The
+// old form ran phase 1 on d threads, the 9 x 9 Gauss-Jordan on ONE thread out of a private array (scratch memory), and re-formed T_j for
+// every entry of C.  Now: 1024 threads; phase 1 deals the d (d_e + 2) dot products one per thread; the inverse is wave 0's, a row per
+// lane, pivot rows through v_readlane (the code of d_clique_elim); T = Einv M_ef once, into LDS; an entry of C is one thread's
+// J_i . J_j - M_ei . T_j.  Sums in the same order as before.
+//   thread (c, p):  M_e*[p][c] = J_p . J_c (p < d_e), g_c = J_c . r, M_cc
+//   wave 0:         (M_ee + mu D)^-1 by Gauss-Jordan (d_e <= 9), Eg = Einv g_e
+//   thread (a, j):  T[a][j] = Einv[a][:] . M_e*[:][d_e + j]
+//   thread (i, j):  C_ij = J_i . J_j - M_ei . T_j over the lower triangle
+// (STAGED is a template parameter so that every pointer into the Jacobian has ONE address space: with a run-time choice between the
+// LDS copy and L2 the loads were flat_load — 100 us per launch for ten 108 x 69 cliques, most of it the latency of un-pipelined flat loads)
+template <bool STAGED>
+__device__ __forceinline__ void d_clique_big(const DevBatch& B, const DevOpt& O, double* Me, double* Tt, double (*Ei)[9], double* Eg, double* ge, int* bad_sp, double* Jl) {
+#define bad_s (*bad_sp)
     if ((int)blockIdx.x >= B.n_clc[3]) return;
     const Clique& C = B.clc_rec[3][blockIdx.x];
     WinState& s = B.ws[C.win];
     if (!s.need_lin) return;
-    const int de = C.d_e, df = C.d_f, d = de + df, nrow = C.n_rows, tid = threadIdx.x;
+    const int de = C.d_e, df = C.d_f, d = de + df, nrow = C.n_rows, tid = threadIdx.x, lane = tid & 63;
     const double* gJ = B.g_J + C.j_off;
     const double* rv = B.g_r + C.r_off;
-    const bool staged = (long long)nrow * d <= CB_LDS_J;
-    if (staged) for (int e = tid; e < nrow * d; e += 256) Jl[e] = gJ[e];
+    // (staged columns are padded to an odd length: threads that walk different columns in step read distinct banks — with the
+    // Jacobian's own column length, 108 rows for two 54-row factors, eight of them shared one)
+    constexpr bool staged = STAGED;
+    const int ldj = staged ? (nrow | 1) : nrow;
+    if (staged) for (int e = tid; e < nrow * d; e += CB_NT) { const int c = e / nrow, k2 = e - c * nrow; Jl[c * ldj + k2] = gJ[e]; }
     if (tid == 0) bad_s = 0;
     __syncthreads();
-    const double* Jc = staged ? Jl : gJ;
-    // 1. M_e*, gradient, diagonal: one column per thread and round
-    for (int c = tid; c < d; c += 256) {
-        const double* col = Jc + (size_t)c * nrow;
-        double gc = 0, mcc = 0, me[9];
-#pragma unroll
-        for (int a = 0; a < 9; a++) me[a] = 0;
-        for (int k = 0; k < nrow; k++) {
-            double x = col[k];
-            gc += x * rv[k]; mcc += x * x;
-#pragma unroll
-            for (int a = 0; a < 9; a++) if (a < de) me[a] += Jc[(size_t)a * nrow + k] * x;
+    const double* __restrict__ Jc = STAGED ? (const double*)Jl : gJ;
+    // 1. M_e*, gradient, diagonal: one dot product per thread and round (k ascending)
+    for (int e = tid; e < d * (de + 2); e += CB_NT) {
+        const int c = e / (de + 2), p = e - c * (de + 2);
+        const double* col = Jc + (size_t)c * ldj;
+        double acc = 0;
+        if (p < de) { const double* ce = Jc + (size_t)p * ldj;
+#pragma unroll 4
+            for (int k = 0; k < nrow; k++) acc += ce[k] * col[k];
+            Me[p * d + c] = acc; }
+        else if (p == de) {
+#pragma unroll 4
+            for (int k = 0; k < nrow; k++) acc += col[k] * rv[k];
+            if (c < de) { B.g[C.e_loc + c] = acc; ge[c] = acc; } else B.cv_graw[C.v_off + c - de] = acc;
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < nrow; k++) acc += col[k] * col[k];
+            if (c < de) B.diag[C.e_loc + c] = acc; else B.cv_dgraw[C.v_off + c - de] = acc;
         }
-#pragma unroll
-        for (int a = 0; a < 9; a++) Me[a][c] = a < de ? me[a] : 0.0;
-        if (c < de) { B.g[C.e_loc + c] = gc; B.diag[C.e_loc + c] = mcc; B.vc[C.e_loc + c] = gc / clampd(mcc, O.min_diag, O.max_diag); ge[c] = gc; }
-        else { B.cv_graw[C.v_off + c - de] = gc; B.cv_dgraw[C.v_off + c - de] = mcc; }
     }
     __syncthreads();
+    if (tid < de) B.vc[C.e_loc + tid] = ge[tid] / clampd(Me[tid * d + tid], O.min_diag, O.max_diag);       // (M_cc of an e column is M_e*[c][c]: the same sum)
     double* Cm = B.C + C.C_off;
     if (de > 0) {
-        // 2. Einv = (M_ee + mu D)^-1, Gauss-Jordan without pivoting (SPD), one thread
-        if (tid == 0) {
-            double A[9][18];
-            for (int i = 0; i < de; i++) for (int j = 0; j < de; j++) { A[i][j] = Me[i][j]; A[i][9 + j] = i == j ? 1.0 : 0.0; }
-            for (int i = 0; i < de; i++) A[i][i] += s.mu * damp_diag(O, A[i][i], B.jsc + C.e_loc + i, s.iter == 0);
+        // 2. Einv = (M_ee + mu D)^-1: [M_ee + mu D | I] -> [I | Einv] by Gauss-Jordan (SPD: no pivoting), wave 0, lane r < d_e keeps row r in
+        //    registers, step k broadcasts the pivot row through SGPRs (v_readlane): no LDS traffic, no barrier
+        if (tid < 64) {
+            constexpr int MAXE = 9;
+            double row[2 * MAXE];
+#pragma unroll
+            for (int j = 0; j < MAXE; j++) {
+                double v = (lane < de && j < de) ? Me[lane * d + j] : 0.0;
+                if (j == lane) v += s.mu * (lane < de ? damp_diag(O, v, B.jsc + C.e_loc + lane, s.iter == 0) : clampd(v, O.min_diag, O.max_diag));
+                row[j] = v; row[MAXE + j] = (j == lane) ? 1.0 : 0.0;
+            }
             bool bad = false;
-            for (int k = 0; k < de; k++) {
-                double piv = A[k][k];
-                if (!(piv > 0.0)) { bad = true; break; }
-                double ip = 1.0 / piv;
-                for (int j = 0; j < de; j++) { A[k][j] *= ip; A[k][9 + j] *= ip; }
-                for (int i = 0; i < de; i++) {
-                    if (i == k) continue;
-                    double f = A[i][k];
-                    for (int j = 0; j < de; j++) { A[i][j] -= f * A[k][j]; A[i][9 + j] -= f * A[k][9 + j]; }
+#pragma unroll
+            for (int k = 0; k < MAXE; k++) {
+                if (k < de) {
+                    double piv = readlane_d(row[k], k);
+                    if (!(piv > 0.0)) bad = true;
+                    double ip = __builtin_amdgcn_rcp(piv);
+                    ip = ip * (2.0 - piv * ip); ip = ip * (2.0 - piv * ip);
+                    double aik = row[k];
+#pragma unroll
+                    for (int j = 0; j < 2 * MAXE; j++) {
+                        double akj = readlane_d(row[j], k) * ip;
+                        row[j] = (lane == k) ? akj : row[j] - aik * akj;
+                    }
                 }
             }
-            if (bad) { s.lin_fail = 1; bad_s = 1; }
-            for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) Ei[i][j] = (!bad && i < de && j < de) ? A[i][9 + j] : 0.0;
-            for (int i = 0; i < 9; i++) { double v = 0; for (int j = 0; j < de; j++) v += Ei[i][j] * ge[j]; Eg[i] = v; }
+            if (bad && lane == 0) { s.lin_fail = 1; bad_s = 1; }
+            if (lane < MAXE) {
+#pragma unroll
+                for (int j = 0; j < MAXE; j++) Ei[lane][j] = (!bad && lane < de && j < de) ? row[MAXE + j] : 0.0;
+            }
         }
         __syncthreads();
         if (bad_s) return;
-        // 3. what the back-substitution needs (Einv | M_ef | g_e) and cs = -M_fe Einv g_e
+        if (tid < 9) { double v = 0; for (int j = 0; j < de; j++) v += Ei[tid][j] * ge[j]; Eg[tid] = v; }
+        // 3. T = Einv M_ef
+        for (int e = tid; e < de * df; e += CB_NT) {
+            const int a = e / df, j = e - a * df;
+            double tj = 0;
+            for (int b2 = 0; b2 < de; b2++) tj += Ei[a][b2] * Me[b2 * d + de + j];
+            Tt[a * df + j] = tj;
+        }
+        __syncthreads();
+        // what the back-substitution needs (Einv | M_ef | g_e) and cs = -M_fe Einv g_e
         double* E = B.cE + C.e_off;
-        for (int e = tid; e < de * de; e += 256) E[e] = Ei[e / de][e % de];
-        for (int j = tid; j < df; j += 256) {
+        for (int e = tid; e < de * de; e += CB_NT) E[e] = Ei[e / de][e % de];
+        for (int j = tid; j < df; j += CB_NT) {
             double v = 0;
-            for (int a = 0; a < de; a++) { E[de * de + a * df + j] = Me[a][de + j]; v -= Me[a][de + j] * Eg[a]; }
+            for (int a = 0; a < de; a++) { E[de * de + a * df + j] = Me[a * d + de + j]; v -= Me[a * d + de + j] * Eg[a]; }
             B.cv_cs[C.v_off + j] = v;
         }
         if (tid < de) E[de * de + de * df + tid] = ge[tid];
     } else {
-        for (int j = tid; j < df; j += 256) B.cv_cs[C.v_off + j] = 0.0;
+        for (int j = tid; j < df; j += CB_NT) B.cv_cs[C.v_off + j] = 0.0;
     }
-    // 4. C = M_ff - M_fe Einv M_ef over the lower triangle (mirrored on write); T_j = Einv M_e,j formed on the fly
+    // 4. C = M_ff - M_fe Einv M_ef over the lower triangle (mirrored on write)
     const long long ntri = (long long)df * (df + 1) / 2;
-    for (long long t = tid; t < ntri; t += 256) {
+    for (long long t = tid; t < ntri; t += CB_NT) {
         int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while ((long long)(i + 1) * (i + 2) / 2 <= t) i++;
         while ((long long)i * (i + 1) / 2 > t) i--;
         int j = (int)(t - (long long)i * (i + 1) / 2);
-        const double* ci = Jc + (size_t)(de + i) * nrow; const double* cj = Jc + (size_t)(de + j) * nrow;
+        const double* ci = Jc + (size_t)(de + i) * ldj; const double* cj = Jc + (size_t)(de + j) * ldj;
         double m = 0;
+#pragma unroll 4
         for (int k = 0; k < nrow; k++) m += ci[k] * cj[k];
-        for (int a = 0; a < de; a++) {
-            double tj = 0;
-            for (int b2 = 0; b2 < de; b2++) tj += Ei[a][b2] * Me[b2][de + j];
-            m -= Me[a][de + i] * tj;
-        }
+        for (int a = 0; a < de; a++) m -= Me[a * d + de + i] * Tt[a * df + j];
         Cm[(size_t)i * df + j] = m; Cm[(size_t)j * df + i] = m;
     }
+}
+#undef bad_s
+__global__ void __launch_bounds__(CB_NT) k_clique_big(DevBatch B, DevOpt O) {
+    __shared__ double Me[CB_MAXED];           // [d_e][d]
+    __shared__ double Tt[CB_MAXED];           // [d_e][d_f]
+    __shared__ double Ei[9][9];
+    __shared__ double Eg[9], ge[9];
+    __shared__ int bad_sv;
+    __shared__ double Jl[CB_LDS_J];           // the staged Jacobian [d][nrow | 1], when it fits
+    if ((int)blockIdx.x >= B.n_clc[3]) return;
+    const Clique& C = B.clc_rec[3][blockIdx.x];
+    if ((long long)(C.n_rows | 1) * (C.d_e + C.d_f) <= CB_LDS_J) d_clique_big<true>(B, O, Me, Tt, Ei, Eg, ge, &bad_sv, Jl);
+    else d_clique_big<false>(B, O, Me, Tt, Ei, Eg, ge, &bad_sv, Jl);
 }
 
 // =========================================================================================
