@@ -78,7 +78,11 @@ for t in range(N):
                 wr = referee.trajectory_referee(w, device_linearize, strategy=strat)
                 e_dev, e_or = np.abs(wg.a["pose"] - wr.a["pose"]).max(), np.abs(wo.a["pose"] - wr.a["pose"]).max()
                 print("   referee: device and oracle poses %.2e apart; from the extended-precision trajectory: device %.2e, oracle %.2e (cond(S) %.2e)" % (dpose, e_dev, e_or, condS), flush=True)
-                if e_dev > 10.0 * e_or + 1e-6: msg.append("pose: device %.2e from the referee, oracle %.2e (cond(S) %.2e, final cost rel %.2e)" % (e_dev, e_or, condS, abs(rg_[-1]["cost"] - ro[-1]["cost"]) / abs(ro[-1]["cost"])))
+                # (where the oracle happens to land very close to the referee — seed 31 case 98: 2.3e-7 at cond(S) 3.9e13 — ten times its distance
+                # is not a yardstick: a backward-stable solve of the LAST accepted step alone leaves sqrt(n) eps cond(S) |step| in the end state)
+                apriori = np.sqrt(eo["n_red"]) * 1.1e-16 * condS * wr.meta.get("referee_last_step_norm", 0.0)
+                print("   a-priori forward error of the last step: %.2e" % apriori, flush=True)
+                if e_dev > max(10.0 * e_or + 1e-6, apriori): msg.append("pose: device %.2e from the referee, oracle %.2e (cond(S) %.2e, final cost rel %.2e)" % (e_dev, e_or, condS, abs(rg_[-1]["cost"] - ro[-1]["cost"]) / abs(ro[-1]["cost"])))
         if strat == 0: wins.append((w, wg, [r["cost"] for r in rg_]))
         bs.close()
     except Exception as e:

@@ -53,5 +53,6 @@ def trajectory_referee(w0, linearize, strategy=0, max_num_iterations=8):
     a measured yardstick instead of a tolerance fitted to the failing case)."""
     import np_dense as nd
     wr = w0.copy()
-    nd.trust_region(wr, linearize, nd.window_cost, strategy="lm" if strategy else "dogleg", max_num_iterations=max_num_iterations)
+    rows, _ = nd.trust_region(wr, linearize, nd.window_cost, strategy="lm" if strategy else "dogleg", max_num_iterations=max_num_iterations)
+    wr.meta = dict(wr.meta); wr.meta["referee_last_step_norm"] = float(next((r["step_norm"] for r in reversed(rows) if r.get("accepted") and r.get("step_norm", 0) > 0), 0.0))
     return wr
