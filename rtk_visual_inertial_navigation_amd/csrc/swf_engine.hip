@@ -232,7 +232,6 @@ struct swf_batch {
         if (aux) { (void)hipStreamSynchronize(aux); handle_cache().give(aux); }
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
-    bool comp_fused = false;               // SWF_COMP_FUSED=1: k_comp_lin instead of the five composite kernels on the latency path (A/B: no gain)
     bool no_lm_clique = false, marg_one_wg = false, marg_no_pchol = false, marg_trace = false, marg_no_crit = false;      // A/B knobs, read once at creation
     int marg_first_check = 6;
     bool post_fuse = false;               // SWF_POST_FUSE=1: the one-grid forms of k_post_chol / k_post_dogleg at every batch size (A/B timing)
@@ -861,7 +860,6 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     // (every A/B knob is read once, here: no getenv on the latency path or inside the marginalisation's sweep loop, and none that could
     // race a setenv from the per-device enqueue threads of swf_solve_batches)
     b->no_lm_clique = getenv("SWF_NO_LM_CLIQUE") != nullptr;
-    b->comp_fused = getenv("SWF_COMP_FUSED") != nullptr;
     b->marg_one_wg = getenv("SWF_MARG_ONE_WG") != nullptr;
     b->marg_no_pchol = getenv("SWF_MARG_NO_PCHOL") != nullptr;
     b->marg_trace = getenv("SWF_MARG_TRACE") != nullptr;
@@ -1477,12 +1475,7 @@ struct Launcher {
             // composite IMU-GNSS factors of the windows that re-linearise: hidden epochs move, re-elimination, prior records rewritten
             // 1024 threads per factor while the chip holds every factor at once (two such workgroups per CU), 256 for larger batches
             const bool wide = b->n_comp <= 2 * b->n_cu;
-            if (wide && !b->comp_eigen_root && b->comp_fused) {
-                // A/B only (SWF_COMP_FUSED=1): one launch, a workgroup per factor through all five phases — measured 298.5 us per iteration of a
-                // cfg3-size window against 296.0 with the five launches (the phases' own memory round trips, not the launches, are what costs)
-                if (b->comp_nmin <= CO_SMALLN) hipLaunchKernelGGL(k_comp_lin<CO_SMALLN>, dim3(b->n_comp), dim3(1024), 0, st, D, b->CA, b->CM);
-                if (b->comp_nmax > CO_SMALLN) hipLaunchKernelGGL(k_comp_lin<CO_MAXN>, dim3(b->n_comp), dim3(1024), 0, st, D, b->CA, b->CM);
-            } else {
+            {
             hipLaunchKernelGGL(k_comp_gather, dim3(b->n_comp), dim3(128), 0, st, D, b->CA, b->CM);
             hipLaunchKernelGGL(k_comp_prep, dim3(b->n_comp), dim3(256), 0, st, b->CA);
             hipLaunchKernelGGL(k_comp_imu, dim3((b->CA.n_iq + 7) / 8), dim3(256), 0, st, b->CA);

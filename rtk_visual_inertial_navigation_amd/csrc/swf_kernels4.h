@@ -603,25 +603,9 @@ __device__ __forceinline__ void d_comp_scatter(const DevBatch& B, const CompArgs
 }
 __global__ void __launch_bounds__(256) k_comp_scatter(DevBatch B, CompArgs A, CompMeta Mt) { d_comp_scatter<256>(B, A, Mt, (int)blockIdx.x); }
 
-// A/B form (round 5, SWF_COMP_FUSED=1; NOT the default): the five phases of a factor's re-linearisation — gather the outer blocks, move
-// the hidden epochs, the chain's IMU factors, the re-elimination with its square root, the prior record — as ONE 1024-thread workgroup
-// per factor, a barrier where a phase reads what the previous one left in memory, instead of five dependent launches.  Same device
-// functions, same thread-to-element maps, same bits.  Measured on a cfg3-size reference-topology window: 298.5 us per iteration against
-// 296.0 with the five launches, a batch of 16 windows 3.83 against 3.48 ms — each phase's exposed memory round trips are the same inside
-// one kernel, the small phases lose the chip-wide parallelism they had as grids of their own, and dependent launches on one stream
-// follow each other without a gap.  Kept as the measurement's record.
-template <int NMAX>
-__global__ void __launch_bounds__(1024, 1) k_comp_lin(DevBatch B, CompArgs A, CompMeta Mt) {
-    const int f = blockIdx.x;
-    if (f >= A.n) return;
-    if ((A.N[f] <= CO_SMALLN) != (NMAX <= CO_SMALLN)) return;          // (the other instantiation's factor)
-    d_comp_gather(B, A, Mt, f);
-    __syncthreads();
-    if (!d_comp_prep(A, f)) return;                                    // (uniform: the window does not re-linearise)
-    __syncthreads();
-    const int q0 = A.e_off[f] + f, q1 = q0 + A.M[f] + 1;               // the chain's IMU factors in the flattened list
-    for (int qb = q0; qb < q1; qb += 8) { d_comp_imu(A, qb, q1); __syncthreads(); }
-    d_comp_elim<NMAX, 1024>(A, f);
-    __syncthreads();
-    d_comp_scatter<1024>(B, A, Mt, f);
-}
+// (Round 5 measured ONE 1024-thread workgroup per factor through all five phases — gather, hidden-epoch move, the chain's IMU factors,
+// re-elimination, prior record — against the five launches: 298.5 against 296.0 us per iteration of a cfg3-size reference-topology
+// window, a batch of 16 windows 3.83 against 3.48 ms.  Each phase's exposed memory round trips are the same inside one kernel, the small
+// phases lose the chip-wide parallelism they have as grids of their own, and dependent launches on one stream follow each other without
+// a gap.  Not kept.  Also measured and not kept: the J^T J / J^T r products of all links formed up front, off the
+// elimination chain (k_comp_elim 76.6 -> 80.1 us).)
