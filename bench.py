@@ -430,11 +430,14 @@ def main():
         fulls = stress_fulls(a.stress_windows)
     topo_wxs = None
     if world == 1 and not a.no_rtk_topology and not a.no_single_window and not os.environ.get("SWF_BENCH_SHARE_GPU"):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import rtk_topology_gen as rt_gen
-        t0_ = time.perf_counter()
-        topo_wxs = rt_gen.explicit_windows(a.topology_windows, K_vis=20, M=4, F=300, S=10)      # (process pool: before HIP is touched)
-        t_topo_gen = time.perf_counter() - t0_
+        try:                                            # an extra: never take the headline line down with it
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import rtk_topology_gen as rt_gen
+            t0_ = time.perf_counter()
+            topo_wxs = rt_gen.explicit_windows(a.topology_windows, K_vis=20, M=4, F=300, S=10)      # (process pool: before HIP is touched)
+            t_topo_gen = time.perf_counter() - t0_
+        except Exception:
+            topo_wxs = None
 
     import torch
     import torch.distributed as dist

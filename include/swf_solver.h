@@ -41,6 +41,8 @@ enum {
  * sizeof(swf_timing) bytes: a caller compiled against an older header must be rebuilt); swf_composite_assemble / _add_mid_prior stride
  * HpN / HNN by N_cap; after an optimising solve swf_get_reduced / swf_batch_export_reduced return L zero outside the parameter_head tail
  * block (the whole factor only after step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY); swf_prior_reset_linearization_point added.
+ * 105 (round 5): no layout change; a composite IMU-GNSS factor may touch one block of elimination group 0 (MyOrdering's own order), which
+ * 104 refused with SWF_E_UNSUPPORTED; SWF_PRIOR_EIGEN keeps every direction of information above eps on healthy windows.
  * swf_abi_sizes reports sizeof(swf_options), sizeof(swf_summary), sizeof(swf_timing), sizeof(swf_flat_window), sizeof(swf_iteration) so a binding can check its own. */
 int swf_version(void);
 int swf_abi_sizes(int32_t out[5]);
@@ -155,6 +157,7 @@ int swf_batch_export_jacobian(swf_batch* b, int32_t w, double* r, double* J, int
  * call blocks the calling thread until the priors exist. */
 enum { SWF_PRIOR_EIGEN = 0, SWF_PRIOR_CHOLESKY = 1 };
 #define SWF_MAX_TAIL_DIM 640
+#define SWF_MAX_COMPOSITE_AMBIGUITIES 64
 int swf_batch_marginalize(swf_batch* b, double eps, int32_t form);
 /* Results of the last swf_batch_marginalize for window w (synchronises).  Any pointer may be NULL; eig receives the n
  * eigenvalues (ascending; for SWF_PRIOR_CHOLESKY the squared diagonal of L_nn). */
@@ -404,8 +407,9 @@ swf_factor_id swf_add_projection_inverse_depth(swf_problem* p, int32_t kind, dou
 /* IMUGNSSFactor(IMUGNSS_info) (R/swf/swf.cpp:713-730, R/factor/gnss_imu_factor.cpp:99-119): the composite factor over
  * (pose_i, sb_i, pose_j, sb_j, N ambiguities) hiding M GNSS epochs.  hidden_pose [M][7] / hidden_sb [M][9] are the epochs'
  * parameter memory (gnss_poses / gnss_speed_bias): read at every solve, updated in place by it.  The other arrays (copied)
- * are laid out as in swf_composite_create for one factor; pre holds M + 1 records.  Its blocks must be variable and outside
- * elimination group 0; N <= 24. */
+ * are laid out as in swf_composite_create for one factor; pre holds M + 1 records.  Its blocks must be variable; at most ONE of them
+ * may be in elimination group 0 (MyOrdering puts every other speed-bias block there, R/swf/swf_gnss.cpp:683-691: pass the ordering as it
+ * is — the factor's rows then join that block's clique); N <= 64 (SWF_MAX_COMPOSITE_AMBIGUITIES). */
 swf_factor_id swf_add_imu_gnss(swf_problem* p, double* pose_i, double* sb_i, double* pose_j, double* sb_j, double* const* ambiguities,
                                int32_t N, int32_t M, double* hidden_pose, double* hidden_sb, const double* pose_lin, const double* sb_lin,
                                const double* Hpp, const double* HpN, const double* rhs_p, const double* HNN, const double* rhsN, const double* pre);

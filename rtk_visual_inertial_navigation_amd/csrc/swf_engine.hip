@@ -27,7 +27,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 extern "C" const char* swf_last_error(void) { return g_err.c_str(); }
 void swf_internal_set_error(const std::string& m) { g_err = m; }
-extern "C" int swf_version(void) { return 104; }
+extern "C" int swf_version(void) { return 105; }
 extern "C" int swf_abi_sizes(int32_t out[5]) {
     if (!out) return fail(SWF_E_INVALID, "swf_abi_sizes: null");
     out[0] = (int32_t)sizeof(swf_options); out[1] = (int32_t)sizeof(swf_summary); out[2] = (int32_t)sizeof(swf_timing);
