@@ -247,14 +247,17 @@ def test_add_mid_marg_info_bookkeeping_equals_numpy_restatement():
 
 
 @pytest.mark.gpu
-def test_composite_topology_at_cfg3_size_against_the_oracle():
+@pytest.mark.parametrize("S,n_red", [(10, 220), (24, 234)])
+def test_composite_topology_at_cfg3_size_against_the_oracle(S, n_red):
     """The reference's own topology at BASELINE cfg3 size: 20 visual frames linked by 19 composite IMU-GNSS factors
     hiding 4 GNSS epochs each (76 epochs pre-eliminated on the device in one batch), ~280 landmarks / ~2 800 observations, 10 ambiguities,
     ordered by MyOrdering as it is (R/swf/swf_gnss.cpp:629-783: every other speed-bias block in elimination group 0, so every composite
     factor touches one group-0 block and the reduced system has cfg3's 220 dimensions).  Same input window for both solvers: the
     yaml's 8 iterations (same accept / reject decisions, first cost to rounding, end states 1e-5 apart, device cost not above the
-    oracle's) and each to its own termination; and the window alone == inside a batch, bit for bit."""
-    wxs = rt.explicit_windows(3, seed0=900, pool=False, K_vis=20, M=4, F=300, S=10)
+    oracle's) and each to its own termination; and the window alone == inside a batch, bit for bit.  S = 24 ambiguities: the largest
+    the small instantiation of k_comp_elim takes (G = 54), cliques of 108 rows x 69 columns (k_clique_big, rewritten in round 5),
+    234 reduced dimensions (k_chol_rr4<15>)."""
+    wxs = rt.explicit_windows(3, seed0=900, pool=False, K_vis=20, M=4, F=300, S=S)
     wins = rt.composite_batch(solver, wxs)
     w = wins[0]
     assert w.a["comp_M"].size == 19 and int(w.a["comp_M"].sum()) == 76
@@ -262,7 +265,7 @@ def test_composite_topology_at_cfg3_size_against_the_oracle():
         wo, wd = w.copy(), w.copy()
         so, _ = ob.solve(wo, default_options(max_num_iterations=iters), export=False)
         bs = solver.BatchSolver([wd]); sd = bs.solve(default_options(max_num_iterations=iters))[0]
-        assert bs.dims(0)["n_red"] == 220 == ob.dims(w)["n_red"]
+        assert bs.dims(0)["n_red"] == n_red == ob.dims(w)["n_red"]
         bs.close()
         ro, rd = so.rows(), sd.rows()
         assert sd.termination == so.termination and (iters == 8 or sd.termination in (1, 2, 3)), (sd.termination, so.termination)
