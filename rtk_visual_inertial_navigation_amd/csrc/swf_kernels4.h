@@ -65,6 +65,8 @@ __device__ __forceinline__ bool d_comp_prep(const CompArgs& A, const int f) {
     const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
     __shared__ double dl2[15], dlN[CO_MAXN], dl0[15];                      // delta5[Pose2], [N], [Pose0]
     __shared__ double sOut[32], sNv[CO_MAXN], sOld[32], sNold[CO_MAXN], sDx[16], sRm[16];
+    constexpr int CP_MAXM = 16;                         // epochs whose increments are kept for the parallel state update (256 threads / 16 lanes)
+    __shared__ double sDxAll[CP_MAXM * 16];
     const int hist = A.history[f];
     if (t < 32) { sOut[t] = A.outer[(size_t)f * 32 + t]; sOld[t] = hist ? A.old[(size_t)f * 32 + t] : A.outer[(size_t)f * 32 + t]; }
     if (t < N) { sNv[t] = A.Nv[n0 + t]; sNold[t] = hist ? A.N_old[n0 + t] : A.Nv[n0 + t]; }
@@ -103,17 +105,37 @@ __device__ __forceinline__ bool d_comp_prep(const CompArgs& A, const int f) {
             __syncthreads();
             if (t < 15) { double s = 0; for (int k = 0; k < 15; k++) s += hi[t * 15 + k] * sRm[k]; sDx[t] = s; }
             __syncthreads();
-            if (t < 15) dl2[t] = sDx[t];
-            double* P = A.pose + (size_t)(e0 + i) * 7; double* Bv = A.sb + (size_t)(e0 + i) * 9;
-            if (t == 32) {
-                for (int k = 0; k < 3; k++) P[k] -= sDx[k];
-                double q[4], dq[4] = { -sDx[3] / 2, -sDx[4] / 2, -sDx[5] / 2, 1.0 };
-                qmul(P + 3, dq, q);
-                double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-                for (int k = 0; k < 4; k++) P[3 + k] = q[k] / nq;
+            if (t < 15) { dl2[t] = sDx[t]; if (i < CP_MAXM) sDxAll[i * 16 + t] = sDx[t]; }
+            if (i >= CP_MAXM) {
+                // (chains beyond CP_MAXM epochs: the epoch's states move inside the loop, a memory round trip per epoch)
+                double* P = A.pose + (size_t)(e0 + i) * 7; double* Bv = A.sb + (size_t)(e0 + i) * 9;
+                if (t == 32) {
+                    for (int k = 0; k < 3; k++) P[k] -= sDx[k];
+                    double q[4], dq[4] = { -sDx[3] / 2, -sDx[4] / 2, -sDx[5] / 2, 1.0 };
+                    qmul(P + 3, dq, q);
+                    double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                    for (int k = 0; k < 4; k++) P[3 + k] = q[k] / nq;
+                }
+                if (t >= 64 && t < 73) Bv[t - 64] -= sDx[6 + t - 64];
             }
-            if (t >= 64 && t < 73) Bv[t - 64] -= sDx[6 + t - 64];
             __syncthreads();
+        }
+        // the epochs' states move AFTER the chain, all at once (round 5: the chain needs only the increments; with the read-modify-write of
+        // an epoch's pose inside the loop every epoch waited a memory round trip at its last barrier): sixteen lanes per epoch, lane 0 the
+        // pose, lanes 1 .. 9 the speed-bias entries — the same operations on the same operands as inside the loop
+        {
+            const int ep = t >> 4, ln = t & 15;
+            if (ep < M && ep < CP_MAXM) {
+                const double* dx = sDxAll + ep * 16;
+                double* P = A.pose + (size_t)(e0 + ep) * 7; double* Bv = A.sb + (size_t)(e0 + ep) * 9;
+                if (ln == 0) {
+                    for (int k = 0; k < 3; k++) P[k] -= dx[k];
+                    double q[4], dq[4] = { -dx[3] / 2, -dx[4] / 2, -dx[5] / 2, 1.0 };
+                    qmul(P + 3, dq, q);
+                    double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                    for (int k = 0; k < 4; k++) P[3 + k] = q[k] / nq;
+                } else if (ln <= 9) Bv[ln - 1] -= dx[6 + ln - 1];
+            }
         }
         __threadfence_block();
     }
