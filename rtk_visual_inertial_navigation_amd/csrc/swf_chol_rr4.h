@@ -27,7 +27,8 @@
 
 #define R4_NT 768
 // NS = tiles per tile wave = the most tile columns the instance takes: 14 (n_red <= 224: no register spills under the 168-register
-// budget of twelve waves) or 15 (224 < n_red <= 240).  A launch of each covers a batch; every window belongs to exactly one.
+// budget of twelve waves), 15 (224 < n_red <= 240) or 16 (240 < n_red <= 256, round 5: a 20-frame window of the reference's topology with 31 .. 46
+// ambiguities; a few accumulator registers spill).  A launch of each covers a batch; every window belongs to exactly one.
 
 // pivot wave: fraction-free elimination of the published diagonal tile D (full symmetric), lane (li, lk), register q <-> M[lk+4q][li].
 // Column c: row c of M (the chain's copy, brought up to date one column ahead as in rr3_pivot_factor) is published for the
@@ -268,7 +269,7 @@ __device__ __forceinline__ void rr4_steps(F& f, std::integer_sequence<int, Js...
 
 template <int R4_NS>
 __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full) {
-    __shared__ double Pn[16][4][64];           // published panel tiles of the step, registers as they are: Pn[I][kk][lane]; the transposition scratch before / after the loop
+    __shared__ double Pn[17][4][64];           // published panel tiles of the step, registers as they are: Pn[I][kk][lane]; the transposition scratch before / after the loop
     __shared__ double Dg[16][4][64];           // the rows' pending diagonal tiles, negated, accumulator layout as it is: Dg[I][q][lane] (owner-private)
     __shared__ double Li[16][16][17];          // Linv_jj of every step (the transforms applied to -I once the loop is through: the backward pass multiplies by them)
     __shared__ double Gop[16][4][64];          // the four block Gauss transforms of every diagonal tile, A-operand layout: Gop[j][k][lane]
@@ -287,10 +288,10 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     if (!st.need_lin || st.lin_fail) return;
     const WinRec& W = B.win[w];
     const int n = W.n_red, tid = threadIdx.x;
-    if (n <= 0 || n > 240) return;                 // larger windows of a mixed batch belong to k_chol_big (launched next to this one)
+    if (n <= 0 || n > 256 || n > B.rr_nmax) return;      // larger windows of a mixed batch belong to k_chol_big (launched next to this one)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int Tc = (n + 15) >> 4;
-    if (R4_NS == 14 ? Tc > 14 : Tc != 15) return;  // the other instance's window
+    if (R4_NS == 14 ? Tc > 14 : Tc != R4_NS) return;      // another instance's window
     // Tile rows -> tile waves (at most nine: three on each SIMD the pivot wave does not use), heaviest first: the right-hand-side row,
     // the k longest matrix rows one each, the other m = Tc - 1 - k rows in pairs (a, m + 1 - a) (a middle row alone).  The trailing
     // work of row I is I (I - 1) / 2 tile updates: dealt over the three SIMDs in snake order, the matrix pipes carry 159 / 150 / 146

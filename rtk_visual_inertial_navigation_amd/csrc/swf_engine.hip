@@ -240,7 +240,8 @@ struct swf_batch {
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
     bool chol_rr2 = false;                // SWF_CHOL_RR2=1: the previous register-resident kernel (A/B testing)
     bool chol_rr3 = false;                // SWF_CHOL_RR3=1: round 3's k_chol_rr3 instead of k_chol_rr4 (A/B testing)
-    bool rr4_has15 = false;               // some window has 224 < n_red <= 240: the 15-column instance of k_chol_rr4 is launched as well
+    bool rr4_has15 = false, rr4_has16 = false;      // some window has 224 < n_red <= 240 / 240 < n_red <= 256: the 15- / 16-column instance of k_chol_rr4 is launched as well
+    int rr_nmax = 256;                    // largest reduced system of the register-resident Cholesky (240 behind the A/B knobs of the older kernels)
     bool export_L_always = false;         // SWF_EXPORT_L=1: k_chol_rr3 writes the whole factor on every solve path
     bool L_full = false;                  // the L buffer holds the whole factor of the last linear solve
     bool fs_fused = true;                 // per-frame sums inside k_eval_ps (SWF_FS_SEPARATE=1: k_frame_sums as its own launch; A/B testing)
@@ -852,6 +853,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
     b->chol_rr2 = getenv("SWF_CHOL_RR2") != nullptr;
     b->chol_rr3 = getenv("SWF_CHOL_RR3") != nullptr;
+    b->rr_nmax = (b->chol_rr2 || b->chol_rr3) ? 240 : 256;
+    b->D.rr_nmax = b->rr_nmax;
     b->export_L_always = getenv("SWF_EXPORT_L") != nullptr;
     b->asm_old = getenv("SWF_ASM_OLD") != nullptr;
     b->post_split = getenv("SWF_POST_SPLIT") != nullptr;
@@ -885,7 +888,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         b->lm_schur_flops += 216 * k * k + 108 * k;
         b->lm_schur_flops_sym += 108 * k * (k - 1) + 162 * k;
     }
-    for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); b->min_red = std::min(b->min_red, W.n_red); if (W.n_red > 224 && W.n_red <= 240) b->rr4_has15 = true; }
+    for (auto& W : B.win) { b->chol_flops += (int64_t)W.n_red * W.n_red * W.n_red / 3; b->max_red = std::max(b->max_red, W.n_red); b->min_red = std::min(b->min_red, W.n_red); if (W.n_red > 224 && W.n_red <= 240) b->rr4_has15 = true; if (W.n_red > 240 && W.n_red <= 256) b->rr4_has16 = true; }
     DevBatch& D = b->D;
     DevPool& P = b->pool;
     int rc = 0;
@@ -1109,7 +1112,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             // left the assembly's lists above, but their tiles are not zero
             std::vector<unsigned> tnz((size_t)n * 4, 0u);
             for (const Pair& Pq : B.pair) {
-                if (B.win[(size_t)Pq.win].n_red > 240) continue;
+                if (B.win[(size_t)Pq.win].n_red > 256) continue;
                 for (int I = Pq.ra / 16; I <= (Pq.ra + Pq.la - 1) / 16; I++)
                     for (int J = Pq.rb / 16; J <= (Pq.rb + Pq.lb - 1) / 16 && J < I; J++) { const int t = I * (I - 1) / 2 + J; tnz[(size_t)Pq.win * 4 + (t >> 5)] |= 1u << (t & 31); }
             }
@@ -1191,6 +1194,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             nonempty_i(tv_loc); nonempty_i(tv_red); nonempty_u(tv_cnt); nonempty_i(tv_src0); nonempty_i(tv_i); nonempty_i(tv_src);
             PUT(asw, asw); PUT(s_tnz, tnz);
             if (getenv("SWF_NO_TNZ")) D.s_tnz = nullptr;        // A/B: k_chol_rr4 loads every tile
+            D.rr_nmax = b->rr_nmax;
             PUT(as_dst, t_dst); PUT(as_cnt, t_cnt); PUT(as_src0, t_src0); PUT(as_aux, t_aux); PUT(as_src, t_src);
             PUT(av_loc, tv_loc); PUT(av_red, tv_red); PUT(av_cnt, tv_cnt); PUT(av_src0, tv_src0); PUT(av_i, tv_i); PUT(av_src, tv_src);
         }
@@ -1217,9 +1221,9 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     rc |= P.zeros(B.n_loc, &D.g); rc |= P.zeros(B.n_loc, &D.diag); rc |= P.zeros(B.n_loc, &D.rhs); rc |= P.zeros(B.n_loc, &D.vc);
     rc |= P.zeros(B.n_loc, &D.y); rc |= P.zeros(B.n_loc, &D.step);
     rc |= P.zeros(B.S_tot, &D.S); rc |= P.zeros(B.Lt_tot, &D.L);
-    if (b->max_red > 240 && b->max_red <= CB_NMAX) rc |= P.zeros((size_t)n * (CB_MAXT - 1) * 256, &D.Linv);
+    if (b->max_red > b->rr_nmax && b->max_red <= CB_NMAX) rc |= P.zeros((size_t)n * (CB_MAXT - 1) * 256, &D.Linv);
     // few windows, one of them on the streamed Cholesky: the factorisation is spread over the chip, two tile columns per launch (k_chol_col)
-    if (b->max_red > 240 && b->max_red <= CC_NMAX && n * 4 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);      // >= 4 workgroups per window
+    if (b->max_red > b->rr_nmax && b->max_red <= CC_NMAX && n * 4 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);      // >= 4 workgroups per window
     rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
     size_t np = (size_t)D.n_proj;
     rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl);
@@ -1572,20 +1576,21 @@ struct Launcher {
         Bracket t(*this, SWF_K_CHOL);
         if (b->max_red <= CB_NMAX && !b->force_chol_v1) {
             // per-window choice (each kernel skips the other's windows): register-resident tiles up to 240 dimensions, streamed above
-            if (b->min_red <= 240) {
+            if (b->min_red <= b->rr_nmax) {
                 if (b->chol_rr2) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
                 else if (b->chol_rr3) hipLaunchKernelGGL(k_chol_rr3, dim3(D.n_win), dim3(1024), 0, st, D, export_full ? 1 : 0);
                 else {
                     if (b->min_red <= 224) hipLaunchKernelGGL(k_chol_rr4<14>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
                     if (b->rr4_has15) hipLaunchKernelGGL(k_chol_rr4<15>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
+                    if (b->rr4_has16) hipLaunchKernelGGL(k_chol_rr4<16>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
                 }
             }
-            if (b->max_red > 240 && D.Wk) {
+            if (b->max_red > b->rr_nmax && D.Wk) {
                 const int Tc = (b->max_red + 15) / 16;
                 const int nbw = std::max(1, std::min(CC_NB, b->n_cu / D.n_win));       // the chip divided by the windows
                 for (int j = 0; j < Tc; j += 2) hipLaunchKernelGGL(k_chol_col, dim3(D.n_win, nbw), dim3(CC_NT), 0, st, D, j);
                 hipLaunchKernelGGL(k_chol_big<true>, dim3(D.n_win), dim3(1024), 0, st, D);      // backward substitution
-            } else if (b->max_red > 240) hipLaunchKernelGGL(k_chol_big<false>, dim3(D.n_win), dim3(1024), 0, st, D);
+            } else if (b->max_red > b->rr_nmax) hipLaunchKernelGGL(k_chol_big<false>, dim3(D.n_win), dim3(1024), 0, st, D);
         }
         else if (b->max_red + 1 <= 256) hipLaunchKernelGGL(k_chol_solve<256>, dim3(D.n_win), dim3(256), 0, st, D);
         else hipLaunchKernelGGL(k_chol_solve<1024>, dim3(D.n_win), dim3(1024), 0, st, D);
@@ -1648,7 +1653,7 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
     DevBatch& D = b->D;
     Launcher L{ b, to_devopt(opt), b->stream };
     L.export_full = opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY || b->export_L_always;
-    b->L_full = L.export_full || b->chol_rr2 || b->min_red > 240 || b->force_chol_v1 || b->max_red > CB_NMAX;
+    b->L_full = L.export_full || b->chol_rr2 || b->min_red > b->rr_nmax || b->force_chol_v1 || b->max_red > CB_NMAX;
     hipStream_t st = b->stream;
     b->ev_used = 0; b->ev_kind.clear();
     int nlin = 0;
@@ -1810,7 +1815,7 @@ extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, doub
         // k_chol_rr3 on a solve path keeps the factor in registers and writes only the block its readers use: the parameter_head
         // tail (from the 16-aligned row / column at or before its start).  Everything else is returned as zero.
         size_t first = 0;
-        if (!b->L_full && n <= 240) { const size_t td = (size_t)b->hw[w].tail_dim; first = td ? ((n - td) >> 4) << 4 : n; }
+        if (!b->L_full && n <= (size_t)b->rr_nmax) { const size_t td = (size_t)b->hw[w].tail_dim; first = td ? ((n - td) >> 4) << 4 : n; }
         for (size_t r = 0; r < n; r++) for (size_t c = 0; c < n; c++)
             L[r * n + c] = (c <= r && c >= first) ? (rr ? Lt[r * n + c] : Lt[c * (n + 1) + r]) : 0.0;
     }

@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
     if (!st.need_lin || st.lin_fail) return;
     const WinRec& W = B.win[w];
     int n = W.n_red, tid = threadIdx.x;
-    if (n <= 240) return;                          // the register-resident kernel's windows: the kernel is chosen per WINDOW, so a
+    if (n <= B.rr_nmax) return;                    // the register-resident kernel's windows: the kernel is chosen per WINDOW, so a
                                                    // window's arithmetic does not depend on what else is in the batch
     int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int Tc = (n + 15) >> 4, Tr = Tc + 1;
@@ -849,7 +849,7 @@ __global__ void __launch_bounds__(CC_NT) k_chol_col(DevBatch B, int j) {
     if (!st.need_lin || st.lin_fail) return;
     const WinRec& W = B.win[w];
     const int n = W.n_red, tid = threadIdx.x;
-    if (n <= 240) return;
+    if (n <= B.rr_nmax) return;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int Tc = (n + 15) >> 4, Tr = Tc + 1;
     if (j >= Tc) return;

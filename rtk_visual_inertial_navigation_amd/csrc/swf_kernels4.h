@@ -400,18 +400,20 @@ __device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f) {
     //   H -= v_r v_r^T,  rhs -= v_r rho_r,
     // and stops when the remaining diagonal is below 1e-14 of the first pivot or 1e-8 absolute (the reference's eigenvalue
     // threshold): the rows beyond the rank are zero.  sum_r v_r v_r^T = H and sum_r v_r rho_r = rhs on the retained range.
-    if constexpr (NMAX <= CO_SMALLN) {
-        // Round 5: LEFT-LOOKING in ONE wavefront, no barrier inside (G + 1 <= 55 lanes: lane i owns row i for good, lane G the right-hand
-        // side, which rides along as row G: its factor row is L^-1 rhs).  Nothing is updated but the running diagonal (a register per
-        // lane); step r forms only the pivot's column, c_i = H[i][p] - sum_{s < r} L[i][s] L[p][s], and stores it as column r.  To
-        // keep column s of L AT position s (every address of the inner product is `row base + s`: contiguous reads along the lane's own
-        // row — rows are padded to an odd length: conflict-free — and LDS broadcasts of the pivot's row) each lane first exchanges, in
-        // its own row, position r with the position that holds H's column p: a column of H is read once, when its index becomes the
-        // pivot; lane q tracks where column q lives (cpos).  Rows never move, so the lane index is the original index, the arg-max is
-        // a ballot, and nothing crosses lanes but the broadcasts.  The factor goes to HBM after the loop, coalesced, by all threads.
-        // G^3 / 6 multiply-adds on one wave instead of G full-matrix updates behind three barriers each, an arg-max through six
-        // ds_bpermute round trips and an IEEE division + square root per step (rounds 1-4: ~180 k of the kernel's 380 k cycles).
-        // What is left is the instructions one wave issues per step (~8 cycles each): 1.1 k cycles a step.
+    {
+        // Round 5: LEFT-LOOKING in ONE wavefront, no barrier inside (lane i owns row i — and row i + 64 in the instantiation for up to 64
+        // ambiguities, G + 1 <= 95 rows — for good; row G is the right-hand side, which rides along: its factor row is L^-1 rhs).  Nothing
+        // is updated but the running diagonal (a register per row); step r forms only the pivot's column,
+        // c_i = H[i][p] - sum_{s < r} L[i][s] L[p][s], and stores it as column r.  To keep column s of L AT position s (every address of the
+        // inner product is `row base + s`: contiguous reads along the lane's own rows — rows are padded to an odd length: conflict-free —
+        // and LDS broadcasts of the pivot's row) each lane first exchanges, in its own rows, position r with the position that holds H's
+        // column p: a column of H is read once, when its index becomes the pivot; the owner of row q tracks where column q lives (cpos).
+        // Rows never move, so the row index is the original index, the arg-max is a ballot, and nothing crosses lanes but the broadcasts.
+        // The factor goes to HBM after the loop, coalesced, by all threads.  G^3 / 6 multiply-adds on one wave instead of G full-matrix
+        // updates behind three barriers each, an arg-max through six ds_bpermute round trips and an IEEE division + square root per step
+        // (rounds 1-4: ~180 k of the small instantiation's 380 k cycles; the large one kept that form until the end of round 5: 234 us per
+        // launch at 40 ambiguities).  What is left is the instructions one wave issues per step (~8 cycles each): 1.4 k cycles a step.
+        constexpr int RPL = (30 + NMAX + 1 + 63) / 64;      // rows per lane: 1 (G + 1 <= 55) or 2 (G + 1 <= 95)
         __shared__ int sRank;
         const int LDP = G | 1;
         for (int e = t; e < G * G; e += NT) { int a = e / G, b = e - a * G; sD[a * LDP + b] = A.Hd[g20 + e]; }
@@ -420,34 +422,63 @@ __device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f) {
         CHSTAMP(45);
         if (t < 64) {
             const double GONE = -1e300;
-            const int me = t <= G ? t : G;                  // (lanes beyond the right-hand side's shadow it; they store nothing)
-            double* const rowi = sD + me * LDP;
-            double di = t < G ? rowi[t] : GONE;
-            int cpos = t;                                   // where column t of H lives in every row
+            int idx[RPL], cpos[RPL];
+            double* rowi[RPL]; double di[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; k++) {
+                idx[k] = t + 64 * k;                        // (rows beyond the right-hand side shadow it; they store nothing)
+                rowi[k] = sD + (idx[k] <= G ? idx[k] : G) * LDP;
+                di[k] = idx[k] < G ? rowi[k][idx[k]] : GONE;
+                cpos[k] = idx[k];                           // where column idx of H lives in every row
+            }
             double d0 = 0.0;
             int r = 0;
             for (; r < G; r++) {
-                const double m16 = grp16_max(di);
+                double dm = di[0];
+#pragma unroll
+                for (int k = 1; k < RPL; k++) dm = fmax(dm, di[k]);
+                const double m16 = grp16_max(dm);
                 const double bv = fmax(fmax(rows_lane(m16, 0), rows_lane(m16, 16)), fmax(rows_lane(m16, 32), rows_lane(m16, 48)));
-                const unsigned long long hit = __builtin_amdgcn_ballot_w64(di == bv);
-                const int p = hit ? (int)__builtin_ctzll(hit) : 0;             // (the first index wins ties)
+                int p = 0;                                  // (the first index wins ties)
+                {
+                    bool found = false;
+#pragma unroll
+                    for (int k = 0; k < RPL; k++) {
+                        const unsigned long long hit = __builtin_amdgcn_ballot_w64(di[k] == bv);
+                        if (!found && hit) { p = 64 * k + (int)__builtin_ctzll(hit); found = true; }
+                    }
+                }
                 if (r == 0) d0 = bv;
                 if (!(bv > 1e-14 * d0) || !(bv > 1e-8)) break;                 // uniform
-                const int P = __builtin_amdgcn_readlane(cpos, p);              // column p of H sits at position P >= r
-                double c = rowi[P];
-                const double hr = rowi[r];
-                asm volatile("" ::: "memory");
-                if (t <= G && P != r) rowi[P] = hr;                            // H's column from position r moves to P (its owner notes it)
-                if (cpos == r) cpos = P;
+                int P = __builtin_amdgcn_readlane(cpos[0], p & 63);            // column p of H sits at position P >= r
+#pragma unroll
+                for (int k = 1; k < RPL; k++) { const int Pk = __builtin_amdgcn_readlane(cpos[k], p & 63); if ((p >> 6) == k) P = Pk; }
+                double c[RPL];
+#pragma unroll
+                for (int k = 0; k < RPL; k++) {
+                    c[k] = rowi[k][P];
+                    const double hr = rowi[k][r];
+                    asm volatile("" ::: "memory");
+                    if (idx[k] <= G && P != r) rowi[k][P] = hr;                // H's column from position r moves to P (its owner notes it)
+                    if (cpos[k] == r) cpos[k] = P;
+                }
                 const double* rp = sD + p * LDP;
 #pragma unroll 4
-                for (int s2 = 0; s2 < r; s2++) c -= rowi[s2] * rp[s2];
-                const bool live = t == G || (t < G && di > 0.5 * GONE);
-                const double v = live ? c * rsqrt_nr(bv) : 0.0;                // (a row that was a pivot has nothing right of its own column)
+                for (int s2 = 0; s2 < r; s2++) {
+                    const double b = rp[s2];
+#pragma unroll
+                    for (int k = 0; k < RPL; k++) c[k] -= rowi[k][s2] * b;
+                }
+                const double isq = rsqrt_nr(bv);
                 asm volatile("" ::: "memory");
-                if (t <= G) rowi[r] = v;
+#pragma unroll
+                for (int k = 0; k < RPL; k++) {
+                    const bool live = idx[k] == G || (idx[k] < G && di[k] > 0.5 * GONE);
+                    const double v = live ? c[k] * isq : 0.0;                  // (a row that was a pivot has nothing right of its own column)
+                    if (idx[k] <= G) rowi[k][r] = v;
+                    di[k] = (idx[k] == p) ? GONE : (live && idx[k] < G ? di[k] - v * v : di[k]);
+                }
                 asm volatile("" ::: "memory");
-                di = (t == p) ? GONE : (live && t < G ? di - v * v : di);
             }
             if (t == 0) sRank = r;
         }
@@ -462,38 +493,6 @@ __device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f) {
             if (A.jac_out) A.jac_out[g20 + (size_t)r2 * G + a] = v;
         }
         if (t < G) { const double v = t < rank ? sD[G * LDP + t] : 0.0; A.r0[g0 + t] = v; A.res_out[g0 + t] = v; }
-    } else {
-        for (int e = t; e < G * G; e += NT) sD[e] = A.Hd[g20 + e];
-        if (t < G) sD[G * G + t] = A.rd[g0 + t];                          // the rhs rides along as row G: its factor row is L^-1 rhs
-        __syncthreads();
-        __shared__ int sPiv, sStop; __shared__ double sPv;
-        for (int e = t; e < G * G; e += NT) { A.Ld[g20 + e] = 0.0; if (A.jac_out) A.jac_out[g20 + e] = 0.0; }
-        if (t < G) { A.r0[g0 + t] = 0.0; A.res_out[g0 + t] = 0.0; }
-        if (t == 0) sStop = 0;
-        __syncthreads();
-        double d0 = 0.0;
-        for (int r = 0; r < G; r++) {
-            if (t < 64) {                                // wave 0: arg max of the diagonal (first index wins ties)
-                double bv = -1.0; int bi = -1;
-                for (int i = t; i < G; i += 64) { double v = sD[i * G + i]; if (v > bv) { bv = v; bi = i; } }
-                for (int o = 32; o > 0; o >>= 1) {
-                    double ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
-                    if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
-                }
-                if (t == 0) { sPv = bv; sPiv = bi; }
-            }
-            __syncthreads();
-            if (r == 0) d0 = sPv;
-            if (!(sPv > 1e-14 * d0) || !(sPv > 1e-8)) break;            // uniform
-            const int p = sPiv; const double isq = 1.0 / sqrt(sPv);
-            double vr = 0.0;
-            if (t < G) { vr = sD[t * G + p] * isq; A.Ld[g20 + (size_t)t * G + r] = vr; if (A.jac_out) A.jac_out[g20 + (size_t)r * G + t] = vr; sdinv[t] = vr; }
-            if (t == 255) { double rho = sD[G * G + p] * isq; A.r0[g0 + r] = rho; A.res_out[g0 + r] = rho; sRes[0] = rho; }
-            __syncthreads();
-            for (int e = t; e < G * G; e += NT) { int a = e / G, b2 = e - a * G; sD[e] = (a == p || b2 == p) ? 0.0 : sD[e] - sdinv[a] * sdinv[b2]; }
-            if (t < G) sD[G * G + t] = t == p ? 0.0 : sD[G * G + t] - sdinv[t] * sRes[0];
-            __syncthreads();
-        }
     }
     if (t < 32) A.old[(size_t)f * 32 + t] = sOut[t];
     if (t < N) A.N_old[n0 + t] = sNv[t];

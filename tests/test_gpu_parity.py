@@ -51,6 +51,9 @@ CASES = [
     dict(config_id=3, K=26, F=40, S=5, seed=11),      # > 21 frames: the 12-consumer-wave k_lm_schur variant; tracks of 17..26
                                                       # observations span two 16-lane groups; n_red > 240: the streaming Cholesky
     dict(config_id=2, K=38, F=24, S=0, seed=12),      # tracks of 33..38 observations span four groups (a whole producer wave)
+    dict(config_id=3, K=22, F=40, S=10, seed=21),     # n_red = 241: the first window of k_chol_rr4<16> (round 5: 240 < n_red <= 256 register-resident)
+    dict(config_id=3, K=22, F=36, S=25, seed=22, head="ambiguities"),      # n_red = 256: the largest, its 25-ambiguity tail exported
+    dict(config_id=3, K=23, F=30, S=5, seed=23),      # n_red = 251 (ragged last tile)
     dict(config_id=3, K=7, F=33, S=12, seed=9, spp=True),          # + rover-only pseudorange / carrier phase and fixed-integer factors
     dict(config_id=3, K=5, F=14, S=6, seed=4, spp=True, head="ambiguities"),   # the same with the ambiguities as parameter_head
     dict(config_id=5),                                # the full stress configuration: 40 KF / 1000 features / 20 sats / dense prior,
