@@ -111,7 +111,7 @@ int swf_batch_summaries(swf_batch* b, swf_summary* out);
  *       its trailing tail_dim x tail_dim block L_nn gives L_nn L_nn^T = marginal information
  *       of the parameter_head states (R/swf/swf_gnss.cpp:85-87).
  *       After a solve with step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY (UpdateSchur's and the marginalisation's mode) L is the
- *       whole factor.  After an optimising solve of a system of up to 240 dimensions only the block the reference reads then
+ *       whole factor.  After an optimising solve of a system of up to 256 dimensions (240 up to library version 104) only the block the reference reads then
  *       (UpdateSchurHessianOnly, R/swf/swf_gnss.cpp:65-94) is kept: rows and columns from the 16-aligned index at or before the
  *       parameter_head tail; the rest is returned as zero (the factor lives in registers and is not written to HBM on solve
  *       paths).  SWF_EXPORT_L=1 in the environment keeps the whole factor everywhere.
