@@ -229,7 +229,7 @@ __device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f) {
     __shared__ double scratch[900 + 15 * NMAX];                            // sJ ; then Ainv | L | T2 | T0 | TN (15 x N)
     double* const sJ = scratch + 450;
     double* const sAinv = scratch; double* const sL = scratch + 225; double* const T2 = scratch + 450; double* const T0 = scratch + 675; double* const TN = scratch + 900;
-    __shared__ double sRes[16], sdinv[30 + NMAX], sOut[32], sNv[NMAX], sDx[16], sDx2[16];
+    __shared__ double sRes[16], sOut[32], sNv[NMAX], sDx[16], sDx2[16];
     __shared__ int sBad;
     const int midk = A.mid[f]; const double* H12 = A.H12 + (size_t)f * 225;
     if (t < 32) sOut[t] = A.outer[(size_t)f * 32 + t];
