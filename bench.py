@@ -674,9 +674,9 @@ def main():
             "windows_per_sec": job_windows * a.steps / dt,
             "iterations_per_window": its_total / job_windows,
             "with_state_upload": {"ms_per_step": 1e3 * dt_up / a.steps, "value": its_total * a.steps / dt_up,
-                                  "note": "parameter blocks re-uploaded from pageable host memory before every solve (PCIe-inclusive)"},
+                                  "note": "parameter blocks re-uploaded from the caller's (pageable) memory before every solve, through the batch's page-locked staging buffer (PCIe-inclusive)"},
             "survey_8d_protocol": {"ms_per_step": 1e3 * dt_ud / a.steps, "value": its_total * a.steps / dt_ud,
-                                   "note": "SURVEY.md 8d timing: state upload, solve, download of the parameter blocks and of the per-window summaries all inside the timed region (pageable host memory)"},
+                                   "note": "SURVEY.md 8d timing: state upload, solve, download of the parameter blocks and of the per-window summaries all inside the timed region (the caller's pageable memory, staged through page-locked buffers)"},
             "strong_scaling_projection": proj,
             "job_final_cost_mean": float(job[:, 0].mean()), "job_windows": int(job.shape[0]),
             # terminations 1..4 = converged / iteration limit; anything else (linear solver failure, ...) would make the rate meaningless
