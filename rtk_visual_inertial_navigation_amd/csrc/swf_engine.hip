@@ -214,6 +214,7 @@ struct swf_batch {
     // composite IMU-GNSS factors of the batch (swf_kernels4.h): operator arguments, solver-side bookkeeping, initial hidden epochs
     CompArgs CA{}; CompMeta CM{}; int n_comp = 0, comp_nmax = 0, comp_nmin = 1 << 30; long long comp_ne = 0;
     bool comp_eigen_root = false;                      // SWF_COMP_EIGEN_ROOT=1 at create: the composite factors expose the reference's eigen square root
+    void* h_sum = nullptr; size_t h_sum_bytes = 0;       // page-locked staging of the per-window states and traces (swf_batch_summaries)
     double* h_x = nullptr;                // page-locked staging of the parameter blocks (state upload / download: one DMA instead of a pageable copy)
     double* co_pose0 = nullptr; double* co_sb0 = nullptr;    // clique class holds IMU factors (its elimination must follow k_eval_imu)
     // marginalisation consumer outputs (allocated at the first swf_batch_marginalize)
@@ -1356,6 +1357,7 @@ extern "C" int swf_batch_destroy(swf_batch* b) {
     if (b->aux) (void)hipStreamSynchronize(b->aux);     // nothing of this batch may still run when its slabs go back to the cache
     for (auto& e : b->ev) handle_cache().give(e, true);
     if (b->h_x) (void)hipHostFree(b->h_x);
+    if (b->h_sum) (void)hipHostFree(b->h_sum);
     b->pool.release();
     delete b;
     return SWF_OK;
@@ -1779,10 +1781,18 @@ extern "C" int swf_batch_summaries(swf_batch* b, swf_summary* out) {
     DeviceGuard dg_(b ? b->device : -1);
     if (!b || !out) return fail(SWF_E_INVALID, "bad arguments");
     size_t n = b->win.size();
-    std::vector<WinState> ws(n);
-    std::vector<swf_iteration> tr(n * SWF_MAX_TRACE);
-    HIPCHK(hipMemcpyAsync(ws.data(), b->D.ws, n * sizeof(WinState), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipMemcpyAsync(tr.data(), b->D.trace, tr.size() * sizeof(swf_iteration), hipMemcpyDeviceToHost, b->stream));
+    // (page-locked staging kept by the batch: the traces are 2.4 MB for 512 windows)
+    const size_t ws_b = (n * sizeof(WinState) + 63) & ~(size_t)63, tr_b = n * SWF_MAX_TRACE * sizeof(swf_iteration);
+    if (b->h_sum_bytes < ws_b + tr_b) {
+        if (b->h_sum) (void)hipHostFree(b->h_sum);
+        b->h_sum = nullptr; b->h_sum_bytes = 0;
+        HIPCHK(hipHostMalloc(&b->h_sum, ws_b + tr_b, hipHostMallocDefault));
+        b->h_sum_bytes = ws_b + tr_b;
+    }
+    WinState* ws = (WinState*)b->h_sum;
+    swf_iteration* tr = (swf_iteration*)((char*)b->h_sum + ws_b);
+    HIPCHK(hipMemcpyAsync(ws, b->D.ws, n * sizeof(WinState), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(tr, b->D.trace, tr_b, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     for (size_t i = 0; i < n; i++) {
         swf_summary& s = out[i];
@@ -1792,7 +1802,7 @@ extern "C" int swf_batch_summaries(swf_batch* b, swf_summary* out) {
         s.num_successful_steps = ws[i].nsucc; s.num_unsuccessful_steps = ws[i].nunsucc;
         s.num_iterations = ws[i].iter; s.termination = ws[i].status;
         s.reduced_dim = b->win[i].n_red; s.tail_dim = b->hw[i].tail_dim;
-        memcpy(s.trace, tr.data() + i * SWF_MAX_TRACE, sizeof(swf_iteration) * SWF_MAX_TRACE);
+        memcpy(s.trace, tr + i * SWF_MAX_TRACE, sizeof(swf_iteration) * SWF_MAX_TRACE);
     }
     return SWF_OK;
 }
