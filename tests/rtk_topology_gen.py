@@ -120,6 +120,45 @@ def assemble_np(M, kept, priors):
     return dict(ids=ids, Hpp=Hpp, HpN=HpN, rhs_p=rhs_p, HNN=HNN, rhsN=rhsN)
 
 
+def plug_into_explicit(wx, wc, clocks_from):
+    """The composite window's solution written into the explicit window's state (visual frames, hidden epochs, landmarks,
+    ambiguities); the receiver clocks, which the composite topology eliminated, come from `clocks_from`."""
+    m = wx.meta
+    w2 = clocks_from.copy()
+    P, B = w2.a["pose"].reshape(-1, 7), w2.a["sb"].reshape(-1, 9)
+    pc, bc = wc.a["pose"].reshape(-1, 7), wc.a["sb"].reshape(-1, 9)
+    for k, v in enumerate(m["vis"]):
+        P[v] = pc[k]; B[v] = bc[k]
+    hp, hs = wc.a["comp_pose"].reshape(-1, 7), wc.a["comp_sb"].reshape(-1, 9)
+    for i, h in enumerate(m["hidden"]):
+        P[h] = hp[i]; B[h] = hs[i]
+    w2.a["lm"][...] = wc.a["lm"]
+    w2.a["sc"][1:1 + m["S"]] = wc.a["sc"][1:1 + m["S"]]
+    return w2
+
+
+def explicit_cost(solver, wx, wc):
+    """Cost of the EXPLICIT problem (no composite factor, no square root of a remainder in it) at the composite window's solution wc, the
+    receiver clocks — which the composite topology eliminated — at their optimum for these states: every other block held constant, a
+    few iterations on the clocks alone (the problem is linear in them).  The one yardstick two composite solutions can be compared by
+    when they differ along a weakly determined direction.  Runs on the device (raw-factor kernels)."""
+    from rtk_visual_inertial_navigation_amd.flat import default_options
+    w0_ = plug_into_explicit(wx, wc, wx)
+    a_ = {k: v.copy() for k, v in w0_.a.items()}
+    ic = np.ones_like(a_["is_const"])
+    first_sc = w0_.bid_sc(0)
+    for b_id, g_id in zip(a_["order_block"], a_["order_group"]):          # the receiver clocks: the scalar blocks of elimination group 0 (bar the dummy anchor)
+        if g_id == 0 and b_id > first_sc:
+            ic[b_id] = 0
+    a_["is_const"] = ic
+    keep = ic[a_["order_block"]] == 0
+    a_["order_block"], a_["order_group"] = a_["order_block"][keep], a_["order_group"][keep]
+    w_ = FlatWindow(n_tail=0, proj_sqrt_info=w0_.proj_sqrt_info, proj_loss_a=w0_.proj_loss_a, pbg=w0_.pbg, gw=w0_.gw, base=w0_.base, meta=dict(w0_.meta), **a_)
+    b_ = solver.BatchSolver([w_]); c_ = b_.solve(default_options(max_num_iterations=4), download=False)[0].final_cost; b_.close()
+    return c_
+
+
+
 def composite_window(wx, chains, reference_ordering=True):
     """The window over the visual frames only: projection factors, the gauge prior, the dummy, and one composite factor per gap
     built from chains[g] = assemble output (Hpp, HpN, rhs_p, HNN, rhsN over that gap's M epochs, ambiguity ids 0..S-1).
@@ -193,7 +232,7 @@ def explicit_windows(n, seed0=900, pool=True, **kw):
     return [_explicit_job(j) for j in jobs]
 
 
-def composite_batch(solver, wxs, timing=None):
+def composite_batch(solver, wxs, timing=None, reference_ordering=True):
     """The device-side construction of the reference's topology for a list of explicit windows (what bench.py's rtk_topology /
     composite legs and tools/prof/gpu_comp_prof.py time): (1) every GNSS epoch of every window as ONE batch through
     swf_batch_marginal_priors (GnssPreprocess, R/swf/swf_gnss.cpp:504-532), (2) AddMargInfo's bookkeeping on the host
@@ -220,7 +259,7 @@ def composite_batch(solver, wxs, timing=None):
             c["ids"] = [inv[id(b)] for b in c["keys"]]
             chains.append(c)
         o += len(es)
-        wins.append(composite_window(wx, chains))
+        wins.append(composite_window(wx, chains, reference_ordering=reference_ordering if isinstance(reference_ordering, bool) else reference_ordering[len(wins)]))
     if timing is not None:
         timing.update(gnss_epochs=len(ews), epoch_priors_s=tm.get("c_abi_call_s"), epoch_priors_with_python_marshalling_s=t_wrap, host_assemble_s=time.perf_counter() - t0)
     return wins

@@ -23,21 +23,7 @@ def oracle_epoch_priors(ews):
     return out
 
 
-def plug_into_explicit(wx, wc, clocks_from):
-    """The composite window's solution written into the explicit window's state (visual frames, hidden epochs, landmarks,
-    ambiguities); the receiver clocks, which the composite topology eliminated, come from `clocks_from`."""
-    m = wx.meta
-    w2 = clocks_from.copy()
-    P, B = w2.a["pose"].reshape(-1, 7), w2.a["sb"].reshape(-1, 9)
-    pc, bc = wc.a["pose"].reshape(-1, 7), wc.a["sb"].reshape(-1, 9)
-    for k, v in enumerate(m["vis"]):
-        P[v] = pc[k]; B[v] = bc[k]
-    hp, hs = wc.a["comp_pose"].reshape(-1, 7), wc.a["comp_sb"].reshape(-1, 9)
-    for i, h in enumerate(m["hidden"]):
-        P[h] = hp[i]; B[h] = hs[i]
-    w2.a["lm"][...] = wc.a["lm"]
-    w2.a["sc"][1:1 + m["S"]] = wc.a["sc"][1:1 + m["S"]]
-    return w2
+plug_into_explicit = rt.plug_into_explicit
 
 
 def build_chains(wx, kept, pri, assemble):
@@ -160,23 +146,7 @@ def test_device_epoch_priors_and_composite_topology(kw, monkeypatch):
         assert sx.final_cost <= so.final_cost * (1 + 1e-6)             # the device drops the noise terms the oracle keeps, never the other way round
         sols[root] = ws_
     assert np.abs(sols["eigen"].a["pose"] - sols["pivoted"].a["pose"]).max() < 1e-6
-    def explicit_cost(wc):
-        # cost of the explicit problem at the composite solution, the receiver clocks (which the composite topology eliminated) at their
-        # optimum for these states: every other block held constant, a few iterations on the clocks alone (the problem is linear in them)
-        from rtk_visual_inertial_navigation_amd.flat import FlatWindow
-        w0_ = plug_into_explicit(wx, wc, wx)
-        a_ = {k: v.copy() for k, v in w0_.a.items()}
-        ic = np.ones_like(a_["is_const"])
-        first_sc = w0_.bid_sc(0)
-        for b_id, g_id in zip(a_["order_block"], a_["order_group"]):          # the receiver clocks: the scalar blocks of elimination group 0 (bar the dummy anchor)
-            if g_id == 0 and b_id > first_sc:
-                ic[b_id] = 0
-        a_["is_const"] = ic
-        keep = ic[a_["order_block"]] == 0
-        a_["order_block"], a_["order_group"] = a_["order_block"][keep], a_["order_group"][keep]
-        w_ = FlatWindow(n_tail=0, proj_sqrt_info=w0_.proj_sqrt_info, proj_loss_a=w0_.proj_loss_a, pbg=w0_.pbg, gw=w0_.gw, base=w0_.base, meta=dict(w0_.meta), **a_)
-        b_ = solver.BatchSolver([w_]); c_ = b_.solve(default_options(max_num_iterations=4), download=False)[0].final_cost; b_.close()
-        return c_
+    explicit_cost = lambda wc: rt.explicit_cost(solver, wx, wc)
     ce_d, ce_o = explicit_cost(sols["pivoted"]), explicit_cost(wo)
     assert abs(ce_d - ce_o) <= 1e-6 * ce_o + 1e-6, (ce_d, ce_o)
     # minimiser of the explicit problem, on the device
