@@ -1,4 +1,4 @@
-"""A fixed-seed slice of the randomised sweeps (tests/perf/fuzz_parity.py, fuzz_marginalize.py) inside the GPU tier: random window
+"""A fixed-seed slice of the randomised sweeps (tests/perf/fuzz_parity.py, fuzz_marginalize.py, fuzz_composite.py) inside the GPU tier: random window
 shapes, factor families, strategies and parameter_head choices against the oracle, every window alone == inside one batch bit for
 bit.  The full sweeps (hundreds of cases, other seeds) stay a tool; this slice is what caught the block-Jacobi schedule bug of
 round 3 only by accident of the seed, so it now runs every time."""
@@ -48,3 +48,12 @@ def test_fuzz_parity_slice_large_windows():
 def test_fuzz_marginalize_slice():
     out = _run("fuzz_marginalize.py", 60, 11)                          # includes tails of 144..155 dimensions next to smaller ones (k_marg_bj)
     assert "60 cases, 0 failures" in out
+
+
+@pytest.mark.gpu
+def test_fuzz_composite_slice():
+    """The reference's own topology (composite IMU-GNSS factors): seed 4 of the sweep, which holds the two four-satellite windows
+    whose device and oracle end states lie a centimetre apart along the weakly determined global position — compared there through the
+    explicit problem's cost (no composite factor, no square root in it)."""
+    out = _run("fuzz_composite.py", 36, 4)
+    assert "36 cases, 0 failures" in out and out.count("explicit-problem cost at the end states") >= 2
