@@ -238,6 +238,7 @@ struct swf_batch {
     int marg_first_check = 6;
     bool post_fuse = false;               // SWF_POST_FUSE=1: the one-grid forms of k_post_chol / k_post_dogleg at every batch size (A/B timing)
     bool post_split = false;              // SWF_POST_SPLIT=1: the landmark segment of k_post_chol apart from the others whatever the batch size (A/B timing)
+    bool no_comp_fuse = false;            // SWF_NO_COMP_FUSE=1: the composite chain and the visual branch as launches of their own on the latency path too (A/B, parity)
     bool lat_fuse = false;                // latency path: fused grids on one stream (see swf_batch_create)
     bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
     bool chol_rr2 = false;                // SWF_CHOL_RR2=1: the previous register-resident kernel (A/B testing)
@@ -865,6 +866,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     // (every A/B knob is read once, here: no getenv on the latency path or inside the marginalisation's sweep loop, and none that could
     // race a setenv from the per-device enqueue threads of swf_solve_batches)
     b->no_lm_clique = getenv("SWF_NO_LM_CLIQUE") != nullptr;
+    b->no_comp_fuse = getenv("SWF_NO_COMP_FUSE") != nullptr;
     b->marg_one_wg = getenv("SWF_MARG_ONE_WG") != nullptr;
     b->marg_no_pchol = getenv("SWF_MARG_NO_PCHOL") != nullptr;
     b->marg_trace = getenv("SWF_MARG_TRACE") != nullptr;
@@ -1481,15 +1483,48 @@ struct Launcher {
     // One linearisation.  Dependencies: the cliques need the IMU and the scalar-factor Jacobians (k_eval_imu, k_eval_ps);
     // k_lm_schur needs k_eval_ps; k_frame_sums needs k_lm_schur (Y g_l); k_assemble_all needs everything.  With an auxiliary
     // stream (small batches) the IMU / clique branch runs next to the projection / landmark branch.
-    void lin_eval() {
+    // the reference-topology latency path (swf_kernels4.h, k_lm_comp): the composite chain and the visual branch in shared grids
+    bool comp_fused = false;
+    bool comp_fuse_ok(int write_S) const {
+        const DevBatch& D = b->D;
+        if (!b->n_comp || !write_S || b->no_comp_fuse || !b->lat_fuse || b->aux || !b->fs_fused || b->comp_eigen_root) return false;
+        if (b->comp_nmax > CO_SMALLN || b->ls_var > 1 || !D.n_lm || D.n_imu || D.n_idp || b->max_prior_dim > PRIOR_LDS_DIM) return false;
+        if (D.n_clc[0] || D.n_clc[1]) return false;                                     // (the cliques of such a window: classes 2, 4 and — from 19 ambiguities on — 3)
+        const int crow = (b->n_comp + D.n_win - 1) / D.n_win;
+        return (long long)D.n_win * (GEMM_SPLIT / b->ls_qpb + crow) <= b->n_cu;         // every workgroup of k_lm_comp resident at once
+    }
+    void lin_eval(int write_S) {
         DevBatch& D = b->D;
+        comp_fused = comp_fuse_ok(write_S);
+        if (comp_fused) {
+            hipLaunchKernelGGL(k_comp_gather_prep, dim3(b->n_comp), dim3(256), 0, st, D, b->CA, b->CM);
+            Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256);
+            {   // projection + scalar factors next to the chains' IMU factors
+                Bracket t(*this, SWF_K_EVAL_PS);
+                hipLaunchKernelGGL(k_eval_ps_comp_imu, dim3(S.e[1] + (b->CA.n_iq + 7) / 8), dim3(256), 0, st, D, S, b->CA);
+            }
+            {   // the landmark Schur product (first tile range) next to the re-elimination of the hidden epochs
+                Bracket t(*this, SWF_K_LM_SCHUR);
+                lm_qpb = b->ls_qpb; lm_folded = b->ls_folded;
+                const int np = GEMM_SPLIT / b->ls_qpb, crow = (b->n_comp + D.n_win - 1) / D.n_win;
+                const int qpb = b->ls_qpb, sd = b->s_direct ? 1 : 0, kms = b->ls_kms;
+                dim3 grid(D.n_win, np + crow);
+                if (b->ls_var == 0) hipLaunchKernelGGL((k_lm_comp<8, 2, 2, 80>), grid, dim3(LS_NT(8, 2)), 0, st, D, O, b->CA, b->CM, qpb, 0, kms, sd, np);
+                else hipLaunchKernelGGL((k_lm_comp<8, 5, 2, 144>), grid, dim3(LS_NT(8, 2)), 0, st, D, O, b->CA, b->CM, qpb, 0, kms, sd, np);
+                lm_next = ls_tiles_per_launch();
+            }
+            if (D.n_prior) {   // the prior records (the composite factors' among them, just rewritten): the prior segment of k_eval_ps alone
+                Segs P{}; P.e[2] = D.n_prior;
+                hipLaunchKernelGGL((k_eval_ps<true, true>), dim3(P.e[2]), dim3(256), 0, st, D, P);
+            }
+            return;
+        }
         if (b->n_comp) {
             // composite IMU-GNSS factors of the windows that re-linearise: hidden epochs move, re-elimination, prior records rewritten
             // 1024 threads per factor while the chip holds every factor at once (two such workgroups per CU), 256 for larger batches
             const bool wide = b->n_comp <= 2 * b->n_cu;
             {
-            hipLaunchKernelGGL(k_comp_gather, dim3(b->n_comp), dim3(128), 0, st, D, b->CA, b->CM);
-            hipLaunchKernelGGL(k_comp_prep, dim3(b->n_comp), dim3(256), 0, st, b->CA);
+            hipLaunchKernelGGL(k_comp_gather_prep, dim3(b->n_comp), dim3(256), 0, st, D, b->CA, b->CM);
             hipLaunchKernelGGL(k_comp_imu, dim3((b->CA.n_iq + 7) / 8), dim3(256), 0, st, b->CA);
             // (an instantiation per class of factor, each passing over the other's: a factor's arithmetic does not depend on its batch)
             if (b->comp_nmin <= CO_SMALLN) {
@@ -1529,7 +1564,12 @@ struct Launcher {
     void lin_elim(int write_S) {
         DevBatch& D = b->D;
         bool clq_fused = false;
-        if (D.n_lm) {
+        if (comp_fused) {
+            // (k_lm_comp of lin_eval took the first tile range of the landmark product)
+            Bracket t(*this, SWF_K_CLIQUE_ELIM);
+            if (D.n_clc[4] + D.n_clc[2]) hipLaunchKernelGGL(k_clique_tall2, dim3(D.n_clc[4] + D.n_clc[2]), dim3(256), 0, st, D, O);
+            if (D.n_clc[3]) hipLaunchKernelGGL(k_clique_big, dim3(D.n_clc[3]), dim3(CB_NT), 0, st, D, O);
+        } else if (D.n_lm) {
             Bracket t(*this, write_S ? SWF_K_LM_SCHUR : SWF_K_LM_ELIM);
             lm_qpb = b->ls_qpb; lm_folded = b->ls_folded;
             if (!write_S) {
@@ -1551,6 +1591,9 @@ struct Launcher {
             if (b->aux) (void)hipStreamWaitEvent(b->aux, b->ev_fork[1], 0);          // scalar-factor Jacobians (k_eval_ps)
             // latency path: a class without IMU factors needs only k_eval_ps and runs on the main stream, next to the IMU branch
             auto cstream = [&](int cls) { return (b->aux && !b->clc_imu[cls]) ? st : sa; };
+            if (comp_fused) {
+                for (; lm_next < b->max_tiles; lm_next += ls_tiles_per_launch()) { Bracket t(*this, SWF_K_LM_SCHUR, sa); lm_launch(lm_next, sa); }
+            } else {
             if (D.n_clc[1]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(1)); hipLaunchKernelGGL((k_clique_elim<32, 48, 9, 1>), dim3(D.n_clc[1]), dim3(64), 0, cstream(1), D, O); }
             if (D.n_clc[0]) { Bracket t(*this, SWF_K_CLIQUE_ELIM, cstream(0)); hipLaunchKernelGGL((k_clique_elim<48, 32, 1, 0>), dim3(D.n_clc[0]), dim3(64), 0, cstream(0), D, O); }
             if (D.n_clc[2] && !clq_fused) {
@@ -1564,6 +1607,7 @@ struct Launcher {
                 // further tile ranges write nothing but their tiles of P (k_lm_schur: outs), so on the latency path they run behind the
                 // IMU / clique branch, next to the first range
                 for (; lm_next < b->max_tiles; lm_next += ls_tiles_per_launch()) { Bracket t(*this, SWF_K_LM_SCHUR, sa); lm_launch(lm_next, sa); }
+            }
             }
             if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);
         }
@@ -1668,7 +1712,7 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
     {
         Launcher::Bracket total(L, SWF_K_TOTAL);
         hipLaunchKernelGGL(k_init, dim3(D.n_win), dim3(256), 0, st, D, L.O);
-        auto LIN = [&](int write_S) { L.lin_eval(); L.lin_elim(write_S); nlin++; };
+        auto LIN = [&](int write_S) { L.lin_eval(write_S); L.lin_elim(write_S); nlin++; };
         LIN(1);
         if (opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) {
             L.reduced();

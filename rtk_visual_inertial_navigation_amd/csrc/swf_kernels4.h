@@ -630,3 +630,47 @@ __global__ void __launch_bounds__(256) k_comp_scatter(DevBatch B, CompArgs A, Co
 // phases lose the chip-wide parallelism they have as grids of their own, and dependent launches on one stream follow each other without
 // a gap.  Not kept.  Also measured and not kept: the J^T J / J^T r products of all links formed up front, off the
 // elimination chain (k_comp_elim 76.6 -> 80.1 us).)
+
+// =========================================================================================
+// Latency path of a window in the reference's topology (few windows, every workgroup resident at once): launches that do not depend on
+// each other ride in ONE grid, as k_lm_clique does for the landmark product and the cliques.  The composite chain (gather -> hidden-state
+// move -> IMU factors -> re-elimination -> prior records) and the visual branch (projection Jacobians -> landmark Schur product) meet
+// only at the cliques, so
+//   k_eval_ps_comp_imu = { projection + scalar-factor segments of k_eval_ps | k_comp_imu }        (both: 256 threads)
+//   k_lm_comp          = { k_lm_schur's workgroups | k_comp_elim<CO_SMALLN, 1024> + k_comp_scatter }  (both: 1024 threads)
+//   k_clique_tall2     = { k_clique_tall | the four-wave form of the 64 x 64 class }              (both: 256 threads)
+// with the prior segment of k_eval_ps (the composite factors' records among them) as a launch of its own behind k_lm_comp.
+// Same device functions, same operands, same order: bit-identical to the separate launches (tested: a window alone against the
+// same window with SWF_NO_COMP_FUSE=1).  One cfg3-size window: 293 -> 271 us per iteration (the chain gather .. cliques 167 -> 141 us).
+// =========================================================================================
+__global__ void __launch_bounds__(256) k_eval_ps_comp_imu(DevBatch B, Segs S, CompArgs A) {
+    __shared__ double sm[FS_BLK * FS_HALF + 168 / 2 + 1];          // the frame sums' staging tile + its frame offsets (as in k_eval_ps)
+    const int bid = blockIdx.x;
+    if (bid < S.e[0]) d_eval_proj_fs(B, bid, (double (*)[FS_HALF])sm, (int*)(sm + FS_BLK * FS_HALF));
+    else if (bid < S.e[1]) d_eval_scalar<true>(B, bid - S.e[0]);
+    else d_comp_imu(A, (bid - S.e[1]) * 8, A.n_iq);
+}
+template <int NCW, int TPW, int TW, int LDR>
+__global__ void __launch_bounds__(LS_NT(NCW, TW)) k_lm_comp(DevBatch B, DevOpt O, CompArgs A, CompMeta Mt, int qpb, int lp, int kms, int s_direct, int n_parts) {
+    static_assert(LS_NT(NCW, TW) == 1024, "k_lm_comp: d_comp_elim<., 1024> synchronises 1024 threads");
+    if ((int)blockIdx.y < n_parts) d_lm_schur<NCW, TPW, TW, LDR, true>(B, O, qpb, lp, kms, s_direct, (int)blockIdx.x, (int)blockIdx.y);
+    else {
+        // the factor's workgroup rewrites its prior record itself (k_comp_scatter's work: what it reads, this workgroup has just written)
+        const int f = ((int)blockIdx.y - n_parts) * (int)gridDim.x + (int)blockIdx.x;
+        d_comp_elim<CO_SMALLN, 1024>(A, f);
+        __syncthreads();
+        d_comp_scatter<1024>(B, A, Mt, f);
+        // (measured and not kept: the factor's prior evaluation — d_eval_prior — behind the scatter in this workgroup instead of the prior
+        // segment of k_eval_ps as a launch of its own: the workgroup runs 11.5 us longer, the launch it saves took 11.3)
+    }
+}
+// the outer blocks collected by the workgroup that moves the factor's hidden epochs (k_comp_gather + k_comp_prep of the solver path: one launch)
+__global__ void __launch_bounds__(256) k_comp_gather_prep(DevBatch B, CompArgs A, CompMeta Mt) {
+    d_comp_gather(B, A, Mt, (int)blockIdx.x);
+    __syncthreads();
+    (void)d_comp_prep(A, (int)blockIdx.x);
+}
+__global__ void __launch_bounds__(256) k_clique_tall2(DevBatch B, DevOpt O) {
+    if ((int)blockIdx.x < B.n_clc[4]) d_clique_elim<CLQ_TALLR, 64, 9, 4, 8, 4>(B, O, (int)blockIdx.x);
+    else d_clique_elim<64, 64, 9, 2, 8, 4>(B, O, (int)blockIdx.x - B.n_clc[4]);
+}

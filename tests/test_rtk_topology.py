@@ -250,3 +250,24 @@ def test_composite_topology_at_cfg3_size_against_the_oracle(S, n_red):
     assert [r["cost"] for r in sms[0].rows()] == single[1]
     for k in ("pose", "sb", "lm", "sc", "comp_pose", "comp_sb"):
         assert np.array_equal(single[0].a[k], batch[0].a[k]), k
+
+
+@pytest.mark.gpu
+def test_composite_latency_path_shared_grids_equal_separate_launches_bitwise(monkeypatch):
+    """The latency path of a reference-topology window runs the composite chain and the visual branch in shared grids (k_eval_ps_comp_imu,
+    k_lm_comp, k_clique_tall2: swf_kernels4.h); SWF_NO_COMP_FUSE=1 at creation keeps every kernel a launch of its own.  Same device
+    functions, same operands: iteration rows and end states bit for bit, and the kernel-time rows show which path ran."""
+    wxs = rt.explicit_windows(2, seed0=910, pool=False, K_vis=12, M=3, F=120, S=9)
+    wins = rt.composite_batch(solver, wxs)
+    res = {}
+    for mode in ("fused", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("SWF_NO_COMP_FUSE", "1")
+        ws = [w.copy() for w in wins]
+        bs = solver.BatchSolver(ws); sms = bs.solve(default_options(max_num_iterations=8)); bs.close()
+        monkeypatch.delenv("SWF_NO_COMP_FUSE", raising=False)
+        res[mode] = (ws, [[(r["cost"], r["step_norm"], r["trust_region_radius"]) for r in s.rows()] for s in sms])
+    assert res["fused"][1] == res["separate"][1]
+    for a, b_ in zip(res["fused"][0], res["separate"][0]):
+        for k in ("pose", "sb", "lm", "sc", "comp_pose", "comp_sb"):
+            assert np.array_equal(a.a[k], b_.a[k]), k
