@@ -305,6 +305,9 @@ __device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f) {
             // ONE wavefront, four entries per lane, no barrier inside: a step's reads (the entry, its row's entry in the pivot column, its
             // column's entry in the pivot row, the pivot) are all issued before its writes, and the LDS executes a wave's operations in
             // order (two workgroup barriers per column cost 11.9 k cycles per epoch at 1024 threads, 9 k at 256; this form 8 k)
+            // (Measured and not kept, end of round 5: the symmetric sweep form of the same elimination on the 120 entries of the upper triangle,
+            // two per lane — half the instructions per step: 10.9 k cycles per epoch against 9.7 k.  A step is a latency chain — the pivot's LDS
+            // round trip, its Newton reciprocal, the update, the write the next pivot is read behind — not an instruction count.)
             int ea[4], eb[4];
 #pragma unroll
             for (int m = 0; m < 4; m++) { const int e = t + 64 * m; ea[m] = e < 225 ? e / 15 : 0; eb[m] = e < 225 ? e - (e / 15) * 15 : 0; }
