@@ -1567,8 +1567,11 @@ struct Launcher {
         if (comp_fused) {
             // (k_lm_comp of lin_eval took the first tile range of the landmark product)
             Bracket t(*this, SWF_K_CLIQUE_ELIM);
-            if (D.n_clc[4] + D.n_clc[2]) hipLaunchKernelGGL(k_clique_tall2, dim3(D.n_clc[4] + D.n_clc[2]), dim3(256), 0, st, D, O);
-            if (D.n_clc[3]) hipLaunchKernelGGL(k_clique_big, dim3(D.n_clc[3]), dim3(CB_NT), 0, st, D, O);
+            if (D.n_clc[3]) {
+                // class 3 next to class 2 in one grid; class 4 (other factors of the batch with fewer ambiguities) on its own
+                hipLaunchKernelGGL(k_clique_big2, dim3(D.n_clc[3] + D.n_clc[2]), dim3(CB_NT), 0, st, D, O);
+                if (D.n_clc[4]) hipLaunchKernelGGL(k_clique_tall, dim3(D.n_clc[4]), dim3(256), 0, st, D, O);
+            } else if (D.n_clc[4] + D.n_clc[2]) hipLaunchKernelGGL(k_clique_tall2, dim3(D.n_clc[4] + D.n_clc[2]), dim3(256), 0, st, D, O);
         } else if (D.n_lm) {
             Bracket t(*this, write_S ? SWF_K_LM_SCHUR : SWF_K_LM_ELIM);
             lm_qpb = b->ls_qpb; lm_folded = b->ls_folded;

@@ -1284,6 +1284,28 @@ __global__ void __launch_bounds__(CB_NT) k_clique_big(DevBatch B, DevOpt O) {
     if ((long long)(C.n_rows | 1) * (C.d_e + C.d_f) <= CB_LDS_J) d_clique_big<true>(B, O, Me, Tt, Ei, Eg, ge, &bad_sv, Jl);
     else d_clique_big<false>(B, O, Me, Tt, Ei, Eg, ge, &bad_sv, Jl);
 }
+// Latency path of a reference-topology window with 19 or more ambiguities: its speed-bias cliques are class 3 (above), the others class 2 —
+// two dependent launches of independent work.  ONE grid: workgroups [0, n_clc[3]) as above, the ones behind them take a class-2 clique on their
+// first four waves (the form and the early exit of k_lm_clique).  The LDS of both functions must fit one workgroup: the staging buffer is
+// 10 KB shorter here (a Jacobian of 11 008 .. 12 288 doubles is read through L2 instead: the same sums in the same order).
+#define CB_LDS_J2 11008
+__global__ void __launch_bounds__(CB_NT) k_clique_big2(DevBatch B, DevOpt O) {
+    if ((int)blockIdx.x >= B.n_clc[3]) {
+        static_assert(CB_NT >= 256, "k_clique_big2: the clique rows keep the four waves d_clique_elim<..., NW = 4> synchronises");
+        if (threadIdx.x >= 256) return;          // (terminated waves are not waited for by s_barrier: see k_lm_clique)
+        d_clique_elim<64, 64, 9, 2, 8, 4, 4>(B, O, (int)blockIdx.x - B.n_clc[3]);
+        return;
+    }
+    __shared__ double Me[CB_MAXED];
+    __shared__ double Tt[CB_MAXED];
+    __shared__ double Ei[9][9];
+    __shared__ double Eg[9], ge[9];
+    __shared__ int bad_sv;
+    __shared__ double Jl[CB_LDS_J2];
+    const Clique& C = B.clc_rec[3][blockIdx.x];
+    if ((long long)(C.n_rows | 1) * (C.d_e + C.d_f) <= CB_LDS_J2) d_clique_big<true>(B, O, Me, Tt, Ei, Eg, ge, &bad_sv, Jl);
+    else d_clique_big<false>(B, O, Me, Tt, Ei, Eg, ge, &bad_sv, Jl);
+}
 
 // =========================================================================================
 // Per-frame raw sums over the projection observations, level 1 of a two-level FIXED-ORDER

@@ -253,11 +253,13 @@ def test_composite_topology_at_cfg3_size_against_the_oracle(S, n_red):
 
 
 @pytest.mark.gpu
-def test_composite_latency_path_shared_grids_equal_separate_launches_bitwise(monkeypatch):
+@pytest.mark.parametrize("S", [9, 21])
+def test_composite_latency_path_shared_grids_equal_separate_launches_bitwise(S, monkeypatch):
     """The latency path of a reference-topology window runs the composite chain and the visual branch in shared grids (k_eval_ps_comp_imu,
     k_lm_comp, k_clique_tall2: swf_kernels4.h); SWF_NO_COMP_FUSE=1 at creation keeps every kernel a launch of its own.  Same device
-    functions, same operands: iteration rows and end states bit for bit, and the kernel-time rows show which path ran."""
-    wxs = rt.explicit_windows(2, seed0=910, pool=False, K_vis=12, M=3, F=120, S=9)
+    functions, same operands: iteration rows and end states bit for bit.  S = 21 ambiguities: the speed-bias cliques are class 3, and
+    k_clique_big2 runs them next to the class-2 cliques (its Jacobian staging buffer is shorter than k_clique_big's)."""
+    wxs = rt.explicit_windows(2, seed0=910, pool=False, K_vis=12, M=3, F=120, S=S)
     wins = rt.composite_batch(solver, wxs)
     res = {}
     for mode in ("fused", "separate"):
