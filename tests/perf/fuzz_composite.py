@@ -36,7 +36,10 @@ for t, (kw, w, ro_) in enumerate(zip(shapes, wins, ords)):
         bs.close()
         e_lin = (rel(g, eo["grad"]), rel(Sg, eo["S"]), rel(rg, eo["rhs"]))
         if n_red != eo["n_red"]: msg.append("n_red %d vs %d" % (n_red, eo["n_red"]))
-        elif e_lin[0] > 1e-10 or e_lin[1] > 1e-10 or e_lin[2] > 1e-9: msg.append("linearisation grad %.1e S %.1e rhs %.1e" % e_lin)
+        # (S to 1e-10 — seen: 4e-14; the gradient and the reduced right-hand side to 1e-9: a noise direction k the oracle's eigen square root keeps
+        # and the pivoted root drops, see below, puts v_k (v_k^T rhs) into J^T r — seen: 1.2e-10 / 3e-10 of the vector in one window of 600, with
+        # 34 ambiguities and a first-cost offset of 3.8e-7; 1e-12 typically)
+        elif e_lin[0] > 1e-9 or e_lin[1] > 1e-10 or e_lin[2] > 1e-9: msg.append("linearisation grad %.1e S %.1e rhs %.1e" % e_lin)
         if rel(Lg @ Lg.T, Sg) > 1e-12: msg.append("LLt %.1e" % rel(Lg @ Lg.T, Sg))
         dp = {}
         for iters in (8, 40):
@@ -61,7 +64,9 @@ for t, (kw, w, ro_) in enumerate(zip(shapes, wins, ords)):
                 if sd.termination not in (1, 2, 3) and sd.termination != so.termination: msg.append("device termination %d (oracle %d)" % (sd.termination, so.termination))
                 # (both stop on function_tolerance 1e-6 or on the budget, along a linearly convergent tail: end costs are defined to a few 1e-6;
                 # where they differ by more, the device is BELOW the oracle — by percents at end costs of tens, the noise terms again)
-                if sd.final_cost > so.final_cost * (1 + 1e-5) + 1e-9: msg.append("final cost %.12e above the oracle's %.12e" % (sd.final_cost, so.final_cost))
+                # (both out of budget: they stand at different points of that tail — the yardstick is the tail's own step, ten times the oracle's last cost change)
+                tail = 10.0 * abs(ro[-1]["cost_change"]) if so.termination == 4 and sd.termination == 4 else 0.0
+                if sd.final_cost > so.final_cost * (1 + 1e-5) + 1e-9 + tail: msg.append("final cost %.12e above the oracle's %.12e" % (sd.final_cost, so.final_cost))
             if iters == 40: fin = "end: termination %d / %d after %d / %d iterations, cost rel %+.1e" % (sd.termination, so.termination, sd.num_iterations, so.num_iterations, (sd.final_cost - so.final_cost) / so.final_cost)
             dp[iters] = max(np.abs(wd.a["pose"] - wo.a["pose"]).max(), np.abs(wd.a["comp_pose"] - wo.a["comp_pose"]).max())
         if dp[40] > 1e-4:
