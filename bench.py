@@ -255,6 +255,13 @@ def rtk_topology_leg(iters, wxs, cpu=True):
         bs.close()
         return float(np.median(lat)), sms, n_red
     dt1, sm1, n_red = timed([wins[0].copy()], 20, 3)
+    # the same window with the reference's own square root of the composite remainders (swf_options::composite_root = SWF_ROOT_EIGEN,
+    # UpdateSchurComponent R/factor/gnss_imu_factor.cpp:454-488): the separate-launch form of the chain + k_comp_eigroot
+    opt_piv = opt
+    opt = default_options(max_num_iterations=iters, composite_root=1)
+    dt1e, sm1e, _ = timed([wins[0].copy()], 20, 3)
+    dtbe, smbe, _ = timed([w.copy() for w in wins], 6)
+    opt = opt_piv
     dtb, smb, _ = timed([w.copy() for w in wins], 10)
     rep = max(1, 512 // n_windows)
     dtr, smr, _ = timed([w.copy() for _ in range(rep) for w in wins], 6)
@@ -263,6 +270,9 @@ def rtk_topology_leg(iters, wxs, cpu=True):
     out = dict(workload="%d visual frames x %d hidden GNSS epochs per gap, %d landmarks, %d observations, %d ambiguities, %d composite factors per window; n_red %d"
                         % (wins[0].meta["K"], wins[0].meta["M"], wins[0].n_lm, wins[0].a["proj_idx"].size // 3, wins[0].meta["N"], wins[0].a["comp_M"].size, n_red),
                single_window=dict(us_per_iteration=1e6 * dt1 / max(1, its1), solve_ms=1e3 * dt1, iterations=int(its1)),
+               eigen_root=dict(single_window_us_per_iteration=1e6 * dt1e / max(1, sm1e[0].num_iterations), single_window_iterations=int(sm1e[0].num_iterations),
+                               batch_windows=n_windows, batch_solve_ms=1e3 * dtbe, batch_iterations_per_s=sum(s.num_iterations for s in smbe) / dtbe,
+                               note="swf_options::composite_root = SWF_ROOT_EIGEN (the reference's SelfAdjointEigenSolver root, cut 1e-8); the rows above and below use the default pivoted root"),
                batch=dict(windows=n_windows, solve_ms=1e3 * dtb, iterations_per_s=itsb / dtb, us_per_window_iteration=1e6 * dtb / itsb,
                           failed_windows=int(sum(s.termination not in (1, 2, 3, 4) for s in smb))),
                batch_replicated=dict(windows=rep * n_windows, solve_ms=1e3 * dtr, iterations_per_s=itsr / dtr, us_per_window_iteration=1e6 * dtr / itsr,
@@ -283,7 +293,7 @@ def rtk_topology_leg(iters, wxs, cpu=True):
         ts, itc = [], 0
         for w in wins[:4]:
             wo = w.copy(); t0 = time.perf_counter(); so, _ = ob.solve(wo, opt, export=False); ts.append(time.perf_counter() - t0); itc += so.num_iterations
-        out["cpu_oracle"] = dict(us_per_iteration=1e6 * sum(ts) / max(1, itc), solve_ms=1e3 * float(np.mean(ts)), threads=int(os.environ.get("OMP_NUM_THREADS", "0")) or None,
+        out["cpu_oracle"] = dict(us_per_iteration=1e6 * sum(ts) / max(1, itc), solve_ms=1e3 * float(np.mean(ts)), threads=int(opt.num_threads),
                                  sample="the first 4 of the same windows, %d iterations each, plain-C port" % iters)
         out["single_window"]["speedup_vs_cpu_oracle"] = out["cpu_oracle"]["us_per_iteration"] / out["single_window"]["us_per_iteration"]
     return out
@@ -428,7 +438,7 @@ def main():
     fulls = None
     if world == 1 and a.stress_windows > 0 and not a.no_single_window and not os.environ.get("SWF_BENCH_SHARE_GPU"):
         fulls = stress_fulls(a.stress_windows)
-    topo_wxs = None
+    topo_wxs, topo_err = None, None
     if world == 1 and not a.no_rtk_topology and not a.no_single_window and not os.environ.get("SWF_BENCH_SHARE_GPU"):
         try:                                            # an extra: never take the headline line down with it
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -436,8 +446,8 @@ def main():
             t0_ = time.perf_counter()
             topo_wxs = rt_gen.explicit_windows(a.topology_windows, K_vis=20, M=4, F=300, S=10)      # (process pool: before HIP is touched)
             t_topo_gen = time.perf_counter() - t0_
-        except Exception:
-            topo_wxs = None
+        except Exception as e:
+            topo_wxs, topo_err = None, repr(e)
 
     import torch
     import torch.distributed as dist
@@ -556,7 +566,8 @@ def main():
                                         projected_efficiency=(dt / a.steps) / (g_ * float(np.median(ts_))))
         # the natural deployment of independent windows is WEAK scaling (every GPU its own 512 windows; --scaling weak): no data-path collective,
         # one host thread per device, so the per-GPU step is this run's own and the job's rate is N times it
-        proj["weak_scaling"] = dict(windows_per_gpu=B, ms_per_solve=1e3 * dt / a.steps, projected_efficiency=1.0,
+        proj["weak_scaling"] = dict(windows_per_gpu=B, ms_per_solve=1e3 * dt / a.steps, projected_efficiency=None,
+                                    assumption="independent windows, no data-path collective: per-GPU step time = this run's own; NOT measured (no multi-GPU node in the builder's reach)",
                                     note="python bench.py --gpus N --scaling weak: B windows per GPU, no collective in the data path (harness all-reduce of the wall time only)")
 
     if rank == 0:
@@ -716,6 +727,8 @@ def main():
                 out["stress"] = stress_leg(fulls, a.stress_windows, a.iters)
             except Exception as e:                      # an extra: never take the headline line down with it
                 out["stress"] = dict(error=repr(e))
+        if topo_err is not None:
+            out["rtk_topology"] = dict(error="window generation failed: " + topo_err)
         if topo_wxs is not None:
             try:
                 out["rtk_topology"] = rtk_topology_leg(a.iters, topo_wxs, cpu=not a.no_cpu_baseline)

@@ -423,6 +423,7 @@ struct Solver {
                                              // Levenberg-Marquardt, where it is supported); every Options block that selects DOGLEG sets it to 0 (R/swf/swf.cpp:26-27)
         double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16;
         std::shared_ptr<ParameterBlockOrdering> linear_solver_ordering;      // null: automatic ordering (swf_set_ordering, n = 0)
+        int swf_composite_root = SWF_ROOT_PIVOTED_CHOLESKY;                  // extension (not in ceres): swf_options::composite_root; SWF_ROOT_EIGEN = UpdateSchurComponent's own root
     };
     struct Summary {
         double initial_cost = 0, final_cost = 0, minimizer_time_in_seconds = 0;
@@ -451,6 +452,7 @@ inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* s) {
     std::memset(&s->raw, 0, sizeof(s->raw));
     s->message.clear();
     int rc = SWF_OK;
+    opt.composite_root = o.swf_composite_root;
     opt.jacobi_scaling = o.jacobi_scaling ? 1 : 0;       // (with DOGLEG the engine refuses it: SWF_E_UNSUPPORTED, reported below like any failure)
     if (rc == SWF_OK) rc = p->SyncIsUse();
     if (rc == SWF_OK) {

@@ -43,6 +43,11 @@ enum {
  * block (the whole factor only after step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY); swf_prior_reset_linearization_point added.
  * 105 (round 5): no layout change; a composite IMU-GNSS factor may touch one block of elimination group 0 (MyOrdering's own order), which
  * 104 refused with SWF_E_UNSUPPORTED; SWF_PRIOR_EIGEN keeps every direction of information above eps on healthy windows.
+ * 106 (round 6): swf_options::reserved became swf_options::composite_root (same offset and size; 0 = the previous behaviour); the
+ * environment variable SWF_COMP_EIGEN_ROOT is gone, as are the A/B kernels behind SWF_CHOL_RR2 / RR3 / V1, SWF_ASM_OLD, SWF_POST_*.
+ * Structural limits of a group-0 clique (a non-landmark block of elimination group 0 with the factors touching it): at most 9 eliminated
+ * dimensions d_e, at most 768 columns d = d_e + d_f, and — for cliques beyond one wavefront's 64 x 64 / 96 x 64, which take the
+ * workgroup kernel — d_e * d <= 1536 (d <= 170 at d_e = 9, 256 at d_e = 6, 512 at d_e = 3): SWF_E_UNSUPPORTED beyond.
  * swf_abi_sizes reports sizeof(swf_options), sizeof(swf_summary), sizeof(swf_timing), sizeof(swf_flat_window), sizeof(swf_iteration) so a binding can check its own. */
 int swf_version(void);
 int swf_abi_sizes(int32_t out[5]);
@@ -286,9 +291,11 @@ int swf_composite_set_mid_links(swf_composite* c, const int32_t* mid, const doub
 /* Which square root of the remaining system the factor exposes.  SWF_ROOT_PIVOTED_CHOLESKY (default): rows v_r of a diagonally pivoted
  * outer-product Cholesky.  SWF_ROOT_EIGEN: the reference's own (UpdateSchurComponent :454-488): J = sqrt(lam+) V^T, r = lam+^-1/2 V^T rhs,
  * eigenvalues <= 1e-8 dropped, rows in ascending eigenvalue order — the reference's residual vector up to the sign of each eigenvector.
- * Both give the same J^T J, J^T r and |r|^2.  Inside a solve (swf_flat_window::comp_*) the environment variable SWF_COMP_EIGEN_ROOT=1
- * selects the eigen form for every composite factor of batches created while it is set. */
-enum { SWF_ROOT_PIVOTED_CHOLESKY = 0, SWF_ROOT_EIGEN = 1 };
+ * Both give the same J^T J and J^T r (to rounding; the pivoted root stops at pivots the eigen root's absolute 1e-8 cut may keep, and
+ * the directions kept by one and dropped by the other are rounding noise of a matrix with entries ~1e8: their r_k = v_k^T rhs / sqrt(lam_k)
+ * are O(1), so |r|^2 — the factor's contribution to the COST — differs by a constant of that size, the gradient and the step do not).
+ * Inside a solve (swf_flat_window::comp_*) swf_options::composite_root selects the form for every composite factor of the solve
+ * (enum in swf_types.h). */
 int swf_composite_set_root(swf_composite* c, int32_t form);
 int swf_composite_destroy(swf_composite* c);
 

@@ -193,7 +193,11 @@ typedef struct swf_options {
                                             default, in force for the default-options solves (R/swf/swf_gnss.cpp:205-214, 562-572): columns
                                             scaled by 1 / (1 + sqrt(diag(J^T J))) of the FIRST linearisation; supported with
                                             SWF_LEVENBERG_MARQUARDT (those solves' strategy), refused with SWF_DOGLEG */
-    int32_t reserved;
+    int32_t composite_root;              /* which square root of its (30 + N)^2 remainder a composite IMU-GNSS factor exposes INSIDE a solve:
+                                            SWF_ROOT_PIVOTED_CHOLESKY (0, default: rows of a diagonally pivoted outer-product Cholesky) or
+                                            SWF_ROOT_EIGEN (1: the reference's own, UpdateSchurComponent R/factor/gnss_imu_factor.cpp:454-488:
+                                            SelfAdjointEigenSolver, eigenvalues <= 1e-8 dropped).  Same J^T J and J^T r on the retained
+                                            range; |r|^2 differs by the constant the dropped / kept noise directions carry */
     double initial_trust_region_radius;  /* 1e4 */
     double max_trust_region_radius;      /* 1e16 */
     double min_trust_region_radius;      /* 1e-32 */
@@ -206,6 +210,7 @@ typedef struct swf_options {
 } swf_options;
 
 enum { SWF_OPTIMIZE = 0, SWF_ASSEMBLE_ELIMINATE_ONLY = 1 };
+enum { SWF_ROOT_PIVOTED_CHOLESKY = 0, SWF_ROOT_EIGEN = 1 };
 enum { SWF_DOGLEG = 0, SWF_LEVENBERG_MARQUARDT = 1 };
 
 /* termination codes */
@@ -256,7 +261,7 @@ static inline void swf_options_default(swf_options* o) {
     o->num_threads = 1;
     o->trust_region_strategy = SWF_DOGLEG;
     o->jacobi_scaling = 0;
-    o->reserved = 0;
+    o->composite_root = SWF_ROOT_PIVOTED_CHOLESKY;
     o->initial_trust_region_radius = 1e4;
     o->max_trust_region_radius = 1e16;
     o->min_trust_region_radius = 1e-32;

@@ -1949,6 +1949,22 @@ static void co_update_hidden(oracle_composite* c) {
         for (int k = 0; k < 9; k++) B[k] -= d[6 + k];
     }
 }
+/* TEST SWITCH (default off = the reference, literally).  UpdateSchurComponent cuts eigenvalues at an ABSOLUTE 1e-8 of a matrix whose
+ * entries reach 1e8..1e11: for a remainder that is singular by construction (a single gap pins neither the heading nor the absolute
+ * position) the null eigenvalues come out as rounding noise of size eps * lambda_max ~ 1e-5..1e-3, most of it above 1e-8, and each kept
+ * noise direction adds r_k^2 = (v_k^T rhs)^2 / lambda_k = O(1) to the factor's cost — an implementation-defined number (it depends on the
+ * eigensolver's rounding).  With rel > 0 the cut is max(1e-8, rel * lambda_max): the NOISE-FREE restatement the device's roots are
+ * compared with two-sidedly, while the literal reference is compared with the noise-free one inside the oracle (same decisions, cost
+ * above it by exactly the counted noise terms: g_co_noise_*).  Not thread-safe; tests set it around single solves. */
+static double g_co_eig_cut_rel = 0.0;
+static double g_co_noise_cost = 0.0;      /* sum of r_k^2 / 2 over eigenvalues in (1e-8, 1e-14 lambda_max] that were KEPT, since the last reset */
+static long long g_co_noise_count = 0;    /* how many such eigenvalues */
+void oracle_set_composite_eig_cut(double rel) { g_co_eig_cut_rel = rel; }
+void oracle_composite_noise_stats(double* cost_sum, long long* count, int reset) {
+    if (cost_sum) *cost_sum = g_co_noise_cost;
+    if (count) *count = g_co_noise_count;
+    if (reset) { g_co_noise_cost = 0.0; g_co_noise_count = 0; }
+}
 /* UpdateSchurComponent :454-488: dense (30+N) system in the order [Pose0 | Pose1 (= frame j after the shifts) | N], eigen square root */
 static void co_schur_component(oracle_composite* c) {
     const int map[3] = { CO_POSE0, CO_POSE1, CO_N };
@@ -1966,11 +1982,14 @@ static void co_schur_component(oracle_composite* c) {
     for (int a = 0; a < G; a++) for (int b = 0; b < a; b++) Hd[a * G + b] = Hd[b * G + a];          /* selfadjointView<Upper> */
     double* V = (double*)malloc(sizeof(double) * G * G); double* w = (double*)malloc(sizeof(double) * G);
     sym_eig_jacobi(G, Hd, V, w);
+    double cut = 1e-8;                                                  /* :470 (the reference: absolute) */
+    if (g_co_eig_cut_rel > 0.0 && g_co_eig_cut_rel * w[G - 1] > cut) cut = g_co_eig_cut_rel * w[G - 1];      /* test switch, see above (w ascending) */
     for (int k = 0; k < G; k++) {
-        double lam = w[k] > 1e-8 ? w[k] : 0.0, sq = sqrt(lam), isq = lam > 0 ? 1.0 / sqrt(lam) : 0.0;
+        double lam = w[k] > cut ? w[k] : 0.0, sq = sqrt(lam), isq = lam > 0 ? 1.0 / sqrt(lam) : 0.0;
         double dot = 0;
         for (int a = 0; a < G; a++) { c->J[k * G + a] = sq * V[a * G + k]; dot += V[a * G + k] * rd[a]; }
         c->r[k] = isq * dot;
+        if (lam > 0 && w[k] <= 1e-14 * w[G - 1]) { g_co_noise_cost += 0.5 * c->r[k] * c->r[k]; g_co_noise_count++; }
     }
     free(Hd); free(rd); free(V); free(w);
 }

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libswf_hip.so")
 SOURCES = ["swf_engine.hip", "swf_problem.cpp", "swf_producers.hip", "swf_gnss_epochs.cpp"]
-HEADERS = ["swf_dev.h", "swf_kernels.h", "swf_lmschur.h", "swf_chol_rr.h", "swf_chol_rr4.h", "swf_kernels2.h", "swf_kernels3.h", "swf_kernels4.h",
+HEADERS = ["swf_dev.h", "swf_kernels.h", "swf_lmschur.h", "swf_chol_rr4.h", "swf_kernels2.h", "swf_kernels3.h", "swf_kernels4.h",
            os.path.join("..", "..", "include", "swf_types.h"),
            os.path.join("..", "..", "include", "swf_solver.h")]
 

@@ -26,6 +26,19 @@
 #include <type_traits>
 
 #define R4_NT 768
+// transpose a 16x16 tile held in the accumulator layout through a wave-private [16][17] LDS scratch.  No s_waitcnt between the
+// writes and the reads: the LDS executes one wave's instructions in order, so only the compiler has to keep them in place.
+__device__ __forceinline__ void rr4_transpose(double4_t& a, double* X, int li, int lk) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; q++) X[(lk + 4 * q) * 17 + li] = a[q];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; q++) a[q] = X[li * 17 + lk + 4 * q];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 // NS = tiles per tile wave = the most tile columns the instance takes: 14 (n_red <= 224: no register spills under the 168-register
 // budget of twelve waves), 15 (224 < n_red <= 240) or 16 (240 < n_red <= 256, round 5: a 20-frame window of the reference's topology with 31 .. 46
 // ambiguities; a few accumulator registers spill).  A launch of each covers a batch; every window belongs to exactly one.
@@ -120,7 +133,7 @@ __device__ __forceinline__ void rr4_rho(double* rsdJ, const double* colb, double
 __device__ __forceinline__ int rr4_progress(const unsigned* flagb) {
     return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flagb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
-__device__ __forceinline__ void rr4_gops(double (*GoJ)[64], const double* colb, unsigned* flagb, int lane, int li, int lk, bool prof = false) {
+__device__ __forceinline__ void rr4_gops(double (*GoJ)[64], const double* colb, unsigned* flagb, int* failp, int lane, int li, int lk, bool prof = false) {
 #pragma clang fp contract(off)
     const int pli = (li & 3) * 4 + (li >> 2);             // where row li sits in a published row
     int avail = 0;
@@ -129,6 +142,7 @@ __device__ __forceinline__ void rr4_gops(double (*GoJ)[64], const double* colb, 
     for (int k = 0; k < 4; k++) {
         const int c0 = 4 * k;
         for (int spin = 0; spin < (1 << 22) && avail < c0 + 4; spin++) { avail = rr4_progress(flagb); if (avail < c0 + 4) __builtin_amdgcn_s_sleep(0); }
+        if (avail < c0 + 4 && lane == 0) *failp = 1;      // a stalled pivot wave: the window reports a linear-solver failure (never a silently wrong factor)
         asm volatile("" ::: "memory");
         CST(prof, 16 + k);
         // position of row c0 + u in a published row: 4 ((c0 + u) mod 4) + (c0 + u) / 4 = 4 u + k
@@ -385,9 +399,9 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
         __syncthreads();                                   // A_0
         for (int j = 0; j < Tc; j++) {
 #ifdef SWF_PROFILE_CHOLW
-            rr4_gops(Gop[j], colb, flagb, lane, li, lk, j == g_chol_wstep);
+            rr4_gops(Gop[j], colb, flagb, &fail, lane, li, lk, j == g_chol_wstep);
 #else
-            rr4_gops(Gop[j], colb, flagb, lane, li, lk);
+            rr4_gops(Gop[j], colb, flagb, &fail, lane, li, lk);
 #endif
             WST(j, 1);
             __syncthreads();                               // B_j
@@ -459,7 +473,7 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     for (int J = 0; J < R4_NS; J++)
         if (J < Ia ? ((tzA >> J) & 1u) != 0u : (R4_NS - 1 - J < Ib && ((tzB >> (R4_NS - 1 - J)) & 1u) != 0u)) {
             if (J < Ia) rr4_tile_mask(acc[J], n, rwA, J, li); else rr4_tile_mask(acc[J], n, rwB, R4_NS - 1 - J, li);
-            rr3_transpose(acc[J], Xs, li, lk);
+            rr4_transpose(acc[J], Xs, li, lk);
         }
     CHSTAMP2(18);
     WST(-1, 2);
@@ -560,7 +574,7 @@ __global__ void __launch_bounds__(R4_NT) k_chol_rr4(DevBatch B, int export_full)
     for (int J = 0; J < R4_NS; J++) {
         const bool a = J < Ia, b = R4_NS - 1 - J < Ib;
         if (!(a || b)) continue;
-        rr3_transpose(acc[J], Xs, li, lk);
+        rr4_transpose(acc[J], Xs, li, lk);
         const int I = a ? Ia : Ib, Jc = a ? J : R4_NS - 1 - J;
 #pragma unroll
         for (int q = 0; q < 4; q++) {

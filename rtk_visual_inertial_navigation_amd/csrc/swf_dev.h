@@ -183,8 +183,9 @@ struct DevBatch {
     const AsmWin* asw; int as_max_ne, as_max_nv;
     const int* as_dst; const unsigned* as_cnt; const int* as_src0; const int* as_aux; const int* as_src;
     const int* av_loc; const int* av_red; const unsigned* av_cnt; const int* av_src0; const int* av_i; const int* av_src;
-    const unsigned* s_tnz;                     // per window, 4 words: bit I (I - 1) / 2 + J = some block pair reaches tile (I, J), I > J, of the reduced matrix (k_chol_rr4 loads only those; n_red <= 240)
-    int rr_nmax;                 // reduced systems up to this size take the register-resident Cholesky (256 with k_chol_rr4, 240 with the round 2-4 kernels behind their A/B knobs); the streamed kernels take the rest
+    const unsigned* s_tnz;                     // per window, 4 words: bit I (I - 1) / 2 + J = some block pair reaches tile (I, J), I > J, of the reduced matrix (k_chol_rr4 loads only those; n_red <= 256)
+    int spec;                    // this launch evaluates Jacobians at the CANDIDATE of the windows with a proposed step (swf_kernels.h: eval_gate / eval_src); 0 in the batch the engine keeps
+    int rr_nmax;                 // reduced systems up to this size take the register-resident Cholesky (256: k_chol_rr4); the streamed kernels take the rest
 };
 
 // ------------------------------------------------------------------ device math

@@ -27,7 +27,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 extern "C" const char* swf_last_error(void) { return g_err.c_str(); }
 void swf_internal_set_error(const std::string& m) { g_err = m; }
-extern "C" int swf_version(void) { return 105; }
+extern "C" int swf_version(void) { return 106; }
 extern "C" int swf_abi_sizes(int32_t out[5]) {
     if (!out) return fail(SWF_E_INVALID, "swf_abi_sizes: null");
     out[0] = (int32_t)sizeof(swf_options); out[1] = (int32_t)sizeof(swf_summary); out[2] = (int32_t)sizeof(swf_timing);
@@ -213,7 +213,7 @@ struct swf_batch {
     bool clc_imu[5] = { false, false, false, false, false };
     // composite IMU-GNSS factors of the batch (swf_kernels4.h): operator arguments, solver-side bookkeeping, initial hidden epochs
     CompArgs CA{}; CompMeta CM{}; int n_comp = 0, comp_nmax = 0, comp_nmin = 1 << 30; long long comp_ne = 0;
-    bool comp_eigen_root = false;                      // SWF_COMP_EIGEN_ROOT=1 at create: the composite factors expose the reference's eigen square root
+    bool comp_eigen_root = false;                      // swf_options::composite_root == SWF_ROOT_EIGEN in the current solve: the composite factors expose the reference's eigen square root
     void* h_sum = nullptr; size_t h_sum_bytes = 0;       // page-locked staging of the per-window states and traces (swf_batch_summaries)
     double* h_x = nullptr;                // page-locked staging of the parameter blocks (state upload / download: one DMA instead of a pageable copy)
     double* co_pose0 = nullptr; double* co_sb0 = nullptr;    // clique class holds IMU factors (its elimination must follow k_eval_imu)
@@ -234,21 +234,12 @@ struct swf_batch {
         if (aux) { (void)hipStreamSynchronize(aux); handle_cache().give(aux); }
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
-    bool no_lm_clique = false, marg_one_wg = false, marg_no_pchol = false, marg_trace = false, marg_no_crit = false;      // A/B knobs, read once at creation
-    int marg_first_check = 6;
-    bool post_fuse = false;               // SWF_POST_FUSE=1: the one-grid forms of k_post_chol / k_post_dogleg at every batch size (A/B timing)
-    bool post_split = false;              // SWF_POST_SPLIT=1: the landmark segment of k_post_chol apart from the others whatever the batch size (A/B timing)
+    bool no_spec = false;                 // SWF_NO_SPEC_EVAL=1: the dogleg loop with a cost pass at the candidate and a Jacobian pass behind k_decide (parity: bit-identical to the speculative flow)
     bool no_comp_fuse = false;            // SWF_NO_COMP_FUSE=1: the composite chain and the visual branch as launches of their own on the latency path too (A/B, parity)
     bool lat_fuse = false;                // latency path: fused grids on one stream (see swf_batch_create)
-    bool force_chol_v1 = false;           // SWF_CHOL_V1=1: use the row-per-thread kernel (A/B testing)
-    bool chol_rr2 = false;                // SWF_CHOL_RR2=1: the previous register-resident kernel (A/B testing)
-    bool chol_rr3 = false;                // SWF_CHOL_RR3=1: round 3's k_chol_rr3 instead of k_chol_rr4 (A/B testing)
     bool rr4_has15 = false, rr4_has16 = false;      // some window has 224 < n_red <= 240 / 240 < n_red <= 256: the 15- / 16-column instance of k_chol_rr4 is launched as well
-    int rr_nmax = 256;                    // largest reduced system of the register-resident Cholesky (240 behind the A/B knobs of the older kernels)
-    bool export_L_always = false;         // SWF_EXPORT_L=1: k_chol_rr3 writes the whole factor on every solve path
+    int rr_nmax = 256;                    // largest reduced system of the register-resident Cholesky (k_chol_rr4)
     bool L_full = false;                  // the L buffer holds the whole factor of the last linear solve
-    bool fs_fused = true;                 // per-frame sums inside k_eval_ps (SWF_FS_SEPARATE=1: k_frame_sums as its own launch; A/B testing)
-    bool asm_old = false;                 // SWF_ASM_OLD=1: the pair-walking assembly kernel instead of the flat program (A/B testing)
     int asm_programs = 0;                 // distinct assembly programs of the batch (windows of identical structure share one)
     int ls_qpb = 1, ls_var = 0, ls_kms = 8; bool ls_folded = false, s_direct = false;     // k_lm_schur launch shape, fixed at creation (the pair lists depend on it)
     int timing = 0;                       // bitmask of SWF_K_* brackets
@@ -722,7 +713,9 @@ int build_window(Build& B, const swf_flat_window* w, int wi, HostWin& hw) {
         C.d_f = df;
         if (!t.is_static && C.d_e + df > CB_MAXD) return fail(SWF_E_UNSUPPORTED, "clique with more than 768 columns");
         if (!t.is_static && C.d_e > 9) return fail(SWF_E_UNSUPPORTED, "group-0 block larger than 9 dimensions");
-        if (!t.is_static && (long long)C.d_e * (C.d_e + df) > CB_MAXED) return fail(SWF_E_UNSUPPORTED, "clique: d_e (d_e + d_f) beyond 1536");
+        // (k_clique_big keeps the e-rows of M and T = Einv M_ef in LDS: only the cliques that take it — beyond 64 x 64 / 96 x 64 — are bound by that)
+        if (!t.is_static && (nrows > CLQ_TALLR || C.d_e + df > 64) && (long long)C.d_e * (C.d_e + df) > CB_MAXED)
+            return fail(SWF_E_UNSUPPORTED, "clique beyond one wavefront with d_e (d_e + d_f) > 1536 (swf_solver.h: limits of a group-0 clique)");
         C.C_off = B.C_tot; B.C_tot += (long long)df * df;
         C.v_off = B.v_tot; B.v_tot += df;
         C.e_off = B.e_tot; B.e_tot += C.d_e * C.d_e + C.d_e * df + C.d_e;
@@ -840,38 +833,21 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         return fail(SWF_E_NODEVICE, "no HIP device: this library has no CPU fallback");
     Build B;
     std::vector<HostWin> hw(n);
-    const bool trace = getenv("SWF_TRACE_REBUILD") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tc0 = now();
     for (int i = 0; i < n; i++) {
         int rc = build_window(B, windows[i], i, hw[i]);
         if (rc != SWF_OK) return rc;
     }
-    const double tc1 = now();
     if (B.n_x > 0x7fffffffLL || B.n_loc > 0x7fffffffLL) return fail(SWF_E_UNSUPPORTED, "batch too large for 32-bit offsets");
     swf_batch* b = new swf_batch();
     b->device = current_device();
     b->stream = (hipStream_t)stream;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) b->n_cu = pr.multiProcessorCount; }
-    b->force_chol_v1 = getenv("SWF_CHOL_V1") != nullptr;
-    b->chol_rr2 = getenv("SWF_CHOL_RR2") != nullptr;
-    b->chol_rr3 = getenv("SWF_CHOL_RR3") != nullptr;
-    b->rr_nmax = (b->chol_rr2 || b->chol_rr3) ? 240 : 256;
     b->D.rr_nmax = b->rr_nmax;
-    b->export_L_always = getenv("SWF_EXPORT_L") != nullptr;
-    b->asm_old = getenv("SWF_ASM_OLD") != nullptr;
-    b->post_split = getenv("SWF_POST_SPLIT") != nullptr;
-    b->post_fuse = getenv("SWF_POST_FUSE") != nullptr;
-    b->fs_fused = getenv("SWF_FS_SEPARATE") == nullptr;
-    // (every A/B knob is read once, here: no getenv on the latency path or inside the marginalisation's sweep loop, and none that could
-    // race a setenv from the per-device enqueue threads of swf_solve_batches)
-    b->no_lm_clique = getenv("SWF_NO_LM_CLIQUE") != nullptr;
+    // (the launch-shape knobs that remain are test aids, each exercised by the GPU tier, and are read once, here: no getenv on the latency
+    // path or inside the marginalisation's sweep loop, and none that could race a setenv from the per-device enqueue threads of
+    // swf_solve_batches.  Nothing that changes RESULTS is an environment variable: those are fields of swf_options.)
     b->no_comp_fuse = getenv("SWF_NO_COMP_FUSE") != nullptr;
-    b->marg_one_wg = getenv("SWF_MARG_ONE_WG") != nullptr;
-    b->marg_no_pchol = getenv("SWF_MARG_NO_PCHOL") != nullptr;
-    b->marg_trace = getenv("SWF_MARG_TRACE") != nullptr;
-    b->marg_no_crit = getenv("SWF_MARG_NO_CRIT") != nullptr;
-    b->marg_first_check = getenv("SWF_MARG_FIRST_CHECK") ? atoi(getenv("SWF_MARG_FIRST_CHECK")) : 6;
+    b->no_spec = getenv("SWF_NO_SPEC_EVAL") != nullptr;
     // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
     // fills what one-block-per-window kernels leave idle (measured: 256 windows 5.52 -> 5.22 ms, 128 windows 3.73 -> 3.49 ms per solve; 64 and
     // 512 windows: no gain)
@@ -879,8 +855,8 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     // scalar factors, every clique size class in one launch) on ONE stream.  Round 3 ran the IMU / clique branch of such batches on the
     // auxiliary stream instead; the kernel trace shows what that buys: every cross-queue edge (event record -> stream wait) costs 6-13 us
     // of dependency resolution, as much as the overlap saves (one window: 1.432 ms with the auxiliary stream, 1.443 without).
-    { const char* lm = getenv("SWF_LAT_FUSE_MAX"); b->lat_fuse = (lm ? n <= atoi(lm) : n * 8 <= b->n_cu) && !getenv("SWF_NO_LAT_FUSE"); }
-    if ((((n * 16 <= b->n_cu && !b->lat_fuse) || (2 * n >= b->n_cu && n <= b->n_cu)) || getenv("SWF_AUX_STREAM_ALWAYS")) && !getenv("SWF_NO_AUX_STREAM")) {            // fork / join inside a linearisation
+    b->lat_fuse = n * 8 <= b->n_cu && !getenv("SWF_NO_LAT_FUSE");
+    if ((n * 16 <= b->n_cu && !b->lat_fuse) || (2 * n >= b->n_cu && n <= b->n_cu)) {            // fork / join inside a linearisation
         bool ok = (b->aux = handle_cache().stream()) != nullptr;
         for (int i = 0; i < 3 && ok; i++) ok = (b->ev_fork[i] = handle_cache().event(false)) != nullptr;
         if (!ok) { handle_cache().give(b->aux); b->aux = nullptr; }
@@ -941,7 +917,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         b->ls_qpb = qpb;
         b->ls_var = (b->max_tiles <= 10 && force < 1) ? 0 : (b->max_tiles <= 36 && force < 2) ? 1 : (b->max_tiles <= 136 && force < 3) ? 2 : 3;
         b->ls_folded = qpb == GEMM_SPLIT && b->ls_var <= 1;          // must mirror CAN_FOLD in k_lm_schur
-        b->s_direct = b->ls_folded && !getenv("SWF_NO_S_DIRECT");
+        b->s_direct = b->ls_folded;
     }
     {
         // k_lm_schur task table.  A wave task = the four 16-lane groups of one producer wave = four landmarks, one group and three of the
@@ -1197,7 +1173,6 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             nonempty_i(t_dst); nonempty_u(t_cnt); nonempty_i(t_src0); nonempty_i(t_aux); nonempty_i(t_src);
             nonempty_i(tv_loc); nonempty_i(tv_red); nonempty_u(tv_cnt); nonempty_i(tv_src0); nonempty_i(tv_i); nonempty_i(tv_src);
             PUT(asw, asw); PUT(s_tnz, tnz);
-            if (getenv("SWF_NO_TNZ")) D.s_tnz = nullptr;        // A/B: k_chol_rr4 loads every tile
             D.rr_nmax = b->rr_nmax;
             PUT(as_dst, t_dst); PUT(as_cnt, t_cnt); PUT(as_src0, t_src0); PUT(as_aux, t_aux); PUT(as_src, t_src);
             PUT(av_loc, tv_loc); PUT(av_red, tv_red); PUT(av_cnt, tv_cnt); PUT(av_src0, tv_src0); PUT(av_i, tv_i); PUT(av_src, tv_src);
@@ -1265,7 +1240,6 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             Coff[f] = Cq.is_static ? Cq.C_off : -1; voff[f] = Cq.is_static ? Cq.v_off : -1;
         }
         b->comp_ne = eo[nc];
-        { const char* ev = getenv("SWF_COMP_EIGEN_ROOT"); b->comp_eigen_root = ev && ev[0] == '1'; }
         CompArgs& A = b->CA; CompMeta& Mt = b->CM;
         A.n = nc; A.want_jac = 1;
         rc |= P.put(B.co_M, &A.M); rc |= P.put(B.co_N, &A.N); rc |= P.put(eo, &A.e_off); rc |= P.put(no, &A.n_off);
@@ -1293,13 +1267,10 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         rc |= P.put(Joff, &Mt.Joff); rc |= P.put(roff, &Mt.roff); rc |= P.put(x0off, &Mt.x0off); rc |= P.put(Coff, &Mt.Coff); rc |= P.put(voff, &Mt.voff);
         Mt.prior_J = (double*)D.prior_J; Mt.prior_Jt = (double*)D.prior_Jt; Mt.prior_r0 = (double*)D.prior_r0; Mt.prior_x0 = (double*)D.prior_x0;
     }
-    const double tc2 = now();
     if (!rc) rc = P.flush();
     if (rc) { P.release(); delete b; return fail(SWF_E_NODEVICE, "device allocation / upload failed"); }
     *out = b;
-    const double tc3 = now();
     int urc = swf_batch_upload_state(b);
-    if (trace) fprintf(stderr, "[swf] batch_create: symbolic %.3f ms, tables %.3f ms, flush %.3f ms, upload_state %.3f ms\n", tc1 - tc0, tc2 - tc1, tc3 - tc2, now() - tc3);
     if (urc != SWF_OK) { swf_batch_destroy(b); *out = nullptr; return urc; }
     return SWF_OK;
 }
@@ -1432,7 +1403,7 @@ namespace {
 struct Launcher {
     swf_batch* b; DevOpt O; hipStream_t st;
     bool lm_folded = false;     // k_lm_schur of the current linearisation wrote ONE folded product (else GEMM_SPLIT partials)
-    bool export_full = false;   // k_chol_rr3 writes the whole factor (ASSEMBLE_ELIMINATE_ONLY: marginalisation, swf_batch_export_reduced), else the tail block only
+    bool export_full = false;   // k_chol_rr4 writes the whole factor (ASSEMBLE_ELIMINATE_ONLY: marginalisation, swf_batch_export_reduced), else the tail block only
     int lm_next = 0, lm_qpb = 1;                 // first tile of the ranges of k_lm_schur still to launch (with the clique kernels)
     int ls_tiles_per_launch() const { return b->ls_var == 0 ? 16 : b->ls_var == 1 ? 40 : 72; }
     // one launch of the landmark Schur kernel over the tile-list entries [tile_base, tile_base + tiles per launch), by row class
@@ -1487,15 +1458,18 @@ struct Launcher {
     bool comp_fused = false;
     bool comp_fuse_ok(int write_S) const {
         const DevBatch& D = b->D;
-        if (!b->n_comp || !write_S || b->no_comp_fuse || !b->lat_fuse || b->aux || !b->fs_fused || b->comp_eigen_root) return false;
+        if (!b->n_comp || !write_S || b->no_comp_fuse || !b->lat_fuse || b->aux || b->comp_eigen_root) return false;
         if (b->comp_nmax > CO_SMALLN || b->ls_var > 1 || !D.n_lm || D.n_imu || D.n_idp || b->max_prior_dim > PRIOR_LDS_DIM) return false;
         if (D.n_clc[0] || D.n_clc[1]) return false;                                     // (the cliques of such a window: classes 2, 4 and — from 19 ambiguities on — 3)
         const int crow = (b->n_comp + D.n_win - 1) / D.n_win;
         return (long long)D.n_win * (GEMM_SPLIT / b->ls_qpb + crow) <= b->n_cu;         // every workgroup of k_lm_comp resident at once
     }
-    void lin_eval(int write_S) {
-        DevBatch& D = b->D;
-        comp_fused = comp_fuse_ok(write_S);
+    // spec: the Jacobian evaluation of the dogleg loop's speculative flow — at the candidate of every window with a proposed step
+    // (swf_kernels.h: eval_gate / eval_src); the evaluation kernels get a copy of the batch record with the flag set
+    void lin_eval(int write_S, bool spec = false) {
+        DevBatch Dv = b->D; Dv.spec = spec ? 1 : 0;
+        const DevBatch& D = Dv;
+        comp_fused = !spec && comp_fuse_ok(write_S);
         if (comp_fused) {
             hipLaunchKernelGGL(k_comp_gather_prep, dim3(b->n_comp), dim3(256), 0, st, D, b->CA, b->CM);
             Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256);
@@ -1519,7 +1493,7 @@ struct Launcher {
             }
             return;
         }
-        if (b->n_comp) {
+        if (b->n_comp && !spec) {
             // composite IMU-GNSS factors of the windows that re-linearise: hidden epochs move, re-elimination, prior records rewritten
             // 1024 threads per factor while the chip holds every factor at once (two such workgroups per CU), 256 for larger batches
             const bool wide = b->n_comp <= 2 * b->n_cu;
@@ -1542,24 +1516,28 @@ struct Launcher {
             hipLaunchKernelGGL(k_comp_scatter, dim3(b->n_comp), dim3(256), 0, st, D, b->CA, b->CM);
             }
         }
-        hipStream_t sa = b->aux ? b->aux : st;
-        if (b->aux) { (void)hipEventRecord(b->ev_fork[0], st); (void)hipStreamWaitEvent(b->aux, b->ev_fork[0], 0); }
+        // (speculative flow: k_decide, on the main stream, reads every family's candidate costs — the whole evaluation stays on the main
+        // stream, and the fork event the clique branch waits for is recorded behind k_decide, see swf_batch_solve)
+        const bool fork = b->aux && !spec;
+        hipStream_t sa = fork ? b->aux : st;
+        if (fork) { (void)hipEventRecord(b->ev_fork[0], st); (void)hipStreamWaitEvent(b->aux, b->ev_fork[0], 0); }
         bool imu_fused = false;
         if (D.n_proj + D.n_sc + D.n_prior) {
             Bracket t(*this, SWF_K_EVAL_PS);
             bool pf = b->max_prior_dim <= PRIOR_LDS_DIM;          // priors fused as a segment
-            // (the projection segment: one workgroup per frame-sum block, the per-frame sums fused in; SWF_FS_SEPARATE=1: k_frame_sums as its own launch)
-            Segs S{}; S.e[0] = b->fs_fused ? D.n_fsb : nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
-            imu_fused = b->lat_fuse && b->fs_fused && D.n_imu > 0;          // latency path: the IMU factors as a segment of this grid
+            // (the projection segment: one workgroup per frame-sum block, the per-frame sums formed in the same kernel)
+            Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
+            imu_fused = b->lat_fuse && D.n_imu > 0;          // latency path: the IMU factors as a segment of this grid
             S.e[3] = S.e[2] + (imu_fused ? nb(D.n_imu, IMU_FPB) : 0);
             if (imu_fused) hipLaunchKernelGGL((k_eval_ps<true, true, true>), dim3(S.e[3]), dim3(256), 0, st, D, S);
-            else if (b->fs_fused) hipLaunchKernelGGL((k_eval_ps<true, true>), dim3(S.e[2]), dim3(256), 0, st, D, S);
-            else hipLaunchKernelGGL((k_eval_ps<true, false>), dim3(S.e[2]), dim3(256), 0, st, D, S);
+            else hipLaunchKernelGGL((k_eval_ps<true, true>), dim3(S.e[2]), dim3(256), 0, st, D, S);
         }
         if (D.n_idp) hipLaunchKernelGGL(k_eval_idp<true>, GRID(D.n_idp, 128), dim3(128), 0, st, D);
-        if (b->aux) (void)hipEventRecord(b->ev_fork[1], st);
-        if (D.n_imu && !imu_fused) { Bracket t(*this, SWF_K_EVAL_IMU, sa); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, sa, D); }
+        // (large priors before the fork event: a prior-type record inside a group-0 clique writes its rows into that clique's Jacobian, and a
+        // clique class with IMU factors runs on the auxiliary stream behind ev_fork[1] alone)
         if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
+        if (fork) (void)hipEventRecord(b->ev_fork[1], st);
+        if (D.n_imu && !imu_fused) { Bracket t(*this, SWF_K_EVAL_IMU, sa); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, sa, D); }
     }
     void lin_elim(int write_S) {
         DevBatch& D = b->D;
@@ -1583,7 +1561,7 @@ struct Launcher {
                 // latency path: the one-wavefront cliques ride in the same grid (k_lm_clique); the 64-frame class has no LDS to spare for them
                 // (a workgroup of that grid fills a CU: only while all of them — landmark parts and cliques — are resident at once)
                 const int crow = D.n_win > 0 ? (D.n_clc[2] + D.n_win - 1) / D.n_win : 0;
-                clq_fused = b->lat_fuse && b->ls_var <= 2 && D.n_clc[2] > 0 && !D.n_clc[0] && !D.n_clc[1] && !b->no_lm_clique
+                clq_fused = b->lat_fuse && b->ls_var <= 2 && D.n_clc[2] > 0 && !D.n_clc[0] && !D.n_clc[1]
                             && (long long)D.n_win * (GEMM_SPLIT / b->ls_qpb + crow) <= b->n_cu;
                 lm_launch(0, st, clq_fused ? crow : 0);
                 lm_next = ls_tiles_per_launch();        // further tile ranges: launched below, on the auxiliary stream when there is one
@@ -1614,31 +1592,22 @@ struct Launcher {
             }
             if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);
         }
-        if (D.n_fsb && !b->fs_fused) { Bracket t(*this, SWF_K_FRAME_SUMS); hipLaunchKernelGGL(k_frame_sums, dim3(D.n_fsb), dim3(FS_BLK), 0, st, D); }
         if (b->aux) (void)hipStreamWaitEvent(st, b->ev_fork[2], 0);                  // join before the assembly
-        if (D.n_pd && !b->asm_old) {
+        if (D.n_pd) {
             Bracket t(*this, SWF_K_ASSEMBLE);
             const int nbS = write_S ? nb((size_t)D.as_max_ne, 256) : 0, nbV = nb((size_t)D.as_max_nv, 256);
             hipLaunchKernelGGL(k_assemble_flat, dim3(nbS + nbV, D.n_win), dim3(256), 0, st, D, O, write_S, nbS);
-        } else if (D.n_pd) {
-            Bracket t(*this, SWF_K_ASSEMBLE);
-            Segs S{}; S.e[0] = nb((size_t)D.n_pd * 64, 256); S.e[1] = S.e[0] + (write_S ? nb((size_t)D.n_po * 16, 256) : 0);
-            hipLaunchKernelGGL(k_assemble_all, dim3(S.e[1]), dim3(256), 0, st, D, O, write_S, S, b->s_direct ? 0 : lm_folded ? 1 : GEMM_SPLIT, lm_folded ? 1 : GEMM_SPLIT);
         }
     }
     void reduced() {
         DevBatch& D = b->D;
         Bracket t(*this, SWF_K_CHOL);
-        if (b->max_red <= CB_NMAX && !b->force_chol_v1) {
+        if (b->max_red <= CB_NMAX) {
             // per-window choice (each kernel skips the other's windows): register-resident tiles up to 240 dimensions, streamed above
             if (b->min_red <= b->rr_nmax) {
-                if (b->chol_rr2) hipLaunchKernelGGL(k_chol_rr2<9>, dim3(D.n_win), dim3(1024), 0, st, D);
-                else if (b->chol_rr3) hipLaunchKernelGGL(k_chol_rr3, dim3(D.n_win), dim3(1024), 0, st, D, export_full ? 1 : 0);
-                else {
-                    if (b->min_red <= 224) hipLaunchKernelGGL(k_chol_rr4<14>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
-                    if (b->rr4_has15) hipLaunchKernelGGL(k_chol_rr4<15>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
-                    if (b->rr4_has16) hipLaunchKernelGGL(k_chol_rr4<16>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
-                }
+                if (b->min_red <= 224) hipLaunchKernelGGL(k_chol_rr4<14>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
+                if (b->rr4_has15) hipLaunchKernelGGL(k_chol_rr4<15>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
+                if (b->rr4_has16) hipLaunchKernelGGL(k_chol_rr4<16>, dim3(D.n_win), dim3(R4_NT), 0, st, D, export_full ? 1 : 0);
             }
             if (b->max_red > b->rr_nmax && D.Wk) {
                 const int Tc = (b->max_red + 15) / 16;
@@ -1658,7 +1627,7 @@ struct Launcher {
             S.e[0] = D.n_lmb; S.e[1] = S.e[0] + nb((size_t)D.n_cle * 16, 256);
             S.e[2] = S.e[1]; S.e[3] = S.e[2] + nb(D.n_sc, 256);                                 // (J D^-2 g of the projections rides in segment 0)
             S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + D.n_prior;      // one workgroup per prior
-            if ((D.n_win < b->n_cu || b->post_fuse) && !b->post_split) { if (S.e[5]) hipLaunchKernelGGL(k_post_chol<0>, dim3(S.e[5]), dim3(256), 0, st, D, O, S); }
+            if (D.n_win < b->n_cu) { if (S.e[5]) hipLaunchKernelGGL(k_post_chol<0>, dim3(S.e[5]), dim3(256), 0, st, D, O, S); }
             else {
                 if (S.e[0]) hipLaunchKernelGGL(k_post_chol<1>, dim3(S.e[0]), dim3(256), 0, st, D, O, S);
                 if (S.e[5] > S.e[0]) hipLaunchKernelGGL(k_post_chol<2>, dim3(S.e[5] - S.e[0]), dim3(256), 0, st, D, O, S);
@@ -1670,6 +1639,10 @@ struct Launcher {
             else hipLaunchKernelGGL((k_dogleg<4, 4, 2>), dim3(D.n_win), dim3(CTL_NT), 0, st, D, O);
         }
     }
+    void decide() {
+        DevBatch& D = b->D;
+        { Bracket t(*this, SWF_K_DECIDE); hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(CTL_NT), 0, st, D, O); }
+    }
     void cand_eval() {
         DevBatch& D = b->D;
         {
@@ -1679,7 +1652,7 @@ struct Launcher {
             S.e[2] = S.e[1] + (b->max_prior_dim <= PRIOR_LDS_DIM ? D.n_prior : 0);
             // small batches (latency path): the candidate IMU residuals ride along as a segment; large batches keep them in
             // their own launch (the segment's LDS would cost the memory-bound segments occupancy).  Same results either way.
-            bool fuse_imu = D.n_win < b->n_cu || b->post_fuse;
+            bool fuse_imu = D.n_win < b->n_cu;
             S.e[3] = S.e[2] + (fuse_imu ? nb(D.n_imu, IMU_FPB) : 0);
             if (S.e[3] && fuse_imu) hipLaunchKernelGGL((k_post_dogleg<true, 0>), dim3(S.e[3]), dim3(256), 0, st, D, O, S);
             else if (S.e[3]) {
@@ -1693,7 +1666,7 @@ struct Launcher {
             Bracket t(*this, SWF_K_CAND_EVAL);
             if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
         }
-        { Bracket t(*this, SWF_K_DECIDE); hipLaunchKernelGGL(k_decide, dim3(D.n_win), dim3(CTL_NT), 0, st, D, O); }
+        decide();
     }
 };
 }  // namespace
@@ -1703,12 +1676,14 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
     if (!b || !opt) return fail(SWF_E_INVALID, "swf_batch_solve: bad arguments");
     if (opt->max_num_iterations < 0 || opt->max_num_iterations >= SWF_MAX_TRACE) return fail(SWF_E_INVALID, "max_num_iterations out of range");
     if (opt->trust_region_strategy != SWF_DOGLEG && opt->trust_region_strategy != SWF_LEVENBERG_MARQUARDT) return fail(SWF_E_INVALID, "unknown trust_region_strategy");
+    if (opt->composite_root != SWF_ROOT_PIVOTED_CHOLESKY && opt->composite_root != SWF_ROOT_EIGEN) return fail(SWF_E_INVALID, "unknown composite_root");
+    b->comp_eigen_root = opt->composite_root == SWF_ROOT_EIGEN;
     if (opt->jacobi_scaling && opt->trust_region_strategy == SWF_DOGLEG && opt->step_mode == SWF_OPTIMIZE)
         return fail(SWF_E_UNSUPPORTED, "jacobi_scaling with the dogleg strategy (the reference sets jacobi_scaling = 0 wherever it selects DOGLEG: R/swf/swf.cpp:26-27)");
     DevBatch& D = b->D;
     Launcher L{ b, to_devopt(opt), b->stream };
-    L.export_full = opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY || b->export_L_always;
-    b->L_full = L.export_full || b->chol_rr2 || b->min_red > b->rr_nmax || b->force_chol_v1 || b->max_red > CB_NMAX;
+    L.export_full = opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY;
+    b->L_full = L.export_full || b->min_red > b->rr_nmax || b->max_red > CB_NMAX;
     hipStream_t st = b->stream;
     b->ev_used = 0; b->ev_kind.clear();
     int nlin = 0;
@@ -1720,11 +1695,21 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
         if (opt->step_mode == SWF_ASSEMBLE_ELIMINATE_ONLY) {
             L.reduced();
         } else {
+            // Speculative flow (dogleg, no composite factors): the candidate of a proposed step is evaluated WITH its Jacobians — an accepted
+            // candidate is the next linearisation point, a rejected dogleg step re-uses the reduced system it came from, an invalid one never
+            // gets a candidate (k_dogleg) — so the cost pass at the candidate and the Jacobian pass at the same point that followed it
+            // are one pass, and the elimination kernels behind k_decide find the new point's Jacobians in place.  Levenberg-Marquardt
+            // re-linearises at the UNCHANGED point after a rejected step (new damping) and keeps the two passes.
+            const bool spec = opt->trust_region_strategy == SWF_DOGLEG && !b->n_comp && !b->no_spec;
             for (int it = 1; it <= opt->max_num_iterations; it++) {
                 L.reduced();
                 L.step_rest();
-                L.cand_eval();
-                LIN(it < opt->max_num_iterations ? 1 : 0);
+                if (spec) {
+                    L.lin_eval(1, true); L.decide();
+                    if (b->aux) (void)hipEventRecord(b->ev_fork[1], st);          // the auxiliary stream's clique branch starts behind k_decide
+                    L.lin_elim(it < opt->max_num_iterations ? 1 : 0); nlin++;
+                }
+                else { L.cand_eval(); LIN(it < opt->max_num_iterations ? 1 : 0); }
             }
         }
         hipLaunchKernelGGL(k_finalize, dim3(D.n_win), dim3(256), 0, st, D, L.O);
@@ -1875,8 +1860,8 @@ extern "C" int swf_batch_export_reduced(swf_batch* b, int32_t w, double* S, doub
     if (L) {
         std::vector<double> Lt((n + 1) * (n + 1));
         HIPCHK(hipMemcpy(Lt.data(), b->D.L + W.Lt_base, Lt.size() * sizeof(double), hipMemcpyDeviceToHost));
-        bool rr = b->max_red <= CB_NMAX && !b->force_chol_v1;      // k_chol_rr3 / k_chol_big write row-major lower, ld = n
-        // k_chol_rr3 on a solve path keeps the factor in registers and writes only the block its readers use: the parameter_head
+        bool rr = b->max_red <= CB_NMAX;      // k_chol_rr4 / k_chol_big write row-major lower, ld = n
+        // k_chol_rr4 on a solve path keeps the factor in registers and writes only the block its readers use: the parameter_head
         // tail (from the 16-aligned row / column at or before its start).  Everything else is returned as zero.
         size_t first = 0;
         if (!b->L_full && n <= (size_t)b->rr_nmax) { const size_t td = (size_t)b->hw[w].tail_dim; first = td ? ((n - td) >> 4) << 4 : n; }
@@ -1890,7 +1875,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
     DeviceGuard dg_(b ? b->device : -1);
     if (!b || (form != SWF_PRIOR_EIGEN && form != SWF_PRIOR_CHOLESKY) || !(eps >= 0.0)) return fail(SWF_E_INVALID, "swf_batch_marginalize: bad arguments");
     if (b->last_mode != SWF_ASSEMBLE_ELIMINATE_ONLY) return fail(SWF_E_STATE, "swf_batch_marginalize needs a preceding solve with step_mode = SWF_ASSEMBLE_ELIMINATE_ONLY");
-    if (b->max_red > CB_NMAX || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "marginalisation needs the row-major Cholesky factor (n_red <= 640)");
+    if (b->max_red > CB_NMAX) return fail(SWF_E_UNSUPPORTED, "marginalisation needs the row-major Cholesky factor (n_red <= 640)");
     int nw = (int)b->win.size(), ldn = 1;
     for (int w = 0; w < nw; w++) ldn = std::max(ldn, b->hw[w].tail_dim);
     if (form == SWF_PRIOR_EIGEN && ldn > MG_BIGN) return fail(SWF_E_UNSUPPORTED, "eigen square root: parameter_head tail larger than 640 dimensions (use SWF_PRIOR_CHOLESKY)");
@@ -1938,11 +1923,10 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                                b->mg_A, b->mg_b, b->mg_J, b->mg_r0, b->mg_w, b->mg_rank, b->mg_M,
                                (const double*)b->mg_resM, (const double*)b->mg_resb, (const int*)b->mg_resok, force, ph, b->mg_bjok);
         };
-        if (b->marg_one_wg) phase(0);              // A/B: the single-workgroup sweeps
-        else {
+        {
             phase(1);
             hipLaunchKernelGGL(k_marg_gram, dim3((ldn * ldn + 255) / 256, nw), dim3(256), 0, b->stream, (const int*)b->mg_tail, ldn, (const double*)b->mg_M, b->mg_A, (const int*)b->mg_bjok);
-            if (!b->marg_no_pchol) {
+            {
                 // the Jacobi preconditioner: pivoted Cholesky of A into the G slab (9 sweeps instead of 16 at the 263-dimension tail)
                 const size_t lds = sizeof(double) * ((size_t)(RS_POOL + 1) * (size_t)ldn + (size_t)RS_POOL * (size_t)mg_rc);
                 if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_marg_pchol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1956,7 +1940,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
             std::vector<int> hrot((size_t)nw * MG_SWEEPS);
             // from the sixth sweep on, one look at the rotation counts per sweep: 30 us of synchronisation against the 34 launches of a
             // 263-dimension sweep (0.55 ms) that a check every fourth sweep ran up to three times too often
-            const int mg_first_check = b->marg_first_check;
+            const int mg_first_check = 6;
             for (int sweep = 0; sweep < MG_SWEEPS; sweep++) {
                 if (sweep >= mg_first_check) {
                     // every four sweeps: has every window reported a sweep without rotations?  (the launches of a converged window return
@@ -1965,7 +1949,6 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                     HIPCHK(hipStreamSynchronize(b->stream));
                     bool all = true;
                     for (int w = 0; w < nw && all; w++) { bool done = false; for (int k = 0; k < sweep; k++) done = done || hrot[(size_t)w * MG_SWEEPS + k] == 0; all = done; }
-                    if (b->marg_trace) { fprintf(stderr, "marg sweep %d rotations (window 0):", sweep); for (int k = 0; k < sweep; k++) fprintf(stderr, " %d", hrot[k]); fprintf(stderr, "\n"); }
                     if (all) break;
                 }
 #define BJ_LAUNCH(BS_, LDM_, NR_) hipLaunchKernelGGL((k_marg_bj<BS_, LDM_, NR_>), grid, dim3(1024), 0, b->stream, (const int*)b->mg_tail, ldn, b->mg_M, b->mg_rot, b->mg_crit, (const int*)b->mg_bjok, sweep, st)
@@ -1982,7 +1965,7 @@ extern "C" int swf_batch_marginalize(swf_batch* b, double eps, int32_t form) {
                     for (int st = -1; st < nbe - 1; st++) { dim3 grid(nbe / 2, nw); BJ_LAUNCH(4, 640, 10); }
                 }
 #undef BJ_LAUNCH
-                if (!b->marg_no_crit) hipLaunchKernelGGL(k_marg_bj_crit, dim3((nw + 63) / 64), dim3(64), 0, b->stream, (const int*)b->mg_tail, nw, b->mg_rot, b->mg_crit, (const int*)b->mg_bjok, sweep);
+                hipLaunchKernelGGL(k_marg_bj_crit, dim3((nw + 63) / 64), dim3(64), 0, b->stream, (const int*)b->mg_tail, nw, b->mg_rot, b->mg_crit, (const int*)b->mg_bjok, sweep);
             }
             phase(2);
         }
@@ -1997,7 +1980,7 @@ extern "C" int swf_batch_tail_covariance(swf_batch* b) {
     DeviceGuard dg_(b ? b->device : -1);
     if (!b) return fail(SWF_E_INVALID, "swf_batch_tail_covariance: null batch");
     if (b->last_mode < 0) return fail(SWF_E_STATE, "swf_batch_tail_covariance needs a preceding solve");
-    if (b->max_red > CB_NMAX || b->force_chol_v1) return fail(SWF_E_UNSUPPORTED, "the tail covariance needs the row-major Cholesky factor (n_red <= 640)");
+    if (b->max_red > CB_NMAX) return fail(SWF_E_UNSUPPORTED, "the tail covariance needs the row-major Cholesky factor (n_red <= 640)");
     int nw = (int)b->win.size(), ldn = 1;
     for (int w = 0; w < nw; w++) ldn = std::max(ldn, b->hw[w].tail_dim);
     if (!b->tc_A) {

@@ -39,6 +39,15 @@ __device__ __forceinline__ double damp_diag(const DevOpt& O, double d, double* j
     return clampd(d / q, O.min_diag, O.max_diag) * q;
 }
 
+// Where an evaluation reads its parameter blocks and what gates it.  Cost-only evaluations (JAC = false) run at the candidate xc of the
+// windows whose k_dogleg proposed a step (eval_cand).  Jacobian evaluations run at x for the windows that re-linearise (need_lin) — or,
+// in the SPECULATIVE flow of the dogleg loop (DevBatch::spec, set per launch by the engine), at the CANDIDATE of the windows with a
+// proposed step: the accepted candidate is the next linearisation point, so its residuals, costs AND Jacobians are formed in one pass
+// instead of a cost pass at xc followed by a Jacobian pass at the same point (k_decide then turns the accepted candidate into x and
+// the elimination kernels find its Jacobians in place; a rejected dogleg step re-uses the previous reduced system and needs no Jacobian).
+template <bool JAC> __device__ __forceinline__ bool eval_gate(const DevBatch& B, const WinState& s) { return (JAC && !B.spec) ? s.need_lin != 0 : s.eval_cand != 0; }
+template <bool JAC> __device__ __forceinline__ const double* eval_src(const DevBatch& B) { return (JAC && !B.spec) ? B.x : B.xc; }
+
 #define CLIGHT_D 299792458.0
 #define OMGE_D 7.2921151467E-5
 
@@ -61,9 +70,9 @@ template <bool JAC, bool STORE = true>
 __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double* keep) {
     int w = B.p_win[i];
     const WinState& s = B.ws[w];
-    if (JAC ? !s.need_lin : !s.eval_cand) return;
+    if (!eval_gate<JAC>(B, s)) return;
     const WinRec& W = B.win[w];
-    const double* xs = JAC ? B.x : B.xc;
+    const double* xs = eval_src<JAC>(B);
     const double* pose = xs + B.p_xpose[i];
     const double* ex = xs + B.p_xex[i];
     const double* lm = xs + B.p_xlm[i];
@@ -325,9 +334,9 @@ __device__ __forceinline__ void d_eval_imu(const DevBatch& B, int bid) {
     int f = B.imu_gf[valid ? q : B.n_imu - 1];
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
-    bool act = valid && (JAC ? s.need_lin : s.eval_cand);
+    bool act = valid && eval_gate<JAC>(B, s);
     const WinRec& W = B.win[G.win];
-    const double* xs = JAC ? B.x : B.xc;
+    const double* xs = eval_src<JAC>(B);
     const double* pre = B.imu_pre + (size_t)G.data * SWF_PRE_DOUBLES;
     if (act) {
         for (int k = sub; k < SWF_PRE_SQRTINFO; k += LPF) pr[fl][k] = pre[k];
@@ -348,7 +357,7 @@ __device__ __forceinline__ void d_eval_imu(const DevBatch& B, int bid) {
         if (q2 < B.n_imu) {
             const GFac& G2 = B.gf[B.imu_gf[q2]];
             const WinState& s2 = B.ws[G2.win];
-            if (JAC ? s2.need_lin : s2.eval_cand) {
+            if (eval_gate<JAC>(B, s2)) {
                 imu_unwhitened(st[fq], st[fq] + 7, st[fq] + 16, st[fq] + 23, pr[fq],
                                pr[fq] + SWF_PRE_SQRTINFO, pr[fq] + SWF_PRE_SQRTINFO + 3, raw[fq], U[JAC ? fq : 0], JAC, part);
             }
@@ -390,10 +399,10 @@ __device__ __forceinline__ void d_eval_scalar(const DevBatch& B, int bid) {
     int f = B.sc_gf[q];
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
-    if (JAC ? !s.need_lin : !s.eval_cand) return;
+    if (!eval_gate<JAC>(B, s)) return;
     if (G.type == GF_IDP || G.type == GF_PROJX) return;          // two-row projection factors: their own kernel (k_eval_idp), they only share the J v code
     const WinRec& W = B.win[G.win];
-    const double* xs = JAC ? B.x : B.xc;
+    const double* xs = eval_src<JAC>(B);
     int s0 = G.slot0, ld = G.jld;          // column stride of the clique's dense column-major Jacobian
     double r;
     if (G.type == GF_CP) {
@@ -500,9 +509,9 @@ __global__ void __launch_bounds__(128) k_eval_idp(DevBatch B) {
     int f = B.idp_gf[q];
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
-    if (JAC ? !s.need_lin : !s.eval_cand) return;
+    if (!eval_gate<JAC>(B, s)) return;
     const WinRec& W = B.win[G.win];
-    const double* xs = JAC ? B.x : B.xc;
+    const double* xs = eval_src<JAC>(B);
     int s0 = G.slot0, ld = G.jld;
     if (G.type == GF_PROJX) {
         // projection_factor::Evaluate (R/factor/projection_factor.cpp:13-65) with ALL THREE Jacobian blocks: pose_j, the camera
@@ -623,8 +632,8 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
     int f = B.prior_gf[q];
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
-    if (JAC ? !s.need_lin : !s.eval_cand) return;
-    const double* xs = JAC ? B.x : B.xc;
+    if (!eval_gate<JAC>(B, s)) return;
+    const double* xs = eval_src<JAC>(B);
     int k = G.data, n = G.nres;
     double* dx = sm; double* rr = sm + n; double* red = sm + 2 * n;
     const double* Jp = B.prior_J + B.prior_Joff[k];
@@ -1360,10 +1369,9 @@ __global__ void __launch_bounds__(CB_NT) k_clique_big2(DevBatch B, DevOpt O) {
 #define FS_HALF 14                            // values staged per pass
 // The same, fused into the Jacobian evaluation (k_eval_ps<true>, one workgroup per frame-sum block): thread t evaluates observation t of
 // the block and the 27 products never leave the chip — Jp and r are not read back (112 B per observation and one launch less).
-// Same products, same staging, same owner loop as k_frame_sums below: bit-identical partial sums.
 __device__ __forceinline__ void d_eval_proj_fs(const DevBatch& B, int blk, double (*V)[FS_HALF], int* foff) {
     int w = B.fsb_win[blk];
-    if (!B.ws[w].need_lin) return;                           // uniform per block (a block holds observations of one window)
+    if (!eval_gate<true>(B, B.ws[w])) return;                // uniform per block (a block holds observations of one window)
     const WinRec& W = B.win[w];
     int o_beg = B.fsb_obs0[blk], cnt = B.fsb_obs0[blk + 1] - o_beg, tid = threadIdx.x;
     int nF = W.nF;
@@ -1394,68 +1402,6 @@ __device__ __forceinline__ void d_eval_proj_fs(const DevBatch& B, int blk, doubl
             for (int k = 0; k < FS_HALF; k++) if (k < nv) V[rk][k] = val[v0 + k];
         }
         __syncthreads();
-        for (int e = tid; e < nF * nv; e += FS_BLK) {
-            int f = e / nv, v = e - f * nv;
-            double acc = 0;
-            int q = foff[f], q1 = foff[f + 1];
-            for (; q + 4 <= q1; q += 4) {
-                double x0 = V[q][v], x1 = V[q + 1][v], x2 = V[q + 2][v], x3 = V[q + 3][v];
-                acc += x0; acc += x1; acc += x2; acc += x3;
-            }
-            for (; q < q1; q++) acc += V[q][v];
-            out[f * FS_VAL + v0 + v] = acc;
-        }
-    }
-}
-__global__ void __launch_bounds__(FS_BLK) k_frame_sums(DevBatch B) {
-    __shared__ double V[FS_BLK][FS_HALF];
-    int blk = blockIdx.x;
-    if (blk >= B.n_fsb) return;
-    int w = B.fsb_win[blk];
-    if (!B.ws[w].need_lin) return;
-    const WinRec& W = B.win[w];
-    int o_beg = B.fsb_obs0[blk], cnt = B.fsb_obs0[blk + 1] - o_beg, tid = threadIdx.x, n = B.n_proj;
-    // thread t loads observation t (coalesced) and stages it at its frame-sorted rank, so that the owner loop below
-    // walks V sequentially (no index chase)
-    __shared__ int foff[168];
-    int nF = W.nF;
-    for (int e = tid; e <= nF; e += FS_BLK) foff[e] = B.fsb_foff[B.fsb_foff0[blk] + e];
-    // the 27 values are staged in two halves (14 + 13): V = 28.7 KB, five blocks per CU
-    double val[FS_VAL];
-#pragma unroll
-    for (int k = 0; k < FS_VAL; k++) val[k] = 0.0;
-    int rk = 0;
-    if (tid < cnt) {
-        int o = o_beg + tid;
-        rk = B.fsb_perm[o];
-        double a[6], b[6];
-        const bool lv = B.p_llm[o] >= 0;                 // translation half of Jp = -Jl (not stored next to a variable landmark)
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const bool tl = i < 3 && lv;
-            a[i] = tl ? -B.p_Jl[i * n + o] : B.p_Jp[i * n + o]; b[i] = tl ? -B.p_Jl[(3 + i) * n + o] : B.p_Jp[(6 + i) * n + o];
-        }
-        double r0 = B.p_r[o], r1 = B.p_r[n + o];
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = 0; j <= i; j++) val[k++] = a[i] * a[j] + b[i] * b[j];
-#pragma unroll
-        for (int i = 0; i < 6; i++) val[21 + i] = a[i] * r0 + b[i] * r1;
-    }
-    double* out = B.fs_part + (size_t)B.fsb_out0[blk] * FS_VAL;
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int v0 = half * FS_HALF, nv = half == 0 ? FS_HALF : FS_VAL - FS_HALF;
-        if (half) __syncthreads();                          // the first half's sums are done
-        if (tid < cnt) {
-#pragma unroll
-            for (int k = 0; k < FS_HALF; k++) if (k < nv) V[rk][k] = val[v0 + k];
-        }
-        __syncthreads();
-        // owner (frame f, value v) adds the block's observations of frame f in permutation order;
-        // loads are issued four at a time, the additions keep their order
         for (int e = tid; e < nF * nv; e += FS_BLK) {
             int f = e / nv, v = e - f * nv;
             double acc = 0;
@@ -1557,148 +1503,4 @@ __global__ void __launch_bounds__(256) k_assemble_flat(DevBatch B, DevOpt O, int
     // the reduced rhs is kept twice: in the local-space vector, and as row n of the window's S storage
     // (the Cholesky carries it as one more tile row with the same addressing as every other tile)
     if (write_S) { B.rhs[loc] = gi + cs; B.S[A.S_base + (size_t)A.n_red * A.n_red + B.av_red[k]] = gi + cs; }
-}
-
-// =========================================================================================
-// Owner-computes assembly of the reduced system: one wavefront per structurally non-zero
-// block pair (a >= b in elimination order) writes S[a,b] (lower triangle) exactly once:
-//   S_ab = [a,b poses with observations]  (a==b ? sum_o Jp^T Jp : 0) - P[fa,fb]
-//        + sum_cliques C_k[a,b]  + (a==b) mu * clamp(diag_a)
-// Diagonal pairs also produce g_a, diag_a and rhs_a = g_a + sum cs_k - (Y g_l)_a.
-// =========================================================================================
-// DIAG = true : one wavefront per diagonal pair (needs wave reductions over the frame's observations)
-// DIAG = false: 16 lanes per off-diagonal pair (four pairs per wavefront; no cross-lane traffic)
-template <bool DIAG>
-__device__ __forceinline__ void d_assemble(const DevBatch& B, const DevOpt& O, int write_S, int bid, int n_part, int n_qpart) {
-    constexpr int G = DIAG ? 64 : 16;
-    int gidx = (bid * blockDim.x + threadIdx.x) / G, lane = threadIdx.x % G;
-    if (gidx >= (DIAG ? B.n_pd : B.n_po)) return;
-    const Pair& Pr = (DIAG ? B.pair_d : B.pair_o)[gidx];
-    const WinState& s = B.ws[Pr.win];
-    if (!s.need_lin) return;
-    int la = Pr.la, lb = Pr.lb, n = Pr.n, m = Pr.m;
-    double* S = B.S + Pr.S_base;
-    const double* P = B.P + Pr.P_base * GEMM_SPLIT;
-    double acc = 0;                                   // lane k of a diagonal pair's wave: frame sum k (H 0..20 | g 21..26), q = sum Y g_l in lanes 27..32
-    bool obs = DIAG && Pr.fa >= 0;
-    if (obs) {
-        // level 2: lanes v < 33 add this frame's block partials in block order
-        // (block offsets fetched lane-parallel and broadcast, so the value loads do not chain behind index loads)
-        for (int b0 = Pr.fsb0; b0 < Pr.fsb1; b0 += 64) {
-            int myoff = (b0 + lane < Pr.fsb1) ? B.fsb_out0[b0 + lane] : 0;
-            int nn = (Pr.fsb1 - b0) < 64 ? (Pr.fsb1 - b0) : 64;
-#pragma unroll 4
-            for (int c = 0; c < nn; c++) {
-                int off = __shfl(myoff, c, 64);
-                double v = B.fs_part[((size_t)off + Pr.fa) * FS_VAL + (lane < FS_VAL ? lane : 0)];
-                acc += lane < FS_VAL ? v : 0.0;
-            }
-        }
-        // q: the window's landmark parts as k_lm_schur left them (one folded vector, or GEMM_SPLIT partials added in order)
-        if (lane >= FS_VAL && lane < FS_VAL + 6) {
-            const double* Q = B.lmq + Pr.q_base + 6 * Pr.fa + (lane - FS_VAL);
-#pragma unroll
-            for (int q = 0; q < GEMM_SPLIT; q++) if (q < n_qpart) acc += Q[(size_t)q * m];
-        }
-    }
-    // contribution descriptors: lane c of the group keeps descriptor c0 + c (+ G per round) in
-    // registers, so the value loads below do not chain behind descriptor loads
-    int gbase = DIAG ? 0 : (threadIdx.x & 48);            // first lane of my group inside the wave
-    int ncon = Pr.c1 - Pr.c0;
-    // diagonal bookkeeping first (needed for damping)
-    double dg_i = 0;    // lane i < la: raw diag of column i
-    if (DIAG) {
-        double gi = 0, cs = 0;
-        if (obs) {
-            // the frame sums stay in their lanes: each use is one ds_bpermute (a register array indexed by lane spilled to scratch)
-            int i = lane < 6 ? lane : 0;
-            double g0 = __shfl(acc, 21 + i, 64), h0 = __shfl(acc, i * (i + 1) / 2 + i, 64), q0 = __shfl(acc, 27 + i, 64);
-            if (lane < la) { gi = g0; dg_i = h0; cs = -q0; }
-        }
-        for (int cb0 = 0; cb0 < ncon; cb0 += 64) {
-            int myv = (cb0 + lane < ncon) ? B.pc_voff[Pr.c0 + cb0 + lane] : 0;
-            int nn = (ncon - cb0) < 64 ? (ncon - cb0) : 64;
-#pragma unroll 4
-            for (int c = 0; c < nn; c++) {
-                int vo = __shfl(myv, c, 64);
-                if (lane < la) { gi += B.cv_graw[vo + lane]; dg_i += B.cv_dgraw[vo + lane]; cs += B.cv_cs[vo + lane]; }
-            }
-        }
-        if (lane < la) {
-            B.g[Pr.loc_a + lane] = gi; B.diag[Pr.loc_a + lane] = dg_i; B.vc[Pr.loc_a + lane] = gi / clampd(dg_i, O.min_diag, O.max_diag);
-            // the reduced rhs is kept twice: in the local-space vector, and as row n of the window's S storage
-            // (the Cholesky carries it as one more tile row with the same addressing as every other tile)
-            if (write_S) { B.rhs[Pr.loc_a + lane] = gi + cs; S[(size_t)n * n + Pr.ra + lane] = gi + cs; }
-        }
-    }
-    if (!write_S) return;      // final pass: cost + gradient only, keep (S, rhs, L) of the last solve
-    // damping source per entry, fetched in uniform control flow (la*lb <= 81 => two rounds)
-    double dgs0 = 0, dgs1 = 0;
-    if (DIAG) { dgs0 = __shfl(dg_i, (lane / lb) & 63, 64); dgs1 = __shfl(dg_i, ((lane + 64) / lb) & 63, 64); }
-    // per-entry contribution sums; descriptors broadcast from the holding lane
-    int nent = la * lb;
-    constexpr int NR = DIAG ? 2 : 6;               // la * lb <= 81 entries over G lanes
-    // entry (i, j) of every round, computed once (the divisions used to sit in the contribution loop)
-    int ei[NR], ej[NR];
-    bool ev[NR];
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-        int e = lane + r * G;
-        ev[r] = e < nent;
-        int i = ev[r] ? e / lb : 0;
-        ei[r] = i; ej[r] = ev[r] ? e - i * lb : 0;
-    }
-    // rounds this wave needs: the largest entry count of its pairs (the host sorts the off-diagonal pairs by size, so the
-    // waves are homogeneous and a wave of 1x6 / 1x1 pairs runs one round instead of six); wave-uniform, from ballots
-    int nrw = 0;
-#pragma unroll
-    for (int r = NR - 1; r >= 0; r--) if (nrw == 0 && __ballot(nent > r * G) != 0ULL) nrw = r + 1;
-    nrw = __builtin_amdgcn_readfirstlane(nrw);
-    double vsum[NR], hsum[NR];
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-        vsum[r] = 0; hsum[r] = 0;
-        if (obs) { int i = ei[r] < 6 ? ei[r] : 0, j = ej[r] < 6 ? ej[r] : 0, hi = i > j ? i : j, lo = i > j ? j : i; hsum[r] = __shfl(acc, hi * (hi + 1) / 2 + lo, 64); }
-    }
-    for (int cb0 = 0; cb0 < ncon; cb0 += G) {
-        long long myo = (cb0 + lane < ncon) ? B.pc_coff[Pr.c0 + cb0 + lane] : 0;
-        int myl = (cb0 + lane < ncon) ? B.pc_cld[Pr.c0 + cb0 + lane] : 0;
-        int nn = (ncon - cb0) < G ? (ncon - cb0) : G;
-        // loads are unconditional (invalid lanes read entry (0,0)) so several contributions are in flight;
-        // every entry is still summed in contribution order
-#pragma unroll 4
-        for (int c = 0; c < nn; c++) {
-            long long co = __shfl(myo, gbase + c, 64);
-            int cl = __shfl(myl, gbase + c, 64);
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                if (r < nrw) {
-                    double cv = B.C[co + (size_t)ei[r] * cl + ej[r]];
-                    vsum[r] += ev[r] ? cv : 0.0;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-        int e = lane + r * G;
-        if (!ev[r]) continue;
-        int i = ei[r], j = ej[r];
-        if (DIAG && j > i) continue;                // lower half only; the mirror is the host's job at export
-        double v = vsum[r];
-        if (Pr.fa >= 0 && Pr.fb >= 0) {
-            int pr = 6 * Pr.fa + i, pc = 6 * Pr.fb + j;
-            size_t pi = (pr >= pc) ? (size_t)pr * m + pc : (size_t)pc * m + pr;
-            if (n_part == 0) v = S[(size_t)(Pr.ra + i) * n + Pr.rb + j] + v;         // k_lm_schur left -P in place (s_direct): -P + c == c - P
-            else {
-                double ps = 0;
-#pragma unroll
-                for (int q = 0; q < GEMM_SPLIT; q++) if (q < n_part) ps += P[(size_t)q * m * m + pi];     // fixed order (n_part = 1: folded by k_lm_schur)
-                v -= ps;
-            }
-            if (obs) v += hsum[r];
-        }
-        if (DIAG && i == j) v += s.mu * damp_diag(O, e < 64 ? dgs0 : dgs1, B.jsc + Pr.loc_a + i, s.iter == 0);
-        S[(size_t)(Pr.ra + i) * n + Pr.rb + j] = v;      // lower triangle only; exports mirror on the host
-    }
 }

@@ -346,230 +346,6 @@ __device__ __forceinline__ bool chol_pivot_tile(double (*D)[17], double (*LiJ)[1
     return bad;
 }
 
-// =========================================================================================
-// k_chol_rr2 — the register-resident tiled Cholesky with ROLE-SPECIALISED waves and lookahead.
-//   wave 0       "pivot wave": factors + inverts the 16x16 diagonal tiles (lane = row / column,
-//                v_readlane broadcasts) and does the small solves of the backward pass.  It owns
-//                no tiles, so its register budget is free for the pivot arrays (no spills).
-//   waves 1..15  own the tiles, owner(I,J) = 1 + (I+J) mod 15, <= 9 tiles each at n_red <= 240.
-// Step j:  [pivot: factor tile j]  B_j  [panel column j on MFMA]  C_j  [owner updates tile
-// (j+1,j+1) first and publishes it]  A_{j+1}  [remaining trailing updates  ||  pivot: factor
-// tile j+1].  Three workgroup barriers per step; every wave executes the same barrier sequence.
-// Plain dense Cholesky of S in the predefined elimination order, only tiled.
-// =========================================================================================
-template <int RR_NS>
-__global__ void __launch_bounds__(1024) k_chol_rr2(DevBatch B) {
-    __shared__ double Pn[16][16][17];
-    __shared__ double Li[16][16][17];
-    __shared__ double Dt[2][16][17];           // published diagonal tiles, double-buffered
-    __shared__ double dinv[16];
-    __shared__ double zs[256];
-    __shared__ double yv[256];
-    __shared__ int sI_t[16][10], sJ_t[16][10];
-    __shared__ int fail;
-    int w = blockIdx.x;
-    WinState& st = B.ws[w];
-    if (!st.need_lin || st.lin_fail) return;
-    const WinRec& W = B.win[w];
-    int n = W.n_red, tid = threadIdx.x;
-    if (n <= 0 || n > 240) return;                 // larger windows of a mixed batch belong to k_chol_big (launched next to this one)
-    int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    int Tc = (n + 15) >> 4, Tr = Tc + 1;
-    if (tid == 0) fail = 0;
-#ifdef SWF_PROFILE_CHOL
-    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 64; i++) g_chol_stamps[i] = 0;
-    unsigned long long tq = 0;
-#endif
-    CHSTAMP(0);
-#ifdef SWF_PROFILE_CHOL
-    if (blockIdx.x == 0 && lane == 0) g_chol_stamps[32 + wv] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);   // HW_ID
-#endif
-    if (wv == 0) {
-        // =============================== pivot wave ===============================
-#ifdef SWF_CHOL_PRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
-        __syncthreads();                                   // tables / fail initialised
-        __syncthreads();                                   // A_0: tile (0,0) published
-        CHSTAMP(3);
-        for (int j = 0; j < Tc; j++) {
-            double (*D)[17] = Dt[j & 1];
-#ifdef SWF_PROFILE_CHOL
-            tq = __builtin_amdgcn_s_memtime();
-#endif
-            bool bad = chol_pivot_tile(D, Li[j], li, lk, dinv);
-            if (bad && lane == 0) fail = 1;
-            CHACC(9, tq);
-#ifdef SWF_PROFILE_CHOL
-            tq = __builtin_amdgcn_s_memtime();
-#endif
-            __syncthreads();                               // B_j
-            CHACC(8, tq);
-#ifdef SWF_PROFILE_CHOL
-            tq = __builtin_amdgcn_s_memtime();
-#endif
-            if (fail) { if (tid == 0) { st.lin_fail = 1; st.chol_fail = 1; } return; }
-            __syncthreads();                               // C_j
-            CHACC(10, tq);
-#ifdef SWF_PROFILE_CHOL
-            tq = __builtin_amdgcn_s_memtime();
-#endif
-            __syncthreads();                               // A_{j+1}
-            CHACC(11, tq);
-        }
-        CHSTAMP(1);
-        __syncthreads();                                   // E: L exported, yv ready, zs cleared
-        CHSTAMP(4);
-        // backward solve y = L^-T z, right-looking: yv holds z; once y_J is known the tiles of row J subtract
-        // L_{J,J'}^T y_J from the pending blocks J' < J.  Here: y_J = Linv_JJ^T yv_J on all 64 lanes
-        // (lane (li, lk) sums the rows r = lk + 4q, then two cross-row steps).
-        for (int J = Tc - 1; J >= 0; J--) {
-            double p = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) p += Li[J][lk + 4 * q][li] * yv[16 * J + lk + 4 * q];
-            p += __shfl_xor(p, 16, 64);
-            p += __shfl_xor(p, 32, 64);
-            if (lk == 0) zs[16 * J + li] = p;
-            __syncthreads();                               // X_J: y_J published
-            __syncthreads();                               // Y_J: row J applied to the pending blocks
-        }
-        CHSTAMP(2);
-        return;
-    }
-    // =============================== tile waves ===============================
-    const double* S = B.S + W.S_base;
-    const double* rhs = B.rhs + W.loc_base + W.n_e;
-    double* Lrm = B.L + W.Lt_base;
-    // tile table of this wave, in closed form: wave wv owns the tiles with (I + J) mod 15 == wv - 1.  Column J (one
-    // lane each) has at most two of them: I0 = J + ((wv - 1 - 2J) mod 15) and I0 + 15; slots follow (J, I) order.
-    {
-        if (lane < 10) { sI_t[wv][lane] = -1; sJ_t[wv][lane] = -1; }
-        int k = wv - 1, J = lane;
-        int d = (k - 2 * J) % 15; if (d < 0) d += 15;
-        int I0 = J + d, I1 = I0 + 15;
-        bool c0 = J < Tc && I0 < Tr, c1 = J < Tc && I1 < Tr;
-        unsigned long long m0 = __ballot(c0), m1 = __ballot(c1), lt = (1ULL << lane) - 1ULL;
-        int slot = __popcll(m0 & lt) + __popcll(m1 & lt);
-        if (c0 && slot < 10) { sI_t[wv][slot] = I0; sJ_t[wv][slot] = J; }
-        if (c1 && slot + 1 < 10) { sI_t[wv][slot + 1] = I1; sJ_t[wv][slot + 1] = J; }
-    }
-    for (int e = tid - 64; e < 256; e += 960) zs[e] = 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    int sI[RR_NS], sJ[RR_NS];
-    double4_t acc[RR_NS];
-    // all loads of the wave's tiles are issued branch-free (clamped addresses, values selected afterwards):
-    // S is stored lower; diagonal tiles are loaded fully symmetric (the pivot wave needs both triangles);
-    // the extra tile row Tc carries the right-hand side in its first row; padding rows/columns are identity
-#pragma unroll
-    for (int s = 0; s < RR_NS; s++) {                          // wave-uniform: keep the tile coordinates in SGPRs
-        sI[s] = __builtin_amdgcn_readfirstlane(sI_t[wv][s]); sJ[s] = __builtin_amdgcn_readfirstlane(sJ_t[wv][s]);
-    }
-#pragma unroll
-    for (int s = 0; s < RR_NS; s++) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int I = sI[s], J = sJ[s];
-            int r = 16 * I + lk + 4 * q, c = 16 * J + li;
-            bool rhs_el = I == Tc && lk + 4 * q == 0;                 // row n of the S storage = reduced rhs
-            int rr = rhs_el ? n : r;
-            bool inside = I >= 0 && c < n && (rhs_el || (r < n && (c <= r || I == J)));
-            int rc = rr < n ? rr : (rhs_el ? n : n - 1), cc = c < n ? c : n - 1;
-            if (I < 0) { rc = 0; cc = 0; }
-            int off = (cc > rc) ? cc * n + rc : rc * n + cc;          // 32-bit element offset from the one S base
-            double v = S[off];
-            acc[s][q] = inside ? v : ((I >= 0 && I < Tc && r == c) ? 1.0 : 0.0);
-        }
-    }
-    __syncthreads();                                       // tables / fail initialised (pairs with pivot)
-#pragma unroll
-    for (int s = 0; s < RR_NS; s++)
-        if (sI[s] == 0 && sJ[s] == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) Dt[0][lk + 4 * q][li] = acc[s][q];
-        }
-    __syncthreads();                                       // A_0
-    for (int j = 0; j < Tc; j++) {
-        __syncthreads();                                   // B_j: L_jj, Linv_jj ready; trailing updates of step j-1 done
-        if (fail) return;
-        // panel of column j
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++) {
-            if (sJ[s] != j) continue;
-            int I = sI[s];
-            if (I == j) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) acc[s][q] = Dt[j & 1][lk + 4 * q][li];
-                continue;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = acc[s][q];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++) {
-            if (sJ[s] != j || sI[s] == j) continue;
-            int I = sI[s];
-            double4_t X = { 0, 0, 0, 0 };
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[I][li][lk + 4 * kk], Li[j][li][lk + 4 * kk], X, 0, 0, 0);
-            acc[s] = X;
-#pragma unroll
-            for (int q = 0; q < 4; q++) Pn[I][lk + 4 * q][li] = X[q];
-        }
-        __syncthreads();                                   // C_j: panel published
-        // lookahead: the next diagonal tile first, published for the pivot wave
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++) {
-            if (sI[s] != j + 1 || sJ[s] != j + 1) continue;
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[j + 1][li][lk + 4 * kk], Pn[j + 1][li][lk + 4 * kk], acc[s], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; q++) Dt[(j + 1) & 1][lk + 4 * q][li] = acc[s][q];
-        }
-        __syncthreads();                                   // A_{j+1}
-        // remaining trailing updates (overlap with the pivot wave's factorisation of tile j+1)
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++) {
-            int J = sJ[s], I = sI[s];
-            if (J <= j || I < 0 || (I == j + 1 && J == j + 1)) continue;
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[I][li][lk + 4 * kk], Pn[J][li][lk + 4 * kk], acc[s], 0, 0, 0);
-        }
-    }
-    // export L (row-major lower), y = L^-1 rhs from the rhs tile row
-#pragma unroll
-    for (int s = 0; s < RR_NS; s++) {
-        int I = sI[s], J = sJ[s];
-        if (I < 0) continue;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int r = 16 * I + lk + 4 * q, c = 16 * J + li;
-            if (I < Tc) { if (r < n && c <= r) Lrm[(size_t)r * n + c] = acc[s][q]; }
-            else if (lk + 4 * q == 0) yv[c] = acc[s][q];
-        }
-    }
-    __syncthreads();                                       // E
-    for (int J = Tc - 1; J >= 0; J--) {
-        __syncthreads();                                   // X_J: y_J published
-#pragma unroll
-        for (int s = 0; s < RR_NS; s++) {
-            if (sI[s] != J || sJ[s] >= J) continue;        // tiles (J, J') of row J, J' < J: yv_J' -= L_{J,J'}^T y_J
-            double p = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) p += acc[s][q] * zs[16 * J + lk + 4 * q];
-            p += __shfl_xor(p, 16, 64);
-            p += __shfl_xor(p, 32, 64);
-            if (lk == 0) yv[16 * sJ[s] + li] -= p;
-        }
-        __syncthreads();                                   // Y_J
-    }
-    double* y = B.y + W.loc_base + W.n_e;
-    for (int e = tid - 64; e < n; e += 960) y[e] = zs[e];
-}
-
-#include "swf_chol_rr.h"
 #include "swf_chol_rr4.h"
 
 // =========================================================================================
@@ -1196,12 +972,6 @@ __global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs 
     else if (bid < S.e[2]) d_eval_prior<false>(B, bid - S.e[1], sm_prior);
     else if (WITH_IMU) d_eval_imu<false>(B, bid - S.e[2]);    // candidate IMU residuals (8 factors per workgroup), small batches only
 }
-// diagonal + off-diagonal block assembly of the reduced system
-__global__ void __launch_bounds__(256) k_assemble_all(DevBatch B, DevOpt O, int write_S, Segs S, int n_part, int n_qpart) {
-    int bid = blockIdx.x;
-    if (bid < S.e[0]) d_assemble<true>(B, O, write_S, bid, n_part, n_qpart);
-    else d_assemble<false>(B, O, write_S, bid - S.e[0], n_part, n_qpart);
-}
 
 // =========================================================================================
 // per-window control kernels (one 256-thread workgroup per window)
@@ -1455,6 +1225,7 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     if (!go) return;
     // ComputeTraditionalDoglegStep in the scaled space, un-scaled on the fly
     double gnorm = sqrt(gsq), gnn = sqrt(ynn), alpha = s.alpha, radius = s.radius;
+    const double mu_s = s.mu;
     int mode; double c1 = 0, c2 = 0;          // step = c1 * g / dclamp + c2 * y
     double dnorm;
     if (O.strategy == SWF_LEVENBERG_MARQUARDT) { mode = 0; c1 = 0; c2 = -1.0; dnorm = gnn; }      // the damped step itself
@@ -1475,11 +1246,30 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     //   H y = g - mu D^2 y          (y solves the damped system)  =>  v^T H y = |g / D|^2 - mu g.y,   y^T H y = g.y - mu |D y|^2,
     // and g.v = |g / D|^2: every term is one of the sums of the pass above.  (The identity holds to the backward error of the linear
     // solve, 1e-12 of the terms; round 1 re-read every Jacobian for this — 73 + 35 us per iteration of the cfg4 batch.)
-    if (tid == 0) {
-        const double gy = -gdot, mu = s.mu;
+    // (every thread forms it: an invalid step — model cost change not positive, TrustRegionMinimizer::HandleInvalidStep — is handled HERE,
+    // before any candidate is evaluated, so that no kernel behind this one sees a candidate of such a step: the speculative flow keeps the
+    // Jacobians of x in place for the re-linearisation that follows.  Same bookkeeping as k_decide's branch of the same name.)
+    double mcc;
+    {
+        const double gy = -gdot, mu = mu_s;
         const double sHs = c1 * c1 * jg_sq + 2.0 * c1 * c2 * (gsq - mu * gy) + c2 * c2 * (gy - mu * ynn);
-        s.model_cost_change = -(c1 * gsq + c2 * gy + 0.5 * sHs);
+        mcc = -(c1 * gsq + c2 * gy + 0.5 * sHs);
     }
+    if (!(mcc > 0.0)) {
+        __syncthreads();                                   // (uniform: every thread holds the same mcc; all reads of the window's state lie before)
+        if (tid == 0) {
+            swf_iteration& rec = tr[s.iter < B.max_iter_trace ? s.iter : B.max_iter_trace - 1];
+            s.model_cost_change = mcc; s.eval_cand = 0;
+            rec.model_cost_change = mcc;
+            rec.step_is_valid = 0; rec.cost = s.x_cost; rec.trust_region_radius = s.radius;
+            s.reuse = 0; s.need_lin = 1;
+            if (++s.invalid_run >= 5) s.status = SWF_LINEAR_SOLVER_FAILURE;
+            else if (O.strategy == SWF_LEVENBERG_MARQUARDT) { s.radius /= s.lm_dec; s.lm_dec *= 2.0; s.mu = 1.0 / s.radius; rec.trust_region_radius = s.radius; }
+            else s.mu *= O.mu_inc;
+        }
+        return;
+    }
+    if (tid == 0) s.model_cost_change = mcc;
     // the step and the candidate = Plus(x, step) in one pass over the local dimensions, from the registers of the pass above; the pose
     // threads form their six step entries from the same operands (the same bits as step[]) and apply PoseLocalParameterization::Plus
     double a_s = 0, a_n = 0;

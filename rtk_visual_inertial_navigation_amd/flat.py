@@ -50,7 +50,7 @@ class OptionsC(C.Structure):
     _fields_ = [
         ("max_num_iterations", C.c_int32), ("step_mode", C.c_int32),
         ("num_threads", C.c_int32), ("trust_region_strategy", C.c_int32),
-        ("jacobi_scaling", C.c_int32), ("reserved", C.c_int32),
+        ("jacobi_scaling", C.c_int32), ("composite_root", C.c_int32),
         ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
@@ -60,7 +60,7 @@ class OptionsC(C.Structure):
     ]
 
 
-def default_options(max_num_iterations=8, step_mode=0, num_threads=1, strategy=0, jacobi_scaling=0):
+def default_options(max_num_iterations=8, step_mode=0, num_threads=1, strategy=0, jacobi_scaling=0, composite_root=0):
     """Solver::Options the reference sets (R/swf/swf.cpp:25-30) + Ceres 2.x defaults."""
     o = OptionsC()
     o.max_num_iterations = max_num_iterations
@@ -68,7 +68,7 @@ def default_options(max_num_iterations=8, step_mode=0, num_threads=1, strategy=0
     o.num_threads = num_threads
     o.trust_region_strategy = strategy          # 0 DOGLEG (R/swf/swf.cpp:26), 1 LEVENBERG_MARQUARDT (ceres default)
     o.jacobi_scaling = jacobi_scaling           # 0 what the reference's window solves set; 1 ceres default (LM only)
-    o.reserved = 0
+    o.composite_root = composite_root    # 0 pivoted Cholesky root, 1 the reference's eigen root (composite IMU-GNSS factors inside a solve)
     o.initial_trust_region_radius = 1e4
     o.max_trust_region_radius = 1e16
     o.min_trust_region_radius = 1e-32

@@ -127,6 +127,31 @@ def solve(win, opt=None, export=True):
     return sm, out
 
 
+class composite_eig_cut:
+    """Context manager around oracle solves: the composite factors' eigen square root cuts at max(1e-8, rel * lambda_max) instead of the
+    reference's absolute 1e-8 (oracle/swf_oracle.c: the NOISE-FREE restatement; rel = 0 is the reference, literally).  .noise() returns
+    (sum of r_k^2 / 2, count) over the noise eigenvalues (<= 1e-14 lambda_max) that were KEPT since the context was entered."""
+    def __init__(self, rel):
+        self.rel = float(rel)
+
+    def __enter__(self):
+        l = lib()
+        l.oracle_set_composite_eig_cut.restype = None
+        l.oracle_set_composite_eig_cut(C.c_double(self.rel))
+        l.oracle_composite_noise_stats.restype = None
+        l.oracle_composite_noise_stats(None, None, 1)
+        return self
+
+    def noise(self):
+        c, k = C.c_double(0), C.c_longlong(0)
+        lib().oracle_composite_noise_stats(C.byref(c), C.byref(k), 0)
+        return c.value, k.value
+
+    def __exit__(self, *a):
+        lib().oracle_set_composite_eig_cut(C.c_double(0.0))
+        return False
+
+
 def eval_proj(pose, ex, lm, uv, sqrt_info, pbg):
     r, Jp, Jex, Jlm = np.zeros(2), np.zeros((2, 6)), np.zeros((2, 6)), np.zeros((2, 3))
     a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pose, ex, lm, uv, pbg)]

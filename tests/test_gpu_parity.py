@@ -293,6 +293,70 @@ def test_streamed_cholesky_over_the_chip_equals_the_single_workgroup_kernel_bitw
         assert all(np.array_equal(c.a[k], one.a[k]) for k in ("pose", "sb", "lm", "sc"))
 
 
+def test_speculative_dogleg_flow_equals_the_two_pass_flow_bitwise(monkeypatch):
+    """The dogleg loop evaluates the candidate of a proposed step WITH its Jacobians (an accepted candidate is the next linearisation
+    point: one pass instead of a cost pass at the candidate and a Jacobian pass at the same point behind k_decide); SWF_NO_SPEC_EVAL=1
+    keeps the two passes, SWF_NO_LAT_FUSE=1 the batch launch shapes for a few windows.  Same device functions, same operands: iteration
+    rows and end states bit for bit — for windows that accept every step, windows that reject steps (a small initial radius), a window
+    with a variable extrinsic and inverse-depth landmarks (generic two-row factors), a large prior (its own evaluation launch), and a
+    batch that runs the clique branch on the auxiliary stream."""
+    import idepth_gen as ig
+    ws = [synth.make_window(3, K=9, F=50, S=6, seed=160), synth.make_window(2, K=6, F=30, S=0, seed=161),
+          synth.with_variable_extrinsic(synth.make_window(2, K=6, F=30, S=0, seed=162)),
+          ig.convert_short_tracks(synth.make_window(2, K=7, F=40, seed=163), max_track=5),
+          synth.make_window(3, K=26, F=40, S=5, seed=164), synth.make_window(3)]
+    keys = ("pose", "sb", "lm", "sc")
+
+    def shaken(w, seed):
+        # far from the minimum (metres, tenths of a radian): Gauss-Newton steps that overshoot and get rejected
+        rng = np.random.default_rng(seed); c = w.copy()
+        c.a["pose"][:, :3] += rng.normal(0, 1.0, c.a["pose"][:, :3].shape)
+        for q in c.a["pose"][:, 3:7]:
+            d = np.append(rng.normal(0, 0.15, 3), 1.0); d /= np.linalg.norm(d)
+            x, y, z, w_ = q; dx, dy, dz, dw = d
+            q[:] = (w_ * dx + x * dw + y * dz - z * dy, w_ * dy - x * dz + y * dw + z * dx, w_ * dz + x * dy - y * dx + z * dw, w_ * dw - x * dx - y * dy - z * dz)
+        c.a["lm"] += rng.normal(0, 2.0, c.a["lm"].shape)
+        return c
+    base = ws
+    for r0 in (1e4, 0.05, -1.0):
+        opt = default_options(max_num_iterations=10)
+        opt.initial_trust_region_radius = r0 if r0 > 0 else 1e4
+        ws = base if r0 > 0 else [shaken(w, 170 + i) for i, w in enumerate(base[:3])]
+        got = {}
+        for mode, env in (("spec", {}), ("two-pass", {"SWF_NO_SPEC_EVAL": "1"}), ("spec, batch shapes", {"SWF_NO_LAT_FUSE": "1"})):
+            for k in ("SWF_NO_SPEC_EVAL", "SWF_NO_LAT_FUSE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            res = []
+            for w in ws:
+                c = w.copy()
+                bs = solver.BatchSolver([c]); sm = bs.solve(opt)[0]; bs.close()
+                res.append(([(r["cost"], r["step_norm"], r["trust_region_radius"], r["step_is_successful"], r["gradient_max_norm"]) for r in sm.rows()], sm.termination,
+                            np.concatenate([c.a[k].ravel() for k in keys])))
+            got[mode] = res
+        for k in ("SWF_NO_SPEC_EVAL", "SWF_NO_LAT_FUSE"):
+            monkeypatch.delenv(k, raising=False)
+        if r0 < 0: assert any(not r[3] for res in got["spec"] for r in res[0][1:]), "the shaken windows were meant to produce rejected steps"
+        for mode in ("two-pass", "spec, batch shapes"):
+            for i, (a, b_) in enumerate(zip(got["spec"], got[mode])):
+                assert a[0] == b_[0] and a[1] == b_[1], (r0, mode, i)
+                assert np.array_equal(a[2], b_[2]), (r0, mode, i)
+    ws = base
+    # 160 windows: between half a chip and a chip of windows the IMU / clique branch rides the auxiliary stream behind k_decide
+    many = [ws[i % 2].copy() for i in range(160)]
+    bs = solver.BatchSolver(many); sms = bs.solve(default_options(max_num_iterations=10)); bs.close()
+    opt = default_options(max_num_iterations=10)
+    for i in range(2):
+        c = ws[i].copy()
+        monkeypatch.setenv("SWF_NO_SPEC_EVAL", "1")
+        bs = solver.BatchSolver([c]); sm = bs.solve(opt)[0]; bs.close()
+        monkeypatch.delenv("SWF_NO_SPEC_EVAL", raising=False)
+        for j in range(i, 160, 2):
+            assert [r["cost"] for r in sms[j].rows()] == [r["cost"] for r in sm.rows()], j
+            assert all(np.array_equal(many[j].a[k], c.a[k]) for k in keys), j
+
+
 def test_landmark_quarters_per_block_and_kernel_variant_do_not_change_results(monkeypatch):
     """k_lm_schur lets one workgroup process 1 .. 16 landmark parts (chosen from the batch size) and is
     instantiated per tile count; every quarter keeps its own partial product and the arithmetic is pinned, so all

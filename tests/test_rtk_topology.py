@@ -128,18 +128,15 @@ def test_device_epoch_priors_and_composite_topology(kw, monkeypatch):
     assert np.abs(wd.a["sc"] - wo.a["sc"]).max() < 1e-4 and np.abs(wd.a["lm"] - wo.a["lm"]).max() < 1e-3
     # ... and the gap DEMONSTRATED rather than asserted around.  Same input for both solvers (the oracle-built window), so
     # nothing but the solvers differs: (1) they take the same accept / reject decisions and end 1e-5 apart or closer; (2) the device's
-    # choice of square root is not what separates them — the reference's eigen square root on the device (SWF_COMP_EIGEN_ROOT) gives the
+    # choice of square root is not what separates them — the reference's eigen square root on the device (swf_options::composite_root) gives the
     # pivoted factor's trajectory to 1e-6; (3) the composite-window COSTS differ by up to 15 % from the first step on while the states
     # agree: the difference is the oracle's (= the reference's) pseudo-inverse keeping eigenvalues between 1e-8 and eps lambda_max —
     # rounding noise of a matrix with entries of 1e8 — whose r_k = v_k^T rhs / sqrt(lambda_k) are of order one; measured with ONE cost
     # function that has no square root in it, the explicit problem's, the two solutions are the same point.
     sols = {}
     for root in ("pivoted", "eigen"):
-        if root == "eigen":
-            monkeypatch.setenv("SWF_COMP_EIGEN_ROOT", "1")
         ws_ = wo_in.copy()
-        bsx = solver.BatchSolver([ws_]); sx = bsx.solve(default_options(max_num_iterations=30))[0]; bsx.close()
-        monkeypatch.delenv("SWF_COMP_EIGEN_ROOT", raising=False)
+        bsx = solver.BatchSolver([ws_]); sx = bsx.solve(default_options(max_num_iterations=30, composite_root=1 if root == "eigen" else 0))[0]; bsx.close()
         assert [r["step_is_successful"] for r in sx.rows()] == [r["step_is_successful"] for r in so.rows()], root
         assert abs(sx.rows()[0]["cost"] - so.rows()[0]["cost"]) <= 1e-10 * so.rows()[0]["cost"]
         assert np.abs(ws_.a["pose"] - wo.a["pose"]).max() < 1e-5 and np.abs(ws_.a["comp_pose"] - wo.a["comp_pose"]).max() < 1e-5

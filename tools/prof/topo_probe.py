@@ -14,10 +14,8 @@ for kw in T.CASES:
     w_or = wo.copy()
     so, _ = ob.solve(w_or, default_options(max_num_iterations=30), export=False)
     for root in ("pivoted", "eigen"):
-        if root == "eigen": os.environ["SWF_COMP_EIGEN_ROOT"] = "1"
-        else: os.environ.pop("SWF_COMP_EIGEN_ROOT", None)
         wd = wo.copy()
-        bs = solver.BatchSolver([wd]); sd = bs.solve(default_options(max_num_iterations=30))[0]; bs.close()
+        bs = solver.BatchSolver([wd]); sd = bs.solve(default_options(max_num_iterations=30, composite_root=1 if root == "eigen" else 0))[0]; bs.close()
         ro, rd = so.rows(), sd.rows()
         same = [r["step_is_successful"] for r in rd] == [r["step_is_successful"] for r in ro]
         dc = [abs(a["cost"] - b["cost"]) / (abs(b["cost"]) + 1e-3) for a, b in zip(rd, ro)]
