@@ -30,6 +30,7 @@ struct WinRec {
     int fsb0, fsb1;              // frame-sum blocks of this window
     int tail_dim;                // dimensions of the parameter_head tail (last rows of the reduced system): the block of L its consumers read
     int n_pose_blk;              // the window's first n_pose_blk blocks are its pose blocks (7 -> 6, PoseLocalParameterization)
+    int lmb0, lmb1;              // landmark back-substitution blocks of this window (DevBatch::lmb_rec)
     double proj_sqrt_info, proj_loss_a;
     double pbg[3], gw[3], base[3];
 };
@@ -129,7 +130,11 @@ struct DevBatch {
     const int* p_win; const int* p_xpose; const int* p_xex; const int* p_xlm;
     const int* p_lpose; const int* p_llm; const int* p_fr; const int* p_lm;
     const double* p_uv;
-    double* p_r; double* p_Jp; double* p_Jl; double* p_cost; double* p_aux;
+    double* p_r; double* p_Jp; double* p_Jl;
+    // block partial sums (round 6): the cost of a frame-sum block's observations (written by every projection evaluation, one value per
+    // block) and |J D^-2 g|^2 of a landmark back-substitution block's observations (k_post_chol).  The per-window control kernels add
+    // a dozen block values in block order instead of reading 16 B per observation; per-observation costs are not stored any more.
+    double* p_cpart; double* p_apart;
     // two-level per-frame sums: blocks of <= 256 observations of one window
     int n_fsb; const int* fsb_win; const int* fsb_obs0; const int* fsb_perm; const int* fsb_foff; const int* fsb_foff0; const int* fsb_out0;
     double* fs_part;

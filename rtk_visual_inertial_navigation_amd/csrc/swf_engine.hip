@@ -234,6 +234,8 @@ struct swf_batch {
         if (aux) { (void)hipStreamSynchronize(aux); handle_cache().give(aux); }
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
+    WinState* ws_primary = nullptr; WinState* ws_alt = nullptr;      // the per-window solver states and the second buffer the latency path's fused step kernel alternates with
+    bool no_step_fuse = false;            // SWF_NO_STEP_FUSE=1: k_dogleg and the candidate's evaluation as two launches on the latency path too (parity: bit-identical)
     bool no_spec = false;                 // SWF_NO_SPEC_EVAL=1: the dogleg loop with a cost pass at the candidate and a Jacobian pass behind k_decide (parity: bit-identical to the speculative flow)
     bool no_comp_fuse = false;            // SWF_NO_COMP_FUSE=1: the composite chain and the visual branch as launches of their own on the latency path too (A/B, parity)
     bool lat_fuse = false;                // latency path: fused grids on one stream (see swf_batch_create)
@@ -848,6 +850,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     // swf_solve_batches.  Nothing that changes RESULTS is an environment variable: those are fields of swf_options.)
     b->no_comp_fuse = getenv("SWF_NO_COMP_FUSE") != nullptr;
     b->no_spec = getenv("SWF_NO_SPEC_EVAL") != nullptr;
+    b->no_step_fuse = getenv("SWF_NO_STEP_FUSE") != nullptr;
     // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
     // fills what one-block-per-window kernels leave idle (measured: 256 windows 5.52 -> 5.22 ms, 128 windows 3.73 -> 3.49 ms per solve; 64 and
     // 512 windows: no gain)
@@ -873,8 +876,31 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     DevPool& P = b->pool;
     int rc = 0;
     D.n_win = n; D.n_x = (int)B.n_x; D.n_loc_total = (int)B.n_loc; D.max_iter_trace = SWF_MAX_TRACE;
+    std::vector<int> lmb_lr;
+    {
+        // landmark back-substitution blocks: consecutive landmarks of one window with at most 256 observations together
+        // (built before the window records are uploaded: a window knows its block range, WinRec::lmb0 / lmb1)
+        std::vector<int>& lr = lmb_lr;
+        std::vector<int> obs0 = B.lm_obs0; obs0.push_back((int)B.p_win.size());
+        for (WinRec& Wr : B.win) {
+            Wr.lmb0 = (int)(lr.size() / 4);
+            int l = Wr.lm0;
+            while (l < Wr.lm1) {
+                const int o0 = obs0[(size_t)l]; int l1 = l, cnt = 0;
+                while (l1 < Wr.lm1 && l1 - l < 256 && cnt + (obs0[(size_t)l1 + 1] - obs0[(size_t)l1]) <= 256) { cnt += obs0[(size_t)l1 + 1] - obs0[(size_t)l1]; l1++; }
+                if (l1 == l) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "landmark with more than 256 observations"); }
+                lr.push_back(o0); lr.push_back(cnt); lr.push_back(l); lr.push_back(l1 - l);
+                l = l1;
+            }
+            Wr.lmb1 = (int)(lr.size() / 4);
+        }
+        D.n_lmb = (int)(lr.size() / 4);
+        if (lr.empty()) lr.resize(4, 0);
+        b->win = B.win;                                   // (the host's copy of the records, with the block ranges)
+    }
 #define PUT(field, vec) rc |= P.put(vec, &D.field)
     PUT(win, B.win);
+    PUT(lmb_rec, lmb_lr);
     PUT(blk_xoff, B.blk_xoff); PUT(blk_loc, B.blk_loc); PUT(blk_gs, B.blk_gs);
     if (B.loc2x.empty()) B.loc2x.push_back(-1);
     PUT(loc2x, B.loc2x); PUT(x_var, B.x_var);
@@ -884,23 +910,6 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     D.n_lm = (int)B.lm_win.size();
     B.lm_obs0.push_back(D.n_proj);
     PUT(lm_win, B.lm_win); PUT(lm_obs0, B.lm_obs0); PUT(lm_loc, B.lm_loc); PUT(lm_col, B.lm_col); PUT(lm_fmask, B.lm_fmask);
-    {
-        // landmark back-substitution blocks: consecutive landmarks of one window with at most 256 observations together
-        std::vector<int> lr;
-        for (const WinRec& Wr : B.win) {
-            int l = Wr.lm0;
-            while (l < Wr.lm1) {
-                const int o0 = B.lm_obs0[(size_t)l]; int l1 = l, cnt = 0;
-                while (l1 < Wr.lm1 && l1 - l < 256 && cnt + (B.lm_obs0[(size_t)l1 + 1] - B.lm_obs0[(size_t)l1]) <= 256) { cnt += B.lm_obs0[(size_t)l1 + 1] - B.lm_obs0[(size_t)l1]; l1++; }
-                if (l1 == l) { P.release(); delete b; return fail(SWF_E_UNSUPPORTED, "landmark with more than 256 observations"); }
-                lr.push_back(o0); lr.push_back(cnt); lr.push_back(l); lr.push_back(l1 - l);
-                l = l1;
-            }
-        }
-        D.n_lmb = (int)(lr.size() / 4);
-        if (lr.empty()) lr.resize(4, 0);
-        PUT(lmb_rec, lr);
-    }
     {
         // k_lm_schur's launch shape: the row class of the panel by the batch's largest window (<= 10 / 21 / 42 / 64 observing frames) and
         // the landmark parts per block — as many as still leave >= 2 blocks per CU.  SWF_LS_VARIANT / SWF_LS_QPB: test / debugging aids.
@@ -1203,10 +1212,11 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     if (b->max_red > b->rr_nmax && b->max_red <= CB_NMAX) rc |= P.zeros((size_t)n * (CB_MAXT - 1) * 256, &D.Linv);
     // few windows, one of them on the streamed Cholesky: the factorisation is spread over the chip, two tile columns per launch (k_chol_col)
     if (b->max_red > b->rr_nmax && b->max_red <= CC_NMAX && n * 4 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);      // >= 4 workgroups per window
-    rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
+    rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n, &b->ws_alt); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
+    b->ws_primary = D.ws;
     size_t np = (size_t)D.n_proj;
     rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl);
-    rc |= P.zeros(np, &D.p_cost); rc |= P.zeros(np, &D.p_aux);
+    rc |= P.zeros((size_t)std::max(1, D.n_fsb), &D.p_cpart); rc |= P.zeros((size_t)std::max(1, D.n_lmb), &D.p_apart);
     rc |= P.zeros(6 * (size_t)D.n_lm, &D.lm_Einv); rc |= P.zeros(3 * (size_t)D.n_lm, &D.lm_g);
     rc |= P.zeros(B.P_tot * GEMM_SPLIT, &D.P);
     rc |= P.zeros((size_t)std::max(1, 6 * B.n_fr) * GEMM_SPLIT, &D.lmq);
@@ -1633,11 +1643,31 @@ struct Launcher {
                 if (S.e[5] > S.e[0]) hipLaunchKernelGGL(k_post_chol<2>, dim3(S.e[5] - S.e[0]), dim3(256), 0, st, D, O, S);
             }
         }
-        {
-            Bracket t(*this, SWF_K_DOGLEG);
-            if (b->lat_fuse) hipLaunchKernelGGL((k_dogleg<16, 12, 4>), dim3(D.n_win), dim3(CTL_NT), 0, st, D, O);
-            else hipLaunchKernelGGL((k_dogleg<4, 4, 2>), dim3(D.n_win), dim3(CTL_NT), 0, st, D, O);
-        }
+        if (!step_fused) dogleg();
+    }
+    bool step_fused = false;    // this solve runs k_dogleg inside the candidate's evaluation (k_step_eval): one window on the latency path, speculative flow
+    void dogleg() {
+        DevBatch& D = b->D;
+        Bracket t(*this, SWF_K_DOGLEG);
+        if (b->lat_fuse) hipLaunchKernelGGL((k_dogleg<16, 4>), dim3(D.n_win), dim3(CTL_NT), 0, st, D, O);
+        else hipLaunchKernelGGL((k_dogleg<4, 2>), dim3(D.n_win), dim3(CTL_NT), 0, st, D, O);
+    }
+    bool step_fuse_ok() const {
+        const DevBatch& D = b->D;
+        return b->lat_fuse && !b->no_step_fuse && !b->aux && D.n_win == 1 && b->win[0].x_n <= XCL_MAX && b->max_prior_dim <= PRIOR_LDS_DIM && !D.n_idp && !b->n_comp
+               && D.n_fsb + nb(D.n_sc, 256) + D.n_prior + nb(D.n_imu, IMU_FPB) > 0;
+    }
+    // k_dogleg + the Jacobian evaluation at its candidate in one grid (k_step_eval); the window's state moves to the other buffer
+    void step_eval() {
+        DevBatch& D = b->D;
+        Bracket t(*this, SWF_K_EVAL_PS);
+        Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + D.n_prior;
+        const bool imu = D.n_imu > 0;
+        S.e[3] = S.e[2] + (imu ? nb(D.n_imu, IMU_FPB) : 0);
+        WinState* out = D.ws == b->ws_primary ? b->ws_alt : b->ws_primary;
+        if (imu) hipLaunchKernelGGL((k_step_eval<true>), dim3(S.e[3]), dim3(256), 0, st, D, O, S, out, b->win[0]);
+        else hipLaunchKernelGGL((k_step_eval<false>), dim3(S.e[2]), dim3(256), 0, st, D, O, S, out, b->win[0]);
+        D.ws = out;
     }
     void decide() {
         DevBatch& D = b->D;
@@ -1648,7 +1678,7 @@ struct Launcher {
         {
             Bracket t(*this, SWF_K_POST_DOGLEG);
             Segs S{};
-            S.e[0] = nb(D.n_proj, 256); S.e[1] = S.e[0] + nb(D.n_sc, 256);
+            S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256);            // (the projection segment: one workgroup per frame-sum block, as in the Jacobian evaluation)
             S.e[2] = S.e[1] + (b->max_prior_dim <= PRIOR_LDS_DIM ? D.n_prior : 0);
             // small batches (latency path): the candidate IMU residuals ride along as a segment; large batches keep them in
             // their own launch (the segment's LDS would cost the memory-bound segments occupancy).  Same results either way.
@@ -1701,18 +1731,21 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
             // are one pass, and the elimination kernels behind k_decide find the new point's Jacobians in place.  Levenberg-Marquardt
             // re-linearises at the UNCHANGED point after a rejected step (new damping) and keeps the two passes.
             const bool spec = opt->trust_region_strategy == SWF_DOGLEG && !b->n_comp && !b->no_spec;
+            L.step_fused = spec && L.step_fuse_ok();
             for (int it = 1; it <= opt->max_num_iterations; it++) {
                 L.reduced();
                 L.step_rest();
                 if (spec) {
-                    L.lin_eval(1, true); L.decide();
+                    if (L.step_fused) L.step_eval(); else L.lin_eval(1, true);
+                    L.decide();
                     if (b->aux) (void)hipEventRecord(b->ev_fork[1], st);          // the auxiliary stream's clique branch starts behind k_decide
                     L.lin_elim(it < opt->max_num_iterations ? 1 : 0); nlin++;
                 }
                 else { L.cand_eval(); LIN(it < opt->max_num_iterations ? 1 : 0); }
             }
         }
-        hipLaunchKernelGGL(k_finalize, dim3(D.n_win), dim3(256), 0, st, D, L.O);
+        hipLaunchKernelGGL(k_finalize, dim3(D.n_win), dim3(256), 0, st, D, L.O, b->ws_primary);
+        D.ws = b->ws_primary;
     }
     HIPCHK(hipGetLastError());
     b->last = swf_timing{};

@@ -45,7 +45,8 @@ __device__ __forceinline__ double damp_diag(const DevOpt& O, double d, double* j
 // proposed step: the accepted candidate is the next linearisation point, so its residuals, costs AND Jacobians are formed in one pass
 // instead of a cost pass at xc followed by a Jacobian pass at the same point (k_decide then turns the accepted candidate into x and
 // the elimination kernels find its Jacobians in place; a rejected dogleg step re-uses the previous reduced system and needs no Jacobian).
-template <bool JAC> __device__ __forceinline__ bool eval_gate(const DevBatch& B, const WinState& s) { return (JAC && !B.spec) ? s.need_lin != 0 : s.eval_cand != 0; }
+// (spec == 2: the fused step kernel of the latency path — its workgroups formed the candidate themselves and evaluate it ungated)
+template <bool JAC> __device__ __forceinline__ bool eval_gate(const DevBatch& B, const WinState& s) { return B.spec == 2 ? true : (JAC && !B.spec) ? s.need_lin != 0 : s.eval_cand != 0; }
 template <bool JAC> __device__ __forceinline__ const double* eval_src(const DevBatch& B) { return (JAC && !B.spec) ? B.x : B.xc; }
 
 #define CLIGHT_D 299792458.0
@@ -63,14 +64,15 @@ template <bool JAC> __device__ __forceinline__ const double* eval_src(const DevB
 // the arithmetic of one observation from its inputs in registers (P pose, E extrinsic, X landmark, (u0, u1) image point; jp / jl: the pose /
 // the landmark is variable) — d_eval_proj_at below loads them one dependent level after another; the back-substitution pass fetches
 // them together with everything else it needs
+// returns the observation's cost (0.5 rho(|r|^2)); the caller's block adds its observations' costs into one partial sum
 template <bool JAC, bool STORE>
-__device__ __forceinline__ void proj_core(const DevBatch& B, int i, const WinRec& W, const double* P, const double* E, const double* X,
+__device__ __forceinline__ double proj_core(const DevBatch& B, int i, const WinRec& W, const double* P, const double* E, const double* X,
                                           double u0, double u1, bool jp, bool jl, double* keep);
 template <bool JAC, bool STORE = true>
-__device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double* keep) {
+__device__ __forceinline__ double d_eval_proj_at(const DevBatch& B, int i, double* keep) {
     int w = B.p_win[i];
     const WinState& s = B.ws[w];
-    if (!eval_gate<JAC>(B, s)) return;
+    if (!eval_gate<JAC>(B, s)) return 0.0;
     const WinRec& W = B.win[w];
     const double* xs = eval_src<JAC>(B);
     const double* pose = xs + B.p_xpose[i];
@@ -80,10 +82,10 @@ __device__ __forceinline__ void d_eval_proj_at(const DevBatch& B, int i, double*
 #pragma unroll
     for (int k = 0; k < 7; k++) { P[k] = pose[k]; E[k] = ex[k]; }
     X[0] = lm[0]; X[1] = lm[1]; X[2] = lm[2];
-    proj_core<JAC, STORE>(B, i, W, P, E, X, B.p_uv[2 * i], B.p_uv[2 * i + 1], JAC && B.p_lpose[i] >= 0, JAC && B.p_llm[i] >= 0, keep);
+    return proj_core<JAC, STORE>(B, i, W, P, E, X, B.p_uv[2 * i], B.p_uv[2 * i + 1], JAC && B.p_lpose[i] >= 0, JAC && B.p_llm[i] >= 0, keep);
 }
 template <bool JAC, bool STORE>
-__device__ __forceinline__ void proj_core(const DevBatch& B, int i, const WinRec& W, const double* P, const double* E, const double* X,
+__device__ __forceinline__ double proj_core(const DevBatch& B, int i, const WinRec& W, const double* P, const double* E, const double* X,
                                           double u0, double u1, bool jp, bool jl, double* keep) {
     double Qj_inv[4], qic_inv[4], d[3], pts_imu[3], t[3], pc[3];
     qinv(P + 3, Qj_inv);
@@ -104,12 +106,11 @@ __device__ __forceinline__ void proj_core(const DevBatch& B, int i, const WinRec
         cost = 0.5 * b * log(sum);
         sr = sqrt(inv > 2.2250738585072014e-308 ? inv : 2.2250738585072014e-308);
     } else cost = 0.5 * sq;
-    if (STORE) B.p_cost[i] = cost;
-    if (!JAC) return;
+    if (!JAC) return cost;
     int n = B.n_proj;
     if (STORE) { B.p_r[i] = r0 * sr; B.p_r[n + i] = r1 * sr; }
     if (keep) { keep[12] = r0 * sr; keep[13] = r1 * sr; }
-    if (!jp && !jl) return;
+    if (!jp && !jl) return cost;
     double Rj[9], ric[9], ricT[9], RjT[9], A[9];
     q2R(P + 3, Rj); q2R(E + 3, ric);
     mat3T(ric, ricT); mat3T(Rj, RjT);
@@ -143,13 +144,20 @@ __device__ __forceinline__ void proj_core(const DevBatch& B, int i, const WinRec
                 if (keep) keep[14 + a * 3 + j] = u * sr;
             }
     }
+    return cost;
 }
 
-template <bool JAC>
-__device__ __forceinline__ void d_eval_proj(const DevBatch& B, int bid) {
-    int i = bid * blockDim.x + threadIdx.x;
-    if (i >= B.n_proj) return;
-    d_eval_proj_at<JAC>(B, i, nullptr);
+// cost-only evaluation of one frame-sum block's observations at the candidate (k_post_dogleg): the block's cost in p_cpart, formed
+// exactly as the Jacobian evaluation of the same block forms it (d_eval_proj_fs: thread t <-> observation t of the block, block_sum)
+__device__ __forceinline__ void d_eval_proj_cost(const DevBatch& B, int blk) {
+    __shared__ double csum[16];
+    const int w = B.fsb_win[blk];
+    if (!eval_gate<false>(B, B.ws[w])) return;               // uniform per block (a block holds observations of one window)
+    const int o_beg = B.fsb_obs0[blk], cnt = B.fsb_obs0[blk + 1] - o_beg, tid = threadIdx.x;
+    double c = 0.0;
+    if (tid < cnt) c = d_eval_proj_at<false>(B, o_beg + tid, nullptr);
+    c = block_sum(c, csum);
+    if (tid == 0) B.p_cpart[blk] = c;
 }
 
 // =========================================================================================
@@ -737,23 +745,6 @@ template <int MODE>
 __device__ __forceinline__ double vec_at(const DevBatch& B, const DevOpt& O, int loc) {
     if (MODE == 1) return B.step[loc];
     return B.vc[loc];                  // g / clamp(diag), stored by the producers of g and diag
-}
-template <int MODE>
-__device__ __forceinline__ void d_jtimes_proj(const DevBatch& B, const DevOpt& O, int bid) {
-    int i = bid * blockDim.x + threadIdx.x;
-    if (i >= B.n_proj) return;
-    const WinState& s = B.ws[B.p_win[i]];
-    if (MODE == 0 ? !s.need_lin : !s.eval_cand) return;
-    int n = B.n_proj, lp = B.p_lpose[i], ll = B.p_llm[i];
-    double a0 = 0, a1 = 0;
-    if (lp >= 0) for (int j = 0; j < 6; j++) {
-        double v = vec_at<MODE>(B, O, lp + j);
-        const bool tl = j < 3 && ll >= 0;                 // translation half of Jp = -Jl (not stored next to a variable landmark)
-        a0 += (tl ? -B.p_Jl[j * n + i] : B.p_Jp[j * n + i]) * v; a1 += (tl ? -B.p_Jl[(3 + j) * n + i] : B.p_Jp[(6 + j) * n + i]) * v;
-    }
-    if (ll >= 0) for (int j = 0; j < 3; j++) { double v = vec_at<MODE>(B, O, ll + j); a0 += B.p_Jl[j * n + i] * v; a1 += B.p_Jl[(3 + j) * n + i] * v; }
-    if (MODE == 0) B.p_aux[i] = a0 * a0 + a1 * a1;
-    else B.p_aux[i] = a0 * (B.p_r[i] + a0 / 2.0) + a1 * (B.p_r[n + i] + a1 / 2.0);
 }
 // row k of (J v) for a generic factor
 template <int MODE>
@@ -1380,7 +1371,13 @@ __device__ __forceinline__ void d_eval_proj_fs(const DevBatch& B, int blk, doubl
 #pragma unroll
     for (int k = 0; k < 20; k++) keep[k] = 0.0;
     int rk = 0;
-    if (tid < cnt) { rk = B.fsb_perm[o_beg + tid]; d_eval_proj_at<true>(B, o_beg + tid, keep); }
+    double cost = 0.0;
+    if (tid < cnt) { rk = B.fsb_perm[o_beg + tid]; cost = d_eval_proj_at<true>(B, o_beg + tid, keep); }
+    {   // the block's cost (what the per-window control kernels add up instead of per-observation costs)
+        __shared__ double csum[16];
+        cost = block_sum(cost, csum);
+        if (tid == 0) B.p_cpart[blk] = cost;
+    }
     double val[FS_VAL];
     {
         const double* a = keep; const double* b = keep + 6;

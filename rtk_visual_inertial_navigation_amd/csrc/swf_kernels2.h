@@ -841,7 +841,7 @@ __device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O,
     { const int q = loc >= 0 ? loc : 0; vl0 = B.vc[q]; vl1 = B.vc[q + 1]; vl2 = B.vc[q + 2]; }
     if (loc < 0) { vl0 = 0; vl1 = 0; vl2 = 0; }
     if (!need) return;                                         // uniform: the block belongs to one window
-    double c0 = 0, c1 = 0, c2 = 0;
+    double c0 = 0, c1 = 0, c2 = 0, aux = 0;
     if (ho) {
         // the observation's Jacobian, re-derived at the linearisation point from its inputs (pose, extrinsic and landmark sit in cache
         // for the whole track; 16 B of image coordinates per observation) rather than read back: 144 B per observation less traffic
@@ -860,12 +860,16 @@ __device__ __forceinline__ void d_backsub_lm(const DevBatch& B, const DevOpt& O,
                 a0 += ja * vp[i]; a1 += jb * vp[i];
             }
         }
-        B.p_aux[o] = a0 * a0 + a1 * a1;
+        aux = a0 * a0 + a1 * a1;
         if (pfr >= 0) { c0 = -(jl0 * w0 + jl3 * w1); c1 = -(jl1 * w0 + jl4 * w1); c2 = -(jl2 * w0 + jl5 * w1); }
     }
     (void)n;
     sc[0][tid] = c0; sc[1][tid] = c1; sc[2][tid] = c2;
-    __syncthreads();
+    {   // the block's share of |J D^-2 g|^2 (k_dogleg adds the window's blocks in order)
+        __shared__ double asum[16];
+        aux = block_sum(aux, asum);                      // (its barriers also order the staging above before the reads below)
+        if (tid == 0) B.p_apart[bid] = aux;
+    }
     if (!hl || failed || lloc < 0) return;
     double t0 = 0, t1 = 0, t2 = 0;
     for (int q = lob - o0, qe = loe - o0; q < qe; q++) { t0 += sc[0][q]; t1 += sc[1][q]; t2 += sc[2][q]; }
@@ -934,7 +938,7 @@ __global__ void __launch_bounds__(256) k_eval_ps(DevBatch B, Segs S) {
     constexpr int SM_PRIOR = 2 * PRIOR_LDS_DIM + 16, SM_FS = FS ? FS_BLK * FS_HALF + 168 / 2 + 1 : 1;
     __shared__ double sm[SM_PRIOR > SM_FS ? SM_PRIOR : SM_FS];
     int bid = blockIdx.x;
-    if (bid < S.e[0]) { if (FS) d_eval_proj_fs(B, bid, (double (*)[FS_HALF])sm, (int*)(sm + FS_BLK * FS_HALF)); else d_eval_proj<JAC>(B, bid); }
+    if (bid < S.e[0]) { static_assert(FS && JAC, "the projection segment evaluates Jacobians by frame-sum block"); d_eval_proj_fs(B, bid, (double (*)[FS_HALF])sm, (int*)(sm + FS_BLK * FS_HALF)); }
     else if (bid < S.e[1]) d_eval_scalar<JAC>(B, bid - S.e[0]);
     else if (!IMU || bid < S.e[2]) d_eval_prior<JAC>(B, bid - S.e[1], sm);              // one workgroup per prior (segment empty for large priors)
     else d_eval_imu<JAC>(B, bid - S.e[2]);
@@ -965,9 +969,9 @@ template <bool WITH_IMU, int PART>
 __global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs S) {
     __shared__ double sm_prior[PART == 1 ? 1 : 2 * PRIOR_LDS_DIM + 16];
     int bid = blockIdx.x;
-    if (PART == 1) { d_eval_proj<false>(B, bid); return; }     // grid = S.e[0]
+    if (PART == 1) { d_eval_proj_cost(B, bid); return; }       // grid = S.e[0] = the frame-sum blocks
     if (PART == 2) bid += S.e[0];                              // skip the projection segment
-    if (PART == 0 && bid < S.e[0]) d_eval_proj<false>(B, bid);
+    if (PART == 0 && bid < S.e[0]) d_eval_proj_cost(B, bid);
     else if (bid < S.e[1]) d_eval_scalar<false>(B, bid - S.e[0]);
     else if (bid < S.e[2]) d_eval_prior<false>(B, bid - S.e[1], sm_prior);
     else if (WITH_IMU) d_eval_imu<false>(B, bid - S.e[2]);    // candidate IMU residuals (8 factors per workgroup), small batches only
@@ -976,38 +980,27 @@ __global__ void __launch_bounds__(256) k_post_dogleg(DevBatch B, DevOpt O, Segs 
 // =========================================================================================
 // per-window control kernels (one 256-thread workgroup per window)
 // =========================================================================================
-__device__ __forceinline__ double win_cost_sum(const DevBatch& B, const WinRec& W, double* red) {
+// A window's cost = (its frame-sum blocks' projection costs, added in block order) + (its generic factors' costs: per-thread strided
+// sums in index order, wave butterfly, waves in order).  The SAME formula in k_dogleg, k_decide and k_finalize, in every launch shape.
+// The block values travel through LDS: one load per lane, all in flight at once (a sequential loop over global memory would be a chain of
+// round trips), staged BEFORE a block reduction and added, in block order, by every thread AFTER it (the reduction's barriers order the two).
+#define WP_LDS 256              // block values staged per window (a cfg3 window has 12 of each; beyond: read in place, in order)
+__device__ __forceinline__ void win_part_stage(const double* part, int q0, int q1, double* st) {
+    for (int q = q0 + (int)threadIdx.x; q < q1 && q - q0 < WP_LDS; q += (int)blockDim.x) st[q - q0] = part[q];
+}
+__device__ __forceinline__ double win_part_sum(const double* part, int q0, int q1, const double* st) {
     double a = 0;
-    for (int i = W.proj0 + threadIdx.x; i < W.proj1; i += blockDim.x) a += B.p_cost[i];
+    const int n = q1 - q0;
+    for (int q = 0; q < n && q < WP_LDS; q++) a += st[q];
+    for (int q = WP_LDS; q < n; q++) a += part[q0 + q];
+    return a;
+}
+__device__ __forceinline__ double win_cost_sum(const DevBatch& B, const WinRec& W, double* red, double* st) {
+    win_part_stage(B.p_cpart, W.fsb0, W.fsb1, st);
+    double a = 0;
     for (int i = W.gf0 + threadIdx.x; i < W.gf1; i += blockDim.x) a += B.g_cost[i];
-    return block_sum(a, red);
-}
-__device__ __forceinline__ double win_aux_sum(const DevBatch& B, const WinRec& W, double* red) {
-    double a = 0;
-    for (int i = W.proj0 + threadIdx.x; i < W.proj1; i += blockDim.x) a += B.p_aux[i];
-    for (int i = W.gf0 + threadIdx.x; i < W.gf1; i += blockDim.x) a += B.g_aux[i];
-    return block_sum(a, red);
-}
-// per-thread partials (no reduction): cost and model term in one pass over the window's factors
-__device__ __forceinline__ void win_cost_aux_part(const DevBatch& B, const WinRec& W, double& c, double& a) {
-    c = 0; a = 0;
-    // twelve guarded loads of each array in flight per thread (a 3000-observation window is one round); the adds
-    // stay in index order
-    constexpr int U = 12;
-    for (int base = W.proj0 + threadIdx.x; base < W.proj1; base += U * blockDim.x) {
-        double cv[U], av[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) { int i = base + u * blockDim.x; bool ok = i < W.proj1; cv[u] = ok ? B.p_cost[i] : 0.0; av[u] = ok ? B.p_aux[i] : 0.0; }
-#pragma unroll
-        for (int u = 0; u < U; u++) { c += cv[u]; a += av[u]; }
-    }
-    for (int base = W.gf0 + threadIdx.x; base < W.gf1; base += 4 * blockDim.x) {
-        double cv[4], av[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { int i = base + u * blockDim.x; bool ok = i < W.gf1; cv[u] = ok ? B.g_cost[i] : 0.0; av[u] = ok ? B.g_aux[i] : 0.0; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) { c += cv[u]; a += av[u]; }
-    }
+    a = block_sum(a, red);
+    return win_part_sum(B.p_cpart, W.fsb0, W.fsb1, st) + a;
 }
 // || x ||_2 over variable blocks (ambient coordinates)
 __device__ __forceinline__ double win_x_norm(const DevBatch& B, const WinRec& W, const double* x, double* red) {
@@ -1075,32 +1068,37 @@ __device__ unsigned long long g_dog_stamps[16];
 // coordinate of local dimension i (-1 for the six dimensions of a pose block, which a thread per pose block handles with Plus);
 // every load of a pass depends on nothing but the window record, so a pass is one round trip.  Constant blocks are never written:
 // xc holds their values since the upload (swf_batch_upload_state / _reset_state copy x to xc).
-// DU / PU / GU: strided elements per thread whose loads are issued up front and kept in registers (the latency path takes a cfg3 window
+// DU / GU: strided elements per thread whose loads are issued up front and kept in registers (the latency path takes a cfg3 window
 // whole: 256 registers, one workgroup per CU; batches take a quarter and walk the rest in the loops behind — two workgroups per CU and
 // more: 512 windows 33.5 -> ? us).  The sums run in index order either way: same bits.
-template <int DU, int PU, int GU>
-__global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
-    __shared__ double red[16 * 6];
-    __shared__ int go;
+// The body of k_dogleg as a device function, so that the latency path can run it at the head of its candidate evaluation (k_step_eval:
+// EVERY workgroup of that grid forms the step redundantly — same loads, same sums in the same order, same bits — and goes on to evaluate
+// its share of the factors at the candidate it holds in LDS; the launch of k_dogleg, its dependent round trips and the candidate's trip
+// through HBM disappear).  sin: the window's state as the previous kernels left it (read only); sout: where the LEAD workgroup's thread 0
+// leaves the new state (== sin for the in-place form of the k_dogleg launch; another buffer in k_step_eval, whose other workgroups are
+// still reading sin).  Only the lead writes global memory (state, trace, step, candidate).  xcl != nullptr: the candidate's coordinates,
+// window-relative, for this workgroup's evaluation (filled here: x, then the candidate over it; constant blocks keep x's values;
+// x_n <= XU * 256).  W: the window's record — in k_step_eval a kernel argument, so that every load below but the pose threads' second
+// level depends on nothing but the kernel's arguments: ONE round trip ahead of the sums (the record and the state were one of their own).
+// Returns 1 (uniform over the workgroup) if a candidate was formed.
+template <int DU, int GU, int XU = 1>
+__device__ __forceinline__ int d_dogleg(const DevBatch& B, const DevOpt& O, const int w, const WinRec& W, const WinState* sin, WinState* sout, const bool lead, double* xcl, double* red, double* pst /* LDS, 2 WP_LDS doubles */) {
 #ifdef SWF_PROFILE_DOG
     unsigned long long td_ = __builtin_amdgcn_s_memtime();
     if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < 16; i++) g_dog_stamps[i] = 0;
 #endif
-    int w = blockIdx.x, tid = threadIdx.x;
-    WinState& s = B.ws[w];
-    if (s.status != SWF_RUNNING) return;
-    const WinRec& W = B.win[w];
+    const int tid = threadIdx.x;
+    // every thread carries the window's state (uniform values) through the same bookkeeping; the lead's thread 0 stores it
+    WinState t = *sin;
+    const bool wr = lead && tid == 0;
     swf_iteration* tr = B.trace + (size_t)w * B.max_iter_trace;
-    int fresh = s.need_lin;
-    double x_cost = s.x_cost, gmax = s.gmax, jg_sq = s.jg_sq;
     const double* g = B.g + W.loc_base; const double* dg = B.diag + W.loc_base; const double* y = B.y + W.loc_base;
     const int* l2x = B.loc2x + W.loc_base;
     double* step = B.step + W.loc_base;
-    int n = W.n_loc;
-    const bool want_gmax = fresh && !s.lin_fail;
+    const int n = W.n_loc, xb = W.x_base;
     // one pass, one barrier pair: cost, |J D^-2 g|^2, gradient max-norm (fresh linearisation only) and the scalars of the
     // scaled problem |g/d|^2, |d y|^2, (g/d).(-d y).
-    // EVERY load of the kernel is issued here, before the first value is used: the first PU / GU / DU strided elements per thread of the
+    // EVERY load of the kernel is issued here, before the first value is used: the first GU / DU strided elements per thread of the
     // cost arrays and of g, diag, y, loc2x stay in registers (a cfg3 window: all of them) and serve the step pass below as well, which
     // then touches no memory but its stores.  Two exposed round trips (the tables, then x through loc2x) instead of eight.
     double v[6] = { 0, 0, 0, 0, 0, 0 };
@@ -1108,12 +1106,18 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     // the pose blocks (the window's first blocks; constant ones have no local dimensions): a thread each
     int p_lo = -1, p_xo = 0;
     if (tid < W.n_pose_blk) { p_lo = B.blk_loc[W.blk_base + tid]; p_xo = B.blk_xoff[W.blk_base + tid]; }
-    double cvp[PU], avp[PU], cvg[GU], avg[GU], gv[DU], yv[DU], dgv[DU], xv[DU];
+    double cvg[GU], avg[GU], gv[DU], yv[DU], dgv[DU], xv[DU];
     int lxv[DU];
+    // the projection factors' share of the cost and of |J D^-2 g|^2: the blocks' partial sums (left by the evaluation and by k_post_chol)
+    // (none of these loads waits for the window's state: whether the linearisation is fresh decides only what is added up)
+    win_part_stage(B.p_cpart, W.fsb0, W.fsb1, pst); win_part_stage(B.p_apart, W.lmb0, W.lmb1, pst + WP_LDS);
+    double xin[XU];
+    if (xcl) {
 #pragma unroll
-    for (int u = 0; u < PU; u++) { int i = W.proj0 + tid + u * CTL_NT; bool ok = fresh && i < W.proj1; cvp[u] = ok ? B.p_cost[i] : 0.0; avp[u] = ok ? B.p_aux[i] : 0.0; }
+        for (int u = 0; u < XU; u++) { int i = tid + u * CTL_NT; xin[u] = i < W.x_n ? B.x[xb + i] : 0.0; }
+    }
 #pragma unroll
-    for (int u = 0; u < GU; u++) { int i = W.gf0 + tid + u * CTL_NT; bool ok = fresh && i < W.gf1; cvg[u] = ok ? B.g_cost[i] : 0.0; avg[u] = ok ? B.g_aux[i] : 0.0; }
+    for (int u = 0; u < GU; u++) { int i = W.gf0 + tid + u * CTL_NT; bool ok = i < W.gf1; cvg[u] = ok ? B.g_cost[i] : 0.0; avg[u] = ok ? B.g_aux[i] : 0.0; }
 #pragma unroll
     for (int u = 0; u < DU; u++) { int i = tid + u * CTL_NT; bool ok = i < n; gv[u] = ok ? g[i] : 0.0; yv[u] = ok ? y[i] : 0.0; dgv[u] = ok ? dg[i] : 1.0; lxv[u] = ok ? l2x[i] : -1; }
     double xp[7] = { 0, 0, 0, 0, 0, 0, 1 }, pg[6] = { 0, 0, 0, 0, 0, 0 }, pd[6] = { 1, 1, 1, 1, 1, 1 }, py[6] = { 0, 0, 0, 0, 0, 0 };
@@ -1123,19 +1127,20 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
 #pragma unroll
         for (int k = 0; k < 6; k++) { pg[k] = B.g[p_lo + k]; pd[k] = B.diag[p_lo + k]; py[k] = B.y[p_lo + k]; }
     }
+    if (!xcl) {
 #pragma unroll
-    for (int u = 0; u < DU; u++) xv[u] = lxv[u] >= 0 ? B.x[lxv[u]] : 0.0;
+        for (int u = 0; u < DU; u++) xv[u] = lxv[u] >= 0 ? B.x[lxv[u]] : 0.0;
+    } else {
+        // x into LDS (the candidate is formed over it); this thread's coordinates come back from there behind the first reduction
+#pragma unroll
+        for (int u = 0; u < XU; u++) { int i = tid + u * CTL_NT; if (i < W.x_n) xcl[i] = xin[u]; }
+    }
+    if (t.status != SWF_RUNNING) { if (wr && sout != sin) *sout = t; return 0; }          // (uniform)
+    const int fresh = t.need_lin;
+    double x_cost = t.x_cost, gmax = t.gmax, jg_sq = t.jg_sq;
+    const bool want_gmax = fresh && !t.lin_fail;
     if (fresh) {
-        // (the sums in the order of win_cost_aux_part: index order per thread, projection factors first)
-#pragma unroll
-        for (int u = 0; u < PU; u++) { v[0] += cvp[u]; v[1] += avp[u]; }
-        for (int base = W.proj0 + tid + PU * CTL_NT; base < W.proj1; base += PU * CTL_NT) {
-            double cv[PU], av[PU];
-#pragma unroll
-            for (int u = 0; u < PU; u++) { int i = base + u * CTL_NT; bool ok = i < W.proj1; cv[u] = ok ? B.p_cost[i] : 0.0; av[u] = ok ? B.p_aux[i] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < PU; u++) { v[0] += cv[u]; v[1] += av[u]; }
-        }
+        // (the generic factors: index order per thread)
 #pragma unroll
         for (int u = 0; u < GU; u++) { v[0] += cvg[u]; v[1] += avg[u]; }
         for (int base = W.gf0 + tid + GU * CTL_NT; base < W.gf1; base += GU * CTL_NT) {
@@ -1180,52 +1185,61 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     DST(3);
     block_reduce<5, 1>(v, red);
     DST(4);
-    if (fresh) { x_cost = v[0]; if (!s.lin_fail) { jg_sq = v[1]; gmax = v[5]; } }
-    double gsq = v[2], ynn = v[3], gdot = v[4];
-    __syncthreads();
-    if (tid == 0) {
-        go = 0;
-        int it = s.iter;
+    if (xcl) {
+#pragma unroll
+        for (int u = 0; u < DU; u++) xv[u] = lxv[u] >= 0 ? xcl[lxv[u] - xb] : 0.0;
+    }
+    if (fresh) {
+        x_cost = win_part_sum(B.p_cpart, W.fsb0, W.fsb1, pst) + v[0];
+        if (!t.lin_fail) { jg_sq = win_part_sum(B.p_apart, W.lmb0, W.lmb1, pst + WP_LDS) + v[1]; gmax = v[5]; }
+    }
+    const double gsq = v[2], ynn = v[3], gdot = v[4];
+    // the bookkeeping of FinalizeIterationAndCheckIfMinimizerCanContinue, by every thread on its copy of the state (uniform)
+    int go = 0;
+    {
+        int it = t.iter;
         if (fresh) {
-            s.x_cost = x_cost; s.gmax = gmax; s.jg_sq = jg_sq;
-            if (it == 0) { s.initial_cost = x_cost; tr[0].cost = x_cost; tr[0].trust_region_radius = s.radius; tr[0].step_is_valid = 1; tr[0].step_is_successful = 1; }
-            else tr[it].cost = x_cost;
-            tr[it].gradient_max_norm = gmax;
-            s.need_lin = 0;
+            t.x_cost = x_cost; t.gmax = gmax; t.jg_sq = jg_sq;
+            if (wr) {
+                if (it == 0) { tr[0].cost = x_cost; tr[0].trust_region_radius = t.radius; tr[0].step_is_valid = 1; tr[0].step_is_successful = 1; }
+                else tr[it].cost = x_cost;
+                tr[it].gradient_max_norm = gmax;
+            }
+            if (it == 0) t.initial_cost = x_cost;
+            t.need_lin = 0;
         }
-        if (it >= O.max_iter) s.status = SWF_NO_CONVERGENCE;
-        else if (gmax <= O.gtol && !s.lin_fail) s.status = SWF_CONVERGED_GRADIENT;
-        else if (s.radius < O.min_r) s.status = SWF_RADIUS_TOO_SMALL;
+        if (it >= O.max_iter) t.status = SWF_NO_CONVERGENCE;
+        else if (gmax <= O.gtol && !t.lin_fail) t.status = SWF_CONVERGED_GRADIENT;
+        else if (t.radius < O.min_r) t.status = SWF_RADIUS_TOO_SMALL;
         else {
-            it = ++s.iter;
+            it = ++t.iter;
             swf_iteration& rec = tr[it < B.max_iter_trace ? it : B.max_iter_trace - 1];
-            rec.gradient_max_norm = gmax;
-            if (s.lin_fail) {
+            if (wr) rec.gradient_max_norm = gmax;
+            if (t.lin_fail) {
                 // Gauss-Newton solve failed: DoglegStrategy raises mu; HandleInvalidStep
-                rec.step_is_valid = 0; rec.cost = s.x_cost; rec.trust_region_radius = s.radius;
-                s.lin_fail = 0; s.chol_fail = 0; s.eval_cand = 0;
-                s.reuse = 0; s.need_lin = 1;
+                if (wr) { rec.step_is_valid = 0; rec.cost = t.x_cost; rec.trust_region_radius = t.radius; }
+                t.lin_fail = 0; t.chol_fail = 0; t.eval_cand = 0;
+                t.reuse = 0; t.need_lin = 1;
                 if (O.strategy == SWF_LEVENBERG_MARQUARDT) {
                     // LevenbergMarquardtStrategy::StepIsInvalid = StepRejected(0)
-                    if (++s.invalid_run >= 5) s.status = SWF_LINEAR_SOLVER_FAILURE;
-                    else { s.radius /= s.lm_dec; s.lm_dec *= 2.0; s.mu = 1.0 / s.radius; rec.trust_region_radius = s.radius; }
+                    if (++t.invalid_run >= 5) t.status = SWF_LINEAR_SOLVER_FAILURE;
+                    else { t.radius /= t.lm_dec; t.lm_dec *= 2.0; t.mu = 1.0 / t.radius; if (wr) rec.trust_region_radius = t.radius; }
                 } else {
-                    s.mu *= O.mu_inc;
-                    if (++s.invalid_run >= 5 || s.mu >= O.max_mu) s.status = SWF_LINEAR_SOLVER_FAILURE;
+                    t.mu *= O.mu_inc;
+                    if (++t.invalid_run >= 5 || t.mu >= O.max_mu) t.status = SWF_LINEAR_SOLVER_FAILURE;
                 }
             } else {
-                if (!s.reuse) s.alpha = gsq / jg_sq;
-                s.reuse = 1;
+                if (!t.reuse) t.alpha = gsq / jg_sq;
+                t.reuse = 1;
                 go = 1;
             }
         }
     }
-    __syncthreads();
     DST(5);
-    if (!go) return;
+    if (!go) { if (wr) *sout = t; return 0; }
     // ComputeTraditionalDoglegStep in the scaled space, un-scaled on the fly
-    double gnorm = sqrt(gsq), gnn = sqrt(ynn), alpha = s.alpha, radius = s.radius;
-    const double mu_s = s.mu;
+    double gnorm = sqrt(gsq), gnn = sqrt(ynn), alpha = t.alpha, radius = t.radius;
+    const double mu_s = t.mu;
     int mode; double c1 = 0, c2 = 0;          // step = c1 * g / dclamp + c2 * y
     double dnorm;
     if (O.strategy == SWF_LEVENBERG_MARQUARDT) { mode = 0; c1 = 0; c2 = -1.0; dnorm = gnn; }      // the damped step itself
@@ -1246,30 +1260,27 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     //   H y = g - mu D^2 y          (y solves the damped system)  =>  v^T H y = |g / D|^2 - mu g.y,   y^T H y = g.y - mu |D y|^2,
     // and g.v = |g / D|^2: every term is one of the sums of the pass above.  (The identity holds to the backward error of the linear
     // solve, 1e-12 of the terms; round 1 re-read every Jacobian for this — 73 + 35 us per iteration of the cfg4 batch.)
-    // (every thread forms it: an invalid step — model cost change not positive, TrustRegionMinimizer::HandleInvalidStep — is handled HERE,
-    // before any candidate is evaluated, so that no kernel behind this one sees a candidate of such a step: the speculative flow keeps the
-    // Jacobians of x in place for the re-linearisation that follows.  Same bookkeeping as k_decide's branch of the same name.)
+    // An invalid step — model cost change not positive, TrustRegionMinimizer::HandleInvalidStep — is handled HERE, before any candidate
+    // exists, so that no kernel behind this one sees a candidate of such a step: the speculative flow keeps the Jacobians of x in place
+    // for the re-linearisation that follows.
     double mcc;
     {
         const double gy = -gdot, mu = mu_s;
         const double sHs = c1 * c1 * jg_sq + 2.0 * c1 * c2 * (gsq - mu * gy) + c2 * c2 * (gy - mu * ynn);
         mcc = -(c1 * gsq + c2 * gy + 0.5 * sHs);
     }
+    t.model_cost_change = mcc;
     if (!(mcc > 0.0)) {
-        __syncthreads();                                   // (uniform: every thread holds the same mcc; all reads of the window's state lie before)
-        if (tid == 0) {
-            swf_iteration& rec = tr[s.iter < B.max_iter_trace ? s.iter : B.max_iter_trace - 1];
-            s.model_cost_change = mcc; s.eval_cand = 0;
-            rec.model_cost_change = mcc;
-            rec.step_is_valid = 0; rec.cost = s.x_cost; rec.trust_region_radius = s.radius;
-            s.reuse = 0; s.need_lin = 1;
-            if (++s.invalid_run >= 5) s.status = SWF_LINEAR_SOLVER_FAILURE;
-            else if (O.strategy == SWF_LEVENBERG_MARQUARDT) { s.radius /= s.lm_dec; s.lm_dec *= 2.0; s.mu = 1.0 / s.radius; rec.trust_region_radius = s.radius; }
-            else s.mu *= O.mu_inc;
-        }
-        return;
+        swf_iteration& rec = tr[t.iter < B.max_iter_trace ? t.iter : B.max_iter_trace - 1];
+        t.eval_cand = 0;
+        if (wr) { rec.model_cost_change = mcc; rec.step_is_valid = 0; rec.cost = t.x_cost; rec.trust_region_radius = t.radius; }
+        t.reuse = 0; t.need_lin = 1;
+        if (++t.invalid_run >= 5) t.status = SWF_LINEAR_SOLVER_FAILURE;
+        else if (O.strategy == SWF_LEVENBERG_MARQUARDT) { t.radius /= t.lm_dec; t.lm_dec *= 2.0; t.mu = 1.0 / t.radius; if (wr) rec.trust_region_radius = t.radius; }
+        else t.mu *= O.mu_inc;
+        if (wr) *sout = t;
+        return 0;
     }
-    if (tid == 0) s.model_cost_change = mcc;
     // the step and the candidate = Plus(x, step) in one pass over the local dimensions, from the registers of the pass above; the pose
     // threads form their six step entries from the same operands (the same bits as step[]) and apply PoseLocalParameterization::Plus
     double a_s = 0, a_n = 0;
@@ -1283,8 +1294,8 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
             double sc = c1 * (gv[u] * ir) + c2 * (dc * ir * yv[u]);
             a_s += sc * sc;
             const double st = sc * ir;
-            step[i] = st;
-            if (lxv[u] >= 0) { const double x0 = xv[u], xn = x0 + st; B.xc[lxv[u]] = xn; const double dv = x0 - xn; a_n += dv * dv; }
+            if (lead) step[i] = st;
+            if (lxv[u] >= 0) { const double x0 = xv[u], xn = x0 + st; if (lead) B.xc[lxv[u]] = xn; if (xcl) xcl[lxv[u] - xb] = xn; const double dv = x0 - xn; a_n += dv * dv; }
         }
     }
     for (int i = tid + DU * CTL_NT; i < n; i += CTL_NT) {
@@ -1294,8 +1305,8 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
         double sc = c1 * (g[i] * ir) + c2 * (dc * ir * y[i]);
         a_s += sc * sc;
         const double st = sc * ir;
-        step[i] = st;
-        if (a >= 0) { const double x0 = B.x[a], xn = x0 + st; B.xc[a] = xn; const double dv = x0 - xn; a_n += dv * dv; }
+        if (lead) step[i] = st;
+        if (a >= 0) { const double x0 = B.x[a], xn = x0 + st; if (lead) B.xc[a] = xn; if (xcl) xcl[a - xb] = xn; const double dv = x0 - xn; a_n += dv * dv; }
     }
     DST(6);
     if (p_lo >= 0) {
@@ -1309,21 +1320,59 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
         }
         pose_plus(xp, d, o);
 #pragma unroll
-        for (int k = 0; k < 7; k++) { B.xc[p_xo + k] = o[k]; const double dv = xp[k] - o[k]; a_n += dv * dv; }
+        for (int k = 0; k < 7; k++) { if (lead) B.xc[p_xo + k] = o[k]; if (xcl) xcl[p_xo + k - xb] = o[k]; const double dv = xp[k] - o[k]; a_n += dv * dv; }
     }
     DST(7);
-    double r2[2] = { a_s, a_n };
-    block_reduce<2, 0>(r2, red);
-    if (mode == 2) dnorm = sqrt(r2[0]);
-    double stepn = sqrt(r2[1]);
-    if (tid == 0) { s.dogleg_step_norm = dnorm; s.step_norm = stepn; s.eval_cand = 1; }
+    if (lead) {           // (the step's norms go into the state only: the other workgroups of a fused grid leave them out)
+        double r2[2] = { a_s, a_n };
+        block_reduce<2, 0>(r2, red);
+        if (mode == 2) dnorm = sqrt(r2[0]);
+        t.dogleg_step_norm = dnorm; t.step_norm = sqrt(r2[1]); t.eval_cand = 1;
+        if (wr) *sout = t;
+    }
     DST(8);
+    return 1;
+}
+template <int DU, int GU>
+__global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
+    __shared__ double red[16 * 6];
+    __shared__ double pst[2 * WP_LDS];
+    WinState* s = B.ws + blockIdx.x;
+    (void)d_dogleg<DU, GU>(B, O, (int)blockIdx.x, B.win[blockIdx.x], s, s, true, nullptr, red, pst);
+}
+
+// Latency path of ONE window in the speculative dogleg flow: k_dogleg and the Jacobian evaluation at its candidate as ONE grid.
+// Every workgroup of k_eval_ps's grid (frame-sum blocks of projection observations | scalar factors | priors | IMU factors) first forms
+// the dogleg step for itself — d_dogleg: the same loads, sums and bits in every workgroup; workgroup 0 alone writes the state (into
+// ws_out: the others are still reading B.ws), the trace, the step and the candidate — keeps the candidate in LDS and evaluates its
+// factors there.  What it replaces: a launch of one workgroup (12.8 us for a cfg3 window: dispatch, two dependent round trips, a
+// reduction, the candidate written to HBM) in front of a launch that began by reading that candidate back.
+#define XCL_MAX 4096            // ambient coordinates of a window the fused form takes (32 KB of LDS)
+template <bool IMU>
+__global__ void __launch_bounds__(256) k_step_eval(DevBatch B, DevOpt O, Segs S, WinState* ws_out, WinRec W) {
+    constexpr int SM_PRIOR = 2 * PRIOR_LDS_DIM + 16, SM_FS = FS_BLK * FS_HALF + 168 / 2 + 1;
+    __shared__ double sm[SM_PRIOR > SM_FS ? SM_PRIOR : SM_FS];
+    __shared__ double red[16 * 6];
+    __shared__ double pst[2 * WP_LDS];
+    __shared__ double xcl[XCL_MAX];
+    const int bid = blockIdx.x;
+    static_assert(XCL_MAX == 16 * CTL_NT, "d_dogleg stages x through XU = 16 registers per thread");
+    const int go = d_dogleg<16, 4, 16>(B, O, 0, W, B.ws, ws_out, bid == 0, xcl, red, pst);
+    __syncthreads();
+    if (!go) return;
+    DevBatch E = B;
+    E.xc = xcl - W.x_base; E.spec = 2;                  // evaluate at the LDS candidate, ungated (the state this grid reads still says "no candidate")
+    if (bid < S.e[0]) d_eval_proj_fs(E, bid, (double (*)[FS_HALF])sm, (int*)(sm + FS_BLK * FS_HALF));
+    else if (bid < S.e[1]) d_eval_scalar<true>(E, bid - S.e[0]);
+    else if (!IMU || bid < S.e[2]) d_eval_prior<true>(E, bid - S.e[1], sm);
+    else d_eval_imu<true>(E, bid - S.e[2]);
 }
 
 // acceptance test + trust-region update (TrustRegionMinimizer::Minimize loop body,
 // DoglegStrategy::StepAccepted / StepRejected / StepIsInvalid)
 __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
     __shared__ double red[16 * 2];
+    __shared__ double pst[WP_LDS];
     __shared__ int accept;
     int w = blockIdx.x, tid = threadIdx.x;
     WinState& s = B.ws[w];
@@ -1333,25 +1382,15 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
     // every load up front, as in k_dogleg: the candidate costs, and — speculatively — the candidate itself with the flags of its
     // coordinates (the first XU strided coordinates per thread: a cfg3 window's 1447 are all of them), so that an accepted step is stored
     // from registers
-    constexpr int U = 12, XU = 8;
-    double cvp[U], cvg[4], xcv[XU]; unsigned char xfl[XU];
-#pragma unroll
-    for (int u = 0; u < U; u++) { int i = W.proj0 + tid + u * CTL_NT; cvp[u] = i < W.proj1 ? B.p_cost[i] : 0.0; }
+    constexpr int XU = 8;
+    double cvg[4], xcv[XU]; unsigned char xfl[XU];
+    win_part_stage(B.p_cpart, W.fsb0, W.fsb1, pst);          // the projection factors' candidate costs: one value per frame-sum block
 #pragma unroll
     for (int u = 0; u < 4; u++) { int i = W.gf0 + tid + u * CTL_NT; cvg[u] = i < W.gf1 ? B.g_cost[i] : 0.0; }
 #pragma unroll
     for (int u = 0; u < XU; u++) { int i = W.x_base + tid + u * CTL_NT; bool ok = i < W.x_base + W.x_n; xcv[u] = ok ? B.xc[i] : 0.0; xfl[u] = ok ? B.x_var[i] : (unsigned char)0; }
     {
-        // candidate cost: the same guarded load groups and index-ordered additions as win_cost_aux_part, costs only
-#pragma unroll
-        for (int u = 0; u < U; u++) ca[0] += cvp[u];
-        for (int base = W.proj0 + tid + U * CTL_NT; base < W.proj1; base += U * CTL_NT) {
-            double cv[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) { int i = base + u * CTL_NT; cv[u] = i < W.proj1 ? B.p_cost[i] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < U; u++) ca[0] += cv[u];
-        }
+        // candidate cost: the formula of win_cost_sum (the generic factors' costs in index order per thread; the blocks' values behind the reduction)
 #pragma unroll
         for (int u = 0; u < 4; u++) ca[0] += cvg[u];
         for (int base = W.gf0 + tid + 4 * CTL_NT; base < W.gf1; base += 4 * CTL_NT) {
@@ -1363,7 +1402,7 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
         }
     }
     block_reduce<2, 0>(ca, red);
-    double cand = ca[0], model_cost_change = s.model_cost_change;
+    double cand = win_part_sum(B.p_cpart, W.fsb0, W.fsb1, pst) + ca[0], model_cost_change = s.model_cost_change;
     if (!(cand == cand) || cand > 1.7976931348623157e308) cand = 1.7976931348623157e308;
     __syncthreads();
     if (tid == 0) {
@@ -1429,14 +1468,17 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
 }
 
 // after the last slot: fold the final linearisation (cost, gradient norm) into the trace
-__global__ void __launch_bounds__(256) k_finalize(DevBatch B, DevOpt O) {
+__global__ void __launch_bounds__(256) k_finalize(DevBatch B, DevOpt O, WinState* ws_primary) {
     __shared__ double red[16];
+    __shared__ double pst[WP_LDS];
     int w = blockIdx.x, tid = threadIdx.x;
-    WinState& s = B.ws[w];
+    // (the latency path's fused step kernel leaves a window's state in the other of two buffers at every iteration: the solve ends in the primary one)
+    if (ws_primary != B.ws) { if (tid == 0) ws_primary[w] = B.ws[w]; __syncthreads(); }
+    WinState& s = ws_primary[w];
     const WinRec& W = B.win[w];
     swf_iteration* tr = B.trace + (size_t)w * B.max_iter_trace;
     if (s.need_lin && (s.status == SWF_RUNNING)) {
-        double x_cost = win_cost_sum(B, W, red);
+        double x_cost = win_cost_sum(B, W, red, pst);
         double gmax = win_gmax(B, W, red);
         if (tid == 0) {
             s.x_cost = x_cost; s.gmax = gmax; s.need_lin = 0;
