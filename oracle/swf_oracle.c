@@ -1957,7 +1957,8 @@ static void co_update_hidden(oracle_composite* c) {
  * compared with two-sidedly, while the literal reference is compared with the noise-free one inside the oracle (same decisions, cost
  * above it by exactly the counted noise terms: g_co_noise_*).  Not thread-safe; tests set it around single solves. */
 static double g_co_eig_cut_rel = 0.0;
-static double g_co_noise_cost = 0.0;      /* sum of r_k^2 / 2 over eigenvalues in (1e-8, 1e-14 lambda_max] that were KEPT, since the last reset */
+static double g_co_noise_cost = 0.0;      /* sum of r_k^2 / 2 over the NEAR-NULL eigenvalues that were KEPT — above the cut, at most 1e-10 lambda_max: rounding noise
+                                            * of the null space (<= ~1e-13 lambda_max) and the directions a rank-revealing factorisation may drop next to it — since the last reset */
 static long long g_co_noise_count = 0;    /* how many such eigenvalues */
 void oracle_set_composite_eig_cut(double rel) { g_co_eig_cut_rel = rel; }
 void oracle_composite_noise_stats(double* cost_sum, long long* count, int reset) {
@@ -1989,7 +1990,7 @@ static void co_schur_component(oracle_composite* c) {
         double dot = 0;
         for (int a = 0; a < G; a++) { c->J[k * G + a] = sq * V[a * G + k]; dot += V[a * G + k] * rd[a]; }
         c->r[k] = isq * dot;
-        if (lam > 0 && w[k] <= 1e-14 * w[G - 1]) { g_co_noise_cost += 0.5 * c->r[k] * c->r[k]; g_co_noise_count++; }
+        if (lam > 0 && w[k] <= 1e-10 * w[G - 1]) { g_co_noise_cost += 0.5 * c->r[k] * c->r[k]; g_co_noise_count++; }
     }
     free(Hd); free(rd); free(V); free(w);
 }

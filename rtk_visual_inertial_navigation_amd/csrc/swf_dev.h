@@ -31,6 +31,7 @@ struct WinRec {
     int tail_dim;                // dimensions of the parameter_head tail (last rows of the reduced system): the block of L its consumers read
     int n_pose_blk;              // the window's first n_pose_blk blocks are its pose blocks (7 -> 6, PoseLocalParameterization)
     int lmb0, lmb1;              // landmark back-substitution blocks of this window (DevBatch::lmb_rec)
+    int pch0, pch1;              // row chunks of this window's priors (DevBatch::pch_q / pch_r0)
     double proj_sqrt_info, proj_loss_a;
     double pbg[3], gw[3], base[3];
 };
@@ -164,7 +165,12 @@ struct DevBatch {
     int n_idp; const int* idp_gf;              // two-row projection factors of the generic path: inverse-depth (GF_IDP) and world-point (GF_PROJX) ones (also members of sc_gf for the J v products)
     int n_sc;  const int* sc_gf;
     int n_prior; const int* prior_gf;
-    // priors
+    // priors.  A prior of more than PRIOR_SPLIT_DIM rows is evaluated by one workgroup per chunk of PRIOR_CHUNK rows (its n x n record is
+    // n^2 doubles through ONE compute unit otherwise: 553 KB, 19 us per pass, for the 263-dimension marginalisation prior of BASELINE
+    // config 5); smaller ones are one chunk.  pch_q / pch_r0: prior and first row of every chunk; pr_cpart / pr_apart: the chunk's cost and
+    // its share of |J D^-2 g|^2, which the per-window control kernels add in chunk order (a prior's generic cost slot stays zero).
+    int n_pch; const int* pch_q; const int* pch_r0; const int* prior_nch;
+    double* pr_cpart; double* pr_apart;
     const int* prior_dim; const long long* prior_Joff; const int* prior_roff; const int* prior_x0off;
     const double* prior_J; const double* prior_r0; const double* prior_x0;
     const double* prior_Jt;          // the same records transposed (element (k, c) at c * n + k): the J v products read these, lanes over rows

@@ -236,6 +236,7 @@ struct swf_batch {
     }
     WinState* ws_primary = nullptr; WinState* ws_alt = nullptr;      // the per-window solver states and the second buffer the latency path's fused step kernel alternates with
     bool no_step_fuse = false;            // SWF_NO_STEP_FUSE=1: k_dogleg and the candidate's evaluation as two launches on the latency path too (parity: bit-identical)
+    int n_pch_split = 0;                  // row chunks of priors evaluated by several workgroups (dimension > PRIOR_SPLIT_DIM) with a static clique: k_prior_graw is launched
     bool no_spec = false;                 // SWF_NO_SPEC_EVAL=1: the dogleg loop with a cost pass at the candidate and a Jacobian pass behind k_decide (parity: bit-identical to the speculative flow)
     bool no_comp_fuse = false;            // SWF_NO_COMP_FUSE=1: the composite chain and the visual branch as launches of their own on the latency path too (A/B, parity)
     bool lat_fuse = false;                // latency path: fused grids on one stream (see swf_batch_create)
@@ -896,11 +897,30 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
         }
         D.n_lmb = (int)(lr.size() / 4);
         if (lr.empty()) lr.resize(4, 0);
+    }
+    std::vector<int> pch_q, pch_r0, prior_nch;
+    {
+        // row chunks of the priors (swf_dev.h): a prior beyond PRIOR_SPLIT_DIM rows is evaluated by one workgroup per PRIOR_CHUNK rows;
+        // a window's priors (the composite factors' records among them) are contiguous in prior_gf, and so are their chunks
+        for (WinRec& Wr : B.win) { Wr.pch0 = 0; Wr.pch1 = 0; }
+        int cur_w = -1;
+        for (size_t q = 0; q < B.prior_gf.size(); q++) {
+            const GFac& G = B.gf[(size_t)B.prior_gf[q]];
+            const int n = G.nres, nch = n > PRIOR_SPLIT_DIM ? (n + PRIOR_CHUNK - 1) / PRIOR_CHUNK : 1;
+            if (G.win != cur_w) { cur_w = G.win; B.win[(size_t)cur_w].pch0 = (int)pch_q.size(); }
+            prior_nch.push_back(nch);
+            for (int c = 0; c < nch; c++) { pch_q.push_back((int)q); pch_r0.push_back(nch > 1 ? c * PRIOR_CHUNK : 0); }
+            B.win[(size_t)cur_w].pch1 = (int)pch_q.size();
+            if (nch > 1 && G.clique >= 0 && B.cl[(size_t)G.clique].is_static) b->n_pch_split += nch;
+        }
+        D.n_pch = (int)pch_q.size();
+        if (pch_q.empty()) { pch_q.push_back(0); pch_r0.push_back(0); }
+        if (prior_nch.empty()) prior_nch.push_back(1);
         b->win = B.win;                                   // (the host's copy of the records, with the block ranges)
     }
 #define PUT(field, vec) rc |= P.put(vec, &D.field)
     PUT(win, B.win);
-    PUT(lmb_rec, lmb_lr);
+    PUT(lmb_rec, lmb_lr); PUT(pch_q, pch_q); PUT(pch_r0, pch_r0); PUT(prior_nch, prior_nch);
     PUT(blk_xoff, B.blk_xoff); PUT(blk_loc, B.blk_loc); PUT(blk_gs, B.blk_gs);
     if (B.loc2x.empty()) B.loc2x.push_back(-1);
     PUT(loc2x, B.loc2x); PUT(x_var, B.x_var);
@@ -1217,6 +1237,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     size_t np = (size_t)D.n_proj;
     rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl);
     rc |= P.zeros((size_t)std::max(1, D.n_fsb), &D.p_cpart); rc |= P.zeros((size_t)std::max(1, D.n_lmb), &D.p_apart);
+    rc |= P.zeros((size_t)std::max(1, D.n_pch), &D.pr_cpart); rc |= P.zeros((size_t)std::max(1, D.n_pch), &D.pr_apart);
     rc |= P.zeros(6 * (size_t)D.n_lm, &D.lm_Einv); rc |= P.zeros(3 * (size_t)D.n_lm, &D.lm_g);
     rc |= P.zeros(B.P_tot * GEMM_SPLIT, &D.P);
     rc |= P.zeros((size_t)std::max(1, 6 * B.n_fr) * GEMM_SPLIT, &D.lmq);
@@ -1498,7 +1519,7 @@ struct Launcher {
                 lm_next = ls_tiles_per_launch();
             }
             if (D.n_prior) {   // the prior records (the composite factors' among them, just rewritten): the prior segment of k_eval_ps alone
-                Segs P{}; P.e[2] = D.n_prior;
+                Segs P{}; P.e[2] = D.n_pch;
                 hipLaunchKernelGGL((k_eval_ps<true, true>), dim3(P.e[2]), dim3(256), 0, st, D, P);
             }
             return;
@@ -1536,7 +1557,7 @@ struct Launcher {
             Bracket t(*this, SWF_K_EVAL_PS);
             bool pf = b->max_prior_dim <= PRIOR_LDS_DIM;          // priors fused as a segment
             // (the projection segment: one workgroup per frame-sum block, the per-frame sums formed in the same kernel)
-            Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_prior : 0);
+            Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + (pf ? D.n_pch : 0);
             imu_fused = b->lat_fuse && D.n_imu > 0;          // latency path: the IMU factors as a segment of this grid
             S.e[3] = S.e[2] + (imu_fused ? nb(D.n_imu, IMU_FPB) : 0);
             if (imu_fused) hipLaunchKernelGGL((k_eval_ps<true, true, true>), dim3(S.e[3]), dim3(256), 0, st, D, S);
@@ -1545,7 +1566,7 @@ struct Launcher {
         if (D.n_idp) hipLaunchKernelGGL(k_eval_idp<true>, GRID(D.n_idp, 128), dim3(128), 0, st, D);
         // (large priors before the fork event: a prior-type record inside a group-0 clique writes its rows into that clique's Jacobian, and a
         // clique class with IMU factors runs on the auxiliary stream behind ev_fork[1] alone)
-        if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
+        if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) { Bracket t(*this, SWF_K_EVAL_PRIOR); hipLaunchKernelGGL(k_eval_prior<true>, dim3(D.n_pch), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D); }
         if (fork) (void)hipEventRecord(b->ev_fork[1], st);
         if (D.n_imu && !imu_fused) { Bracket t(*this, SWF_K_EVAL_IMU, sa); hipLaunchKernelGGL(k_eval_imu<true>, GRID(D.n_imu, IMU_FPB), dim3(IMU_FPB * IMU_LPF), 0, sa, D); }
     }
@@ -1602,6 +1623,8 @@ struct Launcher {
             }
             if (b->aux) (void)hipEventRecord(b->ev_fork[2], b->aux);
         }
+        // chunked priors with a static clique: graw = J^T r over column chunks, from the rows the evaluation left in g_r
+        if (b->n_pch_split) hipLaunchKernelGGL(k_prior_graw, dim3(D.n_pch), dim3(256), 0, st, D);
         if (b->aux) (void)hipStreamWaitEvent(st, b->ev_fork[2], 0);                  // join before the assembly
         if (D.n_pd) {
             Bracket t(*this, SWF_K_ASSEMBLE);
@@ -1636,7 +1659,7 @@ struct Launcher {
             Segs S{};
             S.e[0] = D.n_lmb; S.e[1] = S.e[0] + nb((size_t)D.n_cle * 16, 256);
             S.e[2] = S.e[1]; S.e[3] = S.e[2] + nb(D.n_sc, 256);                                 // (J D^-2 g of the projections rides in segment 0)
-            S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + D.n_prior;      // one workgroup per prior
+            S.e[4] = S.e[3] + nb((size_t)D.n_imu * 16, 256); S.e[5] = S.e[4] + D.n_pch;        // one workgroup per prior row chunk
             if (D.n_win < b->n_cu) { if (S.e[5]) hipLaunchKernelGGL(k_post_chol<0>, dim3(S.e[5]), dim3(256), 0, st, D, O, S); }
             else {
                 if (S.e[0]) hipLaunchKernelGGL(k_post_chol<1>, dim3(S.e[0]), dim3(256), 0, st, D, O, S);
@@ -1655,13 +1678,13 @@ struct Launcher {
     bool step_fuse_ok() const {
         const DevBatch& D = b->D;
         return b->lat_fuse && !b->no_step_fuse && !b->aux && D.n_win == 1 && b->win[0].x_n <= XCL_MAX && b->max_prior_dim <= PRIOR_LDS_DIM && !D.n_idp && !b->n_comp
-               && D.n_fsb + nb(D.n_sc, 256) + D.n_prior + nb(D.n_imu, IMU_FPB) > 0;
+               && D.n_fsb + nb(D.n_sc, 256) + D.n_pch + nb(D.n_imu, IMU_FPB) > 0;
     }
     // k_dogleg + the Jacobian evaluation at its candidate in one grid (k_step_eval); the window's state moves to the other buffer
     void step_eval() {
         DevBatch& D = b->D;
         Bracket t(*this, SWF_K_EVAL_PS);
-        Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + D.n_prior;
+        Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + D.n_pch;
         const bool imu = D.n_imu > 0;
         S.e[3] = S.e[2] + (imu ? nb(D.n_imu, IMU_FPB) : 0);
         WinState* out = D.ws == b->ws_primary ? b->ws_alt : b->ws_primary;
@@ -1679,7 +1702,7 @@ struct Launcher {
             Bracket t(*this, SWF_K_POST_DOGLEG);
             Segs S{};
             S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256);            // (the projection segment: one workgroup per frame-sum block, as in the Jacobian evaluation)
-            S.e[2] = S.e[1] + (b->max_prior_dim <= PRIOR_LDS_DIM ? D.n_prior : 0);
+            S.e[2] = S.e[1] + (b->max_prior_dim <= PRIOR_LDS_DIM ? D.n_pch : 0);
             // small batches (latency path): the candidate IMU residuals ride along as a segment; large batches keep them in
             // their own launch (the segment's LDS would cost the memory-bound segments occupancy).  Same results either way.
             bool fuse_imu = D.n_win < b->n_cu;
@@ -1694,7 +1717,7 @@ struct Launcher {
         }
         {
             Bracket t(*this, SWF_K_CAND_EVAL);
-            if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_prior), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
+            if (D.n_prior && b->max_prior_dim > PRIOR_LDS_DIM) hipLaunchKernelGGL(k_eval_prior<false>, dim3(D.n_pch), dim3(256), (2 * b->max_prior_dim + 16) * sizeof(double), st, D);
         }
         decide();
     }

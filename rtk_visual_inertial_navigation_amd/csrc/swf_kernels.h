@@ -634,9 +634,13 @@ __device__ __forceinline__ void prior_block_dx(const double* x, const double* x0
     dx[3] = sg * dq[0]; dx[4] = sg * dq[1]; dx[5] = sg * dq[2];
 }
 #define PRIOR_LDS_DIM 512               // priors up to this dimension ride as a segment of the fused evaluation grids
+#define PRIOR_SPLIT_DIM 96              // priors beyond this dimension are evaluated in row chunks, a workgroup each
+#define PRIOR_CHUNK 32
 template <bool JAC>
-__device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* sm) {      // sm: dx[n] | r[n] | red[16]
-    if (q >= B.n_prior) return;
+__device__ __forceinline__ void d_eval_prior(const DevBatch& B, int blk, double* sm) {      // sm: dx[n] | r[n] | red[16]
+    if (blk >= B.n_pch) return;
+    const int q = B.pch_q[blk], i_lo = B.pch_r0[blk];
+    const bool chunked = B.prior_nch[q] > 1;
     int f = B.prior_gf[q];
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
@@ -662,8 +666,9 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
     double part = 0;
     {
         const int q = threadIdx.x & 3, rq = threadIdx.x >> 2, rpb = blockDim.x >> 2;
-        for (int i0 = 0; i0 < n; i0 += rpb) {
-            const int i = i0 + rq;
+        const int i_hi = chunked ? (i_lo + PRIOR_CHUNK < n ? i_lo + PRIOR_CHUNK : n) : n;        // this workgroup's rows
+        for (int i0 = i_lo; i0 < i_hi; i0 += rpb) {
+            const int i = i0 + rq < i_hi ? i0 + rq : n;
             double a = 0;
             if (i < n) {
                 const double* row = Jp + (size_t)i * n;
@@ -684,9 +689,10 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
         }
     }
     double tot = block_sum(part, red);
-    if (threadIdx.x == 0) B.g_cost[f] = 0.5 * tot;
+    if (threadIdx.x == 0) B.pr_cpart[blk] = 0.5 * tot;
     if (!JAC) return;
     const Clique& C = B.cl[G.clique];
+    if (chunked && (C.is_static || i_lo > 0)) return;     // static: graw = J^T r needs every chunk's rows (k_prior_graw); else: the first chunk copies the record
     if (!C.is_static) {
         // a prior-type record inside the clique of a group-0 block (a composite factor on an eliminated speed-bias block): its columns
         // go into the clique's dense column-major Jacobian, next to the other factors' rows; J^T J, J^T r and the elimination are the
@@ -728,6 +734,41 @@ __device__ __forceinline__ void d_eval_prior(const DevBatch& B, int q, double* s
         if (mc >= 0) B.cv_graw[C.v_off + mc] = a;
     }
 }
+
+// graw = J^T r of a chunked prior with a static clique: a workgroup per chunk of PRIOR_CHUNK COLUMNS, behind the evaluation that left r
+// in g_r (a launch of its own, only when a batch holds such priors).  Thread (rg, jc): rows rg, rg + 8, ... of column jc; the eight
+// partial sums of a column added in a fixed order.
+__device__ __forceinline__ void d_prior_graw(const DevBatch& B, int blk) {
+    __shared__ double ps[8][PRIOR_CHUNK + 1];
+    if (blk >= B.n_pch) return;
+    const int q = B.pch_q[blk], j_lo = B.pch_r0[blk];
+    if (B.prior_nch[q] <= 1) return;
+    const GFac& G = B.gf[B.prior_gf[q]];
+    const WinState& s = B.ws[G.win];
+    if (!s.need_lin) return;
+    const Clique& C = B.cl[G.clique];
+    if (!C.is_static) return;
+    const int k = G.data, n = G.nres, jc = threadIdx.x & (PRIOR_CHUNK - 1), rg = threadIdx.x / PRIOR_CHUNK, j = j_lo + jc;
+    const double* Jp = B.prior_J + B.prior_Joff[k];
+    const double* r = B.g_r + G.roff;
+    double a = 0;
+    if (j < n) {
+        int i = rg;
+        for (; i + 24 < n; i += 32) {
+            const double x0 = Jp[(size_t)i * n + j], x1 = Jp[(size_t)(i + 8) * n + j], x2 = Jp[(size_t)(i + 16) * n + j], x3 = Jp[(size_t)(i + 24) * n + j];
+            a += x0 * r[i]; a += x1 * r[i + 8]; a += x2 * r[i + 16]; a += x3 * r[i + 24];
+        }
+        for (; i < n; i += 8) a += Jp[(size_t)i * n + j] * r[i];
+    }
+    ps[rg][jc] = a;
+    __syncthreads();
+    if (rg == 0 && j < n) {
+        double t = ((ps[0][jc] + ps[1][jc]) + (ps[2][jc] + ps[3][jc])) + ((ps[4][jc] + ps[5][jc]) + (ps[6][jc] + ps[7][jc]));
+        const int mc = B.prior_colcc[B.prior_roff[k] + j];
+        if (mc >= 0) B.cv_graw[C.v_off + mc] = t;
+    }
+}
+__global__ void __launch_bounds__(256) k_prior_graw(DevBatch B) { d_prior_graw(B, (int)blockIdx.x); }
 
 // stand-alone launch for priors larger than PRIOR_LDS_DIM (dynamic LDS)
 template <bool JAC>
@@ -822,9 +863,11 @@ __device__ __forceinline__ void d_jtimes_imu(const DevBatch& B, const DevOpt& O,
 // (every configuration but the stress window) bit-identical to the one-wavefront form.
 #define PRB_MAX 512
 template <int MODE>
-__device__ __forceinline__ void d_jtimes_prior(const DevBatch& B, const DevOpt& O, int q, double* sv, int* sl, double* sw) {
+__device__ __forceinline__ void d_jtimes_prior(const DevBatch& B, const DevOpt& O, int blk, double* sv, int* sl, double* sw) {
     const int tid = threadIdx.x;
-    if (q >= B.n_prior) return;
+    if (blk >= B.n_pch) return;
+    const int q = B.pch_q[blk], k_lo = B.pch_r0[blk];
+    const bool chunked = B.prior_nch[q] > 1;
     int f = B.prior_gf[q];
     const GFac& G = B.gf[f];
     const WinState& s = B.ws[G.win];
@@ -835,27 +878,49 @@ __device__ __forceinline__ void d_jtimes_prior(const DevBatch& B, const DevOpt& 
     if (staged) for (int c = tid; c < n; c += 256) { int lo = cl[c]; sl[c] = lo; sv[c] = lo >= 0 ? vec_at<MODE>(B, O, lo) : 0.0; }
     __syncthreads();
     double part = 0;
-    for (int k = tid; k < n; k += 256) {
-        double a;
-        if (staged) {
-            const double* ck = B.prior_Jt + B.prior_Joff[G.data] + k;
-            a = 0;
-            int c = 0;
-            for (; c + 8 <= n; c += 8) {
-                double cv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) cv[u] = ck[(size_t)(c + u) * n];
-#pragma unroll
-                for (int u = 0; u < 8; u++) if (sl[c + u] >= 0) a += cv[u] * sv[c + u];
+    if (chunked && staged) {
+        // a chunk of PRIOR_CHUNK rows: eight lanes per row over every eighth column (row-major record: a row's lanes read one run),
+        // the eight partial sums of a row added in a fixed order
+        const int p = tid & 7, k = k_lo + (tid >> 3);
+        double a = 0;
+        if (k < n) {
+            const double* row = B.prior_J + B.prior_Joff[G.data] + (size_t)k * n;
+            int c = p;
+            for (; c + 24 < n; c += 32) {
+                const double x0 = row[c], x1 = row[c + 8], x2 = row[c + 16], x3 = row[c + 24];
+                if (sl[c] >= 0) a += x0 * sv[c];
+                if (sl[c + 8] >= 0) a += x1 * sv[c + 8];
+                if (sl[c + 16] >= 0) a += x2 * sv[c + 16];
+                if (sl[c + 24] >= 0) a += x3 * sv[c + 24];
             }
-            for (; c < n; c++) if (sl[c] >= 0) a += ck[(size_t)c * n] * sv[c];
-        } else a = gf_row_dot<MODE>(B, O, G, k);
-        part += gf_row_term<MODE>(B, G, k, a);
+            for (; c < n; c += 8) if (sl[c] >= 0) a += row[c] * sv[c];
+        }
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+        if (k < n && p == 0) part = gf_row_term<MODE>(B, G, k, a);
+    } else {
+        const int k_hi = chunked ? (k_lo + PRIOR_CHUNK < n ? k_lo + PRIOR_CHUNK : n) : n;
+        for (int k = k_lo + tid; k < k_hi; k += 256) {
+            double a;
+            if (staged) {
+                const double* ck = B.prior_Jt + B.prior_Joff[G.data] + k;
+                a = 0;
+                int c = 0;
+                for (; c + 8 <= n; c += 8) {
+                    double cv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) cv[u] = ck[(size_t)(c + u) * n];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (sl[c + u] >= 0) a += cv[u] * sv[c + u];
+                }
+                for (; c < n; c++) if (sl[c] >= 0) a += ck[(size_t)c * n] * sv[c];
+            } else a = gf_row_dot<MODE>(B, O, G, k);
+            part += gf_row_term<MODE>(B, G, k, a);
+        }
     }
     part = wave_sum(part);
     if ((tid & 63) == 0) sw[tid >> 6] = part;
     __syncthreads();
-    if (tid == 0) B.g_aux[f] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+    if (tid == 0) B.pr_apart[blk] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
 }
 
 #include "swf_lmschur.h"

@@ -995,12 +995,14 @@ __device__ __forceinline__ double win_part_sum(const double* part, int q0, int q
     for (int q = WP_LDS; q < n; q++) a += part[q0 + q];
     return a;
 }
-__device__ __forceinline__ double win_cost_sum(const DevBatch& B, const WinRec& W, double* red, double* st) {
+// cost = ((projection blocks + prior chunks) + generic factors)
+__device__ __forceinline__ double win_cost_sum(const DevBatch& B, const WinRec& W, double* red, double* st /* 2 WP_LDS */) {
     win_part_stage(B.p_cpart, W.fsb0, W.fsb1, st);
+    win_part_stage(B.pr_cpart, W.pch0, W.pch1, st + WP_LDS);
     double a = 0;
     for (int i = W.gf0 + threadIdx.x; i < W.gf1; i += blockDim.x) a += B.g_cost[i];
     a = block_sum(a, red);
-    return win_part_sum(B.p_cpart, W.fsb0, W.fsb1, st) + a;
+    return (win_part_sum(B.p_cpart, W.fsb0, W.fsb1, st) + win_part_sum(B.pr_cpart, W.pch0, W.pch1, st + WP_LDS)) + a;
 }
 // || x ||_2 over variable blocks (ambient coordinates)
 __device__ __forceinline__ double win_x_norm(const DevBatch& B, const WinRec& W, const double* x, double* red) {
@@ -1082,7 +1084,7 @@ __device__ unsigned long long g_dog_stamps[16];
 // level depends on nothing but the kernel's arguments: ONE round trip ahead of the sums (the record and the state were one of their own).
 // Returns 1 (uniform over the workgroup) if a candidate was formed.
 template <int DU, int GU, int XU = 1>
-__device__ __forceinline__ int d_dogleg(const DevBatch& B, const DevOpt& O, const int w, const WinRec& W, const WinState* sin, WinState* sout, const bool lead, double* xcl, double* red, double* pst /* LDS, 2 WP_LDS doubles */) {
+__device__ __forceinline__ int d_dogleg(const DevBatch& B, const DevOpt& O, const int w, const WinRec& W, const WinState* sin, WinState* sout, const bool lead, double* xcl, double* red, double* pst /* LDS, 4 WP_LDS doubles */) {
 #ifdef SWF_PROFILE_DOG
     unsigned long long td_ = __builtin_amdgcn_s_memtime();
     if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < 16; i++) g_dog_stamps[i] = 0;
@@ -1111,6 +1113,7 @@ __device__ __forceinline__ int d_dogleg(const DevBatch& B, const DevOpt& O, cons
     // the projection factors' share of the cost and of |J D^-2 g|^2: the blocks' partial sums (left by the evaluation and by k_post_chol)
     // (none of these loads waits for the window's state: whether the linearisation is fresh decides only what is added up)
     win_part_stage(B.p_cpart, W.fsb0, W.fsb1, pst); win_part_stage(B.p_apart, W.lmb0, W.lmb1, pst + WP_LDS);
+    win_part_stage(B.pr_cpart, W.pch0, W.pch1, pst + 2 * WP_LDS); win_part_stage(B.pr_apart, W.pch0, W.pch1, pst + 3 * WP_LDS);
     double xin[XU];
     if (xcl) {
 #pragma unroll
@@ -1190,8 +1193,8 @@ __device__ __forceinline__ int d_dogleg(const DevBatch& B, const DevOpt& O, cons
         for (int u = 0; u < DU; u++) xv[u] = lxv[u] >= 0 ? xcl[lxv[u] - xb] : 0.0;
     }
     if (fresh) {
-        x_cost = win_part_sum(B.p_cpart, W.fsb0, W.fsb1, pst) + v[0];
-        if (!t.lin_fail) { jg_sq = win_part_sum(B.p_apart, W.lmb0, W.lmb1, pst + WP_LDS) + v[1]; gmax = v[5]; }
+        x_cost = (win_part_sum(B.p_cpart, W.fsb0, W.fsb1, pst) + win_part_sum(B.pr_cpart, W.pch0, W.pch1, pst + 2 * WP_LDS)) + v[0];
+        if (!t.lin_fail) { jg_sq = (win_part_sum(B.p_apart, W.lmb0, W.lmb1, pst + WP_LDS) + win_part_sum(B.pr_apart, W.pch0, W.pch1, pst + 3 * WP_LDS)) + v[1]; gmax = v[5]; }
     }
     const double gsq = v[2], ynn = v[3], gdot = v[4];
     // the bookkeeping of FinalizeIterationAndCheckIfMinimizerCanContinue, by every thread on its copy of the state (uniform)
@@ -1336,7 +1339,7 @@ __device__ __forceinline__ int d_dogleg(const DevBatch& B, const DevOpt& O, cons
 template <int DU, int GU>
 __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
     __shared__ double red[16 * 6];
-    __shared__ double pst[2 * WP_LDS];
+    __shared__ double pst[4 * WP_LDS];
     WinState* s = B.ws + blockIdx.x;
     (void)d_dogleg<DU, GU>(B, O, (int)blockIdx.x, B.win[blockIdx.x], s, s, true, nullptr, red, pst);
 }
@@ -1353,7 +1356,7 @@ __global__ void __launch_bounds__(256) k_step_eval(DevBatch B, DevOpt O, Segs S,
     constexpr int SM_PRIOR = 2 * PRIOR_LDS_DIM + 16, SM_FS = FS_BLK * FS_HALF + 168 / 2 + 1;
     __shared__ double sm[SM_PRIOR > SM_FS ? SM_PRIOR : SM_FS];
     __shared__ double red[16 * 6];
-    __shared__ double pst[2 * WP_LDS];
+    __shared__ double pst[4 * WP_LDS];
     __shared__ double xcl[XCL_MAX];
     const int bid = blockIdx.x;
     static_assert(XCL_MAX == 16 * CTL_NT, "d_dogleg stages x through XU = 16 registers per thread");
@@ -1372,7 +1375,7 @@ __global__ void __launch_bounds__(256) k_step_eval(DevBatch B, DevOpt O, Segs S,
 // DoglegStrategy::StepAccepted / StepRejected / StepIsInvalid)
 __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
     __shared__ double red[16 * 2];
-    __shared__ double pst[WP_LDS];
+    __shared__ double pst[2 * WP_LDS];
     __shared__ int accept;
     int w = blockIdx.x, tid = threadIdx.x;
     WinState& s = B.ws[w];
@@ -1385,6 +1388,7 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
     constexpr int XU = 8;
     double cvg[4], xcv[XU]; unsigned char xfl[XU];
     win_part_stage(B.p_cpart, W.fsb0, W.fsb1, pst);          // the projection factors' candidate costs: one value per frame-sum block
+    win_part_stage(B.pr_cpart, W.pch0, W.pch1, pst + WP_LDS);   // the priors': one per row chunk
 #pragma unroll
     for (int u = 0; u < 4; u++) { int i = W.gf0 + tid + u * CTL_NT; cvg[u] = i < W.gf1 ? B.g_cost[i] : 0.0; }
 #pragma unroll
@@ -1402,7 +1406,7 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
         }
     }
     block_reduce<2, 0>(ca, red);
-    double cand = win_part_sum(B.p_cpart, W.fsb0, W.fsb1, pst) + ca[0], model_cost_change = s.model_cost_change;
+    double cand = (win_part_sum(B.p_cpart, W.fsb0, W.fsb1, pst) + win_part_sum(B.pr_cpart, W.pch0, W.pch1, pst + WP_LDS)) + ca[0], model_cost_change = s.model_cost_change;
     if (!(cand == cand) || cand > 1.7976931348623157e308) cand = 1.7976931348623157e308;
     __syncthreads();
     if (tid == 0) {
@@ -1470,7 +1474,7 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
 // after the last slot: fold the final linearisation (cost, gradient norm) into the trace
 __global__ void __launch_bounds__(256) k_finalize(DevBatch B, DevOpt O, WinState* ws_primary) {
     __shared__ double red[16];
-    __shared__ double pst[WP_LDS];
+    __shared__ double pst[2 * WP_LDS];
     int w = blockIdx.x, tid = threadIdx.x;
     // (the latency path's fused step kernel leaves a window's state in the other of two buffers at every iteration: the solve ends in the primary one)
     if (ws_primary != B.ws) { if (tid == 0) ws_primary[w] = B.ws[w]; __syncthreads(); }

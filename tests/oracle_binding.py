@@ -130,7 +130,7 @@ def solve(win, opt=None, export=True):
 class composite_eig_cut:
     """Context manager around oracle solves: the composite factors' eigen square root cuts at max(1e-8, rel * lambda_max) instead of the
     reference's absolute 1e-8 (oracle/swf_oracle.c: the NOISE-FREE restatement; rel = 0 is the reference, literally).  .noise() returns
-    (sum of r_k^2 / 2, count) over the noise eigenvalues (<= 1e-14 lambda_max) that were KEPT since the context was entered."""
+    (sum of r_k^2 / 2, count) over the near-null eigenvalues (<= 1e-10 lambda_max) that were KEPT since the context was entered."""
     def __init__(self, rel):
         self.rel = float(rel)
 

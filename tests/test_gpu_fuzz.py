@@ -52,8 +52,9 @@ def test_fuzz_marginalize_slice():
 
 @pytest.mark.gpu
 def test_fuzz_composite_slice():
-    """The reference's own topology (composite IMU-GNSS factors): seed 4 of the sweep, which holds the two four-satellite windows
-    whose device and oracle end states lie a centimetre apart along the weakly determined global position — compared there through the
-    explicit problem's cost (no composite factor, no square root in it)."""
+    """The reference's own topology (composite IMU-GNSS factors): seed 4 of the sweep, with BOTH square roots against the oracle's
+    noise-free restatement two-sidedly and against the literal reference within the near-null cost it kept (tests/composite_parity.py).
+    The seed holds a four-satellite window whose device and oracle end states lie apart along the weakly determined global position —
+    compared there, two-sidedly, through the explicit problem's cost (no composite factor, no square root in it)."""
     out = _run("fuzz_composite.py", 36, 4)
-    assert "36 cases, 0 failures" in out and out.count("explicit-problem cost at the end states") >= 2
+    assert "36 cases, 0 failures" in out and out.count("explicit-problem cost at the end states") >= 1
