@@ -234,7 +234,8 @@ struct swf_batch {
         if (aux) { (void)hipStreamSynchronize(aux); handle_cache().give(aux); }
         for (auto& e : ev_fork) handle_cache().give(e, false);
     }
-    WinState* ws_primary = nullptr; WinState* ws_alt = nullptr;      // the per-window solver states and the second buffer the latency path's fused step kernel alternates with
+    WinState* ws_primary = nullptr; WinState* ws_alt = nullptr; WinState* ws_alt2 = nullptr;      // the per-window solver states and the two further buffers the latency path's fused kernels rotate through (k_step_eval, k_decide_lm_clique)
+    bool no_decide_fuse = false;          // SWF_NO_DECIDE_FUSE=1: k_decide as its own launch on the latency path too (parity: bit-identical)
     bool no_step_fuse = false;            // SWF_NO_STEP_FUSE=1: k_dogleg and the candidate's evaluation as two launches on the latency path too (parity: bit-identical)
     int n_pch_split = 0;                  // row chunks of priors evaluated by several workgroups (dimension > PRIOR_SPLIT_DIM) with a static clique: k_prior_graw is launched
     bool no_spec = false;                 // SWF_NO_SPEC_EVAL=1: the dogleg loop with a cost pass at the candidate and a Jacobian pass behind k_decide (parity: bit-identical to the speculative flow)
@@ -852,6 +853,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     b->no_comp_fuse = getenv("SWF_NO_COMP_FUSE") != nullptr;
     b->no_spec = getenv("SWF_NO_SPEC_EVAL") != nullptr;
     b->no_step_fuse = getenv("SWF_NO_STEP_FUSE") != nullptr;
+    b->no_decide_fuse = getenv("SWF_NO_DECIDE_FUSE") != nullptr;
     // auxiliary stream: the latency path (<= n_CU / 16 windows), and batches of half a chip to a chip of windows, where the IMU / clique branch
     // fills what one-block-per-window kernels leave idle (measured: 256 windows 5.52 -> 5.22 ms, 128 windows 3.73 -> 3.49 ms per solve; 64 and
     // 512 windows: no gain)
@@ -1232,7 +1234,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
     if (b->max_red > b->rr_nmax && b->max_red <= CB_NMAX) rc |= P.zeros((size_t)n * (CB_MAXT - 1) * 256, &D.Linv);
     // few windows, one of them on the streamed Cholesky: the factorisation is spread over the chip, two tile columns per launch (k_chol_col)
     if (b->max_red > b->rr_nmax && b->max_red <= CC_NMAX && n * 4 <= b->n_cu && !getenv("SWF_NO_CHOL_COL")) rc |= P.zeros(B.Lt_tot, &D.Wk);      // >= 4 workgroups per window
-    rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n, &b->ws_alt); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
+    rc |= P.zeros((size_t)n, &D.ws); rc |= P.zeros((size_t)n, &b->ws_alt); rc |= P.zeros((size_t)n, &b->ws_alt2); rc |= P.zeros((size_t)n * SWF_MAX_TRACE, &D.trace);
     b->ws_primary = D.ws;
     size_t np = (size_t)D.n_proj;
     rc |= P.zeros(2 * np, &D.p_r); rc |= P.zeros(12 * np, &D.p_Jp); rc |= P.zeros(6 * np, &D.p_Jl);
@@ -1438,6 +1440,8 @@ struct Launcher {
     int lm_next = 0, lm_qpb = 1;                 // first tile of the ranges of k_lm_schur still to launch (with the clique kernels)
     int ls_tiles_per_launch() const { return b->ls_var == 0 ? 16 : b->ls_var == 1 ? 40 : 72; }
     // one launch of the landmark Schur kernel over the tile-list entries [tile_base, tile_base + tiles per launch), by row class
+    WinState* ws_next(WinState* p) const { return p == b->ws_primary ? b->ws_alt : p == b->ws_alt ? b->ws_alt2 : b->ws_primary; }
+    bool decide_fused = false;  // this iteration's k_decide rides at the head of the elimination grid (k_decide_lm_clique)
     void lm_launch(int tile_base, hipStream_t on, int clique_rows = 0) {
         DevBatch& D = b->D;
         dim3 grid(D.n_win, GEMM_SPLIT / b->ls_qpb);
@@ -1445,6 +1449,13 @@ struct Launcher {
         if (clique_rows > 0) {
             const int np = (int)grid.y;
             grid.y += clique_rows;
+            if (decide_fused) {
+                WinState* out = ws_next(D.ws);                  // (its failure flags were cleared by k_step_eval's lead)
+                if (b->ls_var == 0) hipLaunchKernelGGL((k_decide_lm_clique<8, 2, 2, 80>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd, np, out);
+                else hipLaunchKernelGGL((k_decide_lm_clique<8, 5, 2, 144>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd, np, out);
+                D.ws = out;
+                return;
+            }
             switch (b->ls_var) {
             case 0: hipLaunchKernelGGL((k_lm_clique<8, 2, 2, 80>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd, np); break;
             case 1: hipLaunchKernelGGL((k_lm_clique<8, 5, 2, 144>), grid, dim3(LS_NT(8, 2)), 0, on, D, O, qpb, lp, kms, sd, np); break;
@@ -1592,8 +1603,7 @@ struct Launcher {
                 // latency path: the one-wavefront cliques ride in the same grid (k_lm_clique); the 64-frame class has no LDS to spare for them
                 // (a workgroup of that grid fills a CU: only while all of them — landmark parts and cliques — are resident at once)
                 const int crow = D.n_win > 0 ? (D.n_clc[2] + D.n_win - 1) / D.n_win : 0;
-                clq_fused = b->lat_fuse && b->ls_var <= 2 && D.n_clc[2] > 0 && !D.n_clc[0] && !D.n_clc[1]
-                            && (long long)D.n_win * (GEMM_SPLIT / b->ls_qpb + crow) <= b->n_cu;
+                clq_fused = clq_fuse_ok();
                 lm_launch(0, st, clq_fused ? crow : 0);
                 lm_next = ls_tiles_per_launch();        // further tile ranges: launched below, on the auxiliary stream when there is one
             }
@@ -1675,6 +1685,15 @@ struct Launcher {
         if (b->lat_fuse) hipLaunchKernelGGL((k_dogleg<16, 4>), dim3(D.n_win), dim3(CTL_NT), 0, st, D, O);
         else hipLaunchKernelGGL((k_dogleg<4, 2>), dim3(D.n_win), dim3(CTL_NT), 0, st, D, O);
     }
+    bool clq_fuse_ok() const {
+        const DevBatch& D = b->D;
+        const int crow = D.n_win > 0 ? (D.n_clc[2] + D.n_win - 1) / D.n_win : 0;
+        return b->lat_fuse && b->ls_var <= 2 && D.n_lm > 0 && D.n_clc[2] > 0 && !D.n_clc[0] && !D.n_clc[1]
+               && (long long)D.n_win * (GEMM_SPLIT / b->ls_qpb + crow) <= b->n_cu;
+    }
+    // k_decide at the head of the elimination grid: one window, the fused step kernel in front (three state buffers in rotation), the
+    // cliques in the landmark product's grid, the two smaller size classes of that grid (the third has no LDS to spare)
+    bool decide_fuse_ok() const { return step_fused && !b->no_decide_fuse && clq_fuse_ok() && b->ls_var <= 1 && b->max_tiles <= ls_tiles_per_launch(); }
     bool step_fuse_ok() const {
         const DevBatch& D = b->D;
         return b->lat_fuse && !b->no_step_fuse && !b->aux && D.n_win == 1 && b->win[0].x_n <= XCL_MAX && b->max_prior_dim <= PRIOR_LDS_DIM && !D.n_idp && !b->n_comp
@@ -1687,9 +1706,10 @@ struct Launcher {
         Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + D.n_pch;
         const bool imu = D.n_imu > 0;
         S.e[3] = S.e[2] + (imu ? nb(D.n_imu, IMU_FPB) : 0);
-        WinState* out = D.ws == b->ws_primary ? b->ws_alt : b->ws_primary;
-        if (imu) hipLaunchKernelGGL((k_step_eval<true>), dim3(S.e[3]), dim3(256), 0, st, D, O, S, out, b->win[0]);
-        else hipLaunchKernelGGL((k_step_eval<false>), dim3(S.e[2]), dim3(256), 0, st, D, O, S, out, b->win[0]);
+        WinState* out = ws_next(D.ws);
+        WinState* clr = decide_fused ? ws_next(out) : nullptr;      // the buffer k_decide_lm_clique will write: its failure flags go down here
+        if (imu) hipLaunchKernelGGL((k_step_eval<true>), dim3(S.e[3]), dim3(256), 0, st, D, O, S, out, b->win[0], clr);
+        else hipLaunchKernelGGL((k_step_eval<false>), dim3(S.e[2]), dim3(256), 0, st, D, O, S, out, b->win[0], clr);
         D.ws = out;
     }
     void decide() {
@@ -1759,8 +1779,9 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
                 L.reduced();
                 L.step_rest();
                 if (spec) {
+                    L.decide_fused = it < opt->max_num_iterations && L.decide_fuse_ok();
                     if (L.step_fused) L.step_eval(); else L.lin_eval(1, true);
-                    L.decide();
+                    if (!L.decide_fused) L.decide();
                     if (b->aux) (void)hipEventRecord(b->ev_fork[1], st);          // the auxiliary stream's clique branch starts behind k_decide
                     L.lin_elim(it < opt->max_num_iterations ? 1 : 0); nlin++;
                 }

@@ -1352,7 +1352,7 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
 // reduction, the candidate written to HBM) in front of a launch that began by reading that candidate back.
 #define XCL_MAX 4096            // ambient coordinates of a window the fused form takes (32 KB of LDS)
 template <bool IMU>
-__global__ void __launch_bounds__(256) k_step_eval(DevBatch B, DevOpt O, Segs S, WinState* ws_out, WinRec W) {
+__global__ void __launch_bounds__(256) k_step_eval(DevBatch B, DevOpt O, Segs S, WinState* ws_out, WinRec W, WinState* ws_clr) {
     constexpr int SM_PRIOR = 2 * PRIOR_LDS_DIM + 16, SM_FS = FS_BLK * FS_HALF + 168 / 2 + 1;
     __shared__ double sm[SM_PRIOR > SM_FS ? SM_PRIOR : SM_FS];
     __shared__ double red[16 * 6];
@@ -1360,6 +1360,9 @@ __global__ void __launch_bounds__(256) k_step_eval(DevBatch B, DevOpt O, Segs S,
     __shared__ double xcl[XCL_MAX];
     const int bid = blockIdx.x;
     static_assert(XCL_MAX == 16 * CTL_NT, "d_dogleg stages x through XU = 16 registers per thread");
+    // (ws_clr: the buffer the elimination grid behind k_decide will leave the state in — k_decide_lm_clique; nothing reads it during this
+    // grid, and its failure flags have to be down before that grid's workgroups may raise them)
+    if (bid == 0 && threadIdx.x == 0 && ws_clr) { ws_clr->lin_fail = 0; ws_clr->chol_fail = 0; }
     const int go = d_dogleg<16, 4, 16>(B, O, 0, W, B.ws, ws_out, bid == 0, xcl, red, pst);
     __syncthreads();
     if (!go) return;
@@ -1373,27 +1376,38 @@ __global__ void __launch_bounds__(256) k_step_eval(DevBatch B, DevOpt O, Segs S,
 
 // acceptance test + trust-region update (TrustRegionMinimizer::Minimize loop body,
 // DoglegStrategy::StepAccepted / StepRejected / StepIsInvalid)
-__global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
-    __shared__ double red[16 * 2];
-    __shared__ double pst[2 * WP_LDS];
-    __shared__ int accept;
-    int w = blockIdx.x, tid = threadIdx.x;
-    WinState& s = B.ws[w];
-    if (s.status != SWF_RUNNING || !s.eval_cand) return;
+// every field of the window's state but the failure flags (which the kernels of a linearisation set on their own: see k_decide_lm_clique)
+__device__ __forceinline__ void ws_store_nofail(WinState* d, const WinState& t) {
+    d->radius = t.radius; d->mu = t.mu; d->x_cost = t.x_cost; d->x_norm = t.x_norm; d->alpha = t.alpha; d->dogleg_step_norm = t.dogleg_step_norm;
+    d->step_norm = t.step_norm; d->gmax = t.gmax; d->jg_sq = t.jg_sq; d->initial_cost = t.initial_cost; d->lm_dec = t.lm_dec;
+    d->model_cost_change = t.model_cost_change; d->status = t.status; d->iter = t.iter; d->need_lin = t.need_lin; d->reuse = t.reuse;
+    d->eval_cand = t.eval_cand; d->invalid_run = t.invalid_run; d->nsucc = t.nsucc; d->nunsucc = t.nunsucc;
+}
+// The body of k_decide as a device function (the latency path runs it at the head of the elimination grid: k_decide_lm_clique).  Threads
+// [0, CTL_NT) of the workgroup carry the sums (the same strided order whatever the workgroup's size: the other waves add zeros); EVERY
+// thread takes the decision on its copy t of the state (uniform values, same bits); the LEAD workgroup alone writes: the trace, an
+// accepted candidate into x, and the new state into sout (every field but the failure flags; sout == sin for the in-place launch).
+// t: the state after the decision (t.x_norm is refreshed in the lead only: nothing in the same grid reads it).
+__device__ __forceinline__ void d_decide(const DevBatch& B, const DevOpt& O, const int w, const WinState* sin, WinState* sout, const bool lead,
+                                         double* red /* 32 */, double* pst /* 2 WP_LDS */, WinState& t) {
+    const int tid = threadIdx.x;
+    t = *sin;
+    const bool wr = lead && tid == 0;
+    if (t.status != SWF_RUNNING || !t.eval_cand) { if (wr && sout != sin) ws_store_nofail(sout, t); return; }
     const WinRec& W = B.win[w];
     double ca[2] = { 0.0, 0.0 };
-    // every load up front, as in k_dogleg: the candidate costs, and — speculatively — the candidate itself with the flags of its
-    // coordinates (the first XU strided coordinates per thread: a cfg3 window's 1447 are all of them), so that an accepted step is stored
-    // from registers
+    // every load up front, as in k_dogleg: the candidate costs, and — speculatively, in the lead — the candidate itself with the flags of
+    // its coordinates (the first XU strided coordinates per thread: a cfg3 window's 1447 are all of them), so that an accepted step is
+    // stored from registers
     constexpr int XU = 8;
+    const bool st_ = tid < CTL_NT;                            // the threads of the strided sums
     double cvg[4], xcv[XU]; unsigned char xfl[XU];
-    win_part_stage(B.p_cpart, W.fsb0, W.fsb1, pst);          // the projection factors' candidate costs: one value per frame-sum block
-    win_part_stage(B.pr_cpart, W.pch0, W.pch1, pst + WP_LDS);   // the priors': one per row chunk
+    if (st_) { win_part_stage(B.p_cpart, W.fsb0, W.fsb1, pst); win_part_stage(B.pr_cpart, W.pch0, W.pch1, pst + WP_LDS); }      // (staged by CTL_NT threads: blockDim may be larger)
 #pragma unroll
-    for (int u = 0; u < 4; u++) { int i = W.gf0 + tid + u * CTL_NT; cvg[u] = i < W.gf1 ? B.g_cost[i] : 0.0; }
+    for (int u = 0; u < 4; u++) { int i = W.gf0 + tid + u * CTL_NT; cvg[u] = (st_ && i < W.gf1) ? B.g_cost[i] : 0.0; }
 #pragma unroll
-    for (int u = 0; u < XU; u++) { int i = W.x_base + tid + u * CTL_NT; bool ok = i < W.x_base + W.x_n; xcv[u] = ok ? B.xc[i] : 0.0; xfl[u] = ok ? B.x_var[i] : (unsigned char)0; }
-    {
+    for (int u = 0; u < XU; u++) { int i = W.x_base + tid + u * CTL_NT; bool ok = lead && st_ && i < W.x_base + W.x_n; xcv[u] = ok ? B.xc[i] : 0.0; xfl[u] = ok ? B.x_var[i] : (unsigned char)0; }
+    if (st_) {
         // candidate cost: the formula of win_cost_sum (the generic factors' costs in index order per thread; the blocks' values behind the reduction)
 #pragma unroll
         for (int u = 0; u < 4; u++) ca[0] += cvg[u];
@@ -1406,69 +1420,117 @@ __global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
         }
     }
     block_reduce<2, 0>(ca, red);
-    double cand = (win_part_sum(B.p_cpart, W.fsb0, W.fsb1, pst) + win_part_sum(B.pr_cpart, W.pch0, W.pch1, pst + WP_LDS)) + ca[0], model_cost_change = s.model_cost_change;
+    double cand = (win_part_sum(B.p_cpart, W.fsb0, W.fsb1, pst) + win_part_sum(B.pr_cpart, W.pch0, W.pch1, pst + WP_LDS)) + ca[0];
+    const double model_cost_change = t.model_cost_change;
     if (!(cand == cand) || cand > 1.7976931348623157e308) cand = 1.7976931348623157e308;
-    __syncthreads();
-    if (tid == 0) {
-        accept = 0;
+    int accept = 0;
+    {
         swf_iteration* tr = B.trace + (size_t)w * B.max_iter_trace;
-        swf_iteration& rec = tr[s.iter < B.max_iter_trace ? s.iter : B.max_iter_trace - 1];
-        s.eval_cand = 0;
-        rec.model_cost_change = model_cost_change;
+        swf_iteration& rec = tr[t.iter < B.max_iter_trace ? t.iter : B.max_iter_trace - 1];
+        swf_iteration r_{};                                   // the record's fields, written by the lead's thread 0 below
+        t.eval_cand = 0;
+        int fld = 0;                                          // bit 0: step_norm / cost_change, bit 1: relative_decrease / step_is_successful
         if (!(model_cost_change > 0.0)) {
-            rec.step_is_valid = 0; rec.cost = s.x_cost; rec.trust_region_radius = s.radius;
-            s.reuse = 0; s.need_lin = 1;
-            if (++s.invalid_run >= 5) s.status = SWF_LINEAR_SOLVER_FAILURE;
-            else if (O.strategy == SWF_LEVENBERG_MARQUARDT) { s.radius /= s.lm_dec; s.lm_dec *= 2.0; s.mu = 1.0 / s.radius; rec.trust_region_radius = s.radius; }
-            else s.mu *= O.mu_inc;
+            r_.step_is_valid = 0; r_.cost = t.x_cost; r_.trust_region_radius = t.radius;
+            t.reuse = 0; t.need_lin = 1;
+            if (++t.invalid_run >= 5) t.status = SWF_LINEAR_SOLVER_FAILURE;
+            else if (O.strategy == SWF_LEVENBERG_MARQUARDT) { t.radius /= t.lm_dec; t.lm_dec *= 2.0; t.mu = 1.0 / t.radius; r_.trust_region_radius = t.radius; }
+            else t.mu *= O.mu_inc;
         } else {
-            rec.step_is_valid = 1; s.invalid_run = 0;
-            rec.step_norm = s.step_norm;
-            rec.cost_change = s.x_cost - cand;
-            if (s.step_norm <= O.ptol * (s.x_norm + O.ptol)) {
-                rec.cost = s.x_cost; rec.trust_region_radius = s.radius; s.status = SWF_CONVERGED_PARAMETER;
-            } else if (fabs(rec.cost_change) <= O.ftol * s.x_cost) {
-                rec.cost = s.x_cost; rec.trust_region_radius = s.radius; s.status = SWF_CONVERGED_FUNCTION;
+            r_.step_is_valid = 1; t.invalid_run = 0;
+            r_.step_norm = t.step_norm;
+            r_.cost_change = t.x_cost - cand;
+            fld = 1;
+            if (t.step_norm <= O.ptol * (t.x_norm + O.ptol)) {
+                r_.cost = t.x_cost; r_.trust_region_radius = t.radius; t.status = SWF_CONVERGED_PARAMETER;
+            } else if (fabs(r_.cost_change) <= O.ftol * t.x_cost) {
+                r_.cost = t.x_cost; r_.trust_region_radius = t.radius; t.status = SWF_CONVERGED_FUNCTION;
             } else {
-                rec.relative_decrease = rec.cost_change / model_cost_change;
-                if (rec.relative_decrease > O.min_rel_dec) {
+                fld = 3;
+                r_.relative_decrease = r_.cost_change / model_cost_change;
+                if (r_.relative_decrease > O.min_rel_dec) {
                     accept = 1;
-                    rec.step_is_successful = 1; rec.cost = cand; s.x_cost = cand; s.nsucc++;
+                    r_.step_is_successful = 1; r_.cost = cand; t.x_cost = cand; t.nsucc++;
                     if (O.strategy == SWF_LEVENBERG_MARQUARDT) {
                         // LevenbergMarquardtStrategy::StepAccepted
-                        double q = 2.0 * rec.relative_decrease - 1.0, f = 1.0 - q * q * q;
-                        s.radius = s.radius / (f > 1.0 / 3.0 ? f : 1.0 / 3.0);
-                        s.radius = s.radius < O.max_r ? s.radius : O.max_r;
-                        s.lm_dec = 2.0; s.mu = 1.0 / s.radius;
+                        double q = 2.0 * r_.relative_decrease - 1.0, f = 1.0 - q * q * q;
+                        t.radius = t.radius / (f > 1.0 / 3.0 ? f : 1.0 / 3.0);
+                        t.radius = t.radius < O.max_r ? t.radius : O.max_r;
+                        t.lm_dec = 2.0; t.mu = 1.0 / t.radius;
                     } else {
-                        if (rec.relative_decrease < 0.25) s.radius *= 0.5;
-                        if (rec.relative_decrease > 0.75) s.radius = s.radius > 3.0 * s.dogleg_step_norm ? s.radius : 3.0 * s.dogleg_step_norm;
-                        double m2 = 2.0 * s.mu / O.mu_inc;
-                        s.mu = O.min_mu > m2 ? O.min_mu : m2;
+                        if (r_.relative_decrease < 0.25) t.radius *= 0.5;
+                        if (r_.relative_decrease > 0.75) t.radius = t.radius > 3.0 * t.dogleg_step_norm ? t.radius : 3.0 * t.dogleg_step_norm;
+                        double m2 = 2.0 * t.mu / O.mu_inc;
+                        t.mu = O.min_mu > m2 ? O.min_mu : m2;
                     }
-                    s.reuse = 0; s.need_lin = 1;
+                    t.reuse = 0; t.need_lin = 1;
                 } else {
-                    rec.step_is_successful = 0; rec.cost = s.x_cost; s.nunsucc++;
+                    r_.step_is_successful = 0; r_.cost = t.x_cost; t.nunsucc++;
                     if (O.strategy == SWF_LEVENBERG_MARQUARDT) {
                         // LevenbergMarquardtStrategy::StepRejected: the same Jacobian is damped harder — the window re-linearises at
                         // the unchanged point (bit-identical Jacobians) so that the assembly picks up the new mu
-                        s.radius /= s.lm_dec; s.lm_dec *= 2.0; s.mu = 1.0 / s.radius; s.reuse = 0; s.need_lin = 1;
-                    } else { s.radius *= 0.5; s.reuse = 1; }
+                        t.radius /= t.lm_dec; t.lm_dec *= 2.0; t.mu = 1.0 / t.radius; t.reuse = 0; t.need_lin = 1;
+                    } else { t.radius *= 0.5; t.reuse = 1; }
                 }
-                rec.trust_region_radius = s.radius;
+                r_.trust_region_radius = t.radius;
             }
         }
+        if (wr) {
+            // (the fields k_decide has always written, no others: the rest of the row belongs to k_dogleg)
+            rec.model_cost_change = model_cost_change;
+            rec.step_is_valid = r_.step_is_valid; rec.cost = r_.cost; rec.trust_region_radius = r_.trust_region_radius;
+            if (fld & 1) { rec.step_norm = r_.step_norm; rec.cost_change = r_.cost_change; }
+            if (fld & 2) { rec.relative_decrease = r_.relative_decrease; rec.step_is_successful = r_.step_is_successful; }
+        }
     }
-    __syncthreads();
-    if (accept) {
+    if (lead && accept) {
         // x <- candidate and || x || over the variable blocks in one pass (x_var: host-built flag per ambient coordinate)
         double a = 0;
+        if (st_) {
 #pragma unroll
-        for (int u = 0; u < XU; u++) { int i = W.x_base + tid + u * CTL_NT; if (i < W.x_base + W.x_n) { B.x[i] = xcv[u]; if (xfl[u]) a += xcv[u] * xcv[u]; } }
-        for (int i = W.x_base + tid + XU * CTL_NT; i < W.x_base + W.x_n; i += CTL_NT) { const double xv = B.xc[i]; B.x[i] = xv; if (B.x_var[i]) a += xv * xv; }
-        const double xn = sqrt(block_sum(a, red));
-        if (tid == 0) s.x_norm = xn;
+            for (int u = 0; u < XU; u++) { int i = W.x_base + tid + u * CTL_NT; if (i < W.x_base + W.x_n) { B.x[i] = xcv[u]; if (xfl[u]) a += xcv[u] * xcv[u]; } }
+            for (int i = W.x_base + tid + XU * CTL_NT; i < W.x_base + W.x_n; i += CTL_NT) { const double xv = B.xc[i]; B.x[i] = xv; if (B.x_var[i]) a += xv * xv; }
+        }
+        t.x_norm = sqrt(block_sum(a, red));
     }
+    if (wr) ws_store_nofail(sout, t);
+}
+__global__ void __launch_bounds__(CTL_NT) k_decide(DevBatch B, DevOpt O) {
+    __shared__ double red[16 * 2];
+    __shared__ double pst[2 * WP_LDS];
+    WinState* s = B.ws + blockIdx.x;
+    WinState t;
+    d_decide(B, O, (int)blockIdx.x, s, s, true, red, pst, t);
+}
+
+// Latency path of ONE window: k_decide at the head of the elimination grid (k_lm_clique).  Every workgroup takes the accept / reject
+// decision for itself (d_decide: same loads, sums, bits), keeps the window's state AFTER the decision in LDS and runs its share of
+// the landmark Schur product / its clique against that copy; workgroup (0, 0) alone commits — the trace, an accepted candidate into x,
+// the new state into ws_out (a THIRD buffer: the other workgroups are still reading B.ws, and k_step_eval's lead cleared ws_out's
+// failure flags two launches ago so that a workgroup of this grid may raise them without racing the lead's store, which leaves
+// those two fields alone).  A rejected step (or a finished window) makes every workgroup return right behind the decision.
+// What it replaces: a launch of one workgroup between two grids (5.9 us of a cfg3 window's iteration).
+template <int NCW, int TPW, int TW, int LDR>
+__global__ void __launch_bounds__(LS_NT(NCW, TW)) k_decide_lm_clique(DevBatch B, DevOpt O, int qpb, int lp, int kms, int s_direct, int n_parts, WinState* ws_out) {
+    __shared__ double red[16 * 2];
+    __shared__ double pst[2 * WP_LDS];
+    __shared__ WinState s_loc;
+    WinState t;
+    const bool lead = blockIdx.x == 0 && blockIdx.y == 0;
+    d_decide(B, O, 0, B.ws, ws_out, lead, red, pst, t);
+    if (threadIdx.x == 0) s_loc = t;
+    __syncthreads();
+    if (!t.need_lin || t.status != SWF_RUNNING) return;       // (uniform over the grid)
+    DevBatch E = B;
+    E.ws = &s_loc;                                             // window 0's state = the copy behind the decision (reads of need_lin / mu / iter, a raised lin_fail)
+    if ((int)blockIdx.y < n_parts) d_lm_schur<NCW, TPW, TW, LDR, true>(E, O, qpb, lp, kms, s_direct, (int)blockIdx.x, (int)blockIdx.y);
+    else {
+        constexpr int CLQ_NW = 4;                              // (as in k_lm_clique: waves 4 .. 15 end here, the four survivors synchronise among themselves)
+        if (threadIdx.x >= CLQ_NW * 64) return;
+        d_clique_elim<64, 64, 9, 2, 8, 4, CLQ_NW>(E, O, ((int)blockIdx.y - n_parts) * (int)gridDim.x + (int)blockIdx.x);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_loc.lin_fail) ws_out->lin_fail = 1;
 }
 
 // after the last slot: fold the final linearisation (cost, gradient norm) into the trace

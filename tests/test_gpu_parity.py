@@ -297,7 +297,8 @@ def test_speculative_dogleg_flow_equals_the_two_pass_flow_bitwise(monkeypatch):
     """The dogleg loop evaluates the candidate of a proposed step WITH its Jacobians (an accepted candidate is the next linearisation
     point: one pass instead of a cost pass at the candidate and a Jacobian pass at the same point behind k_decide); SWF_NO_SPEC_EVAL=1
     keeps the two passes, SWF_NO_LAT_FUSE=1 the batch launch shapes for a few windows; a single window's latency path runs k_dogleg inside
-    the candidate's evaluation grid (k_step_eval: every workgroup forms the step for itself; SWF_NO_STEP_FUSE=1: two launches).  Same device functions, same operands: iteration
+    the candidate's evaluation grid (k_step_eval: every workgroup forms the step for itself; SWF_NO_STEP_FUSE=1: two launches) and k_decide
+    at the head of the elimination grid (k_decide_lm_clique: every workgroup decides for itself; SWF_NO_DECIDE_FUSE=1: its own launch).  Same device functions, same operands: iteration
     rows and end states bit for bit — for windows that accept every step, windows that reject steps (a small initial radius), a window
     with a variable extrinsic and inverse-depth landmarks (generic two-row factors), a large prior (its own evaluation launch), and a
     batch that runs the clique branch on the auxiliary stream."""
@@ -324,8 +325,9 @@ def test_speculative_dogleg_flow_equals_the_two_pass_flow_bitwise(monkeypatch):
         opt.initial_trust_region_radius = r0 if r0 > 0 else 1e4
         ws = base if r0 > 0 else [shaken(w, 170 + i) for i, w in enumerate(base[:3])]
         got = {}
-        for mode, env in (("spec", {}), ("two-pass", {"SWF_NO_SPEC_EVAL": "1"}), ("spec, batch shapes", {"SWF_NO_LAT_FUSE": "1"}), ("spec, k_dogleg as its own launch", {"SWF_NO_STEP_FUSE": "1"})):
-            for k in ("SWF_NO_SPEC_EVAL", "SWF_NO_LAT_FUSE", "SWF_NO_STEP_FUSE"):
+        for mode, env in (("spec", {}), ("two-pass", {"SWF_NO_SPEC_EVAL": "1"}), ("spec, batch shapes", {"SWF_NO_LAT_FUSE": "1"}), ("spec, k_dogleg as its own launch", {"SWF_NO_STEP_FUSE": "1"}),
+                          ("spec, k_decide as its own launch", {"SWF_NO_DECIDE_FUSE": "1"})):
+            for k in ("SWF_NO_SPEC_EVAL", "SWF_NO_LAT_FUSE", "SWF_NO_STEP_FUSE", "SWF_NO_DECIDE_FUSE"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -336,10 +338,10 @@ def test_speculative_dogleg_flow_equals_the_two_pass_flow_bitwise(monkeypatch):
                 res.append(([(r["cost"], r["step_norm"], r["trust_region_radius"], r["step_is_successful"], r["gradient_max_norm"]) for r in sm.rows()], sm.termination,
                             np.concatenate([c.a[k].ravel() for k in keys])))
             got[mode] = res
-        for k in ("SWF_NO_SPEC_EVAL", "SWF_NO_LAT_FUSE", "SWF_NO_STEP_FUSE"):
+        for k in ("SWF_NO_SPEC_EVAL", "SWF_NO_LAT_FUSE", "SWF_NO_STEP_FUSE", "SWF_NO_DECIDE_FUSE"):
             monkeypatch.delenv(k, raising=False)
         if r0 < 0: assert any(not r[3] for res in got["spec"] for r in res[0][1:]), "the shaken windows were meant to produce rejected steps"
-        for mode in ("two-pass", "spec, batch shapes", "spec, k_dogleg as its own launch"):
+        for mode in ("two-pass", "spec, batch shapes", "spec, k_dogleg as its own launch", "spec, k_decide as its own launch"):
             for i, (a, b_) in enumerate(zip(got["spec"], got[mode])):
                 assert a[0] == b_[0] and a[1] == b_[1], (r0, mode, i)
                 assert np.array_equal(a[2], b_[2]), (r0, mode, i)
