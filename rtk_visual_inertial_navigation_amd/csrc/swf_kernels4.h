@@ -508,27 +508,36 @@ __global__ void __launch_bounds__(NT, (NT == 256 && NMAX <= CO_SMALLN) ? 4 : 1) 
 // Optional phase 4: the reference's square root itself (UpdateSchurComponent, R/factor/gnss_imu_factor.cpp:454-488):
 //   H = V diag(lam) V^T,  J = sqrt(lam+) V^T,  r = lam+^-1/2 V^T rhs,  eigenvalues <= 1e-8 dropped, rows in ascending eigenvalue order
 // — for callers that want the residual VECTOR of the reference (up to the sign of each eigenvector), not only J^T J, J^T r and |r|^2.
-// The pivoted factor of phase 3 is a square root R (rows v_r, R^T R = H on the retained range), so the eigenvectors of H are the right
-// singular vectors of R: a one-sided (Hestenes) Jacobi on the columns of R — G columns of length rank, 8 lanes per column pair,
-// round-robin pairing, V accumulated — never forms H again and keeps small eigenvalues to high relative accuracy.  One 256-thread
-// workgroup per factor; off by default (swf_composite_set_root / SWF_COMP_EIGEN_ROOT): it costs a few sweeps of G - 1 barrier steps.
+// The pivoted factor of phase 3 is a square root (rows v_r, sum_r v_r v_r^T = H on the retained range): a one-sided (Hestenes) Jacobi
+// orthogonalises the v_r — 8 lanes per pair, round-robin pairing — never forms H again and keeps small eigenvalues to high relative
+// accuracy (see the kernel for what is rotated, and why).  One 256-thread workgroup per factor; off by default (swf_composite_set_root,
+// swf_options::composite_root): it costs some ten sweeps of G - 1 barrier steps.
 template <int NMAX>
 __global__ void __launch_bounds__(NMAX <= CO_SMALLN ? 256 : 512) k_comp_eigroot(CompArgs A) {
-    constexpr int NT = NMAX <= CO_SMALLN ? 256 : 512;          // 8 lanes per column pair: 32 / 64 pairs per step (G <= 54 / 94 columns)
+    constexpr int NT = NMAX <= CO_SMALLN ? 256 : 512;          // 8 lanes per pair: 32 / 64 pairs per step (G <= 54 / 94 vectors)
     const int f = blockIdx.x, t = threadIdx.x;
     if (f >= A.n || !A.todo[f]) return;
     const int N = A.N[f], G = 30 + N;
     const long long g0 = A.g_off[f], g20 = A.g2_off[f];
     constexpr int GM_ = 30 + NMAX;
-    __shared__ double Rm[GM_ * GM_], Vm[GM_ * GM_];      // column-major: column c at [c * G, c * G + G)
+    // Round 6: the Jacobi rotates the ROWS v_r of the pivoted factor (H = sum_r v_r v_r^T = L L^T, L = [v_0 v_1 ...]) from the right,
+    // L W = U Sigma, instead of its columns with an accumulated V: the implicit Gram matrix L^T L of a diagonally pivoted factor is
+    // close to diagonal (Veselic / Hari, the preconditioning of the marginalisation consumer's k_marg_bj), where the columns' Gram
+    // matrix was H itself — 40 sweeps did not always converge on remainders with eigenvalues from 1e-4 to 3e11, ~10 do now —, one
+    // matrix is rotated instead of two, and nothing is divided by a small singular value: the final vectors ARE the rows sqrt(lam_k) u_k^T
+    // of the square root, lam_k their squared norms, r_k = (vector_k . rhs) / lam_k.
+    __shared__ double Lm[GM_ * GM_];                      // vector r at [r * G, r * G + G)
     __shared__ double lam[GM_], rho[GM_], srd[GM_];
     __shared__ int srank[GM_];
-    for (int e = t; e < G * G; e += NT) { Rm[e] = A.Ld[g20 + e]; int c = e / G, r = e - c * G; Vm[e] = c == r ? 1.0 : 0.0; }   // Ld[a * G + r] = component a of row r
+    for (int e = t; e < G * G; e += NT) { const int r = e / G, a = e - r * G; Lm[e] = A.Ld[g20 + (size_t)a * G + r]; }      // Ld[a * G + r] = component a of row r
     if (t < G) srd[t] = A.rd[g0 + t];
     __syncthreads();
     const int Ge = (G + 1) & ~1, np = Ge / 2;            // round-robin over an even number of players (a bye when G is odd)
     const int pi = t >> 3, ln = t & 7;
-    for (int sweep = 0; sweep < 40; sweep++) {
+#ifndef SWF_EIG_MAXSWEEP
+#define SWF_EIG_MAXSWEEP 40
+#endif
+    for (int sweep = 0; sweep < SWF_EIG_MAXSWEEP; sweep++) {
         int rotated = 0;
         for (int step = 0; step < Ge - 1; step++) {
             // circle method: player Ge-1 stays, the others rotate; pair pi plays (a, b)
@@ -539,26 +548,24 @@ __global__ void __launch_bounds__(NMAX <= CO_SMALLN ? 256 : 512) k_comp_eigroot(
                 if (q >= G) p = -1;                      // the bye
             }
             double al = 0, be = 0, ga = 0;
-            if (p >= 0) for (int r = ln; r < G; r += 8) { double x = Rm[p * G + r], y = Rm[q * G + r]; al += x * x; be += y * y; ga += x * y; }
+            if (p >= 0) for (int r = ln; r < G; r += 8) { double x = Lm[p * G + r], y = Lm[q * G + r]; al += x * x; be += y * y; ga += x * y; }
             for (int o = 4; o > 0; o >>= 1) { al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64); }
-            if (p >= 0 && fabs(ga) > 1e-15 * sqrt(al * be) && fabs(ga) > 1e-300) {
+            // (rotation threshold G eps: below it the cosine of a pair is rounding noise of the G-term inner products)
+            if (p >= 0 && fabs(ga) > (double)G * 1.2e-16 * sqrt(al * be) && fabs(ga) > 1e-300) {
                 double zeta = (be - al) / (2.0 * ga);
                 double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
-                for (int r = ln; r < G; r += 8) {
-                    double x = Rm[p * G + r], y = Rm[q * G + r]; Rm[p * G + r] = c * x - sn * y; Rm[q * G + r] = sn * x + c * y;
-                    double u = Vm[p * G + r], v = Vm[q * G + r]; Vm[p * G + r] = c * u - sn * v; Vm[q * G + r] = sn * u + c * v;
-                }
+                for (int r = ln; r < G; r += 8) { double x = Lm[p * G + r], y = Lm[q * G + r]; Lm[p * G + r] = c * x - sn * y; Lm[q * G + r] = sn * x + c * y; }
                 rotated = 1;
             }
             __syncthreads();
         }
         if (!__syncthreads_or(rotated)) break;
     }
-    // eigenvalues = squared column norms; rows of the output in ascending eigenvalue order (Eigen's SelfAdjointEigenSolver order)
+    // eigenvalues = squared norms of the final vectors; rows of the output in ascending eigenvalue order (Eigen's SelfAdjointEigenSolver order)
     if (t < G) {
         double s2 = 0, d = 0;
-        for (int r = 0; r < G; r++) { double x = Rm[t * G + r]; s2 += x * x; d += Vm[t * G + r] * srd[r]; }
+        for (int r = 0; r < G; r++) { double x = Lm[t * G + r]; s2 += x * x; d += x * srd[r]; }
         lam[t] = s2; rho[t] = d;
     }
     __syncthreads();
@@ -566,11 +573,11 @@ __global__ void __launch_bounds__(NMAX <= CO_SMALLN ? 256 : 512) k_comp_eigroot(
     __syncthreads();
     for (int e = t; e < G * G; e += NT) {
         int k = e / G, a = e - k * G, row = srank[k];
-        double v = lam[k] > 1e-8 ? sqrt(lam[k]) * Vm[k * G + a] : 0.0;
+        double v = lam[k] > 1e-8 ? Lm[k * G + a] : 0.0;
         A.Ld[g20 + (size_t)a * G + row] = v;
         if (A.jac_out) A.jac_out[g20 + (size_t)row * G + a] = v;
     }
-    if (t < G) { double v = lam[t] > 1e-8 ? rho[t] / sqrt(lam[t]) : 0.0; A.r0[g0 + srank[t]] = v; A.res_out[g0 + srank[t]] = v; }
+    if (t < G) { double v = lam[t] > 1e-8 ? rho[t] / lam[t] : 0.0; A.r0[g0 + srank[t]] = v; A.res_out[g0 + srank[t]] = v; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
