@@ -1544,12 +1544,16 @@ struct Launcher {
             hipLaunchKernelGGL(k_comp_imu, dim3((b->CA.n_iq + 7) / 8), dim3(256), 0, st, b->CA);
             // (an instantiation per class of factor, each passing over the other's: a factor's arithmetic does not depend on its batch)
             if (b->comp_nmin <= CO_SMALLN) {
-                if (wide) hipLaunchKernelGGL((k_comp_elim<CO_SMALLN, 1024>), dim3(b->n_comp), dim3(1024), 0, st, b->CA);
-                else hipLaunchKernelGGL((k_comp_elim<CO_SMALLN, 256>), dim3(b->n_comp), dim3(256), 0, st, b->CA);
+                if (wide) hipLaunchKernelGGL((k_comp_elim<CO_SMALLN, 1024>), dim3(b->n_comp), dim3(1024), 0, st, b->CA, 0);
+                else {
+                    // batches: factors of up to 12 ambiguities in the instantiation that fits six workgroups to a CU
+                    if (b->comp_nmin <= CO_TINYN) hipLaunchKernelGGL((k_comp_elim<CO_TINYN, 256>), dim3(b->n_comp), dim3(256), 0, st, b->CA, 0);
+                    if (b->comp_nmax > CO_TINYN) hipLaunchKernelGGL((k_comp_elim<CO_SMALLN, 256>), dim3(b->n_comp), dim3(256), 0, st, b->CA, CO_TINYN + 1);
+                }
             }
             if (b->comp_nmax > CO_SMALLN) {
-                if (wide) hipLaunchKernelGGL((k_comp_elim<CO_MAXN, 1024>), dim3(b->n_comp), dim3(1024), 0, st, b->CA);
-                else hipLaunchKernelGGL((k_comp_elim<CO_MAXN, 256>), dim3(b->n_comp), dim3(256), 0, st, b->CA);
+                if (wide) hipLaunchKernelGGL((k_comp_elim<CO_MAXN, 1024>), dim3(b->n_comp), dim3(1024), 0, st, b->CA, CO_SMALLN + 1);
+                else hipLaunchKernelGGL((k_comp_elim<CO_MAXN, 256>), dim3(b->n_comp), dim3(256), 0, st, b->CA, CO_SMALLN + 1);
             }
             if (b->comp_eigen_root) {
                 if (b->comp_nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_eigroot<CO_SMALLN>, dim3(b->n_comp), dim3(256), 0, st, b->CA);
@@ -2367,8 +2371,8 @@ extern "C" int swf_composite_evaluate(swf_composite* c, const double* outer, con
     A.want_jac = want_jac ? 1 : 0;
     hipLaunchKernelGGL(k_comp_prep, dim3(c->n), dim3(256), 0, st, A);
     hipLaunchKernelGGL(k_comp_imu, dim3((A.n_iq + 7) / 8), dim3(256), 0, st, A);
-    if (c->nmin <= CO_SMALLN) hipLaunchKernelGGL((k_comp_elim<CO_SMALLN, 256>), dim3(c->n), dim3(256), 0, st, A);
-    if (c->nmax > CO_SMALLN) hipLaunchKernelGGL((k_comp_elim<CO_MAXN, 256>), dim3(c->n), dim3(256), 0, st, A);
+    if (c->nmin <= CO_SMALLN) hipLaunchKernelGGL((k_comp_elim<CO_SMALLN, 256>), dim3(c->n), dim3(256), 0, st, A, 0);
+    if (c->nmax > CO_SMALLN) hipLaunchKernelGGL((k_comp_elim<CO_MAXN, 256>), dim3(c->n), dim3(256), 0, st, A, CO_SMALLN + 1);
     if (c->eigen_root) {
         if (c->nmax <= CO_SMALLN) hipLaunchKernelGGL(k_comp_eigroot<CO_SMALLN>, dim3(c->n), dim3(256), 0, st, A);
         else hipLaunchKernelGGL(k_comp_eigroot<CO_MAXN>, dim3(c->n), dim3(512), 0, st, A);

@@ -17,6 +17,7 @@
 
 #define CO_MAXN 64                         // ambiguities per composite factor (the reference's data model: 3 constellations x NFREQ 2 on up to MAXOBS 64
                                            // satellites, R/gnss/include/common_function.h:24-37; 30..48 per gap is a normal open-sky epoch)
+#define CO_TINYN 12                        // batches: a third instantiation for <= 12 ambiguities (25 KB of LDS and 84 registers: six workgroups per CU; the chain of a factor is latency-bound, so what a batch gains is factors in flight)
 #define CO_SMALLN 24                       // k_comp_elim / k_comp_eigroot are instantiated for <= 24 (36 KB of LDS, four workgroups per CU) and <= 64 ambiguities
 #define CO_MAXG (30 + CO_MAXN)
 
@@ -210,12 +211,14 @@ __global__ void __launch_bounds__(256) k_comp_imu(CompArgs A) { d_comp_imu(A, (i
 // T products and Schur update at 256 threads).  Every output element is one thread's, from the same operands in the same order:
 // the thread count does not change a bit.
 template <int NMAX, int NT>
-__device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f) {
+__device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f, const int n_lo = 0) {
     const int t = threadIdx.x;
     if (f >= A.n || !A.todo[f]) return;
-    // the instantiation is the FACTOR's (a launch of each covers a batch with factors of both classes): a factor's arithmetic does not
-    // depend on what else is in its batch (the two instantiations take different square roots since round 5)
-    if ((A.N[f] <= CO_SMALLN) != (NMAX <= CO_SMALLN)) return;
+    // the instantiation is the FACTOR's (a launch of each covers a batch with factors of several classes: this one takes n_lo <= N <= NMAX):
+    // a factor's arithmetic does not depend on what else is in its batch.  Up to CO_SMALLN ambiguities the instantiations differ in array
+    // strides only (same sums, same bits: the latency path runs <CO_SMALLN, 1024> on what a batch gives to <CO_TINYN, 256>); beyond, the
+    // square root is another algorithm (round 5), and the class boundary CO_SMALLN is the same everywhere.
+    if (A.N[f] < n_lo || A.N[f] > NMAX) return;
     const int M = A.M[f], N = A.N[f], G = 30 + N, e0 = A.e_off[f], n0 = A.n_off[f];
     const long long pn0 = A.pn_off[f], nn0 = A.nn_off[f], g0 = A.g_off[f], g20 = A.g2_off[f];
     CHSTAMP(32);
@@ -503,7 +506,7 @@ __device__ __forceinline__ void d_comp_elim(const CompArgs& A, const int f) {
     CHSTAMP(47);
 }
 template <int NMAX, int NT>
-__global__ void __launch_bounds__(NT, (NT == 256 && NMAX <= CO_SMALLN) ? 4 : 1) k_comp_elim(CompArgs A) { d_comp_elim<NMAX, NT>(A, (int)blockIdx.x); }
+__global__ void __launch_bounds__(NT, (NT == 256 && NMAX <= CO_TINYN) ? 6 : (NT == 256 && NMAX <= CO_SMALLN) ? 4 : 1) k_comp_elim(CompArgs A, int n_lo) { d_comp_elim<NMAX, NT>(A, (int)blockIdx.x, n_lo); }
 
 // Optional phase 4: the reference's square root itself (UpdateSchurComponent, R/factor/gnss_imu_factor.cpp:454-488):
 //   H = V diag(lam) V^T,  J = sqrt(lam+) V^T,  r = lam+^-1/2 V^T rhs,  eigenvalues <= 1e-8 dropped, rows in ascending eigenvalue order
