@@ -770,6 +770,7 @@ def test_cfg5_prior_obtained_by_marginalising_a_41st_frame():
     c = w5.counts()
     assert c["n_pose"] == 41 and c["n_lm"] > 900 and c["n_cp"] == 800
     w5o = w5.copy()
+    w5_in = w5.copy()
     bs, s5 = gpu_solve(w5, default_options())
     bs.close()
     assert s5.termination in (1, 2, 3, 4) and s5.final_cost < 1e-3 * s5.initial_cost
@@ -782,6 +783,21 @@ def test_cfg5_prior_obtained_by_marginalising_a_41st_frame():
     for a, b in zip(s5.rows(), s5o.rows()):
         assert abs(a["cost"] - b["cost"]) <= 2e-6 * abs(b["cost"]) + 5e-5
     assert np.abs(w5.a["pose"] - w5o.a["pose"]).max() < 1e-6 and np.abs(w5.a["sb"] - w5o.a["sb"]).max() < 1e-5
+    # round 6: the 263-dimension prior is evaluated in row chunks over several workgroups (PRIOR_SPLIT_DIM).  The window inside a batch of
+    # two (the batch launch shapes: k_dogleg / k_decide as launches of their own, no fused step kernel) == alone, bit for bit; and the
+    # Levenberg-Marquardt strategy — the cost-only pass over the chunks (k_post_dogleg) and its J v products — against the oracle's
+    pair = [w5_in.copy(), w5_in.copy()]
+    bs = solver.BatchSolver(pair); sms = bs.solve(default_options()); bs.close()
+    for c, sm in zip(pair, sms):
+        assert [r["cost"] for r in sm.rows()] == [r["cost"] for r in s5.rows()]
+        assert all(np.array_equal(c.a[k], w5.a[k]) for k in ("pose", "sb", "lm", "sc"))
+    wl, wlo = w5_in.copy(), w5_in.copy()
+    bs, sl = gpu_solve(wl, default_options(strategy=1)); bs.close()
+    slo, _ = ob.solve(wlo, default_options(strategy=1), export=False)
+    assert [r["step_is_successful"] for r in sl.rows()] == [r["step_is_successful"] for r in slo.rows()]
+    for a, b in zip(sl.rows(), slo.rows()):
+        assert abs(a["cost"] - b["cost"]) <= 2e-6 * abs(b["cost"]) + 5e-5
+    assert np.abs(wl.a["pose"] - wlo.a["pose"]).max() < 1e-6
 
 
 def test_full_size_properties_cfg5_and_batch():
