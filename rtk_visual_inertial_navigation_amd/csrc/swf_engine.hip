@@ -1698,21 +1698,25 @@ struct Launcher {
     // k_decide at the head of the elimination grid: one window, the fused step kernel in front (three state buffers in rotation), the
     // cliques in the landmark product's grid, the two smaller size classes of that grid (the third has no LDS to spare)
     bool decide_fuse_ok() const { return step_fused && !b->no_decide_fuse && clq_fuse_ok() && b->ls_var <= 1 && b->max_tiles <= ls_tiles_per_launch(); }
+    // (spec = false: the two-pass flows — Levenberg-Marquardt, windows with composite factors — whose cost-only candidate evaluation takes the step the same way)
     bool step_fuse_ok() const {
         const DevBatch& D = b->D;
-        return b->lat_fuse && !b->no_step_fuse && !b->aux && D.n_win == 1 && b->win[0].x_n <= XCL_MAX && b->max_prior_dim <= PRIOR_LDS_DIM && !D.n_idp && !b->n_comp
+        return b->lat_fuse && !b->no_step_fuse && !b->aux && D.n_win == 1 && b->win[0].x_n <= XCL_MAX && b->max_prior_dim <= PRIOR_LDS_DIM && !D.n_idp
                && D.n_fsb + nb(D.n_sc, 256) + D.n_pch + nb(D.n_imu, IMU_FPB) > 0;
     }
     // k_dogleg + the Jacobian evaluation at its candidate in one grid (k_step_eval); the window's state moves to the other buffer
-    void step_eval() {
+    void step_eval(bool jac = true) {
         DevBatch& D = b->D;
-        Bracket t(*this, SWF_K_EVAL_PS);
+        Bracket t(*this, jac ? SWF_K_EVAL_PS : SWF_K_POST_DOGLEG);
         Segs S{}; S.e[0] = D.n_fsb; S.e[1] = S.e[0] + nb(D.n_sc, 256); S.e[2] = S.e[1] + D.n_pch;
         const bool imu = D.n_imu > 0;
         S.e[3] = S.e[2] + (imu ? nb(D.n_imu, IMU_FPB) : 0);
         WinState* out = ws_next(D.ws);
         WinState* clr = decide_fused ? ws_next(out) : nullptr;      // the buffer k_decide_lm_clique will write: its failure flags go down here
-        if (imu) hipLaunchKernelGGL((k_step_eval<true>), dim3(S.e[3]), dim3(256), 0, st, D, O, S, out, b->win[0], clr);
+        if (!jac) {
+            if (imu) hipLaunchKernelGGL((k_step_eval<true, false>), dim3(S.e[3]), dim3(256), 0, st, D, O, S, out, b->win[0], clr);
+            else hipLaunchKernelGGL((k_step_eval<false, false>), dim3(S.e[2]), dim3(256), 0, st, D, O, S, out, b->win[0], clr);
+        } else if (imu) hipLaunchKernelGGL((k_step_eval<true>), dim3(S.e[3]), dim3(256), 0, st, D, O, S, out, b->win[0], clr);
         else hipLaunchKernelGGL((k_step_eval<false>), dim3(S.e[2]), dim3(256), 0, st, D, O, S, out, b->win[0], clr);
         D.ws = out;
     }
@@ -1778,7 +1782,7 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
             // are one pass, and the elimination kernels behind k_decide find the new point's Jacobians in place.  Levenberg-Marquardt
             // re-linearises at the UNCHANGED point after a rejected step (new damping) and keeps the two passes.
             const bool spec = opt->trust_region_strategy == SWF_DOGLEG && !b->n_comp && !b->no_spec;
-            L.step_fused = spec && L.step_fuse_ok();
+            L.step_fused = L.step_fuse_ok();
             for (int it = 1; it <= opt->max_num_iterations; it++) {
                 L.reduced();
                 L.step_rest();
@@ -1789,7 +1793,10 @@ extern "C" int swf_batch_solve(swf_batch* b, const swf_options* opt) {
                     if (b->aux) (void)hipEventRecord(b->ev_fork[1], st);          // the auxiliary stream's clique branch starts behind k_decide
                     L.lin_elim(it < opt->max_num_iterations ? 1 : 0); nlin++;
                 }
-                else { L.cand_eval(); LIN(it < opt->max_num_iterations ? 1 : 0); }
+                else {
+                    if (L.step_fused) { L.decide_fused = false; L.step_eval(false); L.decide(); } else L.cand_eval();
+                    LIN(it < opt->max_num_iterations ? 1 : 0);
+                }
             }
         }
         hipLaunchKernelGGL(k_finalize, dim3(D.n_win), dim3(256), 0, st, D, L.O, b->ws_primary);

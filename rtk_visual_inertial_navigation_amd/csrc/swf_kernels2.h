@@ -1351,9 +1351,11 @@ __global__ void __launch_bounds__(CTL_NT) k_dogleg(DevBatch B, DevOpt O) {
 // factors there.  What it replaces: a launch of one workgroup (12.8 us for a cfg3 window: dispatch, two dependent round trips, a
 // reduction, the candidate written to HBM) in front of a launch that began by reading that candidate back.
 #define XCL_MAX 4096            // ambient coordinates of a window the fused form takes (32 KB of LDS)
-template <bool IMU>
+// JAC = false: the two-pass flows (Levenberg-Marquardt; windows with composite factors, whose re-linearisation a rejected candidate would
+// have to undo): the same grid with the COST-ONLY evaluation of the candidate behind the step (k_dogleg + k_post_dogleg in one launch).
+template <bool IMU, bool JAC = true>
 __global__ void __launch_bounds__(256) k_step_eval(DevBatch B, DevOpt O, Segs S, WinState* ws_out, WinRec W, WinState* ws_clr) {
-    constexpr int SM_PRIOR = 2 * PRIOR_LDS_DIM + 16, SM_FS = FS_BLK * FS_HALF + 168 / 2 + 1;
+    constexpr int SM_PRIOR = 2 * PRIOR_LDS_DIM + 16, SM_FS = JAC ? FS_BLK * FS_HALF + 168 / 2 + 1 : 1;
     __shared__ double sm[SM_PRIOR > SM_FS ? SM_PRIOR : SM_FS];
     __shared__ double red[16 * 6];
     __shared__ double pst[4 * WP_LDS];
@@ -1368,10 +1370,10 @@ __global__ void __launch_bounds__(256) k_step_eval(DevBatch B, DevOpt O, Segs S,
     if (!go) return;
     DevBatch E = B;
     E.xc = xcl - W.x_base; E.spec = 2;                  // evaluate at the LDS candidate, ungated (the state this grid reads still says "no candidate")
-    if (bid < S.e[0]) d_eval_proj_fs(E, bid, (double (*)[FS_HALF])sm, (int*)(sm + FS_BLK * FS_HALF));
-    else if (bid < S.e[1]) d_eval_scalar<true>(E, bid - S.e[0]);
-    else if (!IMU || bid < S.e[2]) d_eval_prior<true>(E, bid - S.e[1], sm);
-    else d_eval_imu<true>(E, bid - S.e[2]);
+    if (bid < S.e[0]) { if (JAC) d_eval_proj_fs(E, bid, (double (*)[FS_HALF])sm, (int*)(sm + FS_BLK * FS_HALF)); else d_eval_proj_cost(E, bid); }
+    else if (bid < S.e[1]) d_eval_scalar<JAC>(E, bid - S.e[0]);
+    else if (!IMU || bid < S.e[2]) d_eval_prior<JAC>(E, bid - S.e[1], sm);
+    else d_eval_imu<JAC>(E, bid - S.e[2]);
 }
 
 // acceptance test + trust-region update (TrustRegionMinimizer::Minimize loop body,

@@ -346,6 +346,20 @@ def test_speculative_dogleg_flow_equals_the_two_pass_flow_bitwise(monkeypatch):
                 assert a[0] == b_[0] and a[1] == b_[1], (r0, mode, i)
                 assert np.array_equal(a[2], b_[2]), (r0, mode, i)
     ws = base
+    # Levenberg-Marquardt keeps the two passes (a rejected step re-linearises at the unchanged point); one window still takes its step at
+    # the head of the cost-only candidate evaluation (k_step_eval<., false>): against the two launches, and against the batch shapes
+    opt = default_options(max_num_iterations=10, strategy=1)
+    for w in base[:3] + [shaken(base[0], 180)]:
+        got_lm = []
+        for env in ({}, {"SWF_NO_STEP_FUSE": "1"}, {"SWF_NO_LAT_FUSE": "1"}):
+            for k in ("SWF_NO_STEP_FUSE", "SWF_NO_LAT_FUSE"): monkeypatch.delenv(k, raising=False)
+            for k, v in env.items(): monkeypatch.setenv(k, v)
+            c = w.copy()
+            bs = solver.BatchSolver([c]); sm = bs.solve(opt)[0]; bs.close()
+            got_lm.append(([(r["cost"], r["step_norm"], r["trust_region_radius"], r["step_is_successful"]) for r in sm.rows()], np.concatenate([c.a[k].ravel() for k in keys])))
+        for k in ("SWF_NO_STEP_FUSE", "SWF_NO_LAT_FUSE"): monkeypatch.delenv(k, raising=False)
+        for g_ in got_lm[1:]:
+            assert g_[0] == got_lm[0][0] and np.array_equal(g_[1], got_lm[0][1])
     # 160 windows: between half a chip and a chip of windows the IMU / clique branch rides the auxiliary stream behind k_decide
     many = [ws[i % 2].copy() for i in range(160)]
     bs = solver.BatchSolver(many); sms = bs.solve(default_options(max_num_iterations=10)); bs.close()

@@ -295,3 +295,13 @@ def test_composite_latency_path_shared_grids_equal_separate_launches_bitwise(S, 
     for a, b_ in zip(res["fused"][0], res["separate"][0]):
         for k in ("pose", "sb", "lm", "sc", "comp_pose", "comp_sb"):
             assert np.array_equal(a.a[k], b_.a[k]), k
+    # round 6: ONE such window runs k_dogleg at the head of its cost-only candidate evaluation (k_step_eval<., false>: the two-pass flow of
+    # windows with composite factors); SWF_NO_STEP_FUSE=1 keeps the two launches; the window inside the batch above took them anyway
+    for env in ({}, {"SWF_NO_STEP_FUSE": "1"}):
+        for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+        one = wins[0].copy()
+        bs = solver.BatchSolver([one]); sm = bs.solve(default_options(max_num_iterations=8))[0]; bs.close()
+        monkeypatch.delenv("SWF_NO_STEP_FUSE", raising=False)
+        assert [(r["cost"], r["step_norm"], r["trust_region_radius"]) for r in sm.rows()] == res["fused"][1][0], env
+        for k in ("pose", "sb", "lm", "sc", "comp_pose", "comp_sb"):
+            assert np.array_equal(one.a[k], res["fused"][0][0].a[k]), (env, k)
