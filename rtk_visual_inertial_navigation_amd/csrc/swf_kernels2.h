@@ -953,9 +953,6 @@ __global__ void __launch_bounds__(256) k_post_chol(DevBatch B, DevOpt O, Segs S)
     __shared__ double sm_pv[PART == 1 ? 1 : PRB_MAX]; __shared__ int sm_pl[PART == 1 ? 1 : PRB_MAX]; __shared__ double sm_pw[4];
     if (PART != 2 && bid < S.e[0]) { d_backsub_lm(B, O, bid, sm_bs); return; }   // also the projection part of |J D^-2 g|^2
     if (PART == 1) return;
-#ifdef SWF_DEBUG_POST_SKIP        // timing experiments only (tools/prof/post_segments.sh): leave segments out to see which one a launch waits for
-    { const int sg = bid < S.e[1] ? 1 : bid < S.e[3] ? 2 : bid < S.e[4] ? 4 : 8; if (SWF_DEBUG_POST_SKIP & sg) return; }
-#endif
     if (bid < S.e[1]) d_backsub_clique(B, bid - S.e[0]);
     else if (bid < S.e[3]) d_jtimes_scalar<0>(B, O, bid - S.e[2]);
     else if (bid < S.e[4]) d_jtimes_imu<0>(B, O, bid - S.e[3]);

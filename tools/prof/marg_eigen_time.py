@@ -1,5 +1,5 @@
 # eigen square root of the cfg5 marginalisation prior (263 dimensions) on the device: wall time and residuals,
-# block Jacobi over many workgroups (k_marg_bj) vs the single-workgroup sweeps (SWF_MARG_ONE_WG=1)
+# block Jacobi over many workgroups (k_marg_bj)
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

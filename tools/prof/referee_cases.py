@@ -1,5 +1,5 @@
 """First-step error against the extended-precision referee (tests/referee.py) for the degenerate windows of the parity test and cfg2/cfg3:
-device, oracle, eps * cond(S).  SWF_CHOL_RR3=1 for round 3's kernel."""
+device, oracle, eps * cond(S)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
