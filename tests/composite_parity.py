@@ -51,8 +51,18 @@ def check(sd, wd, orc, decisions_vs_literal=True, report=None, tol_first=TOL_FIR
     rd, rn, rl = sd.rows(), sn.rows(), sl.rows()
     bad = []
     acc = lambda rows: [r["step_is_successful"] for r in rows][:n_dec]
+
+    def same_decisions(ra, sa, rb, sb):
+        # the same accept / reject decisions over the common iterations; one solver may stop an iteration before the other ONLY when both
+        # stop on a convergence test (the function-tolerance test |cost change| <= 1e-6 cost is a threshold: a tie breaks on rounding)
+        # (the row of the iteration a solver converges in is not a successful step: where one stops an iteration early, that row is left out)
+        a, b_ = acc(ra), acc(rb)
+        if len(a) == len(b_): return a == b_
+        n = min(len(a), len(b_))
+        short = sa if len(a) < len(b_) else sb
+        return abs(len(a) - len(b_)) == 1 and a[:n - 1] == b_[:n - 1] and short.termination in (1, 2, 3)
     # (A) against the noise-free restatement
-    if acc(rd) != acc(rn): bad.append("A: accept / reject sequence differs from the noise-free oracle's")
+    if not same_decisions(rd, sd, rn, sn): bad.append("A: accept / reject sequence differs from the noise-free oracle's")
     c0 = rn[0]["cost"]
     e0 = abs(rd[0]["cost"] - c0) / c0
     if e0 > tol_first: bad.append("A: first cost %.3e off" % e0)
@@ -65,7 +75,7 @@ def check(sd, wd, orc, decisions_vs_literal=True, report=None, tol_first=TOL_FIR
     est2 = max(np.abs(wd.a[k] - wn.a[k]).max() if wd.a[k].size else 0.0 for k in ("sb", "sc", "comp_sb"))
     if len(rd) == len(rn) and (est > tol_state or est2 > 10 * tol_state): bad.append("A: end states %.3e / %.3e apart" % (est, est2))
     # (B) against the literal reference
-    if decisions_vs_literal and acc(rd) != acc(rl): bad.append("B: accept / reject sequence differs from the literal oracle's")
+    if decisions_vs_literal and not same_decisions(rd, sd, rl, sl): bad.append("B: accept / reject sequence differs from the literal oracle's")
     l0 = rl[0]["cost"]
     if abs(rd[0]["cost"] - l0) / l0 > tol_first + NOISE_FACTOR * noise / l0: bad.append("B: first cost %.3e off" % (abs(rd[0]["cost"] - l0) / l0))
     lo = hi = 0.0
