@@ -186,12 +186,14 @@ int swf_batch_get_tail_covariance(swf_batch* b, int32_t w, double* A, double* Qy
  * ms[k] = summed duration, calls[k] = number of launches bracketed.
  * One id per distinct kernel.  Mutually independent small kernels run as segments of one fused grid:
  *   LM_SCHUR    = k_lm_schur        landmark elimination + reduced-camera product (cells stay in LDS)
- *   EVAL_PS     = k_eval_ps<true>   projection + scalar-factor residuals and Jacobians
+ *   EVAL_PS     = k_eval_ps<true>   projection + scalar-factor residuals and Jacobians (round 6, dogleg: at the candidate; one window: k_step_eval,
+ *                                   which carries k_dogleg at its head — no DOGLEG bracket then; SWF_K_FRAME_SUMS is never recorded any more)
  *   POST_CHOL   = k_post_chol       back-substitution + |J D^-2 g|^2 of the Cauchy point
- *   POST_DOGLEG = k_post_dogleg     J*step + candidate residuals of projection/scalar factors
+ *   POST_DOGLEG = k_post_dogleg     cost-only candidate residuals (Levenberg-Marquardt, windows with composite factors; one window: k_step_eval<., false>)
+ *   DECIDE      = k_decide          (one window, dogleg: inside k_decide_lm_clique, recorded under LM_SCHUR)
  *   CAND_EVAL   = k_eval_imu<false> + k_eval_prior<false> (candidate residuals)
  *   CLIQUE_ELIM = the (up to three) size classes of k_clique_elim
- *   ASSEMBLE    = k_assemble_all    diagonal + off-diagonal blocks of the reduced system */
+ *   ASSEMBLE    = k_assemble_flat   the reduced system and its vectors from the static assembly program */
 enum { SWF_K_TOTAL = 0, SWF_K_EVAL_PS = 1, SWF_K_EVAL_IMU = 2, SWF_K_FRAME_SUMS = 3, SWF_K_EVAL_PRIOR = 4,
        SWF_K_LM_SCHUR = 5, SWF_K_CLIQUE_ELIM = 6, SWF_K_LM_ELIM = 7, SWF_K_ASSEMBLE = 8, SWF_K_CHOL = 9,
        SWF_K_POST_CHOL = 10, SWF_K_POST_DOGLEG = 11, SWF_K_DOGLEG = 12, SWF_K_CAND_EVAL = 13, SWF_K_DECIDE = 14,

@@ -1087,7 +1087,7 @@ extern "C" int swf_batch_create(const swf_flat_window* const* windows, int32_t n
             if (b->s_direct && !Pq.is_diag && Pq.fa >= 0 && Pq.fb >= 0 && Pq.c0 == Pq.c1) continue;       // -P is already in S, nothing to add
             (Pq.is_diag ? pd : po).push_back((int)i);
         }
-        // off-diagonal pairs by descending entry rounds (16 entries per round): k_assemble_all's waves (four pairs each) become
+        // off-diagonal pairs by descending entry rounds (16 entries per round): the round-2 pair-walking assembly's waves (four pairs each) become
         // homogeneous and skip the rounds none of their pairs has; every pair is still written once, by the same arithmetic
         std::stable_sort(po.begin(), po.end(), [&](int a, int c) {
             return (B.pair[a].la * B.pair[a].lb + 15) / 16 > (B.pair[c].la * B.pair[c].lb + 15) / 16; });
@@ -1494,7 +1494,7 @@ struct Launcher {
     };
     static int nb(size_t n, int per) { return (int)((n + per - 1) / per); }
     // One linearisation.  Dependencies: the cliques need the IMU and the scalar-factor Jacobians (k_eval_imu, k_eval_ps);
-    // k_lm_schur needs k_eval_ps; k_frame_sums needs k_lm_schur (Y g_l); k_assemble_all needs everything.  With an auxiliary
+    // k_lm_schur needs k_eval_ps; k_assemble_flat needs everything.  With an auxiliary
     // stream (small batches) the IMU / clique branch runs next to the projection / landmark branch.
     // the reference-topology latency path (swf_kernels4.h, k_lm_comp): the composite chain and the visual branch in shared grids
     bool comp_fused = false;

@@ -62,7 +62,7 @@ __device__ unsigned long long g_chol_stamps[64];
 #define CHSTAMP2(i)
 #define CHACC2(i, t0)
 #endif
-// per-wave time stamps of ONE step of k_chol_rr3 (-DSWF_PROFILE_CHOLW): plain stores, no read-modify-write, the step chosen at run time
+// per-wave time stamps of ONE step of k_chol_rr4 (-DSWF_PROFILE_CHOLW): plain stores, no read-modify-write, the step chosen at run time
 // (swf_debug_chol_wstep).  slot [wave][k]; wave 0: 0 pivot start, 1 pivot end, 2 past B_j, 3 past C_j; wave 1: 1 inverse end;
 // tile waves: 0 past B_j, 1 panel done, 2 past C_j, 3 mask read, 4 diagonal terms done, 5 trailing done, 6 at B_j+1, 7 past B_j+1
 #ifdef SWF_PROFILE_CHOLW
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? CH_OCC : 4) k_chol_solve(DevBa
     CHSTAMP(2);
 }
 
-// Factor and invert one 16x16 SPD tile with the 64 lanes of one wavefront (shared by k_chol_rr2 and k_chol_big).
+// Factor and invert one 16x16 SPD tile with the 64 lanes of one wavefront (shared by k_chol_col and k_chol_big; k_chol_rr2, its first user, left the tree in round 6).
 // D: the full symmetric tile in LDS, overwritten by L (lower, zeros above); LiJ: receives L^-1 (lower).  Returns
 // true if a pivot was not positive.
 __device__ __forceinline__ bool chol_pivot_tile(double (*D)[17], double (*LiJ)[17], int li, int lk, double* ipb /* LDS, 16 doubles */) {
@@ -349,7 +349,7 @@ __device__ __forceinline__ bool chol_pivot_tile(double (*D)[17], double (*LiJ)[1
 #include "swf_chol_rr4.h"
 
 // =========================================================================================
-// k_chol_big — the same pivot / panel / look-ahead pipeline as k_chol_rr2 for 240 < n_red <= 640, where the factor
+// k_chol_big — the pivot / panel / look-ahead pipeline of round 1's k_chol_rr2 for 256 < n_red <= 640, where the factor
 // (n^2/2 doubles, up to 1 MB) no longer fits the register file.  The tiles live in HBM/L2 in the window's L buffer
 // (row-major, ld = n, the reduced rhs as row n) and are streamed through registers step by step:
 //   wave 0        pivot wave: chol_pivot_tile on the published diagonal tile, Linv_jj kept in LDS for the panel and
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(1024) k_chol_big(DevBatch B) {
         CHSTAMP(1);
         __syncthreads();                                   // E: yv ready
         CHSTAMP(4);
-        // backward solve y = L^-T z, right-looking (see k_chol_rr2); Linv_JJ comes back from the slab
+        // backward solve y = L^-T z, right-looking; Linv_JJ comes back from the slab
         for (int J = Tc - 1; J >= 0; J--) {
             double p = 0;
 #pragma unroll
@@ -927,7 +927,7 @@ struct Segs { int e[8]; };     // exclusive end block of segment k (cumulative)
 
 // Jacobian/residual evaluation of the one-lane-per-factor families: projection + scalar GNSS/prior factors
 // FS (Jacobian evaluations): the projection segment runs one workgroup per frame-sum block and leaves the per-frame partial sums of
-// Jp^T Jp | Jp^T r next to the Jacobians (d_eval_proj_fs); k_frame_sums is then not launched.
+// Jp^T Jp | Jp^T r next to the Jacobians (d_eval_proj_fs).
 // IMU (latency path, few windows): the IMU factors ride along as a fourth segment (8 factors per workgroup) instead of their own launch
 // behind this one — the two evaluations are independent, and on the latency path a launch costs its whole dependent-load chain
 // (one window: 7.6 + 11.8 us as two kernels).  Large batches keep k_eval_imu apart: its LDS and registers would cost the HBM-bound

@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(MG_NT) k_marginalize(DevBatch B, const int* ta
     if (GM && phase == 1 && tid == 0) bj_ok[w] = 0;
     if (n <= 0 || n > ldn || m < 0 || (s.lin_fail && !rescued) || (form == 0 && n > MG_BIGN)) { if (tid == 0) outrank[w] = -1; return; }
     double* Mm = GM ? Mscr + o2 : lds;
-    const double* L = B.L + W.Lt_base;                // row-major lower, ld = n_red (k_chol_rr2 / k_chol_big)
+    const double* L = B.L + W.Lt_base;                // row-major lower, ld = n_red (k_chol_rr4 with export_full / k_chol_big)
     const double* y = B.y + W.loc_base + W.n_e + m;   // tail of the solution of S y = rhs
     if (form == 1) {
         // Cholesky square root, straight from the L buffer (no LDS residency, any tail up to ldn):

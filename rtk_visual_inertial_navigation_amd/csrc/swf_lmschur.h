@@ -231,7 +231,7 @@ __device__ __forceinline__ void d_lm_schur(const DevBatch& B, const DevOpt& O, i
         double* P = B.P + W.P_base * GEMM_SPLIT + (size_t)(fold ? 0 : sp0 + sq) * m * m;
         if (fold && s_direct) {
             // large batches: the folded product goes straight to where it ends up, S_pp = -P in the reduced system's own order
-            // (k_assemble_all then adds the few other contributions on top and never touches a frame pair that has none — 171 of the
+            // (k_assemble_flat then adds the few other contributions on top and never touches a frame pair that has none — 171 of the
             // 190 pose pairs of a cfg3 window).  -P + c == c - P bit for bit, so the result is that of the P route.
             double* Sw = B.S + W.S_base; const int nr = W.n_red; const int* fred = freds;
 #pragma unroll
